@@ -1,0 +1,305 @@
+"""Seeded synthetic block-sparse normal-equation systems ``Lambda * dx = eta``.
+
+None of the datasets BASELINE.json names (Manhattan3500, Sphere2500, Venice) ships
+with the reference and there is no network, so every configuration is exercised
+with a look-alike of the same size and block structure.  The
+generators only produce *data*; they are used by the tests, by bench.py and by
+tests/golden/make_golden.py, never by the solver itself.
+
+Storage mirrors what the reference's solvers read out of ``CUberBlockMatrix``
+(/root/reference/include/slam/BlockMatrixBase.h:380-503): block-CSC, only the
+upper triangle (block row <= block column) populated, block rows sorted inside a
+block column, every block dense column-major.
+"""
+from __future__ import annotations
+
+import dataclasses
+import struct
+
+import numpy as np
+
+MAGIC = b"SPPLAM01"
+
+
+@dataclasses.dataclass
+class BlockSystem:
+    """Upper-triangular block-CSC matrix + right-hand side."""
+
+    cumsum: np.ndarray      # int64 [n_bcols+1] scalar offset of every block column / row
+    bcol_ptr: np.ndarray    # int64 [n_bcols+1]
+    brow_idx: np.ndarray    # int32 [n_blocks]
+    values: np.ndarray      # float64, blocks packed in block-CSC order, each column-major
+    rhs: np.ndarray         # float64 [n_scalars]
+    n_matrix_cut: int = 0   # BA: number of leading camera block columns (0 = not a BA system)
+    name: str = ""
+
+    @property
+    def n_bcols(self) -> int:
+        return len(self.cumsum) - 1
+
+    @property
+    def n_blocks(self) -> int:
+        return len(self.brow_idx)
+
+    @property
+    def n_scalars(self) -> int:
+        return int(self.cumsum[-1])
+
+    def block_value_offsets(self) -> np.ndarray:
+        """int64 [n_blocks+1] offset of every block in ``values``."""
+        dims = np.diff(self.cumsum)
+        cols = np.repeat(np.arange(self.n_bcols), np.diff(self.bcol_ptr))
+        sz = dims[self.brow_idx] * dims[cols]
+        off = np.zeros(self.n_blocks + 1, dtype=np.int64)
+        np.cumsum(sz, out=off[1:])
+        return off
+
+    def to_scipy(self):
+        """Full symmetric scalar CSC matrix (tests only)."""
+        import scipy.sparse as sp
+
+        dims = np.diff(self.cumsum)
+        cols = np.repeat(np.arange(self.n_bcols), np.diff(self.bcol_ptr))
+        off = self.block_value_offsets()
+        ri, ci, vv = [], [], []
+        for (h, w) in sorted(set(zip(dims[self.brow_idx].tolist(), dims[cols].tolist()))):
+            sel = np.nonzero((dims[self.brow_idx] == h) & (dims[cols] == w))[0]
+            if not len(sel):
+                continue
+            idx = off[sel][:, None] + np.arange(h * w)[None, :]
+            v = self.values[idx]                                  # [nb, w*h] col-major
+            rr = np.tile(np.arange(h), w)[None, :] + self.cumsum[self.brow_idx[sel]][:, None]
+            cc = np.repeat(np.arange(w), h)[None, :] + self.cumsum[cols[sel]][:, None]
+            ri.append(rr.ravel()); ci.append(cc.ravel()); vv.append(v.ravel())
+        ri = np.concatenate(ri); ci = np.concatenate(ci); vv = np.concatenate(vv)
+        n = self.n_scalars
+        up = sp.triu(sp.coo_matrix((vv, (ri, ci)), shape=(n, n)).tocsc(), k=0)
+        return (up + sp.triu(up, k=1).T).tocsc()  # diagonal blocks hold both triangles: keep one
+
+    def save(self, path: str) -> None:
+        with open(path, "wb") as f:
+            f.write(MAGIC)
+            f.write(struct.pack("<8q", self.n_bcols, self.n_blocks, self.n_scalars,
+                                len(self.values), self.n_matrix_cut, 0, 0, 0))
+            f.write(np.ascontiguousarray(self.cumsum, dtype="<i8").tobytes())
+            f.write(np.ascontiguousarray(self.bcol_ptr, dtype="<i8").tobytes())
+            f.write(np.ascontiguousarray(self.brow_idx, dtype="<i8").tobytes())
+            f.write(np.ascontiguousarray(self.values, dtype="<f8").tobytes())
+            f.write(np.ascontiguousarray(self.rhs, dtype="<f8").tobytes())
+
+    @staticmethod
+    def load(path: str) -> "BlockSystem":
+        with open(path, "rb") as f:
+            if f.read(8) != MAGIC:
+                raise ValueError(f"{path}: not a SPPLAM01 file")
+            n_bcols, n_blocks, n_scalars, n_values, cut, _, _, _ = struct.unpack("<8q", f.read(64))
+            cumsum = np.frombuffer(f.read(8 * (n_bcols + 1)), dtype="<i8").copy()
+            bcol_ptr = np.frombuffer(f.read(8 * (n_bcols + 1)), dtype="<i8").copy()
+            brow = np.frombuffer(f.read(8 * n_blocks), dtype="<i8").astype(np.int32)
+            values = np.frombuffer(f.read(8 * n_values), dtype="<f8").copy()
+            rhs = np.frombuffer(f.read(8 * n_scalars), dtype="<f8").copy()
+        return BlockSystem(cumsum, bcol_ptr, brow, values, rhs, int(cut))
+
+
+# --------------------------------------------------------------------------------------
+# pose graphs (uniform d x d blocks)
+# --------------------------------------------------------------------------------------
+
+def _assemble_pose_graph(n: int, d: int, ei: np.ndarray, ej: np.ndarray, rng, sigma: float,
+                         prior: float, name: str) -> BlockSystem:
+    """Lambda = sum over edges [Ja Jb]^T [Ja Jb] + prior*I on pose 0, eta ~ N(0,1).
+
+    Ja = I + sigma*G, Jb = -I + sigma*G are near-orthogonal relative-pose Jacobians,
+    which keeps Lambda well conditioned (SURVEY.md section 7 'Conditioning vs the 1e-10 bar').
+    """
+    assert np.all(ei < ej)
+    key = ei.astype(np.int64) * n + ej
+    _, first = np.unique(key, return_index=True)      # drop duplicate edges, keep a stable order
+    first.sort()
+    ei, ej = ei[first], ej[first]
+    E = len(ei)
+    eye = np.eye(d)
+    Ja = eye[None] + sigma * rng.standard_normal((E, d, d))
+    Jb = -eye[None] + sigma * rng.standard_normal((E, d, d))
+    Hii = np.einsum("eki,ekj->eij", Ja, Ja)
+    Hij = np.einsum("eki,ekj->eij", Ja, Jb)
+    Hjj = np.einsum("eki,ekj->eij", Jb, Jb)
+    diag = np.zeros((n, d, d))
+    np.add.at(diag, ei, Hii)
+    np.add.at(diag, ej, Hjj)
+    diag[0] += prior * eye
+    # block-CSC: column j holds its off-diagonal blocks (rows i < j, sorted) then the diagonal block
+    order = np.lexsort((ei, ej))
+    ei_s, ej_s, Hij_s = ei[order], ej[order], Hij[order]
+    cnt = np.bincount(ej_s, minlength=n) + 1
+    bcol_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(cnt, out=bcol_ptr[1:])
+    nb = int(bcol_ptr[-1])
+    brow = np.empty(nb, dtype=np.int32)
+    vals = np.empty((nb, d * d))
+    diag_pos = bcol_ptr[1:] - 1
+    brow[diag_pos] = np.arange(n, dtype=np.int32)
+    vals[diag_pos] = diag.transpose(0, 2, 1).reshape(n, d * d)
+    mask = np.ones(nb, dtype=bool)
+    mask[diag_pos] = False
+    off_pos = np.nonzero(mask)[0]
+    brow[off_pos] = ei_s
+    vals[off_pos] = Hij_s.transpose(0, 2, 1).reshape(E, d * d)
+    cumsum = np.arange(n + 1, dtype=np.int64) * d
+    rhs = rng.standard_normal(n * d)
+    return BlockSystem(cumsum, bcol_ptr, brow, vals.ravel(), rhs, 0, name)
+
+
+def pose_chain(n: int = 100_000, d: int = 6, loop_every: int = 50, loop_min: int = 26,
+               loop_max: int = 50, sigma: float = 0.02, prior: float = 100.0,
+               seed: int = 12345) -> BlockSystem:
+    """C3 look-alike: odometry chain (i, i+1) + one loop closure per ``loop_every`` poses to a
+    pose ``loop_min..loop_max`` back.  n=100000, d=6 gives 201 998 upper blocks."""
+    rng = np.random.default_rng(seed)
+    ci = np.arange(n - 1)
+    ends = np.arange(loop_every, n, loop_every)
+    back = rng.integers(loop_min, loop_max + 1, size=len(ends))
+    li = ends - back
+    ok = li >= 0
+    ei = np.concatenate([ci, li[ok]])
+    ej = np.concatenate([ci + 1, ends[ok]])
+    return _assemble_pose_graph(n, d, ei, ej, rng, sigma, prior, f"pose_chain_n{n}_d{d}")
+
+
+def sphere(n_rings: int = 50, per_ring: int = 50, d: int = 6, sigma: float = 0.02,
+           prior: float = 100.0, seed: int = 2500) -> BlockSystem:
+    """C2 look-alike (Sphere2500): poses on rings; each pose is linked to its successor along the
+    spiral (odometry) and to the pose one ring below (loop closures).  2 500 poses, 4 949 edges."""
+    rng = np.random.default_rng(seed)
+    n = n_rings * per_ring
+    ci = np.arange(n - 1)
+    vi = np.arange(n - per_ring)
+    ei = np.concatenate([ci, vi])
+    ej = np.concatenate([ci + 1, vi + per_ring])
+    return _assemble_pose_graph(n, d, ei, ej, rng, sigma, prior, f"sphere_{n_rings}x{per_ring}_d{d}")
+
+
+def manhattan(n: int = 3500, d: int = 3, world: int = 30, sigma: float = 0.02,
+              prior: float = 100.0, seed: int = 3500, max_loops_per_pose: int = 2) -> BlockSystem:
+    """C1 look-alike (Manhattan3500): random walk on a grid, loop closure whenever the walk
+    revisits a cell (SE(2), 3x3 blocks; about 5.5k edges at n=3500)."""
+    rng = np.random.default_rng(seed)
+    steps = np.array([[1, 0], [-1, 0], [0, 1], [0, -1]])
+    pos = np.zeros((n, 2), dtype=np.int64)
+    heading = 0
+    for i in range(1, n):
+        if rng.random() < 0.3:
+            heading = int(rng.integers(0, 4))
+        p = pos[i - 1] + steps[heading]
+        if np.any(np.abs(p) > world):
+            heading ^= 1
+            p = pos[i - 1] + steps[heading]
+        pos[i] = p
+    seen: dict[tuple[int, int], list[int]] = {}
+    ei, ej = list(range(n - 1)), list(range(1, n))
+    for i in range(n):
+        key = (int(pos[i, 0]), int(pos[i, 1]))
+        prev = seen.setdefault(key, [])
+        cands = [p for p in prev if p < i - 1]
+        for p in cands[-max_loops_per_pose:]:
+            ei.append(p); ej.append(i)
+        prev.append(i)
+    return _assemble_pose_graph(n, d, np.array(ei), np.array(ej), rng, sigma, prior,
+                                f"manhattan_n{n}_d{d}")
+
+
+# --------------------------------------------------------------------------------------
+# bundle adjustment (6x6 cameras first, 3x3 points last)
+# --------------------------------------------------------------------------------------
+
+def ba(n_cams: int = 1000, n_pts: int = 500_000, k: int = 4, mode: str = "band",
+       damping: float = 0.1, seed: int = 777, cam_dim: int = 6, pt_dim: int = 3) -> BlockSystem:
+    """C4/C5 look-alike.  Every point is seen by ``k`` cameras (``mode='venice'``: k drawn from a
+    clipped geometric distribution, mean about 5.3).  Cameras of a point: ``band`` = c0 + 7j mod nc
+    (sparse S), ``uniform`` = k distinct random cameras (dense S).  Per observation
+    Jc in R^{2x6}, Jp in R^{2x3} ~ N(0,1):  A_cc += Jc^T Jc, C_pp += Jp^T Jp, U_cp = Jc^T Jp;
+    ``damping``*I on every diagonal block."""
+    rng = np.random.default_rng(seed)
+    if mode == "venice":
+        kk = np.clip(rng.geometric(0.19, size=n_pts) + 1, 2, min(30, n_cams))
+    else:
+        kk = np.full(n_pts, min(k, n_cams), dtype=np.int64)
+    n_obs = int(kk.sum())
+    pt_of = np.repeat(np.arange(n_pts), kk)
+    first = np.zeros(n_pts + 1, dtype=np.int64)
+    np.cumsum(kk, out=first[1:])
+    j_in_pt = np.arange(n_obs) - first[pt_of]
+    if mode == "uniform":
+        # k distinct cameras per point: random start + distinct random strides would bias; use
+        # rejection-free construction: sorted sample via random offsets in disjoint strata
+        strata = (n_cams // kk.max()) if kk.max() else 1
+        strata = max(int(strata), 1)
+        cam_of = (j_in_pt * strata + rng.integers(0, strata, size=n_obs)
+                  + np.repeat(rng.integers(0, n_cams, size=n_pts), kk)) % n_cams
+    else:
+        c0 = rng.integers(0, n_cams, size=n_pts)
+        cam_of = (c0[pt_of] + 7 * j_in_pt) % n_cams
+    # make sure cameras are distinct within a point (band with 7*j mod nc may wrap for tiny nc)
+    key = pt_of.astype(np.int64) * n_cams + cam_of
+    _, uniq = np.unique(key, return_index=True)
+    uniq.sort()
+    pt_of, cam_of = pt_of[uniq], cam_of[uniq]
+    n_obs = len(pt_of)
+    cd, pd_ = cam_dim, pt_dim
+    Jc = rng.standard_normal((n_obs, 2, cd))
+    Jp = rng.standard_normal((n_obs, 2, pd_))
+    Acc = np.zeros((n_cams, cd, cd))
+    np.add.at(Acc, cam_of, np.einsum("oki,okj->oij", Jc, Jc))
+    Cpp = np.zeros((n_pts, pd_, pd_))
+    np.add.at(Cpp, pt_of, np.einsum("oki,okj->oij", Jp, Jp))
+    Ucp = np.einsum("oki,okj->oij", Jc, Jp)                 # [n_obs, 6, 3]
+    Acc += damping * np.eye(cd)[None]
+    Cpp += damping * np.eye(pd_)[None]
+    # block-CSC layout
+    order = np.lexsort((cam_of, pt_of))
+    pt_s, cam_s, U_s = pt_of[order], cam_of[order], Ucp[order]
+    cnt_pt = np.bincount(pt_s, minlength=n_pts) + 1
+    n_bc = n_cams + n_pts
+    bcol_ptr = np.zeros(n_bc + 1, dtype=np.int64)
+    bcol_ptr[1:n_cams + 1] = np.arange(1, n_cams + 1)
+    np.cumsum(cnt_pt, out=bcol_ptr[n_cams + 1:])
+    bcol_ptr[n_cams + 1:] += n_cams
+    nb = int(bcol_ptr[-1])
+    brow = np.empty(nb, dtype=np.int32)
+    brow[:n_cams] = np.arange(n_cams)
+    diag_pos = bcol_ptr[n_cams + 1:] - 1
+    brow[diag_pos] = n_cams + np.arange(n_pts, dtype=np.int32)
+    mask = np.ones(nb, dtype=bool)
+    mask[:n_cams] = False
+    mask[diag_pos] = False
+    off_pos = np.nonzero(mask)[0]
+    brow[off_pos] = cam_s
+    # values: cams 36 each, then per point column: k blocks of 18 + one of 9
+    sz = np.empty(nb, dtype=np.int64)
+    sz[:n_cams] = cd * cd
+    sz[diag_pos] = pd_ * pd_
+    sz[off_pos] = cd * pd_
+    off = np.zeros(nb + 1, dtype=np.int64)
+    np.cumsum(sz, out=off[1:])
+    vals = np.empty(int(off[-1]))
+    vals[:n_cams * cd * cd] = Acc.transpose(0, 2, 1).ravel()
+    vals[(off[diag_pos][:, None] + np.arange(pd_ * pd_)[None, :]).ravel()] = \
+        Cpp.transpose(0, 2, 1).ravel()
+    vals[(off[off_pos][:, None] + np.arange(cd * pd_)[None, :]).ravel()] = \
+        U_s.transpose(0, 2, 1).ravel()
+    cumsum = np.concatenate([np.arange(n_cams + 1, dtype=np.int64) * cd,
+                             n_cams * cd + np.arange(1, n_pts + 1, dtype=np.int64) * pd_])
+    rhs = rng.standard_normal(int(cumsum[-1]))
+    return BlockSystem(cumsum, bcol_ptr, brow, vals, rhs, n_cams,
+                       f"ba_{n_cams}x{n_pts}_{mode}_k{k}")
+
+
+def indefinite(n: int = 40, d: int = 6, seed: int = 5) -> BlockSystem:
+    """A small system that is *not* positive definite (negative test: solvers must return false)."""
+    s = pose_chain(n=n, d=d, loop_every=10, loop_min=3, loop_max=8, seed=seed)
+    off = s.block_value_offsets()
+    j = n // 2
+    diag_block = int(s.bcol_ptr[j + 1] - 1)
+    blk = s.values[off[diag_block]:off[diag_block + 1]].reshape(d, d)
+    blk -= 50.0 * np.eye(d)
+    return dataclasses.replace(s, name=f"indefinite_n{n}_d{d}")
