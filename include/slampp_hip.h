@@ -1,0 +1,156 @@
+/*
+ * slampp_hip.h -- C ABI of libslampp_hip.so: an MI355X (gfx950) sparse block Cholesky /
+ * Schur-complement solver for the normal equations  Lambda * dx = eta  of SLAM++.
+ *
+ * This is the drop-in boundary for the reference's linear-solver concept
+ * (/root/reference/include/slam/LinearSolverTags.h:38-135).  The reference binds its solvers
+ * as compile-time template parameters, so the binding a maintainer adds is the header class
+ * include/slam/LinearSolver_HIP.h (CLinearSolver_HIP / CLinearSolver_Schur_HIP), which gathers
+ * the blocks of a CUberBlockMatrix and forwards to the entry points below.  Each entry point
+ * names the reference call it stands in for.
+ *
+ * Conventions
+ *   - plain C types only; all functions return a status (SLAMPP_HIP_*), never throw, never exit;
+ *   - Lambda is passed exactly as the reference stores it (BlockMatrixBase.h:380-503): block-CSC,
+ *     only the upper triangle populated (LinearSolver_CholMod.cpp:57), block rows sorted inside a
+ *     block column, each block dense column-major;  values are passed packed in that block order;
+ *   - eta is overwritten with the solution (same contract as Solve_PosDef, LinearSolver_CholMod.h:186);
+ *   - a handle is not thread-safe; different handles are independent (no process-global state).
+ */
+#ifndef SLAMPP_HIP_H_INCLUDED
+#define SLAMPP_HIP_H_INCLUDED
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct slampp_hip_solver slampp_hip_solver; /* opaque */
+
+enum {
+	SLAMPP_HIP_OK = 0,
+	SLAMPP_HIP_NOT_POSDEF = 1,          /* reference: Solve_PosDef returns false (LinearSolver_CholMod.cpp:310-317) */
+	SLAMPP_HIP_ERR_INVALID = -1,        /* bad argument / call order */
+	SLAMPP_HIP_ERR_ALLOC = -2,          /* host or device out of memory (reference: std::bad_alloc) */
+	SLAMPP_HIP_ERR_DEVICE = -3,         /* HIP runtime error (reference: std::runtime_error, LinearSolver_Schur.h:1196-1209) */
+	SLAMPP_HIP_ERR_UNSUPPORTED = -4     /* structure outside what this build handles (e.g. block dimension > 8) */
+};
+
+enum {
+	SLAMPP_HIP_MODE_SPARSE = 0,         /* pose-graph path: fill-reducing ordering + sparse block Cholesky */
+	SLAMPP_HIP_MODE_SCHUR = 1           /* BA path: Schur complement on the last (landmark) block columns, dense reduced system */
+};
+
+/* phase wall-clock of the last factor_solve, ms; names follow the reference's timers
+ * (NonlinearSolver_Lambda.h:250, LinearSolver_Schur.h:1896-1911) */
+typedef struct slampp_hip_times {
+	double order_ms, symbolic_ms, upload_ms, factor_ms, solve_ms, download_ms;  /* sparse path */
+	double schur_ms, reduce_ms, cholsol_ms, backsubst_ms;                        /* Schur path */
+	double total_ms;
+} slampp_hip_times;
+
+typedef struct slampp_hip_stats {
+	int64_t n_bcols, n_blocks_upper, n_scalars, nnz_upper;  /* Lambda, as given */
+	int64_t l_blocks, l_nnz;          /* block / scalar nonzeros of the factor under our ordering */
+	double  factor_flops, solve_flops; /* CHOLMOD's convention: sum of squared column counts; 4*lnz */
+	int64_t n_stages, n_tasks, etree_height, n_update_pairs;
+	int64_t n_cams, n_points, n_observations, schur_dim;     /* Schur path, else 0 */
+	int64_t device_bytes;
+} slampp_hip_stats;
+
+/* lifecycle -- stands in for the solver object's ctor / dtor / Free_Memory()
+ * (LinearSolver_CholMod.h:148-167).  device_id: HIP device ordinal. */
+int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id);
+void slampp_hip_destroy(slampp_hip_solver *p_solver);
+int slampp_hip_free_memory(slampp_hip_solver *p_solver);
+const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
+
+/* tuning knobs: "leaf_size" (nested-dissection leaf, default 32), "subtree_size" (max columns one
+ * wave eliminates sequentially, default 32), "dense_nb" (dense panel width, default 64) */
+int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int64_t n_value);
+
+/* structure of Lambda -- stands in for what the reference's wrappers read through
+ * n_BlockColumn_Num() / n_BlockColumn_Base() / n_BlockColumn_Block_Num() / n_Block_Row()
+ * (BlockMatrix.h:343-392,407-431) and for p_BlockStructure_to_Sparse (BlockMatrix.cpp:3880-3958).
+ * Calling it again means "the block structure changed" = Clear_SymbolicDecomposition()
+ * (LinearSolverTags.h:112-120). */
+int slampp_hip_set_structure(slampp_hip_solver *p_solver, int64_t n_bcols,
+	const int64_t *p_bcol_cumsum /* [n_bcols+1] */, const int64_t *p_bcol_ptr /* [n_bcols+1] */,
+	const int32_t *p_brow_idx /* [n_blocks] */);
+
+/* ordering + symbolic analysis -- stands in for SymbolicDecomposition_Blocky()
+ * (LinearSolver_CholMod.cpp:868-951, LinearSolver_UberBlock.h:256-310; Schur: LinearSolver_Schur.h:1566-1606).
+ * SCHUR mode: block columns [n_matrix_cut, n_bcols) are the landmarks (the reference's guided
+ * ordering, LinearSolver_Schur.cpp:771-838, puts them last); they must form a block-diagonal C. */
+int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix_cut);
+
+/* numeric factorization + solve -- stands in for Solve_PosDef_Blocky(lambda, eta)
+ * (LinearSolverTags.h:130-134; LinearSolver_CholMod.cpp:738-866; LinearSolver_Schur.h:1623-1935).
+ * p_values: packed block values of Lambda (host); p_rhs_inout: eta on entry, dx on return (host).
+ * Returns SLAMPP_HIP_NOT_POSDEF if a pivot is not positive. p_times may be NULL. */
+int slampp_hip_factor_solve(slampp_hip_solver *p_solver, const double *p_values,
+	double *p_rhs_inout, slampp_hip_times *p_times);
+
+/* same with both arrays already resident in device memory (HBM); used by bench.py so that the
+ * timed region excludes PCIe.  p_rhs_inout_dev is overwritten with the solution. */
+int slampp_hip_factor_solve_device(slampp_hip_solver *p_solver, const double *p_values_dev,
+	double *p_rhs_inout_dev, slampp_hip_times *p_times);
+
+/* another right-hand side with the factor of the last factor_solve
+ * (reference: cholmod_solve / cs_lsolve+cs_ltsolve on a kept factor, LinearSolver_CholMod.cpp:322-347) */
+int slampp_hip_solve_again(slampp_hip_solver *p_solver, double *p_rhs_inout);
+
+/* enqueue-only variants for benchmarking / stream capture: no host synchronisation, no status
+ * read-back; slampp_hip_sync() waits and returns OK / NOT_POSDEF / error for everything enqueued */
+int slampp_hip_factor_solve_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,
+	double *p_rhs_inout_dev);
+int slampp_hip_sync(slampp_hip_solver *p_solver);
+void *slampp_hip_stream(slampp_hip_solver *p_solver); /* the hipStream_t every kernel is launched on */
+
+int slampp_hip_get_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_stats);
+
+/* Multi-GPU BA (new functionality, no reference counterpart -- SURVEY.md section 8e): every rank
+ * holds a landmark shard (its own points + all cameras); the partial reduced camera system
+ * [S | rhs] is summed over ranks by this callback (RCCL all-reduce over xGMI) between the Schur
+ * accumulation and the dense factorization.  p_dev: device pointer, n_count doubles, in place,
+ * on stream p_hip_stream.  Return 0 on success.  NULL callback = single GPU. */
+typedef int (*slampp_hip_allreduce_fn)(void *p_context, double *p_dev, size_t n_count, void *p_hip_stream);
+int slampp_hip_set_allreduce(slampp_hip_solver *p_solver, slampp_hip_allreduce_fn p_fn, void *p_context);
+
+/* test hook: copies the elimination plan (permutation, factor structure, update lists, schedule)
+ * into caller-provided buffers so that tests can replay it on the CPU (oracle/plan_exec.c).
+ * First call with all pointers NULL to get the sizes. */
+typedef struct slampp_hip_plan_view {
+	int64_t n_bcols, l_blocks, n_pairs, n_row_entries, n_stages, n_tasks, n_task_cols, l_values;
+	int32_t *p_perm;        /* [n_bcols] perm[new] = old */
+	int32_t *p_dim;         /* [n_bcols] block dimension in the new order */
+	int64_t *p_lptr;        /* [n_bcols+1] */
+	int32_t *p_lrow;        /* [l_blocks] block row (new order), first of every column = diagonal */
+	int64_t *p_loff;        /* [l_blocks] offset of the block in the factor values */
+	int64_t *p_asrc;        /* [l_blocks] offset in the packed Lambda values, -1 = fill-in; */
+	int32_t *p_atrans;      /* [l_blocks] 1 = source block must be transposed */
+	int64_t *p_pptr;        /* [l_blocks+1] update pairs of every block */
+	int32_t *p_pa, *p_pb;   /* [n_pairs] factor block ids: L(i,c) and L(j,c) */
+	int64_t *p_rptr;        /* [n_bcols+1] row lists (forward solve) */
+	int32_t *p_rblk;        /* [n_row_entries] */
+	int32_t *p_stage_ptr;   /* [n_stages+1] -> tasks */
+	int64_t *p_task_ptr;    /* [n_tasks+1] -> task columns */
+	int32_t *p_task_cols;   /* [n_task_cols] */
+} slampp_hip_plan_view;
+int slampp_hip_get_plan(const slampp_hip_solver *p_solver, slampp_hip_plan_view *p_view);
+
+/* the same analysis without a solver or a GPU (host code only): lets the CPU-only test suite
+ * check ordering, symbolic factorization and schedule.  n_leaf_size / n_subtree_size <= 0 = default. */
+typedef struct slampp_hip_plan slampp_hip_plan;
+int slampp_hip_plan_create(slampp_hip_plan **pp_plan, int64_t n_bcols, const int64_t *p_bcol_cumsum,
+	const int64_t *p_bcol_ptr, const int32_t *p_brow_idx, int n_leaf_size, int n_subtree_size);
+int slampp_hip_plan_get(const slampp_hip_plan *p_plan, slampp_hip_plan_view *p_view, slampp_hip_stats *p_stats);
+void slampp_hip_plan_destroy(slampp_hip_plan *p_plan);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SLAMPP_HIP_H_INCLUDED */

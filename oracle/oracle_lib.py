@@ -1,0 +1,97 @@
+"""ctypes binding of oracle/liboracle.so (TEST INFRASTRUCTURE -- the CPU restatement of the
+reference's Lambda-solve path, see oracle/slampp_oracle.c).  Imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; never by slam_plus_plus_amd."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+REF_HARNESS = os.path.join(_HERE, "_ref", "ref_harness")
+_lib = None
+
+
+def build() -> None:
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.oracle_solve_sparse.restype = C.c_int
+        _lib.oracle_solve_schur.restype = C.c_int
+        _lib.oracle_exec_plan.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def solve_sparse(lam, perm=None):
+    """(ok, x, stats) -- up-looking block Cholesky + substitutions on the CPU."""
+    cs = np.ascontiguousarray(lam.cumsum, dtype=np.int64)
+    bp = np.ascontiguousarray(lam.bcol_ptr, dtype=np.int64)
+    br = np.ascontiguousarray(lam.brow_idx, dtype=np.int32)
+    vals = np.ascontiguousarray(lam.values, dtype=np.float64)
+    x = np.array(lam.rhs, dtype=np.float64, copy=True)
+    pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
+    stats = np.zeros(4)
+    rc = lib().oracle_solve_sparse(C.c_int64(lam.n_bcols), _p(cs), _p(bp), _p(br), _p(vals), _p(x), _p(pm), _p(stats))
+    if rc < 0:
+        raise ValueError("oracle_solve_sparse: bad input")
+    return rc == 0, x, {"r_blocks": int(stats[0]), "r_values": int(stats[1])}
+
+
+def solve_schur(lam, n_cut=None, want_S=False):
+    """(ok, x, S or None, rhs_reduced)."""
+    n_cut = int(lam.n_matrix_cut if n_cut is None else n_cut)
+    cs = np.ascontiguousarray(lam.cumsum, dtype=np.int64)
+    bp = np.ascontiguousarray(lam.bcol_ptr, dtype=np.int64)
+    br = np.ascontiguousarray(lam.brow_idx, dtype=np.int32)
+    vals = np.ascontiguousarray(lam.values, dtype=np.float64)
+    x = np.array(lam.rhs, dtype=np.float64, copy=True)
+    N = int(cs[n_cut])
+    S = np.zeros(N * N) if want_S else None
+    rr = np.zeros(N)
+    rc = lib().oracle_solve_schur(C.c_int64(lam.n_bcols), _p(cs), _p(bp), _p(br), _p(vals), _p(x),
+                                  C.c_int64(n_cut), _p(S), _p(rr))
+    if rc < 0:
+        raise ValueError("oracle_solve_schur: bad structure")
+    return rc == 0, x, (S.reshape(N, N).T.copy() if want_S else None), rr   # S returned row-major [row, col]
+
+
+def exec_plan(lam, plan: dict):
+    """Replays the product's elimination plan on the CPU: (status, x); status 0 ok, 1 not PD, 2 bad schedule."""
+    vals = np.ascontiguousarray(lam.values, dtype=np.float64)
+    x = np.array(lam.rhs, dtype=np.float64, copy=True)
+    cs = np.ascontiguousarray(lam.cumsum, dtype=np.int64)
+    a = {k: np.ascontiguousarray(v) for k, v in plan.items() if isinstance(v, np.ndarray)}
+    rc = lib().oracle_exec_plan(
+        C.c_int64(plan["n_bcols"]), _p(a["perm"]), _p(a["dim"]), _p(a["lptr"]), _p(a["lrow"]), _p(a["loff"]),
+        _p(a["asrc"]), _p(a["atrans"]), _p(a["pptr"]), _p(a["pa"]), _p(a["pb"]), _p(a["rptr"]), _p(a["rblk"]),
+        C.c_int64(plan["n_stages"]), _p(a["stage_ptr"]), _p(a["task_ptr"]), _p(a["task_cols"]),
+        _p(cs), C.c_int64(plan["l_values"]), _p(vals), _p(x))
+    return rc, x
+
+
+def have_reference() -> bool:
+    return os.path.exists(REF_HARNESS) and os.access(REF_HARNESS, os.X_OK)
+
+
+def reference_solve(problem_path: str, solver: str, x_path: str = "-", reps: int = 1, timeout: int = 600):
+    """Runs the compiled reference (oracle/_ref/ref_harness) on a SPPLAM01 file; returns its JSON."""
+    import json
+    out = subprocess.run([REF_HARNESS, "solve", problem_path, solver, x_path, str(reps)],
+                         capture_output=True, text=True, timeout=timeout)
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if not line:
+        raise RuntimeError(f"ref_harness failed: {out.stdout} {out.stderr}")
+    return json.loads(line[-1])

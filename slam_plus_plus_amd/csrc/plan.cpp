@@ -1,0 +1,599 @@
+// plan.cpp -- ordering + symbolic factorization + schedule, see plan.h
+#include "plan.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <numeric>
+
+namespace slampp {
+
+namespace {
+
+double now_ms()
+{
+	using namespace std::chrono;
+	return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------------------------------------
+// nested dissection on level structures
+// ---------------------------------------------------------------------------------------------
+
+class CNestedDissection {
+	const int32_t m_n;
+	const std::vector<int64_t> &m_ptr;
+	const std::vector<int32_t> &m_adj;
+	const int m_leaf;
+	std::vector<int32_t> m_set;    // id of the subset a vertex currently belongs to
+	std::vector<int32_t> m_level;  // BFS level (valid for the subset being processed)
+	std::vector<int32_t> m_queue;  // BFS queue scratch
+	std::vector<int32_t> &m_out;
+	int32_t m_next_id;
+
+public:
+	CNestedDissection(int32_t n, const std::vector<int64_t> &ptr, const std::vector<int32_t> &adj,
+		int leaf, std::vector<int32_t> &out)
+		:m_n(n), m_ptr(ptr), m_adj(adj), m_leaf(std::max(leaf, 1)), m_set(n, -1), m_level(n, -1),
+		m_out(out), m_next_id(0)
+	{
+		m_out.clear();
+		m_out.reserve(n);
+		m_queue.reserve(n);
+	}
+
+	void Run()
+	{
+		std::vector<int32_t> all(m_n);
+		std::iota(all.begin(), all.end(), 0);
+		Order(all);
+	}
+
+private:
+	// BFS inside subset `id` from `root`; fills m_queue with the visit order and m_level; returns #levels
+	int32_t BFS(int32_t root, int32_t id)
+	{
+		m_queue.clear();
+		m_queue.push_back(root);
+		m_level[root] = 0;
+		int32_t n_levels = 1;
+		for(size_t h = 0; h < m_queue.size(); ++ h) {
+			const int32_t v = m_queue[h], lv = m_level[v];
+			for(int64_t e = m_ptr[v]; e < m_ptr[v + 1]; ++ e) {
+				const int32_t w = m_adj[e];
+				if(m_set[w] == id && m_level[w] < 0) {
+					m_level[w] = lv + 1;
+					n_levels = lv + 2;
+					m_queue.push_back(w);
+				}
+			}
+		}
+		return n_levels;
+	}
+
+	void Reset_Levels(const std::vector<int32_t> &verts)
+	{
+		for(int32_t v : verts)
+			m_level[v] = -1;
+	}
+
+	int32_t Degree_In(int32_t v, int32_t id) const
+	{
+		int32_t d = 0;
+		for(int64_t e = m_ptr[v]; e < m_ptr[v + 1]; ++ e)
+			d += (m_set[m_adj[e]] == id);
+		return d;
+	}
+
+	// orders a (possibly disconnected) vertex subset
+	void Order(std::vector<int32_t> &S)
+	{
+		if(S.empty())
+			return;
+		const int32_t id = m_next_id ++;
+		for(int32_t v : S) {
+			m_set[v] = id;
+			m_level[v] = -1;
+		}
+		// split into connected components first (iteratively, flat storage: the landmark part
+		// of a BA system has 500k single-vertex components), then order each one
+		std::vector<int32_t> comp_verts;
+		std::vector<size_t> comp_ptr(1, 0);
+		comp_verts.reserve(S.size());
+		for(size_t s = 0; s < S.size() && comp_verts.size() < S.size(); ++ s) {
+			if(m_level[S[s]] >= 0)
+				continue; // already in an earlier component
+			BFS(S[s], id);
+			if(m_queue.size() == S.size()) {
+				Order_Connected(S, id); // the whole subset is one component
+				return;
+			}
+			comp_verts.insert(comp_verts.end(), m_queue.begin(), m_queue.end());
+			comp_ptr.push_back(comp_verts.size());
+		}
+		{
+			std::vector<int32_t> empty;
+			S.swap(empty);
+		}
+		std::vector<int32_t> comp;
+		for(size_t c = 0; c + 1 < comp_ptr.size(); ++ c) {
+			comp.assign(comp_verts.begin() + comp_ptr[c], comp_verts.begin() + comp_ptr[c + 1]);
+			if(comp.size() == 1) {
+				m_out.push_back(comp[0]);
+				continue;
+			}
+			const int32_t cid = m_next_id ++; // own id: the recursion must not see the other components
+			for(int32_t v : comp)
+				m_set[v] = cid;
+			Order_Connected(comp, cid);
+		}
+	}
+
+	// Cuthill-McKee-like order of a small connected subset
+	void Order_Leaf(const std::vector<int32_t> &S, int32_t id)
+	{
+		Reset_Levels(S);
+		BFS(S[0], id);
+		const int32_t far = m_queue.back();
+		Reset_Levels(S);
+		BFS(far, id);
+		m_out.insert(m_out.end(), m_queue.begin(), m_queue.end());
+	}
+
+	void Order_Connected(std::vector<int32_t> &S, int32_t id)
+	{
+		if(S.size() <= size_t(m_leaf)) {
+			Order_Leaf(S, id);
+			return;
+		}
+		// pseudo-peripheral root: repeat BFS from a minimum-degree vertex of the last level
+		Reset_Levels(S);
+		int32_t root = S[0];
+		int32_t n_levels = BFS(root, id);
+		for(int n_pass = 0; n_pass < 3; ++ n_pass) {
+			const int32_t last = n_levels - 1;
+			int32_t best = -1, best_deg = INT32_MAX;
+			for(size_t k = m_queue.size(); k > 0 && m_level[m_queue[k - 1]] == last; -- k) {
+				const int32_t v = m_queue[k - 1], d = Degree_In(v, id);
+				if(d < best_deg) {
+					best_deg = d;
+					best = v;
+				}
+			}
+			Reset_Levels(S);
+			const int32_t n_new = BFS(best, id);
+			root = best;
+			if(n_new <= n_levels) {
+				n_levels = n_new;
+				break;
+			}
+			n_levels = n_new;
+		}
+		if(n_levels < 3) { // clique-like: no level separates anything
+			m_out.insert(m_out.end(), m_queue.begin(), m_queue.end());
+			return;
+		}
+		// level sizes; pick the smallest level that leaves >= 1/4 of the vertices on either side,
+		// the median level if there is none
+		std::vector<int32_t> count(n_levels, 0);
+		for(int32_t v : S)
+			++ count[m_level[v]];
+		const int64_t n_total = int64_t(S.size());
+		int32_t m_best = -1;
+		{
+			int64_t below = 0;
+			int64_t best_size = INT64_MAX, best_imbalance = INT64_MAX;
+			for(int32_t l = 0; l < n_levels; ++ l) {
+				const int64_t above = n_total - below - count[l];
+				if(l > 0 && l < n_levels - 1 && below * 4 >= n_total && above * 4 >= n_total) {
+					const int64_t imb = std::abs(below - above);
+					if(count[l] < best_size || (count[l] == best_size && imb < best_imbalance)) {
+						best_size = count[l];
+						best_imbalance = imb;
+						m_best = l;
+					}
+				}
+				below += count[l];
+			}
+			if(m_best < 0) {
+				below = 0;
+				for(int32_t l = 0; l < n_levels; ++ l) {
+					below += count[l];
+					if(below * 2 >= n_total) {
+						m_best = std::min(std::max(l, 1), n_levels - 2);
+						break;
+					}
+				}
+			}
+		}
+		// separator = vertices of level m with a neighbour in level m+1; the rest of level m joins the lower part
+		std::vector<int32_t> sep, lower, upper;
+		lower.reserve(S.size() / 2 + 1);
+		upper.reserve(S.size() / 2 + 1);
+		for(int32_t v : S) {
+			const int32_t lv = m_level[v];
+			if(lv < m_best)
+				lower.push_back(v);
+			else if(lv > m_best)
+				upper.push_back(v);
+			else {
+				bool b_sep = false;
+				for(int64_t e = m_ptr[v]; e < m_ptr[v + 1] && !b_sep; ++ e) {
+					const int32_t w = m_adj[e];
+					b_sep = (m_set[w] == id && m_level[w] == m_best + 1);
+				}
+				(b_sep? sep : lower).push_back(v);
+			}
+		}
+		{
+			std::vector<int32_t> empty;
+			S.swap(empty); // release before recursing
+		}
+		Order(lower);
+		Order(upper);
+		m_out.insert(m_out.end(), sep.begin(), sep.end());
+	}
+};
+
+} // anonymous namespace
+
+void nested_dissection(int32_t n, const std::vector<int64_t> &adj_ptr, const std::vector<int32_t> &adj,
+	int leaf_size, std::vector<int32_t> &perm)
+{
+	CNestedDissection nd(n, adj_ptr, adj, leaf_size, perm);
+	nd.Run();
+}
+
+// ---------------------------------------------------------------------------------------------
+// symbolic factorization + schedule
+// ---------------------------------------------------------------------------------------------
+
+std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bcol_ptr,
+	const int32_t *brow, const PlanOptions &opt, Plan &P)
+{
+	P = Plan();
+	if(n_bcols <= 0 || n_bcols > INT32_MAX / 2)
+		return "invalid number of block columns";
+	const int32_t n = int32_t(n_bcols);
+	const int64_t n_ablocks = bcol_ptr[n];
+	P.n = n;
+
+	double t0 = now_ms();
+
+	// ---- block graph (symmetric adjacency, no self loops) ----
+	std::vector<int64_t> gptr(n + 1, 0);
+	for(int32_t c = 0; c < n; ++ c) {
+		if(bcol_ptr[c + 1] < bcol_ptr[c])
+			return "block column pointers are not monotonic";
+		for(int64_t k = bcol_ptr[c]; k < bcol_ptr[c + 1]; ++ k) {
+			const int32_t r = brow[k];
+			if(r < 0 || r > c)
+				return "block structure is not upper triangular";
+			if(k > bcol_ptr[c] && brow[k - 1] >= r)
+				return "block rows are not sorted inside a block column";
+			if(r != c) {
+				++ gptr[r + 1];
+				++ gptr[c + 1];
+			}
+		}
+		if(bcol_ptr[c + 1] == bcol_ptr[c] || brow[bcol_ptr[c + 1] - 1] != c)
+			return "a diagonal block is missing";
+	}
+	for(int32_t c = 0; c < n; ++ c)
+		gptr[c + 1] += gptr[c];
+	std::vector<int32_t> gadj(gptr[n]);
+	{
+		std::vector<int64_t> fill(gptr.begin(), gptr.end() - 1);
+		for(int32_t c = 0; c < n; ++ c) {
+			for(int64_t k = bcol_ptr[c]; k < bcol_ptr[c + 1]; ++ k) {
+				const int32_t r = brow[k];
+				if(r != c) {
+					gadj[fill[r] ++] = c;
+					gadj[fill[c] ++] = r;
+				}
+			}
+		}
+	}
+
+	// ---- ordering ----
+	nested_dissection(n, gptr, gadj, opt.leaf_size, P.perm);
+	if(int32_t(P.perm.size()) != n)
+		return "internal error: ordering lost vertices";
+	P.pinv.assign(n, -1);
+	for(int32_t j = 0; j < n; ++ j)
+		P.pinv[P.perm[j]] = j;
+	for(int32_t j = 0; j < n; ++ j) {
+		if(P.pinv[j] < 0)
+			return "internal error: ordering is not a permutation";
+	}
+	P.dim.resize(n);
+	P.cs_new.assign(n + 1, 0);
+	P.cs_src.resize(n);
+	P.max_dim = 0;
+	for(int32_t j = 0; j < n; ++ j) {
+		const int32_t o = P.perm[j];
+		const int64_t d = cumsum[o + 1] - cumsum[o];
+		if(d <= 0)
+			return "block column of zero or negative width";
+		P.dim[j] = int32_t(d);
+		P.cs_src[j] = cumsum[o];
+		P.cs_new[j + 1] = P.cs_new[j] + d;
+		P.max_dim = std::max(P.max_dim, int32_t(d));
+		P.uniform_dim = P.uniform_dim && d == (cumsum[1] - cumsum[0]);
+	}
+	double t1 = now_ms();
+	P.order_ms = t1 - t0;
+
+	// ---- permuted lower-triangular structure of Lambda ----
+	// offsets of the source blocks in the packed value array
+	std::vector<int64_t> aoff(n_ablocks + 1, 0);
+	for(int32_t c = 0; c < n; ++ c) {
+		const int64_t w = cumsum[c + 1] - cumsum[c];
+		for(int64_t k = bcol_ptr[c]; k < bcol_ptr[c + 1]; ++ k) {
+			const int64_t h = cumsum[brow[k] + 1] - cumsum[brow[k]];
+			aoff[k + 1] = aoff[k] + h * w;
+			P.nnz_upper += (brow[k] == c)? w * (w + 1) / 2 : h * w;
+		}
+	}
+	struct TAEntry { int32_t row; int32_t trans; int64_t src; };
+	std::vector<int64_t> acol_ptr(n + 1, 0);
+	for(int32_t c = 0; c < n; ++ c) {
+		for(int64_t k = bcol_ptr[c]; k < bcol_ptr[c + 1]; ++ k)
+			++ acol_ptr[std::min(P.pinv[brow[k]], P.pinv[c]) + 1];
+	}
+	for(int32_t j = 0; j < n; ++ j)
+		acol_ptr[j + 1] += acol_ptr[j];
+	std::vector<TAEntry> aent(n_ablocks);
+	{
+		std::vector<int64_t> fill(acol_ptr.begin(), acol_ptr.end() - 1);
+		for(int32_t c = 0; c < n; ++ c) {
+			for(int64_t k = bcol_ptr[c]; k < bcol_ptr[c + 1]; ++ k) {
+				const int32_t i0 = P.pinv[brow[k]], j0 = P.pinv[c];
+				// stored block is Lambda(r, c); the lower-triangular slot (max, min) needs it
+				// as is when new_row(r) > new_row(c), transposed otherwise
+				TAEntry e;
+				if(i0 >= j0) { e.row = i0; e.trans = 0; e.src = aoff[k]; aent[fill[j0] ++] = e; }
+				else { e.row = j0; e.trans = 1; e.src = aoff[k]; aent[fill[i0] ++] = e; }
+			}
+		}
+	}
+
+	// ---- column structure of L by merging children (symbolic Cholesky on the block graph) ----
+	P.parent.assign(n, -1);
+	P.lptr.assign(n + 1, 0);
+	P.lrow.clear();
+	P.lrow.reserve(size_t(n_ablocks) * 2);
+	std::vector<int32_t> first_child(n, -1), next_sibling(n, -1);
+	std::vector<int32_t> mark(n, -1), rows;
+	std::vector<int64_t> pos(n, -1); // block id of row i in the column being built
+	P.asrc.clear();
+	P.atrans.clear();
+	for(int32_t j = 0; j < n; ++ j) {
+		rows.clear();
+		rows.push_back(j);
+		mark[j] = j;
+		for(int64_t e = acol_ptr[j]; e < acol_ptr[j + 1]; ++ e) {
+			const int32_t i = aent[e].row;
+			if(mark[i] != j) {
+				mark[i] = j;
+				rows.push_back(i);
+			}
+		}
+		for(int32_t c = first_child[j]; c >= 0; c = next_sibling[c]) {
+			for(int64_t k = P.lptr[c] + 1; k < P.lptr[c + 1]; ++ k) {
+				const int32_t i = P.lrow[k];
+				if(mark[i] != j) {
+					mark[i] = j;
+					rows.push_back(i);
+				}
+			}
+		}
+		std::sort(rows.begin() + 1, rows.end());
+		const int64_t base = int64_t(P.lrow.size());
+		for(size_t t = 0; t < rows.size(); ++ t) {
+			pos[rows[t]] = base + int64_t(t);
+			P.lrow.push_back(rows[t]);
+			P.asrc.push_back(-1);
+			P.atrans.push_back(0);
+		}
+		for(int64_t e = acol_ptr[j]; e < acol_ptr[j + 1]; ++ e) {
+			const int64_t k = pos[aent[e].row];
+			P.asrc[k] = aent[e].src;
+			P.atrans[k] = aent[e].trans;
+		}
+		P.lptr[j + 1] = int64_t(P.lrow.size());
+		if(rows.size() > 1) {
+			const int32_t p = rows[1];
+			P.parent[j] = p;
+			next_sibling[j] = first_child[p];
+			first_child[p] = j;
+		}
+	}
+	const int64_t n_lblocks = int64_t(P.lrow.size());
+	if(n_lblocks > INT32_MAX)
+		return "factor has too many blocks";
+	P.loff.assign(n_lblocks + 1, 0);
+	P.blk_col.resize(n_lblocks);
+	P.linv_off.assign(n + 1, 0);
+	for(int32_t j = 0; j < n; ++ j) {
+		const int64_t dj = P.dim[j];
+		int64_t below = 0;
+		for(int64_t k = P.lptr[j]; k < P.lptr[j + 1]; ++ k) {
+			const int64_t di = P.dim[P.lrow[k]];
+			P.loff[k + 1] = P.loff[k] + di * dj;
+			P.blk_col[k] = j;
+			if(k > P.lptr[j])
+				below += di;
+		}
+		P.linv_off[j + 1] = P.linv_off[j] + dj * dj;
+		P.l_nnz += dj * (dj + 1) / 2 + dj * below;
+		for(int64_t t = 0; t < dj; ++ t) {
+			const double c = double(dj - t + below);
+			P.factor_flops += c * c;
+		}
+	}
+
+	// ---- update lists ----
+	// column c contributes L(i,c) L(j,c)^T to block (i,j) for every pair of its sub-diagonal rows i >= j
+	{
+		std::vector<int32_t> tgt;
+		std::vector<int32_t> ga, gb;
+		for(int32_t c = 0; c < n; ++ c) {
+			const int64_t kb0 = P.lptr[c] + 1, kb1 = P.lptr[c + 1];
+			for(int64_t kb = kb0; kb < kb1; ++ kb) {
+				const int32_t j = P.lrow[kb];
+				int64_t t = P.lptr[j]; // walks down column j; rows of c (>= j) are a subset of rows of j
+				const int64_t t_end = P.lptr[j + 1];
+				for(int64_t ka = kb; ka < kb1; ++ ka) {
+					const int32_t i = P.lrow[ka];
+					while(t < t_end && P.lrow[t] < i)
+						++ t;
+					if(t == t_end || P.lrow[t] != i)
+						return "internal error: symbolic structure is not closed under updates";
+					tgt.push_back(int32_t(t));
+					ga.push_back(int32_t(ka));
+					gb.push_back(int32_t(kb));
+				}
+			}
+		}
+		const size_t n_pairs = tgt.size();
+		P.pptr.assign(n_lblocks + 1, 0);
+		for(size_t p = 0; p < n_pairs; ++ p)
+			++ P.pptr[tgt[p] + 1];
+		for(int64_t k = 0; k < n_lblocks; ++ k)
+			P.pptr[k + 1] += P.pptr[k];
+		P.pa.resize(n_pairs);
+		P.pb.resize(n_pairs);
+		std::vector<int64_t> fill(P.pptr.begin(), P.pptr.end() - 1);
+		for(size_t p = 0; p < n_pairs; ++ p) { // stable: pairs of a block stay ordered by source column
+			const int64_t d = fill[tgt[p]] ++;
+			P.pa[d] = ga[p];
+			P.pb[d] = gb[p];
+		}
+	}
+
+	// ---- row lists ----
+	{
+		P.rptr.assign(n + 1, 0);
+		for(int32_t j = 0; j < n; ++ j) {
+			for(int64_t k = P.lptr[j] + 1; k < P.lptr[j + 1]; ++ k)
+				++ P.rptr[P.lrow[k] + 1];
+		}
+		for(int32_t j = 0; j < n; ++ j)
+			P.rptr[j + 1] += P.rptr[j];
+		P.rblk.resize(P.rptr[n]);
+		std::vector<int64_t> fill(P.rptr.begin(), P.rptr.end() - 1);
+		for(int32_t j = 0; j < n; ++ j) {
+			for(int64_t k = P.lptr[j] + 1; k < P.lptr[j + 1]; ++ k)
+				P.rblk[fill[P.lrow[k]] ++] = int32_t(k);
+		}
+	}
+
+	// ---- schedule ----
+	{
+		const int32_t T = std::max(opt.subtree_size, 1);
+		std::vector<int32_t> sz(n, 1), height(n, 1);
+		for(int32_t j = 0; j < n; ++ j) {
+			const int32_t p = P.parent[j];
+			if(p >= 0) {
+				sz[p] += sz[j];
+				height[p] = std::max(height[p], height[j] + 1);
+			}
+			P.etree_height = std::max(P.etree_height, height[j]);
+		}
+		// task id of every column. bottom: whole subtrees of <= T columns; top: maximal chains
+		std::vector<int32_t> task_of(n, -1), task_level;
+		std::vector<int32_t> troot(n, -1);
+		for(int32_t j = n - 1; j >= 0; -- j) {
+			if(sz[j] <= T) {
+				const int32_t p = P.parent[j];
+				troot[j] = (p >= 0 && sz[p] <= T)? troot[p] : j;
+			}
+		}
+		std::vector<int32_t> n_top_children(n, 0), n_bottom_children(n, 0), last_top_child(n, -1);
+		for(int32_t j = 0; j < n; ++ j) {
+			const int32_t p = P.parent[j];
+			if(p >= 0) {
+				if(troot[j] >= 0)
+					++ n_bottom_children[p];
+				else {
+					++ n_top_children[p];
+					last_top_child[p] = j;
+				}
+			}
+		}
+		int32_t n_tasks = 0;
+		std::vector<int32_t> root_task(n, -1);
+		for(int32_t j = 0; j < n; ++ j) {
+			if(troot[j] >= 0) {
+				int32_t &r = root_task[troot[j]];
+				if(r < 0) {
+					r = n_tasks ++;
+					task_level.push_back(0);
+				}
+				task_of[j] = r;
+			} else {
+				// troot[j] < 0 implies sz[j] > T; children were visited before (they have smaller indices)
+				if(n_top_children[j] == 1 && n_bottom_children[j] == 0) {
+					task_of[j] = task_of[last_top_child[j]]; // extend the chain
+				} else {
+					task_of[j] = n_tasks ++;
+					task_level.push_back(1);
+				}
+			}
+		}
+		// level of a top task = 1 + max level of the tasks of its columns' children
+		for(int32_t j = 0; j < n; ++ j) {
+			const int32_t p = P.parent[j];
+			if(p >= 0 && task_of[p] != task_of[j]) {
+				int32_t &lp = task_level[task_of[p]];
+				lp = std::max(lp, task_level[task_of[j]] + 1);
+			}
+		}
+		// a chain task's level may have been raised after its children were examined: iterate in
+		// column order again until stable (columns ascend, so one extra pass suffices for trees,
+		// but chains merge several columns; loop to be safe)
+		for(bool b_changed = true; b_changed;) {
+			b_changed = false;
+			for(int32_t j = 0; j < n; ++ j) {
+				const int32_t p = P.parent[j];
+				if(p >= 0 && task_of[p] != task_of[j] &&
+				   task_level[task_of[p]] < task_level[task_of[j]] + 1) {
+					task_level[task_of[p]] = task_level[task_of[j]] + 1;
+					b_changed = true;
+				}
+			}
+		}
+		int32_t n_stages = 0;
+		for(int32_t t = 0; t < n_tasks; ++ t)
+			n_stages = std::max(n_stages, task_level[t] + 1);
+		// renumber tasks by (stage, first column)
+		std::vector<int32_t> stage_count(n_stages + 1, 0);
+		for(int32_t t = 0; t < n_tasks; ++ t)
+			++ stage_count[task_level[t] + 1];
+		for(int32_t s = 0; s < n_stages; ++ s)
+			stage_count[s + 1] += stage_count[s];
+		P.stage_ptr.assign(stage_count.begin(), stage_count.end());
+		std::vector<int32_t> new_id(n_tasks);
+		{
+			std::vector<int32_t> fill(stage_count.begin(), stage_count.end() - 1);
+			for(int32_t t = 0; t < n_tasks; ++ t) // old ids ascend with the first column
+				new_id[t] = fill[task_level[t]] ++;
+		}
+		P.task_ptr.assign(n_tasks + 1, 0);
+		for(int32_t j = 0; j < n; ++ j)
+			++ P.task_ptr[new_id[task_of[j]] + 1];
+		for(int32_t t = 0; t < n_tasks; ++ t)
+			P.task_ptr[t + 1] += P.task_ptr[t];
+		P.task_cols.resize(n);
+		{
+			std::vector<int64_t> fill(P.task_ptr.begin(), P.task_ptr.end() - 1);
+			for(int32_t j = 0; j < n; ++ j)
+				P.task_cols[fill[new_id[task_of[j]]] ++] = j;
+		}
+	}
+	P.symbolic_ms = now_ms() - t1;
+	return std::string();
+}
+
+} // namespace slampp

@@ -1,0 +1,63 @@
+// plan.h -- host-side symbolic analysis of the block-sparse Cholesky (ordering, elimination
+// tree, factor structure, update lists, stage schedule).  Everything here works on the *block*
+// graph (n_bcols nodes), never on scalars -- the reference's native solver does the same
+// (/root/reference/include/slam/LinearSolver_UberBlock.h:285-310) while its CHOLMOD wrapper
+// orders the 6x larger scalar graph (/root/reference/src/slam/LinearSolver_CholMod.cpp:294-300).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace slampp {
+
+struct Plan {
+	int32_t n = 0;                    // block columns
+	int32_t max_dim = 0;
+	bool uniform_dim = true;          // all block columns have the same dimension
+	std::vector<int32_t> perm, pinv;  // perm[new] = old, pinv[old] = new
+	std::vector<int32_t> dim;         // [n] dimension of block column, new order
+	std::vector<int64_t> cs_new;      // [n+1] scalar offset in the permuted vector
+	std::vector<int64_t> cs_src;      // [n] scalar offset of new column j in the caller's (original) vector
+	std::vector<int32_t> parent;      // [n] elimination tree (new order), -1 = root
+	// factor structure: block-CSC of L (lower), rows sorted, first block of a column = diagonal
+	std::vector<int64_t> lptr;        // [n+1]
+	std::vector<int32_t> lrow;        // [l_blocks]
+	std::vector<int64_t> loff;        // [l_blocks+1] offset in the factor values
+	std::vector<int64_t> asrc;        // [l_blocks] offset in the packed Lambda values or -1 (fill-in)
+	std::vector<int32_t> atrans;      // [l_blocks] source block is stored transposed
+	std::vector<int64_t> linv_off;    // [n+1] offset of inv(L_jj) in the linv array
+	// update lists: L(i,j) = A(i,j) - sum over pairs L[pa] * L[pb]^T
+	std::vector<int64_t> pptr;        // [l_blocks+1]
+	std::vector<int32_t> pa, pb;      // [n_pairs] factor block ids
+	// row lists (forward substitution): blocks L(j,c), c < j, of every block row j
+	std::vector<int64_t> rptr;        // [n+1]
+	std::vector<int32_t> rblk;        // [n_row_entries] factor block ids
+	std::vector<int32_t> blk_col;     // [l_blocks] column of every factor block
+	// schedule: stage -> tasks -> columns; tasks of one stage are independent, a task's columns
+	// are eliminated in order by one workgroup
+	std::vector<int32_t> stage_ptr;   // [n_stages+1]
+	std::vector<int64_t> task_ptr;    // [n_tasks+1]
+	std::vector<int32_t> task_cols;   // [n]
+	// statistics
+	int64_t l_nnz = 0;                // scalar nonzeros of L (lower, incl. diagonal)
+	double factor_flops = 0;          // sum over scalar columns of (column count)^2  (CHOLMOD's "fl")
+	int64_t nnz_upper = 0;            // scalar nonzeros of triu(Lambda)
+	int32_t etree_height = 0;
+	double order_ms = 0, symbolic_ms = 0;
+};
+
+struct PlanOptions {
+	int leaf_size = 32;       // nested dissection stops at subgraphs of this many block columns
+	int subtree_size = 32;    // a subtree of at most this many columns is one sequential task
+};
+
+// returns empty string on success, else an error message
+std::string build_plan(int64_t n_bcols, const int64_t *bcol_cumsum, const int64_t *bcol_ptr,
+	const int32_t *brow_idx, const PlanOptions &opt, Plan &plan);
+
+// fill-reducing, parallelism-exposing ordering of the block graph: nested dissection with
+// BFS level-structure separators; perm[new] = old
+void nested_dissection(int32_t n, const std::vector<int64_t> &adj_ptr, const std::vector<int32_t> &adj,
+	int leaf_size, std::vector<int32_t> &perm);
+
+} // namespace slampp

@@ -1,0 +1,126 @@
+// solver.h -- the object behind the C ABI (include/slampp_hip.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdint>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/slampp_hip.h"
+#include "plan.h"
+#include "sparse_kernels.h"
+
+namespace slampp {
+
+struct CDeviceError : public std::runtime_error {
+	explicit CDeviceError(const std::string &s) :std::runtime_error(s) {}
+};
+
+#define SLAMPP_HIP_CHECK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
+	throw slampp::CDeviceError(std::string(#call) + ": " + hipGetErrorString(e_)); } } while(0)
+
+inline double wall_ms()
+{
+	using namespace std::chrono;
+	return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// owning device array
+template <class T>
+class CDevArray {
+	T *m_p;
+	size_t m_n;
+public:
+	CDevArray() :m_p(0), m_n(0) {}
+	~CDevArray() { Free(); }
+	CDevArray(const CDevArray&) = delete;
+	CDevArray &operator =(const CDevArray&) = delete;
+	void Free() { if(m_p) (void)hipFree(m_p); m_p = 0; m_n = 0; }
+	void Alloc(size_t n) // throw(std::bad_alloc, CDeviceError)
+	{
+		if(n <= m_n && m_p)
+			return;
+		Free();
+		if(!n)
+			n = 1;
+		hipError_t e = hipMalloc((void**)&m_p, n * sizeof(T));
+		if(e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+			(void)hipGetLastError();
+			m_p = 0;
+			throw std::bad_alloc();
+		}
+		if(e != hipSuccess) {
+			m_p = 0;
+			throw CDeviceError(std::string("hipMalloc: ") + hipGetErrorString(e));
+		}
+		m_n = n;
+	}
+	void Upload(const std::vector<T> &v, hipStream_t s)
+	{
+		Alloc(v.size());
+		if(!v.empty())
+			SLAMPP_HIP_CHECK(hipMemcpyAsync(m_p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+	}
+	T *p() const { return m_p; }
+	size_t n() const { return m_n; }
+	size_t n_Bytes() const { return m_p? m_n * sizeof(T) : 0; }
+};
+
+struct CSchurState; // schur.hip
+
+} // namespace slampp
+
+struct slampp_hip_solver {
+	int n_device;
+	hipStream_t stream;
+	std::string s_error;
+	slampp::PlanOptions opt;
+	int n_dense_nb;
+	int b_shard_primary;
+
+	// Lambda structure as given
+	bool b_has_structure, b_analyzed, b_factored;
+	int n_mode;
+	int64_t n_matrix_cut;
+	std::vector<int64_t> cumsum, bcol_ptr;
+	std::vector<int32_t> brow;
+	int64_t n_values, n_scalars;
+
+	// sparse path
+	slampp::Plan plan;
+	std::vector<int> stage_waves;
+	slampp::TDevPlan dplan;
+	slampp::CDevArray<int32_t> d_dim, d_lrow, d_rcol, d_task_cols;
+	slampp::CDevArray<int64_t> d_cs_new, d_cs_src, d_lptr, d_loff, d_asrc, d_linv_off, d_pptr, d_rptr, d_roff, d_task_ptr;
+	slampp::CDevArray<longlong2> d_pairs;
+	slampp::CDevArray<double> d_A, d_rhs, d_L, d_Linv, d_w;
+	slampp::CDevArray<int> d_flag;
+	int *p_host_flag; // pinned
+
+	slampp::CSchurState *p_schur;
+
+	slampp_hip_allreduce_fn p_allreduce;
+	void *p_allreduce_context;
+
+	slampp_hip_times times;
+
+	slampp_hip_solver();
+	~slampp_hip_solver();
+	void Free_Device();
+	size_t n_Device_Bytes() const;
+	void Analyze_Sparse();
+	void Enqueue_Sparse(const double *p_values_dev, double *p_rhs_dev, bool b_factor);
+};
+
+namespace slampp {
+
+// Schur path entry points (schur.hip)
+void schur_destroy(CSchurState *p);
+CSchurState *schur_analyze(slampp_hip_solver &s); // throws
+void schur_enqueue(slampp_hip_solver &s, const double *p_values_dev, double *p_rhs_dev); // throws
+size_t schur_device_bytes(const CSchurState *p);
+void schur_fill_stats(const CSchurState *p, slampp_hip_stats &st);
+
+} // namespace slampp

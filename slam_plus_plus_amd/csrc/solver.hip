@@ -1,0 +1,561 @@
+// solver.hip -- C ABI of libslampp_hip.so (include/slampp_hip.h): handle, device memory,
+// orchestration of the sparse-Cholesky and Schur paths.  Host code only; kernels live in
+// sparse_kernels.hip / schur.hip / dense_chol.hip.
+#include "solver.h"
+
+#include <algorithm>
+#include <cstring>
+
+using namespace slampp;
+
+slampp_hip_solver::slampp_hip_solver()
+	:n_device(0), stream(0), n_dense_nb(64), b_shard_primary(1), b_has_structure(false),
+	b_analyzed(false), b_factored(false), n_mode(SLAMPP_HIP_MODE_SPARSE), n_matrix_cut(0),
+	n_values(0), n_scalars(0), p_host_flag(0), p_schur(0), p_allreduce(0), p_allreduce_context(0)
+{
+	memset(&dplan, 0, sizeof(dplan));
+	memset(&times, 0, sizeof(times));
+}
+
+slampp_hip_solver::~slampp_hip_solver()
+{
+	Free_Device();
+	if(p_host_flag)
+		(void)hipHostFree(p_host_flag);
+	if(stream)
+		(void)hipStreamDestroy(stream);
+}
+
+void slampp_hip_solver::Free_Device()
+{
+	d_dim.Free(); d_lrow.Free(); d_rcol.Free(); d_task_cols.Free();
+	d_cs_new.Free(); d_cs_src.Free(); d_lptr.Free(); d_loff.Free(); d_asrc.Free(); d_linv_off.Free();
+	d_pptr.Free(); d_rptr.Free(); d_roff.Free(); d_task_ptr.Free(); d_pairs.Free();
+	d_A.Free(); d_rhs.Free(); d_L.Free(); d_Linv.Free(); d_w.Free(); d_flag.Free();
+	if(p_schur) {
+		schur_destroy(p_schur);
+		p_schur = 0;
+	}
+	b_analyzed = false;
+	b_factored = false;
+}
+
+size_t slampp_hip_solver::n_Device_Bytes() const
+{
+	return d_dim.n_Bytes() + d_lrow.n_Bytes() + d_rcol.n_Bytes() + d_task_cols.n_Bytes() +
+		d_cs_new.n_Bytes() + d_cs_src.n_Bytes() + d_lptr.n_Bytes() + d_loff.n_Bytes() +
+		d_asrc.n_Bytes() + d_linv_off.n_Bytes() + d_pptr.n_Bytes() + d_rptr.n_Bytes() +
+		d_roff.n_Bytes() + d_task_ptr.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
+		d_rhs.n_Bytes() + d_L.n_Bytes() + d_Linv.n_Bytes() + d_w.n_Bytes() + d_flag.n_Bytes() +
+		(p_schur? schur_device_bytes(p_schur) : 0);
+}
+
+void slampp_hip_solver::Analyze_Sparse()
+{
+	std::string s_err = build_plan(int64_t(cumsum.size()) - 1, cumsum.data(), bcol_ptr.data(),
+		brow.data(), opt, plan);
+	if(!s_err.empty())
+		throw std::invalid_argument(s_err);
+	if(plan.max_dim > 8)
+		throw std::domain_error("block dimensions above 8 are not supported by the sparse path");
+	const Plan &P = plan;
+	const int64_t n_lblocks = int64_t(P.lrow.size());
+
+	// per-stage workgroup width: one wave for the bottom subtrees, more for wide separator columns
+	const int n_stages = int(P.stage_ptr.size()) - 1;
+	stage_waves.assign(n_stages, 1);
+	for(int s = 1; s < n_stages; ++ s) {
+		int64_t n_max_blocks = 0;
+		for(int t = P.stage_ptr[s]; t < P.stage_ptr[s + 1]; ++ t) {
+			for(int64_t c = P.task_ptr[t]; c < P.task_ptr[t + 1]; ++ c) {
+				const int j = P.task_cols[c];
+				n_max_blocks = std::max(n_max_blocks, P.lptr[j + 1] - P.lptr[j]);
+			}
+		}
+		stage_waves[s] = (n_max_blocks <= 3)? 1 : (n_max_blocks <= 24)? 4 : 16;
+	}
+
+	// device copies
+	std::vector<int64_t> asrc_enc(n_lblocks);
+	for(int64_t k = 0; k < n_lblocks; ++ k)
+		asrc_enc[k] = (P.asrc[k] < 0)? -1 : P.asrc[k] * 2 + P.atrans[k];
+	std::vector<longlong2> pairs(P.pa.size());
+	for(size_t e = 0; e < P.pa.size(); ++ e) {
+		const int64_t dc = P.dim[P.blk_col[P.pa[e]]];
+		pairs[e].x = P.loff[P.pa[e]] | (dc << 56);
+		pairs[e].y = P.loff[P.pb[e]];
+	}
+	std::vector<int64_t> roff(P.rblk.size());
+	std::vector<int32_t> rcol(P.rblk.size());
+	for(size_t e = 0; e < P.rblk.size(); ++ e) {
+		roff[e] = P.loff[P.rblk[e]];
+		rcol[e] = P.blk_col[P.rblk[e]];
+	}
+	d_dim.Upload(P.dim, stream);
+	d_cs_new.Upload(P.cs_new, stream);
+	d_cs_src.Upload(P.cs_src, stream);
+	d_lptr.Upload(P.lptr, stream);
+	d_lrow.Upload(P.lrow, stream);
+	d_loff.Upload(P.loff, stream);
+	d_asrc.Upload(asrc_enc, stream);
+	d_linv_off.Upload(P.linv_off, stream);
+	d_pptr.Upload(P.pptr, stream);
+	d_pairs.Upload(pairs, stream);
+	d_rptr.Upload(P.rptr, stream);
+	d_roff.Upload(roff, stream);
+	d_rcol.Upload(rcol, stream);
+	d_task_ptr.Upload(P.task_ptr, stream);
+	d_task_cols.Upload(P.task_cols, stream);
+	d_L.Alloc(size_t(P.loff[n_lblocks]));
+	d_Linv.Alloc(size_t(P.linv_off[P.n]));
+	d_w.Alloc(size_t(P.cs_new[P.n]));
+	d_flag.Alloc(1);
+	SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // the staging vectors above die here
+
+	dplan.dim = d_dim.p(); dplan.cs_new = d_cs_new.p(); dplan.cs_src = d_cs_src.p();
+	dplan.lptr = d_lptr.p(); dplan.lrow = d_lrow.p(); dplan.loff = d_loff.p(); dplan.asrc = d_asrc.p();
+	dplan.linv_off = d_linv_off.p(); dplan.pptr = d_pptr.p(); dplan.pairs = d_pairs.p();
+	dplan.rptr = d_rptr.p(); dplan.roff = d_roff.p(); dplan.rcol = d_rcol.p();
+	dplan.task_ptr = d_task_ptr.p(); dplan.task_cols = d_task_cols.p();
+}
+
+void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs_dev, bool b_factor)
+{
+	const Plan &P = plan;
+	const int n_stages = int(P.stage_ptr.size()) - 1;
+	if(b_factor) {
+		SLAMPP_HIP_CHECK(hipMemsetAsync(d_flag.p(), 0, sizeof(int), stream));
+		for(int s = 0; s < n_stages; ++ s) {
+			launch_factor_stage(dplan, p_values_dev, d_L.p(), d_Linv.p(), P.stage_ptr[s],
+				P.stage_ptr[s + 1] - P.stage_ptr[s], stage_waves[s], d_flag.p(), stream);
+		}
+	}
+	for(int s = 0; s < n_stages; ++ s) {
+		launch_forward_stage(dplan, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
+			P.stage_ptr[s + 1] - P.stage_ptr[s], stream);
+	}
+	for(int s = n_stages; s > 0; -- s) {
+		launch_backward_stage(dplan, d_L.p(), d_Linv.p(), d_w.p(), p_rhs_dev, P.stage_ptr[s - 1],
+			P.stage_ptr[s] - P.stage_ptr[s - 1], stream);
+	}
+	SLAMPP_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+
+namespace {
+
+// runs f, maps exceptions to status codes, records the message
+template <class F>
+int guarded(slampp_hip_solver *p, F f)
+{
+	if(!p)
+		return SLAMPP_HIP_ERR_INVALID;
+	try {
+		if(hipSetDevice(p->n_device) != hipSuccess)
+			throw CDeviceError("hipSetDevice failed");
+		return f();
+	} catch(std::bad_alloc&) {
+		p->s_error = "out of memory";
+		return SLAMPP_HIP_ERR_ALLOC;
+	} catch(CDeviceError &e) {
+		p->s_error = e.what();
+		return SLAMPP_HIP_ERR_DEVICE;
+	} catch(std::domain_error &e) {
+		p->s_error = e.what();
+		return SLAMPP_HIP_ERR_UNSUPPORTED;
+	} catch(std::exception &e) {
+		p->s_error = e.what();
+		return SLAMPP_HIP_ERR_INVALID;
+	}
+}
+
+int fail(slampp_hip_solver *p, int n_code, const char *p_s_msg)
+{
+	p->s_error = p_s_msg;
+	return n_code;
+}
+
+} // anonymous namespace
+
+extern "C" {
+
+int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id)
+{
+	if(!pp_solver)
+		return SLAMPP_HIP_ERR_INVALID;
+	*pp_solver = 0;
+	int n_count = 0;
+	if(hipGetDeviceCount(&n_count) != hipSuccess || n_count <= 0 || device_id < 0 || device_id >= n_count)
+		return SLAMPP_HIP_ERR_DEVICE; // no silent CPU fallback: without a GPU there is no solver
+	slampp_hip_solver *p = new(std::nothrow) slampp_hip_solver();
+	if(!p)
+		return SLAMPP_HIP_ERR_ALLOC;
+	p->n_device = device_id;
+	if(hipSetDevice(device_id) != hipSuccess ||
+	   hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
+	   hipHostMalloc((void**)&p->p_host_flag, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+		delete p;
+		return SLAMPP_HIP_ERR_DEVICE;
+	}
+	*pp_solver = p;
+	return SLAMPP_HIP_OK;
+}
+
+void slampp_hip_destroy(slampp_hip_solver *p_solver)
+{
+	if(p_solver) {
+		(void)hipSetDevice(p_solver->n_device);
+		delete p_solver;
+	}
+}
+
+int slampp_hip_free_memory(slampp_hip_solver *p_solver)
+{
+	return guarded(p_solver, [&]() -> int {
+		SLAMPP_HIP_CHECK(hipStreamSynchronize(p_solver->stream));
+		p_solver->Free_Device();
+		p_solver->plan = Plan();
+		return SLAMPP_HIP_OK;
+	});
+}
+
+const char *slampp_hip_last_error(const slampp_hip_solver *p_solver)
+{
+	return p_solver? p_solver->s_error.c_str() : "null solver handle";
+}
+
+int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int64_t n_value)
+{
+	if(!p_solver || !p_s_name)
+		return SLAMPP_HIP_ERR_INVALID;
+	const std::string s(p_s_name);
+	if(s == "leaf_size" && n_value >= 1)
+		p_solver->opt.leaf_size = int(n_value);
+	else if(s == "subtree_size" && n_value >= 1)
+		p_solver->opt.subtree_size = int(n_value);
+	else if(s == "dense_nb" && (n_value == 32 || n_value == 64 || n_value == 128))
+		p_solver->n_dense_nb = int(n_value);
+	else if(s == "shard_primary")
+		p_solver->b_shard_primary = (n_value != 0);
+	else
+		return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "unknown option or value out of range");
+	p_solver->b_analyzed = false; // options take effect at the next analyze
+	return SLAMPP_HIP_OK;
+}
+
+int slampp_hip_set_structure(slampp_hip_solver *p_solver, int64_t n_bcols, const int64_t *p_bcol_cumsum,
+	const int64_t *p_bcol_ptr, const int32_t *p_brow_idx)
+{
+	return guarded(p_solver, [&]() -> int {
+		if(n_bcols <= 0 || !p_bcol_cumsum || !p_bcol_ptr || (p_bcol_ptr[n_bcols] > 0 && !p_brow_idx))
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "set_structure: null or empty structure");
+		if(p_bcol_cumsum[0] != 0 || p_bcol_ptr[0] != 0)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "set_structure: cumsum / pointer arrays must start at 0");
+		slampp_hip_solver &s = *p_solver;
+		s.cumsum.assign(p_bcol_cumsum, p_bcol_cumsum + n_bcols + 1);
+		s.bcol_ptr.assign(p_bcol_ptr, p_bcol_ptr + n_bcols + 1);
+		s.brow.assign(p_brow_idx, p_brow_idx + p_bcol_ptr[n_bcols]);
+		int64_t n_values = 0;
+		for(int64_t c = 0; c < n_bcols; ++ c) {
+			const int64_t w = s.cumsum[c + 1] - s.cumsum[c];
+			if(w <= 0 || s.bcol_ptr[c + 1] < s.bcol_ptr[c])
+				return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "set_structure: malformed cumsum / pointer arrays");
+			for(int64_t k = s.bcol_ptr[c]; k < s.bcol_ptr[c + 1]; ++ k) {
+				const int32_t r = s.brow[k];
+				if(r < 0 || r > c)
+					return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "set_structure: block outside the upper triangle");
+				n_values += (s.cumsum[r + 1] - s.cumsum[r]) * w;
+			}
+		}
+		s.n_values = n_values;
+		s.n_scalars = s.cumsum[n_bcols];
+		s.b_has_structure = true;
+		s.b_analyzed = false;
+		s.b_factored = false;
+		return SLAMPP_HIP_OK;
+	});
+}
+
+int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix_cut)
+{
+	return guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_has_structure)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "analyze: set_structure was not called");
+		if(n_mode != SLAMPP_HIP_MODE_SPARSE && n_mode != SLAMPP_HIP_MODE_SCHUR)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "analyze: unknown mode");
+		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+		s.Free_Device();
+		memset(&s.times, 0, sizeof(s.times));
+		s.n_mode = n_mode;
+		s.n_matrix_cut = n_matrix_cut;
+		const double t0 = wall_ms();
+		if(n_mode == SLAMPP_HIP_MODE_SPARSE) {
+			s.Analyze_Sparse();
+			s.times.order_ms = s.plan.order_ms;
+			s.times.symbolic_ms = wall_ms() - t0 - s.plan.order_ms;
+		} else {
+			const int64_t n = int64_t(s.cumsum.size()) - 1;
+			if(n_matrix_cut <= 0 || n_matrix_cut >= n)
+				return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "analyze: n_matrix_cut must split the block columns");
+			s.p_schur = schur_analyze(s);
+			s.times.symbolic_ms = wall_ms() - t0;
+		}
+		s.b_analyzed = true;
+		return SLAMPP_HIP_OK;
+	});
+}
+
+int slampp_hip_factor_solve_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,
+	double *p_rhs_inout_dev)
+{
+	return guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_analyzed)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factor_solve: analyze was not called");
+		if(!p_values_dev || !p_rhs_inout_dev)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factor_solve: null pointer");
+		if(s.n_mode == SLAMPP_HIP_MODE_SPARSE)
+			s.Enqueue_Sparse(p_values_dev, p_rhs_inout_dev, true);
+		else
+			schur_enqueue(s, p_values_dev, p_rhs_inout_dev);
+		s.b_factored = true;
+		return SLAMPP_HIP_OK;
+	});
+}
+
+int slampp_hip_sync(slampp_hip_solver *p_solver)
+{
+	return guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		*s.p_host_flag = 0;
+		if(s.d_flag.p())
+			SLAMPP_HIP_CHECK(hipMemcpyAsync(s.p_host_flag, s.d_flag.p(), sizeof(int), hipMemcpyDeviceToHost, s.stream));
+		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+		if(*s.p_host_flag & 2)
+			return fail(p_solver, SLAMPP_HIP_ERR_DEVICE, "all-reduce callback failed");
+		if(*s.p_host_flag) {
+			s.b_factored = false;
+			return fail(p_solver, SLAMPP_HIP_NOT_POSDEF, "matrix is not positive definite");
+		}
+		return SLAMPP_HIP_OK;
+	});
+}
+
+void *slampp_hip_stream(slampp_hip_solver *p_solver)
+{
+	return p_solver? (void*)p_solver->stream : 0;
+}
+
+int slampp_hip_factor_solve_device(slampp_hip_solver *p_solver, const double *p_values_dev,
+	double *p_rhs_inout_dev, slampp_hip_times *p_times)
+{
+	if(!p_solver)
+		return SLAMPP_HIP_ERR_INVALID;
+	const double t0 = wall_ms();
+	int n_result = slampp_hip_factor_solve_device_async(p_solver, p_values_dev, p_rhs_inout_dev);
+	if(n_result == SLAMPP_HIP_OK)
+		n_result = slampp_hip_sync(p_solver);
+	p_solver->times.total_ms = wall_ms() - t0;
+	if(p_times)
+		*p_times = p_solver->times;
+	return n_result;
+}
+
+int slampp_hip_factor_solve(slampp_hip_solver *p_solver, const double *p_values, double *p_rhs_inout,
+	slampp_hip_times *p_times)
+{
+	int n_result = guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_analyzed)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factor_solve: analyze was not called");
+		if(!p_values || !p_rhs_inout)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factor_solve: null pointer");
+		const double t0 = wall_ms();
+		s.d_A.Alloc(size_t(s.n_values));
+		s.d_rhs.Alloc(size_t(s.n_scalars));
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_A.p(), p_values, size_t(s.n_values) * sizeof(double), hipMemcpyHostToDevice, s.stream));
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_rhs.p(), p_rhs_inout, size_t(s.n_scalars) * sizeof(double), hipMemcpyHostToDevice, s.stream));
+		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+		s.times.upload_ms = wall_ms() - t0;
+		return SLAMPP_HIP_OK;
+	});
+	if(n_result != SLAMPP_HIP_OK)
+		return n_result;
+	slampp_hip_solver &s = *p_solver;
+	const double t1 = wall_ms();
+	n_result = slampp_hip_factor_solve_device_async(p_solver, s.d_A.p(), s.d_rhs.p());
+	if(n_result == SLAMPP_HIP_OK)
+		n_result = slampp_hip_sync(p_solver);
+	const double t2 = wall_ms();
+	if(s.n_mode == SLAMPP_HIP_MODE_SPARSE)
+		s.times.factor_ms = t2 - t1; // factor + both substitutions (one stream, no sync between them)
+	else
+		s.times.schur_ms = t2 - t1;
+	if(n_result == SLAMPP_HIP_OK) {
+		n_result = guarded(p_solver, [&]() -> int {
+			SLAMPP_HIP_CHECK(hipMemcpyAsync(p_rhs_inout, s.d_rhs.p(), size_t(s.n_scalars) * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+			SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+			return SLAMPP_HIP_OK;
+		});
+	}
+	s.times.download_ms = wall_ms() - t2;
+	s.times.total_ms = s.times.upload_ms + (t2 - t1) + s.times.download_ms;
+	if(p_times)
+		*p_times = s.times;
+	return n_result;
+}
+
+int slampp_hip_solve_again(slampp_hip_solver *p_solver, double *p_rhs_inout)
+{
+	return guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_factored)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "solve_again: no valid factorization");
+		if(s.n_mode != SLAMPP_HIP_MODE_SPARSE)
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "solve_again: only the sparse path keeps its factor");
+		if(!p_rhs_inout)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "solve_again: null pointer");
+		s.d_rhs.Alloc(size_t(s.n_scalars));
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_rhs.p(), p_rhs_inout, size_t(s.n_scalars) * sizeof(double), hipMemcpyHostToDevice, s.stream));
+		s.Enqueue_Sparse(0, s.d_rhs.p(), false);
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(p_rhs_inout, s.d_rhs.p(), size_t(s.n_scalars) * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+		return SLAMPP_HIP_OK;
+	});
+}
+
+int slampp_hip_get_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_stats)
+{
+	if(!p_solver || !p_stats)
+		return SLAMPP_HIP_ERR_INVALID;
+	const slampp_hip_solver &s = *p_solver;
+	memset(p_stats, 0, sizeof(*p_stats));
+	if(!s.b_has_structure)
+		return SLAMPP_HIP_ERR_INVALID;
+	p_stats->n_bcols = int64_t(s.cumsum.size()) - 1;
+	p_stats->n_blocks_upper = int64_t(s.brow.size());
+	p_stats->n_scalars = s.n_scalars;
+	if(s.b_analyzed && s.n_mode == SLAMPP_HIP_MODE_SPARSE) {
+		const Plan &P = s.plan;
+		p_stats->nnz_upper = P.nnz_upper;
+		p_stats->l_blocks = int64_t(P.lrow.size());
+		p_stats->l_nnz = P.l_nnz;
+		p_stats->factor_flops = P.factor_flops;
+		p_stats->solve_flops = 4.0 * double(P.l_nnz);
+		p_stats->n_stages = int64_t(P.stage_ptr.size()) - 1;
+		p_stats->n_tasks = int64_t(P.task_ptr.size()) - 1;
+		p_stats->etree_height = P.etree_height;
+		p_stats->n_update_pairs = int64_t(P.pa.size());
+	} else if(s.b_analyzed && s.p_schur)
+		schur_fill_stats(s.p_schur, *p_stats);
+	p_stats->device_bytes = int64_t(s.n_Device_Bytes());
+	return SLAMPP_HIP_OK;
+}
+
+int slampp_hip_set_allreduce(slampp_hip_solver *p_solver, slampp_hip_allreduce_fn p_fn, void *p_context)
+{
+	if(!p_solver)
+		return SLAMPP_HIP_ERR_INVALID;
+	p_solver->p_allreduce = p_fn;
+	p_solver->p_allreduce_context = p_context;
+	return SLAMPP_HIP_OK;
+}
+
+static void Fill_PlanView(const Plan &P, slampp_hip_plan_view *v)
+{
+	v->n_bcols = P.n;
+	v->l_blocks = int64_t(P.lrow.size());
+	v->n_pairs = int64_t(P.pa.size());
+	v->n_row_entries = int64_t(P.rblk.size());
+	v->n_stages = int64_t(P.stage_ptr.size()) - 1;
+	v->n_tasks = int64_t(P.task_ptr.size()) - 1;
+	v->n_task_cols = int64_t(P.task_cols.size());
+	v->l_values = P.loff.back();
+#define COPY_OUT(dst, src) do { if(dst) memcpy(dst, (src).data(), (src).size() * sizeof((src)[0])); } while(0)
+	COPY_OUT(v->p_perm, P.perm);
+	COPY_OUT(v->p_dim, P.dim);
+	COPY_OUT(v->p_lptr, P.lptr);
+	COPY_OUT(v->p_lrow, P.lrow);
+	if(v->p_loff)
+		memcpy(v->p_loff, P.loff.data(), P.lrow.size() * sizeof(int64_t));
+	COPY_OUT(v->p_asrc, P.asrc);
+	COPY_OUT(v->p_atrans, P.atrans);
+	COPY_OUT(v->p_pptr, P.pptr);
+	COPY_OUT(v->p_pa, P.pa);
+	COPY_OUT(v->p_pb, P.pb);
+	COPY_OUT(v->p_rptr, P.rptr);
+	COPY_OUT(v->p_rblk, P.rblk);
+	COPY_OUT(v->p_stage_ptr, P.stage_ptr);
+	COPY_OUT(v->p_task_ptr, P.task_ptr);
+	COPY_OUT(v->p_task_cols, P.task_cols);
+#undef COPY_OUT
+}
+
+int slampp_hip_get_plan(const slampp_hip_solver *p_solver, slampp_hip_plan_view *p_view)
+{
+	if(!p_solver || !p_view || !p_solver->b_analyzed || p_solver->n_mode != SLAMPP_HIP_MODE_SPARSE)
+		return SLAMPP_HIP_ERR_INVALID;
+	Fill_PlanView(p_solver->plan, p_view);
+	return SLAMPP_HIP_OK;
+}
+
+struct slampp_hip_plan {
+	Plan plan;
+};
+
+int slampp_hip_plan_create(slampp_hip_plan **pp_plan, int64_t n_bcols, const int64_t *p_bcol_cumsum,
+	const int64_t *p_bcol_ptr, const int32_t *p_brow_idx, int n_leaf_size, int n_subtree_size)
+{
+	if(!pp_plan || !p_bcol_cumsum || !p_bcol_ptr || !p_brow_idx)
+		return SLAMPP_HIP_ERR_INVALID;
+	*pp_plan = 0;
+	try {
+		slampp_hip_plan *p = new slampp_hip_plan();
+		PlanOptions opt;
+		if(n_leaf_size > 0)
+			opt.leaf_size = n_leaf_size;
+		if(n_subtree_size > 0)
+			opt.subtree_size = n_subtree_size;
+		if(!build_plan(n_bcols, p_bcol_cumsum, p_bcol_ptr, p_brow_idx, opt, p->plan).empty()) {
+			delete p;
+			return SLAMPP_HIP_ERR_INVALID;
+		}
+		*pp_plan = p;
+		return SLAMPP_HIP_OK;
+	} catch(std::bad_alloc&) {
+		return SLAMPP_HIP_ERR_ALLOC;
+	}
+}
+
+int slampp_hip_plan_get(const slampp_hip_plan *p_plan, slampp_hip_plan_view *p_view, slampp_hip_stats *p_stats)
+{
+	if(!p_plan || !p_view)
+		return SLAMPP_HIP_ERR_INVALID;
+	Fill_PlanView(p_plan->plan, p_view);
+	if(p_stats) {
+		const Plan &P = p_plan->plan;
+		memset(p_stats, 0, sizeof(*p_stats));
+		p_stats->n_bcols = P.n;
+		p_stats->nnz_upper = P.nnz_upper;
+		p_stats->l_blocks = int64_t(P.lrow.size());
+		p_stats->l_nnz = P.l_nnz;
+		p_stats->factor_flops = P.factor_flops;
+		p_stats->solve_flops = 4.0 * double(P.l_nnz);
+		p_stats->n_stages = int64_t(P.stage_ptr.size()) - 1;
+		p_stats->n_tasks = int64_t(P.task_ptr.size()) - 1;
+		p_stats->etree_height = P.etree_height;
+		p_stats->n_update_pairs = int64_t(P.pa.size());
+	}
+	return SLAMPP_HIP_OK;
+}
+
+void slampp_hip_plan_destroy(slampp_hip_plan *p_plan)
+{
+	delete p_plan;
+}
+
+} // extern "C"

@@ -1,0 +1,330 @@
+"""Host-side mirror of the reference's linear-solver interface over the C ABI of libslampp_hip.so.
+
+The reference binds a linear solver as a duck-typed template parameter
+(/root/reference/include/slam/LinearSolverTags.h:38-135); the C++ binding is
+include/slam/LinearSolver_HIP.h.  This module is the same surface for Python callers and for the
+parity tests: same method names, same argument meaning (``eta`` is overwritten with the solution),
+same error behaviour (``False`` = not positive definite, ``MemoryError`` = std::bad_alloc,
+``RuntimeError`` = std::runtime_error) as
+
+* ``CLinearSolver_CholMod`` / ``CLinearSolver_UberBlock``  (LinearSolver_CholMod.h:148-214,
+  LinearSolver_UberBlock.h:256-426)  ->  :class:`CLinearSolver_HIP`
+* ``CLinearSolver_Schur``  (LinearSolver_Schur.h:1423-1935)  ->  :class:`CLinearSolver_Schur_HIP`
+
+There is no CPU fallback: if the shared library is missing, or there is no GPU, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslampp_hip.so")
+
+OK, NOT_POSDEF = 0, 1
+ERR_INVALID, ERR_ALLOC, ERR_DEVICE, ERR_UNSUPPORTED = -1, -2, -3, -4
+MODE_SPARSE, MODE_SCHUR = 0, 1
+
+
+class Times(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "order_ms", "symbolic_ms", "upload_ms", "factor_ms", "solve_ms", "download_ms",
+        "schur_ms", "reduce_ms", "cholsol_ms", "backsubst_ms", "total_ms")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_bcols", C.c_int64), ("n_blocks_upper", C.c_int64), ("n_scalars", C.c_int64),
+                ("nnz_upper", C.c_int64), ("l_blocks", C.c_int64), ("l_nnz", C.c_int64),
+                ("factor_flops", C.c_double), ("solve_flops", C.c_double),
+                ("n_stages", C.c_int64), ("n_tasks", C.c_int64), ("etree_height", C.c_int64),
+                ("n_update_pairs", C.c_int64), ("n_cams", C.c_int64), ("n_points", C.c_int64),
+                ("n_observations", C.c_int64), ("schur_dim", C.c_int64), ("device_bytes", C.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class PlanView(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_bcols", "l_blocks", "n_pairs", "n_row_entries",
+                                         "n_stages", "n_tasks", "n_task_cols", "l_values")] + [
+        ("p_perm", C.c_void_p), ("p_dim", C.c_void_p), ("p_lptr", C.c_void_p), ("p_lrow", C.c_void_p),
+        ("p_loff", C.c_void_p), ("p_asrc", C.c_void_p), ("p_atrans", C.c_void_p), ("p_pptr", C.c_void_p),
+        ("p_pa", C.c_void_p), ("p_pb", C.c_void_p), ("p_rptr", C.c_void_p), ("p_rblk", C.c_void_p),
+        ("p_stage_ptr", C.c_void_p), ("p_task_ptr", C.c_void_p), ("p_task_cols", C.c_void_p)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+# every symbol include/slampp_hip.h declares: (restype, argtypes)
+_P = C.c_void_p
+ABI = {
+    "slampp_hip_create": (C.c_int, [C.POINTER(_P), C.c_int]),
+    "slampp_hip_destroy": (None, [_P]),
+    "slampp_hip_free_memory": (C.c_int, [_P]),
+    "slampp_hip_last_error": (C.c_char_p, [_P]),
+    "slampp_hip_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "slampp_hip_set_structure": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
+    "slampp_hip_analyze": (C.c_int, [_P, C.c_int, C.c_int64]),
+    "slampp_hip_factor_solve": (C.c_int, [_P, _P, _P, C.POINTER(Times)]),
+    "slampp_hip_factor_solve_device": (C.c_int, [_P, _P, _P, C.POINTER(Times)]),
+    "slampp_hip_solve_again": (C.c_int, [_P, _P]),
+    "slampp_hip_factor_solve_device_async": (C.c_int, [_P, _P, _P]),
+    "slampp_hip_sync": (C.c_int, [_P]),
+    "slampp_hip_stream": (_P, [_P]),
+    "slampp_hip_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "slampp_hip_set_allreduce": (C.c_int, [_P, ALLREDUCE_FN, _P]),
+    "slampp_hip_get_plan": (C.c_int, [_P, C.POINTER(PlanView)]),
+    "slampp_hip_plan_create": (C.c_int, [C.POINTER(_P), C.c_int64, _P, _P, _P, C.c_int, C.c_int]),
+    "slampp_hip_plan_get": (C.c_int, [_P, C.POINTER(PlanView), C.POINTER(Stats)]),
+    "slampp_hip_plan_destroy": (None, [_P]),
+}
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Loads libslampp_hip.so (built in-tree by ``__graft_entry__.build()``); raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in ABI.items():
+            fn = getattr(lib, name)   # AttributeError if the library does not export the symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+_PLAN_FIELDS = [("perm", "p_perm", np.int32, "n_bcols", 0), ("dim", "p_dim", np.int32, "n_bcols", 0),
+                ("lptr", "p_lptr", np.int64, "n_bcols", 1), ("lrow", "p_lrow", np.int32, "l_blocks", 0),
+                ("loff", "p_loff", np.int64, "l_blocks", 0), ("asrc", "p_asrc", np.int64, "l_blocks", 0),
+                ("atrans", "p_atrans", np.int32, "l_blocks", 0), ("pptr", "p_pptr", np.int64, "l_blocks", 1),
+                ("pa", "p_pa", np.int32, "n_pairs", 0), ("pb", "p_pb", np.int32, "n_pairs", 0),
+                ("rptr", "p_rptr", np.int64, "n_bcols", 1), ("rblk", "p_rblk", np.int32, "n_row_entries", 0),
+                ("stage_ptr", "p_stage_ptr", np.int32, "n_stages", 1),
+                ("task_ptr", "p_task_ptr", np.int64, "n_tasks", 1),
+                ("task_cols", "p_task_cols", np.int32, "n_task_cols", 0)]
+
+
+def _fetch_plan(getter) -> dict:
+    v = PlanView()
+    getter(v)                                   # sizes
+    out = {}
+    for name, field, dt, size_field, extra in _PLAN_FIELDS:
+        arr = np.zeros(getattr(v, size_field) + extra, dtype=dt)
+        out[name] = arr
+        setattr(v, field, arr.ctypes.data)
+    getter(v)                                   # contents
+    for f in ("n_bcols", "l_blocks", "n_pairs", "n_row_entries", "n_stages", "n_tasks", "l_values"):
+        out[f] = getattr(v, f)
+    return out
+
+
+def host_plan(lam, leaf_size: int = 0, subtree_size: int = 0):
+    """Ordering + symbolic analysis + schedule on the host only (no GPU): (plan dict, stats dict)."""
+    lib = load_library()
+    h = C.c_void_p()
+    cs = np.ascontiguousarray(lam.cumsum, dtype=np.int64)
+    bp = np.ascontiguousarray(lam.bcol_ptr, dtype=np.int64)
+    br = np.ascontiguousarray(lam.brow_idx, dtype=np.int32)
+    rc = lib.slampp_hip_plan_create(C.byref(h), lam.n_bcols, _ptr(cs), _ptr(bp), _ptr(br),
+                                    leaf_size, subtree_size)
+    if rc != OK:
+        raise ValueError(f"slampp_hip_plan_create failed ({rc})")
+    try:
+        st = Stats()
+
+        def getter(v):
+            if lib.slampp_hip_plan_get(h, C.byref(v), C.byref(st)) != OK:
+                raise RuntimeError("slampp_hip_plan_get failed")
+        plan = _fetch_plan(getter)
+        return plan, st.as_dict()
+    finally:
+        lib.slampp_hip_plan_destroy(h)
+
+
+class _SolverBase:
+    """Shared plumbing: handle life cycle, structure caching, status -> exception mapping."""
+
+    _mode = MODE_SPARSE
+
+    def __init__(self, device: int = 0, **options):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.slampp_hip_create(C.byref(self._h), int(device))
+        if rc != OK:
+            self._h = None
+            raise RuntimeError(f"slampp_hip_create(device={device}) failed ({rc}): no usable HIP device")
+        self._options = dict(options)
+        for k, v in options.items():
+            self._check(self._lib.slampp_hip_set_option(self._h, k.encode(), int(v)))
+        self._structure_key = None
+        self._analyzed = False
+        self._keepalive = None
+        self.times = Times()
+
+    # copies do not carry state, as in the reference (LinearSolver_CholMod.h:163-167,
+    # NonlinearSolver_Base.h:400,438), but they do keep the configuration
+    def __copy__(self):
+        return type(self)(**self._ctor_args())
+
+    def _ctor_args(self):
+        return dict(self._options)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.slampp_hip_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _error(self) -> str:
+        return (self._lib.slampp_hip_last_error(self._h) or b"").decode()
+
+    def _check(self, rc: int) -> bool:
+        if rc == OK:
+            return True
+        if rc == NOT_POSDEF:
+            return False
+        if rc == ERR_ALLOC:
+            raise MemoryError(self._error())
+        if rc == ERR_INVALID:
+            raise ValueError(self._error())
+        if rc == ERR_UNSUPPORTED:
+            raise NotImplementedError(self._error())
+        raise RuntimeError(self._error())
+
+    def Free_Memory(self) -> None:
+        self._check(self._lib.slampp_hip_free_memory(self._h))
+        self._structure_key = None
+        self._analyzed = False
+
+    def Clear_SymbolicDecomposition(self) -> None:
+        """LinearSolverTags.h:112-120: the block structure is about to change."""
+        self._structure_key = None
+        self._analyzed = False
+
+    @staticmethod
+    def _key(lam):
+        return (lam.n_bcols, lam.n_blocks, int(lam.cumsum[-1]),
+                hash(lam.bcol_ptr.tobytes()), hash(lam.brow_idx.tobytes()), hash(lam.cumsum.tobytes()))
+
+    def _n_matrix_cut(self, lam) -> int:
+        return 0
+
+    def SymbolicDecomposition_Blocky(self, lam) -> bool:
+        cs = np.ascontiguousarray(lam.cumsum, dtype=np.int64)
+        bp = np.ascontiguousarray(lam.bcol_ptr, dtype=np.int64)
+        br = np.ascontiguousarray(lam.brow_idx, dtype=np.int32)
+        self._check(self._lib.slampp_hip_set_structure(self._h, lam.n_bcols, _ptr(cs), _ptr(bp), _ptr(br)))
+        self._check(self._lib.slampp_hip_analyze(self._h, self._mode, self._n_matrix_cut(lam)))
+        self._structure_key = self._key(lam)
+        self._analyzed = True
+        return True
+
+    def Solve_PosDef_Blocky(self, lam, eta: np.ndarray) -> bool:
+        """Reuses ordering / symbolic analysis while the block structure is unchanged
+        (LinearSolverTags.h:130-134).  ``eta``: rhs on entry, solution on return."""
+        if eta.dtype != np.float64 or not eta.flags.c_contiguous or eta.shape != (lam.n_scalars,):
+            raise ValueError("eta must be a contiguous float64 vector of the system's dimension")
+        if not self._analyzed or self._structure_key != self._key(lam):
+            self.SymbolicDecomposition_Blocky(lam)
+        vals = np.ascontiguousarray(lam.values, dtype=np.float64)
+        return self._check(self._lib.slampp_hip_factor_solve(self._h, _ptr(vals), _ptr(eta), C.byref(self.times)))
+
+    def Solve_PosDef(self, lam, eta: np.ndarray) -> bool:
+        """Cold solve: ordering + symbolic + numeric (LinearSolver_CholMod.cpp:264-358)."""
+        self.Clear_SymbolicDecomposition()
+        return self.Solve_PosDef_Blocky(lam, eta)
+
+    def Solve_Again(self, eta: np.ndarray) -> bool:
+        return self._check(self._lib.slampp_hip_solve_again(self._h, _ptr(eta)))
+
+    def stats(self) -> dict:
+        st = Stats()
+        self._check(self._lib.slampp_hip_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def plan(self) -> dict:
+        def getter(v):
+            self._check(self._lib.slampp_hip_get_plan(self._h, C.byref(v)))
+        return _fetch_plan(getter)
+
+    # ---- device-resident entry points (bench.py; torch only provides the memory) ----
+    def factor_solve_device(self, values_ptr: int, rhs_ptr: int) -> bool:
+        return self._check(self._lib.slampp_hip_factor_solve_device(self._h, values_ptr, rhs_ptr, C.byref(self.times)))
+
+    def factor_solve_device_async(self, values_ptr: int, rhs_ptr: int) -> None:
+        self._check(self._lib.slampp_hip_factor_solve_device_async(self._h, values_ptr, rhs_ptr))
+
+    def sync(self) -> bool:
+        return self._check(self._lib.slampp_hip_sync(self._h))
+
+    def stream(self) -> int:
+        return int(self._lib.slampp_hip_stream(self._h) or 0)
+
+    def set_allreduce(self, fn) -> None:
+        """fn(dev_ptr:int, count:int, stream:int) -> int; kept alive by the solver."""
+        if fn is None:
+            self._keepalive = None
+            self._check(self._lib.slampp_hip_set_allreduce(self._h, C.cast(None, ALLREDUCE_FN), None))
+            return
+
+        def tramp(_ctx, p, n, s):
+            try:
+                return int(fn(int(p or 0), int(n), int(s or 0)))
+            except Exception:      # never unwind through C
+                return 1
+        self._keepalive = ALLREDUCE_FN(tramp)
+        self._check(self._lib.slampp_hip_set_allreduce(self._h, self._keepalive, None))
+
+
+class CLinearSolver_HIP(_SolverBase):
+    """Sparse block Cholesky on the GPU; stands where CLinearSolver_CholMod / _CSparse / _UberBlock do."""
+
+    _Tag = "CBlockwiseLinearSolverTag"   # LinearSolverTags.h:54
+    _mode = MODE_SPARSE
+
+
+class CLinearSolver_Schur_HIP(_SolverBase):
+    """Schur-complement solver for BA systems; same public surface as CLinearSolver_Schur
+    (LinearSolver_Schur.h:1472-1553, 1623).  The guided ordering (cameras = wide block columns first,
+    landmarks last; LinearSolver_Schur.cpp:771-838) is computed here from the block widths."""
+
+    _Tag = "CBlockwiseLinearSolverTag"
+    _mode = MODE_SCHUR
+
+    def __init__(self, base_solver=None, device: int = 0, **options):
+        # the reference's constructor takes (and ignores) a base solver instance
+        # (LinearSolver_Schur.h:1472-1474); accepted for signature parity
+        super().__init__(device=device, **options)
+        self._cut_override = None
+
+    def _n_matrix_cut(self, lam) -> int:
+        if self._cut_override is not None:
+            return int(self._cut_override)
+        if getattr(lam, "n_matrix_cut", 0):
+            return int(lam.n_matrix_cut)
+        dims = np.diff(lam.cumsum)
+        wide = dims == dims.max()
+        n_cut = int(np.count_nonzero(wide))
+        if n_cut == 0 or n_cut == len(dims) or not np.all(wide[:n_cut]):
+            raise NotImplementedError("guided ordering: cameras must precede landmarks in Lambda")
+        return n_cut
+
+    def SymbolicDecomposition_Blocky(self, lam, b_force_guided_ordering: bool = False) -> bool:
+        return super().SymbolicDecomposition_Blocky(lam)

@@ -1,0 +1,81 @@
+"""GPU parity tests of the sparse block Cholesky path (pose graphs): the HIP path, called through
+the C ABI (slam_plus_plus_amd.hip_solver), against the CPU oracle on the same seeded inputs.
+Tolerance: BASELINE.json's north_star, ||x_gpu - x_ref||_inf / ||x_ref||_inf < 1e-10 (fp64)."""
+import numpy as np
+import pytest
+
+from slam_plus_plus_amd import synth
+from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP
+from oracle import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def rel_inf(x, ref):
+    return float(np.abs(x - ref).max() / np.abs(ref).max())
+
+
+CASES = {
+    "chain6": lambda: synth.pose_chain(n=3000, d=6),
+    "chain3": lambda: synth.pose_chain(n=2000, d=3, seed=7),
+    "chain7": lambda: synth.pose_chain(n=1500, d=7, seed=8),
+    "sphere": lambda: synth.sphere(50, 50),                 # C2 look-alike, full size
+    "manhattan": lambda: synth.manhattan(3500),             # C1 look-alike, full size
+    "tiny": lambda: synth.pose_chain(n=2, d=6, loop_every=50),
+    "single": lambda: synth.pose_chain(n=1, d=6),
+    "ba_sparse_path": lambda: synth.ba(30, 2000),           # mixed 6/3 blocks through the sparse path
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_parity_with_oracle(name):
+    lam = CASES[name]()
+    ok, x_ref, _ = O.solve_sparse(lam)
+    assert ok
+    solver = CLinearSolver_HIP()
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta)
+    assert rel_inf(eta, x_ref) < TOL
+    # warm path: structure cached, new values / rhs
+    eta2 = 2.0 * lam.rhs
+    assert solver.Solve_PosDef_Blocky(lam, eta2)
+    assert rel_inf(eta2, 2.0 * x_ref) < TOL
+    # another rhs with the kept factor
+    eta3 = lam.rhs.copy()
+    assert solver.Solve_Again(eta3)
+    assert rel_inf(eta3, x_ref) < TOL
+
+
+@pytest.mark.parametrize("leaf,sub", [(1, 1), (4, 64), (64, 4), (1000000, 1000000)])
+def test_schedule_knobs_do_not_change_the_answer(leaf, sub):
+    lam = synth.sphere(20, 20)
+    ok, x_ref, _ = O.solve_sparse(lam)
+    solver = CLinearSolver_HIP(leaf_size=leaf, subtree_size=sub)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta)
+    assert rel_inf(eta, x_ref) < TOL
+
+
+def test_not_positive_definite_returns_false():
+    lam = synth.indefinite()
+    ok, _, _ = O.solve_sparse(lam)
+    assert not ok
+    solver = CLinearSolver_HIP()
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta) is False
+
+
+def test_residual_full_size_c3():
+    """BASELINE config C3 (100k-pose SE(3)): too big for the scalar oracle to be quick, so check the
+    size-independent property ||Lambda x - eta|| / ||eta|| and linearity in eta."""
+    lam = synth.pose_chain()
+    A = lam.to_scipy()
+    solver = CLinearSolver_HIP()
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta)
+    r = A @ eta - lam.rhs
+    assert np.abs(r).max() / np.abs(lam.rhs).max() < 1e-9
+    eta2 = -3.0 * lam.rhs
+    assert solver.Solve_PosDef_Blocky(lam, eta2)
+    assert rel_inf(eta2, -3.0 * eta) < TOL
