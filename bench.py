@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- Lambda-solve benchmark on MI355X (BASELINE.json metric: "Lambda solve wall-clock ms +
+GFLOP/s vs roofline, 100k-pose SE(3) and BA Schur").
+
+A "step" is one pass of the hot path over one synthetic system: numeric factorization of Lambda plus
+the two substitutions, i.e. what every Gauss-Newton iteration after the first asks of
+Solve_PosDef_Blocky (/root/reference/include/slam/NonlinearSolver_Lambda.h:618).  Lambda (packed
+block values) and eta are resident in HBM when the timed region starts; PCIe-inclusive numbers
+are in DESIGN.md, never here.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3            # default workload: C3, 100k-pose SE(3)
+  python bench.py --workload ba                             # C4: 1k cams x 500k points, Schur path
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: the pose-graph factorization does not shard (one elimination tree) -> N independent
+replicas, "scaling": "weak".  The BA workload shards landmarks over the ranks (weak: a fixed
+number of points per GPU) with one RCCL all-reduce of the reduced camera system per step.
+
+One JSON line on stdout (rank 0).  `value` = algorithmic GFLOP/s of the whole job; `ms_per_step` =
+wall-clock per Lambda solve; `roofline` = dominant kernel against HBM peak, timed with HIP events
+on the solver's stream inside the timed region; `cpu_baseline` = the compiled reference's CHOLMOD
+path (oracle/_ref/ref_harness) on this box's host cores, bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (vendor figure quoted in SURVEY.md section 8d)
+
+# Algorithmic work of the default C3 instance (synth.pose_chain(), seed 12345), counted by the
+# reference's own CHOLMOD (AMD ordering) with oracle/_ref/ref_harness cholmod_phases in the build
+# container: Common.lnz, Common.fl, nnz(triu(Lambda)).  SURVEY.md section 8d convention:
+# factor flops = fl, solve flops = 4 lnz, factor bytes = 8 (nnz + lnz), solve bytes = 16 lnz + 32 n.
+C3_REF = {"n": 600_000, "nnz_triu": 7_271_928, "lnz": 8_360_436, "fl": 122_411_332.0}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def algorithmic_counts_c3(lam, stats):
+    if lam.n_bcols == 100_000 and lam.n_blocks == 201_998:
+        c = dict(C3_REF)
+        c["source"] = "reference CHOLMOD/AMD counters (fl, lnz) on this instance"
+    else:  # other sizes: our own ordering's counts (upper bound on the reference's)
+        c = {"n": lam.n_scalars, "nnz_triu": stats["nnz_upper"], "lnz": stats["l_nnz"],
+             "fl": stats["factor_flops"], "source": "own ordering"}
+    c["flops"] = c["fl"] + 4.0 * c["lnz"]
+    c["factor_bytes"] = 8.0 * (c["nnz_triu"] + c["lnz"])
+    c["solve_bytes"] = 16.0 * c["lnz"] + 32.0 * c["n"]
+    return c
+
+
+def per_kernel_bytes_sparse(plan):
+    """Algorithmic bytes each kernel of the sparse path moves per step, from the plan (our own
+    factor structure): factor = 8 (nnz of the Lambda blocks read + nnz of the L columns written),
+    substitution = 8 nnz(L columns) + vectors, split into the bottom-stage launch and the rest."""
+    dim = plan["dim"].astype(np.int64)
+    lptr, lrow, asrc = plan["lptr"], plan["lrow"].astype(np.int64), plan["asrc"]
+    n = len(dim)
+    col_of = np.repeat(np.arange(n), np.diff(lptr))
+    is_diag = np.zeros(len(lrow), dtype=bool)
+    is_diag[lptr[:-1]] = True
+    dj, di = dim[col_of], dim[lrow]
+    blk_nnz = np.where(is_diag, dj * (dj + 1) // 2, di * dj)
+    l_col = np.bincount(col_of, weights=blk_nnz, minlength=n)
+    a_col = np.bincount(col_of, weights=np.where(asrc >= 0, blk_nnz, 0), minlength=n)
+    stage0 = np.zeros(n, dtype=bool)
+    t0, t1 = plan["stage_ptr"][0], plan["stage_ptr"][1]
+    stage0[plan["task_cols"][plan["task_ptr"][t0]:plan["task_ptr"][t1]]] = True
+    fac = 8.0 * (l_col + a_col)
+    sub = 8.0 * l_col + 32.0 * dim / 2          # per substitution: read L column, read+write vector
+    return {"factor_subtree": float(fac[stage0].sum()), "factor_upper": float(fac[~stage0].sum()),
+            "forward": float(sub.sum()), "backward": float(sub.sum()),
+            "stage0_cols": int(stage0.sum())}
+
+
+def cpu_baseline_c3(lam, counts, budget_reps=12):
+    from oracle import oracle_lib as O
+    with tempfile.TemporaryDirectory() as td:
+        if O.have_reference():
+            path = os.path.join(td, "c3.bin")
+            lam.save(path)
+            t0 = time.perf_counter()
+            r = O.reference_solve(path, "cholmod_auto", "-", reps=budget_reps)
+            wall = time.perf_counter() - t0
+            ms = float(np.median(r["times_ms"]))
+            return {"value": counts["flops"] / (ms * 1e-3) / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "reference",
+                    "ms_per_solve": ms, "sample": f"{budget_reps} x CLinearSolver_CholMod(CHOLMOD_AUTO, AMD)::Solve_PosDef "
+                    f"on the same 100k-pose system (median; {wall:.1f} s of CPU incl. load); Cholesky/solves are serial in the reference"}
+    t0 = time.perf_counter()
+    ok, _, _ = O.solve_sparse(lam)
+    ms = (time.perf_counter() - t0) * 1e3
+    return {"value": counts["flops"] / (ms * 1e-3) / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "ms_per_solve": ms, "sample": "1 x oracle/slampp_oracle.c up-looking block Cholesky, natural order"}
+
+
+def run_c3(args, rank, world, local_rank, dist):
+    import torch
+    from slam_plus_plus_amd import synth
+    from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP
+
+    dev = torch.device(f"cuda:{local_rank}")
+    lam = synth.pose_chain(n=args.poses)
+    solver = CLinearSolver_HIP(device=local_rank)
+    t0 = time.perf_counter()
+    solver.SymbolicDecomposition_Blocky(lam)
+    analyze_ms = (time.perf_counter() - t0) * 1e3
+    stats = solver.stats()
+    counts = algorithmic_counts_c3(lam, stats)
+    vals = torch.from_numpy(lam.values).to(dev)
+    rhs0 = torch.from_numpy(lam.rhs).to(dev)
+    bufs = [rhs0.clone() for _ in range(args.steps + args.warmup)]
+    torch.cuda.synchronize()
+    for k in range(args.warmup):
+        solver.factor_solve_device_async(vals.data_ptr(), bufs[k].data_ptr())
+    if not solver.sync():
+        raise SystemExit("warm-up solve failed: not positive definite")
+    solver.set_option("profile", 1)
+    solver.profile(reset=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        solver.factor_solve_device_async(vals.data_ptr(), bufs[k].data_ptr())
+    ok = solver.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if not ok:
+        raise SystemExit("solve failed: not positive definite")
+    if rank != 0:
+        return None
+    # parity guard on the last timed solution: ||Lambda x - eta||_inf / ||eta||_inf
+    x = bufs[-1].cpu().numpy()
+    resid = float(np.abs(lam.to_scipy() @ x - lam.rhs).max() / np.abs(lam.rhs).max())
+    ms_per_step = dt / args.steps * 1e3
+    prof = solver.profile()
+    kb = per_kernel_bytes_sparse(solver.plan())
+    n_stages = stats["n_stages"]
+    launches = {"factor_subtree": 1, "factor_upper": max(n_stages - 1, 1), "forward": n_stages, "backward": n_stages}
+    names = {"factor_subtree": "factor_subtree_kernel", "factor_upper": "factor_stage_kernel<W>",
+             "forward": "forward_stage_kernel", "backward": "backward_stage_kernel"}
+    kernels = []
+    for ph, (cnt, tot_ms) in prof.items():
+        if ph not in kb or cnt == 0:
+            continue
+        per_step_ms = tot_ms / cnt
+        kernels.append({"kernel": names[ph], "launches_per_step": launches[ph], "ms_per_step": per_step_ms,
+                        "avg_launch_us": per_step_ms / launches[ph] * 1e3,
+                        "algorithmic_bytes_per_launch": kb[ph] / launches[ph],
+                        "achieved_GBs": kb[ph] / (per_step_ms * 1e-3) / 1e9})
+    kernels.sort(key=lambda k: -k["ms_per_step"])
+    dom = kernels[0]
+    out = {
+        "metric": "Lambda solve GFLOP/s (algorithmic factor+solve flops / wall-clock), 100k-pose SE(3)",
+        "value": counts["flops"] * world / (dt / args.steps) / 1e9, "unit": "GFLOP/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"C3: synthetic {lam.n_bcols}-pose SE(3) chain + loop closures, 6x6 blocks, "
+                               f"{lam.n_blocks} upper blocks, n={lam.n_scalars}; numeric factor + 2 substitutions per step "
+                               "(symbolic analysis cached, inputs resident in HBM)",
+                   "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (path does not shard)"},
+        "solve_residual_rel_inf": resid,
+        "algorithmic": {"flops_per_step": counts["flops"], "factor_bytes": counts["factor_bytes"],
+                        "solve_bytes": counts["solve_bytes"], "source": counts["source"]},
+        "own_ordering": {"l_nnz": stats["l_nnz"], "factor_flops": stats["factor_flops"], "n_stages": n_stages,
+                         "n_tasks": stats["n_tasks"], "analyze_ms_cold": analyze_ms},
+        "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_us": dom["avg_launch_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
+        "kernels": kernels,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_c3(lam, counts)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=["c3", "ba"])
+    ap.add_argument("--poses", type=int, default=100_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        torch.cuda.set_device(local_rank)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    if args.workload == "c3":
+        out = run_c3(args, rank, world, local_rank, dist)
+    else:
+        from bench_ba import run_ba
+        out = run_ba(args, rank, world, local_rank, dist)
+    if rank == 0 and out is not None:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,8 +67,9 @@ void slampp_hip_destroy(slampp_hip_solver *p_solver);
 int slampp_hip_free_memory(slampp_hip_solver *p_solver);
 const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
 
-/* tuning knobs: "leaf_size" (nested-dissection leaf, default 32), "subtree_size" (max columns one
- * wave eliminates sequentially, default 32), "dense_nb" (dense panel width, default 64) */
+/* tuning knobs: "leaf_size" (nested-dissection leaf, default 4), "subtree_size" (max columns one
+ * wave eliminates sequentially, default 16), "dense_nb" (dense panel width, default 64),
+ * "profile" (0/1, see slampp_hip_get_profile), "shard_primary" (multi-GPU BA: this rank adds A and eta_x) */
 int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int64_t n_value);
 
 /* structure of Lambda -- stands in for what the reference's wrappers read through
@@ -110,6 +111,19 @@ int slampp_hip_sync(slampp_hip_solver *p_solver);
 void *slampp_hip_stream(slampp_hip_solver *p_solver); /* the hipStream_t every kernel is launched on */
 
 int slampp_hip_get_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_stats);
+
+/* device-side phase timing (the counterpart of the reference's __SCHUR_PROFILING / CTimerSampler
+ * phase timers, LinearSolver_Schur.h:1681-1912, Timer.h:391): with option "profile" = 1 every phase
+ * of factor_solve is bracketed by HIP events on the solver's stream; the totals are collected at
+ * slampp_hip_sync().  Phases: factor_subtree, factor_upper, forward, backward (sparse path);
+ * schur_points, schur_gather, schur_rhs, dense_chol, dense_solve, backsubst (Schur path). */
+typedef struct slampp_hip_phase_time {
+	char name[32];
+	int64_t n_count;      /* times the phase ran */
+	double f_total_ms;    /* summed device time */
+} slampp_hip_phase_time;
+int slampp_hip_get_profile(slampp_hip_solver *p_solver, slampp_hip_phase_time *p_phases, int n_max_phases,
+	int *p_phase_num, int b_reset);
 
 /* Multi-GPU BA (new functionality, no reference counterpart -- SURVEY.md section 8e): every rank
  * holds a landmark shard (its own points + all cameras); the partial reduced camera system

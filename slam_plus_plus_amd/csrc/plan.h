@@ -47,8 +47,8 @@ struct Plan {
 };
 
 struct PlanOptions {
-	int leaf_size = 32;       // nested dissection stops at subgraphs of this many block columns
-	int subtree_size = 32;    // a subtree of at most this many columns is one sequential task
+	int leaf_size = 4;        // nested dissection stops at subgraphs of this many block columns
+	int subtree_size = 16;    // a subtree of at most this many columns is one sequential task
 };
 
 // returns empty string on success, else an error message

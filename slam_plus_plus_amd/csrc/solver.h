@@ -106,6 +106,19 @@ struct slampp_hip_solver {
 
 	slampp_hip_times times;
 
+	// optional per-phase device timing with HIP events on `stream` (option "profile")
+	struct TPhaseRecord { int n_label; hipEvent_t start, stop; };
+	int b_profile;
+	std::vector<std::string> phase_names;
+	std::vector<double> phase_ms;
+	std::vector<int64_t> phase_count;
+	std::vector<TPhaseRecord> phase_pending;
+	std::vector<hipEvent_t> event_pool;
+	int n_open_phase;
+	void Phase_Begin(const char *p_s_label);
+	void Phase_End();
+	void Phase_Collect(); // after a stream synchronisation
+
 	slampp_hip_solver();
 	~slampp_hip_solver();
 	void Free_Device();

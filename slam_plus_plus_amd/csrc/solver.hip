@@ -11,7 +11,8 @@ using namespace slampp;
 slampp_hip_solver::slampp_hip_solver()
 	:n_device(0), stream(0), n_dense_nb(64), b_shard_primary(1), b_has_structure(false),
 	b_analyzed(false), b_factored(false), n_mode(SLAMPP_HIP_MODE_SPARSE), n_matrix_cut(0),
-	n_values(0), n_scalars(0), p_host_flag(0), p_schur(0), p_allreduce(0), p_allreduce_context(0)
+	n_values(0), n_scalars(0), p_host_flag(0), p_schur(0), p_allreduce(0), p_allreduce_context(0),
+	b_profile(0), n_open_phase(-1)
 {
 	memset(&dplan, 0, sizeof(dplan));
 	memset(&times, 0, sizeof(times));
@@ -20,6 +21,12 @@ slampp_hip_solver::slampp_hip_solver()
 slampp_hip_solver::~slampp_hip_solver()
 {
 	Free_Device();
+	for(size_t i = 0; i < phase_pending.size(); ++ i) {
+		(void)hipEventDestroy(phase_pending[i].start);
+		(void)hipEventDestroy(phase_pending[i].stop);
+	}
+	for(size_t i = 0; i < event_pool.size(); ++ i)
+		(void)hipEventDestroy(event_pool[i]);
 	if(p_host_flag)
 		(void)hipHostFree(p_host_flag);
 	if(stream)
@@ -48,6 +55,60 @@ size_t slampp_hip_solver::n_Device_Bytes() const
 		d_roff.n_Bytes() + d_task_ptr.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
 		d_rhs.n_Bytes() + d_L.n_Bytes() + d_Linv.n_Bytes() + d_w.n_Bytes() + d_flag.n_Bytes() +
 		(p_schur? schur_device_bytes(p_schur) : 0);
+}
+
+void slampp_hip_solver::Phase_Begin(const char *p_s_label)
+{
+	if(!b_profile)
+		return;
+	int n_label = -1;
+	for(size_t i = 0; i < phase_names.size(); ++ i) {
+		if(phase_names[i] == p_s_label)
+			n_label = int(i);
+	}
+	if(n_label < 0) {
+		n_label = int(phase_names.size());
+		phase_names.push_back(p_s_label);
+		phase_ms.push_back(0);
+		phase_count.push_back(0);
+	}
+	TPhaseRecord r;
+	r.n_label = n_label;
+	for(int i = 0; i < 2; ++ i) {
+		hipEvent_t e;
+		if(!event_pool.empty()) {
+			e = event_pool.back();
+			event_pool.pop_back();
+		} else
+			SLAMPP_HIP_CHECK(hipEventCreate(&e));
+		(i? r.stop : r.start) = e;
+	}
+	SLAMPP_HIP_CHECK(hipEventRecord(r.start, stream));
+	phase_pending.push_back(r);
+	n_open_phase = int(phase_pending.size()) - 1;
+}
+
+void slampp_hip_solver::Phase_End()
+{
+	if(!b_profile || n_open_phase < 0)
+		return;
+	SLAMPP_HIP_CHECK(hipEventRecord(phase_pending[n_open_phase].stop, stream));
+	n_open_phase = -1;
+}
+
+void slampp_hip_solver::Phase_Collect()
+{
+	for(size_t i = 0; i < phase_pending.size(); ++ i) {
+		float f_ms = 0;
+		if(hipEventElapsedTime(&f_ms, phase_pending[i].start, phase_pending[i].stop) == hipSuccess) {
+			phase_ms[phase_pending[i].n_label] += f_ms;
+			++ phase_count[phase_pending[i].n_label];
+		} else
+			(void)hipGetLastError();
+		event_pool.push_back(phase_pending[i].start);
+		event_pool.push_back(phase_pending[i].stop);
+	}
+	phase_pending.clear();
 }
 
 void slampp_hip_solver::Analyze_Sparse()
@@ -126,18 +187,26 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 	if(b_factor) {
 		SLAMPP_HIP_CHECK(hipMemsetAsync(d_flag.p(), 0, sizeof(int), stream));
 		for(int s = 0; s < n_stages; ++ s) {
+			if(s < 2)
+				Phase_Begin(s? "factor_upper" : "factor_subtree");
 			launch_factor_stage(dplan, p_values_dev, d_L.p(), d_Linv.p(), P.stage_ptr[s],
-				P.stage_ptr[s + 1] - P.stage_ptr[s], stage_waves[s], d_flag.p(), stream);
+				P.stage_ptr[s + 1] - P.stage_ptr[s], s? stage_waves[s] : 0, d_flag.p(), stream);
+			if(!s || s == n_stages - 1)
+				Phase_End();
 		}
 	}
+	Phase_Begin("forward");
 	for(int s = 0; s < n_stages; ++ s) {
 		launch_forward_stage(dplan, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
 			P.stage_ptr[s + 1] - P.stage_ptr[s], stream);
 	}
+	Phase_End();
+	Phase_Begin("backward");
 	for(int s = n_stages; s > 0; -- s) {
 		launch_backward_stage(dplan, d_L.p(), d_Linv.p(), d_w.p(), p_rhs_dev, P.stage_ptr[s - 1],
 			P.stage_ptr[s] - P.stage_ptr[s - 1], stream);
 	}
+	Phase_End();
 	SLAMPP_HIP_CHECK(hipGetLastError());
 }
 
@@ -240,6 +309,10 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 		p_solver->n_dense_nb = int(n_value);
 	else if(s == "shard_primary")
 		p_solver->b_shard_primary = (n_value != 0);
+	else if(s == "profile") {
+		p_solver->b_profile = (n_value != 0);
+		return SLAMPP_HIP_OK; // does not invalidate the analysis
+	}
 	else
 		return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "unknown option or value out of range");
 	p_solver->b_analyzed = false; // options take effect at the next analyze
@@ -335,6 +408,7 @@ int slampp_hip_sync(slampp_hip_solver *p_solver)
 		if(s.d_flag.p())
 			SLAMPP_HIP_CHECK(hipMemcpyAsync(s.p_host_flag, s.d_flag.p(), sizeof(int), hipMemcpyDeviceToHost, s.stream));
 		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+		s.Phase_Collect();
 		if(*s.p_host_flag & 2)
 			return fail(p_solver, SLAMPP_HIP_ERR_DEVICE, "all-reduce callback failed");
 		if(*s.p_host_flag) {
@@ -453,6 +527,26 @@ int slampp_hip_get_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_
 	} else if(s.b_analyzed && s.p_schur)
 		schur_fill_stats(s.p_schur, *p_stats);
 	p_stats->device_bytes = int64_t(s.n_Device_Bytes());
+	return SLAMPP_HIP_OK;
+}
+
+int slampp_hip_get_profile(slampp_hip_solver *p_solver, slampp_hip_phase_time *p_phases, int n_max_phases,
+	int *p_phase_num, int b_reset)
+{
+	if(!p_solver || !p_phase_num)
+		return SLAMPP_HIP_ERR_INVALID;
+	slampp_hip_solver &s = *p_solver;
+	*p_phase_num = int(s.phase_names.size());
+	for(int i = 0; i < *p_phase_num && i < n_max_phases && p_phases; ++ i) {
+		memset(p_phases[i].name, 0, sizeof(p_phases[i].name));
+		strncpy(p_phases[i].name, s.phase_names[i].c_str(), sizeof(p_phases[i].name) - 1);
+		p_phases[i].n_count = s.phase_count[i];
+		p_phases[i].f_total_ms = s.phase_ms[i];
+	}
+	if(b_reset) {
+		std::fill(s.phase_ms.begin(), s.phase_ms.end(), 0.0);
+		std::fill(s.phase_count.begin(), s.phase_count.end(), int64_t(0));
+	}
 	return SLAMPP_HIP_OK;
 }
 

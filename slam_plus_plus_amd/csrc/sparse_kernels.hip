@@ -57,17 +57,16 @@ __device__ __forceinline__ double accumulate_block(const TDevPlan &p, const doub
 	return acc;
 }
 
+// one task = a chain of block columns eliminated in order by one workgroup of W waves
 template <int W>
-__global__ void __launch_bounds__(64 * W)
-factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double *Linv,
-	int task_begin, int *p_flag)
+__device__ __forceinline__ void factor_task(const TDevPlan &p, const double *__restrict__ A, double *L,
+	double *Linv, int task, int *p_flag)
 {
 	__shared__ double s_linv[64];      // inv(L_jj), element (r,c) at r + 8 c
 	__shared__ double s_rdiag[8];      // 1 / L_jj(k,k)
 	__shared__ double s_tile[W][64];
 
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int task = task_begin + blockIdx.x;
 	const int64_t c_end = p.task_ptr[task + 1];
 	for(int64_t c = p.task_ptr[task]; c < c_end; ++ c) {
 		const int j = p.task_cols[c];
@@ -150,6 +149,23 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 		}
 		__syncthreads(); // column j is complete (and visible to this workgroup) before the next one starts
 	}
+}
+
+// bottom stage: whole elimination subtrees, one wave each (the launch that touches most of Lambda and L)
+__global__ void __launch_bounds__(64)
+factor_subtree_kernel(TDevPlan p, const double *__restrict__ A, double *L, double *Linv,
+	int task_begin, int *p_flag)
+{
+	factor_task<1>(p, A, L, Linv, task_begin + blockIdx.x, p_flag);
+}
+
+// upper stages: separator columns / chains, W waves per column
+template <int W>
+__global__ void __launch_bounds__(64 * W)
+factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double *Linv,
+	int task_begin, int *p_flag)
+{
+	factor_task<W>(p, A, L, Linv, task_begin + blockIdx.x, p_flag);
 }
 
 // forward substitution  y_j = inv(L_jj) (b_j - sum_c L(j,c) y_c), one wave per task, lanes = 8 entry
@@ -242,7 +258,9 @@ void launch_factor_stage(const TDevPlan &p, const double *A, double *L, double *
 {
 	if(n_tasks <= 0)
 		return;
-	if(n_waves <= 1)
+	if(n_waves <= 0)
+		hipLaunchKernelGGL(factor_subtree_kernel, dim3(n_tasks), dim3(64), 0, stream, p, A, L, Linv, task_begin, p_flag);
+	else if(n_waves <= 1)
 		hipLaunchKernelGGL(factor_stage_kernel<1>, dim3(n_tasks), dim3(64), 0, stream, p, A, L, Linv, task_begin, p_flag);
 	else if(n_waves <= 4)
 		hipLaunchKernelGGL(factor_stage_kernel<4>, dim3(n_tasks), dim3(256), 0, stream, p, A, L, Linv, task_begin, p_flag);

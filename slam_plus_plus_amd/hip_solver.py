@@ -58,6 +58,10 @@ class PlanView(C.Structure):
         ("p_stage_ptr", C.c_void_p), ("p_task_ptr", C.c_void_p), ("p_task_cols", C.c_void_p)]
 
 
+class PhaseTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("n_count", C.c_int64), ("f_total_ms", C.c_double)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 # every symbol include/slampp_hip.h declares: (restype, argtypes)
@@ -77,6 +81,7 @@ ABI = {
     "slampp_hip_sync": (C.c_int, [_P]),
     "slampp_hip_stream": (_P, [_P]),
     "slampp_hip_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "slampp_hip_get_profile": (C.c_int, [_P, C.POINTER(PhaseTime), C.c_int, C.POINTER(C.c_int), C.c_int]),
     "slampp_hip_set_allreduce": (C.c_int, [_P, ALLREDUCE_FN, _P]),
     "slampp_hip_get_plan": (C.c_int, [_P, C.POINTER(PlanView)]),
     "slampp_hip_plan_create": (C.c_int, [C.POINTER(_P), C.c_int64, _P, _P, _P, C.c_int, C.c_int]),
@@ -258,6 +263,16 @@ class _SolverBase:
         st = Stats()
         self._check(self._lib.slampp_hip_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    def set_option(self, name: str, value: int) -> None:
+        self._check(self._lib.slampp_hip_set_option(self._h, name.encode(), int(value)))
+
+    def profile(self, reset: bool = False) -> dict:
+        """{phase: (count, total_ms)} measured with HIP events on the solver's stream (option profile=1)."""
+        buf = (PhaseTime * 32)()
+        n = C.c_int(0)
+        self._check(self._lib.slampp_hip_get_profile(self._h, buf, 32, C.byref(n), int(reset)))
+        return {buf[i].name.decode(): (int(buf[i].n_count), float(buf[i].f_total_ms)) for i in range(min(n.value, 32))}
 
     def plan(self) -> dict:
         def getter(v):
