@@ -1,10 +1,547 @@
-// schur.hip -- placeholder, replaced below
+// schur.hip -- the BA path: Schur complement of the landmark block, dense reduced camera system,
+// back-substitution.  Restates CLinearSolver_Schur::Solve_PosDef_Blocky, steps 2-13
+// (/root/reference/include/slam/LinearSolver_Schur.h:1699-1886) for gfx950:
+//
+//   Lambda = | A U |    S  = A - U C^-1 U^T           (reference: SliceTo / InverseOf_BlockDiag /
+//            | V C |    r  = x - U C^-1 l              two MultiplyToWith_FBS / AddTo_FBS / PreMultiply_Add)
+//                       dx = S^-1 r                   (reference: Eigen LLT on the densified S)
+//                       dl = C^-1 (l - U^T dx)        (reference: PostMultiply_Add + PreMultiply_Add)
+//
+// Landmarks are independent units (C is block diagonal), so every kernel but the dense factor is a
+// stream over the observations: HBM-bound integer/fp64 work, no MFMA.
+//   schur_point_inverse : C_p^-1, one thread per point                        (72 B in, 72 B out)
+//   schur_obs_W         : W_o = U_o C_p^-1, one thread per observation         (144 B in, 144 B out)
+//   schur_gather_S      : one wave per nonzero block of S sums its contributions U_b W_a^T from a
+//                         precomputed list -- no atomics, bit-reproducible      (288 B per contribution)
+//   schur_rhs           : r_c = x_c - sum W_o l_p, one wave per camera
+//   dense_cholesky / dense_backsolve (dense_chol.hip)
+//   schur_obs_t, schur_point_backsubst : dl
+// Multi-GPU (landmark shards): the all-reduce callback sums [S | r] over the ranks right before the
+// dense factorization; only the primary shard adds A and x.
 #include "solver.h"
+#include "dense_chol.h"
+
+#include <algorithm>
+#include <cstring>
+
 namespace slampp {
-struct CSchurState {};
+
+struct CSchurState {
+	int DC, DP;
+	int64_t nc, np, n_obs, n_ablocks, n_sblocks, n_entries;
+	int N, Npad;
+	CDevArray<int64_t> d_ptr;       // [n+1] block column pointers of Lambda
+	CDevArray<int32_t> d_brow;      // [n_blocks]
+	CDevArray<int32_t> d_obs_pt;    // [n_obs]
+	CDevArray<int64_t> d_sb_ptr;    // [n_sblocks+1]
+	CDevArray<int32_t> d_sb_row, d_sb_col;
+	CDevArray<int32_t> d_ent_a;     // [n_entries] observation whose W is used
+	CDevArray<int64_t> d_ent_uoff;  // [n_entries] offset of the U block of the other observation in the values
+	CDevArray<int64_t> d_cam_ptr;   // [nc+1]
+	CDevArray<int32_t> d_cam_obs;   // [n_obs] observations of every camera, ascending
+	CDevArray<double> d_S, d_W, d_Cinv, d_t, d_invdiag, d_z, d_x;
+};
+
 void schur_destroy(CSchurState *p) { delete p; }
-CSchurState *schur_analyze(slampp_hip_solver &) { throw std::domain_error("Schur path not built yet"); }
-void schur_enqueue(slampp_hip_solver &, const double *, double *) { throw std::domain_error("Schur path not built yet"); }
-size_t schur_device_bytes(const CSchurState *) { return 0; }
-void schur_fill_stats(const CSchurState *, slampp_hip_stats &) {}
+
+size_t schur_device_bytes(const CSchurState *p)
+{
+	return p->d_ptr.n_Bytes() + p->d_brow.n_Bytes() + p->d_obs_pt.n_Bytes() + p->d_sb_ptr.n_Bytes() +
+		p->d_sb_row.n_Bytes() + p->d_sb_col.n_Bytes() + p->d_ent_a.n_Bytes() + p->d_ent_uoff.n_Bytes() +
+		p->d_cam_ptr.n_Bytes() + p->d_cam_obs.n_Bytes() + p->d_S.n_Bytes() + p->d_W.n_Bytes() +
+		p->d_Cinv.n_Bytes() + p->d_t.n_Bytes() + p->d_invdiag.n_Bytes() + p->d_z.n_Bytes() + p->d_x.n_Bytes();
 }
+
+void schur_fill_stats(const CSchurState *p, slampp_hip_stats &st)
+{
+	st.n_cams = p->nc;
+	st.n_points = p->np;
+	st.n_observations = p->n_obs;
+	st.schur_dim = p->N;
+	st.n_update_pairs = p->n_entries;
+	st.l_blocks = p->n_sblocks;
+	const double n = double(p->N);
+	st.factor_flops = n * n * n / 3.0 + n * (n - 1) / 2.0 + n; // dense Cholesky (slam_schur_orderings/Main.cpp:682)
+	st.solve_flops = 2.0 * n * n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host analysis
+// ---------------------------------------------------------------------------------------------
+
+CSchurState *schur_analyze(slampp_hip_solver &s)
+{
+	const int64_t n = int64_t(s.cumsum.size()) - 1, nc = s.n_matrix_cut, np = n - nc;
+	const int64_t *cs = s.cumsum.data(), *ptr = s.bcol_ptr.data();
+	const int32_t *brow = s.brow.data();
+	const int64_t DC = cs[1] - cs[0], DP = cs[nc + 1] - cs[nc];
+	for(int64_t c = 0; c < n; ++ c) {
+		if(cs[c + 1] - cs[c] != (c < nc? DC : DP))
+			throw std::domain_error("Schur path: cameras and landmarks must each have one block size");
+	}
+	if(!((DC == 6 && DP == 3) || (DC == 7 && DP == 3) || (DC == 3 && DP == 2)))
+		throw std::domain_error("Schur path: supported (camera, landmark) block sizes are (6,3), (7,3), (3,2)");
+	for(int64_t c = nc; c < n; ++ c) {
+		if(ptr[c + 1] == ptr[c] || brow[ptr[c + 1] - 1] != c)
+			throw std::invalid_argument("Schur path: a landmark has no diagonal block");
+		if(ptr[c + 1] - ptr[c] >= 2 && brow[ptr[c + 1] - 2] >= nc)
+			throw std::domain_error("Schur path: landmark-landmark blocks present, C is not block diagonal");
+	}
+	for(int64_t c = 0; c < nc; ++ c) {
+		if(ptr[c + 1] == ptr[c] || brow[ptr[c + 1] - 1] != c)
+			throw std::invalid_argument("Schur path: a camera has no diagonal block");
+	}
+	if(nc * DC + 64 > INT32_MAX / 2)
+		throw std::domain_error("Schur path: reduced system too large");
+
+	CSchurState *p = new CSchurState();
+	try {
+		CSchurState &S = *p;
+		S.DC = int(DC); S.DP = int(DP);
+		S.nc = nc; S.np = np;
+		S.n_ablocks = ptr[nc];
+		S.n_obs = ptr[n] - ptr[nc] - np;
+		S.N = int(nc * DC);
+		S.Npad = dense_padded_dim(S.N);
+		if(S.n_obs > INT32_MAX)
+			throw std::domain_error("Schur path: too many observations");
+
+		std::vector<int32_t> obs_pt(S.n_obs), obs_cam(S.n_obs);
+		std::vector<int64_t> cam_ptr(nc + 1, 0);
+		for(int64_t pt = 0; pt < np; ++ pt) {
+			const int64_t c = nc + pt, o0 = ptr[c] - ptr[nc] - pt;
+			for(int64_t k = ptr[c]; k < ptr[c + 1] - 1; ++ k) {
+				const int64_t o = o0 + (k - ptr[c]);
+				obs_pt[o] = int32_t(pt);
+				obs_cam[o] = brow[k];
+				++ cam_ptr[brow[k] + 1];
+			}
+		}
+		for(int64_t c = 0; c < nc; ++ c)
+			cam_ptr[c + 1] += cam_ptr[c];
+		std::vector<int32_t> cam_obs(S.n_obs);
+		{
+			std::vector<int64_t> fill(cam_ptr.begin(), cam_ptr.end() - 1);
+			for(int64_t o = 0; o < S.n_obs; ++ o)
+				cam_obs[fill[obs_cam[o]] ++] = int32_t(o);
+		}
+		// contributions to S grouped by block (row = camera of b, col = camera of a, a <= b within a point)
+		const int64_t ubase = S.n_ablocks * DC * DC;
+		std::vector<int64_t> sb_ptr;
+		std::vector<int32_t> sb_row, sb_col, ent_a;
+		std::vector<int64_t> ent_uoff;
+		{
+			int64_t n_entries = 0;
+			for(int64_t pt = 0; pt < np; ++ pt) {
+				const int64_t k = ptr[nc + pt + 1] - ptr[nc + pt] - 1;
+				n_entries += k * (k + 1) / 2;
+			}
+			S.n_entries = n_entries;
+			ent_a.resize(n_entries);
+			ent_uoff.resize(n_entries);
+			if(nc * nc <= (int64_t(1) << 26)) { // counting sort on the dense key space
+				std::vector<int64_t> cnt(nc * nc + 1, 0);
+				for(int64_t pt = 0; pt < np; ++ pt) {
+					const int64_t o0 = ptr[nc + pt] - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
+					for(int64_t a = o0; a < o1; ++ a)
+						for(int64_t b = a; b < o1; ++ b)
+							++ cnt[int64_t(obs_cam[a]) * nc + obs_cam[b] + 1];
+				}
+				for(int64_t key = 0; key < nc * nc; ++ key) {
+					if(cnt[key + 1]) {
+						sb_ptr.push_back(cnt[key]);
+						sb_col.push_back(int32_t(key / nc));
+						sb_row.push_back(int32_t(key % nc));
+					}
+					cnt[key + 1] += cnt[key];
+				}
+				sb_ptr.push_back(n_entries);
+				for(int64_t pt = 0; pt < np; ++ pt) {
+					const int64_t o0 = ptr[nc + pt] - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
+					for(int64_t a = o0; a < o1; ++ a)
+						for(int64_t b = a; b < o1; ++ b) {
+							const int64_t d = cnt[int64_t(obs_cam[a]) * nc + obs_cam[b]] ++;
+							ent_a[d] = int32_t(a);
+							ent_uoff[d] = ubase + b * DC * DP + pt * DP * DP;
+						}
+				}
+			} else { // comparison sort on (key, a, b)
+				struct TE { int64_t key; int32_t a, b; };
+				std::vector<TE> ents(n_entries);
+				int64_t e = 0;
+				for(int64_t pt = 0; pt < np; ++ pt) {
+					const int64_t o0 = ptr[nc + pt] - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
+					for(int64_t a = o0; a < o1; ++ a)
+						for(int64_t b = a; b < o1; ++ b) {
+							ents[e].key = int64_t(obs_cam[a]) * nc + obs_cam[b];
+							ents[e].a = int32_t(a);
+							ents[e].b = int32_t(b);
+							++ e;
+						}
+				}
+				std::sort(ents.begin(), ents.end(), [](const TE &x, const TE &y) {
+					return x.key < y.key || (x.key == y.key && x.a < y.a); });
+				for(e = 0; e < n_entries; ++ e) {
+					if(!e || ents[e].key != ents[e - 1].key) {
+						sb_ptr.push_back(e);
+						sb_col.push_back(int32_t(ents[e].key / nc));
+						sb_row.push_back(int32_t(ents[e].key % nc));
+					}
+					ent_a[e] = ents[e].a;
+					ent_uoff[e] = ubase + int64_t(ents[e].b) * DC * DP + int64_t(obs_pt[ents[e].b]) * DP * DP;
+				}
+				sb_ptr.push_back(n_entries);
+			}
+		}
+		S.n_sblocks = int64_t(sb_row.size());
+
+		hipStream_t st = s.stream;
+		S.d_ptr.Upload(s.bcol_ptr, st);
+		S.d_brow.Upload(s.brow, st);
+		S.d_obs_pt.Upload(obs_pt, st);
+		S.d_sb_ptr.Upload(sb_ptr, st);
+		S.d_sb_row.Upload(sb_row, st);
+		S.d_sb_col.Upload(sb_col, st);
+		S.d_ent_a.Upload(ent_a, st);
+		S.d_ent_uoff.Upload(ent_uoff, st);
+		S.d_cam_ptr.Upload(cam_ptr, st);
+		S.d_cam_obs.Upload(cam_obs, st);
+		S.d_S.Alloc(size_t(S.Npad) * S.Npad);
+		S.d_W.Alloc(size_t(S.n_obs) * DC * DP);
+		S.d_Cinv.Alloc(size_t(np) * DP * DP);
+		S.d_t.Alloc(size_t(S.n_obs) * DP);
+		S.d_invdiag.Alloc(size_t(S.Npad / dense_NB) * dense_NB * dense_NB);
+		S.d_z.Alloc(S.Npad);
+		S.d_x.Alloc(S.Npad);
+		s.d_flag.Alloc(1);
+		SLAMPP_HIP_CHECK(hipStreamSynchronize(st));
+	} catch(...) {
+		delete p;
+		throw;
+	}
+	return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+
+// S(lower) := A^T blocks, r := eta_x   (primary shard only; S was zeroed before)
+template <int DC>
+__global__ void schur_scatter_A_kernel(const int64_t *ptr, const int32_t *brow, int64_t nc,
+	const double *__restrict__ A, const double *__restrict__ eta, double *S, int ld, int n)
+{
+	const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	const int64_t n_elems = ptr[nc] * DC * DC;
+	if(gid < n_elems) {
+		const int64_t k = gid / (DC * DC);
+		const int e = int(gid - k * (DC * DC)), rr = e % DC, q = e / DC; // element (rr, q) of block k = Lambda(r, c), r <= c
+		// column of block k: binary search in ptr[0..nc]
+		int64_t lo = 0, hi = nc;
+		while(hi - lo > 1) {
+			const int64_t mid = (lo + hi) >> 1;
+			if(ptr[mid] <= k) lo = mid; else hi = mid;
+		}
+		const int64_t c = lo, r = brow[k];
+		S[size_t(c * DC + q) + size_t(r * DC + rr) * ld] = A[gid]; // lower block (c, r) = block^T
+	}
+	if(gid < n)
+		S[size_t(ld - 1) + size_t(gid) * ld] = eta[gid];
+}
+
+// small SPD inverse through its Cholesky factor; returns false on a non-positive pivot
+template <int D>
+__device__ __forceinline__ bool spd_inverse(const double *a /* column-major, upper triangle read */, double *inv)
+{
+	double L[D][D], X[D][D];
+	bool ok = true;
+	#pragma unroll
+	for(int j = 0; j < D; ++ j) {
+		double s = a[j + j * D];
+		#pragma unroll
+		for(int k = 0; k < D; ++ k)
+			if(k < j) s -= L[j][k] * L[j][k];
+		if(!(s > 0)) { ok = false; s = 1; }
+		const double d = sqrt(s);
+		L[j][j] = d;
+		#pragma unroll
+		for(int i = 0; i < D; ++ i) {
+			if(i > j) {
+				double t = a[j + i * D]; // element (j, i) of the upper triangle = (i, j)
+				#pragma unroll
+				for(int k = 0; k < D; ++ k)
+					if(k < j) t -= L[i][k] * L[j][k];
+				L[i][j] = t / d;
+			}
+		}
+	}
+	// X = L^-1 (lower)
+	#pragma unroll
+	for(int c = 0; c < D; ++ c) {
+		#pragma unroll
+		for(int r = 0; r < D; ++ r) {
+			if(r < c) X[r][c] = 0;
+			else if(r == c) X[r][c] = 1.0 / L[r][r];
+			else {
+				double t = 0;
+				#pragma unroll
+				for(int k = 0; k < D; ++ k)
+					if(k >= c && k < r) t += L[r][k] * X[k][c];
+				X[r][c] = -t / L[r][r];
+			}
+		}
+	}
+	// inv = X^T X
+	#pragma unroll
+	for(int c = 0; c < D; ++ c)
+		#pragma unroll
+		for(int r = 0; r < D; ++ r) {
+			double t = 0;
+			#pragma unroll
+			for(int k = 0; k < D; ++ k)
+				if(k >= r && k >= c) t += X[k][r] * X[k][c];
+			inv[r + c * D] = t;
+		}
+	return ok;
+}
+
+template <int DC, int DP>
+__global__ void schur_point_inverse_kernel(const int64_t *ptr, int64_t nc, int64_t np, int64_t ubase,
+	const double *__restrict__ A, double *Cinv, int *p_flag)
+{
+	const int64_t pt = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(pt >= np)
+		return;
+	const int64_t o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
+	const double *C = A + ubase + o1 * (DC * DP) + pt * (DP * DP);
+	double c[DP * DP], inv[DP * DP];
+	#pragma unroll
+	for(int i = 0; i < DP * DP; ++ i)
+		c[i] = C[i];
+	if(!spd_inverse<DP>(c, inv))
+		atomicOr(p_flag, 1);
+	#pragma unroll
+	for(int i = 0; i < DP * DP; ++ i)
+		Cinv[pt * (DP * DP) + i] = inv[i];
+}
+
+template <int DC, int DP>
+__global__ void schur_obs_W_kernel(int64_t n_obs, int64_t ubase, const int32_t *obs_pt,
+	const double *__restrict__ A, const double *__restrict__ Cinv, double *W)
+{
+	const int64_t o = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(o >= n_obs)
+		return;
+	const int64_t pt = obs_pt[o];
+	const double *U = A + ubase + o * (DC * DP) + pt * (DP * DP);
+	double u[DC * DP], ci[DP * DP];
+	#pragma unroll
+	for(int i = 0; i < DC * DP; ++ i)
+		u[i] = U[i];
+	#pragma unroll
+	for(int i = 0; i < DP * DP; ++ i)
+		ci[i] = Cinv[pt * (DP * DP) + i];
+	#pragma unroll
+	for(int q = 0; q < DP; ++ q)
+		#pragma unroll
+		for(int r = 0; r < DC; ++ r) {
+			double t = 0;
+			#pragma unroll
+			for(int k = 0; k < DP; ++ k)
+				t += u[r + k * DC] * ci[k + q * DP];
+			W[o * (DC * DP) + r + q * DC] = t;
+		}
+}
+
+// one wave per nonzero block of S: S(row, col) -= sum_e U_b W_a^T
+template <int DC, int DP>
+__global__ void __launch_bounds__(64)
+schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *sb_row, const int32_t *sb_col,
+	const int32_t *ent_a, const int64_t *ent_uoff, const double *__restrict__ A, const double *__restrict__ W,
+	double *S, int ld)
+{
+	const int64_t sb = blockIdx.x;
+	const int lane = threadIdx.x;
+	const bool b_act = lane < DC * DC;
+	const int r = b_act? lane % DC : 0, q = b_act? lane / DC : 0;
+	double acc = 0;
+	const int64_t e1 = sb_ptr[sb + 1];
+	#pragma unroll 4
+	for(int64_t e = sb_ptr[sb]; e < e1; ++ e) {
+		const double *Wa = W + int64_t(ent_a[e]) * (DC * DP) + q;
+		const double *Ub = A + ent_uoff[e] + r;
+		#pragma unroll
+		for(int t = 0; t < DP; ++ t)
+			acc += Ub[t * DC] * Wa[t * DC];
+	}
+	if(b_act) {
+		const size_t idx = size_t(int64_t(sb_row[sb]) * DC + r) + size_t(int64_t(sb_col[sb]) * DC + q) * ld;
+		S[idx] -= acc;
+	}
+}
+
+// one wave per camera: r_c -= sum over its observations of W_o l_p
+template <int DC, int DP>
+__global__ void __launch_bounds__(64)
+schur_rhs_kernel(const int64_t *cam_ptr, const int32_t *cam_obs, const int32_t *obs_pt, int n,
+	const double *__restrict__ W, const double *__restrict__ eta, double *S, int ld)
+{
+	const int64_t c = blockIdx.x;
+	const int lane = threadIdx.x;
+	double acc[DC];
+	#pragma unroll
+	for(int i = 0; i < DC; ++ i)
+		acc[i] = 0;
+	const int64_t e1 = cam_ptr[c + 1];
+	for(int64_t e = cam_ptr[c] + lane; e < e1; e += 64) {
+		const int64_t o = cam_obs[e];
+		const double *Wo = W + o * (DC * DP), *l = eta + n + int64_t(obs_pt[o]) * DP;
+		#pragma unroll
+		for(int t = 0; t < DP; ++ t) {
+			const double lt = l[t];
+			#pragma unroll
+			for(int i = 0; i < DC; ++ i)
+				acc[i] += Wo[i + t * DC] * lt;
+		}
+	}
+	#pragma unroll
+	for(int i = 0; i < DC; ++ i) {
+		#pragma unroll
+		for(int m = 32; m >= 1; m >>= 1)
+			acc[i] += __shfl_xor(acc[i], m);
+	}
+	if(lane == 0) {
+		#pragma unroll
+		for(int i = 0; i < DC; ++ i)
+			S[size_t(ld - 1) + size_t(c * DC + i) * ld] -= acc[i];
+	}
+}
+
+template <int DC, int DP>
+__global__ void schur_obs_t_kernel(int64_t n_obs, int64_t ubase, int64_t nc, const int64_t *ptr, const int32_t *brow,
+	const int32_t *obs_pt, const double *__restrict__ A, const double *__restrict__ dx, double *T)
+{
+	const int64_t o = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(o >= n_obs)
+		return;
+	const int64_t pt = obs_pt[o];
+	const int64_t cam = brow[ptr[nc] + o + pt]; // block index of observation o = ptr[nc] + o + (number of C blocks before it)
+	const double *U = A + ubase + o * (DC * DP) + pt * (DP * DP);
+	double x[DC];
+	#pragma unroll
+	for(int i = 0; i < DC; ++ i)
+		x[i] = dx[cam * DC + i];
+	#pragma unroll
+	for(int t = 0; t < DP; ++ t) {
+		double s = 0;
+		#pragma unroll
+		for(int i = 0; i < DC; ++ i)
+			s += U[i + t * DC] * x[i];
+		T[o * DP + t] = s;
+	}
+}
+
+template <int DC, int DP>
+__global__ void schur_point_backsubst_kernel(const int64_t *ptr, int64_t nc, int64_t np, int n,
+	const double *__restrict__ Cinv, const double *__restrict__ T, const double *__restrict__ dx, double *out)
+{
+	const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(gid < np) {
+		const int64_t pt = gid;
+		const int64_t o0 = ptr[nc + pt] - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
+		double v[DP];
+		#pragma unroll
+		for(int t = 0; t < DP; ++ t)
+			v[t] = out[n + pt * DP + t];
+		for(int64_t o = o0; o < o1; ++ o) {
+			#pragma unroll
+			for(int t = 0; t < DP; ++ t)
+				v[t] -= T[o * DP + t];
+		}
+		#pragma unroll
+		for(int r = 0; r < DP; ++ r) {
+			double s = 0;
+			#pragma unroll
+			for(int t = 0; t < DP; ++ t)
+				s += Cinv[pt * (DP * DP) + r + t * DP] * v[t];
+			out[n + pt * DP + r] = s;
+		}
+	}
+	if(gid < n)
+		out[gid] = dx[gid];
+}
+
+template <int DC, int DP>
+static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *A, double *rhs)
+{
+	hipStream_t st = s.stream;
+	const int ld = S.Npad, n = S.N;
+	const int64_t ubase = S.n_ablocks * DC * DC;
+	SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), st));
+
+	s.Phase_Begin("schur_init");
+	SLAMPP_HIP_CHECK(hipMemsetAsync(S.d_S.p(), 0, size_t(ld) * ld * sizeof(double), st));
+	dense_prepare_padding(S.d_S.p(), ld, n, st);
+	if(s.b_shard_primary) {
+		const int64_t n_work = std::max<int64_t>(S.n_ablocks * DC * DC, n);
+		hipLaunchKernelGGL((schur_scatter_A_kernel<DC>), dim3(unsigned((n_work + 255) / 256)), dim3(256), 0, st,
+			S.d_ptr.p(), S.d_brow.p(), S.nc, A, rhs, S.d_S.p(), ld, n);
+	}
+	s.Phase_End();
+
+	s.Phase_Begin("schur_points");
+	hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((S.np + 255) / 256)), dim3(256), 0, st,
+		S.d_ptr.p(), S.nc, S.np, ubase, A, S.d_Cinv.p(), s.d_flag.p());
+	hipLaunchKernelGGL((schur_obs_W_kernel<DC, DP>), dim3(unsigned((S.n_obs + 255) / 256)), dim3(256), 0, st,
+		S.n_obs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p());
+	s.Phase_End();
+
+	s.Phase_Begin("schur_gather");
+	if(S.n_sblocks > 0)
+		hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP>), dim3(unsigned(S.n_sblocks)), dim3(64), 0, st,
+			S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
+			S.d_W.p(), S.d_S.p(), ld);
+	s.Phase_End();
+
+	s.Phase_Begin("schur_rhs");
+	hipLaunchKernelGGL((schur_rhs_kernel<DC, DP>), dim3(unsigned(S.nc)), dim3(64), 0, st,
+		S.d_cam_ptr.p(), S.d_cam_obs.p(), S.d_obs_pt.p(), n, S.d_W.p(), rhs, S.d_S.p(), ld);
+	s.Phase_End();
+
+	if(s.p_allreduce) {
+		s.Phase_Begin("allreduce");
+		// only the lower triangle and the rhs row carry data; the callback sums the whole buffer
+		if(s.p_allreduce(s.p_allreduce_context, S.d_S.p(), size_t(ld) * ld, (void*)st) != 0)
+			throw CDeviceError("all-reduce callback failed");
+		s.Phase_End();
+	}
+
+	s.Phase_Begin("dense_chol");
+	dense_cholesky(S.d_S.p(), ld, n, S.d_invdiag.p(), s.d_flag.p(), st);
+	s.Phase_End();
+	s.Phase_Begin("dense_solve");
+	dense_backsolve(S.d_S.p(), ld, n, S.d_invdiag.p(), S.d_z.p(), S.d_x.p(), st);
+	s.Phase_End();
+
+	s.Phase_Begin("backsubst");
+	hipLaunchKernelGGL((schur_obs_t_kernel<DC, DP>), dim3(unsigned((S.n_obs + 255) / 256)), dim3(256), 0, st,
+		S.n_obs, ubase, S.nc, S.d_ptr.p(), S.d_brow.p(), S.d_obs_pt.p(), A, S.d_x.p(), S.d_t.p());
+	const int64_t n_work = std::max<int64_t>(S.np, n);
+	hipLaunchKernelGGL((schur_point_backsubst_kernel<DC, DP>), dim3(unsigned((n_work + 255) / 256)), dim3(256), 0, st,
+		S.d_ptr.p(), S.nc, S.np, n, S.d_Cinv.p(), S.d_t.p(), S.d_x.p(), rhs);
+	s.Phase_End();
+	SLAMPP_HIP_CHECK(hipGetLastError());
+}
+
+void schur_enqueue(slampp_hip_solver &s, const double *p_values_dev, double *p_rhs_dev)
+{
+	CSchurState &S = *s.p_schur;
+	if(S.DC == 6 && S.DP == 3)
+		schur_enqueue_t<6, 3>(s, S, p_values_dev, p_rhs_dev);
+	else if(S.DC == 7 && S.DP == 3)
+		schur_enqueue_t<7, 3>(s, S, p_values_dev, p_rhs_dev);
+	else
+		schur_enqueue_t<3, 2>(s, S, p_values_dev, p_rhs_dev);
+}
+
+} // namespace slampp

@@ -1,0 +1,101 @@
+"""GPU parity tests of the BA path (Schur complement + dense reduced camera system) against the CPU
+oracle's restatement of CLinearSolver_Schur (oracle/slampp_oracle.c), through the C ABI.
+Tolerance: ||x_gpu - x_ref||_inf / ||x_ref||_inf < 1e-10 (BASELINE.json north_star, fp64)."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from slam_plus_plus_amd import synth
+from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP, CLinearSolver_Schur_HIP
+from oracle import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def rel_inf(x, ref):
+    return float(np.abs(x - ref).max() / np.abs(ref).max())
+
+
+CASES = {
+    "band_k4": lambda: synth.ba(50, 3000, k=4, mode="band"),
+    "uniform_dense_S": lambda: synth.ba(40, 5000, k=4, mode="uniform"),
+    "venice_ragged": lambda: synth.ba(60, 3000, mode="venice"),
+    "k1_single_obs": lambda: synth.ba(30, 500, k=1),
+    "sim3_7x7": lambda: synth.ba(25, 1500, k=3, cam_dim=7, pt_dim=3, seed=11),
+    "se2_3x2": lambda: synth.ba(30, 1000, k=3, cam_dim=3, pt_dim=2, seed=12),
+    "n63_fits_one_tile": lambda: synth.ba(9, 300, k=3, cam_dim=7, pt_dim=3, seed=13),   # N = 63: rhs row is row 63
+    "n126": lambda: synth.ba(21, 800, k=4),                                          # N = 126 -> padded to 128
+    "n192_tile_multiple": lambda: synth.ba(32, 1000, k=4),                            # N = 192 -> a whole extra tile
+    "two_cams": lambda: synth.ba(2, 50, k=2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_parity_with_oracle(name):
+    lam = CASES[name]()
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok
+    solver = CLinearSolver_Schur_HIP()
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta)
+    assert rel_inf(eta, x_ref) < TOL
+    n_x = int(lam.cumsum[lam.n_matrix_cut])
+    assert rel_inf(eta[:n_x], x_ref[:n_x]) < TOL      # dx (cameras)
+    assert rel_inf(eta[n_x:], x_ref[n_x:]) < TOL      # dl (landmarks)
+    eta2 = -0.5 * lam.rhs                               # warm: structure cached
+    assert solver.Solve_PosDef_Blocky(lam, eta2)
+    assert rel_inf(eta2, -0.5 * x_ref) < TOL
+
+
+def test_schur_and_sparse_paths_agree():
+    lam = synth.ba(40, 2000, mode="venice", seed=3)
+    a, b = lam.rhs.copy(), lam.rhs.copy()
+    assert CLinearSolver_Schur_HIP().Solve_PosDef(lam, a)
+    assert CLinearSolver_HIP().Solve_PosDef(lam, b)
+    assert rel_inf(a, b) < TOL
+
+
+def test_indefinite_landmark_block_returns_false():
+    lam = synth.ba(10, 100, k=3)
+    off = lam.block_value_offsets()
+    last = lam.n_blocks - 1                      # C block of the last point
+    vals = lam.values.copy()
+    vals[off[last]:off[last + 1]] -= 50.0 * np.eye(3).ravel()
+    bad = dataclasses.replace(lam, values=vals)
+    assert O.solve_schur(bad)[0] is False
+    eta = bad.rhs.copy()
+    assert CLinearSolver_Schur_HIP().Solve_PosDef(bad, eta) is False
+
+
+def test_indefinite_reduced_system_returns_false():
+    lam = synth.ba(10, 100, k=3)
+    off = lam.block_value_offsets()
+    vals = lam.values.copy()
+    vals[off[4]:off[5]] -= 1e4 * np.eye(6).ravel()   # camera 4's diagonal block
+    bad = dataclasses.replace(lam, values=vals)
+    assert O.solve_schur(bad)[0] is False
+    eta = bad.rhs.copy()
+    assert CLinearSolver_Schur_HIP().Solve_PosDef(bad, eta) is False
+
+
+def test_unsupported_structure_raises():
+    lam = synth.pose_chain(n=50, d=6)                 # no landmark part at all
+    solver = CLinearSolver_Schur_HIP()
+    with pytest.raises((NotImplementedError, ValueError)):
+        solver.Solve_PosDef(lam, lam.rhs.copy())
+
+
+def test_full_size_c4_residual_and_linearity():
+    """BASELINE config C4 (1k cams x 500k points): size-independent checks -- the residual of the
+    full system and linearity in eta."""
+    lam = synth.ba(1000, 500_000, k=4, mode="band")
+    A = lam.to_scipy()
+    solver = CLinearSolver_Schur_HIP()
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta)
+    assert np.abs(A @ eta - lam.rhs).max() / np.abs(lam.rhs).max() < 1e-9
+    eta2 = 4.0 * lam.rhs
+    assert solver.Solve_PosDef_Blocky(lam, eta2)
+    assert rel_inf(eta2, 4.0 * eta) < TOL
