@@ -213,12 +213,14 @@ def manhattan(n: int = 3500, d: int = 3, world: int = 30, sigma: float = 0.02,
 # --------------------------------------------------------------------------------------
 
 def ba(n_cams: int = 1000, n_pts: int = 500_000, k: int = 4, mode: str = "band",
-       damping: float = 0.1, seed: int = 777, cam_dim: int = 6, pt_dim: int = 3) -> BlockSystem:
+       damping: float = 0.1, seed: int = 777, cam_dim: int = 6, pt_dim: int = 3,
+       cam_damping: float | None = None) -> BlockSystem:
     """C4/C5 look-alike.  Every point is seen by ``k`` cameras (``mode='venice'``: k drawn from a
     clipped geometric distribution, mean about 5.3).  Cameras of a point: ``band`` = c0 + 7j mod nc
     (sparse S), ``uniform`` = k distinct random cameras (dense S).  Per observation
     Jc in R^{2x6}, Jp in R^{2x3} ~ N(0,1):  A_cc += Jc^T Jc, C_pp += Jp^T Jp, U_cp = Jc^T Jp;
-    ``damping``*I on every diagonal block."""
+    ``damping``*I on every diagonal block.  ``cam_damping`` overrides the
+    damping of the camera blocks (landmark shards of one system each carry 1/world of it)."""
     rng = np.random.default_rng(seed)
     if mode == "venice":
         kk = np.clip(rng.geometric(0.19, size=n_pts) + 1, 2, min(30, n_cams))
@@ -253,7 +255,7 @@ def ba(n_cams: int = 1000, n_pts: int = 500_000, k: int = 4, mode: str = "band",
     Cpp = np.zeros((n_pts, pd_, pd_))
     np.add.at(Cpp, pt_of, np.einsum("oki,okj->oij", Jp, Jp))
     Ucp = np.einsum("oki,okj->oij", Jc, Jp)                 # [n_obs, 6, 3]
-    Acc += damping * np.eye(cd)[None]
+    Acc += (damping if cam_damping is None else cam_damping) * np.eye(cd)[None]
     Cpp += damping * np.eye(pd_)[None]
     # block-CSC layout
     order = np.lexsort((cam_of, pt_of))
