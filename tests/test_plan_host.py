@@ -1,0 +1,82 @@
+"""Host logic of the product without a GPU: nested-dissection ordering, block symbolic factorization,
+update lists and the stage schedule (libslampp_hip.so, slampp_hip_plan_*), replayed on the CPU by
+oracle_exec_plan -- which performs the same left-looking arithmetic as the HIP kernels and checks
+that every operand was produced in an earlier stage or earlier in the same task."""
+import numpy as np
+import pytest
+
+from oracle import oracle_lib as O
+from slam_plus_plus_amd import synth
+from slam_plus_plus_amd.hip_solver import host_plan
+from golden_util import golden_names, load_golden, rel_inf
+
+TOL = 1e-10
+
+
+def check_plan_invariants(lam, plan):
+    n = lam.n_bcols
+    perm = plan["perm"]
+    assert sorted(perm.tolist()) == list(range(n))
+    lptr, lrow = plan["lptr"], plan["lrow"]
+    for j in range(n):
+        rows = lrow[lptr[j]:lptr[j + 1]]
+        assert rows[0] == j and np.all(np.diff(rows) > 0)         # diagonal first, sorted, lower triangular
+    assert sorted(plan["task_cols"].tolist()) == list(range(n))   # every column scheduled exactly once
+    assert np.all(np.diff(plan["stage_ptr"]) > 0)
+    dims = np.diff(lam.cumsum)[perm]
+    assert np.array_equal(plan["dim"], dims)
+    # every source block of Lambda lands in exactly one factor block
+    assert np.count_nonzero(plan["asrc"] >= 0) == lam.n_blocks
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if not n.startswith("indefinite")])
+@pytest.mark.parametrize("leaf,sub", [(0, 0), (1, 1), (3, 7), (1000, 1000)])
+def test_plan_replay_matches_reference(name, leaf, sub):
+    lam, ref = load_golden(name)
+    plan, stats = host_plan(lam, leaf, sub)
+    check_plan_invariants(lam, plan)
+    status, x = O.exec_plan(lam, plan)
+    assert status == 0
+    assert rel_inf(x, ref["x_cholmod_super"]) < TOL
+    assert stats["l_blocks"] == plan["l_blocks"] and stats["n_stages"] == plan["n_stages"]
+
+
+def test_plan_replay_detects_indefinite():
+    lam, _ = load_golden("indefinite_n40")
+    plan, _ = host_plan(lam)
+    status, _ = O.exec_plan(lam, plan)
+    assert status == 1
+
+
+@pytest.mark.parametrize("make", [
+    lambda: synth.pose_chain(n=5000, d=6, seed=21),
+    lambda: synth.sphere(40, 40, seed=22),
+    lambda: synth.manhattan(2000, seed=23),
+    lambda: synth.ba(30, 3000, mode="venice", seed=24),     # mixed block sizes, many single-vertex components
+], ids=["chain5000", "sphere1600", "manhattan2000", "ba_mixed"])
+def test_plan_replay_matches_oracle_medium(make):
+    lam = make()
+    ok, x_ref, _ = O.solve_sparse(lam)
+    plan, stats = host_plan(lam)
+    check_plan_invariants(lam, plan)
+    status, x = O.exec_plan(lam, plan)
+    assert ok and status == 0 and rel_inf(x, x_ref) < TOL
+
+
+def test_nested_dissection_exposes_parallelism_on_a_chain():
+    """The point of the ordering: a 20k-pose chain must not become a 20k-deep elimination path
+    (AMD's tree for a chain is essentially a path, SURVEY.md section 7 'hard parts')."""
+    lam = synth.pose_chain(n=20000, d=6, seed=31)
+    _, stats = host_plan(lam)
+    assert stats["etree_height"] < 100
+    assert stats["n_stages"] < 40
+    # fill stays close to what a banded/AMD ordering gives (about 2 blocks per column + loop closures)
+    assert stats["l_blocks"] < 4.0 * lam.n_bcols
+
+
+def test_structure_errors_are_reported():
+    lam = synth.pose_chain(n=10, d=6)
+    import dataclasses
+    bad = dataclasses.replace(lam, brow_idx=lam.brow_idx[::-1].copy())   # rows not sorted / not upper
+    with pytest.raises(ValueError):
+        host_plan(bad)
