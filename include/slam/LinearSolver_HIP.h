@@ -1,0 +1,416 @@
+/*
+ * LinearSolver_HIP.h -- the binding a SLAM++ maintainer adds: linear solver classes with exactly
+ * the member functions SLAM++'s nonlinear solvers expect from their CLinearSolver template
+ * argument, forwarding to the C ABI of libslampp_hip.so (include/slampp_hip.h).
+ *
+ *   CLinearSolver_HIP            stands where CLinearSolver_CholMod / _CSparse / _UberBlock do
+ *                                (/root/reference/include/slam/LinearSolver_CholMod.h:78-300,
+ *                                 LinearSolver_UberBlock.h:41-461)
+ *   CLinearSolver_Schur_HIP<..>  stands where CLinearSolver_Schur<CBaseSolver, CAMatrixBlockSizes,
+ *                                CSystem> does (LinearSolver_Schur.h:1423-2392)
+ *
+ * Contract (LinearSolverTags.h:38-135): typedef _Tag; default ctor; copy ctor / operator = that copy
+ * the configuration but no state (the nonlinear solver stores its solver by value,
+ * NonlinearSolver_Base.h:344-346,400,438); Free_Memory(); Solve_PosDef(lambda, eta) with eta
+ * overwritten by the solution; for the blockwise tag also Clear_SymbolicDecomposition(),
+ * SymbolicDecomposition_Blocky(lambda), Solve_PosDef_Blocky(lambda, eta).
+ * Errors: false = not positive definite; std::bad_alloc on host/device OOM (CLinearSolver_Schur
+ * catches it to fall back to a sparse solver, LinearSolver_Schur.h:1844-1853); std::runtime_error
+ * for device errors (precedent LinearSolver_Schur.h:1196-1209).  Never exits.
+ *
+ * Lambda is read through public const accessors only (BlockMatrix.h:343-485): the block structure
+ * is handed over once per structure change, the block values are gathered (OpenMP) into a packed
+ * staging array on every call -- CUberBlockMatrix keeps its blocks in pooled pages behind
+ * per-block pointers (BlockMatrixBase.h:321,374,449-453), so there is nothing contiguous to pass.
+ *
+ * Usage, as with any other solver (cf. src/slam_simple_example/Main.cpp:63-67):
+ *     typedef CLinearSolver_HIP CLinearSolverType;
+ *     CNonlinearSolver_Lambda<CSystemType, CLinearSolverType> solver(system);
+ */
+#pragma once
+#ifndef __LINEAR_SOLVER_HIP_INCLUDED
+#define __LINEAR_SOLVER_HIP_INCLUDED
+
+#include <stdint.h>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "slam/LinearSolverTags.h"
+#include "slam/BlockMatrix.h"
+#include "slampp_hip.h"
+
+/**
+ *	@brief shared plumbing of the two solver classes: handle life cycle, structure + value hand-over
+ */
+class CLinearSolver_HIP_Base {
+protected:
+	slampp_hip_solver *m_p_solver; /**< @brief C ABI handle (owned; never copied) */
+	int m_n_device; /**< @brief HIP device ordinal (configuration, copied) */
+	bool m_b_structure_valid; /**< @brief ordering / symbolic analysis matches the last structure */
+	std::vector<int64_t> m_cumsum, m_bcol_ptr; /**< @brief structure handed to the library */
+	std::vector<int32_t> m_brow;
+	std::vector<size_t> m_order; /**< @brief new block column -> old (empty = identity) */
+	struct TGatherEntry { uint32_t n_col, n_blk; int64_t n_dest; int32_t n_rows, n_cols; bool b_transpose; };
+	std::vector<TGatherEntry> m_gather; /**< @brief where every block of lambda goes in the packed values */
+	std::vector<double> m_values, m_rhs; /**< @brief staging */
+	slampp_hip_times m_t_times;
+
+	void Throw_On_Error(int n_result) const // throw(std::bad_alloc, std::runtime_error)
+	{
+		if(n_result == SLAMPP_HIP_ERR_ALLOC)
+			throw std::bad_alloc();
+		if(n_result < 0) {
+			throw std::runtime_error(std::string("CLinearSolver_HIP: ") +
+				(m_p_solver? slampp_hip_last_error(m_p_solver) : "no device / library handle"));
+		}
+	}
+
+	void Require_Handle() // throw(std::bad_alloc, std::runtime_error)
+	{
+		if(!m_p_solver)
+			Throw_On_Error(slampp_hip_create(&m_p_solver, m_n_device));
+	}
+
+	/**
+	 *	@brief hands the block structure of lambda (optionally symmetrically permuted by
+	 *		p_order: new -> old, keeping the upper triangle) to the library and analyzes it
+	 */
+	bool Analyze(const CUberBlockMatrix &r_lambda, int n_mode, size_t n_matrix_cut,
+		const std::vector<size_t> *p_order) // throw(std::bad_alloc, std::runtime_error)
+	{
+		_ASSERTE(r_lambda.b_SymmetricLayout());
+		Require_Handle();
+		const size_t n = r_lambda.n_BlockColumn_Num();
+		std::vector<size_t> inv_order(n);
+		if(p_order) {
+			m_order = *p_order;
+			for(size_t i = 0; i < n; ++ i)
+				inv_order[m_order[i]] = i;
+		} else {
+			m_order.clear();
+			for(size_t i = 0; i < n; ++ i)
+				inv_order[i] = i;
+		}
+		m_cumsum.resize(n + 1);
+		m_cumsum[0] = 0;
+		for(size_t i = 0; i < n; ++ i)
+			m_cumsum[i + 1] = m_cumsum[i] + int64_t(r_lambda.n_BlockColumn_Column_Num(p_order? m_order[i] : i));
+		// count the blocks of every destination column (upper triangle of the permuted matrix)
+		m_bcol_ptr.assign(n + 1, 0);
+		size_t n_block_num = 0;
+		for(size_t c = 0; c < n; ++ c) {
+			for(size_t j = 0, m = r_lambda.n_BlockColumn_Block_Num(c); j < m; ++ j) {
+				const size_t r = r_lambda.n_Block_Row(c, j);
+				if(r > c)
+					continue; // only the upper triangle is used, as in the reference's solvers
+				++ m_bcol_ptr[std::max(inv_order[r], inv_order[c]) + 1];
+				++ n_block_num;
+			}
+		}
+		for(size_t i = 0; i < n; ++ i)
+			m_bcol_ptr[i + 1] += m_bcol_ptr[i];
+		m_brow.resize(n_block_num);
+		m_gather.resize(n_block_num);
+		{
+			// place, then sort the rows of every destination column
+			std::vector<int64_t> fill(m_bcol_ptr.begin(), m_bcol_ptr.end() - 1);
+			std::vector<std::pair<int32_t, TGatherEntry> > placed(n_block_num);
+			for(size_t c = 0; c < n; ++ c) {
+				for(size_t j = 0, m = r_lambda.n_BlockColumn_Block_Num(c); j < m; ++ j) {
+					const size_t r = r_lambda.n_Block_Row(c, j);
+					if(r > c)
+						continue;
+					const size_t nr = inv_order[r], nc = inv_order[c];
+					TGatherEntry t;
+					t.n_col = uint32_t(c);
+					t.n_blk = uint32_t(j);
+					t.n_rows = int32_t(r_lambda.n_BlockColumn_Column_Num(r)); // symmetric layout
+					t.n_cols = int32_t(r_lambda.n_BlockColumn_Column_Num(c));
+					t.b_transpose = nr > nc; // lands below the diagonal: store its transpose above
+					t.n_dest = 0;
+					const size_t n_dest_col = std::max(nr, nc), n_dest_row = std::min(nr, nc);
+					placed[fill[n_dest_col] ++] = std::make_pair(int32_t(n_dest_row), t);
+				}
+			}
+			int64_t n_value_num = 0;
+			for(size_t c = 0; c < n; ++ c) {
+				std::sort(placed.begin() + m_bcol_ptr[c], placed.begin() + m_bcol_ptr[c + 1],
+					[](const std::pair<int32_t, TGatherEntry> &a, const std::pair<int32_t, TGatherEntry> &b) {
+						return a.first < b.first; });
+				for(int64_t k = m_bcol_ptr[c]; k < m_bcol_ptr[c + 1]; ++ k) {
+					m_brow[k] = placed[k].first;
+					m_gather[k] = placed[k].second;
+					m_gather[k].n_dest = n_value_num;
+					n_value_num += int64_t(m_gather[k].n_rows) * m_gather[k].n_cols;
+				}
+			}
+			m_values.resize(size_t(n_value_num));
+		}
+		int n_result = slampp_hip_set_structure(m_p_solver, int64_t(n), &m_cumsum[0], &m_bcol_ptr[0],
+			m_brow.empty()? 0 : &m_brow[0]);
+		if(n_result == SLAMPP_HIP_OK)
+			n_result = slampp_hip_analyze(m_p_solver, n_mode, int64_t(n_matrix_cut));
+		Throw_On_Error(n_result);
+		m_b_structure_valid = true;
+		return true;
+	}
+
+	bool b_Structure_Matches(const CUberBlockMatrix &r_lambda) const
+	{
+		return m_b_structure_valid && m_p_solver && r_lambda.n_BlockColumn_Num() + 1 == m_cumsum.size() &&
+			size_t(m_cumsum.back()) == r_lambda.n_Column_Num();
+		// like the reference (LinearSolver_Schur.h:1627), only sizes are compared here; a caller that
+		// changes the structure announces it through Clear_SymbolicDecomposition()
+	}
+
+	bool Gather_And_Solve(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta) // throw(std::bad_alloc, std::runtime_error)
+	{
+		_ASSERTE(size_t(r_eta.rows()) == r_lambda.n_Column_Num());
+		const long n_block_num = long(m_gather.size());
+		#pragma omp parallel for schedule(static) if(n_block_num > 512)
+		for(long k = 0; k < n_block_num; ++ k) {
+			const TGatherEntry &t = m_gather[k];
+			CUberBlockMatrix::_TyConstMatrixXdRef block = r_lambda.t_Block_AtColumn(t.n_col, t.n_blk);
+			const double *p_src = block.data();
+			double *p_dest = &m_values[size_t(t.n_dest)];
+			if(!t.b_transpose) {
+				for(int i = 0, m = t.n_rows * t.n_cols; i < m; ++ i)
+					p_dest[i] = p_src[i];
+			} else {
+				for(int c = 0; c < t.n_cols; ++ c)
+					for(int r = 0; r < t.n_rows; ++ r)
+						p_dest[c + r * t.n_cols] = p_src[r + c * t.n_rows]; // dest is n_cols x n_rows
+			}
+		}
+		double *p_rhs = &r_eta(0);
+		const size_t n = m_cumsum.size() - 1;
+		if(!m_order.empty()) { // permute eta by blocks (cf. BlockMatrix.cpp:9291-9401)
+			m_rhs.resize(size_t(r_eta.rows()));
+			for(size_t i = 0; i < n; ++ i) {
+				const size_t n_src = r_lambda.n_BlockColumn_Base(m_order[i]);
+				for(int64_t d = 0, w = m_cumsum[i + 1] - m_cumsum[i]; d < w; ++ d)
+					m_rhs[size_t(m_cumsum[i] + d)] = r_eta(n_src + d);
+			}
+			p_rhs = &m_rhs[0];
+		}
+		const int n_result = slampp_hip_factor_solve(m_p_solver, m_values.empty()? 0 : &m_values[0], p_rhs, &m_t_times);
+		if(n_result == SLAMPP_HIP_NOT_POSDEF)
+			return false;
+		Throw_On_Error(n_result);
+		if(!m_order.empty()) {
+			for(size_t i = 0; i < n; ++ i) {
+				const size_t n_dst = r_lambda.n_BlockColumn_Base(m_order[i]);
+				for(int64_t d = 0, w = m_cumsum[i + 1] - m_cumsum[i]; d < w; ++ d)
+					r_eta(n_dst + d) = m_rhs[size_t(m_cumsum[i] + d)];
+			}
+		}
+		return true;
+	}
+
+public:
+	inline CLinearSolver_HIP_Base(int n_device = 0)
+		:m_p_solver(0), m_n_device(n_device), m_b_structure_valid(false)
+	{}
+
+	/** @brief copy-constructor; copies the configuration, not the state */
+	inline CLinearSolver_HIP_Base(const CLinearSolver_HIP_Base &r_other)
+		:m_p_solver(0), m_n_device(r_other.m_n_device), m_b_structure_valid(false)
+	{}
+
+	inline ~CLinearSolver_HIP_Base()
+	{
+		if(m_p_solver)
+			slampp_hip_destroy(m_p_solver);
+	}
+
+	/** @brief copy operator; copies the configuration, not the state */
+	inline CLinearSolver_HIP_Base &operator =(const CLinearSolver_HIP_Base &r_other)
+	{
+		m_n_device = r_other.m_n_device;
+		return *this;
+	}
+
+	/** @brief deletes memory for all the auxiliary buffers and matrices, host and device */
+	void Free_Memory()
+	{
+		if(m_p_solver) {
+			slampp_hip_destroy(m_p_solver);
+			m_p_solver = 0;
+		}
+		m_b_structure_valid = false;
+		{ std::vector<int64_t> e0, e1; m_cumsum.swap(e0); m_bcol_ptr.swap(e1); }
+		{ std::vector<int32_t> e; m_brow.swap(e); }
+		{ std::vector<TGatherEntry> e; m_gather.swap(e); }
+		{ std::vector<double> e0, e1; m_values.swap(e0); m_rhs.swap(e1); }
+	}
+
+	/** @brief clears the symbolic decomposition (the block structure of lambda is about to change) */
+	inline void Clear_SymbolicDecomposition()
+	{
+		m_b_structure_valid = false;
+	}
+
+	/** @brief phase timing of the last solve (ms) */
+	inline const slampp_hip_times &t_Last_Times() const
+	{
+		return m_t_times;
+	}
+};
+
+/**
+ *	@brief sparse block Cholesky on the GPU (fill-reducing ordering on the block graph, symbolic
+ *		analysis cached across calls while the block structure is unchanged)
+ */
+class CLinearSolver_HIP : public CLinearSolver_HIP_Base {
+public:
+	typedef CBlockwiseLinearSolverTag _Tag; /**< @brief solver type tag */
+
+	inline CLinearSolver_HIP(int n_device = 0)
+		:CLinearSolver_HIP_Base(n_device)
+	{}
+
+	/**
+	 *	@brief solves linear system given by positive-definite matrix
+	 *	@param[in] r_lambda is positive-definite matrix (symmetric layout, upper triangle stored)
+	 *	@param[in,out] r_eta is the right-side vector, and is overwritten with the solution
+	 *	@return Returns true on success, false on failure (not positive definite).
+	 *	@note This function throws std::bad_alloc and std::runtime_error.
+	 */
+	bool Solve_PosDef(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta) // throw(std::bad_alloc, std::runtime_error)
+	{
+		Clear_SymbolicDecomposition();
+		return Solve_PosDef_Blocky(r_lambda, r_eta);
+	}
+
+	/** @brief calculates ordering and symbolic decomposition of a block matrix, to be reused by Solve_PosDef_Blocky() */
+	bool SymbolicDecomposition_Blocky(const CUberBlockMatrix &r_lambda) // throw(std::bad_alloc, std::runtime_error)
+	{
+		return Analyze(r_lambda, SLAMPP_HIP_MODE_SPARSE, 0, 0);
+	}
+
+	/** @brief solves, reusing the symbolic decomposition for as long as the block structure stays the same */
+	bool Solve_PosDef_Blocky(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta) // throw(std::bad_alloc, std::runtime_error)
+	{
+		if(!b_Structure_Matches(r_lambda))
+			SymbolicDecomposition_Blocky(r_lambda);
+		return Gather_And_Solve(r_lambda, r_eta);
+	}
+};
+
+/**
+ *	@brief Schur-complement solver on the GPU with the public surface of CLinearSolver_Schur
+ *
+ *	@tparam CBaseSolver is the base linear solver type (accepted for signature parity; the reduced
+ *		camera system is factorized densely on the GPU, as CLinearSolver_Schur's GPU build does with
+ *		CLinearSolver_DenseGPU, LinearSolver_Schur.h:1427-1435)
+ *	@tparam CAMatrixBlockSizes is list of the block sizes (unused: sizes are read from lambda)
+ *	@tparam CSystem is the optimized system type (unused)
+ */
+template <class CBaseSolver = CLinearSolver_HIP, class CAMatrixBlockSizes = void, class CSystem = void>
+class CLinearSolver_Schur_HIP : public CLinearSolver_HIP_Base {
+public:
+	typedef CBlockwiseLinearSolverTag _Tag; /**< @brief solver type tag */
+
+protected:
+	size_t m_n_matrix_cut; /**< @brief number of camera (reduced system) block columns */
+	CLinearSolver_HIP m_sparse_fallback; /**< @brief used when lambda has no landmark part */
+
+	/**
+	 *	@brief the reference's guided ordering (LinearSolver_Schur.cpp:771-838): block columns of the
+	 *		widest size first (cameras / poses), all others last (landmarks), both in stable order
+	 *	@return Returns the number of camera block columns.
+	 */
+	static size_t n_Calculate_GuidedOrdering(std::vector<size_t> &r_order, const CUberBlockMatrix &r_lambda)
+	{
+		const size_t n = r_lambda.n_BlockColumn_Num();
+		size_t n_pose_dim = 0;
+		for(size_t i = 0; i < n; ++ i)
+			n_pose_dim = std::max(n_pose_dim, r_lambda.n_BlockColumn_Column_Num(i));
+		r_order.clear();
+		r_order.reserve(n);
+		for(size_t i = 0; i < n; ++ i) {
+			if(r_lambda.n_BlockColumn_Column_Num(i) == n_pose_dim)
+				r_order.push_back(i);
+		}
+		const size_t n_cut = r_order.size();
+		for(size_t i = 0; i < n; ++ i) {
+			if(r_lambda.n_BlockColumn_Column_Num(i) != n_pose_dim)
+				r_order.push_back(i);
+		}
+		return n_cut;
+	}
+
+public:
+	inline CLinearSolver_Schur_HIP(int n_device = 0)
+		:CLinearSolver_HIP_Base(n_device), m_n_matrix_cut(size_t(-1)), m_sparse_fallback(n_device)
+	{}
+
+	/** @brief the reference's constructor signature (LinearSolver_Schur.h:1472): the base solver instance is unused */
+	inline CLinearSolver_Schur_HIP(const CBaseSolver &UNUSED(r_solver), int n_device = 0)
+		:CLinearSolver_HIP_Base(n_device), m_n_matrix_cut(size_t(-1)), m_sparse_fallback(n_device)
+	{}
+
+	inline CLinearSolver_Schur_HIP(const CLinearSolver_Schur_HIP &r_other)
+		:CLinearSolver_HIP_Base(r_other), m_n_matrix_cut(size_t(-1)), m_sparse_fallback(r_other.m_sparse_fallback)
+	{}
+
+	inline CLinearSolver_Schur_HIP &operator =(const CLinearSolver_Schur_HIP &r_other)
+	{
+		CLinearSolver_HIP_Base::operator =(r_other);
+		return *this;
+	}
+
+	void Free_Memory()
+	{
+		CLinearSolver_HIP_Base::Free_Memory();
+		m_sparse_fallback.Free_Memory();
+		m_n_matrix_cut = size_t(-1);
+	}
+
+	inline void Clear_SymbolicDecomposition()
+	{
+		CLinearSolver_HIP_Base::Clear_SymbolicDecomposition();
+		m_sparse_fallback.Clear_SymbolicDecomposition();
+		m_n_matrix_cut = size_t(-1);
+	}
+
+	bool Solve_PosDef(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta) // throw(std::bad_alloc, std::runtime_error)
+	{
+		SymbolicDecomposition_Blocky(r_lambda);
+		return Solve_PosDef_Blocky(r_lambda, r_eta);
+	}
+
+	inline bool SymbolicDecomposition_Blocky(const CUberBlockMatrix &r_lambda) // throw(std::bad_alloc, std::runtime_error)
+	{
+		return SymbolicDecomposition_Blocky(r_lambda, false);
+	}
+
+	/** @brief calculates the Schur ordering (always the guided one here) and analyzes the structure */
+	bool SymbolicDecomposition_Blocky(const CUberBlockMatrix &r_lambda, bool UNUSED(b_force_guided_ordering)) // throw(std::bad_alloc, std::runtime_error)
+	{
+		std::vector<size_t> order;
+		m_n_matrix_cut = n_Calculate_GuidedOrdering(order, r_lambda);
+		if(m_n_matrix_cut == 0 || m_n_matrix_cut == order.size()) {
+			m_b_structure_valid = false;
+			return m_sparse_fallback.SymbolicDecomposition_Blocky(r_lambda); // no landmark part (cf. LinearSolver_Schur.h:1635-1638)
+		}
+		bool b_identity = true;
+		for(size_t i = 0; i < order.size() && b_identity; ++ i)
+			b_identity = order[i] == i;
+		return Analyze(r_lambda, SLAMPP_HIP_MODE_SCHUR, m_n_matrix_cut, b_identity? 0 : &order);
+	}
+
+	bool Solve_PosDef_Blocky(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta) // throw(std::bad_alloc, std::runtime_error)
+	{
+		if(m_n_matrix_cut == size_t(-1) || (!b_Structure_Matches(r_lambda) &&
+		   m_n_matrix_cut != 0 && m_n_matrix_cut != r_lambda.n_BlockColumn_Num()))
+			SymbolicDecomposition_Blocky(r_lambda); // nonconforming ordering: calculate a new one (LinearSolver_Schur.h:1627-1628)
+		if(m_n_matrix_cut == 0 || m_n_matrix_cut == r_lambda.n_BlockColumn_Num())
+			return m_sparse_fallback.Solve_PosDef_Blocky(r_lambda, r_eta);
+		return Gather_And_Solve(r_lambda, r_eta);
+	}
+};
+
+#endif // !__LINEAR_SOLVER_HIP_INCLUDED

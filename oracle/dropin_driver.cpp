@@ -1,0 +1,272 @@
+/*
+ * oracle/dropin_driver.cpp -- TEST INFRASTRUCTURE.  End-to-end drop-in check, compiled against the
+ * reference's own headers and libraries (oracle/Makefile.ref) and linked with libslampp_hip.so:
+ *
+ *   1. an SE(2) pose graph optimized by the reference's CNonlinearSolver_Lambda, unchanged, once
+ *      with CLinearSolver_CholMod and once with CLinearSolver_HIP (include/slam/LinearSolver_HIP.h)
+ *      as its CLinearSolver template argument: same iteration count, chi2 and vertex states;
+ *   2. the same with an SE(3) graph;
+ *   3. a BA-shaped CUberBlockMatrix (from a SPPLAM01 file, optionally with cameras and landmarks
+ *      interleaved so that the guided ordering has to permute) solved by the reference's
+ *      CLinearSolver_Schur and by CLinearSolver_Schur_HIP.
+ *
+ * Needs a GPU at run time (there is no CPU fallback in the product); prints one JSON line and
+ * returns 0 iff all comparisons are within 1e-10 (relative, infinity norm).
+ *
+ * usage: dropin_driver [ba_problem.bin]
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <math.h>
+#include <vector>
+#include <random>
+
+#include "slam/LinearSolver_CholMod.h"
+#include "slam/LinearSolver_UberBlock.h"
+#include "slam/LinearSolver_Schur.h"
+#include "slam/ConfigSolvers.h"
+#include "slam/SE2_Types.h"
+#include "slam/SE3_Types.h"
+#include "slam/BA_Types.h"
+#include "slam/LinearSolver_HIP.h"
+
+template <class CSystemType, class CLinearSolverType>
+static std::vector<double> Optimize_SE2(size_t n_poses, unsigned n_seed, double &r_f_chi2)
+{
+	CSystemType system;
+	CNonlinearSolver_Lambda<CSystemType, CLinearSolverType> solver(system);
+	Eigen::Matrix3d information = Eigen::Matrix3d::Identity() * 45;
+	std::mt19937_64 rng(n_seed);
+	std::normal_distribution<double> noise(0, 0.02);
+	std::vector<Eigen::Vector3d> truth(n_poses);
+	truth[0] = Eigen::Vector3d(0, 0, 0);
+	for(size_t i = 1; i < n_poses; ++ i) {
+		const double turn = (rng() % 4 == 0)? ((rng() % 2)? M_PI / 2 : -M_PI / 2) : 0;
+		const double th = truth[i - 1](2);
+		truth[i] = Eigen::Vector3d(truth[i - 1](0) + cos(th), truth[i - 1](1) + sin(th), th + turn);
+	}
+	for(size_t i = 1; i < n_poses; ++ i) {
+		for(int n_pass = 0; n_pass < 2; ++ n_pass) {
+			size_t j = i - 1;
+			if(n_pass == 1) { // a loop closure to an earlier pose nearby, if there is one
+				bool b_found = false;
+				for(size_t k = 0; k + 5 < i && !b_found; ++ k) {
+					if((truth[k].head<2>() - truth[i].head<2>()).norm() < 1.5) {
+						j = k;
+						b_found = true;
+					}
+				}
+				if(!b_found)
+					break;
+			}
+			const double c = cos(truth[j](2)), s = sin(truth[j](2));
+			const double dx = truth[i](0) - truth[j](0), dy = truth[i](1) - truth[j](1);
+			Eigen::Vector3d z(c * dx + s * dy + noise(rng), -s * dx + c * dy + noise(rng),
+				truth[i](2) - truth[j](2) + noise(rng));
+			system.r_Add_Edge(CEdgePose2D(j, i, z, information, system));
+		}
+	}
+	solver.Optimize(8, 1e-6);
+	r_f_chi2 = solver.f_Chi_Squared_Error_Denorm();
+	std::vector<double> state;
+	for(size_t i = 0, n = system.r_Vertex_Pool().n_Size(); i < n; ++ i) {
+		Eigen::VectorXd v = system.r_Vertex_Pool()[i].v_State();
+		for(int d = 0; d < v.rows(); ++ d)
+			state.push_back(v(d));
+	}
+	return state;
+}
+
+template <class CSystemType, class CLinearSolverType>
+static std::vector<double> Optimize_SE3(size_t n_poses, unsigned n_seed, double &r_f_chi2)
+{
+	CSystemType system;
+	CNonlinearSolver_Lambda<CSystemType, CLinearSolverType> solver(system);
+	Eigen::Matrix<double, 6, 6> information = Eigen::Matrix<double, 6, 6>::Identity() * 100;
+	std::mt19937_64 rng(n_seed);
+	std::normal_distribution<double> noise(0, 0.01);
+	// a helix; measurements = small relative motions, expressed as (translation, axis-angle)
+	for(size_t i = 1; i < n_poses; ++ i) {
+		Eigen::Matrix<double, 6, 1> z;
+		z << 1 + noise(rng), noise(rng), 0.05 + noise(rng), noise(rng), noise(rng), 0.1 + noise(rng);
+		system.r_Add_Edge(CEdgePose3D(i - 1, i, z, information, system));
+		if(i >= 10 && i % 7 == 0) { // a "loop closure": composition of the last 3 odometry steps is unknown to us, so
+			// add a second, slightly different measurement of the same edge pair instead (keeps the graph consistent)
+			Eigen::Matrix<double, 6, 1> z2 = z;
+			z2(0) += noise(rng);
+			system.r_Add_Edge(CEdgePose3D(i - 1, i, z2, information, system));
+		}
+	}
+	solver.Optimize(6, 1e-6);
+	r_f_chi2 = solver.f_Chi_Squared_Error_Denorm();
+	std::vector<double> state;
+	for(size_t i = 0, n = system.r_Vertex_Pool().n_Size(); i < n; ++ i) {
+		Eigen::VectorXd v = system.r_Vertex_Pool()[i].v_State();
+		for(int d = 0; d < v.rows(); ++ d)
+			state.push_back(v(d));
+	}
+	return state;
+}
+
+static double f_RelInf(const std::vector<double> &a, const std::vector<double> &b)
+{
+	if(a.size() != b.size() || a.empty())
+		return 1e300;
+	double f_diff = 0, f_ref = 0;
+	for(size_t i = 0; i < a.size(); ++ i) {
+		f_diff = std::max(f_diff, fabs(a[i] - b[i]));
+		f_ref = std::max(f_ref, fabs(b[i]));
+	}
+	return f_diff / f_ref;
+}
+
+struct TProblem {
+	int64_t n_bcols, n_blocks, n_scalars, n_values, n_matrix_cut;
+	std::vector<int64_t> cumsum, bcol_ptr, brow;
+	std::vector<double> values, rhs;
+};
+
+static bool Read_Problem(const char *p_s_file, TProblem &r)
+{
+	FILE *f = fopen(p_s_file, "rb");
+	if(!f)
+		return false;
+	char magic[8];
+	int64_t hdr[8];
+	bool ok = fread(magic, 1, 8, f) == 8 && !memcmp(magic, "SPPLAM01", 8) && fread(hdr, 8, 8, f) == 8;
+	if(ok) {
+		r.n_bcols = hdr[0]; r.n_blocks = hdr[1]; r.n_scalars = hdr[2]; r.n_values = hdr[3]; r.n_matrix_cut = hdr[4];
+		r.cumsum.resize(r.n_bcols + 1); r.bcol_ptr.resize(r.n_bcols + 1);
+		r.brow.resize(r.n_blocks); r.values.resize(r.n_values); r.rhs.resize(r.n_scalars);
+		ok = fread(&r.cumsum[0], 8, r.n_bcols + 1, f) == size_t(r.n_bcols + 1) &&
+			fread(&r.bcol_ptr[0], 8, r.n_bcols + 1, f) == size_t(r.n_bcols + 1) &&
+			fread(&r.brow[0], 8, r.n_blocks, f) == size_t(r.n_blocks) &&
+			fread(&r.values[0], 8, r.n_values, f) == size_t(r.n_values) &&
+			fread(&r.rhs[0], 8, r.n_scalars, f) == size_t(r.n_scalars);
+	}
+	fclose(f);
+	return ok;
+}
+
+/**
+ *	@brief builds lambda from the file; with b_interleave, block column i of the file becomes block
+ *		column order[i], cameras and landmarks alternating (the upper triangle is kept by transposing)
+ */
+static void Build_Lambda(const TProblem &p, bool b_interleave, CUberBlockMatrix &r_lambda,
+	Eigen::VectorXd &r_rhs, std::vector<size_t> &r_new_of_old)
+{
+	const size_t n = size_t(p.n_bcols), nc = size_t(p.n_matrix_cut);
+	r_new_of_old.resize(n);
+	if(b_interleave) { // camera k goes to slot spread over the landmarks
+		const size_t n_stride = std::max<size_t>((n - nc) / nc, 1);
+		std::vector<size_t> order; // new -> old
+		size_t c = 0, l = nc;
+		while(order.size() < n) {
+			if(c < nc)
+				order.push_back(c ++);
+			for(size_t k = 0; k < n_stride && l < n; ++ k)
+				order.push_back(l ++);
+			if(c == nc)
+				while(l < n) order.push_back(l ++);
+		}
+		for(size_t i = 0; i < n; ++ i)
+			r_new_of_old[order[i]] = i;
+	} else {
+		for(size_t i = 0; i < n; ++ i)
+			r_new_of_old[i] = i;
+	}
+	std::vector<size_t> dims(n), cs(n);
+	for(size_t o = 0; o < n; ++ o)
+		dims[r_new_of_old[o]] = size_t(p.cumsum[o + 1] - p.cumsum[o]);
+	size_t n_sum = 0;
+	for(size_t i = 0; i < n; ++ i)
+		cs[i] = (n_sum += dims[i]);
+	CUberBlockMatrix lambda(cs.begin(), cs.end(), cs.begin(), cs.end());
+	r_rhs.resize(p.n_scalars);
+	const double *p_val = &p.values[0];
+	for(size_t c = 0; c < n; ++ c) {
+		const size_t w = size_t(p.cumsum[c + 1] - p.cumsum[c]);
+		for(int64_t k = p.bcol_ptr[c]; k < p.bcol_ptr[c + 1]; ++ k) {
+			const size_t r = size_t(p.brow[k]), h = size_t(p.cumsum[r + 1] - p.cumsum[r]);
+			Eigen::Map<const Eigen::MatrixXd> blk(p_val, h, w);
+			const size_t nr = r_new_of_old[r], ncol = r_new_of_old[c];
+			if(nr <= ncol)
+				lambda.t_GetBlock_Log(nr, ncol, h, w, true, true) = blk;
+			else
+				lambda.t_GetBlock_Log(ncol, nr, w, h, true, true) = blk.transpose();
+			p_val += h * w;
+		}
+		const size_t n_dst = cs[r_new_of_old[c]] - w;
+		for(size_t d = 0; d < w; ++ d)
+			r_rhs(n_dst + d) = p.rhs[size_t(p.cumsum[c]) + d];
+	}
+	r_lambda.Swap(lambda);
+}
+
+int main(int n_arg_num, const char **p_arg_list)
+{
+	int n_fail = 0;
+	printf("{");
+	try {
+		{
+			typedef MakeTypelist(CVertexPose2D) TVertexTypelist;
+			typedef MakeTypelist(CEdgePose2D) TEdgeTypelist;
+			typedef CFlatSystem<CVertexPose2D, TVertexTypelist, CEdgePose2D, TEdgeTypelist> CSystemType;
+			double f_chi2_ref, f_chi2_hip;
+			std::vector<double> ref = Optimize_SE2<CSystemType, CLinearSolver_CholMod>(400, 1234, f_chi2_ref);
+			std::vector<double> hip = Optimize_SE2<CSystemType, CLinearSolver_HIP>(400, 1234, f_chi2_hip);
+			const double f_err = f_RelInf(hip, ref);
+			printf("\"se2_lambda_solver\": {\"chi2_ref\": %.12g, \"chi2_hip\": %.12g, \"state_rel_inf\": %.3g}, ",
+				f_chi2_ref, f_chi2_hip, f_err);
+			n_fail += !(f_err < 1e-9 && fabs(f_chi2_ref - f_chi2_hip) <= 1e-9 * fabs(f_chi2_ref));
+		}
+		{
+			typedef MakeTypelist(CVertexPose3D) TVertexTypelist;
+			typedef MakeTypelist(CEdgePose3D) TEdgeTypelist;
+			typedef CFlatSystem<CVertexPose3D, TVertexTypelist, CEdgePose3D, TEdgeTypelist> CSystemType;
+			double f_chi2_ref, f_chi2_hip;
+			std::vector<double> ref = Optimize_SE3<CSystemType, CLinearSolver_CholMod>(300, 77, f_chi2_ref);
+			std::vector<double> hip = Optimize_SE3<CSystemType, CLinearSolver_HIP>(300, 77, f_chi2_hip);
+			const double f_err = f_RelInf(hip, ref);
+			printf("\"se3_lambda_solver\": {\"chi2_ref\": %.12g, \"chi2_hip\": %.12g, \"state_rel_inf\": %.3g}, ",
+				f_chi2_ref, f_chi2_hip, f_err);
+			n_fail += !(f_err < 1e-9 && fabs(f_chi2_ref - f_chi2_hip) <= 1e-9 * fabs(f_chi2_ref));
+		}
+		if(n_arg_num > 1) {
+			TProblem p;
+			if(!Read_Problem(p_arg_list[1], p) || !p.n_matrix_cut) {
+				fprintf(stderr, "error: can't read BA problem %s\n", p_arg_list[1]);
+				return 2;
+			}
+			typedef CFlatSystem<CBaseVertex, MakeTypelist_Safe((CVertexCam, CVertexXYZ)),
+				CEdgeP2C3D, MakeTypelist_Safe((CEdgeP2C3D))> TBASystem;
+			typedef CLinearSolver_Schur<CLinearSolver_CholMod, TBASystem::_TyJacobianMatrixBlockList, TBASystem> TRefSchur;
+			typedef CLinearSolver_Schur_HIP<CLinearSolver_CholMod, TBASystem::_TyJacobianMatrixBlockList, TBASystem> THipSchur;
+			for(int b_interleave = 0; b_interleave < 2; ++ b_interleave) {
+				CUberBlockMatrix lambda;
+				Eigen::VectorXd rhs;
+				std::vector<size_t> new_of_old;
+				Build_Lambda(p, b_interleave != 0, lambda, rhs, new_of_old);
+				Eigen::VectorXd x_ref = rhs, x_hip = rhs, x_hip2 = rhs;
+				CLinearSolver_CholMod base;
+				TRefSchur ref_solver(base);
+				THipSchur hip_solver(base);
+				const bool b_ref = ref_solver.Solve_PosDef(lambda, x_ref);
+				const bool b_hip = hip_solver.Solve_PosDef(lambda, x_hip);
+				const bool b_hip2 = hip_solver.Solve_PosDef_Blocky(lambda, x_hip2); // cached structure
+				const double f_err = (x_hip - x_ref).lpNorm<Eigen::Infinity>() / x_ref.lpNorm<Eigen::Infinity>();
+				const double f_err2 = (x_hip2 - x_ref).lpNorm<Eigen::Infinity>() / x_ref.lpNorm<Eigen::Infinity>();
+				printf("\"schur_%s\": {\"ok_ref\": %d, \"ok_hip\": %d, \"rel_inf\": %.3g, \"rel_inf_warm\": %.3g}, ",
+					b_interleave? "interleaved" : "cams_first", int(b_ref), int(b_hip && b_hip2), f_err, f_err2);
+				n_fail += !(b_ref && b_hip && b_hip2 && f_err < 1e-10 && f_err2 < 1e-10);
+			}
+		}
+	} catch(std::exception &r_exc) {
+		printf("\"exception\": \"%s\", ", r_exc.what());
+		++ n_fail;
+	}
+	printf("\"failures\": %d}\n", n_fail);
+	return n_fail? 1 : 0;
+}

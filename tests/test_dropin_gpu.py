@@ -1,0 +1,32 @@
+"""End-to-end drop-in check on the GPU box: the reference's own CNonlinearSolver_Lambda (compiled from
+/root/reference into oracle/_ref/dropin_driver by oracle/Makefile.ref, in the build container) runs
+unchanged with CLinearSolver_HIP (include/slam/LinearSolver_HIP.h) as its linear solver, and
+CLinearSolver_Schur_HIP solves CUberBlockMatrix BA systems next to the reference's CLinearSolver_Schur
+-- same process, same inputs, 1e-10 agreement.  Skipped where the prebuilt driver is absent."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from slam_plus_plus_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "dropin_driver")
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/dropin_driver was not prebuilt")
+def test_reference_nonlinear_solver_with_hip_linear_solver(tmp_path):
+    lam = synth.ba(24, 1500, mode="venice", seed=42)
+    p = tmp_path / "ba.bin"
+    lam.save(str(p))
+    out = subprocess.run([DRIVER, str(p)], capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert line, out.stdout + out.stderr
+    r = json.loads(line[-1])
+    assert out.returncode == 0 and r["failures"] == 0, r
+    assert r["se2_lambda_solver"]["state_rel_inf"] < 1e-9
+    assert r["se3_lambda_solver"]["state_rel_inf"] < 1e-9
+    assert r["schur_cams_first"]["rel_inf"] < 1e-10
+    assert r["schur_interleaved"]["rel_inf"] < 1e-10
