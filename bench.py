@@ -80,8 +80,8 @@ def per_kernel_bytes_sparse(plan):
     stage0 = np.zeros(n, dtype=bool)
     t0, t1 = plan["stage_ptr"][0], plan["stage_ptr"][1]
     stage0[plan["task_cols"][plan["task_ptr"][t0]:plan["task_ptr"][t1]]] = True
-    fac = 8.0 * (l_col + a_col)
-    sub = 8.0 * l_col + 32.0 * dim / 2          # per substitution: read L column, read+write vector
+    fac = 8.0 * (l_col + a_col) + 16.0 * dim     # + the fused forward substitution's vector traffic
+    sub = 8.0 * l_col + 16.0 * dim               # a substitution reads the L column, reads + writes the vector
     return {"factor_subtree": float(fac[stage0].sum()), "factor_upper": float(fac[~stage0].sum()),
             "forward": float(sub.sum()), "backward": float(sub.sum()),
             "stage0_cols": int(stage0.sum())}
@@ -157,7 +157,7 @@ def run_c3(args, rank, world, local_rank, dist):
     kb = per_kernel_bytes_sparse(solver.plan())
     n_stages = stats["n_stages"]
     launches = {"factor_subtree": 1, "factor_upper": max(n_stages - 1, 1), "forward": n_stages, "backward": n_stages}
-    names = {"factor_subtree": "factor_subtree_kernel", "factor_upper": "factor_stage_kernel<W>",
+    names = {"factor_subtree": "factor_subtree_kernel<D>", "factor_upper": "factor_stage_kernel<D, 8>",
              "forward": "forward_stage_kernel", "backward": "backward_stage_kernel"}
     kernels = []
     for ph, (cnt, tot_ms) in prof.items():

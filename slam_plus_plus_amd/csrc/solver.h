@@ -92,9 +92,11 @@ struct slampp_hip_solver {
 	slampp::Plan plan;
 	std::vector<int> stage_waves;
 	slampp::TDevPlan dplan;
-	slampp::CDevArray<int32_t> d_dim, d_lrow, d_rcol, d_task_cols;
-	slampp::CDevArray<int64_t> d_cs_new, d_cs_src, d_lptr, d_loff, d_asrc, d_linv_off, d_pptr, d_rptr, d_roff, d_task_ptr;
+	slampp::CDevArray<slampp::TColDesc> d_cols;
+	slampp::CDevArray<slampp::TBlkDesc> d_blks;
+	slampp::CDevArray<slampp::TRowEnt> d_rents;
 	slampp::CDevArray<longlong2> d_pairs;
+	slampp::CDevArray<int64_t> d_task_ptr;
 	slampp::CDevArray<double> d_A, d_rhs, d_L, d_Linv, d_w;
 	slampp::CDevArray<int> d_flag;
 	int *p_host_flag; // pinned

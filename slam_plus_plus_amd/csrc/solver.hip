@@ -35,9 +35,7 @@ slampp_hip_solver::~slampp_hip_solver()
 
 void slampp_hip_solver::Free_Device()
 {
-	d_dim.Free(); d_lrow.Free(); d_rcol.Free(); d_task_cols.Free();
-	d_cs_new.Free(); d_cs_src.Free(); d_lptr.Free(); d_loff.Free(); d_asrc.Free(); d_linv_off.Free();
-	d_pptr.Free(); d_rptr.Free(); d_roff.Free(); d_task_ptr.Free(); d_pairs.Free();
+	d_cols.Free(); d_blks.Free(); d_rents.Free(); d_pairs.Free(); d_task_ptr.Free();
 	d_A.Free(); d_rhs.Free(); d_L.Free(); d_Linv.Free(); d_w.Free(); d_flag.Free();
 	if(p_schur) {
 		schur_destroy(p_schur);
@@ -49,10 +47,8 @@ void slampp_hip_solver::Free_Device()
 
 size_t slampp_hip_solver::n_Device_Bytes() const
 {
-	return d_dim.n_Bytes() + d_lrow.n_Bytes() + d_rcol.n_Bytes() + d_task_cols.n_Bytes() +
-		d_cs_new.n_Bytes() + d_cs_src.n_Bytes() + d_lptr.n_Bytes() + d_loff.n_Bytes() +
-		d_asrc.n_Bytes() + d_linv_off.n_Bytes() + d_pptr.n_Bytes() + d_rptr.n_Bytes() +
-		d_roff.n_Bytes() + d_task_ptr.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
+	return d_cols.n_Bytes() + d_blks.n_Bytes() + d_rents.n_Bytes() +
+		d_task_ptr.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
 		d_rhs.n_Bytes() + d_L.n_Bytes() + d_Linv.n_Bytes() + d_w.n_Bytes() + d_flag.n_Bytes() +
 		(p_schur? schur_device_bytes(p_schur) : 0);
 }
@@ -122,62 +118,66 @@ void slampp_hip_solver::Analyze_Sparse()
 	const Plan &P = plan;
 	const int64_t n_lblocks = int64_t(P.lrow.size());
 
-	// per-stage workgroup width: one wave for the bottom subtrees, more for wide separator columns
-	const int n_stages = int(P.stage_ptr.size()) - 1;
-	stage_waves.assign(n_stages, 1);
-	for(int s = 1; s < n_stages; ++ s) {
-		int64_t n_max_blocks = 0;
-		for(int t = P.stage_ptr[s]; t < P.stage_ptr[s + 1]; ++ t) {
-			for(int64_t c = P.task_ptr[t]; c < P.task_ptr[t + 1]; ++ c) {
-				const int j = P.task_cols[c];
-				n_max_blocks = std::max(n_max_blocks, P.lptr[j + 1] - P.lptr[j]);
-			}
-		}
-		stage_waves[s] = (n_max_blocks <= 3)? 1 : (n_max_blocks <= 24)? 4 : 16;
-	}
+	if(P.cs_new[P.n] >= INT32_MAX)
+		throw std::domain_error("systems with 2^31 or more scalar unknowns are not supported by the sparse path");
 
-	// device copies
-	std::vector<int64_t> asrc_enc(n_lblocks);
-	for(int64_t k = 0; k < n_lblocks; ++ k)
-		asrc_enc[k] = (P.asrc[k] < 0)? -1 : P.asrc[k] * 2 + P.atrans[k];
+	// packed device records (see sparse_kernels.h)
+	std::vector<TColDesc> cols(P.n); // in schedule order
+	for(int32_t i = 0; i < P.n; ++ i) {
+		const int32_t j = P.task_cols[i];
+		TColDesc &c = cols[i];
+		memset(&c, 0, sizeof(c));
+		c.k0 = P.lptr[j];
+		c.nb = int32_t(P.lptr[j + 1] - P.lptr[j]);
+		c.dj = P.dim[j];
+		c.linv_off = P.linv_off[j];
+		c.cs_new = P.cs_new[j];
+		c.cs_src = P.cs_src[j];
+		c.r0 = P.rptr[j];
+		c.nr = int32_t(P.rptr[j + 1] - P.rptr[j]);
+		c.p0 = P.pptr[P.lptr[j] + 1]; // pairs are stored block by block: those of the sub-diagonal blocks are contiguous
+		const int64_t np = P.pptr[P.lptr[j + 1]] - c.p0;
+		c.np = int32_t(std::min<int64_t>(np, INT32_MAX));
+	}
+	std::vector<TBlkDesc> blks(n_lblocks);
+	for(int64_t k = 0; k < n_lblocks; ++ k) {
+		TBlkDesc &b = blks[k];
+		const int64_t np = P.pptr[k + 1] - P.pptr[k];
+		if(np >= (int64_t(1) << 24))
+			throw std::domain_error("a factor block has 2^24 or more updates: use the dense path");
+		b.loff = P.loff[k];
+		b.asrc = (P.asrc[k] < 0)? -1 : P.asrc[k] * 2 + P.atrans[k];
+		b.p0 = P.pptr[k];
+		b.np_di = uint32_t(np) | (uint32_t(P.dim[P.lrow[k]]) << 24);
+		b.xcs = int32_t(P.cs_new[P.lrow[k]]);
+	}
 	std::vector<longlong2> pairs(P.pa.size());
 	for(size_t e = 0; e < P.pa.size(); ++ e) {
 		const int64_t dc = P.dim[P.blk_col[P.pa[e]]];
 		pairs[e].x = P.loff[P.pa[e]] | (dc << 56);
 		pairs[e].y = P.loff[P.pb[e]];
 	}
-	std::vector<int64_t> roff(P.rblk.size());
-	std::vector<int32_t> rcol(P.rblk.size());
+	std::vector<TRowEnt> rents(P.rblk.size());
 	for(size_t e = 0; e < P.rblk.size(); ++ e) {
-		roff[e] = P.loff[P.rblk[e]];
-		rcol[e] = P.blk_col[P.rblk[e]];
+		const int32_t c = P.blk_col[P.rblk[e]];
+		rents[e].off = P.loff[P.rblk[e]];
+		rents[e].ycs = int32_t(P.cs_new[c]);
+		rents[e].dc = P.dim[c];
 	}
-	d_dim.Upload(P.dim, stream);
-	d_cs_new.Upload(P.cs_new, stream);
-	d_cs_src.Upload(P.cs_src, stream);
-	d_lptr.Upload(P.lptr, stream);
-	d_lrow.Upload(P.lrow, stream);
-	d_loff.Upload(P.loff, stream);
-	d_asrc.Upload(asrc_enc, stream);
-	d_linv_off.Upload(P.linv_off, stream);
-	d_pptr.Upload(P.pptr, stream);
+	d_cols.Upload(cols, stream);
+	d_blks.Upload(blks, stream);
 	d_pairs.Upload(pairs, stream);
-	d_rptr.Upload(P.rptr, stream);
-	d_roff.Upload(roff, stream);
-	d_rcol.Upload(rcol, stream);
+	d_rents.Upload(rents, stream);
 	d_task_ptr.Upload(P.task_ptr, stream);
-	d_task_cols.Upload(P.task_cols, stream);
 	d_L.Alloc(size_t(P.loff[n_lblocks]));
 	d_Linv.Alloc(size_t(P.linv_off[P.n]));
 	d_w.Alloc(size_t(P.cs_new[P.n]));
 	d_flag.Alloc(1);
 	SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // the staging vectors above die here
 
-	dplan.dim = d_dim.p(); dplan.cs_new = d_cs_new.p(); dplan.cs_src = d_cs_src.p();
-	dplan.lptr = d_lptr.p(); dplan.lrow = d_lrow.p(); dplan.loff = d_loff.p(); dplan.asrc = d_asrc.p();
-	dplan.linv_off = d_linv_off.p(); dplan.pptr = d_pptr.p(); dplan.pairs = d_pairs.p();
-	dplan.rptr = d_rptr.p(); dplan.roff = d_roff.p(); dplan.rcol = d_rcol.p();
-	dplan.task_ptr = d_task_ptr.p(); dplan.task_cols = d_task_cols.p();
+	dplan.cols = d_cols.p(); dplan.blks = d_blks.p(); dplan.pairs = d_pairs.p(); dplan.rents = d_rents.p();
+	dplan.task_ptr = d_task_ptr.p();
+	dplan.uniform_dim = P.uniform_dim? P.max_dim : 0;
 }
 
 void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs_dev, bool b_factor)
@@ -185,22 +185,24 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 	const Plan &P = plan;
 	const int n_stages = int(P.stage_ptr.size()) - 1;
 	if(b_factor) {
+		// numeric factorization with the forward substitution fused in
 		SLAMPP_HIP_CHECK(hipMemsetAsync(d_flag.p(), 0, sizeof(int), stream));
 		for(int s = 0; s < n_stages; ++ s) {
 			if(s < 2)
 				Phase_Begin(s? "factor_upper" : "factor_subtree");
-			launch_factor_stage(dplan, p_values_dev, d_L.p(), d_Linv.p(), P.stage_ptr[s],
-				P.stage_ptr[s + 1] - P.stage_ptr[s], s? stage_waves[s] : 0, d_flag.p(), stream);
+			launch_factor_stage(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
+				P.stage_ptr[s + 1] - P.stage_ptr[s], s == 0, d_flag.p(), stream);
 			if(!s || s == n_stages - 1)
 				Phase_End();
 		}
+	} else {
+		Phase_Begin("forward");
+		for(int s = 0; s < n_stages; ++ s) {
+			launch_forward_stage(dplan, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
+				P.stage_ptr[s + 1] - P.stage_ptr[s], stream);
+		}
+		Phase_End();
 	}
-	Phase_Begin("forward");
-	for(int s = 0; s < n_stages; ++ s) {
-		launch_forward_stage(dplan, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
-			P.stage_ptr[s + 1] - P.stage_ptr[s], stream);
-	}
-	Phase_End();
 	Phase_Begin("backward");
 	for(int s = n_stages; s > 0; -- s) {
 		launch_backward_stage(dplan, d_L.p(), d_Linv.p(), d_w.p(), p_rhs_dev, P.stage_ptr[s - 1],

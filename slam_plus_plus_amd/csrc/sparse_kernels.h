@@ -5,28 +5,52 @@
 
 namespace slampp {
 
-struct TDevPlan {
-	const int32_t *dim;        // [n] block dimension, new order
-	const int64_t *cs_new;     // [n+1] scalar offset in the permuted workspace
-	const int64_t *cs_src;     // [n] scalar offset in the caller's vector
-	const int64_t *lptr;       // [n+1]
-	const int32_t *lrow;       // [l_blocks]
-	const int64_t *loff;       // [l_blocks+1]
-	const int64_t *asrc;       // [l_blocks] (offset in Lambda values) * 2 + transposed, or -1
-	const int64_t *linv_off;   // [n+1]
-	const int64_t *pptr;       // [l_blocks+1]
-	const longlong2 *pairs;    // [n_pairs] x = offset of L(i,c) | dim(c) << 56, y = offset of L(j,c)
-	const int64_t *rptr;       // [n+1]
-	const int64_t *roff;       // [n_row_entries] offset of L(j,c)
-	const int32_t *rcol;       // [n_row_entries] c
-	const int64_t *task_ptr;   // [n_tasks+1]
-	const int32_t *task_cols;  // [n]
+// One record per block column / factor block / row entry, packed so that a kernel gets everything
+// it needs about an item with one (wave-uniform, broadcast) load instead of a chain of dependent
+// index loads -- the path is latency-bound, every dependent load on it costs about a microsecond.
+struct TColDesc { // 64 B
+	int64_t k0;        // first factor block of the column (the diagonal one)
+	int32_t nb, dj;    // number of blocks, column dimension
+	int64_t linv_off;  // offset of inv(L_jj)
+	int64_t cs_new;    // scalar offset in the permuted workspace
+	int64_t cs_src;    // scalar offset in the caller's vector
+	int64_t r0;        // first row entry
+	int32_t nr;        // number of row entries = blocks L(j,c), c < j
+	int32_t np;        // number of update pairs of the sub-diagonal blocks of the column (contiguous)
+	int64_t p0;        // first of them
 };
 
-void launch_factor_stage(const TDevPlan &p, const double *A, double *L, double *Linv,
-	int task_begin, int n_tasks, int n_waves, int *p_flag, hipStream_t stream);
+struct TBlkDesc { // 32 B
+	int64_t loff;      // offset of the block in the factor values
+	int64_t asrc;      // (offset in Lambda values) * 2 + transposed, or -1
+	int64_t p0;        // first update pair
+	uint32_t np_di;    // number of pairs (low 24 bits) | row dimension << 24
+	int32_t xcs;       // scalar offset of the block's row in the permuted workspace
+};
+
+struct TRowEnt { // 16 B: block L(j,c) of block row j
+	int64_t off;       // offset of the block
+	int32_t ycs;       // scalar offset of column c in the permuted workspace
+	int32_t dc;        // dimension of column c
+};
+
+struct TDevPlan {
+	const TColDesc *cols;      // [n] in *schedule* order: the columns of task t are cols[task_ptr[t] .. task_ptr[t+1])
+	const TBlkDesc *blks;      // [l_blocks]
+	const longlong2 *pairs;    // [n_pairs] x = offset of L(i,c) | dim(c) << 56, y = offset of L(j,c)
+	const TRowEnt *rents;      // [n_row_entries]
+	const int64_t *task_ptr;   // [n_tasks+1]
+	int uniform_dim;           // > 0: every block column has this dimension (3, 6, 7 get unrolled kernels)
+};
+
+// numeric factorization of one stage, with the forward substitution y = L^-1 b fused in
+// (b is read at its original position, y written to the permuted workspace w)
+void launch_factor_stage(const TDevPlan &p, const double *A, double *L, double *Linv, const double *b,
+	double *w, int task_begin, int n_tasks, bool b_bottom_stage, int *p_flag, hipStream_t stream);
+// stand-alone forward substitution (another right-hand side with a kept factor)
 void launch_forward_stage(const TDevPlan &p, const double *L, const double *Linv, const double *b,
 	double *w, int task_begin, int n_tasks, hipStream_t stream);
+// backward substitution x = L^-T y, scattering x to its original position
 void launch_backward_stage(const TDevPlan &p, const double *L, const double *Linv, double *w,
 	double *x_out, int task_begin, int n_tasks, hipStream_t stream);
 

@@ -13,14 +13,23 @@
 //   acc(i,j)  = Lambda(i,j) - sum_pairs L(i,c) L(j,c)^T          (lanes = elements of the block)
 //   L(j,j)    = chol(acc(j,j)),  Linv(j) = inv(L(j,j))           (in-wave, shuffles + LDS)
 //   L(i,j)    = acc(i,j) Linv(j)^T
+//   y(j)      = Linv(j) (b(j) - sum_c L(j,c) y(c))               (forward substitution, fused: the
+//               blocks L(j,c) it needs are exactly the operands of the diagonal block's update)
 // Traffic is one read of Lambda, one write of L, plus re-reads of L blocks by the updates that
-// mostly hit L2 (the producer ran in the same wave or in the previous stage): HBM-bound, and in
-// practice latency-bound by the dependency chain -- see DESIGN.md.
+// mostly hit L2 (the producer ran in the same wave or in the previous stage): HBM-bound on paper,
+// latency-bound by the dependency chain in practice -- see DESIGN.md.
+//
+// Kernels are instantiated for uniform block dimension D = 3 / 6 / 7 (SE(2), SE(3), Sim(3) pose
+// graphs: inner loops fully unrolled, all operand loads of an update issued before the FMAs) and
+// for D = 0 (any mix of dimensions <= 8, e.g. poses + landmarks).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sparse_kernels.h"
 
 namespace slampp {
+
+enum { Y_LANE0 = 56 }; // lanes 56.. carry the right-hand side of the column when its dimension is <= 7
+enum { CHUNK = 16 };   // blocks of a column whose partial sums live in LDS at a time (multi-wave kernel)
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -31,255 +40,599 @@ __device__ __forceinline__ void wave_sync()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// acc(r,q) of factor block k: source block of Lambda minus the update pairs
-__device__ __forceinline__ double accumulate_block(const TDevPlan &p, const double *__restrict__ A,
-	const double *L, int64_t k, int r, int q, int di, int dj, bool b_diag)
+// sum over the update pairs e = first, first + step, ... of block (i,j):  sum_t L(i,c)[r,t] L(j,c)[q,t]
+template <int D>
+__device__ __forceinline__ double accumulate_pairs(const longlong2 *__restrict__ pairs, int64_t p0, int np,
+	int first, int step, const double *L, int r, int q, int di, int dj)
 {
 	double acc = 0;
-	const int64_t enc = p.asrc[k];
-	if(enc >= 0) {
-		const int64_t off = enc >> 1;
-		// diagonal blocks: read the upper triangle, which is what the reference's solvers consume
-		// (src/slam/LinearSolver_CholMod.cpp:57); off-diagonal: as stored or transposed
-		const bool b_trans = (enc & 1) || b_diag;
-		acc = b_trans? A[off + q + int64_t(r) * dj] : A[off + r + int64_t(q) * di];
-	}
-	const int64_t p1 = p.pptr[k + 1];
-	for(int64_t e = p.pptr[k]; e < p1; ++ e) {
-		const longlong2 pr = p.pairs[e];
-		const int dc = int(pr.x >> 56);
+	for(int e = first; e < np; e += step) {
+		const longlong2 pr = pairs[p0 + e];
 		const double *a = L + (pr.x & ((int64_t(1) << 56) - 1)) + r;
 		const double *b = L + pr.y + q;
-		#pragma unroll 2
-		for(int t = 0; t < dc; ++ t)
-			acc -= a[t * di] * b[t * dj];
+		if(D) {
+			double av[D? D : 1], bv[D? D : 1];
+			#pragma unroll
+			for(int t = 0; t < D; ++ t) {
+				av[t] = a[t * D];
+				bv[t] = b[t * D];
+			}
+			#pragma unroll
+			for(int t = 0; t < D; ++ t)
+				acc += av[t] * bv[t];
+		} else {
+			const int dc = int(pr.x >> 56);
+			for(int t = 0; t < dc; ++ t)
+				acc += a[t * di] * b[t * dj];
+		}
 	}
 	return acc;
 }
 
-// one task = a chain of block columns eliminated in order by one workgroup of W waves
-template <int W>
-__device__ __forceinline__ void factor_task(const TDevPlan &p, const double *__restrict__ A, double *L,
-	double *Linv, int task, int *p_flag)
+// the same for the diagonal block, driven by the row entries L(j,c) of block row j; lanes flagged
+// b_y accumulate the right-hand side instead: sum_t y_c[t] L(j,c)[q,t]
+template <int D>
+__device__ __forceinline__ double accumulate_row(const TRowEnt *__restrict__ rents, int64_t r0, int nr,
+	int first, int step, const double *L, const double *w, int r, int q, int dj, bool b_y)
 {
-	__shared__ double s_linv[64];      // inv(L_jj), element (r,c) at r + 8 c
-	__shared__ double s_rdiag[8];      // 1 / L_jj(k,k)
-	__shared__ double s_tile[W][64];
-
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int64_t c_end = p.task_ptr[task + 1];
-	for(int64_t c = p.task_ptr[task]; c < c_end; ++ c) {
-		const int j = p.task_cols[c];
-		const int dj = p.dim[j];
-		const int64_t k0 = p.lptr[j];
-		const int nb = int(p.lptr[j + 1] - k0);
-
-		if(wave == 0) {
-			// ---- diagonal block: lanes (r, q), lane = r + q dj ----
-			const bool b_act = lane < dj * dj;
-			const int r = b_act? lane % dj : 0, q = b_act? lane / dj : 0;
-			double a = accumulate_block(p, A, L, k0, r, q, dj, dj, true);
-			if(r < q)
-				a = 0;
-			bool b_bad = false;
-			for(int kk = 0; kk < dj; ++ kk) {
-				double piv = __shfl(a, kk + kk * dj);
-				if(!(piv > 0)) { // also catches NaN
-					b_bad = true;
-					piv = 1;
-				}
-				const double s = 1.0 / sqrt(piv);
-				const double lcol = a * s; // meaningful in lanes (., kk)
-				const double lr = __shfl(lcol, r + kk * dj);
-				const double lq = __shfl(lcol, q + kk * dj);
-				if(q == kk)
-					a = (r >= kk)? lcol : 0;
-				else if(q > kk && r >= q)
-					a -= lr * lq;
-				if(lane == 0)
-					s_rdiag[kk] = s;
+	double acc = 0;
+	for(int e = first; e < nr; e += step) {
+		const TRowEnt en = rents[r0 + e];
+		const double *b = L + en.off + q;
+		const double *a = b_y? w + en.ycs : L + en.off + r;
+		const int as = b_y? 1 : dj;
+		if(D) {
+			double av[D? D : 1], bv[D? D : 1];
+			#pragma unroll
+			for(int t = 0; t < D; ++ t) {
+				av[t] = a[t * as];
+				bv[t] = b[t * D];
 			}
-			if(b_bad && lane == 0)
-				atomicOr(p_flag, 1);
-			if(b_act) {
-				L[p.loff[k0] + lane] = a;
-				s_tile[0][r + 8 * q] = a;
-			}
-			wave_sync();
-			// inverse of the lower-triangular L_jj: lane q computes column q by forward substitution
-			if(lane < dj) {
-				const int cq = lane;
-				for(int rr = 0; rr < dj; ++ rr) {
-					double x;
-					if(rr < cq)
-						x = 0;
-					else if(rr == cq)
-						x = s_rdiag[rr];
-					else {
-						double sum = 0;
-						for(int t = cq; t < rr; ++ t)
-							sum += s_tile[0][rr + 8 * t] * s_linv[t + 8 * cq];
-						x = -sum * s_rdiag[rr];
-					}
-					s_linv[rr + 8 * cq] = x;
-				}
-			}
-			wave_sync();
-			if(b_act)
-				Linv[p.linv_off[j] + lane] = s_linv[r + 8 * q];
+			#pragma unroll
+			for(int t = 0; t < D; ++ t)
+				acc += av[t] * bv[t];
+		} else {
+			for(int t = 0; t < en.dc; ++ t)
+				acc += a[t * as] * b[t * dj];
 		}
-		__syncthreads();
+	}
+	return acc;
+}
 
-		// ---- sub-diagonal blocks: L(i,j) = acc(i,j) * inv(L_jj)^T ----
-		for(int kb = 1 + wave; kb < nb; kb += W) {
-			const int64_t k = k0 + kb;
-			const int di = p.dim[p.lrow[k]];
-			const bool b_act = lane < di * dj;
-			const int r = b_act? lane % di : 0, q = b_act? lane / di : 0;
-			const double acc = accumulate_block(p, A, L, k, r, q, di, dj, false);
-			wave_sync(); // the previous iteration's reads of the tile are done
-			if(b_act)
-				s_tile[wave][r + 8 * q] = acc;
-			wave_sync();
-			double v = 0;
-			for(int t = 0; t <= q; ++ t)
-				v += s_tile[wave][r + 8 * t] * s_linv[q + 8 * t];
-			if(b_act)
-				L[p.loff[k] + lane] = v;
+__device__ __forceinline__ double lambda_element(const double *__restrict__ A, int64_t enc, int r, int q,
+	int di, int dj, bool b_diag)
+{
+	if(enc < 0)
+		return 0;
+	// diagonal blocks: read the upper triangle, which is what the reference's solvers consume
+	// (src/slam/LinearSolver_CholMod.cpp:57); off-diagonal: as stored or transposed
+	const int64_t off = enc >> 1;
+	return ((enc & 1) || b_diag)? A[off + q + int64_t(r) * dj] : A[off + r + int64_t(q) * di];
+}
+
+// wave 0, diagonal block: Cholesky of the d x d block held one element per lane (lane = r + q d),
+// its inverse, the forward-substituted right-hand side; everything is written out
+template <int D>
+__device__ __forceinline__ void finish_diagonal(const TColDesc &cd, double a, double ay, int lane, int r, int q,
+	bool b_act, bool b_y_inline, const TDevPlan &p, double *L, double *Linv, const double *b, double *w,
+	int64_t loff, int *p_flag, double *s_linv, double *s_rdiag, double *s_tile0)
+{
+	const int dj = D? D : cd.dj;
+	if(r < q)
+		a = 0;
+	bool b_bad = false;
+	for(int kk = 0; kk < dj; ++ kk) {
+		double piv = __shfl(a, kk + kk * dj);
+		if(!(piv > 0)) { // also catches NaN
+			b_bad = true;
+			piv = 1;
 		}
-		__syncthreads(); // column j is complete (and visible to this workgroup) before the next one starts
+		const double s = 1.0 / sqrt(piv);
+		const double lcol = a * s; // meaningful in lanes (., kk)
+		const double lr = __shfl(lcol, r + kk * dj);
+		const double lq = __shfl(lcol, q + kk * dj);
+		if(q == kk)
+			a = (r >= kk)? lcol : 0;
+		else if(q > kk && r >= q)
+			a -= lr * lq;
+		if(lane == 0)
+			s_rdiag[kk] = s;
+	}
+	if(b_bad && lane == 0)
+		atomicOr(p_flag, 1);
+	if(b_act) {
+		L[loff + lane] = a;
+		s_tile0[r + 8 * q] = a;
+	}
+	wave_sync();
+	// inverse of the lower-triangular L_jj: lane c computes column c by forward substitution
+	if(lane < dj) {
+		const int cq = lane;
+		for(int rr = 0; rr < dj; ++ rr) {
+			double x;
+			if(rr < cq)
+				x = 0;
+			else if(rr == cq)
+				x = s_rdiag[rr];
+			else {
+				double sum = 0;
+				for(int t = cq; t < rr; ++ t)
+					sum += s_tile0[rr + 8 * t] * s_linv[t + 8 * cq];
+				x = -sum * s_rdiag[rr];
+			}
+			s_linv[rr + 8 * cq] = x;
+		}
+	}
+	wave_sync();
+	if(b_act)
+		Linv[cd.linv_off + lane] = s_linv[r + 8 * q];
+	// y_j = inv(L_jj) (b_j - sum L(j,c) y_c); the bracket sits in ay of lanes Y_LANE0 + t
+	if(b_y_inline) {
+		const int yq = lane - Y_LANE0;
+		double y = 0;
+		for(int t = 0; t < dj; ++ t) {
+			const double vt = __shfl(ay, Y_LANE0 + t);
+			if(yq >= t)
+				y += vt * s_linv[(yq & 7) + 8 * t];
+		}
+		if(yq >= 0 && yq < dj)
+			w[cd.cs_new + yq] = y;
 	}
 }
 
-// bottom stage: whole elimination subtrees, one wave each (the launch that touches most of Lambda and L)
+// dimension-8 columns have no spare lanes for the right-hand side: a second pass by lanes 0..7
+__device__ __forceinline__ void finish_rhs_wide(const TColDesc &cd, int lane, const TDevPlan &p, const double *L,
+	const double *b, double *w, const double *s_linv)
+{
+	const int dj = cd.dj, q = lane & 7;
+	double ay = accumulate_row<0>(p.rents, cd.r0, cd.nr, lane >> 3, 8, L, w, 0, q, dj, true);
+	ay += __shfl_xor(ay, 8);
+	ay += __shfl_xor(ay, 16);
+	ay += __shfl_xor(ay, 32);
+	ay = ((q < dj)? b[cd.cs_src + q] : 0) - ay;
+	double y = 0;
+	for(int t = 0; t < dj; ++ t) {
+		const double vt = __shfl(ay, t);
+		if(q >= t)
+			y += vt * s_linv[q + 8 * t];
+	}
+	if(lane < dj)
+		w[cd.cs_new + lane] = y;
+}
+
+// L(i,j) = acc Linv^T through the wave's LDS tile
+template <int D>
+__device__ __forceinline__ void finish_offdiagonal(double acc, int lane, int r, int q, bool b_act, int dj,
+	double *L, int64_t loff, double *s_tile, const double *s_linv)
+{
+	wave_sync(); // the previous use of the tile is over
+	if(b_act)
+		s_tile[r + 8 * q] = acc;
+	wave_sync();
+	double v = 0;
+	if(D) {
+		#pragma unroll
+		for(int t = 0; t < D; ++ t)
+			if(t <= q) v += s_tile[r + 8 * t] * s_linv[q + 8 * t];
+	} else {
+		for(int t = 0; t <= q; ++ t)
+			v += s_tile[r + 8 * t] * s_linv[q + 8 * t];
+	}
+	if(b_act)
+		L[loff + lane] = v;
+}
+
+// block a lane's element belongs to when all blocks of the column have dimension di x dj
+struct TLaneMap {
+	bool b_act;
+	int r, q;
+};
+
+__device__ __forceinline__ TLaneMap lane_map(int lane, int di, int dj)
+{
+	TLaneMap m;
+	m.b_act = lane < di * dj;
+	m.r = m.b_act? lane % di : 0;
+	m.q = m.b_act? lane / di : 0;
+	return m;
+}
+
+// which sub-diagonal block of the column update pair g belongs to (blocks own consecutive pair ranges)
+__device__ __forceinline__ int pair_block(const TBlkDesc *s_blk, int nb, int64_t g)
+{
+	int kb = 1;
+	while(kb + 1 < nb && s_blk[kb + 1].p0 <= g)
+		++ kb;
+	return kb;
+}
+
+// one update pair: sum_t L(i,c)[r,t] L(j,c)[q,t]
+template <int D>
+__device__ __forceinline__ double pair_product(const longlong2 pr, const double *L, int r, int q, int di, int dj)
+{
+	const double *a = L + (pr.x & ((int64_t(1) << 56) - 1)) + r;
+	const double *b = L + pr.y + q;
+	double sum = 0;
+	if(D) {
+		double av[D? D : 1], bv[D? D : 1];
+		#pragma unroll
+		for(int t = 0; t < D; ++ t) {
+			av[t] = a[t * D];
+			bv[t] = b[t * D];
+		}
+		#pragma unroll
+		for(int t = 0; t < D; ++ t)
+			sum += av[t] * bv[t];
+	} else {
+		const int dc = int(pr.x >> 56);
+		for(int t = 0; t < dc; ++ t)
+			sum += a[t * di] * b[t * dj];
+	}
+	return sum;
+}
+
+// one row entry for the diagonal block (or, in the y lanes, for the right-hand side)
+template <int D>
+__device__ __forceinline__ double row_product(const TRowEnt en, const double *L, const double *w, int r, int q,
+	int dj, bool b_y)
+{
+	const double *b = L + en.off + q;
+	const double *a = b_y? w + en.ycs : L + en.off + r;
+	const int as = b_y? 1 : dj;
+	double sum = 0;
+	if(D) {
+		double av[D? D : 1], bv[D? D : 1];
+		#pragma unroll
+		for(int t = 0; t < D; ++ t) {
+			av[t] = a[t * as];
+			bv[t] = b[t * D];
+		}
+		#pragma unroll
+		for(int t = 0; t < D; ++ t)
+			sum += av[t] * bv[t];
+	} else {
+		for(int t = 0; t < en.dc; ++ t)
+			sum += a[t * as] * b[t * dj];
+	}
+	return sum;
+}
+
+// ---- bottom stage: whole elimination subtrees, one wave each (touches most of Lambda and L) ----
+// With 8 waves per SIMD resident this kernel is bound by instruction issue, not by memory latency
+// (measured: staging the index records of a column through LDS to save dependent loads made it
+// slower), so it keeps the instruction count per column low: one block, one update at a time.
+template <int D>
 __global__ void __launch_bounds__(64)
 factor_subtree_kernel(TDevPlan p, const double *__restrict__ A, double *L, double *Linv,
-	int task_begin, int *p_flag)
+	const double *__restrict__ b, double *w, int task_begin, int *p_flag)
 {
-	factor_task<1>(p, A, L, Linv, task_begin + blockIdx.x, p_flag);
+	__shared__ double s_linv[64];  // inv(L_jj), element (r,c) at r + 8 c
+	__shared__ double s_rdiag[8];  // 1 / L_jj(k,k)
+	__shared__ double s_tile[64];
+	const int lane = threadIdx.x;
+	const int task = task_begin + blockIdx.x;
+	const int64_t c_begin = p.task_ptr[task], c_end = p.task_ptr[task + 1];
+	TColDesc cd_next = p.cols[c_begin];
+	for(int64_t c = c_begin; c < c_end; ++ c) {
+		const TColDesc cd = cd_next;
+		if(c + 1 < c_end)
+			cd_next = p.cols[c + 1]; // index data does not depend on the numbers: fetch it a column ahead
+		const int dj = D? D : cd.dj;
+		const bool b_y_inline = dj <= 7;
+		const bool b_y = b_y_inline && lane >= Y_LANE0 && lane < Y_LANE0 + dj;
+		{
+			const TBlkDesc bd = p.blks[cd.k0];
+			const TLaneMap md = lane_map(lane, dj, dj);
+			const int yq = b_y? lane - Y_LANE0 : md.q;
+			const double init = b_y? b[cd.cs_src + yq] : (md.b_act? lambda_element(A, bd.asrc, md.r, md.q, dj, dj, true) : 0);
+			const double acc = init - accumulate_row<D>(p.rents, cd.r0, cd.nr, 0, 1, L, w, md.r, yq, dj, b_y);
+			finish_diagonal<D>(cd, acc, acc, lane, b_y? 0 : md.r, b_y? 0 : md.q, md.b_act, b_y_inline, p, L, Linv, b, w,
+				bd.loff, p_flag, s_linv, s_rdiag, s_tile);
+			if(!D && !b_y_inline)
+				finish_rhs_wide(cd, lane, p, L, b, w, s_linv);
+		}
+		for(int kb = 1; kb < cd.nb; ++ kb) {
+			const TBlkDesc bd = p.blks[cd.k0 + kb];
+			const int di = D? D : int(bd.np_di >> 24), np = int(bd.np_di & 0xffffff);
+			const TLaneMap m = lane_map(lane, di, dj);
+			const double acc = lambda_element(A, bd.asrc, m.r, m.q, di, dj, false) -
+				accumulate_pairs<D>(p.pairs, bd.p0, np, 0, 1, L, m.r, m.q, di, dj);
+			finish_offdiagonal<D>(acc, lane, m.r, m.q, m.b_act, dj, L, bd.loff, s_tile, s_linv);
+		}
+		__syncthreads(); // column j (and y_j) complete and visible to this wave before the next column reads them
+	}
 }
 
-// upper stages: separator columns / chains, W waves per column
-template <int W>
+// ---- upper stages: separator columns; W waves split the updates of the column ----
+// Fast path (<= CHUNK blocks, <= UP_NR row entries, <= UP_NP pairs): index records staged through
+// LDS by the whole workgroup, update e handled by wave e mod W into that wave's private partial sums.
+enum { UP_NR = 128, UP_NP = 512 };
+
+template <int D, int W>
 __global__ void __launch_bounds__(64 * W)
 factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double *Linv,
-	int task_begin, int *p_flag)
+	const double *__restrict__ b, double *w, int task_begin, int *p_flag)
 {
-	factor_task<W>(p, A, L, Linv, task_begin + blockIdx.x, p_flag);
+	__shared__ double s_linv[64];
+	__shared__ double s_rdiag[8];
+	__shared__ double s_tile[W][64];
+	__shared__ double s_part[W][CHUNK][64]; // partial sums: [wave][block][lane]
+	__shared__ TBlkDesc s_blk[CHUNK];
+	__shared__ TRowEnt s_rent[UP_NR];
+	__shared__ longlong2 s_prec[UP_NP];
+	__shared__ unsigned char s_ptag[UP_NP];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+	const int task = task_begin + blockIdx.x;
+	const int64_t c_begin = p.task_ptr[task], c_end = p.task_ptr[task + 1];
+	for(int64_t c = c_begin; c < c_end; ++ c) {
+		const TColDesc cd = p.cols[c];
+		const int dj = D? D : cd.dj;
+		const bool b_y_inline = dj <= 7;
+		const bool b_y = b_y_inline && lane >= Y_LANE0 && lane < Y_LANE0 + dj;
+		const TLaneMap md = lane_map(lane, dj, dj);
+		const int yq = b_y? lane - Y_LANE0 : md.q;
+		if(cd.nb <= CHUNK && cd.nr <= UP_NR && cd.np <= UP_NP) {
+			for(int e = tid; e < cd.nb; e += 64 * W)
+				s_blk[e] = p.blks[cd.k0 + e];
+			for(int e = tid; e < cd.nr; e += 64 * W)
+				s_rent[e] = p.rents[cd.r0 + e];
+			for(int e = tid; e < cd.np; e += 64 * W)
+				s_prec[e] = p.pairs[cd.p0 + e];
+			__syncthreads();
+			for(int e = tid; e < cd.np; e += 64 * W)
+				s_ptag[e] = (unsigned char)pair_block(s_blk, cd.nb, cd.p0 + e);
+			// phase A: partial sums start from minus the Lambda element in the wave that owns the block
+			double acc0 = 0;
+			if(wave == 0)
+				acc0 = b_y? -b[cd.cs_src + yq] : (md.b_act? -lambda_element(A, s_blk[0].asrc, md.r, md.q, dj, dj, true) : 0);
+			for(int kb = 1; kb < cd.nb; ++ kb) {
+				double init = 0;
+				if(kb % W == wave) {
+					const TBlkDesc bd = s_blk[kb];
+					const int di = D? D : int(bd.np_di >> 24);
+					const TLaneMap m = lane_map(lane, di, dj);
+					init = -lambda_element(A, bd.asrc, m.r, m.q, di, dj, false);
+				}
+				s_part[wave][kb][lane] = init;
+			}
+			__syncthreads(); // tags visible
+			#pragma unroll 2
+			for(int e = wave; e < cd.nr; e += W)
+				acc0 += row_product<D>(s_rent[e], L, w, md.r, yq, dj, b_y);
+			s_part[wave][0][lane] = acc0;
+			#pragma unroll 2
+			for(int e = wave; e < cd.np; e += W) {
+				const int kb = s_ptag[e];
+				const int di = D? D : int(s_blk[kb].np_di >> 24);
+				const TLaneMap m = lane_map(lane, di, dj);
+				s_part[wave][kb][lane] += pair_product<D>(s_prec[e], L, m.r, m.q, di, dj);
+			}
+			__syncthreads();
+			// phase B: the diagonal block first (wave 0), then the sub-diagonal blocks round-robin
+			if(wave == 0) {
+				double acc = 0;
+				#pragma unroll
+				for(int ww = 0; ww < W; ++ ww)
+					acc -= s_part[ww][0][lane];
+				finish_diagonal<D>(cd, acc, acc, lane, b_y? 0 : md.r, b_y? 0 : md.q, md.b_act, b_y_inline, p, L, Linv, b, w,
+					s_blk[0].loff, p_flag, s_linv, s_rdiag, s_tile[0]);
+				if(!D && !b_y_inline)
+					finish_rhs_wide(cd, lane, p, L, b, w, s_linv);
+			}
+			__syncthreads();
+			for(int kb = 1 + wave; kb < cd.nb; kb += W) {
+				const TBlkDesc bd = s_blk[kb];
+				const int di = D? D : int(bd.np_di >> 24);
+				const TLaneMap m = lane_map(lane, di, dj);
+				double acc = 0;
+				#pragma unroll
+				for(int ww = 0; ww < W; ++ ww)
+					acc -= s_part[ww][kb][lane];
+				finish_offdiagonal<D>(acc, lane, m.r, m.q, m.b_act, dj, L, bd.loff, s_tile[wave], s_linv);
+			}
+			__syncthreads(); // LDS records and partial sums consumed; column complete
+			continue;
+		}
+		// general path: any number of blocks, CHUNK at a time, records read from global memory
+		for(int kb0 = 0; kb0 < cd.nb; kb0 += CHUNK) {
+			const int kbn = min(int(CHUNK), cd.nb - kb0);
+			for(int s = 0; s < kbn; ++ s) {
+				const int kb = kb0 + s;
+				double part;
+				if(kb == 0)
+					part = accumulate_row<D>(p.rents, cd.r0, cd.nr, wave, W, L, w, md.r, yq, dj, b_y);
+				else {
+					const TBlkDesc bd = p.blks[cd.k0 + kb];
+					const int di = D? D : int(bd.np_di >> 24), np = int(bd.np_di & 0xffffff);
+					const TLaneMap m = lane_map(lane, di, dj);
+					part = accumulate_pairs<D>(p.pairs, bd.p0, np, wave, W, L, m.r, m.q, di, dj);
+				}
+				s_part[wave][s][lane] = part;
+			}
+			__syncthreads();
+			if(kb0 == 0) {
+				if(wave == 0) {
+					const TBlkDesc bd = p.blks[cd.k0];
+					double acc = b_y? b[cd.cs_src + yq] : (md.b_act? lambda_element(A, bd.asrc, md.r, md.q, dj, dj, true) : 0);
+					#pragma unroll
+					for(int ww = 0; ww < W; ++ ww)
+						acc -= s_part[ww][0][lane];
+					finish_diagonal<D>(cd, acc, acc, lane, b_y? 0 : md.r, b_y? 0 : md.q, md.b_act, b_y_inline, p, L, Linv, b, w,
+						bd.loff, p_flag, s_linv, s_rdiag, s_tile[0]);
+					if(!D && !b_y_inline)
+						finish_rhs_wide(cd, lane, p, L, b, w, s_linv);
+				}
+				__syncthreads();
+			}
+			for(int s = wave; s < kbn; s += W) {
+				const int kb = kb0 + s;
+				if(kb == 0)
+					continue;
+				const TBlkDesc bd = p.blks[cd.k0 + kb];
+				const int di = D? D : int(bd.np_di >> 24);
+				const TLaneMap m = lane_map(lane, di, dj);
+				double acc = lambda_element(A, bd.asrc, m.r, m.q, di, dj, false);
+				#pragma unroll
+				for(int ww = 0; ww < W; ++ ww)
+					acc -= s_part[ww][s][lane];
+				finish_offdiagonal<D>(acc, lane, m.r, m.q, m.b_act, dj, L, bd.loff, s_tile[wave], s_linv);
+			}
+			__syncthreads(); // partial sums consumed; column complete after the last chunk
+		}
+	}
 }
 
-// forward substitution  y_j = inv(L_jj) (b_j - sum_c L(j,c) y_c), one wave per task, lanes = 8 entry
-// groups x 8 rows.  Reads b at its original (unpermuted) position, writes y to the permuted workspace.
+// ---- substitutions: one wave per task, one lane per block of the row / column ----
+template <int D>
+__device__ __forceinline__ void reduce_over_wave(double (&v)[D? D : 8])
+{
+	#pragma unroll
+	for(int i = 0; i < (D? D : 8); ++ i) {
+		#pragma unroll
+		for(int m = 32; m >= 1; m >>= 1)
+			v[i] += __shfl_xor(v[i], m);
+	}
+}
+
+// stand-alone forward substitution y_j = inv(L_jj) (b_j - sum_c L(j,c) y_c) (solve_again)
+template <int D>
 __global__ void __launch_bounds__(64)
 forward_stage_kernel(TDevPlan p, const double *L, const double *Linv, const double *__restrict__ b,
 	double *w, int task_begin)
 {
-	const int lane = threadIdx.x & 63, g = lane >> 3, r = lane & 7;
+	enum { DM = D? D : 8 };
+	const int lane = threadIdx.x;
 	const int task = task_begin + blockIdx.x;
 	const int64_t c_end = p.task_ptr[task + 1];
 	for(int64_t c = p.task_ptr[task]; c < c_end; ++ c) {
-		const int j = p.task_cols[c];
-		const int dj = p.dim[j];
-		const int rr = (r < dj)? r : 0;
-		double acc = 0;
-		const int64_t e1 = p.rptr[j + 1];
-		for(int64_t e = p.rptr[j] + g; e < e1; e += 8) {
-			const int cc = p.rcol[e];
-			const int dc = p.dim[cc];
-			const double *Lb = L + p.roff[e] + rr;
-			const double *y = w + p.cs_new[cc];
-			for(int t = 0; t < dc; ++ t)
-				acc += Lb[t * dj] * y[t];
+		const TColDesc cd = p.cols[c];
+		const int dj = D? D : cd.dj;
+		double v[DM];
+		#pragma unroll
+		for(int i = 0; i < DM; ++ i)
+			v[i] = 0;
+		for(int e = lane; e < cd.nr; e += 64) {
+			const TRowEnt en = p.rents[cd.r0 + e];
+			const double *Lb = L + en.off, *y = w + en.ycs;
+			const int dc = D? D : en.dc;
+			#pragma unroll
+			for(int t = 0; t < DM; ++ t) {
+				if(t < dc) {
+					const double yt = y[t];
+					#pragma unroll
+					for(int i = 0; i < DM; ++ i)
+						if(i < dj) v[i] += Lb[i + t * dj] * yt;
+				}
+			}
 		}
-		acc += __shfl_xor(acc, 8);
-		acc += __shfl_xor(acc, 16);
-		acc += __shfl_xor(acc, 32);
-		const double v = (r < dj)? b[p.cs_src[j] + r] - acc : 0;
-		const double *Li = Linv + p.linv_off[j];
+		reduce_over_wave<D>(v);
+		double val = 0;
+		#pragma unroll
+		for(int i = 0; i < DM; ++ i)
+			if(lane == i) val = v[i];
+		val = (lane < dj)? b[cd.cs_src + lane] - val : 0;
+		const double *Li = Linv + cd.linv_off;
 		double y = 0;
 		for(int t = 0; t < dj; ++ t) {
-			const double vt = __shfl(v, t);
-			if(t <= rr)
-				y += Li[rr + t * dj] * vt;
+			const double vt = __shfl(val, t);
+			if(lane < dj && t <= lane)
+				y += Li[lane + t * dj] * vt;
 		}
 		if(lane < dj)
-			w[p.cs_new[j] + lane] = y;
-		__syncthreads(); // single-wave workgroup: makes y_j visible to the following columns
+			w[cd.cs_new + lane] = y;
+		__syncthreads(); // single-wave workgroup: y_j visible to the following columns
 	}
 }
 
-// backward substitution  x_j = inv(L_jj)^T (y_j - sum_i L(i,j)^T x_i); tasks and columns in reverse.
+// backward substitution x_j = inv(L_jj)^T (y_j - sum_i L(i,j)^T x_i); tasks and columns in reverse.
 // Overwrites the workspace in place and scatters x to its original position.
+template <int D>
 __global__ void __launch_bounds__(64)
 backward_stage_kernel(TDevPlan p, const double *L, const double *Linv, double *w,
 	double *__restrict__ x_out, int task_begin)
 {
-	const int lane = threadIdx.x & 63, g = lane >> 3, q = lane & 7;
+	enum { DM = D? D : 8 };
+	const int lane = threadIdx.x;
 	const int task = task_begin + blockIdx.x;
 	const int64_t c_begin = p.task_ptr[task];
 	for(int64_t c = p.task_ptr[task + 1]; c > c_begin; -- c) {
-		const int j = p.task_cols[c - 1];
-		const int dj = p.dim[j];
-		const int qq = (q < dj)? q : 0;
-		const int64_t k0 = p.lptr[j];
-		const int nb = int(p.lptr[j + 1] - k0);
-		double acc = 0;
-		for(int kb = 1 + g; kb < nb; kb += 8) {
-			const int64_t k = k0 + kb;
-			const int i = p.lrow[k];
-			const int di = p.dim[i];
-			const double *Lb = L + p.loff[k] + int64_t(qq) * di;
-			const double *x = w + p.cs_new[i];
-			for(int t = 0; t < di; ++ t)
-				acc += Lb[t] * x[t];
+		const TColDesc cd = p.cols[c - 1];
+		const int dj = D? D : cd.dj;
+		double v[DM];
+		#pragma unroll
+		for(int i = 0; i < DM; ++ i)
+			v[i] = 0;
+		for(int kb = 1 + lane; kb < cd.nb; kb += 64) {
+			const TBlkDesc bd = p.blks[cd.k0 + kb];
+			const int di = D? D : int(bd.np_di >> 24);
+			const double *Lb = L + bd.loff, *x = w + bd.xcs;
+			#pragma unroll
+			for(int t = 0; t < DM; ++ t) {
+				if(t < di) {
+					const double xt = x[t];
+					#pragma unroll
+					for(int i = 0; i < DM; ++ i)
+						if(i < dj) v[i] += Lb[t + i * di] * xt;
+				}
+			}
 		}
-		acc += __shfl_xor(acc, 8);
-		acc += __shfl_xor(acc, 16);
-		acc += __shfl_xor(acc, 32);
-		const double v = (q < dj)? w[p.cs_new[j] + q] - acc : 0;
-		const double *Li = Linv + p.linv_off[j];
+		reduce_over_wave<D>(v);
+		double val = 0;
+		#pragma unroll
+		for(int i = 0; i < DM; ++ i)
+			if(lane == i) val = v[i];
+		val = (lane < dj)? w[cd.cs_new + lane] - val : 0;
+		const double *Li = Linv + cd.linv_off;
 		double x = 0;
 		for(int t = 0; t < dj; ++ t) {
-			const double vt = __shfl(v, t);
-			if(t >= qq)
-				x += Li[t + qq * dj] * vt;
+			const double vt = __shfl(val, t);
+			if(lane < dj && t >= lane)
+				x += Li[t + lane * dj] * vt;
 		}
 		__syncthreads(); // every lane has read y_j before it is overwritten
 		if(lane < dj) {
-			w[p.cs_new[j] + lane] = x;
-			x_out[p.cs_src[j] + lane] = x;
+			w[cd.cs_new + lane] = x;
+			x_out[cd.cs_src + lane] = x;
 		}
 		__syncthreads();
 	}
 }
 
-void launch_factor_stage(const TDevPlan &p, const double *A, double *L, double *Linv,
-	int task_begin, int n_tasks, int n_waves, int *p_flag, hipStream_t stream)
+// ---- launchers ----
+#define DISPATCH_DIM(D_runtime, CALL) do { switch(D_runtime) { \
+	case 3: { enum { D = 3 }; CALL; } break; \
+	case 6: { enum { D = 6 }; CALL; } break; \
+	case 7: { enum { D = 7 }; CALL; } break; \
+	default: { enum { D = 0 }; CALL; } break; } } while(0)
+
+void launch_factor_stage(const TDevPlan &p, const double *A, double *L, double *Linv, const double *b,
+	double *w, int task_begin, int n_tasks, bool b_bottom_stage, int *p_flag, hipStream_t stream)
 {
 	if(n_tasks <= 0)
 		return;
-	if(n_waves <= 0)
-		hipLaunchKernelGGL(factor_subtree_kernel, dim3(n_tasks), dim3(64), 0, stream, p, A, L, Linv, task_begin, p_flag);
-	else if(n_waves <= 1)
-		hipLaunchKernelGGL(factor_stage_kernel<1>, dim3(n_tasks), dim3(64), 0, stream, p, A, L, Linv, task_begin, p_flag);
-	else if(n_waves <= 4)
-		hipLaunchKernelGGL(factor_stage_kernel<4>, dim3(n_tasks), dim3(256), 0, stream, p, A, L, Linv, task_begin, p_flag);
-	else
-		hipLaunchKernelGGL(factor_stage_kernel<16>, dim3(n_tasks), dim3(1024), 0, stream, p, A, L, Linv, task_begin, p_flag);
+	if(b_bottom_stage) {
+		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_subtree_kernel<D>), dim3(n_tasks), dim3(64), 0, stream,
+			p, A, L, Linv, b, w, task_begin, p_flag));
+	} else {
+		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_stage_kernel<D, 8>), dim3(n_tasks), dim3(512), 0, stream,
+			p, A, L, Linv, b, w, task_begin, p_flag));
+	}
 }
 
 void launch_forward_stage(const TDevPlan &p, const double *L, const double *Linv, const double *b,
 	double *w, int task_begin, int n_tasks, hipStream_t stream)
 {
 	if(n_tasks > 0)
-		hipLaunchKernelGGL(forward_stage_kernel, dim3(n_tasks), dim3(64), 0, stream, p, L, Linv, b, w, task_begin);
+		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((forward_stage_kernel<D>), dim3(n_tasks), dim3(64), 0, stream,
+			p, L, Linv, b, w, task_begin));
 }
 
 void launch_backward_stage(const TDevPlan &p, const double *L, const double *Linv, double *w,
 	double *x_out, int task_begin, int n_tasks, hipStream_t stream)
 {
 	if(n_tasks > 0)
-		hipLaunchKernelGGL(backward_stage_kernel, dim3(n_tasks), dim3(64), 0, stream, p, L, Linv, w, x_out, task_begin);
+		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((backward_stage_kernel<D>), dim3(n_tasks), dim3(64), 0, stream,
+			p, L, Linv, w, x_out, task_begin));
 }
 
 } // namespace slampp
