@@ -8,7 +8,8 @@
 //   potrf_diag : one workgroup factors the 64x64 diagonal tile in registers (4x4 per thread) and
 //                inverts it (so that the panel solve becomes a GEMM)
 //   trsm       : L21 = A21 inv(L11)^T, one workgroup per 64-row tile          (MFMA f64 16x16x4)
-//   syrk       : A22 -= L21 L21^T, one workgroup per lower 64x64 tile        (MFMA f64 16x16x4)
+//   syrk       : A22 -= L21 L21^T, one workgroup per lower 64x64 tile        (MFMA f64 16x16x4),
+//                two-level blocked: panel-local after every step, trailing matrix once per 256 columns
 // The right-hand side rides along as the last row of the matrix, so the forward substitution
 // costs nothing extra; the backward substitution is right-looking, one launch per panel.
 // This is the MFMA-bound kernel of the path: n^3/3 flops (72 GFLOP at 1k cameras).
@@ -40,7 +41,7 @@ void dense_prepare_padding(double *M, int n_pad, int n, hipStream_t stream)
 __device__ __forceinline__ void tile_product(const double *Ps, const double *Qs, int wave, int lane, v4f64 acc[4])
 {
 	const int lo = lane & 15, hi = lane >> 4;
-	#pragma unroll 4
+	#pragma unroll
 	for(int ks = 0; ks < NB / 4; ++ ks) {
 		const int k = ks * 4 + hi;
 		const double a = Qs[k * LDS_LD + 16 * wave + lo];
@@ -55,19 +56,29 @@ __device__ __forceinline__ void tile_product(const double *Ps, const double *Qs,
 // loads the 64 x 64 tile at (row0, col0) of the column-major matrix into LDS as [col][row]
 __device__ __forceinline__ void load_tile(double *Ts, const double *M, int ld, int row0, int col0)
 {
-	const int r = threadIdx.x & 63;
-	for(int c = threadIdx.x >> 6; c < NB; c += 4)
-		Ts[c * LDS_LD + r] = M[size_t(row0 + r) + size_t(col0 + c) * ld];
+	// 16-byte loads: thread t moves rows 2 (t & 31), +1 of columns t >> 5, +8, ...; all loads are
+	// issued before the first LDS store (row0, ld and LDS_LD are even, so everything is 16-B aligned)
+	const int r = (threadIdx.x & 31) * 2, c0 = threadIdx.x >> 5;
+	double2 v[NB / 8];
+	#pragma unroll
+	for(int i = 0; i < NB / 8; ++ i)
+		v[i] = *reinterpret_cast<const double2*>(M + size_t(row0 + r) + size_t(col0 + c0 + 8 * i) * ld);
+	#pragma unroll
+	for(int i = 0; i < NB / 8; ++ i)
+		*reinterpret_cast<double2*>(Ts + (c0 + 8 * i) * LDS_LD + r) = v[i];
 }
 
 // ---- diagonal tile: Cholesky in registers + inverse ----
+// Cholesky: thread (br, bc) owns a 4 x 4 register tile; step k broadcasts column k through a
+// ping-pong LDS buffer (one barrier per step).  Inverse: thread c of wave 0 owns column c of
+// inv(L) in 64 registers; the two loops are fully unrolled so that the column never leaves the
+// register file, L(r,t) comes from LDS as a broadcast read.
 __global__ void __launch_bounds__(256)
 potrf_diag_kernel(double *M, int ld, int kb, int n, double *invL, int *p_flag)
 {
-	__shared__ double s_col[NB];       // column k of the trailing matrix at step k (unscaled)
+	__shared__ double s_col[2][NB];    // column k of the trailing matrix at step k (unscaled), double-buffered
 	__shared__ double s_piv[NB];
 	__shared__ double s_L[NB][NB + 1];
-	__shared__ double s_X[NB][NB + 1]; // inverse, [column][row]
 
 	const int t = threadIdx.x;
 	const int br = t >> 4, bc = t & 15; // 4 x 4 register tile at rows 4 br.., columns 4 bc..
@@ -85,14 +96,14 @@ potrf_diag_kernel(double *M, int ld, int kb, int n, double *invL, int *p_flag)
 		#pragma unroll
 		for(int kj = 0; kj < 4; ++ kj) {
 			const int k = 4 * k4 + kj;
-			__syncthreads(); // the previous step's reads of s_col are done
+			double *col = s_col[k & 1];
 			if(bc == k4) { // owners of column k publish it
 				#pragma unroll
 				for(int i = 0; i < 4; ++ i)
-					s_col[4 * br + i] = a[i][kj];
+					col[4 * br + i] = a[i][kj];
 			}
 			__syncthreads();
-			double piv = s_col[k];
+			double piv = col[k];
 			if(!(piv > 0)) {
 				if(o + k < n)
 					b_bad = true;
@@ -105,8 +116,8 @@ potrf_diag_kernel(double *M, int ld, int kb, int n, double *invL, int *p_flag)
 				double cr[4], cc[4];
 				#pragma unroll
 				for(int i = 0; i < 4; ++ i) {
-					cr[i] = s_col[4 * br + i];
-					cc[i] = s_col[4 * bc + i] * s2;
+					cr[i] = col[4 * br + i];
+					cc[i] = col[4 * bc + i] * s2;
 				}
 				#pragma unroll
 				for(int i = 0; i < 4; ++ i)
@@ -141,32 +152,21 @@ potrf_diag_kernel(double *M, int ld, int kb, int n, double *invL, int *p_flag)
 		}
 	}
 	__syncthreads();
-	// inverse of the lower-triangular tile, 4 lanes per column
-	{
-		const int col = t >> 2, part = t & 3;
+	if(t < NB) {
+		// column c = t of X = inv(L): x_r = ((r == c) - sum_{u < r} L(r,u) x_u) / L(r,r); x_u = 0 for u < c falls out
+		const int c = t;
+		double x[NB];
+		#pragma unroll
 		for(int r = 0; r < NB; ++ r) {
 			double sum = 0;
-			for(int u = col + part; u < r; u += 4)
-				sum += s_L[r][u] * s_X[col][u];
-			sum += __shfl_xor(sum, 1);
-			sum += __shfl_xor(sum, 2);
-			double x = 0;
-			if(r == col)
-				x = 1.0 / s_L[r][r];
-			else if(r > col)
-				x = -sum / s_L[r][r];
-			if(part == 0)
-				s_X[col][r] = x;
-			// the 4 lanes of a column sit in one wave: LDS accesses of a wave execute in order
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			#pragma unroll
+			for(int u = 0; u < r; ++ u)
+				sum += s_L[r][u] * x[u];
+			x[r] = (((r == c)? 1.0 : 0.0) - sum) / s_L[r][r];
 		}
-	}
-	__syncthreads();
-	for(int e = t; e < NB * NB; e += 256) {
-		const int r = e & 63, c = e >> 6;
-		invL[r + c * NB] = s_X[c][r]; // column-major inverse
+		#pragma unroll
+		for(int r = 0; r < NB; ++ r)
+			invL[r + c * NB] = x[r]; // column-major inverse
 	}
 }
 
@@ -192,46 +192,84 @@ trsm_kernel(double *M, int ld, int kb, const double *invL)
 			M[size_t(row0 + 16 * c + lo) + size_t(col0 + 16 * wave + hi + 4 * reg) * ld] = acc[c][reg];
 }
 
-// ---- trailing update: A22 -= L21 L21^T (lower tiles only) ----
+// ---- symmetric update: A(ti,tj) -= sum over K tiles kt in [k0, k1) of L(ti,kt) L(tj,kt)^T ----
+// for target column tiles tj in [c0, c1) and row tiles ti in [tj, n_blocks).  One workgroup per
+// 64 x 64 target tile; the read-modify-write of the target happens once, after the whole K range.
+// Two-level blocking: inside an outer panel (4 tiles = 256 columns) only the panel's own columns are
+// updated after every 64-wide step (k1 - k0 = 1); the big trailing matrix is touched once per outer
+// panel with K = 256, which cuts its HBM traffic fourfold compared with 64-wide right-looking.
 __global__ void __launch_bounds__(256)
-syrk_kernel(double *M, int ld, int kb, int n_tiles)
+syrk_kernel(double *M, int ld, int n_blocks, int k0, int k1, int c0, int c1)
 {
 	__shared__ double Ps[NB * LDS_LD];
 	__shared__ double Qs[NB * LDS_LD];
-	// linear index -> (ti >= tj)
-	int ti = int((sqrt(8.0 * double(blockIdx.x) + 1.0) - 1.0) * 0.5);
-	while((ti + 1) * (ti + 2) / 2 <= int(blockIdx.x))
-		++ ti;
-	while(ti * (ti + 1) / 2 > int(blockIdx.x))
-		-- ti;
-	const int tj = int(blockIdx.x) - ti * (ti + 1) / 2;
+	// linear index -> (tj, ti): column tile by column tile, rows tj .. n_blocks-1
+	int tj = c0, idx = int(blockIdx.x);
+	if(c1 == n_blocks) { // full lower triangle of the trailing matrix: closed form on the reversed index
+		const int T = n_blocks - c0;
+		const int total = T * (T + 1) / 2, rev = total - 1 - idx; // rev counts from the last (smallest) column
+		int m = int((sqrt(8.0 * double(rev) + 1.0) - 1.0) * 0.5);
+		while((m + 1) * (m + 2) / 2 <= rev) ++ m;
+		while(m * (m + 1) / 2 > rev) -- m;
+		// column with m+1 rows is tj = n_blocks - 1 - m; position inside it, counted from the end
+		tj = n_blocks - 1 - m;
+		idx = m - (rev - m * (m + 1) / 2);
+	} else {
+		while(idx >= n_blocks - tj) {
+			idx -= n_blocks - tj;
+			++ tj;
+		}
+	}
+	const int ti = tj + idx;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int row0 = (kb + 1 + ti) * NB, colq = (kb + 1 + tj) * NB, colp = kb * NB;
-	load_tile(Ps, M, ld, row0, colp);
-	load_tile(Qs, M, ld, colq, colp);
-	__syncthreads();
-	v4f64 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-	tile_product(Ps, Qs, wave, lane, acc);
+	const int row0 = ti * NB, colq = tj * NB;
 	const int lo = lane & 15, hi = lane >> 4;
+	// the target tile is requested first: its HBM latency hides behind the K loop
+	double cv[4][4];
 	#pragma unroll
 	for(int c = 0; c < 4; ++ c)
 		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg) {
-			const size_t idx = size_t(row0 + 16 * c + lo) + size_t(colq + 16 * wave + hi + 4 * reg) * ld;
-			M[idx] -= acc[c][reg];
-		}
+		for(int reg = 0; reg < 4; ++ reg)
+			cv[c][reg] = M[size_t(row0 + 16 * c + lo) + size_t(colq + 16 * wave + hi + 4 * reg) * ld];
+	v4f64 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+	for(int kt = k0; kt < k1; ++ kt) {
+		if(kt > k0)
+			__syncthreads(); // the previous K tile has been consumed
+		load_tile(Ps, M, ld, row0, kt * NB);
+		load_tile(Qs, M, ld, colq, kt * NB);
+		__syncthreads();
+		tile_product(Ps, Qs, wave, lane, acc);
+	}
+	#pragma unroll
+	for(int c = 0; c < 4; ++ c)
+		#pragma unroll
+		for(int reg = 0; reg < 4; ++ reg)
+			M[size_t(row0 + 16 * c + lo) + size_t(colq + 16 * wave + hi + 4 * reg) * ld] = cv[c][reg] - acc[c][reg];
 }
+
+enum { OUTER_TILES = 4 }; // outer panel = 4 x 64 columns
 
 void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag, hipStream_t stream)
 {
 	const int n_blocks = n_pad / NB;
-	for(int kb = 0; kb < n_blocks; ++ kb) {
-		double *invL = p_invdiag + size_t(kb) * NB * NB;
-		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, stream, M, n_pad, kb, n, invL, p_flag);
-		const int n_tiles = n_blocks - kb - 1;
-		if(n_tiles > 0) {
-			hipLaunchKernelGGL(trsm_kernel, dim3(n_tiles), dim3(256), 0, stream, M, n_pad, kb, invL);
-			hipLaunchKernelGGL(syrk_kernel, dim3(n_tiles * (n_tiles + 1) / 2), dim3(256), 0, stream, M, n_pad, kb, n_tiles);
+	for(int ob = 0; ob < n_blocks; ob += OUTER_TILES) {
+		const int oe = (ob + OUTER_TILES < n_blocks)? ob + OUTER_TILES : n_blocks;
+		for(int kb = ob; kb < oe; ++ kb) {
+			double *invL = p_invdiag + size_t(kb) * NB * NB;
+			hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, stream, M, n_pad, kb, n, invL, p_flag);
+			const int n_below = n_blocks - kb - 1;
+			if(n_below > 0)
+				hipLaunchKernelGGL(trsm_kernel, dim3(n_below), dim3(256), 0, stream, M, n_pad, kb, invL);
+			if(kb + 1 < oe) { // update the rest of the outer panel with this 64-wide step
+				int n_tiles = 0;
+				for(int tj = kb + 1; tj < oe; ++ tj)
+					n_tiles += n_blocks - tj;
+				hipLaunchKernelGGL(syrk_kernel, dim3(n_tiles), dim3(256), 0, stream, M, n_pad, n_blocks, kb, kb + 1, kb + 1, oe);
+			}
+		}
+		if(oe < n_blocks) { // trailing matrix, once per outer panel, K = the whole panel
+			const int T = n_blocks - oe;
+			hipLaunchKernelGGL(syrk_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, stream, M, n_pad, n_blocks, ob, oe, oe, n_blocks);
 		}
 	}
 }

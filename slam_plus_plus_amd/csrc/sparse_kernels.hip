@@ -545,49 +545,61 @@ forward_stage_kernel(TDevPlan p, const double *L, const double *Linv, const doub
 }
 
 // backward substitution x_j = inv(L_jj)^T (y_j - sum_i L(i,j)^T x_i); tasks and columns in reverse.
+// Lanes = 8 block slots x 8 columns of the block: lane (g, q) sums L(i,j)[:,q]^T x_i over the blocks
+// kb = 1 + g, 9 + g, ...; three shuffle steps combine the slots (a column of an elimination subtree
+// has 2-3 sub-diagonal blocks, a separator column a few dozen).
 // Overwrites the workspace in place and scatters x to its original position.
 template <int D>
 __global__ void __launch_bounds__(64)
 backward_stage_kernel(TDevPlan p, const double *L, const double *Linv, double *w,
 	double *__restrict__ x_out, int task_begin)
 {
-	enum { DM = D? D : 8 };
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x, g = lane >> 3, q = lane & 7;
 	const int task = task_begin + blockIdx.x;
 	const int64_t c_begin = p.task_ptr[task];
 	for(int64_t c = p.task_ptr[task + 1]; c > c_begin; -- c) {
 		const TColDesc cd = p.cols[c - 1];
 		const int dj = D? D : cd.dj;
-		double v[DM];
-		#pragma unroll
-		for(int i = 0; i < DM; ++ i)
-			v[i] = 0;
-		for(int kb = 1 + lane; kb < cd.nb; kb += 64) {
+		const int qq = (q < dj)? q : 0;
+		double acc = 0;
+		for(int kb = 1 + g; kb < cd.nb; kb += 8) {
 			const TBlkDesc bd = p.blks[cd.k0 + kb];
 			const int di = D? D : int(bd.np_di >> 24);
-			const double *Lb = L + bd.loff, *x = w + bd.xcs;
-			#pragma unroll
-			for(int t = 0; t < DM; ++ t) {
-				if(t < di) {
-					const double xt = x[t];
-					#pragma unroll
-					for(int i = 0; i < DM; ++ i)
-						if(i < dj) v[i] += Lb[t + i * di] * xt;
+			const double *Lb = L + bd.loff + qq * di, *x = w + bd.xcs;
+			if(D) {
+				double lv[D? D : 1], xv[D? D : 1];
+				#pragma unroll
+				for(int t = 0; t < D; ++ t) {
+					lv[t] = Lb[t];
+					xv[t] = x[t];
 				}
+				#pragma unroll
+				for(int t = 0; t < D; ++ t)
+					acc += lv[t] * xv[t];
+			} else {
+				for(int t = 0; t < di; ++ t)
+					acc += Lb[t] * x[t];
 			}
 		}
-		reduce_over_wave<D>(v);
-		double val = 0;
-		#pragma unroll
-		for(int i = 0; i < DM; ++ i)
-			if(lane == i) val = v[i];
-		val = (lane < dj)? w[cd.cs_new + lane] - val : 0;
+		acc += __shfl_xor(acc, 8);
+		acc += __shfl_xor(acc, 16);
+		acc += __shfl_xor(acc, 32);
+		const double val = (q < dj)? w[cd.cs_new + q] - acc : 0; // every slot g holds the same totals
 		const double *Li = Linv + cd.linv_off;
 		double x = 0;
-		for(int t = 0; t < dj; ++ t) {
-			const double vt = __shfl(val, t);
-			if(lane < dj && t >= lane)
-				x += Li[t + lane * dj] * vt;
+		if(D) {
+			#pragma unroll
+			for(int t = 0; t < D; ++ t) {
+				const double vt = __shfl(val, t);
+				if(t >= qq)
+					x += Li[t + qq * D] * vt;
+			}
+		} else {
+			for(int t = 0; t < dj; ++ t) {
+				const double vt = __shfl(val, t);
+				if(t >= qq)
+					x += Li[t + qq * dj] * vt;
+			}
 		}
 		__syncthreads(); // every lane has read y_j before it is overwritten
 		if(lane < dj) {
@@ -610,7 +622,9 @@ void launch_factor_stage(const TDevPlan &p, const double *A, double *L, double *
 {
 	if(n_tasks <= 0)
 		return;
-	if(b_bottom_stage) {
+	// one wave per task for the bottom stage and for wide stages (more tasks than the 8-wave kernel
+	// can keep resident at 2 workgroups per CU): there, throughput matters more than the latency of one column
+	if(b_bottom_stage || n_tasks > 1024) {
 		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_subtree_kernel<D>), dim3(n_tasks), dim3(64), 0, stream,
 			p, A, L, Linv, b, w, task_begin, p_flag));
 	} else {
