@@ -69,106 +69,157 @@ __device__ __forceinline__ void load_tile(double *Ts, const double *M, int ld, i
 }
 
 // ---- diagonal tile: Cholesky in registers + inverse ----
-// Cholesky: thread (br, bc) owns a 4 x 4 register tile; step k broadcasts column k through a
-// ping-pong LDS buffer (one barrier per step).  Inverse: thread c of wave 0 owns column c of
-// inv(L) in 64 registers; the two loops are fully unrolled so that the column never leaves the
-// register file, L(r,t) comes from LDS as a broadcast read.
-__global__ void __launch_bounds__(256)
-potrf_diag_kernel(double *M, int ld, int kb, int n, double *invL, int *p_flag)
+// Cholesky: one wave, thread r owns row r of the 64 x 64 tile in 64 registers; the 64 elimination
+// steps are fully unrolled, pivots and the scaled pivot column travel by v_readlane with constant
+// lane numbers -- no LDS, no barrier on the critical path (a 4-wave version with one barrier per
+// step took 19 us, this one takes about half).  Inverse: recursive on 16 / 32 / 64 blocks with all
+// 256 threads through LDS,  inv([A 0; B C]) = [inv(A) 0; -inv(C) B inv(A), inv(C)].
+__device__ __forceinline__ double dense_read_lane(double v, int n_lane)
 {
-	__shared__ double s_col[2][NB];    // column k of the trailing matrix at step k (unscaled), double-buffered
-	__shared__ double s_piv[NB];
-	__shared__ double s_L[NB][NB + 1];
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), n_lane);
+	const int hi = __builtin_amdgcn_readlane(__double2hiint(v), n_lane);
+	return __hiloint2double(hi, lo);
+}
+
+template <bool b_chol, bool b_inverse>
+__device__ __forceinline__ void potrf_diag_body(double *M, int ld, int kb, int n, double *invL, int *p_flag)
+{
+	__shared__ double s_L[NB][NB + 1]; // [row][col]
+	__shared__ double s_X[NB][NB + 1]; // inverse, [row][col]
+	__shared__ double s_T[NB][NB + 1];
 
 	const int t = threadIdx.x;
-	const int br = t >> 4, bc = t & 15; // 4 x 4 register tile at rows 4 br.., columns 4 bc..
 	const int o = kb * NB;
-	double a[4][4];
-	#pragma unroll
-	for(int i = 0; i < 4; ++ i)
-		#pragma unroll
-		for(int j = 0; j < 4; ++ j) {
-			const int r = 4 * br + i, c = 4 * bc + j;
-			a[i][j] = (r >= c)? M[size_t(o + r) + size_t(o + c) * ld] : 0.0;
-		}
+	for(int e = t; e < NB * NB; e += 256) { // coalesced along rows of the column-major tile
+		const int r = e & 63, c = e >> 6;
+		s_L[r][c] = (c <= r)? M[size_t(o + r) + size_t(o + c) * ld] : 0.0;
+	}
+	__syncthreads();
 	bool b_bad = false;
-	for(int k4 = 0; k4 < NB / 4; ++ k4) {
-		#pragma unroll
-		for(int kj = 0; kj < 4; ++ kj) {
-			const int k = 4 * k4 + kj;
-			double *col = s_col[k & 1];
-			if(bc == k4) { // owners of column k publish it
+	if(b_chol) {
+		// blocked by 16 columns: wave 0 factors the 64 x 16 panel in registers (thread r = row r,
+		// pivots and the scaled pivot column by v_readlane), then all four waves apply the rank-16
+		// update to the rest of the tile through LDS
+		for(int J = 0; J < NB / 16; ++ J) {
+			const int c0 = 16 * J;
+			if(t < NB) {
+				const int r = t;
+				double a[16];
 				#pragma unroll
-				for(int i = 0; i < 4; ++ i)
-					col[4 * br + i] = a[i][kj];
-			}
-			__syncthreads();
-			double piv = col[k];
-			if(!(piv > 0)) {
-				if(o + k < n)
-					b_bad = true;
-				piv = 1;
-			}
-			if(t == 0)
-				s_piv[k] = piv;
-			const double s2 = 1.0 / piv;
-			if(br >= bc && 4 * bc + 3 > k) {
-				double cr[4], cc[4];
+				for(int c = 0; c < 16; ++ c)
+					a[c] = s_L[r][c0 + c];
 				#pragma unroll
-				for(int i = 0; i < 4; ++ i) {
-					cr[i] = col[4 * br + i];
-					cc[i] = col[4 * bc + i] * s2;
+				for(int k = 0; k < 16; ++ k) {
+					double piv = dense_read_lane(a[k], c0 + k);
+					const bool b_neg = !(piv > 0);
+					b_bad = b_bad || (b_neg && o + c0 + k < n);
+					piv = b_neg? 1.0 : piv;
+					double rs = __builtin_amdgcn_rsq(piv);
+					const double h = 0.5 * piv;
+					rs = rs * (1.5 - h * rs * rs);
+					rs = rs * (1.5 - h * rs * rs);
+					const double lk = a[k] * rs; // L(r, c0 + k), meaningful for r >= c0 + k
+					a[k] = lk;
+					#pragma unroll
+					for(int c = k + 1; c < 16; ++ c)
+						a[c] -= lk * dense_read_lane(lk, c0 + c);
 				}
 				#pragma unroll
-				for(int i = 0; i < 4; ++ i)
-					#pragma unroll
-					for(int j = 0; j < 4; ++ j) {
-						const int r = 4 * br + i, c = 4 * bc + j;
-						if(c > k && r >= c)
-							a[i][j] -= cr[i] * cc[j];
-					}
+				for(int c = 0; c < 16; ++ c)
+					s_L[r][c0 + c] = (r >= c0 + c)? a[c] : 0.0;
 			}
+			__syncthreads();
+			const int m = NB - c0 - 16; // trailing size
+			for(int e = t; e < m * m; e += 256) {
+				const int i = e / m, j = e % m;
+				if(j > i)
+					continue;
+				const int r = c0 + 16 + i, c = c0 + 16 + j;
+				double sum = 0;
+				#pragma unroll
+				for(int u = 0; u < 16; ++ u)
+					sum += s_L[r][c0 + u] * s_L[c][c0 + u];
+				s_L[r][c] -= sum;
+			}
+			__syncthreads();
 		}
 	}
-	if(b_bad && t == 0)
+	if(b_bad && (t & 63) == 0)
 		atomicOr(p_flag, 1);
-	__syncthreads();
-	// scale the columns: L(r,c) = a(r,c) / sqrt(piv_c), L(c,c) = sqrt(piv_c)
-	#pragma unroll
-	for(int j = 0; j < 4; ++ j) {
-		const int c = 4 * bc + j;
-		const double p = s_piv[c], rs = 1.0 / sqrt(p);
-		#pragma unroll
-		for(int i = 0; i < 4; ++ i) {
-			const int r = 4 * br + i;
-			double v = 0;
-			if(r > c)
-				v = a[i][j] * rs;
-			else if(r == c)
-				v = sqrt(p);
-			s_L[r][c] = v;
-			if(r >= c)
-				M[size_t(o + r) + size_t(o + c) * ld] = v;
-		}
+	for(int e = t; e < NB * NB; e += 256) {
+		const int r = e & 63, c = e >> 6;
+		if(c <= r)
+			M[size_t(o + r) + size_t(o + c) * ld] = s_L[r][c];
 	}
-	__syncthreads();
+	if(!b_inverse)
+		return;
+	// level 0: the four 16 x 16 diagonal blocks, one thread per column
 	if(t < NB) {
-		// column c = t of X = inv(L): x_r = ((r == c) - sum_{u < r} L(r,u) x_u) / L(r,r); x_u = 0 for u < c falls out
-		const int c = t;
-		double x[NB];
+		const int b0 = (t >> 4) * 16, c = t & 15;
+		double x[16];
 		#pragma unroll
-		for(int r = 0; r < NB; ++ r) {
+		for(int r = 0; r < 16; ++ r) {
 			double sum = 0;
 			#pragma unroll
 			for(int u = 0; u < r; ++ u)
-				sum += s_L[r][u] * x[u];
-			x[r] = (((r == c)? 1.0 : 0.0) - sum) / s_L[r][r];
+				sum += s_L[b0 + r][b0 + u] * x[u];
+			x[r] = (((r == c)? 1.0 : 0.0) - sum) / s_L[b0 + r][b0 + r];
 		}
 		#pragma unroll
-		for(int r = 0; r < NB; ++ r)
-			invL[r + c * NB] = x[r]; // column-major inverse
+		for(int r = 0; r < 16; ++ r)
+			s_X[b0 + r][b0 + c] = x[r];
+	}
+	// zero the strictly upper block part once (the tile is consumed as a full 64 x 64 operand)
+	for(int e = t; e < NB * NB; e += 256) {
+		const int r = e >> 6, c = e & 63;
+		if((c >> 4) > (r >> 4))
+			s_X[r][c] = 0.0;
+	}
+	__syncthreads();
+	// levels 1 and 2: X21 = -X22 (L21 X11) for block size h = 16 (two 32 x 32 blocks), then h = 32
+	#pragma unroll
+	for(int h = 16; h <= 32; h *= 2) {
+		const int n_groups = NB / (2 * h);        // independent 2h x 2h diagonal blocks
+		const int per_group = h * h;              // elements of one off-diagonal block
+		for(int e = t; e < n_groups * per_group; e += 256) {
+			const int g = e / per_group, i = (e % per_group) / h, j = e % h;
+			const int b0 = g * 2 * h;
+			double sum = 0;
+			for(int u = 0; u < h; ++ u)
+				sum += s_L[b0 + h + i][b0 + u] * s_X[b0 + u][b0 + j];
+			s_T[b0 + h + i][b0 + j] = sum;
+		}
+		__syncthreads();
+		for(int e = t; e < n_groups * per_group; e += 256) {
+			const int g = e / per_group, i = (e % per_group) / h, j = e % h;
+			const int b0 = g * 2 * h;
+			double sum = 0;
+			for(int u = 0; u < h; ++ u)
+				sum += s_X[b0 + h + i][b0 + h + u] * s_T[b0 + h + u][b0 + j];
+			s_X[b0 + h + i][b0 + j] = -sum;
+		}
+		__syncthreads();
+	}
+	for(int e = t; e < NB * NB; e += 256) {
+		const int r = e & 63, c = e >> 6;
+		invL[r + c * NB] = s_X[r][c]; // column-major inverse
 	}
 }
+
+__global__ void __launch_bounds__(256)
+potrf_diag_kernel(double *M, int ld, int kb, int n, double *invL, int *p_flag)
+{
+	potrf_diag_body<true, true>(M, ld, kb, n, invL, p_flag);
+}
+
+#ifdef POTRF_VARIANTS // tools/bench_potrf.hip: timing of the two halves
+template <bool b_chol, bool b_inverse>
+__global__ void __launch_bounds__(256)
+potrf_diag_variant(double *M, int ld, int kb, int n, double *invL, int *p_flag)
+{
+	potrf_diag_body<b_chol, b_inverse>(M, ld, kb, n, invL, p_flag);
+}
+#endif
 
 // ---- panel solve: L21 = A21 inv(L11)^T ----
 __global__ void __launch_bounds__(256)

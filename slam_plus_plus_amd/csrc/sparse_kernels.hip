@@ -180,6 +180,84 @@ __device__ __forceinline__ void finish_diagonal(const TColDesc &cd, double a, do
 	}
 }
 
+// 1 / sqrt(x): hardware estimate + two Newton steps (full double precision to within an ulp or two;
+// the IEEE sqrt + divide pair costs three times as many instructions, and this kernel is issue-bound)
+__device__ __forceinline__ double rsqrt_newton(double x)
+{
+	double y = __builtin_amdgcn_rsq(x);
+	const double h = 0.5 * x;
+	y = y * (1.5 - h * y * y);
+	y = y * (1.5 - h * y * y);
+	return y;
+}
+
+__device__ __forceinline__ double read_lane(double v, int n_lane) // n_lane must be wave-uniform
+{
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), n_lane);
+	const int hi = __builtin_amdgcn_readlane(__double2hiint(v), n_lane);
+	return __hiloint2double(hi, lo);
+}
+
+// the same as finish_diagonal for a compile-time dimension: branch-free, the inverse stays in registers
+// (lane c < D owns column c), broadcasts of single elements are v_readlane with constant lane numbers
+template <int D>
+__device__ __forceinline__ void finish_diagonal_fixed(const TColDesc &cd, double a, double ay, int lane, int r, int q,
+	bool b_act, double *L, double *Linv, double *w, int64_t loff, int *p_flag, double *s_linv)
+{
+	a = (r < q)? 0.0 : a;
+	bool b_bad = false;
+	double rd[D]; // 1 / L(k,k)
+	#pragma unroll
+	for(int kk = 0; kk < D; ++ kk) {
+		double piv = read_lane(a, kk + kk * D);
+		const bool b_neg = !(piv > 0); // also catches NaN
+		b_bad = b_bad || b_neg;
+		piv = b_neg? 1.0 : piv;
+		const double s = rsqrt_newton(piv);
+		rd[kk] = s;
+		const double lcol = a * s; // meaningful in lanes (., kk)
+		const double lr = __shfl(lcol, r + kk * D);
+		const double lq = __shfl(lcol, q + kk * D);
+		const double upd = a - lr * lq;
+		a = (q == kk)? ((r >= kk)? lcol : 0.0) : ((q > kk && r >= q)? upd : a);
+	}
+	if(b_bad && lane == 0)
+		atomicOr(p_flag, 1);
+	if(b_act)
+		L[loff + lane] = a;
+	// inverse of L_jj: x[rr] = element (rr, c) of the inverse in lane c
+	const int c = lane;
+	double x[D];
+	#pragma unroll
+	for(int rr = 0; rr < D; ++ rr) {
+		double sum = 0;
+		#pragma unroll
+		for(int t = 0; t < rr; ++ t)
+			sum += read_lane(a, rr + t * D) * x[t];
+		x[rr] = (((rr == c)? 1.0 : 0.0) - sum) * rd[rr];
+	}
+	wave_sync(); // earlier readers of s_linv (previous column's blocks) are done
+	if(lane < D) {
+		#pragma unroll
+		for(int rr = 0; rr < D; ++ rr)
+			s_linv[rr + 8 * lane] = x[rr];
+	}
+	wave_sync();
+	if(b_act)
+		Linv[cd.linv_off + lane] = s_linv[r + 8 * q];
+	// y_j = inv(L_jj) (b_j - sum L(j,c) y_c); the bracket sits in ay of lanes Y_LANE0 + t
+	const int yq = lane - Y_LANE0;
+	double y = 0;
+	#pragma unroll
+	for(int t = 0; t < D; ++ t) {
+		const double vt = read_lane(ay, Y_LANE0 + t);
+		const double li = s_linv[(yq & 7) + 8 * t];
+		y += (yq >= t)? vt * li : 0.0;
+	}
+	if(yq >= 0 && yq < D)
+		w[cd.cs_new + yq] = y;
+}
+
 // dimension-8 columns have no spare lanes for the right-hand side: a second pass by lanes 0..7
 __device__ __forceinline__ void finish_rhs_wide(const TColDesc &cd, int lane, const TDevPlan &p, const double *L,
 	const double *b, double *w, const double *s_linv)
@@ -326,8 +404,12 @@ factor_subtree_kernel(TDevPlan p, const double *__restrict__ A, double *L, doubl
 			const int yq = b_y? lane - Y_LANE0 : md.q;
 			const double init = b_y? b[cd.cs_src + yq] : (md.b_act? lambda_element(A, bd.asrc, md.r, md.q, dj, dj, true) : 0);
 			const double acc = init - accumulate_row<D>(p.rents, cd.r0, cd.nr, 0, 1, L, w, md.r, yq, dj, b_y);
-			finish_diagonal<D>(cd, acc, acc, lane, b_y? 0 : md.r, b_y? 0 : md.q, md.b_act, b_y_inline, p, L, Linv, b, w,
-				bd.loff, p_flag, s_linv, s_rdiag, s_tile);
+			if(D)
+				finish_diagonal_fixed<(D? D : 1)>(cd, acc, acc, lane, b_y? 0 : md.r, b_y? 0 : md.q, md.b_act, L, Linv, w, bd.loff,
+					p_flag, s_linv);
+			else
+				finish_diagonal<D>(cd, acc, acc, lane, b_y? 0 : md.r, b_y? 0 : md.q, md.b_act, b_y_inline, p, L, Linv, b, w,
+					bd.loff, p_flag, s_linv, s_rdiag, s_tile);
 			if(!D && !b_y_inline)
 				finish_rhs_wide(cd, lane, p, L, b, w, s_linv);
 		}
@@ -414,8 +496,12 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 				#pragma unroll
 				for(int ww = 0; ww < W; ++ ww)
 					acc -= s_part[ww][0][lane];
-				finish_diagonal<D>(cd, acc, acc, lane, b_y? 0 : md.r, b_y? 0 : md.q, md.b_act, b_y_inline, p, L, Linv, b, w,
-					s_blk[0].loff, p_flag, s_linv, s_rdiag, s_tile[0]);
+				if(D)
+					finish_diagonal_fixed<(D? D : 1)>(cd, acc, acc, lane, b_y? 0 : md.r, b_y? 0 : md.q, md.b_act, L, Linv, w,
+						s_blk[0].loff, p_flag, s_linv);
+				else
+					finish_diagonal<D>(cd, acc, acc, lane, b_y? 0 : md.r, b_y? 0 : md.q, md.b_act, b_y_inline, p, L, Linv, b, w,
+						s_blk[0].loff, p_flag, s_linv, s_rdiag, s_tile[0]);
 				if(!D && !b_y_inline)
 					finish_rhs_wide(cd, lane, p, L, b, w, s_linv);
 			}
@@ -457,8 +543,12 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 					#pragma unroll
 					for(int ww = 0; ww < W; ++ ww)
 						acc -= s_part[ww][0][lane];
-					finish_diagonal<D>(cd, acc, acc, lane, b_y? 0 : md.r, b_y? 0 : md.q, md.b_act, b_y_inline, p, L, Linv, b, w,
-						bd.loff, p_flag, s_linv, s_rdiag, s_tile[0]);
+					if(D)
+						finish_diagonal_fixed<(D? D : 1)>(cd, acc, acc, lane, b_y? 0 : md.r, b_y? 0 : md.q, md.b_act, L, Linv, w,
+							bd.loff, p_flag, s_linv);
+					else
+						finish_diagonal<D>(cd, acc, acc, lane, b_y? 0 : md.r, b_y? 0 : md.q, md.b_act, b_y_inline, p, L, Linv, b, w,
+							bd.loff, p_flag, s_linv, s_rdiag, s_tile[0]);
 					if(!D && !b_y_inline)
 						finish_rhs_wide(cd, lane, p, L, b, w, s_linv);
 				}
