@@ -63,7 +63,25 @@ def algorithmic_counts_c3(lam, stats):
     return c
 
 
-def per_kernel_bytes_sparse(plan):
+def load_traffic(workload):
+    """HBM traffic per launch from the committed PMC summary of this round (tools/profile_round.sh ->
+    profiles/*_traffic.json): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB units,
+    FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md prescribes."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_traffic.json")))
+    if not files:
+        return {}, None
+    return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+
+
+def kernel_traffic(traffic, needle):
+    for name, v in traffic.items():
+        if needle in name:
+            return v["hbm_bytes_per_launch_corrected"]
+    return None
+
+
+def per_kernel_bytes_sparse(plan, n_bottom_stages=1):
     """Algorithmic bytes each kernel of the sparse path moves per step, from the plan (our own
     factor structure): factor = 8 (nnz of the Lambda blocks read + nnz of the L columns written),
     substitution = 8 nnz(L columns) + vectors, split into the bottom-stage launch and the rest."""
@@ -77,8 +95,8 @@ def per_kernel_bytes_sparse(plan):
     blk_nnz = np.where(is_diag, dj * (dj + 1) // 2, di * dj)
     l_col = np.bincount(col_of, weights=blk_nnz, minlength=n)
     a_col = np.bincount(col_of, weights=np.where(asrc >= 0, blk_nnz, 0), minlength=n)
-    stage0 = np.zeros(n, dtype=bool)
-    t0, t1 = plan["stage_ptr"][0], plan["stage_ptr"][1]
+    stage0 = np.zeros(n, dtype=bool)     # columns handled by the one-wave kernel (bottom + wide stages)
+    t0, t1 = plan["stage_ptr"][0], plan["stage_ptr"][n_bottom_stages]
     stage0[plan["task_cols"][plan["task_ptr"][t0]:plan["task_ptr"][t1]]] = True
     fac = 8.0 * (l_col + a_col) + 16.0 * dim     # + the fused forward substitution's vector traffic
     sub = 8.0 * l_col + 16.0 * dim               # a substitution reads the L column, reads + writes the vector
@@ -154,11 +172,12 @@ def run_c3(args, rank, world, local_rank, dist):
     resid = float(np.abs(lam.to_scipy() @ x - lam.rhs).max() / np.abs(lam.rhs).max())
     ms_per_step = dt / args.steps * 1e3
     prof = solver.profile()
-    kb = per_kernel_bytes_sparse(solver.plan())
-    n_stages = stats["n_stages"]
-    launches = {"factor_subtree": 1, "factor_upper": max(n_stages - 1, 1), "forward": n_stages, "backward": n_stages}
-    names = {"factor_subtree": "factor_subtree_kernel<D>", "factor_upper": "factor_stage_kernel<D, 8>",
+    n_stages, n_bottom = stats["n_stages"], stats["n_bottom_stages"]
+    kb = per_kernel_bytes_sparse(solver.plan(), n_bottom)
+    launches = {"factor_subtree": n_bottom, "factor_upper": max(n_stages - n_bottom, 1), "forward": n_stages, "backward": n_stages}
+    names = {"factor_subtree": "factor_subtree_kernel", "factor_upper": "factor_stage_kernel",
              "forward": "forward_stage_kernel", "backward": "backward_stage_kernel"}
+    traffic, traffic_file = load_traffic("c3")
     kernels = []
     for ph, (cnt, tot_ms) in prof.items():
         if ph not in kb or cnt == 0:
@@ -167,7 +186,8 @@ def run_c3(args, rank, world, local_rank, dist):
         kernels.append({"kernel": names[ph], "launches_per_step": launches[ph], "ms_per_step": per_step_ms,
                         "avg_launch_us": per_step_ms / launches[ph] * 1e3,
                         "algorithmic_bytes_per_launch": kb[ph] / launches[ph],
-                        "achieved_GBs": kb[ph] / (per_step_ms * 1e-3) / 1e9})
+                        "achieved_GBs": kb[ph] / (per_step_ms * 1e-3) / 1e9,
+                        "hbm_traffic_bytes_per_launch": kernel_traffic(traffic, names[ph])})
     kernels.sort(key=lambda k: -k["ms_per_step"])
     dom = kernels[0]
     out = {
@@ -185,8 +205,10 @@ def run_c3(args, rank, world, local_rank, dist):
         "own_ordering": {"l_nnz": stats["l_nnz"], "factor_flops": stats["factor_flops"], "n_stages": n_stages,
                          "n_tasks": stats["n_tasks"], "analyze_ms_cold": analyze_ms},
         "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
-                     "avg_launch_us": dom["avg_launch_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
+                     "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS,
+                     "traffic": dom["hbm_traffic_bytes_per_launch"], "traffic_source": traffic_file,
+                     "avg_launch_us": dom["avg_launch_us"], "launches_per_step": dom["launches_per_step"],
+                     "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
         "kernels": kernels,
     }
     if world == 1 and not args.no_cpu_baseline:
@@ -293,10 +315,19 @@ def run_ba(args, rank, world, local_rank, dist):
         "n_gpus": world, "steps": steps, "schur_dim": N, "n_observations_per_gpu": n_obs, "analyze_ms_cold": analyze_ms,
         "phases_ms": prof,
     }
+    traffic, traffic_file = load_traffic("ba")
     if "dense_chol" in prof:
         tf = st["factor_flops"] / (prof["dense_chol"] * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "dense_cholesky (potrf_diag + trsm + syrk kernels)", "achieved": tf,
-                           "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS, "traffic": None}
+        n_panels = (N + 1 + 63) // 64
+        tr = None
+        if traffic:   # HBM bytes of the whole factorization = sum over its three kernels of launches x bytes per launch
+            tr = sum((kernel_traffic(traffic, k_) or 0.0) * traffic[[n for n in traffic if k_ in n][0]]["launches"]
+                     for k_ in ("potrf_diag_kernel", "trsm_kernel", "syrk_kernel")) / \
+                max(traffic[[n for n in traffic if "potrf_diag_kernel" in n][0]]["launches"] / n_panels, 1)
+        out["roofline"] = {"bound": "mfma", "kernel": "dense_cholesky (potrf_diag + trsm + syrk kernels, one factorization)",
+                           "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS,
+                           "traffic": tr, "traffic_source": traffic_file, "flops_per_factorization": st["factor_flops"],
+                           "ms_per_factorization": prof["dense_chol"]}
     if "schur_gather" in prof:
         gb = (288.0 * st["n_update_pairs"] + 2 * 8.0 * 36 * st["l_blocks"]) / (prof["schur_gather"] * 1e-3) / 1e9
         out["roofline_schur_gather"] = {"bound": "hbm", "kernel": "schur_gather_S_kernel", "achieved": gb, "peak": HBM_PEAK_GBS,

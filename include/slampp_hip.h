@@ -58,6 +58,7 @@ typedef struct slampp_hip_stats {
 	int64_t n_stages, n_tasks, etree_height, n_update_pairs;
 	int64_t n_cams, n_points, n_observations, schur_dim;     /* Schur path, else 0 */
 	int64_t device_bytes;
+	int64_t n_bottom_stages;          /* leading stages run by the one-wave-per-task kernel (factor_subtree_kernel) */
 } slampp_hip_stats;
 
 /* lifecycle -- stands in for the solver object's ctor / dtor / Free_Memory()

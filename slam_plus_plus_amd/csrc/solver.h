@@ -90,7 +90,7 @@ struct slampp_hip_solver {
 
 	// sparse path
 	slampp::Plan plan;
-	std::vector<int> stage_waves;
+	int n_bottom_stages; // leading stages launched with one wave per task
 	slampp::TDevPlan dplan;
 	slampp::CDevArray<slampp::TColDesc> d_cols;
 	slampp::CDevArray<slampp::TBlkDesc> d_blks;

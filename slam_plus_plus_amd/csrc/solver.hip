@@ -11,7 +11,7 @@ using namespace slampp;
 slampp_hip_solver::slampp_hip_solver()
 	:n_device(0), stream(0), n_dense_nb(64), b_shard_primary(1), b_has_structure(false),
 	b_analyzed(false), b_factored(false), n_mode(SLAMPP_HIP_MODE_SPARSE), n_matrix_cut(0),
-	n_values(0), n_scalars(0), p_host_flag(0), p_schur(0), p_allreduce(0), p_allreduce_context(0),
+	n_values(0), n_scalars(0), n_bottom_stages(1), p_host_flag(0), p_schur(0), p_allreduce(0), p_allreduce_context(0),
 	b_profile(0), n_open_phase(-1)
 {
 	memset(&dplan, 0, sizeof(dplan));
@@ -117,6 +117,12 @@ void slampp_hip_solver::Analyze_Sparse()
 		throw std::domain_error("block dimensions above 8 are not supported by the sparse path");
 	const Plan &P = plan;
 	const int64_t n_lblocks = int64_t(P.lrow.size());
+	// the bottom stage and the wide stages right above it (more tasks than the 8-wave kernel keeps
+	// resident at 2 workgroups per CU) run one wave per task: there throughput beats single-column latency
+	n_bottom_stages = 1;
+	while(n_bottom_stages < int(P.stage_ptr.size()) - 1 &&
+	   P.stage_ptr[n_bottom_stages + 1] - P.stage_ptr[n_bottom_stages] > 1024)
+		++ n_bottom_stages;
 
 	if(P.cs_new[P.n] >= INT32_MAX)
 		throw std::domain_error("systems with 2^31 or more scalar unknowns are not supported by the sparse path");
@@ -188,11 +194,11 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 		// numeric factorization with the forward substitution fused in
 		SLAMPP_HIP_CHECK(hipMemsetAsync(d_flag.p(), 0, sizeof(int), stream));
 		for(int s = 0; s < n_stages; ++ s) {
-			if(s < 2)
+			if(s == 0 || s == n_bottom_stages)
 				Phase_Begin(s? "factor_upper" : "factor_subtree");
 			launch_factor_stage(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
-				P.stage_ptr[s + 1] - P.stage_ptr[s], s == 0, d_flag.p(), stream);
-			if(!s || s == n_stages - 1)
+				P.stage_ptr[s + 1] - P.stage_ptr[s], s < n_bottom_stages, d_flag.p(), stream);
+			if(s == n_bottom_stages - 1 || s == n_stages - 1)
 				Phase_End();
 		}
 	} else {
@@ -526,6 +532,7 @@ int slampp_hip_get_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_
 		p_stats->n_tasks = int64_t(P.task_ptr.size()) - 1;
 		p_stats->etree_height = P.etree_height;
 		p_stats->n_update_pairs = int64_t(P.pa.size());
+		p_stats->n_bottom_stages = s.n_bottom_stages;
 	} else if(s.b_analyzed && s.p_schur)
 		schur_fill_stats(s.p_schur, *p_stats);
 	p_stats->device_bytes = int64_t(s.n_Device_Bytes());

@@ -712,9 +712,7 @@ void launch_factor_stage(const TDevPlan &p, const double *A, double *L, double *
 {
 	if(n_tasks <= 0)
 		return;
-	// one wave per task for the bottom stage and for wide stages (more tasks than the 8-wave kernel
-	// can keep resident at 2 workgroups per CU): there, throughput matters more than the latency of one column
-	if(b_bottom_stage || n_tasks > 1024) {
+	if(b_bottom_stage) { // one wave per task (the host decides which stages: solver.hip, n_bottom_stages)
 		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_subtree_kernel<D>), dim3(n_tasks), dim3(64), 0, stream,
 			p, A, L, Linv, b, w, task_begin, p_flag));
 	} else {

@@ -43,7 +43,8 @@ class Stats(C.Structure):
                 ("factor_flops", C.c_double), ("solve_flops", C.c_double),
                 ("n_stages", C.c_int64), ("n_tasks", C.c_int64), ("etree_height", C.c_int64),
                 ("n_update_pairs", C.c_int64), ("n_cams", C.c_int64), ("n_points", C.c_int64),
-                ("n_observations", C.c_int64), ("schur_dim", C.c_int64), ("device_bytes", C.c_int64)]
+                ("n_observations", C.c_int64), ("schur_dim", C.c_int64), ("device_bytes", C.c_int64),
+                ("n_bottom_stages", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
