@@ -2,7 +2,11 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -20,6 +24,9 @@ double now_ms()
 // nested dissection on level structures
 // ---------------------------------------------------------------------------------------------
 
+// Sub-problems are independent (disjoint vertex sets, disjoint output ranges known up front), so the
+// two halves of a large bisection run on separate threads down to a fixed depth: the ordering is the
+// cold path's largest host cost and the hosts of MI355X boxes have cores to spare.
 class CNestedDissection {
 	const int32_t m_n;
 	const std::vector<int64_t> &m_ptr;
@@ -27,9 +34,9 @@ class CNestedDissection {
 	const int m_leaf;
 	std::vector<int32_t> m_set;    // id of the subset a vertex currently belongs to
 	std::vector<int32_t> m_level;  // BFS level (valid for the subset being processed)
-	std::vector<int32_t> m_queue;  // BFS queue scratch
-	std::vector<int32_t> &m_out;
-	int32_t m_next_id;
+	std::vector<int32_t> &m_out;   // perm[new] = old; every call fills its own range
+	std::atomic<int32_t> m_next_id;
+	enum { parallel_min_size = 4096, parallel_max_depth = 6 };
 
 public:
 	CNestedDissection(int32_t n, const std::vector<int64_t> &ptr, const std::vector<int32_t> &adj,
@@ -37,34 +44,32 @@ public:
 		:m_n(n), m_ptr(ptr), m_adj(adj), m_leaf(std::max(leaf, 1)), m_set(n, -1), m_level(n, -1),
 		m_out(out), m_next_id(0)
 	{
-		m_out.clear();
-		m_out.reserve(n);
-		m_queue.reserve(n);
+		m_out.assign(n, -1);
 	}
 
 	void Run()
 	{
 		std::vector<int32_t> all(m_n);
 		std::iota(all.begin(), all.end(), 0);
-		Order(all);
+		Order(all, 0, 0);
 	}
 
 private:
-	// BFS inside subset `id` from `root`; fills m_queue with the visit order and m_level; returns #levels
-	int32_t BFS(int32_t root, int32_t id)
+	// BFS inside subset `id` from `root`; fills r_queue with the visit order and m_level; returns #levels
+	int32_t BFS(int32_t root, int32_t id, std::vector<int32_t> &r_queue)
 	{
-		m_queue.clear();
-		m_queue.push_back(root);
+		r_queue.clear();
+		r_queue.push_back(root);
 		m_level[root] = 0;
 		int32_t n_levels = 1;
-		for(size_t h = 0; h < m_queue.size(); ++ h) {
-			const int32_t v = m_queue[h], lv = m_level[v];
+		for(size_t h = 0; h < r_queue.size(); ++ h) {
+			const int32_t v = r_queue[h], lv = m_level[v];
 			for(int64_t e = m_ptr[v]; e < m_ptr[v + 1]; ++ e) {
 				const int32_t w = m_adj[e];
 				if(m_set[w] == id && m_level[w] < 0) {
 					m_level[w] = lv + 1;
 					n_levels = lv + 2;
-					m_queue.push_back(w);
+					r_queue.push_back(w);
 				}
 			}
 		}
@@ -85,8 +90,8 @@ private:
 		return d;
 	}
 
-	// orders a (possibly disconnected) vertex subset
-	void Order(std::vector<int32_t> &S)
+	// orders a (possibly disconnected) vertex subset into m_out[n_out .. n_out + |S|)
+	void Order(std::vector<int32_t> &S, size_t n_out, int n_depth)
 	{
 		if(S.empty())
 			return;
@@ -97,18 +102,19 @@ private:
 		}
 		// split into connected components first (iteratively, flat storage: the landmark part
 		// of a BA system has 500k single-vertex components), then order each one
-		std::vector<int32_t> comp_verts;
+		std::vector<int32_t> queue, comp_verts;
 		std::vector<size_t> comp_ptr(1, 0);
+		queue.reserve(S.size());
 		comp_verts.reserve(S.size());
 		for(size_t s = 0; s < S.size() && comp_verts.size() < S.size(); ++ s) {
 			if(m_level[S[s]] >= 0)
 				continue; // already in an earlier component
-			BFS(S[s], id);
-			if(m_queue.size() == S.size()) {
-				Order_Connected(S, id); // the whole subset is one component
+			BFS(S[s], id, queue);
+			if(queue.size() == S.size()) {
+				Order_Connected(S, id, n_out, n_depth, queue); // the whole subset is one component
 				return;
 			}
-			comp_verts.insert(comp_verts.end(), m_queue.begin(), m_queue.end());
+			comp_verts.insert(comp_verts.end(), queue.begin(), queue.end());
 			comp_ptr.push_back(comp_verts.size());
 		}
 		{
@@ -118,51 +124,52 @@ private:
 		std::vector<int32_t> comp;
 		for(size_t c = 0; c + 1 < comp_ptr.size(); ++ c) {
 			comp.assign(comp_verts.begin() + comp_ptr[c], comp_verts.begin() + comp_ptr[c + 1]);
+			const size_t n_comp_out = n_out + comp_ptr[c];
 			if(comp.size() == 1) {
-				m_out.push_back(comp[0]);
+				m_out[n_comp_out] = comp[0];
 				continue;
 			}
 			const int32_t cid = m_next_id ++; // own id: the recursion must not see the other components
 			for(int32_t v : comp)
 				m_set[v] = cid;
-			Order_Connected(comp, cid);
+			Reset_Levels(comp);
+			BFS(comp[0], cid, queue);
+			Order_Connected(comp, cid, n_comp_out, n_depth, queue);
 		}
 	}
 
 	// Cuthill-McKee-like order of a small connected subset
-	void Order_Leaf(const std::vector<int32_t> &S, int32_t id)
+	void Order_Leaf(const std::vector<int32_t> &S, int32_t id, size_t n_out, std::vector<int32_t> &r_queue)
 	{
 		Reset_Levels(S);
-		BFS(S[0], id);
-		const int32_t far = m_queue.back();
+		BFS(S[0], id, r_queue);
+		const int32_t far = r_queue.back();
 		Reset_Levels(S);
-		BFS(far, id);
-		m_out.insert(m_out.end(), m_queue.begin(), m_queue.end());
+		BFS(far, id, r_queue);
+		std::copy(r_queue.begin(), r_queue.end(), m_out.begin() + n_out);
 	}
 
-	void Order_Connected(std::vector<int32_t> &S, int32_t id)
+	// r_queue: scratch; on entry it holds a BFS of S (levels set) from an arbitrary root
+	void Order_Connected(std::vector<int32_t> &S, int32_t id, size_t n_out, int n_depth, std::vector<int32_t> &r_queue)
 	{
 		if(S.size() <= size_t(m_leaf)) {
-			Order_Leaf(S, id);
+			Order_Leaf(S, id, n_out, r_queue);
 			return;
 		}
 		// pseudo-peripheral root: repeat BFS from a minimum-degree vertex of the last level
-		Reset_Levels(S);
-		int32_t root = S[0];
-		int32_t n_levels = BFS(root, id);
+		int32_t n_levels = m_level[r_queue.back()] + 1;
 		for(int n_pass = 0; n_pass < 3; ++ n_pass) {
 			const int32_t last = n_levels - 1;
 			int32_t best = -1, best_deg = INT32_MAX;
-			for(size_t k = m_queue.size(); k > 0 && m_level[m_queue[k - 1]] == last; -- k) {
-				const int32_t v = m_queue[k - 1], d = Degree_In(v, id);
+			for(size_t k = r_queue.size(); k > 0 && m_level[r_queue[k - 1]] == last; -- k) {
+				const int32_t v = r_queue[k - 1], d = Degree_In(v, id);
 				if(d < best_deg) {
 					best_deg = d;
 					best = v;
 				}
 			}
 			Reset_Levels(S);
-			const int32_t n_new = BFS(best, id);
-			root = best;
+			const int32_t n_new = BFS(best, id, r_queue);
 			if(n_new <= n_levels) {
 				n_levels = n_new;
 				break;
@@ -170,7 +177,7 @@ private:
 			n_levels = n_new;
 		}
 		if(n_levels < 3) { // clique-like: no level separates anything
-			m_out.insert(m_out.end(), m_queue.begin(), m_queue.end());
+			std::copy(r_queue.begin(), r_queue.end(), m_out.begin() + n_out);
 			return;
 		}
 		// level sizes; pick the smallest level that leaves >= 1/4 of the vertices on either side,
@@ -229,9 +236,16 @@ private:
 			std::vector<int32_t> empty;
 			S.swap(empty); // release before recursing
 		}
-		Order(lower);
-		Order(upper);
-		m_out.insert(m_out.end(), sep.begin(), sep.end());
+		const size_t n_lower = lower.size(), n_upper = upper.size();
+		std::copy(sep.begin(), sep.end(), m_out.begin() + n_out + n_lower + n_upper);
+		if(n_depth < parallel_max_depth && std::min(n_lower, n_upper) >= size_t(parallel_min_size)) {
+			std::thread other([&]() { Order(upper, n_out + n_lower, n_depth + 1); });
+			Order(lower, n_out, n_depth + 1);
+			other.join();
+		} else {
+			Order(lower, n_out, n_depth + 1);
+			Order(upper, n_out + n_lower, n_depth + 1);
+		}
 	}
 };
 
@@ -324,6 +338,13 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 	double t1 = now_ms();
 	P.order_ms = t1 - t0;
 
+	const bool b_timing = getenv("SLAMPP_HIP_PLAN_TIMING") != 0;
+	double t_phase = now_ms();
+#define PLAN_PHASE(name) do { if(b_timing) { const double t_ = now_ms(); \
+	fprintf(stderr, "[plan] %-12s %8.2f ms\n", name, t_ - t_phase); t_phase = t_; } } while(0)
+	if(b_timing)
+		fprintf(stderr, "[plan] %-12s %8.2f ms\n", "order", P.order_ms);
+
 	// ---- permuted lower-triangular structure of Lambda ----
 	// offsets of the source blocks in the packed value array
 	std::vector<int64_t> aoff(n_ablocks + 1, 0);
@@ -358,6 +379,7 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 		}
 	}
 
+	PLAN_PHASE("permute");
 	// ---- column structure of L by merging children (symbolic Cholesky on the block graph) ----
 	P.parent.assign(n, -1);
 	P.lptr.assign(n + 1, 0);
@@ -433,6 +455,7 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 		}
 	}
 
+	PLAN_PHASE("symbolic");
 	// ---- update lists ----
 	// column c contributes L(i,c) L(j,c)^T to block (i,j) for every pair of its sub-diagonal rows i >= j
 	{
@@ -472,6 +495,7 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 		}
 	}
 
+	PLAN_PHASE("pairs");
 	// ---- row lists ----
 	{
 		P.rptr.assign(n + 1, 0);
@@ -489,6 +513,7 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 		}
 	}
 
+	PLAN_PHASE("rows");
 	// ---- schedule ----
 	{
 		const int32_t T = std::max(opt.subtree_size, 1);
@@ -592,6 +617,8 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 				P.task_cols[fill[new_id[task_of[j]]] ++] = j;
 		}
 	}
+	PLAN_PHASE("schedule");
+#undef PLAN_PHASE
 	P.symbolic_ms = now_ms() - t1;
 	return std::string();
 }
