@@ -56,7 +56,7 @@ typedef struct slampp_hip_stats {
 	int64_t l_blocks, l_nnz;          /* block / scalar nonzeros of the factor under our ordering */
 	double  factor_flops, solve_flops; /* CHOLMOD's convention: sum of squared column counts; 4*lnz */
 	int64_t n_stages, n_tasks, etree_height, n_update_pairs;
-	int64_t n_cams, n_points, n_observations, schur_dim;     /* Schur path, else 0 */
+	int64_t n_cams, n_points, n_observations, schur_dim;     /* Schur path, else 0 (sparse path: schur_dim = dimension of the dense top) */
 	int64_t device_bytes;
 	int64_t n_bottom_stages;          /* leading stages run by the one-wave-per-task kernel (factor_subtree_kernel) */
 } slampp_hip_stats;
@@ -70,6 +70,8 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
 
 /* tuning knobs: "leaf_size" (nested-dissection leaf, default 4), "subtree_size" (max columns one
  * wave eliminates sequentially, default 16), "dense_nb" (dense panel width, default 64),
+ * "dense_top_nb" (sparse path: block columns with at least this many blocks, and their ancestors, are factored as
+ * one dense matrix on the matrix cores; default 32, 0 = off), "dense_top_max_dim" (cap on its dimension, default 12288),
  * "profile" (0/1, see slampp_hip_get_profile), "shard_primary" (multi-GPU BA: this rank adds A and eta_x) */
 int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int64_t n_value);
 
@@ -153,6 +155,8 @@ typedef struct slampp_hip_plan_view {
 	int32_t *p_stage_ptr;   /* [n_stages+1] -> tasks */
 	int64_t *p_task_ptr;    /* [n_tasks+1] -> task columns */
 	int32_t *p_task_cols;   /* [n_task_cols] */
+	int32_t *p_dense_pos;   /* [n_bcols] scalar offset of the column in the dense top, -1 = eliminated block by block */
+	int64_t dense_dim;      /* scalar dimension of the dense top (0 = none) */
 } slampp_hip_plan_view;
 int slampp_hip_get_plan(const slampp_hip_solver *p_solver, slampp_hip_plan_view *p_view);
 
@@ -160,7 +164,8 @@ int slampp_hip_get_plan(const slampp_hip_solver *p_solver, slampp_hip_plan_view 
  * check ordering, symbolic factorization and schedule.  n_leaf_size / n_subtree_size <= 0 = default. */
 typedef struct slampp_hip_plan slampp_hip_plan;
 int slampp_hip_plan_create(slampp_hip_plan **pp_plan, int64_t n_bcols, const int64_t *p_bcol_cumsum,
-	const int64_t *p_bcol_ptr, const int32_t *p_brow_idx, int n_leaf_size, int n_subtree_size);
+	const int64_t *p_bcol_ptr, const int32_t *p_brow_idx, int n_leaf_size, int n_subtree_size,
+	int n_dense_top_nb /* < 0 = default */);
 int slampp_hip_plan_get(const slampp_hip_plan *p_plan, slampp_hip_plan_view *p_view, slampp_hip_stats *p_stats);
 void slampp_hip_plan_destroy(slampp_hip_plan *p_plan);
 

@@ -78,7 +78,7 @@ def exec_plan(lam, plan: dict):
         C.c_int64(plan["n_bcols"]), _p(a["perm"]), _p(a["dim"]), _p(a["lptr"]), _p(a["lrow"]), _p(a["loff"]),
         _p(a["asrc"]), _p(a["atrans"]), _p(a["pptr"]), _p(a["pa"]), _p(a["pb"]), _p(a["rptr"]), _p(a["rblk"]),
         C.c_int64(plan["n_stages"]), _p(a["stage_ptr"]), _p(a["task_ptr"]), _p(a["task_cols"]),
-        _p(cs), C.c_int64(plan["l_values"]), _p(vals), _p(x))
+        _p(cs), C.c_int64(plan["l_values"]), _p(vals), _p(x), _p(a["dense_pos"]), C.c_int64(plan["dense_dim"]))
     return rc, x
 
 

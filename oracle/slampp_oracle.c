@@ -644,7 +644,8 @@ int oracle_exec_plan(int64_t n, const int32_t *perm, const int32_t *dim, const i
 	const int32_t *lrow, const int64_t *loff, const int64_t *asrc, const int32_t *atrans,
 	const int64_t *pptr, const int32_t *pa, const int32_t *pb, const int64_t *rptr, const int32_t *rblk,
 	int64_t n_stages, const int32_t *stage_ptr, const int64_t *task_ptr, const int32_t *task_cols,
-	const int64_t *cs_old, int64_t l_values, const double *val, double *rhs_inout)
+	const int64_t *cs_old, int64_t l_values, const double *val, double *rhs_inout,
+	const int32_t *dense_pos, int64_t dense_dim)
 {
 	const int64_t nbl = lptr[n];
 	double *L = (double*)calloc(l_values? l_values : 1, sizeof(double));
@@ -750,11 +751,12 @@ int oracle_exec_plan(int64_t n, const int32_t *perm, const int32_t *dim, const i
 		}
 	}
 	for(j = 0; j < n && !result; ++ j) {
-		if(done_stage[j] < 0)
+		if(done_stage[j] < 0 && !(dense_dim && dense_pos[j] >= 0))
 			result = 2; /* a column was never scheduled */
 	}
+	/* forward substitution of the block-eliminated columns (needed before the dense top's right-hand side) */
 	if(!result) {
-		/* forward substitution in schedule order, backward in reverse */
+		/* forward substitution in schedule order */
 		for(s = 0; s < n_stages; ++ s)
 			for(t = stage_ptr[s]; t < stage_ptr[s + 1]; ++ t)
 				for(c = task_ptr[t]; c < task_ptr[t + 1]; ++ c) {
@@ -778,6 +780,93 @@ int oracle_exec_plan(int64_t n, const int32_t *perm, const int32_t *dim, const i
 						w[cs_new[j] + r] = sum;
 					}
 				}
+	}
+	if(!result && dense_dim) {
+		/* dense top: assemble the Schur complement onto the dense-top columns from the kept update
+		 * lists (sources outside the dense top only), factor it densely, solve for x of those columns */
+		const int64_t N = dense_dim;
+		double *Dm = (double*)calloc((size_t)(N * N), sizeof(double)), *rd = (double*)calloc((size_t)N, sizeof(double));
+		for(j = 0; j < n && !result; ++ j) {
+			int64_t dj, r, q, u;
+			if(dense_pos[j] < 0)
+				continue;
+			dj = dim[j];
+			for(k = lptr[j]; k < lptr[j + 1] && !result; ++ k) {
+				const int64_t i = lrow[k], di = dim[i];
+				if(dense_pos[i] < 0) { result = 2; break; }
+				for(q = 0; q < dj; ++ q)
+					for(r = 0; r < di; ++ r) {
+						double v = 0;
+						if(asrc[k] >= 0)
+							v = (atrans[k] || k == lptr[j])? val[asrc[k] + q + r * dj] : val[asrc[k] + r + q * di];
+						Dm[(dense_pos[i] + r) + (dense_pos[j] + q) * N] = v;
+					}
+				for(e = pptr[k]; e < pptr[k + 1]; ++ e) {
+					const int64_t cc = blk_col[pa[e]], dc = dim[cc];
+					const double *Pa = L + loff[pa[e]], *Pb = L + loff[pb[e]];
+					if(dense_pos[cc] >= 0 || done_stage[cc] < 0 || lrow[pa[e]] != i || lrow[pb[e]] != j) { result = 2; break; }
+					for(q = 0; q < dj; ++ q)
+						for(r = 0; r < di; ++ r) {
+							double sum = 0;
+							for(u = 0; u < dc; ++ u)
+								sum += Pa[r + u * di] * Pb[q + u * dj];
+							Dm[(dense_pos[i] + r) + (dense_pos[j] + q) * N] -= sum;
+						}
+				}
+			}
+			for(r = 0; r < dj; ++ r)
+				rd[dense_pos[j] + r] = rhs_inout[cs_old[perm[j]] + r];
+			for(e = rptr[j]; e < rptr[j + 1]; ++ e) {
+				const int64_t kb = rblk[e], cc = blk_col[kb], dc = dim[cc];
+				const double *B = L + loff[kb];
+				if(dense_pos[cc] >= 0) { result = 2; break; }
+				for(r = 0; r < dj; ++ r)
+					for(u = 0; u < dc; ++ u)
+						rd[dense_pos[j] + r] -= B[r + u * dj] * w[cs_new[cc] + u];
+			}
+		}
+		if(!result) { /* dense lower Cholesky + two substitutions */
+			int64_t r, q, u;
+			for(q = 0; q < N && !result; ++ q) { /* right-looking, column-oriented: every inner loop is contiguous */
+				double p = Dm[q + q * N], *cq = Dm + q * N;
+				if(!(p > 0)) { result = 1; break; }
+				p = sqrt(p);
+				cq[q] = p;
+				for(r = q + 1; r < N; ++ r)
+					cq[r] /= p;
+				for(u = q + 1; u < N; ++ u) {
+					const double f = cq[u];
+					double *cu = Dm + u * N;
+					if(f != 0)
+						for(r = u; r < N; ++ r)
+							cu[r] -= cq[r] * f;
+				}
+			}
+			for(q = 0; q < N && !result; ++ q) {
+				double v = rd[q];
+				for(u = 0; u < q; ++ u)
+					v -= Dm[q + u * N] * rd[u];
+				rd[q] = v / Dm[q + q * N];
+			}
+			for(q = N; q > 0 && !result; -- q) {
+				double v = rd[q - 1];
+				for(u = q; u < N; ++ u)
+					v -= Dm[u + (q - 1) * N] * rd[u];
+				rd[q - 1] = v / Dm[(q - 1) + (q - 1) * N];
+			}
+			for(j = 0; j < n && !result; ++ j) {
+				if(dense_pos[j] < 0)
+					continue;
+				for(r = 0; r < dim[j]; ++ r) {
+					w[cs_new[j] + r] = rd[dense_pos[j] + r];
+					rhs_inout[cs_old[perm[j]] + r] = rd[dense_pos[j] + r];
+				}
+			}
+		}
+		free(Dm); free(rd);
+	}
+	if(!result) {
+		/* backward substitution of the block-eliminated columns, schedule reversed */
 		for(s = n_stages; s > 0; -- s)
 			for(t = stage_ptr[s]; t > stage_ptr[s - 1]; -- t)
 				for(c = task_ptr[t]; c > task_ptr[t - 1]; -- c) {

@@ -24,4 +24,8 @@ void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag,
 // x = L^-T y with y taken from row n_pad-1 of the factor; p_z: workspace n_pad doubles; p_x: n_pad doubles, x in [0, n)
 void dense_backsolve(const double *M, int n_pad, int n, const double *p_invdiag, double *p_z, double *p_x, hipStream_t stream);
 
+// y = L^-1 r for another right-hand side with a kept factor: r sits in row n_pad-1 (columns < n) and is
+// replaced by y, ready for dense_backsolve
+void dense_forwardsolve(double *M, int n_pad, const double *p_invdiag, hipStream_t stream);
+
 } // namespace slampp

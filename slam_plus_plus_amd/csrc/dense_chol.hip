@@ -333,6 +333,76 @@ __global__ void dense_backsolve_init_kernel(const double *M, int ld, int n, doub
 		z[i] = (i < n)? M[size_t(ld - 1) + size_t(i) * ld] : 0.0;
 }
 
+// ---- stand-alone forward substitution y = L^-1 r with a kept factor (another right-hand side) ----
+// r is taken from row ld-1 of M (where dense_assemble leaves it), y is written back there, so that
+// dense_backsolve finds it where the fused factorization would have put it
+__global__ void __launch_bounds__(256)
+dense_forward_step_kernel(double *M, int ld, int kb, const double *invL)
+{
+	__shared__ double s_y[NB];
+	__shared__ double s_red[4][NB];
+	const int t = threadIdx.x, c = t >> 2, part = t & 3;
+	const int jb = kb + 1 + blockIdx.x; // row tile to update; the extra last workgroup only publishes y_kb
+	const size_t last = size_t(ld - 1);
+	{
+		double sum = 0; // y_kb = inv(L_kk) r_kb: row c of the inverse
+		for(int u = part; u <= c; u += 4)
+			sum += invL[c + u * NB] * M[last + size_t(kb * NB + u) * ld];
+		sum += __shfl_xor(sum, 1);
+		sum += __shfl_xor(sum, 2);
+		if(part == 0)
+			s_y[c] = sum;
+	}
+	__syncthreads();
+	const int n_blocks = ld / NB;
+	if(jb >= n_blocks) { // the publishing workgroup runs after no one needs r_kb any more? no: it must not
+		return;
+	}
+	// r_jb -= L(jb, kb) y_kb; thread (r, part): rows contiguous, 4 partial sums over the 64 columns
+	const int r = t & 63, pc = t >> 6;
+	double sum = 0;
+	for(int u = pc * 16; u < pc * 16 + 16; ++ u)
+		sum += M[size_t(jb * NB + r) + size_t(kb * NB + u) * ld] * s_y[u];
+	s_red[pc][r] = sum;
+	__syncthreads();
+	if(t < NB) {
+		const double tot = (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]);
+		const int row = jb * NB + t;
+		if(row != ld - 1) // the last row of the matrix is the right-hand side itself, not an equation
+			M[last + size_t(row) * ld] -= tot;
+	}
+}
+
+__global__ void __launch_bounds__(256)
+dense_forward_finish_kernel(double *M, int ld, int kb, const double *invL)
+{
+	// r_kb <- y_kb in place, after every reader of r_kb (own launch)
+	__shared__ double s_r[NB];
+	const int t = threadIdx.x, c = t >> 2, part = t & 3;
+	const size_t last = size_t(ld - 1);
+	if(t < NB)
+		s_r[t] = M[last + size_t(kb * NB + t) * ld];
+	__syncthreads();
+	double sum = 0;
+	for(int u = part; u <= c; u += 4)
+		sum += invL[c + u * NB] * s_r[u];
+	sum += __shfl_xor(sum, 1);
+	sum += __shfl_xor(sum, 2);
+	if(part == 0 && kb * NB + c != ld - 1)
+		M[last + size_t(kb * NB + c) * ld] = sum;
+}
+
+void dense_forwardsolve(double *M, int n_pad, const double *p_invdiag, hipStream_t stream)
+{
+	const int n_blocks = n_pad / NB;
+	for(int kb = 0; kb < n_blocks; ++ kb) {
+		const double *invL = p_invdiag + size_t(kb) * NB * NB;
+		if(kb + 1 < n_blocks)
+			hipLaunchKernelGGL(dense_forward_step_kernel, dim3(n_blocks - kb - 1), dim3(256), 0, stream, M, n_pad, kb, invL);
+		hipLaunchKernelGGL(dense_forward_finish_kernel, dim3(1), dim3(256), 0, stream, M, n_pad, kb, invL);
+	}
+}
+
 // one launch per diagonal tile kb (descending): every workgroup recomputes x_kb = inv(L_kk)^T z_kb
 // (4 lanes per entry), workgroup 0 publishes it to x, workgroup jb < kb applies z_jb -= L(kb,jb)^T x_kb
 __global__ void __launch_bounds__(256)

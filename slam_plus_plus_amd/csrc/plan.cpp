@@ -455,6 +455,41 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 		}
 	}
 
+	// ---- dense top ----
+	std::vector<char> in_dense(n, 0);
+	P.dense_pos.assign(n, -1);
+	P.dense_dim = 0;
+	if(opt.dense_top_nb > 0) {
+		int64_t n_dim = 0;
+		for(int n_threshold = opt.dense_top_nb;; n_threshold = n_threshold * 3 / 2 + 1) {
+			std::fill(in_dense.begin(), in_dense.end(), char(0));
+			n_dim = 0;
+			for(int32_t j = 0; j < n; ++ j) { // parents have larger indices: one ascending pass closes the set upwards
+				if(P.lptr[j + 1] - P.lptr[j] >= n_threshold)
+					in_dense[j] = 1;
+				if(in_dense[j]) {
+					n_dim += P.dim[j];
+					if(P.parent[j] >= 0)
+						in_dense[P.parent[j]] = 1;
+				}
+			}
+			if(n_dim <= opt.dense_top_max_dim)
+				break;
+		}
+		if(n_dim < opt.dense_top_min_dim)
+			std::fill(in_dense.begin(), in_dense.end(), char(0));
+		else {
+			int32_t n_pos = 0;
+			for(int32_t j = 0; j < n; ++ j) {
+				if(in_dense[j]) {
+					P.dense_pos[j] = n_pos;
+					n_pos += P.dim[j];
+				}
+			}
+			P.dense_dim = n_pos;
+		}
+	}
+
 	PLAN_PHASE("symbolic");
 	// ---- update lists ----
 	// column c contributes L(i,c) L(j,c)^T to block (i,j) for every pair of its sub-diagonal rows i >= j
@@ -462,6 +497,8 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 		std::vector<int32_t> tgt;
 		std::vector<int32_t> ga, gb;
 		for(int32_t c = 0; c < n; ++ c) {
+			if(in_dense[c])
+				continue; // updates among dense-top columns happen inside the dense factorization
 			const int64_t kb0 = P.lptr[c] + 1, kb1 = P.lptr[c + 1];
 			for(int64_t kb = kb0; kb < kb1; ++ kb) {
 				const int32_t j = P.lrow[kb];
@@ -500,6 +537,8 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 	{
 		P.rptr.assign(n + 1, 0);
 		for(int32_t j = 0; j < n; ++ j) {
+			if(in_dense[j])
+				continue; // blocks of dense-top columns exist only inside the dense factor
 			for(int64_t k = P.lptr[j] + 1; k < P.lptr[j + 1]; ++ k)
 				++ P.rptr[P.lrow[k] + 1];
 		}
@@ -508,6 +547,8 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 		P.rblk.resize(P.rptr[n]);
 		std::vector<int64_t> fill(P.rptr.begin(), P.rptr.end() - 1);
 		for(int32_t j = 0; j < n; ++ j) {
+			if(in_dense[j])
+				continue;
 			for(int64_t k = P.lptr[j] + 1; k < P.lptr[j + 1]; ++ k)
 				P.rblk[fill[P.lrow[k]] ++] = int32_t(k);
 		}
@@ -517,28 +558,37 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 	// ---- schedule ----
 	{
 		const int32_t T = std::max(opt.subtree_size, 1);
+		// the forest that is eliminated block by block: dense-top columns removed
+		std::vector<int32_t> par(n, -1);
+		int32_t n_sched = 0;
+		for(int32_t j = 0; j < n; ++ j) {
+			if(!in_dense[j]) {
+				++ n_sched;
+				par[j] = (P.parent[j] >= 0 && !in_dense[P.parent[j]])? P.parent[j] : -1;
+			}
+		}
 		std::vector<int32_t> sz(n, 1), height(n, 1);
 		for(int32_t j = 0; j < n; ++ j) {
 			const int32_t p = P.parent[j];
-			if(p >= 0) {
-				sz[p] += sz[j];
+			if(p >= 0)
 				height[p] = std::max(height[p], height[j] + 1);
-			}
 			P.etree_height = std::max(P.etree_height, height[j]);
+			if(!in_dense[j] && par[j] >= 0)
+				sz[par[j]] += sz[j];
 		}
 		// task id of every column. bottom: whole subtrees of <= T columns; top: maximal chains
 		std::vector<int32_t> task_of(n, -1), task_level;
 		std::vector<int32_t> troot(n, -1);
 		for(int32_t j = n - 1; j >= 0; -- j) {
-			if(sz[j] <= T) {
-				const int32_t p = P.parent[j];
+			if(!in_dense[j] && sz[j] <= T) {
+				const int32_t p = par[j];
 				troot[j] = (p >= 0 && sz[p] <= T)? troot[p] : j;
 			}
 		}
 		std::vector<int32_t> n_top_children(n, 0), n_bottom_children(n, 0), last_top_child(n, -1);
 		for(int32_t j = 0; j < n; ++ j) {
-			const int32_t p = P.parent[j];
-			if(p >= 0) {
+			const int32_t p = par[j];
+			if(!in_dense[j] && p >= 0) {
 				if(troot[j] >= 0)
 					++ n_bottom_children[p];
 				else {
@@ -550,6 +600,8 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 		int32_t n_tasks = 0;
 		std::vector<int32_t> root_task(n, -1);
 		for(int32_t j = 0; j < n; ++ j) {
+			if(in_dense[j])
+				continue;
 			if(troot[j] >= 0) {
 				int32_t &r = root_task[troot[j]];
 				if(r < 0) {
@@ -569,8 +621,8 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 		}
 		// level of a top task = 1 + max level of the tasks of its columns' children
 		for(int32_t j = 0; j < n; ++ j) {
-			const int32_t p = P.parent[j];
-			if(p >= 0 && task_of[p] != task_of[j]) {
+			const int32_t p = par[j];
+			if(!in_dense[j] && p >= 0 && task_of[p] != task_of[j]) {
 				int32_t &lp = task_level[task_of[p]];
 				lp = std::max(lp, task_level[task_of[j]] + 1);
 			}
@@ -581,8 +633,8 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 		for(bool b_changed = true; b_changed;) {
 			b_changed = false;
 			for(int32_t j = 0; j < n; ++ j) {
-				const int32_t p = P.parent[j];
-				if(p >= 0 && task_of[p] != task_of[j] &&
+				const int32_t p = par[j];
+				if(!in_dense[j] && p >= 0 && task_of[p] != task_of[j] &&
 				   task_level[task_of[p]] < task_level[task_of[j]] + 1) {
 					task_level[task_of[p]] = task_level[task_of[j]] + 1;
 					b_changed = true;
@@ -607,14 +659,14 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 		}
 		P.task_ptr.assign(n_tasks + 1, 0);
 		for(int32_t j = 0; j < n; ++ j)
-			++ P.task_ptr[new_id[task_of[j]] + 1];
+			if(!in_dense[j]) ++ P.task_ptr[new_id[task_of[j]] + 1];
 		for(int32_t t = 0; t < n_tasks; ++ t)
 			P.task_ptr[t + 1] += P.task_ptr[t];
-		P.task_cols.resize(n);
+		P.task_cols.resize(n_sched);
 		{
 			std::vector<int64_t> fill(P.task_ptr.begin(), P.task_ptr.end() - 1);
 			for(int32_t j = 0; j < n; ++ j)
-				P.task_cols[fill[new_id[task_of[j]]] ++] = j;
+				if(!in_dense[j]) P.task_cols[fill[new_id[task_of[j]]] ++] = j;
 		}
 	}
 	PLAN_PHASE("schedule");

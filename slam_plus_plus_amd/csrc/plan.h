@@ -37,7 +37,12 @@ struct Plan {
 	// are eliminated in order by one workgroup
 	std::vector<int32_t> stage_ptr;   // [n_stages+1]
 	std::vector<int64_t> task_ptr;    // [n_tasks+1]
-	std::vector<int32_t> task_cols;   // [n]
+	std::vector<int32_t> task_cols;   // [n - number of dense-top columns]
+	// dense top: an upper set of the elimination tree (the big separators of 2-D-like graphs) is not
+	// eliminated block by block; its Schur complement is assembled into one dense matrix and handed to
+	// the dense MFMA Cholesky (dense_chol.hip).  dense_pos[j] = scalar offset of column j there, or -1.
+	std::vector<int32_t> dense_pos;   // [n]
+	int32_t dense_dim = 0;            // scalar dimension of the dense top, 0 = none
 	// statistics
 	int64_t l_nnz = 0;                // scalar nonzeros of L (lower, incl. diagonal)
 	double factor_flops = 0;          // sum over scalar columns of (column count)^2  (CHOLMOD's "fl")
@@ -49,6 +54,9 @@ struct Plan {
 struct PlanOptions {
 	int leaf_size = 4;        // nested dissection stops at subgraphs of this many block columns
 	int subtree_size = 16;    // a subtree of at most this many columns is one sequential task
+	int dense_top_nb = 32;    // columns with this many blocks or more (and their ancestors) form the dense top; 0 = off
+	int dense_top_max_dim = 12288; // cap on its scalar dimension (the threshold is raised until it fits)
+	int dense_top_min_dim = 192;   // below this the dense top is not worth its launches
 };
 
 // returns empty string on success, else an error message

@@ -11,6 +11,7 @@
 #include "../../include/slampp_hip.h"
 #include "plan.h"
 #include "sparse_kernels.h"
+#include "dense_chol.h"
 
 namespace slampp {
 
@@ -97,6 +98,11 @@ struct slampp_hip_solver {
 	slampp::CDevArray<slampp::TRowEnt> d_rents;
 	slampp::CDevArray<longlong2> d_pairs;
 	slampp::CDevArray<int64_t> d_task_ptr;
+	// dense top of the sparse path (plan.h): assembled Schur complement + dense factor workspaces
+	slampp::CDevArray<slampp::TDenseBlk> d_dense_blks;
+	slampp::CDevArray<slampp::TDenseCol> d_dense_cols;
+	slampp::CDevArray<double> d_dense, d_dense_invdiag, d_dense_z, d_dense_x;
+	int n_dense_blks, n_dense_cols, n_dense_dim, n_dense_pad;
 	slampp::CDevArray<double> d_A, d_rhs, d_L, d_Linv, d_w;
 	slampp::CDevArray<int> d_flag;
 	int *p_host_flag; // pinned

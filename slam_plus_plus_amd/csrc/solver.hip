@@ -11,7 +11,8 @@ using namespace slampp;
 slampp_hip_solver::slampp_hip_solver()
 	:n_device(0), stream(0), n_dense_nb(64), b_shard_primary(1), b_has_structure(false),
 	b_analyzed(false), b_factored(false), n_mode(SLAMPP_HIP_MODE_SPARSE), n_matrix_cut(0),
-	n_values(0), n_scalars(0), n_bottom_stages(1), p_host_flag(0), p_schur(0), p_allreduce(0), p_allreduce_context(0),
+	n_values(0), n_scalars(0), n_bottom_stages(1), n_dense_blks(0), n_dense_cols(0), n_dense_dim(0), n_dense_pad(0),
+	p_host_flag(0), p_schur(0), p_allreduce(0), p_allreduce_context(0),
 	b_profile(0), n_open_phase(-1)
 {
 	memset(&dplan, 0, sizeof(dplan));
@@ -36,6 +37,8 @@ slampp_hip_solver::~slampp_hip_solver()
 void slampp_hip_solver::Free_Device()
 {
 	d_cols.Free(); d_blks.Free(); d_rents.Free(); d_pairs.Free(); d_task_ptr.Free();
+	d_dense_blks.Free(); d_dense_cols.Free(); d_dense.Free(); d_dense_invdiag.Free(); d_dense_z.Free(); d_dense_x.Free();
+	n_dense_blks = n_dense_cols = n_dense_dim = n_dense_pad = 0;
 	d_A.Free(); d_rhs.Free(); d_L.Free(); d_Linv.Free(); d_w.Free(); d_flag.Free();
 	if(p_schur) {
 		schur_destroy(p_schur);
@@ -47,7 +50,8 @@ void slampp_hip_solver::Free_Device()
 
 size_t slampp_hip_solver::n_Device_Bytes() const
 {
-	return d_cols.n_Bytes() + d_blks.n_Bytes() + d_rents.n_Bytes() +
+	return d_dense_blks.n_Bytes() + d_dense_cols.n_Bytes() + d_dense.n_Bytes() + d_dense_invdiag.n_Bytes() +
+		d_dense_z.n_Bytes() + d_dense_x.n_Bytes() + d_cols.n_Bytes() + d_blks.n_Bytes() + d_rents.n_Bytes() +
 		d_task_ptr.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
 		d_rhs.n_Bytes() + d_L.n_Bytes() + d_Linv.n_Bytes() + d_w.n_Bytes() + d_flag.n_Bytes() +
 		(p_schur? schur_device_bytes(p_schur) : 0);
@@ -128,8 +132,9 @@ void slampp_hip_solver::Analyze_Sparse()
 		throw std::domain_error("systems with 2^31 or more scalar unknowns are not supported by the sparse path");
 
 	// packed device records (see sparse_kernels.h)
-	std::vector<TColDesc> cols(P.n); // in schedule order
-	for(int32_t i = 0; i < P.n; ++ i) {
+	const int32_t n_sched = int32_t(P.task_cols.size()); // all columns but those of the dense top
+	std::vector<TColDesc> cols(n_sched); // in schedule order
+	for(int32_t i = 0; i < n_sched; ++ i) {
 		const int32_t j = P.task_cols[i];
 		TColDesc &c = cols[i];
 		memset(&c, 0, sizeof(c));
@@ -170,6 +175,48 @@ void slampp_hip_solver::Analyze_Sparse()
 		rents[e].ycs = int32_t(P.cs_new[c]);
 		rents[e].dc = P.dim[c];
 	}
+	// dense top
+	n_dense_dim = P.dense_dim;
+	n_dense_pad = n_dense_dim? dense_padded_dim(n_dense_dim) : 0;
+	std::vector<TDenseBlk> dense_blks;
+	std::vector<TDenseCol> dense_cols;
+	if(n_dense_dim) {
+		for(int32_t j = 0; j < P.n; ++ j) {
+			if(P.dense_pos[j] < 0)
+				continue;
+			TDenseCol dc;
+			dc.cs_new = P.cs_new[j]; dc.cs_src = P.cs_src[j]; dc.pos = P.dense_pos[j]; dc.dj = P.dim[j];
+			dense_cols.push_back(dc);
+			for(int64_t k = P.lptr[j]; k < P.lptr[j + 1]; ++ k) {
+				const int32_t i = P.lrow[k];
+				if(P.dense_pos[i] < 0)
+					throw std::logic_error("dense top is not closed upwards");
+				TDenseBlk b;
+				memset(&b, 0, sizeof(b));
+				b.asrc = (P.asrc[k] < 0)? -1 : P.asrc[k] * 2 + P.atrans[k];
+				b.p0 = P.pptr[k];
+				b.np = int32_t(P.pptr[k + 1] - P.pptr[k]);
+				b.dst = int64_t(P.dense_pos[i]) + int64_t(P.dense_pos[j]) * n_dense_pad;
+				b.di = P.dim[i]; b.dj = P.dim[j];
+				if(k == P.lptr[j]) {
+					b.r0 = P.rptr[j];
+					b.nr = int32_t(P.rptr[j + 1] - P.rptr[j]);
+					b.cs_src = P.cs_src[j];
+					b.pos = P.dense_pos[j];
+				} else
+					b.nr = -1;
+				dense_blks.push_back(b);
+			}
+		}
+		d_dense_blks.Upload(dense_blks, stream);
+		d_dense_cols.Upload(dense_cols, stream);
+		d_dense.Alloc(size_t(n_dense_pad) * n_dense_pad);
+		d_dense_invdiag.Alloc(size_t(n_dense_pad / dense_NB) * dense_NB * dense_NB);
+		d_dense_z.Alloc(n_dense_pad);
+		d_dense_x.Alloc(n_dense_pad);
+	}
+	n_dense_blks = int(dense_blks.size());
+	n_dense_cols = int(dense_cols.size());
 	d_cols.Upload(cols, stream);
 	d_blks.Upload(blks, stream);
 	d_pairs.Upload(pairs, stream);
@@ -207,6 +254,31 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			launch_forward_stage(dplan, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
 				P.stage_ptr[s + 1] - P.stage_ptr[s], stream);
 		}
+		Phase_End();
+	}
+	if(n_dense_dim) {
+		// dense top: Schur complement onto the big separators, dense MFMA Cholesky, both substitutions
+		const int ld = n_dense_pad;
+		if(b_factor) {
+			Phase_Begin("dense_assemble");
+			SLAMPP_HIP_CHECK(hipMemsetAsync(d_dense.p(), 0, size_t(ld) * ld * sizeof(double), stream));
+			dense_prepare_padding(d_dense.p(), ld, n_dense_dim, stream);
+			launch_dense_assemble(dplan, d_dense_blks.p(), n_dense_blks, p_values_dev, d_L.p(), p_rhs_dev, d_w.p(),
+				d_dense.p(), ld, false, stream);
+			Phase_End();
+			Phase_Begin("dense_chol");
+			dense_cholesky(d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), d_flag.p(), stream);
+			Phase_End();
+		} else {
+			Phase_Begin("dense_forward");
+			launch_dense_assemble(dplan, d_dense_blks.p(), n_dense_blks, 0, d_L.p(), p_rhs_dev, d_w.p(),
+				d_dense.p(), ld, true, stream);
+			dense_forwardsolve(d_dense.p(), ld, d_dense_invdiag.p(), stream);
+			Phase_End();
+		}
+		Phase_Begin("dense_solve");
+		dense_backsolve(d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), d_dense_z.p(), d_dense_x.p(), stream);
+		launch_dense_scatter(d_dense_cols.p(), n_dense_cols, d_dense_x.p(), d_w.p(), p_rhs_dev, stream);
 		Phase_End();
 	}
 	Phase_Begin("backward");
@@ -315,6 +387,10 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 		p_solver->opt.subtree_size = int(n_value);
 	else if(s == "dense_nb" && (n_value == 32 || n_value == 64 || n_value == 128))
 		p_solver->n_dense_nb = int(n_value);
+	else if(s == "dense_top_nb" && n_value >= 0)
+		p_solver->opt.dense_top_nb = int(n_value);
+	else if(s == "dense_top_max_dim" && n_value >= 0)
+		p_solver->opt.dense_top_max_dim = int(n_value);
 	else if(s == "shard_primary")
 		p_solver->b_shard_primary = (n_value != 0);
 	else if(s == "profile") {
@@ -533,6 +609,7 @@ int slampp_hip_get_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_
 		p_stats->etree_height = P.etree_height;
 		p_stats->n_update_pairs = int64_t(P.pa.size());
 		p_stats->n_bottom_stages = s.n_bottom_stages;
+		p_stats->schur_dim = P.dense_dim; // sparse path: dimension of the dense top (0 = none)
 	} else if(s.b_analyzed && s.p_schur)
 		schur_fill_stats(s.p_schur, *p_stats);
 	p_stats->device_bytes = int64_t(s.n_Device_Bytes());
@@ -595,6 +672,8 @@ static void Fill_PlanView(const Plan &P, slampp_hip_plan_view *v)
 	COPY_OUT(v->p_stage_ptr, P.stage_ptr);
 	COPY_OUT(v->p_task_ptr, P.task_ptr);
 	COPY_OUT(v->p_task_cols, P.task_cols);
+	COPY_OUT(v->p_dense_pos, P.dense_pos);
+	v->dense_dim = P.dense_dim;
 #undef COPY_OUT
 }
 
@@ -611,7 +690,7 @@ struct slampp_hip_plan {
 };
 
 int slampp_hip_plan_create(slampp_hip_plan **pp_plan, int64_t n_bcols, const int64_t *p_bcol_cumsum,
-	const int64_t *p_bcol_ptr, const int32_t *p_brow_idx, int n_leaf_size, int n_subtree_size)
+	const int64_t *p_bcol_ptr, const int32_t *p_brow_idx, int n_leaf_size, int n_subtree_size, int n_dense_top_nb)
 {
 	if(!pp_plan || !p_bcol_cumsum || !p_bcol_ptr || !p_brow_idx)
 		return SLAMPP_HIP_ERR_INVALID;
@@ -623,6 +702,8 @@ int slampp_hip_plan_create(slampp_hip_plan **pp_plan, int64_t n_bcols, const int
 			opt.leaf_size = n_leaf_size;
 		if(n_subtree_size > 0)
 			opt.subtree_size = n_subtree_size;
+		if(n_dense_top_nb >= 0)
+			opt.dense_top_nb = n_dense_top_nb;
 		if(!build_plan(n_bcols, p_bcol_cumsum, p_bcol_ptr, p_brow_idx, opt, p->plan).empty()) {
 			delete p;
 			return SLAMPP_HIP_ERR_INVALID;
@@ -652,6 +733,7 @@ int slampp_hip_plan_get(const slampp_hip_plan *p_plan, slampp_hip_plan_view *p_v
 		p_stats->n_tasks = int64_t(P.task_ptr.size()) - 1;
 		p_stats->etree_height = P.etree_height;
 		p_stats->n_update_pairs = int64_t(P.pa.size());
+		p_stats->schur_dim = P.dense_dim;
 	}
 	return SLAMPP_HIP_OK;
 }

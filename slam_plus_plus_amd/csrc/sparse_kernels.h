@@ -34,6 +34,24 @@ struct TRowEnt { // 16 B: block L(j,c) of block row j
 	int32_t dc;        // dimension of column c
 };
 
+// dense top: one record per factor block (i,j) with j in the dense top, and one per dense-top column
+struct TDenseBlk { // 64 B
+	int64_t asrc;      // source in the Lambda values (encoded as in TBlkDesc) or -1
+	int64_t p0;        // first update pair (pairs from columns outside the dense top only)
+	int64_t dst;       // offset of element (0,0) of the block in the dense matrix
+	int64_t r0;        // diagonal blocks: first row entry
+	int32_t np, nr;    // number of pairs; number of row entries, -1 for off-diagonal blocks
+	int32_t di, dj;
+	int64_t cs_src;    // diagonal blocks: scalar offset of the column in the caller's vector
+	int32_t pos;       // diagonal blocks: scalar offset of the column in the dense system
+	int32_t pad;
+};
+
+struct TDenseCol { // 24 B
+	int64_t cs_new, cs_src;
+	int32_t pos, dj;
+};
+
 struct TDevPlan {
 	const TColDesc *cols;      // [n] in *schedule* order: the columns of task t are cols[task_ptr[t] .. task_ptr[t+1])
 	const TBlkDesc *blks;      // [l_blocks]
@@ -53,5 +71,13 @@ void launch_forward_stage(const TDevPlan &p, const double *L, const double *Linv
 // backward substitution x = L^-T y, scattering x to its original position
 void launch_backward_stage(const TDevPlan &p, const double *L, const double *Linv, double *w,
 	double *x_out, int task_begin, int n_tasks, hipStream_t stream);
+
+// dense top (see plan.h): Schur complement of the block-eliminated part onto the dense-top columns,
+// written into the lower triangle of the dense matrix Dm (leading dimension ld, right-hand side in row ld-1)
+void launch_dense_assemble(const TDevPlan &p, const TDenseBlk *blks, int n_blks, const double *A, const double *L,
+	const double *b, const double *w, double *Dm, int ld, bool b_rhs_only, hipStream_t stream);
+// x of the dense-top columns from the dense solver's vector into the workspace and the caller's vector
+void launch_dense_scatter(const TDenseCol *cols, int n_cols, const double *x_dense, double *w, double *x_out,
+	hipStream_t stream);
 
 } // namespace slampp

@@ -700,6 +700,66 @@ backward_stage_kernel(TDevPlan p, const double *L, const double *Linv, double *w
 	}
 }
 
+// ---- dense top: assemble the Schur complement onto the dense-top columns ----
+// one workgroup of 4 waves per block (i,j), j in the dense top: D(i,j) = Lambda(i,j) - sum of the updates
+// from block-eliminated columns (the updates among dense-top columns happen in dense_cholesky);
+// diagonal blocks also produce the right-hand side  b_j - sum_c L(j,c) y_c  into row ld-1
+template <int D>
+__global__ void __launch_bounds__(256)
+dense_assemble_kernel(TDevPlan p, const TDenseBlk *__restrict__ blks, const double *__restrict__ A, const double *L,
+	const double *__restrict__ b, const double *w, double *Dm, int ld, int b_rhs_only)
+{
+	__shared__ double s_part[4][64];
+	const TDenseBlk bd = blks[blockIdx.x];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int di = D? D : bd.di, dj = D? D : bd.dj;
+	const bool b_diag = bd.nr >= 0;
+	if(b_rhs_only && !b_diag)
+		return;
+	const bool b_y_inline = dj <= 7;
+	const bool b_y = b_diag && b_y_inline && lane >= Y_LANE0 && lane < Y_LANE0 + dj;
+	const TLaneMap m = lane_map(lane, di, dj);
+	const int yq = b_y? lane - Y_LANE0 : m.q;
+	double part;
+	if(b_y)
+		part = accumulate_row<D>(p.rents, bd.r0, bd.nr, wave, 4, L, w, 0, yq, dj, true);
+	else
+		part = b_rhs_only? 0.0 : accumulate_pairs<D>(p.pairs, bd.p0, bd.np, wave, 4, L, m.r, m.q, di, dj);
+	s_part[wave][lane] = part;
+	__syncthreads();
+	if(wave == 0) {
+		const double sum = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
+		if(b_y)
+			Dm[size_t(ld - 1) + size_t(bd.pos + yq) * ld] = b[bd.cs_src + yq] - sum;
+		else if(m.b_act && !b_rhs_only)
+			Dm[bd.dst + m.r + size_t(m.q) * ld] = lambda_element(A, bd.asrc, m.r, m.q, di, dj, b_diag) - sum;
+		if(!D && b_diag && !b_y_inline) { // 8-wide column: right-hand side by lanes 0..7 in a second pass
+			const int q = lane & 7;
+			double ay = accumulate_row<0>(p.rents, bd.r0, bd.nr, lane >> 3, 8, L, w, 0, q, dj, true);
+			ay += __shfl_xor(ay, 8);
+			ay += __shfl_xor(ay, 16);
+			ay += __shfl_xor(ay, 32);
+			if(lane < dj)
+				Dm[size_t(ld - 1) + size_t(bd.pos + lane) * ld] = b[bd.cs_src + lane] - ay;
+		}
+	}
+}
+
+__global__ void dense_scatter_kernel(const TDenseCol *__restrict__ cols, int n_cols, const double *__restrict__ x,
+	double *w, double *x_out)
+{
+	const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+	const int c = gid >> 3, q = gid & 7;
+	if(c < n_cols) {
+		const TDenseCol cd = cols[c];
+		if(q < cd.dj) {
+			const double v = x[cd.pos + q];
+			w[cd.cs_new + q] = v;
+			x_out[cd.cs_src + q] = v;
+		}
+	}
+}
+
 // ---- launchers ----
 #define DISPATCH_DIM(D_runtime, CALL) do { switch(D_runtime) { \
 	case 3: { enum { D = 3 }; CALL; } break; \
@@ -735,6 +795,22 @@ void launch_backward_stage(const TDevPlan &p, const double *L, const double *Lin
 	if(n_tasks > 0)
 		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((backward_stage_kernel<D>), dim3(n_tasks), dim3(64), 0, stream,
 			p, L, Linv, w, x_out, task_begin));
+}
+
+void launch_dense_assemble(const TDevPlan &p, const TDenseBlk *blks, int n_blks, const double *A, const double *L,
+	const double *b, const double *w, double *Dm, int ld, bool b_rhs_only, hipStream_t stream)
+{
+	if(n_blks > 0)
+		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((dense_assemble_kernel<D>), dim3(n_blks), dim3(256), 0, stream,
+			p, blks, A, L, b, w, Dm, ld, int(b_rhs_only)));
+}
+
+void launch_dense_scatter(const TDenseCol *cols, int n_cols, const double *x_dense, double *w, double *x_out,
+	hipStream_t stream)
+{
+	if(n_cols > 0)
+		hipLaunchKernelGGL(dense_scatter_kernel, dim3((n_cols * 8 + 255) / 256), dim3(256), 0, stream, cols, n_cols,
+			x_dense, w, x_out);
 }
 
 } // namespace slampp

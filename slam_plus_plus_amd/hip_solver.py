@@ -56,7 +56,8 @@ class PlanView(C.Structure):
         ("p_perm", C.c_void_p), ("p_dim", C.c_void_p), ("p_lptr", C.c_void_p), ("p_lrow", C.c_void_p),
         ("p_loff", C.c_void_p), ("p_asrc", C.c_void_p), ("p_atrans", C.c_void_p), ("p_pptr", C.c_void_p),
         ("p_pa", C.c_void_p), ("p_pb", C.c_void_p), ("p_rptr", C.c_void_p), ("p_rblk", C.c_void_p),
-        ("p_stage_ptr", C.c_void_p), ("p_task_ptr", C.c_void_p), ("p_task_cols", C.c_void_p)]
+        ("p_stage_ptr", C.c_void_p), ("p_task_ptr", C.c_void_p), ("p_task_cols", C.c_void_p),
+        ("p_dense_pos", C.c_void_p), ("dense_dim", C.c_int64)]
 
 
 class PhaseTime(C.Structure):
@@ -85,7 +86,7 @@ ABI = {
     "slampp_hip_get_profile": (C.c_int, [_P, C.POINTER(PhaseTime), C.c_int, C.POINTER(C.c_int), C.c_int]),
     "slampp_hip_set_allreduce": (C.c_int, [_P, ALLREDUCE_FN, _P]),
     "slampp_hip_get_plan": (C.c_int, [_P, C.POINTER(PlanView)]),
-    "slampp_hip_plan_create": (C.c_int, [C.POINTER(_P), C.c_int64, _P, _P, _P, C.c_int, C.c_int]),
+    "slampp_hip_plan_create": (C.c_int, [C.POINTER(_P), C.c_int64, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
     "slampp_hip_plan_get": (C.c_int, [_P, C.POINTER(PlanView), C.POINTER(Stats)]),
     "slampp_hip_plan_destroy": (None, [_P]),
 }
@@ -122,7 +123,8 @@ _PLAN_FIELDS = [("perm", "p_perm", np.int32, "n_bcols", 0), ("dim", "p_dim", np.
                 ("rptr", "p_rptr", np.int64, "n_bcols", 1), ("rblk", "p_rblk", np.int32, "n_row_entries", 0),
                 ("stage_ptr", "p_stage_ptr", np.int32, "n_stages", 1),
                 ("task_ptr", "p_task_ptr", np.int64, "n_tasks", 1),
-                ("task_cols", "p_task_cols", np.int32, "n_task_cols", 0)]
+                ("task_cols", "p_task_cols", np.int32, "n_task_cols", 0),
+                ("dense_pos", "p_dense_pos", np.int32, "n_bcols", 0)]
 
 
 def _fetch_plan(getter) -> dict:
@@ -134,20 +136,21 @@ def _fetch_plan(getter) -> dict:
         out[name] = arr
         setattr(v, field, arr.ctypes.data)
     getter(v)                                   # contents
-    for f in ("n_bcols", "l_blocks", "n_pairs", "n_row_entries", "n_stages", "n_tasks", "l_values"):
+    for f in ("n_bcols", "l_blocks", "n_pairs", "n_row_entries", "n_stages", "n_tasks", "l_values", "dense_dim"):
         out[f] = getattr(v, f)
     return out
 
 
-def host_plan(lam, leaf_size: int = 0, subtree_size: int = 0):
-    """Ordering + symbolic analysis + schedule on the host only (no GPU): (plan dict, stats dict)."""
+def host_plan(lam, leaf_size: int = 0, subtree_size: int = 0, dense_top_nb: int = -1):
+    """Ordering + symbolic analysis + schedule on the host only (no GPU): (plan dict, stats dict).
+    ``dense_top_nb`` < 0 = the library default, 0 = no dense top."""
     lib = load_library()
     h = C.c_void_p()
     cs = np.ascontiguousarray(lam.cumsum, dtype=np.int64)
     bp = np.ascontiguousarray(lam.bcol_ptr, dtype=np.int64)
     br = np.ascontiguousarray(lam.brow_idx, dtype=np.int32)
     rc = lib.slampp_hip_plan_create(C.byref(h), lam.n_bcols, _ptr(cs), _ptr(bp), _ptr(br),
-                                    leaf_size, subtree_size)
+                                    leaf_size, subtree_size, dense_top_nb)
     if rc != OK:
         raise ValueError(f"slampp_hip_plan_create failed ({rc})")
     try:
