@@ -54,7 +54,7 @@ struct Plan {
 struct PlanOptions {
 	int leaf_size = 4;        // nested dissection stops at subgraphs of this many block columns
 	int subtree_size = 16;    // a subtree of at most this many columns is one sequential task
-	int dense_top_nb = 32;    // columns with this many blocks or more (and their ancestors) form the dense top; 0 = off
+	int dense_top_nb = 24;    // columns with this many blocks or more (and their ancestors) form the dense top; 0 = off
 	int dense_top_max_dim = 12288; // cap on its scalar dimension (the threshold is raised until it fits)
 	int dense_top_min_dim = 192;   // below this the dense top is not worth its launches
 };

@@ -21,7 +21,12 @@ def check_plan_invariants(lam, plan):
     for j in range(n):
         rows = lrow[lptr[j]:lptr[j + 1]]
         assert rows[0] == j and np.all(np.diff(rows) > 0)         # diagonal first, sorted, lower triangular
-    assert sorted(plan["task_cols"].tolist()) == list(range(n))   # every column scheduled exactly once
+    dense = plan["dense_pos"] >= 0                               # dense-top columns are not scheduled block by block
+    assert sorted(plan["task_cols"].tolist()) == np.nonzero(~dense)[0].tolist()   # every other column exactly once
+    if plan["dense_dim"]:
+        parent = np.array([lrow[lptr[j] + 1] if lptr[j + 1] - lptr[j] > 1 else -1 for j in range(n)])
+        assert all(parent[j] < 0 or dense[parent[j]] for j in np.nonzero(dense)[0])   # closed upwards in the etree
+        assert plan["dense_dim"] == int(plan["dim"][dense].sum())
     assert np.all(np.diff(plan["stage_ptr"]) > 0)
     dims = np.diff(lam.cumsum)[perm]
     assert np.array_equal(plan["dim"], dims)
@@ -30,10 +35,10 @@ def check_plan_invariants(lam, plan):
 
 
 @pytest.mark.parametrize("name", [n for n in golden_names() if not n.startswith("indefinite")])
-@pytest.mark.parametrize("leaf,sub", [(0, 0), (1, 1), (3, 7), (1000, 1000)])
-def test_plan_replay_matches_reference(name, leaf, sub):
+@pytest.mark.parametrize("leaf,sub,dense_nb", [(0, 0, -1), (1, 1, 0), (3, 7, 4), (1000, 1000, 0), (2, 4, 2)])
+def test_plan_replay_matches_reference(name, leaf, sub, dense_nb):
     lam, ref = load_golden(name)
-    plan, stats = host_plan(lam, leaf, sub)
+    plan, stats = host_plan(lam, leaf, sub, dense_nb)
     check_plan_invariants(lam, plan)
     status, x = O.exec_plan(lam, plan)
     assert status == 0
@@ -56,11 +61,21 @@ def test_plan_replay_detects_indefinite():
 ], ids=["chain5000", "sphere1600", "manhattan2000", "ba_mixed"])
 def test_plan_replay_matches_oracle_medium(make):
     lam = make()
-    ok, x_ref, _ = O.solve_sparse(lam)
-    plan, stats = host_plan(lam)
-    check_plan_invariants(lam, plan)
-    status, x = O.exec_plan(lam, plan)
-    assert ok and status == 0 and rel_inf(x, x_ref) < TOL
+    if lam.n_matrix_cut:   # cameras-first natural order fills in completely under the sparse oracle: use the Schur one
+        ok, x_ref, _, _ = O.solve_schur(lam)
+    else:
+        ok, x_ref, _ = O.solve_sparse(lam)
+    for dense_nb in (-1, 0):          # default dense top (active on the 2-D-like graphs) and none
+        plan, stats = host_plan(lam, dense_top_nb=dense_nb)
+        check_plan_invariants(lam, plan)
+        status, x = O.exec_plan(lam, plan)
+        assert ok and status == 0 and rel_inf(x, x_ref) < TOL
+
+
+def test_dense_top_is_used_where_separators_are_big_and_not_on_chains():
+    _, st_grid = host_plan(synth.sphere(40, 40, seed=22))
+    _, st_chain = host_plan(synth.pose_chain(n=5000, d=6, seed=21))
+    assert st_grid["schur_dim"] >= 192 and st_chain["schur_dim"] == 0
 
 
 def test_nested_dissection_exposes_parallelism_on_a_chain():

@@ -47,14 +47,31 @@ def test_parity_with_oracle(name):
     assert rel_inf(eta3, x_ref) < TOL
 
 
-@pytest.mark.parametrize("leaf,sub", [(1, 1), (4, 64), (64, 4), (1000000, 1000000)])
-def test_schedule_knobs_do_not_change_the_answer(leaf, sub):
+@pytest.mark.parametrize("leaf,sub,dense_nb", [(1, 1, 0), (4, 64, 24), (64, 4, 8), (1000000, 1000000, 0), (4, 16, 1)])
+def test_schedule_knobs_do_not_change_the_answer(leaf, sub, dense_nb):
     lam = synth.sphere(20, 20)
     ok, x_ref, _ = O.solve_sparse(lam)
-    solver = CLinearSolver_HIP(leaf_size=leaf, subtree_size=sub)
+    solver = CLinearSolver_HIP(leaf_size=leaf, subtree_size=sub, dense_top_nb=dense_nb)
     eta = lam.rhs.copy()
     assert solver.Solve_PosDef(lam, eta)
     assert rel_inf(eta, x_ref) < TOL
+
+
+def test_dense_top_not_positive_definite_returns_false():
+    """An indefinite block deep inside a big separator: the failure must surface from the dense factorization."""
+    import dataclasses
+    lam = synth.sphere(24, 24, seed=3)
+    solver = CLinearSolver_HIP()
+    assert solver.Solve_PosDef(lam, lam.rhs.copy()) and solver.stats()["schur_dim"] > 0
+    dense = solver.plan()["dense_pos"] >= 0
+    j_old = int(solver.plan()["perm"][np.nonzero(dense)[0][-1]])      # the last eliminated column
+    off = lam.block_value_offsets()
+    k = int(lam.bcol_ptr[j_old + 1] - 1)
+    vals = lam.values.copy()
+    vals[off[k]:off[k + 1]] -= 1e4 * np.eye(6).ravel()
+    bad = dataclasses.replace(lam, values=vals)
+    assert O.solve_sparse(bad)[0] is False
+    assert solver.Solve_PosDef_Blocky(bad, bad.rhs.copy()) is False
 
 
 def test_not_positive_definite_returns_false():
