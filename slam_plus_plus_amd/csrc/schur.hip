@@ -354,33 +354,59 @@ __global__ void schur_obs_W_kernel(int64_t n_obs, int64_t ubase, const int32_t *
 }
 
 // one workgroup of W waves per nonzero block of S: S(row, col) -= sum_e U_b W_a^T; contribution e is
-// summed by wave e mod W, the partial sums are combined in a fixed order (bit-reproducible)
+// summed by wave e mod W, the partial sums are combined in a fixed order (bit-reproducible).
+// The kernel is bound by the address path, not by bytes, so it spends as few vector-memory
+// instructions as it can: the entry indices are fetched 64 at a time (one coalesced load, then
+// v_readlane), the two operand blocks of an entry with ONE load (lanes 0..17 U_b, lanes 18..35 W_a,
+// both contiguous) and handed to the 36 accumulating lanes through LDS, four entries per batch.
 template <int DC, int DP, int W>
 __global__ void __launch_bounds__(64 * W)
 schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *sb_row, const int32_t *sb_col,
 	const int32_t *ent_a, const int64_t *ent_uoff, const double *__restrict__ A, const double *__restrict__ W_,
 	double *S, int ld)
 {
+	enum { BLK = DC * DP, BATCH = 4 };
+	__shared__ double s_ops[W][BATCH][2 * BLK];
 	__shared__ double s_part[W][64];
 	const int64_t sb = blockIdx.x;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const bool b_act = lane < DC * DC;
 	const int r = b_act? lane % DC : 0, q = b_act? lane / DC : 0;
+	const bool b_loader = lane < 2 * BLK;
 	double acc = 0;
-	const int64_t e1 = sb_ptr[sb + 1];
-	#pragma unroll 4
-	for(int64_t e = sb_ptr[sb] + wave; e < e1; e += W) {
-		const double *Wa = W_ + int64_t(ent_a[e]) * (DC * DP) + q;
-		const double *Ub = A + ent_uoff[e] + r;
-		double wv[DP], uv[DP];
-		#pragma unroll
-		for(int t = 0; t < DP; ++ t) {
-			wv[t] = Wa[t * DC];
-			uv[t] = Ub[t * DC];
+	const int64_t e0 = sb_ptr[sb], e1 = sb_ptr[sb + 1];
+	// this wave's entries: e0 + wave, e0 + wave + W, ...; processed in chunks of 64
+	for(int64_t base = e0 + wave; base < e1; base += int64_t(64) * W) {
+		const int64_t my = base + int64_t(lane) * W;
+		const int32_t my_a = (my < e1)? ent_a[my] : 0;
+		const int64_t my_u = (my < e1)? ent_uoff[my] : 0;
+		const int n_chunk = int(min(int64_t(64), (e1 - base + W - 1) / W));
+		for(int i = 0; i < n_chunk; i += BATCH) {
+			#pragma unroll
+			for(int j = 0; j < BATCH; ++ j) {
+				const int idx = min(i + j, n_chunk - 1); // the tail re-reads the last entry, its product is skipped below
+				const int32_t a = __builtin_amdgcn_readlane(my_a, idx);
+				const int64_t u = (int64_t(__builtin_amdgcn_readlane(int(my_u >> 32), idx)) << 32) |
+					uint32_t(__builtin_amdgcn_readlane(int(my_u), idx));
+				const double *src = (lane < BLK)? A + u + lane : W_ + int64_t(a) * BLK + (lane - BLK);
+				if(b_loader)
+					s_ops[wave][j][lane] = *src;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			#pragma unroll
+			for(int j = 0; j < BATCH; ++ j) {
+				if(i + j < n_chunk) {
+					#pragma unroll
+					for(int t = 0; t < DP; ++ t)
+						acc += s_ops[wave][j][r + t * DC] * s_ops[wave][j][BLK + q + t * DC];
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		}
-		#pragma unroll
-		for(int t = 0; t < DP; ++ t)
-			acc += uv[t] * wv[t];
 	}
 	if(W > 1) {
 		s_part[wave][lane] = acc;
@@ -516,10 +542,9 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 
 	s.Phase_Begin("schur_gather");
 	if(S.n_sblocks > 0) {
-		// one wave per block of S; 8 waves only when there are too few blocks to fill the chip
-		// (measured at C4, 4000 blocks x 1250 contributions: 1 wave 1.62 ms, 8 waves 1.85 ms -- the kernel is
-		// bound by the address path, 6 strided load instructions per contribution, not by latency)
-		if(S.n_sblocks < 2048 && S.n_entries > 64 * S.n_sblocks)
+		// one wave per block of S for short contribution lists (dense S: 500k blocks x 10 contributions),
+		// 8 waves per block for long ones (C4's band structure: 4000 blocks x 1250 contributions: 1.18 -> 0.69 ms)
+		if(S.n_entries > 256 * S.n_sblocks)
 			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 8>), dim3(unsigned(S.n_sblocks)), dim3(512), 0, st,
 				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
 				S.d_W.p(), S.d_S.p(), ld);

@@ -4,6 +4,8 @@
 #include "solver.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 using namespace slampp;
@@ -113,8 +115,13 @@ void slampp_hip_solver::Phase_Collect()
 
 void slampp_hip_solver::Analyze_Sparse()
 {
+	const bool b_timing = getenv("SLAMPP_HIP_PLAN_TIMING") != 0;
+	double t_phase = wall_ms();
+#define SETUP_PHASE(name) do { if(b_timing) { const double t_ = wall_ms(); \
+	fprintf(stderr, "[setup] %-12s %8.2f ms\n", name, t_ - t_phase); t_phase = t_; } } while(0)
 	std::string s_err = build_plan(int64_t(cumsum.size()) - 1, cumsum.data(), bcol_ptr.data(),
 		brow.data(), opt, plan);
+	SETUP_PHASE("build_plan");
 	if(!s_err.empty())
 		throw std::invalid_argument(s_err);
 	if(plan.max_dim > 8)
@@ -175,6 +182,7 @@ void slampp_hip_solver::Analyze_Sparse()
 		rents[e].ycs = int32_t(P.cs_new[c]);
 		rents[e].dc = P.dim[c];
 	}
+	SETUP_PHASE("records");
 	// dense top
 	n_dense_dim = P.dense_dim;
 	n_dense_pad = n_dense_dim? dense_padded_dim(n_dense_dim) : 0;
@@ -222,11 +230,15 @@ void slampp_hip_solver::Analyze_Sparse()
 	d_pairs.Upload(pairs, stream);
 	d_rents.Upload(rents, stream);
 	d_task_ptr.Upload(P.task_ptr, stream);
+	SETUP_PHASE("uploads");
 	d_L.Alloc(size_t(P.loff[n_lblocks]));
 	d_Linv.Alloc(size_t(P.linv_off[P.n]));
 	d_w.Alloc(size_t(P.cs_new[P.n]));
 	d_flag.Alloc(1);
+	SETUP_PHASE("allocs");
 	SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // the staging vectors above die here
+	SETUP_PHASE("sync");
+#undef SETUP_PHASE
 
 	dplan.cols = d_cols.p(); dplan.blks = d_blks.p(); dplan.pairs = d_pairs.p(); dplan.rents = d_rents.p();
 	dplan.task_ptr = d_task_ptr.p();
