@@ -128,6 +128,32 @@ typedef struct slampp_hip_phase_time {
 int slampp_hip_get_profile(slampp_hip_solver *p_solver, slampp_hip_phase_time *p_phases, int n_max_phases,
 	int *p_phase_num, int b_reset);
 
+/* Lambda and eta assembled on the device from per-edge Jacobians (first row after the
+ * solve): replaces the host loop that computes every edge's Hessian blocks and the reduction that sums
+ * them into Lambda (include/slam/BaseTypes_Binary.h:759-840 Calculate_Hessians_v2,
+ * include/slam/NonlinearSolver_Lambda_Base.h:1634-1688 Refresh_Lambda, :1520-1580 the unary factor) for one
+ * homogeneous set of binary edges, so that Lambda never visits the host between linearization and solve.
+ *
+ * create: after slampp_hip_set_structure().  Edge e joins block columns p_vertex0[e] and p_vertex1[e] of
+ * Lambda (all vertex0 of one dimension d0, all vertex1 of one dimension d1, both <= 7) with an
+ * n_residual_dim-vector residual (<= 8); Lambda must hold the block (min, max) of every edge.
+ *
+ * assemble: device arrays, edge-major, every matrix column-major as the reference's Eigen types are:
+ *   p_J0_dev [n_edges][rd x d0], p_J1_dev [n_edges][rd x d1], p_sigma_inv_dev [n_edges][rd x rd],
+ *   p_error_dev [n_edges][rd], p_weight_dev [n_edges] robust weights or NULL (= 1).
+ * p_unary_factor (host, d x d column-major, or NULL) and p_unary_error (host, d, or NULL) anchor
+ * block column n_unary_vertex: U^T U is added to its diagonal block and the error to its eta.
+ * Writes the packed block values of Lambda (the layout slampp_hip_factor_solve_device reads) and eta;
+ * with b_accumulate != 0 adds to what the two arrays hold instead (a second edge set of the same Lambda).
+ * Sums run in a fixed order: results are bit-reproducible.  Enqueue-only, on the solver's stream. */
+typedef struct slampp_hip_assembly slampp_hip_assembly; /* opaque */
+int slampp_hip_assembly_create(slampp_hip_solver *p_solver, slampp_hip_assembly **pp_assembly, int64_t n_edges,
+	const int64_t *p_vertex0, const int64_t *p_vertex1, int n_residual_dim);
+void slampp_hip_assembly_destroy(slampp_hip_assembly *p_assembly); /* in either order with its solver's destroy */
+int slampp_hip_assemble_device_async(slampp_hip_assembly *p_assembly, const double *p_J0_dev, const double *p_J1_dev,
+	const double *p_sigma_inv_dev, const double *p_error_dev, const double *p_weight_dev, int64_t n_unary_vertex,
+	const double *p_unary_factor, const double *p_unary_error, double *p_values_dev, double *p_eta_dev, int b_accumulate);
+
 /* Multi-GPU BA (new functionality, no reference counterpart -- SURVEY.md section 8e): every rank
  * holds a landmark shard (its own points + all cameras); the partial reduced camera system
  * [S | rhs] is summed over ranks by this callback (RCCL all-reduce over xGMI) between the Schur

@@ -28,6 +28,7 @@ def lib() -> C.CDLL:
         _lib.oracle_solve_sparse.restype = C.c_int
         _lib.oracle_solve_schur.restype = C.c_int
         _lib.oracle_exec_plan.restype = C.c_int
+        _lib.oracle_assemble_lambda.restype = C.c_int
     return _lib
 
 
@@ -80,6 +81,26 @@ def exec_plan(lam, plan: dict):
         C.c_int64(plan["n_stages"]), _p(a["stage_ptr"]), _p(a["task_ptr"]), _p(a["task_cols"]),
         _p(cs), C.c_int64(plan["l_values"]), _p(vals), _p(x), _p(a["dense_pos"]), C.c_int64(plan["dense_dim"]))
     return rc, x
+
+
+def assemble_lambda(lam, edges):
+    """(values, eta) of Lambda for one edge set (slam_plus_plus_amd.synth.EdgeSet) on the structure of ``lam``."""
+    cs = np.ascontiguousarray(lam.cumsum, dtype=np.int64)
+    bp = np.ascontiguousarray(lam.bcol_ptr, dtype=np.int64)
+    br = np.ascontiguousarray(lam.brow_idx, dtype=np.int32)
+    values = np.zeros(lam.values.shape[0])
+    eta = np.zeros(int(cs[-1]))
+    f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    J0, J1, si, err, w = f(edges.J0), f(edges.J1), f(edges.sigma_inv), f(edges.err), f(edges.weight)
+    uf, ue = f(edges.unary_factor), f(edges.unary_error)
+    v0 = np.ascontiguousarray(edges.v0, dtype=np.int64)
+    v1 = np.ascontiguousarray(edges.v1, dtype=np.int64)
+    rc = lib().oracle_assemble_lambda(C.c_int64(lam.n_bcols), _p(cs), _p(bp), _p(br), C.c_int64(edges.n_edges),
+                                      _p(v0), _p(v1), C.c_int64(edges.rd), _p(J0), _p(J1), _p(si), _p(err), _p(w),
+                                      C.c_int64(edges.unary_vertex), _p(uf), _p(ue), _p(values), _p(eta))
+    if rc != 0:
+        raise ValueError("oracle_assemble_lambda: bad edge set")
+    return values, eta
 
 
 def have_reference() -> bool:

@@ -29,6 +29,14 @@
  *       with the symbolic decomposition reused where the reference's class supports it)
  *   ref_harness cholmod_phases <problem> <super|simp|auto> [reps]
  *       convert / analyze / factorize / solve split + CHOLMOD's lnz and fl counters
+ *   ref_harness lambda_dump <se2|se3> <n_poses> <seed> <out_prefix>
+ *       builds a pose graph with the reference's own vertex / edge types, lets the reference's
+ *       CNonlinearSolver_Lambda assemble Lambda and eta (include/slam/NonlinearSolver_Lambda_Base.h:1634-1688,
+ *       per-edge Hessians include/slam/BaseTypes_Binary.h:759-840) and records what it hands to its linear
+ *       solver on the first iteration; also dumps, per edge, the Jacobians, Sigma^-1, the error and the
+ *       robust weight at that linearization point.  <prefix>.lambda.bin (SPPLAM01, rhs = eta),
+ *       <prefix>.edges.bin ("SPPASM01": int64 n_verts, n_edges, d, rd; int64 v0[], v1[]; double J0[], J1[]
+ *       (rd x d column-major per edge), SigmaInv[] (rd x rd), err[] (rd), weight[]; unary factor d x d, unary error d)
  *   ref_harness schur_dump <problem> <out_prefix>
  *       replays LinearSolver_Schur.h:1687-1886 with public CUberBlockMatrix calls and dumps
  *       S (dense, col-major), reduced rhs, dx, dl, x as raw doubles
@@ -47,7 +55,10 @@
 #include "slam/ConfigSolvers.h"
 #include "slam/BA_Types.h"
 #include "slam/LinearSolver_Schur.h"
+#include "slam/SE2_Types.h"
+#include "slam/SE3_Types.h"
 #include "slam/Timer.h"
+#include <random>
 
 struct TProblem {
 	int64_t n_bcols, n_blocks, n_scalars, n_values, n_matrix_cut;
@@ -334,6 +345,184 @@ static int Main_SchurDump(int argc, char **argv)
 	return b_ok? 0 : 3;
 }
 
+/**
+ *	@brief a linear solver that records the first system it is asked to solve, then lets CHOLMOD solve it
+ */
+struct TRecordedSystem {
+	bool b_have;
+	std::vector<int64_t> cumsum, bcol_ptr, brow;
+	std::vector<double> values, eta;
+};
+static TRecordedSystem g_recorded;
+
+class CLinearSolver_Recorder {
+public:
+	typedef CBasicLinearSolverTag _Tag;
+protected:
+	CLinearSolver_CholMod m_inner;
+public:
+	CLinearSolver_Recorder() {}
+	CLinearSolver_Recorder(const CLinearSolver_Recorder &UNUSED(r_other)) {}
+	CLinearSolver_Recorder &operator =(const CLinearSolver_Recorder &UNUSED(r_other)) { return *this; }
+	void Free_Memory() { m_inner.Free_Memory(); }
+	bool Solve_PosDef(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta)
+	{
+		if(!g_recorded.b_have) {
+			TRecordedSystem &r = g_recorded;
+			const size_t n = r_lambda.n_BlockColumn_Num();
+			r.cumsum.assign(1, 0);
+			r.bcol_ptr.assign(1, 0);
+			for(size_t c = 0; c < n; ++ c) {
+				r.cumsum.push_back(r.cumsum.back() + int64_t(r_lambda.n_BlockColumn_Column_Num(c)));
+				for(size_t j = 0, m = r_lambda.n_BlockColumn_Block_Num(c); j < m; ++ j) {
+					const size_t row = r_lambda.n_Block_Row(c, j);
+					if(row > c)
+						continue;
+					CUberBlockMatrix::_TyConstMatrixXdRef b = r_lambda.t_Block_AtColumn(c, j);
+					r.brow.push_back(int64_t(row));
+					r.values.insert(r.values.end(), b.data(), b.data() + b.rows() * b.cols());
+				}
+				r.bcol_ptr.push_back(int64_t(r.brow.size()));
+			}
+			r.eta.assign(&r_eta(0), &r_eta(0) + r_eta.rows());
+			r.b_have = true;
+		}
+		return m_inner.Solve_PosDef(r_lambda, r_eta);
+	}
+};
+
+struct TEdgeDump {
+	std::vector<int64_t> v0, v1;
+	std::vector<double> J0, J1, sigma_inv, err, weight;
+};
+
+template <class CEdge, class CVector>
+static inline double f_Edge_RobustWeight(const CEdge &UNUSED(r_edge), const CVector &UNUSED(r_v_error))
+{
+	return 1; // not a robust edge (BaseTypes_Binary.h:747-750)
+}
+
+template <class CVector>
+static inline double f_Edge_RobustWeight(const CEdgePose3D &r_edge, const CVector &r_v_error)
+{
+	return r_edge.f_RobustWeight(r_v_error); // what f_Get_RobustWeight forwards to (BaseTypes_Binary.h:741-744)
+}
+
+template <int n_dim>
+struct CDumpEdges {
+	TEdgeDump *m_p_dump;
+	CDumpEdges(TEdgeDump &r_dump) :m_p_dump(&r_dump) {}
+	template <class CEdge>
+	void operator ()(const CEdge &r_edge)
+	{
+		Eigen::Matrix<double, n_dim, n_dim> J0, J1;
+		Eigen::Matrix<double, n_dim, 1> v_exp, v_err;
+		r_edge.Calculate_Jacobians_Expectation_Error(J0, J1, v_exp, v_err);
+		const Eigen::Matrix<double, n_dim, n_dim> t_sigma_inv = r_edge.t_Sigma_Inv();
+		TEdgeDump &d = *m_p_dump;
+		d.v0.push_back(int64_t(r_edge.n_Vertex_Id(0)));
+		d.v1.push_back(int64_t(r_edge.n_Vertex_Id(1)));
+		d.J0.insert(d.J0.end(), J0.data(), J0.data() + n_dim * n_dim);
+		d.J1.insert(d.J1.end(), J1.data(), J1.data() + n_dim * n_dim);
+		d.sigma_inv.insert(d.sigma_inv.end(), t_sigma_inv.data(), t_sigma_inv.data() + n_dim * n_dim);
+		d.err.insert(d.err.end(), v_err.data(), v_err.data() + n_dim);
+		d.weight.push_back(f_Edge_RobustWeight(r_edge, v_err));
+	}
+};
+
+template <class CSystemType, class CEdgeType, int n_dim>
+static int Lambda_Dump(size_t n_poses, unsigned n_seed, const std::string &r_s_prefix)
+{
+	CSystemType system;
+	CNonlinearSolver_Lambda<CSystemType, CLinearSolver_Recorder> solver(system);
+	Eigen::Matrix<double, n_dim, n_dim> information = Eigen::Matrix<double, n_dim, n_dim>::Identity() * 40;
+	for(int i = 0; i < n_dim; ++ i)
+		information(i, i) += 3 * i; // not a multiple of identity
+	std::mt19937_64 rng(n_seed);
+	std::normal_distribution<double> noise(0, 0.03);
+	for(size_t i = 1; i < n_poses; ++ i) {
+		Eigen::Matrix<double, n_dim, 1> z;
+		for(int d = 0; d < n_dim; ++ d)
+			z(d) = ((d == 0)? 1.0 : (d == n_dim - 1)? 0.15 : 0.02 * d) + noise(rng);
+		system.r_Add_Edge(CEdgeType(i - 1, i, z, information, system));
+		if(i >= 6 && i % 5 == 0) { // a second measurement of an earlier pair and a longer-range edge
+			Eigen::Matrix<double, n_dim, 1> z2 = z;
+			z2(0) += noise(rng);
+			system.r_Add_Edge(CEdgeType(i - 1, i, z2, information, system));
+			Eigen::Matrix<double, n_dim, 1> z3 = 3.0 * z;
+			for(int d = 0; d < n_dim; ++ d)
+				z3(d) += noise(rng);
+			system.r_Add_Edge(CEdgeType(i - 3, i, z3, information, system));
+		}
+		if(i >= 8 && i % 7 == 0) { // an edge from the later vertex back to an earlier one (the transposed-block case, BaseTypes_Binary.h:779-806)
+			Eigen::Matrix<double, n_dim, 1> z4 = -4.0 * z;
+			for(int d = 0; d < n_dim; ++ d)
+				z4(d) += noise(rng);
+			system.r_Add_Edge(CEdgeType(i, i - 4, z4, information, system));
+		}
+	}
+	TEdgeDump dump;
+	system.r_Edge_Pool().For_Each(CDumpEdges<n_dim>(dump)); // at the initial linearization point
+	g_recorded.b_have = false;
+	solver.Optimize(1, 0); // one iteration: Lambda and eta of the initial point go to the recorder
+	if(!g_recorded.b_have)
+		return 1;
+	{
+		FILE *f = fopen((r_s_prefix + ".lambda.bin").c_str(), "wb");
+		if(!f) return 1;
+		const TRecordedSystem &r = g_recorded;
+		int64_t hdr[8] = {int64_t(r.cumsum.size()) - 1, int64_t(r.brow.size()), r.cumsum.back(), int64_t(r.values.size()), 0, 0, 0, 0};
+		fwrite("SPPLAM01", 1, 8, f);
+		fwrite(hdr, 8, 8, f);
+		fwrite(&r.cumsum[0], 8, r.cumsum.size(), f);
+		fwrite(&r.bcol_ptr[0], 8, r.bcol_ptr.size(), f);
+		fwrite(&r.brow[0], 8, r.brow.size(), f);
+		fwrite(&r.values[0], 8, r.values.size(), f);
+		fwrite(&r.eta[0], 8, r.eta.size(), f);
+		fclose(f);
+	}
+	{
+		FILE *f = fopen((r_s_prefix + ".edges.bin").c_str(), "wb");
+		if(!f) return 1;
+		int64_t hdr[4] = {int64_t(system.r_Vertex_Pool().n_Size()), int64_t(dump.v0.size()), n_dim, n_dim};
+		fwrite("SPPASM01", 1, 8, f);
+		fwrite(hdr, 8, 4, f);
+		fwrite(&dump.v0[0], 8, dump.v0.size(), f);
+		fwrite(&dump.v1[0], 8, dump.v1.size(), f);
+		fwrite(&dump.J0[0], 8, dump.J0.size(), f);
+		fwrite(&dump.J1[0], 8, dump.J1.size(), f);
+		fwrite(&dump.sigma_inv[0], 8, dump.sigma_inv.size(), f);
+		fwrite(&dump.err[0], 8, dump.err.size(), f);
+		fwrite(&dump.weight[0], 8, dump.weight.size(), f);
+		Eigen::MatrixXd uf = system.r_t_Unary_Factor();
+		Eigen::VectorXd ue = system.r_v_Unary_Error();
+		if(uf.rows() != n_dim || uf.cols() != n_dim || ue.rows() != n_dim)
+			return 1;
+		fwrite(uf.data(), 8, n_dim * n_dim, f);
+		fwrite(ue.data(), 8, n_dim, f);
+		fclose(f);
+	}
+	printf("{\"ok\": true, \"n_verts\": %ld, \"n_edges\": %ld, \"n_blocks\": %ld}\n",
+		(long)system.r_Vertex_Pool().n_Size(), (long)dump.v0.size(), (long)g_recorded.brow.size());
+	return 0;
+}
+
+static int Main_LambdaDump(int argc, char **argv)
+{
+	if(argc < 6) return 2;
+	const std::string s_kind = argv[2];
+	const size_t n_poses = size_t(atol(argv[3]));
+	const unsigned n_seed = unsigned(atol(argv[4]));
+	if(s_kind == "se2") {
+		typedef CFlatSystem<CVertexPose2D, MakeTypelist(CVertexPose2D), CEdgePose2D, MakeTypelist(CEdgePose2D)> CSystemType;
+		return Lambda_Dump<CSystemType, CEdgePose2D, 3>(n_poses, n_seed, argv[5]);
+	} else if(s_kind == "se3") {
+		typedef CFlatSystem<CVertexPose3D, MakeTypelist(CVertexPose3D), CEdgePose3D, MakeTypelist(CEdgePose3D)> CSystemType;
+		return Lambda_Dump<CSystemType, CEdgePose3D, 6>(n_poses, n_seed, argv[5]);
+	}
+	return 2;
+}
+
 int main(int argc, char **argv)
 {
 	if(argc >= 2) {
@@ -344,6 +533,8 @@ int main(int argc, char **argv)
 				return Main_CholmodPhases(argc, argv);
 			if(!strcmp(argv[1], "schur_dump"))
 				return Main_SchurDump(argc, argv);
+			if(!strcmp(argv[1], "lambda_dump"))
+				return Main_LambdaDump(argc, argv);
 		} catch(std::exception &r_exc) {
 			fprintf(stderr, "error: uncaught exception: %s\n", r_exc.what());
 			return 4;

@@ -898,3 +898,108 @@ int oracle_exec_plan(int64_t n, const int32_t *perm, const int32_t *dim, const i
 	free(L); free(Linv); free(cs_new); free(blk_col); free(done_stage); free(done_task); free(w);
 	return result;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Lambda / eta assembly from per-edge Jacobians (the row after the solve in SURVEY.md section 8f).
+ * Restates, for one homogeneous set of binary edges:
+ *   per-edge Hessian blocks and right-hand sides       include/slam/BaseTypes_Binary.h:759-840
+ *       H0S = J0^T Sigma^-1 [* w]                       :771-777
+ *       off-diagonal (min id, max id) = H0S J1, or J1^T H0S^T when id0 > id1   :779-806
+ *       vertex 0: H0S J0,  rhs H0S e [* w]  (w enters twice for a robust edge)  :809-823
+ *       vertex 1: J1^T Sigma^-1 J1 [* w],  rhs J1^T (Sigma^-1 e) [* w]          :824-840
+ *   the sums per block / per vertex (the reduction plan) include/slam/NonlinearSolver_Lambda_Base.h:1634-1688
+ *   the unary factor on the anchor vertex: += U^T U, eta += unary error        :1520-1580
+ * Pinned against Lambda / eta recorded from the reference's CNonlinearSolver_Lambda (ref_harness lambda_dump,
+ * tests/golden/assembly_*.npz).  weight may be NULL (not a robust edge).  Returns 0, or -1 on a bad edge.
+ * ------------------------------------------------------------------------------------------- */
+int oracle_assemble_lambda(int64_t n, const int64_t *cs, const int64_t *ptr, const int32_t *brow,
+	int64_t n_edges, const int64_t *v0, const int64_t *v1, int64_t rd,
+	const double *J0, const double *J1, const double *sigma_inv, const double *err, const double *weight,
+	int64_t unary_vertex, const double *unary_factor, const double *unary_error,
+	double *values, double *eta)
+{
+	int64_t *voff = (int64_t*)malloc((size_t)(ptr[n] + 1) * sizeof(int64_t));
+	int64_t c, k, e, i, j, a, b;
+	if(!voff)
+		return -1;
+	voff[0] = 0;
+	for(c = 0; c < n; ++ c)
+		for(k = ptr[c]; k < ptr[c + 1]; ++ k)
+			voff[k + 1] = voff[k] + (cs[brow[k] + 1] - cs[brow[k]]) * (cs[c + 1] - cs[c]);
+	memset(values, 0, (size_t)voff[ptr[n]] * sizeof(double));
+	memset(eta, 0, (size_t)cs[n] * sizeof(double));
+	for(e = 0; e < n_edges; ++ e) {
+		const int64_t id0 = v0[e], id1 = v1[e];
+		const int64_t d0 = cs[id0 + 1] - cs[id0], d1 = cs[id1 + 1] - cs[id1];
+		const double *j0 = J0 + e * rd * d0, *j1 = J1 + e * rd * d1, *S = sigma_inv + e * rd * rd, *er = err + e * rd;
+		const double w = weight? weight[e] : 1.0;
+		double H0S[8 * 8], H1S[8 * 8], Se[8]; /* H0S: d0 x rd column-major */
+		const int64_t r = (id0 < id1)? id0 : id1, cc = (id0 < id1)? id1 : id0;
+		double *dst = 0, *d00, *d11;
+		if(id0 == id1 || d0 > 8 || d1 > 8 || rd > 8) { free(voff); return -1; }
+		for(k = ptr[cc]; k < ptr[cc + 1]; ++ k)
+			if(brow[k] == r) dst = values + voff[k];
+		if(!dst || brow[ptr[id0 + 1] - 1] != id0 || brow[ptr[id1 + 1] - 1] != id1) { free(voff); return -1; }
+		d00 = values + voff[ptr[id0 + 1] - 1];
+		d11 = values + voff[ptr[id1 + 1] - 1];
+		for(i = 0; i < d0; ++ i)
+			for(b = 0; b < rd; ++ b) {
+				double s = 0;
+				for(a = 0; a < rd; ++ a) s += j0[a + i * rd] * S[a + b * rd];
+				H0S[i + b * d0] = s * w;
+			}
+		for(i = 0; i < d1; ++ i)
+			for(b = 0; b < rd; ++ b) {
+				double s = 0;
+				for(a = 0; a < rd; ++ a) s += j1[a + i * rd] * S[a + b * rd];
+				H1S[i + b * d1] = s;
+			}
+		for(a = 0; a < rd; ++ a) {
+			double s = 0;
+			for(b = 0; b < rd; ++ b) s += S[a + b * rd] * er[b];
+			Se[a] = s;
+		}
+		/* off-diagonal: (i, j) of H0S J1 goes to (i, j) of a d0 x d1 block, or to (j, i) of a d1 x d0 block */
+		for(i = 0; i < d0; ++ i)
+			for(j = 0; j < d1; ++ j) {
+				double s = 0;
+				for(b = 0; b < rd; ++ b) s += H0S[i + b * d0] * j1[b + j * rd];
+				if(id0 < id1) dst[i + j * d0] += s;
+				else dst[j + i * d1] += s;
+			}
+		for(i = 0; i < d0; ++ i) {
+			double s = 0;
+			for(j = 0; j < d0; ++ j) {
+				double h = 0;
+				for(b = 0; b < rd; ++ b) h += H0S[i + b * d0] * j0[b + j * rd];
+				d00[i + j * d0] += h;
+			}
+			for(b = 0; b < rd; ++ b) s += H0S[i + b * d0] * er[b];
+			eta[cs[id0] + i] += s * w; /* sic: w is already in H0S (:813-815) */
+		}
+		for(i = 0; i < d1; ++ i) {
+			double s = 0;
+			for(j = 0; j < d1; ++ j) {
+				double h = 0;
+				for(b = 0; b < rd; ++ b) h += H1S[i + b * d1] * j1[b + j * rd];
+				d11[i + j * d1] += h * w;
+			}
+			for(a = 0; a < rd; ++ a) s += j1[a + i * rd] * Se[a];
+			eta[cs[id1] + i] += s * w;
+		}
+	}
+	if(unary_factor && unary_vertex >= 0 && unary_vertex < n) {
+		const int64_t d = cs[unary_vertex + 1] - cs[unary_vertex];
+		double *dd = values + voff[ptr[unary_vertex + 1] - 1];
+		for(i = 0; i < d; ++ i)
+			for(j = 0; j < d; ++ j) {
+				double s = 0;
+				for(k = 0; k < d; ++ k) s += unary_factor[k + i * d] * unary_factor[k + j * d];
+				dd[i + j * d] += s;
+			}
+		for(i = 0; i < d && unary_error; ++ i)
+			eta[cs[unary_vertex] + i] += unary_error[i];
+	}
+	free(voff);
+	return 0;
+}

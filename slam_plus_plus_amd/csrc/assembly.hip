@@ -1,0 +1,291 @@
+// assembly.hip -- Lambda and eta assembled on the device from per-edge Jacobians.
+//
+// Stands where the reference computes the per-edge Hessian blocks on the host and runs its reduction plan
+// (/root/reference/include/slam/BaseTypes_Binary.h:759-840 Calculate_Hessians_v2;
+//  include/slam/NonlinearSolver_Lambda_Base.h:1634-1688 Refresh_Lambda, :1520-1580 unary factor), for one
+// homogeneous set of binary edges (J0: rd x d0, J1: rd x d1, Sigma^-1: rd x rd, error: rd, robust weight w):
+//   off-diagonal block (min id, max id)   = J0^T (w Sigma^-1) J1          (transposed if id0 > id1, :779-806)
+//   diagonal block of vertex 0 / vertex 1 += J0^T (w Sigma^-1) J0  /  J1^T (w Sigma^-1) J1
+//   eta of vertex 0                       += w^2 J0^T Sigma^-1 e   (sic: the reference multiplies by w twice, :813-815)
+//   eta of vertex 1                       += w   J1^T Sigma^-1 e                                           (:836-838)
+//   diagonal block / eta of the anchor    += U^T U / unary error   (NonlinearSolver_Lambda_Base.h:1551-1567)
+// One wave per block of Lambda sums the contributions of its edges in a fixed order from host-built lists
+// (no atomics, bit-reproducible) and writes the block where the solver's packed value array expects it, so
+// that factor_solve_device can run on the result without Lambda ever visiting the host.  HBM-bound.
+#include "solver.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace slampp {
+
+struct TAsmBlk { // 32 B: one block of Lambda and the edges that contribute to it
+	int64_t dst;       // offset in the packed Lambda values
+	int64_t e0;        // first entry of its edge list
+	int64_t eta_off;   // diagonal blocks: scalar offset of the vertex in eta
+	int32_t ne;        // number of entries
+	int16_t rows, cols;
+};
+
+struct CAssemblyState {
+	int64_t n_edges;
+	int d0, d1, rd;
+	int64_t n_offdiag, n_diag;
+	CDevArray<TAsmBlk> d_offdiag, d_diag;
+	CDevArray<int32_t> d_entries;   // edge index * 2 + (off-diagonal: flipped; diagonal: side)
+	CDevArray<double> d_unary;      // [64 + 8]: U^T U (column-major d x d), unary error
+	double h_unary[72];             // what d_unary holds
+	bool b_unary_valid;
+	slampp_hip_solver *p_solver;
+};
+
+void assembly_destroy(CAssemblyState *p) { delete p; }
+
+CAssemblyState *assembly_setup(slampp_hip_solver &s, int64_t n_edges, const int64_t *v0, const int64_t *v1, int rd)
+{
+	if(!s.b_has_structure)
+		throw std::invalid_argument("assembly_setup: set_structure was not called");
+	if(n_edges <= 0 || !v0 || !v1 || rd <= 0 || rd > 8)
+		throw std::invalid_argument("assembly_setup: bad edge set");
+	const int64_t n = int64_t(s.cumsum.size()) - 1;
+	const int64_t *cs = s.cumsum.data(), *ptr = s.bcol_ptr.data();
+	const int32_t *brow = s.brow.data();
+	for(int64_t e = 0; e < n_edges; ++ e) {
+		if(v0[e] < 0 || v0[e] >= n || v1[e] < 0 || v1[e] >= n || v0[e] == v1[e])
+			throw std::invalid_argument("assembly_setup: edge refers to a vertex outside Lambda, or to one vertex twice");
+	}
+	const int d0 = int(cs[v0[0] + 1] - cs[v0[0]]), d1 = int(cs[v1[0] + 1] - cs[v1[0]]);
+	if(d0 > 7 || d1 > 7)
+		throw std::domain_error("assembly: vertex dimensions above 7 are not supported");
+	for(int64_t e = 0; e < n_edges; ++ e) {
+		if(cs[v0[e] + 1] - cs[v0[e]] != d0 || cs[v1[e] + 1] - cs[v1[e]] != d1)
+			throw std::domain_error("assembly: all edges of a set must join vertices of the same two dimensions");
+	}
+	// value offset of every block of Lambda
+	std::vector<int64_t> voff(ptr[n] + 1, 0);
+	for(int64_t c = 0; c < n; ++ c)
+		for(int64_t k = ptr[c]; k < ptr[c + 1]; ++ k)
+			voff[k + 1] = voff[k] + (cs[brow[k] + 1] - cs[brow[k]]) * (cs[c + 1] - cs[c]);
+	// edge lists per block: count, then fill (stable: edges stay in their given order inside a list)
+	std::vector<int64_t> blk_of_edge(n_edges);
+	std::vector<int32_t> cnt_off(ptr[n], 0), cnt_diag(n, 0);
+	for(int64_t e = 0; e < n_edges; ++ e) {
+		const int64_t r = std::min(v0[e], v1[e]), c = std::max(v0[e], v1[e]);
+		const int32_t *b = std::lower_bound(brow + ptr[c], brow + ptr[c + 1], int32_t(r));
+		if(b == brow + ptr[c + 1] || *b != r)
+			throw std::invalid_argument("assembly_setup: Lambda has no block for an edge");
+		blk_of_edge[e] = b - brow;
+		++ cnt_off[b - brow];
+		++ cnt_diag[v0[e]];
+		++ cnt_diag[v1[e]];
+	}
+	std::vector<TAsmBlk> offdiag, diag(n);
+	std::vector<int64_t> off_slot(ptr[n], -1);
+	int64_t n_entries = 0;
+	for(int64_t c = 0; c < n; ++ c) {
+		for(int64_t k = ptr[c]; k < ptr[c + 1]; ++ k) {
+			if(brow[k] == c)
+				continue;
+			TAsmBlk b;
+			b.dst = voff[k]; b.e0 = n_entries; b.ne = cnt_off[k]; b.eta_off = 0;
+			b.rows = int16_t(cs[brow[k] + 1] - cs[brow[k]]); b.cols = int16_t(cs[c + 1] - cs[c]);
+			n_entries += cnt_off[k];
+			off_slot[k] = int64_t(offdiag.size());
+			offdiag.push_back(b); // blocks without an edge are written as zeros
+		}
+	}
+	for(int64_t v = 0; v < n; ++ v) {
+		if(ptr[v + 1] == ptr[v] || brow[ptr[v + 1] - 1] != v)
+			throw std::invalid_argument("assembly_setup: a diagonal block is missing");
+		TAsmBlk &b = diag[v];
+		b.dst = voff[ptr[v + 1] - 1]; b.e0 = n_entries; b.ne = cnt_diag[v]; b.eta_off = cs[v];
+		b.rows = b.cols = int16_t(cs[v + 1] - cs[v]);
+		if(b.rows > 7)
+			throw std::domain_error("assembly: vertex dimensions above 7 are not supported");
+		n_entries += cnt_diag[v];
+	}
+	if(n_edges >= (int64_t(1) << 30))
+		throw std::domain_error("assembly: too many edges");
+	std::vector<int32_t> entries(n_entries);
+	{
+		std::vector<int64_t> fill_off(offdiag.size()), fill_diag(n);
+		for(size_t i = 0; i < offdiag.size(); ++ i) fill_off[i] = offdiag[i].e0;
+		for(int64_t v = 0; v < n; ++ v) fill_diag[v] = diag[v].e0;
+		for(int64_t e = 0; e < n_edges; ++ e) {
+			entries[fill_off[off_slot[blk_of_edge[e]]] ++] = int32_t(e * 2 + (v0[e] > v1[e]));
+			entries[fill_diag[v0[e]] ++] = int32_t(e * 2);
+			entries[fill_diag[v1[e]] ++] = int32_t(e * 2 + 1);
+		}
+	}
+	CAssemblyState *p = new CAssemblyState();
+	try {
+		p->n_edges = n_edges; p->d0 = d0; p->d1 = d1; p->rd = rd;
+		p->n_offdiag = int64_t(offdiag.size()); p->n_diag = n;
+		p->d_offdiag.Upload(offdiag, s.stream);
+		p->d_diag.Upload(diag, s.stream);
+		p->d_entries.Upload(entries, s.stream);
+		p->d_unary.Alloc(72);
+		p->b_unary_valid = false;
+		p->p_solver = &s;
+		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+	} catch(...) {
+		delete p;
+		throw;
+	}
+	return p;
+}
+
+// t[b] = sum_a J[a + col * rd] * S[a + b * rd]  (row `col` of J^T Sigma^-1), b < rd
+template <int RD>
+__device__ __forceinline__ void jt_sigma_row(const double *__restrict__ J, const double *__restrict__ S, int col, int rd,
+	double (&t)[RD? RD : 8])
+{
+	enum { N = RD? RD : 8 };
+	double j[N];
+	#pragma unroll
+	for(int a = 0; a < N; ++ a)
+		j[a] = (RD || a < rd)? J[a + col * rd] : 0.0;
+	#pragma unroll
+	for(int b = 0; b < N; ++ b) {
+		double sum = 0;
+		if(RD || b < rd) {
+			#pragma unroll
+			for(int a = 0; a < N; ++ a)
+				if(RD || a < rd) sum += j[a] * S[a + b * rd];
+		}
+		t[b] = sum;
+	}
+}
+
+template <int RD>
+__device__ __forceinline__ double dot_rd(const double (&t)[RD? RD : 8], const double *__restrict__ v, int rd)
+{
+	enum { N = RD? RD : 8 };
+	double sum = 0;
+	#pragma unroll
+	for(int b = 0; b < N; ++ b)
+		if(RD || b < rd) sum += t[b] * v[b];
+	return sum;
+}
+
+// one wave per off-diagonal block (row vertex < column vertex): sum over its edges of J_row^T (w S) J_col
+template <int RD>
+__global__ void __launch_bounds__(64)
+assemble_offdiag_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__restrict__ entries, int d0, int d1, int n_rd,
+	const double *__restrict__ J0, const double *__restrict__ J1, const double *__restrict__ Si,
+	const double *__restrict__ wgt, double *values, int b_accumulate)
+{
+	const int rd = RD? RD : n_rd;
+	const TAsmBlk bd = blks[blockIdx.x];
+	const int lane = threadIdx.x;
+	if(lane >= bd.rows * bd.cols)
+		return;
+	const int r = lane % bd.rows, q = lane / bd.rows;
+	double acc = b_accumulate? values[bd.dst + lane] : 0.0;
+	for(int i = 0; i < bd.ne; ++ i) {
+		const int32_t ent = entries[bd.e0 + i];
+		const int64_t e = ent >> 1;
+		const bool b_flip = ent & 1; // vertex 0 has the larger id: the stored block is (J0^T w S J1)^T
+		// element (c0, c1) of J0^T (w S) J1 lands on (r, q) of the stored block
+		const int c0 = b_flip? q : r, c1 = b_flip? r : q;
+		double t[RD? RD : 8];
+		jt_sigma_row<RD>(J0 + e * rd * d0, Si + e * rd * rd, c0, rd, t);
+		acc += dot_rd<RD>(t, J1 + e * rd * d1 + c1 * rd, rd) * (wgt? wgt[e] : 1.0);
+	}
+	values[bd.dst + lane] = acc; // a structural block without an edge becomes zeros
+}
+
+// one wave per vertex: diagonal block (lanes r + q d) and eta (lanes 56 + q)
+template <int RD>
+__global__ void __launch_bounds__(64)
+assemble_diag_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__restrict__ entries, int d0, int d1, int n_rd,
+	const double *__restrict__ J0, const double *__restrict__ J1, const double *__restrict__ Si,
+	const double *__restrict__ err, const double *__restrict__ wgt, int unary_vertex, const double *__restrict__ unary,
+	double *values, double *eta, int b_accumulate)
+{
+	const int rd = RD? RD : n_rd;
+	const TAsmBlk bd = blks[blockIdx.x];
+	const int lane = threadIdx.x;
+	const int d = bd.rows;
+	const bool b_blk = lane < d * d, b_y = lane >= 56 && lane < 56 + d;
+	if(!b_blk && !b_y)
+		return;
+	const int r = b_blk? lane % d : lane - 56, q = b_blk? lane / d : 0;
+	double *p_dst = b_blk? values + bd.dst + lane : eta + bd.eta_off + r;
+	double acc = b_accumulate? *p_dst : 0.0;
+	for(int i = 0; i < bd.ne; ++ i) {
+		const int32_t ent = entries[bd.e0 + i];
+		const int64_t e = ent >> 1;
+		const int side = ent & 1;
+		const double *J = side? J1 + e * rd * d1 : J0 + e * rd * d0;
+		const double w = wgt? wgt[e] : 1.0;
+		double t[RD? RD : 8];
+		jt_sigma_row<RD>(J, Si + e * rd * rd, r, rd, t); // row r of J^T Sigma^-1
+		// block lanes: times column q of J, weighted once; eta lanes: times the error, and the reference
+		// weights vertex 0's right-hand side twice (BaseTypes_Binary.h:813-815 against :836-838)
+		acc += dot_rd<RD>(t, b_blk? J + q * rd : err + e * rd, rd) * ((b_blk || side)? w : w * w);
+	}
+	if(int(blockIdx.x) == unary_vertex)
+		acc += b_blk? unary[lane] : unary[64 + r];
+	*p_dst = acc;
+}
+
+void assembly_enqueue(CAssemblyState &a, const double *J0, const double *J1, const double *Si, const double *err,
+	const double *wgt, int64_t n_unary_vertex, const double *p_unary_factor, const double *p_unary_error,
+	double *values_out, double *eta_out, int b_accumulate)
+{
+	slampp_hip_solver &s = *a.p_solver;
+	hipStream_t st = s.stream;
+	if(!J0 || !J1 || !Si || !err || !values_out || !eta_out)
+		throw std::invalid_argument("assemble: null device pointer");
+	int n_unary = -1;
+	if(p_unary_factor) {
+		if(n_unary_vertex < 0 || n_unary_vertex >= a.n_diag)
+			throw std::invalid_argument("assemble: the unary factor's vertex is outside Lambda");
+		const int d = int(s.cumsum[n_unary_vertex + 1] - s.cumsum[n_unary_vertex]);
+		double h[72];
+		memset(h, 0, sizeof(h));
+		for(int q = 0; q < d; ++ q) {
+			for(int r = 0; r < d; ++ r) {
+				double sum = 0; // U^T U, U column-major d x d (NonlinearSolver_Lambda_Base.h:1551-1553)
+				for(int k = 0; k < d; ++ k)
+					sum += p_unary_factor[k + r * d] * p_unary_factor[k + q * d];
+				h[r + q * d] = sum;
+			}
+		}
+		for(int q = 0; q < d && p_unary_error; ++ q)
+			h[64 + q] = p_unary_error[q];
+		if(!a.b_unary_valid || memcmp(h, a.h_unary, sizeof(h))) {
+			SLAMPP_HIP_CHECK(hipStreamSynchronize(st)); // an earlier launch may still read d_unary
+			memcpy(a.h_unary, h, sizeof(h));
+			SLAMPP_HIP_CHECK(hipMemcpyAsync(a.d_unary.p(), a.h_unary, sizeof(h), hipMemcpyHostToDevice, st));
+			a.b_unary_valid = true;
+		}
+		n_unary = int(n_unary_vertex);
+	}
+	s.Phase_Begin("assemble");
+#define LAUNCH_ASM(RD) do { \
+		if(a.n_offdiag > 0) \
+			hipLaunchKernelGGL(assemble_offdiag_kernel<RD>, dim3(unsigned(a.n_offdiag)), dim3(64), 0, st, a.d_offdiag.p(), \
+				a.d_entries.p(), a.d0, a.d1, a.rd, J0, J1, Si, wgt, values_out, b_accumulate); \
+		hipLaunchKernelGGL(assemble_diag_kernel<RD>, dim3(unsigned(a.n_diag)), dim3(64), 0, st, a.d_diag.p(), \
+			a.d_entries.p(), a.d0, a.d1, a.rd, J0, J1, Si, err, wgt, n_unary, a.d_unary.p(), values_out, eta_out, \
+			b_accumulate); } while(0)
+	switch(a.rd) {
+	case 2: LAUNCH_ASM(2); break;
+	case 3: LAUNCH_ASM(3); break;
+	case 6: LAUNCH_ASM(6); break;
+	case 7: LAUNCH_ASM(7); break;
+	default: LAUNCH_ASM(0); break;
+	}
+#undef LAUNCH_ASM
+	s.Phase_End();
+	SLAMPP_HIP_CHECK(hipGetLastError());
+}
+
+size_t assembly_device_bytes(const CAssemblyState *p)
+{
+	return p->d_offdiag.n_Bytes() + p->d_diag.n_Bytes() + p->d_entries.n_Bytes() + p->d_unary.n_Bytes();
+}
+
+} // namespace slampp

@@ -214,6 +214,7 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 		S.d_z.Alloc(S.Npad);
 		S.d_x.Alloc(S.Npad);
 		s.d_flag.Alloc(1);
+		SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), s.stream)); // sync() before the first factorization reads it
 		SLAMPP_HIP_CHECK(hipStreamSynchronize(st));
 	} catch(...) {
 		delete p;

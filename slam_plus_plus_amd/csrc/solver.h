@@ -70,8 +70,15 @@ public:
 };
 
 struct CSchurState; // schur.hip
+struct CAssemblyState; // assembly.hip
 
 } // namespace slampp
+
+struct slampp_hip_assembly {
+	slampp_hip_solver *p_solver;     // null once the solver is gone
+	slampp::CAssemblyState *p_state;
+	bool b_stale;                    // set_structure() was called since: the block offsets no longer apply
+};
 
 struct slampp_hip_solver {
 	int n_device;
@@ -108,6 +115,7 @@ struct slampp_hip_solver {
 	int *p_host_flag; // pinned
 
 	slampp::CSchurState *p_schur;
+	std::vector<slampp_hip_assembly*> assemblies; // live Lambda assemblies created from this solver
 
 	slampp_hip_allreduce_fn p_allreduce;
 	void *p_allreduce_context;
@@ -135,6 +143,7 @@ struct slampp_hip_solver {
 	void Enqueue_Sparse(const double *p_values_dev, double *p_rhs_dev, bool b_factor);
 };
 
+
 namespace slampp {
 
 // Schur path entry points (schur.hip)
@@ -143,5 +152,13 @@ CSchurState *schur_analyze(slampp_hip_solver &s); // throws
 void schur_enqueue(slampp_hip_solver &s, const double *p_values_dev, double *p_rhs_dev); // throws
 size_t schur_device_bytes(const CSchurState *p);
 void schur_fill_stats(const CSchurState *p, slampp_hip_stats &st);
+
+// Lambda assembly (assembly.hip)
+CAssemblyState *assembly_setup(slampp_hip_solver &s, int64_t n_edges, const int64_t *v0, const int64_t *v1, int rd); // throws
+void assembly_destroy(CAssemblyState *p);
+void assembly_enqueue(CAssemblyState &a, const double *J0, const double *J1, const double *Si, const double *err,
+	const double *wgt, int64_t n_unary_vertex, const double *p_unary_factor, const double *p_unary_error,
+	double *values_out, double *eta_out, int b_accumulate); // throws
+size_t assembly_device_bytes(const CAssemblyState *p);
 
 } // namespace slampp

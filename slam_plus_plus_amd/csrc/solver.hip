@@ -235,6 +235,7 @@ void slampp_hip_solver::Analyze_Sparse()
 	d_Linv.Alloc(size_t(P.linv_off[P.n]));
 	d_w.Alloc(size_t(P.cs_new[P.n]));
 	d_flag.Alloc(1);
+	SLAMPP_HIP_CHECK(hipMemsetAsync(d_flag.p(), 0, sizeof(int), stream)); // sync() before the first factorization reads it
 	SETUP_PHASE("allocs");
 	SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // the staging vectors above die here
 	SETUP_PHASE("sync");
@@ -369,6 +370,12 @@ void slampp_hip_destroy(slampp_hip_solver *p_solver)
 {
 	if(p_solver) {
 		(void)hipSetDevice(p_solver->n_device);
+		(void)hipStreamSynchronize(p_solver->stream);
+		for(slampp_hip_assembly *p_assembly : p_solver->assemblies) { // orphaned, not freed: the caller owns the handles
+			assembly_destroy(p_assembly->p_state);
+			p_assembly->p_state = 0;
+			p_assembly->p_solver = 0;
+		}
 		delete p_solver;
 	}
 }
@@ -424,6 +431,14 @@ int slampp_hip_set_structure(slampp_hip_solver *p_solver, int64_t n_bcols, const
 		if(p_bcol_cumsum[0] != 0 || p_bcol_ptr[0] != 0)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "set_structure: cumsum / pointer arrays must start at 0");
 		slampp_hip_solver &s = *p_solver;
+		const bool b_same = s.b_has_structure && int64_t(s.cumsum.size()) == n_bcols + 1 &&
+			std::equal(s.cumsum.begin(), s.cumsum.end(), p_bcol_cumsum) &&
+			std::equal(s.bcol_ptr.begin(), s.bcol_ptr.end(), p_bcol_ptr) &&
+			std::equal(s.brow.begin(), s.brow.end(), p_brow_idx);
+		if(!b_same) {
+			for(slampp_hip_assembly *p_assembly : s.assemblies)
+				p_assembly->b_stale = true; // their block offsets belong to the previous structure
+		}
 		s.cumsum.assign(p_bcol_cumsum, p_bcol_cumsum + n_bcols + 1);
 		s.bcol_ptr.assign(p_bcol_ptr, p_bcol_ptr + n_bcols + 1);
 		s.brow.assign(p_brow_idx, p_brow_idx + p_bcol_ptr[n_bcols]);
@@ -687,6 +702,63 @@ static void Fill_PlanView(const Plan &P, slampp_hip_plan_view *v)
 	COPY_OUT(v->p_dense_pos, P.dense_pos);
 	v->dense_dim = P.dense_dim;
 #undef COPY_OUT
+}
+
+int slampp_hip_assembly_create(slampp_hip_solver *p_solver, slampp_hip_assembly **pp_assembly, int64_t n_edges,
+	const int64_t *p_vertex0, const int64_t *p_vertex1, int n_residual_dim)
+{
+	if(!pp_assembly)
+		return SLAMPP_HIP_ERR_INVALID;
+	*pp_assembly = 0;
+	return guarded(p_solver, [&]() -> int {
+		CAssemblyState *p_state = assembly_setup(*p_solver, n_edges, p_vertex0, p_vertex1, n_residual_dim);
+		slampp_hip_assembly *p = new(std::nothrow) slampp_hip_assembly;
+		if(!p) {
+			assembly_destroy(p_state);
+			throw std::bad_alloc();
+		}
+		p->p_solver = p_solver;
+		p->p_state = p_state;
+		p->b_stale = false;
+		try {
+			p_solver->assemblies.push_back(p);
+		} catch(...) {
+			assembly_destroy(p_state);
+			delete p;
+			throw;
+		}
+		*pp_assembly = p;
+		return SLAMPP_HIP_OK;
+	});
+}
+
+void slampp_hip_assembly_destroy(slampp_hip_assembly *p_assembly)
+{
+	if(!p_assembly)
+		return;
+	if(slampp_hip_solver *p_solver = p_assembly->p_solver) {
+		(void)hipSetDevice(p_solver->n_device);
+		(void)hipStreamSynchronize(p_solver->stream);
+		assembly_destroy(p_assembly->p_state);
+		std::vector<slampp_hip_assembly*> &r_list = p_solver->assemblies;
+		r_list.erase(std::remove(r_list.begin(), r_list.end(), p_assembly), r_list.end());
+	}
+	delete p_assembly;
+}
+
+int slampp_hip_assemble_device_async(slampp_hip_assembly *p_assembly, const double *p_J0_dev, const double *p_J1_dev,
+	const double *p_sigma_inv_dev, const double *p_error_dev, const double *p_weight_dev, int64_t n_unary_vertex,
+	const double *p_unary_factor, const double *p_unary_error, double *p_values_dev, double *p_eta_dev, int b_accumulate)
+{
+	if(!p_assembly || !p_assembly->p_solver)
+		return SLAMPP_HIP_ERR_INVALID; // the solver it was created from is gone
+	return guarded(p_assembly->p_solver, [&]() -> int {
+		if(p_assembly->b_stale)
+			throw std::invalid_argument("assemble: set_structure was called after this assembly was created");
+		assembly_enqueue(*p_assembly->p_state, p_J0_dev, p_J1_dev, p_sigma_inv_dev, p_error_dev, p_weight_dev,
+			n_unary_vertex, p_unary_factor, p_unary_error, p_values_dev, p_eta_dev, b_accumulate);
+		return SLAMPP_HIP_OK;
+	});
 }
 
 int slampp_hip_get_plan(const slampp_hip_solver *p_solver, slampp_hip_plan_view *p_view)

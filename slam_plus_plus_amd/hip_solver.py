@@ -10,6 +10,8 @@ same error behaviour (``False`` = not positive definite, ``MemoryError`` = std::
 * ``CLinearSolver_CholMod`` / ``CLinearSolver_UberBlock``  (LinearSolver_CholMod.h:148-214,
   LinearSolver_UberBlock.h:256-426)  ->  :class:`CLinearSolver_HIP`
 * ``CLinearSolver_Schur``  (LinearSolver_Schur.h:1423-1935)  ->  :class:`CLinearSolver_Schur_HIP`
+* ``CNonlinearSolver_Lambda::Refresh_Lambda`` (NonlinearSolver_Lambda_Base.h:1634-1688) for one edge set
+  ->  :class:`CLambdaAssembly_HIP`
 
 There is no CPU fallback: if the shared library is missing, or there is no GPU, construction raises.
 """
@@ -85,6 +87,9 @@ ABI = {
     "slampp_hip_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "slampp_hip_get_profile": (C.c_int, [_P, C.POINTER(PhaseTime), C.c_int, C.POINTER(C.c_int), C.c_int]),
     "slampp_hip_set_allreduce": (C.c_int, [_P, ALLREDUCE_FN, _P]),
+    "slampp_hip_assembly_create": (C.c_int, [_P, C.POINTER(_P), C.c_int64, _P, _P, C.c_int]),
+    "slampp_hip_assembly_destroy": (None, [_P]),
+    "slampp_hip_assemble_device_async": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, C.c_int]),
     "slampp_hip_get_plan": (C.c_int, [_P, C.POINTER(PlanView)]),
     "slampp_hip_plan_create": (C.c_int, [C.POINTER(_P), C.c_int64, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
     "slampp_hip_plan_get": (C.c_int, [_P, C.POINTER(PlanView), C.POINTER(Stats)]),
@@ -347,3 +352,44 @@ class CLinearSolver_Schur_HIP(_SolverBase):
 
     def SymbolicDecomposition_Blocky(self, lam, b_force_guided_ordering: bool = False) -> bool:
         return super().SymbolicDecomposition_Blocky(lam)
+
+
+class CLambdaAssembly_HIP:
+    """Lambda and eta assembled on the device from per-edge Jacobians, written where the solver reads them.
+
+    Stands where the reference computes every edge's Hessian blocks on the host and sums them with its
+    reduction plan (BaseTypes_Binary.h:759-840, NonlinearSolver_Lambda_Base.h:1634-1688), for one homogeneous
+    set of binary edges.  ``lam`` supplies the block structure (it must hold block (min, max) of every edge)."""
+
+    def __init__(self, solver: _SolverBase, lam, v0: np.ndarray, v1: np.ndarray, n_residual_dim: int):
+        self._solver = solver          # keeps the solver (and its stream) alive
+        self._lib = solver._lib
+        self._a = C.c_void_p()
+        if not solver._analyzed or solver._structure_key != solver._key(lam):
+            solver.SymbolicDecomposition_Blocky(lam)
+        v0 = np.ascontiguousarray(v0, dtype=np.int64)
+        v1 = np.ascontiguousarray(v1, dtype=np.int64)
+        if v0.shape != v1.shape or v0.ndim != 1:
+            raise ValueError("v0 and v1 must be vectors of one length")
+        solver._check(self._lib.slampp_hip_assembly_create(solver._h, C.byref(self._a), v0.shape[0], _ptr(v0), _ptr(v1),
+                                                           int(n_residual_dim)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_a", None):
+                self._lib.slampp_hip_assembly_destroy(self._a)
+                self._a = None
+        except Exception:
+            pass
+
+    def Refresh_Lambda_device(self, J0_ptr: int, J1_ptr: int, sigma_inv_ptr: int, error_ptr: int, weight_ptr: int,
+                              values_ptr: int, eta_ptr: int, unary_vertex: int = 0, unary_factor=None,
+                              unary_error=None, accumulate: bool = False) -> None:
+        """Enqueues the assembly on the solver's stream (device pointers as integers; ``weight_ptr`` 0 = no
+        robust weights).  ``unary_factor`` is the d x d factor U of the anchor (column-major) and
+        ``unary_error`` its error vector, both host arrays or None."""
+        uf = None if unary_factor is None else np.ascontiguousarray(unary_factor, dtype=np.float64)
+        ue = None if unary_error is None else np.ascontiguousarray(unary_error, dtype=np.float64)
+        self._solver._check(self._lib.slampp_hip_assemble_device_async(
+            self._a, J0_ptr, J1_ptr, sigma_inv_ptr, error_ptr, weight_ptr or None, int(unary_vertex),
+            None if uf is None else _ptr(uf), None if ue is None else _ptr(ue), values_ptr, eta_ptr, int(bool(accumulate))))

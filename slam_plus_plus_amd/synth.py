@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import dataclasses
 import struct
+from typing import Optional
 
 import numpy as np
 
@@ -305,3 +306,94 @@ def indefinite(n: int = 40, d: int = 6, seed: int = 5) -> BlockSystem:
     blk = s.values[off[diag_block]:off[diag_block + 1]].reshape(d, d)
     blk -= 50.0 * np.eye(d)
     return dataclasses.replace(s, name=f"indefinite_n{n}_d{d}")
+
+
+# ------------------------------------------------------------------------------------------------
+# edge sets: the per-edge inputs of Lambda assembly (Jacobians, Sigma^-1, errors, robust weights)
+# ------------------------------------------------------------------------------------------------
+
+@dataclasses.dataclass
+class EdgeSet:
+    """One homogeneous set of binary edges at a linearization point -- what the reference's
+    Calculate_Hessians_v2 works from (BaseTypes_Binary.h:759-777).  Every matrix is column-major:
+    J0[e] is (rd x d0) stored as J0[e, col, row]."""
+    n_verts: int
+    v0: np.ndarray          # int64 [n_edges]
+    v1: np.ndarray          # int64 [n_edges]
+    J0: np.ndarray          # float64 [n_edges, d0, rd]   (column-major rd x d0)
+    J1: np.ndarray          # float64 [n_edges, d1, rd]
+    sigma_inv: np.ndarray   # float64 [n_edges, rd, rd]
+    err: np.ndarray         # float64 [n_edges, rd]
+    weight: Optional[np.ndarray] = None   # float64 [n_edges] robust weights, None = 1
+    unary_vertex: int = 0
+    unary_factor: Optional[np.ndarray] = None   # [d, d] column-major (stored transposed, as the others)
+    unary_error: Optional[np.ndarray] = None    # [d]
+
+    @property
+    def n_edges(self) -> int:
+        return int(self.v0.shape[0])
+
+    @property
+    def rd(self) -> int:
+        return int(self.err.shape[1])
+
+    @staticmethod
+    def load(path: str) -> "EdgeSet":
+        """Reads an SPPASM01 edge-set file (the format tests/golden/make_golden.py converts into fixtures)."""
+        with open(path, "rb") as f:
+            if f.read(8) != b"SPPASM01":
+                raise ValueError("not an SPPASM01 file")
+            n_verts, n_edges, d, rd = (int(x) for x in np.fromfile(f, np.int64, 4))
+            v0 = np.fromfile(f, np.int64, n_edges)
+            v1 = np.fromfile(f, np.int64, n_edges)
+            J0 = np.fromfile(f, np.float64, n_edges * rd * d).reshape(n_edges, d, rd)
+            J1 = np.fromfile(f, np.float64, n_edges * rd * d).reshape(n_edges, d, rd)
+            si = np.fromfile(f, np.float64, n_edges * rd * rd).reshape(n_edges, rd, rd)
+            err = np.fromfile(f, np.float64, n_edges * rd).reshape(n_edges, rd)
+            w = np.fromfile(f, np.float64, n_edges)
+            uf = np.fromfile(f, np.float64, d * d).reshape(d, d)
+            ue = np.fromfile(f, np.float64, d)
+        return EdgeSet(n_verts, v0, v1, J0, J1, si, err, w, 0, uf, ue)
+
+
+def structure_from_edges(dims: np.ndarray, v0: np.ndarray, v1: np.ndarray) -> BlockSystem:
+    """The upper block structure of Lambda for a graph: a diagonal block per vertex and a block
+    (min, max) per distinct vertex pair (NonlinearSolver_Lambda_Base.h:1634-1660); values zero."""
+    dims = np.asarray(dims, dtype=np.int64)
+    n = int(dims.shape[0])
+    r = np.minimum(v0, v1).astype(np.int64)
+    c = np.maximum(v0, v1).astype(np.int64)
+    key = np.unique(np.concatenate([c * n + r, np.arange(n, dtype=np.int64) * (n + 1)]))
+    cols, rows = key // n, key % n
+    bcol_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(bcol_ptr, cols + 1, 1)
+    bcol_ptr = np.cumsum(bcol_ptr)
+    cumsum = np.concatenate([[0], np.cumsum(dims)]).astype(np.int64)
+    n_values = int(np.sum(dims[rows] * dims[cols]))
+    return BlockSystem(cumsum=cumsum, bcol_ptr=bcol_ptr, brow_idx=rows.astype(np.int32),
+                       values=np.zeros(n_values), rhs=np.zeros(int(cumsum[-1])), n_matrix_cut=0)
+
+
+def random_edge_set(dims: np.ndarray, v0: np.ndarray, v1: np.ndarray, rd: int, seed: int = 0,
+                    robust: bool = True, anchor: int = 0) -> EdgeSet:
+    """Seeded synthetic linearization: Jacobians near [-I, +I]-like full-rank blocks, SPD Sigma^-1,
+    small errors, robust weights in (0.5, 1] -- Lambda comes out positive definite thanks to the anchor."""
+    rng = np.random.default_rng(seed)
+    dims = np.asarray(dims, dtype=np.int64)
+    v0 = np.asarray(v0, dtype=np.int64)
+    v1 = np.asarray(v1, dtype=np.int64)
+    ne = int(v0.shape[0])
+    d0, d1 = int(dims[v0[0]]), int(dims[v1[0]])
+
+    def jac(d, sign):
+        J = 0.2 * rng.standard_normal((ne, d, rd))
+        k = min(d, rd)
+        J[:, np.arange(k), np.arange(k)] += sign
+        return J
+    A = 0.3 * rng.standard_normal((ne, rd, rd))
+    si = np.einsum("eij,ekj->eik", A, A) + np.eye(rd)[None] * (1.0 + rng.random((ne, 1, 1)) * 20)
+    d_a = int(dims[anchor])
+    return EdgeSet(int(dims.shape[0]), v0, v1, jac(d0, -1.0), jac(d1, 1.0), si,
+                   0.05 * rng.standard_normal((ne, rd)),
+                   (0.5 + 0.5 * rng.random(ne)) if robust else None,
+                   anchor, np.eye(d_a) * 100.0, np.zeros(d_a))

@@ -13,6 +13,11 @@ reference's own solver classes on those inputs:
     x_schur, S, rhs_reduced (BA)     : CLinearSolver_Schur<...>::Solve_PosDef and the intermediates of
                                        its steps replayed through public CUberBlockMatrix calls
     ok_* (negative case)             : the boolean each solver returned
+    assembly_*.npz                   : `ref_harness lambda_dump`: a pose graph built from the reference's own
+                                       vertex / edge types; per edge the Jacobians, Sigma^-1, error and robust
+                                       weight at the initial point (inputs), and the Lambda / eta that
+                                       CNonlinearSolver_Lambda handed to its linear solver (outputs), plus
+                                       the CHOLMOD solution of that system
 Fixtures are data only; no reference source text is stored.
 """
 import json
@@ -77,6 +82,22 @@ def main():
         np.savez_compressed(path, **rec)
         print(f"{name}: n={lam.n_scalars} blocks={lam.n_blocks} -> {os.path.getsize(path) / 1024:.1f} KiB",
               {k: bool(v) for k, v in rec.items() if k.startswith("ok_")})
+    for name, kind, n_poses, seed in (("assembly_se2_n40", "se2", 40, 1), ("assembly_se3_n40", "se3", 40, 2)):
+        with tempfile.TemporaryDirectory() as td:
+            prefix = os.path.join(td, "ld")
+            run(["lambda_dump", kind, str(n_poses), str(seed), prefix])
+            lam = synth.BlockSystem.load(prefix + ".lambda.bin")
+            es = synth.EdgeSet.load(prefix + ".edges.bin")
+            xf = os.path.join(td, "x.bin")
+            assert run(["solve", prefix + ".lambda.bin", "cholmod_super", xf, "1"])["ok"]
+            rec = {"cumsum": lam.cumsum, "bcol_ptr": lam.bcol_ptr, "brow_idx": lam.brow_idx, "values": lam.values,
+                   "rhs": lam.rhs, "v0": es.v0, "v1": es.v1, "J0": es.J0, "J1": es.J1, "sigma_inv": es.sigma_inv,
+                   "err": es.err, "weight": es.weight, "unary_vertex": np.int64(es.unary_vertex),
+                   "unary_factor": es.unary_factor, "unary_error": es.unary_error, "x_cholmod_super": np.fromfile(xf)}
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **rec)
+        print(f"{name}: verts={lam.n_bcols} edges={es.n_edges} flipped={int((es.v0 > es.v1).sum())} "
+              f"-> {os.path.getsize(path) / 1024:.1f} KiB")
 
 
 if __name__ == "__main__":

@@ -8,8 +8,29 @@ from slam_plus_plus_amd.synth import BlockSystem
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def golden_names():
+def _names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def golden_names():
+    """Linear systems with the reference solvers' solutions."""
+    return [n for n in _names() if not n.startswith("assembly_")]
+
+
+def assembly_names():
+    """Edge sets with the Lambda / eta the reference's nonlinear solver assembled from them."""
+    return [n for n in _names() if n.startswith("assembly_")]
+
+
+def load_assembly(name):
+    """(BlockSystem holding the reference's Lambda and eta, EdgeSet, dx of the reference's CHOLMOD solve)."""
+    from slam_plus_plus_amd.synth import EdgeSet
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    lam = BlockSystem(z["cumsum"].astype(np.int64), z["bcol_ptr"].astype(np.int64), z["brow_idx"].astype(np.int32),
+                      z["values"], z["rhs"], 0, name)
+    es = EdgeSet(int(lam.n_bcols), z["v0"], z["v1"], z["J0"], z["J1"], z["sigma_inv"], z["err"], z["weight"],
+                 int(z["unary_vertex"]), z["unary_factor"], z["unary_error"])
+    return lam, es, z["x_cholmod_super"]
 
 
 def load_golden(name):

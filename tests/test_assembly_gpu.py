@@ -1,0 +1,155 @@
+"""GPU parity of the device-side Lambda / eta assembly through the C ABI: against the
+Lambda the reference's CNonlinearSolver_Lambda assembled (golden fixtures), and against the CPU oracle on seeded
+synthetic edge sets.  fp64, tolerance 1e-12 relative to the largest entry (sums of a handful of products; the
+summation order differs from the reference's reduction plan, nothing else)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import assembly_names, load_assembly, rel_inf
+from oracle import oracle_lib as O
+from slam_plus_plus_amd import synth
+from slam_plus_plus_amd.hip_solver import CLambdaAssembly_HIP, CLinearSolver_HIP, CLinearSolver_Schur_HIP
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def assemble_on_gpu(solver, lam, es, accumulate_into=None):
+    asm = CLambdaAssembly_HIP(solver, lam, es.v0, es.v1, es.rd)
+    bufs = [dev(a) for a in (es.J0, es.J1, es.sigma_inv, es.err, es.weight)]
+    if accumulate_into is None:
+        values = torch.full((lam.values.shape[0],), float("nan"), dtype=torch.float64, device="cuda")
+        eta = torch.full((lam.n_scalars,), float("nan"), dtype=torch.float64, device="cuda")
+    else:
+        values, eta = accumulate_into
+    torch.cuda.synchronize()
+    asm.Refresh_Lambda_device(*[ptr(b) for b in bufs], values.data_ptr(), eta.data_ptr(), es.unary_vertex,
+                              es.unary_factor, es.unary_error, accumulate=accumulate_into is not None)
+    assert solver.sync()
+    return values, eta, asm
+
+
+@pytest.mark.parametrize("name", assembly_names())
+def test_matches_reference_lambda(name):
+    lam, es, x_ref = load_assembly(name)
+    solver = CLinearSolver_HIP()
+    values, eta, asm = assemble_on_gpu(solver, lam, es)
+    assert rel_inf(values.cpu().numpy(), lam.values) < TOL
+    assert rel_inf(eta.cpu().numpy(), lam.rhs) < TOL
+    # and straight into the solve, Lambda never leaving the device: dx of the reference's own linear solver
+    assert solver.factor_solve_device(values.data_ptr(), eta.data_ptr())
+    assert rel_inf(eta.cpu().numpy(), x_ref) < 1e-10
+
+
+def pose_graph_edges(n, seed, n_loops):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(30, n, n_loops)
+    b = a - rng.integers(2, 30, n_loops)
+    flip = rng.random(n_loops) < 0.5
+    v0 = np.concatenate([np.arange(n - 1), np.where(flip, a, b)])
+    v1 = np.concatenate([np.arange(1, n), np.where(flip, b, a)])
+    return v0.astype(np.int64), v1.astype(np.int64)
+
+
+@pytest.mark.parametrize("d,rd,n,robust", [(6, 6, 20000, True), (3, 3, 5000, False), (7, 7, 3000, True), (6, 4, 2000, True),
+                                          (3, 8, 500, True)])
+def test_pose_graph_matches_oracle(d, rd, n, robust):
+    v0, v1 = pose_graph_edges(n, seed=d * 100 + rd, n_loops=n // 4)
+    dims = np.full(n, d)
+    es = synth.random_edge_set(dims, v0, v1, rd=rd, seed=11, robust=robust, anchor=5)
+    lam = synth.structure_from_edges(dims, v0, v1)
+    ref_values, ref_eta = O.assemble_lambda(lam, es)
+    solver = CLinearSolver_HIP()
+    values, eta, asm = assemble_on_gpu(solver, lam, es)
+    assert rel_inf(values.cpu().numpy(), ref_values) < TOL
+    assert rel_inf(eta.cpu().numpy(), ref_eta) < TOL
+    # bit-reproducible: fixed summation order, no atomics
+    values2, eta2, _ = assemble_on_gpu(solver, lam, es)
+    assert torch.equal(values, values2) and torch.equal(eta, eta2)
+    if rd >= d:   # full-rank measurements: the assembled system is positive definite, solve it where it lies
+        lam.values, lam.rhs = ref_values, ref_eta
+        ok, x_ref, _ = O.solve_sparse(lam)
+        assert ok and solver.factor_solve_device(values.data_ptr(), eta.data_ptr())
+        assert rel_inf(eta.cpu().numpy(), x_ref) < 1e-10
+
+
+def test_ba_edges_cameras_and_points():
+    """Projection edges: vertex 0 a camera (6), vertex 1 a landmark (3), 2-D residual; cameras first in Lambda, so
+    every edge has id0 < id1 ... and the mirrored set (landmark first) exercises the flipped blocks."""
+    rng = np.random.default_rng(5)
+    n_cams, n_pts, k = 40, 3000, 4
+    cam = (np.arange(n_pts)[:, None] * n_cams // n_pts + rng.integers(0, 6, (n_pts, k))) % n_cams
+    cam = np.sort(cam, axis=1)
+    keep = np.concatenate([np.ones((n_pts, 1), bool), np.diff(cam, axis=1) > 0], axis=1)
+    pt = np.broadcast_to(np.arange(n_pts)[:, None] + n_cams, cam.shape)
+    v_cam, v_pt = cam[keep].astype(np.int64), pt[keep].astype(np.int64)
+    dims = np.concatenate([np.full(n_cams, 6), np.full(n_pts, 3)])
+    lam = synth.structure_from_edges(dims, v_cam, v_pt)
+    lam.n_matrix_cut = n_cams
+    for v0, v1 in ((v_cam, v_pt), (v_pt, v_cam)):
+        es = synth.random_edge_set(dims, v0, v1, rd=2, seed=9, robust=True, anchor=int(v0[0]))
+        ref_values, ref_eta = O.assemble_lambda(lam, es)
+        solver = CLinearSolver_Schur_HIP()
+        values, eta, asm = assemble_on_gpu(solver, lam, es)
+        assert rel_inf(values.cpu().numpy(), ref_values) < TOL
+        assert rel_inf(eta.cpu().numpy(), ref_eta) < TOL
+
+
+def test_two_edge_sets_accumulate():
+    """Pose-pose edges, then pose-landmark edges added onto the same Lambda (b_accumulate)."""
+    n_poses, n_lm = 400, 900
+    rng = np.random.default_rng(8)
+    dims = np.concatenate([np.full(n_poses, 6), np.full(n_lm, 3)])
+    a0, a1 = np.arange(n_poses - 1), np.arange(1, n_poses)
+    b0 = rng.integers(0, n_poses, 3 * n_lm)
+    b1 = np.repeat(np.arange(n_lm), 3) + n_poses
+    lam = synth.structure_from_edges(dims, np.concatenate([a0, b0]), np.concatenate([a1, b1]))
+    es_a = synth.random_edge_set(dims, a0, a1, rd=6, seed=1, anchor=0)
+    es_b = synth.random_edge_set(dims, b0, b1, rd=3, seed=2, anchor=0)
+    es_b.unary_factor = None
+    va, ea = O.assemble_lambda(lam, es_a)
+    vb, eb = O.assemble_lambda(lam, es_b)
+    solver = CLinearSolver_HIP()
+    values, eta, asm_a = assemble_on_gpu(solver, lam, es_a)
+    values, eta, asm_b = assemble_on_gpu(solver, lam, es_b, accumulate_into=(values, eta))
+    assert rel_inf(values.cpu().numpy(), va + vb) < TOL
+    assert rel_inf(eta.cpu().numpy(), ea + eb) < TOL
+    lam.values, lam.rhs = va + vb, ea + eb
+    ok, x_ref, _ = O.solve_sparse(lam)
+    assert ok and solver.factor_solve_device(values.data_ptr(), eta.data_ptr())
+    assert rel_inf(eta.cpu().numpy(), x_ref) < 1e-10
+
+
+def test_errors():
+    lam, es, _ = load_assembly("assembly_se2_n40")
+    solver = CLinearSolver_HIP()
+    v1 = es.v1.copy()
+    v1[0] = 39                                   # no block (0, 39) in Lambda
+    with pytest.raises(ValueError):
+        CLambdaAssembly_HIP(solver, lam, es.v0, v1, es.rd)
+    with pytest.raises(ValueError):
+        CLambdaAssembly_HIP(solver, lam, es.v0, es.v0, es.rd)     # an edge joining a vertex to itself
+    with pytest.raises(ValueError):
+        CLambdaAssembly_HIP(solver, lam, es.v0, es.v1, 9)         # residual dimension out of range
+    asm = CLambdaAssembly_HIP(solver, lam, es.v0, es.v1, es.rd)
+    with pytest.raises(ValueError):
+        asm.Refresh_Lambda_device(0, 0, 0, 0, 0, 0, 0)            # null device pointers
+    # a different structure makes the assembly stale
+    other = synth.pose_chain(n=50, d=3)
+    solver.SymbolicDecomposition_Blocky(other)
+    t = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError):
+        asm.Refresh_Lambda_device(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, t.data_ptr(), t.data_ptr())
+    # destroying the solver first is allowed
+    del solver
+    asm._solver = None
+    del asm
