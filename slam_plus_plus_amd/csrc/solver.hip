@@ -169,11 +169,16 @@ void slampp_hip_solver::Analyze_Sparse()
 		b.np_di = uint32_t(np) | (uint32_t(P.dim[P.lrow[k]]) << 24);
 		b.xcs = int32_t(P.cs_new[P.lrow[k]]);
 	}
+	if(P.loff[n_lblocks] >= (int64_t(1) << 48))
+		throw std::domain_error("the factor has 2^48 or more values");
 	std::vector<longlong2> pairs(P.pa.size());
-	for(size_t e = 0; e < P.pa.size(); ++ e) {
-		const int64_t dc = P.dim[P.blk_col[P.pa[e]]];
-		pairs[e].x = P.loff[P.pa[e]] | (dc << 56);
-		pairs[e].y = P.loff[P.pb[e]];
+	for(int64_t k = 0; k < n_lblocks; ++ k) { // pairs are stored block by block
+		const int64_t n_pos = std::min<int64_t>(k - P.lptr[P.blk_col[k]], 255); // position of the target block in its column
+		for(int64_t e = P.pptr[k]; e < P.pptr[k + 1]; ++ e) {
+			const int64_t dc = P.dim[P.blk_col[P.pa[e]]];
+			pairs[e].x = P.loff[P.pa[e]] | (n_pos << 48) | (dc << 56);
+			pairs[e].y = P.loff[P.pb[e]];
+		}
 	}
 	std::vector<TRowEnt> rents(P.rblk.size());
 	for(size_t e = 0; e < P.rblk.size(); ++ e) {
@@ -244,6 +249,12 @@ void slampp_hip_solver::Analyze_Sparse()
 	dplan.cols = d_cols.p(); dplan.blks = d_blks.p(); dplan.pairs = d_pairs.p(); dplan.rents = d_rents.p();
 	dplan.task_ptr = d_task_ptr.p();
 	dplan.uniform_dim = P.uniform_dim? P.max_dim : 0;
+	dplan.p_timing = 0;
+	if(getenv("SLAMPP_HIP_STAGE_TIMING")) { // development aid: clock samples of the upper-stage kernel, printed at sync
+		d_timing.Alloc(1 + 32 * 4096);
+		SLAMPP_HIP_CHECK(hipMemsetAsync(d_timing.p(), 0, (1 + 32 * 4096) * sizeof(long long), stream));
+		dplan.p_timing = d_timing.p();
+	}
 }
 
 void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs_dev, bool b_factor)
@@ -520,6 +531,18 @@ int slampp_hip_sync(slampp_hip_solver *p_solver)
 			SLAMPP_HIP_CHECK(hipMemcpyAsync(s.p_host_flag, s.d_flag.p(), sizeof(int), hipMemcpyDeviceToHost, s.stream));
 		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
 		s.Phase_Collect();
+		if(s.dplan.p_timing && s.d_timing.p()) { // development aid: the last launches' clock samples (100 MHz ticks)
+			std::vector<long long> tm(1 + 32 * 4096);
+			SLAMPP_HIP_CHECK(hipMemcpy(tm.data(), s.d_timing.p(), tm.size() * sizeof(long long), hipMemcpyDeviceToHost));
+			const long long n_launches = std::min<long long>(tm[0], 4096);
+			for(long long i = std::max<long long>(0, n_launches - 24); i < n_launches; ++ i) {
+				fprintf(stderr, "stage_timing launch %lld:", i);
+				for(int k = 1; k < 32 && tm[1 + 32 * i + k]; ++ k)
+					fprintf(stderr, " %.2f", double(tm[1 + 32 * i + k] - tm[1 + 32 * i + k - 1]) * 0.01);
+				fprintf(stderr, " us\n");
+			}
+			SLAMPP_HIP_CHECK(hipMemset(s.d_timing.p(), 0, tm.size() * sizeof(long long)));
+		}
 		if(*s.p_host_flag & 2)
 			return fail(p_solver, SLAMPP_HIP_ERR_DEVICE, "all-reduce callback failed");
 		if(*s.p_host_flag) {

@@ -55,10 +55,12 @@ struct TDenseCol { // 24 B
 struct TDevPlan {
 	const TColDesc *cols;      // [n] in *schedule* order: the columns of task t are cols[task_ptr[t] .. task_ptr[t+1])
 	const TBlkDesc *blks;      // [l_blocks]
-	const longlong2 *pairs;    // [n_pairs] x = offset of L(i,c) | dim(c) << 56, y = offset of L(j,c)
+	const longlong2 *pairs;    // [n_pairs] x = offset of L(i,c) | position of the target block in its column << 48 | dim(c) << 56, y = offset of L(j,c)
 	const TRowEnt *rents;      // [n_row_entries]
 	const int64_t *task_ptr;   // [n_tasks+1]
 	int uniform_dim;           // > 0: every block column has this dimension (3, 6, 7 get unrolled kernels)
+	long long *p_timing;       // development aid (SLAMPP_HIP_STAGE_TIMING): [0] = launches so far, then 32 clock
+	                           // samples per launch of workgroup 0 of the multi-wave factor kernel; normally null
 };
 
 // numeric factorization of one stage, with the forward substitution y = L^-1 b fused in

@@ -28,6 +28,7 @@
 
 namespace slampp {
 
+static const int64_t PAIR_OFF_MASK = (int64_t(1) << 48) - 1; // pair.x = offset | position of the target block in its column << 48 | dim << 56
 enum { Y_LANE0 = 56 }; // lanes 56.. carry the right-hand side of the column when its dimension is <= 7
 enum { CHUNK = 16 };   // blocks of a column whose partial sums live in LDS at a time (multi-wave kernel)
 
@@ -48,7 +49,7 @@ __device__ __forceinline__ double accumulate_pairs(const longlong2 *__restrict__
 	double acc = 0;
 	for(int e = first; e < np; e += step) {
 		const longlong2 pr = pairs[p0 + e];
-		const double *a = L + (pr.x & ((int64_t(1) << 56) - 1)) + r;
+		const double *a = L + (pr.x & PAIR_OFF_MASK) + r;
 		const double *b = L + pr.y + q;
 		if(D) {
 			double av[D? D : 1], bv[D? D : 1];
@@ -328,7 +329,7 @@ __device__ __forceinline__ int pair_block(const TBlkDesc *s_blk, int nb, int64_t
 template <int D>
 __device__ __forceinline__ double pair_product(const longlong2 pr, const double *L, int r, int q, int di, int dj)
 {
-	const double *a = L + (pr.x & ((int64_t(1) << 56) - 1)) + r;
+	const double *a = L + (pr.x & PAIR_OFF_MASK) + r;
 	const double *b = L + pr.y + q;
 	double sum = 0;
 	if(D) {
@@ -443,24 +444,90 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 	__shared__ TRowEnt s_rent[UP_NR];
 	__shared__ longlong2 s_prec[UP_NP];
 	__shared__ unsigned char s_ptag[UP_NP];
+	__shared__ longlong2 s_ent[D? UP_NR + UP_NP : 1]; // fixed block size: row entries, then pairs, as (a, b) offsets
+	__shared__ int s_ycs[D? UP_NR + UP_NP : 1];
+	__shared__ unsigned char s_tag[D? UP_NR + UP_NP : 1];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
 	const int task = task_begin + blockIdx.x;
+	long long *p_tm = 0;
+	int n_tm = 0;
+	if(p.p_timing && blockIdx.x == 0 && tid == 0) {
+		p_tm = p.p_timing + 1 + 32 * atomicAdd((unsigned long long*)p.p_timing, 1ull);
+		p_tm[n_tm ++] = wall_clock64();
+	}
+#define STAGE_TICK() do { if(p_tm && n_tm < 32) p_tm[n_tm ++] = wall_clock64(); } while(0)
 	const int64_t c_begin = p.task_ptr[task], c_end = p.task_ptr[task + 1];
 	for(int64_t c = c_begin; c < c_end; ++ c) {
 		const TColDesc cd = p.cols[c];
 		const int dj = D? D : cd.dj;
+		STAGE_TICK(); // column descriptor here
 		const bool b_y_inline = dj <= 7;
 		const bool b_y = b_y_inline && lane >= Y_LANE0 && lane < Y_LANE0 + dj;
 		const TLaneMap md = lane_map(lane, dj, dj);
 		const int yq = b_y? lane - Y_LANE0 : md.q;
+		const bool b_staged = D != 0;
 		if(cd.nb <= CHUNK && cd.nr <= UP_NR && cd.np <= UP_NP) {
 			for(int e = tid; e < cd.nb; e += 64 * W)
 				s_blk[e] = p.blks[cd.k0 + e];
-			for(int e = tid; e < cd.nr; e += 64 * W)
-				s_rent[e] = p.rents[cd.r0 + e];
-			for(int e = tid; e < cd.np; e += 64 * W)
-				s_prec[e] = p.pairs[cd.p0 + e];
+			if(b_staged) { // rows and pairs as one list of (a, b) operand offsets for the unified loop below
+				for(int e = tid; e < cd.nr; e += 64 * W) {
+					const TRowEnt en = p.rents[cd.r0 + e];
+					s_ent[e] = longlong2{en.off, en.off};
+					s_ycs[e] = en.ycs;
+					s_tag[e] = 0;
+				}
+				for(int e = tid; e < cd.np; e += 64 * W) {
+					const longlong2 pr = p.pairs[cd.p0 + e];
+					s_ent[cd.nr + e] = longlong2{pr.x & PAIR_OFF_MASK, pr.y};
+					s_tag[cd.nr + e] = (unsigned char)((pr.x >> 48) & 0xff);
+				}
+			} else {
+				for(int e = tid; e < cd.nr; e += 64 * W)
+					s_rent[e] = p.rents[cd.r0 + e];
+				for(int e = tid; e < cd.np; e += 64 * W)
+					s_prec[e] = p.pairs[cd.p0 + e];
+			}
 			__syncthreads();
+			STAGE_TICK(); // records staged
+			if(b_staged) {
+				// phase A: the Lambda elements are requested first and join the wave's partial sums last, so that
+				// their latency hides behind the products
+				double init0 = 0, init1 = 0;
+				if(wave == 0)
+					init0 = b_y? -b[cd.cs_src + yq] : (md.b_act? -lambda_element(A, s_blk[0].asrc, md.r, md.q, D, D, true) : 0);
+				else if(wave < cd.nb)
+					init0 = md.b_act? -lambda_element(A, s_blk[wave].asrc, md.r, md.q, D, D, false) : 0;
+				if(wave + W < cd.nb)
+					init1 = md.b_act? -lambda_element(A, s_blk[wave + W].asrc, md.r, md.q, D, D, false) : 0;
+				const int ne = cd.nr + cd.np;
+				for(int kb = 0; kb < cd.nb; ++ kb)
+					s_part[wave][kb][lane] = 0;
+				// every update (row entries of the diagonal block and pairs of the others alike) goes through one loop
+				#pragma unroll 4
+				for(int e = wave; e < ne; e += W) {
+					const longlong2 en = s_ent[e];
+					const int tag = s_tag[e];
+					const bool b_vec = tag == 0 && b_y; // the right-hand side rides along the diagonal block
+					const double *pa = b_vec? w + s_ycs[e] : L + en.x + md.r;
+					const double *pb = L + en.y + ((tag == 0)? yq : md.q);
+					const int as = b_vec? 1 : D;
+					double av[D? D : 1], bv[D? D : 1];
+					#pragma unroll
+					for(int t = 0; t < D; ++ t) {
+						av[t] = pa[t * as];
+						bv[t] = pb[t * D];
+					}
+					double sum = 0;
+					#pragma unroll
+					for(int t = 0; t < D; ++ t)
+						sum += av[t] * bv[t];
+					s_part[wave][tag][lane] += sum;
+				}
+				if(wave < cd.nb)
+					s_part[wave][wave][lane] += init0;
+				if(wave + W < cd.nb)
+					s_part[wave][wave + W][lane] += init1;
+			} else {
 			for(int e = tid; e < cd.np; e += 64 * W)
 				s_ptag[e] = (unsigned char)pair_block(s_blk, cd.nb, cd.p0 + e);
 			// phase A: partial sums start from minus the Lambda element in the wave that owns the block
@@ -478,18 +545,20 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 				s_part[wave][kb][lane] = init;
 			}
 			__syncthreads(); // tags visible
-			#pragma unroll 2
+			#pragma unroll 4
 			for(int e = wave; e < cd.nr; e += W)
 				acc0 += row_product<D>(s_rent[e], L, w, md.r, yq, dj, b_y);
 			s_part[wave][0][lane] = acc0;
-			#pragma unroll 2
+			#pragma unroll 4
 			for(int e = wave; e < cd.np; e += W) {
 				const int kb = s_ptag[e];
 				const int di = D? D : int(s_blk[kb].np_di >> 24);
 				const TLaneMap m = lane_map(lane, di, dj);
 				s_part[wave][kb][lane] += pair_product<D>(s_prec[e], L, m.r, m.q, di, dj);
 			}
+			}
 			__syncthreads();
+			STAGE_TICK(); // products done
 			// phase B: the diagonal block first (wave 0), then the sub-diagonal blocks round-robin
 			if(wave == 0) {
 				double acc = 0;
@@ -506,6 +575,7 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 					finish_rhs_wide(cd, lane, p, L, b, w, s_linv);
 			}
 			__syncthreads();
+			STAGE_TICK(); // diagonal block done
 			for(int kb = 1 + wave; kb < cd.nb; kb += W) {
 				const TBlkDesc bd = s_blk[kb];
 				const int di = D? D : int(bd.np_di >> 24);
@@ -517,6 +587,7 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 				finish_offdiagonal<D>(acc, lane, m.r, m.q, m.b_act, dj, L, bd.loff, s_tile[wave], s_linv);
 			}
 			__syncthreads(); // LDS records and partial sums consumed; column complete
+			STAGE_TICK(); // column done
 			continue;
 		}
 		// general path: any number of blocks, CHUNK at a time, records read from global memory
