@@ -211,9 +211,44 @@ def run_c3(args, rank, world, local_rank, dist):
                      "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
         "kernels": kernels,
     }
+    out["assembly"] = assembly_leg(solver, lam, dev)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_c3(lam, counts)
     return out
+
+
+def assembly_leg(solver, lam, dev, reps=20):
+    """Outside the timed region: Lambda and eta of the same graph assembled on the device from synthetic per-edge
+    Jacobians, written where the solver reads them.  HBM-bound: bytes in (J0, J1, Sigma^-1,
+    error, weight per edge) + bytes out (Lambda values, eta) over the HIP-event time of the two kernels."""
+    import torch
+    from slam_plus_plus_amd import synth
+    from slam_plus_plus_amd.hip_solver import CLambdaAssembly_HIP
+    col = np.repeat(np.arange(lam.n_bcols), np.diff(lam.bcol_ptr))
+    off = lam.brow_idx != col
+    v0, v1 = lam.brow_idx[off].astype(np.int64), col[off].astype(np.int64)
+    dims = np.diff(lam.cumsum)
+    d = int(dims[0])
+    es = synth.random_edge_set(dims, v0, v1, rd=d, seed=3)
+    asm = CLambdaAssembly_HIP(solver, lam, v0, v1, d)
+    bufs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (es.J0, es.J1, es.sigma_inv, es.err, es.weight)]
+    values = torch.empty(lam.values.shape[0], dtype=torch.float64, device=dev)
+    eta = torch.empty(lam.n_scalars, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    args = [t.data_ptr() for t in bufs] + [values.data_ptr(), eta.data_ptr(), es.unary_vertex, es.unary_factor, es.unary_error]
+    asm.Refresh_Lambda_device(*args)
+    solver.sync()
+    solver.profile(reset=True)
+    for _ in range(reps):
+        asm.Refresh_Lambda_device(*args)
+    solver.sync()
+    cnt, ms = solver.profile().get("assemble", (0, 0.0))
+    ok = solver.factor_solve_device(values.data_ptr(), eta.data_ptr())     # the assembled system, solved where it lies
+    n_bytes = 8 * (sum(int(np.prod(t.shape)) for t in bufs) + values.numel() + eta.numel())
+    us = ms / max(cnt, 1) * 1e3
+    return {"n_edges": int(v0.shape[0]), "us_per_assembly": us, "algorithmic_bytes": n_bytes,
+            "achieved_GBs": n_bytes / (us * 1e-6) / 1e9 if us > 0 else None, "peak_GBs": HBM_PEAK_GBS,
+            "assembled_system_solved": bool(ok)}
 
 
 class _DevPtr:
