@@ -420,10 +420,15 @@ def main():
                        "config": {"workload": ba["workload"]}, "roofline": ba.get("roofline"),
                        "cpu_baseline": ba.get("cpu_baseline")}
             out["ba_schur"] = ba
-    if rank == 0 and out is not None:
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and out is not None:
+        try:    # RCCL prints its version banner through C stdio: get it out before the one JSON line, not after it
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

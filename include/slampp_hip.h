@@ -155,10 +155,14 @@ int slampp_hip_assemble_device_async(slampp_hip_assembly *p_assembly, const doub
 	const double *p_unary_factor, const double *p_unary_error, double *p_values_dev, double *p_eta_dev, int b_accumulate);
 
 /* Multi-GPU BA (new functionality, no reference counterpart -- SURVEY.md section 8e): every rank
- * holds a landmark shard (its own points + all cameras); the partial reduced camera system
- * [S | rhs] is summed over ranks by this callback (RCCL all-reduce over xGMI) between the Schur
+ * holds a landmark shard (its own points + all cameras); the partial reduced camera systems
+ * [S | rhs] are summed over ranks by this callback (RCCL all-reduce over xGMI) between the Schur
  * accumulation and the dense factorization.  p_dev: device pointer, n_count doubles, in place,
- * on stream p_hip_stream.  Return 0 on success.  NULL callback = single GPU. */
+ * on stream p_hip_stream.  Return 0 on success.  NULL callback = single GPU.
+ * What travels is not the dense n x n buffer but the 6x6 (7x7, 3x3) blocks of S that are nonzero on at
+ * least one rank, plus the right-hand side: on the first step with a new callback the ranks agree on that
+ * set by summing an indicator over the lower triangle of the camera-block grid through the same
+ * callback (one extra, synchronous call), so every rank must register its callback before the same step. */
 typedef int (*slampp_hip_allreduce_fn)(void *p_context, double *p_dev, size_t n_count, void *p_hip_stream);
 int slampp_hip_set_allreduce(slampp_hip_solver *p_solver, slampp_hip_allreduce_fn p_fn, void *p_context);
 

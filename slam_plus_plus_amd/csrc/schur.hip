@@ -40,6 +40,15 @@ struct CSchurState {
 	CDevArray<int64_t> d_cam_ptr;   // [nc+1]
 	CDevArray<int32_t> d_cam_obs;   // [n_obs] observations of every camera, ascending
 	CDevArray<double> d_S, d_W, d_Cinv, d_t, d_invdiag, d_z, d_x;
+	// multi-GPU: the all-reduce moves only the blocks of S that are nonzero on some rank
+	std::vector<int32_t> h_blk_row, h_blk_col; // this rank's nonzero blocks of S (lower triangle; camera indices)
+	slampp_hip_allreduce_fn p_union_fn;        // the callback the union below was agreed through
+	void *p_union_context;
+	bool b_union_dense;                        // too many cameras for the indicator exchange: reduce the whole buffer
+	int64_t n_union;
+	CDevArray<int32_t> d_un_row, d_un_col;
+	CDevArray<double> d_pack;                  // [n_union DC^2 + N]
+	CSchurState() :p_union_fn(0), p_union_context(0), b_union_dense(false), n_union(0) {}
 };
 
 void schur_destroy(CSchurState *p) { delete p; }
@@ -49,6 +58,7 @@ size_t schur_device_bytes(const CSchurState *p)
 	return p->d_ptr.n_Bytes() + p->d_brow.n_Bytes() + p->d_obs_pt.n_Bytes() + p->d_sb_ptr.n_Bytes() +
 		p->d_sb_row.n_Bytes() + p->d_sb_col.n_Bytes() + p->d_ent_a.n_Bytes() + p->d_ent_uoff.n_Bytes() +
 		p->d_cam_ptr.n_Bytes() + p->d_cam_obs.n_Bytes() + p->d_S.n_Bytes() + p->d_W.n_Bytes() +
+		p->d_un_row.n_Bytes() + p->d_un_col.n_Bytes() + p->d_pack.n_Bytes() +
 		p->d_Cinv.n_Bytes() + p->d_t.n_Bytes() + p->d_invdiag.n_Bytes() + p->d_z.n_Bytes() + p->d_x.n_Bytes();
 }
 
@@ -194,6 +204,14 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 			}
 		}
 		S.n_sblocks = int64_t(sb_row.size());
+		S.h_blk_row = sb_row;
+		S.h_blk_col = sb_col;
+		for(int64_t c = 0; c < nc; ++ c) { // the camera-camera blocks of Lambda land in S too (transposed: lower triangle)
+			for(int64_t k = ptr[c]; k < ptr[c + 1]; ++ k) {
+				S.h_blk_row.push_back(int32_t(c));
+				S.h_blk_col.push_back(brow[k]);
+			}
+		}
 
 		hipStream_t st = s.stream;
 		S.d_ptr.Upload(s.bcol_ptr, st);
@@ -516,6 +534,74 @@ __global__ void schur_point_backsubst_kernel(const int64_t *ptr, int64_t nc, int
 		out[gid] = dx[gid];
 }
 
+// multi-GPU exchange: copies the union blocks of S (and the right-hand side row) into / out of one contiguous buffer
+__global__ void __launch_bounds__(64)
+schur_pack_kernel(const int32_t *__restrict__ un_row, const int32_t *__restrict__ un_col, int64_t n_union, int dc,
+	double *S, int ld, int n, double *pack, int b_unpack)
+{
+	const int64_t b = blockIdx.x;
+	const int lane = threadIdx.x;
+	double *p_s, *p_p;
+	if(b < n_union) {
+		if(lane >= dc * dc)
+			return;
+		p_s = S + size_t(un_row[b] * dc + lane % dc) + size_t(un_col[b] * dc + lane / dc) * ld;
+		p_p = pack + b * dc * dc + lane;
+	} else {
+		const int64_t i = (b - n_union) * 64 + lane;
+		if(i >= n)
+			return;
+		p_s = S + size_t(ld - 1) + size_t(i) * ld;
+		p_p = pack + n_union * dc * dc + i;
+	}
+	if(b_unpack)
+		*p_s = *p_p;
+	else
+		*p_p = *p_s;
+}
+
+// Agrees with the other ranks on the set of blocks to exchange: every rank marks its own nonzero blocks in an
+// indicator over the lower triangle of the camera-block grid, the indicators are summed through the caller's
+// all-reduce, and every rank derives the same ordered list from the result.  One-time, synchronous.
+static void schur_agree_on_union(slampp_hip_solver &s, CSchurState &S)
+{
+	hipStream_t st = s.stream;
+	S.p_union_fn = s.p_allreduce;
+	S.p_union_context = s.p_allreduce_context;
+	S.n_union = 0;
+	S.b_union_dense = S.nc > 16384; // the indicator would exceed a gigabyte
+	if(S.b_union_dense)
+		return;
+	const int64_t nc = S.nc, n_tri = nc * (nc + 1) / 2;
+	std::vector<double> ind(size_t(n_tri), 0.0);
+	for(size_t i = 0; i < S.h_blk_row.size(); ++ i) {
+		const int64_t r = S.h_blk_row[i], c = S.h_blk_col[i];
+		ind[size_t(c * nc - c * (c - 1) / 2 + (r - c))] = 1.0;
+	}
+	CDevArray<double> d_ind;
+	d_ind.Alloc(size_t(n_tri));
+	SLAMPP_HIP_CHECK(hipMemcpyAsync(d_ind.p(), ind.data(), size_t(n_tri) * sizeof(double), hipMemcpyHostToDevice, st));
+	if(s.p_allreduce(s.p_allreduce_context, d_ind.p(), size_t(n_tri), (void*)st) != 0)
+		throw CDeviceError("all-reduce callback failed");
+	SLAMPP_HIP_CHECK(hipMemcpyAsync(ind.data(), d_ind.p(), size_t(n_tri) * sizeof(double), hipMemcpyDeviceToHost, st));
+	SLAMPP_HIP_CHECK(hipStreamSynchronize(st));
+	std::vector<int32_t> un_row, un_col;
+	size_t k = 0;
+	for(int64_t c = 0; c < nc; ++ c) {
+		for(int64_t r = c; r < nc; ++ r, ++ k) {
+			if(ind[k] > 0.5) {
+				un_row.push_back(int32_t(r));
+				un_col.push_back(int32_t(c));
+			}
+		}
+	}
+	S.n_union = int64_t(un_row.size());
+	S.d_un_row.Upload(un_row, st);
+	S.d_un_col.Upload(un_col, st);
+	S.d_pack.Alloc(size_t(S.n_union) * S.DC * S.DC + size_t(S.N));
+	SLAMPP_HIP_CHECK(hipStreamSynchronize(st)); // un_row / un_col live on this stack frame
+}
+
 template <int DC, int DP>
 static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *A, double *rhs)
 {
@@ -562,10 +648,23 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 	s.Phase_End();
 
 	if(s.p_allreduce) {
+		if(S.p_union_fn != s.p_allreduce || S.p_union_context != s.p_allreduce_context)
+			schur_agree_on_union(s, S); // first step with this callback
 		s.Phase_Begin("allreduce");
-		// only the lower triangle and the rhs row carry data; the callback sums the whole buffer
-		if(s.p_allreduce(s.p_allreduce_context, S.d_S.p(), size_t(ld) * ld, (void*)st) != 0)
-			throw CDeviceError("all-reduce callback failed");
+		if(S.b_union_dense) {
+			// only the lower triangle and the rhs row carry data; the callback sums the whole buffer
+			if(s.p_allreduce(s.p_allreduce_context, S.d_S.p(), size_t(ld) * ld, (void*)st) != 0)
+				throw CDeviceError("all-reduce callback failed");
+		} else {
+			const unsigned n_grid = unsigned(S.n_union + (n + 63) / 64);
+			const size_t n_count = size_t(S.n_union) * DC * DC + size_t(n);
+			hipLaunchKernelGGL(schur_pack_kernel, dim3(n_grid), dim3(64), 0, st, S.d_un_row.p(), S.d_un_col.p(), S.n_union, DC,
+				S.d_S.p(), ld, n, S.d_pack.p(), 0);
+			if(s.p_allreduce(s.p_allreduce_context, S.d_pack.p(), n_count, (void*)st) != 0)
+				throw CDeviceError("all-reduce callback failed");
+			hipLaunchKernelGGL(schur_pack_kernel, dim3(n_grid), dim3(64), 0, st, S.d_un_row.p(), S.d_un_col.p(), S.n_union, DC,
+				S.d_S.p(), ld, n, S.d_pack.p(), 1);
+		}
 		s.Phase_End();
 	}
 

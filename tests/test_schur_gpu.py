@@ -99,3 +99,78 @@ def test_full_size_c4_residual_and_linearity():
     eta2 = 4.0 * lam.rhs
     assert solver.Solve_PosDef_Blocky(lam, eta2)
     assert rel_inf(eta2, 4.0 * eta) < TOL
+
+
+def test_two_landmark_shards_with_summing_callback():
+    """Two ranks of the landmark-sharded path in one process (two solver handles on the same GPU, one thread each):
+    the all-reduce callback is a barrier + sum, so the whole multi-GPU code path runs -- the agreement on the union
+    of nonzero S blocks, the packed exchange, redundant dense solves -- and must reproduce the unsharded solution."""
+    import threading
+    import torch
+    from slam_plus_plus_amd import sharding
+
+    torch.zeros(1, device="cuda")                         # torch's lazy CUDA init belongs on the main thread
+    lam = synth.ba(40, 4000, mode="venice", seed=21)
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok
+    world = 2
+    barrier = threading.Barrier(world)
+    slots, total, counts, errors = [None] * world, [None], [], []
+
+    class DevPtr:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+    def make_fn(rank):
+        def fn(ptr, count, stream):
+            try:
+                torch.cuda.synchronize()                  # the solver's stream has produced the partial sums
+                slots[rank] = torch.as_tensor(DevPtr(ptr, count), device="cuda")
+                barrier.wait()
+                if rank == 0:
+                    assert all(t.numel() == count for t in slots)
+                    total[0] = torch.stack(slots).sum(dim=0)
+                    counts.append(count)
+                barrier.wait()
+                slots[rank].copy_(total[0])
+                torch.cuda.synchronize()
+                barrier.wait()
+                return 0
+            except Exception as e:                        # pragma: no cover
+                import traceback
+                errors.append(traceback.format_exc())
+                raise
+        return fn
+
+    results = [None] * world
+
+    def run(rank):
+        try:
+            shard, sl = sharding.landmark_shard(lam, rank, world)
+            solver = CLinearSolver_Schur_HIP()
+            solver.set_allreduce(make_fn(rank))
+            eta = shard.rhs.copy()
+            assert solver.Solve_PosDef(shard, eta)
+            eta2 = shard.rhs.copy()                       # second step: the agreed block list is reused
+            assert solver.Solve_PosDef_Blocky(shard, eta2)
+            assert np.array_equal(eta, eta2)
+            results[rank] = (eta, sl)
+        except Exception as e:                            # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(timeout=120) for t in threads]
+    assert not errors, errors
+    n_x = int(lam.cumsum[lam.n_matrix_cut])
+    x = np.zeros_like(x_ref)
+    for eta, sl in results:
+        x[sl] = eta[n_x:]
+    x[:n_x] = results[0][0][:n_x]
+    assert rel_inf(results[1][0][:n_x], results[0][0][:n_x]) < 1e-13      # dx is computed redundantly
+    assert rel_inf(x, x_ref) < TOL
+    # what travelled: first the indicator over the camera-block triangle, then packed blocks -- never the dense square
+    nc, N = lam.n_matrix_cut, n_x
+    assert counts[0] == nc * (nc + 1) // 2
+    assert all(c < (N + 64) ** 2 // 2 for c in counts[1:]) and (counts[1] - N) % 36 == 0
