@@ -391,6 +391,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # development aid: SLAMPP_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 with the gloo backend, so that the
+    # multi-rank control flow (rendezvous, block-list agreement, max-over-ranks timing) can be run on a 1-GPU box
+    one_device = os.environ.get("SLAMPP_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     dist = None
@@ -402,7 +407,10 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     else:
         torch.cuda.set_device(local_rank)
     if not torch.cuda.is_available():

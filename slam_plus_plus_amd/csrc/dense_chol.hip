@@ -302,8 +302,11 @@ potrf_diag_variant(double *M, int ld, int kb, int n, double *invL, int *p_flag)
 #endif
 
 // ---- panel solve: L21 = A21 inv(L11)^T ----
+// With b_update_next the workgroup of the first row tile also applies this step's update to the next diagonal
+// tile, A(kb+1,kb+1) -= L(kb+1,kb) L(kb+1,kb)^T, so that the next potrf can follow this launch directly (the rest of
+// the 64-wide update rides in that potrf's launch).
 __global__ void __launch_bounds__(256)
-trsm_kernel(double *M, int ld, int kb, const double *invL)
+trsm_kernel(double *M, int ld, int kb, const double *invL, int b_update_next)
 {
 	__shared__ double Ps[NB * NB];
 	__shared__ double Qs[NB * NB];
@@ -311,16 +314,41 @@ trsm_kernel(double *M, int ld, int kb, const double *invL)
 	const int row0 = (kb + 1 + blockIdx.x) * NB, col0 = kb * NB;
 	load_tile(Ps, M, ld, row0, col0);
 	load_tile(Qs, invL, NB, 0, 0);
+	const int lo = lane & 15, hi = lane >> 4;
+	const bool b_diag = b_update_next && blockIdx.x == 0; // workgroup-uniform
+	double cv[4][4];
+	if(b_diag) { // the next diagonal tile is requested now, its latency hides behind the two products
+		#pragma unroll
+		for(int c = 0; c < 4; ++ c)
+			#pragma unroll
+			for(int reg = 0; reg < 4; ++ reg)
+				cv[c][reg] = M[size_t(row0 + 16 * c + lo) + size_t(row0 + 16 * wave + hi + 4 * reg) * ld];
+	}
 	__syncthreads();
 	v4f64 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 	tile_product(Ps, Qs, wave, lane, acc);
 	// every thread has read its operands out of LDS; the tile in global memory can be overwritten
-	const int lo = lane & 15, hi = lane >> 4;
 	#pragma unroll
 	for(int c = 0; c < 4; ++ c)
 		#pragma unroll
 		for(int reg = 0; reg < 4; ++ reg)
 			M[size_t(row0 + 16 * c + lo) + size_t(col0 + 16 * wave + hi + 4 * reg) * ld] = acc[c][reg];
+	if(!b_diag)
+		return;
+	__syncthreads(); // every wave is done with Ps
+	#pragma unroll
+	for(int c = 0; c < 4; ++ c)
+		#pragma unroll
+		for(int reg = 0; reg < 4; ++ reg)
+			Ps[lds_at(16 * wave + hi + 4 * reg, 16 * c + lo)] = acc[c][reg]; // L(kb+1,kb) as an operand: [k = column][row]
+	__syncthreads();
+	v4f64 upd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+	tile_product(Ps, Ps, wave, lane, upd);
+	#pragma unroll
+	for(int c = 0; c < 4; ++ c)
+		#pragma unroll
+		for(int reg = 0; reg < 4; ++ reg)
+			M[size_t(row0 + 16 * c + lo) + size_t(row0 + 16 * wave + hi + 4 * reg) * ld] = cv[c][reg] - upd[c][reg];
 }
 
 // ---- symmetric update: A(ti,tj) -= sum over K tiles kt in [k0, k1) of L(ti,kt) L(tj,kt)^T ----
@@ -394,11 +422,12 @@ syrk_kernel(double *M, int ld, int n_blocks, int k0, int k1, int c0, int c1)
 	syrk_tile(M, ld, n_blocks, k0, k1, c0, c1, int(blockIdx.x), s_buf, s_buf + NB * NB);
 }
 
-// workgroup 0 factors and inverts the diagonal tile kb; the others run tiles of up to two symmetric updates
+// workgroup 0 factors and inverts the diagonal tile kb; the others run tiles of up to three symmetric updates
 // that do not depend on it (see the schedule in dense_cholesky): the single-workgroup step that every panel
 // has to wait for gives the rest of the chip something to do
 __global__ void __launch_bounds__(256)
-potrf_diag_kernel(double *M, int ld, int kb, int n, double *invL, int *p_flag, int n_blocks, TSyrkJob t_job_a, TSyrkJob t_job_b)
+potrf_diag_kernel(double *M, int ld, int kb, int n, double *invL, int *p_flag, int n_blocks, TSyrkJob t_job_a, TSyrkJob t_job_b,
+	TSyrkJob t_job_c)
 {
 	__shared__ double s_buf[(int(POTRF_LDS_DOUBLES) > 2 * NB * NB)? int(POTRF_LDS_DOUBLES) : 2 * NB * NB];
 	if(blockIdx.x == 0) {
@@ -406,10 +435,15 @@ potrf_diag_kernel(double *M, int ld, int kb, int n, double *invL, int *p_flag, i
 		return;
 	}
 	int idx = int(blockIdx.x) - 1;
-	const bool b_first = idx < t_job_a.n_tiles;
-	const TSyrkJob t_job = b_first? t_job_a : t_job_b;
-	if(!b_first)
+	TSyrkJob t_job = t_job_a;
+	if(idx >= t_job_a.n_tiles) {
 		idx -= t_job_a.n_tiles;
+		t_job = t_job_b;
+		if(idx >= t_job_b.n_tiles) {
+			idx -= t_job_b.n_tiles;
+			t_job = t_job_c;
+		}
+	}
 	syrk_tile(M, ld, n_blocks, t_job.k0, t_job.k1, t_job.c0, t_job.c1, t_job.tile0 + idx, s_buf, s_buf + NB * NB);
 }
 
@@ -431,10 +465,12 @@ static inline void launch_syrk(double *M, int n_pad, int n_blocks, int k0, int k
 }
 
 // Schedule, on one stream.  The matrix is cut into outer panels of OUTER_TILES 64-wide tiles; panel b is
-// factored by the chain potrf -> trsm -> syrk(rest of panel b) per tile.  The updates panel b owes to everything
-// right of it are not run after that chain but inside it, as extra workgroups of the potrf launches (which would
+// factored by the chain potrf -> trsm per tile, the trsm also updating the next diagonal tile.  Every other
+// update does not run after that chain but inside it, as extra workgroups of the potrf launches (which would
 // otherwise keep one CU busy and 255 idle):
-//   potrf of tile k >= 1 of panel b  carries  the 64-wide update of panel b + 1 by tile k - 1 of panel b,
+//   potrf of tile k >= 1 of panel b  carries  the rest of tile k - 1's 64-wide update of panel b (all but the
+//                                             diagonal tile the trsm has done), and
+//                                             the 64-wide update of panel b + 1 by tile k - 1,
 //   potrf of tile 0 of panel b       carries  the K = 256 update of panel b + 1 by panel b - 1,
 //   every potrf of panel b           carries  a slice of the K = 256 update of panels >= b + 2 by panel b - 1.
 // Only the 64-wide update of panel b + 1 by the last tile of panel b separates two chains.  Launches on one
@@ -452,23 +488,22 @@ void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag,
 		const int n_far_tiles = (b > 0)? n_syrk_tiles(n_blocks, v0, n_blocks) : 0;
 		for(int kb = t0; kb < t1; ++ kb) {
 			const int k = kb - t0, m = t1 - t0;
-			TSyrkJob t_near = {0, 0, 0, 0, 0, 0}, t_far = {0, 0, 0, 0, 0, 0};
-			if(k > 0)
+			TSyrkJob t_inner = {0, 0, 0, 0, 0, 0}, t_near = {0, 0, 0, 0, 0, 0}, t_far = {0, 0, 0, 0, 0, 0};
+			if(k > 0) {
+				t_inner = TSyrkJob{kb - 1, kb, kb, t1, 1, n_syrk_tiles(n_blocks, kb, t1) - 1}; // tile 0 = (kb, kb): done by the trsm
 				t_near = TSyrkJob{kb - 1, kb, u0, u1, 0, n_next_tiles};
-			else if(b > 0)
+			} else if(b > 0)
 				t_near = TSyrkJob{p0, p1, u0, u1, 0, n_next_tiles};
 			if(n_far_tiles > 0) {
 				const int n_begin = int(int64_t(n_far_tiles) * k / m), n_end = int(int64_t(n_far_tiles) * (k + 1) / m);
 				t_far = TSyrkJob{p0, p1, v0, n_blocks, n_begin, n_end - n_begin};
 			}
 			double *invL = p_invdiag + size_t(kb) * NB * NB;
-			hipLaunchKernelGGL(potrf_diag_kernel, dim3(1 + t_near.n_tiles + t_far.n_tiles), dim3(256), 0, stream, M, n_pad, kb, n,
-				invL, p_flag, n_blocks, t_near, t_far);
+			hipLaunchKernelGGL(potrf_diag_kernel, dim3(1 + t_inner.n_tiles + t_near.n_tiles + t_far.n_tiles), dim3(256), 0, stream,
+				M, n_pad, kb, n, invL, p_flag, n_blocks, t_inner, t_near, t_far);
 			const int n_below = n_blocks - kb - 1;
 			if(n_below > 0)
-				hipLaunchKernelGGL(trsm_kernel, dim3(n_below), dim3(256), 0, stream, M, n_pad, kb, invL);
-			if(kb + 1 < t1) // update the rest of the outer panel with this 64-wide step
-				launch_syrk(M, n_pad, n_blocks, kb, kb + 1, kb + 1, t1, stream);
+				hipLaunchKernelGGL(trsm_kernel, dim3(n_below), dim3(256), 0, stream, M, n_pad, kb, invL, int(kb + 1 < t1));
 		}
 		launch_syrk(M, n_pad, n_blocks, t1 - 1, t1, u0, u1, stream); // the last tile's update of the next panel
 	}

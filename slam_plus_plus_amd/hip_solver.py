@@ -107,6 +107,13 @@ def load_library() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)")
+        try:
+            # Python callers get their device memory from torch, which bundles its own HIP runtime: load that one
+            # first, so that this library binds to it too -- two HIP runtimes in one process do not share the GPU
+            # (whichever initialises second reports "no HIP GPUs")
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in ABI.items():
             fn = getattr(lib, name)   # AttributeError if the library does not export the symbol
