@@ -290,8 +290,10 @@ def cpu_baseline_ba(lam, flops):
                       f"{wall:.1f} s of CPU incl. load); OpenMP only in the block-diagonal inverse and one SpMV, dense LLT serial"}
 
 
-def run_ba(args, rank, world, local_rank, dist):
-    """C4 (N=1) / landmark-sharded weak scaling (N>1): `--ba-cams` cameras, `--ba-points` points per GPU."""
+def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1):
+    """C4 (N=1) / landmark-sharded weak scaling (N>1): `--ba-cams` cameras, `--ba-points` points per GPU.
+    schur_sparse: -1 = the library decides how to factor the reduced camera system (sparse block path when under 3 %
+    of its blocks are nonzero, as with this workload's band visibility), 0 = force the dense MFMA factorization."""
     import torch
     from slam_plus_plus_amd import synth
     from slam_plus_plus_amd.hip_solver import CLinearSolver_Schur_HIP
@@ -299,7 +301,7 @@ def run_ba(args, rank, world, local_rank, dist):
     dev = torch.device(f"cuda:{local_rank}")
     k = 4
     lam = synth.ba(args.ba_cams, args.ba_points, k=k, mode="band", seed=777 + rank, cam_damping=0.1 / world)
-    solver = CLinearSolver_Schur_HIP(device=local_rank)
+    solver = CLinearSolver_Schur_HIP(device=local_rank, schur_sparse=schur_sparse)
     t0 = time.perf_counter()
     solver.SymbolicDecomposition_Blocky(lam)
     analyze_ms = (time.perf_counter() - t0) * 1e3
@@ -341,11 +343,16 @@ def run_ba(args, rank, world, local_rank, dist):
     # products, 2 flops per stored scalar of U for each of the 3 SpMV passes, n^3/3 + ... for the dense factor
     schur_flops = n_pts * 58.0 + 108.0 * n_obs + 216.0 * st["n_update_pairs"] + 3 * 2.0 * 18 * n_obs
     dense_flops = st["factor_flops"] + st["solve_flops"]
-    flops = schur_flops * world + dense_flops          # the dense factor is redundant on every rank: counted once
     prof = {k_: v[1] / max(v[0], 1) for k_, v in solver.profile().items()}
+    b_dense = "dense_chol" in prof
+    # the dense factor is redundant on every rank: counted once; with the sparse reduced solve its (much smaller) flop
+    # count is not known here and is left out
+    flops = schur_flops * world + (dense_flops if b_dense else 0.0)
     out = {
         "workload": f"{'C4' if world == 1 else 'landmark-sharded'}: BA {args.ba_cams} cams x {args.ba_points * world} points "
-                    f"({args.ba_points}/GPU), {k} obs/point, band visibility; Schur complement + dense reduced system, per step",
+                    f"({args.ba_points}/GPU), {k} obs/point, band visibility; Schur complement + "
+                    f"{'dense (MFMA)' if b_dense else 'sparse block'} factorization of the reduced system, per step",
+        "reduced_system": "dense" if b_dense else "sparse",
         "ms_per_step": ms, "points_per_s": n_pts * world / (dt / steps), "GFLOP/s": flops / (dt / steps) / 1e9,
         "n_gpus": world, "steps": steps, "schur_dim": N, "n_observations_per_gpu": n_obs, "analyze_ms_cold": analyze_ms,
         "phases_ms": prof,
@@ -366,12 +373,16 @@ def run_ba(args, rank, world, local_rank, dist):
     if "schur_gather" in prof:
         gb = (288.0 * st["n_update_pairs"] + 2 * 8.0 * 36 * st["l_blocks"]) / (prof["schur_gather"] * 1e-3) / 1e9
         out["roofline_schur_gather"] = {"bound": "hbm", "kernel": "schur_gather_S_kernel", "achieved": gb, "peak": HBM_PEAK_GBS,
-                                        "unit": "GB/s", "frac": gb / HBM_PEAK_GBS}
+                                        "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
+                                        "traffic": kernel_traffic(traffic, "schur_gather_S_kernel"), "traffic_source": traffic_file,
+                                        "ms_per_launch": prof["schur_gather"]}
+        if not b_dense:   # then the gather is the dominant kernel of the step
+            out["roofline"] = out["roofline_schur_gather"]
     if world == 1:
         x = bufs[-1].cpu().numpy()
         out["solve_residual_rel_inf"] = float(np.abs(lam.to_scipy() @ x - lam.rhs).max() / np.abs(lam.rhs).max())
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_ba(lam, flops)
+        if not args.no_cpu_baseline and schur_sparse != 0:
+            out["cpu_baseline"] = cpu_baseline_ba(lam, schur_flops + dense_flops)   # the reference factors S densely
     return out
 
 
@@ -428,6 +439,10 @@ def main():
                        "config": {"workload": ba["workload"]}, "roofline": ba.get("roofline"),
                        "cpu_baseline": ba.get("cpu_baseline")}
             out["ba_schur"] = ba
+        if world == 1:   # the same system with the reduced camera system forced through the dense MFMA factorization
+            ba_dense = run_ba(args, rank, world, local_rank, dist, schur_sparse=0)
+            if rank == 0:
+                out["ba_schur_dense_S"] = ba_dense
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0 and out is not None:

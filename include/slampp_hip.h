@@ -72,7 +72,10 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
  * wave eliminates sequentially, default 16), "dense_nb" (dense panel width, default 64),
  * "dense_top_nb" (sparse path: block columns with at least this many blocks, and their ancestors, are factored as
  * one dense matrix on the matrix cores; default 24, 0 = off), "dense_top_max_dim" (cap on its dimension, default 12288),
- * "profile" (0/1, see slampp_hip_get_profile), "shard_primary" (multi-GPU BA: this rank adds A and eta_x) */
+ * "profile" (0/1, see slampp_hip_get_profile), "shard_primary" (multi-GPU BA: this rank adds A and eta_x),
+ * "schur_sparse" (Schur mode: the reduced camera system S is factored by the sparse block path instead of the dense
+ * one; -1 = when fewer than 3 % of its camera-camera blocks are nonzero (default), 0 = never, 1 = always; the
+ * reference makes this choice at compile time: __SCHUR_USE_DENSE_SOLVER, include/slam/LinearSolver_Schur.h:48-55, "faster if ... dense enough") */
 int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int64_t n_value);
 
 /* structure of Lambda -- stands in for what the reference's wrappers read through

@@ -48,8 +48,26 @@ struct CSchurState {
 	int64_t n_union;
 	CDevArray<int32_t> d_un_row, d_un_col;
 	CDevArray<double> d_pack;                  // [n_union DC^2 + N]
-	CSchurState() :p_union_fn(0), p_union_context(0), b_union_dense(false), n_union(0) {}
+	std::vector<int32_t> h_un_row, h_un_col;   // the agreed list, sorted by (column, row)
+	// sparse reduced system: S handed to the sparse block path as its own little Lambda
+	bool b_reduced_decided, b_reduced_sparse;
+	slampp_hip_solver *p_inner;
+	int64_t n_in_blocks;
+	CDevArray<int32_t> d_in_row, d_in_col;     // lower blocks of S (row >= col) ...
+	CDevArray<int64_t> d_in_off;               // ... and where their transposes sit in the packed upper block-CSC values
+	CDevArray<double> d_in_values, d_in_rhs;
+	CSchurState() :p_union_fn(0), p_union_context(0), b_union_dense(false), n_union(0), b_reduced_decided(false),
+		b_reduced_sparse(false), p_inner(0), n_in_blocks(0) {}
+	~CSchurState();
 };
+
+CSchurState::~CSchurState()
+{
+	if(p_inner) {
+		p_inner->stream = 0; // borrowed from the owning solver
+		delete p_inner;
+	}
+}
 
 void schur_destroy(CSchurState *p) { delete p; }
 
@@ -58,7 +76,8 @@ size_t schur_device_bytes(const CSchurState *p)
 	return p->d_ptr.n_Bytes() + p->d_brow.n_Bytes() + p->d_obs_pt.n_Bytes() + p->d_sb_ptr.n_Bytes() +
 		p->d_sb_row.n_Bytes() + p->d_sb_col.n_Bytes() + p->d_ent_a.n_Bytes() + p->d_ent_uoff.n_Bytes() +
 		p->d_cam_ptr.n_Bytes() + p->d_cam_obs.n_Bytes() + p->d_S.n_Bytes() + p->d_W.n_Bytes() +
-		p->d_un_row.n_Bytes() + p->d_un_col.n_Bytes() + p->d_pack.n_Bytes() +
+		p->d_un_row.n_Bytes() + p->d_un_col.n_Bytes() + p->d_pack.n_Bytes() + p->d_in_row.n_Bytes() + p->d_in_col.n_Bytes() +
+		p->d_in_off.n_Bytes() + p->d_in_values.n_Bytes() + p->d_in_rhs.n_Bytes() + (p->p_inner? p->p_inner->n_Device_Bytes() : 0) +
 		p->d_Cinv.n_Bytes() + p->d_t.n_Bytes() + p->d_invdiag.n_Bytes() + p->d_z.n_Bytes() + p->d_x.n_Bytes();
 }
 
@@ -569,6 +588,9 @@ static void schur_agree_on_union(slampp_hip_solver &s, CSchurState &S)
 	S.p_union_fn = s.p_allreduce;
 	S.p_union_context = s.p_allreduce_context;
 	S.n_union = 0;
+	S.h_un_row.clear();
+	S.h_un_col.clear();
+	S.b_reduced_decided = false; // the block list the sparse reduced system is built from may change
 	S.b_union_dense = S.nc > 16384; // the indicator would exceed a gigabyte
 	if(S.b_union_dense)
 		return;
@@ -596,10 +618,124 @@ static void schur_agree_on_union(slampp_hip_solver &s, CSchurState &S)
 		}
 	}
 	S.n_union = int64_t(un_row.size());
+	S.h_un_row = un_row;
+	S.h_un_col = un_col;
 	S.d_un_row.Upload(un_row, st);
 	S.d_un_col.Upload(un_col, st);
 	S.d_pack.Alloc(size_t(S.n_union) * S.DC * S.DC + size_t(S.N));
 	SLAMPP_HIP_CHECK(hipStreamSynchronize(st)); // un_row / un_col live on this stack frame
+}
+
+// sparse reduced system: the nonzero blocks of S (lower triangle of the dense buffer) go, transposed, into the
+// packed upper block-CSC values of a block matrix the sparse path can factor; the right-hand side row into a vector
+__global__ void __launch_bounds__(64)
+schur_reduced_pack_kernel(const int32_t *__restrict__ in_row, const int32_t *__restrict__ in_col,
+	const int64_t *__restrict__ in_off, int64_t n_in_blocks, int dc, const double *__restrict__ S, int ld, int n,
+	double *values, double *r)
+{
+	const int64_t b = blockIdx.x;
+	const int lane = threadIdx.x;
+	if(b < n_in_blocks) {
+		if(lane >= dc * dc)
+			return;
+		const int i = lane % dc, j = lane / dc; // element (i, j) of the upper block (in_col[b], in_row[b])
+		const int64_t br = in_row[b], bc = in_col[b];
+		// = element (j, i) of the lower block (in_row[b], in_col[b]); diagonal blocks are mirrored from their lower triangle
+		const bool b_mirror = br == bc && i > j;
+		const size_t src = b_mirror? size_t(br * dc + i) + size_t(bc * dc + j) * ld : size_t(br * dc + j) + size_t(bc * dc + i) * ld;
+		values[in_off[b] + lane] = S[src];
+	} else {
+		const int64_t k = (b - n_in_blocks) * 64 + lane;
+		if(k < n)
+			r[k] = S[size_t(ld - 1) + size_t(k) * ld];
+	}
+}
+
+__global__ void schur_merge_flag_kernel(const int *p_from, int *p_to)
+{
+	if(*p_from)
+		atomicOr(p_to, *p_from);
+}
+
+// Decides how the reduced camera system is factored and, for the sparse choice, builds the inner solver: S becomes
+// a block matrix with one block column per camera whose structure is the block list every rank agreed on (or this
+// rank's own list on a single GPU), analyzed once by the same ordering / symbolic / scheduling code as a pose graph.
+static void schur_setup_reduced(slampp_hip_solver &s, CSchurState &S)
+{
+	S.b_reduced_decided = true;
+	S.b_reduced_sparse = false;
+	if(S.p_inner) {
+		S.p_inner->stream = 0;
+		delete S.p_inner;
+		S.p_inner = 0;
+	}
+	if(s.n_schur_sparse == 0 || (s.p_allreduce && S.b_union_dense))
+		return;
+	std::vector<int32_t> rows, cols;
+	if(s.p_allreduce) {
+		rows = S.h_un_row;
+		cols = S.h_un_col;
+	} else {
+		std::vector<int64_t> keys(S.h_blk_row.size());
+		for(size_t i = 0; i < keys.size(); ++ i)
+			keys[i] = int64_t(S.h_blk_col[i]) * S.nc + S.h_blk_row[i];
+		std::sort(keys.begin(), keys.end());
+		keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+		rows.resize(keys.size());
+		cols.resize(keys.size());
+		for(size_t i = 0; i < keys.size(); ++ i) {
+			cols[i] = int32_t(keys[i] / S.nc);
+			rows[i] = int32_t(keys[i] % S.nc);
+		}
+	}
+	const int64_t nc = S.nc, n_list = int64_t(rows.size());
+	const double f_fill = double(n_list) / (0.5 * double(nc) * double(nc + 1));
+	if(s.n_schur_sparse < 0 && !(nc >= 128 && f_fill < 0.03))
+		return; // dense: the MFMA factorization wins once fill-in makes S effectively dense
+	// upper block-CSC: the lower block (r, c) is the transpose of the upper block (c, r) in block column r
+	std::vector<int64_t> cumsum(nc + 1), bcol_ptr(nc + 1, 0);
+	for(int64_t c = 0; c <= nc; ++ c)
+		cumsum[c] = c * S.DC;
+	for(int64_t i = 0; i < n_list; ++ i)
+		++ bcol_ptr[rows[i] + 1];
+	for(int64_t c = 0; c < nc; ++ c)
+		bcol_ptr[c + 1] += bcol_ptr[c];
+	std::vector<int32_t> brow(n_list);
+	std::vector<int64_t> in_off(n_list);
+	{
+		std::vector<int64_t> fill(bcol_ptr.begin(), bcol_ptr.end() - 1);
+		for(int64_t i = 0; i < n_list; ++ i) { // the list is sorted by (col, row): within a block column the rows come out ascending
+			const int64_t k = fill[rows[i]] ++;
+			brow[k] = cols[i];
+			in_off[i] = k * S.DC * S.DC;
+		}
+	}
+	for(int64_t c = 0; c < nc; ++ c) {
+		if(bcol_ptr[c + 1] == bcol_ptr[c] || brow[bcol_ptr[c + 1] - 1] != c)
+			throw std::logic_error("reduced camera system: a camera has no diagonal block");
+	}
+	slampp_hip_solver *p_inner = new slampp_hip_solver();
+	S.p_inner = p_inner;
+	p_inner->n_device = s.n_device;
+	p_inner->stream = s.stream; // borrowed
+	p_inner->opt = s.opt;
+	p_inner->cumsum = cumsum;
+	p_inner->bcol_ptr = bcol_ptr;
+	p_inner->brow = brow;
+	p_inner->n_values = n_list * S.DC * S.DC;
+	p_inner->n_scalars = nc * S.DC;
+	p_inner->b_has_structure = true;
+	p_inner->n_mode = SLAMPP_HIP_MODE_SPARSE;
+	p_inner->Analyze_Sparse();
+	p_inner->b_analyzed = true;
+	S.n_in_blocks = n_list;
+	S.d_in_row.Upload(rows, s.stream);
+	S.d_in_col.Upload(cols, s.stream);
+	S.d_in_off.Upload(in_off, s.stream);
+	S.d_in_values.Alloc(size_t(n_list) * S.DC * S.DC);
+	S.d_in_rhs.Alloc(size_t(S.N));
+	SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream)); // the host vectors live on this stack frame
+	S.b_reduced_sparse = true;
 }
 
 template <int DC, int DP>
@@ -668,19 +804,33 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 		s.Phase_End();
 	}
 
-	s.Phase_Begin("dense_chol");
-	dense_cholesky(S.d_S.p(), ld, n, S.d_invdiag.p(), s.d_flag.p(), st);
-	s.Phase_End();
-	s.Phase_Begin("dense_solve");
-	dense_backsolve(S.d_S.p(), ld, n, S.d_invdiag.p(), S.d_z.p(), S.d_x.p(), st);
-	s.Phase_End();
+	if(!S.b_reduced_decided)
+		schur_setup_reduced(s, S); // first step (after the ranks agreed on the block list, if there are ranks)
+	const double *p_dx = S.d_x.p();
+	if(S.b_reduced_sparse) {
+		s.Phase_Begin("reduced_sparse");
+		hipLaunchKernelGGL(schur_reduced_pack_kernel, dim3(unsigned(S.n_in_blocks + (n + 63) / 64)), dim3(64), 0, st,
+			S.d_in_row.p(), S.d_in_col.p(), S.d_in_off.p(), S.n_in_blocks, DC, S.d_S.p(), ld, n, S.d_in_values.p(),
+			S.d_in_rhs.p());
+		S.p_inner->Enqueue_Sparse(S.d_in_values.p(), S.d_in_rhs.p(), true);
+		hipLaunchKernelGGL(schur_merge_flag_kernel, dim3(1), dim3(1), 0, st, S.p_inner->d_flag.p(), s.d_flag.p());
+		s.Phase_End();
+		p_dx = S.d_in_rhs.p();
+	} else {
+		s.Phase_Begin("dense_chol");
+		dense_cholesky(S.d_S.p(), ld, n, S.d_invdiag.p(), s.d_flag.p(), st);
+		s.Phase_End();
+		s.Phase_Begin("dense_solve");
+		dense_backsolve(S.d_S.p(), ld, n, S.d_invdiag.p(), S.d_z.p(), S.d_x.p(), st);
+		s.Phase_End();
+	}
 
 	s.Phase_Begin("backsubst");
 	hipLaunchKernelGGL((schur_obs_t_kernel<DC, DP>), dim3(unsigned((S.n_obs + 255) / 256)), dim3(256), 0, st,
-		S.n_obs, ubase, S.nc, S.d_ptr.p(), S.d_brow.p(), S.d_obs_pt.p(), A, S.d_x.p(), S.d_t.p());
+		S.n_obs, ubase, S.nc, S.d_ptr.p(), S.d_brow.p(), S.d_obs_pt.p(), A, p_dx, S.d_t.p());
 	const int64_t n_work = std::max<int64_t>(S.np, n);
 	hipLaunchKernelGGL((schur_point_backsubst_kernel<DC, DP>), dim3(unsigned((n_work + 255) / 256)), dim3(256), 0, st,
-		S.d_ptr.p(), S.nc, S.np, n, S.d_Cinv.p(), S.d_t.p(), S.d_x.p(), rhs);
+		S.d_ptr.p(), S.nc, S.np, n, S.d_Cinv.p(), S.d_t.p(), p_dx, rhs);
 	s.Phase_End();
 	SLAMPP_HIP_CHECK(hipGetLastError());
 }

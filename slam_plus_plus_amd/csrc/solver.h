@@ -87,6 +87,7 @@ struct slampp_hip_solver {
 	slampp::PlanOptions opt;
 	int n_dense_nb;
 	int b_shard_primary;
+	int n_schur_sparse; // reduced camera system: -1 = sparse path when few of its blocks are nonzero, 0 = always dense, 1 = always sparse
 
 	// Lambda structure as given
 	bool b_has_structure, b_analyzed, b_factored;

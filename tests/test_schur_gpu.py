@@ -101,7 +101,8 @@ def test_full_size_c4_residual_and_linearity():
     assert rel_inf(eta2, 4.0 * eta) < TOL
 
 
-def test_two_landmark_shards_with_summing_callback():
+@pytest.mark.parametrize("sparse", [0, 1])
+def test_two_landmark_shards_with_summing_callback(sparse):
     """Two ranks of the landmark-sharded path in one process (two solver handles on the same GPU, one thread each):
     the all-reduce callback is a barrier + sum, so the whole multi-GPU code path runs -- the agreement on the union
     of nonzero S blocks, the packed exchange, redundant dense solves -- and must reproduce the unsharded solution."""
@@ -147,7 +148,7 @@ def test_two_landmark_shards_with_summing_callback():
     def run(rank):
         try:
             shard, sl = sharding.landmark_shard(lam, rank, world)
-            solver = CLinearSolver_Schur_HIP()
+            solver = CLinearSolver_Schur_HIP(schur_sparse=sparse)
             solver.set_allreduce(make_fn(rank))
             eta = shard.rhs.copy()
             assert solver.Solve_PosDef(shard, eta)
@@ -174,3 +175,38 @@ def test_two_landmark_shards_with_summing_callback():
     nc, N = lam.n_matrix_cut, n_x
     assert counts[0] == nc * (nc + 1) // 2
     assert all(c < (N + 64) ** 2 // 2 for c in counts[1:]) and (counts[1] - N) % 36 == 0
+
+
+@pytest.mark.parametrize("mode,k", [("band", 4), ("venice", 6)])
+@pytest.mark.parametrize("sparse", [0, 1])
+def test_reduced_system_sparse_or_dense_same_answer(mode, k, sparse):
+    """The reduced camera system through the dense MFMA factorization and through the sparse block path."""
+    lam = synth.ba(150, 6000, k=k, mode=mode, seed=31)
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok
+    solver = CLinearSolver_Schur_HIP(schur_sparse=sparse, profile=1)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta)
+    assert rel_inf(eta, x_ref) < TOL
+    eta2 = 3.0 * lam.rhs
+    assert solver.Solve_PosDef_Blocky(lam, eta2)
+    assert rel_inf(eta2, 3.0 * x_ref) < TOL
+    phases = solver.profile()
+    assert ("reduced_sparse" in phases) == bool(sparse) and ("dense_chol" in phases) != bool(sparse)
+
+
+def test_reduced_system_auto_picks_sparse_for_band_structure():
+    lam = synth.ba(500, 10000, k=4, mode="band", seed=32)      # under 3 % of the camera pairs share a point
+    solver = CLinearSolver_Schur_HIP(profile=1)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta)
+    assert "reduced_sparse" in solver.profile()
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok and rel_inf(eta, x_ref) < TOL
+    # and an indefinite reduced system is reported from inside the sparse factorization
+    bad = dataclasses.replace(lam, values=lam.values.copy())
+    off = bad.block_value_offsets()
+    k = int(bad.bcol_ptr[1] - 1)                                 # diagonal block of camera 0
+    bad.values[off[k]:off[k] + 36] *= -1.0
+    assert not solver.Solve_PosDef_Blocky(bad, bad.rhs.copy())
+    assert solver.Solve_PosDef_Blocky(lam, lam.rhs.copy())       # and the solver recovers
