@@ -48,6 +48,7 @@ class CLinearSolver_HIP_Base {
 protected:
 	slampp_hip_solver *m_p_solver; /**< @brief C ABI handle (owned; never copied) */
 	int m_n_device; /**< @brief HIP device ordinal (configuration, copied) */
+	std::vector<std::pair<std::string, int64_t> > m_options; /**< @brief tuning knobs of slampp_hip_set_option (configuration, copied) */
 	bool m_b_structure_valid; /**< @brief ordering / symbolic analysis matches the last structure */
 	std::vector<int64_t> m_cumsum, m_bcol_ptr; /**< @brief structure handed to the library */
 	std::vector<int32_t> m_brow;
@@ -69,8 +70,11 @@ protected:
 
 	void Require_Handle() // throw(std::bad_alloc, std::runtime_error)
 	{
-		if(!m_p_solver)
+		if(!m_p_solver) {
 			Throw_On_Error(slampp_hip_create(&m_p_solver, m_n_device));
+			for(size_t i = 0, n = m_options.size(); i < n; ++ i)
+				Throw_On_Error(slampp_hip_set_option(m_p_solver, m_options[i].first.c_str(), m_options[i].second));
+		}
 	}
 
 	/**
@@ -216,7 +220,7 @@ public:
 
 	/** @brief copy-constructor; copies the configuration, not the state */
 	inline CLinearSolver_HIP_Base(const CLinearSolver_HIP_Base &r_other)
-		:m_p_solver(0), m_n_device(r_other.m_n_device), m_b_structure_valid(false)
+		:m_p_solver(0), m_n_device(r_other.m_n_device), m_options(r_other.m_options), m_b_structure_valid(false)
 	{}
 
 	inline ~CLinearSolver_HIP_Base()
@@ -229,7 +233,27 @@ public:
 	inline CLinearSolver_HIP_Base &operator =(const CLinearSolver_HIP_Base &r_other)
 	{
 		m_n_device = r_other.m_n_device;
+		m_options = r_other.m_options;
 		return *this;
+	}
+
+	/**
+	 *	@brief sets a tuning knob of the library (see slampp_hip_set_option() in slampp_hip.h, e.g. "schur_sparse",
+	 *		"dense_top_nb"); part of the configuration: survives Free_Memory() and is copied with the solver
+	 *	@note This throws std::runtime_error on an unknown name or a value out of range.
+	 */
+	void Set_Option(const char *p_s_name, int64_t n_value) // throw(std::bad_alloc, std::runtime_error)
+	{
+		if(m_p_solver)
+			Throw_On_Error(slampp_hip_set_option(m_p_solver, p_s_name, n_value));
+		size_t i = 0;
+		while(i < m_options.size() && m_options[i].first != p_s_name)
+			++ i;
+		if(i == m_options.size())
+			m_options.push_back(std::make_pair(std::string(p_s_name), n_value));
+		else
+			m_options[i].second = n_value;
+		m_b_structure_valid = false; // options take effect at the next analysis
 	}
 
 	/** @brief deletes memory for all the auxiliary buffers and matrices, host and device */

@@ -261,6 +261,15 @@ int main(int n_arg_num, const char **p_arg_list)
 				printf("\"schur_%s\": {\"ok_ref\": %d, \"ok_hip\": %d, \"rel_inf\": %.3g, \"rel_inf_warm\": %.3g}, ",
 					b_interleave? "interleaved" : "cams_first", int(b_ref), int(b_hip && b_hip2), f_err, f_err2);
 				n_fail += !(b_ref && b_hip && b_hip2 && f_err < 1e-10 && f_err2 < 1e-10);
+				if(!b_interleave) { // a copy keeps the configuration: the reduced system through the sparse block path
+					hip_solver.Set_Option("schur_sparse", 1);
+					THipSchur hip_copy(hip_solver);
+					Eigen::VectorXd x_hip3 = rhs;
+					const bool b_hip3 = hip_copy.Solve_PosDef(lambda, x_hip3);
+					const double f_err3 = (x_hip3 - x_ref).lpNorm<Eigen::Infinity>() / x_ref.lpNorm<Eigen::Infinity>();
+					printf("\"schur_sparse_reduced\": {\"ok_hip\": %d, \"rel_inf\": %.3g}, ", int(b_hip3), f_err3);
+					n_fail += !(b_hip3 && f_err3 < 1e-10);
+				}
 			}
 		}
 	} catch(std::exception &r_exc) {

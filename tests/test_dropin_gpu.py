@@ -30,3 +30,4 @@ def test_reference_nonlinear_solver_with_hip_linear_solver(tmp_path):
     assert r["se3_lambda_solver"]["state_rel_inf"] < 1e-9
     assert r["schur_cams_first"]["rel_inf"] < 1e-10
     assert r["schur_interleaved"]["rel_inf"] < 1e-10
+    assert r["schur_sparse_reduced"]["ok_hip"] == 1 and r["schur_sparse_reduced"]["rel_inf"] < 1e-10
