@@ -396,14 +396,17 @@ __global__ void schur_obs_W_kernel(int64_t n_obs, int64_t ubase, const int32_t *
 // The kernel is bound by the address path, not by bytes, so it spends as few vector-memory
 // instructions as it can: the entry indices are fetched 64 at a time (one coalesced load, then
 // v_readlane), the two operand blocks of an entry with ONE load (lanes 0..17 U_b, lanes 18..35 W_a,
-// both contiguous) and handed to the 36 accumulating lanes through LDS, four entries per batch.
+// both contiguous) into LDS, eight entries per batch; a batch is then one small GEMM on the matrix cores
+// (v_mfma_f64_16x16x4: S block += [U_1 .. U_8] [W_1 .. W_8]^T, K = 24).  The kernel is bound by HBM fetch efficiency
+// (144-byte operand blocks straddle 64-byte sectors: about twice the algorithmic bytes are fetched), not by the
+// arithmetic: FMA and MFMA versions run equally fast, and giving each XCD a contiguous range of blocks did not help.
 template <int DC, int DP, int W>
 __global__ void __launch_bounds__(64 * W)
 schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *sb_row, const int32_t *sb_col,
 	const int32_t *ent_a, const int64_t *ent_uoff, const double *__restrict__ A, const double *__restrict__ W_,
 	double *S, int ld)
 {
-	enum { BLK = DC * DP, BATCH = 4 };
+	enum { BLK = DC * DP, BATCH = 8 };
 	__shared__ double s_ops[W][BATCH][2 * BLK];
 	__shared__ double s_part[W][64];
 	const int64_t sb = blockIdx.x;
@@ -411,7 +414,8 @@ schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *s
 	const bool b_act = lane < DC * DC;
 	const int r = b_act? lane % DC : 0, q = b_act? lane / DC : 0;
 	const bool b_loader = lane < 2 * BLK;
-	double acc = 0;
+	typedef double v4f64 __attribute__((ext_vector_type(4)));
+	v4f64 macc = {0, 0, 0, 0};
 	const int64_t e0 = sb_ptr[sb], e1 = sb_ptr[sb + 1];
 	// this wave's entries: e0 + wave, e0 + wave + W, ...; processed in chunks of 64
 	for(int64_t base = e0 + wave; base < e1; base += int64_t(64) * W) {
@@ -433,25 +437,33 @@ schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *s
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			// the batch is one small GEMM: S block (DC x DC) += [U_1 .. U_BATCH] [W_1 .. W_BATCH]^T with K = BATCH * DP,
+			// four k at a time on the matrix cores (rows / columns >= DC of the 16 x 16 tile are don't-cares)
 			#pragma unroll
-			for(int j = 0; j < BATCH; ++ j) {
-				if(i + j < n_chunk) {
-					#pragma unroll
-					for(int t = 0; t < DP; ++ t)
-						acc += s_ops[wave][j][r + t * DC] * s_ops[wave][j][BLK + q + t * DC];
-				}
+			for(int q4 = 0; q4 < BATCH * DP / 4; ++ q4) {
+				const int kg = 4 * q4 + (lane >> 4), ent = kg / DP, t = kg % DP;
+				const int m = lane & 15, mm = (m < DC)? m : 0;
+				const double a = (i + ent < n_chunk)? s_ops[wave][ent][mm + t * DC] : 0.0; // the tail repeats its last entry: not summed
+				const double b = s_ops[wave][ent][BLK + mm + t * DC];
+				macc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, macc, 0, 0, 0);
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		}
 	}
-	if(W > 1) {
-		s_part[wave][lane] = acc;
-		__syncthreads();
-		if(wave != 0)
-			return;
-		acc = 0;
+	// lane l holds the tile elements ((l >> 4) + 4 reg, l & 15): hand the DC x DC corner to the lanes that write it
+	#pragma unroll
+	for(int reg = 0; reg < 4; ++ reg) {
+		const int row = (lane >> 4) + 4 * reg, col = lane & 15;
+		if(row < DC && col < DC)
+			s_part[wave][row + col * DC] = macc[reg];
+	}
+	__syncthreads();
+	if(wave != 0)
+		return;
+	double acc = 0;
+	if(b_act) {
 		#pragma unroll
 		for(int ww = 0; ww < W; ++ ww)
 			acc += s_part[ww][lane];
