@@ -251,6 +251,47 @@ def assembly_leg(solver, lam, dev, reps=20):
             "assembled_system_solved": bool(ok)}
 
 
+def run_small_configs(args, local_rank):
+    """BASELINE.json configs[0] and configs[1] (parity-test cases, not the benchmark workload): the Manhattan3500 SE(2)
+    and Sphere2500 SE(3) look-alikes, warm numeric factor + solve on the GPU next to the reference's CHOLMOD on the
+    host.  Reported as extra objects of the JSON line; N = 1 only."""
+    import torch
+    from slam_plus_plus_amd import synth
+    from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP
+    from oracle import oracle_lib as O
+    dev = torch.device(f"cuda:{local_rank}")
+    out = {}
+    for key, name, lam in (("C1", "Manhattan3500 SE(2) look-alike, 3x3 blocks", synth.manhattan(3500)),
+                           ("C2", "Sphere2500 SE(3) look-alike, 6x6 blocks", synth.sphere(50, 50))):
+        solver = CLinearSolver_HIP(device=local_rank)
+        t0 = time.perf_counter()
+        solver.SymbolicDecomposition_Blocky(lam)
+        analyze_ms = (time.perf_counter() - t0) * 1e3
+        vals = torch.from_numpy(lam.values).to(dev)
+        reps = 20
+        bufs = [torch.from_numpy(lam.rhs).to(dev) for _ in range(reps + 1)]
+        torch.cuda.synchronize()
+        if not solver.factor_solve_device(vals.data_ptr(), bufs[0].data_ptr()):
+            raise SystemExit(f"{key}: not positive definite")
+        t0 = time.perf_counter()
+        for b in bufs[1:]:
+            solver.factor_solve_device_async(vals.data_ptr(), b.data_ptr())
+        solver.sync()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        x = bufs[-1].cpu().numpy()
+        rec = {"workload": f"{name}, n={lam.n_scalars}", "ms_per_solve": ms, "analyze_ms_cold": analyze_ms,
+               "dense_top_dim": solver.stats()["schur_dim"],
+               "solve_residual_rel_inf": float(np.abs(lam.to_scipy() @ x - lam.rhs).max() / np.abs(lam.rhs).max())}
+        if not args.no_cpu_baseline and O.have_reference():
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "p.bin")
+                lam.save(path)
+                r = O.reference_solve(path, "cholmod_auto", "-", reps=5)
+            rec["reference_cholmod_ms"] = float(np.median(r["times_ms"]))
+        out[key] = rec
+    return out
+
+
 class _DevPtr:
     """Lets torch wrap a raw device pointer (the solver's [S | r] buffer) without copying."""
 
@@ -439,6 +480,8 @@ def main():
                        "config": {"workload": ba["workload"]}, "roofline": ba.get("roofline"),
                        "cpu_baseline": ba.get("cpu_baseline")}
             out["ba_schur"] = ba
+        if world == 1 and args.workload == "all":
+            out["other_configs"] = run_small_configs(args, local_rank)
         if world == 1:   # the same system with the reduced camera system forced through the dense MFMA factorization
             ba_dense = run_ba(args, rank, world, local_rank, dist, schur_sparse=0)
             if rank == 0:

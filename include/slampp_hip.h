@@ -73,6 +73,9 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
  * "dense_top_nb" (sparse path: block columns with at least this many blocks, and their ancestors, are factored as
  * one dense matrix on the matrix cores; default 24, 0 = off), "dense_top_max_dim" (cap on its dimension, default 12288),
  * "profile" (0/1, see slampp_hip_get_profile), "shard_primary" (multi-GPU BA: this rank adds A and eta_x),
+ * "dense_top_tiles" (sparse path: the dense top is factored tile column by tile column (0), or by the levels of its
+ * tile elimination tree, touching only structurally nonzero 64x64 tiles (1); -1 = the latter when it shortens the
+ * chain of dependent launches, default),
  * "schur_sparse" (Schur mode: the reduced camera system S is factored by the sparse block path instead of the dense
  * one; -1 = when fewer than 3 % of its camera-camera blocks are nonzero (default), 0 = never, 1 = always; the
  * reference makes this choice at compile time: __SCHUR_USE_DENSE_SOLVER, include/slam/LinearSolver_Schur.h:48-55, "faster if ... dense enough") */

@@ -825,6 +825,19 @@ int oracle_exec_plan(int64_t n, const int32_t *perm, const int32_t *dim, const i
 						rd[dense_pos[j] + r] -= B[r + u * dj] * w[cs_new[cc] + u];
 			}
 		}
+		if(!result) { /* positions no column maps to (the plan aligns independent chains to tile boundaries): identity */
+			char *covered = (char*)calloc((size_t)N, 1);
+			int64_t q;
+			for(j = 0; j < n; ++ j) {
+				if(dense_pos[j] >= 0)
+					memset(covered + dense_pos[j], 1, (size_t)dim[j]);
+			}
+			for(q = 0; q < N; ++ q) {
+				if(!covered[q])
+					Dm[q + q * N] = 1.0;
+			}
+			free(covered);
+		}
 		if(!result) { /* dense lower Cholesky + two substitutions */
 			int64_t r, q, u;
 			for(q = 0; q < N && !result; ++ q) { /* right-looking, column-oriented: every inner loop is contiguous */

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace slampp {
 
@@ -13,6 +14,8 @@ inline int dense_padded_dim(int n) { return ((n + 1 + dense_NB - 1) / dense_NB) 
 // Writes identity on the padding diagonal (rows n .. n_pad-2), zeroes nothing else: the caller
 // fills the lower triangle of rows < n and the right-hand side into row n_pad-1, columns < n.
 void dense_prepare_padding(double *M, int n_pad, int n, hipStream_t stream);
+// the same for a list of positions inside the matrix (device array)
+void dense_prepare_gaps(double *M, int n_pad, const int32_t *p_positions_dev, int n_positions, hipStream_t stream);
 
 // In-place lower Cholesky M = L L^T of the n_pad x n_pad column-major matrix (ld = n_pad); only the
 // lower triangle is read or written.  Row n_pad-1 carries the right-hand side, so after the call
@@ -20,6 +23,38 @@ void dense_prepare_padding(double *M, int n_pad, int n, hipStream_t stream);
 // p_invdiag: workspace (n_pad / 64) * 64 * 64 doubles, receives inv(L_kk) of every diagonal tile.
 // Sets *p_flag |= 1 if a pivot of a row < n is not positive.
 void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag, hipStream_t stream);
+
+// Tile-sparse variant for the dense top of the sparse path: the separators assembled into one dense matrix still
+// form a tree, so many 64 x 64 tiles are structurally zero and tile columns in different subtrees are independent.
+// The schedule (built once per structure from the set of nonzero tiles) groups the tile columns by their height in
+// the tile elimination tree; a level is three launches (potrf of all its diagonal tiles, trsm of all their
+// sub-diagonal tiles, one gather-update per target tile that any of them touches), so the dependent chain is as
+// long as the tree is high, not as long as the matrix is wide.
+struct CTileSchedule {
+	int n_tiles;                       // tiles per dimension
+	int n_levels;
+	std::vector<int> level_potrf_ptr, level_trsm_ptr, level_tgt_ptr; // [n_levels + 1] each
+	int *d_potrf;                      // tile columns, level by level
+	int2 *d_trsm;                      // (row tile, column tile)
+	int4 *d_tgt;                       // (row tile, column tile, first source, one past the last source)
+	int *d_src;                        // source tile columns of the targets
+	CTileSchedule() :n_tiles(0), n_levels(0), d_potrf(0), d_trsm(0), d_tgt(0), d_src(0) {}
+	~CTileSchedule() { Free(); }
+	CTileSchedule(const CTileSchedule&) = delete;
+	CTileSchedule &operator =(const CTileSchedule&) = delete;
+	void Free();
+	size_t n_Bytes() const { return n_bytes; }
+	// p_nonzero: n_tiles x n_tiles flags, column-major, lower triangle (row >= col); the diagonal and the last
+	// tile row (it carries the right-hand side) are always taken as nonzero.  Returns false if the device arrays
+	// could not be set up (the caller then uses dense_cholesky)
+	bool Build(int n_tiles, const std::vector<char> &r_nonzero, hipStream_t stream);
+private:
+	size_t n_bytes = 0;
+};
+
+// same contract as dense_cholesky(), on the tiles of the schedule only
+void tile_cholesky(const CTileSchedule &r_schedule, double *M, int n_pad, int n, double *p_invdiag, int *p_flag,
+	hipStream_t stream);
 
 // x = L^-T y with y taken from row n_pad-1 of the factor; p_z: workspace n_pad doubles; p_x: n_pad doubles, x in [0, n)
 void dense_backsolve(const double *M, int n_pad, int n, const double *p_invdiag, double *p_z, double *p_x, hipStream_t stream);

@@ -479,12 +479,28 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 		if(n_dim < opt.dense_top_min_dim)
 			std::fill(in_dense.begin(), in_dense.end(), char(0));
 		else {
+			// the dense-top columns form a forest (restricted elimination tree); a chain that starts at one of its leaves
+			// is independent of every other such chain until the two meet in a common ancestor.  Chains of at least one
+			// tile start at a tile boundary (positions skipped that way get an identity diagonal), so that no 64 x 64
+			// tile couples two of them
+			std::vector<int32_t> n_dense_children(n, 0);
+			for(int32_t j = 0; j < n; ++ j) {
+				if(in_dense[j] && P.parent[j] >= 0)
+					++ n_dense_children[P.parent[j]];
+			}
 			int32_t n_pos = 0;
 			for(int32_t j = 0; j < n; ++ j) {
-				if(in_dense[j]) {
-					P.dense_pos[j] = n_pos;
-					n_pos += P.dim[j];
+				if(!in_dense[j])
+					continue;
+				if(opt.dense_top_align > 1 && !n_dense_children[j]) { // a leaf of the forest: how long is its chain?
+					int64_t n_chain = 0;
+					for(int32_t c = j; c >= 0 && n_dense_children[c] <= 1; c = P.parent[c])
+						n_chain += P.dim[c];
+					if(n_chain >= opt.dense_top_align)
+						n_pos = (n_pos + opt.dense_top_align - 1) / opt.dense_top_align * opt.dense_top_align;
 				}
+				P.dense_pos[j] = n_pos;
+				n_pos += P.dim[j];
 			}
 			P.dense_dim = n_pos;
 		}

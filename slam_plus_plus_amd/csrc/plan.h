@@ -57,6 +57,8 @@ struct PlanOptions {
 	int dense_top_nb = 24;    // columns with this many blocks or more (and their ancestors) form the dense top; 0 = off
 	int dense_top_max_dim = 12288; // cap on its scalar dimension (the threshold is raised until it fits)
 	int dense_top_min_dim = 192;   // below this the dense top is not worth its launches
+	int dense_top_align = 64;      // independent chains of dense-top columns start at multiples of this (tile) size, so that
+	                               // the tile schedule of the dense factorization can run them side by side; 0 = packed
 };
 
 // returns empty string on success, else an error message

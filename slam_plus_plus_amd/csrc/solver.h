@@ -111,6 +111,11 @@ struct slampp_hip_solver {
 	slampp::CDevArray<slampp::TDenseBlk> d_dense_blks;
 	slampp::CDevArray<slampp::TDenseCol> d_dense_cols;
 	slampp::CDevArray<double> d_dense, d_dense_invdiag, d_dense_z, d_dense_x;
+	slampp::CDevArray<int32_t> d_dense_gaps; // positions inside the dense top that no column maps to (alignment padding)
+	int n_dense_gaps;
+	slampp::CTileSchedule dense_tiles; // level schedule over the nonzero tiles of the dense top (dense_chol.h)
+	bool b_dense_tiles;                // use it (its dependent chain is clearly shorter than the tile count)
+	int n_dense_top_tiles;             // option: -1 = decide per structure, 0 = always the dense schedule, 1 = always the tile schedule
 	int n_dense_blks, n_dense_cols, n_dense_dim, n_dense_pad;
 	slampp::CDevArray<double> d_A, d_rhs, d_L, d_Linv, d_w;
 	slampp::CDevArray<int> d_flag;

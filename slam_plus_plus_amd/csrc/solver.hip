@@ -13,7 +13,8 @@ using namespace slampp;
 slampp_hip_solver::slampp_hip_solver()
 	:n_device(0), stream(0), n_dense_nb(64), b_shard_primary(1), n_schur_sparse(-1), b_has_structure(false),
 	b_analyzed(false), b_factored(false), n_mode(SLAMPP_HIP_MODE_SPARSE), n_matrix_cut(0),
-	n_values(0), n_scalars(0), n_bottom_stages(1), n_dense_blks(0), n_dense_cols(0), n_dense_dim(0), n_dense_pad(0),
+	n_values(0), n_scalars(0), n_bottom_stages(1), n_dense_gaps(0), b_dense_tiles(false), n_dense_top_tiles(-1), n_dense_blks(0), n_dense_cols(0),
+	n_dense_dim(0), n_dense_pad(0),
 	p_host_flag(0), p_schur(0), p_allreduce(0), p_allreduce_context(0),
 	b_profile(0), n_open_phase(-1)
 {
@@ -41,6 +42,10 @@ void slampp_hip_solver::Free_Device()
 	d_cols.Free(); d_blks.Free(); d_rents.Free(); d_pairs.Free(); d_task_ptr.Free();
 	d_dense_blks.Free(); d_dense_cols.Free(); d_dense.Free(); d_dense_invdiag.Free(); d_dense_z.Free(); d_dense_x.Free();
 	n_dense_blks = n_dense_cols = n_dense_dim = n_dense_pad = 0;
+	dense_tiles.Free();
+	b_dense_tiles = false;
+	d_dense_gaps.Free();
+	n_dense_gaps = 0;
 	d_A.Free(); d_rhs.Free(); d_L.Free(); d_Linv.Free(); d_w.Free(); d_flag.Free();
 	if(p_schur) {
 		schur_destroy(p_schur);
@@ -52,7 +57,7 @@ void slampp_hip_solver::Free_Device()
 
 size_t slampp_hip_solver::n_Device_Bytes() const
 {
-	return d_dense_blks.n_Bytes() + d_dense_cols.n_Bytes() + d_dense.n_Bytes() + d_dense_invdiag.n_Bytes() +
+	return d_dense_blks.n_Bytes() + d_dense_cols.n_Bytes() + d_dense.n_Bytes() + d_dense_invdiag.n_Bytes() + dense_tiles.n_Bytes() +
 		d_dense_z.n_Bytes() + d_dense_x.n_Bytes() + d_cols.n_Bytes() + d_blks.n_Bytes() + d_rents.n_Bytes() +
 		d_task_ptr.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
 		d_rhs.n_Bytes() + d_L.n_Bytes() + d_Linv.n_Bytes() + d_w.n_Bytes() + d_flag.n_Bytes() +
@@ -223,10 +228,48 @@ void slampp_hip_solver::Analyze_Sparse()
 		}
 		d_dense_blks.Upload(dense_blks, stream);
 		d_dense_cols.Upload(dense_cols, stream);
+		{
+			std::vector<char> covered(n_dense_dim, 0);
+			for(size_t k = 0; k < dense_cols.size(); ++ k)
+				std::fill(covered.begin() + dense_cols[k].pos, covered.begin() + dense_cols[k].pos + dense_cols[k].dj, char(1));
+			std::vector<int32_t> gaps;
+			for(int32_t q = 0; q < n_dense_dim; ++ q) {
+				if(!covered[q])
+					gaps.push_back(q);
+			}
+			n_dense_gaps = int(gaps.size());
+			d_dense_gaps.Upload(gaps, stream);
+			SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // gaps lives in this scope
+		}
 		d_dense.Alloc(size_t(n_dense_pad) * n_dense_pad);
 		d_dense_invdiag.Alloc(size_t(n_dense_pad / dense_NB) * dense_NB * dense_NB);
 		d_dense_z.Alloc(n_dense_pad);
 		d_dense_x.Alloc(n_dense_pad);
+		// which 64 x 64 tiles of the dense top are structurally nonzero, and how long the dependent chain is if only
+		// those are touched and independent tile columns are factored side by side
+		b_dense_tiles = false;
+		if(n_dense_top_tiles != 0) {
+			const int T = n_dense_pad / dense_NB;
+			std::vector<char> nonzero(size_t(T) * T, 0);
+			for(size_t k = 0; k < dense_blks.size(); ++ k) {
+				const int64_t r0 = dense_blks[k].dst % n_dense_pad, c0 = dense_blks[k].dst / n_dense_pad;
+				for(int64_t tr = r0 / dense_NB; tr <= (r0 + dense_blks[k].di - 1) / dense_NB; ++ tr) {
+					for(int64_t tc = c0 / dense_NB; tc <= (c0 + dense_blks[k].dj - 1) / dense_NB; ++ tc)
+						nonzero[size_t(std::max(tr, tc)) + size_t(std::min(tr, tc)) * T] = 1;
+				}
+			}
+			if(dense_tiles.Build(T, nonzero, stream)) // two launches (26 us) per tile against three (34 us) per level, and fewer tiles touched
+				b_dense_tiles = n_dense_top_tiles > 0 || 100 * dense_tiles.n_levels <= 85 * T;
+			if(b_timing) {
+				size_t n_nz = 0;
+				for(size_t k = 0; k < nonzero.size(); ++ k)
+					n_nz += nonzero[k];
+				fprintf(stderr, "[setup] dense top: %d tiles per side, %zu of %d lower tiles nonzero before fill, %d levels, "
+					"%d trsm tiles, %d update targets -> %s schedule\n", T, n_nz, T * (T + 1) / 2, dense_tiles.n_levels,
+					dense_tiles.level_trsm_ptr.empty()? 0 : dense_tiles.level_trsm_ptr.back(),
+					dense_tiles.level_tgt_ptr.empty()? 0 : dense_tiles.level_tgt_ptr.back(), b_dense_tiles? "tile" : "dense");
+			}
+		}
 	}
 	n_dense_blks = int(dense_blks.size());
 	n_dense_cols = int(dense_cols.size());
@@ -287,11 +330,15 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			Phase_Begin("dense_assemble");
 			SLAMPP_HIP_CHECK(hipMemsetAsync(d_dense.p(), 0, size_t(ld) * ld * sizeof(double), stream));
 			dense_prepare_padding(d_dense.p(), ld, n_dense_dim, stream);
+			dense_prepare_gaps(d_dense.p(), ld, d_dense_gaps.p(), n_dense_gaps, stream);
 			launch_dense_assemble(dplan, d_dense_blks.p(), n_dense_blks, p_values_dev, d_L.p(), p_rhs_dev, d_w.p(),
 				d_dense.p(), ld, false, stream);
 			Phase_End();
 			Phase_Begin("dense_chol");
-			dense_cholesky(d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), d_flag.p(), stream);
+			if(b_dense_tiles)
+				tile_cholesky(dense_tiles, d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), d_flag.p(), stream);
+			else
+				dense_cholesky(d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), d_flag.p(), stream);
 			Phase_End();
 		} else {
 			Phase_Begin("dense_forward");
@@ -425,6 +472,10 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 		p_solver->b_shard_primary = (n_value != 0);
 	else if(s == "schur_sparse" && n_value >= -1 && n_value <= 1)
 		p_solver->n_schur_sparse = int(n_value);
+	else if(s == "dense_top_tiles" && n_value >= -1 && n_value <= 1) {
+		p_solver->n_dense_top_tiles = int(n_value);
+		p_solver->opt.dense_top_align = n_value? 64 : 0; // the alignment padding only serves the tile schedule
+	}
 	else if(s == "profile") {
 		p_solver->b_profile = (n_value != 0);
 		return SLAMPP_HIP_OK; // does not invalidate the analysis

@@ -26,7 +26,12 @@ def check_plan_invariants(lam, plan):
     if plan["dense_dim"]:
         parent = np.array([lrow[lptr[j] + 1] if lptr[j + 1] - lptr[j] > 1 else -1 for j in range(n)])
         assert all(parent[j] < 0 or dense[parent[j]] for j in np.nonzero(dense)[0])   # closed upwards in the etree
-        assert plan["dense_dim"] == int(plan["dim"][dense].sum())
+        # positions ascend with the elimination order and do not overlap; independent chains may start at a tile
+        # boundary (the gaps get an identity diagonal), so the dimension is at least the sum of the column dimensions
+        pos, dim = plan["dense_pos"][dense], plan["dim"][dense]
+        assert pos[0] >= 0 and np.all(pos[1:] >= pos[:-1] + dim[:-1])
+        assert plan["dense_dim"] == int(pos[-1] + dim[-1]) >= int(dim.sum())
+        assert np.all(pos[1:][pos[1:] > pos[:-1] + dim[:-1]] % 64 == 0)
     assert np.all(np.diff(plan["stage_ptr"]) > 0)
     dims = np.diff(lam.cumsum)[perm]
     assert np.array_equal(plan["dim"], dims)
