@@ -71,7 +71,8 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
 /* tuning knobs: "leaf_size" (nested-dissection leaf, default 4), "subtree_size" (max columns one
  * wave eliminates sequentially, default 16), "dense_nb" (dense panel width, default 64),
  * "dense_top_nb" (sparse path: block columns with at least this many blocks, and their ancestors, are factored as
- * one dense matrix on the matrix cores; default 24, 0 = off), "dense_top_max_dim" (cap on its dimension, default 12288),
+ * one dense matrix on the matrix cores; default: 24, or 16 / 36 where a model of the dependent launch chain clearly
+ * prefers that; setting the option fixes the threshold; 0 = off), "dense_top_max_dim" (cap on its dimension, default 12288),
  * "profile" (0/1, see slampp_hip_get_profile), "shard_primary" (multi-GPU BA: this rank adds A and eta_x),
  * "dense_top_tiles" (sparse path: the dense top is factored tile column by tile column (0), or by the levels of its
  * tile elimination tree, touching only structurally nonzero 64x64 tiles (1); -1 = the latter when it shortens the

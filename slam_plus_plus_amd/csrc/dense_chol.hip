@@ -15,6 +15,8 @@
 // This is the MFMA-bound kernel of the path: n^3/3 flops (72 GFLOP at 1k cameras).
 #include <hip/hip_runtime.h>
 #include "dense_chol.h"
+#include "plan.h"
+#include <algorithm>
 
 namespace slampp {
 
@@ -618,29 +620,8 @@ bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hi
 		nz[size_t(j) + size_t(j) * T] = 1;
 		nz[size_t(T - 1) + size_t(j) * T] = 1; // the right-hand side rides in the last row
 	}
-	for(int j = 0; j < T; ++ j) {
-		for(int i2 = j + 1; i2 < T; ++ i2) {
-			if(!nz[size_t(i2) + size_t(j) * T])
-				continue;
-			for(int i1 = i2; i1 < T; ++ i1) {
-				if(nz[size_t(i1) + size_t(j) * T])
-					nz[size_t(i1) + size_t(i2) * T] = 1;
-			}
-		}
-	}
-	// height of every tile column: one more than the highest column it depends on
-	std::vector<int> height(T, 0);
-	int n_max_height = 0;
-	for(int i = 0; i < T; ++ i) {
-		int h = 0;
-		for(int j = 0; j < i; ++ j) {
-			if(nz[size_t(i) + size_t(j) * T] && height[j] + 1 > h)
-				h = height[j] + 1;
-		}
-		height[i] = h;
-		if(h > n_max_height)
-			n_max_height = h;
-	}
+	const std::vector<int> height = tile_symbolic(T, nz);
+	const int n_max_height = *std::max_element(height.begin(), height.end());
 	n_tiles = T;
 	n_levels = n_max_height + 1;
 	std::vector<int> potrf;

@@ -262,7 +262,127 @@ void nested_dissection(int32_t n, const std::vector<int64_t> &adj_ptr, const std
 // symbolic factorization + schedule
 // ---------------------------------------------------------------------------------------------
 
+std::vector<int> tile_symbolic(int T, std::vector<char> &nz)
+{
+	for(int j = 0; j < T; ++ j) {
+		for(int i2 = j + 1; i2 < T; ++ i2) {
+			if(!nz[size_t(i2) + size_t(j) * T])
+				continue;
+			for(int i1 = i2; i1 < T; ++ i1) {
+				if(nz[size_t(i1) + size_t(j) * T])
+					nz[size_t(i1) + size_t(i2) * T] = 1;
+			}
+		}
+	}
+	std::vector<int> height(T, 0);
+	for(int i = 0; i < T; ++ i) {
+		int h = 0;
+		for(int j = 0; j < i; ++ j) {
+			if(nz[size_t(i) + size_t(j) * T] && height[j] + 1 > h)
+				h = height[j] + 1;
+		}
+		height[i] = h;
+	}
+	return height;
+}
+
+int dense_top_tile_pattern(const Plan &P, std::vector<char> &nz)
+{
+	enum { NB = 64 };
+	const int T = (P.dense_dim + 1 + NB - 1) / NB; // one more row: the right-hand side
+	nz.assign(size_t(T) * T, 0);
+	for(int32_t j = 0; j < P.n; ++ j) {
+		if(P.dense_pos[j] < 0)
+			continue;
+		const int c0 = P.dense_pos[j] / NB, c1 = (P.dense_pos[j] + P.dim[j] - 1) / NB;
+		for(int64_t k = P.lptr[j]; k < P.lptr[j + 1]; ++ k) {
+			const int32_t i = P.lrow[k];
+			if(P.dense_pos[i] < 0)
+				continue;
+			const int r0 = P.dense_pos[i] / NB, r1 = (P.dense_pos[i] + P.dim[i] - 1) / NB;
+			for(int tr = r0; tr <= r1; ++ tr) {
+				for(int tc = c0; tc <= c1; ++ tc)
+					nz[size_t(std::max(tr, tc)) + size_t(std::min(tr, tc)) * T] = 1;
+			}
+		}
+	}
+	for(int j = 0; j < T; ++ j) {
+		nz[size_t(j) + size_t(j) * T] = 1;
+		nz[size_t(T - 1) + size_t(j) * T] = 1; // the right-hand side rides in the last row
+	}
+	return T;
+}
+
+double plan_chain_estimate_us(const Plan &P)
+{
+	// measured on MI355X: a separator column costs about 5 us plus 0.08 us per block product (8 us at the
+	// 40 products of a pose-chain separator; 12 vector-memory instructions per product bound it) in the multi-wave
+	// stage kernel, a quarter more in the one-wave kernel, the backward substitution about 3 us per column; a level
+	// of the tile schedule 34 us, a tile of the dense schedule 26 us, four tiles of the dense backward substitution 11 us
+	double f_us = 0;
+	const int n_stages = int(P.stage_ptr.size()) - 1;
+	for(int s = 0; s < n_stages; ++ s) {
+		double f_longest = 0;
+		for(int32_t t = P.stage_ptr[s]; t < P.stage_ptr[s + 1]; ++ t) {
+			double f_task = 0;
+			for(int64_t c = P.task_ptr[t]; c < P.task_ptr[t + 1]; ++ c) {
+				const int32_t j = P.task_cols[c];
+				const int64_t n_products = (P.pptr[P.lptr[j + 1]] - P.pptr[P.lptr[j] + 1]) + (P.rptr[j + 1] - P.rptr[j]);
+				f_task += 5.0 + 0.08 * double(n_products) + 0.15 * double(P.lptr[j + 1] - P.lptr[j]) + 3.0;
+			}
+			f_longest = std::max(f_longest, f_task);
+		}
+		const bool b_wide = P.stage_ptr[s + 1] - P.stage_ptr[s] > 1024;
+		f_us += f_longest * (b_wide? 1.25 : 1.0) + 4.0;
+	}
+	if(P.dense_dim) {
+		std::vector<char> nz;
+		const int T = dense_top_tile_pattern(P, nz);
+		const std::vector<int> height = tile_symbolic(T, nz);
+		const int n_levels = *std::max_element(height.begin(), height.end()) + 1;
+		f_us += std::min(34.0 * n_levels, 26.0 * T) + 11.0 * ((T + 3) / 4) + 60.0;
+	}
+	return f_us;
+}
+
+static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const int64_t *bcol_ptr,
+	const int32_t *brow, const PlanOptions &opt, Plan &P);
+
 std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bcol_ptr,
+	const int32_t *brow, const PlanOptions &opt, Plan &P)
+{
+	std::string s_err = build_plan_once(n_bcols, cumsum, bcol_ptr, brow, opt, P);
+	if(!s_err.empty() || !opt.dense_top_auto || !P.dense_dim)
+		return s_err;
+	// a dense top: where the line between block-by-block elimination and the dense factorization is best drawn
+	// depends on the graph (Manhattan-like: lower, sphere-like: higher); try two more thresholds
+	double f_best = plan_chain_estimate_us(P);
+	const bool b_print = getenv("SLAMPP_HIP_PLAN_TIMING") != 0;
+	if(b_print)
+		fprintf(stderr, "[plan] dense_top_nb %d: dense dim %d, chain estimate %.0f us\n", opt.dense_top_nb, P.dense_dim, f_best);
+	const int p_candidates[] = {opt.dense_top_nb * 2 / 3, opt.dense_top_nb * 3 / 2};
+	for(int i = 0; i < 2; ++ i) {
+		PlanOptions t_opt = opt;
+		t_opt.dense_top_nb = p_candidates[i];
+		Plan t_plan;
+		if(t_opt.dense_top_nb < 4 || !build_plan_once(n_bcols, cumsum, bcol_ptr, brow, t_opt, t_plan).empty())
+			continue;
+		const double f_us = plan_chain_estimate_us(t_plan);
+		if(b_print)
+			fprintf(stderr, "[plan] dense_top_nb %d: dense dim %d, chain estimate %.0f us\n", t_opt.dense_top_nb, t_plan.dense_dim, f_us);
+		// a clear win only: the model is rough, and rougher for the heavy columns a higher threshold leaves to the
+		// block-by-block kernels
+		if(f_us < f_best * (i? 0.85 : 0.95)) {
+			f_best = f_us;
+			t_plan.order_ms += P.order_ms;
+			t_plan.symbolic_ms += P.symbolic_ms;
+			std::swap(P, t_plan);
+		}
+	}
+	return s_err;
+}
+
+static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const int64_t *bcol_ptr,
 	const int32_t *brow, const PlanOptions &opt, Plan &P)
 {
 	P = Plan();

@@ -55,11 +55,24 @@ struct PlanOptions {
 	int leaf_size = 4;        // nested dissection stops at subgraphs of this many block columns
 	int subtree_size = 16;    // a subtree of at most this many columns is one sequential task
 	int dense_top_nb = 24;    // columns with this many blocks or more (and their ancestors) form the dense top; 0 = off
+	bool dense_top_auto = true; // when that gives a dense top, also try 16 and 36 and keep the plan whose estimated chain
+	                            // of dependent launches is shortest (the caller did not ask for a specific threshold)
 	int dense_top_max_dim = 12288; // cap on its scalar dimension (the threshold is raised until it fits)
 	int dense_top_min_dim = 192;   // below this the dense top is not worth its launches
 	int dense_top_align = 64;      // independent chains of dense-top columns start at multiples of this (tile) size, so that
 	                               // the tile schedule of the dense factorization can run them side by side; 0 = packed
 };
+
+// structure of the tile factor of a matrix whose nonzero T x T tile pattern is r_nonzero (column-major flags, lower
+// triangle): closes the pattern under elimination in place and returns, per tile column, its height in the tile
+// elimination tree (columns of one height are independent of each other)
+std::vector<int> tile_symbolic(int T, std::vector<char> &r_nonzero);
+
+// tile pattern of the dense top of a plan (64 x 64 tiles, last tile row = right-hand side) and its padded tile count
+int dense_top_tile_pattern(const Plan &plan, std::vector<char> &r_nonzero);
+
+// rough model of the chain of dependent launches of one factor + solve, in microseconds
+double plan_chain_estimate_us(const Plan &plan);
 
 // returns empty string on success, else an error message
 std::string build_plan(int64_t n_bcols, const int64_t *bcol_cumsum, const int64_t *bcol_ptr,

@@ -249,15 +249,10 @@ void slampp_hip_solver::Analyze_Sparse()
 		// those are touched and independent tile columns are factored side by side
 		b_dense_tiles = false;
 		if(n_dense_top_tiles != 0) {
-			const int T = n_dense_pad / dense_NB;
-			std::vector<char> nonzero(size_t(T) * T, 0);
-			for(size_t k = 0; k < dense_blks.size(); ++ k) {
-				const int64_t r0 = dense_blks[k].dst % n_dense_pad, c0 = dense_blks[k].dst / n_dense_pad;
-				for(int64_t tr = r0 / dense_NB; tr <= (r0 + dense_blks[k].di - 1) / dense_NB; ++ tr) {
-					for(int64_t tc = c0 / dense_NB; tc <= (c0 + dense_blks[k].dj - 1) / dense_NB; ++ tc)
-						nonzero[size_t(std::max(tr, tc)) + size_t(std::min(tr, tc)) * T] = 1;
-				}
-			}
+			std::vector<char> nonzero;
+			const int T = dense_top_tile_pattern(P, nonzero);
+			if(T != n_dense_pad / dense_NB)
+				throw std::logic_error("dense top: tile count mismatch");
 			if(dense_tiles.Build(T, nonzero, stream)) // two launches (26 us) per tile against three (34 us) per level, and fewer tiles touched
 				b_dense_tiles = n_dense_top_tiles > 0 || 100 * dense_tiles.n_levels <= 85 * T;
 			if(b_timing) {
@@ -464,8 +459,10 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 		p_solver->opt.subtree_size = int(n_value);
 	else if(s == "dense_nb" && (n_value == 32 || n_value == 64 || n_value == 128))
 		p_solver->n_dense_nb = int(n_value);
-	else if(s == "dense_top_nb" && n_value >= 0)
+	else if(s == "dense_top_nb" && n_value >= 0) {
 		p_solver->opt.dense_top_nb = int(n_value);
+		p_solver->opt.dense_top_auto = false; // the caller's threshold, as is
+	}
 	else if(s == "dense_top_max_dim" && n_value >= 0)
 		p_solver->opt.dense_top_max_dim = int(n_value);
 	else if(s == "shard_primary")
@@ -862,8 +859,10 @@ int slampp_hip_plan_create(slampp_hip_plan **pp_plan, int64_t n_bcols, const int
 			opt.leaf_size = n_leaf_size;
 		if(n_subtree_size > 0)
 			opt.subtree_size = n_subtree_size;
-		if(n_dense_top_nb >= 0)
+		if(n_dense_top_nb >= 0) {
 			opt.dense_top_nb = n_dense_top_nb;
+			opt.dense_top_auto = false;
+		}
 		if(!build_plan(n_bcols, p_bcol_cumsum, p_bcol_ptr, p_brow_idx, opt, p->plan).empty()) {
 			delete p;
 			return SLAMPP_HIP_ERR_INVALID;
