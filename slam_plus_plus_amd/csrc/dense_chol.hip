@@ -15,19 +15,9 @@
 // This is the MFMA-bound kernel of the path: n^3/3 flops (72 GFLOP at 1k cameras).
 #include <hip/hip_runtime.h>
 #include "dense_chol.h"
-#include "plan.h"
-#include <algorithm>
 
 namespace slampp {
-
-typedef double v4f64 __attribute__((ext_vector_type(4)));
-
-enum { NB = dense_NB };
-
-// LDS operand tiles are stored [k][row] with leading dimension 64 and rows XOR-swizzled by 16 on odd k: the
-// two k-groups a half-wave reads in one fragment load land on disjoint halves of the banks, and a 64 x 64
-// operand pair takes 64 KB, so two workgroups (or one next to the diagonal-tile kernel) fit on a CU
-__device__ __forceinline__ int lds_at(int k, int row) { return k * NB + (row ^ ((k & 1) << 4)); }
+#include "dense_device.inl"
 
 __global__ void dense_pad_kernel(double *M, int ld, int n)
 {
@@ -40,270 +30,6 @@ void dense_prepare_padding(double *M, int n_pad, int n, hipStream_t stream)
 {
 	const int cnt = n_pad - n;
 	hipLaunchKernelGGL(dense_pad_kernel, dim3((cnt + 63) / 64), dim3(64), 0, stream, M, n_pad, n);
-}
-
-__global__ void dense_gap_kernel(double *M, int ld, const int32_t *__restrict__ p_positions, int n_positions)
-{
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if(i < n_positions)
-		M[p_positions[i] + size_t(p_positions[i]) * ld] = 1.0;
-}
-
-void dense_prepare_gaps(double *M, int n_pad, const int32_t *p_positions_dev, int n_positions, hipStream_t stream)
-{
-	if(n_positions > 0)
-		hipLaunchKernelGGL(dense_gap_kernel, dim3((n_positions + 63) / 64), dim3(64), 0, stream, M, n_pad, p_positions_dev, n_positions);
-}
-
-// ---- 64 x 64 x 64 tile product on the matrix cores ----
-// acc[c][reg] (+)= sum_k Q[i][k] P[j][k] with i = 16 wave + (lane >> 4) + 4 reg, j = 16 c + (lane & 15);
-// both operands live in LDS as [k][row], swizzled (lds_at).
-__device__ __forceinline__ void tile_product(const double *Ps, const double *Qs, int wave, int lane, v4f64 acc[4])
-{
-	const int lo = lane & 15, hi = lane >> 4;
-	#pragma unroll
-	for(int ks = 0; ks < NB / 4; ++ ks) {
-		const int k = ks * 4 + hi;
-		const double a = Qs[lds_at(k, 16 * wave + lo)];
-		#pragma unroll
-		for(int c = 0; c < 4; ++ c) {
-			const double b = Ps[lds_at(k, 16 * c + lo)];
-			acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
-		}
-	}
-}
-
-// the 64 x 64 tile at (row0, col0) of the column-major matrix, on its way into LDS as [col][row]:
-// 16-byte loads, thread t moves rows 2 (t & 31), +1 of columns t >> 5, +8, ...; all loads are issued before
-// the first LDS store (row0 and ld are even and the swizzle keeps row pairs together, so everything is
-// 16-B aligned).  Split in two so that the loads of the next K tile can fly during the current product.
-typedef double v2f64 __attribute__((ext_vector_type(2)));
-
-struct TTileRegs {
-	v2f64 v[NB / 8];
-};
-
-__device__ __forceinline__ void fetch_tile(TTileRegs &t_regs, const double *M, int ld, int row0, int col0)
-{
-	const int r = (threadIdx.x & 31) * 2, c0 = threadIdx.x >> 5;
-	#pragma unroll
-	for(int i = 0; i < NB / 8; ++ i)
-		t_regs.v[i] = *reinterpret_cast<const v2f64*>(M + size_t(row0 + r) + size_t(col0 + c0 + 8 * i) * ld);
-}
-
-__device__ __forceinline__ void stage_tile(double *Ts, const TTileRegs &t_regs)
-{
-	const int r = (threadIdx.x & 31) * 2, c0 = threadIdx.x >> 5;
-	#pragma unroll
-	for(int i = 0; i < NB / 8; ++ i)
-		*reinterpret_cast<v2f64*>(Ts + lds_at(c0 + 8 * i, r)) = t_regs.v[i];
-}
-
-__device__ __forceinline__ void load_tile(double *Ts, const double *M, int ld, int row0, int col0)
-{
-	TTileRegs t_regs;
-	fetch_tile(t_regs, M, ld, row0, col0);
-	stage_tile(Ts, t_regs);
-}
-
-// ---- diagonal tile: Cholesky + inverse ----
-// Cholesky, blocked by 16 columns: wave 0 factors a 64 x 16 panel in registers (thread r = row r; pivots and
-// the scaled pivot column travel by v_readlane with constant lane numbers -- no LDS, no barrier inside the
-// 16 steps), then the rank-16 update of the next panel's columns runs on the matrix cores (one 16 x 16 tile
-// per wave); the updates of the columns further right and the inverse of the finished 16 x 16 diagonal block
-// are done by waves 1-3 while wave 0 is already inside the next panel.
-// Inverse (so that the panel solve becomes a GEMM): recursive on 16 / 32 / 64 blocks,
-// inv([A 0; B C]) = [inv(A) 0; -inv(C) B inv(A), inv(C)], the products on the matrix cores.
-// All LDS tiles use the odd leading dimension PL: row-wise and column-wise fragment reads both stay at
-// most 2-way bank conflicted, so no transposed copies are needed.
-__device__ __forceinline__ double dense_read_lane(double v, int n_lane)
-{
-	const int lo = __builtin_amdgcn_readlane(__double2loint(v), n_lane);
-	const int hi = __builtin_amdgcn_readlane(__double2hiint(v), n_lane);
-	return __hiloint2double(hi, lo);
-}
-
-enum { PL = NB + 1, TL = NB / 2 + 1 };
-
-// D[m][n] += sum_{k < K} A[m][k] B[k][n] for one 16 x 16 tile; A[m][k] = p_A[m * a_m + k * a_k], B[k][n] =
-// p_B[k * b_k + n * b_n]; lane l holds D[(l >> 4) + 4 reg][l & 15] in acc[reg]
-__device__ __forceinline__ v4f64 mfma_tile16(const double *p_A, int a_m, int a_k, const double *p_B, int b_k, int b_n,
-	int K, int lane, v4f64 acc)
-{
-	const int lo = lane & 15, hi = lane >> 4;
-	for(int ks = 0; ks < K; ks += 4) {
-		const double a = p_A[lo * a_m + (ks + hi) * a_k];
-		const double b = p_B[(ks + hi) * b_k + lo * b_n];
-		acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-	}
-	return acc;
-}
-
-// trailing update inside the diagonal tile: S(ti, tj) -= P(ti) P(tj)^T with the 16-column panel at column c0;
-// computed transposed (m = column of S, n = row) so that the read-modify-write runs along rows
-__device__ __forceinline__ void potrf_update_tile(double *s_L, int c0, int ti, int tj, int lane)
-{
-	const v4f64 zero = {0, 0, 0, 0};
-	const v4f64 acc = mfma_tile16(s_L + c0 * PL + 16 * tj, 1, PL, s_L + c0 * PL + 16 * ti, PL, 1, 16, lane, zero);
-	const int lo = lane & 15, hi = lane >> 4;
-	#pragma unroll
-	for(int reg = 0; reg < 4; ++ reg)
-		s_L[(16 * tj + hi + 4 * reg) * PL + 16 * ti + lo] -= acc[reg];
-}
-
-// inverse of the 16 x 16 lower triangular diagonal block at b0: lane c < 16 of the calling wave solves column c
-__device__ __forceinline__ void potrf_invert_block16(const double *s_L, const double *s_rd, double *s_X, int b0, int lane)
-{
-	if(lane >= 16)
-		return;
-	const int c = lane;
-	double x[16];
-	#pragma unroll
-	for(int r = 0; r < 16; ++ r) {
-		double sum = (r == c)? 1.0 : 0.0;
-		#pragma unroll
-		for(int u = 0; u < r; ++ u)
-			sum -= s_L[(b0 + u) * PL + b0 + r] * x[u];
-		x[r] = sum * s_rd[b0 + r];
-	}
-	#pragma unroll
-	for(int r = 0; r < 16; ++ r)
-		s_X[(b0 + r) * PL + b0 + c] = x[r];
-}
-
-enum { POTRF_LDS_DOUBLES = 2 * NB * PL + (NB / 2) * TL + NB };
-
-template <bool b_chol, bool b_inverse>
-__device__ __forceinline__ void potrf_diag_body(double *M, int ld, int kb, int n, double *invL, int *p_flag, double *s_buf)
-{
-	double *s_L = s_buf;                  // the tile, [col][row]
-	double *s_X = s_L + NB * PL;          // its inverse, [row][col]
-	double *s_T = s_X + NB * PL;          // products L21 X11, [row][col]
-	double *s_rd = s_T + (NB / 2) * TL;   // reciprocals of the diagonal of L
-
-	const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-	const int o = kb * NB;
-	{
-		double v[NB * NB / 256];
-		#pragma unroll
-		for(int i = 0; i < NB * NB / 256; ++ i) { // coalesced along rows of the column-major tile
-			const int e = t + 256 * i, r = e & 63, c = e >> 6;
-			v[i] = (c <= r)? M[size_t(o + r) + size_t(o + c) * ld] : 0.0;
-		}
-		#pragma unroll
-		for(int i = 0; i < NB * NB / 256; ++ i) {
-			const int e = t + 256 * i, r = e & 63, c = e >> 6;
-			s_L[c * PL + r] = v[i];
-			s_X[c * PL + r] = 0.0;
-		}
-	}
-	if(!b_chol && t < NB)
-		s_rd[t] = 1.0 / M[size_t(o + t) + size_t(o + t) * ld];
-	__syncthreads();
-	bool b_bad = false;
-	if(b_chol) {
-		for(int J = 0; J < NB / 16; ++ J) {
-			const int c0 = 16 * J;
-			if(wave == 0) {
-				const int r = lane;
-				double a[16];
-				#pragma unroll
-				for(int c = 0; c < 16; ++ c)
-					a[c] = s_L[(c0 + c) * PL + r];
-				#pragma unroll
-				for(int k = 0; k < 16; ++ k) {
-					double piv = dense_read_lane(a[k], c0 + k);
-					const bool b_neg = !(piv > 0);
-					b_bad = b_bad || (b_neg && o + c0 + k < n);
-					piv = b_neg? 1.0 : piv;
-					double rs = __builtin_amdgcn_rsq(piv);
-					const double h = 0.5 * piv;
-					rs = rs * (1.5 - h * rs * rs);
-					rs = rs * (1.5 - h * rs * rs);
-					const double lk = a[k] * rs; // L(r, c0 + k), meaningful for r >= c0 + k
-					a[k] = lk;
-					if(r == c0 + k)
-						s_rd[c0 + k] = rs;
-					#pragma unroll
-					for(int c = k + 1; c < 16; ++ c)
-						a[c] -= lk * dense_read_lane(lk, c0 + c);
-				}
-				#pragma unroll
-				for(int c = 0; c < 16; ++ c)
-					s_L[(c0 + c) * PL + r] = (r >= c0 + c)? a[c] : 0.0;
-			}
-			__syncthreads();
-			// the next panel's columns first: tiles (ti, J + 1), ti = J + 1 .. 3, one per wave
-			if(J + 1 + wave < NB / 16)
-				potrf_update_tile(s_L, c0, J + 1 + wave, J + 1, lane);
-			__syncthreads();
-			// columns further right and the inverse of this diagonal block: waves 1-3, next to wave 0's next panel
-			if(wave > 0) {
-				int n_idx = 0;
-				for(int tj = J + 2; tj < NB / 16; ++ tj) {
-					for(int ti = tj; ti < NB / 16; ++ ti, ++ n_idx) {
-						if(n_idx % 3 == wave - 1)
-							potrf_update_tile(s_L, c0, ti, tj, lane);
-					}
-				}
-				if(b_inverse && wave == 1 + J % 3)
-					potrf_invert_block16(s_L, s_rd, s_X, c0, lane);
-			}
-		}
-		__syncthreads();
-	} else if(b_inverse) {
-		if(wave < NB / 16)
-			potrf_invert_block16(s_L, s_rd, s_X, 16 * wave, lane);
-		__syncthreads();
-	}
-	if(b_bad && lane == 0)
-		atomicOr(p_flag, 1);
-	#pragma unroll
-	for(int i = 0; i < NB * NB / 256; ++ i) {
-		const int e = t + 256 * i, r = e & 63, c = e >> 6;
-		if(c <= r)
-			M[size_t(o + r) + size_t(o + c) * ld] = s_L[c * PL + r];
-	}
-	if(!b_inverse)
-		return;
-	const int lo = lane & 15, hi = lane >> 4;
-	const v4f64 zero = {0, 0, 0, 0};
-	// level 1: the off-diagonal 16 x 16 block of the two 32 x 32 diagonal blocks, X21 = -X22 (L21 X11); waves 0 and 1
-	if(wave < 2) {
-		const int b0 = 32 * wave;
-		const v4f64 acc = mfma_tile16(s_L + b0 * PL + b0 + 16, 1, PL, s_X + b0 * PL + b0, PL, 1, 16, lane, zero);
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			s_T[(16 * wave + hi + 4 * reg) * TL + lo] = acc[reg];
-	}
-	__syncthreads();
-	if(wave < 2) {
-		const int b0 = 32 * wave;
-		const v4f64 acc = mfma_tile16(s_X + (b0 + 16) * PL + b0 + 16, PL, 1, s_T + 16 * wave * TL, TL, 1, 16, lane, zero);
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			s_X[(b0 + 16 + hi + 4 * reg) * PL + b0 + lo] = -acc[reg];
-	}
-	__syncthreads();
-	// level 2: the 32 x 32 off-diagonal block, one 16 x 16 tile per wave
-	{
-		const int mt = wave >> 1, nt = wave & 1;
-		v4f64 acc = mfma_tile16(s_L + 32 + 16 * mt, 1, PL, s_X + 16 * nt, PL, 1, 32, lane, zero);
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			s_T[(16 * mt + hi + 4 * reg) * TL + 16 * nt + lo] = acc[reg];
-		__syncthreads();
-		acc = mfma_tile16(s_X + (32 + 16 * mt) * PL + 32, PL, 1, s_T + 16 * nt, TL, 1, 32, lane, zero);
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			s_X[(32 + 16 * mt + hi + 4 * reg) * PL + 16 * nt + lo] = -acc[reg];
-	}
-	__syncthreads();
-	#pragma unroll
-	for(int i = 0; i < NB * NB / 256; ++ i) {
-		const int e = t + 256 * i, r = e & 63, c = e >> 6;
-		invL[r + c * NB] = s_X[r * PL + c]; // column-major inverse
-	}
 }
 
 #ifdef POTRF_VARIANTS // tools/bench_potrf.hip: timing of the two halves
@@ -521,192 +247,6 @@ void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag,
 				hipLaunchKernelGGL(trsm_kernel, dim3(n_below), dim3(256), 0, stream, M, n_pad, kb, invL, int(kb + 1 < t1));
 		}
 		launch_syrk(M, n_pad, n_blocks, t1 - 1, t1, u0, u1, stream); // the last tile's update of the next panel
-	}
-}
-
-// ---- tile-sparse, level-scheduled variant (see dense_chol.h) ----
-__global__ void __launch_bounds__(256)
-tile_potrf_kernel(double *M, int ld, int n, double *p_invdiag, int *p_flag, const int *__restrict__ p_tiles)
-{
-	__shared__ double s_buf[POTRF_LDS_DOUBLES];
-	const int kb = p_tiles[blockIdx.x];
-	potrf_diag_body<true, true>(M, ld, kb, n, p_invdiag + size_t(kb) * NB * NB, p_flag, s_buf);
-}
-
-__global__ void __launch_bounds__(256)
-tile_trsm_kernel(double *M, int ld, const double *p_invdiag, const int2 *__restrict__ p_pairs)
-{
-	__shared__ double Ps[NB * NB];
-	__shared__ double Qs[NB * NB];
-	const int2 t_pair = p_pairs[blockIdx.x];
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int row0 = t_pair.x * NB, col0 = t_pair.y * NB;
-	load_tile(Ps, M, ld, row0, col0);
-	load_tile(Qs, p_invdiag + size_t(t_pair.y) * NB * NB, NB, 0, 0);
-	__syncthreads();
-	v4f64 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-	tile_product(Ps, Qs, wave, lane, acc);
-	const int lo = lane & 15, hi = lane >> 4;
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			M[size_t(row0 + 16 * c + lo) + size_t(col0 + 16 * wave + hi + 4 * reg) * ld] = acc[c][reg];
-}
-
-// target tile (ti, tj) -= sum over its source tile columns kt of L(ti, kt) L(tj, kt)^T
-__global__ void __launch_bounds__(256)
-tile_update_kernel(double *M, int ld, const int4 *__restrict__ p_targets, const int *__restrict__ p_sources)
-{
-	__shared__ double Ps[NB * NB];
-	__shared__ double Qs[NB * NB];
-	const int4 t_tgt = p_targets[blockIdx.x];
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int row0 = t_tgt.x * NB, colq = t_tgt.y * NB;
-	const int lo = lane & 15, hi = lane >> 4;
-	double cv[4][4];
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			cv[c][reg] = M[size_t(row0 + 16 * c + lo) + size_t(colq + 16 * wave + hi + 4 * reg) * ld];
-	v4f64 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-	TTileRegs t_p, t_q;
-	int kt = p_sources[t_tgt.z];
-	fetch_tile(t_p, M, ld, row0, kt * NB);
-	fetch_tile(t_q, M, ld, colq, kt * NB);
-	for(int e = t_tgt.z; e < t_tgt.w; ++ e) {
-		if(e > t_tgt.z)
-			__syncthreads(); // the previous source has been consumed
-		stage_tile(Ps, t_p);
-		stage_tile(Qs, t_q);
-		__syncthreads();
-		if(e + 1 < t_tgt.w) {
-			kt = p_sources[e + 1];
-			fetch_tile(t_p, M, ld, row0, kt * NB);
-			fetch_tile(t_q, M, ld, colq, kt * NB);
-		}
-		tile_product(Ps, Qs, wave, lane, acc);
-	}
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			M[size_t(row0 + 16 * c + lo) + size_t(colq + 16 * wave + hi + 4 * reg) * ld] = cv[c][reg] - acc[c][reg];
-}
-
-void CTileSchedule::Free()
-{
-	if(d_potrf) (void)hipFree(d_potrf);
-	if(d_trsm) (void)hipFree(d_trsm);
-	if(d_tgt) (void)hipFree(d_tgt);
-	if(d_src) (void)hipFree(d_src);
-	d_potrf = 0; d_trsm = 0; d_tgt = 0; d_src = 0;
-	n_bytes = 0;
-	n_levels = 0;
-	n_tiles = 0;
-}
-
-bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hipStream_t stream)
-{
-	Free();
-	const int T = n_tile_num;
-	if(T <= 0 || r_nonzero.size() != size_t(T) * T)
-		return false;
-	// structure of the tile factor: symbolic elimination at tile granularity (the block-level structure it comes
-	// from is already closed; whole tiles are not, e.g. two blocks of different columns sharing a tile column)
-	std::vector<char> nz(r_nonzero);
-	for(int j = 0; j < T; ++ j) {
-		nz[size_t(j) + size_t(j) * T] = 1;
-		nz[size_t(T - 1) + size_t(j) * T] = 1; // the right-hand side rides in the last row
-	}
-	const std::vector<int> height = tile_symbolic(T, nz);
-	const int n_max_height = *std::max_element(height.begin(), height.end());
-	n_tiles = T;
-	n_levels = n_max_height + 1;
-	std::vector<int> potrf;
-	std::vector<int2> trsm;
-	std::vector<int4> tgt;
-	std::vector<int> src;
-	level_potrf_ptr.assign(1, 0);
-	level_trsm_ptr.assign(1, 0);
-	level_tgt_ptr.assign(1, 0);
-	std::vector<int> tgt_of(size_t(T) * T, -1); // per level: index of the target record of a tile
-	for(int l = 0; l < n_levels; ++ l) {
-		const size_t n_tgt0 = tgt.size();
-		std::vector<std::vector<int> > sources; // per target of this level
-		for(int j = 0; j < T; ++ j) {
-			if(height[j] != l)
-				continue;
-			potrf.push_back(j);
-			for(int i = j + 1; i < T; ++ i) {
-				if(nz[size_t(i) + size_t(j) * T])
-					trsm.push_back(int2{i, j});
-			}
-			for(int i2 = j + 1; i2 < T; ++ i2) {
-				if(!nz[size_t(i2) + size_t(j) * T])
-					continue;
-				for(int i1 = i2; i1 < T; ++ i1) {
-					if(!nz[size_t(i1) + size_t(j) * T])
-						continue;
-					int &r_idx = tgt_of[size_t(i1) + size_t(i2) * T];
-					if(r_idx < int(n_tgt0)) { // not seen in this level yet (stale indices of earlier levels are smaller)
-						r_idx = int(n_tgt0 + sources.size());
-						tgt.push_back(int4{i1, i2, 0, 0});
-						sources.push_back(std::vector<int>());
-					}
-					sources[r_idx - n_tgt0].push_back(j);
-				}
-			}
-		}
-		for(size_t k = 0; k < sources.size(); ++ k) {
-			tgt[n_tgt0 + k].z = int(src.size());
-			src.insert(src.end(), sources[k].begin(), sources[k].end());
-			tgt[n_tgt0 + k].w = int(src.size());
-		}
-		level_potrf_ptr.push_back(int(potrf.size()));
-		level_trsm_ptr.push_back(int(trsm.size()));
-		level_tgt_ptr.push_back(int(tgt.size()));
-	}
-	const size_t n_b0 = potrf.size() * sizeof(int), n_b1 = (trsm.size() + 1) * sizeof(int2),
-		n_b2 = (tgt.size() + 1) * sizeof(int4), n_b3 = (src.size() + 1) * sizeof(int);
-	if(hipMalloc((void**)&d_potrf, n_b0) != hipSuccess || hipMalloc((void**)&d_trsm, n_b1) != hipSuccess ||
-	   hipMalloc((void**)&d_tgt, n_b2) != hipSuccess || hipMalloc((void**)&d_src, n_b3) != hipSuccess) {
-		(void)hipGetLastError();
-		Free();
-		return false;
-	}
-	bool b_ok = hipMemcpyAsync(d_potrf, potrf.data(), n_b0, hipMemcpyHostToDevice, stream) == hipSuccess;
-	if(!trsm.empty())
-		b_ok = b_ok && hipMemcpyAsync(d_trsm, trsm.data(), trsm.size() * sizeof(int2), hipMemcpyHostToDevice, stream) == hipSuccess;
-	if(!tgt.empty())
-		b_ok = b_ok && hipMemcpyAsync(d_tgt, tgt.data(), tgt.size() * sizeof(int4), hipMemcpyHostToDevice, stream) == hipSuccess;
-	if(!src.empty())
-		b_ok = b_ok && hipMemcpyAsync(d_src, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice, stream) == hipSuccess;
-	b_ok = b_ok && hipStreamSynchronize(stream) == hipSuccess; // the host vectors live on this stack frame
-	if(!b_ok) {
-		(void)hipGetLastError();
-		Free();
-		return false;
-	}
-	n_bytes = n_b0 + n_b1 + n_b2 + n_b3;
-	n_tiles = T;
-	n_levels = n_max_height + 1;
-	return true;
-}
-
-void tile_cholesky(const CTileSchedule &r_s, double *M, int n_pad, int n, double *p_invdiag, int *p_flag, hipStream_t stream)
-{
-	for(int l = 0; l < r_s.n_levels; ++ l) {
-		const int p0 = r_s.level_potrf_ptr[l], p1 = r_s.level_potrf_ptr[l + 1];
-		const int t0 = r_s.level_trsm_ptr[l], t1 = r_s.level_trsm_ptr[l + 1];
-		const int g0 = r_s.level_tgt_ptr[l], g1 = r_s.level_tgt_ptr[l + 1];
-		if(p1 > p0)
-			hipLaunchKernelGGL(tile_potrf_kernel, dim3(p1 - p0), dim3(256), 0, stream, M, n_pad, n, p_invdiag, p_flag, r_s.d_potrf + p0);
-		if(t1 > t0)
-			hipLaunchKernelGGL(tile_trsm_kernel, dim3(t1 - t0), dim3(256), 0, stream, M, n_pad, p_invdiag, r_s.d_trsm + t0);
-		if(g1 > g0)
-			hipLaunchKernelGGL(tile_update_kernel, dim3(g1 - g0), dim3(256), 0, stream, M, n_pad, r_s.d_tgt + g0, r_s.d_src);
 	}
 }
 
