@@ -50,3 +50,32 @@ def test_product_does_not_reference_the_oracle():
                                  open(os.path.join(dirpath, f), errors="ignore").read()):
                         offenders.append(os.path.join(dirpath, f))
     assert not offenders, offenders
+
+
+def test_dense_kernels_keep_two_workgroups_per_cu(tmp_path):
+    """The trailing updates ride in the diagonal-tile launches and need two workgroups per CU; the register allocation
+    of that kernel has been seen to flip (260 instead of 204 registers) when unrelated kernels were added to its
+    translation unit.  Compile it the way the Makefile does and read the compiler's resource report."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "slam_plus_plus_amd", "csrc", "dense_chol.hip")
+    out = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "--cuda-device-only", "-c",
+                          "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "x.o"), src],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    report, name = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            report[name] = {}
+        m = re.search(r"remark:\s+(Occupancy \[waves/SIMD\]|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and name:
+            report[name][m.group(1).split(" [")[0]] = int(m.group(2))
+    for needle in ("potrf_diag_kernel", "11syrk_kernel", "11trsm_kernel"):
+        hits = [v for k, v in report.items() if needle in k and "variant" not in k]
+        assert hits, (needle, list(report))
+        assert hits[0]["Occupancy"] >= 2 and hits[0]["ScratchSize"] == 0 and hits[0]["LDS Size"] <= 80 * 1024, (needle, hits[0])
