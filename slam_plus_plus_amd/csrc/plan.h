@@ -53,7 +53,7 @@ struct Plan {
 
 struct PlanOptions {
 	int leaf_size = 4;        // nested dissection stops at subgraphs of this many block columns
-	int subtree_size = 16;    // a subtree of at most this many columns is one sequential task
+	int subtree_size = 8;     // a subtree of at most this many columns is one sequential task (8: best from 2k to 100k poses)
 	int dense_top_nb = 24;    // columns with this many blocks or more (and their ancestors) form the dense top; 0 = off
 	bool dense_top_auto = true; // when that gives a dense top, also try 16 and 36 and keep the plan whose estimated chain
 	                            // of dependent launches is shortest (the caller did not ask for a specific threshold)
