@@ -210,3 +210,20 @@ def test_reduced_system_auto_picks_sparse_for_band_structure():
     bad.values[off[k]:off[k] + 36] *= -1.0
     assert not solver.Solve_PosDef_Blocky(bad, bad.rhs.copy())
     assert solver.Solve_PosDef_Blocky(lam, lam.rhs.copy())       # and the solver recovers
+
+
+@pytest.mark.parametrize("cam_dim,pt_dim", [(7, 3), (3, 2)])
+def test_sparse_reduced_system_other_block_sizes(cam_dim, pt_dim):
+    """Sim(3)-style 7x7 cameras and the planar (3, 2) case through the sparse reduced system (inner solver kernels for
+    7x7 / 3x3 blocks) against the dense one and the oracle."""
+    lam = synth.ba(300, 5000, k=4, mode="band", seed=41, cam_dim=cam_dim, pt_dim=pt_dim)
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok
+    out = {}
+    for sparse in (0, 1):
+        solver = CLinearSolver_Schur_HIP(schur_sparse=sparse)
+        eta = lam.rhs.copy()
+        assert solver.Solve_PosDef(lam, eta)
+        assert rel_inf(eta, x_ref) < TOL
+        out[sparse] = eta
+    assert rel_inf(out[1], out[0]) < 1e-11
