@@ -53,9 +53,9 @@ struct CSchurState {
 	bool b_reduced_decided, b_reduced_sparse;
 	slampp_hip_solver *p_inner;
 	int64_t n_in_blocks;
-	CDevArray<int32_t> d_in_row, d_in_col;     // lower blocks of S (row >= col) ...
-	CDevArray<int64_t> d_in_off;               // ... and where their transposes sit in the packed upper block-CSC values
-	CDevArray<double> d_in_values, d_in_rhs;
+	CDevArray<int64_t> d_sb_dst, d_a_dst;      // where the blocks of S this rank computes / the camera blocks of Lambda sit
+	                                           // in the packed upper block-CSC values of the inner solver
+	CDevArray<double> d_in_buf;                // [values (n_in_blocks DC^2) | right-hand side (N)]: also what the ranks exchange
 	CSchurState() :p_union_fn(0), p_union_context(0), b_union_dense(false), n_union(0), b_reduced_decided(false),
 		b_reduced_sparse(false), p_inner(0), n_in_blocks(0) {}
 	~CSchurState();
@@ -76,8 +76,8 @@ size_t schur_device_bytes(const CSchurState *p)
 	return p->d_ptr.n_Bytes() + p->d_brow.n_Bytes() + p->d_obs_pt.n_Bytes() + p->d_sb_ptr.n_Bytes() +
 		p->d_sb_row.n_Bytes() + p->d_sb_col.n_Bytes() + p->d_ent_a.n_Bytes() + p->d_ent_uoff.n_Bytes() +
 		p->d_cam_ptr.n_Bytes() + p->d_cam_obs.n_Bytes() + p->d_S.n_Bytes() + p->d_W.n_Bytes() +
-		p->d_un_row.n_Bytes() + p->d_un_col.n_Bytes() + p->d_pack.n_Bytes() + p->d_in_row.n_Bytes() + p->d_in_col.n_Bytes() +
-		p->d_in_off.n_Bytes() + p->d_in_values.n_Bytes() + p->d_in_rhs.n_Bytes() + (p->p_inner? p->p_inner->n_Device_Bytes() : 0) +
+		p->d_un_row.n_Bytes() + p->d_un_col.n_Bytes() + p->d_pack.n_Bytes() + p->d_sb_dst.n_Bytes() + p->d_a_dst.n_Bytes() +
+		p->d_in_buf.n_Bytes() + (p->p_inner? p->p_inner->n_Device_Bytes() : 0) +
 		p->d_Cinv.n_Bytes() + p->d_t.n_Bytes() + p->d_invdiag.n_Bytes() + p->d_z.n_Bytes() + p->d_x.n_Bytes();
 }
 
@@ -243,13 +243,9 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 		S.d_ent_uoff.Upload(ent_uoff, st);
 		S.d_cam_ptr.Upload(cam_ptr, st);
 		S.d_cam_obs.Upload(cam_obs, st);
-		S.d_S.Alloc(size_t(S.Npad) * S.Npad);
 		S.d_W.Alloc(size_t(S.n_obs) * DC * DP);
 		S.d_Cinv.Alloc(size_t(np) * DP * DP);
 		S.d_t.Alloc(size_t(S.n_obs) * DP);
-		S.d_invdiag.Alloc(size_t(S.Npad / dense_NB) * dense_NB * dense_NB);
-		S.d_z.Alloc(S.Npad);
-		S.d_x.Alloc(S.Npad);
 		s.d_flag.Alloc(1);
 		SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), s.stream)); // sync() before the first factorization reads it
 		SLAMPP_HIP_CHECK(hipStreamSynchronize(st));
@@ -264,10 +260,13 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 // kernels
 // ---------------------------------------------------------------------------------------------
 
-// S(lower) := A^T blocks, r := eta_x   (primary shard only; S was zeroed before)
+// S(lower) := A^T blocks, r := eta_x   (primary shard only; S was zeroed before).  The reduced system lives either in
+// the dense buffer S (leading dimension ld, right-hand side in its last row) or, when p_dst is given, in the packed
+// upper block-CSC values of the inner sparse solver (block k of Lambda goes to p_dst[k] as it is) and the vector p_r
 template <int DC>
 __global__ void schur_scatter_A_kernel(const int64_t *ptr, const int32_t *brow, int64_t nc,
-	const double *__restrict__ A, const double *__restrict__ eta, double *S, int ld, int n)
+	const double *__restrict__ A, const double *__restrict__ eta, double *S, int ld, int n,
+	const int64_t *__restrict__ p_dst, double *p_r)
 {
 	const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
 	const int64_t n_elems = ptr[nc] * DC * DC;
@@ -281,10 +280,17 @@ __global__ void schur_scatter_A_kernel(const int64_t *ptr, const int32_t *brow, 
 			if(ptr[mid] <= k) lo = mid; else hi = mid;
 		}
 		const int64_t c = lo, r = brow[k];
-		S[size_t(c * DC + q) + size_t(r * DC + rr) * ld] = A[gid]; // lower block (c, r) = block^T
+		if(p_dst)
+			S[p_dst[k] + e] = A[gid]; // the upper block (r, c), as stored
+		else
+			S[size_t(c * DC + q) + size_t(r * DC + rr) * ld] = A[gid]; // lower block (c, r) = block^T
 	}
-	if(gid < n)
-		S[size_t(ld - 1) + size_t(gid) * ld] = eta[gid];
+	if(gid < n) {
+		if(p_dst)
+			p_r[gid] = eta[gid];
+		else
+			S[size_t(ld - 1) + size_t(gid) * ld] = eta[gid];
+	}
 }
 
 // small SPD inverse through its Cholesky factor; returns false on a non-positive pivot
@@ -404,7 +410,7 @@ template <int DC, int DP, int W>
 __global__ void __launch_bounds__(64 * W)
 schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *sb_row, const int32_t *sb_col,
 	const int32_t *ent_a, const int64_t *ent_uoff, const double *__restrict__ A, const double *__restrict__ W_,
-	double *S, int ld)
+	double *S, int ld, const int64_t *__restrict__ p_dst)
 {
 	enum { BLK = DC * DP, BATCH = 8 };
 	__shared__ double s_ops[W][BATCH][2 * BLK];
@@ -468,8 +474,9 @@ schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *s
 		for(int ww = 0; ww < W; ++ ww)
 			acc += s_part[ww][lane];
 	}
-	if(b_act) {
-		const size_t idx = size_t(int64_t(sb_row[sb]) * DC + r) + size_t(int64_t(sb_col[sb]) * DC + q) * ld;
+	if(b_act) { // dense: the lower block (row, col); packed: its transpose, the upper block (col, row) of the inner solver
+		const size_t idx = p_dst? size_t(p_dst[sb]) + q + r * DC :
+			size_t(int64_t(sb_row[sb]) * DC + r) + size_t(int64_t(sb_col[sb]) * DC + q) * ld;
 		S[idx] -= acc;
 	}
 }
@@ -478,7 +485,7 @@ schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *s
 template <int DC, int DP>
 __global__ void __launch_bounds__(64)
 schur_rhs_kernel(const int64_t *cam_ptr, const int32_t *cam_obs, const int32_t *obs_pt, int n,
-	const double *__restrict__ W, const double *__restrict__ eta, double *S, int ld)
+	const double *__restrict__ W, const double *__restrict__ eta, double *S, int ld, double *p_r)
 {
 	const int64_t c = blockIdx.x;
 	const int lane = threadIdx.x;
@@ -506,8 +513,12 @@ schur_rhs_kernel(const int64_t *cam_ptr, const int32_t *cam_obs, const int32_t *
 	}
 	if(lane == 0) {
 		#pragma unroll
-		for(int i = 0; i < DC; ++ i)
-			S[size_t(ld - 1) + size_t(c * DC + i) * ld] -= acc[i];
+		for(int i = 0; i < DC; ++ i) {
+			if(p_r)
+				p_r[c * DC + i] -= acc[i];
+			else
+				S[size_t(ld - 1) + size_t(c * DC + i) * ld] -= acc[i];
+		}
 	}
 }
 
@@ -634,33 +645,7 @@ static void schur_agree_on_union(slampp_hip_solver &s, CSchurState &S)
 	S.h_un_col = un_col;
 	S.d_un_row.Upload(un_row, st);
 	S.d_un_col.Upload(un_col, st);
-	S.d_pack.Alloc(size_t(S.n_union) * S.DC * S.DC + size_t(S.N));
 	SLAMPP_HIP_CHECK(hipStreamSynchronize(st)); // un_row / un_col live on this stack frame
-}
-
-// sparse reduced system: the nonzero blocks of S (lower triangle of the dense buffer) go, transposed, into the
-// packed upper block-CSC values of a block matrix the sparse path can factor; the right-hand side row into a vector
-__global__ void __launch_bounds__(64)
-schur_reduced_pack_kernel(const int32_t *__restrict__ in_row, const int32_t *__restrict__ in_col,
-	const int64_t *__restrict__ in_off, int64_t n_in_blocks, int dc, const double *__restrict__ S, int ld, int n,
-	double *values, double *r)
-{
-	const int64_t b = blockIdx.x;
-	const int lane = threadIdx.x;
-	if(b < n_in_blocks) {
-		if(lane >= dc * dc)
-			return;
-		const int i = lane % dc, j = lane / dc; // element (i, j) of the upper block (in_col[b], in_row[b])
-		const int64_t br = in_row[b], bc = in_col[b];
-		// = element (j, i) of the lower block (in_row[b], in_col[b]); diagonal blocks are mirrored from their lower triangle
-		const bool b_mirror = br == bc && i > j;
-		const size_t src = b_mirror? size_t(br * dc + i) + size_t(bc * dc + j) * ld : size_t(br * dc + j) + size_t(bc * dc + i) * ld;
-		values[in_off[b] + lane] = S[src];
-	} else {
-		const int64_t k = (b - n_in_blocks) * 64 + lane;
-		if(k < n)
-			r[k] = S[size_t(ld - 1) + size_t(k) * ld];
-	}
 }
 
 __global__ void schur_merge_flag_kernel(const int *p_from, int *p_to)
@@ -672,9 +657,24 @@ __global__ void schur_merge_flag_kernel(const int *p_from, int *p_to)
 // Decides how the reduced camera system is factored and, for the sparse choice, builds the inner solver: S becomes
 // a block matrix with one block column per camera whose structure is the block list every rank agreed on (or this
 // rank's own list on a single GPU), analyzed once by the same ordering / symbolic / scheduling code as a pose graph.
+static void schur_try_sparse_reduced(slampp_hip_solver &s, CSchurState &S);
+
 static void schur_setup_reduced(slampp_hip_solver &s, CSchurState &S)
 {
+	schur_try_sparse_reduced(s, S);
+	if(!S.b_reduced_sparse) { // the dense buffers are only needed now
+		S.d_S.Alloc(size_t(S.Npad) * S.Npad);
+		S.d_invdiag.Alloc(size_t(S.Npad / dense_NB) * dense_NB * dense_NB);
+		S.d_z.Alloc(S.Npad);
+		S.d_x.Alloc(S.Npad);
+		if(s.p_allreduce && !S.b_union_dense)
+			S.d_pack.Alloc(size_t(S.n_union) * S.DC * S.DC + size_t(S.N));
+	}
 	S.b_reduced_decided = true;
+}
+
+static void schur_try_sparse_reduced(slampp_hip_solver &s, CSchurState &S)
+{
 	S.b_reduced_sparse = false;
 	if(S.p_inner) {
 		S.p_inner->stream = 0;
@@ -743,11 +743,22 @@ static void schur_setup_reduced(slampp_hip_solver &s, CSchurState &S)
 	p_inner->Analyze_Sparse();
 	p_inner->b_analyzed = true;
 	S.n_in_blocks = n_list;
-	S.d_in_row.Upload(rows, s.stream);
-	S.d_in_col.Upload(cols, s.stream);
-	S.d_in_off.Upload(in_off, s.stream);
-	S.d_in_values.Alloc(size_t(n_list) * S.DC * S.DC);
-	S.d_in_rhs.Alloc(size_t(S.N));
+	// where this rank's own blocks go: the list is sorted by (col, row)
+	std::vector<int64_t> keys(n_list);
+	for(int64_t i = 0; i < n_list; ++ i)
+		keys[i] = int64_t(cols[i]) * nc + rows[i];
+	const size_t n_own = S.h_blk_row.size() - size_t(S.n_ablocks); // h_blk = [blocks of the gather | camera blocks of Lambda]
+	std::vector<int64_t> sb_dst(n_own), a_dst(S.n_ablocks);
+	for(size_t i = 0; i < S.h_blk_row.size(); ++ i) {
+		const int64_t key = int64_t(S.h_blk_col[i]) * nc + S.h_blk_row[i];
+		const size_t k = size_t(std::lower_bound(keys.begin(), keys.end(), key) - keys.begin());
+		if(k == keys.size() || keys[k] != key)
+			throw std::logic_error("reduced camera system: a block of this rank is missing from the agreed list");
+		((i < n_own)? sb_dst[i] : a_dst[i - n_own]) = in_off[k];
+	}
+	S.d_sb_dst.Upload(sb_dst, s.stream);
+	S.d_a_dst.Upload(a_dst, s.stream);
+	S.d_in_buf.Alloc(size_t(n_list) * S.DC * S.DC + size_t(S.N));
 	SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream)); // the host vectors live on this stack frame
 	S.b_reduced_sparse = true;
 }
@@ -758,15 +769,30 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 	hipStream_t st = s.stream;
 	const int ld = S.Npad, n = S.N;
 	const int64_t ubase = S.n_ablocks * DC * DC;
+	// first step (or a new all-reduce callback): the ranks agree on the blocks of S, then it is decided whether the
+	// reduced system is assembled into the dense buffer or straight into the inner sparse solver's values
+	if(s.p_allreduce && (S.p_union_fn != s.p_allreduce || S.p_union_context != s.p_allreduce_context))
+		schur_agree_on_union(s, S);
+	if(!S.b_reduced_decided)
+		schur_setup_reduced(s, S);
+	const bool b_sparse = S.b_reduced_sparse;
+	const size_t n_in_values = size_t(S.n_in_blocks) * DC * DC;
+	double *p_S = b_sparse? S.d_in_buf.p() : S.d_S.p();         // where the blocks go
+	double *p_r = b_sparse? S.d_in_buf.p() + n_in_values : 0;   // the reduced right-hand side, if it is a vector of its own
+	const int64_t *p_sb_dst = b_sparse? S.d_sb_dst.p() : 0, *p_a_dst = b_sparse? S.d_a_dst.p() : 0;
 	SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), st));
 
 	s.Phase_Begin("schur_init");
-	SLAMPP_HIP_CHECK(hipMemsetAsync(S.d_S.p(), 0, size_t(ld) * ld * sizeof(double), st));
-	dense_prepare_padding(S.d_S.p(), ld, n, st);
+	if(b_sparse)
+		SLAMPP_HIP_CHECK(hipMemsetAsync(p_S, 0, (n_in_values + size_t(n)) * sizeof(double), st));
+	else {
+		SLAMPP_HIP_CHECK(hipMemsetAsync(p_S, 0, size_t(ld) * ld * sizeof(double), st));
+		dense_prepare_padding(p_S, ld, n, st);
+	}
 	if(s.b_shard_primary) {
 		const int64_t n_work = std::max<int64_t>(S.n_ablocks * DC * DC, n);
 		hipLaunchKernelGGL((schur_scatter_A_kernel<DC>), dim3(unsigned((n_work + 255) / 256)), dim3(256), 0, st,
-			S.d_ptr.p(), S.d_brow.p(), S.nc, A, rhs, S.d_S.p(), ld, n);
+			S.d_ptr.p(), S.d_brow.p(), S.nc, A, rhs, p_S, ld, n, p_a_dst, p_r);
 	}
 	s.Phase_End();
 
@@ -784,59 +810,57 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 		if(S.n_entries > 256 * S.n_sblocks)
 			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 8>), dim3(unsigned(S.n_sblocks)), dim3(512), 0, st,
 				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
-				S.d_W.p(), S.d_S.p(), ld);
+				S.d_W.p(), p_S, ld, p_sb_dst);
 		else
 			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 1>), dim3(unsigned(S.n_sblocks)), dim3(64), 0, st,
 				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
-				S.d_W.p(), S.d_S.p(), ld);
+				S.d_W.p(), p_S, ld, p_sb_dst);
 	}
 	s.Phase_End();
 
 	s.Phase_Begin("schur_rhs");
 	hipLaunchKernelGGL((schur_rhs_kernel<DC, DP>), dim3(unsigned(S.nc)), dim3(64), 0, st,
-		S.d_cam_ptr.p(), S.d_cam_obs.p(), S.d_obs_pt.p(), n, S.d_W.p(), rhs, S.d_S.p(), ld);
+		S.d_cam_ptr.p(), S.d_cam_obs.p(), S.d_obs_pt.p(), n, S.d_W.p(), rhs, p_S, ld, p_r);
 	s.Phase_End();
 
 	if(s.p_allreduce) {
-		if(S.p_union_fn != s.p_allreduce || S.p_union_context != s.p_allreduce_context)
-			schur_agree_on_union(s, S); // first step with this callback
 		s.Phase_Begin("allreduce");
-		if(S.b_union_dense) {
+		if(b_sparse) {
+			// the packed values and the right-hand side are one buffer, and every rank built it from the same block list
+			if(s.p_allreduce(s.p_allreduce_context, p_S, n_in_values + size_t(n), (void*)st) != 0)
+				throw CDeviceError("all-reduce callback failed");
+		} else if(S.b_union_dense) {
 			// only the lower triangle and the rhs row carry data; the callback sums the whole buffer
-			if(s.p_allreduce(s.p_allreduce_context, S.d_S.p(), size_t(ld) * ld, (void*)st) != 0)
+			if(s.p_allreduce(s.p_allreduce_context, p_S, size_t(ld) * ld, (void*)st) != 0)
 				throw CDeviceError("all-reduce callback failed");
 		} else {
 			const unsigned n_grid = unsigned(S.n_union + (n + 63) / 64);
 			const size_t n_count = size_t(S.n_union) * DC * DC + size_t(n);
 			hipLaunchKernelGGL(schur_pack_kernel, dim3(n_grid), dim3(64), 0, st, S.d_un_row.p(), S.d_un_col.p(), S.n_union, DC,
-				S.d_S.p(), ld, n, S.d_pack.p(), 0);
+				p_S, ld, n, S.d_pack.p(), 0);
 			if(s.p_allreduce(s.p_allreduce_context, S.d_pack.p(), n_count, (void*)st) != 0)
 				throw CDeviceError("all-reduce callback failed");
 			hipLaunchKernelGGL(schur_pack_kernel, dim3(n_grid), dim3(64), 0, st, S.d_un_row.p(), S.d_un_col.p(), S.n_union, DC,
-				S.d_S.p(), ld, n, S.d_pack.p(), 1);
+				p_S, ld, n, S.d_pack.p(), 1);
 		}
 		s.Phase_End();
 	}
 
-	if(!S.b_reduced_decided)
-		schur_setup_reduced(s, S); // first step (after the ranks agreed on the block list, if there are ranks)
-	const double *p_dx = S.d_x.p();
-	if(S.b_reduced_sparse) {
+	const double *p_dx;
+	if(b_sparse) {
 		s.Phase_Begin("reduced_sparse");
-		hipLaunchKernelGGL(schur_reduced_pack_kernel, dim3(unsigned(S.n_in_blocks + (n + 63) / 64)), dim3(64), 0, st,
-			S.d_in_row.p(), S.d_in_col.p(), S.d_in_off.p(), S.n_in_blocks, DC, S.d_S.p(), ld, n, S.d_in_values.p(),
-			S.d_in_rhs.p());
-		S.p_inner->Enqueue_Sparse(S.d_in_values.p(), S.d_in_rhs.p(), true);
+		S.p_inner->Enqueue_Sparse(p_S, p_r, true); // p_r: the reduced right-hand side on entry, dx on return
 		hipLaunchKernelGGL(schur_merge_flag_kernel, dim3(1), dim3(1), 0, st, S.p_inner->d_flag.p(), s.d_flag.p());
 		s.Phase_End();
-		p_dx = S.d_in_rhs.p();
+		p_dx = p_r;
 	} else {
 		s.Phase_Begin("dense_chol");
-		dense_cholesky(S.d_S.p(), ld, n, S.d_invdiag.p(), s.d_flag.p(), st);
+		dense_cholesky(p_S, ld, n, S.d_invdiag.p(), s.d_flag.p(), st);
 		s.Phase_End();
 		s.Phase_Begin("dense_solve");
-		dense_backsolve(S.d_S.p(), ld, n, S.d_invdiag.p(), S.d_z.p(), S.d_x.p(), st);
+		dense_backsolve(p_S, ld, n, S.d_invdiag.p(), S.d_z.p(), S.d_x.p(), st);
 		s.Phase_End();
+		p_dx = S.d_x.p();
 	}
 
 	s.Phase_Begin("backsubst");
