@@ -227,3 +227,16 @@ def test_sparse_reduced_system_other_block_sizes(cam_dim, pt_dim):
         assert rel_inf(eta, x_ref) < TOL
         out[sparse] = eta
     assert rel_inf(out[1], out[0]) < 1e-11
+
+
+def test_many_cameras_sparse_reduced_system():
+    """10 000 cameras: the dense reduced system would be a 60 000 x 60 000 buffer (28.8 GB); the sparse one is a few
+    megabytes.  Also the comparison-sort branch of the contribution lists (camera-pair key space above 2^26)."""
+    lam = synth.ba(10000, 40000, k=4, mode="band", seed=51)
+    solver = CLinearSolver_Schur_HIP(profile=1)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta)
+    assert "reduced_sparse" in solver.profile()
+    assert solver.stats()["device_bytes"] < 1 << 30
+    resid = np.abs(lam.to_scipy() @ eta - lam.rhs).max() / np.abs(lam.rhs).max()
+    assert resid < 1e-10
