@@ -347,6 +347,8 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1):
     solver.SymbolicDecomposition_Blocky(lam)
     analyze_ms = (time.perf_counter() - t0) * 1e3
     if dist is not None:
+        solver.set_option("shard_rank", rank)
+        solver.set_option("shard_world", world)
         solver.set_allreduce(make_allreduce(dist, torch, dev))
     st = solver.stats()
     vals = torch.from_numpy(lam.values).to(dev)

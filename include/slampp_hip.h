@@ -74,6 +74,9 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
  * one dense matrix on the matrix cores; default: 24, or 16 / 36 where a model of the dependent launch chain clearly
  * prefers that; setting the option fixes the threshold; 0 = off), "dense_top_max_dim" (cap on its dimension, default 12288),
  * "profile" (0/1, see slampp_hip_get_profile), "shard_primary" (multi-GPU BA: this rank adds A and eta_x),
+ * "shard_rank" / "shard_world" (multi-GPU BA, optional: who this rank is among the ranks behind the all-reduce
+ * callback; lets them exchange their block lists, which scales with the nonzero blocks of S, instead of an indicator
+ * over all camera pairs, which is limited to 16384 cameras),
  * "dense_top_tiles" (sparse path: the dense top is factored tile column by tile column (0), or by the levels of its
  * tile elimination tree, touching only structurally nonzero 64x64 tiles (1); -1 = the latter when it shortens the
  * chain of dependent launches, default),
@@ -168,8 +171,9 @@ int slampp_hip_assemble_device_async(slampp_hip_assembly *p_assembly, const doub
  * on stream p_hip_stream.  Return 0 on success.  NULL callback = single GPU.
  * What travels is not the dense n x n buffer but the 6x6 (7x7, 3x3) blocks of S that are nonzero on at
  * least one rank, plus the right-hand side: on the first step with a new callback the ranks agree on that
- * set by summing an indicator over the lower triangle of the camera-block grid through the same
- * callback (one extra, synchronous call), so every rank must register its callback before the same step. */
+ * set through the same callback (one or two extra, synchronous calls: concatenated block lists when
+ * "shard_rank" / "shard_world" are set, else an indicator over the lower triangle of the camera-block grid),
+ * so every rank must register its callback before the same step. */
 typedef int (*slampp_hip_allreduce_fn)(void *p_context, double *p_dev, size_t n_count, void *p_hip_stream);
 int slampp_hip_set_allreduce(slampp_hip_solver *p_solver, slampp_hip_allreduce_fn p_fn, void *p_context);
 

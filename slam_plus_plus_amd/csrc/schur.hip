@@ -602,9 +602,10 @@ schur_pack_kernel(const int32_t *__restrict__ un_row, const int32_t *__restrict_
 		*p_p = *p_s;
 }
 
-// Agrees with the other ranks on the set of blocks to exchange: every rank marks its own nonzero blocks in an
-// indicator over the lower triangle of the camera-block grid, the indicators are summed through the caller's
-// all-reduce, and every rank derives the same ordered list from the result.  One-time, synchronous.
+// Agrees with the other ranks on the set of blocks to exchange, through the caller's sum all-reduce alone: with
+// "shard_rank" / "shard_world" set, the ranks concatenate their block lists (each writes into its own slot of a
+// zeroed buffer); without, every rank marks its blocks in an indicator over the lower triangle of the camera-block
+// grid.  Either way every rank derives the same ordered list from the sum.  One-time, synchronous.
 static void schur_agree_on_union(slampp_hip_solver &s, CSchurState &S)
 {
 	hipStream_t st = s.stream;
@@ -614,29 +615,82 @@ static void schur_agree_on_union(slampp_hip_solver &s, CSchurState &S)
 	S.h_un_row.clear();
 	S.h_un_col.clear();
 	S.b_reduced_decided = false; // the block list the sparse reduced system is built from may change
-	S.b_union_dense = S.nc > 16384; // the indicator would exceed a gigabyte
-	if(S.b_union_dense)
-		return;
-	const int64_t nc = S.nc, n_tri = nc * (nc + 1) / 2;
-	std::vector<double> ind(size_t(n_tri), 0.0);
-	for(size_t i = 0; i < S.h_blk_row.size(); ++ i) {
-		const int64_t r = S.h_blk_row[i], c = S.h_blk_col[i];
-		ind[size_t(c * nc - c * (c - 1) / 2 + (r - c))] = 1.0;
-	}
-	CDevArray<double> d_ind;
-	d_ind.Alloc(size_t(n_tri));
-	SLAMPP_HIP_CHECK(hipMemcpyAsync(d_ind.p(), ind.data(), size_t(n_tri) * sizeof(double), hipMemcpyHostToDevice, st));
-	if(s.p_allreduce(s.p_allreduce_context, d_ind.p(), size_t(n_tri), (void*)st) != 0)
-		throw CDeviceError("all-reduce callback failed");
-	SLAMPP_HIP_CHECK(hipMemcpyAsync(ind.data(), d_ind.p(), size_t(n_tri) * sizeof(double), hipMemcpyDeviceToHost, st));
-	SLAMPP_HIP_CHECK(hipStreamSynchronize(st));
+	const int64_t nc = S.nc;
 	std::vector<int32_t> un_row, un_col;
-	size_t k = 0;
-	for(int64_t c = 0; c < nc; ++ c) {
-		for(int64_t r = c; r < nc; ++ r, ++ k) {
-			if(ind[k] > 0.5) {
-				un_row.push_back(int32_t(r));
-				un_col.push_back(int32_t(c));
+	// this rank's blocks as sorted, unique keys col * nc + row
+	std::vector<int64_t> own(S.h_blk_row.size());
+	for(size_t i = 0; i < own.size(); ++ i)
+		own[i] = int64_t(S.h_blk_col[i]) * nc + S.h_blk_row[i];
+	std::sort(own.begin(), own.end());
+	own.erase(std::unique(own.begin(), own.end()), own.end());
+	const int n_world = s.n_shard_world, n_rank = s.n_shard_rank;
+	S.b_union_dense = false;
+	if(n_world > 0 && n_rank >= 0 && n_rank < n_world) {
+		// the caller told us who we are: every rank writes its list into its own slot of a zeroed buffer and the sum
+		// is the concatenation -- the exchange grows with the number of nonzero blocks, not with nc^2
+		std::vector<double> len(size_t(n_world), 0.0);
+		len[n_rank] = double(own.size());
+		CDevArray<double> d_len;
+		d_len.Alloc(size_t(n_world));
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(d_len.p(), len.data(), len.size() * sizeof(double), hipMemcpyHostToDevice, st));
+		if(s.p_allreduce(s.p_allreduce_context, d_len.p(), len.size(), (void*)st) != 0)
+			throw CDeviceError("all-reduce callback failed");
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(len.data(), d_len.p(), len.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+		SLAMPP_HIP_CHECK(hipStreamSynchronize(st));
+		size_t n_total = 0, n_before = 0;
+		for(int r = 0; r < n_world; ++ r) {
+			if(r == n_rank)
+				n_before = n_total;
+			n_total += size_t(len[r]);
+		}
+		if(size_t(len[n_rank]) != own.size())
+			throw std::invalid_argument("shard_rank / shard_world do not match the ranks behind the all-reduce callback");
+		std::vector<double> all(n_total, 0.0);
+		for(size_t i = 0; i < own.size(); ++ i)
+			all[n_before + i] = double(own[i]); // exact: keys are below 2^53
+		CDevArray<double> d_all;
+		d_all.Alloc(n_total);
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(d_all.p(), all.data(), n_total * sizeof(double), hipMemcpyHostToDevice, st));
+		if(s.p_allreduce(s.p_allreduce_context, d_all.p(), n_total, (void*)st) != 0)
+			throw CDeviceError("all-reduce callback failed");
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(all.data(), d_all.p(), n_total * sizeof(double), hipMemcpyDeviceToHost, st));
+		SLAMPP_HIP_CHECK(hipStreamSynchronize(st));
+		std::vector<int64_t> keys(n_total);
+		for(size_t i = 0; i < n_total; ++ i)
+			keys[i] = int64_t(all[i]);
+		std::sort(keys.begin(), keys.end());
+		keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+		for(size_t i = 0; i < keys.size(); ++ i) {
+			if(keys[i] < 0 || keys[i] >= nc * nc || keys[i] % nc < keys[i] / nc)
+				throw std::invalid_argument("block-list exchange returned an impossible key: is the callback a sum over all ranks?");
+			un_col.push_back(int32_t(keys[i] / nc));
+			un_row.push_back(int32_t(keys[i] % nc));
+		}
+	} else {
+		// ranks unknown: an indicator over the lower triangle of the camera-block grid, summed
+		S.b_union_dense = S.nc > 16384; // the indicator would exceed a gigabyte
+		if(S.b_union_dense)
+			return;
+		const int64_t n_tri = nc * (nc + 1) / 2;
+		std::vector<double> ind(size_t(n_tri), 0.0);
+		for(size_t i = 0; i < own.size(); ++ i) {
+			const int64_t c = own[i] / nc, r = own[i] % nc;
+			ind[size_t(c * nc - c * (c - 1) / 2 + (r - c))] = 1.0;
+		}
+		CDevArray<double> d_ind;
+		d_ind.Alloc(size_t(n_tri));
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(d_ind.p(), ind.data(), size_t(n_tri) * sizeof(double), hipMemcpyHostToDevice, st));
+		if(s.p_allreduce(s.p_allreduce_context, d_ind.p(), size_t(n_tri), (void*)st) != 0)
+			throw CDeviceError("all-reduce callback failed");
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(ind.data(), d_ind.p(), size_t(n_tri) * sizeof(double), hipMemcpyDeviceToHost, st));
+		SLAMPP_HIP_CHECK(hipStreamSynchronize(st));
+		size_t k = 0;
+		for(int64_t c = 0; c < nc; ++ c) {
+			for(int64_t r = c; r < nc; ++ r, ++ k) {
+				if(ind[k] > 0.5) {
+					un_row.push_back(int32_t(r));
+					un_col.push_back(int32_t(c));
+				}
 			}
 		}
 	}

@@ -101,8 +101,8 @@ def test_full_size_c4_residual_and_linearity():
     assert rel_inf(eta2, 4.0 * eta) < TOL
 
 
-@pytest.mark.parametrize("sparse", [0, 1])
-def test_two_landmark_shards_with_summing_callback(sparse):
+@pytest.mark.parametrize("sparse,know_ranks", [(0, False), (1, False), (1, True), (0, True)])
+def test_two_landmark_shards_with_summing_callback(sparse, know_ranks):
     """Two ranks of the landmark-sharded path in one process (two solver handles on the same GPU, one thread each):
     the all-reduce callback is a barrier + sum, so the whole multi-GPU code path runs -- the agreement on the union
     of nonzero S blocks, the packed exchange, redundant dense solves -- and must reproduce the unsharded solution."""
@@ -149,6 +149,9 @@ def test_two_landmark_shards_with_summing_callback(sparse):
         try:
             shard, sl = sharding.landmark_shard(lam, rank, world)
             solver = CLinearSolver_Schur_HIP(schur_sparse=sparse)
+            if know_ranks:                                # block lists are concatenated instead of an indicator summed
+                solver.set_option("shard_rank", rank)
+                solver.set_option("shard_world", world)
             solver.set_allreduce(make_fn(rank))
             eta = shard.rhs.copy()
             assert solver.Solve_PosDef(shard, eta)
@@ -173,7 +176,11 @@ def test_two_landmark_shards_with_summing_callback(sparse):
     assert rel_inf(x, x_ref) < TOL
     # what travelled: first the indicator over the camera-block triangle, then packed blocks -- never the dense square
     nc, N = lam.n_matrix_cut, n_x
-    assert counts[0] == nc * (nc + 1) // 2
+    if know_ranks:
+        assert counts[0] == world and counts[1] <= world * (nc * (nc + 1) // 2)   # lengths, then the concatenated lists
+        counts = counts[1:]
+    else:
+        assert counts[0] == nc * (nc + 1) // 2
     assert all(c < (N + 64) ** 2 // 2 for c in counts[1:]) and (counts[1] - N) % 36 == 0
 
 
