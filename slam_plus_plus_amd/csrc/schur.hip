@@ -403,9 +403,11 @@ __global__ void schur_obs_W_kernel(int64_t n_obs, int64_t ubase, const int32_t *
 // instructions as it can: the entry indices are fetched 64 at a time (one coalesced load, then
 // v_readlane), the two operand blocks of an entry with ONE load (lanes 0..17 U_b, lanes 18..35 W_a,
 // both contiguous) into LDS, eight entries per batch; a batch is then one small GEMM on the matrix cores
-// (v_mfma_f64_16x16x4: S block += [U_1 .. U_8] [W_1 .. W_8]^T, K = 24).  The kernel is bound by HBM fetch efficiency
-// (144-byte operand blocks straddle 64-byte sectors: about twice the algorithmic bytes are fetched), not by the
-// arithmetic: FMA and MFMA versions run equally fast, and giving each XCD a contiguous range of blocks did not help.
+// (v_mfma_f64_16x16x4: S block += [U_1 .. U_8] [W_1 .. W_8]^T, K = 24).  All eight requests of a batch are issued
+// before the first LDS store: written as "load, store" per entry the compiler serialized them, eight memory
+// latencies per batch (0.71 -> 0.50 ms at C4 once hoisted).  Measured and not kept: batches of 16 (slower), an
+// XCD-contiguous block order, camera-major copies of U and W (gather 4 % faster, the scattered writes of the copy
+// cost 0.24 ms).  144-byte operand blocks straddle 64-byte sectors: about 1.9x the algorithmic bytes are fetched.
 template <int DC, int DP, int W>
 __global__ void __launch_bounds__(64 * W)
 schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *sb_row, const int32_t *sb_col,
@@ -430,6 +432,7 @@ schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *s
 		const int64_t my_u = (my < e1)? ent_uoff[my] : 0;
 		const int n_chunk = int(min(int64_t(64), (e1 - base + W - 1) / W));
 		for(int i = 0; i < n_chunk; i += BATCH) {
+			double v[BATCH]; // all requests of the batch first, then the LDS stores: one memory latency per batch, not eight
 			#pragma unroll
 			for(int j = 0; j < BATCH; ++ j) {
 				const int idx = min(i + j, n_chunk - 1); // the tail re-reads the last entry, its product is skipped below
@@ -437,8 +440,12 @@ schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *s
 				const int64_t u = (int64_t(__builtin_amdgcn_readlane(int(my_u >> 32), idx)) << 32) |
 					uint32_t(__builtin_amdgcn_readlane(int(my_u), idx));
 				const double *src = (lane < BLK)? A + u + lane : W_ + int64_t(a) * BLK + (lane - BLK);
+				v[j] = b_loader? *src : 0.0;
+			}
+			#pragma unroll
+			for(int j = 0; j < BATCH; ++ j) {
 				if(b_loader)
-					s_ops[wave][j][lane] = *src;
+					s_ops[wave][j][lane] = v[j];
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
