@@ -717,9 +717,14 @@ backward_stage_kernel(TDevPlan p, const double *L, const double *Linv, double *w
 {
 	const int lane = threadIdx.x, g = lane >> 3, q = lane & 7;
 	const int task = task_begin + blockIdx.x;
-	const int64_t c_begin = p.task_ptr[task];
-	for(int64_t c = p.task_ptr[task + 1]; c > c_begin; -- c) {
-		const TColDesc cd = p.cols[c - 1];
+	const int64_t c_begin = p.task_ptr[task], c_end = p.task_ptr[task + 1];
+	if(c_end <= c_begin)
+		return;
+	TColDesc cd_next = p.cols[c_end - 1];
+	for(int64_t c = c_end; c > c_begin; -- c) {
+		const TColDesc cd = cd_next;
+		if(c - 1 > c_begin)
+			cd_next = p.cols[c - 2]; // index data does not depend on the numbers: fetch it a column ahead
 		const int dj = D? D : cd.dj;
 		const int qq = (q < dj)? q : 0;
 		double acc = 0;
