@@ -68,7 +68,8 @@ void slampp_hip_destroy(slampp_hip_solver *p_solver);
 int slampp_hip_free_memory(slampp_hip_solver *p_solver);
 const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
 
-/* tuning knobs: "leaf_size" (nested-dissection leaf, default 4), "subtree_size" (max columns one
+/* tuning knobs: "leaf_size" (nested-dissection leaf, default 4), "nd_balance" (percent of the vertices a separator
+ * must leave on either side, default 15), "subtree_size" (max columns one
  * wave eliminates sequentially, default 8), "dense_nb" (dense panel width, default 64),
  * "dense_top_nb" (sparse path: block columns with at least this many blocks, and their ancestors, are factored as
  * one dense matrix on the matrix cores; default: 24, or 16 / 36 where a model of the dependent launch chain clearly

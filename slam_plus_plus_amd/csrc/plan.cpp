@@ -32,6 +32,7 @@ class CNestedDissection {
 	const std::vector<int64_t> &m_ptr;
 	const std::vector<int32_t> &m_adj;
 	const int m_leaf;
+	const int m_n_balance_pct; // a separator must leave at least this share of the vertices on either side
 	std::vector<int32_t> m_set;    // id of the subset a vertex currently belongs to
 	std::vector<int32_t> m_level;  // BFS level (valid for the subset being processed)
 	std::vector<int32_t> &m_out;   // perm[new] = old; every call fills its own range
@@ -40,8 +41,9 @@ class CNestedDissection {
 
 public:
 	CNestedDissection(int32_t n, const std::vector<int64_t> &ptr, const std::vector<int32_t> &adj,
-		int leaf, std::vector<int32_t> &out)
-		:m_n(n), m_ptr(ptr), m_adj(adj), m_leaf(std::max(leaf, 1)), m_set(n, -1), m_level(n, -1),
+		int leaf, int n_balance_pct, std::vector<int32_t> &out)
+		:m_n(n), m_ptr(ptr), m_adj(adj), m_leaf(std::max(leaf, 1)), m_n_balance_pct(std::min(std::max(n_balance_pct, 1), 49)),
+		m_set(n, -1), m_level(n, -1),
 		m_out(out), m_next_id(0)
 	{
 		m_out.assign(n, -1);
@@ -192,7 +194,7 @@ private:
 			int64_t best_size = INT64_MAX, best_imbalance = INT64_MAX;
 			for(int32_t l = 0; l < n_levels; ++ l) {
 				const int64_t above = n_total - below - count[l];
-				if(l > 0 && l < n_levels - 1 && below * 4 >= n_total && above * 4 >= n_total) {
+				if(l > 0 && l < n_levels - 1 && below * 100 >= n_total * m_n_balance_pct && above * 100 >= n_total * m_n_balance_pct) {
 					const int64_t imb = std::abs(below - above);
 					if(count[l] < best_size || (count[l] == best_size && imb < best_imbalance)) {
 						best_size = count[l];
@@ -252,9 +254,9 @@ private:
 } // anonymous namespace
 
 void nested_dissection(int32_t n, const std::vector<int64_t> &adj_ptr, const std::vector<int32_t> &adj,
-	int leaf_size, std::vector<int32_t> &perm)
+	int leaf_size, std::vector<int32_t> &perm, int n_balance_pct)
 {
-	CNestedDissection nd(n, adj_ptr, adj, leaf_size, perm);
+	CNestedDissection nd(n, adj_ptr, adj, leaf_size, n_balance_pct, perm);
 	nd.Run();
 }
 
@@ -354,26 +356,37 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 	std::string s_err = build_plan_once(n_bcols, cumsum, bcol_ptr, brow, opt, P);
 	if(!s_err.empty() || !opt.dense_top_auto || !P.dense_dim)
 		return s_err;
-	// a dense top: where the line between block-by-block elimination and the dense factorization is best drawn
-	// depends on the graph (Manhattan-like: lower, sphere-like: higher); try two more thresholds
-	double f_best = plan_chain_estimate_us(P);
+	// A dense top: a 2-D-like graph.  Where the line between block-by-block elimination and the dense factorization
+	// is best drawn depends on the graph (Manhattan-like: lower, sphere-like: higher), and its separators are long
+	// enough that balanced halves beat the smallest separator (the opposite of pose chains, whose separators are one
+	// or two vertices and for which the default of 15 % is tuned).  Rebuild with 25 % as the base, then try a lower
+	// and a higher threshold; keep what the chain model clearly prefers.
 	const bool b_print = getenv("SLAMPP_HIP_PLAN_TIMING") != 0;
-	if(b_print)
-		fprintf(stderr, "[plan] dense_top_nb %d: dense dim %d, chain estimate %.0f us\n", opt.dense_top_nb, P.dense_dim, f_best);
-	const int p_candidates[] = {opt.dense_top_nb * 2 / 3, opt.dense_top_nb * 3 / 2};
-	for(int i = 0; i < 2; ++ i) {
+	double f_best = plan_chain_estimate_us(P);
+	if(b_print) {
+		fprintf(stderr, "[plan] dense_top_nb %d, balance %d %%: dense dim %d, chain estimate %.0f us\n", opt.dense_top_nb,
+			opt.nd_balance_pct, P.dense_dim, f_best);
+	}
+	const int n_balanced = std::max(opt.nd_balance_pct, 25);
+	const int p_candidates[][2] = {{opt.dense_top_nb, n_balanced}, {opt.dense_top_nb * 2 / 3, n_balanced},
+		{opt.dense_top_nb * 3 / 2, n_balanced}};
+	for(int i = (n_balanced == opt.nd_balance_pct)? 1 : 0; i < 3; ++ i) {
 		PlanOptions t_opt = opt;
-		t_opt.dense_top_nb = p_candidates[i];
+		t_opt.dense_top_nb = p_candidates[i][0];
+		t_opt.nd_balance_pct = p_candidates[i][1];
 		Plan t_plan;
 		if(t_opt.dense_top_nb < 4 || !build_plan_once(n_bcols, cumsum, bcol_ptr, brow, t_opt, t_plan).empty())
 			continue;
 		const double f_us = plan_chain_estimate_us(t_plan);
-		if(b_print)
-			fprintf(stderr, "[plan] dense_top_nb %d: dense dim %d, chain estimate %.0f us\n", t_opt.dense_top_nb, t_plan.dense_dim, f_us);
-		// a clear win only: the model is rough, and rougher for the heavy columns a higher threshold leaves to the
-		// block-by-block kernels
-		if(f_us < f_best * (i? 0.85 : 0.95)) {
-			f_best = f_us;
+		if(b_print) {
+			fprintf(stderr, "[plan] dense_top_nb %d, balance %d %%: dense dim %d, chain estimate %.0f us\n", t_opt.dense_top_nb,
+				t_opt.nd_balance_pct, t_plan.dense_dim, f_us);
+		}
+		// the balanced base replaces the first plan unless it is clearly worse; the other thresholds must be clearly
+		// better (the model is rough, and rougher for the heavy columns a higher threshold leaves to the block kernels)
+		const double f_margin = (i == 0)? 1.10 : (i == 2)? 0.85 : 0.95;
+		if(t_plan.dense_dim && f_us < f_best * f_margin) {
+			f_best = (i == 0)? f_us : std::min(f_best, f_us);
 			t_plan.order_ms += P.order_ms;
 			t_plan.symbolic_ms += P.symbolic_ms;
 			std::swap(P, t_plan);
@@ -430,7 +443,7 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 	}
 
 	// ---- ordering ----
-	nested_dissection(n, gptr, gadj, opt.leaf_size, P.perm);
+	nested_dissection(n, gptr, gadj, opt.leaf_size, P.perm, opt.nd_balance_pct);
 	if(int32_t(P.perm.size()) != n)
 		return "internal error: ordering lost vertices";
 	P.pinv.assign(n, -1);

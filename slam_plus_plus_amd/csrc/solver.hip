@@ -457,6 +457,8 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 		p_solver->opt.leaf_size = int(n_value);
 	else if(s == "subtree_size" && n_value >= 1)
 		p_solver->opt.subtree_size = int(n_value);
+	else if(s == "nd_balance" && n_value >= 1 && n_value <= 49)
+		p_solver->opt.nd_balance_pct = int(n_value);
 	else if(s == "dense_nb" && (n_value == 32 || n_value == 64 || n_value == 128))
 		p_solver->n_dense_nb = int(n_value);
 	else if(s == "dense_top_nb" && n_value >= 0) {
