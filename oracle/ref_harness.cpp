@@ -37,6 +37,10 @@
  *       robust weight at that linearization point.  <prefix>.lambda.bin (SPPLAM01, rhs = eta),
  *       <prefix>.edges.bin ("SPPASM01": int64 n_verts, n_edges, d, rd; int64 v0[], v1[]; double J0[], J1[]
  *       (rd x d column-major per edge), SigmaInv[] (rd x rd), err[] (rd), weight[]; unary factor d x d, unary error d)
+ *   ref_harness dump_mm <problem> <out.mtx> <out.bla>
+ *       writes Lambda with the reference's Save_MatrixMarket / Save_BlockLayout, as its -dsm option does
+ *   ref_harness load_mm <in.mtx> <in.bla> <problem>
+ *       reads the pair with the reference's Load_MatrixMarket and compares the upper triangle with <problem>
  *   ref_harness schur_dump <problem> <out_prefix>
  *       replays LinearSolver_Schur.h:1687-1886 with public CUberBlockMatrix calls and dumps
  *       S (dense, col-major), reduced rhs, dx, dl, x as raw doubles
@@ -523,10 +527,58 @@ static int Main_LambdaDump(int argc, char **argv)
 	return 2;
 }
 
+/* ref_harness dump_mm <problem> <out.mtx> <out.bla>: the system matrix written by the reference's own
+ * CUberBlockMatrix::Save_MatrixMarket with the arguments its nonlinear solvers use for -dsm
+ * (include/slam/NonlinearSolver_Lambda.h:325-326) */
+static int Main_DumpMM(int argc, char **argv)
+{
+	if(argc < 5) return 2;
+	TProblem p;
+	if(!Read_Problem(argv[2], p)) return 3;
+	CUberBlockMatrix lambda;
+	Build_Lambda(p, lambda);
+	const bool b_ok = lambda.Save_MatrixMarket(argv[3], argv[4], "lambda matrix for SLAM problem",
+		"matrix coordinate real symmetric", 'U');
+	printf("{\"ok\": %s}\n", b_ok? "true" : "false");
+	return b_ok? 0 : 1;
+}
+
+/* ref_harness load_mm <in.mtx> <in.bla> <problem>: reads the pair with the reference's own
+ * CUberBlockMatrix::Load_MatrixMarket (BlockMatrix.h:3814) and compares the upper triangle with <problem> */
+static int Main_LoadMM(int argc, char **argv)
+{
+	if(argc < 5) return 2;
+	TProblem p;
+	if(!Read_Problem(argv[4], p)) return 3;
+	CUberBlockMatrix lambda, loaded;
+	Build_Lambda(p, lambda);
+	if(!loaded.Load_MatrixMarket(argv[2], argv[3])) {
+		printf("{\"ok\": false}\n");
+		return 1;
+	}
+	Eigen::MatrixXd A, B;
+	lambda.Convert_to_Dense(A);
+	loaded.Convert_to_Dense(B);
+	double f_err = -1;
+	if(A.rows() == B.rows() && A.cols() == B.cols()) {
+		f_err = 0;
+		for(int c = 0; c < A.cols(); ++ c)
+			for(int r = 0; r <= c; ++ r)
+				f_err = std::max(f_err, fabs(A(r, c) - B(r, c)));
+	}
+	printf("{\"ok\": true, \"block_cols\": %ld, \"blocks\": %ld, \"max_abs_diff_upper\": %.3g, \"max_abs\": %.3g}\n",
+		(long)loaded.n_BlockColumn_Num(), (long)loaded.n_Block_Num(), f_err, A.cwiseAbs().maxCoeff());
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	if(argc >= 2) {
 		try {
+			if(!strcmp(argv[1], "load_mm"))
+				return Main_LoadMM(argc, argv);
+			if(!strcmp(argv[1], "dump_mm"))
+				return Main_DumpMM(argc, argv);
 			if(!strcmp(argv[1], "solve"))
 				return Main_Solve(argc, argv);
 			if(!strcmp(argv[1], "cholmod_phases"))

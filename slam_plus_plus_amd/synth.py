@@ -14,6 +14,7 @@ block column, every block dense column-major.
 from __future__ import annotations
 
 import dataclasses
+import os
 import struct
 from typing import Optional
 
@@ -397,3 +398,92 @@ def random_edge_set(dims: np.ndarray, v0: np.ndarray, v1: np.ndarray, rd: int, s
                    0.05 * rng.standard_normal((ne, rd)),
                    (0.5 + 0.5 * rng.random(ne)) if robust else None,
                    anchor, np.eye(d_a) * 100.0, np.zeros(d_a))
+
+
+# ------------------------------------------------------------------------------------------------
+# interop: the reference's matrix dumps (-dsm: MatrixMarket values + .bla block layout)
+# ------------------------------------------------------------------------------------------------
+
+def load_matrix_market(mtx_path: str, bla_path: str, rhs: Optional[np.ndarray] = None,
+                       n_matrix_cut: int = 0) -> BlockSystem:
+    """Reads a system matrix dumped by the reference (``CUberBlockMatrix::Save_MatrixMarket`` +
+    ``Save_BlockLayout``, /root/reference/src/slam/BlockMatrix.cpp:12063-12199; what ``-dsm`` and
+    ``slam_schur_orderings`` exchange).  The .bla layout is four lines: ``rows x cols (nnz)``, ``brows x bcols
+    (nblocks)``, the block-row and the block-column cumulative sums.  The .mtx holds every scalar of every stored
+    block (zeros included); symmetric dumps hold the upper triangle written as MatrixMarket *lower* entries
+    (``col row value``), general dumps all entries.  Only the upper block triangle is kept, and the diagonal blocks
+    are completed by symmetry.  ``rhs`` (not part of a dump) defaults to zeros."""
+    with open(bla_path) as f:
+        lines = [ln for ln in f.read().splitlines() if ln.strip()]
+    rows_cs = np.array(lines[2].split(), dtype=np.int64)
+    cols_cs = np.array(lines[3].split(), dtype=np.int64)
+    if not np.array_equal(rows_cs, cols_cs) or rows_cs[0] != 0:
+        raise ValueError("not a square symmetric block layout")
+    cumsum = cols_cs
+    n = int(cumsum.shape[0]) - 1
+    with open(mtx_path) as f:
+        header = f.readline()
+        if not header.startswith("%%MatrixMarket matrix coordinate real"):
+            raise ValueError("not a real coordinate MatrixMarket file")
+        b_symmetric = "symmetric" in header
+        line = f.readline()
+        while line.startswith("%"):
+            line = f.readline()
+        n_rows, n_cols, n_nnz = (int(t) for t in line.split())
+        data = np.loadtxt(f, dtype=np.float64, ndmin=2) if n_nnz else np.zeros((0, 3))
+    if n_rows != cumsum[-1] or n_cols != cumsum[-1] or data.shape[0] != n_nnz:
+        raise ValueError("matrix and layout disagree")
+    i = data[:, 0].astype(np.int64) - 1
+    j = data[:, 1].astype(np.int64) - 1
+    v = data[:, 2]
+    if b_symmetric:      # stored as (larger index, smaller index): the upper entry is (j, i)
+        i, j = np.minimum(i, j), np.maximum(i, j)
+    else:
+        keep = i <= j
+        i, j, v = i[keep], j[keep], v[keep]
+    bi = np.searchsorted(cumsum, i, side="right") - 1
+    bj = np.searchsorted(cumsum, j, side="right") - 1
+    key = np.unique(bj * n + bi)
+    bcols, brows = key // n, key % n
+    bcol_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(bcol_ptr, bcols + 1, 1)
+    bcol_ptr = np.cumsum(bcol_ptr)
+    dims = np.diff(cumsum)
+    sizes = dims[brows] * dims[bcols]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    values = np.zeros(int(offs[-1]))
+    k = np.searchsorted(key, bj * n + bi)                 # block of every scalar
+    pos = offs[k] + (i - cumsum[bi]) + (j - cumsum[bj]) * dims[bi]
+    values[pos] = v
+    diag = bi == bj                                       # mirror the diagonal blocks' upper triangle
+    values[offs[k[diag]] + (j[diag] - cumsum[bj[diag]]) + (i[diag] - cumsum[bi[diag]]) * dims[bi[diag]]] = v[diag]
+    return BlockSystem(cumsum=cumsum, bcol_ptr=bcol_ptr, brow_idx=brows.astype(np.int32), values=values,
+                       rhs=np.zeros(int(cumsum[-1])) if rhs is None else np.asarray(rhs, dtype=np.float64),
+                       n_matrix_cut=int(n_matrix_cut), name=os.path.basename(mtx_path))
+
+
+def save_matrix_market(lam: BlockSystem, mtx_path: str, bla_path: str) -> None:
+    """Writes the pair of files the reference's ``Load_MatrixMarket`` / ``Load_BlockLayout`` read: the upper triangle as
+    a symmetric MatrixMarket matrix (entries ``col row value``) and the four-line block layout."""
+    off = lam.block_value_offsets()
+    dims = np.diff(lam.cumsum)
+    col = np.repeat(np.arange(lam.n_bcols), np.diff(lam.bcol_ptr))
+    rows, cols, vals = [], [], []
+    for k in range(lam.n_blocks):
+        r, c = int(lam.brow_idx[k]), int(col[k])
+        blk = lam.values[off[k]:off[k + 1]].reshape(dims[c], dims[r]).T      # [row, col]
+        ii, jj = np.meshgrid(np.arange(dims[r]), np.arange(dims[c]), indexing="ij")
+        gi, gj = lam.cumsum[r] + ii, lam.cumsum[c] + jj
+        keep = gj >= gi
+        rows.append(gi[keep]); cols.append(gj[keep]); vals.append(blk[keep])
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    n = int(lam.cumsum[-1])
+    with open(bla_path, "w") as f:
+        f.write(f"{n} x {n} ({int(off[-1])})\n{lam.n_bcols} x {lam.n_bcols} ({lam.n_blocks})\n")
+        f.write(" ".join(str(int(x)) for x in lam.cumsum) + "\n")
+        f.write(" ".join(str(int(x)) for x in lam.cumsum) + "\n")
+    with open(mtx_path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n% block matrix dump (upper triangle)\n")
+        f.write(f"{n} {n} {vals.shape[0]}\n")
+        for a, b, x in zip(cols, rows, vals):
+            f.write(f"{int(a) + 1} {int(b) + 1} {x:.17g}\n")

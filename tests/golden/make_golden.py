@@ -18,6 +18,8 @@ reference's own solver classes on those inputs:
                                        weight at the initial point (inputs), and the Lambda / eta that
                                        CNonlinearSolver_Lambda handed to its linear solver (outputs), plus
                                        the CHOLMOD solution of that system
+    dump_*.mtx / .bla / .npz         : a system written by the reference's Save_MatrixMarket / Save_BlockLayout (the format of
+                                       its -dsm option), next to the arrays it was written from
 Fixtures are data only; no reference source text is stored.
 """
 import json
@@ -98,6 +100,18 @@ def main():
         np.savez_compressed(path, **rec)
         print(f"{name}: verts={lam.n_bcols} edges={es.n_edges} flipped={int((es.v0 > es.v1).sum())} "
               f"-> {os.path.getsize(path) / 1024:.1f} KiB")
+    # the reference's own dump format (-dsm): written by CUberBlockMatrix::Save_MatrixMarket / Save_BlockLayout
+    for name, make in (("dump_chain6_n12", lambda: synth.pose_chain(n=12, d=6, loop_every=5, loop_min=2, loop_max=4, seed=3)),
+                       ("dump_ba_5x40", lambda: synth.ba(5, 40, k=3, seed=4))):
+        lam = make()
+        with tempfile.TemporaryDirectory() as td:
+            prob = os.path.join(td, "p.bin")
+            lam.save(prob)
+            mtx, bla = os.path.join(HERE, name + ".mtx"), os.path.join(HERE, name + ".bla")
+            assert run(["dump_mm", prob, mtx, bla])["ok"]
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), cumsum=lam.cumsum, bcol_ptr=lam.bcol_ptr,
+                            brow_idx=lam.brow_idx, values=lam.values, rhs=lam.rhs, n_matrix_cut=np.int64(lam.n_matrix_cut))
+        print(f"{name}: {os.path.getsize(mtx) / 1024:.1f} KiB .mtx")
 
 
 if __name__ == "__main__":

@@ -14,7 +14,20 @@ def _names():
 
 def golden_names():
     """Linear systems with the reference solvers' solutions."""
-    return [n for n in _names() if not n.startswith("assembly_")]
+    return [n for n in _names() if not n.startswith(("assembly_", "dump_"))]
+
+
+def dump_names():
+    """Systems with the files the reference's Save_MatrixMarket / Save_BlockLayout wrote for them."""
+    return [n for n in _names() if n.startswith("dump_")]
+
+
+def load_dump(name):
+    """(BlockSystem the dump was written from, path of the .mtx, path of the .bla)."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    lam = BlockSystem(z["cumsum"].astype(np.int64), z["bcol_ptr"].astype(np.int64), z["brow_idx"].astype(np.int32),
+                      z["values"], z["rhs"], int(z["n_matrix_cut"]), name)
+    return lam, os.path.join(GOLDEN_DIR, name + ".mtx"), os.path.join(GOLDEN_DIR, name + ".bla")
 
 
 def assembly_names():
