@@ -169,7 +169,8 @@ protected:
 		// changes the structure announces it through Clear_SymbolicDecomposition()
 	}
 
-	bool Gather_And_Solve(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta) // throw(std::bad_alloc, std::runtime_error)
+	bool Gather_And_Solve(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta,
+		bool b_landmarks_only = false) // throw(std::bad_alloc, std::runtime_error)
 	{
 		_ASSERTE(size_t(r_eta.rows()) == r_lambda.n_Column_Num());
 		const long n_block_num = long(m_gather.size());
@@ -199,7 +200,9 @@ protected:
 			}
 			p_rhs = &m_rhs[0];
 		}
-		const int n_result = slampp_hip_factor_solve(m_p_solver, m_values.empty()? 0 : &m_values[0], p_rhs, &m_t_times);
+		const int n_result = b_landmarks_only?
+			slampp_hip_solve_marginal_poses(m_p_solver, m_values.empty()? 0 : &m_values[0], p_rhs) :
+			slampp_hip_factor_solve(m_p_solver, m_values.empty()? 0 : &m_values[0], p_rhs, &m_t_times);
 		if(n_result == SLAMPP_HIP_NOT_POSDEF)
 			return false;
 		Throw_On_Error(n_result);
@@ -434,6 +437,20 @@ public:
 		if(m_n_matrix_cut == 0 || m_n_matrix_cut == r_lambda.n_BlockColumn_Num())
 			return m_sparse_fallback.Solve_PosDef_Blocky(r_lambda, r_eta);
 		return Gather_And_Solve(r_lambda, r_eta);
+	}
+
+	/**
+	 *	@brief solves for the landmarks only (dl = C^-1 eta_l), the solution for the poses is zeroed out;
+	 *		the counterpart of CLinearSolver_Schur::Solve_PosDef_Blocky_MarginalPoses() (LinearSolver_Schur.h:1956-2143)
+	 *	@note Unlike the reference, this returns false if a landmark block is not positive definite.
+	 */
+	bool Solve_PosDef_Blocky_MarginalPoses(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta) // throw(std::bad_alloc, std::runtime_error)
+	{
+		if(m_n_matrix_cut == size_t(-1) || !b_Structure_Matches(r_lambda))
+			SymbolicDecomposition_Blocky(r_lambda, true); // force guided, as the reference does
+		if(m_n_matrix_cut == 0 || m_n_matrix_cut == r_lambda.n_BlockColumn_Num())
+			throw std::runtime_error("CLinearSolver_Schur_HIP: no landmarks to marginalize the poses against");
+		return Gather_And_Solve(r_lambda, r_eta, true);
 	}
 };
 

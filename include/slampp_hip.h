@@ -117,6 +117,13 @@ int slampp_hip_factor_solve_device(slampp_hip_solver *p_solver, const double *p_
  * (reference: cholmod_solve / cs_lsolve+cs_ltsolve on a kept factor, LinearSolver_CholMod.cpp:322-347) */
 int slampp_hip_solve_again(slampp_hip_solver *p_solver, double *p_rhs_inout);
 
+/* Schur mode only: solves for the landmarks alone, dl = C^-1 eta_l, and zeroes the camera part of the vector -- the
+ * reference's CLinearSolver_Schur::Solve_PosDef_Blocky_MarginalPoses (include/slam/LinearSolver_Schur.h:1956-2143).
+ * Returns SLAMPP_HIP_NOT_POSDEF if a landmark block is not positive definite (the reference inverts it regardless). */
+int slampp_hip_solve_marginal_poses(slampp_hip_solver *p_solver, const double *p_values, double *p_rhs_inout);
+int slampp_hip_solve_marginal_poses_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,
+	double *p_rhs_inout_dev);
+
 /* enqueue-only variants for benchmarking / stream capture: no host synchronisation, no status
  * read-back; slampp_hip_sync() waits and returns OK / NOT_POSDEF / error for everything enqueued */
 int slampp_hip_factor_solve_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,

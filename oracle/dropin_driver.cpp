@@ -261,6 +261,17 @@ int main(int n_arg_num, const char **p_arg_list)
 				printf("\"schur_%s\": {\"ok_ref\": %d, \"ok_hip\": %d, \"rel_inf\": %.3g, \"rel_inf_warm\": %.3g}, ",
 					b_interleave? "interleaved" : "cams_first", int(b_ref), int(b_hip && b_hip2), f_err, f_err2);
 				n_fail += !(b_ref && b_hip && b_hip2 && f_err < 1e-10 && f_err2 < 1e-10);
+				{ // landmarks only (the reference requires the guided ordering for it)
+					Eigen::VectorXd x_ref_mp = rhs, x_hip_mp = rhs;
+					TRefSchur ref_mp(base);
+					ref_mp.SymbolicDecomposition_Blocky(lambda, true);
+					const bool b_ref_mp = ref_mp.Solve_PosDef_Blocky_MarginalPoses(lambda, x_ref_mp);
+					const bool b_hip_mp = hip_solver.Solve_PosDef_Blocky_MarginalPoses(lambda, x_hip_mp);
+					const double f_err_mp = (x_hip_mp - x_ref_mp).lpNorm<Eigen::Infinity>() / x_ref_mp.lpNorm<Eigen::Infinity>();
+					printf("\"marginal_poses_%s\": {\"ok_ref\": %d, \"ok_hip\": %d, \"rel_inf\": %.3g}, ",
+						b_interleave? "interleaved" : "cams_first", int(b_ref_mp), int(b_hip_mp), f_err_mp);
+					n_fail += !(b_ref_mp && b_hip_mp && f_err_mp < 1e-10);
+				}
 				if(!b_interleave) { // a copy keeps the configuration: the reduced system through the sparse block path
 					hip_solver.Set_Option("schur_sparse", 1);
 					THipSchur hip_copy(hip_solver);

@@ -151,10 +151,11 @@ struct CSolverDriver {
 	CLinearSolver_UberBlock<TBlocks_7> *p_ub7;
 	CLinearSolver_UberBlock<TBlocks_BA> *p_ubba;
 	TSchurSolver *p_schur;
+	bool b_marginal_poses;
 
 	CSolverDriver(const char *p_s_name, int n_dim)
 		:s_name(p_s_name), n_uniform_dim(n_dim), p_cholmod(0), p_csparse(0),
-		p_ub3(0), p_ub6(0), p_ub7(0), p_ubba(0), p_schur(0)
+		p_ub3(0), p_ub6(0), p_ub7(0), p_ubba(0), p_schur(0), b_marginal_poses(false)
 	{
 		if(s_name == "cholmod_auto")
 			p_cholmod = new CLinearSolver_CholMod(CHOLMOD_AUTO, CHOLMOD_AMD);
@@ -169,9 +170,10 @@ struct CSolverDriver {
 			else if(n_dim == 6) p_ub6 = new CLinearSolver_UberBlock<TBlocks_6>();
 			else if(n_dim == 7) p_ub7 = new CLinearSolver_UberBlock<TBlocks_7>();
 			else p_ubba = new CLinearSolver_UberBlock<TBlocks_BA>();
-		} else if(s_name == "schur") {
+		} else if(s_name == "schur" || s_name == "schur_marginal_poses") {
 			CLinearSolver_CholMod base;
 			p_schur = new TSchurSolver(base);
+			b_marginal_poses = s_name == "schur_marginal_poses";
 		} else {
 			fprintf(stderr, "error: unknown solver \'%s\'\n", p_s_name);
 			exit(2);
@@ -189,6 +191,11 @@ struct CSolverDriver {
 		BLOCKY_SOLVE(p_ub6);
 		BLOCKY_SOLVE(p_ub7);
 		BLOCKY_SOLVE(p_ubba);
+		if(p_schur && b_marginal_poses) { // landmarks only, poses zeroed (LinearSolver_Schur.h:1956-2143)
+			if(b_first)
+				p_schur->SymbolicDecomposition_Blocky(r_lambda, true); // the guided ordering it requires
+			return p_schur->Solve_PosDef_Blocky_MarginalPoses(r_lambda, r_x);
+		}
 		if(p_schur) {
 			if(b_first)
 				return p_schur->Solve_PosDef(r_lambda, r_x); // ordering + solve

@@ -934,6 +934,58 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 	SLAMPP_HIP_CHECK(hipGetLastError());
 }
 
+// dl_p = C_p^-1 l_p, dx = 0
+template <int DP>
+__global__ void schur_landmarks_only_kernel(int64_t np, int n, const double *__restrict__ Cinv, double *out)
+{
+	const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(gid < np) {
+		double v[DP];
+		#pragma unroll
+		for(int t = 0; t < DP; ++ t)
+			v[t] = out[n + gid * DP + t];
+		#pragma unroll
+		for(int r = 0; r < DP; ++ r) {
+			double sum = 0;
+			#pragma unroll
+			for(int t = 0; t < DP; ++ t)
+				sum += Cinv[gid * (DP * DP) + r + t * DP] * v[t];
+			out[n + gid * DP + r] = sum;
+		}
+	}
+	if(gid < n)
+		out[gid] = 0.0;
+}
+
+template <int DC, int DP>
+static void schur_enqueue_marginal_t(slampp_hip_solver &s, CSchurState &S, const double *A, double *rhs)
+{
+	hipStream_t st = s.stream;
+	const int64_t ubase = S.n_ablocks * DC * DC;
+	SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), st));
+	s.Phase_Begin("landmarks_only");
+	hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((S.np + 255) / 256)), dim3(256), 0, st,
+		S.d_ptr.p(), S.nc, S.np, ubase, A, S.d_Cinv.p(), s.d_flag.p());
+	const int64_t n_work = std::max<int64_t>(S.np, S.N);
+	hipLaunchKernelGGL((schur_landmarks_only_kernel<DP>), dim3(unsigned((n_work + 255) / 256)), dim3(256), 0, st,
+		S.np, S.N, S.d_Cinv.p(), rhs);
+	s.Phase_End();
+	SLAMPP_HIP_CHECK(hipGetLastError());
+}
+
+// the reference's Solve_PosDef_Blocky_MarginalPoses (LinearSolver_Schur.h:1956-2143): the landmarks' block of the
+// system alone, dl = C^-1 eta_l, the pose part of the solution zeroed
+void schur_enqueue_marginal_poses(slampp_hip_solver &s, const double *p_values_dev, double *p_rhs_dev)
+{
+	CSchurState &S = *s.p_schur;
+	if(S.DC == 6 && S.DP == 3)
+		schur_enqueue_marginal_t<6, 3>(s, S, p_values_dev, p_rhs_dev);
+	else if(S.DC == 7 && S.DP == 3)
+		schur_enqueue_marginal_t<7, 3>(s, S, p_values_dev, p_rhs_dev);
+	else
+		schur_enqueue_marginal_t<3, 2>(s, S, p_values_dev, p_rhs_dev);
+}
+
 void schur_enqueue(slampp_hip_solver &s, const double *p_values_dev, double *p_rhs_dev)
 {
 	CSchurState &S = *s.p_schur;

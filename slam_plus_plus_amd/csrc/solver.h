@@ -158,6 +158,7 @@ namespace slampp {
 void schur_destroy(CSchurState *p);
 CSchurState *schur_analyze(slampp_hip_solver &s); // throws
 void schur_enqueue(slampp_hip_solver &s, const double *p_values_dev, double *p_rhs_dev); // throws
+void schur_enqueue_marginal_poses(slampp_hip_solver &s, const double *p_values_dev, double *p_rhs_dev); // throws
 size_t schur_device_bytes(const CSchurState *p);
 void schur_fill_stats(const CSchurState *p, slampp_hip_stats &st);
 

@@ -676,6 +676,53 @@ int slampp_hip_factor_solve(slampp_hip_solver *p_solver, const double *p_values,
 	return n_result;
 }
 
+int slampp_hip_solve_marginal_poses_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,
+	double *p_rhs_inout_dev)
+{
+	return guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_analyzed)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "solve_marginal_poses: analyze was not called");
+		if(s.n_mode != SLAMPP_HIP_MODE_SCHUR)
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "solve_marginal_poses: needs the Schur mode (cameras and landmarks)");
+		if(!p_values_dev || !p_rhs_inout_dev)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "solve_marginal_poses: null pointer");
+		schur_enqueue_marginal_poses(s, p_values_dev, p_rhs_inout_dev);
+		s.b_factored = false; // no factor of the reduced system comes out of this
+		return SLAMPP_HIP_OK;
+	});
+}
+
+int slampp_hip_solve_marginal_poses(slampp_hip_solver *p_solver, const double *p_values, double *p_rhs_inout)
+{
+	int n_result = guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_analyzed)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "solve_marginal_poses: analyze was not called");
+		if(!p_values || !p_rhs_inout)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "solve_marginal_poses: null pointer");
+		s.d_A.Alloc(size_t(s.n_values));
+		s.d_rhs.Alloc(size_t(s.n_scalars));
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_A.p(), p_values, size_t(s.n_values) * sizeof(double), hipMemcpyHostToDevice, s.stream));
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_rhs.p(), p_rhs_inout, size_t(s.n_scalars) * sizeof(double), hipMemcpyHostToDevice, s.stream));
+		return SLAMPP_HIP_OK;
+	});
+	if(n_result != SLAMPP_HIP_OK)
+		return n_result;
+	slampp_hip_solver &s = *p_solver;
+	n_result = slampp_hip_solve_marginal_poses_device_async(p_solver, s.d_A.p(), s.d_rhs.p());
+	if(n_result == SLAMPP_HIP_OK)
+		n_result = slampp_hip_sync(p_solver);
+	if(n_result == SLAMPP_HIP_OK) {
+		n_result = guarded(p_solver, [&]() -> int {
+			SLAMPP_HIP_CHECK(hipMemcpyAsync(p_rhs_inout, s.d_rhs.p(), size_t(s.n_scalars) * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+			SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+			return SLAMPP_HIP_OK;
+		});
+	}
+	return n_result;
+}
+
 int slampp_hip_solve_again(slampp_hip_solver *p_solver, double *p_rhs_inout)
 {
 	return guarded(p_solver, [&]() -> int {

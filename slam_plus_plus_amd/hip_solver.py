@@ -81,6 +81,8 @@ ABI = {
     "slampp_hip_factor_solve": (C.c_int, [_P, _P, _P, C.POINTER(Times)]),
     "slampp_hip_factor_solve_device": (C.c_int, [_P, _P, _P, C.POINTER(Times)]),
     "slampp_hip_solve_again": (C.c_int, [_P, _P]),
+    "slampp_hip_solve_marginal_poses": (C.c_int, [_P, _P, _P]),
+    "slampp_hip_solve_marginal_poses_device_async": (C.c_int, [_P, _P, _P]),
     "slampp_hip_factor_solve_device_async": (C.c_int, [_P, _P, _P]),
     "slampp_hip_sync": (C.c_int, [_P]),
     "slampp_hip_stream": (_P, [_P]),
@@ -359,6 +361,16 @@ class CLinearSolver_Schur_HIP(_SolverBase):
 
     def SymbolicDecomposition_Blocky(self, lam, b_force_guided_ordering: bool = False) -> bool:
         return super().SymbolicDecomposition_Blocky(lam)
+
+    def Solve_PosDef_Blocky_MarginalPoses(self, lam, eta: np.ndarray) -> bool:
+        """LinearSolver_Schur.h:1956-2143: only the landmarks are solved for (dl = C^-1 eta_l), the pose part of
+        ``eta`` is zeroed."""
+        if eta.dtype != np.float64 or not eta.flags.c_contiguous or eta.shape != (lam.n_scalars,):
+            raise ValueError("eta must be a contiguous float64 vector of the system's dimension")
+        if not self._analyzed or self._structure_key != self._key(lam):
+            self.SymbolicDecomposition_Blocky(lam, True)
+        vals = np.ascontiguousarray(lam.values, dtype=np.float64)
+        return self._check(self._lib.slampp_hip_solve_marginal_poses(self._h, _ptr(vals), _ptr(eta)))
 
 
 class CLambdaAssembly_HIP:

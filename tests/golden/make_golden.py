@@ -12,6 +12,7 @@ reference's own solver classes on those inputs:
     x_uberblock                      : CLinearSolver_UberBlock<...>::Solve_PosDef_Blocky
     x_schur, S, rhs_reduced (BA)     : CLinearSolver_Schur<...>::Solve_PosDef and the intermediates of
                                        its steps replayed through public CUberBlockMatrix calls
+    x_schur_marginal_poses (BA)      : CLinearSolver_Schur<...>::Solve_PosDef_Blocky_MarginalPoses (landmarks only)
     ok_* (negative case)             : the boolean each solver returned
     assembly_*.npz                   : `ref_harness lambda_dump`: a pose graph built from the reference's own
                                        vertex / edge types; per edge the Jacobians, Sigma^-1, error and robust
@@ -67,7 +68,8 @@ def main():
         with tempfile.TemporaryDirectory() as td:
             prob = os.path.join(td, "p.bin")
             lam.save(prob)
-            solvers = ["cholmod_super", "cholmod_simp", "csparse", "uberblock"] + (["schur"] if lam.n_matrix_cut else [])
+            solvers = ["cholmod_super", "cholmod_simp", "csparse", "uberblock"] + \
+                (["schur", "schur_marginal_poses"] if lam.n_matrix_cut else [])
             for s in solvers:
                 xf = os.path.join(td, f"x_{s}.bin")
                 r = run(["solve", prob, s, xf, "1"])

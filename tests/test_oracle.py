@@ -90,3 +90,21 @@ def test_oracle_matches_live_reference_on_a_fresh_system(tmp_path):
     assert r["ok"]
     ok, x, _ = O.solve_sparse(lam)
     assert ok and rel_inf(x, np.fromfile(str(xf))) < TOL
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("ba_")])
+def test_marginal_poses_restatement(name):
+    """LinearSolver_Schur.h:1956-2143 restated: dx = 0, dl_p = C_p^-1 eta_p."""
+    lam, ref = load_golden(name)
+    nc = lam.n_matrix_cut
+    n_x = int(lam.cumsum[nc])
+    off = lam.block_value_offsets()
+    x = np.zeros(lam.n_scalars)
+    for p in range(lam.n_bcols - nc):
+        k = int(lam.bcol_ptr[nc + p + 1] - 1)
+        d = int(lam.cumsum[nc + p + 1] - lam.cumsum[nc + p])
+        Cp = lam.values[off[k]:off[k + 1]].reshape(d, d).T
+        Cp = np.triu(Cp) + np.triu(Cp, 1).T
+        s0 = int(lam.cumsum[nc + p])
+        x[s0:s0 + d] = np.linalg.solve(Cp, lam.rhs[s0:s0 + d])
+    assert rel_inf(x, ref["x_schur_marginal_poses"]) < 1e-13

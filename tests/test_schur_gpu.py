@@ -247,3 +247,25 @@ def test_many_cameras_sparse_reduced_system():
     assert solver.stats()["device_bytes"] < 1 << 30
     resid = np.abs(lam.to_scipy() @ eta - lam.rhs).max() / np.abs(lam.rhs).max()
     assert resid < 1e-10
+
+
+@pytest.mark.parametrize("name", ["ba_12x150_venice", "ba_10x120_band"])
+def test_marginal_poses_matches_reference(name):
+    """Solve_PosDef_Blocky_MarginalPoses: landmarks only, poses zeroed -- against the reference's output (golden)."""
+    from golden_util import load_golden
+    lam, ref = load_golden(name)
+    solver = CLinearSolver_Schur_HIP()
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef_Blocky_MarginalPoses(lam, eta)
+    n_x = int(lam.cumsum[lam.n_matrix_cut])
+    assert np.all(eta[:n_x] == 0.0)
+    assert rel_inf(eta, ref["x_schur_marginal_poses"]) < TOL
+    # the full solve still works afterwards on the same handle
+    eta2 = lam.rhs.copy()
+    assert solver.Solve_PosDef_Blocky(lam, eta2) and rel_inf(eta2, ref["x_schur"]) < TOL
+
+
+def test_marginal_poses_needs_schur_mode():
+    lam = synth.pose_chain(n=50, d=6)
+    with pytest.raises(NotImplementedError):
+        CLinearSolver_Schur_HIP().Solve_PosDef_Blocky_MarginalPoses(lam, lam.rhs.copy())
