@@ -32,6 +32,7 @@
 #define __LINEAR_SOLVER_HIP_INCLUDED
 
 #include <stdint.h>
+#include <string.h>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -169,10 +170,9 @@ protected:
 		// changes the structure announces it through Clear_SymbolicDecomposition()
 	}
 
-	bool Gather_And_Solve(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta,
-		bool b_landmarks_only = false) // throw(std::bad_alloc, std::runtime_error)
+	/** @brief copies the block values of lambda into the packed array the library reads */
+	void Gather_Values(const CUberBlockMatrix &r_lambda)
 	{
-		_ASSERTE(size_t(r_eta.rows()) == r_lambda.n_Column_Num());
 		const long n_block_num = long(m_gather.size());
 		#pragma omp parallel for schedule(static) if(n_block_num > 512)
 		for(long k = 0; k < n_block_num; ++ k) {
@@ -189,6 +189,13 @@ protected:
 						p_dest[c + r * t.n_cols] = p_src[r + c * t.n_rows]; // dest is n_cols x n_rows
 			}
 		}
+	}
+
+	bool Gather_And_Solve(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta,
+		bool b_landmarks_only = false) // throw(std::bad_alloc, std::runtime_error)
+	{
+		_ASSERTE(size_t(r_eta.rows()) == r_lambda.n_Column_Num());
+		Gather_Values(r_lambda);
 		double *p_rhs = &r_eta(0);
 		const size_t n = m_cumsum.size() - 1;
 		if(!m_order.empty()) { // permute eta by blocks (cf. BlockMatrix.cpp:9291-9401)
@@ -287,16 +294,122 @@ public:
 };
 
 /**
+ *	@brief numeric factorization of a pre-ordered matrix, the factor handed back as a block matrix
+ *		(what the reference's L / FastL solvers ask of their linear solver, LinearSolver_CholMod.cpp:362-544);
+ *		its own library handle, configured to keep the caller's order and to factor every column block by block
+ */
+class CLinearSolver_HIP_Factorizer : public CLinearSolver_HIP_Base {
+protected:
+	std::vector<int32_t> m_l_perm, m_l_dim, m_l_row; /**< @brief structure of the factor (slampp_hip_plan_view) */
+	std::vector<int64_t> m_l_ptr, m_l_off;
+	std::vector<double> m_l_values;
+
+public:
+	inline CLinearSolver_HIP_Factorizer(int n_device = 0)
+		:CLinearSolver_HIP_Base(n_device)
+	{
+		Set_Option("natural_order", 1);
+		Set_Option("dense_top_nb", 0);
+	}
+
+	/**
+	 *	@brief factorizes r_lambda (upper triangle read), writes R (or L = R^T) into r_factor at the given block offset
+	 *	@return Returns true on success, false if r_lambda is not positive definite.
+	 */
+	bool Factorize(CUberBlockMatrix &r_factor, const CUberBlockMatrix &r_lambda,
+		size_t n_dest_row_id, size_t n_dest_column_id, bool b_upper_factor) // throw(std::bad_alloc, std::runtime_error)
+	{
+		const size_t n = r_lambda.n_BlockColumn_Num();
+		if(!b_Structure_Matches(r_lambda) || m_l_ptr.size() != n + 1) {
+			Analyze(r_lambda, SLAMPP_HIP_MODE_SPARSE, 0, 0);
+			slampp_hip_plan_view t_view;
+			memset(&t_view, 0, sizeof(t_view));
+			Throw_On_Error(slampp_hip_get_plan(m_p_solver, &t_view)); // sizes
+			m_l_perm.resize(size_t(t_view.n_bcols)); m_l_dim.resize(size_t(t_view.n_bcols));
+			m_l_ptr.resize(size_t(t_view.n_bcols) + 1);
+			m_l_row.resize(size_t(t_view.l_blocks)); m_l_off.resize(size_t(t_view.l_blocks));
+			m_l_values.resize(size_t(t_view.l_values));
+			t_view.p_perm = m_l_perm.empty()? 0 : &m_l_perm[0];
+			t_view.p_dim = m_l_dim.empty()? 0 : &m_l_dim[0];
+			t_view.p_lptr = &m_l_ptr[0];
+			t_view.p_lrow = m_l_row.empty()? 0 : &m_l_row[0];
+			t_view.p_loff = m_l_off.empty()? 0 : &m_l_off[0];
+			Throw_On_Error(slampp_hip_get_plan(m_p_solver, &t_view)); // contents
+			for(size_t i = 0; i < n; ++ i) {
+				if(size_t(m_l_perm[i]) != i)
+					throw std::runtime_error("CLinearSolver_HIP: the factorization did not keep the caller's order");
+			}
+		}
+		Gather_Values(r_lambda);
+		const int n_result = slampp_hip_factorize(m_p_solver, m_values.empty()? 0 : &m_values[0],
+			m_l_values.empty()? 0 : &m_l_values[0]);
+		if(n_result == SLAMPP_HIP_NOT_POSDEF)
+			return false;
+		Throw_On_Error(n_result);
+		for(size_t j = 0; j < n; ++ j) {
+			const int dj = m_l_dim[j];
+			for(int64_t k = m_l_ptr[j]; k < m_l_ptr[j + 1]; ++ k) {
+				const size_t i = size_t(m_l_row[size_t(k)]);
+				const int di = m_l_dim[i];
+				Eigen::Map<const Eigen::MatrixXd> t_L_ij(&m_l_values[size_t(m_l_off[size_t(k)])], di, dj); // L(i, j), i >= j
+				if(b_upper_factor) {
+					double *p_dest = r_factor.p_GetBlock_Log(n_dest_row_id + j, n_dest_column_id + i, dj, di, true, false);
+					if(!p_dest)
+						return false; // incorrect structure of r_factor
+					Eigen::Map<Eigen::MatrixXd>(p_dest, dj, di) = t_L_ij.transpose(); // R(j, i)
+				} else {
+					double *p_dest = r_factor.p_GetBlock_Log(n_dest_row_id + i, n_dest_column_id + j, di, dj, true, false);
+					if(!p_dest)
+						return false;
+					Eigen::Map<Eigen::MatrixXd>(p_dest, di, dj) = t_L_ij;
+				}
+			}
+		}
+		return true;
+	}
+};
+
+/**
  *	@brief sparse block Cholesky on the GPU (fill-reducing ordering on the block graph, symbolic
  *		analysis cached across calls while the block structure is unchanged)
  */
 class CLinearSolver_HIP : public CLinearSolver_HIP_Base {
+protected:
+	CLinearSolver_HIP_Factorizer m_factorizer; /**< @brief for Factorize_PosDef_Blocky() (own handle, natural order) */
+
 public:
 	typedef CBlockwiseLinearSolverTag _Tag; /**< @brief solver type tag */
 
 	inline CLinearSolver_HIP(int n_device = 0)
-		:CLinearSolver_HIP_Base(n_device)
+		:CLinearSolver_HIP_Base(n_device), m_factorizer(n_device)
 	{}
+
+	/**
+	 *	@brief factorizes a pre-ordered block matrix, puts result in another block matrix; same contract as
+	 *		CLinearSolver_CholMod::Factorize_PosDef_Blocky() (LinearSolver_CholMod.h:196-214)
+	 *
+	 *	@param[out] r_factor is destination for the factor (must contain structure but not any nonzero blocks)
+	 *	@param[in] r_lambda is a pre-ordered block matrix to be factorized
+	 *	@param[in] r_workspace is unused (the reference needs it for CUberBlockMatrix::From_Sparse())
+	 *	@param[in] n_dest_row_id is id of block row where the factor should be put
+	 *	@param[in] n_dest_column_id is id of block column where the factor should be put
+	 *	@param[in] b_upper_factor is the factor flag (if set, factor is U (R), if not set, factor is L)
+	 *
+	 *	@return Returns true on success, false on failure (not pos def or incorrect structure of r_factor).
+	 */
+	bool Factorize_PosDef_Blocky(CUberBlockMatrix &r_factor, const CUberBlockMatrix &r_lambda,
+		std::vector<size_t> &UNUSED(r_workspace), size_t n_dest_row_id = 0,
+		size_t n_dest_column_id = 0, bool b_upper_factor = true) // throw(std::bad_alloc, std::runtime_error)
+	{
+		return m_factorizer.Factorize(r_factor, r_lambda, n_dest_row_id, n_dest_column_id, b_upper_factor);
+	}
+
+	/** @brief deletes memory for all the auxiliary buffers and matrices, host and device */
+	void Free_Memory()
+	{
+		CLinearSolver_HIP_Base::Free_Memory();
+		m_factorizer.Free_Memory();
+	}
 
 	/**
 	 *	@brief solves linear system given by positive-definite matrix

@@ -68,7 +68,8 @@ void slampp_hip_destroy(slampp_hip_solver *p_solver);
 int slampp_hip_free_memory(slampp_hip_solver *p_solver);
 const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
 
-/* tuning knobs: "leaf_size" (nested-dissection leaf, default 4), "nd_balance" (percent of the vertices a separator
+/* tuning knobs: "natural_order" (0/1: keep the caller's block order instead of nested dissection, default 0),
+ * "leaf_size" (nested-dissection leaf, default 4), "nd_balance" (percent of the vertices a separator
  * must leave on either side, default 15), "subtree_size" (max columns one
  * wave eliminates sequentially, default 8), "dense_nb" (dense panel width, default 64),
  * "dense_top_nb" (sparse path: block columns with at least this many blocks, and their ancestors, are factored as
@@ -116,6 +117,14 @@ int slampp_hip_factor_solve_device(slampp_hip_solver *p_solver, const double *p_
 /* another right-hand side with the factor of the last factor_solve
  * (reference: cholmod_solve / cs_lsolve+cs_ltsolve on a kept factor, LinearSolver_CholMod.cpp:322-347) */
 int slampp_hip_solve_again(slampp_hip_solver *p_solver, double *p_rhs_inout);
+
+/* Numeric factorization only, the factor handed back to the host -- for CLinearSolverTag-style callers that keep
+ * the factor themselves (the reference's Factorize_PosDef_Blocky, LinearSolver_CholMod.cpp:362-544, used by its
+ * L / FastL solvers on a matrix they have ordered: set the option "natural_order" to 1 for that, and "dense_top_nb"
+ * to 0).  p_factor_out receives l_values doubles (slampp_hip_plan_view): the lower factor L of the permuted Lambda,
+ * block-CSC as described by the view's lptr / lrow / loff, blocks column-major, the diagonal block first in each
+ * column.  Returns SLAMPP_HIP_NOT_POSDEF if a pivot is not positive. */
+int slampp_hip_factorize(slampp_hip_solver *p_solver, const double *p_values, double *p_factor_out);
 
 /* Schur mode only: solves for the landmarks alone, dl = C^-1 eta_l, and zeroes the camera part of the vector -- the
  * reference's CLinearSolver_Schur::Solve_PosDef_Blocky_MarginalPoses (include/slam/LinearSolver_Schur.h:1956-2143).

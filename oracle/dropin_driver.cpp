@@ -234,6 +234,49 @@ int main(int n_arg_num, const char **p_arg_list)
 				f_chi2_ref, f_chi2_hip, f_err);
 			n_fail += !(f_err < 1e-9 && fabs(f_chi2_ref - f_chi2_hip) <= 1e-9 * fabs(f_chi2_ref));
 		}
+		{ // Factorize_PosDef_Blocky: the factor handed back as a block matrix, next to CHOLMOD's on the same matrices
+			for(int n_case = 0; n_case < 2; ++ n_case) {
+				const size_t n_blocks = n_case? 60 : 150;
+				const int n_dim = n_case? 3 : 6;
+				std::vector<size_t> cumsums(n_blocks);
+				for(size_t i = 0; i < n_blocks; ++ i)
+					cumsums[i] = (i + 1) * n_dim;
+				CUberBlockMatrix lambda(cumsums.begin(), cumsums.end(), cumsums.begin(), cumsums.end());
+				std::mt19937_64 rng(1234 + n_case);
+				std::normal_distribution<double> nd(0, 1);
+				for(size_t c = 0; c < n_blocks; ++ c) {
+					const size_t p_rows[3] = {c, (c >= 1)? c - 1 : c, (c >= 7 && c % 5 == 0)? c - 7 : c};
+					for(int t = 0; t < 3; ++ t) {
+						if(t && p_rows[t] == c)
+							continue;
+						Eigen::MatrixXd M(n_dim, n_dim);
+						for(int i = 0; i < n_dim * n_dim; ++ i)
+							M.data()[i] = 0.3 * nd(rng);
+						if(!t)
+							M = M * M.transpose() + Eigen::MatrixXd::Identity(n_dim, n_dim) * 8.0; // diagonally dominant overall
+						lambda.t_GetBlock_Log(p_rows[t], c, n_dim, n_dim, true, true) += M;
+					}
+				}
+				for(int b_upper = 1; b_upper >= 0; -- b_upper) {
+					CUberBlockMatrix R_ref, R_hip;
+					lambda.CopyLayoutTo(R_ref);
+					lambda.CopyLayoutTo(R_hip);
+					std::vector<size_t> workspace;
+					CLinearSolver_CholMod ref_solver;
+					CLinearSolver_HIP hip_solver;
+					const bool b_ref = ref_solver.Factorize_PosDef_Blocky(R_ref, lambda, workspace, 0, 0, b_upper != 0);
+					const bool b_hip = hip_solver.Factorize_PosDef_Blocky(R_hip, lambda, workspace, 0, 0, b_upper != 0);
+					Eigen::MatrixXd A, B;
+					R_ref.Convert_to_Dense(A);
+					R_hip.Convert_to_Dense(B);
+					const double f_err = (A - B).cwiseAbs().maxCoeff() / A.cwiseAbs().maxCoeff();
+					printf("\"factorize_%dx%d_%s\": {\"ok_ref\": %d, \"ok_hip\": %d, \"blocks_ref\": %ld, \"blocks_hip\": %ld, "
+						"\"rel_max\": %.3g}, ", n_dim, n_dim, b_upper? "R" : "L", int(b_ref), int(b_hip), (long)R_ref.n_Block_Num(),
+						(long)R_hip.n_Block_Num(), f_err);
+					n_fail += !(b_ref && b_hip && f_err < 1e-11);
+				}
+			}
+		}
 		if(n_arg_num > 1) {
 			TProblem p;
 			if(!Read_Problem(p_arg_list[1], p) || !p.n_matrix_cut) {

@@ -443,7 +443,11 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 	}
 
 	// ---- ordering ----
-	nested_dissection(n, gptr, gadj, opt.leaf_size, P.perm, opt.nd_balance_pct);
+	if(opt.natural_order) {
+		P.perm.resize(n);
+		std::iota(P.perm.begin(), P.perm.end(), 0);
+	} else
+		nested_dissection(n, gptr, gadj, opt.leaf_size, P.perm, opt.nd_balance_pct);
 	if(int32_t(P.perm.size()) != n)
 		return "internal error: ordering lost vertices";
 	P.pinv.assign(n, -1);

@@ -52,6 +52,8 @@ struct Plan {
 };
 
 struct PlanOptions {
+	bool natural_order = false; // no fill-reducing ordering: the caller's order is kept (Factorize_PosDef_Blocky: the factor
+	                            // goes back to a caller that has ordered the matrix itself)
 	int leaf_size = 4;        // nested dissection stops at subgraphs of this many block columns
 	int nd_balance_pct = 15;  // a separator must leave at least this share (percent) of the vertices on either side; small
 	                          // separators beat balanced halves here: 15 is 5-15 % faster than 25 on pose chains of 30k-300k poses

@@ -148,7 +148,7 @@ struct slampp_hip_solver {
 	void Free_Device();
 	size_t n_Device_Bytes() const;
 	void Analyze_Sparse();
-	void Enqueue_Sparse(const double *p_values_dev, double *p_rhs_dev, bool b_factor);
+	void Enqueue_Sparse(const double *p_values_dev, double *p_rhs_dev, bool b_factor, bool b_factor_only = false);
 };
 
 

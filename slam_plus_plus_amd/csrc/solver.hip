@@ -295,7 +295,7 @@ void slampp_hip_solver::Analyze_Sparse()
 	}
 }
 
-void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs_dev, bool b_factor)
+void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs_dev, bool b_factor, bool b_factor_only)
 {
 	const Plan &P = plan;
 	const int n_stages = int(P.stage_ptr.size()) - 1;
@@ -317,6 +317,10 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 				P.stage_ptr[s + 1] - P.stage_ptr[s], stream);
 		}
 		Phase_End();
+	}
+	if(b_factor_only) { // (only without a dense top: the caller wants every column of L)
+		SLAMPP_HIP_CHECK(hipGetLastError());
+		return;
 	}
 	if(n_dense_dim) {
 		// dense top: Schur complement onto the big separators, dense MFMA Cholesky, both substitutions
@@ -457,6 +461,8 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 		p_solver->opt.leaf_size = int(n_value);
 	else if(s == "subtree_size" && n_value >= 1)
 		p_solver->opt.subtree_size = int(n_value);
+	else if(s == "natural_order")
+		p_solver->opt.natural_order = (n_value != 0);
 	else if(s == "nd_balance" && n_value >= 1 && n_value <= 49)
 		p_solver->opt.nd_balance_pct = int(n_value);
 	else if(s == "dense_nb" && (n_value == 32 || n_value == 64 || n_value == 128))
@@ -721,6 +727,40 @@ int slampp_hip_solve_marginal_poses(slampp_hip_solver *p_solver, const double *p
 		});
 	}
 	return n_result;
+}
+
+int slampp_hip_factorize(slampp_hip_solver *p_solver, const double *p_values, double *p_factor_out)
+{
+	int n_result = guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_analyzed)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factorize: analyze was not called");
+		if(s.n_mode != SLAMPP_HIP_MODE_SPARSE)
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "factorize: the sparse mode only");
+		if(s.n_dense_dim)
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "factorize: set the option dense_top_nb to 0 (the dense top keeps its part of the factor in another layout)");
+		if(!p_values || !p_factor_out)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factorize: null pointer");
+		s.d_A.Alloc(size_t(s.n_values));
+		s.d_rhs.Alloc(size_t(s.n_scalars));
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_A.p(), p_values, size_t(s.n_values) * sizeof(double), hipMemcpyHostToDevice, s.stream));
+		SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_rhs.p(), 0, size_t(s.n_scalars) * sizeof(double), s.stream)); // the fused forward substitution runs on zeros
+		s.Enqueue_Sparse(s.d_A.p(), s.d_rhs.p(), true, true);
+		s.b_factored = true;
+		return SLAMPP_HIP_OK;
+	});
+	if(n_result != SLAMPP_HIP_OK)
+		return n_result;
+	n_result = slampp_hip_sync(p_solver);
+	if(n_result != SLAMPP_HIP_OK)
+		return n_result;
+	return guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		const size_t n_l_values = size_t(s.plan.loff[s.plan.lrow.size()]);
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(p_factor_out, s.d_L.p(), n_l_values * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+		return SLAMPP_HIP_OK;
+	});
 }
 
 int slampp_hip_solve_again(slampp_hip_solver *p_solver, double *p_rhs_inout)

@@ -81,6 +81,7 @@ ABI = {
     "slampp_hip_factor_solve": (C.c_int, [_P, _P, _P, C.POINTER(Times)]),
     "slampp_hip_factor_solve_device": (C.c_int, [_P, _P, _P, C.POINTER(Times)]),
     "slampp_hip_solve_again": (C.c_int, [_P, _P]),
+    "slampp_hip_factorize": (C.c_int, [_P, _P, _P]),
     "slampp_hip_solve_marginal_poses": (C.c_int, [_P, _P, _P]),
     "slampp_hip_solve_marginal_poses_device_async": (C.c_int, [_P, _P, _P]),
     "slampp_hip_factor_solve_device_async": (C.c_int, [_P, _P, _P]),
@@ -276,6 +277,17 @@ class _SolverBase:
 
     def Solve_Again(self, eta: np.ndarray) -> bool:
         return self._check(self._lib.slampp_hip_solve_again(self._h, _ptr(eta)))
+
+    def factorize(self, lam):
+        """Numeric factor only (sparse mode, no dense top): ``(ok, plan, l_values)`` -- the lower factor of the permuted
+        Lambda in the plan's block-CSC layout (``plan['lptr']``, ``['lrow']``, ``['loff']``, ``['perm']``, ``['dim']``)."""
+        if not self._analyzed or self._structure_key != self._key(lam):
+            self.SymbolicDecomposition_Blocky(lam)
+        plan = self.plan()
+        vals = np.ascontiguousarray(lam.values, dtype=np.float64)
+        out = np.zeros(int(plan["l_values"]))
+        ok = self._check(self._lib.slampp_hip_factorize(self._h, _ptr(vals), _ptr(out)))
+        return ok, plan, out
 
     def stats(self) -> dict:
         st = Stats()

@@ -114,3 +114,44 @@ def test_dense_top_tile_schedule_matches_dense_schedule(name, tiles):
     eta2 = lam.rhs.copy()
     assert solver.Solve_Again(eta2)          # the kept factor: stand-alone forward substitution over the same tiles
     assert rel_inf(eta2, x_ref) < TOL
+
+
+def dense_factor(lam, plan, l_values):
+    """The lower factor as a dense matrix in the plan's (permuted) order."""
+    dim, lptr, lrow, loff = plan["dim"], plan["lptr"], plan["lrow"], plan["loff"]
+    cs = np.concatenate([[0], np.cumsum(dim)])
+    Lm = np.zeros((cs[-1], cs[-1]))
+    for j in range(len(dim)):
+        for k in range(lptr[j], lptr[j + 1]):
+            i = lrow[k]
+            Lm[cs[i]:cs[i + 1], cs[j]:cs[j + 1]] = l_values[loff[k]:loff[k] + dim[i] * dim[j]].reshape(dim[j], dim[i]).T
+    return Lm, cs
+
+
+@pytest.mark.parametrize("natural", [1, 0])
+@pytest.mark.parametrize("name", ["chain6", "sphere_small", "mixed"])
+def test_factorize_returns_the_cholesky_factor(name, natural):
+    """slampp_hip_factorize (the reference's Factorize_PosDef_Blocky hands its factor back to the nonlinear solver): L of
+    the permuted Lambda against numpy's Cholesky; with natural_order the permutation is the identity."""
+    lam = {"chain6": lambda: synth.pose_chain(n=300, d=6, seed=3), "sphere_small": lambda: synth.sphere(12, 12, seed=4),
+           "mixed": lambda: synth.ba(10, 150, seed=5)}[name]()
+    solver = CLinearSolver_HIP(natural_order=natural, dense_top_nb=0)
+    ok, plan, l_values = solver.factorize(lam)
+    assert ok
+    perm = plan["perm"]
+    assert (natural == 0) or np.array_equal(perm, np.arange(lam.n_bcols))
+    Lm, cs_new = dense_factor(lam, plan, l_values)
+    A = lam.to_scipy().toarray()
+    cs_old = lam.cumsum
+    idx = np.concatenate([np.arange(cs_old[o], cs_old[o + 1]) for o in perm])
+    Lref = np.linalg.cholesky(A[np.ix_(idx, idx)])
+    assert np.abs(np.triu(Lm, 1)).max() == 0.0
+    assert np.abs(Lm - Lref).max() < 1e-11 * np.abs(Lref).max()
+
+
+def test_factorize_not_posdef_and_dense_top_refused():
+    lam = synth.indefinite(40, 6, seed=5)
+    ok, _, _ = CLinearSolver_HIP(natural_order=1, dense_top_nb=0).factorize(lam)
+    assert not ok
+    with pytest.raises(NotImplementedError):
+        CLinearSolver_HIP().factorize(synth.sphere(30, 30))      # a dense top keeps part of the factor elsewhere
