@@ -110,6 +110,74 @@ static std::vector<double> Optimize_SE3(size_t n_poses, unsigned n_seed, double 
 	return state;
 }
 
+// CLinearSolver_HIP with call counters, to show which of its members the reference's solver went through
+class CLinearSolver_HIP_Counting : public CLinearSolver_HIP {
+public:
+	static size_t &n_Factorize_Calls() { static size_t n = 0; return n; }
+	static size_t &n_Solve_Calls() { static size_t n = 0; return n; }
+
+	bool Factorize_PosDef_Blocky(CUberBlockMatrix &r_factor, const CUberBlockMatrix &r_lambda,
+		std::vector<size_t> &r_workspace, size_t n_dest_row_id = 0,
+		size_t n_dest_column_id = 0, bool b_upper_factor = true)
+	{
+		++ n_Factorize_Calls();
+		return CLinearSolver_HIP::Factorize_PosDef_Blocky(r_factor, r_lambda, r_workspace,
+			n_dest_row_id, n_dest_column_id, b_upper_factor);
+	}
+
+	bool Solve_PosDef(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta)
+	{
+		++ n_Solve_Calls();
+		return CLinearSolver_HIP::Solve_PosDef(r_lambda, r_eta);
+	}
+};
+
+// the same graph through the reference's incremental solver (-fL): it keeps the factor R itself and asks its linear
+// solver for Solve_PosDef() and Factorize_PosDef_Blocky() (NonlinearSolver_FastL.h:1724, 2131, 2388)
+template <class CSystemType, class CLinearSolverType>
+static std::vector<double> Optimize_SE3_FastL(size_t n_poses, unsigned n_seed, double &r_f_chi2, bool b_incremental)
+{
+	CSystemType system;
+	CNonlinearSolver_FastL<CSystemType, CLinearSolverType> solver(system, (b_incremental)?
+		TIncrementalSolveSetting(solve::Nonlinear(frequency::Every(5))) : TIncrementalSolveSetting());
+	// incremental: a nonlinear solve each 5 vertices, as slam_online_example/Main.cpp:51 does each 1
+	Eigen::Matrix<double, 6, 6> information = Eigen::Matrix<double, 6, 6>::Identity() * 100;
+	std::mt19937_64 rng(n_seed);
+	std::normal_distribution<double> noise(0, 0.001); // small: plain Gauss-Newton, and the loop closures span up to 26 poses
+	std::vector<Eigen::Matrix<double, 6, 1> > truth(1, Eigen::Matrix<double, 6, 1>::Zero()); // noiseless trajectory
+	for(size_t i = 1; i < n_poses; ++ i) {
+		Eigen::Matrix<double, 6, 1> z, z_exact, v_next;
+		z_exact << 1, 0, 0.05, 0, 0, 0.1;
+		C3DJacobians::Relative_to_Absolute(truth.back(), z_exact, v_next);
+		truth.push_back(v_next);
+		z << 1 + noise(rng), noise(rng), 0.05 + noise(rng), noise(rng), noise(rng), 0.1 + noise(rng);
+		if(b_incremental)
+			solver.Incremental_Step(system.r_Add_Edge(CEdgePose3D(i - 1, i, z, information, system)));
+		else
+			system.r_Add_Edge(CEdgePose3D(i - 1, i, z, information, system));
+		if(i >= 30 && i % 7 == 0) { // a loop closure to an older pose (makes FastL refactorize a part of R)
+			const size_t j = i - 10 - (i % 17);
+			Eigen::Matrix<double, 6, 1> z2;
+			C3DJacobians::Absolute_to_Relative(truth[j], truth[i], z2);
+			for(int d = 0; d < 6; ++ d)
+				z2(d) += noise(rng);
+			if(b_incremental)
+				solver.Incremental_Step(system.r_Add_Edge(CEdgePose3D(j, i, z2, information, system)));
+			else
+				system.r_Add_Edge(CEdgePose3D(j, i, z2, information, system));
+		}
+	}
+	solver.Optimize(6, 1e-6);
+	r_f_chi2 = solver.f_Chi_Squared_Error_Denorm();
+	std::vector<double> state;
+	for(size_t i = 0, n = system.r_Vertex_Pool().n_Size(); i < n; ++ i) {
+		Eigen::VectorXd v = system.r_Vertex_Pool()[i].v_State();
+		for(int d = 0; d < v.rows(); ++ d)
+			state.push_back(v(d));
+	}
+	return state;
+}
+
 static double f_RelInf(const std::vector<double> &a, const std::vector<double> &b)
 {
 	if(a.size() != b.size() || a.empty())
@@ -233,6 +301,26 @@ int main(int n_arg_num, const char **p_arg_list)
 			printf("\"se3_lambda_solver\": {\"chi2_ref\": %.12g, \"chi2_hip\": %.12g, \"state_rel_inf\": %.3g}, ",
 				f_chi2_ref, f_chi2_hip, f_err);
 			n_fail += !(f_err < 1e-9 && fabs(f_chi2_ref - f_chi2_hip) <= 1e-9 * fabs(f_chi2_ref));
+		}
+		{
+			typedef MakeTypelist(CVertexPose3D) TVertexTypelist;
+			typedef MakeTypelist(CEdgePose3D) TEdgeTypelist;
+			typedef CFlatSystem<CVertexPose3D, TVertexTypelist, CEdgePose3D, TEdgeTypelist> CSystemType;
+			for(int n_pass = 0; n_pass < 2; ++ n_pass) {
+				const bool b_incremental = n_pass == 1;
+				CLinearSolver_HIP_Counting::n_Factorize_Calls() = 0;
+				CLinearSolver_HIP_Counting::n_Solve_Calls() = 0;
+				double f_chi2_ref, f_chi2_hip;
+				std::vector<double> ref = Optimize_SE3_FastL<CSystemType, CLinearSolver_CholMod>(200, 78, f_chi2_ref, b_incremental);
+				std::vector<double> hip = Optimize_SE3_FastL<CSystemType, CLinearSolver_HIP_Counting>(200, 78, f_chi2_hip, b_incremental);
+				const double f_err = f_RelInf(hip, ref);
+				const size_t n_calls = CLinearSolver_HIP_Counting::n_Factorize_Calls() + CLinearSolver_HIP_Counting::n_Solve_Calls();
+				printf("\"%s\": {\"chi2_ref\": %.12g, \"chi2_hip\": %.12g, \"state_rel_inf\": %.3g, "
+					"\"hip_factorize_calls\": %d, \"hip_solve_calls\": %d}, ", (b_incremental)? "se3_fastl_incremental" :
+					"se3_fastl_solver", f_chi2_ref, f_chi2_hip, f_err, int(CLinearSolver_HIP_Counting::n_Factorize_Calls()),
+					int(CLinearSolver_HIP_Counting::n_Solve_Calls()));
+				n_fail += !(f_err < 1e-9 && fabs(f_chi2_ref - f_chi2_hip) <= 1e-9 * fabs(f_chi2_ref) && n_calls > 0);
+			}
 		}
 		{ // Factorize_PosDef_Blocky: the factor handed back as a block matrix, next to CHOLMOD's on the same matrices
 			for(int n_case = 0; n_case < 2; ++ n_case) {

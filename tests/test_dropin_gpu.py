@@ -28,6 +28,10 @@ def test_reference_nonlinear_solver_with_hip_linear_solver(tmp_path):
     assert out.returncode == 0 and r["failures"] == 0, r
     assert r["se2_lambda_solver"]["state_rel_inf"] < 1e-9
     assert r["se3_lambda_solver"]["state_rel_inf"] < 1e-9
+    # the reference's incremental solver (CNonlinearSolver_FastL) driving Solve_PosDef + Factorize_PosDef_Blocky
+    for k in ("se3_fastl_solver", "se3_fastl_incremental"):
+        assert r[k]["state_rel_inf"] < 1e-9, (k, r[k])
+        assert r[k]["hip_factorize_calls"] + r[k]["hip_solve_calls"] > 0, (k, r[k])
     assert r["schur_cams_first"]["rel_inf"] < 1e-10
     assert r["schur_interleaved"]["rel_inf"] < 1e-10
     assert r["schur_sparse_reduced"]["ok_hip"] == 1 and r["schur_sparse_reduced"]["rel_inf"] < 1e-10
