@@ -331,6 +331,74 @@ def cpu_baseline_ba(lam, flops):
                       f"{wall:.1f} s of CPU incl. load); OpenMP only in the block-diagonal inverse and one SpMV, dense LLT serial"}
 
 
+def marginals_leg(args, solver, lam, vals, dev, torch):
+    """Block diagonal of the covariance on the bench's BA system, after the timed solves:
+    the reduced system assembled densely, factored, inverted on the matrix cores (2 n^3 / 3 flops), gathered per landmark.
+    The reference's CSchurComplement_Marginals is run beside it on a bounded sample (--no-cpu-baseline skips it)."""
+    nc, n_pts = lam.n_matrix_cut, lam.n_bcols - lam.n_matrix_cut
+    cams = torch.empty(nc * 36, dtype=torch.float64, device=dev)
+    pts = torch.empty(n_pts * 9, dtype=torch.float64, device=dev)
+    solver.schur_marginals_device_async(vals.data_ptr(), cams.data_ptr(), pts.data_ptr())
+    if not solver.sync():
+        return None
+    solver.profile(reset=True)
+    reps = 3
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        solver.schur_marginals_device_async(vals.data_ptr(), cams.data_ptr(), pts.data_ptr())
+    ok = solver.sync()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    prof = {k_: v[1] / max(v[0], 1) for k_, v in solver.profile().items() if k_.startswith("marginals")}
+    solver.profile(reset=True)
+    n = 6.0 * nc
+    tf = 2.0 * n ** 3 / 3.0 / (prof["marginals_inverse"] * 1e-3) / 1e12
+    # a sampled check against the definition: column j of the covariance is the solution of Lambda x = e_j
+    c_np, p_np = cams.cpu().numpy().reshape(nc, 6, 6), pts.cpu().numpy().reshape(n_pts, 3, 3)
+    err = 0.0
+    for (idx, blk, d, base) in ((nc // 3, c_np, 6, 0), (n_pts // 2, p_np, 3, 6 * nc)):
+        e = np.zeros(lam.n_scalars)
+        e[base + d * idx] = 1.0
+        if not solver.Solve_PosDef_Blocky(lam, e):
+            return None
+        ref = e[base + d * idx: base + d * idx + d]
+        err = max(err, float(np.abs(ref - blk[idx][:, 0]).max() / np.abs(ref).max()))
+    out = {"workload": f"block diagonal of Lambda^-1: {nc} camera blocks 6x6 + {n_pts} landmark blocks 3x3", "ok": bool(ok),
+           "ms_per_call": ms, "phases_ms": prof, "column_check_rel_inf": err,
+           "roofline": {"bound": "mfma", "kernel": "inverse_level_kernel + inverse_lauum_kernel (inverse of S from its factor)",
+                        "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS,
+                        "traffic": None, "flops": 2.0 * n ** 3 / 3.0, "ms": prof["marginals_inverse"]}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle_lib as O
+        if O.have_reference():
+            import subprocess
+            sample = dataclasses_replace_points(lam, min(n_pts, 100_000))
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "ba.bin")
+                sample.save(path)
+                t0 = time.perf_counter()
+                r = subprocess.run([O.REF_HARNESS, "schur_marginals", path, os.path.join(td, "m")], capture_output=True, text=True,
+                                   timeout=900)
+                wall = time.perf_counter() - t0
+            if '"ok": true' in r.stdout:
+                out["cpu_baseline"] = {"value": wall * 1e3, "unit": "ms", "cores": os.cpu_count(), "kind": "reference",
+                                       "sample": f"CSchurComplement_Marginals::Schur_Marginals on the first "
+                                                 f"{sample.n_bcols - nc} landmarks of the same system (all {nc} cameras), with the "
+                                                 f"Schur complement and its Cholesky factor it needs, incl. load; OpenMP"}
+    return out
+
+
+def dataclasses_replace_points(lam, n_keep):
+    """The same BA system cut down to its first n_keep landmarks (block columns are stored landmark by landmark)."""
+    from slam_plus_plus_amd.synth import BlockSystem
+    nc = lam.n_matrix_cut
+    n = nc + n_keep
+    nb = int(lam.bcol_ptr[n])
+    off = lam.block_value_offsets()
+    return BlockSystem(lam.cumsum[:n + 1].copy(), lam.bcol_ptr[:n + 1].copy(), lam.brow_idx[:nb].copy(),
+                       lam.values[:off[nb]].copy(), lam.rhs[:int(lam.cumsum[n])].copy(), nc)
+
+
 def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1):
     """C4 (N=1) / landmark-sharded weak scaling (N>1): `--ba-cams` cameras, `--ba-points` points per GPU.
     schur_sparse: -1 = the library decides how to factor the reduced camera system (sparse block path when under 3 %
@@ -426,6 +494,8 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1):
         out["solve_residual_rel_inf"] = float(np.abs(lam.to_scipy() @ x - lam.rhs).max() / np.abs(lam.rhs).max())
         if not args.no_cpu_baseline and schur_sparse != 0:
             out["cpu_baseline"] = cpu_baseline_ba(lam, schur_flops + dense_flops)   # the reference factors S densely
+        if schur_sparse != 0:
+            out["marginals"] = marginals_leg(args, solver, lam, vals, dev, torch)
     return out
 
 

@@ -565,6 +565,55 @@ public:
 			throw std::runtime_error("CLinearSolver_Schur_HIP: no landmarks to marginalize the poses against");
 		return Gather_And_Solve(r_lambda, r_eta, true);
 	}
+
+	/**
+	 *	@brief calculates block diagonal of the covariance matrix (the inverse of lambda); the counterpart of
+	 *		CSchurComplement_Marginals::Schur_Marginals() (BAMarginals.h:579-806), which the reference's solvers
+	 *		call with a Cholesky factor of the Schur complement they compute for the purpose
+	 *		(NonlinearSolver_Lambda_DL.h:1590-1640) -- here lambda is all that is needed
+	 *
+	 *	@param[out] r_cam_cov is filled with camera marginals (one diagonal block per camera,
+	 *		in the order the cameras have in lambda)
+	 *	@param[in] b_do_cam_marginals is camera marginals flag (if not set, r_cam_cov is left empty)
+	 *	@param[out] r_lm_cov is filled with landmark marginals (one diagonal block per landmark,
+	 *		in the order the landmarks have in lambda)
+	 *	@param[in] r_lambda is the system matrix (symmetric layout, upper triangle stored)
+	 *
+	 *	@return Returns true on success, false if lambda is not positive definite.
+	 *	@note This function throws std::bad_alloc and std::runtime_error.
+	 */
+	bool Schur_Marginals(CUberBlockMatrix &r_cam_cov, bool b_do_cam_marginals, CUberBlockMatrix &r_lm_cov,
+		const CUberBlockMatrix &r_lambda) // throw(std::bad_alloc, std::runtime_error)
+	{
+		if(m_n_matrix_cut == size_t(-1) || !b_Structure_Matches(r_lambda))
+			SymbolicDecomposition_Blocky(r_lambda, true);
+		const size_t n = r_lambda.n_BlockColumn_Num(), n_cut = m_n_matrix_cut;
+		if(n_cut == 0 || n_cut == n)
+			throw std::runtime_error("CLinearSolver_Schur_HIP: no landmarks, the system has no Schur complement");
+		Gather_Values(r_lambda);
+		const size_t dc = size_t(m_cumsum[1] - m_cumsum[0]), dp = size_t(m_cumsum[n_cut + 1] - m_cumsum[n_cut]);
+		std::vector<double> cams((b_do_cam_marginals)? n_cut * dc * dc : 0), lms((n - n_cut) * dp * dp);
+		const int n_result = slampp_hip_schur_marginals(m_p_solver, m_values.empty()? 0 : &m_values[0],
+			(b_do_cam_marginals)? &cams[0] : 0, &lms[0]);
+		if(n_result == SLAMPP_HIP_NOT_POSDEF)
+			return false;
+		Throw_On_Error(n_result);
+		r_cam_cov.Clear();
+		r_lm_cov.Clear();
+		for(size_t i = 0; i < n_cut && b_do_cam_marginals; ++ i) {
+			double *p_dest = r_cam_cov.p_GetBlock_Log(i, i, dc, dc, true, false);
+			if(!p_dest)
+				throw std::runtime_error("CLinearSolver_Schur_HIP: cannot write the camera marginals");
+			std::copy(&cams[i * dc * dc], &cams[(i + 1) * dc * dc], p_dest);
+		}
+		for(size_t i = 0; i < n - n_cut; ++ i) {
+			double *p_dest = r_lm_cov.p_GetBlock_Log(i, i, dp, dp, true, false);
+			if(!p_dest)
+				throw std::runtime_error("CLinearSolver_Schur_HIP: cannot write the landmark marginals");
+			std::copy(&lms[i * dp * dp], &lms[(i + 1) * dp * dp], p_dest);
+		}
+		return true;
+	}
 };
 
 #endif // !__LINEAR_SOLVER_HIP_INCLUDED

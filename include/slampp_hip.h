@@ -133,6 +133,20 @@ int slampp_hip_solve_marginal_poses(slampp_hip_solver *p_solver, const double *p
 int slampp_hip_solve_marginal_poses_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,
 	double *p_rhs_inout_dev);
 
+/* Schur mode only: block diagonal of the covariance matrix Lambda^-1 -- the reference's
+ * CSchurComplement_Marginals::Schur_Marginals (include/slam/BAMarginals.h:579-806, called from
+ * NonlinearSolver_Lambda_LM.h:1326 and NonlinearSolver_Lambda_DL.h:1640 with the Cholesky factor of the Schur
+ * complement it has to compute for the purpose).  Here the reduced camera system is assembled, factored and inverted
+ * on the device in one call: p_cam_cov receives n_cams blocks of dc x dc doubles (the diagonal blocks of S^-1; may be
+ * NULL to skip them, as b_do_cam_marginals = false does), p_point_cov n_points blocks of dp x dp doubles
+ * (C_p^-1 + W_p^T S^-1 W_p), column-major, in the block order of slampp_hip_set_structure.  The reduced system is
+ * always taken dense for this (2 x 8 n^2 bytes of device memory, n = n_cams dc).  With landmark shards every rank
+ * calls it, passes its own values and receives the covariances of its own landmarks (the all-reduce callback is
+ * invoked once on the whole n_pad^2 buffer).  Returns SLAMPP_HIP_NOT_POSDEF like the solve. */
+int slampp_hip_schur_marginals(slampp_hip_solver *p_solver, const double *p_values, double *p_cam_cov, double *p_point_cov);
+int slampp_hip_schur_marginals_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,
+	double *p_cam_cov_dev, double *p_point_cov_dev);
+
 /* enqueue-only variants for benchmarking / stream capture: no host synchronisation, no status
  * read-back; slampp_hip_sync() waits and returns OK / NOT_POSDEF / error for everything enqueued */
 int slampp_hip_factor_solve_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,

@@ -30,6 +30,9 @@
 #include "slam/SE2_Types.h"
 #include "slam/SE3_Types.h"
 #include "slam/BA_Types.h"
+#include "slam/OrderingMagic.h"
+#include "slam/Marginals.h"
+#include "slam/BAMarginals.h"
 #include "slam/LinearSolver_HIP.h"
 
 template <class CSystemType, class CLinearSolverType>
@@ -375,6 +378,8 @@ int main(int n_arg_num, const char **p_arg_list)
 				CEdgeP2C3D, MakeTypelist_Safe((CEdgeP2C3D))> TBASystem;
 			typedef CLinearSolver_Schur<CLinearSolver_CholMod, TBASystem::_TyJacobianMatrixBlockList, TBASystem> TRefSchur;
 			typedef CLinearSolver_Schur_HIP<CLinearSolver_CholMod, TBASystem::_TyJacobianMatrixBlockList, TBASystem> THipSchur;
+			CUberBlockMatrix margs_cams_ref, margs_lms_ref;
+			bool b_margs_ref = false;
 			for(int b_interleave = 0; b_interleave < 2; ++ b_interleave) {
 				CUberBlockMatrix lambda;
 				Eigen::VectorXd rhs;
@@ -402,6 +407,56 @@ int main(int n_arg_num, const char **p_arg_list)
 					printf("\"marginal_poses_%s\": {\"ok_ref\": %d, \"ok_hip\": %d, \"rel_inf\": %.3g}, ",
 						b_interleave? "interleaved" : "cams_first", int(b_ref_mp), int(b_hip_mp), f_err_mp);
 					n_fail += !(b_ref_mp && b_hip_mp && f_err_mp < 1e-10);
+				}
+				{ // block diagonal of the covariance: the reference's CSchurComplement_Marginals, fed the way its solvers feed it
+					if(!b_interleave) { // interleaving keeps the cameras and the landmarks in their relative order: one reference result
+						const size_t n = lambda.n_BlockColumn_Num(), n_cut = size_t(p.n_matrix_cut);
+						typedef MakeTypelist_Safe((Eigen::Matrix<double, 6, 6>)) TSC_Bs;
+						typedef MakeTypelist_Safe((Eigen::Matrix<double, 6, 3>)) TU_Bs;
+						typedef MakeTypelist_Safe((Eigen::Matrix<double, 3, 6>)) TV_Bs;
+						typedef MakeTypelist_Safe((Eigen::Matrix<double, 3, 3>)) TD_Bs;
+						typedef MakeTypelist_Safe((Eigen::Matrix<double, 6, 6>, Eigen::Matrix<double, 6, 3>,
+							Eigen::Matrix<double, 3, 6>, Eigen::Matrix<double, 3, 3>)) TAll_Bs;
+						CUberBlockMatrix A, U, C, V, minus_Dinv, minus_U_Dinv, SC, S, SC_perm;
+						lambda.SliceTo(A, 0, n_cut, 0, n_cut, true);
+						lambda.SliceTo(U, 0, n_cut, n_cut, n, true);
+						lambda.SliceTo(C, n_cut, n, n_cut, n, true);
+						U.TransposeTo(V);
+						minus_Dinv.InverseOf_BlockDiag_FBS_Parallel<TAll_Bs>(C);
+						minus_Dinv.Scale(-1.0);
+						U.MultiplyToWith_FBS<TAll_Bs, TAll_Bs>(minus_U_Dinv, minus_Dinv);
+						minus_U_Dinv.MultiplyToWith_FBS<TAll_Bs, TAll_Bs>(SC, V, true);
+						A.AddTo_FBS<TAll_Bs>(SC);
+						CMatrixOrdering SC_mord;
+						SC_mord.p_BlockOrdering(SC, true);
+						SC.Permute_UpperTriangular_To(SC_perm, SC_mord.p_Get_InverseOrdering(), SC_mord.n_Ordering_Size(), true);
+						b_margs_ref = S.CholeskyOf_FBS<TSC_Bs>(SC_perm);
+						if(b_margs_ref) {
+							CSchurComplement_Marginals<TSC_Bs, TU_Bs, TV_Bs, TD_Bs> margs(false);
+							margs.Schur_Marginals(margs_cams_ref, true, margs_lms_ref, S, SC_mord, minus_Dinv, minus_U_Dinv, true);
+						}
+					}
+					CUberBlockMatrix margs_cams, margs_lms;
+					const bool b_margs_hip = hip_solver.Schur_Marginals(margs_cams, true, margs_lms, lambda);
+					double f_cam_err = 0, f_lm_err = 0, f_cam_max = 0, f_lm_max = 0;
+					if(b_margs_ref && b_margs_hip) {
+						for(size_t i = 0, n = margs_cams_ref.n_BlockColumn_Num(); i < n; ++ i) {
+							Eigen::MatrixXd r = margs_cams_ref.t_GetBlock_Log(i, i), h = margs_cams.t_GetBlock_Log(i, i);
+							f_cam_err = std::max(f_cam_err, (r - h).cwiseAbs().maxCoeff());
+							f_cam_max = std::max(f_cam_max, r.cwiseAbs().maxCoeff());
+						}
+						for(size_t i = 0, n = margs_lms_ref.n_BlockColumn_Num(); i < n; ++ i) {
+							Eigen::MatrixXd r = margs_lms_ref.t_GetBlock_Log(i, i), h = margs_lms.t_GetBlock_Log(i, i);
+							f_lm_err = std::max(f_lm_err, (r - h).cwiseAbs().maxCoeff());
+							f_lm_max = std::max(f_lm_max, r.cwiseAbs().maxCoeff());
+						}
+					}
+					const bool b_same_shape = margs_cams.n_BlockColumn_Num() == margs_cams_ref.n_BlockColumn_Num() &&
+						margs_lms.n_BlockColumn_Num() == margs_lms_ref.n_BlockColumn_Num();
+					printf("\"schur_marginals_%s\": {\"ok_ref\": %d, \"ok_hip\": %d, \"cam_rel_inf\": %.3g, \"lm_rel_inf\": %.3g}, ",
+						b_interleave? "interleaved" : "cams_first", int(b_margs_ref), int(b_margs_hip && b_same_shape),
+						f_cam_err / std::max(f_cam_max, 1e-300), f_lm_err / std::max(f_lm_max, 1e-300));
+					n_fail += !(b_margs_ref && b_margs_hip && b_same_shape && f_cam_err < 1e-10 * f_cam_max && f_lm_err < 1e-10 * f_lm_max);
 				}
 				if(!b_interleave) { // a copy keeps the configuration: the reduced system through the sparse block path
 					hip_solver.Set_Option("schur_sparse", 1);

@@ -103,6 +103,38 @@ def assemble_lambda(lam, edges):
     return values, eta
 
 
+def schur_marginals(lam, n_cut=None):
+    """(camera blocks [nc, dc, dc], landmark blocks [np, dp, dp]) of the covariance Lambda^-1 -- numpy restatement of
+    CSchurComplement_Marginals::Schur_Marginals (/root/reference/include/slam/BAMarginals.h:579-806) as its callers
+    feed it (NonlinearSolver_Lambda_DL.h:1590-1640): S = A - U Dinv U^T = R^T R; landmark i gets
+    Dinv_ii + (R^-T U Dinv_i)^T (R^-T U Dinv_i) (BAMarginals.h:703-727), the cameras the diagonal blocks of S^-1
+    (:765-772).  Dense, for test sizes only."""
+    import scipy.linalg as sl
+    n_cut = int(lam.n_matrix_cut if n_cut is None else n_cut)
+    cs = np.asarray(lam.cumsum)
+    nx = int(cs[n_cut])
+    dense = lam.to_scipy().toarray()
+    A, U, D = dense[:nx, :nx], dense[:nx, nx:], dense[nx:, nx:]
+    dc, dp = int(cs[1] - cs[0]), int(cs[n_cut + 1] - cs[n_cut])
+    n_pts = lam.n_bcols - n_cut
+    Dinv = np.zeros_like(D)
+    for i in range(n_pts):
+        sl_ = slice(i * dp, (i + 1) * dp)
+        Dinv[sl_, sl_] = np.linalg.inv(D[sl_, sl_])
+    U_Dinv = U @ Dinv
+    S = A - U_Dinv @ U.T
+    R = np.linalg.cholesky(S).T                                    # upper, S = R^T R
+    B = sl.solve_triangular(R, U_Dinv, trans="T", lower=False)     # R^-T U Dinv, all landmark columns at once
+    pts = np.empty((n_pts, dp, dp))
+    for i in range(n_pts):
+        sl_ = slice(i * dp, (i + 1) * dp)
+        pts[i] = Dinv[sl_, sl_] + B[:, sl_].T @ B[:, sl_]
+    Rinv = sl.solve_triangular(R, np.eye(nx), lower=False)
+    Sinv = Rinv @ Rinv.T
+    cams = np.stack([Sinv[c * dc:(c + 1) * dc, c * dc:(c + 1) * dc] for c in range(n_cut)])
+    return cams, pts
+
+
 def have_reference() -> bool:
     return os.path.exists(REF_HARNESS) and os.access(REF_HARNESS, os.X_OK)
 

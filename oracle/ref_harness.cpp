@@ -41,6 +41,9 @@
  *       writes Lambda with the reference's Save_MatrixMarket / Save_BlockLayout, as its -dsm option does
  *   ref_harness load_mm <in.mtx> <in.bla> <problem>
  *       reads the pair with the reference's Load_MatrixMarket and compares the upper triangle with <problem>
+ *   ref_harness schur_marginals <problem> <out_prefix>
+ *       CSchurComplement_Marginals::Schur_Marginals (include/slam/BAMarginals.h:579) fed as
+ *       NonlinearSolver_Lambda_DL.h:1590-1640 feeds it: block diagonal of the covariance
  *   ref_harness schur_dump <problem> <out_prefix>
  *       replays LinearSolver_Schur.h:1687-1886 with public CUberBlockMatrix calls and dumps
  *       S (dense, col-major), reduced rhs, dx, dl, x as raw doubles
@@ -59,6 +62,9 @@
 #include "slam/ConfigSolvers.h"
 #include "slam/BA_Types.h"
 #include "slam/LinearSolver_Schur.h"
+#include "slam/OrderingMagic.h"
+#include "slam/Marginals.h"
+#include "slam/BAMarginals.h"
 #include "slam/SE2_Types.h"
 #include "slam/SE3_Types.h"
 #include "slam/Timer.h"
@@ -357,6 +363,68 @@ static int Main_SchurDump(int argc, char **argv)
 }
 
 /**
+ *	@brief block diagonal of the covariance of a BA system: the steps NonlinearSolver_Lambda_DL.h:1590-1640 takes
+ *		before it calls CSchurComplement_Marginals::Schur_Marginals (include/slam/BAMarginals.h:579-806), then that
+ *		call; the system is already ordered cameras-first.  Writes <prefix>.cam_cov.bin (n_cams blocks 6x6) and
+ *		<prefix>.lm_cov.bin (n_points blocks 3x3), column-major.
+ */
+static int Main_SchurMarginals(int argc, char **argv)
+{
+	if(argc < 4) return 2;
+	TProblem p;
+	if(!Read_Problem(argv[2], p)) return 1;
+	std::string prefix = argv[3];
+	CUberBlockMatrix lambda;
+	Build_Lambda(p, lambda);
+	const size_t n = lambda.n_BlockColumn_Num(), n_cut = size_t(p.n_matrix_cut);
+	if(!n_cut || n_cut >= n) { fprintf(stderr, "error: n_matrix_cut not set\n"); return 1; }
+	typedef TBlocks_BA TBs;
+	typedef MakeTypelist_Safe((Eigen::Matrix<double, 6, 6>)) TSC_Bs;
+	typedef MakeTypelist_Safe((Eigen::Matrix<double, 6, 3>)) TU_Bs;
+	typedef MakeTypelist_Safe((Eigen::Matrix<double, 3, 6>)) TV_Bs;
+	typedef MakeTypelist_Safe((Eigen::Matrix<double, 3, 3>)) TD_Bs;
+	CUberBlockMatrix A, U, C, V;
+	lambda.SliceTo(A, 0, n_cut, 0, n_cut, true);
+	lambda.SliceTo(U, 0, n_cut, n_cut, n, true);
+	lambda.SliceTo(C, n_cut, n, n_cut, n, true);
+	U.TransposeTo(V);
+	if(!C.b_BlockDiagonal()) { fprintf(stderr, "error: C is not block diagonal\n"); return 1; }
+	CUberBlockMatrix minus_Dinv;
+	minus_Dinv.InverseOf_BlockDiag_FBS_Parallel<TBs>(C);
+	minus_Dinv.Scale(-1.0);
+	CUberBlockMatrix minus_U_Dinv, SC;
+	U.MultiplyToWith_FBS<TBs, TBs>(minus_U_Dinv, minus_Dinv);
+	minus_U_Dinv.MultiplyToWith_FBS<TBs, TBs>(SC, V, true);
+	A.AddTo_FBS<TBs>(SC);
+	CUberBlockMatrix S, SC_perm;
+	CMatrixOrdering SC_mord;
+	SC_mord.p_BlockOrdering(SC, true);
+	SC.Permute_UpperTriangular_To(SC_perm, SC_mord.p_Get_InverseOrdering(), SC_mord.n_Ordering_Size(), true);
+	if(!S.CholeskyOf_FBS<TSC_Bs>(SC_perm)) {
+		printf("{\"ok\": false}\n");
+		return 3;
+	}
+	CSchurComplement_Marginals<TSC_Bs, TU_Bs, TV_Bs, TD_Bs> margs(false);
+	CUberBlockMatrix margs_cams, margs_lms;
+	margs.Schur_Marginals(margs_cams, true, margs_lms, S, SC_mord, minus_Dinv, minus_U_Dinv, true);
+	std::vector<double> cams(n_cut * 36), lms((n - n_cut) * 9);
+	for(size_t i = 0; i < n_cut; ++ i) {
+		Eigen::Matrix<double, 6, 6> b = margs_cams.t_GetBlock_Log(i, i);
+		std::copy(b.data(), b.data() + 36, cams.begin() + i * 36);
+	}
+	for(size_t i = 0; i < n - n_cut; ++ i) {
+		Eigen::Matrix<double, 3, 3> b = margs_lms.t_GetBlock_Log(i, i);
+		std::copy(b.data(), b.data() + 9, lms.begin() + i * 9);
+	}
+	if(!Write_Doubles((prefix + ".cam_cov.bin").c_str(), &cams[0], cams.size()) ||
+	   !Write_Doubles((prefix + ".lm_cov.bin").c_str(), &lms[0], lms.size()))
+		return 1;
+	printf("{\"ok\": true, \"n_cams\": %ld, \"n_points\": %ld, \"S_blocks\": %ld}\n", (long)n_cut, (long)(n - n_cut),
+		(long)SC.n_Block_Num());
+	return 0;
+}
+
+/**
  *	@brief a linear solver that records the first system it is asked to solve, then lets CHOLMOD solve it
  */
 struct TRecordedSystem {
@@ -592,6 +660,8 @@ int main(int argc, char **argv)
 				return Main_CholmodPhases(argc, argv);
 			if(!strcmp(argv[1], "schur_dump"))
 				return Main_SchurDump(argc, argv);
+			if(!strcmp(argv[1], "schur_marginals"))
+				return Main_SchurMarginals(argc, argv);
 			if(!strcmp(argv[1], "lambda_dump"))
 				return Main_LambdaDump(argc, argv);
 		} catch(std::exception &r_exc) {

@@ -63,4 +63,10 @@ void dense_backsolve(const double *M, int n_pad, int n, const double *p_invdiag,
 // replaced by y, ready for dense_backsolve
 void dense_forwardsolve(double *M, int n_pad, const double *p_invdiag, hipStream_t stream);
 
+// Inverse of the matrix from its factor: on entry M holds L (dense_cholesky) and p_invdiag the inverses of its
+// diagonal tiles; on return M holds X = inv(L) (lower; diagonal tiles as full tiles with zeros above) and Z the
+// inverse X^T X = inv(L L^T): its lower tiles and the whole of its diagonal tiles (Z also serves as the scratch of
+// the first step).  2 n^3 / 3 flops in 2 log2(n / 64) + 2 launches.
+void dense_inverse_from_factor(double *M, int n_pad, const double *p_invdiag, double *Z, hipStream_t stream);
+
 } // namespace slampp

@@ -56,6 +56,8 @@ struct CSchurState {
 	CDevArray<int64_t> d_sb_dst, d_a_dst;      // where the blocks of S this rank computes / the camera blocks of Lambda sit
 	                                           // in the packed upper block-CSC values of the inner solver
 	CDevArray<double> d_in_buf;                // [values (n_in_blocks DC^2) | right-hand side (N)]: also what the ranks exchange
+	// marginal covariances (own buffers: the factor the last solve left behind stays usable)
+	CDevArray<double> d_m_S, d_m_Z, d_m_invdiag, d_m_zero;
 	CSchurState() :p_union_fn(0), p_union_context(0), b_union_dense(false), n_union(0), b_reduced_decided(false),
 		b_reduced_sparse(false), p_inner(0), n_in_blocks(0) {}
 	~CSchurState();
@@ -77,7 +79,8 @@ size_t schur_device_bytes(const CSchurState *p)
 		p->d_sb_row.n_Bytes() + p->d_sb_col.n_Bytes() + p->d_ent_a.n_Bytes() + p->d_ent_uoff.n_Bytes() +
 		p->d_cam_ptr.n_Bytes() + p->d_cam_obs.n_Bytes() + p->d_S.n_Bytes() + p->d_W.n_Bytes() +
 		p->d_un_row.n_Bytes() + p->d_un_col.n_Bytes() + p->d_pack.n_Bytes() + p->d_sb_dst.n_Bytes() + p->d_a_dst.n_Bytes() +
-		p->d_in_buf.n_Bytes() + (p->p_inner? p->p_inner->n_Device_Bytes() : 0) +
+		p->d_in_buf.n_Bytes() + (p->p_inner? p->p_inner->n_Device_Bytes() : 0) + p->d_m_S.n_Bytes() + p->d_m_Z.n_Bytes() +
+		p->d_m_invdiag.n_Bytes() + p->d_m_zero.n_Bytes() +
 		p->d_Cinv.n_Bytes() + p->d_t.n_Bytes() + p->d_invdiag.n_Bytes() + p->d_z.n_Bytes() + p->d_x.n_Bytes();
 }
 
@@ -971,6 +974,81 @@ static void schur_enqueue_marginal_t(slampp_hip_solver &s, CSchurState &S, const
 		S.np, S.N, S.d_Cinv.p(), rhs);
 	s.Phase_End();
 	SLAMPP_HIP_CHECK(hipGetLastError());
+}
+
+void schur_marginals_launch(int DC, int DP, int64_t nc, int64_t np, const int64_t *ptr, const int32_t *brow, const double *W,
+	const double *Cinv, const double *Z, int ld, double *cam_cov, double *point_cov, hipStream_t stream); // schur_marginals.hip
+
+// Block diagonal of Lambda^-1 (see schur_marginals.hip): the reduced system is assembled into a dense buffer of its
+// own whatever way the solves factor it, factored, inverted on the matrix cores, then gathered per landmark.
+// Landmark shards: S is summed over the ranks as a whole buffer (the padding diagonal comes back as the number
+// of ranks, which its decoupled rows do not mind); every rank then writes the covariances of its own landmarks.
+template <int DC, int DP>
+static void schur_enqueue_marginals_t(slampp_hip_solver &s, CSchurState &S, const double *A, double *cam_cov, double *point_cov)
+{
+	hipStream_t st = s.stream;
+	const int ld = S.Npad, n = S.N;
+	const int64_t ubase = S.n_ablocks * DC * DC;
+	if(!S.d_m_S.p()) {
+		S.d_m_S.Alloc(size_t(ld) * ld);
+		S.d_m_Z.Alloc(size_t(ld) * ld);
+		S.d_m_invdiag.Alloc(size_t(ld / dense_NB) * dense_NB * dense_NB);
+		S.d_m_zero.Alloc(size_t(n));
+		SLAMPP_HIP_CHECK(hipMemsetAsync(S.d_m_zero.p(), 0, size_t(n) * sizeof(double), st));
+	}
+	double *p_S = S.d_m_S.p();
+	SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), st));
+	s.Phase_Begin("marginals_assemble");
+	SLAMPP_HIP_CHECK(hipMemsetAsync(p_S, 0, size_t(ld) * ld * sizeof(double), st));
+	dense_prepare_padding(p_S, ld, n, st);
+	if(s.b_shard_primary) {
+		const int64_t n_work = std::max<int64_t>(S.n_ablocks * DC * DC, n);
+		hipLaunchKernelGGL((schur_scatter_A_kernel<DC>), dim3(unsigned((n_work + 255) / 256)), dim3(256), 0, st,
+			S.d_ptr.p(), S.d_brow.p(), S.nc, A, S.d_m_zero.p(), p_S, ld, n, (const int64_t*)0, (double*)0);
+	}
+	hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((S.np + 255) / 256)), dim3(256), 0, st,
+		S.d_ptr.p(), S.nc, S.np, ubase, A, S.d_Cinv.p(), s.d_flag.p());
+	hipLaunchKernelGGL((schur_obs_W_kernel<DC, DP>), dim3(unsigned((S.n_obs + 255) / 256)), dim3(256), 0, st,
+		S.n_obs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p());
+	if(S.n_sblocks > 0) {
+		if(S.n_entries > 256 * S.n_sblocks)
+			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 8>), dim3(unsigned(S.n_sblocks)), dim3(512), 0, st,
+				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
+				S.d_W.p(), p_S, ld, (const int64_t*)0);
+		else
+			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 1>), dim3(unsigned(S.n_sblocks)), dim3(64), 0, st,
+				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
+				S.d_W.p(), p_S, ld, (const int64_t*)0);
+	}
+	s.Phase_End();
+	if(s.p_allreduce) {
+		s.Phase_Begin("allreduce");
+		if(s.p_allreduce(s.p_allreduce_context, p_S, size_t(ld) * ld, (void*)st) != 0)
+			throw CDeviceError("all-reduce callback failed");
+		s.Phase_End();
+	}
+	s.Phase_Begin("marginals_factor");
+	dense_cholesky(p_S, ld, n, S.d_m_invdiag.p(), s.d_flag.p(), st);
+	s.Phase_End();
+	s.Phase_Begin("marginals_inverse");
+	dense_inverse_from_factor(p_S, ld, S.d_m_invdiag.p(), S.d_m_Z.p(), st);
+	s.Phase_End();
+	s.Phase_Begin("marginals_gather");
+	schur_marginals_launch(DC, DP, S.nc, S.np, S.d_ptr.p(), S.d_brow.p(), S.d_W.p(), S.d_Cinv.p(), S.d_m_Z.p(), ld,
+		cam_cov, point_cov, st);
+	s.Phase_End();
+	SLAMPP_HIP_CHECK(hipGetLastError());
+}
+
+void schur_enqueue_marginals(slampp_hip_solver &s, const double *p_values_dev, double *p_cam_cov_dev, double *p_point_cov_dev)
+{
+	CSchurState &S = *s.p_schur;
+	if(S.DC == 6 && S.DP == 3)
+		schur_enqueue_marginals_t<6, 3>(s, S, p_values_dev, p_cam_cov_dev, p_point_cov_dev);
+	else if(S.DC == 7 && S.DP == 3)
+		schur_enqueue_marginals_t<7, 3>(s, S, p_values_dev, p_cam_cov_dev, p_point_cov_dev);
+	else
+		schur_enqueue_marginals_t<3, 2>(s, S, p_values_dev, p_cam_cov_dev, p_point_cov_dev);
 }
 
 // the reference's Solve_PosDef_Blocky_MarginalPoses (LinearSolver_Schur.h:1956-2143): the landmarks' block of the

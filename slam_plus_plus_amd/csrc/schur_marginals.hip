@@ -1,0 +1,110 @@
+// schur_marginals.hip -- block diagonal of the covariance Lambda^-1 of a BA system from its Schur complement:
+//   cameras    Sigma_cc = blocks (c, c) of Z = S^-1
+//   landmarks  Sigma_pp = C_p^-1 + sum over the cameras a, b observing p of W_a^T Z(a,b) W_b,   W_o = U_o C_p^-1
+// which is what CSchurComplement_Marginals::Schur_Marginals computes
+// (/root/reference/include/slam/BAMarginals.h:579-806: Dinv + (R^-T U Dinv)^T (R^-T U Dinv) with S = R^T R, and the
+// diagonal blocks of S^-1 by the recursive formula).  Z is dense here (dense_inverse.hip): only its lower triangle
+// and the whole of its diagonal 64 x 64 tiles are valid, element (i, j) is read as (max, min).
+// The landmark kernel is a gather: k (k + 1) / 2 blocks of Z per landmark with k observations, DC column segments
+// each; neighbouring landmarks see neighbouring cameras, so most of them come out of L2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace slampp {
+
+template <int DC>
+__global__ void schur_cam_cov_kernel(int64_t nc, const double *__restrict__ Z, int ld, double *out)
+{
+	const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(gid >= nc * (DC * DC))
+		return;
+	const int64_t c = gid / (DC * DC);
+	const int e = int(gid - c * (DC * DC)), r = e % DC, q = e / DC;
+	const int hi = (r > q)? r : q, lo = (r > q)? q : r;
+	out[gid] = Z[size_t(c * DC + hi) + size_t(c * DC + lo) * ld];
+}
+
+template <int DC, int DP>
+__global__ void __launch_bounds__(128)
+schur_point_cov_kernel(const int64_t *__restrict__ ptr, const int32_t *__restrict__ brow, int64_t nc, int64_t np,
+	const double *__restrict__ W, const double *__restrict__ Cinv, const double *__restrict__ Z, int ld, double *out)
+{
+	const int64_t pt = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(pt >= np)
+		return;
+	const int64_t k0 = ptr[nc + pt], k1 = ptr[nc + pt + 1] - 1; // the last block of the column is C_p itself
+	const int64_t o0 = k0 - ptr[nc] - pt;
+	double cov[DP * DP];
+	#pragma unroll
+	for(int i = 0; i < DP * DP; ++ i)
+		cov[i] = Cinv[pt * (DP * DP) + i];
+	for(int64_t a = k0; a < k1; ++ a) {
+		const int64_t ca = brow[a];
+		double wa[DC * DP];
+		#pragma unroll
+		for(int i = 0; i < DC * DP; ++ i)
+			wa[i] = W[(o0 + (a - k0)) * (DC * DP) + i];
+		for(int64_t b = k0; b <= a; ++ b) { // block rows ascend inside a column: cb <= ca, the lower triangle of Z
+			const int64_t cb = brow[b];
+			double wb[DC * DP], t[DC * DP];
+			#pragma unroll
+			for(int i = 0; i < DC * DP; ++ i) {
+				wb[i] = W[(o0 + (b - k0)) * (DC * DP) + i];
+				t[i] = 0;
+			}
+			#pragma unroll
+			for(int q = 0; q < DC; ++ q) {
+				#pragma unroll
+				for(int r = 0; r < DC; ++ r) {
+					const int hi = (r > q)? r : q, lo = (r > q)? q : r;
+					const double z = (a == b)? Z[size_t(ca * DC + hi) + size_t(ca * DC + lo) * ld] :
+						Z[size_t(ca * DC + r) + size_t(cb * DC + q) * ld];
+					#pragma unroll
+					for(int j = 0; j < DP; ++ j)
+						t[r + j * DC] += z * wb[q + j * DC];
+				}
+			}
+			#pragma unroll
+			for(int j = 0; j < DP; ++ j) {
+				#pragma unroll
+				for(int i = 0; i < DP; ++ i) {
+					double sum = 0;
+					#pragma unroll
+					for(int r = 0; r < DC; ++ r)
+						sum += wa[r + i * DC] * t[r + j * DC];
+					cov[i + j * DP] += sum;
+					if(a != b)
+						cov[j + i * DP] += sum; // the mirrored pair (b, a) contributes the transpose
+				}
+			}
+		}
+	}
+	#pragma unroll
+	for(int i = 0; i < DP * DP; ++ i)
+		out[pt * (DP * DP) + i] = cov[i];
+}
+
+template <int DC, int DP>
+static void launch_t(int64_t nc, int64_t np, const int64_t *ptr, const int32_t *brow, const double *W, const double *Cinv,
+	const double *Z, int ld, double *cam_cov, double *point_cov, hipStream_t stream)
+{
+	if(cam_cov)
+		hipLaunchKernelGGL((schur_cam_cov_kernel<DC>), dim3(unsigned((nc * DC * DC + 255) / 256)), dim3(256), 0, stream,
+			nc, Z, ld, cam_cov);
+	if(point_cov)
+		hipLaunchKernelGGL((schur_point_cov_kernel<DC, DP>), dim3(unsigned((np + 127) / 128)), dim3(128), 0, stream,
+			ptr, brow, nc, np, W, Cinv, Z, ld, point_cov);
+}
+
+void schur_marginals_launch(int DC, int DP, int64_t nc, int64_t np, const int64_t *ptr, const int32_t *brow, const double *W,
+	const double *Cinv, const double *Z, int ld, double *cam_cov, double *point_cov, hipStream_t stream)
+{
+	if(DC == 6 && DP == 3)
+		launch_t<6, 3>(nc, np, ptr, brow, W, Cinv, Z, ld, cam_cov, point_cov, stream);
+	else if(DC == 7 && DP == 3)
+		launch_t<7, 3>(nc, np, ptr, brow, W, Cinv, Z, ld, cam_cov, point_cov, stream);
+	else
+		launch_t<3, 2>(nc, np, ptr, brow, W, Cinv, Z, ld, cam_cov, point_cov, stream);
+}
+
+} // namespace slampp

@@ -118,7 +118,7 @@ struct slampp_hip_solver {
 	bool b_dense_tiles;                // use it (its dependent chain is clearly shorter than the tile count)
 	int n_dense_top_tiles;             // option: -1 = decide per structure, 0 = always the dense schedule, 1 = always the tile schedule
 	int n_dense_blks, n_dense_cols, n_dense_dim, n_dense_pad;
-	slampp::CDevArray<double> d_A, d_rhs, d_L, d_Linv, d_w;
+	slampp::CDevArray<double> d_A, d_rhs, d_L, d_Linv, d_w, d_cov;
 	slampp::CDevArray<int> d_flag;
 	int *p_host_flag; // pinned
 
@@ -159,6 +159,7 @@ void schur_destroy(CSchurState *p);
 CSchurState *schur_analyze(slampp_hip_solver &s); // throws
 void schur_enqueue(slampp_hip_solver &s, const double *p_values_dev, double *p_rhs_dev); // throws
 void schur_enqueue_marginal_poses(slampp_hip_solver &s, const double *p_values_dev, double *p_rhs_dev); // throws
+void schur_enqueue_marginals(slampp_hip_solver &s, const double *p_values_dev, double *p_cam_cov_dev, double *p_point_cov_dev); // throws
 size_t schur_device_bytes(const CSchurState *p);
 void schur_fill_stats(const CSchurState *p, slampp_hip_stats &st);
 

@@ -60,7 +60,7 @@ size_t slampp_hip_solver::n_Device_Bytes() const
 	return d_dense_blks.n_Bytes() + d_dense_cols.n_Bytes() + d_dense.n_Bytes() + d_dense_invdiag.n_Bytes() + dense_tiles.n_Bytes() +
 		d_dense_z.n_Bytes() + d_dense_x.n_Bytes() + d_cols.n_Bytes() + d_blks.n_Bytes() + d_rents.n_Bytes() +
 		d_task_ptr.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
-		d_rhs.n_Bytes() + d_L.n_Bytes() + d_Linv.n_Bytes() + d_w.n_Bytes() + d_flag.n_Bytes() +
+		d_rhs.n_Bytes() + d_L.n_Bytes() + d_Linv.n_Bytes() + d_w.n_Bytes() + d_cov.n_Bytes() + d_flag.n_Bytes() +
 		(p_schur? schur_device_bytes(p_schur) : 0);
 }
 
@@ -697,6 +697,64 @@ int slampp_hip_solve_marginal_poses_device_async(slampp_hip_solver *p_solver, co
 		s.b_factored = false; // no factor of the reduced system comes out of this
 		return SLAMPP_HIP_OK;
 	});
+}
+
+int slampp_hip_schur_marginals_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,
+	double *p_cam_cov_dev, double *p_point_cov_dev)
+{
+	return guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_analyzed)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "schur_marginals: analyze was not called");
+		if(s.n_mode != SLAMPP_HIP_MODE_SCHUR)
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "schur_marginals: needs the Schur mode (cameras and landmarks)");
+		if(!p_values_dev || (!p_cam_cov_dev && !p_point_cov_dev))
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "schur_marginals: null pointer");
+		schur_enqueue_marginals(s, p_values_dev, p_cam_cov_dev, p_point_cov_dev);
+		s.b_factored = false; // C^-1 and W were recomputed from these values: a kept factor may no longer match them
+		return SLAMPP_HIP_OK;
+	});
+}
+
+int slampp_hip_schur_marginals(slampp_hip_solver *p_solver, const double *p_values, double *p_cam_cov, double *p_point_cov)
+{
+	size_t n_cam_doubles = 0, n_point_doubles = 0;
+	int n_result = guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_analyzed)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "schur_marginals: analyze was not called");
+		if(s.n_mode != SLAMPP_HIP_MODE_SCHUR)
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "schur_marginals: needs the Schur mode (cameras and landmarks)");
+		if(!p_values || (!p_cam_cov && !p_point_cov))
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "schur_marginals: null pointer");
+		const int64_t nc = s.n_matrix_cut, np = int64_t(s.cumsum.size()) - 1 - nc;
+		const int64_t dc = s.cumsum[1] - s.cumsum[0], dp = s.cumsum[nc + 1] - s.cumsum[nc];
+		n_cam_doubles = size_t(nc * dc * dc);
+		n_point_doubles = size_t(np * dp * dp);
+		s.d_A.Alloc(size_t(s.n_values));
+		s.d_cov.Alloc(n_cam_doubles + n_point_doubles);
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_A.p(), p_values, size_t(s.n_values) * sizeof(double), hipMemcpyHostToDevice, s.stream));
+		return SLAMPP_HIP_OK;
+	});
+	if(n_result != SLAMPP_HIP_OK)
+		return n_result;
+	slampp_hip_solver &s = *p_solver;
+	n_result = slampp_hip_schur_marginals_device_async(p_solver, s.d_A.p(), p_cam_cov? s.d_cov.p() : 0,
+		p_point_cov? s.d_cov.p() + n_cam_doubles : 0);
+	if(n_result == SLAMPP_HIP_OK)
+		n_result = slampp_hip_sync(p_solver);
+	if(n_result == SLAMPP_HIP_OK) {
+		n_result = guarded(p_solver, [&]() -> int {
+			if(p_cam_cov)
+				SLAMPP_HIP_CHECK(hipMemcpyAsync(p_cam_cov, s.d_cov.p(), n_cam_doubles * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+			if(p_point_cov)
+				SLAMPP_HIP_CHECK(hipMemcpyAsync(p_point_cov, s.d_cov.p() + n_cam_doubles, n_point_doubles * sizeof(double),
+					hipMemcpyDeviceToHost, s.stream));
+			SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+			return SLAMPP_HIP_OK;
+		});
+	}
+	return n_result;
 }
 
 int slampp_hip_solve_marginal_poses(slampp_hip_solver *p_solver, const double *p_values, double *p_rhs_inout)

@@ -84,6 +84,8 @@ ABI = {
     "slampp_hip_factorize": (C.c_int, [_P, _P, _P]),
     "slampp_hip_solve_marginal_poses": (C.c_int, [_P, _P, _P]),
     "slampp_hip_solve_marginal_poses_device_async": (C.c_int, [_P, _P, _P]),
+    "slampp_hip_schur_marginals": (C.c_int, [_P, _P, _P, _P]),
+    "slampp_hip_schur_marginals_device_async": (C.c_int, [_P, _P, _P, _P]),
     "slampp_hip_factor_solve_device_async": (C.c_int, [_P, _P, _P]),
     "slampp_hip_sync": (C.c_int, [_P]),
     "slampp_hip_stream": (_P, [_P]),
@@ -383,6 +385,29 @@ class CLinearSolver_Schur_HIP(_SolverBase):
             self.SymbolicDecomposition_Blocky(lam, True)
         vals = np.ascontiguousarray(lam.values, dtype=np.float64)
         return self._check(self._lib.slampp_hip_solve_marginal_poses(self._h, _ptr(vals), _ptr(eta)))
+
+    def Schur_Marginals(self, lam, b_do_cam_marginals: bool = True):
+        """Block diagonal of the covariance Lambda^-1, as CSchurComplement_Marginals::Schur_Marginals returns it
+        (BAMarginals.h:579-806): (camera blocks [nc, dc, dc] or None, landmark blocks [np, dp, dp]); the reduced
+        camera system is assembled, factored and inverted on the device.  Raises if Lambda is not positive definite."""
+        if not self._analyzed or self._structure_key != self._key(lam):
+            self.SymbolicDecomposition_Blocky(lam, True)
+        nc = self._n_matrix_cut(lam)
+        dims = np.diff(lam.cumsum)
+        dc, dp = int(dims[0]), int(dims[nc])
+        cams = np.empty((nc, dc, dc), dtype=np.float64) if b_do_cam_marginals else None
+        pts = np.empty((len(dims) - nc, dp, dp), dtype=np.float64)
+        vals = np.ascontiguousarray(lam.values, dtype=np.float64)
+        ok = self._check(self._lib.slampp_hip_schur_marginals(self._h, _ptr(vals), _ptr(cams) if cams is not None else None,
+                                                              _ptr(pts)))
+        if not ok:
+            raise ArithmeticError("Schur_Marginals: the system is not positive definite")
+        # blocks are column-major and symmetric: the C-order view is the same matrix
+        return cams, pts
+
+    def schur_marginals_device_async(self, values_ptr: int, cam_cov_ptr: int, point_cov_ptr: int) -> None:
+        self._check(self._lib.slampp_hip_schur_marginals_device_async(self._h, values_ptr, cam_cov_ptr or None,
+                                                                      point_cov_ptr or None))
 
 
 class CLambdaAssembly_HIP:

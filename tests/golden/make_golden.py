@@ -13,6 +13,8 @@ reference's own solver classes on those inputs:
     x_schur, S, rhs_reduced (BA)     : CLinearSolver_Schur<...>::Solve_PosDef and the intermediates of
                                        its steps replayed through public CUberBlockMatrix calls
     x_schur_marginal_poses (BA)      : CLinearSolver_Schur<...>::Solve_PosDef_Blocky_MarginalPoses (landmarks only)
+    cam_cov, lm_cov (BA)             : CSchurComplement_Marginals::Schur_Marginals, fed as NonlinearSolver_Lambda_DL.h:1590-1640
+                                       feeds it: the diagonal blocks of the covariance Lambda^-1
     ok_* (negative case)             : the boolean each solver returned
     assembly_*.npz                   : `ref_harness lambda_dump`: a pose graph built from the reference's own
                                        vertex / edge types; per edge the Jacobians, Sigma^-1, error and robust
@@ -82,6 +84,9 @@ def main():
                 rec["S"] = np.fromfile(os.path.join(td, "sd.S.bin")).reshape(N, N).T.copy()   # [row, col], upper triangle
                 rec["rhs_reduced"] = np.fromfile(os.path.join(td, "sd.rhs_reduced.bin"))
                 rec["x_schur_steps"] = np.fromfile(os.path.join(td, "sd.x.bin"))
+                assert run(["schur_marginals", prob, os.path.join(td, "sm")])["ok"]
+                rec["cam_cov"] = np.fromfile(os.path.join(td, "sm.cam_cov.bin")).reshape(-1, 6, 6)   # symmetric blocks
+                rec["lm_cov"] = np.fromfile(os.path.join(td, "sm.lm_cov.bin")).reshape(-1, 3, 3)
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **rec)
         print(f"{name}: n={lam.n_scalars} blocks={lam.n_blocks} -> {os.path.getsize(path) / 1024:.1f} KiB",

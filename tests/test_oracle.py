@@ -108,3 +108,19 @@ def test_marginal_poses_restatement(name):
         s0 = int(lam.cumsum[nc + p])
         x[s0:s0 + d] = np.linalg.solve(Cp, lam.rhs[s0:s0 + d])
     assert rel_inf(x, ref["x_schur_marginal_poses"]) < 1e-13
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("ba_")])
+def test_schur_marginals_restatement(name):
+    """BAMarginals.h:579-806 restated in numpy against what the reference's CSchurComplement_Marginals returned, and
+    against the definition (the diagonal blocks of the inverse of the whole Lambda)."""
+    lam, ref = load_golden(name)
+    cams, pts = O.schur_marginals(lam)
+    assert rel_inf(cams, ref["cam_cov"]) < 1e-12
+    assert rel_inf(pts, ref["lm_cov"]) < 1e-12
+    full = np.linalg.inv(lam.to_scipy().toarray())
+    nx = int(lam.cumsum[lam.n_matrix_cut])
+    for c in (0, lam.n_matrix_cut - 1):
+        assert rel_inf(cams[c], full[6 * c:6 * c + 6, 6 * c:6 * c + 6]) < 1e-11
+    for p in (0, len(pts) - 1):
+        assert rel_inf(pts[p], full[nx + 3 * p:nx + 3 * p + 3, nx + 3 * p:nx + 3 * p + 3]) < 1e-11

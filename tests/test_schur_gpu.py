@@ -269,3 +269,86 @@ def test_marginal_poses_needs_schur_mode():
     lam = synth.pose_chain(n=50, d=6)
     with pytest.raises(NotImplementedError):
         CLinearSolver_Schur_HIP().Solve_PosDef_Blocky_MarginalPoses(lam, lam.rhs.copy())
+
+
+@pytest.mark.parametrize("name", ["ba_12x150_venice", "ba_10x120_band"])
+def test_schur_marginals_match_reference(name):
+    """Block diagonal of the covariance against CSchurComplement_Marginals::Schur_Marginals' output (golden)."""
+    from golden_util import load_golden
+    lam, ref = load_golden(name)
+    solver = CLinearSolver_Schur_HIP()
+    cams, pts = solver.Schur_Marginals(lam)
+    assert rel_inf(cams, ref["cam_cov"]) < TOL
+    assert rel_inf(pts, ref["lm_cov"]) < TOL
+    # per block as well: small blocks must not hide behind the largest one
+    for got, want in ((cams, ref["cam_cov"]), (pts, ref["lm_cov"])):
+        err = np.abs(got - want).reshape(len(got), -1).max(axis=1) / np.abs(want).reshape(len(got), -1).max(axis=1)
+        assert err.max() < 1e-9
+    # solving on the same handle before and after is unaffected
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef_Blocky(lam, eta) and rel_inf(eta, ref["x_schur"]) < TOL
+    _, pts2 = solver.Schur_Marginals(lam, b_do_cam_marginals=False)
+    assert np.array_equal(pts, pts2)
+
+
+MARGINAL_CASES = {
+    "band_sparse_reduced": (lambda: synth.ba(200, 6000, k=4, mode="band", seed=21), {}),     # the solves use the sparse S
+    "uniform_dense_S": (lambda: synth.ba(40, 3000, k=4, mode="uniform", seed=22), {}),
+    "venice_ragged": (lambda: synth.ba(70, 2500, mode="venice", seed=23), {}),
+    "sim3_7x7": (lambda: synth.ba(25, 1200, k=3, cam_dim=7, pt_dim=3, seed=24), {}),
+    "se2_3x2": (lambda: synth.ba(30, 900, k=3, cam_dim=3, pt_dim=2, seed=25), {}),
+    "k1_single_obs": (lambda: synth.ba(30, 400, k=1, seed=26), {}),
+    "n63_one_tile": (lambda: synth.ba(9, 300, k=3, cam_dim=7, pt_dim=3, seed=27), {}),
+    "n192_tile_multiple": (lambda: synth.ba(32, 900, k=4, seed=28), {}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MARGINAL_CASES))
+def test_schur_marginals_parity_with_oracle(name):
+    make, opts = MARGINAL_CASES[name]
+    lam = make()
+    cams_ref, pts_ref = O.schur_marginals(lam)
+    solver = CLinearSolver_Schur_HIP(**opts)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta)
+    cams, pts = solver.Schur_Marginals(lam)
+    assert rel_inf(cams, cams_ref) < TOL and rel_inf(pts, pts_ref) < TOL
+    assert np.abs(cams - cams.transpose(0, 2, 1)).max() == 0.0           # symmetric by construction
+    assert rel_inf(pts, pts.transpose(0, 2, 1)) < 1e-14
+
+
+def test_schur_marginals_full_size_properties():
+    """C4-sized: no oracle at this size; the identity Sigma_pp = C_p^-1 + W_p^T Sigma_cc' W_p is checked through
+    Lambda Sigma = I on sampled block columns instead: Lambda_pp Sigma_pp + sum_c U_cp^T Sigma_cp = I needs the
+    off-diagonal blocks, so the check uses solves -- column j of Sigma is the solution of Lambda x = e_j."""
+    lam = synth.ba(300, 60000, k=4, mode="band", seed=31)
+    solver = CLinearSolver_Schur_HIP()
+    cams, pts = solver.Schur_Marginals(lam)
+    nc = lam.n_matrix_cut
+    nx = int(lam.cumsum[nc])
+    rng = np.random.default_rng(0)
+    for c in rng.integers(0, nc, 3):
+        for j in range(6):
+            e = np.zeros(lam.n_scalars)
+            e[6 * c + j] = 1.0
+            assert solver.Solve_PosDef_Blocky(lam, e)
+            assert rel_inf(e[6 * c:6 * c + 6], cams[c][:, j]) < 1e-9
+    for p in rng.integers(0, lam.n_bcols - nc, 3):
+        for j in range(3):
+            e = np.zeros(lam.n_scalars)
+            e[nx + 3 * p + j] = 1.0
+            assert solver.Solve_PosDef_Blocky(lam, e)
+            assert rel_inf(e[nx + 3 * p:nx + 3 * p + 3], pts[p][:, j]) < 1e-9
+
+
+def test_schur_marginals_not_posdef_and_wrong_mode():
+    lam = synth.ba(20, 400, k=3, seed=41)
+    bad = dataclasses.replace(lam, values=lam.values.copy())
+    off = lam.block_value_offsets()
+    k = int(lam.bcol_ptr[3 + 1] - 1)        # diagonal block of camera 3
+    bad.values[off[k]:off[k + 1]] *= -1.0
+    with pytest.raises(ArithmeticError):
+        CLinearSolver_Schur_HIP().Schur_Marginals(bad)
+    chain = synth.pose_chain(n=50, d=6)
+    with pytest.raises((NotImplementedError, ValueError)):
+        CLinearSolver_Schur_HIP().Schur_Marginals(chain)
