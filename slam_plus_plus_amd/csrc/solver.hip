@@ -170,6 +170,8 @@ void slampp_hip_solver::Analyze_Sparse()
 			throw std::domain_error("a factor block has 2^24 or more updates: use the dense path");
 		b.loff = P.loff[k];
 		b.asrc = (P.asrc[k] < 0)? -1 : P.asrc[k] * 2 + P.atrans[k];
+		if(k == P.lptr[P.blk_col[k]] && b.asrc >= 0)
+			b.asrc |= 1; // diagonal blocks are read transposed: the lower triangle of the factor block then comes from the upper triangle of Lambda's block, the one the reference's solvers consume
 		b.p0 = P.pptr[k];
 		b.np_di = uint32_t(np) | (uint32_t(P.dim[P.lrow[k]]) << 24);
 		b.xcs = int32_t(P.cs_new[P.lrow[k]]);
@@ -287,6 +289,9 @@ void slampp_hip_solver::Analyze_Sparse()
 	dplan.cols = d_cols.p(); dplan.blks = d_blks.p(); dplan.pairs = d_pairs.p(); dplan.rents = d_rents.p();
 	dplan.task_ptr = d_task_ptr.p();
 	dplan.uniform_dim = P.uniform_dim? P.max_dim : 0;
+	dplan.n_blks = n_lblocks;
+	dplan.n_pairs = int64_t(pairs.size());
+	dplan.n_rents = int64_t(rents.size());
 	dplan.p_timing = 0;
 	if(getenv("SLAMPP_HIP_STAGE_TIMING")) { // development aid: clock samples of the upper-stage kernel, printed at sync
 		d_timing.Alloc(1 + 32 * 4096);
@@ -600,7 +605,7 @@ int slampp_hip_sync(slampp_hip_solver *p_solver)
 			std::vector<long long> tm(1 + 32 * 4096);
 			SLAMPP_HIP_CHECK(hipMemcpy(tm.data(), s.d_timing.p(), tm.size() * sizeof(long long), hipMemcpyDeviceToHost));
 			const long long n_launches = std::min<long long>(tm[0], 4096);
-			for(long long i = std::max<long long>(0, n_launches - 24); i < n_launches; ++ i) {
+			for(long long i = std::max<long long>(0, n_launches - 40); i < n_launches; ++ i) {
 				fprintf(stderr, "stage_timing launch %lld:", i);
 				for(int k = 1; k < 32 && tm[1 + 32 * i + k]; ++ k)
 					fprintf(stderr, " %.2f", double(tm[1 + 32 * i + k] - tm[1 + 32 * i + k - 1]) * 0.01);

@@ -59,6 +59,7 @@ struct TDevPlan {
 	const TRowEnt *rents;      // [n_row_entries]
 	const int64_t *task_ptr;   // [n_tasks+1]
 	int uniform_dim;           // > 0: every block column has this dimension (3, 6, 7 get unrolled kernels)
+	int64_t n_blks, n_pairs, n_rents; // lengths of the arrays above (bulk loads of a task's records stop there)
 	long long *p_timing;       // development aid (SLAMPP_HIP_STAGE_TIMING): [0] = launches so far, then 32 clock
 	                           // samples per launch of workgroup 0 of the multi-wave factor kernel; normally null
 };
@@ -67,6 +68,9 @@ struct TDevPlan {
 // (b is read at its original position, y written to the permuted workspace w)
 void launch_factor_stage(const TDevPlan &p, const double *A, double *L, double *Linv, const double *b,
 	double *w, int task_begin, int n_tasks, bool b_bottom_stage, int *p_flag, hipStream_t stream);
+// bottom stages out of LDS (subtree_kernel.hip); returns false if the block dimension has no such kernel
+bool launch_factor_subtree_image(const TDevPlan &p, const double *A, double *L, double *Linv, const double *b,
+	double *w, int task_begin, int n_tasks, int *p_flag, hipStream_t stream);
 // stand-alone forward substitution (another right-hand side with a kept factor)
 void launch_forward_stage(const TDevPlan &p, const double *L, const double *Linv, const double *b,
 	double *w, int task_begin, int n_tasks, hipStream_t stream);
