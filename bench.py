@@ -175,7 +175,7 @@ def run_c3(args, rank, world, local_rank, dist):
     n_stages, n_bottom = stats["n_stages"], stats["n_bottom_stages"]
     kb = per_kernel_bytes_sparse(solver.plan(), n_bottom)
     launches = {"factor_subtree": n_bottom, "factor_upper": max(n_stages - n_bottom, 1), "forward": n_stages, "backward": n_stages}
-    names = {"factor_subtree": "factor_subtree_kernel", "factor_upper": "factor_stage_kernel",
+    names = {"factor_subtree": "factor_subtree_image_kernel", "factor_upper": "factor_stage_kernel",
              "forward": "forward_stage_kernel", "backward": "backward_stage_kernel"}
     traffic, traffic_file = load_traffic("c3")
     kernels = []
