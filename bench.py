@@ -217,7 +217,7 @@ def run_c3(args, rank, world, local_rank, dist):
     return out
 
 
-def assembly_leg(solver, lam, dev, reps=20):
+def assembly_leg(solver, lam, dev, reps=20, rd=None, column_vertex_first=False):
     """Outside the timed region: Lambda and eta of the same graph assembled on the device from synthetic per-edge
     Jacobians, written where the solver reads them.  HBM-bound: bytes in (J0, J1, Sigma^-1,
     error, weight per edge) + bytes out (Lambda values, eta) over the HIP-event time of the two kernels."""
@@ -227,8 +227,10 @@ def assembly_leg(solver, lam, dev, reps=20):
     col = np.repeat(np.arange(lam.n_bcols), np.diff(lam.bcol_ptr))
     off = lam.brow_idx != col
     v0, v1 = lam.brow_idx[off].astype(np.int64), col[off].astype(np.int64)
+    if column_vertex_first:   # BA: vertex 0 of a projection edge is the landmark (EDGE_P2MC xyz_id cam_id), the later block column
+        v0, v1 = v1, v0
     dims = np.diff(lam.cumsum)
-    d = int(dims[0])
+    d = int(dims[0]) if rd is None else int(rd)
     es = synth.random_edge_set(dims, v0, v1, rd=d, seed=3)
     asm = CLambdaAssembly_HIP(solver, lam, v0, v1, d)
     bufs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (es.J0, es.J1, es.sigma_inv, es.err, es.weight)]
@@ -496,6 +498,8 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1):
             out["cpu_baseline"] = cpu_baseline_ba(lam, schur_flops + dense_flops)   # the reference factors S densely
         if schur_sparse != 0:
             out["marginals"] = marginals_leg(args, solver, lam, vals, dev, torch)
+            # Lambda of the same structure assembled on the device from 2-d projection residuals (one edge per observation)
+            out["assembly"] = assembly_leg(solver, lam, dev, reps=5, rd=2, column_vertex_first=True)
     return out
 
 

@@ -32,6 +32,16 @@ struct CAssemblyState {
 	int d0, d1, rd;
 	int64_t n_offdiag, n_diag;
 	CDevArray<TAsmBlk> d_offdiag, d_diag;
+	CDevArray<int32_t> d_diag_vertex; // vertex of every record of d_diag (the lists below took some of them out)
+	CDevArray<TAsmBlk> d_long;      // vertices with long edge lists (BA cameras, hubs): summed edge-parallel by their own kernel
+	CDevArray<int32_t> d_long_vertex;
+	int64_t n_long;
+	CDevArray<TAsmBlk> d_small;     // low-dimensional vertices with short lists (BA landmarks): several share a wave
+	CDevArray<int32_t> d_small_vertex;
+	int64_t n_small;
+	int n_small_elems;              // lanes per vertex in that kernel: d^2 + d of the largest of them
+	int n_long_dim;                 // their common dimension (0: none qualify)
+	int n_off_elems;                // largest off-diagonal block, in elements: 64 / that many blocks share a wave
 	CDevArray<int32_t> d_entries;   // edge index * 2 + (off-diagonal: flipped; diagonal: side)
 	CDevArray<double> d_unary;      // [64 + 8]: U^T U (column-major d x d), unary error
 	double h_unary[72];             // what d_unary holds
@@ -40,6 +50,12 @@ struct CAssemblyState {
 };
 
 void assembly_destroy(CAssemblyState *p) { delete p; }
+
+// (residual dimension, vertex dimension) pairs the edge-parallel kernel is instantiated for
+static bool long_kernel_exists(int rd, int d)
+{
+	return (rd == 2 && (d == 6 || d == 7 || d == 3)) || (rd == 3 && d == 3) || (rd == 6 && d == 6) || (rd == 7 && d == 7);
+}
 
 CAssemblyState *assembly_setup(slampp_hip_solver &s, int64_t n_edges, const int64_t *v0, const int64_t *v1, int rd)
 {
@@ -117,12 +133,57 @@ CAssemblyState *assembly_setup(slampp_hip_solver &s, int64_t n_edges, const int6
 			entries[fill_diag[v1[e]] ++] = int32_t(e * 2 + 1);
 		}
 	}
+	// Three kernels share the vertices: long lists go to the edge-parallel kernel (one lane per edge, tree reduction)
+	// when it exists for their dimension; low-dimensional vertices with short lists (the landmarks of a BA system:
+	// 12 of 64 lanes busy otherwise) are packed several to a wave when the residual is small enough to unroll; the
+	// rest stay with one wave per vertex
+	std::vector<TAsmBlk> long_blks, small_blks, plain_blks;
+	std::vector<int32_t> long_vertex, small_vertex, plain_vertex;
+	int n_long_dim = 0, n_small_elems = 0;
+	{
+		enum { LONG_LIST = 96 };
+		const bool b_can_pack = rd == 2 || rd == 3;
+		for(int64_t v = 0; v < n; ++ v) {
+			const int d = diag[v].rows;
+			if(diag[v].ne >= LONG_LIST && long_kernel_exists(rd, d) && (!n_long_dim || d == n_long_dim)) {
+				n_long_dim = d;
+				long_blks.push_back(diag[v]);
+				long_vertex.push_back(int32_t(v));
+			} else if(b_can_pack && 2 * (d * d + d) <= 64) {
+				n_small_elems = std::max(n_small_elems, d * d + d);
+				small_blks.push_back(diag[v]);
+				small_vertex.push_back(int32_t(v));
+			} else {
+				plain_blks.push_back(diag[v]);
+				plain_vertex.push_back(int32_t(v));
+			}
+		}
+	}
+	int n_off_elems = 1;
+	for(size_t i = 0; i < offdiag.size(); ++ i) {
+		n_off_elems = std::max(n_off_elems, int(offdiag[i].rows) * int(offdiag[i].cols));
+		if(offdiag[i].ne == 1)
+			offdiag[i].e0 = entries[offdiag[i].e0]; // a single entry rides in the record: one dependent load less
+	}
 	CAssemblyState *p = new CAssemblyState();
 	try {
+		p->n_long = int64_t(long_blks.size()); p->n_long_dim = n_long_dim; p->n_off_elems = n_off_elems;
+		if(!long_blks.empty()) {
+			p->d_long.Upload(long_blks, s.stream);
+			p->d_long_vertex.Upload(long_vertex, s.stream);
+		}
+		p->n_small = int64_t(small_blks.size()); p->n_small_elems = n_small_elems;
+		if(!small_blks.empty()) {
+			p->d_small.Upload(small_blks, s.stream);
+			p->d_small_vertex.Upload(small_vertex, s.stream);
+		}
 		p->n_edges = n_edges; p->d0 = d0; p->d1 = d1; p->rd = rd;
-		p->n_offdiag = int64_t(offdiag.size()); p->n_diag = n;
+		p->n_offdiag = int64_t(offdiag.size()); p->n_diag = int64_t(plain_blks.size());
 		p->d_offdiag.Upload(offdiag, s.stream);
-		p->d_diag.Upload(diag, s.stream);
+		if(!plain_blks.empty()) {
+			p->d_diag.Upload(plain_blks, s.stream);
+			p->d_diag_vertex.Upload(plain_vertex, s.stream);
+		}
 		p->d_entries.Upload(entries, s.stream);
 		p->d_unary.Alloc(72);
 		p->b_unary_valid = false;
@@ -168,7 +229,8 @@ __device__ __forceinline__ double dot_rd(const double (&t)[RD? RD : 8], const do
 	return sum;
 }
 
-// one wave per off-diagonal block (row vertex < column vertex): sum over its edges of J_row^T (w S) J_col
+// off-diagonal blocks (row vertex < column vertex): sum over the block's edges of J_row^T (w S) J_col, one wave per
+// block; its record and loop bounds stay in scalar registers
 template <int RD>
 __global__ void __launch_bounds__(64)
 assemble_offdiag_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__restrict__ entries, int d0, int d1, int n_rd,
@@ -177,13 +239,13 @@ assemble_offdiag_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__restr
 {
 	const int rd = RD? RD : n_rd;
 	const TAsmBlk bd = blks[blockIdx.x];
-	const int lane = threadIdx.x;
-	if(lane >= bd.rows * bd.cols)
+	const int el = threadIdx.x;
+	if(el >= bd.rows * bd.cols)
 		return;
-	const int r = lane % bd.rows, q = lane / bd.rows;
-	double acc = b_accumulate? values[bd.dst + lane] : 0.0;
+	const int r = el % bd.rows, q = el / bd.rows;
+	double acc = b_accumulate? values[bd.dst + el] : 0.0;
 	for(int i = 0; i < bd.ne; ++ i) {
-		const int32_t ent = entries[bd.e0 + i];
+		const int32_t ent = (bd.ne == 1)? int32_t(bd.e0) : entries[bd.e0 + i];
 		const int64_t e = ent >> 1;
 		const bool b_flip = ent & 1; // vertex 0 has the larger id: the stored block is (J0^T w S J1)^T
 		// element (c0, c1) of J0^T (w S) J1 lands on (r, q) of the stored block
@@ -192,13 +254,44 @@ assemble_offdiag_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__restr
 		jt_sigma_row<RD>(J0 + e * rd * d0, Si + e * rd * rd, c0, rd, t);
 		acc += dot_rd<RD>(t, J1 + e * rd * d1 + c1 * rd, rd) * (wgt? wgt[e] : 1.0);
 	}
-	values[bd.dst + lane] = acc; // a structural block without an edge becomes zeros
+	values[bd.dst + el] = acc; // a structural block without an edge becomes zeros
+}
+
+// The same for small blocks with small residuals (a BA system: 6 x 3 blocks, one edge each, 2-d residuals): as many
+// blocks share a wave as fit, lane = (slot, element) -- 2 M single-block waves with 18 busy lanes took 0.58 ms at C4,
+// three to a wave 0.27 ms.  (Working on several such groups per wave with their loads batched was slower: 0.32 ms.)
+template <int RD>
+__global__ void __launch_bounds__(64)
+assemble_offdiag_packed_kernel(const TAsmBlk *__restrict__ blks, int64_t n_blks, int n_per_wave, int n_slot_elems,
+	const int32_t *__restrict__ entries, int d0, int d1,
+	const double *__restrict__ J0, const double *__restrict__ J1, const double *__restrict__ Si,
+	const double *__restrict__ wgt, double *values, int b_accumulate)
+{
+	const int sub = int(threadIdx.x) / n_slot_elems, el = int(threadIdx.x) - sub * n_slot_elems;
+	const int64_t bi = int64_t(blockIdx.x) * n_per_wave + sub;
+	if(sub >= n_per_wave || bi >= n_blks)
+		return;
+	const TAsmBlk bd = blks[bi];
+	if(el >= bd.rows * bd.cols)
+		return;
+	const int r = el % bd.rows, q = el / bd.rows;
+	double acc = b_accumulate? values[bd.dst + el] : 0.0;
+	for(int i = 0; i < bd.ne; ++ i) {
+		const int32_t ent = (bd.ne == 1)? int32_t(bd.e0) : entries[bd.e0 + i];
+		const int64_t e = ent >> 1;
+		const int c0 = (ent & 1)? q : r, c1 = (ent & 1)? r : q;
+		double t[RD];
+		jt_sigma_row<RD>(J0 + e * RD * d0, Si + e * RD * RD, c0, RD, t);
+		acc += dot_rd<RD>(t, J1 + e * RD * d1 + c1 * RD, RD) * (wgt? wgt[e] : 1.0);
+	}
+	values[bd.dst + el] = acc;
 }
 
 // one wave per vertex: diagonal block (lanes r + q d) and eta (lanes 56 + q)
 template <int RD>
 __global__ void __launch_bounds__(64)
-assemble_diag_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__restrict__ entries, int d0, int d1, int n_rd,
+assemble_diag_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__restrict__ vertex_of,
+	const int32_t *__restrict__ entries, int d0, int d1, int n_rd,
 	const double *__restrict__ J0, const double *__restrict__ J1, const double *__restrict__ Si,
 	const double *__restrict__ err, const double *__restrict__ wgt, int unary_vertex, const double *__restrict__ unary,
 	double *values, double *eta, int b_accumulate)
@@ -225,9 +318,180 @@ assemble_diag_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__restrict
 		// weights vertex 0's right-hand side twice (BaseTypes_Binary.h:813-815 against :836-838)
 		acc += dot_rd<RD>(t, b_blk? J + q * rd : err + e * rd, rd) * ((b_blk || side)? w : w * w);
 	}
-	if(int(blockIdx.x) == unary_vertex)
+	if(vertex_of[blockIdx.x] == unary_vertex)
 		acc += b_blk? unary[lane] : unary[64 + r];
 	*p_dst = acc;
+}
+
+// The same for low-dimensional vertices with short lists and small residuals (the landmarks of a BA system): several
+// vertices share a wave (lane = (slot, element), elements 0 .. d^2-1 the block, d^2 .. d^2+d-1 the right-hand side), and
+// the operands of UNR edges are requested before the first of them is used
+template <int RD, int UNR>
+__global__ void __launch_bounds__(64)
+assemble_diag_packed_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__restrict__ vertex_of, int64_t n_blks,
+	int n_per_wave, int n_slot_elems, const int32_t *__restrict__ entries, int d0, int d1,
+	const double *__restrict__ J0, const double *__restrict__ J1, const double *__restrict__ Si,
+	const double *__restrict__ err, const double *__restrict__ wgt, int unary_vertex, const double *__restrict__ unary,
+	double *values, double *eta, int b_accumulate)
+{
+	const int sub = int(threadIdx.x) / n_slot_elems, el = int(threadIdx.x) - sub * n_slot_elems;
+	const int64_t bi = int64_t(blockIdx.x) * n_per_wave + sub;
+	if(sub >= n_per_wave || bi >= n_blks)
+		return;
+	const TAsmBlk bd = blks[bi];
+	const int d = bd.rows;
+	const bool b_blk = el < d * d, b_y = !b_blk && el < d * d + d;
+	if(!b_blk && !b_y)
+		return;
+	const int r = b_blk? el % d : el - d * d, q = b_blk? el / d : 0;
+	double *p_dst = b_blk? values + bd.dst + el : eta + bd.eta_off + r;
+	double acc = b_accumulate? *p_dst : 0.0;
+	for(int i0 = 0; i0 < bd.ne; i0 += UNR) {
+		int32_t ent[UNR];
+		#pragma unroll
+		for(int u = 0; u < UNR; ++ u)
+			ent[u] = (i0 + u < bd.ne)? entries[bd.e0 + i0 + u] : -1;
+		double jr[UNR][RD], sm[UNR][RD * RD], v[UNR][RD], w[UNR];
+		#pragma unroll
+		for(int u = 0; u < UNR; ++ u) {
+			const int32_t en = (ent[u] >= 0)? ent[u] : 0;
+			const int64_t e = en >> 1;
+			const double *J = (en & 1)? J1 + e * RD * d1 : J0 + e * RD * d0;
+			#pragma unroll
+			for(int a = 0; a < RD; ++ a) {
+				jr[u][a] = (ent[u] >= 0)? J[a + r * RD] : 0.0;
+				v[u][a] = (ent[u] >= 0)? (b_blk? J[a + q * RD] : err[e * RD + a]) : 0.0;
+			}
+			#pragma unroll
+			for(int a = 0; a < RD * RD; ++ a)
+				sm[u][a] = (ent[u] >= 0)? Si[e * RD * RD + a] : 0.0;
+			const double we = wgt? wgt[e] : 1.0;
+			w[u] = (ent[u] < 0)? 0.0 : ((b_blk || (en & 1))? we : we * we); // vertex 0's right-hand side is weighted twice (see above)
+		}
+		#pragma unroll
+		for(int u = 0; u < UNR; ++ u) {
+			double sum = 0; // the arithmetic and its order are those of the one-wave kernel
+			#pragma unroll
+			for(int b = 0; b < RD; ++ b) {
+				double t = 0;
+				#pragma unroll
+				for(int a = 0; a < RD; ++ a)
+					t += jr[u][a] * sm[u][a + b * RD];
+				sum += t * v[u][b];
+			}
+			if(ent[u] >= 0)
+				acc += sum * w[u];
+		}
+	}
+	if(vertex_of[bi] == unary_vertex)
+		acc += b_blk? unary[el] : unary[64 + r];
+	*p_dst = acc;
+}
+
+// Vertices with long edge lists (a BA camera sees thousands of points; one wave walking its list edge by edge took
+// 1.1 ms at 2 000 edges per camera): one workgroup per vertex, one LANE per edge -- each lane reads its edge's Jacobian,
+// Sigma^-1 and error (contiguous per edge) and keeps the lower triangle of J^T (w S) J and the D entries of the
+// right-hand side in registers; the lanes are then summed by a butterfly, the waves through LDS, both in a fixed
+// order (bit-reproducible).
+template <int RD, int D>
+__global__ void __launch_bounds__(256)
+assemble_long_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__restrict__ vertex_of, const int32_t *__restrict__ entries,
+	int d0, int d1, const double *__restrict__ J0, const double *__restrict__ J1, const double *__restrict__ Si,
+	const double *__restrict__ err, const double *__restrict__ wgt, int unary_vertex, const double *__restrict__ unary,
+	double *values, double *eta, int b_accumulate)
+{
+	enum { NT = D * (D + 1) / 2, NV = NT + D, W = 4 };
+	__shared__ double s_part[W][NV];
+	const TAsmBlk bd = blks[blockIdx.x];
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	double acc[NV];
+	#pragma unroll
+	for(int i = 0; i < NV; ++ i)
+		acc[i] = 0;
+	for(int i = tid; i < bd.ne; i += 64 * W) {
+		const int32_t ent = entries[bd.e0 + i];
+		const int64_t e = ent >> 1;
+		const int side = ent & 1;
+		const double *J = side? J1 + e * RD * d1 : J0 + e * RD * d0;
+		const double *S = Si + e * RD * RD, *ev = err + e * RD;
+		const double w = wgt? wgt[e] : 1.0;
+		double j[RD][D], sm[RD][RD], se[RD];
+		#pragma unroll
+		for(int c = 0; c < D; ++ c)
+			#pragma unroll
+			for(int a = 0; a < RD; ++ a)
+				j[a][c] = J[a + c * RD];
+		#pragma unroll
+		for(int b = 0; b < RD; ++ b)
+			#pragma unroll
+			for(int a = 0; a < RD; ++ a)
+				sm[a][b] = S[a + b * RD];
+		#pragma unroll
+		for(int b = 0; b < RD; ++ b) { // (Sigma^-1 e)[b], by columns as the one-wave kernel sums it: sum_a .. S[a + b rd]
+			double sum = 0;
+			#pragma unroll
+			for(int a = 0; a < RD; ++ a)
+				sum += ev[a] * sm[a][b];
+			se[b] = sum;
+		}
+		const double wy = side? w : w * w; // the reference weights vertex 0's right-hand side twice (see above)
+		int k = 0;
+		#pragma unroll
+		for(int q = 0; q < D; ++ q) {
+			double t[RD]; // (w S J)[:, q]
+			#pragma unroll
+			for(int a = 0; a < RD; ++ a) {
+				double sum = 0;
+				#pragma unroll
+				for(int b = 0; b < RD; ++ b)
+					sum += sm[a][b] * j[b][q];
+				t[a] = sum * w;
+			}
+			#pragma unroll
+			for(int r = q; r < D; ++ r, ++ k) {
+				double sum = 0;
+				#pragma unroll
+				for(int a = 0; a < RD; ++ a)
+					sum += j[a][r] * t[a];
+				acc[k] += sum;
+			}
+			double sum = 0;
+			#pragma unroll
+			for(int a = 0; a < RD; ++ a)
+				sum += j[a][q] * se[a];
+			acc[NT + q] += sum * wy;
+		}
+	}
+	#pragma unroll
+	for(int i = 0; i < NV; ++ i) {
+		double v = acc[i];
+		#pragma unroll
+		for(int m = 32; m >= 1; m >>= 1)
+			v += __shfl_xor(v, m);
+		if(lane == 0)
+			s_part[wave][i] = v;
+	}
+	__syncthreads();
+	if(tid >= D * D + D)
+		return;
+	const bool b_blk = tid < D * D;
+	const int r = b_blk? tid % D : tid - D * D, q = b_blk? tid / D : 0;
+	int idx;
+	if(b_blk) {
+		const int hi = (r > q)? r : q, lo = (r > q)? q : r; // lower triangle, column by column: column lo starts after lo (2D - lo + 1) / 2
+		idx = lo * (2 * D - lo + 1) / 2 + (hi - lo);
+	} else
+		idx = NT + r;
+	double sum = 0;
+	#pragma unroll
+	for(int ww = 0; ww < W; ++ ww)
+		sum += s_part[ww][idx];
+	double *p_dst = b_blk? values + bd.dst + tid : eta + bd.eta_off + r;
+	if(b_accumulate)
+		sum += *p_dst;
+	if(vertex_of[blockIdx.x] == unary_vertex)
+		sum += b_blk? unary[tid] : unary[64 + r];
+	*p_dst = sum;
 }
 
 void assembly_enqueue(CAssemblyState &a, const double *J0, const double *J1, const double *Si, const double *err,
@@ -240,7 +504,7 @@ void assembly_enqueue(CAssemblyState &a, const double *J0, const double *J1, con
 		throw std::invalid_argument("assemble: null device pointer");
 	int n_unary = -1;
 	if(p_unary_factor) {
-		if(n_unary_vertex < 0 || n_unary_vertex >= a.n_diag)
+		if(n_unary_vertex < 0 || n_unary_vertex >= int64_t(s.cumsum.size()) - 1)
 			throw std::invalid_argument("assemble: the unary factor's vertex is outside Lambda");
 		const int d = int(s.cumsum[n_unary_vertex + 1] - s.cumsum[n_unary_vertex]);
 		double h[72];
@@ -264,13 +528,36 @@ void assembly_enqueue(CAssemblyState &a, const double *J0, const double *J1, con
 		n_unary = int(n_unary_vertex);
 	}
 	s.Phase_Begin("assemble");
+	const bool b_pack_off = (a.rd == 2 || a.rd == 3) && 2 * a.n_off_elems <= 64;
+	enum { OFF_UNR = 1, DIAG_UNR = 4 }; // landmarks at C4: 297 us one wave each, 186 us packed with the operands of 4 edges in flight
+	const int n_off_per_wave = std::max(1, 64 / a.n_off_elems);
+	const unsigned n_off_grid = unsigned((a.n_offdiag + int64_t(n_off_per_wave) * OFF_UNR - 1) / (int64_t(n_off_per_wave) * OFF_UNR));
+	const int n_small_per_wave = a.n_small? std::max(1, 64 / a.n_small_elems) : 1;
+	const unsigned n_small_grid = unsigned((a.n_small + n_small_per_wave - 1) / n_small_per_wave);
+#define LAUNCH_PACKED(RD) do { \
+		if(a.n_offdiag > 0 && b_pack_off) \
+			hipLaunchKernelGGL((assemble_offdiag_packed_kernel<RD>), dim3(n_off_grid), dim3(64), 0, st, a.d_offdiag.p(), \
+				a.n_offdiag, n_off_per_wave, a.n_off_elems, a.d_entries.p(), a.d0, a.d1, J0, J1, Si, wgt, values_out, b_accumulate); \
+		if(a.n_small > 0) \
+			hipLaunchKernelGGL((assemble_diag_packed_kernel<RD, DIAG_UNR>), dim3(n_small_grid), dim3(64), 0, st, a.d_small.p(), \
+				a.d_small_vertex.p(), a.n_small, n_small_per_wave, a.n_small_elems, a.d_entries.p(), a.d0, a.d1, J0, J1, Si, err, wgt, \
+				n_unary, a.d_unary.p(), values_out, eta_out, b_accumulate); } while(0)
+	if(a.rd == 2)
+		LAUNCH_PACKED(2);
+	else if(a.rd == 3)
+		LAUNCH_PACKED(3);
+#undef LAUNCH_PACKED
 #define LAUNCH_ASM(RD) do { \
-		if(a.n_offdiag > 0) \
+		if(a.n_offdiag > 0 && !b_pack_off) \
 			hipLaunchKernelGGL(assemble_offdiag_kernel<RD>, dim3(unsigned(a.n_offdiag)), dim3(64), 0, st, a.d_offdiag.p(), \
 				a.d_entries.p(), a.d0, a.d1, a.rd, J0, J1, Si, wgt, values_out, b_accumulate); \
-		hipLaunchKernelGGL(assemble_diag_kernel<RD>, dim3(unsigned(a.n_diag)), dim3(64), 0, st, a.d_diag.p(), \
-			a.d_entries.p(), a.d0, a.d1, a.rd, J0, J1, Si, err, wgt, n_unary, a.d_unary.p(), values_out, eta_out, \
-			b_accumulate); } while(0)
+		if(a.n_diag > 0) \
+			hipLaunchKernelGGL(assemble_diag_kernel<RD>, dim3(unsigned(a.n_diag)), dim3(64), 0, st, a.d_diag.p(), a.d_diag_vertex.p(), \
+				a.d_entries.p(), a.d0, a.d1, a.rd, J0, J1, Si, err, wgt, n_unary, a.d_unary.p(), values_out, eta_out, \
+				b_accumulate); } while(0)
+#define LAUNCH_LONG(RD, D) hipLaunchKernelGGL((assemble_long_kernel<RD, D>), dim3(unsigned(a.n_long)), dim3(256), 0, st, \
+		a.d_long.p(), a.d_long_vertex.p(), a.d_entries.p(), a.d0, a.d1, J0, J1, Si, err, wgt, n_unary, a.d_unary.p(), \
+		values_out, eta_out, b_accumulate)
 	switch(a.rd) {
 	case 2: LAUNCH_ASM(2); break;
 	case 3: LAUNCH_ASM(3); break;
@@ -278,6 +565,19 @@ void assembly_enqueue(CAssemblyState &a, const double *J0, const double *J1, con
 	case 7: LAUNCH_ASM(7); break;
 	default: LAUNCH_ASM(0); break;
 	}
+	if(a.n_long > 0) {
+		const int key = a.rd * 10 + a.n_long_dim;
+		switch(key) {
+		case 26: LAUNCH_LONG(2, 6); break;
+		case 27: LAUNCH_LONG(2, 7); break;
+		case 23: LAUNCH_LONG(2, 3); break;
+		case 33: LAUNCH_LONG(3, 3); break;
+		case 66: LAUNCH_LONG(6, 6); break;
+		case 77: LAUNCH_LONG(7, 7); break;
+		default: throw std::logic_error("assembly: no edge-parallel kernel for a vertex that was set aside for it");
+		}
+	}
+#undef LAUNCH_LONG
 #undef LAUNCH_ASM
 	s.Phase_End();
 	SLAMPP_HIP_CHECK(hipGetLastError());
@@ -285,7 +585,9 @@ void assembly_enqueue(CAssemblyState &a, const double *J0, const double *J1, con
 
 size_t assembly_device_bytes(const CAssemblyState *p)
 {
-	return p->d_offdiag.n_Bytes() + p->d_diag.n_Bytes() + p->d_entries.n_Bytes() + p->d_unary.n_Bytes();
+	return p->d_offdiag.n_Bytes() + p->d_diag.n_Bytes() + p->d_diag_vertex.n_Bytes() + p->d_long.n_Bytes() + p->d_long_vertex.n_Bytes() +
+		p->d_small.n_Bytes() + p->d_small_vertex.n_Bytes() +
+		p->d_entries.n_Bytes() + p->d_unary.n_Bytes();
 }
 
 } // namespace slampp

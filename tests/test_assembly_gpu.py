@@ -153,3 +153,31 @@ def test_errors():
     del solver
     asm._solver = None
     del asm
+
+
+@pytest.mark.parametrize("d,rd", [(6, 6), (3, 3), (7, 7), (6, 4)])
+def test_hub_vertices_long_lists(d, rd):
+    """A few vertices with hundreds of edges (the edge-parallel kernel where it exists for (rd, d), the one-wave kernel
+    otherwise), on either side of their edges, one of them the anchored vertex; and accumulation onto existing values."""
+    n = 1500
+    rng = np.random.default_rng(d * 10 + rd)
+    c0, c1 = np.arange(n - 1), np.arange(1, n)
+    hubs = np.array([0, 700, 1499])
+    spokes = [np.setdiff1d(rng.choice(n, 400, replace=False), [h - 1, h, h + 1]) for h in hubs]
+    h0 = np.concatenate([np.full(len(s_), h) for h, s_ in zip(hubs, spokes)])
+    h1 = np.concatenate(spokes)
+    flip = rng.random(len(h0)) < 0.5
+    v0 = np.concatenate([c0, np.where(flip, h1, h0)]).astype(np.int64)
+    v1 = np.concatenate([c1, np.where(flip, h0, h1)]).astype(np.int64)
+    dims = np.full(n, d)
+    es = synth.random_edge_set(dims, v0, v1, rd=rd, seed=3, robust=True, anchor=700)
+    lam = synth.structure_from_edges(dims, v0, v1)
+    ref_values, ref_eta = O.assemble_lambda(lam, es)
+    solver = CLinearSolver_HIP()
+    values, eta, asm = assemble_on_gpu(solver, lam, es)
+    assert rel_inf(values.cpu().numpy(), ref_values) < TOL
+    assert rel_inf(eta.cpu().numpy(), ref_eta) < TOL
+    values2, eta2, _ = assemble_on_gpu(solver, lam, es)
+    assert torch.equal(values, values2) and torch.equal(eta, eta2)
+    values3, eta3, _ = assemble_on_gpu(solver, lam, es, accumulate_into=(values2, eta2))
+    assert rel_inf(values3.cpu().numpy(), 2 * ref_values) < TOL and rel_inf(eta3.cpu().numpy(), 2 * ref_eta) < TOL
