@@ -352,3 +352,61 @@ def test_schur_marginals_not_posdef_and_wrong_mode():
     chain = synth.pose_chain(n=50, d=6)
     with pytest.raises((NotImplementedError, ValueError)):
         CLinearSolver_Schur_HIP().Schur_Marginals(chain)
+
+
+def test_schur_marginals_two_landmark_shards():
+    """The covariances with the landmarks split over two ranks (threads, as above): the reduced system is summed through
+    the callback as one buffer, every rank gets all camera blocks and the blocks of its own landmarks."""
+    import threading
+    import torch
+    from slam_plus_plus_amd import sharding
+
+    torch.zeros(1, device="cuda")
+    lam = synth.ba(30, 2400, mode="venice", seed=61)
+    cams_ref, pts_ref = O.schur_marginals(lam)
+    world = 2
+    barrier = threading.Barrier(world)
+    slots, total, errors, results = [None] * world, [None], [], [None] * world
+
+    class DevPtr:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+    def make_fn(rank):
+        def fn(ptr, count, stream):
+            torch.cuda.synchronize()
+            slots[rank] = torch.as_tensor(DevPtr(ptr, count), device="cuda")
+            barrier.wait()
+            if rank == 0:
+                total[0] = torch.stack(slots).sum(dim=0)
+            barrier.wait()
+            slots[rank].copy_(total[0])
+            torch.cuda.synchronize()
+            barrier.wait()
+            return 0
+        return fn
+
+    def run(rank):
+        try:
+            shard, sl = sharding.landmark_shard(lam, rank, world)
+            solver = CLinearSolver_Schur_HIP()
+            solver.set_allreduce(make_fn(rank))
+            cams, pts = solver.Schur_Marginals(shard)
+            eta = shard.rhs.copy()                        # and a solve on the same handle afterwards
+            assert solver.Solve_PosDef(shard, eta)
+            results[rank] = (cams, pts, sl)
+        except Exception:                                 # pragma: no cover
+            import traceback
+            errors.append(traceback.format_exc())
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(timeout=120) for t in threads]
+    assert not errors, errors
+    n_x = int(lam.cumsum[lam.n_matrix_cut])
+    pts = np.zeros_like(pts_ref)
+    for cams, p, sl in results:
+        assert rel_inf(cams, cams_ref) < TOL
+        pts[(sl.start - n_x) // 3:(sl.stop - n_x) // 3] = p
+    assert rel_inf(pts, pts_ref) < TOL
