@@ -187,6 +187,14 @@ int slampp_hip_get_profile(slampp_hip_solver *p_solver, slampp_hip_phase_time *p
  * Writes the packed block values of Lambda (the layout slampp_hip_factor_solve_device reads) and eta;
  * with b_accumulate != 0 adds to what the two arrays hold instead (a second edge set of the same Lambda).
  * Sums run in a fixed order: results are bit-reproducible.  Enqueue-only, on the solver's stream. */
+/* Levenberg-Marquardt damping of device-resident values (the ones slampp_hip_assemble_device_async wrote): adds
+ * f_alpha to the diagonal of the diagonal blocks of block columns [n_first_vertex, n_last_vertex) -- the reference's
+ * ApplyDamping(r_lambda, f_alpha, n_first_vertex, n_last_vertex), include/slam/NonlinearSolver_Lambda_LM.h:228-239,
+ * which it runs on the host matrix between Refresh_Lambda and the linear solve.  A negative f_alpha takes it back
+ * out (the LM loop re-damps the same Lambda).  Enqueue-only, on the solver's stream; needs set_structure only. */
+int slampp_hip_apply_damping_device_async(slampp_hip_solver *p_solver, double *p_values_dev, double f_alpha,
+	int64_t n_first_vertex, int64_t n_last_vertex);
+
 typedef struct slampp_hip_assembly slampp_hip_assembly; /* opaque */
 int slampp_hip_assembly_create(slampp_hip_solver *p_solver, slampp_hip_assembly **pp_assembly, int64_t n_edges,
 	const int64_t *p_vertex0, const int64_t *p_vertex1, int n_residual_dim);

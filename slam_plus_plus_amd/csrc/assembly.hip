@@ -583,6 +583,26 @@ void assembly_enqueue(CAssemblyState &a, const double *J0, const double *J1, con
 	SLAMPP_HIP_CHECK(hipGetLastError());
 }
 
+// Levenberg-Marquardt damping on device-resident values: alpha onto the diagonal of the diagonal blocks of block
+// columns [n_first, n_last) -- the reference's ApplyDamping (include/slam/NonlinearSolver_Lambda_LM.h:228-239)
+__global__ void damping_kernel(const int64_t *__restrict__ p_off_dim, int64_t n_first, int64_t n_last, double f_alpha, double *values)
+{
+	const int64_t v = n_first + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(v >= n_last)
+		return;
+	const int64_t off = p_off_dim[2 * v], d = p_off_dim[2 * v + 1];
+	for(int64_t r = 0; r < d; ++ r)
+		values[off + r * (d + 1)] += f_alpha;
+}
+
+void damping_enqueue(const int64_t *p_off_dim_dev, int64_t n_first, int64_t n_last, double f_alpha, double *p_values_dev,
+	hipStream_t stream)
+{
+	if(n_last > n_first)
+		hipLaunchKernelGGL(damping_kernel, dim3(unsigned((n_last - n_first + 255) / 256)), dim3(256), 0, stream, p_off_dim_dev,
+			n_first, n_last, f_alpha, p_values_dev);
+}
+
 size_t assembly_device_bytes(const CAssemblyState *p)
 {
 	return p->d_offdiag.n_Bytes() + p->d_diag.n_Bytes() + p->d_diag_vertex.n_Bytes() + p->d_long.n_Bytes() + p->d_long_vertex.n_Bytes() +

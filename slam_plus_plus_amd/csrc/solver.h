@@ -119,6 +119,8 @@ struct slampp_hip_solver {
 	int n_dense_top_tiles;             // option: -1 = decide per structure, 0 = always the dense schedule, 1 = always the tile schedule
 	int n_dense_blks, n_dense_cols, n_dense_dim, n_dense_pad;
 	slampp::CDevArray<double> d_A, d_rhs, d_L, d_Linv, d_w, d_cov;
+	slampp::CDevArray<int64_t> d_damp_off; // (offset of the diagonal block's first element, dimension) per block column: apply_damping
+	bool b_damp_valid = false;
 	slampp::CDevArray<int> d_flag;
 	int *p_host_flag; // pinned
 
@@ -159,6 +161,8 @@ void schur_destroy(CSchurState *p);
 CSchurState *schur_analyze(slampp_hip_solver &s); // throws
 void schur_enqueue(slampp_hip_solver &s, const double *p_values_dev, double *p_rhs_dev); // throws
 void schur_enqueue_marginal_poses(slampp_hip_solver &s, const double *p_values_dev, double *p_rhs_dev); // throws
+void damping_enqueue(const int64_t *p_off_dim_dev, int64_t n_first, int64_t n_last, double f_alpha, double *p_values_dev,
+	hipStream_t stream); // assembly.hip
 void schur_enqueue_marginals(slampp_hip_solver &s, const double *p_values_dev, double *p_cam_cov_dev, double *p_point_cov_dev); // throws
 size_t schur_device_bytes(const CSchurState *p);
 void schur_fill_stats(const CSchurState *p, slampp_hip_stats &st);

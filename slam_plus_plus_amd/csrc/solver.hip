@@ -540,6 +540,40 @@ int slampp_hip_set_structure(slampp_hip_solver *p_solver, int64_t n_bcols, const
 		s.b_has_structure = true;
 		s.b_analyzed = false;
 		s.b_factored = false;
+		s.b_damp_valid = false;
+		return SLAMPP_HIP_OK;
+	});
+}
+
+int slampp_hip_apply_damping_device_async(slampp_hip_solver *p_solver, double *p_values_dev, double f_alpha,
+	int64_t n_first_vertex, int64_t n_last_vertex)
+{
+	return guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_has_structure)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "apply_damping: set_structure was not called");
+		const int64_t n = int64_t(s.cumsum.size()) - 1;
+		if(!p_values_dev || n_first_vertex < 0 || n_first_vertex > n_last_vertex || n_last_vertex > n)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "apply_damping: null pointer or bad vertex range");
+		if(!s.b_damp_valid) {
+			std::vector<int64_t> off_dim(size_t(2 * n));
+			int64_t n_off = 0;
+			for(int64_t c = 0; c < n; ++ c) {
+				const int64_t w = s.cumsum[c + 1] - s.cumsum[c];
+				if(s.bcol_ptr[c + 1] == s.bcol_ptr[c] || s.brow[s.bcol_ptr[c + 1] - 1] != c)
+					return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "apply_damping: a block column has no diagonal block");
+				for(int64_t k = s.bcol_ptr[c]; k + 1 < s.bcol_ptr[c + 1]; ++ k)
+					n_off += (s.cumsum[s.brow[k] + 1] - s.cumsum[s.brow[k]]) * w;
+				off_dim[2 * c] = n_off; // the diagonal block is the last of its column
+				off_dim[2 * c + 1] = w;
+				n_off += w * w;
+			}
+			s.d_damp_off.Upload(off_dim, s.stream);
+			SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream)); // off_dim lives on this stack frame
+			s.b_damp_valid = true;
+		}
+		damping_enqueue(s.d_damp_off.p(), n_first_vertex, n_last_vertex, f_alpha, p_values_dev, s.stream);
+		SLAMPP_HIP_CHECK(hipGetLastError());
 		return SLAMPP_HIP_OK;
 	});
 }

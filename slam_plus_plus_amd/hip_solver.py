@@ -84,6 +84,7 @@ ABI = {
     "slampp_hip_factorize": (C.c_int, [_P, _P, _P]),
     "slampp_hip_solve_marginal_poses": (C.c_int, [_P, _P, _P]),
     "slampp_hip_solve_marginal_poses_device_async": (C.c_int, [_P, _P, _P]),
+    "slampp_hip_apply_damping_device_async": (C.c_int, [_P, _P, C.c_double, C.c_int64, C.c_int64]),
     "slampp_hip_schur_marginals": (C.c_int, [_P, _P, _P, _P]),
     "slampp_hip_schur_marginals_device_async": (C.c_int, [_P, _P, _P, _P]),
     "slampp_hip_factor_solve_device_async": (C.c_int, [_P, _P, _P]),
@@ -320,6 +321,11 @@ class _SolverBase:
 
     def sync(self) -> bool:
         return self._check(self._lib.slampp_hip_sync(self._h))
+
+    def apply_damping_device_async(self, values_ptr: int, f_alpha: float, n_first_vertex: int, n_last_vertex: int) -> None:
+        """ApplyDamping of the reference's LM solver (NonlinearSolver_Lambda_LM.h:228-239) on device-resident values."""
+        self._check(self._lib.slampp_hip_apply_damping_device_async(self._h, values_ptr, float(f_alpha), int(n_first_vertex),
+                                                                    int(n_last_vertex)))
 
     def stream(self) -> int:
         return int(self._lib.slampp_hip_stream(self._h) or 0)

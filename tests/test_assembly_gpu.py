@@ -2,6 +2,8 @@
 Lambda the reference's CNonlinearSolver_Lambda assembled (golden fixtures), and against the CPU oracle on seeded
 synthetic edge sets.  fp64, tolerance 1e-12 relative to the largest entry (sums of a handful of products; the
 summation order differs from the reference's reduction plan, nothing else)."""
+import dataclasses
+
 import numpy as np
 import pytest
 import torch
@@ -181,3 +183,31 @@ def test_hub_vertices_long_lists(d, rd):
     assert torch.equal(values, values2) and torch.equal(eta, eta2)
     values3, eta3, _ = assemble_on_gpu(solver, lam, es, accumulate_into=(values2, eta2))
     assert rel_inf(values3.cpu().numpy(), 2 * ref_values) < TOL and rel_inf(eta3.cpu().numpy(), 2 * ref_eta) < TOL
+
+
+def test_lm_damping_on_device_values():
+    """Assembly -> damping -> solve without Lambda leaving the device: the reference's ApplyDamping
+    (NonlinearSolver_Lambda_LM.h:228-239) on a vertex range, against the same done on the host arrays; then taken out."""
+    lam, es, _ = load_assembly("assembly_se3_n40")
+    solver = CLinearSolver_HIP()
+    values, eta, asm = assemble_on_gpu(solver, lam, es)
+    undamped = values.clone()
+    alpha, first, last = 3.5, 5, 33
+    solver.apply_damping_device_async(values.data_ptr(), alpha, first, last)
+    assert solver.sync()
+    ref = dataclasses.replace(lam, values=lam.values.copy())
+    off = lam.block_value_offsets()
+    for v in range(first, last):
+        k = int(lam.bcol_ptr[v + 1] - 1)
+        d = int(lam.cumsum[v + 1] - lam.cumsum[v])
+        ref.values[off[k]:off[k + 1]].reshape(d, d)[np.arange(d), np.arange(d)] += alpha
+    assert rel_inf(values.cpu().numpy(), ref.values) < TOL
+    ok, x_ref, _ = O.solve_sparse(ref)
+    rhs = eta.clone()
+    assert ok and solver.factor_solve_device(values.data_ptr(), rhs.data_ptr())
+    assert rel_inf(rhs.cpu().numpy(), x_ref) < 1e-10
+    solver.apply_damping_device_async(values.data_ptr(), -alpha, first, last)
+    assert solver.sync()
+    assert rel_inf(values.cpu().numpy(), undamped.cpu().numpy()) < 1e-15
+    with pytest.raises(ValueError):
+        solver.apply_damping_device_async(values.data_ptr(), 1.0, 10, 5)
