@@ -106,7 +106,8 @@ struct slampp_hip_solver {
 	slampp::CDevArray<slampp::TBlkDesc> d_blks;
 	slampp::CDevArray<slampp::TRowEnt> d_rents;
 	slampp::CDevArray<longlong2> d_pairs;
-	slampp::CDevArray<int64_t> d_task_ptr;
+	slampp::CDevArray<int64_t> d_task_ptr, d_task_pkg;
+	slampp::CDevArray<longlong2> d_pkg;
 	slampp::CDevArray<long long> d_timing; // development aid, see TDevPlan::p_timing
 	// dense top of the sparse path (plan.h): assembled Schur complement + dense factor workspaces
 	slampp::CDevArray<slampp::TDenseBlk> d_dense_blks;

@@ -39,7 +39,7 @@ slampp_hip_solver::~slampp_hip_solver()
 
 void slampp_hip_solver::Free_Device()
 {
-	d_cols.Free(); d_blks.Free(); d_rents.Free(); d_pairs.Free(); d_task_ptr.Free();
+	d_cols.Free(); d_blks.Free(); d_rents.Free(); d_pairs.Free(); d_task_ptr.Free(); d_task_pkg.Free(); d_pkg.Free();
 	d_dense_blks.Free(); d_dense_cols.Free(); d_dense.Free(); d_dense_invdiag.Free(); d_dense_z.Free(); d_dense_x.Free();
 	n_dense_blks = n_dense_cols = n_dense_dim = n_dense_pad = 0;
 	dense_tiles.Free();
@@ -59,7 +59,7 @@ size_t slampp_hip_solver::n_Device_Bytes() const
 {
 	return d_dense_blks.n_Bytes() + d_dense_cols.n_Bytes() + d_dense.n_Bytes() + d_dense_invdiag.n_Bytes() + dense_tiles.n_Bytes() +
 		d_dense_z.n_Bytes() + d_dense_x.n_Bytes() + d_cols.n_Bytes() + d_blks.n_Bytes() + d_rents.n_Bytes() +
-		d_task_ptr.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
+		d_task_ptr.n_Bytes() + d_task_pkg.n_Bytes() + d_pkg.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
 		d_rhs.n_Bytes() + d_L.n_Bytes() + d_Linv.n_Bytes() + d_w.n_Bytes() + d_cov.n_Bytes() + d_flag.n_Bytes() +
 		(p_schur? schur_device_bytes(p_schur) : 0);
 }
@@ -194,6 +194,41 @@ void slampp_hip_solver::Analyze_Sparse()
 		rents[e].ycs = int32_t(P.cs_new[c]);
 		rents[e].dc = P.dim[c];
 	}
+	// column packages for the upper stages (see sparse_kernels.h); the limits are those of factor_stage_kernel's staged path
+	std::vector<longlong2> pkg;
+	std::vector<int64_t> task_pkg(P.task_ptr.size() - 1, -1);
+	if(P.uniform_dim && (P.max_dim == 3 || P.max_dim == 6 || P.max_dim == 7)) {
+		enum { PKG_CHUNK = 16, PKG_NR = 128, PKG_NP = 512 };
+		const int n_stages = int(P.stage_ptr.size()) - 1;
+		for(int t = (n_bottom_stages < n_stages)? P.stage_ptr[n_bottom_stages] : int(task_pkg.size()); t < int(task_pkg.size()); ++ t) {
+			task_pkg[t] = int64_t(pkg.size());
+			for(int64_t i = P.task_ptr[t]; i < P.task_ptr[t + 1]; ++ i) {
+				const TColDesc &c = cols[i];
+				const size_t n_at = pkg.size();
+				const bool b_fits = c.nb <= PKG_CHUNK && c.nr <= PKG_NR && c.np <= PKG_NP;
+				const int ne = b_fits? c.nr + c.np : 0;
+				pkg.resize(n_at + (b_fits? package_units(c.nb, ne) : 4), longlong2{0, 0});
+				memcpy(&pkg[n_at], &c, sizeof(TColDesc));
+				if(!b_fits)
+					continue;
+				memcpy(&pkg[n_at + 4], &blks[c.k0], size_t(c.nb) * sizeof(TBlkDesc));
+				longlong2 *p_ent = &pkg[n_at + 4 + 2 * c.nb];
+				int32_t *p_ycs = reinterpret_cast<int32_t*>(p_ent + ne);
+				unsigned char *p_tag = reinterpret_cast<unsigned char*>(p_ent + ne + (ne + 3) / 4);
+				for(int e = 0; e < c.nr; ++ e) { // row entries of the diagonal block: both operands are the block L(j,c)
+					p_ent[e] = longlong2{rents[c.r0 + e].off, rents[c.r0 + e].off};
+					p_ycs[e] = rents[c.r0 + e].ycs;
+					p_tag[e] = 0;
+				}
+				for(int e = 0; e < c.np; ++ e) {
+					const longlong2 pr = pairs[c.p0 + e];
+					p_ent[c.nr + e] = longlong2{pr.x & ((int64_t(1) << 48) - 1), pr.y};
+					p_tag[c.nr + e] = (unsigned char)((pr.x >> 48) & 0xff);
+				}
+			}
+		}
+		pkg.resize(pkg.size() + PKG_SPECULATIVE, longlong2{0, 0});
+	}
 	SETUP_PHASE("records");
 	// dense top
 	n_dense_dim = P.dense_dim;
@@ -275,6 +310,13 @@ void slampp_hip_solver::Analyze_Sparse()
 	d_pairs.Upload(pairs, stream);
 	d_rents.Upload(rents, stream);
 	d_task_ptr.Upload(P.task_ptr, stream);
+	if(!pkg.empty()) {
+		d_pkg.Upload(pkg, stream);
+		d_task_pkg.Upload(task_pkg, stream);
+	} else {
+		d_pkg.Free();
+		d_task_pkg.Free();
+	}
 	SETUP_PHASE("uploads");
 	d_L.Alloc(size_t(P.loff[n_lblocks]));
 	d_Linv.Alloc(size_t(P.linv_off[P.n]));
@@ -289,6 +331,8 @@ void slampp_hip_solver::Analyze_Sparse()
 	dplan.cols = d_cols.p(); dplan.blks = d_blks.p(); dplan.pairs = d_pairs.p(); dplan.rents = d_rents.p();
 	dplan.task_ptr = d_task_ptr.p();
 	dplan.uniform_dim = P.uniform_dim? P.max_dim : 0;
+	dplan.pkg = d_pkg.p();
+	dplan.task_pkg = d_pkg.p()? d_task_pkg.p() : 0;
 	dplan.n_blks = n_lblocks;
 	dplan.n_pairs = int64_t(pairs.size());
 	dplan.n_rents = int64_t(rents.size());

@@ -52,6 +52,15 @@ struct TDenseCol { // 24 B
 	int32_t pos, dj;
 };
 
+enum { PKG_SPECULATIVE = 512 }; // 16-byte units fetched before a package's size is known (one per thread of the kernel)
+
+// units of a package: header (4) + nb block records (2 each) + ne = nr + np operand pairs (1 each) + their
+// right-hand side offsets (4 per unit) + their target tags (16 per unit)
+inline __host__ __device__ int package_units(int nb, int ne)
+{
+	return 4 + 2 * nb + ne + (ne + 3) / 4 + (ne + 15) / 16;
+}
+
 struct TDevPlan {
 	const TColDesc *cols;      // [n] in *schedule* order: the columns of task t are cols[task_ptr[t] .. task_ptr[t+1])
 	const TBlkDesc *blks;      // [l_blocks]
@@ -60,6 +69,13 @@ struct TDevPlan {
 	const int64_t *task_ptr;   // [n_tasks+1]
 	int uniform_dim;           // > 0: every block column has this dimension (3, 6, 7 get unrolled kernels)
 	int64_t n_blks, n_pairs, n_rents; // lengths of the arrays above (bulk loads of a task's records stop there)
+	// column packages of the upper stages (fixed block size only): per task the offset, in 16-byte units, of its first
+	// column's package in pkg, or -1; a package is the column's TColDesc followed -- if it fits the staged path of
+	// factor_stage_kernel -- by its records in the very layout that kernel keeps them in LDS, so that one coalesced
+	// read brings the descriptor and the records together instead of one after the other.  The packages of a task's
+	// columns follow each other; pkg is padded so that a read of PKG_SPECULATIVE units from any package start stays inside
+	const longlong2 *pkg;
+	const int64_t *task_pkg;
 	long long *p_timing;       // development aid (SLAMPP_HIP_STAGE_TIMING): [0] = launches so far, then 32 clock
 	                           // samples per launch of workgroup 0 of the multi-wave factor kernel; normally null
 };

@@ -99,9 +99,11 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 	__shared__ TRowEnt s_rent[UP_NR];
 	__shared__ longlong2 s_prec[UP_NP];
 	__shared__ unsigned char s_ptag[UP_NP];
-	__shared__ longlong2 s_ent[D? UP_NR + UP_NP : 1]; // fixed block size: row entries, then pairs, as (a, b) offsets
-	__shared__ int s_ycs[D? UP_NR + UP_NP : 1];
-	__shared__ unsigned char s_tag[D? UP_NR + UP_NP : 1];
+	// fixed block size: the column's package (descriptor, block records, then row entries and pairs alike as (a, b)
+	// operand offsets with their right-hand side offsets and target tags), copied from the plan as it is
+	enum { PKG_UNITS = 4 + 2 * CHUNK + (UP_NR + UP_NP) + (UP_NR + UP_NP + 3) / 4 + (UP_NR + UP_NP + 15) / 16 };
+	__shared__ longlong2 s_pkg[D? PKG_UNITS : 1];
+	static_assert(64 * W == PKG_SPECULATIVE && PKG_SPECULATIVE <= PKG_UNITS, "one speculative unit per thread");
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
 	const int task = task_begin + blockIdx.x;
 	long long *p_tm = 0;
@@ -112,19 +114,43 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 	}
 #define STAGE_TICK() do { if(p_tm && n_tm < 32) p_tm[n_tm ++] = wall_clock64(); } while(0)
 	const int64_t c_begin = p.task_ptr[task], c_end = p.task_ptr[task + 1];
+	int64_t n_pkg_at = (D && p.task_pkg)? p.task_pkg[task] : -1;
 	for(int64_t c = c_begin; c < c_end; ++ c) {
-		const TColDesc cd = p.cols[c];
+		TColDesc cd;
+		bool b_packaged = false;
+		if(D && n_pkg_at >= 0) {
+			// one unit per thread before the size is known: the descriptor and, for all but the largest columns, every record
+			s_pkg[tid] = p.pkg[n_pkg_at + tid];
+			__syncthreads();
+			cd = *reinterpret_cast<const TColDesc*>(s_pkg);
+			b_packaged = cd.nb <= CHUNK && cd.nr <= UP_NR && cd.np <= UP_NP;
+			const int n_units = b_packaged? package_units(cd.nb, cd.nr + cd.np) : 4;
+			for(int e = 64 * W + tid; e < n_units; e += 64 * W)
+				s_pkg[e] = p.pkg[n_pkg_at + e];
+			n_pkg_at += n_units;
+			__syncthreads();
+		} else
+			cd = p.cols[c];
 		const int dj = D? D : cd.dj;
-		STAGE_TICK(); // column descriptor here
+		STAGE_TICK(); // column descriptor (and records, if packaged) here
 		const bool b_y_inline = dj <= 7;
 		const bool b_y = b_y_inline && lane >= Y_LANE0 && lane < Y_LANE0 + dj;
 		const TLaneMap md = lane_map(lane, dj, dj);
 		const int yq = b_y? lane - Y_LANE0 : md.q;
 		const bool b_staged = D != 0;
 		if(cd.nb <= CHUNK && cd.nr <= UP_NR && cd.np <= UP_NP) {
-			for(int e = tid; e < cd.nb; e += 64 * W)
-				s_blk[e] = p.blks[cd.k0 + e];
-			if(b_staged) { // rows and pairs as one list of (a, b) operand offsets for the unified loop below
+			// where the staged records sit in the package image
+			const int ne_all = cd.nr + cd.np;
+			TBlkDesc *s_pblk = reinterpret_cast<TBlkDesc*>(s_pkg + 4);
+			longlong2 *s_ent = s_pkg + 4 + 2 * cd.nb;
+			int *s_ycs = reinterpret_cast<int*>(s_ent + ne_all);
+			unsigned char *s_tag = reinterpret_cast<unsigned char*>(s_ent + ne_all + (ne_all + 3) / 4);
+			if(b_staged && b_packaged) {
+				if(tid < cd.nb)
+					s_blk[tid] = s_pblk[tid]; // (the code below indexes s_blk)
+			} else if(b_staged) { // rows and pairs as one list of (a, b) operand offsets for the unified loop below
+				for(int e = tid; e < cd.nb; e += 64 * W)
+					s_blk[e] = p.blks[cd.k0 + e];
 				for(int e = tid; e < cd.nr; e += 64 * W) {
 					const TRowEnt en = p.rents[cd.r0 + e];
 					s_ent[e] = longlong2{en.off, en.off};
@@ -137,6 +163,8 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 					s_tag[cd.nr + e] = (unsigned char)((pr.x >> 48) & 0xff);
 				}
 			} else {
+				for(int e = tid; e < cd.nb; e += 64 * W)
+					s_blk[e] = p.blks[cd.k0 + e];
 				for(int e = tid; e < cd.nr; e += 64 * W)
 					s_rent[e] = p.rents[cd.r0 + e];
 				for(int e = tid; e < cd.np; e += 64 * W)
