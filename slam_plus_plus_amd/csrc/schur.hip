@@ -424,9 +424,26 @@ schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *s
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const bool b_act = lane < DC * DC;
 	const int r = b_act? lane % DC : 0, q = b_act? lane / DC : 0;
-	const bool b_loader = lane < 2 * BLK;
+	// Every lane loads (lanes past the two operand blocks repeat the last element: same cache line, no branch around
+	// the load), from one base pointer: lanes 0 .. BLK-1 the block U_b at A + u, the others W_a, addressed relative to A
+	// as well.  All of this is there to keep the wave-instruction count of an entry down -- with eight waves per SIMD
+	// resident the kernel is bound by instruction issue around its loads, not by the loads.
+	const int lane_c = (lane < 2 * BLK)? lane : 2 * BLK - 1;
+	const bool b_u = lane_c < BLK;
+	const int64_t lane_off = b_u? lane_c : lane_c - BLK;
+	const int64_t w_rel = W_ - A; // in doubles; both arrays live in the one flat device address space
 	typedef double v4f64 __attribute__((ext_vector_type(4)));
 	v4f64 macc = {0, 0, 0, 0};
+	// the MFMA fragment a lane reads for step q4 of a batch: entry, and offset of its element of U inside s_ops[wave]
+	int frag_ent[BATCH * DP / 4], frag_off[BATCH * DP / 4];
+	#pragma unroll
+	for(int q4 = 0; q4 < BATCH * DP / 4; ++ q4) {
+		const int kg = 4 * q4 + (lane >> 4), ent = kg / DP, t = kg % DP;
+		const int m = lane & 15, mm = (m < DC)? m : 0;
+		frag_ent[q4] = ent;
+		frag_off[q4] = ent * (2 * BLK) + mm + t * DC;
+	}
+	const double *s_my = &s_ops[wave][0][0];
 	const int64_t e0 = sb_ptr[sb], e1 = sb_ptr[sb + 1];
 	// this wave's entries: e0 + wave, e0 + wave + W, ...; processed in chunks of 64
 	for(int64_t base = e0 + wave; base < e1; base += int64_t(64) * W) {
@@ -442,12 +459,12 @@ schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *s
 				const int32_t a = __builtin_amdgcn_readlane(my_a, idx);
 				const int64_t u = (int64_t(__builtin_amdgcn_readlane(int(my_u >> 32), idx)) << 32) |
 					uint32_t(__builtin_amdgcn_readlane(int(my_u), idx));
-				const double *src = (lane < BLK)? A + u + lane : W_ + int64_t(a) * BLK + (lane - BLK);
-				v[j] = b_loader? *src : 0.0;
+				const int64_t w_at = w_rel + int64_t(a) * BLK; // wave-uniform, like u
+				v[j] = A[(b_u? u : w_at) + lane_off];
 			}
-			#pragma unroll
-			for(int j = 0; j < BATCH; ++ j) {
-				if(b_loader)
+			if(lane < 2 * BLK) {
+				#pragma unroll
+				for(int j = 0; j < BATCH; ++ j)
 					s_ops[wave][j][lane] = v[j];
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -455,12 +472,11 @@ schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *s
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 			// the batch is one small GEMM: S block (DC x DC) += [U_1 .. U_BATCH] [W_1 .. W_BATCH]^T with K = BATCH * DP,
 			// four k at a time on the matrix cores (rows / columns >= DC of the 16 x 16 tile are don't-cares)
+			const int n_left = n_chunk - i; // entries of the batch that exist
 			#pragma unroll
 			for(int q4 = 0; q4 < BATCH * DP / 4; ++ q4) {
-				const int kg = 4 * q4 + (lane >> 4), ent = kg / DP, t = kg % DP;
-				const int m = lane & 15, mm = (m < DC)? m : 0;
-				const double a = (i + ent < n_chunk)? s_ops[wave][ent][mm + t * DC] : 0.0; // the tail repeats its last entry: not summed
-				const double b = s_ops[wave][ent][BLK + mm + t * DC];
+				const double a = (frag_ent[q4] < n_left)? s_my[frag_off[q4]] : 0.0; // the tail repeats its last entry: not summed
+				const double b = s_my[frag_off[q4] + BLK];
 				macc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, macc, 0, 0, 0);
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
