@@ -61,21 +61,24 @@ def test_dense_kernels_keep_two_workgroups_per_cu(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    src = os.path.join(ROOT, "slam_plus_plus_amd", "csrc", "dense_chol.hip")
-    out = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "--cuda-device-only", "-c",
-                          "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "x.o"), src],
-                         capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
     report, name = {}, None
-    for line in out.stderr.splitlines():
-        m = re.search(r"remark:\s+Function Name: (\S+)", line)
-        if m:
-            name = m.group(1)
-            report[name] = {}
-        m = re.search(r"remark:\s+(Occupancy \[waves/SIMD\]|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]): (\d+)", line)
-        if m and name:
-            report[name][m.group(1).split(" [")[0]] = int(m.group(2))
-    for needle in ("potrf_diag_kernel", "11syrk_kernel", "11trsm_kernel"):
+    for fname in ("dense_chol.hip", "dense_inverse.hip"):
+        src = os.path.join(ROOT, "slam_plus_plus_amd", "csrc", fname)
+        out = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "--cuda-device-only",
+                              "-c", "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "x.o"), src],
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        for line in out.stderr.splitlines():
+            m = re.search(r"remark:\s+Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                report[name] = {}
+            m = re.search(r"remark:\s+(Occupancy \[waves/SIMD\]|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]): (\d+)", line)
+            if m and name:
+                report[name][m.group(1).split(" [")[0]] = int(m.group(2))
+    # (the inverse's tile kernels: two workgroups per CU as well, or their 47 TFLOP/s halve)
+    for needle in ("potrf_diag_kernel", "11syrk_kernel", "11trsm_kernel", "inverse_lauum_kernel", "inverse_level_kernelILb0",
+                   "inverse_level_kernelILb1"):
         hits = [v for k, v in report.items() if needle in k and "variant" not in k]
         assert hits, (needle, list(report))
         assert hits[0]["Occupancy"] >= 2 and hits[0]["ScratchSize"] == 0 and hits[0]["LDS Size"] <= 80 * 1024, (needle, hits[0])
