@@ -32,9 +32,10 @@ namespace slampp {
 #include "sparse_device.inl"
 
 // ---- bottom stage: whole elimination subtrees, one wave each (touches most of Lambda and L) ----
-// With 8 waves per SIMD resident this kernel is bound by instruction issue, not by memory latency
-// (measured: staging the index records of a column through LDS to save dependent loads made it
-// slower), so it keeps the instruction count per column low: one block, one update at a time.
+// First version, through global memory; used for mixed block sizes (D = 0) and, with SLAMPP_HIP_SUBTREE_V1 set, for
+// A/B timing against subtree_kernel.hip, which took over the fixed block sizes.  With 8 waves per SIMD resident it is
+// bound by instruction issue, not by memory latency (the LDS version runs at the same speed: DESIGN.md section 4.1),
+// so it keeps the instruction count per column low: one block, one update at a time.
 template <int D>
 __global__ void __launch_bounds__(64)
 factor_subtree_kernel(TDevPlan p, const double *__restrict__ A, double *L, double *Linv,
