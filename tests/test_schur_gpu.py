@@ -410,3 +410,27 @@ def test_schur_marginals_two_landmark_shards():
         assert rel_inf(cams, cams_ref) < TOL
         pts[(sl.start - n_x) // 3:(sl.stop - n_x) // 3] = p
     assert rel_inf(pts, pts_ref) < TOL
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_ba_systems_match_oracle(seed):
+    """Random sizes, visibility patterns, block sizes and reduced-system modes through the Schur path -- solve and
+    covariances against the oracle."""
+    rng = np.random.default_rng(500 + seed)
+    cam_dim, pt_dim = [(6, 3), (7, 3), (3, 2)][int(rng.integers(0, 3))]
+    nc = int(rng.integers(2, 140))
+    n_pts = int(rng.integers(1, 2500))
+    mode = ["band", "uniform", "venice"][int(rng.integers(0, 3))]
+    k = int(rng.integers(1, 7))
+    lam = synth.ba(nc, n_pts, k=k, mode=mode, seed=900 + seed, cam_dim=cam_dim, pt_dim=pt_dim)
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok
+    sparse = int(rng.integers(-1, 2))
+    solver = CLinearSolver_Schur_HIP(schur_sparse=sparse)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta), (seed, nc, n_pts, mode, k, sparse)
+    assert rel_inf(eta, x_ref) < TOL, (seed, nc, n_pts, mode, k, sparse)
+    if seed % 3 == 0:
+        cams_ref, pts_ref = O.schur_marginals(lam)
+        cams, pts = solver.Schur_Marginals(lam)
+        assert rel_inf(cams, cams_ref) < TOL and rel_inf(pts, pts_ref) < TOL

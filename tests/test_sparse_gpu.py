@@ -155,3 +155,59 @@ def test_factorize_not_posdef_and_dense_top_refused():
     assert not ok
     with pytest.raises(NotImplementedError):
         CLinearSolver_HIP().factorize(synth.sphere(30, 30))      # a dense top keeps part of the factor elsewhere
+
+
+def random_system(seed):
+    """Random connected block graph (a spanning chain plus random chords, some hubs), block dimensions uniform or a mix of
+    2 .. 8, diagonally dominant symmetric positive definite values."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(2, 400))
+    dims = np.full(n, rng.choice([3, 6, 7])) if rng.random() < 0.6 else rng.integers(2, 9, n)
+    chords = int(rng.integers(0, 3 * n))
+    a, b = rng.integers(0, n, chords), rng.integers(0, n, chords)
+    if rng.random() < 0.3 and n > 20:                       # a hub: a column with many blocks, a big separator
+        hub = int(rng.integers(0, n))
+        a = np.concatenate([a, np.full(n // 3, hub)])
+        b = np.concatenate([b, rng.integers(0, n, n // 3)])
+    v0 = np.concatenate([np.arange(n - 1), np.minimum(a, b)])
+    v1 = np.concatenate([np.arange(1, n), np.maximum(a, b)])
+    keep = v0 != v1
+    lam = synth.structure_from_edges(dims, v0[keep], v1[keep])
+    off = lam.block_value_offsets()
+    vals = rng.standard_normal(lam.values.shape[0])
+    col = np.repeat(np.arange(n), np.diff(lam.bcol_ptr))
+    row_sum = np.zeros(int(lam.cumsum[-1]))                 # absolute row sums of the off-diagonal part, both triangles
+    for k in range(lam.n_blocks):
+        r, c = int(lam.brow_idx[k]), int(col[k])
+        if r == c:
+            continue
+        blk = vals[off[k]:off[k + 1]].reshape(dims[c], dims[r]).T      # column-major dims[r] x dims[c]
+        row_sum[lam.cumsum[r]:lam.cumsum[r + 1]] += np.abs(blk).sum(axis=1)
+        row_sum[lam.cumsum[c]:lam.cumsum[c + 1]] += np.abs(blk).sum(axis=0)
+    for v in range(n):
+        k = int(lam.bcol_ptr[v + 1] - 1)
+        d = int(dims[v])
+        m = vals[off[k]:off[k + 1]].reshape(d, d)
+        m = 0.5 * (m + m.T)
+        m[np.arange(d), np.arange(d)] = np.abs(m).sum(axis=1) + row_sum[lam.cumsum[v]:lam.cumsum[v + 1]] + 1.0
+        vals[off[k]:off[k + 1]] = m.ravel()
+    lam.values[:] = vals
+    lam.rhs[:] = rng.standard_normal(lam.rhs.shape[0])
+    opts = {}
+    if rng.random() < 0.5:
+        opts = {"leaf_size": int(rng.integers(1, 9)), "subtree_size": int(rng.integers(1, 20)),
+                "dense_top_nb": int(rng.choice([0, 2, 6, 24])), "nd_balance": int(rng.integers(5, 45))}
+    return lam, opts
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_structures_match_oracle(seed):
+    lam, opts = random_system(1000 + seed)
+    ok, x_ref, _ = O.solve_sparse(lam)
+    assert ok
+    solver = CLinearSolver_HIP(**opts)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta), (seed, opts)
+    assert rel_inf(eta, x_ref) < TOL, (seed, opts, lam.n_bcols)
+    eta3 = lam.rhs.copy()
+    assert solver.Solve_Again(eta3) and rel_inf(eta3, x_ref) < TOL
