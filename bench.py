@@ -335,26 +335,40 @@ def cpu_baseline_ba(lam, flops):
 
 def marginals_leg(args, solver, lam, vals, dev, torch):
     """Block diagonal of the covariance on the bench's BA system, after the timed solves:
-    the reduced system assembled densely, factored, inverted on the matrix cores (2 n^3 / 3 flops), gathered per landmark.
-    The reference's CSchurComplement_Marginals is run beside it on a bounded sample (--no-cpu-baseline skips it)."""
+    the reduced system assembled and factored as for a solve, the blocks of its inverse the landmarks need taken from
+    a sparse inverse subset on the factor's pattern -- or, `dense_inverse`, S inverted on the matrix cores (2 n^3 / 3
+    flops) -- then gathered per landmark.  The reference's CSchurComplement_Marginals is run beside it on a bounded
+    sample (--no-cpu-baseline skips it)."""
     nc, n_pts = lam.n_matrix_cut, lam.n_bcols - lam.n_matrix_cut
     cams = torch.empty(nc * 36, dtype=torch.float64, device=dev)
     pts = torch.empty(n_pts * 9, dtype=torch.float64, device=dev)
-    solver.schur_marginals_device_async(vals.data_ptr(), cams.data_ptr(), pts.data_ptr())
-    if not solver.sync():
-        return None
-    solver.profile(reset=True)
-    reps = 3
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    def timed():
         solver.schur_marginals_device_async(vals.data_ptr(), cams.data_ptr(), pts.data_ptr())
-    ok = solver.sync()
-    ms = (time.perf_counter() - t0) / reps * 1e3
-    prof = {k_: v[1] / max(v[0], 1) for k_, v in solver.profile().items() if k_.startswith("marginals")}
-    solver.profile(reset=True)
+        if not solver.sync():
+            return None
+        solver.profile(reset=True)
+        reps = 3
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            solver.schur_marginals_device_async(vals.data_ptr(), cams.data_ptr(), pts.data_ptr())
+        ok_ = solver.sync()
+        ms_ = (time.perf_counter() - t0) / reps * 1e3
+        prof_ = {k_: v[1] / max(v[0], 1) for k_, v in solver.profile().items() if k_.startswith("marginals")}
+        solver.profile(reset=True)
+        return ok_, ms_, prof_
+
+    # first the way the library picks (the sparse inverse subset when the solves factor S by the sparse block path), then
+    # with S inverted densely on the matrix cores: that one has the MFMA roofline
     n = 6.0 * nc
-    tf = 2.0 * n ** 3 / 3.0 / (prof["marginals_inverse"] * 1e-3) / 1e12
+    solver.set_option("marginals_dense", 1)
+    r_dense = timed()
+    solver.set_option("marginals_dense", 0)
+    r = timed()
+    if r is None or r_dense is None:
+        return None
+    ok, ms, prof = r
+    tf = 2.0 * n ** 3 / 3.0 / (r_dense[2]["marginals_inverse"] * 1e-3) / 1e12
     # a sampled check against the definition: column j of the covariance is the solution of Lambda x = e_j
     c_np, p_np = cams.cpu().numpy().reshape(nc, 6, 6), pts.cpu().numpy().reshape(n_pts, 3, 3)
     err = 0.0
@@ -367,9 +381,12 @@ def marginals_leg(args, solver, lam, vals, dev, torch):
         err = max(err, float(np.abs(ref - blk[idx][:, 0]).max() / np.abs(ref).max()))
     out = {"workload": f"block diagonal of Lambda^-1: {nc} camera blocks 6x6 + {n_pts} landmark blocks 3x3", "ok": bool(ok),
            "ms_per_call": ms, "phases_ms": prof, "column_check_rel_inf": err,
-           "roofline": {"bound": "mfma", "kernel": "inverse_level_kernel + inverse_lauum_kernel (inverse of S from its factor)",
-                        "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS,
-                        "traffic": None, "flops": 2.0 * n ** 3 / 3.0, "ms": prof["marginals_inverse"]}}
+           "dense_inverse": {"ok": bool(r_dense[0]), "ms_per_call": r_dense[1], "phases_ms": r_dense[2],
+                             "roofline": {"bound": "mfma",
+                                          "kernel": "inverse_level_kernel + inverse_lauum_kernel (inverse of S from its factor)",
+                                          "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": tf / F64_MFMA_PEAK_TFLOPS, "traffic": None, "flops": 2.0 * n ** 3 / 3.0,
+                                          "ms": r_dense[2]["marginals_inverse"]}}}
     if not args.no_cpu_baseline:
         from oracle import oracle_lib as O
         if O.have_reference():

@@ -84,7 +84,10 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
  * chain of dependent launches, default),
  * "schur_sparse" (Schur mode: the reduced camera system S is factored by the sparse block path instead of the dense
  * one; -1 = when fewer than 3 % of its camera-camera blocks are nonzero (default), 0 = never, 1 = always; the
- * reference makes this choice at compile time: __SCHUR_USE_DENSE_SOLVER, include/slam/LinearSolver_Schur.h:48-55, "faster if ... dense enough") */
+ * reference makes this choice at compile time: __SCHUR_USE_DENSE_SOLVER, include/slam/LinearSolver_Schur.h:48-55, "faster if ... dense enough"),
+ * "marginals_dense" (Schur mode: 1 = slampp_hip_schur_marginals always inverts the reduced system densely; 0 (default) =
+ * when the solves factor it by the sparse block path, the covariances take the blocks of S^-1 they need from a
+ * sparse inverse subset on that factor's pattern) */
 int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int64_t n_value);
 
 /* structure of Lambda -- stands in for what the reference's wrappers read through
@@ -139,10 +142,13 @@ int slampp_hip_solve_marginal_poses_device_async(slampp_hip_solver *p_solver, co
  * complement it has to compute for the purpose).  Here the reduced camera system is assembled, factored and inverted
  * on the device in one call: p_cam_cov receives n_cams blocks of dc x dc doubles (the diagonal blocks of S^-1; may be
  * NULL to skip them, as b_do_cam_marginals = false does), p_point_cov n_points blocks of dp x dp doubles
- * (C_p^-1 + W_p^T S^-1 W_p), column-major, in the block order of slampp_hip_set_structure.  The reduced system is
- * always taken dense for this (2 x 8 n^2 bytes of device memory, n = n_cams dc).  With landmark shards every rank
- * calls it, passes its own values and receives the covariances of its own landmarks (the all-reduce callback is
- * invoked once on the whole n_pad^2 buffer).  Returns SLAMPP_HIP_NOT_POSDEF like the solve. */
+ * (C_p^-1 + W_p^T S^-1 W_p), column-major, in the block order of slampp_hip_set_structure.  When the solves
+ * factor the reduced system by the sparse block path (option "schur_sparse"), the blocks of S^-1 come from a sparse
+ * inverse subset on that factor's pattern (every camera pair that shares a landmark is in it); otherwise, or with
+ * option "marginals_dense", S is inverted densely (2 x 8 n^2 bytes of device memory, n = n_cams dc).  With landmark
+ * shards every rank calls it, passes its own values and receives the covariances of its own landmarks (the
+ * all-reduce callback is invoked once, on the packed blocks or on the whole n_pad^2 buffer).  Returns
+ * SLAMPP_HIP_NOT_POSDEF like the solve. */
 int slampp_hip_schur_marginals(slampp_hip_solver *p_solver, const double *p_values, double *p_cam_cov, double *p_point_cov);
 int slampp_hip_schur_marginals_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,
 	double *p_cam_cov_dev, double *p_point_cov_dev);

@@ -20,6 +20,7 @@
 // dense factorization; only the primary shard adds A and x.
 #include "solver.h"
 #include "dense_chol.h"
+#include "sparse_inverse.h"
 
 #include <algorithm>
 #include <cstring>
@@ -58,13 +59,20 @@ struct CSchurState {
 	CDevArray<double> d_in_buf;                // [values (n_in_blocks DC^2) | right-hand side (N)]: also what the ranks exchange
 	// marginal covariances (own buffers: the factor the last solve left behind stays usable)
 	CDevArray<double> d_m_S, d_m_Z, d_m_invdiag, d_m_zero;
+	// ... through the sparse inverse subset when the reduced system is factored by the sparse block path
+	CSparseInverse *p_sinv;
+	bool b_sinv_tried;
+	CDevArray<double> d_m_Zs;                  // laid out like the inner solver's factor
+	CDevArray<int64_t> d_cam_zoff, d_pair_ptr, d_pair_tab;
 	CSchurState() :p_union_fn(0), p_union_context(0), b_union_dense(false), n_union(0), b_reduced_decided(false),
-		b_reduced_sparse(false), p_inner(0), n_in_blocks(0) {}
+		b_reduced_sparse(false), p_inner(0), n_in_blocks(0), p_sinv(0), b_sinv_tried(false) {}
 	~CSchurState();
 };
 
 CSchurState::~CSchurState()
 {
+	if(p_sinv)
+		sparse_inverse_destroy(p_sinv);
 	if(p_inner) {
 		p_inner->stream = 0; // borrowed from the owning solver
 		delete p_inner;
@@ -80,7 +88,8 @@ size_t schur_device_bytes(const CSchurState *p)
 		p->d_cam_ptr.n_Bytes() + p->d_cam_obs.n_Bytes() + p->d_S.n_Bytes() + p->d_W.n_Bytes() +
 		p->d_un_row.n_Bytes() + p->d_un_col.n_Bytes() + p->d_pack.n_Bytes() + p->d_sb_dst.n_Bytes() + p->d_a_dst.n_Bytes() +
 		p->d_in_buf.n_Bytes() + (p->p_inner? p->p_inner->n_Device_Bytes() : 0) + p->d_m_S.n_Bytes() + p->d_m_Z.n_Bytes() +
-		p->d_m_invdiag.n_Bytes() + p->d_m_zero.n_Bytes() +
+		p->d_m_invdiag.n_Bytes() + p->d_m_zero.n_Bytes() + p->d_m_Zs.n_Bytes() + p->d_cam_zoff.n_Bytes() +
+		p->d_pair_ptr.n_Bytes() + p->d_pair_tab.n_Bytes() + sparse_inverse_bytes(p->p_sinv) +
 		p->d_Cinv.n_Bytes() + p->d_t.n_Bytes() + p->d_invdiag.n_Bytes() + p->d_z.n_Bytes() + p->d_x.n_Bytes();
 }
 
@@ -756,6 +765,11 @@ static void schur_setup_reduced(slampp_hip_solver &s, CSchurState &S)
 static void schur_try_sparse_reduced(slampp_hip_solver &s, CSchurState &S)
 {
 	S.b_reduced_sparse = false;
+	if(S.p_sinv) { // lists of the previous inner solver
+		sparse_inverse_destroy(S.p_sinv);
+		S.p_sinv = 0;
+	}
+	S.b_sinv_tried = false;
 	if(S.p_inner) {
 		S.p_inner->stream = 0;
 		delete S.p_inner;
@@ -999,12 +1013,130 @@ void schur_marginals_launch(int DC, int DP, int64_t nc, int64_t np, const int64_
 // own whatever way the solves factor it, factored, inverted on the matrix cores, then gathered per landmark.
 // Landmark shards: S is summed over the ranks as a whole buffer (the padding diagonal comes back as the number
 // of ranks, which its decoupled rows do not mind); every rank then writes the covariances of its own landmarks.
+void schur_marginals_sparse_launch(int DC, int DP, int64_t nc, int64_t np, const int64_t *ptr, const int64_t *cam_zoff,
+	const int64_t *pair_ptr, const int64_t *pair_tab, const double *W, const double *Cinv, const double *Z, double *cam_cov,
+	double *point_cov, hipStream_t stream); // schur_marginals.hip
+
+// lists of the sparse inverse subset and the tables that say where the blocks the covariances need sit in it; false if
+// the inner solver's plan is not of the kind sparse_inverse_setup takes (then the dense inverse is used)
+static bool schur_setup_sparse_marginals(slampp_hip_solver &s, CSchurState &S)
+{
+	if(S.b_sinv_tried)
+		return S.p_sinv != 0;
+	S.b_sinv_tried = true;
+	const Plan &P = S.p_inner->plan;
+	if(P.max_dim != S.DC)
+		return false;
+	S.p_sinv = sparse_inverse_setup(P, s.stream);
+	if(!S.p_sinv)
+		return false;
+	const int64_t nc = S.nc, np = S.np;
+	const int64_t *ptr = s.bcol_ptr.data();
+	const int32_t *brow = s.brow.data();
+	std::vector<int64_t> cam_zoff(nc), pair_ptr(np + 1, 0);
+	for(int64_t c = 0; c < nc; ++ c)
+		cam_zoff[c] = P.loff[P.lptr[P.pinv[c]]];
+	for(int64_t pt = 0; pt < np; ++ pt) {
+		const int64_t k = ptr[nc + pt + 1] - ptr[nc + pt] - 1;
+		pair_ptr[pt + 1] = pair_ptr[pt] + k * (k + 1) / 2;
+	}
+	std::vector<int64_t> pair_tab((size_t(pair_ptr[np])));
+	for(int64_t pt = 0; pt < np; ++ pt) {
+		const int64_t k0 = ptr[nc + pt], k = ptr[nc + pt + 1] - k0 - 1;
+		int64_t *tab = pair_tab.data() + pair_ptr[pt];
+		for(int64_t a = 0; a < k; ++ a) {
+			const int32_t pa = P.pinv[brow[k0 + a]];
+			for(int64_t b = 0; b <= a; ++ b) {
+				const int32_t pb = P.pinv[brow[k0 + b]];
+				const int64_t off = plan_block_offset(P, std::max(pa, pb), std::min(pa, pb));
+				if(off < 0)
+					throw std::logic_error("covariances: a camera pair that shares a landmark is not a block of the reduced system's factor");
+				tab[a * (a + 1) / 2 + b] = off * 2 + (pa < pb); // Z(cam_a, cam_b) is the stored block, or its transpose
+			}
+		}
+	}
+	S.d_cam_zoff.Upload(cam_zoff, s.stream);
+	S.d_pair_ptr.Upload(pair_ptr, s.stream);
+	S.d_pair_tab.Upload(pair_tab, s.stream);
+	S.d_m_Zs.Alloc(size_t(P.loff.back()));
+	if(!S.d_m_zero.p()) {
+		S.d_m_zero.Alloc(size_t(S.N));
+		SLAMPP_HIP_CHECK(hipMemsetAsync(S.d_m_zero.p(), 0, size_t(S.N) * sizeof(double), s.stream));
+	}
+	SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream)); // the tables live on this stack frame
+	return true;
+}
+
+// the covariances when the reduced system is factored by the sparse block path: the same assembly as a solve (into the
+// inner solver's packed values, summed over the ranks), its factorization, then the blocks of S^-1 on the factor's
+// pattern (sparse_inverse.hip) instead of a dense inverse -- the cost of a second factorization, and no n^2 memory
+template <int DC, int DP>
+static void schur_enqueue_marginals_sparse_t(slampp_hip_solver &s, CSchurState &S, const double *A, double *cam_cov,
+	double *point_cov)
+{
+	hipStream_t st = s.stream;
+	const int n = S.N;
+	const int64_t ubase = S.n_ablocks * DC * DC;
+	const size_t n_in_values = size_t(S.n_in_blocks) * DC * DC;
+	double *p_S = S.d_in_buf.p(), *p_r = S.d_in_buf.p() + n_in_values;
+	SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), st));
+	s.Phase_Begin("marginals_assemble");
+	SLAMPP_HIP_CHECK(hipMemsetAsync(p_S, 0, (n_in_values + size_t(n)) * sizeof(double), st));
+	if(s.b_shard_primary) {
+		const int64_t n_work = std::max<int64_t>(S.n_ablocks * DC * DC, n);
+		hipLaunchKernelGGL((schur_scatter_A_kernel<DC>), dim3(unsigned((n_work + 255) / 256)), dim3(256), 0, st,
+			S.d_ptr.p(), S.d_brow.p(), S.nc, A, S.d_m_zero.p(), p_S, S.Npad, n, S.d_a_dst.p(), p_r);
+	}
+	hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((S.np + 255) / 256)), dim3(256), 0, st,
+		S.d_ptr.p(), S.nc, S.np, ubase, A, S.d_Cinv.p(), s.d_flag.p());
+	hipLaunchKernelGGL((schur_obs_W_kernel<DC, DP>), dim3(unsigned((S.n_obs + 255) / 256)), dim3(256), 0, st,
+		S.n_obs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p());
+	if(S.n_sblocks > 0) {
+		if(S.n_entries > 256 * S.n_sblocks)
+			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 8>), dim3(unsigned(S.n_sblocks)), dim3(512), 0, st,
+				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
+				S.d_W.p(), p_S, S.Npad, S.d_sb_dst.p());
+		else
+			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 1>), dim3(unsigned(S.n_sblocks)), dim3(64), 0, st,
+				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
+				S.d_W.p(), p_S, S.Npad, S.d_sb_dst.p());
+	}
+	s.Phase_End();
+	if(s.p_allreduce) {
+		s.Phase_Begin("allreduce");
+		if(s.p_allreduce(s.p_allreduce_context, p_S, n_in_values + size_t(n), (void*)st) != 0)
+			throw CDeviceError("all-reduce callback failed");
+		s.Phase_End();
+	}
+	s.Phase_Begin("marginals_factor");
+	S.p_inner->Enqueue_Sparse(p_S, p_r, true, true); // numeric factorization only
+	hipLaunchKernelGGL(schur_merge_flag_kernel, dim3(1), dim3(1), 0, st, S.p_inner->d_flag.p(), s.d_flag.p());
+	s.Phase_End();
+	s.Phase_Begin("marginals_inverse");
+	sparse_inverse_enqueue(*S.p_sinv, S.p_inner->plan, S.p_inner->d_L.p(), S.p_inner->d_Linv.p(), S.d_m_Zs.p(), st);
+	s.Phase_End();
+	s.Phase_Begin("marginals_gather");
+	schur_marginals_sparse_launch(DC, DP, S.nc, S.np, S.d_ptr.p(), S.d_cam_zoff.p(), S.d_pair_ptr.p(), S.d_pair_tab.p(),
+		S.d_W.p(), S.d_Cinv.p(), S.d_m_Zs.p(), cam_cov, point_cov, st);
+	s.Phase_End();
+	SLAMPP_HIP_CHECK(hipGetLastError());
+}
+
 template <int DC, int DP>
 static void schur_enqueue_marginals_t(slampp_hip_solver &s, CSchurState &S, const double *A, double *cam_cov, double *point_cov)
 {
 	hipStream_t st = s.stream;
 	const int ld = S.Npad, n = S.N;
 	const int64_t ubase = S.n_ablocks * DC * DC;
+	// decided as for a solve: with the sparse reduced system the covariances go through the sparse inverse subset
+	if(s.p_allreduce && (S.p_union_fn != s.p_allreduce || S.p_union_context != s.p_allreduce_context))
+		schur_agree_on_union(s, S);
+	if(!S.b_reduced_decided)
+		schur_setup_reduced(s, S);
+	if(S.b_reduced_sparse && s.n_marginals_dense == 0 && schur_setup_sparse_marginals(s, S)) {
+		schur_enqueue_marginals_sparse_t<DC, DP>(s, S, A, cam_cov, point_cov);
+		return;
+	}
 	if(!S.d_m_S.p()) {
 		S.d_m_S.Alloc(size_t(ld) * ld);
 		S.d_m_Z.Alloc(size_t(ld) * ld);

@@ -84,6 +84,105 @@ schur_point_cov_kernel(const int64_t *__restrict__ ptr, const int32_t *__restric
 		out[pt * (DP * DP) + i] = cov[i];
 }
 
+// ---- the same from the sparse inverse subset (sparse_inverse.hip): Z is laid out like the factor of the reduced system,
+// in its elimination order; where a block sits and whether it is stored transposed comes from host-built tables ----
+template <int DC>
+__global__ void schur_cam_cov_sparse_kernel(int64_t nc, const int64_t *__restrict__ cam_zoff, const double *__restrict__ Z, double *out)
+{
+	const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(gid >= nc * (DC * DC))
+		return;
+	const int64_t c = gid / (DC * DC);
+	out[gid] = Z[cam_zoff[c] + (gid - c * (DC * DC))]; // diagonal blocks are stored whole
+}
+
+template <int DC, int DP>
+__global__ void __launch_bounds__(128)
+schur_point_cov_sparse_kernel(const int64_t *__restrict__ ptr, int64_t nc, int64_t np, const int64_t *__restrict__ pair_ptr,
+	const int64_t *__restrict__ pair_tab, const double *__restrict__ W, const double *__restrict__ Cinv,
+	const double *__restrict__ Z, double *out)
+{
+	const int64_t pt = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(pt >= np)
+		return;
+	const int64_t k0 = ptr[nc + pt], k1 = ptr[nc + pt + 1] - 1;
+	const int64_t o0 = k0 - ptr[nc] - pt;
+	const int64_t *tab = pair_tab + pair_ptr[pt];
+	double cov[DP * DP];
+	#pragma unroll
+	for(int i = 0; i < DP * DP; ++ i)
+		cov[i] = Cinv[pt * (DP * DP) + i];
+	for(int64_t a = k0; a < k1; ++ a) {
+		double wa[DC * DP];
+		#pragma unroll
+		for(int i = 0; i < DC * DP; ++ i)
+			wa[i] = W[(o0 + (a - k0)) * (DC * DP) + i];
+		for(int64_t b = k0; b <= a; ++ b) {
+			const int64_t ia = a - k0, ib = b - k0;
+			const int64_t ent = tab[ia * (ia + 1) / 2 + ib]; // block Z(cam_a, cam_b): offset * 2 + stored transposed
+			const double *Zb = Z + (ent >> 1);
+			const bool b_tr = ent & 1;
+			double wb[DC * DP], t[DC * DP];
+			#pragma unroll
+			for(int i = 0; i < DC * DP; ++ i) {
+				wb[i] = W[(o0 + ib) * (DC * DP) + i];
+				t[i] = 0;
+			}
+			#pragma unroll
+			for(int q = 0; q < DC; ++ q) {
+				#pragma unroll
+				for(int r = 0; r < DC; ++ r) {
+					const double z = b_tr? Zb[q + r * DC] : Zb[r + q * DC];
+					#pragma unroll
+					for(int j = 0; j < DP; ++ j)
+						t[r + j * DC] += z * wb[q + j * DC];
+				}
+			}
+			#pragma unroll
+			for(int j = 0; j < DP; ++ j) {
+				#pragma unroll
+				for(int i = 0; i < DP; ++ i) {
+					double sum = 0;
+					#pragma unroll
+					for(int r = 0; r < DC; ++ r)
+						sum += wa[r + i * DC] * t[r + j * DC];
+					cov[i + j * DP] += sum;
+					if(a != b)
+						cov[j + i * DP] += sum;
+				}
+			}
+		}
+	}
+	#pragma unroll
+	for(int i = 0; i < DP * DP; ++ i)
+		out[pt * (DP * DP) + i] = cov[i];
+}
+
+template <int DC, int DP>
+static void launch_sparse_t(int64_t nc, int64_t np, const int64_t *ptr, const int64_t *cam_zoff, const int64_t *pair_ptr,
+	const int64_t *pair_tab, const double *W, const double *Cinv, const double *Z, double *cam_cov, double *point_cov,
+	hipStream_t stream)
+{
+	if(cam_cov)
+		hipLaunchKernelGGL((schur_cam_cov_sparse_kernel<DC>), dim3(unsigned((nc * DC * DC + 255) / 256)), dim3(256), 0, stream,
+			nc, cam_zoff, Z, cam_cov);
+	if(point_cov)
+		hipLaunchKernelGGL((schur_point_cov_sparse_kernel<DC, DP>), dim3(unsigned((np + 127) / 128)), dim3(128), 0, stream,
+			ptr, nc, np, pair_ptr, pair_tab, W, Cinv, Z, point_cov);
+}
+
+void schur_marginals_sparse_launch(int DC, int DP, int64_t nc, int64_t np, const int64_t *ptr, const int64_t *cam_zoff,
+	const int64_t *pair_ptr, const int64_t *pair_tab, const double *W, const double *Cinv, const double *Z, double *cam_cov,
+	double *point_cov, hipStream_t stream)
+{
+	if(DC == 6 && DP == 3)
+		launch_sparse_t<6, 3>(nc, np, ptr, cam_zoff, pair_ptr, pair_tab, W, Cinv, Z, cam_cov, point_cov, stream);
+	else if(DC == 7 && DP == 3)
+		launch_sparse_t<7, 3>(nc, np, ptr, cam_zoff, pair_ptr, pair_tab, W, Cinv, Z, cam_cov, point_cov, stream);
+	else
+		launch_sparse_t<3, 2>(nc, np, ptr, cam_zoff, pair_ptr, pair_tab, W, Cinv, Z, cam_cov, point_cov, stream);
+}
+
 template <int DC, int DP>
 static void launch_t(int64_t nc, int64_t np, const int64_t *ptr, const int32_t *brow, const double *W, const double *Cinv,
 	const double *Z, int ld, double *cam_cov, double *point_cov, hipStream_t stream)

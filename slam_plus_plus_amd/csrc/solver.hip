@@ -11,7 +11,7 @@
 using namespace slampp;
 
 slampp_hip_solver::slampp_hip_solver()
-	:n_device(0), stream(0), n_dense_nb(64), b_shard_primary(1), n_shard_rank(-1), n_shard_world(0), n_schur_sparse(-1), b_has_structure(false),
+	:n_device(0), stream(0), n_dense_nb(64), b_shard_primary(1), n_shard_rank(-1), n_shard_world(0), n_marginals_dense(0), n_schur_sparse(-1), b_has_structure(false),
 	b_analyzed(false), b_factored(false), n_mode(SLAMPP_HIP_MODE_SPARSE), n_matrix_cut(0),
 	n_values(0), n_scalars(0), n_bottom_stages(1), n_dense_gaps(0), b_dense_tiles(false), n_dense_top_tiles(-1), n_dense_blks(0), n_dense_cols(0),
 	n_dense_dim(0), n_dense_pad(0),
@@ -530,6 +530,10 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 	} else if(s == "shard_world" && n_value >= 0) {
 		p_solver->n_shard_world = int(n_value);
 		return SLAMPP_HIP_OK;
+	}
+	else if(s == "marginals_dense" && n_value >= 0 && n_value <= 1) {
+		p_solver->n_marginals_dense = int(n_value);
+		return SLAMPP_HIP_OK; // read by schur_marginals: does not invalidate the analysis
 	}
 	else if(s == "schur_sparse" && n_value >= -1 && n_value <= 1)
 		p_solver->n_schur_sparse = int(n_value);

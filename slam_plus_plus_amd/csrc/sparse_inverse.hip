@@ -1,0 +1,193 @@
+// sparse_inverse.hip -- the entries of Z = (L L^T)^-1 on the block pattern of the factor L (a "sparse inverse subset",
+// Takahashi's equations), for the marginal covariances of BA systems whose reduced camera system is factored by the
+// sparse block path: every camera pair that shares a landmark is a block of S, hence of L's pattern, so the landmark
+// covariances C_p^-1 + W_p^T Z W_p need nothing outside that pattern -- and neither does the recursion.  The
+// reference's counterpart is CMarginals::Calculate_DenseMarginals_Recurrent_FBS (/root/reference/include/slam/
+// Marginals.h, called from BAMarginals.h:765-772 for the camera blocks) on its own block Cholesky factor.
+//
+// Columns are processed from the root of the elimination tree downwards (the factorization's stages in reverse, one
+// launch each, one wave per task, a task's columns last to first).  With struct(j) the block rows of column j below
+// the diagonal, all of them ancestors of j and therefore done:
+//     Z(i,j) = -( sum over k in struct(j) of Z(i,k) L(k,j) ) inv(L_jj)          for i in struct(j)
+//     Z(j,j) = inv(L_jj)^T ( inv(L_jj) - sum over k in struct(j) of L(k,j)^T Z(k,j) )
+// Z(i,k) is the stored block (max, min) of the pair, transposed when i < k; it exists because struct(j) is a clique
+// of the filled graph.  Z lives in an array laid out like L.  |struct|^2 small products per column: the cost of the
+// factorization again, latency-bound like it.
+#include <hip/hip_runtime.h>
+#include "sparse_inverse.h"
+#include "solver.h"
+
+#include <algorithm>
+
+namespace slampp {
+
+struct TInvCol { // 40 B
+	int64_t zdiag;   // offset of block (j,j) in L / Z
+	int64_t linv;    // offset of inv(L_jj)
+	int64_t b0;      // first entry of the column's block-offset list (sub-diagonal blocks, rows ascending)
+	int64_t t0;      // first of its (nb-1)^2 term records
+	int32_t nbm;     // number of sub-diagonal blocks
+	int32_t pad;
+};
+
+struct CSparseInverse {
+	int D;
+	int64_t n_cols;
+	CDevArray<TInvCol> d_cols;      // in schedule order (the plan's task_cols)
+	CDevArray<int64_t> d_blk_off;   // offsets of the sub-diagonal blocks of every column
+	CDevArray<int64_t> d_terms;     // (offset of the stored block of Z(i,k)) * 2 + transposed
+	CDevArray<int64_t> d_task_ptr;
+};
+
+void sparse_inverse_destroy(CSparseInverse *p) { delete p; }
+
+size_t sparse_inverse_bytes(const CSparseInverse *p)
+{
+	return p? p->d_cols.n_Bytes() + p->d_blk_off.n_Bytes() + p->d_terms.n_Bytes() + p->d_task_ptr.n_Bytes() : 0;
+}
+
+// offset of the factor block (i, k), i >= k, or -1
+int64_t plan_block_offset(const Plan &P, int32_t i, int32_t k)
+{
+	const int32_t *b = P.lrow.data() + P.lptr[k], *e = P.lrow.data() + P.lptr[k + 1];
+	const int32_t *f = std::lower_bound(b, e, i);
+	return (f != e && *f == i)? P.loff[f - P.lrow.data()] : -1;
+}
+
+CSparseInverse *sparse_inverse_setup(const Plan &P, hipStream_t stream)
+{
+	if(!P.uniform_dim || P.dense_dim != 0 || !(P.max_dim == 3 || P.max_dim == 6 || P.max_dim == 7))
+		return 0; // the dense inverse serves these
+	const int64_t n_sched = int64_t(P.task_cols.size());
+	std::vector<TInvCol> cols(n_sched);
+	std::vector<int64_t> blk_off, terms;
+	for(int64_t s = 0; s < n_sched; ++ s) {
+		const int32_t j = P.task_cols[s];
+		TInvCol &c = cols[s];
+		c.zdiag = P.loff[P.lptr[j]];
+		c.linv = P.linv_off[j];
+		c.nbm = int32_t(P.lptr[j + 1] - P.lptr[j] - 1);
+		c.pad = 0;
+		c.b0 = int64_t(blk_off.size());
+		c.t0 = int64_t(terms.size());
+		for(int64_t k = P.lptr[j] + 1; k < P.lptr[j + 1]; ++ k)
+			blk_off.push_back(P.loff[k]);
+		for(int64_t a = P.lptr[j] + 1; a < P.lptr[j + 1]; ++ a) {
+			for(int64_t b = P.lptr[j] + 1; b < P.lptr[j + 1]; ++ b) {
+				const int32_t i = P.lrow[a], k = P.lrow[b];
+				const int64_t off = plan_block_offset(P, std::max(i, k), std::min(i, k));
+				if(off < 0)
+					throw std::logic_error("sparse inverse: the structure of a factor column is not a clique");
+				terms.push_back(off * 2 + (i < k));
+			}
+		}
+	}
+	CSparseInverse *p = new CSparseInverse();
+	try {
+		p->D = P.max_dim;
+		p->n_cols = n_sched;
+		p->d_cols.Upload(cols, stream);
+		p->d_blk_off.Upload(blk_off, stream);
+		p->d_terms.Upload(terms, stream);
+		p->d_task_ptr.Upload(P.task_ptr, stream);
+		SLAMPP_HIP_CHECK(hipStreamSynchronize(stream));
+	} catch(...) {
+		delete p;
+		throw;
+	}
+	return p;
+}
+
+__device__ __forceinline__ void inv_wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int D>
+__global__ void __launch_bounds__(64)
+sparse_inverse_stage_kernel(const TInvCol *__restrict__ cols, const int64_t *__restrict__ blk_off,
+	const int64_t *__restrict__ terms, const int64_t *__restrict__ task_ptr, int task_begin,
+	const double *__restrict__ L, const double *__restrict__ Linv, double *Z)
+{
+	__shared__ double s_linv[64], s_tile[64], s_z[64];
+	const int lane = threadIdx.x;
+	const bool b_act = lane < D * D;
+	const int r = b_act? lane % D : 0, q = b_act? lane / D : 0;
+	const int task = task_begin + blockIdx.x;
+	for(int64_t c = task_ptr[task + 1]; c > task_ptr[task]; -- c) {
+		const TInvCol cd = cols[c - 1];
+		if(b_act)
+			s_linv[r + 8 * q] = Linv[cd.linv + lane];
+		double m_acc = 0; // sum over k of L(k,j)^T Z(k,j), element (r, q)
+		for(int kb = 0; kb < cd.nbm; ++ kb) {
+			const int64_t zoff_i = blk_off[cd.b0 + kb];
+			double acc = 0; // ( sum over k of Z(i,k) L(k,j) )(r, q)
+			for(int kk = 0; kk < cd.nbm; ++ kk) {
+				const int64_t term = terms[cd.t0 + int64_t(kb) * cd.nbm + kk];
+				const double *Zs = Z + (term >> 1), *Ls = L + blk_off[cd.b0 + kk] + q * D;
+				const int zs = (term & 1)? 1 : D, z0 = (term & 1)? r * D : r; // Z(i,k)(r, t): stored block or its transpose
+				double zv[D], lv[D];
+				#pragma unroll
+				for(int t = 0; t < D; ++ t) {
+					zv[t] = Zs[z0 + t * zs];
+					lv[t] = Ls[t];
+				}
+				#pragma unroll
+				for(int t = 0; t < D; ++ t)
+					acc += zv[t] * lv[t];
+			}
+			inv_wave_sync(); // the previous uses of the tiles are over
+			if(b_act)
+				s_tile[r + 8 * q] = acc;
+			inv_wave_sync();
+			double v = 0;
+			#pragma unroll
+			for(int t = 0; t < D; ++ t)
+				v += s_tile[r + 8 * t] * s_linv[t + 8 * q];
+			v = -v; // Z(i,j)
+			if(b_act) {
+				Z[zoff_i + lane] = v;
+				s_z[r + 8 * q] = v;
+			}
+			inv_wave_sync();
+			const double *Lij = L + zoff_i + r * D; // column r of L(i,j): L(i,j)^T's row r
+			#pragma unroll
+			for(int t = 0; t < D; ++ t)
+				m_acc += Lij[t] * s_z[t + 8 * q];
+		}
+		inv_wave_sync();
+		if(b_act)
+			s_tile[r + 8 * q] = s_linv[r + 8 * q] - m_acc; // inv(L_jj) - M
+		inv_wave_sync();
+		double zjj = 0;
+		#pragma unroll
+		for(int t = 0; t < D; ++ t)
+			zjj += s_linv[t + 8 * r] * s_tile[t + 8 * q];
+		if(b_act)
+			Z[cd.zdiag + lane] = zjj;
+		__syncthreads(); // column j is complete and visible before a descendant in this task reads it
+	}
+}
+
+void sparse_inverse_enqueue(const CSparseInverse &r_inv, const Plan &P, const double *L, const double *Linv, double *Z,
+	hipStream_t stream)
+{
+	const int n_stages = int(P.stage_ptr.size()) - 1;
+	for(int s = n_stages - 1; s >= 0; -- s) {
+		const int n_tasks = P.stage_ptr[s + 1] - P.stage_ptr[s];
+		if(n_tasks <= 0)
+			continue;
+#define LAUNCH_INV(DD) hipLaunchKernelGGL((sparse_inverse_stage_kernel<DD>), dim3(n_tasks), dim3(64), 0, stream, r_inv.d_cols.p(), \
+			r_inv.d_blk_off.p(), r_inv.d_terms.p(), r_inv.d_task_ptr.p(), P.stage_ptr[s], L, Linv, Z)
+		switch(r_inv.D) {
+		case 3: LAUNCH_INV(3); break;
+		case 6: LAUNCH_INV(6); break;
+		default: LAUNCH_INV(7); break;
+		}
+#undef LAUNCH_INV
+	}
+}
+
+} // namespace slampp
