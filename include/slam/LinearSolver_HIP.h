@@ -430,6 +430,40 @@ public:
 		return Analyze(r_lambda, SLAMPP_HIP_MODE_SPARSE, 0, 0);
 	}
 
+	/**
+	 *	@brief calculates block diagonal of the covariance matrix (the inverse of lambda): what the reference's solvers get
+	 *		from CMarginals::Calculate_DenseMarginals_Recurrent_FBS(margs, R, ordering, mpart_Diagonal) after ordering and
+	 *		factoring lambda once more for the purpose (NonlinearSolver_Lambda.h:696-760, "todo - reuse what the linear
+	 *		solver calculated") -- here lambda is all that is needed
+	 *
+	 *	@param[out] r_marginals is filled with one diagonal block per block column of lambda, in lambda's order
+	 *	@param[in] r_lambda is the system matrix (symmetric layout, upper triangle stored, one block size: 3, 6 or 7)
+	 *
+	 *	@return Returns true on success, false if lambda is not positive definite.
+	 *	@note This function throws std::bad_alloc and std::runtime_error (also for plans with a dense top:
+	 *		Set_Option("dense_top_nb", 0) before the first call where the graph has large separators).
+	 */
+	bool Marginals(CUberBlockMatrix &r_marginals, const CUberBlockMatrix &r_lambda) // throw(std::bad_alloc, std::runtime_error)
+	{
+		if(!b_Structure_Matches(r_lambda))
+			SymbolicDecomposition_Blocky(r_lambda);
+		Gather_Values(r_lambda);
+		const size_t n = r_lambda.n_BlockColumn_Num(), d = r_lambda.n_BlockColumn_Column_Num(0);
+		std::vector<double> cov(n * d * d);
+		const int n_result = slampp_hip_marginals(m_p_solver, m_values.empty()? 0 : &m_values[0], &cov[0]);
+		if(n_result == SLAMPP_HIP_NOT_POSDEF)
+			return false;
+		Throw_On_Error(n_result);
+		r_marginals.Clear();
+		for(size_t i = 0; i < n; ++ i) {
+			double *p_dest = r_marginals.p_GetBlock_Log(i, i, d, d, true, false);
+			if(!p_dest)
+				throw std::runtime_error("CLinearSolver_HIP: cannot write the marginals");
+			std::copy(&cov[i * d * d], &cov[(i + 1) * d * d], p_dest);
+		}
+		return true;
+	}
+
 	/** @brief solves, reusing the symbolic decomposition for as long as the block structure stays the same */
 	bool Solve_PosDef_Blocky(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta) // throw(std::bad_alloc, std::runtime_error)
 	{

@@ -136,6 +136,16 @@ int slampp_hip_solve_marginal_poses(slampp_hip_solver *p_solver, const double *p
 int slampp_hip_solve_marginal_poses_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,
 	double *p_rhs_inout_dev);
 
+/* Sparse mode: block diagonal of the covariance matrix Lambda^-1 -- what the reference's nonlinear solvers get from
+ * CMarginals::Calculate_DenseMarginals_Recurrent_FBS(margs, R, ordering, mpart_Diagonal) after ordering and factoring
+ * Lambda once more on the host for the purpose (include/slam/NonlinearSolver_Lambda.h:700-760, "todo - reuse what the
+ * linear solver calculated").  Numeric factorization, then the blocks of the inverse on the factor's pattern by the
+ * recursion run from the root of the elimination tree downwards; p_block_diag receives one dim x dim column-major block
+ * per block column, in the order of slampp_hip_set_structure.  Needs one block size (3, 6 or 7) and a plan without a
+ * dense top (option "dense_top_nb" = 0 where the default plan has one): SLAMPP_HIP_ERR_UNSUPPORTED otherwise. */
+int slampp_hip_marginals(slampp_hip_solver *p_solver, const double *p_values, double *p_block_diag);
+int slampp_hip_marginals_device_async(slampp_hip_solver *p_solver, const double *p_values_dev, double *p_block_diag_dev);
+
 /* Schur mode only: block diagonal of the covariance matrix Lambda^-1 -- the reference's
  * CSchurComplement_Marginals::Schur_Marginals (include/slam/BAMarginals.h:579-806, called from
  * NonlinearSolver_Lambda_LM.h:1326 and NonlinearSolver_Lambda_DL.h:1640 with the Cholesky factor of the Schur

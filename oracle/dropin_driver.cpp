@@ -325,6 +325,47 @@ int main(int n_arg_num, const char **p_arg_list)
 				n_fail += !(f_err < 1e-9 && fabs(f_chi2_ref - f_chi2_hip) <= 1e-9 * fabs(f_chi2_ref) && n_calls > 0);
 			}
 		}
+		{ // block diagonal of the covariance of a pose graph: the reference's recipe (NonlinearSolver_Lambda.h:696-760) next to Marginals()
+			typedef MakeTypelist_Safe((Eigen::Matrix<double, 6, 6>)) TBs;
+			std::mt19937_64 rng(5);
+			std::normal_distribution<double> nd(0, 1);
+			CUberBlockMatrix lambda;
+			const size_t n = 300;
+			for(size_t c = 0; c < n; ++ c) {
+				size_t p_rows[3] = {c, (c > 0)? c - 1 : c, (c > 17 && c % 9 == 0)? c - 17 : c};
+				for(int t = 0; t < 3; ++ t) {
+					if(t && p_rows[t] == c)
+						continue;
+					Eigen::MatrixXd M(6, 6);
+					for(int i = 0; i < 36; ++ i)
+						M.data()[i] = 0.3 * nd(rng);
+					if(!t)
+						M = M * M.transpose() + Eigen::MatrixXd::Identity(6, 6) * 8.0;
+					lambda.t_GetBlock_Log(p_rows[t], c, 6, 6, true, true) += M;
+				}
+			}
+			CMatrixOrdering mord;
+			mord.p_BlockOrdering(lambda, true);
+			CUberBlockMatrix lambda_perm, R, margs_ordered, margs_ref, margs_hip;
+			lambda.Permute_UpperTriangular_To(lambda_perm, mord.p_Get_InverseOrdering(), mord.n_Ordering_Size(), true);
+			const bool b_ref = R.CholeskyOf_FBS<TBs>(lambda_perm);
+			if(b_ref) {
+				CMarginals::Calculate_DenseMarginals_Recurrent_FBS<TBs>(margs_ordered, R, mord, mpart_Diagonal, false);
+				margs_ordered.Permute_UpperTriangular_To(margs_ref, mord.p_Get_Ordering(), mord.n_Ordering_Size(), false);
+			}
+			CLinearSolver_HIP hip_solver;
+			hip_solver.Set_Option("dense_top_nb", 0);
+			const bool b_hip = hip_solver.Marginals(margs_hip, lambda);
+			double f_err = 0, f_max = 0;
+			for(size_t i = 0; i < n && b_ref && b_hip; ++ i) {
+				Eigen::MatrixXd r = margs_ref.t_GetBlock_Log(i, i), h = margs_hip.t_GetBlock_Log(i, i);
+				f_err = std::max(f_err, (r - h).cwiseAbs().maxCoeff());
+				f_max = std::max(f_max, r.cwiseAbs().maxCoeff());
+			}
+			printf("\"pose_graph_marginals\": {\"ok_ref\": %d, \"ok_hip\": %d, \"rel_inf\": %.3g}, ", int(b_ref), int(b_hip),
+				f_err / std::max(f_max, 1e-300));
+			n_fail += !(b_ref && b_hip && f_err < 1e-10 * f_max);
+		}
 		{ // Factorize_PosDef_Blocky: the factor handed back as a block matrix, next to CHOLMOD's on the same matrices
 			for(int n_case = 0; n_case < 2; ++ n_case) {
 				const size_t n_blocks = n_case? 60 : 150;

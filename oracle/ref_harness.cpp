@@ -41,6 +41,9 @@
  *       writes Lambda with the reference's Save_MatrixMarket / Save_BlockLayout, as its -dsm option does
  *   ref_harness load_mm <in.mtx> <in.bla> <problem>
  *       reads the pair with the reference's Load_MatrixMarket and compares the upper triangle with <problem>
+ *   ref_harness sparse_marginals <problem> <out_prefix>
+ *       CMarginals::Calculate_DenseMarginals_Recurrent_FBS(.., mpart_Diagonal) fed as
+ *       NonlinearSolver_Lambda.h:696-760 feeds it: block diagonal of the covariance of a pose graph
  *   ref_harness schur_marginals <problem> <out_prefix>
  *       CSchurComplement_Marginals::Schur_Marginals (include/slam/BAMarginals.h:579) fed as
  *       NonlinearSolver_Lambda_DL.h:1590-1640 feeds it: block diagonal of the covariance
@@ -363,6 +366,57 @@ static int Main_SchurDump(int argc, char **argv)
 }
 
 /**
+ *	@brief block diagonal of the covariance of a pose graph, the way CNonlinearSolver_Lambda gets it
+ *		(include/slam/NonlinearSolver_Lambda.h:696-760): order lambda, permute, CholeskyOf_FBS, then
+ *		CMarginals::Calculate_DenseMarginals_Recurrent_FBS(.., mpart_Diagonal) and permute back.
+ *		Writes <prefix>.cov_diag.bin: one d x d column-major block per block column (all of one size d).
+ */
+template <class TBlockSizes, int n_dim>
+static int SparseMarginals(const TProblem &p, const std::string &prefix)
+{
+	CUberBlockMatrix lambda;
+	Build_Lambda(p, lambda);
+	CMatrixOrdering mord;
+	mord.p_BlockOrdering(lambda, true);
+	const size_t *p_order = mord.p_Get_InverseOrdering();
+	CUberBlockMatrix lambda_perm, R;
+	lambda.Permute_UpperTriangular_To(lambda_perm, p_order, mord.n_Ordering_Size(), true);
+	if(!R.CholeskyOf_FBS<TBlockSizes>(lambda_perm)) {
+		printf("{\"ok\": false}\n");
+		return 3;
+	}
+	CUberBlockMatrix margs_ordered, margs;
+	CMarginals::Calculate_DenseMarginals_Recurrent_FBS<TBlockSizes>(margs_ordered, R, mord, mpart_Diagonal, false);
+	margs_ordered.Permute_UpperTriangular_To(margs, mord.p_Get_Ordering(), mord.n_Ordering_Size(), false);
+	const size_t n = lambda.n_BlockColumn_Num();
+	std::vector<double> out(n * n_dim * n_dim);
+	for(size_t i = 0; i < n; ++ i) {
+		Eigen::Matrix<double, n_dim, n_dim> b = margs.t_GetBlock_Log(i, i);
+		std::copy(b.data(), b.data() + n_dim * n_dim, out.begin() + i * n_dim * n_dim);
+	}
+	if(!Write_Doubles((prefix + ".cov_diag.bin").c_str(), &out[0], out.size()))
+		return 1;
+	printf("{\"ok\": true, \"n\": %ld, \"dim\": %d, \"R_blocks\": %ld}\n", (long)n, n_dim, (long)R.n_Block_Num());
+	return 0;
+}
+
+static int Main_SparseMarginals(int argc, char **argv)
+{
+	if(argc < 4) return 2;
+	TProblem p;
+	if(!Read_Problem(argv[2], p)) return 1;
+	const int d = int(p.cumsum[1] - p.cumsum[0]);
+	for(size_t i = 0; i + 1 < p.cumsum.size(); ++ i) {
+		if(p.cumsum[i + 1] - p.cumsum[i] != d) { fprintf(stderr, "error: one block size expected\n"); return 1; }
+	}
+	if(d == 3) return SparseMarginals<MakeTypelist_Safe((Eigen::Matrix<double, 3, 3>)), 3>(p, argv[3]);
+	if(d == 6) return SparseMarginals<MakeTypelist_Safe((Eigen::Matrix<double, 6, 6>)), 6>(p, argv[3]);
+	if(d == 7) return SparseMarginals<MakeTypelist_Safe((Eigen::Matrix<double, 7, 7>)), 7>(p, argv[3]);
+	fprintf(stderr, "error: block size %d not instantiated\n", d);
+	return 1;
+}
+
+/**
  *	@brief block diagonal of the covariance of a BA system: the steps NonlinearSolver_Lambda_DL.h:1590-1640 takes
  *		before it calls CSchurComplement_Marginals::Schur_Marginals (include/slam/BAMarginals.h:579-806), then that
  *		call; the system is already ordered cameras-first.  Writes <prefix>.cam_cov.bin (n_cams blocks 6x6) and
@@ -662,6 +716,8 @@ int main(int argc, char **argv)
 				return Main_SchurDump(argc, argv);
 			if(!strcmp(argv[1], "schur_marginals"))
 				return Main_SchurMarginals(argc, argv);
+			if(!strcmp(argv[1], "sparse_marginals"))
+				return Main_SparseMarginals(argc, argv);
 			if(!strcmp(argv[1], "lambda_dump"))
 				return Main_LambdaDump(argc, argv);
 		} catch(std::exception &r_exc) {

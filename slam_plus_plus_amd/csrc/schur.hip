@@ -1013,10 +1013,6 @@ void schur_marginals_launch(int DC, int DP, int64_t nc, int64_t np, const int64_
 // own whatever way the solves factor it, factored, inverted on the matrix cores, then gathered per landmark.
 // Landmark shards: S is summed over the ranks as a whole buffer (the padding diagonal comes back as the number
 // of ranks, which its decoupled rows do not mind); every rank then writes the covariances of its own landmarks.
-void schur_marginals_sparse_launch(int DC, int DP, int64_t nc, int64_t np, const int64_t *ptr, const int64_t *cam_zoff,
-	const int64_t *pair_ptr, const int64_t *pair_tab, const double *W, const double *Cinv, const double *Z, double *cam_cov,
-	double *point_cov, hipStream_t stream); // schur_marginals.hip
-
 // lists of the sparse inverse subset and the tables that say where the blocks the covariances need sit in it; false if
 // the inner solver's plan is not of the kind sparse_inverse_setup takes (then the dense inverse is used)
 static bool schur_setup_sparse_marginals(slampp_hip_solver &s, CSchurState &S)

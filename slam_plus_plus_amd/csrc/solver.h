@@ -70,6 +70,7 @@ public:
 };
 
 struct CSchurState; // schur.hip
+struct CSparseInverse; // sparse_inverse.hip
 struct CAssemblyState; // assembly.hip
 
 } // namespace slampp
@@ -121,6 +122,10 @@ struct slampp_hip_solver {
 	int n_dense_top_tiles;             // option: -1 = decide per structure, 0 = always the dense schedule, 1 = always the tile schedule
 	int n_dense_blks, n_dense_cols, n_dense_dim, n_dense_pad;
 	slampp::CDevArray<double> d_A, d_rhs, d_L, d_Linv, d_w, d_cov;
+	slampp::CSparseInverse *p_sinv = 0;    // sparse path: lists of the sparse inverse subset (slampp_hip_marginals), built on first use
+	bool b_sinv_tried = false;
+	slampp::CDevArray<double> d_Z;         // laid out like d_L
+	slampp::CDevArray<int64_t> d_diag_zoff; // offset of every block column's diagonal block in it, original order
 	slampp::CDevArray<int64_t> d_damp_off; // (offset of the diagonal block's first element, dimension) per block column: apply_damping
 	bool b_damp_valid = false;
 	slampp::CDevArray<int> d_flag;
@@ -163,6 +168,9 @@ void schur_destroy(CSchurState *p);
 CSchurState *schur_analyze(slampp_hip_solver &s); // throws
 void schur_enqueue(slampp_hip_solver &s, const double *p_values_dev, double *p_rhs_dev); // throws
 void schur_enqueue_marginal_poses(slampp_hip_solver &s, const double *p_values_dev, double *p_rhs_dev); // throws
+void schur_marginals_sparse_launch(int DC, int DP, int64_t nc, int64_t np, const int64_t *ptr, const int64_t *cam_zoff,
+	const int64_t *pair_ptr, const int64_t *pair_tab, const double *W, const double *Cinv, const double *Z, double *cam_cov,
+	double *point_cov, hipStream_t stream); // schur_marginals.hip
 void damping_enqueue(const int64_t *p_off_dim_dev, int64_t n_first, int64_t n_last, double f_alpha, double *p_values_dev,
 	hipStream_t stream); // assembly.hip
 void schur_enqueue_marginals(slampp_hip_solver &s, const double *p_values_dev, double *p_cam_cov_dev, double *p_point_cov_dev); // throws

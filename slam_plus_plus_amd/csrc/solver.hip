@@ -2,6 +2,7 @@
 // orchestration of the sparse-Cholesky and Schur paths.  Host code only; kernels live in
 // sparse_kernels.hip / schur.hip / dense_chol.hip.
 #include "solver.h"
+#include "sparse_inverse.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -47,6 +48,12 @@ void slampp_hip_solver::Free_Device()
 	d_dense_gaps.Free();
 	n_dense_gaps = 0;
 	d_A.Free(); d_rhs.Free(); d_L.Free(); d_Linv.Free(); d_w.Free(); d_flag.Free();
+	if(p_sinv) {
+		sparse_inverse_destroy(p_sinv);
+		p_sinv = 0;
+	}
+	b_sinv_tried = false;
+	d_Z.Free(); d_diag_zoff.Free();
 	if(p_schur) {
 		schur_destroy(p_schur);
 		p_schur = 0;
@@ -61,6 +68,7 @@ size_t slampp_hip_solver::n_Device_Bytes() const
 		d_dense_z.n_Bytes() + d_dense_x.n_Bytes() + d_cols.n_Bytes() + d_blks.n_Bytes() + d_rents.n_Bytes() +
 		d_task_ptr.n_Bytes() + d_task_pkg.n_Bytes() + d_pkg.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
 		d_rhs.n_Bytes() + d_L.n_Bytes() + d_Linv.n_Bytes() + d_w.n_Bytes() + d_cov.n_Bytes() + d_flag.n_Bytes() +
+		d_Z.n_Bytes() + d_diag_zoff.n_Bytes() + sparse_inverse_bytes(p_sinv) +
 		(p_schur? schur_device_bytes(p_schur) : 0);
 }
 
@@ -120,6 +128,11 @@ void slampp_hip_solver::Phase_Collect()
 
 void slampp_hip_solver::Analyze_Sparse()
 {
+	if(p_sinv) { // lists of the previous plan
+		sparse_inverse_destroy(p_sinv);
+		p_sinv = 0;
+	}
+	b_sinv_tried = false;
 	const bool b_timing = getenv("SLAMPP_HIP_PLAN_TIMING") != 0;
 	double t_phase = wall_ms();
 #define SETUP_PHASE(name) do { if(b_timing) { const double t_ = wall_ms(); \
@@ -784,6 +797,78 @@ int slampp_hip_solve_marginal_poses_device_async(slampp_hip_solver *p_solver, co
 		s.b_factored = false; // no factor of the reduced system comes out of this
 		return SLAMPP_HIP_OK;
 	});
+}
+
+int slampp_hip_marginals_device_async(slampp_hip_solver *p_solver, const double *p_values_dev, double *p_block_diag_dev)
+{
+	return guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_analyzed)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "marginals: analyze was not called");
+		if(s.n_mode != SLAMPP_HIP_MODE_SPARSE)
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "marginals: sparse mode only (Schur mode: slampp_hip_schur_marginals)");
+		if(!p_values_dev || !p_block_diag_dev)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "marginals: null pointer");
+		const Plan &P = s.plan;
+		if(!s.b_sinv_tried) {
+			s.b_sinv_tried = true;
+			s.p_sinv = sparse_inverse_setup(P, s.stream);
+			if(s.p_sinv) {
+				std::vector<int64_t> zoff(size_t(P.n));
+				for(int32_t c = 0; c < P.n; ++ c)
+					zoff[c] = P.loff[P.lptr[P.pinv[c]]];
+				s.d_diag_zoff.Upload(zoff, s.stream);
+				s.d_Z.Alloc(size_t(P.loff.back()));
+				SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream)); // zoff lives on this stack frame
+			}
+		}
+		if(!s.p_sinv)
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "marginals: needs one block size (3, 6 or 7) and no dense top "
+				"(set the option dense_top_nb to 0)");
+		s.d_rhs.Alloc(size_t(s.n_scalars)); // the fused forward substitution reads a right-hand side: whatever is there
+		s.Enqueue_Sparse(p_values_dev, s.d_rhs.p(), true, true); // (opens its own phases: factor_subtree, factor_upper)
+		s.Phase_Begin("marginals_inverse");
+		sparse_inverse_enqueue(*s.p_sinv, P, s.d_L.p(), s.d_Linv.p(), s.d_Z.p(), s.stream);
+		s.Phase_End();
+		const int d = P.max_dim;
+		schur_marginals_sparse_launch(d, (d == 3)? 2 : 3, P.n, 0, 0, s.d_diag_zoff.p(), 0, 0, 0, 0, s.d_Z.p(), p_block_diag_dev, 0,
+			s.stream);
+		SLAMPP_HIP_CHECK(hipGetLastError());
+		s.b_factored = true; // the factor of these values is in place
+		return SLAMPP_HIP_OK;
+	});
+}
+
+int slampp_hip_marginals(slampp_hip_solver *p_solver, const double *p_values, double *p_block_diag)
+{
+	size_t n_out = 0;
+	int n_result = guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_analyzed)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "marginals: analyze was not called");
+		if(!p_values || !p_block_diag)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "marginals: null pointer");
+		for(size_t c = 0; c + 1 < s.cumsum.size(); ++ c)
+			n_out += size_t((s.cumsum[c + 1] - s.cumsum[c]) * (s.cumsum[c + 1] - s.cumsum[c]));
+		s.d_A.Alloc(size_t(s.n_values));
+		s.d_cov.Alloc(n_out);
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_A.p(), p_values, size_t(s.n_values) * sizeof(double), hipMemcpyHostToDevice, s.stream));
+		return SLAMPP_HIP_OK;
+	});
+	if(n_result != SLAMPP_HIP_OK)
+		return n_result;
+	slampp_hip_solver &s = *p_solver;
+	n_result = slampp_hip_marginals_device_async(p_solver, s.d_A.p(), s.d_cov.p());
+	if(n_result == SLAMPP_HIP_OK)
+		n_result = slampp_hip_sync(p_solver);
+	if(n_result == SLAMPP_HIP_OK) {
+		n_result = guarded(p_solver, [&]() -> int {
+			SLAMPP_HIP_CHECK(hipMemcpyAsync(p_block_diag, s.d_cov.p(), n_out * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+			SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+			return SLAMPP_HIP_OK;
+		});
+	}
+	return n_result;
 }
 
 int slampp_hip_schur_marginals_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,

@@ -85,6 +85,8 @@ ABI = {
     "slampp_hip_solve_marginal_poses": (C.c_int, [_P, _P, _P]),
     "slampp_hip_solve_marginal_poses_device_async": (C.c_int, [_P, _P, _P]),
     "slampp_hip_apply_damping_device_async": (C.c_int, [_P, _P, C.c_double, C.c_int64, C.c_int64]),
+    "slampp_hip_marginals": (C.c_int, [_P, _P, _P]),
+    "slampp_hip_marginals_device_async": (C.c_int, [_P, _P, _P]),
     "slampp_hip_schur_marginals": (C.c_int, [_P, _P, _P, _P]),
     "slampp_hip_schur_marginals_device_async": (C.c_int, [_P, _P, _P, _P]),
     "slampp_hip_factor_solve_device_async": (C.c_int, [_P, _P, _P]),
@@ -351,6 +353,24 @@ class CLinearSolver_HIP(_SolverBase):
 
     _Tag = "CBlockwiseLinearSolverTag"   # LinearSolverTags.h:54
     _mode = MODE_SPARSE
+
+
+def _block_diagonal_marginals(self, lam):
+    """Block diagonal of the covariance Lambda^-1 ([n, d, d]), as CMarginals::Calculate_DenseMarginals_Recurrent_FBS
+    (.., mpart_Diagonal) gives the reference's nonlinear solvers (NonlinearSolver_Lambda.h:700-760): factorization and a
+    sparse inverse subset on the factor's pattern.  One block size, no dense top (dense_top_nb=0)."""
+    if not self._analyzed or self._structure_key != self._key(lam):
+        self.SymbolicDecomposition_Blocky(lam)
+    dims = np.diff(lam.cumsum)
+    d = int(dims[0])
+    out = np.empty((len(dims), d, d), dtype=np.float64)
+    vals = np.ascontiguousarray(lam.values, dtype=np.float64)
+    if not self._check(self._lib.slampp_hip_marginals(self._h, _ptr(vals), _ptr(out))):
+        raise ArithmeticError("Marginals: the system is not positive definite")
+    return out.transpose(0, 2, 1).copy()      # blocks come column-major
+
+
+CLinearSolver_HIP.Marginals = _block_diagonal_marginals
 
 
 class CLinearSolver_Schur_HIP(_SolverBase):

@@ -13,6 +13,8 @@ reference's own solver classes on those inputs:
     x_schur, S, rhs_reduced (BA)     : CLinearSolver_Schur<...>::Solve_PosDef and the intermediates of
                                        its steps replayed through public CUberBlockMatrix calls
     x_schur_marginal_poses (BA)      : CLinearSolver_Schur<...>::Solve_PosDef_Blocky_MarginalPoses (landmarks only)
+    cov_diag (pose graphs)           : CMarginals::Calculate_DenseMarginals_Recurrent_FBS(.., mpart_Diagonal), fed as
+                                       NonlinearSolver_Lambda.h:696-760 feeds it: the diagonal blocks of Lambda^-1
     cam_cov, lm_cov (BA)             : CSchurComplement_Marginals::Schur_Marginals, fed as NonlinearSolver_Lambda_DL.h:1590-1640
                                        feeds it: the diagonal blocks of the covariance Lambda^-1
     ok_* (negative case)             : the boolean each solver returned
@@ -78,6 +80,10 @@ def main():
                 rec[f"ok_{s}"] = np.bool_(r["ok"])
                 if r["ok"]:
                     rec[f"x_{s}"] = np.fromfile(xf)
+            if not lam.n_matrix_cut and rec.get("ok_cholmod_super", False):
+                assert run(["sparse_marginals", prob, os.path.join(td, "pm")])["ok"]
+                d = int(lam.cumsum[1])
+                rec["cov_diag"] = np.fromfile(os.path.join(td, "pm.cov_diag.bin")).reshape(-1, d, d)   # symmetric blocks
             if lam.n_matrix_cut:
                 r = run(["schur_dump", prob, os.path.join(td, "sd")])
                 N = int(lam.cumsum[lam.n_matrix_cut])

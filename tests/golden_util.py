@@ -51,7 +51,7 @@ def load_golden(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     lam = BlockSystem(z["cumsum"].astype(np.int64), z["bcol_ptr"].astype(np.int64), z["brow_idx"].astype(np.int32),
                       z["values"], z["rhs"], int(z["n_matrix_cut"]), name)
-    ref = {k: z[k] for k in z.files if k.startswith(("x_", "ok_", "S", "rhs_reduced", "cam_cov", "lm_cov"))}
+    ref = {k: z[k] for k in z.files if k.startswith(("x_", "ok_", "S", "rhs_reduced", "cam_cov", "lm_cov", "cov_diag"))}
     return lam, ref
 
 

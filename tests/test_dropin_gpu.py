@@ -37,6 +37,8 @@ def test_reference_nonlinear_solver_with_hip_linear_solver(tmp_path):
     assert r["schur_sparse_reduced"]["ok_hip"] == 1 and r["schur_sparse_reduced"]["rel_inf"] < 1e-10
     for k in ("factorize_6x6_R", "factorize_6x6_L", "factorize_3x3_R", "factorize_3x3_L"):
         assert r[k]["ok_ref"] == 1 and r[k]["ok_hip"] == 1 and r[k]["rel_max"] < 1e-11, (k, r[k])
+    assert r["pose_graph_marginals"]["ok_ref"] == 1 and r["pose_graph_marginals"]["ok_hip"] == 1
+    assert r["pose_graph_marginals"]["rel_inf"] < 1e-10
     for k in ("schur_marginals_cams_first", "schur_marginals_interleaved"):   # block diagonal of the covariance
         assert r[k]["ok_ref"] == 1 and r[k]["ok_hip"] == 1 and r[k]["cam_rel_inf"] < 1e-10 and r[k]["lm_rel_inf"] < 1e-10, (k, r[k])
     for k in ("marginal_poses_cams_first", "marginal_poses_interleaved"):

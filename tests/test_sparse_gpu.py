@@ -211,3 +211,49 @@ def test_random_structures_match_oracle(seed):
     assert rel_inf(eta, x_ref) < TOL, (seed, opts, lam.n_bcols)
     eta3 = lam.rhs.copy()
     assert solver.Solve_Again(eta3) and rel_inf(eta3, x_ref) < TOL
+
+
+@pytest.mark.parametrize("name", ["chain6_n60", "chain3_n90", "chain7_n40", "sphere_8x8", "manhattan_n150"])
+def test_marginals_match_reference(name):
+    """Block diagonal of the covariance of a pose graph against what the reference's
+    CMarginals::Calculate_DenseMarginals_Recurrent_FBS(.., mpart_Diagonal) returned (golden)."""
+    from golden_util import load_golden
+    lam, ref = load_golden(name)
+    solver = CLinearSolver_HIP(dense_top_nb=0)
+    cov = solver.Marginals(lam)
+    assert rel_inf(cov, ref["cov_diag"]) < TOL
+    err = np.abs(cov - ref["cov_diag"]).reshape(len(cov), -1).max(axis=1) / np.abs(ref["cov_diag"]).reshape(len(cov), -1).max(axis=1)
+    assert err.max() < 1e-9
+    eta = lam.rhs.copy()                                      # the factor the covariances left behind serves a solve
+    assert solver.Solve_Again(eta) and rel_inf(eta, ref["x_cholmod_super"]) < TOL
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_marginals_random_structures(seed):
+    lam, opts = random_system(3000 + seed)
+    dims = np.diff(lam.cumsum)
+    opts = dict(opts, dense_top_nb=0)
+    solver = CLinearSolver_HIP(**opts)
+    if len(set(dims.tolist())) > 1 or int(dims[0]) not in (3, 6, 7):
+        with pytest.raises(NotImplementedError):
+            solver.Marginals(lam)
+        return
+    d = int(dims[0])
+    full = np.linalg.inv(lam.to_scipy().toarray())
+    ref = np.stack([full[d * c:d * c + d, d * c:d * c + d] for c in range(lam.n_bcols)])
+    assert rel_inf(solver.Marginals(lam), ref) < TOL
+
+
+def test_marginals_with_dense_top_are_refused_and_full_size():
+    lam = synth.sphere(50, 50)
+    with pytest.raises(NotImplementedError):
+        CLinearSolver_HIP().Marginals(lam)                   # its default plan has a dense top
+    lam = synth.pose_chain(n=100000)
+    solver = CLinearSolver_HIP()
+    cov = solver.Marginals(lam)
+    for c in (0, 54321, 99999):
+        for j in (0, 5):
+            e = np.zeros(lam.n_scalars)
+            e[6 * c + j] = 1.0
+            assert solver.Solve_PosDef_Blocky(lam, e)
+            assert rel_inf(e[6 * c:6 * c + 6], cov[c][:, j]) < 1e-9
