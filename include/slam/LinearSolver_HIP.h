@@ -440,8 +440,7 @@ public:
 	 *	@param[in] r_lambda is the system matrix (symmetric layout, upper triangle stored, one block size: 3, 6 or 7)
 	 *
 	 *	@return Returns true on success, false if lambda is not positive definite.
-	 *	@note This function throws std::bad_alloc and std::runtime_error (also for plans with a dense top:
-	 *		Set_Option("dense_top_nb", 0) before the first call where the graph has large separators).
+	 *	@note This function throws std::bad_alloc and std::runtime_error.
 	 */
 	bool Marginals(CUberBlockMatrix &r_marginals, const CUberBlockMatrix &r_lambda) // throw(std::bad_alloc, std::runtime_error)
 	{

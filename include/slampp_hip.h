@@ -75,6 +75,7 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
  * "dense_top_nb" (sparse path: block columns with at least this many blocks, and their ancestors, are factored as
  * one dense matrix on the matrix cores; default: 24, or 16 / 36 where a model of the dependent launch chain clearly
  * prefers that; setting the option fixes the threshold; 0 = off), "dense_top_max_dim" (cap on its dimension, default 12288),
+ * "dense_top_min_dim" (below this dimension there is no dense top, default 192),
  * "profile" (0/1, see slampp_hip_get_profile), "shard_primary" (multi-GPU BA: this rank adds A and eta_x),
  * "shard_rank" / "shard_world" (multi-GPU BA, optional: who this rank is among the ranks behind the all-reduce
  * callback; lets them exchange their block lists, which scales with the nonzero blocks of S, instead of an indicator
@@ -141,8 +142,9 @@ int slampp_hip_solve_marginal_poses_device_async(slampp_hip_solver *p_solver, co
  * Lambda once more on the host for the purpose (include/slam/NonlinearSolver_Lambda.h:700-760, "todo - reuse what the
  * linear solver calculated").  Numeric factorization, then the blocks of the inverse on the factor's pattern by the
  * recursion run from the root of the elimination tree downwards; p_block_diag receives one dim x dim column-major block
- * per block column, in the order of slampp_hip_set_structure.  Needs one block size (3, 6 or 7) and a plan without a
- * dense top (option "dense_top_nb" = 0 where the default plan has one): SLAMPP_HIP_ERR_UNSUPPORTED otherwise. */
+ * per block column, in the order of slampp_hip_set_structure.  Where the plan has a dense top, its part of the
+ * inverse is the dense inverse of the top's Schur complement (matrix cores), and the recursion continues below it.
+ * Needs one block size (3, 6 or 7): SLAMPP_HIP_ERR_UNSUPPORTED otherwise. */
 int slampp_hip_marginals(slampp_hip_solver *p_solver, const double *p_values, double *p_block_diag);
 int slampp_hip_marginals_device_async(slampp_hip_solver *p_solver, const double *p_values_dev, double *p_block_diag_dev);
 

@@ -354,7 +354,6 @@ int main(int n_arg_num, const char **p_arg_list)
 				margs_ordered.Permute_UpperTriangular_To(margs_ref, mord.p_Get_Ordering(), mord.n_Ordering_Size(), false);
 			}
 			CLinearSolver_HIP hip_solver;
-			hip_solver.Set_Option("dense_top_nb", 0);
 			const bool b_hip = hip_solver.Marginals(margs_hip, lambda);
 			double f_err = 0, f_max = 0;
 			for(size_t i = 0; i < n && b_ref && b_hip; ++ i) {

@@ -125,6 +125,7 @@ struct slampp_hip_solver {
 	slampp::CSparseInverse *p_sinv = 0;    // sparse path: lists of the sparse inverse subset (slampp_hip_marginals), built on first use
 	bool b_sinv_tried = false;
 	slampp::CDevArray<double> d_Z;         // laid out like d_L
+	slampp::CDevArray<double> d_Zd, d_Zd_work; // inverse of the dense top's Schur complement, and the copy of its factor that gets inverted
 	slampp::CDevArray<int64_t> d_diag_zoff; // offset of every block column's diagonal block in it, original order
 	slampp::CDevArray<int64_t> d_damp_off; // (offset of the diagonal block's first element, dimension) per block column: apply_damping
 	bool b_damp_valid = false;

@@ -53,7 +53,7 @@ void slampp_hip_solver::Free_Device()
 		p_sinv = 0;
 	}
 	b_sinv_tried = false;
-	d_Z.Free(); d_diag_zoff.Free();
+	d_Z.Free(); d_diag_zoff.Free(); d_Zd.Free(); d_Zd_work.Free();
 	if(p_schur) {
 		schur_destroy(p_schur);
 		p_schur = 0;
@@ -68,7 +68,7 @@ size_t slampp_hip_solver::n_Device_Bytes() const
 		d_dense_z.n_Bytes() + d_dense_x.n_Bytes() + d_cols.n_Bytes() + d_blks.n_Bytes() + d_rents.n_Bytes() +
 		d_task_ptr.n_Bytes() + d_task_pkg.n_Bytes() + d_pkg.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
 		d_rhs.n_Bytes() + d_L.n_Bytes() + d_Linv.n_Bytes() + d_w.n_Bytes() + d_cov.n_Bytes() + d_flag.n_Bytes() +
-		d_Z.n_Bytes() + d_diag_zoff.n_Bytes() + sparse_inverse_bytes(p_sinv) +
+		d_Z.n_Bytes() + d_diag_zoff.n_Bytes() + d_Zd.n_Bytes() + d_Zd_work.n_Bytes() + sparse_inverse_bytes(p_sinv) +
 		(p_schur? schur_device_bytes(p_schur) : 0);
 }
 
@@ -535,6 +535,8 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 	}
 	else if(s == "dense_top_max_dim" && n_value >= 0)
 		p_solver->opt.dense_top_max_dim = int(n_value);
+	else if(s == "dense_top_min_dim" && n_value >= 0)
+		p_solver->opt.dense_top_min_dim = int(n_value);
 	else if(s == "shard_primary")
 		p_solver->b_shard_primary = (n_value != 0);
 	else if(s == "shard_rank" && n_value >= 0) {
@@ -812,27 +814,40 @@ int slampp_hip_marginals_device_async(slampp_hip_solver *p_solver, const double 
 		const Plan &P = s.plan;
 		if(!s.b_sinv_tried) {
 			s.b_sinv_tried = true;
-			s.p_sinv = sparse_inverse_setup(P, s.stream);
+			s.p_sinv = sparse_inverse_setup(P, s.stream, true);
 			if(s.p_sinv) {
 				std::vector<int64_t> zoff(size_t(P.n));
-				for(int32_t c = 0; c < P.n; ++ c)
-					zoff[c] = P.loff[P.lptr[P.pinv[c]]];
+				for(int32_t c = 0; c < P.n; ++ c) {
+					const int32_t j = P.pinv[c];
+					zoff[c] = (P.dense_dim && P.dense_pos[j] >= 0)? -int64_t(P.dense_pos[j]) - 1 : P.loff[P.lptr[j]];
+				}
 				s.d_diag_zoff.Upload(zoff, s.stream);
 				s.d_Z.Alloc(size_t(P.loff.back()));
+				if(s.n_dense_dim) {
+					s.d_Zd.Alloc(size_t(s.n_dense_pad) * s.n_dense_pad);
+					s.d_Zd_work.Alloc(size_t(s.n_dense_pad) * s.n_dense_pad);
+				}
 				SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream)); // zoff lives on this stack frame
 			}
 		}
 		if(!s.p_sinv)
-			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "marginals: needs one block size (3, 6 or 7) and no dense top "
-				"(set the option dense_top_nb to 0)");
-		s.d_rhs.Alloc(size_t(s.n_scalars)); // the fused forward substitution reads a right-hand side: whatever is there
-		s.Enqueue_Sparse(p_values_dev, s.d_rhs.p(), true, true); // (opens its own phases: factor_subtree, factor_upper)
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "marginals: needs one block size (3, 6 or 7)");
+		// the fused forward substitution reads a right-hand side, and with a dense top it rides through that factorization
+		// as a row of the matrix: zeros (a NaN there would spread through 0 x NaN in the tile products)
+		s.d_rhs.Alloc(size_t(s.n_scalars));
+		SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_rhs.p(), 0, size_t(s.n_scalars) * sizeof(double), s.stream));
+		// (with a dense top the whole factor + solve runs: the top is factored on the way; opens its own phases)
+		s.Enqueue_Sparse(p_values_dev, s.d_rhs.p(), true, s.n_dense_dim == 0);
 		s.Phase_Begin("marginals_inverse");
-		sparse_inverse_enqueue(*s.p_sinv, P, s.d_L.p(), s.d_Linv.p(), s.d_Z.p(), s.stream);
+		if(s.n_dense_dim) { // the top's inverse from a copy of its factor (the factor itself stays for solve_again)
+			SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_Zd_work.p(), s.d_dense.p(), size_t(s.n_dense_pad) * s.n_dense_pad * sizeof(double),
+				hipMemcpyDeviceToDevice, s.stream));
+			dense_top_clear_rhs_row(s.d_Zd_work.p(), s.n_dense_pad, s.stream);
+			dense_inverse_from_factor(s.d_Zd_work.p(), s.n_dense_pad, s.d_dense_invdiag.p(), s.d_Zd.p(), s.stream);
+		}
+		sparse_inverse_enqueue(*s.p_sinv, P, s.d_L.p(), s.d_Linv.p(), s.d_Z.p(), s.stream, s.d_Zd.p(), s.n_dense_pad);
 		s.Phase_End();
-		const int d = P.max_dim;
-		schur_marginals_sparse_launch(d, (d == 3)? 2 : 3, P.n, 0, 0, s.d_diag_zoff.p(), 0, 0, 0, 0, s.d_Z.p(), p_block_diag_dev, 0,
-			s.stream);
+		inverse_diag_blocks_launch(P.n, P.max_dim, s.d_diag_zoff.p(), s.d_Z.p(), s.d_Zd.p(), s.n_dense_pad, p_block_diag_dev, s.stream);
 		SLAMPP_HIP_CHECK(hipGetLastError());
 		s.b_factored = true; // the factor of these values is in place
 		return SLAMPP_HIP_OK;

@@ -13,6 +13,9 @@
 // Z(i,k) is the stored block (max, min) of the pair, transposed when i < k; it exists because struct(j) is a clique
 // of the filled graph.  Z lives in an array laid out like L.  |struct|^2 small products per column: the cost of the
 // factorization again, latency-bound like it.
+// With a dense top (plan.h) the blocks among dense-top columns are not in that array: they are read from the dense
+// inverse of the top's Schur complement (dense_inverse.hip), whose lower triangle and diagonal tiles are valid; the
+// recursion then covers the block-eliminated columns below it.
 #include <hip/hip_runtime.h>
 #include "sparse_inverse.h"
 #include "solver.h"
@@ -35,7 +38,7 @@ struct CSparseInverse {
 	int64_t n_cols;
 	CDevArray<TInvCol> d_cols;      // in schedule order (the plan's task_cols)
 	CDevArray<int64_t> d_blk_off;   // offsets of the sub-diagonal blocks of every column
-	CDevArray<int64_t> d_terms;     // (offset of the stored block of Z(i,k)) * 2 + transposed
+	CDevArray<int64_t> d_terms;     // (offset of the stored block of Z(i,k)) << 2 | transposed, or (pos_i << 24 | pos_k) << 2 | 2 for the dense top
 	CDevArray<int64_t> d_task_ptr;
 };
 
@@ -54,9 +57,10 @@ int64_t plan_block_offset(const Plan &P, int32_t i, int32_t k)
 	return (f != e && *f == i)? P.loff[f - P.lrow.data()] : -1;
 }
 
-CSparseInverse *sparse_inverse_setup(const Plan &P, hipStream_t stream)
+CSparseInverse *sparse_inverse_setup(const Plan &P, hipStream_t stream, bool b_allow_dense_top)
 {
-	if(!P.uniform_dim || P.dense_dim != 0 || !(P.max_dim == 3 || P.max_dim == 6 || P.max_dim == 7))
+	if(!P.uniform_dim || !(P.max_dim == 3 || P.max_dim == 6 || P.max_dim == 7) || (P.dense_dim != 0 && !b_allow_dense_top) ||
+	   P.dense_dim >= (1 << 24))
 		return 0; // the dense inverse serves these
 	const int64_t n_sched = int64_t(P.task_cols.size());
 	std::vector<TInvCol> cols(n_sched);
@@ -75,10 +79,14 @@ CSparseInverse *sparse_inverse_setup(const Plan &P, hipStream_t stream)
 		for(int64_t a = P.lptr[j] + 1; a < P.lptr[j + 1]; ++ a) {
 			for(int64_t b = P.lptr[j] + 1; b < P.lptr[j + 1]; ++ b) {
 				const int32_t i = P.lrow[a], k = P.lrow[b];
+				if(P.dense_dim && P.dense_pos[i] >= 0 && P.dense_pos[k] >= 0) { // both in the dense top: element-wise from its inverse
+					terms.push_back((((int64_t(P.dense_pos[i]) << 24) | int64_t(P.dense_pos[k])) << 2) | 2);
+					continue;
+				}
 				const int64_t off = plan_block_offset(P, std::max(i, k), std::min(i, k));
 				if(off < 0)
 					throw std::logic_error("sparse inverse: the structure of a factor column is not a clique");
-				terms.push_back(off * 2 + (i < k));
+				terms.push_back((off << 2) | (i < k));
 			}
 		}
 	}
@@ -109,7 +117,7 @@ template <int D>
 __global__ void __launch_bounds__(64)
 sparse_inverse_stage_kernel(const TInvCol *__restrict__ cols, const int64_t *__restrict__ blk_off,
 	const int64_t *__restrict__ terms, const int64_t *__restrict__ task_ptr, int task_begin,
-	const double *__restrict__ L, const double *__restrict__ Linv, double *Z)
+	const double *__restrict__ L, const double *__restrict__ Linv, double *Z, const double *__restrict__ Zd, int ld)
 {
 	__shared__ double s_linv[64], s_tile[64], s_z[64];
 	const int lane = threadIdx.x;
@@ -126,13 +134,24 @@ sparse_inverse_stage_kernel(const TInvCol *__restrict__ cols, const int64_t *__r
 			double acc = 0; // ( sum over k of Z(i,k) L(k,j) )(r, q)
 			for(int kk = 0; kk < cd.nbm; ++ kk) {
 				const int64_t term = terms[cd.t0 + int64_t(kb) * cd.nbm + kk];
-				const double *Zs = Z + (term >> 1), *Ls = L + blk_off[cd.b0 + kk] + q * D;
-				const int zs = (term & 1)? 1 : D, z0 = (term & 1)? r * D : r; // Z(i,k)(r, t): stored block or its transpose
+				const double *Ls = L + blk_off[cd.b0 + kk] + q * D;
 				double zv[D], lv[D];
-				#pragma unroll
-				for(int t = 0; t < D; ++ t) {
-					zv[t] = Zs[z0 + t * zs];
-					lv[t] = Ls[t];
+				if(term & 2) { // both rows in the dense top: element (pos_i + r, pos_k + t) of its inverse, read as (max, min)
+					const int64_t pi = (term >> 26) + r, pk = (term >> 2) & 0xffffff;
+					#pragma unroll
+					for(int t = 0; t < D; ++ t) {
+						const int64_t a = pi, b = pk + t;
+						zv[t] = Zd[((a > b)? a : b) + ((a > b)? b : a) * int64_t(ld)];
+						lv[t] = Ls[t];
+					}
+				} else {
+					const double *Zs = Z + (term >> 2);
+					const int zs = (term & 1)? 1 : D, z0 = (term & 1)? r * D : r; // Z(i,k)(r, t): stored block or its transpose
+					#pragma unroll
+					for(int t = 0; t < D; ++ t) {
+						zv[t] = Zs[z0 + t * zs];
+						lv[t] = Ls[t];
+					}
 				}
 				#pragma unroll
 				for(int t = 0; t < D; ++ t)
@@ -172,7 +191,7 @@ sparse_inverse_stage_kernel(const TInvCol *__restrict__ cols, const int64_t *__r
 }
 
 void sparse_inverse_enqueue(const CSparseInverse &r_inv, const Plan &P, const double *L, const double *Linv, double *Z,
-	hipStream_t stream)
+	hipStream_t stream, const double *p_dense_top_inverse, int n_dense_ld)
 {
 	const int n_stages = int(P.stage_ptr.size()) - 1;
 	for(int s = n_stages - 1; s >= 0; -- s) {
@@ -180,7 +199,7 @@ void sparse_inverse_enqueue(const CSparseInverse &r_inv, const Plan &P, const do
 		if(n_tasks <= 0)
 			continue;
 #define LAUNCH_INV(DD) hipLaunchKernelGGL((sparse_inverse_stage_kernel<DD>), dim3(n_tasks), dim3(64), 0, stream, r_inv.d_cols.p(), \
-			r_inv.d_blk_off.p(), r_inv.d_terms.p(), r_inv.d_task_ptr.p(), P.stage_ptr[s], L, Linv, Z)
+			r_inv.d_blk_off.p(), r_inv.d_terms.p(), r_inv.d_task_ptr.p(), P.stage_ptr[s], L, Linv, Z, p_dense_top_inverse, n_dense_ld)
 		switch(r_inv.D) {
 		case 3: LAUNCH_INV(3); break;
 		case 6: LAUNCH_INV(6); break;
@@ -188,6 +207,45 @@ void sparse_inverse_enqueue(const CSparseInverse &r_inv, const Plan &P, const do
 		}
 #undef LAUNCH_INV
 	}
+}
+
+// diagonal blocks of the inverse, one d x d column-major block per block column in the caller's order: from Z, or
+// (p_where[c] = -(position + 1)) from the dense top's inverse
+__global__ void inverse_diag_blocks_kernel(int64_t n, int d, const int64_t *__restrict__ p_where, const double *__restrict__ Z,
+	const double *__restrict__ Zd, int ld, double *out)
+{
+	const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(gid >= n * d * d)
+		return;
+	const int64_t c = gid / (d * d);
+	const int e = int(gid - c * (d * d)), r = e % d, q = e / d;
+	const int64_t at = p_where[c];
+	if(at >= 0)
+		out[gid] = Z[at + e];
+	else {
+		const int64_t pos = -at - 1, a = pos + ((r > q)? r : q), b = pos + ((r > q)? q : r);
+		out[gid] = Zd[a + b * int64_t(ld)];
+	}
+}
+
+void inverse_diag_blocks_launch(int64_t n, int d, const int64_t *p_where, const double *Z, const double *Zd, int ld, double *out,
+	hipStream_t stream)
+{
+	hipLaunchKernelGGL(inverse_diag_blocks_kernel, dim3(unsigned((n * d * d + 255) / 256)), dim3(256), 0, stream, n, d, p_where, Z,
+		Zd, ld, out);
+}
+
+// the factor of the dense top carries the right-hand side as its last row: an identity row in the copy that gets inverted
+__global__ void dense_top_clear_rhs_row_kernel(double *M, int ld)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < ld)
+		M[size_t(ld - 1) + size_t(i) * ld] = (i == ld - 1)? 1.0 : 0.0;
+}
+
+void dense_top_clear_rhs_row(double *M, int ld, hipStream_t stream)
+{
+	hipLaunchKernelGGL(dense_top_clear_rhs_row_kernel, dim3((ld + 255) / 256), dim3(256), 0, stream, M, ld);
 }
 
 } // namespace slampp

@@ -358,7 +358,8 @@ class CLinearSolver_HIP(_SolverBase):
 def _block_diagonal_marginals(self, lam):
     """Block diagonal of the covariance Lambda^-1 ([n, d, d]), as CMarginals::Calculate_DenseMarginals_Recurrent_FBS
     (.., mpart_Diagonal) gives the reference's nonlinear solvers (NonlinearSolver_Lambda.h:700-760): factorization and a
-    sparse inverse subset on the factor's pattern.  One block size, no dense top (dense_top_nb=0)."""
+    sparse inverse subset on the factor's pattern (below a dense inverse of the plan's dense top, if it has one).  One block
+    size (3, 6 or 7)."""
     if not self._analyzed or self._structure_key != self._key(lam):
         self.SymbolicDecomposition_Blocky(lam)
     dims = np.diff(lam.cumsum)

@@ -219,9 +219,10 @@ def test_marginals_match_reference(name):
     CMarginals::Calculate_DenseMarginals_Recurrent_FBS(.., mpart_Diagonal) returned (golden)."""
     from golden_util import load_golden
     lam, ref = load_golden(name)
-    solver = CLinearSolver_HIP(dense_top_nb=0)
-    cov = solver.Marginals(lam)
-    assert rel_inf(cov, ref["cov_diag"]) < TOL
+    for opts in ({"dense_top_nb": 0}, {"dense_top_nb": 2, "dense_top_min_dim": 0}, {}):   # without / with a (forced) dense top / default
+        solver = CLinearSolver_HIP(**opts)
+        cov = solver.Marginals(lam)
+        assert rel_inf(cov, ref["cov_diag"]) < TOL, opts
     err = np.abs(cov - ref["cov_diag"]).reshape(len(cov), -1).max(axis=1) / np.abs(ref["cov_diag"]).reshape(len(cov), -1).max(axis=1)
     assert err.max() < 1e-9
     eta = lam.rhs.copy()                                      # the factor the covariances left behind serves a solve
@@ -232,7 +233,6 @@ def test_marginals_match_reference(name):
 def test_marginals_random_structures(seed):
     lam, opts = random_system(3000 + seed)
     dims = np.diff(lam.cumsum)
-    opts = dict(opts, dense_top_nb=0)
     solver = CLinearSolver_HIP(**opts)
     if len(set(dims.tolist())) > 1 or int(dims[0]) not in (3, 6, 7):
         with pytest.raises(NotImplementedError):
@@ -244,10 +244,35 @@ def test_marginals_random_structures(seed):
     assert rel_inf(solver.Marginals(lam), ref) < TOL
 
 
-def test_marginals_with_dense_top_are_refused_and_full_size():
-    lam = synth.sphere(50, 50)
-    with pytest.raises(NotImplementedError):
-        CLinearSolver_HIP().Marginals(lam)                   # its default plan has a dense top
+@pytest.mark.parametrize("name", ["sphere", "manhattan"])
+def test_marginals_with_dense_top(name):
+    """C2- / C1-like graphs whose default plan has a dense top: the top's part of the inverse is a dense inverse on the
+    matrix cores, the recursion continues below it.  Against numpy's inverse at a size it handles."""
+    lam = synth.sphere(24, 24) if name == "sphere" else synth.manhattan(1200)
+    solver = CLinearSolver_HIP() if name == "sphere" else CLinearSolver_HIP(dense_top_nb=8, dense_top_min_dim=0)
+    cov = solver.Marginals(lam)
+    assert solver.plan()["dense_dim"] > 0
+    d = int(lam.cumsum[1])
+    full = np.linalg.inv(lam.to_scipy().toarray())
+    ref = np.stack([full[d * c:d * c + d, d * c:d * c + d] for c in range(lam.n_bcols)])
+    assert rel_inf(cov, ref) < TOL
+    err = np.abs(cov - ref).reshape(len(cov), -1).max(axis=1) / np.abs(ref).reshape(len(cov), -1).max(axis=1)
+    assert err.max() < 1e-8
+    eta = lam.rhs.copy()
+    assert solver.Solve_Again(eta) and np.abs(lam.to_scipy() @ eta - lam.rhs).max() / np.abs(lam.rhs).max() < 1e-10
+
+
+def test_marginals_full_size():
+    lam = synth.sphere(50, 50)                               # C2: default plan with a dense top of 3712
+    solver = CLinearSolver_HIP()
+    cov = solver.Marginals(lam)
+    assert solver.plan()["dense_dim"] > 0
+    for c in (0, 1234, 2499):
+        for j in (0, 5):
+            e = np.zeros(lam.n_scalars)
+            e[6 * c + j] = 1.0
+            assert solver.Solve_PosDef_Blocky(lam, e)
+            assert rel_inf(e[6 * c:6 * c + 6], cov[c][:, j]) < 1e-9
     lam = synth.pose_chain(n=100000)
     solver = CLinearSolver_HIP()
     cov = solver.Marginals(lam)
