@@ -212,8 +212,57 @@ def run_c3(args, rank, world, local_rank, dist):
         "kernels": kernels,
     }
     out["assembly"] = assembly_leg(solver, lam, dev)
+    if world == 1:
+        out["marginals"] = marginals_leg_c3(args, solver, lam, vals, dev, torch)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_c3(lam, counts)
+    return out
+
+
+def marginals_leg_c3(args, solver, lam, vals, dev, torch):
+    """Outside the timed region: the block diagonal of the covariance Lambda^-1 of the same pose graph (numeric
+    factorization + sparse inverse subset on the factor's pattern + extraction), next to the reference's recipe for it
+    (ordering, CholeskyOf_FBS, CMarginals::Calculate_DenseMarginals_Recurrent_FBS) on the host."""
+    n, d = lam.n_bcols, int(lam.cumsum[1])
+    cov = torch.empty(n * d * d, dtype=torch.float64, device=dev)
+    lib, h = solver._lib, solver._h
+    solver._check(lib.slampp_hip_marginals_device_async(h, vals.data_ptr(), cov.data_ptr()))
+    if not solver.sync():
+        return None
+    solver.profile(reset=True)
+    reps = 10
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        solver._check(lib.slampp_hip_marginals_device_async(h, vals.data_ptr(), cov.data_ptr()))
+    ok = solver.sync()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    prof = {k_: v[1] / max(v[0], 1) for k_, v in solver.profile().items() if v[0]}
+    solver.profile(reset=True)
+    c_np = cov.cpu().numpy().reshape(n, d, d)
+    err = 0.0
+    for c in (n // 3, n - 1):   # column j of the covariance is the solution of Lambda x = e_j
+        e = np.zeros(lam.n_scalars)
+        e[d * c] = 1.0
+        if not solver.Solve_PosDef_Blocky(lam, e):
+            return None
+        err = max(err, float(np.abs(e[d * c:d * c + d] - c_np[c][:, 0]).max() / np.abs(c_np[c][:, 0]).max()))
+    out = {"workload": f"block diagonal of Lambda^-1: {n} blocks {d}x{d}", "ok": bool(ok), "ms_per_call": ms, "phases_ms": prof,
+           "column_check_rel_inf": err}
+    if not args.no_cpu_baseline:
+        from oracle import oracle_lib as O
+        if O.have_reference():
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "c3.bin")
+                lam.save(path)
+                t0 = time.perf_counter()
+                r = subprocess.run([O.REF_HARNESS, "sparse_marginals", path, os.path.join(td, "m")], capture_output=True, text=True,
+                                   timeout=900)
+                wall = time.perf_counter() - t0
+            if '"ok": true' in r.stdout:
+                out["cpu_baseline"] = {"value": wall * 1e3, "unit": "ms", "cores": 1, "kind": "reference",
+                                       "sample": "block ordering, CholeskyOf_FBS and CMarginals::Calculate_DenseMarginals_Recurrent_FBS"
+                                                 "(.., mpart_Diagonal) on the same system, incl. load"}
     return out
 
 
