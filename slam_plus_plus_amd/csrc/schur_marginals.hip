@@ -12,6 +12,28 @@
 
 namespace slampp {
 
+// N contiguous doubles with 16-byte loads where the address allows it (blocks of 6 x 6 and 6 x 3 doubles start at
+// multiples of 16 bytes; odd sizes end with one 8-byte load)
+template <int N>
+__device__ __forceinline__ void load_block(double (&r_dst)[N], const double *__restrict__ p_src)
+{
+	typedef double v2f64 __attribute__((ext_vector_type(2)));
+	if((reinterpret_cast<uintptr_t>(p_src) & 15) == 0) {
+		#pragma unroll
+		for(int i = 0; i + 1 < N; i += 2) {
+			const v2f64 v = *reinterpret_cast<const v2f64*>(p_src + i);
+			r_dst[i] = v.x;
+			r_dst[i + 1] = v.y;
+		}
+		if(N & 1)
+			r_dst[N - 1] = p_src[N - 1];
+	} else {
+		#pragma unroll
+		for(int i = 0; i < N; ++ i)
+			r_dst[i] = p_src[i];
+	}
+}
+
 template <int DC>
 __global__ void schur_cam_cov_kernel(int64_t nc, const double *__restrict__ Z, int ld, double *out)
 {
@@ -41,27 +63,30 @@ schur_point_cov_kernel(const int64_t *__restrict__ ptr, const int32_t *__restric
 	for(int64_t a = k0; a < k1; ++ a) {
 		const int64_t ca = brow[a];
 		double wa[DC * DP];
-		#pragma unroll
-		for(int i = 0; i < DC * DP; ++ i)
-			wa[i] = W[(o0 + (a - k0)) * (DC * DP) + i];
+		load_block<DC * DP>(wa, W + (o0 + (a - k0)) * (DC * DP));
 		for(int64_t b = k0; b <= a; ++ b) { // block rows ascend inside a column: cb <= ca, the lower triangle of Z
 			const int64_t cb = brow[b];
 			double wb[DC * DP], t[DC * DP];
+			load_block<DC * DP>(wb, W + (o0 + (b - k0)) * (DC * DP));
 			#pragma unroll
-			for(int i = 0; i < DC * DP; ++ i) {
-				wb[i] = W[(o0 + (b - k0)) * (DC * DP) + i];
+			for(int i = 0; i < DC * DP; ++ i)
 				t[i] = 0;
-			}
 			#pragma unroll
 			for(int q = 0; q < DC; ++ q) {
+				double zc[DC]; // column q of the block: contiguous below the diagonal block, (max, min) inside it
+				if(a == b) {
+					#pragma unroll
+					for(int r = 0; r < DC; ++ r) {
+						const int hi = (r > q)? r : q, lo = (r > q)? q : r;
+						zc[r] = Z[size_t(ca * DC + hi) + size_t(ca * DC + lo) * ld];
+					}
+				} else
+					load_block<DC>(zc, Z + size_t(ca * DC) + size_t(cb * DC + q) * ld);
 				#pragma unroll
 				for(int r = 0; r < DC; ++ r) {
-					const int hi = (r > q)? r : q, lo = (r > q)? q : r;
-					const double z = (a == b)? Z[size_t(ca * DC + hi) + size_t(ca * DC + lo) * ld] :
-						Z[size_t(ca * DC + r) + size_t(cb * DC + q) * ld];
 					#pragma unroll
 					for(int j = 0; j < DP; ++ j)
-						t[r + j * DC] += z * wb[q + j * DC];
+						t[r + j * DC] += zc[r] * wb[q + j * DC];
 				}
 			}
 			#pragma unroll
@@ -114,25 +139,22 @@ schur_point_cov_sparse_kernel(const int64_t *__restrict__ ptr, int64_t nc, int64
 		cov[i] = Cinv[pt * (DP * DP) + i];
 	for(int64_t a = k0; a < k1; ++ a) {
 		double wa[DC * DP];
-		#pragma unroll
-		for(int i = 0; i < DC * DP; ++ i)
-			wa[i] = W[(o0 + (a - k0)) * (DC * DP) + i];
+		load_block<DC * DP>(wa, W + (o0 + (a - k0)) * (DC * DP));
 		for(int64_t b = k0; b <= a; ++ b) {
 			const int64_t ia = a - k0, ib = b - k0;
 			const int64_t ent = tab[ia * (ia + 1) / 2 + ib]; // block Z(cam_a, cam_b): offset * 2 + stored transposed
-			const double *Zb = Z + (ent >> 1);
 			const bool b_tr = ent & 1;
-			double wb[DC * DP], t[DC * DP];
+			double wb[DC * DP], zb[DC * DC], t[DC * DP];
+			load_block<DC * DC>(zb, Z + (ent >> 1)); // a thread's scattered loads are paid per instruction: 16 bytes each
+			load_block<DC * DP>(wb, W + (o0 + ib) * (DC * DP));
 			#pragma unroll
-			for(int i = 0; i < DC * DP; ++ i) {
-				wb[i] = W[(o0 + ib) * (DC * DP) + i];
+			for(int i = 0; i < DC * DP; ++ i)
 				t[i] = 0;
-			}
 			#pragma unroll
 			for(int q = 0; q < DC; ++ q) {
 				#pragma unroll
 				for(int r = 0; r < DC; ++ r) {
-					const double z = b_tr? Zb[q + r * DC] : Zb[r + q * DC];
+					const double z = b_tr? zb[q + r * DC] : zb[r + q * DC];
 					#pragma unroll
 					for(int j = 0; j < DP; ++ j)
 						t[r + j * DC] += z * wb[q + j * DC];
