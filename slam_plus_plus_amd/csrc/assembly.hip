@@ -388,6 +388,27 @@ assemble_diag_packed_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__r
 	*p_dst = acc;
 }
 
+// N contiguous doubles with 16-byte loads where the address allows it
+template <int N>
+__device__ __forceinline__ void load_record(double (&r_dst)[N], const double *__restrict__ p_src)
+{
+	typedef double v2f64 __attribute__((ext_vector_type(2)));
+	if(N > 1 && (reinterpret_cast<uintptr_t>(p_src) & 15) == 0) {
+		#pragma unroll
+		for(int i = 0; i + 1 < N; i += 2) {
+			const v2f64 v = *reinterpret_cast<const v2f64*>(p_src + i);
+			r_dst[i] = v.x;
+			r_dst[i + 1] = v.y;
+		}
+		if(N & 1)
+			r_dst[N - 1] = p_src[N - 1];
+	} else {
+		#pragma unroll
+		for(int i = 0; i < N; ++ i)
+			r_dst[i] = p_src[i];
+	}
+}
+
 // Vertices with long edge lists (a BA camera sees thousands of points; one wave walking its list edge by edge took
 // 1.1 ms at 2 000 edges per camera): one workgroup per vertex, one LANE per edge -- each lane reads its edge's Jacobian,
 // Sigma^-1 and error (contiguous per edge) and keeps the lower triangle of J^T (w S) J and the D entries of the
@@ -416,23 +437,30 @@ assemble_long_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__restrict
 		const double *S = Si + e * RD * RD, *ev = err + e * RD;
 		const double w = wgt? wgt[e] : 1.0;
 		double j[RD][D], sm[RD][RD], se[RD];
-		#pragma unroll
-		for(int c = 0; c < D; ++ c)
+		{
+			// a lane's scattered loads are paid per instruction: 16 bytes each where the records start at multiples of 16 bytes
+			double jf[RD * D], sf[RD * RD], ef[RD];
+			load_record<RD * D>(jf, J);
+			load_record<RD * RD>(sf, S);
+			load_record<RD>(ef, ev);
 			#pragma unroll
-			for(int a = 0; a < RD; ++ a)
-				j[a][c] = J[a + c * RD];
-		#pragma unroll
-		for(int b = 0; b < RD; ++ b)
+			for(int c = 0; c < D; ++ c)
+				#pragma unroll
+				for(int a = 0; a < RD; ++ a)
+					j[a][c] = jf[a + c * RD];
 			#pragma unroll
-			for(int a = 0; a < RD; ++ a)
-				sm[a][b] = S[a + b * RD];
-		#pragma unroll
-		for(int b = 0; b < RD; ++ b) { // (Sigma^-1 e)[b], by columns as the one-wave kernel sums it: sum_a .. S[a + b rd]
-			double sum = 0;
+			for(int b = 0; b < RD; ++ b)
+				#pragma unroll
+				for(int a = 0; a < RD; ++ a)
+					sm[a][b] = sf[a + b * RD];
 			#pragma unroll
-			for(int a = 0; a < RD; ++ a)
-				sum += ev[a] * sm[a][b];
-			se[b] = sum;
+			for(int b = 0; b < RD; ++ b) { // (Sigma^-1 e)[b], by columns as the one-wave kernel sums it: sum_a .. S[a + b rd]
+				double sum = 0;
+				#pragma unroll
+				for(int a = 0; a < RD; ++ a)
+					sum += ef[a] * sm[a][b];
+				se[b] = sum;
+			}
 		}
 		const double wy = side? w : w * w; // the reference weights vertex 0's right-hand side twice (see above)
 		int k = 0;
