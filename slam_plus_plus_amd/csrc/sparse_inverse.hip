@@ -132,6 +132,7 @@ sparse_inverse_stage_kernel(const TInvCol *__restrict__ cols, const int64_t *__r
 		for(int kb = 0; kb < cd.nbm; ++ kb) {
 			const int64_t zoff_i = blk_off[cd.b0 + kb];
 			double acc = 0; // ( sum over k of Z(i,k) L(k,j) )(r, q)
+			#pragma unroll 2
 			for(int kk = 0; kk < cd.nbm; ++ kk) {
 				const int64_t term = terms[cd.t0 + int64_t(kb) * cd.nbm + kk];
 				const double *Ls = L + blk_off[cd.b0 + kk] + q * D;
