@@ -191,6 +191,96 @@ sparse_inverse_stage_kernel(const TInvCol *__restrict__ cols, const int64_t *__r
 	}
 }
 
+// The same with W waves per task for the stages near the root, where a stage is a handful of columns with many blocks
+// each and one wave walked (|struct|^2 terms) through them alone: wave w takes the target blocks w, w + W, ... of the
+// column, finishes them, and the partial sums of L(k,j)^T Z(k,j) meet in LDS in a fixed order for Z(j,j).
+template <int D, int W>
+__global__ void __launch_bounds__(64 * W)
+sparse_inverse_wide_kernel(const TInvCol *__restrict__ cols, const int64_t *__restrict__ blk_off,
+	const int64_t *__restrict__ terms, const int64_t *__restrict__ task_ptr, int task_begin,
+	const double *__restrict__ L, const double *__restrict__ Linv, double *Z, const double *__restrict__ Zd, int ld)
+{
+	__shared__ double s_linv[64], s_n[64], s_tile[W][64], s_z[W][64], s_m[W][64];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const bool b_act = lane < D * D;
+	const int r = b_act? lane % D : 0, q = b_act? lane / D : 0;
+	const int task = task_begin + blockIdx.x;
+	for(int64_t c = task_ptr[task + 1]; c > task_ptr[task]; -- c) {
+		const TInvCol cd = cols[c - 1];
+		if(wave == 0 && b_act)
+			s_linv[r + 8 * q] = Linv[cd.linv + lane];
+		__syncthreads();
+		double m_acc = 0;
+		for(int kb = wave; kb < cd.nbm; kb += W) {
+			const int64_t zoff_i = blk_off[cd.b0 + kb];
+			double acc = 0;
+			#pragma unroll 2
+			for(int kk = 0; kk < cd.nbm; ++ kk) {
+				const int64_t term = terms[cd.t0 + int64_t(kb) * cd.nbm + kk];
+				const double *Ls = L + blk_off[cd.b0 + kk] + q * D;
+				double zv[D], lv[D];
+				if(term & 2) {
+					const int64_t pi = (term >> 26) + r, pk = (term >> 2) & 0xffffff;
+					#pragma unroll
+					for(int t = 0; t < D; ++ t) {
+						const int64_t a = pi, b = pk + t;
+						zv[t] = Zd[((a > b)? a : b) + ((a > b)? b : a) * int64_t(ld)];
+						lv[t] = Ls[t];
+					}
+				} else {
+					const double *Zs = Z + (term >> 2);
+					const int zs = (term & 1)? 1 : D, z0 = (term & 1)? r * D : r;
+					#pragma unroll
+					for(int t = 0; t < D; ++ t) {
+						zv[t] = Zs[z0 + t * zs];
+						lv[t] = Ls[t];
+					}
+				}
+				#pragma unroll
+				for(int t = 0; t < D; ++ t)
+					acc += zv[t] * lv[t];
+			}
+			inv_wave_sync();
+			if(b_act)
+				s_tile[wave][r + 8 * q] = acc;
+			inv_wave_sync();
+			double v = 0;
+			#pragma unroll
+			for(int t = 0; t < D; ++ t)
+				v += s_tile[wave][r + 8 * t] * s_linv[t + 8 * q];
+			v = -v;
+			if(b_act) {
+				Z[zoff_i + lane] = v;
+				s_z[wave][r + 8 * q] = v;
+			}
+			inv_wave_sync();
+			const double *Lij = L + zoff_i + r * D;
+			#pragma unroll
+			for(int t = 0; t < D; ++ t)
+				m_acc += Lij[t] * s_z[wave][t + 8 * q];
+		}
+		if(b_act)
+			s_m[wave][r + 8 * q] = m_acc;
+		__syncthreads();
+		if(wave == 0) {
+			double m = 0;
+			#pragma unroll
+			for(int ww = 0; ww < W; ++ ww)
+				m += b_act? s_m[ww][r + 8 * q] : 0.0;
+			if(b_act)
+				s_n[r + 8 * q] = s_linv[r + 8 * q] - m;
+			inv_wave_sync();
+			double zjj = 0;
+			#pragma unroll
+			for(int t = 0; t < D; ++ t)
+				zjj += s_linv[t + 8 * r] * s_n[t + 8 * q];
+			if(b_act)
+				Z[cd.zdiag + lane] = zjj;
+		}
+		__syncthreads(); // column j is complete and visible before a descendant in this task reads it
+	}
+}
+
 void sparse_inverse_enqueue(const CSparseInverse &r_inv, const Plan &P, const double *L, const double *Linv, double *Z,
 	hipStream_t stream, const double *p_dense_top_inverse, int n_dense_ld)
 {
@@ -199,8 +289,14 @@ void sparse_inverse_enqueue(const CSparseInverse &r_inv, const Plan &P, const do
 		const int n_tasks = P.stage_ptr[s + 1] - P.stage_ptr[s];
 		if(n_tasks <= 0)
 			continue;
-#define LAUNCH_INV(DD) hipLaunchKernelGGL((sparse_inverse_stage_kernel<DD>), dim3(n_tasks), dim3(64), 0, stream, r_inv.d_cols.p(), \
-			r_inv.d_blk_off.p(), r_inv.d_terms.p(), r_inv.d_task_ptr.p(), P.stage_ptr[s], L, Linv, Z, p_dense_top_inverse, n_dense_ld)
+		const bool b_wide = n_tasks <= 1024; // as the factorization splits its stages between one wave and eight per task
+#define LAUNCH_INV(DD) do { if(b_wide) \
+			hipLaunchKernelGGL((sparse_inverse_wide_kernel<DD, 8>), dim3(n_tasks), dim3(512), 0, stream, r_inv.d_cols.p(), \
+				r_inv.d_blk_off.p(), r_inv.d_terms.p(), r_inv.d_task_ptr.p(), P.stage_ptr[s], L, Linv, Z, p_dense_top_inverse, n_dense_ld); \
+		else \
+			hipLaunchKernelGGL((sparse_inverse_stage_kernel<DD>), dim3(n_tasks), dim3(64), 0, stream, r_inv.d_cols.p(), \
+				r_inv.d_blk_off.p(), r_inv.d_terms.p(), r_inv.d_task_ptr.p(), P.stage_ptr[s], L, Linv, Z, p_dense_top_inverse, n_dense_ld); \
+		} while(0)
 		switch(r_inv.D) {
 		case 3: LAUNCH_INV(3); break;
 		case 6: LAUNCH_INV(6); break;
