@@ -196,6 +196,13 @@ CAssemblyState *assembly_setup(slampp_hip_solver &s, int64_t n_edges, const int6
 	return p;
 }
 
+__device__ __forceinline__ void wave_sync_lds()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // t[b] = sum_a J[a + col * rd] * S[a + b * rd]  (row `col` of J^T Sigma^-1), b < rd
 template <int RD>
 __device__ __forceinline__ void jt_sigma_row(const double *__restrict__ J, const double *__restrict__ S, int col, int rd,
@@ -230,31 +237,54 @@ __device__ __forceinline__ double dot_rd(const double (&t)[RD? RD : 8], const do
 }
 
 // off-diagonal blocks (row vertex < column vertex): sum over the block's edges of J_row^T (w S) J_col, one wave per
-// block; its record and loop bounds stay in scalar registers
+// block; its record and loop bounds stay in scalar registers.  An edge's J0, J1 and Sigma^-1 are fetched with one
+// coalesced load each into LDS (a lane computing its element straight from global memory issued rd^2 + 2 rd loads per
+// edge, 48 for an SE(3) edge), M = Sigma^-1 J1 is formed once per edge by the wave, and element (c0, c1) of
+// J0^T M is rd LDS reads per operand.
 template <int RD>
 __global__ void __launch_bounds__(64)
 assemble_offdiag_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__restrict__ entries, int d0, int d1, int n_rd,
 	const double *__restrict__ J0, const double *__restrict__ J1, const double *__restrict__ Si,
 	const double *__restrict__ wgt, double *values, int b_accumulate)
 {
+	__shared__ double s_j0[64], s_j1[64], s_s[64], s_m[64];
 	const int rd = RD? RD : n_rd;
 	const TAsmBlk bd = blks[blockIdx.x];
 	const int el = threadIdx.x;
-	if(el >= bd.rows * bd.cols)
-		return;
-	const int r = el % bd.rows, q = el / bd.rows;
-	double acc = b_accumulate? values[bd.dst + el] : 0.0;
+	const bool b_el = el < bd.rows * bd.cols;
+	const int r = b_el? el % bd.rows : 0, q = b_el? el / bd.rows : 0;
+	const int ma = el % rd, mc = el / rd; // this lane's element of M = S J1 (rd x d1)
+	double acc = (b_accumulate && b_el)? values[bd.dst + el] : 0.0;
 	for(int i = 0; i < bd.ne; ++ i) {
 		const int32_t ent = (bd.ne == 1)? int32_t(bd.e0) : entries[bd.e0 + i];
 		const int64_t e = ent >> 1;
 		const bool b_flip = ent & 1; // vertex 0 has the larger id: the stored block is (J0^T w S J1)^T
+		const double v0 = (el < rd * d0)? J0[e * rd * d0 + el] : 0.0, v1 = (el < rd * d1)? J1[e * rd * d1 + el] : 0.0,
+			vs = (el < rd * rd)? Si[e * rd * rd + el] : 0.0;
+		const double w = wgt? wgt[e] : 1.0;
+		wave_sync_lds(); // the previous edge's operands have been consumed
+		s_j0[el] = v0;
+		s_j1[el] = v1;
+		s_s[el] = vs;
+		wave_sync_lds();
+		double m = 0;
+		if(el < rd * d1) {
+			#pragma unroll
+			for(int b2 = 0; b2 < (RD? RD : 8); ++ b2)
+				if(RD || b2 < rd) m += s_s[ma + b2 * rd] * s_j1[b2 + mc * rd];
+		}
+		s_m[el] = m;
+		wave_sync_lds();
 		// element (c0, c1) of J0^T (w S) J1 lands on (r, q) of the stored block
 		const int c0 = b_flip? q : r, c1 = b_flip? r : q;
-		double t[RD? RD : 8];
-		jt_sigma_row<RD>(J0 + e * rd * d0, Si + e * rd * rd, c0, rd, t);
-		acc += dot_rd<RD>(t, J1 + e * rd * d1 + c1 * rd, rd) * (wgt? wgt[e] : 1.0);
+		double sum = 0;
+		#pragma unroll
+		for(int a2 = 0; a2 < (RD? RD : 8); ++ a2)
+			if(RD || a2 < rd) sum += s_j0[a2 + c0 * rd] * s_m[a2 + c1 * rd];
+		acc += sum * w;
 	}
-	values[bd.dst + el] = acc; // a structural block without an edge becomes zeros
+	if(b_el)
+		values[bd.dst + el] = acc; // a structural block without an edge becomes zeros
 }
 
 // The same for small blocks with small residuals (a BA system: 6 x 3 blocks, one edge each, 2-d residuals): as many
@@ -287,7 +317,9 @@ assemble_offdiag_packed_kernel(const TAsmBlk *__restrict__ blks, int64_t n_blks,
 	values[bd.dst + el] = acc;
 }
 
-// one wave per vertex: diagonal block (lanes r + q d) and eta (lanes 56 + q)
+// one wave per vertex: diagonal block (lanes r + q d) and eta (lanes 56 + q); an incident edge's Jacobian, Sigma^-1 and
+// error are fetched with one coalesced load each into LDS, M = Sigma^-1 [J | e] is formed once per edge by the wave
+// (lanes a + c rd the columns of J, lanes 56 + a the error), and a lane's element of J^T M is rd LDS reads per operand
 template <int RD>
 __global__ void __launch_bounds__(64)
 assemble_diag_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__restrict__ vertex_of,
@@ -296,28 +328,51 @@ assemble_diag_kernel(const TAsmBlk *__restrict__ blks, const int32_t *__restrict
 	const double *__restrict__ err, const double *__restrict__ wgt, int unary_vertex, const double *__restrict__ unary,
 	double *values, double *eta, int b_accumulate)
 {
+	__shared__ double s_j[64], s_s[64], s_e[8], s_m[64];
 	const int rd = RD? RD : n_rd;
 	const TAsmBlk bd = blks[blockIdx.x];
 	const int lane = threadIdx.x;
 	const int d = bd.rows;
 	const bool b_blk = lane < d * d, b_y = lane >= 56 && lane < 56 + d;
-	if(!b_blk && !b_y)
-		return;
-	const int r = b_blk? lane % d : lane - 56, q = b_blk? lane / d : 0;
+	const int r = b_blk? lane % d : (b_y? lane - 56 : 0), q = b_blk? lane / d : 0;
+	const int ma = (lane < 56)? lane % rd : lane - 56, mc = lane / rd; // this lane's element of M
 	double *p_dst = b_blk? values + bd.dst + lane : eta + bd.eta_off + r;
-	double acc = b_accumulate? *p_dst : 0.0;
-	for(int i = 0; i < bd.ne; ++ i) {
+	double acc = (b_accumulate && (b_blk || b_y))? *p_dst : 0.0;
+	for(int i = 0; i < bd.ne; ++ i) { // (requesting the records of four edges together changed nothing: 89 -> 91 us at C3)
 		const int32_t ent = entries[bd.e0 + i];
 		const int64_t e = ent >> 1;
 		const int side = ent & 1;
 		const double *J = side? J1 + e * rd * d1 : J0 + e * rd * d0;
+		const double vj = (lane < rd * d)? J[lane] : 0.0, vs = (lane < rd * rd)? Si[e * rd * rd + lane] : 0.0,
+			ve = (lane < rd)? err[e * rd + lane] : 0.0;
 		const double w = wgt? wgt[e] : 1.0;
-		double t[RD? RD : 8];
-		jt_sigma_row<RD>(J, Si + e * rd * rd, r, rd, t); // row r of J^T Sigma^-1
-		// block lanes: times column q of J, weighted once; eta lanes: times the error, and the reference
-		// weights vertex 0's right-hand side twice (BaseTypes_Binary.h:813-815 against :836-838)
-		acc += dot_rd<RD>(t, b_blk? J + q * rd : err + e * rd, rd) * ((b_blk || side)? w : w * w);
+		wave_sync_lds(); // the previous edge's operands have been consumed
+		s_j[lane] = vj;
+		s_s[lane] = vs;
+		if(lane < 8)
+			s_e[lane] = ve;
+		wave_sync_lds();
+		double m = 0;
+		if(lane < rd * d) { // (S J)(ma, mc)
+			#pragma unroll
+			for(int b2 = 0; b2 < (RD? RD : 8); ++ b2)
+				if(RD || b2 < rd) m += s_s[ma + b2 * rd] * s_j[b2 + mc * rd];
+		} else if(lane >= 56 && lane < 56 + rd) { // (S e)(ma)
+			#pragma unroll
+			for(int b2 = 0; b2 < (RD? RD : 8); ++ b2)
+				if(RD || b2 < rd) m += s_s[ma + b2 * rd] * s_e[b2];
+		}
+		s_m[lane] = m; // lanes 56 .. 56 + rd - 1: S e; rd d <= 56, so the two ranges do not meet
+		wave_sync_lds();
+		double sum = 0;
+		#pragma unroll
+		for(int a2 = 0; a2 < (RD? RD : 8); ++ a2)
+			if(RD || a2 < rd) sum += s_j[a2 + r * rd] * (b_blk? s_m[a2 + q * rd] : s_m[56 + a2]);
+		// the reference weights vertex 0's right-hand side twice (BaseTypes_Binary.h:813-815 against :836-838)
+		acc += sum * ((b_blk || side)? w : w * w);
 	}
+	if(!b_blk && !b_y)
+		return;
 	if(vertex_of[blockIdx.x] == unary_vertex)
 		acc += b_blk? unary[lane] : unary[64 + r];
 	*p_dst = acc;
