@@ -40,6 +40,7 @@
 
 #include "slam/LinearSolverTags.h"
 #include "slam/BlockMatrix.h"
+#include "slam/LinearSolver_Schur.h" // the primary template specialized at the end of this file, and its guided ordering helper
 #include "slampp_hip.h"
 
 /**
@@ -54,9 +55,11 @@ protected:
 	std::vector<int64_t> m_cumsum, m_bcol_ptr; /**< @brief structure handed to the library */
 	std::vector<int32_t> m_brow;
 	std::vector<size_t> m_order; /**< @brief new block column -> old (empty = identity) */
-	struct TGatherEntry { uint32_t n_col, n_blk; int64_t n_dest; int32_t n_rows, n_cols; bool b_transpose; };
+	struct TGatherEntry { uint32_t n_col, n_blk; int64_t n_dest; int32_t n_rows, n_cols; uint32_t n_row; bool b_transpose; };
 	std::vector<TGatherEntry> m_gather; /**< @brief where every block of lambda goes in the packed values */
-	std::vector<double> m_values, m_rhs; /**< @brief staging */
+	std::vector<uint32_t> m_col_block_num, m_col_width; /**< @brief blocks and width of every block column of lambda when it was analyzed (its own order) */
+	double *m_p_values, *m_p_rhs; /**< @brief pinned staging owned by the library (slampp_hip_host_staging) */
+	size_t m_n_value_num; /**< @brief number of packed values of lambda */
 	slampp_hip_times m_t_times;
 
 	void Throw_On_Error(int n_result) const // throw(std::bad_alloc, std::runtime_error)
@@ -104,8 +107,12 @@ protected:
 			m_cumsum[i + 1] = m_cumsum[i] + int64_t(r_lambda.n_BlockColumn_Column_Num(p_order? m_order[i] : i));
 		// count the blocks of every destination column (upper triangle of the permuted matrix)
 		m_bcol_ptr.assign(n + 1, 0);
+		m_col_block_num.resize(n);
+		m_col_width.resize(n);
 		size_t n_block_num = 0;
 		for(size_t c = 0; c < n; ++ c) {
+			m_col_block_num[c] = uint32_t(r_lambda.n_BlockColumn_Block_Num(c));
+			m_col_width[c] = uint32_t(r_lambda.n_BlockColumn_Column_Num(c));
 			for(size_t j = 0, m = r_lambda.n_BlockColumn_Block_Num(c); j < m; ++ j) {
 				const size_t r = r_lambda.n_Block_Row(c, j);
 				if(r > c)
@@ -131,6 +138,7 @@ protected:
 					TGatherEntry t;
 					t.n_col = uint32_t(c);
 					t.n_blk = uint32_t(j);
+					t.n_row = uint32_t(r);
 					t.n_rows = int32_t(r_lambda.n_BlockColumn_Column_Num(r)); // symmetric layout
 					t.n_cols = int32_t(r_lambda.n_BlockColumn_Column_Num(c));
 					t.b_transpose = nr > nc; // lands below the diagonal: store its transpose above
@@ -151,86 +159,170 @@ protected:
 					n_value_num += int64_t(m_gather[k].n_rows) * m_gather[k].n_cols;
 				}
 			}
-			m_values.resize(size_t(n_value_num));
+			m_n_value_num = size_t(n_value_num);
 		}
 		int n_result = slampp_hip_set_structure(m_p_solver, int64_t(n), &m_cumsum[0], &m_bcol_ptr[0],
 			m_brow.empty()? 0 : &m_brow[0]);
 		if(n_result == SLAMPP_HIP_OK)
 			n_result = slampp_hip_analyze(m_p_solver, n_mode, int64_t(n_matrix_cut));
+		if(n_result == SLAMPP_HIP_OK)
+			n_result = slampp_hip_host_staging(m_p_solver, &m_p_values, &m_p_rhs);
 		Throw_On_Error(n_result);
 		m_b_structure_valid = true;
 		return true;
 	}
 
+	/**
+	 *	@brief tells whether the cached analysis can still apply to r_lambda: same number, widths and block counts of the
+	 *		block columns (one pass over the columns); the block rows themselves are verified by Gather_Values() while
+	 *		it copies, so that a changed pattern of the same shape is detected without a second pass over the blocks
+	 *	@note The reference's cached solvers compare sizes only (LinearSolver_Schur.h:1627) and rely on the caller
+	 *		announcing a change through Clear_SymbolicDecomposition(); its CHOLMOD Factorize_PosDef_Blocky() re-analyzes on
+	 *		every call (LinearSolver_CholMod.cpp:396-423), and FastL relies on that (NonlinearSolver_FastL.h:2131, 2388).
+	 */
 	bool b_Structure_Matches(const CUberBlockMatrix &r_lambda) const
 	{
-		return m_b_structure_valid && m_p_solver && r_lambda.n_BlockColumn_Num() + 1 == m_cumsum.size() &&
-			size_t(m_cumsum.back()) == r_lambda.n_Column_Num();
-		// like the reference (LinearSolver_Schur.h:1627), only sizes are compared here; a caller that
-		// changes the structure announces it through Clear_SymbolicDecomposition()
+		const size_t n = r_lambda.n_BlockColumn_Num();
+		if(!m_b_structure_valid || !m_p_solver || n + 1 != m_cumsum.size() ||
+		   size_t(m_cumsum.back()) != r_lambda.n_Column_Num() || m_col_block_num.size() != n)
+			return false;
+		for(size_t c = 0; c < n; ++ c) {
+			if(r_lambda.n_BlockColumn_Block_Num(c) != m_col_block_num[c] || r_lambda.n_BlockColumn_Column_Num(c) != m_col_width[c])
+				return false;
+		}
+		return true;
 	}
 
-	/** @brief copies the block values of lambda into the packed array the library reads */
-	void Gather_Values(const CUberBlockMatrix &r_lambda)
+	/**
+	 *	@brief copies the block values of lambda into the packed array the library reads
+	 *	@return Returns true on success, false if a block of lambda is not where the cached structure has it
+	 *		(the block structure changed: the caller re-analyzes and gathers again).
+	 *	@note b_Structure_Matches() must hold (the block counts of the columns bound the indices used here).
+	 */
+	bool Gather_Values(const CUberBlockMatrix &r_lambda) // throw(std::bad_alloc, std::runtime_error)
 	{
 		const long n_block_num = long(m_gather.size());
-		#pragma omp parallel for schedule(static) if(n_block_num > 512)
-		for(long k = 0; k < n_block_num; ++ k) {
-			const TGatherEntry &t = m_gather[k];
-			CUberBlockMatrix::_TyConstMatrixXdRef block = r_lambda.t_Block_AtColumn(t.n_col, t.n_blk);
-			const double *p_src = block.data();
-			double *p_dest = &m_values[size_t(t.n_dest)];
-			if(!t.b_transpose) {
-				for(int i = 0, m = t.n_rows * t.n_cols; i < m; ++ i)
-					p_dest[i] = p_src[i];
-			} else {
-				for(int c = 0; c < t.n_cols; ++ c)
-					for(int r = 0; r < t.n_rows; ++ r)
-						p_dest[c + r * t.n_cols] = p_src[r + c * t.n_rows]; // dest is n_cols x n_rows
+		double *p_values = m_p_values;
+		const int64_t n_chunk_values = int64_t(2) << 20; // 16 MB: chunk k is on the bus while chunk k + 1 is gathered
+		long n_first = 0;
+		int64_t n_sent = 0;
+		while(n_first < n_block_num) {
+			long n_last = n_first;
+			const int64_t n_limit = m_gather[n_first].n_dest + n_chunk_values;
+			if(int64_t(m_n_value_num) <= n_limit)
+				n_last = n_block_num;
+			else {
+				long n_lo = n_first + 1, n_hi = n_block_num; // first entry at or beyond the limit (entries are sorted by n_dest)
+				while(n_lo < n_hi) {
+					const long n_mid = (n_lo + n_hi) / 2;
+					if(m_gather[n_mid].n_dest < n_limit)
+						n_lo = n_mid + 1;
+					else
+						n_hi = n_mid;
+				}
+				n_last = n_lo;
 			}
+			int n_mismatch = 0;
+			#pragma omp parallel for schedule(static) reduction(+:n_mismatch) if(n_last - n_first > 512)
+			for(long k = n_first; k < n_last; ++ k) {
+				const TGatherEntry &t = m_gather[k];
+				if(r_lambda.n_Block_Row(t.n_col, t.n_blk) != t.n_row) {
+					++ n_mismatch;
+					continue;
+				}
+				CUberBlockMatrix::_TyConstMatrixXdRef block = r_lambda.t_Block_AtColumn(t.n_col, t.n_blk);
+				const double *p_src = block.data();
+				double *p_dest = p_values + t.n_dest;
+				if(!t.b_transpose) {
+					for(int i = 0, m = t.n_rows * t.n_cols; i < m; ++ i)
+						p_dest[i] = p_src[i];
+				} else {
+					for(int c = 0; c < t.n_cols; ++ c)
+						for(int r = 0; r < t.n_rows; ++ r)
+							p_dest[c + r * t.n_cols] = p_src[r + c * t.n_rows]; // dest is n_cols x n_rows
+				}
+			}
+			if(n_mismatch) {
+				Throw_On_Error(slampp_hip_upload_values_async(m_p_solver, 0, 0)); // (forget the chunks sent so far)
+				return false;
+			}
+			const int64_t n_end = (n_last < n_block_num)? m_gather[n_last].n_dest : int64_t(m_n_value_num);
+			if(n_last < n_block_num) { // the last chunk goes with the call that consumes the values
+				Throw_On_Error(slampp_hip_upload_values_async(m_p_solver, n_sent, n_end - n_sent));
+				n_sent = n_end;
+			}
+			n_first = n_last;
+		}
+		return true;
+	}
+
+	/** @brief b_Structure_Matches() and Gather_Values() in one: re-analyzes with analyze() if the structure changed */
+	template <class CAnalyze>
+	void Gather_Or_Reanalyze(const CUberBlockMatrix &r_lambda, CAnalyze analyze) // throw(std::bad_alloc, std::runtime_error)
+	{
+		if(!b_Structure_Matches(r_lambda) || !Gather_Values(r_lambda)) {
+			analyze();
+			if(!b_Structure_Matches(r_lambda) || !Gather_Values(r_lambda))
+				throw std::runtime_error("CLinearSolver_HIP: lambda changed while it was being read");
 		}
 	}
 
-	bool Gather_And_Solve(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta,
+	/**
+	 *	@brief solves with the values Gather_Values() has put into the staging; eta goes through the pinned
+	 *		right-hand side staging (permuted by blocks if the analysis reordered lambda, cf. BlockMatrix.cpp:9291-9401)
+	 */
+	bool Solve_Gathered(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta,
 		bool b_landmarks_only = false) // throw(std::bad_alloc, std::runtime_error)
 	{
 		_ASSERTE(size_t(r_eta.rows()) == r_lambda.n_Column_Num());
-		Gather_Values(r_lambda);
-		double *p_rhs = &r_eta(0);
-		const size_t n = m_cumsum.size() - 1;
-		if(!m_order.empty()) { // permute eta by blocks (cf. BlockMatrix.cpp:9291-9401)
-			m_rhs.resize(size_t(r_eta.rows()));
-			for(size_t i = 0; i < n; ++ i) {
+		const long n = long(m_cumsum.size()) - 1, n_scalar_num = long(r_eta.rows());
+		if(size_t(n_scalar_num) != size_t(m_cumsum.back()))
+			throw std::runtime_error("CLinearSolver_HIP: the right-hand side does not match lambda");
+		const double *p_eta = &r_eta(0);
+		if(!m_order.empty()) {
+			#pragma omp parallel for schedule(static) if(n > 4096)
+			for(long i = 0; i < n; ++ i) {
 				const size_t n_src = r_lambda.n_BlockColumn_Base(m_order[i]);
 				for(int64_t d = 0, w = m_cumsum[i + 1] - m_cumsum[i]; d < w; ++ d)
-					m_rhs[size_t(m_cumsum[i] + d)] = r_eta(n_src + d);
+					m_p_rhs[size_t(m_cumsum[i] + d)] = p_eta[n_src + d];
 			}
-			p_rhs = &m_rhs[0];
+		} else {
+			#pragma omp parallel for schedule(static) if(n_scalar_num > 65536)
+			for(long i = 0; i < n_scalar_num; ++ i)
+				m_p_rhs[i] = p_eta[i];
 		}
+		++ n_Solve_Counter();
 		const int n_result = b_landmarks_only?
-			slampp_hip_solve_marginal_poses(m_p_solver, m_values.empty()? 0 : &m_values[0], p_rhs) :
-			slampp_hip_factor_solve(m_p_solver, m_values.empty()? 0 : &m_values[0], p_rhs, &m_t_times);
+			slampp_hip_solve_marginal_poses(m_p_solver, m_p_values, m_p_rhs) :
+			slampp_hip_factor_solve(m_p_solver, m_p_values, m_p_rhs, &m_t_times);
 		if(n_result == SLAMPP_HIP_NOT_POSDEF)
 			return false;
 		Throw_On_Error(n_result);
+		double *p_x = &r_eta(0);
 		if(!m_order.empty()) {
-			for(size_t i = 0; i < n; ++ i) {
+			#pragma omp parallel for schedule(static) if(n > 4096)
+			for(long i = 0; i < n; ++ i) {
 				const size_t n_dst = r_lambda.n_BlockColumn_Base(m_order[i]);
 				for(int64_t d = 0, w = m_cumsum[i + 1] - m_cumsum[i]; d < w; ++ d)
-					r_eta(n_dst + d) = m_rhs[size_t(m_cumsum[i] + d)];
+					p_x[n_dst + d] = m_p_rhs[size_t(m_cumsum[i] + d)];
 			}
+		} else {
+			#pragma omp parallel for schedule(static) if(n_scalar_num > 65536)
+			for(long i = 0; i < n_scalar_num; ++ i)
+				p_x[i] = m_p_rhs[i];
 		}
 		return true;
 	}
 
 public:
 	inline CLinearSolver_HIP_Base(int n_device = 0)
-		:m_p_solver(0), m_n_device(n_device), m_b_structure_valid(false)
+		:m_p_solver(0), m_n_device(n_device), m_b_structure_valid(false), m_p_values(0), m_p_rhs(0), m_n_value_num(0)
 	{}
 
 	/** @brief copy-constructor; copies the configuration, not the state */
 	inline CLinearSolver_HIP_Base(const CLinearSolver_HIP_Base &r_other)
-		:m_p_solver(0), m_n_device(r_other.m_n_device), m_options(r_other.m_options), m_b_structure_valid(false)
+		:m_p_solver(0), m_n_device(r_other.m_n_device), m_options(r_other.m_options), m_b_structure_valid(false),
+		m_p_values(0), m_p_rhs(0), m_n_value_num(0)
 	{}
 
 	inline ~CLinearSolver_HIP_Base()
@@ -277,7 +369,22 @@ public:
 		{ std::vector<int64_t> e0, e1; m_cumsum.swap(e0); m_bcol_ptr.swap(e1); }
 		{ std::vector<int32_t> e; m_brow.swap(e); }
 		{ std::vector<TGatherEntry> e; m_gather.swap(e); }
-		{ std::vector<double> e0, e1; m_values.swap(e0); m_rhs.swap(e1); }
+		{ std::vector<uint32_t> e0, e1; m_col_block_num.swap(e0); m_col_width.swap(e1); }
+		m_p_values = m_p_rhs = 0; // went with the handle
+		m_n_value_num = 0;
+	}
+
+	/** @brief number of solves all instances have sent to the library so far (diagnostic: shows that the GPU path ran) */
+	static size_t &n_Solve_Counter()
+	{
+		static size_t n_counter = 0;
+		return n_counter;
+	}
+
+	/** @brief HIP device ordinal this solver runs on (part of the configuration) */
+	inline int n_Device() const
+	{
+		return m_n_device;
 	}
 
 	/** @brief clears the symbolic decomposition (the block structure of lambda is about to change) */
@@ -320,7 +427,10 @@ public:
 		size_t n_dest_row_id, size_t n_dest_column_id, bool b_upper_factor) // throw(std::bad_alloc, std::runtime_error)
 	{
 		const size_t n = r_lambda.n_BlockColumn_Num();
-		if(!b_Structure_Matches(r_lambda) || m_l_ptr.size() != n + 1) {
+		// the reference's counterpart is stateless (it re-analyzes on every call, LinearSolver_CholMod.cpp:396-423) and
+		// FastL hands it different parts of R without announcing a new structure (NonlinearSolver_FastL.h:2131, 2388):
+		// the cached analysis is reused only if every block of lambda is where it was (verified while gathering)
+		Gather_Or_Reanalyze(r_lambda, [&]() {
 			Analyze(r_lambda, SLAMPP_HIP_MODE_SPARSE, 0, 0);
 			slampp_hip_plan_view t_view;
 			memset(&t_view, 0, sizeof(t_view));
@@ -335,14 +445,14 @@ public:
 			t_view.p_lrow = m_l_row.empty()? 0 : &m_l_row[0];
 			t_view.p_loff = m_l_off.empty()? 0 : &m_l_off[0];
 			Throw_On_Error(slampp_hip_get_plan(m_p_solver, &t_view)); // contents
-			for(size_t i = 0; i < n; ++ i) {
+			for(size_t i = 0, m = m_l_perm.size(); i < m; ++ i) {
 				if(size_t(m_l_perm[i]) != i)
 					throw std::runtime_error("CLinearSolver_HIP: the factorization did not keep the caller's order");
 			}
-		}
-		Gather_Values(r_lambda);
-		const int n_result = slampp_hip_factorize(m_p_solver, m_values.empty()? 0 : &m_values[0],
-			m_l_values.empty()? 0 : &m_l_values[0]);
+		});
+		if(m_l_ptr.size() != n + 1)
+			throw std::runtime_error("CLinearSolver_HIP: the factor's structure does not match lambda");
+		const int n_result = slampp_hip_factorize(m_p_solver, m_p_values, m_l_values.empty()? 0 : &m_l_values[0]);
 		if(n_result == SLAMPP_HIP_NOT_POSDEF)
 			return false;
 		Throw_On_Error(n_result);
@@ -444,12 +554,10 @@ public:
 	 */
 	bool Marginals(CUberBlockMatrix &r_marginals, const CUberBlockMatrix &r_lambda) // throw(std::bad_alloc, std::runtime_error)
 	{
-		if(!b_Structure_Matches(r_lambda))
-			SymbolicDecomposition_Blocky(r_lambda);
-		Gather_Values(r_lambda);
+		Gather_Or_Reanalyze(r_lambda, [&]() { SymbolicDecomposition_Blocky(r_lambda); });
 		const size_t n = r_lambda.n_BlockColumn_Num(), d = r_lambda.n_BlockColumn_Column_Num(0);
 		std::vector<double> cov(n * d * d);
-		const int n_result = slampp_hip_marginals(m_p_solver, m_values.empty()? 0 : &m_values[0], &cov[0]);
+		const int n_result = slampp_hip_marginals(m_p_solver, m_p_values, &cov[0]);
 		if(n_result == SLAMPP_HIP_NOT_POSDEF)
 			return false;
 		Throw_On_Error(n_result);
@@ -466,9 +574,8 @@ public:
 	/** @brief solves, reusing the symbolic decomposition for as long as the block structure stays the same */
 	bool Solve_PosDef_Blocky(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta) // throw(std::bad_alloc, std::runtime_error)
 	{
-		if(!b_Structure_Matches(r_lambda))
-			SymbolicDecomposition_Blocky(r_lambda);
-		return Gather_And_Solve(r_lambda, r_eta);
+		Gather_Or_Reanalyze(r_lambda, [&]() { SymbolicDecomposition_Blocky(r_lambda); });
+		return Solve_Gathered(r_lambda, r_eta);
 	}
 };
 
@@ -520,9 +627,15 @@ public:
 		:CLinearSolver_HIP_Base(n_device), m_n_matrix_cut(size_t(-1)), m_sparse_fallback(n_device)
 	{}
 
-	/** @brief the reference's constructor signature (LinearSolver_Schur.h:1472): the base solver instance is unused */
+	/** @brief the reference's constructor signature (LinearSolver_Schur.h:1472): a base solver of another kind is unused */
 	inline CLinearSolver_Schur_HIP(const CBaseSolver &UNUSED(r_solver), int n_device = 0)
 		:CLinearSolver_HIP_Base(n_device), m_n_matrix_cut(size_t(-1)), m_sparse_fallback(n_device)
+	{}
+
+	/** @brief from a CLinearSolver_HIP-family base solver: its configuration (device, options) is taken over */
+	struct TConfigTag {}; /**< @brief selects the constructor below */
+	inline CLinearSolver_Schur_HIP(const CLinearSolver_HIP_Base &r_config, TConfigTag UNUSED(t_tag))
+		:CLinearSolver_HIP_Base(r_config), m_n_matrix_cut(size_t(-1)), m_sparse_fallback(r_config.n_Device())
 	{}
 
 	inline CLinearSolver_Schur_HIP(const CLinearSolver_Schur_HIP &r_other)
@@ -577,12 +690,14 @@ public:
 
 	bool Solve_PosDef_Blocky(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta) // throw(std::bad_alloc, std::runtime_error)
 	{
-		if(m_n_matrix_cut == size_t(-1) || (!b_Structure_Matches(r_lambda) &&
-		   m_n_matrix_cut != 0 && m_n_matrix_cut != r_lambda.n_BlockColumn_Num()))
-			SymbolicDecomposition_Blocky(r_lambda); // nonconforming ordering: calculate a new one (LinearSolver_Schur.h:1627-1628)
+		if(m_n_matrix_cut == size_t(-1))
+			SymbolicDecomposition_Blocky(r_lambda); // no ordering yet: calculate one (LinearSolver_Schur.h:1627-1628)
+		if(m_n_matrix_cut == 0 || m_n_matrix_cut == r_lambda.n_BlockColumn_Num())
+			return m_sparse_fallback.Solve_PosDef_Blocky(r_lambda, r_eta); // (checks its own cached structure)
+		Gather_Or_Reanalyze(r_lambda, [&]() { SymbolicDecomposition_Blocky(r_lambda); }); // nonconforming ordering: a new one
 		if(m_n_matrix_cut == 0 || m_n_matrix_cut == r_lambda.n_BlockColumn_Num())
 			return m_sparse_fallback.Solve_PosDef_Blocky(r_lambda, r_eta);
-		return Gather_And_Solve(r_lambda, r_eta);
+		return Solve_Gathered(r_lambda, r_eta);
 	}
 
 	/**
@@ -592,11 +707,13 @@ public:
 	 */
 	bool Solve_PosDef_Blocky_MarginalPoses(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta) // throw(std::bad_alloc, std::runtime_error)
 	{
-		if(m_n_matrix_cut == size_t(-1) || !b_Structure_Matches(r_lambda))
+		if(m_n_matrix_cut == size_t(-1))
 			SymbolicDecomposition_Blocky(r_lambda, true); // force guided, as the reference does
+		if(m_n_matrix_cut != 0 && m_n_matrix_cut != r_lambda.n_BlockColumn_Num())
+			Gather_Or_Reanalyze(r_lambda, [&]() { SymbolicDecomposition_Blocky(r_lambda, true); });
 		if(m_n_matrix_cut == 0 || m_n_matrix_cut == r_lambda.n_BlockColumn_Num())
 			throw std::runtime_error("CLinearSolver_Schur_HIP: no landmarks to marginalize the poses against");
-		return Gather_And_Solve(r_lambda, r_eta, true);
+		return Solve_Gathered(r_lambda, r_eta, true);
 	}
 
 	/**
@@ -618,15 +735,16 @@ public:
 	bool Schur_Marginals(CUberBlockMatrix &r_cam_cov, bool b_do_cam_marginals, CUberBlockMatrix &r_lm_cov,
 		const CUberBlockMatrix &r_lambda) // throw(std::bad_alloc, std::runtime_error)
 	{
-		if(m_n_matrix_cut == size_t(-1) || !b_Structure_Matches(r_lambda))
+		if(m_n_matrix_cut == size_t(-1))
 			SymbolicDecomposition_Blocky(r_lambda, true);
+		if(m_n_matrix_cut != 0 && m_n_matrix_cut != r_lambda.n_BlockColumn_Num())
+			Gather_Or_Reanalyze(r_lambda, [&]() { SymbolicDecomposition_Blocky(r_lambda, true); });
 		const size_t n = r_lambda.n_BlockColumn_Num(), n_cut = m_n_matrix_cut;
 		if(n_cut == 0 || n_cut == n)
 			throw std::runtime_error("CLinearSolver_Schur_HIP: no landmarks, the system has no Schur complement");
-		Gather_Values(r_lambda);
 		const size_t dc = size_t(m_cumsum[1] - m_cumsum[0]), dp = size_t(m_cumsum[n_cut + 1] - m_cumsum[n_cut]);
 		std::vector<double> cams((b_do_cam_marginals)? n_cut * dc * dc : 0), lms((n - n_cut) * dp * dp);
-		const int n_result = slampp_hip_schur_marginals(m_p_solver, m_values.empty()? 0 : &m_values[0],
+		const int n_result = slampp_hip_schur_marginals(m_p_solver, m_p_values,
 			(b_do_cam_marginals)? &cams[0] : 0, &lms[0]);
 		if(n_result == SLAMPP_HIP_NOT_POSDEF)
 			return false;
@@ -646,6 +764,49 @@ public:
 			std::copy(&lms[i * dp * dp], &lms[(i + 1) * dp * dp], p_dest);
 		}
 		return true;
+	}
+};
+
+/**
+ *	@brief CLinearSolver_Schur with CLinearSolver_HIP as its base solver *is* the GPU Schur solver
+ *
+ *	The reference's nonlinear solvers hard-wire the type of their Schur solver to
+ *	CLinearSolver_Schur<CLinearSolver, CAMatrixBlockSizes, CSystem> (NonlinearSolver_Base.h:345-346) and construct it
+ *	from the linear solver they were given (:400, :438).  This partial specialization therefore makes
+ *	CNonlinearSolver_Lambda_LM<CSystem, CLinearSolver_HIP> (BA with -us: NonlinearSolver_Lambda_LM.h:1543-1552),
+ *	CNonlinearSolver_Lambda (:526-527, :624) and the dog-leg solver run their Schur path on the GPU with not a line
+ *	of the reference changed: the reduction, the factorization of the reduced camera system and the
+ *	back-substitution all happen in libslampp_hip.so, as with CLinearSolver_Schur_HIP used directly.
+ */
+template <class CAMatrixBlockSizes, class CSystem>
+class CLinearSolver_Schur<CLinearSolver_HIP, CAMatrixBlockSizes, CSystem> :
+	public CLinearSolver_Schur_HIP<CLinearSolver_HIP, CAMatrixBlockSizes, CSystem> {
+public:
+	typedef CLinearSolver_Schur_HIP<CLinearSolver_HIP, CAMatrixBlockSizes, CSystem> _TyBase; /**< @brief the implementation */
+	typedef CBlockwiseLinearSolverTag _Tag; /**< @brief solver type tag */
+
+	// the public types of the primary template (LinearSolver_Schur.h:1426-1449); the nonlinear solvers read _TyGOH
+	// (NonlinearSolver_Lambda_LM.h:397, NonlinearSolver_Lambda_DL.h:266)
+	typedef CLinearSolver_HIP _TyBaseSolver; /**< @brief name of the base linear solver */
+	typedef typename CSystem::_TyVertexTypelist _TyVertexTypelist; /**< @brief list of vertex types */
+	typedef typename CSystem::_TyEdgeTypelist _TyEdgeTypelist; /**< @brief list of edge types */
+	typedef typename CSystem::_TyHessianMatrixBlockList _TyLambdaMatrixBlockSizes; /**< @brief possible block matrices, found in lambda and L */
+	typedef CLinearSolver_HIP::_Tag _TyBaseSolverTag; /**< @brief linear solver tag */
+	typedef schur_detail::CGuidedOrdering_Helper<_TyVertexTypelist, _TyEdgeTypelist> _TyGOH; /**< @brief guided ordering helper */
+
+	/** @brief the reference's constructor (LinearSolver_Schur.h:1472-1474); device and options of r_solver are taken over */
+	inline CLinearSolver_Schur(const CLinearSolver_HIP &r_solver)
+		:_TyBase(r_solver, typename _TyBase::TConfigTag())
+	{}
+
+	inline CLinearSolver_Schur(const CLinearSolver_Schur &r_other)
+		:_TyBase(r_other)
+	{}
+
+	inline CLinearSolver_Schur &operator =(const CLinearSolver_Schur &r_other)
+	{
+		_TyBase::operator =(r_other);
+		return *this;
 	}
 };
 

@@ -113,6 +113,20 @@ int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix
 int slampp_hip_factor_solve(slampp_hip_solver *p_solver, const double *p_values,
 	double *p_rhs_inout, slampp_hip_times *p_times);
 
+/* Pinned host staging owned by the library, for callers that have to gather Lambda's values anyway (the header class:
+ * a CUberBlockMatrix keeps its blocks in pooled pages behind per-block pointers, BlockMatrixBase.h:321,374,449-453):
+ * *pp_values receives room for the packed values, *pp_rhs for the right-hand side / solution (either may be NULL).
+ * Passing exactly these pointers to slampp_hip_factor_solve / _factorize / _marginals / _schur_marginals /
+ * _solve_marginal_poses makes the transfers single DMA copies without a staging pass; any other host array is moved
+ * through the same staging in 32 MB chunks by a few host threads while the previous chunk is on the bus.  Valid until
+ * the next slampp_hip_set_structure / _free_memory / _destroy (call again after set_structure). */
+int slampp_hip_host_staging(slampp_hip_solver *p_solver, double **pp_values, double **pp_rhs);
+
+/* Sends values [n_first, n_first + n_count) of the staging on their way (a copy stream of the library's own) while
+ * the caller is still gathering the rest: chunks must follow each other, n_first = 0 starts a new pass; the next call
+ * that takes the staged values sends what is left and waits for all of it.  Enqueue-only. */
+int slampp_hip_upload_values_async(slampp_hip_solver *p_solver, int64_t n_first, int64_t n_count);
+
 /* same with both arrays already resident in device memory (HBM); used by bench.py so that the
  * timed region excludes PCIe.  p_rhs_inout_dev is overwritten with the solution. */
 int slampp_hip_factor_solve_device(slampp_hip_solver *p_solver, const double *p_values_dev,

@@ -8,12 +8,21 @@
  *   2. the same with an SE(3) graph;
  *   3. a BA-shaped CUberBlockMatrix (from a SPPLAM01 file, optionally with cameras and landmarks
  *      interleaved so that the guided ordering has to permute) solved by the reference's
- *      CLinearSolver_Schur and by CLinearSolver_Schur_HIP.
+ *      CLinearSolver_Schur and by CLinearSolver_Schur_HIP;
+ *   4. a synthetic BA problem (the reference's CVertexCam / CVertexXYZ / CEdgeP2C3D) optimized by the
+ *      reference's CNonlinearSolver_Lambda_LM with the Schur complement on, unchanged, once with
+ *      CLinearSolver_CholMod and once with CLinearSolver_HIP as its linear solver: its m_schur_solver is
+ *      then CLinearSolver_Schur<CLinearSolver_HIP, ..> = the GPU Schur solver (NonlinearSolver_Base.h:345-346,
+ *      NonlinearSolver_Lambda_LM.h:1543-1552);
+ *   5. Factorize_PosDef_Blocky on matrices of one shape and different patterns back to back, and FastL
+ *      with a loop closure at every step (NonlinearSolver_FastL.h:2131, 2388).
  *
  * Needs a GPU at run time (there is no CPU fallback in the product); prints one JSON line and
  * returns 0 iff all comparisons are within 1e-10 (relative, infinity norm).
  *
  * usage: dropin_driver [ba_problem.bin]
+ *        dropin_driver time <problem.bin> [reps]     wall-clock of the reference's solver class and of the HIP one on
+ *                                                    the same CUberBlockMatrix, in one process (what a caller pays)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -34,6 +43,8 @@
 #include "slam/Marginals.h"
 #include "slam/BAMarginals.h"
 #include "slam/LinearSolver_HIP.h"
+#include "slam/NonlinearSolver_Lambda_LM.h"
+#include <chrono>
 
 template <class CSystemType, class CLinearSolverType>
 static std::vector<double> Optimize_SE2(size_t n_poses, unsigned n_seed, double &r_f_chi2)
@@ -138,11 +149,12 @@ public:
 // the same graph through the reference's incremental solver (-fL): it keeps the factor R itself and asks its linear
 // solver for Solve_PosDef() and Factorize_PosDef_Blocky() (NonlinearSolver_FastL.h:1724, 2131, 2388)
 template <class CSystemType, class CLinearSolverType>
-static std::vector<double> Optimize_SE3_FastL(size_t n_poses, unsigned n_seed, double &r_f_chi2, bool b_incremental)
+static std::vector<double> Optimize_SE3_FastL(size_t n_poses, unsigned n_seed, double &r_f_chi2, bool b_incremental,
+	bool b_loop_every_step = false)
 {
 	CSystemType system;
 	CNonlinearSolver_FastL<CSystemType, CLinearSolverType> solver(system, (b_incremental)?
-		TIncrementalSolveSetting(solve::Nonlinear(frequency::Every(5))) : TIncrementalSolveSetting());
+		TIncrementalSolveSetting(solve::Nonlinear(frequency::Every((b_loop_every_step)? 1 : 5))) : TIncrementalSolveSetting());
 	// incremental: a nonlinear solve each 5 vertices, as slam_online_example/Main.cpp:51 does each 1
 	Eigen::Matrix<double, 6, 6> information = Eigen::Matrix<double, 6, 6>::Identity() * 100;
 	std::mt19937_64 rng(n_seed);
@@ -158,8 +170,8 @@ static std::vector<double> Optimize_SE3_FastL(size_t n_poses, unsigned n_seed, d
 			solver.Incremental_Step(system.r_Add_Edge(CEdgePose3D(i - 1, i, z, information, system)));
 		else
 			system.r_Add_Edge(CEdgePose3D(i - 1, i, z, information, system));
-		if(i >= 30 && i % 7 == 0) { // a loop closure to an older pose (makes FastL refactorize a part of R)
-			const size_t j = i - 10 - (i % 17);
+		if((b_loop_every_step && i >= 12) || (i >= 30 && i % 7 == 0)) { // a loop closure to an older pose (makes FastL refactorize a part of R)
+			const size_t j = (b_loop_every_step)? size_t(rng() % (i - 10)) : i - 10 - (i % 17); // every step: anywhere back
 			Eigen::Matrix<double, 6, 1> z2;
 			C3DJacobians::Absolute_to_Relative(truth[j], truth[i], z2);
 			for(int d = 0; d < 6; ++ d)
@@ -179,6 +191,92 @@ static std::vector<double> Optimize_SE3_FastL(size_t n_poses, unsigned n_seed, d
 			state.push_back(v(d));
 	}
 	return state;
+}
+
+// the reference's LM solver with its iteration counter readable
+template <class CSystemType, class CLinearSolverType>
+class CLM_Exposed : public CNonlinearSolver_Lambda_LM<CSystemType, CLinearSolverType> {
+public:
+	CLM_Exposed(CSystemType &r_system, bool b_use_schur)
+		:CNonlinearSolver_Lambda_LM<CSystemType, CLinearSolverType>(r_system, TIncrementalSolveSetting(),
+		TMarginalsComputationPolicy(), false, CLinearSolverType(), b_use_schur)
+	{}
+	size_t n_Iteration_Num() const { return this->m_n_iteration_num; }
+};
+
+// A synthetic BA problem in the reference's own types: cameras on a ring looking at a cloud of points around the origin,
+// every point observed by n_obs_per_point cameras; measurements are the reference's own projection of the true scene
+// (CBAJacobians::Project_P2C) plus pixel noise, the initial state is the truth perturbed.  Optimized by the reference's
+// CNonlinearSolver_Lambda_LM with the Schur complement on (the -us path, NonlinearSolver_Lambda_LM.h:1543-1552).
+template <class CLinearSolverType>
+static std::vector<double> Optimize_BA_LM(size_t n_cams, size_t n_points, size_t n_obs_per_point, unsigned n_seed,
+	double &r_f_chi2, size_t &r_n_iterations)
+{
+	typedef MakeTypelist_Safe((CVertexCam, CVertexXYZ)) TVertexTypelist;
+	typedef MakeTypelist_Safe((CEdgeP2C3D)) TEdgeTypelist;
+	typedef CFlatSystem<CBaseVertex, TVertexTypelist, CEdgeP2C3D, TEdgeTypelist> CSystemType;
+	CSystemType system;
+	CLM_Exposed<CSystemType, CLinearSolverType> solver(system, true);
+	std::mt19937_64 rng(n_seed);
+	std::normal_distribution<double> nd(0, 1);
+	std::vector<Eigen::Matrix<double, 6, 1> > cams(n_cams);
+	Eigen::Matrix<double, 5, 1> intrinsics;
+	intrinsics << 500, 500, 320, 240, 0;
+	for(size_t c = 0; c < n_cams; ++ c) {
+		const double a = 2 * M_PI * double(c) / double(n_cams);
+		Eigen::Vector3d C(8 * cos(a), 8 * sin(a), 1.5 * sin(3 * a)); // camera centre
+		Eigen::Vector3d z = (-C).normalized(), x = Eigen::Vector3d(0, 0, 1).cross(z).normalized(), y = z.cross(x);
+		Eigen::Matrix3d R;
+		R.row(0) = x; R.row(1) = y; R.row(2) = z; // world -> camera
+		cams[c].head<3>() = -R * C;
+		cams[c].tail<3>() = C3DJacobians::v_RotMatrix_to_AxisAngle(R);
+	}
+	std::vector<Eigen::Vector3d> points(n_points);
+	for(size_t p = 0; p < n_points; ++ p)
+		points[p] = Eigen::Vector3d(1.5 * nd(rng), 1.5 * nd(rng), 1.0 * nd(rng));
+	for(size_t c = 0; c < n_cams; ++ c) { // cameras first: ids 0 .. n_cams - 1
+		Eigen::Matrix<double, 11, 1> v;
+		v.head<6>() = cams[c];
+		v.tail<5>() = intrinsics;
+		for(int d = 0; d < 3 && c > 0; ++ d) { // (camera 0 stays at the truth)
+			v(d) += 0.02 * nd(rng);
+			v(3 + d) += 0.005 * nd(rng);
+		}
+		system.template r_Get_Vertex<CVertexCam>(c, v);
+	}
+	for(size_t p = 0; p < n_points; ++ p) {
+		Eigen::Vector3d v = points[p];
+		for(int d = 0; d < 3; ++ d)
+			v(d) += 0.03 * nd(rng);
+		system.template r_Get_Vertex<CVertexXYZ>(n_cams + p, v);
+	}
+	const Eigen::Matrix2d information = Eigen::Matrix2d::Identity();
+	for(size_t p = 0; p < n_points; ++ p) {
+		const size_t c0 = rng() % n_cams;
+		for(size_t k = 0; k < n_obs_per_point; ++ k) {
+			const size_t c = (c0 + k * (n_cams / n_obs_per_point)) % n_cams; // distinct while n_obs_per_point <= n_cams
+			Eigen::Vector2d uv;
+			CBAJacobians::Project_P2C(cams[c], intrinsics, points[p], uv);
+			uv(0) += 0.3 * nd(rng);
+			uv(1) += 0.3 * nd(rng);
+			system.r_Add_Edge(CEdgeP2C3D(n_cams + p, c, uv, information, system)); // (xyz id, camera id, ...)
+		}
+	}
+	solver.Optimize(12, 1e-9);
+	r_f_chi2 = solver.f_Chi_Squared_Error_Denorm();
+	r_n_iterations = solver.n_Iteration_Num();
+	std::vector<double> state;
+	for(size_t i = 0, n = system.r_Vertex_Pool().n_Size(); i < n; ++ i) {
+		Eigen::VectorXd v = system.r_Vertex_Pool()[i].v_State();
+		for(int d = 0; d < v.rows(); ++ d)
+			state.push_back(v(d));
+	}
+	return state;
+}
+
+static double f_NowMs()
+{
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 static double f_RelInf(const std::vector<double> &a, const std::vector<double> &b)
@@ -276,8 +374,97 @@ static void Build_Lambda(const TProblem &p, bool b_interleave, CUberBlockMatrix 
 	r_lambda.Swap(lambda);
 }
 
+// dropin_driver time <problem.bin> [reps]: what a caller of the solver classes pays, reference next to HIP, on one
+// CUberBlockMatrix in one process -- cold = Solve_PosDef (ordering + analysis + solve), warm = Solve_PosDef_Blocky with
+// the cached analysis (gather of the blocks into pinned staging, PCIe, solve, solution back)
+static int Main_Time(int n_arg_num, const char **p_arg_list)
+{
+	TProblem p;
+	if(n_arg_num < 3 || !Read_Problem(p_arg_list[2], p)) {
+		fprintf(stderr, "error: can't read problem\n");
+		return 2;
+	}
+	const int n_reps = (n_arg_num > 3)? atoi(p_arg_list[3]) : 5;
+	CUberBlockMatrix lambda;
+	Eigen::VectorXd rhs;
+	std::vector<size_t> new_of_old;
+	Build_Lambda(p, false, lambda, rhs, new_of_old);
+	std::vector<double> ref_ms, hip_warm_ms;
+	double f_hip_cold_ms = 0, f_err = 0;
+	slampp_hip_times t_times;
+	memset(&t_times, 0, sizeof(t_times));
+	bool b_ok = true;
+	Eigen::VectorXd x_ref = rhs, x_hip = rhs;
+	const int n_ref_reps = (p.n_matrix_cut)? 2 : std::min(n_reps, 3);
+	if(p.n_matrix_cut) {
+		typedef CFlatSystem<CBaseVertex, MakeTypelist_Safe((CVertexCam, CVertexXYZ)),
+			CEdgeP2C3D, MakeTypelist_Safe((CEdgeP2C3D))> TBASystem;
+		typedef CLinearSolver_Schur<CLinearSolver_CholMod, TBASystem::_TyJacobianMatrixBlockList, TBASystem> TRefSchur;
+		typedef CLinearSolver_Schur<CLinearSolver_HIP, TBASystem::_TyJacobianMatrixBlockList, TBASystem> THipSchur;
+		CLinearSolver_CholMod base;
+		TRefSchur ref_solver(base);
+		for(int i = 0; i < n_ref_reps; ++ i) {
+			x_ref = rhs;
+			const double t0 = f_NowMs();
+			b_ok = ((i)? ref_solver.Solve_PosDef_Blocky(lambda, x_ref) : ref_solver.Solve_PosDef(lambda, x_ref)) && b_ok;
+			ref_ms.push_back(f_NowMs() - t0);
+		}
+		CLinearSolver_HIP hip_base;
+		THipSchur hip_solver(hip_base);
+		double t0 = f_NowMs();
+		b_ok = hip_solver.Solve_PosDef(lambda, x_hip) && b_ok;
+		f_hip_cold_ms = f_NowMs() - t0;
+		for(int i = 0; i < n_reps; ++ i) {
+			x_hip = rhs;
+			t0 = f_NowMs();
+			b_ok = hip_solver.Solve_PosDef_Blocky(lambda, x_hip) && b_ok;
+			hip_warm_ms.push_back(f_NowMs() - t0);
+		}
+		t_times = hip_solver.t_Last_Times();
+	} else {
+		CLinearSolver_CholMod ref_solver;
+		for(int i = 0; i < n_ref_reps; ++ i) {
+			x_ref = rhs;
+			const double t0 = f_NowMs();
+			b_ok = ref_solver.Solve_PosDef(lambda, x_ref) && b_ok; // (its tag is basic: the analysis re-runs on every call)
+			ref_ms.push_back(f_NowMs() - t0);
+		}
+		CLinearSolver_HIP hip_solver;
+		double t0 = f_NowMs();
+		b_ok = hip_solver.Solve_PosDef(lambda, x_hip) && b_ok;
+		f_hip_cold_ms = f_NowMs() - t0;
+		for(int i = 0; i < n_reps; ++ i) {
+			x_hip = rhs;
+			t0 = f_NowMs();
+			b_ok = hip_solver.Solve_PosDef_Blocky(lambda, x_hip) && b_ok;
+			hip_warm_ms.push_back(f_NowMs() - t0);
+		}
+		t_times = hip_solver.t_Last_Times();
+	}
+	f_err = (x_hip - x_ref).lpNorm<Eigen::Infinity>() / x_ref.lpNorm<Eigen::Infinity>();
+	std::sort(hip_warm_ms.begin(), hip_warm_ms.end());
+	printf("{\"ok\": %s, \"n_bcols\": %ld, \"n_blocks\": %ld, \"n_values\": %ld, \"rel_inf\": %.3g, \"reference\": \"%s\", "
+		"\"reference_ms\": [", b_ok? "true" : "false", (long)p.n_bcols, (long)p.n_blocks, (long)p.n_values, f_err,
+		p.n_matrix_cut? "CLinearSolver_Schur<CLinearSolver_CholMod>" : "CLinearSolver_CholMod");
+	for(size_t i = 0; i < ref_ms.size(); ++ i)
+		printf("%s%.3f", i? ", " : "", ref_ms[i]);
+	printf("], \"hip_cold_ms\": %.3f, \"hip_warm_ms_median\": %.3f, \"hip_warm_ms_min\": %.3f, \"hip_warm_last_call\": "
+		"{\"upload_wait_ms\": %.3f, \"solve_ms\": %.3f, \"download_ms\": %.3f, \"library_total_ms\": %.3f}}\n", f_hip_cold_ms,
+		hip_warm_ms[hip_warm_ms.size() / 2], hip_warm_ms[0], t_times.upload_ms,
+		(p.n_matrix_cut)? t_times.schur_ms : t_times.factor_ms, t_times.download_ms, t_times.total_ms);
+	return (b_ok && f_err < 1e-10)? 0 : 1;
+}
+
 int main(int n_arg_num, const char **p_arg_list)
 {
+	if(n_arg_num > 1 && !strcmp(p_arg_list[1], "time")) {
+		try {
+			return Main_Time(n_arg_num, p_arg_list);
+		} catch(std::exception &r_exc) {
+			fprintf(stderr, "error: %s\n", r_exc.what());
+			return 3;
+		}
+	}
 	int n_fail = 0;
 	printf("{");
 	try {
@@ -324,6 +511,88 @@ int main(int n_arg_num, const char **p_arg_list)
 					int(CLinearSolver_HIP_Counting::n_Solve_Calls()));
 				n_fail += !(f_err < 1e-9 && fabs(f_chi2_ref - f_chi2_hip) <= 1e-9 * fabs(f_chi2_ref) && n_calls > 0);
 			}
+		}
+		{ // FastL with a loop closure to a random older pose at every step and a nonlinear solve each step: R11 parts
+			// of many shapes and patterns go through Factorize_PosDef_Blocky() of one solver instance
+			typedef MakeTypelist(CVertexPose3D) TVertexTypelist;
+			typedef MakeTypelist(CEdgePose3D) TEdgeTypelist;
+			typedef CFlatSystem<CVertexPose3D, TVertexTypelist, CEdgePose3D, TEdgeTypelist> CSystemType;
+			CLinearSolver_HIP_Counting::n_Factorize_Calls() = 0;
+			CLinearSolver_HIP_Counting::n_Solve_Calls() = 0;
+			double f_chi2_ref, f_chi2_hip;
+			std::vector<double> ref = Optimize_SE3_FastL<CSystemType, CLinearSolver_CholMod>(220, 79, f_chi2_ref, true, true);
+			std::vector<double> hip = Optimize_SE3_FastL<CSystemType, CLinearSolver_HIP_Counting>(220, 79, f_chi2_hip, true, true);
+			const double f_err = f_RelInf(hip, ref);
+			printf("\"se3_fastl_loops_every_step\": {\"chi2_ref\": %.12g, \"chi2_hip\": %.12g, \"state_rel_inf\": %.3g, "
+				"\"hip_factorize_calls\": %d, \"hip_solve_calls\": %d}, ", f_chi2_ref, f_chi2_hip, f_err,
+				int(CLinearSolver_HIP_Counting::n_Factorize_Calls()), int(CLinearSolver_HIP_Counting::n_Solve_Calls()));
+			n_fail += !(f_err < 1e-9 && fabs(f_chi2_ref - f_chi2_hip) <= 1e-9 * fabs(f_chi2_ref) &&
+				CLinearSolver_HIP_Counting::n_Factorize_Calls() > 0);
+		}
+		{ // one solver instance, matrices of one shape (same number and widths of block columns, same number of blocks in
+			// every column) and different patterns, back to back, nothing announced: the cached analysis must not be reused
+			const size_t n_blocks = 80;
+			std::vector<size_t> cumsums(n_blocks);
+			for(size_t i = 0; i < n_blocks; ++ i)
+				cumsums[i] = (i + 1) * 6;
+			CLinearSolver_HIP hip_solver; // shared by all the calls below
+			double f_worst = 0, f_worst_solve = 0;
+			bool b_all_ok = true;
+			for(int n_pattern = 0; n_pattern < 4; ++ n_pattern) {
+				CUberBlockMatrix lambda(cumsums.begin(), cumsums.end(), cumsums.begin(), cumsums.end());
+				std::mt19937_64 rng(4321); // same values in the blocks that coincide
+				std::normal_distribution<double> nd(0, 1);
+				for(size_t c = 0; c < n_blocks; ++ c) {
+					// column c >= 12 holds three blocks: the diagonal, (c - 1, c), and one more whose row depends on the pattern
+					const size_t n_back = 3 + size_t(n_pattern) * 2 + (c % 3);
+					const size_t p_rows[3] = {c, (c >= 1)? c - 1 : c, (c >= 12)? c - n_back : c};
+					for(int t = 0; t < 3; ++ t) {
+						if(t && p_rows[t] == c)
+							continue;
+						Eigen::MatrixXd M(6, 6);
+						for(int i = 0; i < 36; ++ i)
+							M.data()[i] = 0.3 * nd(rng);
+						if(!t)
+							M = M * M.transpose() + Eigen::MatrixXd::Identity(6, 6) * 8.0;
+						lambda.t_GetBlock_Log(p_rows[t], c, 6, 6, true, true) += M;
+					}
+				}
+				CUberBlockMatrix R_ref, R_hip;
+				lambda.CopyLayoutTo(R_ref);
+				lambda.CopyLayoutTo(R_hip);
+				std::vector<size_t> workspace;
+				CLinearSolver_CholMod ref_solver;
+				const bool b_ref = ref_solver.Factorize_PosDef_Blocky(R_ref, lambda, workspace, 0, 0, true);
+				const bool b_hip = hip_solver.Factorize_PosDef_Blocky(R_hip, lambda, workspace, 0, 0, true);
+				Eigen::MatrixXd A, B;
+				R_ref.Convert_to_Dense(A);
+				R_hip.Convert_to_Dense(B);
+				f_worst = std::max(f_worst, (A - B).cwiseAbs().maxCoeff() / A.cwiseAbs().maxCoeff());
+				// and the cached solve path of the same instance, without Clear_SymbolicDecomposition()
+				Eigen::VectorXd x_ref = Eigen::VectorXd::LinSpaced(n_blocks * 6, -1, 1), x_hip = x_ref;
+				const bool b_ref2 = ref_solver.Solve_PosDef(lambda, x_ref);
+				const bool b_hip2 = hip_solver.Solve_PosDef_Blocky(lambda, x_hip);
+				f_worst_solve = std::max(f_worst_solve, (x_hip - x_ref).lpNorm<Eigen::Infinity>() / x_ref.lpNorm<Eigen::Infinity>());
+				b_all_ok = b_all_ok && b_ref && b_hip && b_ref2 && b_hip2;
+			}
+			printf("\"same_shape_new_pattern\": {\"ok\": %d, \"factor_rel_max\": %.3g, \"solve_rel_inf\": %.3g}, ", int(b_all_ok),
+				f_worst, f_worst_solve);
+			n_fail += !(b_all_ok && f_worst < 1e-11 && f_worst_solve < 1e-10);
+		}
+		{ // BA through the reference's LM solver with the Schur complement on: CholMod (CPU Schur solver) against HIP
+			double f_chi2_ref, f_chi2_hip;
+			size_t n_it_ref, n_it_hip;
+			CLinearSolver_HIP_Base::n_Solve_Counter() = 0;
+			std::vector<double> ref = Optimize_BA_LM<CLinearSolver_CholMod>(24, 1500, 6, 99, f_chi2_ref, n_it_ref);
+			const size_t n_hip_calls_during_ref = CLinearSolver_HIP_Base::n_Solve_Counter();
+			std::vector<double> hip = Optimize_BA_LM<CLinearSolver_HIP>(24, 1500, 6, 99, f_chi2_hip, n_it_hip);
+			const size_t n_hip_calls = CLinearSolver_HIP_Base::n_Solve_Counter();
+			const double f_err = f_RelInf(hip, ref);
+			printf("\"ba_lm_schur\": {\"chi2_ref\": %.12g, \"chi2_hip\": %.12g, \"iterations_ref\": %d, \"iterations_hip\": %d, "
+				"\"state_rel_inf\": %.3g, \"hip_schur_solves\": %d}, ", f_chi2_ref, f_chi2_hip, int(n_it_ref), int(n_it_hip), f_err,
+				int(n_hip_calls));
+			n_fail += !(f_err < 1e-8 && fabs(f_chi2_ref - f_chi2_hip) <= 1e-10 * fabs(f_chi2_ref) && n_it_ref == n_it_hip &&
+				n_hip_calls_during_ref == 0 && n_hip_calls >= n_it_hip && n_it_hip > 0);
 		}
 		{ // block diagonal of the covariance of a pose graph: the reference's recipe (NonlinearSolver_Lambda.h:696-760) next to Marginals()
 			typedef MakeTypelist_Safe((Eigen::Matrix<double, 6, 6>)) TBs;

@@ -743,6 +743,23 @@ __global__ void schur_merge_flag_kernel(const int *p_from, int *p_to)
 		atomicOr(p_to, *p_from);
 }
 
+// Landmark shards: a rank whose own landmarks gave a C_p that is not positive definite must not be the only one to
+// return false (the others would carry on into the next collective without it).  The status travels with the data:
+// that rank poisons the first entry of its partial reduced right-hand side before the exchange, and every rank looks
+// at the sum afterwards.
+__global__ void schur_flag_poison_kernel(const int *p_flag, double *p_rhs0)
+{
+	if(*p_flag)
+		*p_rhs0 = __builtin_nan("");
+}
+
+__global__ void schur_flag_check_kernel(const double *p_rhs0, int *p_flag)
+{
+	const double f = *p_rhs0;
+	if(f != f)
+		atomicOr(p_flag, 1);
+}
+
 // Decides how the reduced camera system is factored and, for the sparse choice, builds the inner solver: S becomes
 // a block matrix with one block column per camera whose structure is the block list every rank agreed on (or this
 // rank's own list on a single GPU), analyzed once by the same ordering / symbolic / scheduling code as a pose graph.
@@ -919,6 +936,8 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 
 	if(s.p_allreduce) {
 		s.Phase_Begin("allreduce");
+		double *p_rhs0 = b_sparse? p_r : p_S + n; // dense: the right-hand side is row n of S
+		hipLaunchKernelGGL(schur_flag_poison_kernel, dim3(1), dim3(1), 0, st, s.d_flag.p(), p_rhs0);
 		if(b_sparse) {
 			// the packed values and the right-hand side are one buffer, and every rank built it from the same block list
 			if(s.p_allreduce(s.p_allreduce_context, p_S, n_in_values + size_t(n), (void*)st) != 0)
@@ -937,6 +956,7 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 			hipLaunchKernelGGL(schur_pack_kernel, dim3(n_grid), dim3(64), 0, st, S.d_un_row.p(), S.d_un_col.p(), S.n_union, DC,
 				p_S, ld, n, S.d_pack.p(), 1);
 		}
+		hipLaunchKernelGGL(schur_flag_check_kernel, dim3(1), dim3(1), 0, st, p_rhs0, s.d_flag.p());
 		s.Phase_End();
 	}
 
@@ -1100,8 +1120,10 @@ static void schur_enqueue_marginals_sparse_t(slampp_hip_solver &s, CSchurState &
 	s.Phase_End();
 	if(s.p_allreduce) {
 		s.Phase_Begin("allreduce");
+		hipLaunchKernelGGL(schur_flag_poison_kernel, dim3(1), dim3(1), 0, st, s.d_flag.p(), p_r);
 		if(s.p_allreduce(s.p_allreduce_context, p_S, n_in_values + size_t(n), (void*)st) != 0)
 			throw CDeviceError("all-reduce callback failed");
+		hipLaunchKernelGGL(schur_flag_check_kernel, dim3(1), dim3(1), 0, st, p_r, s.d_flag.p());
 		s.Phase_End();
 	}
 	s.Phase_Begin("marginals_factor");
@@ -1167,8 +1189,10 @@ static void schur_enqueue_marginals_t(slampp_hip_solver &s, CSchurState &S, cons
 	s.Phase_End();
 	if(s.p_allreduce) {
 		s.Phase_Begin("allreduce");
+		hipLaunchKernelGGL(schur_flag_poison_kernel, dim3(1), dim3(1), 0, st, s.d_flag.p(), p_S + n);
 		if(s.p_allreduce(s.p_allreduce_context, p_S, size_t(ld) * ld, (void*)st) != 0)
 			throw CDeviceError("all-reduce callback failed");
+		hipLaunchKernelGGL(schur_flag_check_kernel, dim3(1), dim3(1), 0, st, p_S + n, s.d_flag.p());
 		s.Phase_End();
 	}
 	s.Phase_Begin("marginals_factor");

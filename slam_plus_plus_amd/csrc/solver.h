@@ -132,6 +132,17 @@ struct slampp_hip_solver {
 	slampp::CDevArray<int> d_flag;
 	int *p_host_flag; // pinned
 
+	// host entry points: pinned staging for Lambda's values and the right-hand side, a copy stream for the uploads
+	// (slampp_hip_host_staging / slampp_hip_upload_values_async; callers' own arrays are moved through it in chunks)
+	double *p_pin_values = 0, *p_pin_rhs = 0;
+	size_t n_pin_values = 0, n_pin_rhs = 0;
+	hipStream_t copy_stream = 0;
+	hipEvent_t copy_done = 0;
+	int64_t n_uploaded = 0; // values [0, n_uploaded) of the staging are already on their way to d_A
+	void Require_Staging();  // throws
+	void Free_Staging();
+	void Upload_Values(const double *p_values); // throws; leaves `stream` waiting for the copy
+
 	slampp::CSchurState *p_schur;
 	std::vector<slampp_hip_assembly*> assemblies; // live Lambda assemblies created from this solver
 

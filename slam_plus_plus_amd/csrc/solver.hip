@@ -5,9 +5,11 @@
 #include "sparse_inverse.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 using namespace slampp;
 
@@ -34,8 +36,166 @@ slampp_hip_solver::~slampp_hip_solver()
 		(void)hipEventDestroy(event_pool[i]);
 	if(p_host_flag)
 		(void)hipHostFree(p_host_flag);
+	Free_Staging();
+	if(copy_done)
+		(void)hipEventDestroy(copy_done);
+	if(copy_stream)
+		(void)hipStreamDestroy(copy_stream);
 	if(stream)
 		(void)hipStreamDestroy(stream);
+}
+
+void slampp_hip_solver::Free_Staging()
+{
+	if(p_pin_values)
+		(void)hipHostFree(p_pin_values);
+	if(p_pin_rhs)
+		(void)hipHostFree(p_pin_rhs);
+	p_pin_values = p_pin_rhs = 0;
+	n_pin_values = n_pin_rhs = 0;
+	n_uploaded = 0;
+}
+
+static double *Alloc_Pinned(size_t n_doubles) // throw(std::bad_alloc, CDeviceError)
+{
+	double *p = 0;
+	const hipError_t e = hipHostMalloc((void**)&p, std::max<size_t>(n_doubles, 1) * sizeof(double), hipHostMallocDefault);
+	if(e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+		(void)hipGetLastError();
+		throw std::bad_alloc();
+	}
+	if(e != hipSuccess)
+		throw CDeviceError(std::string("hipHostMalloc: ") + hipGetErrorString(e));
+	return p;
+}
+
+void slampp_hip_solver::Require_Staging()
+{
+	if(!copy_stream)
+		SLAMPP_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+	if(!copy_done)
+		SLAMPP_HIP_CHECK(hipEventCreateWithFlags(&copy_done, hipEventDisableTiming));
+	if(n_pin_values < size_t(n_values) || !p_pin_values) {
+		if(p_pin_values)
+			(void)hipHostFree(p_pin_values);
+		p_pin_values = 0;
+		n_pin_values = 0;
+		p_pin_values = Alloc_Pinned(size_t(n_values));
+		n_pin_values = size_t(n_values);
+		n_uploaded = 0;
+	}
+	if(n_pin_rhs < size_t(n_scalars) || !p_pin_rhs) {
+		if(p_pin_rhs)
+			(void)hipHostFree(p_pin_rhs);
+		p_pin_rhs = 0;
+		n_pin_rhs = 0;
+		p_pin_rhs = Alloc_Pinned(size_t(n_scalars));
+		n_pin_rhs = size_t(n_scalars);
+	}
+	d_A.Alloc(size_t(n_values));
+	d_rhs.Alloc(size_t(n_scalars));
+}
+
+// A caller's array to the device through pinned staging, in chunks: the DMA engines cannot be pointed at pageable
+// memory, and one thread's memcpy is slower than PCIe -- a few host threads copy chunk c + 1 while chunk c is on the bus.
+static void Staged_Upload(double *p_dev, double *p_pin, const double *p_src, size_t n, hipStream_t copy_stream)
+{
+	const size_t n_chunk = size_t(4) << 20; // doubles: 32 MB
+	const size_t n_chunks = (n + n_chunk - 1) / n_chunk;
+	const unsigned n_hw = std::thread::hardware_concurrency();
+	const int n_threads = (n < (size_t(1) << 19))? 1 : int(std::min<unsigned>(8, std::max<unsigned>(n_hw, 1)));
+	if(n_threads == 1) {
+		for(size_t c = 0; c < n_chunks; ++ c) {
+			const size_t b = c * n_chunk, e = std::min(n, b + n_chunk);
+			memcpy(p_pin + b, p_src + b, (e - b) * sizeof(double));
+			SLAMPP_HIP_CHECK(hipMemcpyAsync(p_dev + b, p_pin + b, (e - b) * sizeof(double), hipMemcpyHostToDevice, copy_stream));
+		}
+		return;
+	}
+	std::vector<std::atomic<int> > done(n_chunks);
+	for(size_t c = 0; c < n_chunks; ++ c)
+		done[c].store(0);
+	std::vector<std::thread> workers;
+	for(int t = 0; t < n_threads; ++ t) {
+		workers.emplace_back([=, &done]() {
+			for(size_t c = 0; c < n_chunks; ++ c) {
+				const size_t b = c * n_chunk, e = std::min(n, b + n_chunk), n_piece = (e - b + n_threads - 1) / n_threads;
+				const size_t pb = std::min(e, b + t * n_piece), pe = std::min(e, pb + n_piece);
+				if(pe > pb)
+					memcpy(p_pin + pb, p_src + pb, (pe - pb) * sizeof(double));
+				done[c].fetch_add(1, std::memory_order_release);
+			}
+		});
+	}
+	hipError_t n_err = hipSuccess;
+	for(size_t c = 0; c < n_chunks; ++ c) {
+		while(done[c].load(std::memory_order_acquire) < n_threads)
+			std::this_thread::yield();
+		const size_t b = c * n_chunk, e = std::min(n, b + n_chunk);
+		if(n_err == hipSuccess)
+			n_err = hipMemcpyAsync(p_dev + b, p_pin + b, (e - b) * sizeof(double), hipMemcpyHostToDevice, copy_stream);
+	}
+	for(std::thread &r_t : workers)
+		r_t.join();
+	SLAMPP_HIP_CHECK(n_err);
+}
+
+// the way back: DMA into the pinned staging (already enqueued and waited for by the caller), then out of it
+static void Parallel_Copy(double *p_dst, const double *p_src, size_t n)
+{
+	const unsigned n_hw = std::thread::hardware_concurrency();
+	const int n_threads = (n < (size_t(1) << 19))? 1 : int(std::min<unsigned>(8, std::max<unsigned>(n_hw, 1)));
+	if(n_threads == 1) {
+		memcpy(p_dst, p_src, n * sizeof(double));
+		return;
+	}
+	std::vector<std::thread> workers;
+	const size_t n_piece = (n + n_threads - 1) / n_threads;
+	for(int t = 0; t < n_threads; ++ t) {
+		const size_t b = std::min(n, t * n_piece), e = std::min(n, b + n_piece);
+		if(e > b)
+			workers.emplace_back([=]() { memcpy(p_dst + b, p_src + b, (e - b) * sizeof(double)); });
+	}
+	for(std::thread &r_t : workers)
+		r_t.join();
+}
+
+// Lambda's values to d_A.  From the library's own pinned staging (the header class gathers the blocks of a
+// CUberBlockMatrix straight into it, and may have sent leading chunks already): one DMA transfer of what is left.
+// From a caller's array: through the staging, see Staged_Upload().
+void slampp_hip_solver::Upload_Values(const double *p_values)
+{
+	Require_Staging();
+	const size_t n = size_t(n_values);
+	if(p_values == p_pin_values) {
+		if(size_t(n_uploaded) < n) {
+			SLAMPP_HIP_CHECK(hipMemcpyAsync(d_A.p() + n_uploaded, p_pin_values + n_uploaded, (n - size_t(n_uploaded)) * sizeof(double),
+				hipMemcpyHostToDevice, copy_stream));
+		}
+	} else
+		Staged_Upload(d_A.p(), p_pin_values, p_values, n, copy_stream);
+	n_uploaded = 0;
+}
+
+// the right-hand side to d_rhs (same two cases), then `stream` waits for everything the copy stream was given
+static void Upload_Rhs_And_Join(slampp_hip_solver &s, const double *p_rhs)
+{
+	s.Require_Staging();
+	if(p_rhs == s.p_pin_rhs) {
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_rhs.p(), s.p_pin_rhs, size_t(s.n_scalars) * sizeof(double), hipMemcpyHostToDevice,
+			s.copy_stream));
+	} else
+		Staged_Upload(s.d_rhs.p(), s.p_pin_rhs, p_rhs, size_t(s.n_scalars), s.copy_stream);
+	SLAMPP_HIP_CHECK(hipEventRecord(s.copy_done, s.copy_stream));
+	SLAMPP_HIP_CHECK(hipStreamWaitEvent(s.stream, s.copy_done, 0));
+}
+
+// the values alone (entry points without a right-hand side)
+static void Upload_Values_And_Join(slampp_hip_solver &s, const double *p_values)
+{
+	s.Upload_Values(p_values);
+	SLAMPP_HIP_CHECK(hipEventRecord(s.copy_done, s.copy_stream));
+	SLAMPP_HIP_CHECK(hipStreamWaitEvent(s.stream, s.copy_done, 0));
 }
 
 void slampp_hip_solver::Free_Device()
@@ -48,6 +208,10 @@ void slampp_hip_solver::Free_Device()
 	d_dense_gaps.Free();
 	n_dense_gaps = 0;
 	d_A.Free(); d_rhs.Free(); d_L.Free(); d_Linv.Free(); d_w.Free(); d_flag.Free();
+	d_cov.Free(); d_damp_off.Free(); d_timing.Free();
+	b_damp_valid = false;
+	dplan.p_timing = 0;
+	n_uploaded = 0;
 	if(p_sinv) {
 		sparse_inverse_destroy(p_sinv);
 		p_sinv = 0;
@@ -504,6 +668,9 @@ int slampp_hip_free_memory(slampp_hip_solver *p_solver)
 	return guarded(p_solver, [&]() -> int {
 		SLAMPP_HIP_CHECK(hipStreamSynchronize(p_solver->stream));
 		p_solver->Free_Device();
+		if(p_solver->copy_stream)
+			SLAMPP_HIP_CHECK(hipStreamSynchronize(p_solver->copy_stream));
+		p_solver->Free_Staging();
 		p_solver->plan = Plan();
 		return SLAMPP_HIP_OK;
 	});
@@ -604,6 +771,7 @@ int slampp_hip_set_structure(slampp_hip_solver *p_solver, int64_t n_bcols, const
 		s.b_analyzed = false;
 		s.b_factored = false;
 		s.b_damp_valid = false;
+		s.n_uploaded = 0;
 		return SLAMPP_HIP_OK;
 	});
 }
@@ -650,6 +818,8 @@ int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix
 		if(n_mode != SLAMPP_HIP_MODE_SPARSE && n_mode != SLAMPP_HIP_MODE_SCHUR)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "analyze: unknown mode");
 		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+		if(s.copy_stream)
+			SLAMPP_HIP_CHECK(hipStreamSynchronize(s.copy_stream));
 		s.Free_Device();
 		memset(&s.times, 0, sizeof(s.times));
 		s.n_mode = n_mode;
@@ -710,8 +880,6 @@ int slampp_hip_sync(slampp_hip_solver *p_solver)
 			}
 			SLAMPP_HIP_CHECK(hipMemset(s.d_timing.p(), 0, tm.size() * sizeof(long long)));
 		}
-		if(*s.p_host_flag & 2)
-			return fail(p_solver, SLAMPP_HIP_ERR_DEVICE, "all-reduce callback failed");
 		if(*s.p_host_flag) {
 			s.b_factored = false;
 			return fail(p_solver, SLAMPP_HIP_NOT_POSDEF, "matrix is not positive definite");
@@ -743,26 +911,29 @@ int slampp_hip_factor_solve_device(slampp_hip_solver *p_solver, const double *p_
 int slampp_hip_factor_solve(slampp_hip_solver *p_solver, const double *p_values, double *p_rhs_inout,
 	slampp_hip_times *p_times)
 {
+	const double t0 = wall_ms();
 	int n_result = guarded(p_solver, [&]() -> int {
 		slampp_hip_solver &s = *p_solver;
 		if(!s.b_analyzed)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factor_solve: analyze was not called");
 		if(!p_values || !p_rhs_inout)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factor_solve: null pointer");
-		const double t0 = wall_ms();
-		s.d_A.Alloc(size_t(s.n_values));
-		s.d_rhs.Alloc(size_t(s.n_scalars));
-		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_A.p(), p_values, size_t(s.n_values) * sizeof(double), hipMemcpyHostToDevice, s.stream));
-		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_rhs.p(), p_rhs_inout, size_t(s.n_scalars) * sizeof(double), hipMemcpyHostToDevice, s.stream));
-		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
-		s.times.upload_ms = wall_ms() - t0;
+		s.Upload_Values(p_values);
+		Upload_Rhs_And_Join(s, p_rhs_inout);
 		return SLAMPP_HIP_OK;
 	});
 	if(n_result != SLAMPP_HIP_OK)
 		return n_result;
 	slampp_hip_solver &s = *p_solver;
-	const double t1 = wall_ms();
+	const double t1 = wall_ms(); // (the last chunks may still be on the bus: the solve is enqueued behind them)
+	s.times.upload_ms = t1 - t0;
 	n_result = slampp_hip_factor_solve_device_async(p_solver, s.d_A.p(), s.d_rhs.p());
+	if(n_result == SLAMPP_HIP_OK) {
+		n_result = guarded(p_solver, [&]() -> int { // the solution comes back behind the solve, one synchronization for both
+			SLAMPP_HIP_CHECK(hipMemcpyAsync(s.p_pin_rhs, s.d_rhs.p(), size_t(s.n_scalars) * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+			return SLAMPP_HIP_OK;
+		});
+	}
 	if(n_result == SLAMPP_HIP_OK)
 		n_result = slampp_hip_sync(p_solver);
 	const double t2 = wall_ms();
@@ -770,18 +941,47 @@ int slampp_hip_factor_solve(slampp_hip_solver *p_solver, const double *p_values,
 		s.times.factor_ms = t2 - t1; // factor + both substitutions (one stream, no sync between them)
 	else
 		s.times.schur_ms = t2 - t1;
-	if(n_result == SLAMPP_HIP_OK) {
-		n_result = guarded(p_solver, [&]() -> int {
-			SLAMPP_HIP_CHECK(hipMemcpyAsync(p_rhs_inout, s.d_rhs.p(), size_t(s.n_scalars) * sizeof(double), hipMemcpyDeviceToHost, s.stream));
-			SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
-			return SLAMPP_HIP_OK;
-		});
-	}
+	if(n_result == SLAMPP_HIP_OK && p_rhs_inout != s.p_pin_rhs)
+		Parallel_Copy(p_rhs_inout, s.p_pin_rhs, size_t(s.n_scalars));
 	s.times.download_ms = wall_ms() - t2;
-	s.times.total_ms = s.times.upload_ms + (t2 - t1) + s.times.download_ms;
+	s.times.total_ms = wall_ms() - t0;
 	if(p_times)
 		*p_times = s.times;
 	return n_result;
+}
+
+int slampp_hip_host_staging(slampp_hip_solver *p_solver, double **pp_values, double **pp_rhs)
+{
+	return guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_has_structure)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "host_staging: set_structure was not called");
+		s.Require_Staging();
+		if(pp_values)
+			*pp_values = s.p_pin_values;
+		if(pp_rhs)
+			*pp_rhs = s.p_pin_rhs;
+		return SLAMPP_HIP_OK;
+	});
+}
+
+int slampp_hip_upload_values_async(slampp_hip_solver *p_solver, int64_t n_first, int64_t n_count)
+{
+	return guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.p_pin_values || !s.d_A.p())
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "upload_values: host_staging was not called");
+		if(n_first == 0)
+			s.n_uploaded = 0; // a new pass over the values (what an abandoned pass has sent is simply sent again)
+		if(n_first != s.n_uploaded || n_count < 0 || n_first + n_count > s.n_values)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "upload_values: chunks must follow each other from 0 and stay inside the values");
+		if(n_count) {
+			SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_A.p() + n_first, s.p_pin_values + n_first, size_t(n_count) * sizeof(double),
+				hipMemcpyHostToDevice, s.copy_stream));
+		}
+		s.n_uploaded = n_first + n_count;
+		return SLAMPP_HIP_OK;
+	});
 }
 
 int slampp_hip_solve_marginal_poses_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,
@@ -867,7 +1067,7 @@ int slampp_hip_marginals(slampp_hip_solver *p_solver, const double *p_values, do
 			n_out += size_t((s.cumsum[c + 1] - s.cumsum[c]) * (s.cumsum[c + 1] - s.cumsum[c]));
 		s.d_A.Alloc(size_t(s.n_values));
 		s.d_cov.Alloc(n_out);
-		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_A.p(), p_values, size_t(s.n_values) * sizeof(double), hipMemcpyHostToDevice, s.stream));
+		Upload_Values_And_Join(s, p_values);
 		return SLAMPP_HIP_OK;
 	});
 	if(n_result != SLAMPP_HIP_OK)
@@ -920,7 +1120,7 @@ int slampp_hip_schur_marginals(slampp_hip_solver *p_solver, const double *p_valu
 		n_point_doubles = size_t(np * dp * dp);
 		s.d_A.Alloc(size_t(s.n_values));
 		s.d_cov.Alloc(n_cam_doubles + n_point_doubles);
-		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_A.p(), p_values, size_t(s.n_values) * sizeof(double), hipMemcpyHostToDevice, s.stream));
+		Upload_Values_And_Join(s, p_values);
 		return SLAMPP_HIP_OK;
 	});
 	if(n_result != SLAMPP_HIP_OK)
@@ -954,8 +1154,8 @@ int slampp_hip_solve_marginal_poses(slampp_hip_solver *p_solver, const double *p
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "solve_marginal_poses: null pointer");
 		s.d_A.Alloc(size_t(s.n_values));
 		s.d_rhs.Alloc(size_t(s.n_scalars));
-		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_A.p(), p_values, size_t(s.n_values) * sizeof(double), hipMemcpyHostToDevice, s.stream));
-		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_rhs.p(), p_rhs_inout, size_t(s.n_scalars) * sizeof(double), hipMemcpyHostToDevice, s.stream));
+		s.Upload_Values(p_values);
+		Upload_Rhs_And_Join(s, p_rhs_inout);
 		return SLAMPP_HIP_OK;
 	});
 	if(n_result != SLAMPP_HIP_OK)
@@ -988,7 +1188,7 @@ int slampp_hip_factorize(slampp_hip_solver *p_solver, const double *p_values, do
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factorize: null pointer");
 		s.d_A.Alloc(size_t(s.n_values));
 		s.d_rhs.Alloc(size_t(s.n_scalars));
-		SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_A.p(), p_values, size_t(s.n_values) * sizeof(double), hipMemcpyHostToDevice, s.stream));
+		Upload_Values_And_Join(s, p_values);
 		SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_rhs.p(), 0, size_t(s.n_scalars) * sizeof(double), s.stream)); // the fused forward substitution runs on zeros
 		s.Enqueue_Sparse(s.d_A.p(), s.d_rhs.p(), true, true);
 		s.b_factored = true;

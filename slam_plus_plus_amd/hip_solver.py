@@ -80,6 +80,8 @@ ABI = {
     "slampp_hip_analyze": (C.c_int, [_P, C.c_int, C.c_int64]),
     "slampp_hip_factor_solve": (C.c_int, [_P, _P, _P, C.POINTER(Times)]),
     "slampp_hip_factor_solve_device": (C.c_int, [_P, _P, _P, C.POINTER(Times)]),
+    "slampp_hip_host_staging": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
+    "slampp_hip_upload_values_async": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "slampp_hip_solve_again": (C.c_int, [_P, _P]),
     "slampp_hip_factorize": (C.c_int, [_P, _P, _P]),
     "slampp_hip_solve_marginal_poses": (C.c_int, [_P, _P, _P]),
@@ -262,6 +264,7 @@ class _SolverBase:
         self._check(self._lib.slampp_hip_set_structure(self._h, lam.n_bcols, _ptr(cs), _ptr(bp), _ptr(br)))
         self._check(self._lib.slampp_hip_analyze(self._h, self._mode, self._n_matrix_cut(lam)))
         self._structure_key = self._key(lam)
+        self._n_values = int(lam.values.shape[0])
         self._analyzed = True
         return True
 
@@ -273,6 +276,8 @@ class _SolverBase:
         if not self._analyzed or self._structure_key != self._key(lam):
             self.SymbolicDecomposition_Blocky(lam)
         vals = np.ascontiguousarray(lam.values, dtype=np.float64)
+        if vals.shape != (self._n_values,):
+            raise ValueError("lam.values does not match the block structure")
         return self._check(self._lib.slampp_hip_factor_solve(self._h, _ptr(vals), _ptr(eta), C.byref(self.times)))
 
     def Solve_PosDef(self, lam, eta: np.ndarray) -> bool:
@@ -281,7 +286,26 @@ class _SolverBase:
         return self.Solve_PosDef_Blocky(lam, eta)
 
     def Solve_Again(self, eta: np.ndarray) -> bool:
+        """Another right-hand side with the factor the last solve left behind (cholmod_solve on a kept factor,
+        LinearSolver_CholMod.cpp:322-347)."""
+        if self._structure_key is None or not self._analyzed:
+            raise ValueError("Solve_Again: there is no factorization")
+        n_scalars = self._structure_key[2]
+        if eta.dtype != np.float64 or not eta.flags.c_contiguous or eta.shape != (n_scalars,):
+            raise ValueError("eta must be a contiguous float64 vector of the system's dimension")
         return self._check(self._lib.slampp_hip_solve_again(self._h, _ptr(eta)))
+
+    def host_staging(self):
+        """(values, rhs): numpy views of the library's pinned staging for the current structure -- filling these and
+        passing them to Solve_PosDef_Blocky spares the transfers a staging pass (slampp_hip_host_staging)."""
+        pv, pr = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.slampp_hip_host_staging(self._h, C.byref(pv), C.byref(pr)))
+        st = Stats()
+        self._check(self._lib.slampp_hip_get_stats(self._h, C.byref(st)))
+        n_values = int(self._n_values)
+        values = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_double)), shape=(n_values,))
+        rhs = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_double)), shape=(int(st.n_scalars),))
+        return values, rhs
 
     def factorize(self, lam):
         """Numeric factor only (sparse mode, no dense top): ``(ok, plan, l_values)`` -- the lower factor of the permuted

@@ -107,6 +107,18 @@ class BlockSystem:
 # pose graphs (uniform d x d blocks)
 # --------------------------------------------------------------------------------------
 
+def _segment_sum(idx: np.ndarray, blocks: np.ndarray, n: int) -> np.ndarray:
+    """out[idx[e]] += blocks[e], summed in the order of e (what np.add.at does, element by element with bincount)."""
+    out = np.zeros((n,) + blocks.shape[1:])
+    if blocks.shape[0] == 0:
+        return out
+    flat_in = blocks.reshape(blocks.shape[0], -1)
+    flat_out = out.reshape(n, -1)
+    for c in range(flat_in.shape[1]):
+        flat_out[:, c] = np.bincount(idx, weights=flat_in[:, c], minlength=n)
+    return out
+
+
 def _assemble_pose_graph(n: int, d: int, ei: np.ndarray, ej: np.ndarray, rng, sigma: float,
                          prior: float, name: str) -> BlockSystem:
     """Lambda = sum over edges [Ja Jb]^T [Ja Jb] + prior*I on pose 0, eta ~ N(0,1).
@@ -126,9 +138,7 @@ def _assemble_pose_graph(n: int, d: int, ei: np.ndarray, ej: np.ndarray, rng, si
     Hii = np.einsum("eki,ekj->eij", Ja, Ja)
     Hij = np.einsum("eki,ekj->eij", Ja, Jb)
     Hjj = np.einsum("eki,ekj->eij", Jb, Jb)
-    diag = np.zeros((n, d, d))
-    np.add.at(diag, ei, Hii)
-    np.add.at(diag, ej, Hjj)
+    diag = _segment_sum(np.concatenate([ei, ej]), np.concatenate([Hii, Hjj]), n)
     diag[0] += prior * eye
     # block-CSC: column j holds its off-diagonal blocks (rows i < j, sorted) then the diagonal block
     order = np.lexsort((ei, ej))
@@ -252,10 +262,8 @@ def ba(n_cams: int = 1000, n_pts: int = 500_000, k: int = 4, mode: str = "band",
     cd, pd_ = cam_dim, pt_dim
     Jc = rng.standard_normal((n_obs, 2, cd))
     Jp = rng.standard_normal((n_obs, 2, pd_))
-    Acc = np.zeros((n_cams, cd, cd))
-    np.add.at(Acc, cam_of, np.einsum("oki,okj->oij", Jc, Jc))
-    Cpp = np.zeros((n_pts, pd_, pd_))
-    np.add.at(Cpp, pt_of, np.einsum("oki,okj->oij", Jp, Jp))
+    Acc = _segment_sum(cam_of, np.einsum("oki,okj->oij", Jc, Jc), n_cams)
+    Cpp = _segment_sum(pt_of, np.einsum("oki,okj->oij", Jp, Jp), n_pts)
     Ucp = np.einsum("oki,okj->oij", Jc, Jp)                 # [n_obs, 6, 3]
     Acc += (damping if cam_damping is None else cam_damping) * np.eye(cd)[None]
     Cpp += damping * np.eye(pd_)[None]
@@ -287,10 +295,11 @@ def ba(n_cams: int = 1000, n_pts: int = 500_000, k: int = 4, mode: str = "band",
     np.cumsum(sz, out=off[1:])
     vals = np.empty(int(off[-1]))
     vals[:n_cams * cd * cd] = Acc.transpose(0, 2, 1).ravel()
-    vals[(off[diag_pos][:, None] + np.arange(pd_ * pd_)[None, :]).ravel()] = \
-        Cpp.transpose(0, 2, 1).ravel()
-    vals[(off[off_pos][:, None] + np.arange(cd * pd_)[None, :]).ravel()] = \
-        U_s.transpose(0, 2, 1).ravel()
+    for c in range(pd_):            # element (r, c) of a block sits at c * rows + r (column-major)
+        for r in range(pd_):
+            vals[off[diag_pos] + (c * pd_ + r)] = Cpp[:, r, c]
+        for r in range(cd):
+            vals[off[off_pos] + (c * cd + r)] = U_s[:, r, c]
     cumsum = np.concatenate([np.arange(n_cams + 1, dtype=np.int64) * cd,
                              n_cams * cd + np.arange(1, n_pts + 1, dtype=np.int64) * pd_])
     rhs = rng.standard_normal(int(cumsum[-1]))

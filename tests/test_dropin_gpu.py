@@ -43,3 +43,30 @@ def test_reference_nonlinear_solver_with_hip_linear_solver(tmp_path):
         assert r[k]["ok_ref"] == 1 and r[k]["ok_hip"] == 1 and r[k]["cam_rel_inf"] < 1e-10 and r[k]["lm_rel_inf"] < 1e-10, (k, r[k])
     for k in ("marginal_poses_cams_first", "marginal_poses_interleaved"):
         assert r[k]["ok_ref"] == 1 and r[k]["ok_hip"] == 1 and r[k]["rel_inf"] < 1e-10
+    # FastL with a loop closure at every step: many Factorize_PosDef_Blocky calls of different shapes on one instance
+    k = r["se3_fastl_loops_every_step"]
+    assert k["state_rel_inf"] < 1e-9 and k["hip_factorize_calls"] > 100, k
+    # matrices of one shape and different patterns back to back on one instance (NonlinearSolver_FastL.h:2131, 2388):
+    # the cached analysis must not be reused
+    k = r["same_shape_new_pattern"]
+    assert k["ok"] == 1 and k["factor_rel_max"] < 1e-11 and k["solve_rel_inf"] < 1e-10, k
+    # BA through the reference's CNonlinearSolver_Lambda_LM with the Schur complement on: its m_schur_solver is
+    # CLinearSolver_Schur<CLinearSolver_HIP, ..> = the GPU solver (NonlinearSolver_Base.h:345-346), nothing patched
+    k = r["ba_lm_schur"]
+    assert k["iterations_ref"] == k["iterations_hip"] > 0 and k["hip_schur_solves"] >= k["iterations_hip"], k
+    assert abs(k["chi2_ref"] - k["chi2_hip"]) <= 1e-10 * abs(k["chi2_ref"]) and k["state_rel_inf"] < 1e-8, k
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/dropin_driver was not prebuilt")
+@pytest.mark.parametrize("kind", ["pose", "ba"])
+def test_timing_mode_agrees_with_the_reference(tmp_path, kind):
+    """`dropin_driver time`: the reference's solver class and the HIP one on one CUberBlockMatrix (gather into pinned
+    staging in chunks, uploads overlapped, solution back) -- here only that both give the same answer."""
+    lam = synth.pose_chain(n=5000) if kind == "pose" else synth.ba(100, 20000, mode="venice", seed=5)
+    p = tmp_path / "p.bin"
+    lam.save(str(p))
+    out = subprocess.run([DRIVER, "time", str(p), "3"], capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert line, out.stdout + out.stderr
+    r = json.loads(line[-1])
+    assert out.returncode == 0 and r["ok"] and r["rel_inf"] < 1e-10, r
