@@ -105,24 +105,84 @@ def per_kernel_bytes_sparse(plan, n_bottom_stages=1):
             "stage0_cols": int(stage0.sum())}
 
 
-def cpu_baseline_c3(lam, counts, budget_reps=12):
+def cpu_baseline_c3(lam, counts, x_gpu, budget_reps=12):
+    """The compiled reference on this box's host, on the same system: (a) what its nonlinear solver pays per iteration
+    with CLinearSolver_CholMod -- Solve_PosDef, whose tag is "basic": conversion, ordering and symbolic analysis re-run on
+    every call (LinearSolver_CholMod.h:86-94) -- is `value`; (b) the numeric phases alone (cholmod_factorize +
+    cholmod_solve, the like-for-like of the GPU's warm step) and (c) its fastest solver with a cached analysis, the native
+    block Cholesky (CLinearSolver_UberBlock::Solve_PosDef_Blocky, second call) are reported beside it.  Also returns the
+    rel-inf distance of the GPU's solution from the reference's."""
     from oracle import oracle_lib as O
     with tempfile.TemporaryDirectory() as td:
         if O.have_reference():
-            path = os.path.join(td, "c3.bin")
+            path, xp = os.path.join(td, "c3.bin"), os.path.join(td, "x.bin")
             lam.save(path)
             t0 = time.perf_counter()
-            r = O.reference_solve(path, "cholmod_auto", "-", reps=budget_reps)
+            r = O.reference_solve(path, "cholmod_auto", xp, reps=budget_reps)
             wall = time.perf_counter() - t0
             ms = float(np.median(r["times_ms"]))
-            return {"value": counts["flops"] / (ms * 1e-3) / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "reference",
-                    "ms_per_solve": ms, "sample": f"{budget_reps} x CLinearSolver_CholMod(CHOLMOD_AUTO, AMD)::Solve_PosDef "
-                    f"on the same 100k-pose system (median; {wall:.1f} s of CPU incl. load); Cholesky/solves are serial in the reference"}
+            x_ref = np.fromfile(xp, dtype=np.float64)
+            out = {"value": counts["flops"] / (ms * 1e-3) / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "reference",
+                   "ms_per_solve": ms, "sample": f"{budget_reps} x CLinearSolver_CholMod(CHOLMOD_AUTO, AMD)::Solve_PosDef "
+                   f"on the same 100k-pose system (median; {wall:.1f} s of CPU incl. load); Cholesky/solves are serial in the reference",
+                   "x_gpu_vs_reference_rel_inf": float(np.abs(x_gpu - x_ref).max() / np.abs(x_ref).max())}
+            try:
+                ph = subprocess.run([O.REF_HARNESS, "cholmod_phases", path, "auto", "3"], capture_output=True, text=True, timeout=300)
+                reps = json.loads([l for l in ph.stdout.splitlines() if l.startswith("{")][-1])["reps"]
+                med = {k: float(np.median([q[k] for q in reps])) for k in ("convert_ms", "analyze_ms", "factorize_ms", "solve_ms")}
+                out["cholmod_phases_ms"] = med
+                out["numeric_only_ms"] = med["factorize_ms"] + med["solve_ms"]
+                ub = O.reference_solve(path, "uberblock", "-", reps=3)
+                out["native_block_solver_ms"] = {"first_call": float(ub["times_ms"][0]), "warm": float(min(ub["times_ms"][1:]))}
+            except Exception as e:      # the headline baseline stands without the split
+                out["phases_error"] = str(e)[:200]
+            return out
     t0 = time.perf_counter()
     ok, _, _ = O.solve_sparse(lam)
     ms = (time.perf_counter() - t0) * 1e3
     return {"value": counts["flops"] / (ms * 1e-3) / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
             "ms_per_solve": ms, "sample": "1 x oracle/slampp_oracle.c up-looking block Cholesky, natural order"}
+
+
+def host_path_leg(make_solver, lam, reps=5):
+    """What a caller with *host* arrays pays (cold = ordering + symbolic + upload + factor +
+    solve + download, warm = the same with the analysis cached), through slampp_hip_factor_solve: the values move
+    through the library's pinned staging in chunks, a few host threads ahead of the DMA engine.  PCIe-inclusive: never
+    the headline `value`."""
+    solver = make_solver()
+    eta = lam.rhs.copy()
+    t0 = time.perf_counter()
+    ok = solver.Solve_PosDef(lam, eta)
+    cold = (time.perf_counter() - t0) * 1e3
+    warm, last = [], None
+    for _ in range(reps):
+        eta = lam.rhs.copy()
+        t0 = time.perf_counter()
+        ok = solver.Solve_PosDef_Blocky(lam, eta) and ok
+        warm.append((time.perf_counter() - t0) * 1e3)
+        last = solver.times.as_dict()
+    return {"ok": bool(ok), "cold_ms": cold, "warm_host_ms": float(np.median(warm)), "warm_host_ms_min": float(min(warm)),
+            "bytes_up": int(8 * (lam.values.shape[0] + lam.n_scalars)), "bytes_down": int(8 * lam.n_scalars),
+            "last_call_ms": {k: last[k] for k in ("upload_ms", "factor_ms", "schur_ms", "download_ms", "total_ms")}}
+
+
+def dropin_leg(lam, reps=5):
+    """The C++ boundary itself: oracle/_ref/dropin_driver (the reference's headers + include/slam/LinearSolver_HIP.h, built in
+    the build container) builds the system as a CUberBlockMatrix and times the reference's solver class and the HIP one in
+    one process: gather of the pooled blocks into pinned staging (OpenMP, chunked, overlapped with the uploads) + solve +
+    solution back."""
+    drv = os.path.join(ROOT, "oracle", "_ref", "dropin_driver")
+    if not os.path.exists(drv):
+        return None
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "p.bin")
+        lam.save(path)
+        try:
+            r = subprocess.run([drv, "time", path, str(reps)], capture_output=True, text=True, timeout=900)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            return json.loads(line[-1]) if line else {"error": (r.stdout + r.stderr)[-300:]}
+        except Exception as e:
+            return {"error": str(e)[:200]}
 
 
 def run_c3(args, rank, world, local_rank, dist):
@@ -207,6 +267,7 @@ def run_c3(args, rank, world, local_rank, dist):
         "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS,
                      "traffic": dom["hbm_traffic_bytes_per_launch"], "traffic_source": traffic_file,
+                     "traffic_measured_in": "builder's rocprofv3 --pmc run of this command (replayed from the committed file, not measured in this run)",
                      "avg_launch_us": dom["avg_launch_us"], "launches_per_step": dom["launches_per_step"],
                      "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
         "kernels": kernels,
@@ -214,8 +275,12 @@ def run_c3(args, rank, world, local_rank, dist):
     out["assembly"] = assembly_leg(solver, lam, dev)
     if world == 1:
         out["marginals"] = marginals_leg_c3(args, solver, lam, vals, dev, torch)
+    if world == 1:
+        out["host_path"] = host_path_leg(lambda: CLinearSolver_HIP(device=local_rank), lam)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_c3(lam, counts)
+        out["cpu_baseline"] = cpu_baseline_c3(lam, counts, x)
+        out["solve_x_vs_reference_rel_inf"] = out["cpu_baseline"].get("x_gpu_vs_reference_rel_inf")
+        out["dropin_cpp"] = dropin_leg(lam)
     return out
 
 
@@ -365,19 +430,21 @@ def make_allreduce(dist, torch, dev):
     return fn
 
 
-def cpu_baseline_ba(lam, flops):
+def cpu_baseline_ba(lam, flops, x_gpu):
     from oracle import oracle_lib as O
     if not O.have_reference():
         return None
     with tempfile.TemporaryDirectory() as td:
-        path = os.path.join(td, "ba.bin")
+        path, xp = os.path.join(td, "ba.bin"), os.path.join(td, "x.bin")
         lam.save(path)
         t0 = time.perf_counter()
-        r = O.reference_solve(path, "schur", "-", reps=2, timeout=900)
+        r = O.reference_solve(path, "schur", xp, reps=2, timeout=900)
         wall = time.perf_counter() - t0
+        x_ref = np.fromfile(xp, dtype=np.float64)
     ms = float(r["times_ms"][-1])
     return {"value": flops / (ms * 1e-3) / 1e9, "unit": "GFLOP/s", "cores": os.cpu_count(), "kind": "reference",
             "ms_per_solve": ms, "ms_first_call": float(r["times_ms"][0]),
+            "x_gpu_vs_reference_rel_inf": float(np.abs(x_gpu - x_ref).max() / np.abs(x_ref).max()),
             "sample": f"2 x CLinearSolver_Schur<CholMod>::Solve_PosDef[_Blocky] on the same system (second call, ordering reused; "
                       f"{wall:.1f} s of CPU incl. load); OpenMP only in the block-diagonal inverse and one SpMV, dense LLT serial"}
 
@@ -467,7 +534,7 @@ def dataclasses_replace_points(lam, n_keep):
                        lam.values[:off[nb]].copy(), lam.rhs[:int(lam.cumsum[n])].copy(), nc)
 
 
-def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1):
+def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", extras=True):
     """C4 (N=1) / landmark-sharded weak scaling (N>1): `--ba-cams` cameras, `--ba-points` points per GPU.
     schur_sparse: -1 = the library decides how to factor the reduced camera system (sparse block path when under 3 %
     of its blocks are nonzero, as with this workload's band visibility), 0 = force the dense MFMA factorization."""
@@ -477,7 +544,7 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1):
 
     dev = torch.device(f"cuda:{local_rank}")
     k = 4
-    lam = synth.ba(args.ba_cams, args.ba_points, k=k, mode="band", seed=777 + rank, cam_damping=0.1 / world)
+    lam = synth.ba(args.ba_cams, args.ba_points, k=k, mode=mode, seed=777 + rank, cam_damping=0.1 / world)
     solver = CLinearSolver_Schur_HIP(device=local_rank, schur_sparse=schur_sparse)
     t0 = time.perf_counter()
     solver.SymbolicDecomposition_Blocky(lam)
@@ -529,12 +596,12 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1):
     flops = schur_flops * world + (dense_flops if b_dense else 0.0)
     out = {
         "workload": f"{'C4' if world == 1 else 'landmark-sharded'}: BA {args.ba_cams} cams x {args.ba_points * world} points "
-                    f"({args.ba_points}/GPU), {k} obs/point, band visibility; Schur complement + "
+                    f"({args.ba_points}/GPU), {'2..30 (mean 5.3)' if mode == 'venice' else k} obs/point, {mode} visibility; Schur complement + "
                     f"{'dense (MFMA)' if b_dense else 'sparse block'} factorization of the reduced system, per step",
         "reduced_system": "dense" if b_dense else "sparse",
         "ms_per_step": ms, "points_per_s": n_pts * world / (dt / steps), "GFLOP/s": flops / (dt / steps) / 1e9,
         "n_gpus": world, "steps": steps, "schur_dim": N, "n_observations_per_gpu": n_obs, "analyze_ms_cold": analyze_ms,
-        "phases_ms": prof,
+        "phases_ms": prof, "n_camera_pair_blocks": st["l_blocks"], "n_contributions": st["n_update_pairs"],
     }
     traffic, traffic_file = load_traffic("ba")
     if "dense_chol" in prof:
@@ -553,16 +620,25 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1):
         gb = (288.0 * st["n_update_pairs"] + 2 * 8.0 * 36 * st["l_blocks"]) / (prof["schur_gather"] * 1e-3) / 1e9
         out["roofline_schur_gather"] = {"bound": "hbm", "kernel": "schur_gather_S_kernel", "achieved": gb, "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
-                                        "traffic": kernel_traffic(traffic, "schur_gather_S_kernel"), "traffic_source": traffic_file,
+                                        "traffic": kernel_traffic(traffic, "schur_gather_S_kernel") if mode == "band" else None,
+                                        "traffic_source": traffic_file if mode == "band" else None,
+                                        "traffic_measured_in": "builder's rocprofv3 --pmc run (replayed from the committed file)",
                                         "ms_per_launch": prof["schur_gather"]}
         if not b_dense:   # then the gather is the dominant kernel of the step
             out["roofline"] = out["roofline_schur_gather"]
     if world == 1:
         x = bufs[-1].cpu().numpy()
         out["solve_residual_rel_inf"] = float(np.abs(lam.to_scipy() @ x - lam.rhs).max() / np.abs(lam.rhs).max())
-        if not args.no_cpu_baseline and schur_sparse != 0:
-            out["cpu_baseline"] = cpu_baseline_ba(lam, schur_flops + dense_flops)   # the reference factors S densely
-        if schur_sparse != 0:
+        if not args.no_cpu_baseline and schur_sparse != 0 and extras:
+            # the reference factors S densely whatever its structure: n^3/3 for it even where the GPU path counts none
+            n3 = float(N) ** 3 / 3.0
+            out["cpu_baseline"] = cpu_baseline_ba(lam, schur_flops + (dense_flops if b_dense else n3), x)
+            out["solve_x_vs_reference_rel_inf"] = out["cpu_baseline"]["x_gpu_vs_reference_rel_inf"] if out["cpu_baseline"] else None
+        if extras and schur_sparse != 0:
+            out["host_path"] = host_path_leg(lambda: CLinearSolver_Schur_HIP(device=local_rank), lam, reps=3)
+            if not args.no_cpu_baseline:
+                out["dropin_cpp"] = dropin_leg(lam, reps=3)
+        if extras and schur_sparse != 0:
             out["marginals"] = marginals_leg(args, solver, lam, vals, dev, torch)
             # Lambda of the same structure assembled on the device from 2-d projection residuals (one edge per observation)
             out["assembly"] = assembly_leg(solver, lam, dev, reps=5, rd=2, column_vertex_first=True)
@@ -624,10 +700,14 @@ def main():
             out["ba_schur"] = ba
         if world == 1 and args.workload == "all":
             out["other_configs"] = run_small_configs(args, local_rank)
-        if world == 1:   # the same system with the reduced camera system forced through the dense MFMA factorization
-            ba_dense = run_ba(args, rank, world, local_rank, dist, schur_sparse=0)
-            if rank == 0:
-                out["ba_schur_dense_S"] = ba_dense
+        if world == 1:
+            # SURVEY.md section 8d, "band (sparse S) or uniformly (dense S -- report both)": uniform visibility makes every
+            # camera pair a block of S (500 k short contribution lists, the dense MFMA factorization); the Venice-like
+            # mode has ragged lists (2..30 observations per landmark)
+            for key, mode in (("ba_schur_uniform_dense_S", "uniform"), ("ba_schur_venice", "venice")):
+                leg = run_ba(args, rank, world, local_rank, dist, mode=mode, extras=False)
+                if rank == 0:
+                    out[key] = leg
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0 and out is not None:
