@@ -46,6 +46,11 @@ F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (vendor figure quoted in 
 C3_REF = {"n": 600_000, "nnz_triu": 7_271_928, "lnz": 8_360_436, "fl": 122_411_332.0}
 
 
+def host_cores():
+    from oracle import oracle_lib as O
+    return O.host_cores()
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -127,7 +132,8 @@ def cpu_baseline_c3(lam, counts, x_gpu, budget_reps=12):
                    f"on the same 100k-pose system (median; {wall:.1f} s of CPU incl. load); Cholesky/solves are serial in the reference",
                    "x_gpu_vs_reference_rel_inf": float(np.abs(x_gpu - x_ref).max() / np.abs(x_ref).max())}
             try:
-                ph = subprocess.run([O.REF_HARNESS, "cholmod_phases", path, "auto", "3"], capture_output=True, text=True, timeout=300)
+                ph = subprocess.run([O.REF_HARNESS, "cholmod_phases", path, "auto", "3"], capture_output=True, text=True, timeout=300,
+                                    env=O.reference_env())
                 reps = json.loads([l for l in ph.stdout.splitlines() if l.startswith("{")][-1])["reps"]
                 med = {k: float(np.median([q[k] for q in reps])) for k in ("convert_ms", "analyze_ms", "factorize_ms", "solve_ms")}
                 out["cholmod_phases_ms"] = med
@@ -178,7 +184,8 @@ def dropin_leg(lam, reps=5):
         path = os.path.join(td, "p.bin")
         lam.save(path)
         try:
-            r = subprocess.run([drv, "time", path, str(reps)], capture_output=True, text=True, timeout=900)
+            from oracle import oracle_lib as O
+            r = subprocess.run([drv, "time", path, str(reps)], capture_output=True, text=True, timeout=900, env=O.reference_env())
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             return json.loads(line[-1]) if line else {"error": (r.stdout + r.stderr)[-300:]}
         except Exception as e:
@@ -322,7 +329,7 @@ def marginals_leg_c3(args, solver, lam, vals, dev, torch):
                 lam.save(path)
                 t0 = time.perf_counter()
                 r = subprocess.run([O.REF_HARNESS, "sparse_marginals", path, os.path.join(td, "m")], capture_output=True, text=True,
-                                   timeout=900)
+                                   timeout=900, env=O.reference_env())
                 wall = time.perf_counter() - t0
             if '"ok": true' in r.stdout:
                 out["cpu_baseline"] = {"value": wall * 1e3, "unit": "ms", "cores": 1, "kind": "reference",
@@ -442,7 +449,7 @@ def cpu_baseline_ba(lam, flops, x_gpu):
         wall = time.perf_counter() - t0
         x_ref = np.fromfile(xp, dtype=np.float64)
     ms = float(r["times_ms"][-1])
-    return {"value": flops / (ms * 1e-3) / 1e9, "unit": "GFLOP/s", "cores": os.cpu_count(), "kind": "reference",
+    return {"value": flops / (ms * 1e-3) / 1e9, "unit": "GFLOP/s", "cores": host_cores(), "kind": "reference",
             "ms_per_solve": ms, "ms_first_call": float(r["times_ms"][0]),
             "x_gpu_vs_reference_rel_inf": float(np.abs(x_gpu - x_ref).max() / np.abs(x_ref).max()),
             "sample": f"2 x CLinearSolver_Schur<CholMod>::Solve_PosDef[_Blocky] on the same system (second call, ordering reused; "
@@ -513,10 +520,10 @@ def marginals_leg(args, solver, lam, vals, dev, torch):
                 sample.save(path)
                 t0 = time.perf_counter()
                 r = subprocess.run([O.REF_HARNESS, "schur_marginals", path, os.path.join(td, "m")], capture_output=True, text=True,
-                                   timeout=900)
+                                   timeout=900, env=O.reference_env())
                 wall = time.perf_counter() - t0
             if '"ok": true' in r.stdout:
-                out["cpu_baseline"] = {"value": wall * 1e3, "unit": "ms", "cores": os.cpu_count(), "kind": "reference",
+                out["cpu_baseline"] = {"value": wall * 1e3, "unit": "ms", "cores": host_cores(), "kind": "reference",
                                        "sample": f"CSchurComplement_Marginals::Schur_Marginals on the first "
                                                  f"{sample.n_bcols - nc} landmarks of the same system (all {nc} cameras), with the "
                                                  f"Schur complement and its Cholesky factor it needs, incl. load; OpenMP"}

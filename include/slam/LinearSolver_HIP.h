@@ -37,6 +37,9 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif // _OPENMP
 
 #include "slam/LinearSolverTags.h"
 #include "slam/BlockMatrix.h"
@@ -61,6 +64,21 @@ protected:
 	double *m_p_values, *m_p_rhs; /**< @brief pinned staging owned by the library (slampp_hip_host_staging) */
 	size_t m_n_value_num; /**< @brief number of packed values of lambda */
 	slampp_hip_times m_t_times;
+
+	/**
+	 *	@brief number of threads for the gather / copy loops: copying is memory-bound well before all cores of a big host
+	 *		are busy, and a container with a CPU quota below its visible core count (16 of 256 on the boxes this was
+	 *		measured on) spends 0.8 s per parallel region with one spinning thread per visible core
+	 */
+	static int n_Copy_Thread_Num()
+	{
+#ifdef _OPENMP
+		const int n_max = omp_get_max_threads();
+		return (n_max < 16)? n_max : 16;
+#else // _OPENMP
+		return 1;
+#endif // _OPENMP
+	}
 
 	void Throw_On_Error(int n_result) const // throw(std::bad_alloc, std::runtime_error)
 	{
@@ -202,6 +220,7 @@ protected:
 	bool Gather_Values(const CUberBlockMatrix &r_lambda) // throw(std::bad_alloc, std::runtime_error)
 	{
 		const long n_block_num = long(m_gather.size());
+		const int n_thread_num = n_Copy_Thread_Num();
 		double *p_values = m_p_values;
 		const int64_t n_chunk_values = int64_t(2) << 20; // 16 MB: chunk k is on the bus while chunk k + 1 is gathered
 		long n_first = 0;
@@ -223,7 +242,7 @@ protected:
 				n_last = n_lo;
 			}
 			int n_mismatch = 0;
-			#pragma omp parallel for schedule(static) reduction(+:n_mismatch) if(n_last - n_first > 512)
+			#pragma omp parallel for schedule(static) reduction(+:n_mismatch) num_threads(n_thread_num) if(n_last - n_first > 512)
 			for(long k = n_first; k < n_last; ++ k) {
 				const TGatherEntry &t = m_gather[k];
 				if(r_lambda.n_Block_Row(t.n_col, t.n_blk) != t.n_row) {
@@ -279,15 +298,16 @@ protected:
 		if(size_t(n_scalar_num) != size_t(m_cumsum.back()))
 			throw std::runtime_error("CLinearSolver_HIP: the right-hand side does not match lambda");
 		const double *p_eta = &r_eta(0);
+		const int n_thread_num = n_Copy_Thread_Num();
 		if(!m_order.empty()) {
-			#pragma omp parallel for schedule(static) if(n > 4096)
+			#pragma omp parallel for schedule(static) num_threads(n_thread_num) if(n > 4096)
 			for(long i = 0; i < n; ++ i) {
 				const size_t n_src = r_lambda.n_BlockColumn_Base(m_order[i]);
 				for(int64_t d = 0, w = m_cumsum[i + 1] - m_cumsum[i]; d < w; ++ d)
 					m_p_rhs[size_t(m_cumsum[i] + d)] = p_eta[n_src + d];
 			}
 		} else {
-			#pragma omp parallel for schedule(static) if(n_scalar_num > 65536)
+			#pragma omp parallel for schedule(static) num_threads(n_thread_num) if(n_scalar_num > 65536)
 			for(long i = 0; i < n_scalar_num; ++ i)
 				m_p_rhs[i] = p_eta[i];
 		}
@@ -300,14 +320,14 @@ protected:
 		Throw_On_Error(n_result);
 		double *p_x = &r_eta(0);
 		if(!m_order.empty()) {
-			#pragma omp parallel for schedule(static) if(n > 4096)
+			#pragma omp parallel for schedule(static) num_threads(n_thread_num) if(n > 4096)
 			for(long i = 0; i < n; ++ i) {
 				const size_t n_dst = r_lambda.n_BlockColumn_Base(m_order[i]);
 				for(int64_t d = 0, w = m_cumsum[i + 1] - m_cumsum[i]; d < w; ++ d)
 					p_x[n_dst + d] = m_p_rhs[size_t(m_cumsum[i] + d)];
 			}
 		} else {
-			#pragma omp parallel for schedule(static) if(n_scalar_num > 65536)
+			#pragma omp parallel for schedule(static) num_threads(n_thread_num) if(n_scalar_num > 65536)
 			for(long i = 0; i < n_scalar_num; ++ i)
 				p_x[i] = m_p_rhs[i];
 		}

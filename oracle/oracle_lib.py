@@ -139,11 +139,31 @@ def have_reference() -> bool:
     return os.path.exists(REF_HARNESS) and os.access(REF_HARNESS, os.X_OK)
 
 
+def host_cores() -> int:
+    """CPUs this process may really use: the visible count, cut down to the cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def reference_env() -> dict:
+    """Environment for the compiled reference: its OpenMP loops get as many threads as the process may use (a box that
+    shows 256 CPUs under a 16-CPU quota otherwise runs 256 spinning threads, and every parallel region takes ~1 s)."""
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(host_cores()))
+    return env
+
+
 def reference_solve(problem_path: str, solver: str, x_path: str = "-", reps: int = 1, timeout: int = 600):
     """Runs the compiled reference (oracle/_ref/ref_harness) on a SPPLAM01 file; returns its JSON."""
     import json
     out = subprocess.run([REF_HARNESS, "solve", problem_path, solver, x_path, str(reps)],
-                         capture_output=True, text=True, timeout=timeout)
+                         capture_output=True, text=True, timeout=timeout, env=reference_env())
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if not line:
         raise RuntimeError(f"ref_harness failed: {out.stdout} {out.stderr}")

@@ -1,0 +1,267 @@
+// simt_kernel.hip -- wide stages of the sparse block factorization, one *lane* per task.
+//
+// The stages at the bottom of a nested-dissection elimination tree hold thousands of tasks (at 100 000 poses: 15 894
+// leaf subtrees of 4-8 columns, then 7 513 / 3 675 / 1 931 single separator columns), and those tasks come in a handful
+// of shapes: the same number of columns, blocks, row entries and update pairs, referring to the same relative
+// operands (at 100 000 poses 158 shapes, the six most frequent cover 87 % of the leaves).  The wave-per-task kernel
+// (subtree_kernel.hip) spends about 600 wave-instructions on every 6 x 6 column with 36 of 64 lanes busy, most of
+// them cross-lane traffic of the in-wave Cholesky (v_readlane, ds_bpermute, LDS tiles); it is bound by instruction
+// issue at 6 % of the HBM roof.  Here 64 tasks of one shape share a wave and every lane runs
+// the plain scalar algorithm on its own task: Cholesky, inverse and the block products are straight-line FMAs in
+// registers, no lane ever talks to another, and one wave-instruction serves 64 columns (about 2 000 FMAs per column
+// and lane = 31 wave-instructions per column instead of 600).  What differs between the lanes is data: where the
+// blocks live.  So the *program* of a shape (column / block / pair counts and operand indices) is read with scalar
+// loads, and a per-lane table holds the offsets (of the task's own blocks, of its Lambda blocks, of its operands).
+// Operands go through the caches in the factor's ordinary layout: a lane reads its own 288-byte blocks with 16-byte
+// loads (consecutive instructions of a lane walk down the same lines), and a block written by a lane is re-read by
+// the same lane a column or two later.
+//
+// Arithmetic as in the other factor kernels (left-looking, one writer per block, fixed summation order); results
+// differ from theirs in the last bits only through the order of the sums inside a 6-term dot product.
+// Own translation unit (see dense_tiles.hip for why).
+#include <hip/hip_runtime.h>
+#include "sparse_kernels.h"
+
+namespace slampp {
+
+__device__ __forceinline__ double simt_rsqrt(double x)
+{
+	double y = __builtin_amdgcn_rsq(x);
+	const double h = 0.5 * x;
+	y = y * (1.5 - h * y * y);
+	y = y * (1.5 - h * y * y);
+	return y;
+}
+
+// D consecutive doubles at p (16-byte aligned when D is even: block offsets are multiples of D * D)
+template <int D>
+__device__ __forceinline__ void load_column(const double *__restrict__ p, double (&v)[D])
+{
+	if(D % 2 == 0) {
+		const double2 *p2 = reinterpret_cast<const double2*>(p);
+		#pragma unroll
+		for(int i = 0; i < D / 2; ++ i) {
+			const double2 t = p2[i];
+			v[2 * i] = t.x;
+			v[2 * i + 1] = t.y;
+		}
+	} else {
+		#pragma unroll
+		for(int i = 0; i < D; ++ i)
+			v[i] = p[i];
+	}
+}
+
+template <int D>
+__device__ __forceinline__ void store_block(double *p, const double (&m)[D][D]) // m[r][q] -> p[r + q D]
+{
+	if(D % 2 == 0) {
+		double2 *p2 = reinterpret_cast<double2*>(p);
+		#pragma unroll
+		for(int q = 0; q < D; ++ q) {
+			#pragma unroll
+			for(int r = 0; r < D; r += 2)
+				p2[(r + q * D) / 2] = double2{m[r][q], m[r + 1][q]};
+		}
+	} else {
+		#pragma unroll
+		for(int q = 0; q < D; ++ q) {
+			#pragma unroll
+			for(int r = 0; r < D; ++ r)
+				p[r + q * D] = m[r][q];
+		}
+	}
+}
+
+template <int D>
+__global__ void __launch_bounds__(64)
+factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restrict__ prog, const long long *__restrict__ tab,
+	const double *__restrict__ A, double *L, double *Linv, const double *__restrict__ b, double *w, int *p_flag)
+{
+	enum { DD = D * D };
+	const TSimtChunk ch = chunks[blockIdx.x];
+	const int32_t *P = prog + ch.prog_off;                 // wave-uniform: scalar loads
+	const long long *T = tab + ch.tab_off + threadIdx.x;   // field f of this lane's task at T[64 f]
+	const int n_cols = P[0], n_blocks = P[1], n_ops = P[2];
+	const int f_blk = 4 * n_cols, f_op = f_blk + n_blocks, f_y = f_op + n_ops;
+	int pc = 4, blk0 = 0;
+	bool b_bad = false;
+	for(int ci = 0; ci < n_cols; ++ ci) {
+		const int nb = P[pc], nr = P[pc + 1];
+		pc += 2;
+		const long long l_base = T[64 * (4 * ci)], linv_off = T[64 * (4 * ci + 1)], cs_new = T[64 * (4 * ci + 2)],
+			cs_src = T[64 * (4 * ci + 3)];
+		double a[D][D], y[D]; // a: lower triangle of the diagonal block
+		{
+			// the diagonal block of Lambda: its upper triangle is what the reference's solvers consume
+			// (src/slam/LinearSolver_CholMod.cpp:57); element (r, q), r >= q, is stored element (q, r)
+			const long long enc = T[64 * (f_blk + blk0)];
+			const double *src = A + ((enc < 0)? 0 : (enc >> 1));
+			#pragma unroll
+			for(int r = 0; r < D; ++ r) {
+				double c[D];
+				load_column<D>(src + r * D, c); // column r of the stored block: elements (0..D-1, r)
+				#pragma unroll
+				for(int q = 0; q < D; ++ q)
+					a[r][q] = (q <= r && enc >= 0)? c[q] : 0.0;
+			}
+			load_column<D>(b + cs_src, y);
+		}
+		for(int e = 0; e < nr; ++ e) { // blocks L(j,c) of block row j: update of the diagonal block and of the right-hand side
+			const long long off = T[64 * (f_op + P[pc])], yoff = T[64 * (f_y + P[pc + 1])];
+			pc += 2;
+			double yc[D];
+			load_column<D>(w + yoff, yc);
+			#pragma unroll
+			for(int t = 0; t < D; ++ t) {
+				double c[D];
+				load_column<D>(L + off + t * D, c);
+				#pragma unroll
+				for(int r = 0; r < D; ++ r) {
+					#pragma unroll
+					for(int q = 0; q <= r; ++ q)
+						a[r][q] -= c[r] * c[q];
+					y[r] -= c[r] * yc[t];
+				}
+			}
+		}
+		// Cholesky of the diagonal block, in place; rd[k] = 1 / L(k,k)
+		double rd[D];
+		#pragma unroll
+		for(int k = 0; k < D; ++ k) {
+			double piv = a[k][k];
+			const bool b_neg = !(piv > 0); // also catches NaN
+			b_bad = b_bad || b_neg;
+			piv = b_neg? 1.0 : piv;
+			const double s = simt_rsqrt(piv);
+			rd[k] = s;
+			a[k][k] = piv * s;
+			#pragma unroll
+			for(int r = k + 1; r < D; ++ r)
+				a[r][k] *= s;
+			#pragma unroll
+			for(int q = k + 1; q < D; ++ q) {
+				#pragma unroll
+				for(int r = q; r < D; ++ r)
+					a[r][q] -= a[r][k] * a[q][k];
+			}
+		}
+		// its inverse (lower triangular) and y_j = inv(L_jj) (b_j - sum L(j,c) y_c)
+		double x[D][D];
+		#pragma unroll
+		for(int c = 0; c < D; ++ c) {
+			#pragma unroll
+			for(int r = 0; r < D; ++ r) {
+				if(r < c)
+					x[r][c] = 0.0;
+				else if(r == c)
+					x[r][c] = rd[r];
+				else {
+					double sum = 0;
+					#pragma unroll
+					for(int t = c; t < r; ++ t)
+						sum += a[r][t] * x[t][c];
+					x[r][c] = -sum * rd[r];
+				}
+			}
+		}
+		{
+			double yn[D];
+			#pragma unroll
+			for(int r = 0; r < D; ++ r) {
+				double sum = 0;
+				#pragma unroll
+				for(int t = 0; t <= r; ++ t)
+					sum += x[r][t] * y[t];
+				yn[r] = sum;
+			}
+			#pragma unroll
+			for(int r = 0; r < D; ++ r) {
+				w[cs_new + r] = yn[r];
+				#pragma unroll
+				for(int q = r + 1; q < D; ++ q)
+					a[r][q] = 0.0; // the factor block is stored whole, zeros above its diagonal
+			}
+			store_block<D>(L + l_base, a);
+			store_block<D>(Linv + linv_off, x);
+		}
+		// sub-diagonal blocks: L(i,j) = (Lambda(i,j) - sum L(i,c) L(j,c)^T) inv(L_jj)^T
+		for(int kb = 1; kb < nb; ++ kb) {
+			const int np = P[pc ++];
+			const long long enc = T[64 * (f_blk + blk0 + kb)];
+			double acc[D][D];
+			{
+				const double *src = A + ((enc < 0)? 0 : (enc >> 1));
+				const bool b_trans = (enc & 1) != 0, b_have = enc >= 0;
+				double v[D][D]; // v[c][r] = stored element (r, c)
+				#pragma unroll
+				for(int c = 0; c < D; ++ c)
+					load_column<D>(src + c * D, v[c]);
+				#pragma unroll
+				for(int r = 0; r < D; ++ r) {
+					#pragma unroll
+					for(int q = 0; q < D; ++ q)
+						acc[r][q] = b_have? (b_trans? v[r][q] : v[q][r]) : 0.0;
+				}
+			}
+			for(int e = 0; e < np; ++ e) {
+				const long long off_a = T[64 * (f_op + P[pc])], off_b = T[64 * (f_op + P[pc + 1])];
+				pc += 2;
+				#pragma unroll
+				for(int t = 0; t < D; ++ t) {
+					double ca[D], cb[D];
+					load_column<D>(L + off_a + t * D, ca);
+					load_column<D>(L + off_b + t * D, cb);
+					#pragma unroll
+					for(int r = 0; r < D; ++ r) {
+						#pragma unroll
+						for(int q = 0; q < D; ++ q)
+							acc[r][q] -= ca[r] * cb[q];
+					}
+				}
+			}
+			double out[D][D];
+			#pragma unroll
+			for(int r = 0; r < D; ++ r) {
+				#pragma unroll
+				for(int q = 0; q < D; ++ q) {
+					double sum = 0;
+					#pragma unroll
+					for(int t = 0; t <= q; ++ t)
+						sum += acc[r][t] * x[q][t];
+					out[r][q] = sum;
+				}
+			}
+			store_block<D>(L + l_base + kb * DD, out);
+		}
+		blk0 += nb;
+		// what this lane has stored is what it loads in the following columns
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__syncthreads();
+	}
+	if(b_bad)
+		atomicOr(p_flag, 1);
+}
+
+bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, const int32_t *prog, const int64_t *tab, int n_dim,
+	const double *A, double *L, double *Linv, const double *b, double *w, int *p_flag, hipStream_t stream)
+{
+	if(n_chunks <= 0)
+		return true;
+	const long long *t = reinterpret_cast<const long long*>(tab);
+	switch(n_dim) {
+	case 3:
+		hipLaunchKernelGGL((factor_simt_kernel<3>), dim3(n_chunks), dim3(64), 0, stream, chunks, prog, t, A, L, Linv, b, w, p_flag);
+		return true;
+	case 6:
+		hipLaunchKernelGGL((factor_simt_kernel<6>), dim3(n_chunks), dim3(64), 0, stream, chunks, prog, t, A, L, Linv, b, w, p_flag);
+		return true;
+	case 7:
+		hipLaunchKernelGGL((factor_simt_kernel<7>), dim3(n_chunks), dim3(64), 0, stream, chunks, prog, t, A, L, Linv, b, w, p_flag);
+		return true;
+	default:
+		return false;
+	}
+}
+
+} // namespace slampp

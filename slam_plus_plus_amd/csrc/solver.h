@@ -111,6 +111,14 @@ struct slampp_hip_solver {
 	slampp::CDevArray<int64_t> d_task_ptr, d_task_pkg;
 	slampp::CDevArray<longlong2> d_pkg;
 	slampp::CDevArray<long long> d_timing; // development aid, see TDevPlan::p_timing
+	// lane-per-task kernel of the wide bottom stages (simt_kernel.hip): chunks of 64 same-shaped tasks; the tasks of a
+	// stage whose shape is too rare stay with the wave-per-task kernel (d_simt_rest lists them)
+	slampp::CDevArray<slampp::TSimtChunk> d_simt_chunks;
+	slampp::CDevArray<int32_t> d_simt_prog, d_simt_rest;
+	slampp::CDevArray<int64_t> d_simt_tab;
+	std::vector<int32_t> simt_chunk_ptr, simt_rest_ptr; // [n_bottom_stages + 1] each; empty = not in use
+	int n_simt = -1; // option "simt": 1 / -1 = use it where it applies (default), 0 = never
+	void Build_Simt(); // throws
 	// dense top of the sparse path (plan.h): assembled Schur complement + dense factor workspaces
 	slampp::CDevArray<slampp::TDenseBlk> d_dense_blks;
 	slampp::CDevArray<slampp::TDenseCol> d_dense_cols;

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <thread>
 
 using namespace slampp;
@@ -201,6 +202,8 @@ static void Upload_Values_And_Join(slampp_hip_solver &s, const double *p_values)
 void slampp_hip_solver::Free_Device()
 {
 	d_cols.Free(); d_blks.Free(); d_rents.Free(); d_pairs.Free(); d_task_ptr.Free(); d_task_pkg.Free(); d_pkg.Free();
+	d_simt_chunks.Free(); d_simt_prog.Free(); d_simt_rest.Free(); d_simt_tab.Free();
+	simt_chunk_ptr.clear(); simt_rest_ptr.clear();
 	d_dense_blks.Free(); d_dense_cols.Free(); d_dense.Free(); d_dense_invdiag.Free(); d_dense_z.Free(); d_dense_x.Free();
 	n_dense_blks = n_dense_cols = n_dense_dim = n_dense_pad = 0;
 	dense_tiles.Free();
@@ -231,6 +234,7 @@ size_t slampp_hip_solver::n_Device_Bytes() const
 	return d_dense_blks.n_Bytes() + d_dense_cols.n_Bytes() + d_dense.n_Bytes() + d_dense_invdiag.n_Bytes() + dense_tiles.n_Bytes() +
 		d_dense_z.n_Bytes() + d_dense_x.n_Bytes() + d_cols.n_Bytes() + d_blks.n_Bytes() + d_rents.n_Bytes() +
 		d_task_ptr.n_Bytes() + d_task_pkg.n_Bytes() + d_pkg.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
+		d_simt_chunks.n_Bytes() + d_simt_prog.n_Bytes() + d_simt_rest.n_Bytes() + d_simt_tab.n_Bytes() +
 		d_rhs.n_Bytes() + d_L.n_Bytes() + d_Linv.n_Bytes() + d_w.n_Bytes() + d_cov.n_Bytes() + d_flag.n_Bytes() +
 		d_Z.n_Bytes() + d_diag_zoff.n_Bytes() + d_Zd.n_Bytes() + d_Zd_work.n_Bytes() + sparse_inverse_bytes(p_sinv) +
 		(p_schur? schur_device_bytes(p_schur) : 0);
@@ -514,10 +518,151 @@ void slampp_hip_solver::Analyze_Sparse()
 	dplan.n_pairs = int64_t(pairs.size());
 	dplan.n_rents = int64_t(rents.size());
 	dplan.p_timing = 0;
+	dplan.task_map = 0;
+	Build_Simt();
 	if(getenv("SLAMPP_HIP_STAGE_TIMING")) { // development aid: clock samples of the upper-stage kernel, printed at sync
 		d_timing.Alloc(1 + 32 * 4096);
 		SLAMPP_HIP_CHECK(hipMemsetAsync(d_timing.p(), 0, (1 + 32 * 4096) * sizeof(long long), stream));
 		dplan.p_timing = d_timing.p();
+	}
+}
+
+// Sorts the tasks of the wide bottom stages by shape for the lane-per-task kernel (simt_kernel.hip; the formats are
+// described in sparse_kernels.h).  A shape is the task's whole program -- counts and operand indices, the operands
+// numbered in order of first use -- so two tasks of one shape differ in nothing but where their blocks live.
+void slampp_hip_solver::Build_Simt()
+{
+	simt_chunk_ptr.clear();
+	simt_rest_ptr.clear();
+	const Plan &P = plan;
+	if(!n_simt || !P.uniform_dim || (P.max_dim != 3 && P.max_dim != 6 && P.max_dim != 7))
+		return;
+	enum { MIN_GROUP = 16, MAX_PROG = 4096, MAX_FIELDS = 1024 };
+	const int n_stages = int(P.stage_ptr.size()) - 1;
+	std::vector<TSimtChunk> chunks;
+	std::vector<int32_t> prog_all, rest;
+	std::vector<int64_t> tab;
+	struct TTask { int32_t n_task; std::vector<int32_t> ops; std::vector<int32_t> ys; };
+	std::vector<int32_t> op_index(P.lrow.size(), -1), y_index(size_t(P.n), -1);
+	simt_chunk_ptr.push_back(0);
+	simt_rest_ptr.push_back(0);
+	for(int s = 0; s < n_bottom_stages && s < n_stages; ++ s) {
+		std::map<std::vector<int32_t>, std::vector<TTask> > groups;
+		for(int32_t t = P.stage_ptr[s]; t < P.stage_ptr[s + 1]; ++ t) {
+			std::vector<int32_t> prog(4, 0);
+			TTask tt;
+			tt.n_task = t;
+			int32_t n_blocks = 0;
+			bool b_fits = true;
+			auto op_of = [&](int32_t n_blk) {
+				if(op_index[n_blk] < 0) {
+					op_index[n_blk] = int32_t(tt.ops.size());
+					tt.ops.push_back(n_blk);
+				}
+				return op_index[n_blk];
+			};
+			for(int64_t i = P.task_ptr[t]; i < P.task_ptr[t + 1] && b_fits; ++ i) {
+				const int32_t j = P.task_cols[i];
+				const int32_t nb = int32_t(P.lptr[j + 1] - P.lptr[j]), nr = int32_t(P.rptr[j + 1] - P.rptr[j]);
+				prog.push_back(nb);
+				prog.push_back(nr);
+				n_blocks += nb;
+				for(int64_t e = P.rptr[j]; e < P.rptr[j + 1]; ++ e) {
+					const int32_t n_blk = P.rblk[e], c = P.blk_col[n_blk];
+					if(y_index[c] < 0) {
+						y_index[c] = int32_t(tt.ys.size());
+						tt.ys.push_back(c);
+					}
+					prog.push_back(op_of(n_blk));
+					prog.push_back(y_index[c]);
+				}
+				for(int64_t k = P.lptr[j] + 1; k < P.lptr[j + 1]; ++ k) {
+					prog.push_back(int32_t(P.pptr[k + 1] - P.pptr[k]));
+					for(int64_t e = P.pptr[k]; e < P.pptr[k + 1]; ++ e) {
+						prog.push_back(op_of(P.pa[e]));
+						prog.push_back(op_of(P.pb[e]));
+					}
+				}
+				b_fits = prog.size() <= MAX_PROG;
+			}
+			for(size_t k = 0; k < tt.ops.size(); ++ k)
+				op_index[tt.ops[k]] = -1;
+			for(size_t k = 0; k < tt.ys.size(); ++ k)
+				y_index[tt.ys[k]] = -1;
+			const int32_t n_cols = int32_t(P.task_ptr[t + 1] - P.task_ptr[t]);
+			prog[0] = n_cols;
+			prog[1] = n_blocks;
+			prog[2] = int32_t(tt.ops.size());
+			prog[3] = int32_t(tt.ys.size());
+			if(!b_fits || 4 * n_cols + n_blocks + int32_t(tt.ops.size() + tt.ys.size()) > MAX_FIELDS)
+				rest.push_back(t);
+			else
+				groups[prog].push_back(std::move(tt));
+		}
+		for(auto &r_group : groups) {
+			const std::vector<int32_t> &prog = r_group.first;
+			std::vector<TTask> &tasks = r_group.second;
+			if(tasks.size() < MIN_GROUP) {
+				for(const TTask &tt : tasks)
+					rest.push_back(tt.n_task);
+				continue;
+			}
+			const int32_t n_prog_off = int32_t(prog_all.size());
+			prog_all.insert(prog_all.end(), prog.begin(), prog.end());
+			const int n_cols = prog[0], n_blocks = prog[1], n_ops = prog[2], n_ys = prog[3];
+			const int n_fields = 4 * n_cols + n_blocks + n_ops + n_ys;
+			for(size_t n_first = 0; n_first < tasks.size(); n_first += 64) {
+				const size_t n_in_chunk = std::min<size_t>(64, tasks.size() - n_first);
+				TSimtChunk ch;
+				ch.prog_off = n_prog_off;
+				ch.n_tasks = int32_t(n_in_chunk);
+				ch.tab_off = int64_t(tab.size());
+				chunks.push_back(ch);
+				tab.resize(tab.size() + size_t(n_fields) * 64);
+				int64_t *p_tab = &tab[size_t(ch.tab_off)];
+				for(int n_lane = 0; n_lane < 64; ++ n_lane) {
+					const TTask &tt = tasks[n_first + std::min<size_t>(n_lane, n_in_chunk - 1)]; // spare lanes repeat the last task
+					int f = 0;
+					for(int64_t i = P.task_ptr[tt.n_task]; i < P.task_ptr[tt.n_task + 1]; ++ i) {
+						const int32_t j = P.task_cols[i];
+						p_tab[64 * (f ++) + n_lane] = P.loff[P.lptr[j]];
+						p_tab[64 * (f ++) + n_lane] = P.linv_off[j];
+						p_tab[64 * (f ++) + n_lane] = P.cs_new[j];
+						p_tab[64 * (f ++) + n_lane] = P.cs_src[j];
+					}
+					for(int64_t i = P.task_ptr[tt.n_task]; i < P.task_ptr[tt.n_task + 1]; ++ i) {
+						const int32_t j = P.task_cols[i];
+						for(int64_t k = P.lptr[j]; k < P.lptr[j + 1]; ++ k)
+							p_tab[64 * (f ++) + n_lane] = (P.asrc[k] < 0)? -1 : P.asrc[k] * 2 + P.atrans[k];
+					}
+					for(int32_t n_blk : tt.ops)
+						p_tab[64 * (f ++) + n_lane] = P.loff[n_blk];
+					for(int32_t c : tt.ys)
+						p_tab[64 * (f ++) + n_lane] = P.cs_new[c];
+					if(f != n_fields)
+						throw std::logic_error("lane-per-task tables: field count mismatch");
+				}
+			}
+		}
+		std::sort(rest.begin() + simt_rest_ptr.back(), rest.end());
+		simt_chunk_ptr.push_back(int32_t(chunks.size()));
+		simt_rest_ptr.push_back(int32_t(rest.size()));
+	}
+	if(chunks.empty()) {
+		simt_chunk_ptr.clear();
+		simt_rest_ptr.clear();
+		return;
+	}
+	d_simt_chunks.Upload(chunks, stream);
+	d_simt_prog.Upload(prog_all, stream);
+	d_simt_tab.Upload(tab, stream);
+	d_simt_rest.Upload(rest, stream);
+	SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // the vectors above die here
+	if(getenv("SLAMPP_HIP_PLAN_TIMING")) {
+		for(size_t s = 0; s + 1 < simt_chunk_ptr.size(); ++ s) {
+			fprintf(stderr, "[setup] stage %zu: %d tasks -> %d chunks of 64 lanes, %d tasks left to the wave-per-task kernel\n", s,
+				P.stage_ptr[s + 1] - P.stage_ptr[s], simt_chunk_ptr[s + 1] - simt_chunk_ptr[s], simt_rest_ptr[s + 1] - simt_rest_ptr[s]);
+		}
 	}
 }
 
@@ -528,9 +673,23 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 	if(b_factor) {
 		// numeric factorization with the forward substitution fused in
 		SLAMPP_HIP_CHECK(hipMemsetAsync(d_flag.p(), 0, sizeof(int), stream));
+		// the lane-per-task kernel reads blocks and vectors with 16-byte loads where the block dimension is even
+		const bool b_simt = !simt_chunk_ptr.empty() && (P.max_dim % 2 != 0 ||
+			((reinterpret_cast<uintptr_t>(p_values_dev) | reinterpret_cast<uintptr_t>(p_rhs_dev)) & 15) == 0);
 		for(int s = 0; s < n_stages; ++ s) {
 			if(s == 0 || s == n_bottom_stages)
 				Phase_Begin(s? "factor_upper" : "factor_subtree");
+			if(b_simt && s < n_bottom_stages) {
+				const int n_chunks = simt_chunk_ptr[s + 1] - simt_chunk_ptr[s], n_rest = simt_rest_ptr[s + 1] - simt_rest_ptr[s];
+				launch_factor_simt(d_simt_chunks.p() + simt_chunk_ptr[s], n_chunks, d_simt_prog.p(), d_simt_tab.p(), P.max_dim,
+					p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), d_flag.p(), stream);
+				if(n_rest > 0) {
+					TDevPlan t_rest = dplan;
+					t_rest.task_map = d_simt_rest.p();
+					launch_factor_stage(t_rest, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), simt_rest_ptr[s], n_rest,
+						true, d_flag.p(), stream);
+				}
+			} else
 			launch_factor_stage(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
 				P.stage_ptr[s + 1] - P.stage_ptr[s], s < n_bottom_stages, d_flag.p(), stream);
 			if(s == n_bottom_stages - 1 || s == n_stages - 1)
@@ -723,6 +882,8 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 		p_solver->n_dense_top_tiles = int(n_value);
 		p_solver->opt.dense_top_align = n_value? 64 : 0; // the alignment padding only serves the tile schedule
 	}
+	else if(s == "simt" && n_value >= -1 && n_value <= 1)
+		p_solver->n_simt = int(n_value);
 	else if(s == "profile") {
 		p_solver->b_profile = (n_value != 0);
 		return SLAMPP_HIP_OK; // does not invalidate the analysis

@@ -76,9 +76,27 @@ struct TDevPlan {
 	// columns follow each other; pkg is padded so that a read of PKG_SPECULATIVE units from any package start stays inside
 	const longlong2 *pkg;
 	const int64_t *task_pkg;
+	const int32_t *task_map;   // bottom stages, or null: the tasks a launch of the wave-per-task kernel works on, when they are not
+	                           // a contiguous range (the others of the stage went to the lane-per-task kernel): task = task_map[task_begin + blockIdx.x]
 	long long *p_timing;       // development aid (SLAMPP_HIP_STAGE_TIMING): [0] = launches so far, then 32 clock
 	                           // samples per launch of workgroup 0 of the multi-wave factor kernel; normally null
 };
+
+// lane-per-task kernel of the wide stages (simt_kernel.hip): 64 tasks of one shape per wave.  A chunk names the shape's
+// program (int32 stream: n_cols, n_blocks, n_ops, n_y, then per column nb, nr, nr x (operand, y index), and per
+// sub-diagonal block np, np x (operand a, operand b)) and the chunk's table of per-lane offsets, [field][64]: per column
+// (offset of its first factor block, offset of inv(L_jj), scalar offset in the workspace, scalar offset in the caller's
+// vector), per block its source in Lambda ((offset << 1) | transposed, or -1), per operand its offset in the factor,
+// per y index the scalar offset of that column in the workspace.  Lanes beyond the chunk's tasks repeat its last task.
+struct TSimtChunk { // 16 B
+	int32_t prog_off;  // in int32 units
+	int32_t n_tasks;   // real tasks in the chunk (<= 64)
+	int64_t tab_off;   // in int64 units
+};
+
+// returns false if the block dimension has no such kernel
+bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, const int32_t *prog, const int64_t *tab, int n_dim,
+	const double *A, double *L, double *Linv, const double *b, double *w, int *p_flag, hipStream_t stream);
 
 // numeric factorization of one stage, with the forward substitution y = L^-1 b fused in
 // (b is read at its original position, y written to the permuted workspace w)

@@ -45,7 +45,7 @@ factor_subtree_kernel(TDevPlan p, const double *__restrict__ A, double *L, doubl
 	__shared__ double s_rdiag[8];  // 1 / L_jj(k,k)
 	__shared__ double s_tile[64];
 	const int lane = threadIdx.x;
-	const int task = task_begin + blockIdx.x;
+	const int task = p.task_map? p.task_map[task_begin + blockIdx.x] : task_begin + blockIdx.x;
 	const int64_t c_begin = p.task_ptr[task], c_end = p.task_ptr[task + 1];
 	TColDesc cd_next = p.cols[c_begin];
 	for(int64_t c = c_begin; c < c_end; ++ c) {

@@ -78,7 +78,7 @@ factor_subtree_image_kernel(TDevPlan p, const double *__restrict__ A, double *L,
 	static_assert(sizeof(TColDesc) == 64 && sizeof(TBlkDesc) == 32 && sizeof(TRowEnt) == 16, "record sizes");
 
 	const int lane = threadIdx.x;
-	const int task = task_begin + blockIdx.x;
+	const int task = p.task_map? p.task_map[task_begin + blockIdx.x] : task_begin + blockIdx.x;
 	long long *p_tm = 0; // development aid (SLAMPP_HIP_STAGE_TIMING): clock samples of a workgroup in the middle of the grid
 	int n_tm = 0;
 	if(p.p_timing && blockIdx.x == gridDim.x / 2 && lane == 0) {

@@ -249,10 +249,15 @@ class _SolverBase:
         self._structure_key = None
         self._analyzed = False
 
-    @staticmethod
-    def _key(lam):
-        return (lam.n_bcols, lam.n_blocks, int(lam.cumsum[-1]),
-                hash(lam.bcol_ptr.tobytes()), hash(lam.brow_idx.tobytes()), hash(lam.cumsum.tobytes()))
+    def _key(self, lam):
+        # the same array objects as last time (what an iteration loop passes): no need to hash 10^6 indices again
+        ident = (id(lam.bcol_ptr), id(lam.brow_idx), id(lam.cumsum))
+        if getattr(self, "_key_ident", None) == ident and self._key_arrays[0] is lam.bcol_ptr:
+            return self._key_value
+        key = (lam.n_bcols, lam.n_blocks, int(lam.cumsum[-1]),
+               hash(lam.bcol_ptr.tobytes()), hash(lam.brow_idx.tobytes()), hash(lam.cumsum.tobytes()))
+        self._key_ident, self._key_arrays, self._key_value = ident, (lam.bcol_ptr, lam.brow_idx, lam.cumsum), key
+        return key
 
     def _n_matrix_cut(self, lam) -> int:
         return 0
