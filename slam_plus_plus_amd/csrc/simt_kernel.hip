@@ -53,6 +53,24 @@ __device__ __forceinline__ void load_column(const double *__restrict__ p, double
 }
 
 template <int D>
+__device__ __forceinline__ void load_block(const double *__restrict__ p, double (&v)[D][D]) // v[c][r] = p[r + c D]
+{
+	if(D % 2 == 0) {
+		const double2 *p2 = reinterpret_cast<const double2*>(p);
+		#pragma unroll
+		for(int i = 0; i < D * D / 2; ++ i) {
+			const double2 t = p2[i];
+			v[(2 * i) / D][(2 * i) % D] = t.x;
+			v[(2 * i + 1) / D][(2 * i + 1) % D] = t.y;
+		}
+	} else {
+		#pragma unroll
+		for(int i = 0; i < D * D; ++ i)
+			v[i / D][i % D] = p[i];
+	}
+}
+
+template <int D>
 __device__ __forceinline__ void store_block(double *p, const double (&m)[D][D]) // m[r][q] -> p[r + q D]
 {
 	if(D % 2 == 0) {
@@ -73,29 +91,40 @@ __device__ __forceinline__ void store_block(double *p, const double (&m)[D][D]) 
 	}
 }
 
-template <int D>
+template <int D, int W> // W = tasks (busy lanes) per wave
 __global__ void __launch_bounds__(64)
 factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restrict__ prog, const long long *__restrict__ tab,
-	const double *__restrict__ A, double *L, double *Linv, const double *__restrict__ b, double *w, int *p_flag)
+	const double *__restrict__ A, double *L, double *Linv, const double *__restrict__ b, double *w, int *p_flag,
+	long long *p_timing)
 {
 	enum { DD = D * D };
 	const TSimtChunk ch = chunks[blockIdx.x];
+	if(int(threadIdx.x) >= W)
+		return; // (no barrier below)
+	long long *p_tm = 0; // development aid (SLAMPP_HIP_STAGE_TIMING): clock samples of a wave in the middle of the grid
+	int n_tm = 0;
+	if(p_timing && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {
+		p_tm = p_timing + 1 + 32 * atomicAdd((unsigned long long*)p_timing, 1ull);
+		p_tm[n_tm ++] = wall_clock64();
+	}
+#define SIMT_TICK() do { if(p_tm && n_tm < 32) p_tm[n_tm ++] = wall_clock64(); } while(0)
 	const int32_t *P = prog + ch.prog_off;                 // wave-uniform: scalar loads
-	const long long *T = tab + ch.tab_off + threadIdx.x;   // field f of this lane's task at T[64 f]
+	const long long *T = tab + ch.tab_off + threadIdx.x;   // field f of this lane's task at T[W f]
 	const int n_cols = P[0], n_blocks = P[1], n_ops = P[2];
 	const int f_blk = 4 * n_cols, f_op = f_blk + n_blocks, f_y = f_op + n_ops;
 	int pc = 4, blk0 = 0;
 	bool b_bad = false;
 	for(int ci = 0; ci < n_cols; ++ ci) {
-		const int nb = P[pc], nr = P[pc + 1];
-		pc += 2;
-		const long long l_base = T[64 * (4 * ci)], linv_off = T[64 * (4 * ci + 1)], cs_new = T[64 * (4 * ci + 2)],
-			cs_src = T[64 * (4 * ci + 3)];
+		const int nb = P[pc], nr = P[pc + 1], n_touch = P[pc + 2];
+		pc += 3;
+		pc += n_touch; // (the column's distinct operands, for a variant that requested their lines ahead: measured slower)
+		const long long l_base = T[W * (4 * ci)], linv_off = T[W * (4 * ci + 1)], cs_new = T[W * (4 * ci + 2)],
+			cs_src = T[W * (4 * ci + 3)];
 		double a[D][D], y[D]; // a: lower triangle of the diagonal block
 		{
 			// the diagonal block of Lambda: its upper triangle is what the reference's solvers consume
 			// (src/slam/LinearSolver_CholMod.cpp:57); element (r, q), r >= q, is stored element (q, r)
-			const long long enc = T[64 * (f_blk + blk0)];
+			const long long enc = T[W * (f_blk + blk0)];
 			const double *src = A + ((enc < 0)? 0 : (enc >> 1));
 			#pragma unroll
 			for(int r = 0; r < D; ++ r) {
@@ -107,24 +136,35 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 			}
 			load_column<D>(b + cs_src, y);
 		}
-		for(int e = 0; e < nr; ++ e) { // blocks L(j,c) of block row j: update of the diagonal block and of the right-hand side
-			const long long off = T[64 * (f_op + P[pc])], yoff = T[64 * (f_y + P[pc + 1])];
-			pc += 2;
-			double yc[D];
-			load_column<D>(w + yoff, yc);
-			#pragma unroll
-			for(int t = 0; t < D; ++ t) {
-				double c[D];
-				load_column<D>(L + off + t * D, c);
+		{ // blocks L(j,c) of block row j: update of the diagonal block and of the right-hand side; the offsets of entry
+			// e + 1 are fetched while entry e is being worked on, and a block is requested whole before its first product
+			long long off = 0, yoff = 0;
+			if(nr > 0) {
+				off = T[W * (f_op + P[pc])];
+				yoff = T[W * (f_y + P[pc + 1])];
+			}
+			for(int e = 0; e < nr; ++ e) {
+				pc += 2;
+				double c[D][D], yc[D];
+				load_block<D>(L + off, c);
+				load_column<D>(w + yoff, yc);
+				if(e + 1 < nr) {
+					off = T[W * (f_op + P[pc])];
+					yoff = T[W * (f_y + P[pc + 1])];
+				}
 				#pragma unroll
-				for(int r = 0; r < D; ++ r) {
+				for(int t = 0; t < D; ++ t) {
 					#pragma unroll
-					for(int q = 0; q <= r; ++ q)
-						a[r][q] -= c[r] * c[q];
-					y[r] -= c[r] * yc[t];
+					for(int r = 0; r < D; ++ r) {
+						#pragma unroll
+						for(int q = 0; q <= r; ++ q)
+							a[r][q] -= c[t][r] * c[t][q];
+						y[r] -= c[t][r] * yc[t];
+					}
 				}
 			}
 		}
+		SIMT_TICK(); // Lambda, row entries
 		// Cholesky of the diagonal block, in place; rd[k] = 1 / L(k,k)
 		double rd[D];
 		#pragma unroll
@@ -185,10 +225,11 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 			store_block<D>(L + l_base, a);
 			store_block<D>(Linv + linv_off, x);
 		}
+		SIMT_TICK(); // diagonal block
 		// sub-diagonal blocks: L(i,j) = (Lambda(i,j) - sum L(i,c) L(j,c)^T) inv(L_jj)^T
 		for(int kb = 1; kb < nb; ++ kb) {
 			const int np = P[pc ++];
-			const long long enc = T[64 * (f_blk + blk0 + kb)];
+			const long long enc = T[W * (f_blk + blk0 + kb)];
 			double acc[D][D];
 			{
 				const double *src = A + ((enc < 0)? 0 : (enc >> 1));
@@ -204,23 +245,34 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 						acc[r][q] = b_have? (b_trans? v[r][q] : v[q][r]) : 0.0;
 				}
 			}
-			for(int e = 0; e < np; ++ e) {
-				const long long off_a = T[64 * (f_op + P[pc])], off_b = T[64 * (f_op + P[pc + 1])];
-				pc += 2;
-				#pragma unroll
-				for(int t = 0; t < D; ++ t) {
-					double ca[D], cb[D];
-					load_column<D>(L + off_a + t * D, ca);
-					load_column<D>(L + off_b + t * D, cb);
+			{
+				long long off_a = 0, off_b = 0;
+				if(np > 0) {
+					off_a = T[W * (f_op + P[pc])];
+					off_b = T[W * (f_op + P[pc + 1])];
+				}
+				for(int e = 0; e < np; ++ e) {
+					pc += 2;
+					double ca[D][D], cb[D][D];
+					load_block<D>(L + off_a, ca);
+					load_block<D>(L + off_b, cb);
+					if(e + 1 < np) {
+						off_a = T[W * (f_op + P[pc])];
+						off_b = T[W * (f_op + P[pc + 1])];
+					}
 					#pragma unroll
-					for(int r = 0; r < D; ++ r) {
+					for(int t = 0; t < D; ++ t) {
 						#pragma unroll
-						for(int q = 0; q < D; ++ q)
-							acc[r][q] -= ca[r] * cb[q];
+						for(int r = 0; r < D; ++ r) {
+							#pragma unroll
+							for(int q = 0; q < D; ++ q)
+								acc[r][q] -= ca[t][r] * cb[t][q];
+						}
 					}
 				}
 			}
-			double out[D][D];
+			double xi[D][D], out[D][D]; // xi[c][r] = element (r, c) of inv(L_jj), as this lane stored it above
+			load_block<D>(Linv + linv_off, xi);
 			#pragma unroll
 			for(int r = 0; r < D; ++ r) {
 				#pragma unroll
@@ -228,40 +280,46 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 					double sum = 0;
 					#pragma unroll
 					for(int t = 0; t <= q; ++ t)
-						sum += acc[r][t] * x[q][t];
+						sum += acc[r][t] * xi[t][q];
 					out[r][q] = sum;
 				}
 			}
 			store_block<D>(L + l_base + kb * DD, out);
+			SIMT_TICK(); // one sub-diagonal block
 		}
 		blk0 += nb;
-		// what this lane has stored is what it loads in the following columns
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__syncthreads();
+		// (what a lane loads in the following columns is what the lane itself has stored, or what an earlier launch
+		// has: program order of one thread, no fence)
 	}
 	if(b_bad)
 		atomicOr(p_flag, 1);
 }
 
-bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, const int32_t *prog, const int64_t *tab, int n_dim,
-	const double *A, double *L, double *Linv, const double *b, double *w, int *p_flag, hipStream_t stream)
+bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, int n_width, const int32_t *prog, const int64_t *tab, int n_dim,
+	const double *A, double *L, double *Linv, const double *b, double *w, int *p_flag, hipStream_t stream, long long *p_timing)
 {
 	if(n_chunks <= 0)
 		return true;
 	const long long *t = reinterpret_cast<const long long*>(tab);
+#define SIMT_LAUNCH(D_, W_) hipLaunchKernelGGL((factor_simt_kernel<D_, W_>), dim3(n_chunks), dim3(64), 0, stream, chunks, prog, t, \
+	A, L, Linv, b, w, p_flag, p_timing)
+#define SIMT_WIDTHS(D_) do { if(n_width == 16) SIMT_LAUNCH(D_, 16); else if(n_width == 32) SIMT_LAUNCH(D_, 32); \
+	else SIMT_LAUNCH(D_, 64); } while(0)
 	switch(n_dim) {
 	case 3:
-		hipLaunchKernelGGL((factor_simt_kernel<3>), dim3(n_chunks), dim3(64), 0, stream, chunks, prog, t, A, L, Linv, b, w, p_flag);
+		SIMT_WIDTHS(3);
 		return true;
 	case 6:
-		hipLaunchKernelGGL((factor_simt_kernel<6>), dim3(n_chunks), dim3(64), 0, stream, chunks, prog, t, A, L, Linv, b, w, p_flag);
+		SIMT_WIDTHS(6);
 		return true;
 	case 7:
-		hipLaunchKernelGGL((factor_simt_kernel<7>), dim3(n_chunks), dim3(64), 0, stream, chunks, prog, t, A, L, Linv, b, w, p_flag);
+		SIMT_WIDTHS(7);
 		return true;
 	default:
 		return false;
 	}
+#undef SIMT_WIDTHS
+#undef SIMT_LAUNCH
 }
 
 } // namespace slampp

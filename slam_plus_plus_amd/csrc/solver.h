@@ -118,6 +118,9 @@ struct slampp_hip_solver {
 	slampp::CDevArray<int64_t> d_simt_tab;
 	std::vector<int32_t> simt_chunk_ptr, simt_rest_ptr; // [n_bottom_stages + 1] each; empty = not in use
 	int n_simt = -1; // option "simt": 1 / -1 = use it where it applies (default), 0 = never
+	int n_simt_width = 32; // option "simt_width": tasks per wave (16, 32, 64)
+	int n_simt_stages = 1; // option "simt_stages": how many of the bottom stages it takes (the stages above the leaves hold
+	                       // single separator columns whose operands other waves wrote: no gain there, measured)
 	void Build_Simt(); // throws
 	// dense top of the sparse path (plan.h): assembled Schur complement + dense factor workspaces
 	slampp::CDevArray<slampp::TDenseBlk> d_dense_blks;

@@ -537,7 +537,7 @@ void slampp_hip_solver::Build_Simt()
 	const Plan &P = plan;
 	if(!n_simt || !P.uniform_dim || (P.max_dim != 3 && P.max_dim != 6 && P.max_dim != 7))
 		return;
-	enum { MIN_GROUP = 16, MAX_PROG = 4096, MAX_FIELDS = 1024 };
+	enum { MIN_GROUP = 1, MAX_PROG = 4096, MAX_FIELDS = 1024 }; // (rare shapes run with few busy lanes, beside the others: cheaper than a launch of their own)
 	const int n_stages = int(P.stage_ptr.size()) - 1;
 	std::vector<TSimtChunk> chunks;
 	std::vector<int32_t> prog_all, rest;
@@ -546,7 +546,8 @@ void slampp_hip_solver::Build_Simt()
 	std::vector<int32_t> op_index(P.lrow.size(), -1), y_index(size_t(P.n), -1);
 	simt_chunk_ptr.push_back(0);
 	simt_rest_ptr.push_back(0);
-	for(int s = 0; s < n_bottom_stages && s < n_stages; ++ s) {
+	const size_t W = size_t(n_simt_width);
+	for(int s = 0; s < n_bottom_stages && s < n_stages && s < n_simt_stages; ++ s) {
 		std::map<std::vector<int32_t>, std::vector<TTask> > groups;
 		for(int32_t t = P.stage_ptr[s]; t < P.stage_ptr[s + 1]; ++ t) {
 			std::vector<int32_t> prog(4, 0);
@@ -566,23 +567,34 @@ void slampp_hip_solver::Build_Simt()
 				const int32_t nb = int32_t(P.lptr[j + 1] - P.lptr[j]), nr = int32_t(P.rptr[j + 1] - P.rptr[j]);
 				prog.push_back(nb);
 				prog.push_back(nr);
+				const size_t n_touch_at = prog.size();
+				prog.push_back(0); // number of distinct operands of the column, then their indices
 				n_blocks += nb;
+				std::vector<int32_t> touch, body;
+				auto touch_op = [&](int32_t n_op) {
+					if(std::find(touch.begin(), touch.end(), n_op) == touch.end())
+						touch.push_back(n_op);
+					return n_op;
+				};
 				for(int64_t e = P.rptr[j]; e < P.rptr[j + 1]; ++ e) {
 					const int32_t n_blk = P.rblk[e], c = P.blk_col[n_blk];
 					if(y_index[c] < 0) {
 						y_index[c] = int32_t(tt.ys.size());
 						tt.ys.push_back(c);
 					}
-					prog.push_back(op_of(n_blk));
-					prog.push_back(y_index[c]);
+					body.push_back(touch_op(op_of(n_blk)));
+					body.push_back(y_index[c]);
 				}
 				for(int64_t k = P.lptr[j] + 1; k < P.lptr[j + 1]; ++ k) {
-					prog.push_back(int32_t(P.pptr[k + 1] - P.pptr[k]));
+					body.push_back(int32_t(P.pptr[k + 1] - P.pptr[k]));
 					for(int64_t e = P.pptr[k]; e < P.pptr[k + 1]; ++ e) {
-						prog.push_back(op_of(P.pa[e]));
-						prog.push_back(op_of(P.pb[e]));
+						body.push_back(touch_op(op_of(P.pa[e])));
+						body.push_back(touch_op(op_of(P.pb[e])));
 					}
 				}
+				prog[n_touch_at] = int32_t(touch.size());
+				prog.insert(prog.end(), touch.begin(), touch.end());
+				prog.insert(prog.end(), body.begin(), body.end());
 				b_fits = prog.size() <= MAX_PROG;
 			}
 			for(size_t k = 0; k < tt.ops.size(); ++ k)
@@ -611,34 +623,34 @@ void slampp_hip_solver::Build_Simt()
 			prog_all.insert(prog_all.end(), prog.begin(), prog.end());
 			const int n_cols = prog[0], n_blocks = prog[1], n_ops = prog[2], n_ys = prog[3];
 			const int n_fields = 4 * n_cols + n_blocks + n_ops + n_ys;
-			for(size_t n_first = 0; n_first < tasks.size(); n_first += 64) {
-				const size_t n_in_chunk = std::min<size_t>(64, tasks.size() - n_first);
+			for(size_t n_first = 0; n_first < tasks.size(); n_first += W) {
+				const size_t n_in_chunk = std::min<size_t>(W, tasks.size() - n_first);
 				TSimtChunk ch;
 				ch.prog_off = n_prog_off;
 				ch.n_tasks = int32_t(n_in_chunk);
 				ch.tab_off = int64_t(tab.size());
 				chunks.push_back(ch);
-				tab.resize(tab.size() + size_t(n_fields) * 64);
+				tab.resize(tab.size() + size_t(n_fields) * W);
 				int64_t *p_tab = &tab[size_t(ch.tab_off)];
-				for(int n_lane = 0; n_lane < 64; ++ n_lane) {
+				for(int n_lane = 0; n_lane < int(W); ++ n_lane) {
 					const TTask &tt = tasks[n_first + std::min<size_t>(n_lane, n_in_chunk - 1)]; // spare lanes repeat the last task
 					int f = 0;
 					for(int64_t i = P.task_ptr[tt.n_task]; i < P.task_ptr[tt.n_task + 1]; ++ i) {
 						const int32_t j = P.task_cols[i];
-						p_tab[64 * (f ++) + n_lane] = P.loff[P.lptr[j]];
-						p_tab[64 * (f ++) + n_lane] = P.linv_off[j];
-						p_tab[64 * (f ++) + n_lane] = P.cs_new[j];
-						p_tab[64 * (f ++) + n_lane] = P.cs_src[j];
+						p_tab[W * (f ++) + n_lane] = P.loff[P.lptr[j]];
+						p_tab[W * (f ++) + n_lane] = P.linv_off[j];
+						p_tab[W * (f ++) + n_lane] = P.cs_new[j];
+						p_tab[W * (f ++) + n_lane] = P.cs_src[j];
 					}
 					for(int64_t i = P.task_ptr[tt.n_task]; i < P.task_ptr[tt.n_task + 1]; ++ i) {
 						const int32_t j = P.task_cols[i];
 						for(int64_t k = P.lptr[j]; k < P.lptr[j + 1]; ++ k)
-							p_tab[64 * (f ++) + n_lane] = (P.asrc[k] < 0)? -1 : P.asrc[k] * 2 + P.atrans[k];
+							p_tab[W * (f ++) + n_lane] = (P.asrc[k] < 0)? -1 : P.asrc[k] * 2 + P.atrans[k];
 					}
 					for(int32_t n_blk : tt.ops)
-						p_tab[64 * (f ++) + n_lane] = P.loff[n_blk];
+						p_tab[W * (f ++) + n_lane] = P.loff[n_blk];
 					for(int32_t c : tt.ys)
-						p_tab[64 * (f ++) + n_lane] = P.cs_new[c];
+						p_tab[W * (f ++) + n_lane] = P.cs_new[c];
 					if(f != n_fields)
 						throw std::logic_error("lane-per-task tables: field count mismatch");
 				}
@@ -679,10 +691,10 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 		for(int s = 0; s < n_stages; ++ s) {
 			if(s == 0 || s == n_bottom_stages)
 				Phase_Begin(s? "factor_upper" : "factor_subtree");
-			if(b_simt && s < n_bottom_stages) {
+			if(b_simt && s + 1 < int(simt_chunk_ptr.size())) {
 				const int n_chunks = simt_chunk_ptr[s + 1] - simt_chunk_ptr[s], n_rest = simt_rest_ptr[s + 1] - simt_rest_ptr[s];
-				launch_factor_simt(d_simt_chunks.p() + simt_chunk_ptr[s], n_chunks, d_simt_prog.p(), d_simt_tab.p(), P.max_dim,
-					p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), d_flag.p(), stream);
+				launch_factor_simt(d_simt_chunks.p() + simt_chunk_ptr[s], n_chunks, n_simt_width, d_simt_prog.p(), d_simt_tab.p(), P.max_dim,
+					p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), d_flag.p(), stream, dplan.p_timing);
 				if(n_rest > 0) {
 					TDevPlan t_rest = dplan;
 					t_rest.task_map = d_simt_rest.p();
@@ -884,6 +896,10 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 	}
 	else if(s == "simt" && n_value >= -1 && n_value <= 1)
 		p_solver->n_simt = int(n_value);
+	else if(s == "simt_width" && (n_value == 16 || n_value == 32 || n_value == 64))
+		p_solver->n_simt_width = int(n_value);
+	else if(s == "simt_stages" && n_value >= 0)
+		p_solver->n_simt_stages = int(n_value);
 	else if(s == "profile") {
 		p_solver->b_profile = (n_value != 0);
 		return SLAMPP_HIP_OK; // does not invalidate the analysis

@@ -83,8 +83,8 @@ struct TDevPlan {
 };
 
 // lane-per-task kernel of the wide stages (simt_kernel.hip): 64 tasks of one shape per wave.  A chunk names the shape's
-// program (int32 stream: n_cols, n_blocks, n_ops, n_y, then per column nb, nr, nr x (operand, y index), and per
-// sub-diagonal block np, np x (operand a, operand b)) and the chunk's table of per-lane offsets, [field][64]: per column
+// program (int32 stream: n_cols, n_blocks, n_ops, n_y, then per column nb, nr, n_touch, the column's n_touch distinct operands, nr x (operand, y index), and per
+// sub-diagonal block np, np x (operand a, operand b)) and the chunk's table of per-lane offsets, [field][width]: per column
 // (offset of its first factor block, offset of inv(L_jj), scalar offset in the workspace, scalar offset in the caller's
 // vector), per block its source in Lambda ((offset << 1) | transposed, or -1), per operand its offset in the factor,
 // per y index the scalar offset of that column in the workspace.  Lanes beyond the chunk's tasks repeat its last task.
@@ -95,8 +95,10 @@ struct TSimtChunk { // 16 B
 };
 
 // returns false if the block dimension has no such kernel
-bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, const int32_t *prog, const int64_t *tab, int n_dim,
-	const double *A, double *L, double *Linv, const double *b, double *w, int *p_flag, hipStream_t stream);
+bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, int n_width /* tasks per wave: 16, 32 or 64 */,
+	const int32_t *prog, const int64_t *tab, int n_dim,
+	const double *A, double *L, double *Linv, const double *b, double *w, int *p_flag, hipStream_t stream,
+	long long *p_timing = 0 /* development aid, as TDevPlan::p_timing */);
 
 // numeric factorization of one stage, with the forward substitution y = L^-1 b fused in
 // (b is read at its original position, y written to the permuted workspace w)

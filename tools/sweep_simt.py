@@ -1,0 +1,29 @@
+"""Dev helper: C3 phase times for the lane-per-task kernel's width / number of stages."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from slam_plus_plus_amd import synth
+from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP
+lam = synth.pose_chain(n=int(sys.argv[1]) if len(sys.argv) > 1 else 100000)
+dev = torch.device("cuda:0")
+vals = torch.from_numpy(lam.values).to(dev)
+for opts in ({"simt": 0}, {"simt_width": 64}, {"simt_width": 32}, {"simt_width": 16}, {"simt_width": 32, "simt_stages": 1},
+             {"simt_width": 16, "simt_stages": 1}, {"simt_width": 16, "simt_stages": 2}, {"simt_width": 16, "subtree_size": 6},
+             {"simt_width": 16, "subtree_size": 5, "simt_stages": 1}, {"simt_width": 16, "subtree_size": 12, "simt_stages": 1}):
+    s = CLinearSolver_HIP(**opts)
+    s.SymbolicDecomposition_Blocky(lam)
+    reps = 20
+    bufs = [torch.from_numpy(lam.rhs).to(dev) for _ in range(2 * reps + 1)]
+    torch.cuda.synchronize()
+    assert s.factor_solve_device(vals.data_ptr(), bufs[0].data_ptr())
+    t0 = time.perf_counter()
+    for b in bufs[1:reps + 1]:
+        s.factor_solve_device_async(vals.data_ptr(), b.data_ptr())
+    s.sync(); dt = (time.perf_counter() - t0) / reps
+    s.set_option("profile", 1); s.profile(reset=True)
+    for b in bufs[reps + 1:]:
+        s.factor_solve_device_async(vals.data_ptr(), b.data_ptr())
+    s.sync()
+    x = bufs[-1].cpu().numpy()
+    res = np.abs(lam.to_scipy() @ x - lam.rhs).max() / np.abs(lam.rhs).max()
+    print(opts, f"factor+solve {dt*1e3:.3f} ms  resid {res:.1e}  " + "  ".join(f"{k}={ms/max(c,1)*1e3:.0f}us" for k, (c, ms) in s.profile().items()), flush=True)
