@@ -41,6 +41,7 @@ struct CSchurState {
 	CDevArray<int64_t> d_cam_ptr;   // [nc+1]
 	CDevArray<int32_t> d_cam_obs;   // [n_obs] observations of every camera, ascending
 	CDevArray<double> d_S, d_W, d_Cinv, d_t, d_invdiag, d_z, d_x;
+	CDevArray<int> d_chol_sync; // tickets and flags of the dense factorization (dense_chol.h)
 	// multi-GPU: the all-reduce moves only the blocks of S that are nonzero on some rank
 	std::vector<int32_t> h_blk_row, h_blk_col; // this rank's nonzero blocks of S (lower triangle; camera indices)
 	slampp_hip_allreduce_fn p_union_fn;        // the callback the union below was agreed through
@@ -255,7 +256,7 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 		S.d_ent_uoff.Upload(ent_uoff, st);
 		S.d_cam_ptr.Upload(cam_ptr, st);
 		S.d_cam_obs.Upload(cam_obs, st);
-		S.d_W.Alloc(size_t(S.n_obs) * DC * DP);
+		S.d_W.Alloc(size_t(S.n_obs) * schur_w_stride(DC * DP));
 		S.d_Cinv.Alloc(size_t(np) * DP * DP);
 		S.d_t.Alloc(size_t(S.n_obs) * DP);
 		s.d_flag.Alloc(1);
@@ -405,7 +406,7 @@ __global__ void schur_obs_W_kernel(int64_t n_obs, int64_t ubase, const int32_t *
 			#pragma unroll
 			for(int k = 0; k < DP; ++ k)
 				t += u[r + k * DC] * ci[k + q * DP];
-			W[o * (DC * DP) + r + q * DC] = t;
+			W[o * schur_w_stride(DC * DP) + r + q * DC] = t;
 		}
 }
 
@@ -468,7 +469,7 @@ schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *s
 				const int32_t a = __builtin_amdgcn_readlane(my_a, idx);
 				const int64_t u = (int64_t(__builtin_amdgcn_readlane(int(my_u >> 32), idx)) << 32) |
 					uint32_t(__builtin_amdgcn_readlane(int(my_u), idx));
-				const int64_t w_at = w_rel + int64_t(a) * BLK; // wave-uniform, like u
+				const int64_t w_at = w_rel + int64_t(a) * schur_w_stride(BLK); // wave-uniform, like u
 				v[j] = A[(b_u? u : w_at) + lane_off];
 			}
 			if(lane < 2 * BLK) {
@@ -531,7 +532,7 @@ schur_rhs_kernel(const int64_t *cam_ptr, const int32_t *cam_obs, const int32_t *
 	const int64_t e1 = cam_ptr[c + 1];
 	for(int64_t e = cam_ptr[c] + lane; e < e1; e += 64) {
 		const int64_t o = cam_obs[e];
-		const double *Wo = W + o * (DC * DP), *l = eta + n + int64_t(obs_pt[o]) * DP;
+		const double *Wo = W + o * schur_w_stride(DC * DP), *l = eta + n + int64_t(obs_pt[o]) * DP;
 		#pragma unroll
 		for(int t = 0; t < DP; ++ t) {
 			const double lt = l[t];
@@ -771,6 +772,7 @@ static void schur_setup_reduced(slampp_hip_solver &s, CSchurState &S)
 	if(!S.b_reduced_sparse) { // the dense buffers are only needed now
 		S.d_S.Alloc(size_t(S.Npad) * S.Npad);
 		S.d_invdiag.Alloc(size_t(S.Npad / dense_NB) * dense_NB * dense_NB);
+		S.d_chol_sync.Alloc(size_t(2 * (S.Npad / dense_NB)));
 		S.d_z.Alloc(S.Npad);
 		S.d_x.Alloc(S.Npad);
 		if(s.p_allreduce && !S.b_union_dense)
@@ -969,7 +971,7 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 		p_dx = p_r;
 	} else {
 		s.Phase_Begin("dense_chol");
-		dense_cholesky(p_S, ld, n, S.d_invdiag.p(), s.d_flag.p(), st);
+		dense_cholesky(p_S, ld, n, S.d_invdiag.p(), s.d_flag.p(), S.d_chol_sync.p(), st);
 		s.Phase_End();
 		s.Phase_Begin("dense_solve");
 		dense_backsolve(p_S, ld, n, S.d_invdiag.p(), S.d_z.p(), S.d_x.p(), st);
@@ -1159,6 +1161,7 @@ static void schur_enqueue_marginals_t(slampp_hip_solver &s, CSchurState &S, cons
 		S.d_m_S.Alloc(size_t(ld) * ld);
 		S.d_m_Z.Alloc(size_t(ld) * ld);
 		S.d_m_invdiag.Alloc(size_t(ld / dense_NB) * dense_NB * dense_NB);
+		S.d_chol_sync.Alloc(size_t(2 * (ld / dense_NB)));
 		S.d_m_zero.Alloc(size_t(n));
 		SLAMPP_HIP_CHECK(hipMemsetAsync(S.d_m_zero.p(), 0, size_t(n) * sizeof(double), st));
 	}
@@ -1196,7 +1199,7 @@ static void schur_enqueue_marginals_t(slampp_hip_solver &s, CSchurState &S, cons
 		s.Phase_End();
 	}
 	s.Phase_Begin("marginals_factor");
-	dense_cholesky(p_S, ld, n, S.d_m_invdiag.p(), s.d_flag.p(), st);
+	dense_cholesky(p_S, ld, n, S.d_m_invdiag.p(), s.d_flag.p(), S.d_chol_sync.p(), st);
 	s.Phase_End();
 	s.Phase_Begin("marginals_inverse");
 	dense_inverse_from_factor(p_S, ld, S.d_m_invdiag.p(), S.d_m_Z.p(), st);

@@ -126,6 +126,7 @@ struct slampp_hip_solver {
 	slampp::CDevArray<slampp::TDenseBlk> d_dense_blks;
 	slampp::CDevArray<slampp::TDenseCol> d_dense_cols;
 	slampp::CDevArray<double> d_dense, d_dense_invdiag, d_dense_z, d_dense_x;
+	slampp::CDevArray<int> d_dense_sync; // tickets and flags of the dense factorization (dense_chol.h)
 	slampp::CDevArray<int32_t> d_dense_gaps; // positions inside the dense top that no column maps to (alignment padding)
 	int n_dense_gaps;
 	slampp::CTileSchedule dense_tiles; // level schedule over the nonzero tiles of the dense top (dense_chol.h)
@@ -185,6 +186,10 @@ struct slampp_hip_solver {
 
 
 namespace slampp {
+
+// W = U C^-1 is stored one record per observation, the records padded to whole 64-byte sectors (18 doubles -> 24 for
+// 6 x 3 blocks): a record that starts on a sector boundary is 3 sectors to fetch, one that straddles them 3 or 4
+inline constexpr int schur_w_stride(int n_block_doubles) { return (n_block_doubles * 8 + 63) / 64 * 8; }
 
 // Schur path entry points (schur.hip)
 void schur_destroy(CSchurState *p);
