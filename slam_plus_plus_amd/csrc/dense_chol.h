@@ -21,10 +21,8 @@ void dense_prepare_gaps(double *M, int n_pad, const int32_t *p_positions_dev, in
 // lower triangle is read or written.  Row n_pad-1 carries the right-hand side, so after the call
 // L(n_pad-1, 0:n) = y^T = (L^-1 rhs)^T (forward substitution fused into the panel updates).
 // p_invdiag: workspace (n_pad / 64) * 64 * 64 doubles, receives inv(L_kk) of every diagonal tile.
-// p_sync: workspace of 2 * (n_pad / 64) ints (tickets and "tile factored" flags of the one-launch-per-tile schedule), or
-// null for the schedule with two launches per tile.
-// Sets *p_flag |= 1 if a pivot of a row < n is not positive (|= 4: a wait inside a launch gave up -- a bug, never seen).
-void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag, int *p_sync, hipStream_t stream);
+// Sets *p_flag |= 1 if a pivot of a row < n is not positive.
+void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag, hipStream_t stream);
 
 // Tile-sparse variant for the dense top of the sparse path: the separators assembled into one dense matrix still
 // form a tree, so many 64 x 64 tiles are structurally zero and tile columns in different subtrees are independent.

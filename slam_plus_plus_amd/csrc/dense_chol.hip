@@ -14,7 +14,6 @@
 // costs nothing extra; the backward substitution is right-looking, one launch per panel.
 // This is the MFMA-bound kernel of the path: n^3/3 flops (72 GFLOP at 1k cameras).
 #include <hip/hip_runtime.h>
-#include <stdlib.h>
 #include "dense_chol.h"
 
 namespace slampp {
@@ -189,131 +188,6 @@ potrf_diag_kernel(double *M, int ld, int kb, int n, double *invL, int *p_flag, i
 	syrk_tile(M, ld, n_blocks, t_job.k0, t_job.k1, t_job.c0, t_job.c1, t_job.tile0 + idx, s_buf, s_buf + NB * NB);
 }
 
-// ---- one launch per 64 columns: diagonal tile, panel solve and the panel's own updates together ----
-// The chain potrf -> trsm costs a launch boundary per kernel and keeps the rows below waiting through the whole
-// factorization of the diagonal tile.  Here both live in one launch.  Workgroups take their role from a ticket (an
-// atomic counter, so that the role every other one waits for is always held by a running workgroup, whatever order the
-// hardware starts them in):
-//   ticket 0            factors and inverts the diagonal tile kb, then raises done[kb] (release at agent scope);
-//   tickets 1 .. below  row tile i = kb + ticket: while ticket 0 works they bring their tile of column kb up to date --
-//                       A(i,kb) -= sum over the panel's earlier tiles kk of L(i,kk) L(kb,kk)^T, the updates the
-//                       right-looking schedule ran as separate jobs after every step (left-looking inside the outer
-//                       panel now, same flops, hidden in the wait) -- then wait for done[kb], multiply by inv(L_kk)^T and
-//                       store L(i,kb); ticket 1 also finishes the next diagonal tile, A(kb+1,kb+1) -= sum over the
-//                       panel's tiles kk <= kb of L(kb+1,kk) L(kb+1,kk)^T, so that the next launch can start factoring;
-//   the other tickets   tiles of the symmetric updates that do not depend on this step (panel b + 1 by the previous
-//                       tile, panels >= b + 2 by panel b - 1), as before.
-// A spin that outlasts any sane wait sets bit 2 of *p_flag and goes on (wrong numbers, reported, instead of a hang).
-__device__ __forceinline__ void wait_for_tile(const int *p_done, int *p_flag)
-{
-	if(threadIdx.x == 0) {
-		int n_spins = 0;
-		while(__hip_atomic_load(p_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-			__builtin_amdgcn_s_sleep(1);
-			if(++ n_spins > (1 << 24)) {
-				atomicOr(p_flag, 4);
-				break;
-			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-	}
-	__syncthreads();
-}
-
-__global__ void __launch_bounds__(256)
-chol_step_kernel(double *M, int ld, int kb, int t0, int b_update_next, int n, double *p_invdiag, int *p_flag, int n_blocks,
-	int *p_sync, TSyrkJob t_job_a, TSyrkJob t_job_b)
-{
-	__shared__ double s_buf[(int(POTRF_LDS_DOUBLES) > 2 * NB * NB)? int(POTRF_LDS_DOUBLES) : 2 * NB * NB];
-	__shared__ int s_ticket;
-	if(threadIdx.x == 0)
-		s_ticket = atomicAdd(p_sync + kb, 1);
-	__syncthreads();
-	const int ticket = s_ticket;
-	int *p_done = p_sync + n_blocks + kb;
-	double *invL = p_invdiag + size_t(kb) * NB * NB;
-	const int n_below = n_blocks - kb - 1;
-	if(ticket == 0) {
-		potrf_diag_body<true, true>(M, ld, kb, n, invL, p_flag, s_buf);
-		__syncthreads(); // every wave's stores are out (the barrier waits for them)
-		if(threadIdx.x == 0) {
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			__hip_atomic_store(p_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		return;
-	}
-	if(ticket > n_below) {
-		int idx = ticket - n_below - 1;
-		TSyrkJob t_job = t_job_a;
-		if(idx >= t_job_a.n_tiles) {
-			idx -= t_job_a.n_tiles;
-			t_job = t_job_b;
-		}
-		syrk_tile(M, ld, n_blocks, t_job.k0, t_job.k1, t_job.c0, t_job.c1, t_job.tile0 + idx, s_buf, s_buf + NB * NB);
-		return;
-	}
-	double *Ps = s_buf, *Qs = s_buf + NB * NB;
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int lo = lane & 15, hi = lane >> 4;
-	const int row0 = (kb + ticket) * NB, col0 = kb * NB;
-	const bool b_diag = b_update_next && ticket == 1; // workgroup-uniform
-	// the tile of column kb and, for ticket 1, the next diagonal tile are requested now
-	double cv[4][4], dv[4][4];
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c) {
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg) {
-			cv[c][reg] = M[size_t(row0 + 16 * c + lo) + size_t(col0 + 16 * wave + hi + 4 * reg) * ld];
-			if(b_diag)
-				dv[c][reg] = M[size_t(row0 + 16 * c + lo) + size_t(row0 + 16 * wave + hi + 4 * reg) * ld];
-		}
-	}
-	v4f64 pre[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-	v4f64 upd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-	for(int kk = t0; kk < kb; ++ kk) { // the panel's earlier tiles: left-looking update of this tile (and of the next diagonal tile)
-		if(kk > t0)
-			__syncthreads(); // the previous pair of operand tiles has been consumed
-		load_tile(Ps, M, ld, row0, kk * NB);
-		load_tile(Qs, M, ld, col0, kk * NB);
-		__syncthreads();
-		tile_product(Ps, Qs, wave, lane, pre);
-		if(b_diag)
-			tile_product(Ps, Ps, wave, lane, upd);
-	}
-	__syncthreads();
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			Ps[lds_at(16 * wave + hi + 4 * reg, 16 * c + lo)] = cv[c][reg] - pre[c][reg]; // the updated tile as an operand: [k = column][row]
-	wait_for_tile(p_done, p_flag); // (its barrier also publishes Ps)
-	load_tile(Qs, invL, NB, 0, 0);
-	__syncthreads();
-	v4f64 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-	tile_product(Ps, Qs, wave, lane, acc);
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			M[size_t(row0 + 16 * c + lo) + size_t(col0 + 16 * wave + hi + 4 * reg) * ld] = acc[c][reg];
-	if(!b_diag)
-		return;
-	__syncthreads(); // every wave is done with Ps
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			Ps[lds_at(16 * wave + hi + 4 * reg, 16 * c + lo)] = acc[c][reg]; // L(kb+1,kb) as an operand
-	__syncthreads();
-	tile_product(Ps, Ps, wave, lane, upd);
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			M[size_t(row0 + 16 * c + lo) + size_t(row0 + 16 * wave + hi + 4 * reg) * ld] = dv[c][reg] - upd[c][reg];
-}
-
 enum { OUTER_TILES = 4 }; // outer panel = 4 x 64 columns
 
 static inline int n_syrk_tiles(int n_blocks, int c0, int c1)
@@ -342,7 +216,7 @@ static inline void launch_syrk(double *M, int n_pad, int n_blocks, int k0, int k
 //   every potrf of panel b           carries  a slice of the K = 256 update of panels >= b + 2 by panel b - 1.
 // Only the 64-wide update of panel b + 1 by the last tile of panel b separates two chains.  Launches on one
 // stream serialize the writers of every target tile, and inside one launch no two workgroups share a target.
-static void dense_cholesky_two_launches(double *M, int n_pad, int n, double *p_invdiag, int *p_flag, hipStream_t stream)
+void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag, hipStream_t stream)
 {
 	const int n_blocks = n_pad / NB;
 	const int n_outer = (n_blocks + OUTER_TILES - 1) / OUTER_TILES;
@@ -371,48 +245,6 @@ static void dense_cholesky_two_launches(double *M, int n_pad, int n, double *p_i
 			const int n_below = n_blocks - kb - 1;
 			if(n_below > 0)
 				hipLaunchKernelGGL(trsm_kernel, dim3(n_below), dim3(256), 0, stream, M, n_pad, kb, invL, int(kb + 1 < t1));
-		}
-		launch_syrk(M, n_pad, n_blocks, t1 - 1, t1, u0, u1, stream); // the last tile's update of the next panel
-	}
-}
-
-// The schedule with one launch per tile (chol_step_kernel).  What rides along is what does not depend on the step:
-//   step of tile k >= 1 of panel b  carries  the 64-wide update of panel b + 1 by tile k - 1,
-//   step of tile 0 of panel b       carries  the K = 256 update of panel b + 1 by panel b - 1,
-//   every step of panel b           carries  a slice of the K = 256 update of panels >= b + 2 by panel b - 1;
-// the updates inside panel b are done by the row workgroups themselves while they wait (see the kernel).  Between two
-// panels one launch remains: the 64-wide update of panel b + 1 by the last tile of panel b.
-void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag, int *p_sync, hipStream_t stream)
-{
-	static const bool b_two_launches = getenv("SLAMPP_HIP_DENSE_TWO_LAUNCHES") != 0; // development aid: A/B timing
-	if(!p_sync || b_two_launches) {
-		dense_cholesky_two_launches(M, n_pad, n, p_invdiag, p_flag, stream);
-		return;
-	}
-	const int n_blocks = n_pad / NB;
-	const int n_outer = (n_blocks + OUTER_TILES - 1) / OUTER_TILES;
-	(void)hipMemsetAsync(p_sync, 0, size_t(2 * n_blocks) * sizeof(int), stream);
-	for(int b = 0; b < n_outer; ++ b) {
-		const int t0 = b * OUTER_TILES, t1 = (t0 + OUTER_TILES < n_blocks)? t0 + OUTER_TILES : n_blocks;
-		const int u0 = t1, u1 = (u0 + OUTER_TILES < n_blocks)? u0 + OUTER_TILES : n_blocks; // panel b + 1
-		const int v0 = u1;                                                                   // panel b + 2 onwards
-		const int p0 = t0 - OUTER_TILES, p1 = t0;                                            // panel b - 1
-		const int n_next_tiles = n_syrk_tiles(n_blocks, u0, u1);
-		const int n_far_tiles = (b > 0)? n_syrk_tiles(n_blocks, v0, n_blocks) : 0;
-		for(int kb = t0; kb < t1; ++ kb) {
-			const int k = kb - t0, m = t1 - t0;
-			TSyrkJob t_near = {0, 0, 0, 0, 0, 0}, t_far = {0, 0, 0, 0, 0, 0};
-			if(k > 0)
-				t_near = TSyrkJob{kb - 1, kb, u0, u1, 0, n_next_tiles};
-			else if(b > 0)
-				t_near = TSyrkJob{p0, p1, u0, u1, 0, n_next_tiles};
-			if(n_far_tiles > 0) {
-				const int n_begin = int(int64_t(n_far_tiles) * k / m), n_end = int(int64_t(n_far_tiles) * (k + 1) / m);
-				t_far = TSyrkJob{p0, p1, v0, n_blocks, n_begin, n_end - n_begin};
-			}
-			const int n_below = n_blocks - kb - 1;
-			hipLaunchKernelGGL(chol_step_kernel, dim3(1 + n_below + t_near.n_tiles + t_far.n_tiles), dim3(256), 0, stream,
-				M, n_pad, kb, t0, int(kb + 1 < t1), n, p_invdiag, p_flag, n_blocks, p_sync, t_near, t_far);
 		}
 		launch_syrk(M, n_pad, n_blocks, t1 - 1, t1, u0, u1, stream); // the last tile's update of the next panel
 	}

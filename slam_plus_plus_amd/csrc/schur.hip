@@ -41,7 +41,6 @@ struct CSchurState {
 	CDevArray<int64_t> d_cam_ptr;   // [nc+1]
 	CDevArray<int32_t> d_cam_obs;   // [n_obs] observations of every camera, ascending
 	CDevArray<double> d_S, d_W, d_Cinv, d_t, d_invdiag, d_z, d_x;
-	CDevArray<int> d_chol_sync; // tickets and flags of the dense factorization (dense_chol.h)
 	// multi-GPU: the all-reduce moves only the blocks of S that are nonzero on some rank
 	std::vector<int32_t> h_blk_row, h_blk_col; // this rank's nonzero blocks of S (lower triangle; camera indices)
 	slampp_hip_allreduce_fn p_union_fn;        // the callback the union below was agreed through
@@ -772,7 +771,6 @@ static void schur_setup_reduced(slampp_hip_solver &s, CSchurState &S)
 	if(!S.b_reduced_sparse) { // the dense buffers are only needed now
 		S.d_S.Alloc(size_t(S.Npad) * S.Npad);
 		S.d_invdiag.Alloc(size_t(S.Npad / dense_NB) * dense_NB * dense_NB);
-		S.d_chol_sync.Alloc(size_t(2 * (S.Npad / dense_NB)));
 		S.d_z.Alloc(S.Npad);
 		S.d_x.Alloc(S.Npad);
 		if(s.p_allreduce && !S.b_union_dense)
@@ -971,7 +969,7 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 		p_dx = p_r;
 	} else {
 		s.Phase_Begin("dense_chol");
-		dense_cholesky(p_S, ld, n, S.d_invdiag.p(), s.d_flag.p(), S.d_chol_sync.p(), st);
+		dense_cholesky(p_S, ld, n, S.d_invdiag.p(), s.d_flag.p(), st);
 		s.Phase_End();
 		s.Phase_Begin("dense_solve");
 		dense_backsolve(p_S, ld, n, S.d_invdiag.p(), S.d_z.p(), S.d_x.p(), st);
@@ -1161,7 +1159,6 @@ static void schur_enqueue_marginals_t(slampp_hip_solver &s, CSchurState &S, cons
 		S.d_m_S.Alloc(size_t(ld) * ld);
 		S.d_m_Z.Alloc(size_t(ld) * ld);
 		S.d_m_invdiag.Alloc(size_t(ld / dense_NB) * dense_NB * dense_NB);
-		S.d_chol_sync.Alloc(size_t(2 * (ld / dense_NB)));
 		S.d_m_zero.Alloc(size_t(n));
 		SLAMPP_HIP_CHECK(hipMemsetAsync(S.d_m_zero.p(), 0, size_t(n) * sizeof(double), st));
 	}
@@ -1199,7 +1196,7 @@ static void schur_enqueue_marginals_t(slampp_hip_solver &s, CSchurState &S, cons
 		s.Phase_End();
 	}
 	s.Phase_Begin("marginals_factor");
-	dense_cholesky(p_S, ld, n, S.d_m_invdiag.p(), s.d_flag.p(), S.d_chol_sync.p(), st);
+	dense_cholesky(p_S, ld, n, S.d_m_invdiag.p(), s.d_flag.p(), st);
 	s.Phase_End();
 	s.Phase_Begin("marginals_inverse");
 	dense_inverse_from_factor(p_S, ld, S.d_m_invdiag.p(), S.d_m_Z.p(), st);

@@ -205,7 +205,6 @@ void slampp_hip_solver::Free_Device()
 	d_simt_chunks.Free(); d_simt_prog.Free(); d_simt_rest.Free(); d_simt_tab.Free();
 	simt_chunk_ptr.clear(); simt_rest_ptr.clear();
 	d_dense_blks.Free(); d_dense_cols.Free(); d_dense.Free(); d_dense_invdiag.Free(); d_dense_z.Free(); d_dense_x.Free();
-	d_dense_sync.Free();
 	n_dense_blks = n_dense_cols = n_dense_dim = n_dense_pad = 0;
 	dense_tiles.Free();
 	b_dense_tiles = false;
@@ -462,7 +461,6 @@ void slampp_hip_solver::Analyze_Sparse()
 		}
 		d_dense.Alloc(size_t(n_dense_pad) * n_dense_pad);
 		d_dense_invdiag.Alloc(size_t(n_dense_pad / dense_NB) * dense_NB * dense_NB);
-		d_dense_sync.Alloc(size_t(2 * (n_dense_pad / dense_NB)));
 		d_dense_z.Alloc(n_dense_pad);
 		d_dense_x.Alloc(n_dense_pad);
 		// which 64 x 64 tiles of the dense top are structurally nonzero, and how long the dependent chain is if only
@@ -736,7 +734,7 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			if(b_dense_tiles)
 				tile_cholesky(dense_tiles, d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), d_flag.p(), stream);
 			else
-				dense_cholesky(d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), d_flag.p(), d_dense_sync.p(), stream);
+				dense_cholesky(d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), d_flag.p(), stream);
 			Phase_End();
 		} else {
 			Phase_Begin("dense_forward");
@@ -1058,10 +1056,6 @@ int slampp_hip_sync(slampp_hip_solver *p_solver)
 				fprintf(stderr, " us\n");
 			}
 			SLAMPP_HIP_CHECK(hipMemset(s.d_timing.p(), 0, tm.size() * sizeof(long long)));
-		}
-		if(*s.p_host_flag & 4) {
-			s.b_factored = false;
-			return fail(p_solver, SLAMPP_HIP_ERR_DEVICE, "a wait inside the dense factorization gave up");
 		}
 		if(*s.p_host_flag) {
 			s.b_factored = false;
