@@ -58,7 +58,7 @@ typedef struct slampp_hip_stats {
 	int64_t n_stages, n_tasks, etree_height, n_update_pairs;
 	int64_t n_cams, n_points, n_observations, schur_dim;     /* Schur path, else 0 (sparse path: schur_dim = dimension of the dense top) */
 	int64_t device_bytes;
-	int64_t n_bottom_stages;          /* leading stages run by the one-wave-per-task kernel (factor_subtree_kernel) */
+	int64_t n_bottom_stages;          /* leading (wide) stages: stage 0 by the lane-per-task kernel, the others one wave per task */
 } slampp_hip_stats;
 
 /* lifecycle -- stands in for the solver object's ctor / dtor / Free_Memory()
@@ -191,7 +191,7 @@ int slampp_hip_get_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_
 /* device-side phase timing (the counterpart of the reference's __SCHUR_PROFILING / CTimerSampler
  * phase timers, LinearSolver_Schur.h:1681-1912, Timer.h:391): with option "profile" = 1 every phase
  * of factor_solve is bracketed by HIP events on the solver's stream; the totals are collected at
- * slampp_hip_sync().  Phases: factor_subtree, factor_upper, forward, backward (sparse path);
+ * slampp_hip_sync().  Phases: factor_leaves, factor_wide, factor_upper, forward, backward (sparse path);
  * schur_points, schur_gather, schur_rhs, dense_chol, dense_solve, backsubst (Schur path). */
 typedef struct slampp_hip_phase_time {
 	char name[32];

@@ -91,6 +91,15 @@ __device__ __forceinline__ void store_block(double *p, const double (&m)[D][D]) 
 	}
 }
 
+// position of the next column's header in the program, given the position right behind this column's touch list
+__device__ __forceinline__ int pc_next_column(const int32_t *P, int pc, int nb, int nr)
+{
+	pc += 2 * nr;
+	for(int kb = 1; kb < nb; ++ kb)
+		pc += 1 + 2 * P[pc];
+	return pc;
+}
+
 template <int D, int W> // W = tasks (busy lanes) per wave
 __global__ void __launch_bounds__(64)
 factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restrict__ prog, const long long *__restrict__ tab,
@@ -98,7 +107,15 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 	long long *p_timing)
 {
 	enum { DD = D * D };
+	extern __shared__ long long s_tab[]; // the chunk's table of per-lane offsets: fetched once, in one go, instead of a
+	// trip to memory in front of every operand
 	const TSimtChunk ch = chunks[blockIdx.x];
+	{
+		const int n_entries = (4 * prog[ch.prog_off] + prog[ch.prog_off + 1] + prog[ch.prog_off + 2] + prog[ch.prog_off + 3]) * W;
+		for(int i = threadIdx.x; i < n_entries; i += 64)
+			s_tab[i] = tab[ch.tab_off + i];
+		__syncthreads();
+	}
 	if(int(threadIdx.x) >= W)
 		return; // (no barrier below)
 	long long *p_tm = 0; // development aid (SLAMPP_HIP_STAGE_TIMING): clock samples of a wave in the middle of the grid
@@ -109,15 +126,26 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 	}
 #define SIMT_TICK() do { if(p_tm && n_tm < 32) p_tm[n_tm ++] = wall_clock64(); } while(0)
 	const int32_t *P = prog + ch.prog_off;                 // wave-uniform: scalar loads
-	const long long *T = tab + ch.tab_off + threadIdx.x;   // field f of this lane's task at T[W f]
+	const long long *T = s_tab + threadIdx.x;              // field f of this lane's task at T[W f]
 	const int n_cols = P[0], n_blocks = P[1], n_ops = P[2];
 	const int f_blk = 4 * n_cols, f_op = f_blk + n_blocks, f_y = f_op + n_ops;
 	int pc = 4, blk0 = 0;
 	bool b_bad = false;
+	double f_touched = 0; // keeps the early loads alive
 	for(int ci = 0; ci < n_cols; ++ ci) {
 		const int nb = P[pc], nr = P[pc + 1], n_touch = P[pc + 2];
 		pc += 3;
 		pc += n_touch; // (the column's distinct operands, for a variant that requested their lines ahead: measured slower)
+		// the Lambda blocks of the next column come from memory nobody has touched yet: one load per cache line of each goes
+		// out now, a whole column of arithmetic ahead of their use
+		if(ci + 1 < n_cols) {
+			const int nb_next = P[pc_next_column(P, pc, nb, nr)];
+			for(int kb = 0; kb < nb_next; ++ kb) {
+				const long long enc = T[W * (f_blk + blk0 + nb + kb)];
+				const double *p_src = A + ((enc < 0)? 0 : (enc >> 1));
+				f_touched += p_src[0] + p_src[16] + p_src[DD - 1];
+			}
+		}
 		const long long l_base = T[W * (4 * ci)], linv_off = T[W * (4 * ci + 1)], cs_new = T[W * (4 * ci + 2)],
 			cs_src = T[W * (4 * ci + 3)];
 		double a[D][D], y[D]; // a: lower triangle of the diagonal block
@@ -291,17 +319,17 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 		// (what a lane loads in the following columns is what the lane itself has stored, or what an earlier launch
 		// has: program order of one thread, no fence)
 	}
-	if(b_bad)
+	if(b_bad || f_touched == 1.2345e301) // (never equal: the sum only has to be used)
 		atomicOr(p_flag, 1);
 }
 
-bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, int n_width, const int32_t *prog, const int64_t *tab, int n_dim,
+bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, int n_width, int n_lds_bytes, const int32_t *prog, const int64_t *tab, int n_dim,
 	const double *A, double *L, double *Linv, const double *b, double *w, int *p_flag, hipStream_t stream, long long *p_timing)
 {
 	if(n_chunks <= 0)
 		return true;
 	const long long *t = reinterpret_cast<const long long*>(tab);
-#define SIMT_LAUNCH(D_, W_) hipLaunchKernelGGL((factor_simt_kernel<D_, W_>), dim3(n_chunks), dim3(64), 0, stream, chunks, prog, t, \
+#define SIMT_LAUNCH(D_, W_) hipLaunchKernelGGL((factor_simt_kernel<D_, W_>), dim3(n_chunks), dim3(64), n_lds_bytes, stream, chunks, prog, t, \
 	A, L, Linv, b, w, p_flag, p_timing)
 #define SIMT_WIDTHS(D_) do { if(n_width == 16) SIMT_LAUNCH(D_, 16); else if(n_width == 32) SIMT_LAUNCH(D_, 32); \
 	else SIMT_LAUNCH(D_, 64); } while(0)

@@ -534,10 +534,11 @@ void slampp_hip_solver::Build_Simt()
 {
 	simt_chunk_ptr.clear();
 	simt_rest_ptr.clear();
+	simt_lds_bytes.clear();
 	const Plan &P = plan;
 	if(!n_simt || !P.uniform_dim || (P.max_dim != 3 && P.max_dim != 6 && P.max_dim != 7))
 		return;
-	enum { MIN_GROUP = 1, MAX_PROG = 4096, MAX_FIELDS = 1024 }; // (rare shapes run with few busy lanes, beside the others: cheaper than a launch of their own)
+	enum { MIN_GROUP = 1, MAX_PROG = 4096, MAX_TABLE_BYTES = 40960 }; // (rare shapes run with few busy lanes, beside the others: cheaper than a launch of their own)
 	const int n_stages = int(P.stage_ptr.size()) - 1;
 	std::vector<TSimtChunk> chunks;
 	std::vector<int32_t> prog_all, rest;
@@ -549,6 +550,7 @@ void slampp_hip_solver::Build_Simt()
 	const size_t W = size_t(n_simt_width);
 	for(int s = 0; s < n_bottom_stages && s < n_stages && s < n_simt_stages; ++ s) {
 		std::map<std::vector<int32_t>, std::vector<TTask> > groups;
+		int32_t n_stage_lds = 0;
 		for(int32_t t = P.stage_ptr[s]; t < P.stage_ptr[s + 1]; ++ t) {
 			std::vector<int32_t> prog(4, 0);
 			TTask tt;
@@ -606,7 +608,7 @@ void slampp_hip_solver::Build_Simt()
 			prog[1] = n_blocks;
 			prog[2] = int32_t(tt.ops.size());
 			prog[3] = int32_t(tt.ys.size());
-			if(!b_fits || 4 * n_cols + n_blocks + int32_t(tt.ops.size() + tt.ys.size()) > MAX_FIELDS)
+			if(!b_fits || size_t(4 * n_cols + n_blocks) + tt.ops.size() + tt.ys.size() > MAX_TABLE_BYTES / (8 * W)) // (the table is staged in LDS)
 				rest.push_back(t);
 			else
 				groups[prog].push_back(std::move(tt));
@@ -623,6 +625,7 @@ void slampp_hip_solver::Build_Simt()
 			prog_all.insert(prog_all.end(), prog.begin(), prog.end());
 			const int n_cols = prog[0], n_blocks = prog[1], n_ops = prog[2], n_ys = prog[3];
 			const int n_fields = 4 * n_cols + n_blocks + n_ops + n_ys;
+			n_stage_lds = std::max(n_stage_lds, int32_t(n_fields * W * 8));
 			for(size_t n_first = 0; n_first < tasks.size(); n_first += W) {
 				const size_t n_in_chunk = std::min<size_t>(W, tasks.size() - n_first);
 				TSimtChunk ch;
@@ -659,6 +662,7 @@ void slampp_hip_solver::Build_Simt()
 		std::sort(rest.begin() + simt_rest_ptr.back(), rest.end());
 		simt_chunk_ptr.push_back(int32_t(chunks.size()));
 		simt_rest_ptr.push_back(int32_t(rest.size()));
+		simt_lds_bytes.push_back(n_stage_lds);
 	}
 	if(chunks.empty()) {
 		simt_chunk_ptr.clear();
@@ -688,12 +692,18 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 		// the lane-per-task kernel reads blocks and vectors with 16-byte loads where the block dimension is even
 		const bool b_simt = !simt_chunk_ptr.empty() && (P.max_dim % 2 != 0 ||
 			((reinterpret_cast<uintptr_t>(p_values_dev) | reinterpret_cast<uintptr_t>(p_rhs_dev)) & 15) == 0);
+		// phases: the leaf subtrees (stage 0), the wide stages right above them, the separators further up
+		const int n_wide_end = std::min(n_bottom_stages, n_stages);
 		for(int s = 0; s < n_stages; ++ s) {
-			if(s == 0 || s == n_bottom_stages)
-				Phase_Begin(s? "factor_upper" : "factor_subtree");
+			if(s == 0)
+				Phase_Begin("factor_leaves");
+			else if(s == 1 && s < n_wide_end)
+				Phase_Begin("factor_wide");
+			else if(s == n_wide_end)
+				Phase_Begin("factor_upper");
 			if(b_simt && s + 1 < int(simt_chunk_ptr.size())) {
 				const int n_chunks = simt_chunk_ptr[s + 1] - simt_chunk_ptr[s], n_rest = simt_rest_ptr[s + 1] - simt_rest_ptr[s];
-				launch_factor_simt(d_simt_chunks.p() + simt_chunk_ptr[s], n_chunks, n_simt_width, d_simt_prog.p(), d_simt_tab.p(), P.max_dim,
+				launch_factor_simt(d_simt_chunks.p() + simt_chunk_ptr[s], n_chunks, n_simt_width, simt_lds_bytes[s], d_simt_prog.p(), d_simt_tab.p(), P.max_dim,
 					p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), d_flag.p(), stream, dplan.p_timing);
 				if(n_rest > 0) {
 					TDevPlan t_rest = dplan;
@@ -704,7 +714,7 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			} else
 			launch_factor_stage(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
 				P.stage_ptr[s + 1] - P.stage_ptr[s], s < n_bottom_stages, d_flag.p(), stream);
-			if(s == n_bottom_stages - 1 || s == n_stages - 1)
+			if(s == 0 || s == n_wide_end - 1 || s == n_stages - 1)
 				Phase_End();
 		}
 	} else {

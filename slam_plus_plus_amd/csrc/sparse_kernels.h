@@ -96,6 +96,7 @@ struct TSimtChunk { // 16 B
 
 // returns false if the block dimension has no such kernel
 bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, int n_width /* tasks per wave: 16, 32 or 64 */,
+	int n_lds_bytes /* the largest table of the chunks: fields x width x 8 */,
 	const int32_t *prog, const int64_t *tab, int n_dim,
 	const double *A, double *L, double *Linv, const double *b, double *w, int *p_flag, hipStream_t stream,
 	long long *p_timing = 0 /* development aid, as TDevPlan::p_timing */);

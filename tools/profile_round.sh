@@ -2,7 +2,7 @@
 # Collects the round's profiles on the GPU box (run through gpurun): kernel-trace stats for both workloads and,
 # in separate passes, the HBM traffic counters.  Usage: tools/profile_round.sh <tag>   (writes under gpurun_out/<tag>/)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT

@@ -7,9 +7,8 @@ from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP
 lam = synth.pose_chain(n=int(sys.argv[1]) if len(sys.argv) > 1 else 100000)
 dev = torch.device("cuda:0")
 vals = torch.from_numpy(lam.values).to(dev)
-for opts in ({"simt": 0}, {"simt_width": 64}, {"simt_width": 32}, {"simt_width": 16}, {"simt_width": 32, "simt_stages": 1},
-             {"simt_width": 16, "simt_stages": 1}, {"simt_width": 16, "simt_stages": 2}, {"simt_width": 16, "subtree_size": 6},
-             {"simt_width": 16, "subtree_size": 5, "simt_stages": 1}, {"simt_width": 16, "subtree_size": 12, "simt_stages": 1}):
+for opts in ({"simt": 0}, {"simt_width": 64, "simt_stages": 1}, {"simt_width": 32, "simt_stages": 1}, {"simt_width": 16, "simt_stages": 1},
+             {"simt_width": 32, "simt_stages": 4}, {"simt_width": 32, "simt_stages": 1, "subtree_size": 6}):
     s = CLinearSolver_HIP(**opts)
     s.SymbolicDecomposition_Blocky(lam)
     reps = 20
