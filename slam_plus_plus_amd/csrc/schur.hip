@@ -255,7 +255,7 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 		S.d_ent_uoff.Upload(ent_uoff, st);
 		S.d_cam_ptr.Upload(cam_ptr, st);
 		S.d_cam_obs.Upload(cam_obs, st);
-		S.d_W.Alloc(size_t(S.n_obs) * schur_w_stride(DC * DP));
+		S.d_W.Alloc(size_t(S.n_obs) * (DC * DP));
 		S.d_Cinv.Alloc(size_t(np) * DP * DP);
 		S.d_t.Alloc(size_t(S.n_obs) * DP);
 		s.d_flag.Alloc(1);
@@ -405,7 +405,7 @@ __global__ void schur_obs_W_kernel(int64_t n_obs, int64_t ubase, const int32_t *
 			#pragma unroll
 			for(int k = 0; k < DP; ++ k)
 				t += u[r + k * DC] * ci[k + q * DP];
-			W[o * schur_w_stride(DC * DP) + r + q * DC] = t;
+			W[o * (DC * DP) + r + q * DC] = t;
 		}
 }
 
@@ -434,13 +434,12 @@ schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *s
 	const bool b_act = lane < DC * DC;
 	const int r = b_act? lane % DC : 0, q = b_act? lane / DC : 0;
 	// Every lane loads (lanes past the two operand blocks repeat the last element: same cache line, no branch around
-	// the load), from one base pointer: lanes 0 .. BLK-1 the block U_b at A + u, the others W_a, addressed relative to A
-	// as well.  All of this is there to keep the wave-instruction count of an entry down -- with eight waves per SIMD
+	// the load): lanes 0 .. BLK-1 the block U_b at A + u, the others W_a at W_ + a BLK.  All of this is there to keep the
+	// wave-instruction count of an entry down -- with eight waves per SIMD
 	// resident the kernel is bound by instruction issue around its loads, not by the loads.
 	const int lane_c = (lane < 2 * BLK)? lane : 2 * BLK - 1;
 	const bool b_u = lane_c < BLK;
 	const int64_t lane_off = b_u? lane_c : lane_c - BLK;
-	const int64_t w_rel = W_ - A; // in doubles; both arrays live in the one flat device address space
 	typedef double v4f64 __attribute__((ext_vector_type(4)));
 	v4f64 macc = {0, 0, 0, 0};
 	// the MFMA fragment a lane reads for step q4 of a batch: entry, and offset of its element of U inside s_ops[wave]
@@ -468,8 +467,8 @@ schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *s
 				const int32_t a = __builtin_amdgcn_readlane(my_a, idx);
 				const int64_t u = (int64_t(__builtin_amdgcn_readlane(int(my_u >> 32), idx)) << 32) |
 					uint32_t(__builtin_amdgcn_readlane(int(my_u), idx));
-				const int64_t w_at = w_rel + int64_t(a) * schur_w_stride(BLK); // wave-uniform, like u
-				v[j] = A[(b_u? u : w_at) + lane_off];
+				const double *p_src = b_u? A + u : W_ + int64_t(a) * BLK; // two arrays, one load: the lane picks its base
+				v[j] = p_src[lane_off];
 			}
 			if(lane < 2 * BLK) {
 				#pragma unroll
@@ -531,7 +530,7 @@ schur_rhs_kernel(const int64_t *cam_ptr, const int32_t *cam_obs, const int32_t *
 	const int64_t e1 = cam_ptr[c + 1];
 	for(int64_t e = cam_ptr[c] + lane; e < e1; e += 64) {
 		const int64_t o = cam_obs[e];
-		const double *Wo = W + o * schur_w_stride(DC * DP), *l = eta + n + int64_t(obs_pt[o]) * DP;
+		const double *Wo = W + o * (DC * DP), *l = eta + n + int64_t(obs_pt[o]) * DP;
 		#pragma unroll
 		for(int t = 0; t < DP; ++ t) {
 			const double lt = l[t];

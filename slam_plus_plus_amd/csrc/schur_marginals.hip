@@ -12,8 +12,6 @@
 
 namespace slampp {
 
-inline constexpr int schur_w_stride(int n_block_doubles) { return (n_block_doubles * 8 + 63) / 64 * 8; } // as in solver.h
-
 // N contiguous doubles with 16-byte loads where the address allows it (blocks of 6 x 6 and 6 x 3 doubles start at
 // multiples of 16 bytes; odd sizes end with one 8-byte load)
 template <int N>
@@ -65,11 +63,11 @@ schur_point_cov_kernel(const int64_t *__restrict__ ptr, const int32_t *__restric
 	for(int64_t a = k0; a < k1; ++ a) {
 		const int64_t ca = brow[a];
 		double wa[DC * DP];
-		load_block<DC * DP>(wa, W + (o0 + (a - k0)) * schur_w_stride(DC * DP));
+		load_block<DC * DP>(wa, W + (o0 + (a - k0)) * (DC * DP));
 		for(int64_t b = k0; b <= a; ++ b) { // block rows ascend inside a column: cb <= ca, the lower triangle of Z
 			const int64_t cb = brow[b];
 			double wb[DC * DP], t[DC * DP];
-			load_block<DC * DP>(wb, W + (o0 + (b - k0)) * schur_w_stride(DC * DP));
+			load_block<DC * DP>(wb, W + (o0 + (b - k0)) * (DC * DP));
 			#pragma unroll
 			for(int i = 0; i < DC * DP; ++ i)
 				t[i] = 0;
@@ -141,14 +139,14 @@ schur_point_cov_sparse_kernel(const int64_t *__restrict__ ptr, int64_t nc, int64
 		cov[i] = Cinv[pt * (DP * DP) + i];
 	for(int64_t a = k0; a < k1; ++ a) {
 		double wa[DC * DP];
-		load_block<DC * DP>(wa, W + (o0 + (a - k0)) * schur_w_stride(DC * DP));
+		load_block<DC * DP>(wa, W + (o0 + (a - k0)) * (DC * DP));
 		for(int64_t b = k0; b <= a; ++ b) {
 			const int64_t ia = a - k0, ib = b - k0;
 			const int64_t ent = tab[ia * (ia + 1) / 2 + ib]; // block Z(cam_a, cam_b): offset * 2 + stored transposed
 			const bool b_tr = ent & 1;
 			double wb[DC * DP], zb[DC * DC], t[DC * DP];
 			load_block<DC * DC>(zb, Z + (ent >> 1)); // a thread's scattered loads are paid per instruction: 16 bytes each
-			load_block<DC * DP>(wb, W + (o0 + ib) * schur_w_stride(DC * DP));
+			load_block<DC * DP>(wb, W + (o0 + ib) * (DC * DP));
 			#pragma unroll
 			for(int i = 0; i < DC * DP; ++ i)
 				t[i] = 0;

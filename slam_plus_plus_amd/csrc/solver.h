@@ -187,10 +187,6 @@ struct slampp_hip_solver {
 
 namespace slampp {
 
-// W = U C^-1 is stored one record per observation, the records padded to whole 64-byte sectors (18 doubles -> 24 for
-// 6 x 3 blocks): a record that starts on a sector boundary is 3 sectors to fetch, one that straddles them 3 or 4
-inline constexpr int schur_w_stride(int n_block_doubles) { return (n_block_doubles * 8 + 63) / 64 * 8; }
-
 // Schur path entry points (schur.hip)
 void schur_destroy(CSchurState *p);
 CSchurState *schur_analyze(slampp_hip_solver &s); // throws
