@@ -379,9 +379,13 @@ void slampp_hip_solver::Analyze_Sparse()
 	std::vector<longlong2> pkg;
 	std::vector<int64_t> task_pkg(P.task_ptr.size() - 1, -1);
 	if(P.uniform_dim && (P.max_dim == 3 || P.max_dim == 6 || P.max_dim == 7)) {
-		enum { PKG_CHUNK = 16, PKG_NR = 128, PKG_NP = 512 };
 		const int n_stages = int(P.stage_ptr.size()) - 1;
-		for(int t = (n_bottom_stages < n_stages)? P.stage_ptr[n_bottom_stages] : int(task_pkg.size()); t < int(task_pkg.size()); ++ t) {
+		// (the wide stages above the leaves and the stages near the root run the same kernel with different capacities)
+		const int n_first_stage = (n_stages > 1)? 1 : n_stages;
+		for(int t = (n_first_stage < n_stages)? P.stage_ptr[n_first_stage] : int(task_pkg.size()); t < int(task_pkg.size()); ++ t) {
+			const bool b_wide = t < P.stage_ptr[std::min(n_bottom_stages, n_stages)];
+			const int PKG_CHUNK = b_wide? int(WIDE_CHUNK) : int(UP_CHUNK), PKG_NR = b_wide? int(WIDE_NR) : int(UP_NR),
+				PKG_NP = b_wide? int(WIDE_NP) : int(UP_NP);
 			task_pkg[t] = int64_t(pkg.size());
 			for(int64_t i = P.task_ptr[t]; i < P.task_ptr[t + 1]; ++ i) {
 				const TColDesc &c = cols[i];
@@ -711,7 +715,10 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 					launch_factor_stage(t_rest, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), simt_rest_ptr[s], n_rest,
 						true, d_flag.p(), stream);
 				}
-			} else
+			} else if(s > 0 && s < n_bottom_stages && dplan.task_pkg)
+				launch_factor_wide(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
+					P.stage_ptr[s + 1] - P.stage_ptr[s], d_flag.p(), stream);
+			else
 			launch_factor_stage(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
 				P.stage_ptr[s + 1] - P.stage_ptr[s], s < n_bottom_stages, d_flag.p(), stream);
 			if(s == 0 || s == n_wide_end - 1 || s == n_stages - 1)

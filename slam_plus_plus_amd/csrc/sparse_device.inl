@@ -3,7 +3,7 @@
 
 static const int64_t PAIR_OFF_MASK = (int64_t(1) << 48) - 1; // pair.x = offset | position of the target block in its column << 48 | dim << 56
 enum { Y_LANE0 = 56 }; // lanes 56.. carry the right-hand side of the column when its dimension is <= 7
-enum { CHUNK = 16 };   // blocks of a column whose partial sums live in LDS at a time (multi-wave kernel)
+enum { CHUNK = UP_CHUNK }; // blocks of a column whose partial sums live in LDS at a time (multi-wave kernel)
 
 __device__ __forceinline__ void wave_sync()
 {

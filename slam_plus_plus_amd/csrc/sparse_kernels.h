@@ -52,6 +52,9 @@ struct TDenseCol { // 24 B
 	int32_t pos, dj;
 };
 
+// capacities of the staged path of the separator kernel (blocks, row entries, update pairs of a column): near the root,
+// and in the wide stages right above the leaves
+enum { UP_CHUNK = 16, UP_NR = 128, UP_NP = 512, WIDE_CHUNK = 8, WIDE_NR = 16, WIDE_NP = 48 };
 enum { PKG_SPECULATIVE = 512 }; // 16-byte units fetched before a package's size is known (one per thread of the kernel)
 
 // units of a package: header (4) + nb block records (2 each) + ne = nr + np operand pairs (1 each) + their
@@ -107,6 +110,10 @@ void launch_factor_stage(const TDevPlan &p, const double *A, double *L, double *
 	double *w, int task_begin, int n_tasks, bool b_bottom_stage, int *p_flag, hipStream_t stream);
 // bottom stages out of LDS (subtree_kernel.hip); returns false if the block dimension has no such kernel
 bool launch_factor_subtree_image(const TDevPlan &p, const double *A, double *L, double *Linv, const double *b,
+	double *w, int task_begin, int n_tasks, int *p_flag, hipStream_t stream);
+// the wide stages right above the leaves: thousands of single separator columns whose operands other launches produced;
+// the separator kernel with one wave per column and small capacities (needs the column packages of those tasks)
+void launch_factor_wide(const TDevPlan &p, const double *A, double *L, double *Linv, const double *b,
 	double *w, int task_begin, int n_tasks, int *p_flag, hipStream_t stream);
 // stand-alone forward substitution (another right-hand side with a kept factor)
 void launch_forward_stage(const TDevPlan &p, const double *L, const double *Linv, const double *b,

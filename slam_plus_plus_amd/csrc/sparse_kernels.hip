@@ -83,11 +83,13 @@ factor_subtree_kernel(TDevPlan p, const double *__restrict__ A, double *L, doubl
 }
 
 // ---- upper stages: separator columns; W waves split the updates of the column ----
-// Fast path (<= CHUNK blocks, <= UP_NR row entries, <= UP_NP pairs): index records staged through
+// Fast path (<= CH blocks, <= NR row entries, <= NP pairs): index records staged through
 // LDS by the whole workgroup, update e handled by wave e mod W into that wave's private partial sums.
-enum { UP_NR = 128, UP_NP = 512 };
 
-template <int D, int W>
+// CH / NR / NP: capacities of the staged path (blocks, row entries, update pairs of a column); the separators near the
+// root want (16, 128, 512), the thousands of small columns right above the leaves (8, 16, 48) and one wave each -- a
+// twentieth of the LDS, so that many of them are resident and hide each other's round trips
+template <int D, int W, int CH, int NR, int NP>
 __global__ void __launch_bounds__(64 * W)
 factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double *Linv,
 	const double *__restrict__ b, double *w, int task_begin, int *p_flag)
@@ -95,16 +97,18 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 	__shared__ double s_linv[64];
 	__shared__ double s_rdiag[8];
 	__shared__ double s_tile[W][64];
-	__shared__ double s_part[W][CHUNK][64]; // partial sums: [wave][block][lane]
-	__shared__ TBlkDesc s_blk[CHUNK];
-	__shared__ TRowEnt s_rent[UP_NR];
-	__shared__ longlong2 s_prec[UP_NP];
-	__shared__ unsigned char s_ptag[UP_NP];
+	__shared__ double s_part[W][CH][64]; // partial sums: [wave][block][lane]
+	__shared__ TBlkDesc s_blk[CH];
+	__shared__ TRowEnt s_rent[NR];
+	__shared__ longlong2 s_prec[NP];
+	__shared__ unsigned char s_ptag[NP];
 	// fixed block size: the column's package (descriptor, block records, then row entries and pairs alike as (a, b)
 	// operand offsets with their right-hand side offsets and target tags), copied from the plan as it is
-	enum { PKG_UNITS = 4 + 2 * CHUNK + (UP_NR + UP_NP) + (UP_NR + UP_NP + 3) / 4 + (UP_NR + UP_NP + 15) / 16 };
+	enum { PKG_UNITS = 4 + 2 * CH + (NR + NP) + (NR + NP + 3) / 4 + (NR + NP + 15) / 16 };
 	__shared__ longlong2 s_pkg[D? PKG_UNITS : 1];
-	static_assert(64 * W == PKG_SPECULATIVE && PKG_SPECULATIVE <= PKG_UNITS, "one speculative unit per thread");
+	__shared__ double s_ops[(W == 1 && D)? 16 * D * D : 1]; // one wave per column: operand blocks of eight entries
+	__shared__ double s_yv[(W == 1 && D)? 64 : 1];          // and the y vectors of their row entries
+	static_assert(64 * W <= PKG_SPECULATIVE && 64 * W <= PKG_UNITS, "one speculative unit per thread");
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
 	const int task = task_begin + blockIdx.x;
 	long long *p_tm = 0;
@@ -124,7 +128,7 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 			s_pkg[tid] = p.pkg[n_pkg_at + tid];
 			__syncthreads();
 			cd = *reinterpret_cast<const TColDesc*>(s_pkg);
-			b_packaged = cd.nb <= CHUNK && cd.nr <= UP_NR && cd.np <= UP_NP;
+			b_packaged = cd.nb <= CH && cd.nr <= NR && cd.np <= NP;
 			const int n_units = b_packaged? package_units(cd.nb, cd.nr + cd.np) : 4;
 			for(int e = 64 * W + tid; e < n_units; e += 64 * W)
 				s_pkg[e] = p.pkg[n_pkg_at + e];
@@ -139,7 +143,7 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 		const TLaneMap md = lane_map(lane, dj, dj);
 		const int yq = b_y? lane - Y_LANE0 : md.q;
 		const bool b_staged = D != 0;
-		if(cd.nb <= CHUNK && cd.nr <= UP_NR && cd.np <= UP_NP) {
+		if(cd.nb <= CH && cd.nr <= NR && cd.np <= NP) {
 			// where the staged records sit in the package image
 			const int ne_all = cd.nr + cd.np;
 			TBlkDesc *s_pblk = reinterpret_cast<TBlkDesc*>(s_pkg + 4);
@@ -176,17 +180,64 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 			if(b_staged) {
 				// phase A: the Lambda elements are requested first and join the wave's partial sums last, so that
 				// their latency hides behind the products
-				double init0 = 0, init1 = 0;
-				if(wave == 0)
-					init0 = b_y? -b[cd.cs_src + yq] : (md.b_act? -lambda_element(A, s_blk[0].asrc, md.r, md.q, D, D, true) : 0);
-				else if(wave < cd.nb)
-					init0 = md.b_act? -lambda_element(A, s_blk[wave].asrc, md.r, md.q, D, D, false) : 0;
-				if(wave + W < cd.nb)
-					init1 = md.b_act? -lambda_element(A, s_blk[wave + W].asrc, md.r, md.q, D, D, false) : 0;
+				double init[(CH + W - 1) / W]; // Lambda elements of the blocks wave, wave + W, ...
+				#pragma unroll
+				for(int i = 0; i < (CH + W - 1) / W; ++ i) {
+					const int kb = wave + i * W;
+					init[i] = 0;
+					if(kb == 0)
+						init[i] = b_y? -b[cd.cs_src + yq] : (md.b_act? -lambda_element(A, s_blk[0].asrc, md.r, md.q, D, D, true) : 0);
+					else if(kb < cd.nb)
+						init[i] = md.b_act? -lambda_element(A, s_blk[kb].asrc, md.r, md.q, D, D, false) : 0;
+				}
 				const int ne = cd.nr + cd.np;
 				for(int kb = 0; kb < cd.nb; ++ kb)
 					s_part[wave][kb][lane] = 0;
 				// every update (row entries of the diagonal block and pairs of the others alike) goes through one loop
+				if(W == 1) {
+					// one wave per column (the wide stages): the operand blocks are fetched whole, one coalesced 288-byte load
+					// each, eight entries = sixteen blocks in flight together, and multiplied out of LDS -- a lane fetching its
+					// own twelve operands per entry kept the column 7-10 us in this loop (a sixth of the loads this way, and a
+					// twelfth of the cache lines they touch)
+					enum { BATCH = 8, DD = (D? D * D : 1) };
+					for(int e0 = 0; e0 < ne; e0 += BATCH) {
+						double va[BATCH], vb[BATCH], vy[BATCH];
+						#pragma unroll
+						for(int u = 0; u < BATCH; ++ u) {
+							const int e = min(e0 + u, ne - 1); // the tail repeats the last entry: its product is skipped below
+							const longlong2 en = s_ent[e];
+							va[u] = L[en.x + (md.b_act? lane : 0)];
+							vb[u] = L[en.y + (md.b_act? lane : 0)];
+							vy[u] = (b_y && s_tag[e] == 0)? w[s_ycs[e] + yq] : 0.0;
+						}
+						#pragma unroll
+						for(int u = 0; u < BATCH; ++ u) {
+							if(md.b_act) {
+								s_ops[(2 * u) * DD + lane] = va[u];
+								s_ops[(2 * u + 1) * DD + lane] = vb[u];
+							}
+							if(b_y)
+								s_yv[u * 8 + yq] = vy[u];
+						}
+						wave_sync();
+						#pragma unroll
+						for(int u = 0; u < BATCH; ++ u) {
+							if(e0 + u < ne) { // wave-uniform
+								const int tag = s_tag[e0 + u];
+								const bool b_vec = tag == 0 && b_y;
+								const double *pa = b_vec? s_yv + u * 8 : s_ops + (2 * u) * DD + md.r;
+								const double *pb = s_ops + (2 * u + 1) * DD + ((tag == 0)? yq : md.q);
+								const int as = b_vec? 1 : D;
+								double sum = 0;
+								#pragma unroll
+								for(int t = 0; t < D; ++ t)
+									sum += pa[t * as] * pb[t * D];
+								s_part[0][tag][lane] += sum;
+							}
+						}
+						wave_sync();
+					}
+				} else {
 				#pragma unroll 4
 				for(int e = wave; e < ne; e += W) {
 					const longlong2 en = s_ent[e];
@@ -207,10 +258,12 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 						sum += av[t] * bv[t];
 					s_part[wave][tag][lane] += sum;
 				}
-				if(wave < cd.nb)
-					s_part[wave][wave][lane] += init0;
-				if(wave + W < cd.nb)
-					s_part[wave][wave + W][lane] += init1;
+				}
+				#pragma unroll
+				for(int i = 0; i < (CH + W - 1) / W; ++ i) {
+					if(wave + i * W < cd.nb)
+						s_part[wave][wave + i * W][lane] += init[i];
+				}
 			} else {
 			for(int e = tid; e < cd.np; e += 64 * W)
 				s_ptag[e] = (unsigned char)pair_block(s_blk, cd.nb, cd.p0 + e);
@@ -274,9 +327,9 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 			STAGE_TICK(); // column done
 			continue;
 		}
-		// general path: any number of blocks, CHUNK at a time, records read from global memory
-		for(int kb0 = 0; kb0 < cd.nb; kb0 += CHUNK) {
-			const int kbn = min(int(CHUNK), cd.nb - kb0);
+		// general path: any number of blocks, CH at a time, records read from global memory
+		for(int kb0 = 0; kb0 < cd.nb; kb0 += CH) {
+			const int kbn = min(int(CH), cd.nb - kb0);
 			for(int s = 0; s < kbn; ++ s) {
 				const int kb = kb0 + s;
 				double part;
@@ -539,9 +592,17 @@ void launch_factor_stage(const TDevPlan &p, const double *A, double *L, double *
 		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_subtree_kernel<D>), dim3(n_tasks), dim3(64), 0, stream,
 			p, A, L, Linv, b, w, task_begin, p_flag));
 	} else {
-		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_stage_kernel<D, 8>), dim3(n_tasks), dim3(512), 0, stream,
+		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_stage_kernel<D, 8, CHUNK, UP_NR, UP_NP>), dim3(n_tasks), dim3(512), 0, stream,
 			p, A, L, Linv, b, w, task_begin, p_flag));
 	}
+}
+
+void launch_factor_wide(const TDevPlan &p, const double *A, double *L, double *Linv, const double *b,
+	double *w, int task_begin, int n_tasks, int *p_flag, hipStream_t stream)
+{
+	if(n_tasks > 0)
+		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_stage_kernel<D, 1, WIDE_CHUNK, WIDE_NR, WIDE_NP>), dim3(n_tasks), dim3(64), 0, stream,
+			p, A, L, Linv, b, w, task_begin, p_flag));
 }
 
 void launch_forward_stage(const TDevPlan &p, const double *L, const double *Linv, const double *b,
