@@ -249,8 +249,11 @@ def run_c3(args, rank, world, local_rank, dist):
     kb = per_kernel_bytes_sparse(solver.plan(), n_bottom)
     launches = {"factor_leaves": 1, "factor_wide": max(n_bottom - 1, 1), "factor_upper": max(n_stages - n_bottom, 1),
                 "forward": n_stages, "backward": n_stages}
-    names = {"factor_leaves": "factor_simt_kernel", "factor_wide": "factor_subtree_image_kernel",
-             "factor_upper": "factor_stage_kernel", "forward": "forward_stage_kernel", "backward": "backward_stage_kernel"}
+    names = {"factor_leaves": "factor_simt_kernel", "factor_wide": "factor_stage_kernel<D, 1, 8, 16, 48>",
+             "factor_upper": "factor_stage_kernel<D, 8, 16, 128, 512>", "forward": "forward_stage_kernel",
+             "backward": "backward_stage_kernel"}
+    needles = {"factor_leaves": "factor_simt_kernel", "factor_wide": ", 1, 8, 16, 48>", "factor_upper": ", 8, 16, 128, 512>",
+               "forward": "forward_stage_kernel", "backward": "backward_stage_kernel"}   # as rocprofv3 spells the kernels
     traffic, traffic_file = load_traffic("c3")
     kernels = []
     for ph, (cnt, tot_ms) in prof.items():
@@ -261,7 +264,7 @@ def run_c3(args, rank, world, local_rank, dist):
                         "avg_launch_us": per_step_ms / launches[ph] * 1e3,
                         "algorithmic_bytes_per_launch": kb[ph] / launches[ph],
                         "achieved_GBs": kb[ph] / (per_step_ms * 1e-3) / 1e9,
-                        "hbm_traffic_bytes_per_launch": kernel_traffic(traffic, names[ph])})
+                        "hbm_traffic_bytes_per_launch": kernel_traffic(traffic, needles[ph])})
     kernels.sort(key=lambda k: -k["ms_per_step"])
     # the roofline object is for the kernel that moves the step's bytes: the leaf kernel reads nearly all of Lambda and
     # writes nearly all of L in ONE launch (the other phases are chains of 3 / 18 / 22 launches of 0.1-4 MB each, bound

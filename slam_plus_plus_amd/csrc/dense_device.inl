@@ -165,23 +165,31 @@ __device__ __forceinline__ void potrf_diag_body(double *M, int ld, int kb, int n
 				#pragma unroll
 				for(int c = 0; c < 16; ++ c)
 					a[c] = s_L[(c0 + c) * PL + r];
+				// The sixteen column steps are one dependent chain (pivot -> scaling -> update of the next column -> next
+				// pivot), so it is kept short: the trailing columns are updated in the L D L^T form, a(r,c) -= a(r,k) a(c,k) / d_k,
+				// which needs the reciprocal of the pivot only (v_rcp + two Newton steps, five dependent operations) and
+				// the column k as it stands (its v_readlane broadcasts do not wait for anything); the reciprocal square root
+				// that turns column k into L(:,k) = a(:,k) / sqrt(d_k) is computed beside the chain, not on it
 				#pragma unroll
 				for(int k = 0; k < 16; ++ k) {
 					double piv = dense_read_lane(a[k], c0 + k);
 					const bool b_neg = !(piv > 0);
 					b_bad = b_bad || (b_neg && o + c0 + k < n);
 					piv = b_neg? 1.0 : piv;
+					double rw = __builtin_amdgcn_rcp(piv); // 1 / d_k
+					rw = __builtin_fma(__builtin_fma(-piv, rw, 1.0), rw, rw);
+					rw = __builtin_fma(__builtin_fma(-piv, rw, 1.0), rw, rw);
+					const double tk = a[k] * rw; // a(r,k) / d_k
+					#pragma unroll
+					for(int c = k + 1; c < 16; ++ c)
+						a[c] -= tk * dense_read_lane(a[k], c0 + c);
 					double rs = __builtin_amdgcn_rsq(piv);
 					const double h = 0.5 * piv;
 					rs = rs * (1.5 - h * rs * rs);
 					rs = rs * (1.5 - h * rs * rs);
-					const double lk = a[k] * rs; // L(r, c0 + k), meaningful for r >= c0 + k
-					a[k] = lk;
+					a[k] *= rs; // L(r, c0 + k), meaningful for r >= c0 + k
 					if(r == c0 + k)
 						s_rd[c0 + k] = rs;
-					#pragma unroll
-					for(int c = k + 1; c < 16; ++ c)
-						a[c] -= lk * dense_read_lane(lk, c0 + c);
 				}
 				#pragma unroll
 				for(int c = 0; c < 16; ++ c)
