@@ -76,7 +76,7 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
  * one dense matrix on the matrix cores; default: 24, or 16 / 36 where a model of the dependent launch chain clearly
  * prefers that; setting the option fixes the threshold; 0 = off), "dense_top_max_dim" (cap on its dimension, default 12288),
  * "dense_top_min_dim" (below this dimension there is no dense top, default 192),
- * "profile" (0/1, see slampp_hip_get_profile), "shard_primary" (multi-GPU BA: this rank adds A and eta_x),
+ * "profile" (0 / 1 / 2, see slampp_hip_get_profile), "shard_primary" (multi-GPU BA: this rank adds A and eta_x),
  * "shard_rank" / "shard_world" (multi-GPU BA, optional: who this rank is among the ranks behind the all-reduce
  * callback; lets them exchange their block lists, which scales with the nonzero blocks of S, instead of an indicator
  * over all camera pairs, which is limited to 16384 cameras),
@@ -191,7 +191,7 @@ int slampp_hip_get_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_
 /* device-side phase timing (the counterpart of the reference's __SCHUR_PROFILING / CTimerSampler
  * phase timers, LinearSolver_Schur.h:1681-1912, Timer.h:391): with option "profile" = 1 every phase
  * of factor_solve is bracketed by HIP events on the solver's stream; the totals are collected at
- * slampp_hip_sync().  Phases: factor_leaves, factor_wide, factor_upper, forward, backward (sparse path);
+ * slampp_hip_sync().  Phases: factor_leaves, factor_rest (with "profile" = 2: factor_wide, factor_upper), forward, backward (sparse path);
  * schur_points, schur_gather, schur_rhs, dense_chol, dense_solve, backsubst (Schur path). */
 typedef struct slampp_hip_phase_time {
 	char name[32];

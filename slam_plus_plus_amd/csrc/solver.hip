@@ -701,9 +701,11 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 		for(int s = 0; s < n_stages; ++ s) {
 			if(s == 0)
 				Phase_Begin("factor_leaves");
-			else if(s == 1 && s < n_wide_end)
-				Phase_Begin("factor_wide");
-			else if(s == n_wide_end)
+			else if(s == 1 && (b_profile >= 2 || n_wide_end <= 1))
+				Phase_Begin((s < n_wide_end)? "factor_wide" : "factor_upper");
+			else if(s == 1)
+				Phase_Begin("factor_rest"); // the wide stages and the separators as one phase
+			else if(s == n_wide_end && b_profile >= 2)
 				Phase_Begin("factor_upper");
 			if(b_simt && s + 1 < int(simt_chunk_ptr.size())) {
 				const int n_chunks = simt_chunk_ptr[s + 1] - simt_chunk_ptr[s], n_rest = simt_rest_ptr[s + 1] - simt_rest_ptr[s];
@@ -721,7 +723,7 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			else
 			launch_factor_stage(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
 				P.stage_ptr[s + 1] - P.stage_ptr[s], s < n_bottom_stages, d_flag.p(), stream);
-			if(s == 0 || s == n_wide_end - 1 || s == n_stages - 1)
+			if(s == 0 || (s == n_wide_end - 1 && b_profile >= 2) || s == n_stages - 1)
 				Phase_End();
 		}
 	} else {
@@ -918,7 +920,7 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 	else if(s == "simt_stages" && n_value >= 0)
 		p_solver->n_simt_stages = int(n_value);
 	else if(s == "profile") {
-		p_solver->b_profile = (n_value != 0);
+		p_solver->b_profile = int(n_value); // 0 = off, 1 = phases, 2 = the factorization split further (every event pair costs microseconds)
 		return SLAMPP_HIP_OK; // does not invalidate the analysis
 	}
 	else
