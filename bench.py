@@ -261,10 +261,10 @@ def run_c3(args, rank, world, local_rank, dist):
     kb = per_kernel_bytes_sparse(solver.plan(), n_bottom)
     launches = {"factor_leaves": 1, "factor_wide": max(n_bottom - 1, 1), "factor_upper": max(n_stages - n_bottom, 1),
                 "forward": n_stages, "backward": n_stages}
-    names = {"factor_leaves": "factor_simt_kernel", "factor_wide": "factor_stage_kernel<D, 1, 8, 16, 48>",
+    names = {"factor_leaves": "factor_simt_kernel", "factor_wide": "factor_stage_kernel<D, 1, 8, 32, 48>",
              "factor_upper": "factor_stage_kernel<D, 8, 16, 128, 512>", "forward": "forward_stage_kernel",
              "backward": "backward_stage_kernel"}
-    needles = {"factor_leaves": "factor_simt_kernel", "factor_wide": ", 1, 8, 16, 48>", "factor_upper": ", 8, 16, 128, 512>",
+    needles = {"factor_leaves": "factor_simt_kernel", "factor_wide": ", 1, 8, 32, 48>", "factor_upper": ", 8, 16, 128, 512>",
                "forward": "forward_stage_kernel", "backward": "backward_stage_kernel"}   # as rocprofv3 spells the kernels
     traffic, traffic_file = load_traffic("c3")
     kernels = []

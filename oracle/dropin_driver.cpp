@@ -391,7 +391,14 @@ static int Main_Time(int n_arg_num, const char **p_arg_list)
 	std::vector<size_t> new_of_old;
 	Build_Lambda(p, false, lambda, rhs, new_of_old);
 	std::vector<double> ref_ms, hip_warm_ms;
-	double f_hip_cold_ms = 0, f_err = 0;
+	double f_hip_cold_ms = 0, f_err = 0, f_runtime_init_ms = 0;
+	{ // the HIP runtime and the library's code object load once per process: not part of a solver's cold call
+		const double t0 = f_NowMs();
+		slampp_hip_solver *p_warm = 0;
+		if(slampp_hip_create(&p_warm, 0) == SLAMPP_HIP_OK)
+			slampp_hip_destroy(p_warm);
+		f_runtime_init_ms = f_NowMs() - t0;
+	}
 	slampp_hip_times t_times;
 	memset(&t_times, 0, sizeof(t_times));
 	bool b_ok = true;
@@ -449,8 +456,8 @@ static int Main_Time(int n_arg_num, const char **p_arg_list)
 		p.n_matrix_cut? "CLinearSolver_Schur<CLinearSolver_CholMod>" : "CLinearSolver_CholMod");
 	for(size_t i = 0; i < ref_ms.size(); ++ i)
 		printf("%s%.3f", i? ", " : "", ref_ms[i]);
-	printf("], \"hip_cold_ms\": %.3f, \"hip_warm_ms_median\": %.3f, \"hip_warm_ms_min\": %.3f, \"hip_warm_last_call\": "
-		"{\"upload_wait_ms\": %.3f, \"solve_ms\": %.3f, \"download_ms\": %.3f, \"library_total_ms\": %.3f}}\n", f_hip_cold_ms,
+	printf("], \"hip_runtime_init_ms\": %.3f, \"hip_cold_ms\": %.3f, \"hip_warm_ms_median\": %.3f, \"hip_warm_ms_min\": %.3f, \"hip_warm_last_call\": "
+		"{\"upload_wait_ms\": %.3f, \"solve_ms\": %.3f, \"download_ms\": %.3f, \"library_total_ms\": %.3f}}\n", f_runtime_init_ms, f_hip_cold_ms,
 		hip_warm_ms[hip_warm_ms.size() / 2], hip_warm_ms[0], t_times.upload_ms,
 		(p.n_matrix_cut)? t_times.schur_ms : t_times.factor_ms, t_times.download_ms, t_times.total_ms);
 	return (b_ok && f_err < 1e-10)? 0 : 1;

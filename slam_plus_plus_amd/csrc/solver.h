@@ -119,6 +119,7 @@ struct slampp_hip_solver {
 	std::vector<int32_t> simt_chunk_ptr, simt_rest_ptr; // [n_bottom_stages + 1] each; empty = not in use
 	std::vector<int32_t> simt_lds_bytes; // per stage: the largest chunk table (it is staged in LDS)
 	int n_simt = -1; // option "simt": 1 / -1 = use it where it applies (default), 0 = never
+	int n_wide_min_tasks = 1024; // option "wide_min_tasks": stages with more tasks than this run one wave per task
 	int n_simt_width = 32; // option "simt_width": tasks per wave (16, 32, 64)
 	int n_simt_stages = 1; // option "simt_stages": how many of the bottom stages it takes (the stages above the leaves hold
 	                       // single separator columns whose operands other waves wrote: no gain there, measured)

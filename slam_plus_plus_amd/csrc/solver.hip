@@ -318,7 +318,7 @@ void slampp_hip_solver::Analyze_Sparse()
 	// resident at 2 workgroups per CU) run one wave per task: there throughput beats single-column latency
 	n_bottom_stages = 1;
 	while(n_bottom_stages < int(P.stage_ptr.size()) - 1 &&
-	   P.stage_ptr[n_bottom_stages + 1] - P.stage_ptr[n_bottom_stages] > 1024)
+	   P.stage_ptr[n_bottom_stages + 1] - P.stage_ptr[n_bottom_stages] > n_wide_min_tasks)
 		++ n_bottom_stages;
 
 	if(P.cs_new[P.n] >= INT32_MAX)
@@ -915,6 +915,8 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 	}
 	else if(s == "simt" && n_value >= -1 && n_value <= 1)
 		p_solver->n_simt = int(n_value);
+	else if(s == "wide_min_tasks" && n_value >= 1)
+		p_solver->n_wide_min_tasks = int(n_value);
 	else if(s == "simt_width" && (n_value == 16 || n_value == 32 || n_value == 64))
 		p_solver->n_simt_width = int(n_value);
 	else if(s == "simt_stages" && n_value >= 0)

@@ -54,7 +54,7 @@ struct TDenseCol { // 24 B
 
 // capacities of the staged path of the separator kernel (blocks, row entries, update pairs of a column): near the root,
 // and in the wide stages right above the leaves
-enum { UP_CHUNK = 16, UP_NR = 128, UP_NP = 512, WIDE_CHUNK = 8, WIDE_NR = 16, WIDE_NP = 48 };
+enum { UP_CHUNK = 16, UP_NR = 128, UP_NP = 512, WIDE_CHUNK = 8, WIDE_NR = 32, WIDE_NP = 48 };
 enum { PKG_SPECULATIVE = 512 }; // 16-byte units fetched before a package's size is known (one per thread of the kernel)
 
 // units of a package: header (4) + nb block records (2 each) + ne = nr + np operand pairs (1 each) + their

@@ -87,7 +87,7 @@ factor_subtree_kernel(TDevPlan p, const double *__restrict__ A, double *L, doubl
 // LDS by the whole workgroup, update e handled by wave e mod W into that wave's private partial sums.
 
 // CH / NR / NP: capacities of the staged path (blocks, row entries, update pairs of a column); the separators near the
-// root want (16, 128, 512), the thousands of small columns right above the leaves (8, 16, 48) and one wave each -- a
+// root want (16, 128, 512), the thousands of small columns right above the leaves (8, 32, 48) and one wave each -- a
 // twentieth of the LDS, so that many of them are resident and hide each other's round trips
 template <int D, int W, int CH, int NR, int NP>
 __global__ void __launch_bounds__(64 * W)

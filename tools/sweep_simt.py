@@ -7,8 +7,7 @@ from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP
 lam = synth.pose_chain(n=int(sys.argv[1]) if len(sys.argv) > 1 else 100000)
 dev = torch.device("cuda:0")
 vals = torch.from_numpy(lam.values).to(dev)
-for opts in ({"simt": 0}, {"simt_width": 64, "simt_stages": 1}, {"simt_width": 32, "simt_stages": 1}, {"simt_width": 16, "simt_stages": 1},
-             {"simt_width": 32, "simt_stages": 4}, {"simt_width": 32, "simt_stages": 1, "subtree_size": 6}):
+for opts in ({}, {"wide_min_tasks": 512}, {"wide_min_tasks": 300}, {"wide_min_tasks": 200}, {"wide_min_tasks": 100}, {"wide_min_tasks": 40}):
     s = CLinearSolver_HIP(**opts)
     s.SymbolicDecomposition_Blocky(lam)
     reps = 20
