@@ -486,6 +486,46 @@ def cpu_baseline_ba(lam, flops, x_gpu):
                       f"{wall:.1f} s of CPU incl. load); OpenMP only in the block-diagonal inverse and one SpMV, dense LLT serial"}
 
 
+def incremental_leg(lam, dev, local_rank, torch, share=0.01, reps=5):
+    """Outside the timed region: option schur_incremental.  After a relinearization that moved `share` of the landmarks the
+    reduced camera system is updated from the previous one (the reference's dog-leg solver does that from Omega = delta
+    Lambda, NonlinearSolver_Lambda_DL.h:2301-) instead of rebuilt: the same solve both ways, same values."""
+    from slam_plus_plus_amd.hip_solver import CLinearSolver_Schur_HIP
+    rng = np.random.default_rng(3)
+    nc, n_pts = lam.n_matrix_cut, lam.n_bcols - lam.n_matrix_cut
+    points = np.sort(rng.choice(n_pts, size=max(int(share * n_pts), 1), replace=False))
+    off = lam.block_value_offsets()
+    vals2 = lam.values.copy()
+    for p_ in points:                                             # the moved landmarks: more curvature, scaled projections
+        k0, k1 = int(lam.bcol_ptr[nc + p_]), int(lam.bcol_ptr[nc + p_ + 1])
+        vals2[off[k0]:off[k1 - 1]] *= 0.9
+        vals2[off[k1 - 1]:off[k1]] += 0.5 * np.eye(3).ravel()
+    solver = CLinearSolver_Schur_HIP(device=local_rank, schur_incremental=1)
+    solver.SymbolicDecomposition_Blocky(lam)
+    v1, v2 = torch.from_numpy(lam.values).to(dev), torch.from_numpy(vals2).to(dev)
+    rhs = torch.from_numpy(lam.rhs).to(dev)
+    out = {}
+    for name, use_list in (("full_rebuild_ms", False), ("update_ms", True)):
+        ms, xs = [], None
+        for _ in range(reps):
+            b1, b2 = rhs.clone(), rhs.clone()
+            solver.factor_solve_device(v1.data_ptr(), b1.data_ptr())           # the system before the relinearization
+            if use_list:
+                solver.Set_Changed_Landmarks(points)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ok = solver.factor_solve_device(v2.data_ptr(), b2.data_ptr())
+            ms.append((time.perf_counter() - t0) * 1e3)
+            xs = b2.cpu().numpy()
+        out[name] = float(np.median(ms))
+        out[name.replace("_ms", "_x")] = xs
+    x_full, x_upd = out.pop("full_rebuild_x"), out.pop("update_x")
+    out["update_vs_full_rel_inf"] = float(np.abs(x_upd - x_full).max() / np.abs(x_full).max())
+    out["changed_landmarks"] = int(len(points))
+    out["ok"] = bool(ok)
+    return out
+
+
 def marginals_leg(args, solver, lam, vals, dev, torch):
     """Block diagonal of the covariance on the bench's BA system, after the timed solves:
     the reduced system assembled and factored as for a solve, the blocks of its inverse the landmarks need taken from
@@ -677,6 +717,7 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
                 out["dropin_cpp"] = dropin_leg(lam, reps=3)
         if extras and schur_sparse != 0:
             out["marginals"] = marginals_leg(args, solver, lam, vals, dev, torch)
+            out["incremental_schur_update"] = incremental_leg(lam, dev, local_rank, torch)
             # Lambda of the same structure assembled on the device from 2-d projection residuals (one edge per observation)
             out["assembly"] = assembly_leg(solver, lam, dev, reps=5, rd=2, column_vertex_first=True)
     return out

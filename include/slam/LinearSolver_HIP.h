@@ -37,6 +37,7 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <algorithm>
 #ifdef _OPENMP
 #include <omp.h>
 #endif // _OPENMP
@@ -718,6 +719,42 @@ public:
 		if(m_n_matrix_cut == 0 || m_n_matrix_cut == r_lambda.n_BlockColumn_Num())
 			return m_sparse_fallback.Solve_PosDef_Blocky(r_lambda, r_eta);
 		return Solve_Gathered(r_lambda, r_eta);
+	}
+
+	/**
+	 *	@brief incremental Schur complement: tells the next Solve_PosDef_Blocky() that, since the previous one, only
+	 *		the blocks of the given landmark vertices changed (the camera blocks and eta may have changed freely); the
+	 *		reduced camera system is then updated instead of rebuilt -- what the reference's dog-leg solver does from
+	 *		Omega = delta lambda (NonlinearSolver_Lambda_DL.h:1025-1086, 2301-).  Needs Set_Option("schur_incremental", 1).
+	 *	@param[in] r_vertex_ids is the list of block columns of lambda (landmarks) whose blocks changed; may be empty
+	 *	@note This throws std::runtime_error if there is no analyzed structure or a vertex is not a landmark.
+	 */
+	void Set_Changed_Landmarks(const std::vector<size_t> &r_vertex_ids) // throw(std::bad_alloc, std::runtime_error)
+	{
+		if(!this->m_p_solver || !this->m_b_structure_valid || m_n_matrix_cut == size_t(-1))
+			throw std::runtime_error("CLinearSolver_Schur_HIP: Set_Changed_Landmarks() needs an analyzed structure");
+		const size_t n = this->m_cumsum.size() - 1;
+		std::vector<int64_t> points;
+		points.reserve(r_vertex_ids.size());
+		if(this->m_order.empty()) {
+			for(size_t i = 0, m = r_vertex_ids.size(); i < m; ++ i)
+				points.push_back(int64_t(r_vertex_ids[i]) - int64_t(m_n_matrix_cut));
+		} else {
+			std::vector<size_t> inv_order(n);
+			for(size_t i = 0; i < n; ++ i)
+				inv_order[this->m_order[i]] = i;
+			for(size_t i = 0, m = r_vertex_ids.size(); i < m; ++ i) {
+				if(r_vertex_ids[i] >= n)
+					throw std::runtime_error("CLinearSolver_Schur_HIP: Set_Changed_Landmarks(): no such vertex");
+				points.push_back(int64_t(inv_order[r_vertex_ids[i]]) - int64_t(m_n_matrix_cut));
+			}
+		}
+		std::sort(points.begin(), points.end());
+		points.erase(std::unique(points.begin(), points.end()), points.end());
+		if(!points.empty() && (points.front() < 0 || points.back() >= int64_t(n - m_n_matrix_cut)))
+			throw std::runtime_error("CLinearSolver_Schur_HIP: Set_Changed_Landmarks(): a vertex is not a landmark");
+		this->Throw_On_Error(slampp_hip_schur_set_changed_points(this->m_p_solver, points.empty()? 0 : &points[0],
+			int64_t(points.size())));
 	}
 
 	/**

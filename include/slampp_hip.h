@@ -86,6 +86,7 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
  * "schur_sparse" (Schur mode: the reduced camera system S is factored by the sparse block path instead of the dense
  * one; -1 = when fewer than 3 % of its camera-camera blocks are nonzero (default), 0 = never, 1 = always; the
  * reference makes this choice at compile time: __SCHUR_USE_DENSE_SOLVER, include/slam/LinearSolver_Schur.h:48-55, "faster if ... dense enough"),
+ * "schur_incremental" (Schur mode, 0 / 1: keep the assembled reduced system for slampp_hip_schur_set_changed_points),
  * "marginals_dense" (Schur mode: 1 = slampp_hip_schur_marginals always inverts the reduced system densely; 0 (default) =
  * when the solves factor it by the sparse block path, the covariances take the blocks of S^-1 they need from a
  * sparse inverse subset on that factor's pattern) */
@@ -143,6 +144,19 @@ int slampp_hip_solve_again(slampp_hip_solver *p_solver, double *p_rhs_inout);
  * block-CSC as described by the view's lptr / lrow / loff, blocks column-major, the diagonal block first in each
  * column.  Returns SLAMPP_HIP_NOT_POSDEF if a pivot is not positive. */
 int slampp_hip_factorize(slampp_hip_solver *p_solver, const double *p_values, double *p_factor_out);
+
+/* Schur mode, option "schur_incremental" = 1 (set before slampp_hip_analyze): the next factor_solve updates the reduced
+ * camera system the previous factor_solve of this handle assembled instead of rebuilding it -- the reference's dog-leg
+ * solver does the same from Omega = Lambda_new - Lambda_old (include/slam/NonlinearSolver_Lambda_DL.h:1025-1086, 2301-).
+ * p_points (host): the landmarks, as indices among the landmark block columns, strictly increasing, whose blocks (C_p and
+ * the U blocks of their observations) differ from the previous call's values; the camera-camera blocks and the
+ * right-hand side may differ freely; n_points = 0 says that no landmark changed.  The contributions of the named
+ * landmarks are exchanged (the old ones rebuilt from W = U C^-1 and C^-1, which the previous solve left on the device)
+ * with fp64 atomic adds, so this path -- unlike every other one -- does not sum in a fixed order.  One-shot; falls back
+ * to the full rebuild when there is nothing valid to update (first solve, a solve that was not positive definite, a
+ * covariance call in between, landmark shards).  With the option on, the dense reduced system is kept in a second
+ * n_pad^2 buffer (the factorization works in place). */
+int slampp_hip_schur_set_changed_points(slampp_hip_solver *p_solver, const int64_t *p_points, int64_t n_points);
 
 /* Schur mode only: solves for the landmarks alone, dl = C^-1 eta_l, and zeroes the camera part of the vector -- the
  * reference's CLinearSolver_Schur::Solve_PosDef_Blocky_MarginalPoses (include/slam/LinearSolver_Schur.h:1956-2143).

@@ -797,6 +797,55 @@ int main(int n_arg_num, const char **p_arg_list)
 						f_cam_err / std::max(f_cam_max, 1e-300), f_lm_err / std::max(f_lm_max, 1e-300));
 					n_fail += !(b_margs_ref && b_margs_hip && b_same_shape && f_cam_err < 1e-10 * f_cam_max && f_lm_err < 1e-10 * f_lm_max);
 				}
+				{ // incremental Schur complement: some landmarks and all cameras change, the HIP solver updates its reduced
+					// system from the previous solve, the reference solves the changed system from scratch
+					THipSchur hip_inc(base);
+					hip_inc.Set_Option("schur_incremental", 1);
+					Eigen::VectorXd x_first = rhs;
+					bool b_ok_inc = hip_inc.Solve_PosDef(lambda, x_first);
+					CUberBlockMatrix lambda2;
+					lambda.CopyTo(lambda2);
+					std::vector<size_t> changed;
+					const size_t n_verts = lambda2.n_BlockColumn_Num();
+					size_t n_cam_dim = 0;
+					for(size_t i = 0; i < n_verts; ++ i)
+						n_cam_dim = std::max(n_cam_dim, lambda2.n_BlockColumn_Column_Num(i));
+					for(size_t c = 0, n_lm_seen = 0; c < n_verts; ++ c) {
+						const size_t d = lambda2.n_BlockColumn_Column_Num(c);
+						const bool b_landmark = d != n_cam_dim;
+						if(b_landmark && (n_lm_seen ++) % 11 != 3)
+							continue; // every eleventh landmark moves; every camera does
+						if(b_landmark)
+							changed.push_back(c);
+						for(size_t j = 0, m = lambda2.n_BlockColumn_Block_Num(c); j < m; ++ j) {
+							CUberBlockMatrix::_TyMatrixXdRef blk = lambda2.t_Block_AtColumn(c, j);
+							if(lambda2.n_Block_Row(c, j) == c)
+								blk += Eigen::MatrixXd::Identity(d, d) * 0.4; // stays positive definite
+							else if(b_landmark)
+								blk *= 0.9;
+						}
+					}
+					// (a camera - landmark block stored in the camera's column, as in the interleaved order, belongs to the landmark)
+					for(size_t c = 0; c < n_verts; ++ c) {
+						if(lambda2.n_BlockColumn_Column_Num(c) != n_cam_dim)
+							continue;
+						for(size_t j = 0, m = lambda2.n_BlockColumn_Block_Num(c); j < m; ++ j) {
+							const size_t r = lambda2.n_Block_Row(c, j);
+							if(r != c && lambda2.n_BlockColumn_Column_Num(r) != n_cam_dim &&
+							   std::find(changed.begin(), changed.end(), r) != changed.end())
+								lambda2.t_Block_AtColumn(c, j) *= 0.9;
+						}
+					}
+					Eigen::VectorXd x_ref2 = rhs, x_inc = rhs;
+					TRefSchur ref2(base);
+					const bool b_ref2 = ref2.Solve_PosDef(lambda2, x_ref2);
+					hip_inc.Set_Changed_Landmarks(changed);
+					b_ok_inc = hip_inc.Solve_PosDef_Blocky(lambda2, x_inc) && b_ok_inc;
+					const double f_err_inc = (x_inc - x_ref2).lpNorm<Eigen::Infinity>() / x_ref2.lpNorm<Eigen::Infinity>();
+					printf("\"schur_incremental_%s\": {\"ok_ref\": %d, \"ok_hip\": %d, \"changed_landmarks\": %d, \"rel_inf\": %.3g}, ",
+						b_interleave? "interleaved" : "cams_first", int(b_ref2), int(b_ok_inc), int(changed.size()), f_err_inc);
+					n_fail += !(b_ref2 && b_ok_inc && f_err_inc < 1e-10 && !changed.empty());
+				}
 				if(!b_interleave) { // a copy keeps the configuration: the reduced system through the sparse block path
 					hip_solver.Set_Option("schur_sparse", 1);
 					THipSchur hip_copy(hip_solver);

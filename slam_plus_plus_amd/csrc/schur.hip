@@ -64,6 +64,13 @@ struct CSchurState {
 	bool b_sinv_tried;
 	CDevArray<double> d_m_Zs;                  // laid out like the inner solver's factor
 	CDevArray<int64_t> d_cam_zoff, d_pair_ptr, d_pair_tab;
+	// incremental update of the reduced system (option "schur_incremental"): what the previous solve assembled stays, and
+	// a solve that names the landmarks whose blocks changed exchanges their contributions only
+	bool b_prev_valid = false;                 // the buffers below describe the values of the last solve
+	CDevArray<double> d_A_prev;                // the camera-camera blocks of Lambda of the last solve
+	CDevArray<double> d_S_unf;                 // dense reduced system: S as assembled (d_S is factored in place)
+	CDevArray<int64_t> d_changed;              // landmarks named for the next solve
+	int64_t n_changed = -1;                    // -1: none named (full rebuild)
 	CSchurState() :p_union_fn(0), p_union_context(0), b_union_dense(false), n_union(0), b_reduced_decided(false),
 		b_reduced_sparse(false), p_inner(0), n_in_blocks(0), p_sinv(0), b_sinv_tried(false) {}
 	~CSchurState();
@@ -90,7 +97,30 @@ size_t schur_device_bytes(const CSchurState *p)
 		p->d_in_buf.n_Bytes() + (p->p_inner? p->p_inner->n_Device_Bytes() : 0) + p->d_m_S.n_Bytes() + p->d_m_Z.n_Bytes() +
 		p->d_m_invdiag.n_Bytes() + p->d_m_zero.n_Bytes() + p->d_m_Zs.n_Bytes() + p->d_cam_zoff.n_Bytes() +
 		p->d_pair_ptr.n_Bytes() + p->d_pair_tab.n_Bytes() + sparse_inverse_bytes(p->p_sinv) +
-		p->d_Cinv.n_Bytes() + p->d_t.n_Bytes() + p->d_invdiag.n_Bytes() + p->d_z.n_Bytes() + p->d_x.n_Bytes();
+		p->d_Cinv.n_Bytes() + p->d_t.n_Bytes() + p->d_invdiag.n_Bytes() + p->d_z.n_Bytes() + p->d_x.n_Bytes() +
+		p->d_A_prev.n_Bytes() + p->d_S_unf.n_Bytes() + p->d_changed.n_Bytes();
+}
+
+void schur_invalidate_previous(CSchurState *p)
+{
+	if(p) {
+		p->b_prev_valid = false;
+		p->n_changed = -1;
+	}
+}
+
+// names the landmarks whose blocks differ from the previous solve's (host list, strictly increasing)
+void schur_set_changed_points(slampp_hip_solver &s, const int64_t *p_points, int64_t n_points)
+{
+	CSchurState &S = *s.p_schur;
+	for(int64_t i = 0; i < n_points; ++ i) {
+		if(p_points[i] < 0 || p_points[i] >= S.np || (i && p_points[i] <= p_points[i - 1]))
+			throw std::invalid_argument("schur_set_changed_points: landmark indices must be strictly increasing and in range");
+	}
+	S.d_changed.Alloc(size_t(std::max<int64_t>(n_points, 1)));
+	if(n_points)
+		SLAMPP_HIP_CHECK(hipMemcpy(S.d_changed.p(), p_points, size_t(n_points) * sizeof(int64_t), hipMemcpyHostToDevice));
+	S.n_changed = n_points;
 }
 
 void schur_fill_stats(const CSchurState *p, slampp_hip_stats &st)
@@ -407,6 +437,135 @@ __global__ void schur_obs_W_kernel(int64_t n_obs, int64_t ubase, const int32_t *
 				t += u[r + k * DC] * ci[k + q * DP];
 			W[o * (DC * DP) + r + q * DC] = t;
 		}
+}
+
+
+// ---- incremental update of the reduced camera system ----
+// Stands where the reference's dog-leg solver updates its Schur complement from Omega = Lambda_new - Lambda_old instead
+// of recomputing it (include/slam/NonlinearSolver_Lambda_DL.h:1025-1086, 2301-): after a relinearization that moved a
+// few landmarks, S_new = S_old + (A_new - A_old) - sum over the changed landmarks of (U C^-1 U^T)_new - (U C^-1 U^T)_old.
+// The old contribution of a landmark is rebuilt from what the previous solve left on the device, W = U C^-1 and C^-1
+// (U C^-1 U^T = W C W^T), so no copy of the old values is kept; the reduced right-hand side is recomputed in full (eta
+// changes everywhere).  Several landmarks may touch one block of S at the same time: fp64 atomic adds, so the sum order --
+// unlike everywhere else in this library -- is not fixed (the option is off by default).
+template <int DC>
+__global__ void schur_delta_A_kernel(const int64_t *ptr, const int32_t *brow, int64_t nc,
+	const double *__restrict__ A, double *A_prev, const double *__restrict__ eta, double *S, int ld, int n,
+	const int64_t *__restrict__ p_dst, double *p_r)
+{
+	const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	const int64_t n_elems = ptr[nc] * DC * DC;
+	if(gid < n_elems) {
+		const int64_t k = gid / (DC * DC);
+		const int e = int(gid - k * (DC * DC)), rr = e % DC, q = e / DC;
+		int64_t lo = 0, hi = nc;
+		while(hi - lo > 1) {
+			const int64_t mid = (lo + hi) >> 1;
+			if(ptr[mid] <= k) lo = mid; else hi = mid;
+		}
+		const int64_t c = lo, r = brow[k];
+		const double f_new = A[gid], f_delta = f_new - A_prev[gid];
+		A_prev[gid] = f_new;
+		if(p_dst)
+			S[p_dst[k] + e] += f_delta;
+		else
+			S[size_t(c * DC + q) + size_t(r * DC + rr) * ld] += f_delta;
+	}
+	if(gid < n) {
+		if(p_dst)
+			p_r[gid] = eta[gid];
+		else
+			S[size_t(ld - 1) + size_t(gid) * ld] = eta[gid];
+	}
+}
+
+template <int DC, int DP>
+__global__ void schur_changed_points_kernel(const int64_t *__restrict__ changed, int64_t n_changed, const int64_t *ptr,
+	const int32_t *brow, int64_t nc, int64_t ubase, const double *__restrict__ A, double *Cinv, double *W,
+	int64_t n_sblocks, const int32_t *__restrict__ sb_row, const int32_t *__restrict__ sb_col, double *S, int ld,
+	const int64_t *__restrict__ p_dst, int *p_flag)
+{
+	const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(i >= n_changed)
+		return;
+	const int64_t pt = changed[i];
+	const int64_t k0 = ptr[nc + pt], o0 = k0 - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
+	double c_old[DP * DP], ci_old[DP * DP], c_new[DP * DP], ci_new[DP * DP];
+	#pragma unroll
+	for(int t = 0; t < DP * DP; ++ t)
+		ci_old[t] = Cinv[pt * (DP * DP) + t];
+	spd_inverse<DP>(ci_old, c_old); // C of the previous solve
+	const double *C = A + ubase + o1 * (DC * DP) + pt * (DP * DP);
+	#pragma unroll
+	for(int t = 0; t < DP * DP; ++ t)
+		c_new[t] = C[t];
+	if(!spd_inverse<DP>(c_new, ci_new))
+		atomicOr(p_flag, 1);
+	for(int64_t ob = o0; ob < o1; ++ ob) { // row block: the later (larger) camera
+		const double *Ub = A + ubase + ob * (DC * DP) + pt * (DP * DP);
+		const double *Wb = W + ob * (DC * DP);
+		double wc[DC * DP], wn[DC * DP]; // W_b C_old (old), U_b C^-1_new (new W_b)
+		#pragma unroll
+		for(int q = 0; q < DP; ++ q) {
+			#pragma unroll
+			for(int r = 0; r < DC; ++ r) {
+				double t_old = 0, t_new = 0;
+				#pragma unroll
+				for(int k = 0; k < DP; ++ k) {
+					t_old += Wb[r + k * DC] * c_old[k + q * DP];
+					t_new += Ub[r + k * DC] * ci_new[k + q * DP];
+				}
+				wc[r + q * DC] = t_old;
+				wn[r + q * DC] = t_new;
+			}
+		}
+		const int64_t cam_b = brow[k0 + (ob - o0)];
+		for(int64_t oa = o0; oa <= ob; ++ oa) {
+			const double *Ua = A + ubase + oa * (DC * DP) + pt * (DP * DP);
+			const double *Wa = W + oa * (DC * DP); // (the previous solve's: W is rewritten after the last pair, below)
+			const int64_t cam_a = brow[k0 + (oa - o0)];
+			// the block (row cam_b, column cam_a) of S: binary search on the blocks' sorted keys column * nc + row
+			const int64_t key = cam_a * nc + cam_b;
+			int64_t lo = 0, hi = n_sblocks - 1;
+			while(lo < hi) {
+				const int64_t mid = (lo + hi) >> 1;
+				if(int64_t(sb_col[mid]) * nc + sb_row[mid] < key) lo = mid + 1; else hi = mid;
+			}
+			#pragma unroll
+			for(int q = 0; q < DC; ++ q) {
+				#pragma unroll
+				for(int r = 0; r < DC; ++ r) {
+					double f_old = 0, f_new = 0;
+					#pragma unroll
+					for(int t = 0; t < DP; ++ t) {
+						f_old += wc[r + t * DC] * Wa[q + t * DC]; // (W_b C W_a^T)(r, q)
+						f_new += wn[r + t * DC] * Ua[q + t * DC]; // (U_b C^-1 U_a^T)(r, q)
+					}
+					const size_t idx = p_dst? size_t(p_dst[lo]) + q + r * DC :
+						size_t(cam_b * DC + r) + size_t(cam_a * DC + q) * ld;
+					atomicAdd(S + idx, f_old - f_new); // S = A - sum U C^-1 U^T: the old term comes back, the new one goes
+				}
+			}
+		}
+	}
+	// every pair of the landmark has read the old W: now it is replaced
+	for(int64_t ob = o0; ob < o1; ++ ob) {
+		const double *Ub = A + ubase + ob * (DC * DP) + pt * (DP * DP);
+		#pragma unroll
+		for(int q = 0; q < DP; ++ q) {
+			#pragma unroll
+			for(int r = 0; r < DC; ++ r) {
+				double t_new = 0;
+				#pragma unroll
+				for(int k = 0; k < DP; ++ k)
+					t_new += Ub[r + k * DC] * ci_new[k + q * DP];
+				W[ob * (DC * DP) + r + q * DC] = t_new;
+			}
+		}
+	}
+	#pragma unroll
+	for(int t = 0; t < DP * DP; ++ t)
+		Cinv[pt * (DP * DP) + t] = ci_new[t];
 }
 
 // one workgroup of W waves per nonzero block of S: S(row, col) -= sum_e U_b W_a^T; contribution e is
@@ -887,11 +1046,31 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 		schur_setup_reduced(s, S);
 	const bool b_sparse = S.b_reduced_sparse;
 	const size_t n_in_values = size_t(S.n_in_blocks) * DC * DC;
-	double *p_S = b_sparse? S.d_in_buf.p() : S.d_S.p();         // where the blocks go
+	// option "schur_incremental": what this solve assembles is kept (the dense system in a buffer of its own: the
+	// factorization works in place), and a solve that names the changed landmarks updates it instead of rebuilding it
+	const bool b_keep = s.n_schur_incremental != 0 && !s.p_allreduce && s.b_shard_primary;
+	const bool b_update = b_keep && S.b_prev_valid && S.n_changed >= 0;
+	if(b_keep) {
+		S.d_A_prev.Alloc(size_t(S.n_ablocks) * DC * DC);
+		if(!b_sparse)
+			S.d_S_unf.Alloc(size_t(ld) * ld);
+	}
+	double *p_S = b_sparse? S.d_in_buf.p() : ((b_keep)? S.d_S_unf.p() : S.d_S.p()); // where the blocks go
 	double *p_r = b_sparse? S.d_in_buf.p() + n_in_values : 0;   // the reduced right-hand side, if it is a vector of its own
 	const int64_t *p_sb_dst = b_sparse? S.d_sb_dst.p() : 0, *p_a_dst = b_sparse? S.d_a_dst.p() : 0;
 	SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), st));
 
+	if(b_update) {
+		s.Phase_Begin("schur_update");
+		const int64_t n_work = std::max<int64_t>(S.n_ablocks * DC * DC, n);
+		hipLaunchKernelGGL((schur_delta_A_kernel<DC>), dim3(unsigned((n_work + 255) / 256)), dim3(256), 0, st,
+			S.d_ptr.p(), S.d_brow.p(), S.nc, A, S.d_A_prev.p(), rhs, p_S, ld, n, p_a_dst, p_r);
+		if(S.n_changed > 0)
+			hipLaunchKernelGGL((schur_changed_points_kernel<DC, DP>), dim3(unsigned((S.n_changed + 63) / 64)), dim3(64), 0, st,
+				S.d_changed.p(), S.n_changed, S.d_ptr.p(), S.d_brow.p(), S.nc, ubase, A, S.d_Cinv.p(), S.d_W.p(), S.n_sblocks,
+				S.d_sb_row.p(), S.d_sb_col.p(), p_S, ld, p_sb_dst, s.d_flag.p());
+		s.Phase_End();
+	} else {
 	s.Phase_Begin("schur_init");
 	if(b_sparse)
 		SLAMPP_HIP_CHECK(hipMemsetAsync(p_S, 0, (n_in_values + size_t(n)) * sizeof(double), st));
@@ -904,6 +1083,8 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 		hipLaunchKernelGGL((schur_scatter_A_kernel<DC>), dim3(unsigned((n_work + 255) / 256)), dim3(256), 0, st,
 			S.d_ptr.p(), S.d_brow.p(), S.nc, A, rhs, p_S, ld, n, p_a_dst, p_r);
 	}
+	if(b_keep)
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(S.d_A_prev.p(), A, size_t(S.n_ablocks) * DC * DC * sizeof(double), hipMemcpyDeviceToDevice, st));
 	s.Phase_End();
 
 	s.Phase_Begin("schur_points");
@@ -927,6 +1108,9 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 				S.d_W.p(), p_S, ld, p_sb_dst);
 	}
 	s.Phase_End();
+	}
+	S.b_prev_valid = b_keep; // (a solve that turns out not positive definite takes it back: slampp_hip_sync)
+	S.n_changed = -1;        // the list serves one solve
 
 	s.Phase_Begin("schur_rhs");
 	hipLaunchKernelGGL((schur_rhs_kernel<DC, DP>), dim3(unsigned(S.nc)), dim3(64), 0, st,
@@ -968,6 +1152,10 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 		p_dx = p_r;
 	} else {
 		s.Phase_Begin("dense_chol");
+		if(b_keep) { // the assembled system stays as it is; its copy is factored
+			SLAMPP_HIP_CHECK(hipMemcpyAsync(S.d_S.p(), p_S, size_t(ld) * ld * sizeof(double), hipMemcpyDeviceToDevice, st));
+			p_S = S.d_S.p();
+		}
 		dense_cholesky(p_S, ld, n, S.d_invdiag.p(), s.d_flag.p(), st);
 		s.Phase_End();
 		s.Phase_Begin("dense_solve");
@@ -1209,6 +1397,7 @@ static void schur_enqueue_marginals_t(slampp_hip_solver &s, CSchurState &S, cons
 
 void schur_enqueue_marginals(slampp_hip_solver &s, const double *p_values_dev, double *p_cam_cov_dev, double *p_point_cov_dev)
 {
+	schur_invalidate_previous(s.p_schur); // C^-1, W (and the packed reduced system) are recomputed from these values
 	CSchurState &S = *s.p_schur;
 	if(S.DC == 6 && S.DP == 3)
 		schur_enqueue_marginals_t<6, 3>(s, S, p_values_dev, p_cam_cov_dev, p_point_cov_dev);
@@ -1222,6 +1411,7 @@ void schur_enqueue_marginals(slampp_hip_solver &s, const double *p_values_dev, d
 // system alone, dl = C^-1 eta_l, the pose part of the solution zeroed
 void schur_enqueue_marginal_poses(slampp_hip_solver &s, const double *p_values_dev, double *p_rhs_dev)
 {
+	schur_invalidate_previous(s.p_schur);
 	CSchurState &S = *s.p_schur;
 	if(S.DC == 6 && S.DP == 3)
 		schur_enqueue_marginal_t<6, 3>(s, S, p_values_dev, p_rhs_dev);

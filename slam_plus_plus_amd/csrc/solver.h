@@ -90,6 +90,7 @@ struct slampp_hip_solver {
 	int b_shard_primary;
 	int n_shard_rank, n_shard_world; // optional (-1, 0 = unknown): lets the ranks exchange block lists instead of an nc^2 indicator
 	int n_marginals_dense; // option marginals_dense: 1 = the covariances always through the dense inverse of the reduced system
+	int n_schur_incremental = 0; // option "schur_incremental": keep the assembled reduced system for slampp_hip_schur_set_changed_points
 	int n_schur_sparse; // reduced camera system: -1 = sparse path when few of its blocks are nonzero, 0 = always dense, 1 = always sparse
 
 	// Lambda structure as given
@@ -200,6 +201,8 @@ void damping_enqueue(const int64_t *p_off_dim_dev, int64_t n_first, int64_t n_la
 	hipStream_t stream); // assembly.hip
 void schur_enqueue_marginals(slampp_hip_solver &s, const double *p_values_dev, double *p_cam_cov_dev, double *p_point_cov_dev); // throws
 size_t schur_device_bytes(const CSchurState *p);
+void schur_invalidate_previous(CSchurState *p); // the kept reduced system no longer matches what the caller last solved
+void schur_set_changed_points(slampp_hip_solver &s, const int64_t *p_points, int64_t n_points); // throws
 void schur_fill_stats(const CSchurState *p, slampp_hip_stats &st);
 
 // Lambda assembly (assembly.hip)

@@ -909,6 +909,8 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 	}
 	else if(s == "schur_sparse" && n_value >= -1 && n_value <= 1)
 		p_solver->n_schur_sparse = int(n_value);
+	else if(s == "schur_incremental" && n_value >= 0 && n_value <= 1)
+		p_solver->n_schur_incremental = int(n_value);
 	else if(s == "dense_top_tiles" && n_value >= -1 && n_value <= 1) {
 		p_solver->n_dense_top_tiles = int(n_value);
 		p_solver->opt.dense_top_align = n_value? 64 : 0; // the alignment padding only serves the tile schedule
@@ -1080,6 +1082,7 @@ int slampp_hip_sync(slampp_hip_solver *p_solver)
 		}
 		if(*s.p_host_flag) {
 			s.b_factored = false;
+			schur_invalidate_previous(s.p_schur); // nothing to update from
 			return fail(p_solver, SLAMPP_HIP_NOT_POSDEF, "matrix is not positive definite");
 		}
 		return SLAMPP_HIP_OK;
@@ -1178,6 +1181,22 @@ int slampp_hip_upload_values_async(slampp_hip_solver *p_solver, int64_t n_first,
 				hipMemcpyHostToDevice, s.copy_stream));
 		}
 		s.n_uploaded = n_first + n_count;
+		return SLAMPP_HIP_OK;
+	});
+}
+
+int slampp_hip_schur_set_changed_points(slampp_hip_solver *p_solver, const int64_t *p_points, int64_t n_points)
+{
+	return guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_analyzed || s.n_mode != SLAMPP_HIP_MODE_SCHUR || !s.p_schur)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "schur_set_changed_points: analyze (Schur mode) was not called");
+		if(!s.n_schur_incremental)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "schur_set_changed_points: set the option schur_incremental first");
+		if(n_points < 0 || (n_points > 0 && !p_points))
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "schur_set_changed_points: null list");
+		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream)); // (the previous list may still be read)
+		schur_set_changed_points(s, p_points, n_points);
 		return SLAMPP_HIP_OK;
 	});
 }

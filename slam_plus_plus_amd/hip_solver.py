@@ -84,6 +84,7 @@ ABI = {
     "slampp_hip_upload_values_async": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "slampp_hip_solve_again": (C.c_int, [_P, _P]),
     "slampp_hip_factorize": (C.c_int, [_P, _P, _P]),
+    "slampp_hip_schur_set_changed_points": (C.c_int, [_P, _P, C.c_int64]),
     "slampp_hip_solve_marginal_poses": (C.c_int, [_P, _P, _P]),
     "slampp_hip_solve_marginal_poses_device_async": (C.c_int, [_P, _P, _P]),
     "slampp_hip_apply_damping_device_async": (C.c_int, [_P, _P, C.c_double, C.c_int64, C.c_int64]),
@@ -431,6 +432,14 @@ class CLinearSolver_Schur_HIP(_SolverBase):
 
     def SymbolicDecomposition_Blocky(self, lam, b_force_guided_ordering: bool = False) -> bool:
         return super().SymbolicDecomposition_Blocky(lam)
+
+    def Set_Changed_Landmarks(self, landmark_indices) -> None:
+        """The next Solve_PosDef_Blocky updates the reduced camera system of the previous one instead of rebuilding it
+        (option ``schur_incremental=1``; the reference's dog-leg solver does this from Omega = delta Lambda,
+        NonlinearSolver_Lambda_DL.h:2301-): ``landmark_indices`` = the landmarks (0-based among the landmark block
+        columns) whose blocks changed since the previous call; camera blocks and eta may change freely."""
+        idx = np.unique(np.asarray(landmark_indices, dtype=np.int64))
+        self._check(self._lib.slampp_hip_schur_set_changed_points(self._h, _ptr(idx) if idx.size else None, int(idx.size)))
 
     def Solve_PosDef_Blocky_MarginalPoses(self, lam, eta: np.ndarray) -> bool:
         """LinearSolver_Schur.h:1956-2143: only the landmarks are solved for (dl = C^-1 eta_l), the pose part of

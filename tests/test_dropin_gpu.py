@@ -44,6 +44,8 @@ def test_reference_nonlinear_solver_with_hip_linear_solver(tmp_path):
         assert r[k]["ok_ref"] == 1 and r[k]["ok_hip"] == 1 and r[k]["cam_rel_inf"] < 1e-10 and r[k]["lm_rel_inf"] < 1e-10, (k, r[k])
     for k in ("marginal_poses_cams_first", "marginal_poses_interleaved"):
         assert r[k]["ok_ref"] == 1 and r[k]["ok_hip"] == 1 and r[k]["rel_inf"] < 1e-10
+    for k in ("schur_incremental_cams_first", "schur_incremental_interleaved"):   # reduced system updated, not rebuilt
+        assert r[k]["ok_ref"] == 1 and r[k]["ok_hip"] == 1 and r[k]["changed_landmarks"] > 0 and r[k]["rel_inf"] < 1e-10, (k, r[k])
     # FastL with a loop closure at every step: many Factorize_PosDef_Blocky calls of different shapes on one instance
     # (sensitive to rounding: the yardstick is how far two of the reference's own solvers end apart)
     k = r["se3_fastl_loops_every_step"]

@@ -454,3 +454,79 @@ def test_random_ba_systems_match_oracle(seed):
         cams_ref, pts_ref = O.schur_marginals(lam)
         cams, pts = solver.Schur_Marginals(lam)
         assert rel_inf(cams, cams_ref) < TOL and rel_inf(pts, pts_ref) < TOL
+
+
+def _relinearized(lam, points, rng):
+    """The same BA system after a relinearization that moved the landmarks ``points``: their C blocks and the U blocks
+    of their observations change, so do all camera blocks and the whole right-hand side."""
+    nc = lam.n_matrix_cut
+    off = lam.block_value_offsets()
+    vals = lam.values.copy()
+    for p in points:
+        k0, k1 = int(lam.bcol_ptr[nc + p]), int(lam.bcol_ptr[nc + p + 1])
+        for k in range(k0, k1 - 1):                                  # U blocks of the landmark's observations
+            vals[off[k]:off[k + 1]] *= 1.0 + 0.3 * rng.standard_normal()
+        d = int(lam.cumsum[nc + p + 1] - lam.cumsum[nc + p])
+        vals[off[k1 - 1]:off[k1]] += (0.5 + rng.random()) * np.eye(d).ravel()   # C_p stays positive definite
+    for c in range(nc):                                              # camera blocks: a little more on the diagonal
+        k = int(lam.bcol_ptr[c + 1] - 1)
+        d = int(lam.cumsum[c + 1] - lam.cumsum[c])
+        vals[off[k]:off[k + 1]] += (0.1 + rng.random()) * np.eye(d).ravel()
+    return dataclasses.replace(lam, values=vals, rhs=rng.standard_normal(lam.rhs.shape[0]))
+
+
+@pytest.mark.parametrize("sparse", [0, 1])
+@pytest.mark.parametrize("mode", ["venice", "band"])
+def test_incremental_update_of_the_reduced_system_matches_full_recomputation(mode, sparse):
+    """Option schur_incremental: a solve that names the landmarks whose blocks changed updates the reduced camera system of
+    the previous solve (the reference's dog-leg solver: NonlinearSolver_Lambda_DL.h:2301-) -- against the oracle's full
+    solve of the changed system, over three relinearizations, the last one changing no landmark at all."""
+    rng = np.random.default_rng(17)
+    lam = synth.ba(120, 6000, k=4, mode=mode, seed=19)
+    solver = CLinearSolver_Schur_HIP(schur_incremental=1, schur_sparse=sparse, profile=1)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta)
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok and rel_inf(eta, x_ref) < TOL
+    n_pts = lam.n_bcols - lam.n_matrix_cut
+    for n_changed in (57, 1, 0):
+        points = np.sort(rng.choice(n_pts, size=n_changed, replace=False))
+        lam = _relinearized(lam, points, rng)
+        ok, x_ref, _, _ = O.solve_schur(lam)
+        assert ok
+        solver.profile(reset=True)
+        solver.Set_Changed_Landmarks(points)
+        eta = lam.rhs.copy()
+        assert solver.Solve_PosDef_Blocky(lam, eta)
+        phases = solver.profile()
+        assert phases.get("schur_update", (0, 0))[0] == 1 and phases.get("schur_gather", (0, 0))[0] == 0   # it was an update
+        assert rel_inf(eta, x_ref) < TOL, n_changed
+    # without a list the next solve rebuilds; with the option off the call is refused
+    eta = lam.rhs.copy()
+    solver.profile(reset=True)
+    assert solver.Solve_PosDef_Blocky(lam, eta) and solver.profile().get("schur_gather", (0, 0))[0] == 1
+    assert rel_inf(eta, x_ref) < TOL
+    with pytest.raises(ValueError):
+        CLinearSolver_Schur_HIP().Set_Changed_Landmarks([0])
+
+
+def test_incremental_update_after_a_failed_solve_rebuilds():
+    """A solve that was not positive definite leaves nothing valid to update from: the next one rebuilds, list or not."""
+    rng = np.random.default_rng(5)
+    lam = synth.ba(40, 1500, k=3, seed=23)
+    solver = CLinearSolver_Schur_HIP(schur_incremental=1, profile=1)
+    assert solver.Solve_PosDef(lam, lam.rhs.copy())
+    off = lam.block_value_offsets()
+    bad_vals = lam.values.copy()
+    last = lam.n_blocks - 1
+    bad_vals[off[last]:off[last + 1]] -= 50.0 * np.eye(3).ravel()
+    bad = dataclasses.replace(lam, values=bad_vals)
+    solver.Set_Changed_Landmarks([lam.n_bcols - lam.n_matrix_cut - 1])
+    assert solver.Solve_PosDef_Blocky(bad, bad.rhs.copy()) is False
+    lam2 = _relinearized(lam, [3, 4], rng)
+    ok, x_ref, _, _ = O.solve_schur(lam2)
+    solver.profile(reset=True)
+    solver.Set_Changed_Landmarks([3, 4])
+    eta = lam2.rhs.copy()
+    assert ok and solver.Solve_PosDef_Blocky(lam2, eta) and rel_inf(eta, x_ref) < TOL
+    assert solver.profile().get("schur_gather", (0, 0))[0] == 1
