@@ -33,6 +33,9 @@
 
 #include <stdint.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -81,6 +84,13 @@ protected:
 #endif // _OPENMP
 	}
 
+	static double f_Wall_Ms()
+	{
+		struct timespec t_now;
+		clock_gettime(CLOCK_MONOTONIC, &t_now);
+		return t_now.tv_sec * 1e3 + t_now.tv_nsec * 1e-6;
+	}
+
 	void Throw_On_Error(int n_result) const // throw(std::bad_alloc, std::runtime_error)
 	{
 		if(n_result == SLAMPP_HIP_ERR_ALLOC)
@@ -109,6 +119,8 @@ protected:
 	{
 		_ASSERTE(r_lambda.b_SymmetricLayout());
 		Require_Handle();
+		const bool b_timing = getenv("SLAMPP_HIP_PLAN_TIMING") != 0; // development aid: where the cold call's time goes
+		const double f_t0 = b_timing? f_Wall_Ms() : 0;
 		const size_t n = r_lambda.n_BlockColumn_Num();
 		std::vector<size_t> inv_order(n);
 		if(p_order) {
@@ -180,12 +192,18 @@ protected:
 			}
 			m_n_value_num = size_t(n_value_num);
 		}
+		const double f_t1 = b_timing? f_Wall_Ms() : 0;
 		int n_result = slampp_hip_set_structure(m_p_solver, int64_t(n), &m_cumsum[0], &m_bcol_ptr[0],
 			m_brow.empty()? 0 : &m_brow[0]);
 		if(n_result == SLAMPP_HIP_OK)
 			n_result = slampp_hip_analyze(m_p_solver, n_mode, int64_t(n_matrix_cut));
+		const double f_t2 = b_timing? f_Wall_Ms() : 0;
 		if(n_result == SLAMPP_HIP_OK)
 			n_result = slampp_hip_host_staging(m_p_solver, &m_p_values, &m_p_rhs);
+		if(b_timing) {
+			fprintf(stderr, "[header] structure of lambda %.2f ms, set_structure + analyze %.2f ms, pinned staging %.2f ms\n",
+				f_t1 - f_t0, f_t2 - f_t1, f_Wall_Ms() - f_t2);
+		}
 		Throw_On_Error(n_result);
 		m_b_structure_valid = true;
 		return true;

@@ -523,7 +523,12 @@ void slampp_hip_solver::Analyze_Sparse()
 	dplan.n_rents = int64_t(rents.size());
 	dplan.p_timing = 0;
 	dplan.task_map = 0;
-	Build_Simt();
+	{
+		const double t_simt = wall_ms();
+		Build_Simt();
+		if(b_timing)
+			fprintf(stderr, "[setup] %-12s %8.2f ms\n", "shapes", wall_ms() - t_simt);
+	}
 	if(getenv("SLAMPP_HIP_STAGE_TIMING")) { // development aid: clock samples of the upper-stage kernel, printed at sync
 		d_timing.Alloc(1 + 32 * 4096);
 		SLAMPP_HIP_CHECK(hipMemsetAsync(d_timing.p(), 0, (1 + 32 * 4096) * sizeof(long long), stream));

@@ -7,7 +7,7 @@ from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP
 lam = synth.pose_chain(n=int(sys.argv[1]) if len(sys.argv) > 1 else 100000)
 dev = torch.device("cuda:0")
 vals = torch.from_numpy(lam.values).to(dev)
-for opts in ({}, {"wide_min_tasks": 512}, {"wide_min_tasks": 300}, {"wide_min_tasks": 200}, {"wide_min_tasks": 100}, {"wide_min_tasks": 40}):
+for opts in ({}, {"subtree_size": 7}, {"subtree_size": 6}, {"subtree_size": 5}, {"subtree_size": 4}, {"subtree_size": 6, "leaf_size": 3}, {"subtree_size": 6, "leaf_size": 6}, {"subtree_size": 10}):
     s = CLinearSolver_HIP(**opts)
     s.SymbolicDecomposition_Blocky(lam)
     reps = 20
