@@ -136,61 +136,126 @@ protected:
 		m_cumsum[0] = 0;
 		for(size_t i = 0; i < n; ++ i)
 			m_cumsum[i + 1] = m_cumsum[i] + int64_t(r_lambda.n_BlockColumn_Column_Num(p_order? m_order[i] : i));
-		// count the blocks of every destination column (upper triangle of the permuted matrix)
-		m_bcol_ptr.assign(n + 1, 0);
 		m_col_block_num.resize(n);
 		m_col_width.resize(n);
-		size_t n_block_num = 0;
-		for(size_t c = 0; c < n; ++ c) {
-			m_col_block_num[c] = uint32_t(r_lambda.n_BlockColumn_Block_Num(c));
-			m_col_width[c] = uint32_t(r_lambda.n_BlockColumn_Column_Num(c));
-			for(size_t j = 0, m = r_lambda.n_BlockColumn_Block_Num(c); j < m; ++ j) {
-				const size_t r = r_lambda.n_Block_Row(c, j);
-				if(r > c)
-					continue; // only the upper triangle is used, as in the reference's solvers
-				++ m_bcol_ptr[std::max(inv_order[r], inv_order[c]) + 1];
-				++ n_block_num;
+		bool b_prefix = !p_order;
+		if(b_prefix) {
+			// no permutation, and the block rows ascend inside a column (CUberBlockMatrix keeps them sorted): the upper
+			// triangle is a prefix of every column, in place -- counted, offset and filled column-parallel
+			m_bcol_ptr.assign(n + 1, 0);
+			std::vector<int64_t> value_ptr(n + 1, 0);
+			const int n_thread_num = n_Copy_Thread_Num();
+			const long n_col_num = long(n);
+			int n_unsorted = 0;
+			#pragma omp parallel for schedule(static) num_threads(n_thread_num) reduction(+:n_unsorted)
+			for(long c = 0; c < n_col_num; ++ c) {
+				const size_t m = r_lambda.n_BlockColumn_Block_Num(c);
+				m_col_block_num[c] = uint32_t(m);
+				m_col_width[c] = uint32_t(r_lambda.n_BlockColumn_Column_Num(c));
+				size_t n_upper = 0, n_last_row = 0;
+				int64_t n_height = 0;
+				for(size_t j = 0; j < m; ++ j) {
+					const size_t r = r_lambda.n_Block_Row(c, j);
+					if(j && r <= n_last_row)
+						++ n_unsorted;
+					n_last_row = r;
+					if(r <= size_t(c)) {
+						if(n_upper != j)
+							++ n_unsorted;
+						++ n_upper;
+						n_height += int64_t(m_cumsum[r + 1] - m_cumsum[r]); // symmetric layout
+					}
+				}
+				m_bcol_ptr[c + 1] = int64_t(n_upper);
+				value_ptr[c + 1] = n_height * int64_t(m_col_width[c]);
+			}
+			if(n_unsorted)
+				b_prefix = false; // not the layout assumed: the general path below
+			else {
+				for(size_t i = 0; i < n; ++ i) {
+					m_bcol_ptr[i + 1] += m_bcol_ptr[i];
+					value_ptr[i + 1] += value_ptr[i];
+				}
+				const size_t n_block_num = size_t(m_bcol_ptr[n]);
+				m_brow.resize(n_block_num);
+				m_gather.resize(n_block_num);
+				#pragma omp parallel for schedule(static) num_threads(n_thread_num)
+				for(long c = 0; c < n_col_num; ++ c) {
+					int64_t n_dest = value_ptr[c];
+					const int32_t n_width = int32_t(m_col_width[c]);
+					for(int64_t k = m_bcol_ptr[c], j = 0; k < m_bcol_ptr[c + 1]; ++ k, ++ j) {
+						const size_t r = r_lambda.n_Block_Row(c, size_t(j));
+						TGatherEntry t;
+						t.n_col = uint32_t(c);
+						t.n_blk = uint32_t(j);
+						t.n_row = uint32_t(r);
+						t.n_rows = int32_t(m_cumsum[r + 1] - m_cumsum[r]);
+						t.n_cols = n_width;
+						t.b_transpose = false;
+						t.n_dest = n_dest;
+						n_dest += int64_t(t.n_rows) * n_width;
+						m_brow[k] = int32_t(r);
+						m_gather[k] = t;
+					}
+				}
+				m_n_value_num = size_t(value_ptr[n]);
 			}
 		}
-		for(size_t i = 0; i < n; ++ i)
-			m_bcol_ptr[i + 1] += m_bcol_ptr[i];
-		m_brow.resize(n_block_num);
-		m_gather.resize(n_block_num);
-		{
-			// place, then sort the rows of every destination column
-			std::vector<int64_t> fill(m_bcol_ptr.begin(), m_bcol_ptr.end() - 1);
-			std::vector<std::pair<int32_t, TGatherEntry> > placed(n_block_num);
+		if(!b_prefix) {
+			// count the blocks of every destination column (upper triangle of the permuted matrix)
+			m_bcol_ptr.assign(n + 1, 0);
+			size_t n_block_num = 0;
 			for(size_t c = 0; c < n; ++ c) {
+				m_col_block_num[c] = uint32_t(r_lambda.n_BlockColumn_Block_Num(c));
+				m_col_width[c] = uint32_t(r_lambda.n_BlockColumn_Column_Num(c));
 				for(size_t j = 0, m = r_lambda.n_BlockColumn_Block_Num(c); j < m; ++ j) {
 					const size_t r = r_lambda.n_Block_Row(c, j);
 					if(r > c)
-						continue;
-					const size_t nr = inv_order[r], nc = inv_order[c];
-					TGatherEntry t;
-					t.n_col = uint32_t(c);
-					t.n_blk = uint32_t(j);
-					t.n_row = uint32_t(r);
-					t.n_rows = int32_t(r_lambda.n_BlockColumn_Column_Num(r)); // symmetric layout
-					t.n_cols = int32_t(r_lambda.n_BlockColumn_Column_Num(c));
-					t.b_transpose = nr > nc; // lands below the diagonal: store its transpose above
-					t.n_dest = 0;
-					const size_t n_dest_col = std::max(nr, nc), n_dest_row = std::min(nr, nc);
-					placed[fill[n_dest_col] ++] = std::make_pair(int32_t(n_dest_row), t);
+						continue; // only the upper triangle is used, as in the reference's solvers
+					++ m_bcol_ptr[std::max(inv_order[r], inv_order[c]) + 1];
+					++ n_block_num;
 				}
 			}
-			int64_t n_value_num = 0;
-			for(size_t c = 0; c < n; ++ c) {
-				std::sort(placed.begin() + m_bcol_ptr[c], placed.begin() + m_bcol_ptr[c + 1],
-					[](const std::pair<int32_t, TGatherEntry> &a, const std::pair<int32_t, TGatherEntry> &b) {
-						return a.first < b.first; });
-				for(int64_t k = m_bcol_ptr[c]; k < m_bcol_ptr[c + 1]; ++ k) {
-					m_brow[k] = placed[k].first;
-					m_gather[k] = placed[k].second;
-					m_gather[k].n_dest = n_value_num;
-					n_value_num += int64_t(m_gather[k].n_rows) * m_gather[k].n_cols;
+			for(size_t i = 0; i < n; ++ i)
+				m_bcol_ptr[i + 1] += m_bcol_ptr[i];
+			m_brow.resize(n_block_num);
+			m_gather.resize(n_block_num);
+			{
+				// place, then sort the rows of every destination column
+				std::vector<int64_t> fill(m_bcol_ptr.begin(), m_bcol_ptr.end() - 1);
+				std::vector<std::pair<int32_t, TGatherEntry> > placed(n_block_num);
+				for(size_t c = 0; c < n; ++ c) {
+					for(size_t j = 0, m = r_lambda.n_BlockColumn_Block_Num(c); j < m; ++ j) {
+						const size_t r = r_lambda.n_Block_Row(c, j);
+						if(r > c)
+							continue;
+						const size_t nr = inv_order[r], nc = inv_order[c];
+						TGatherEntry t;
+						t.n_col = uint32_t(c);
+						t.n_blk = uint32_t(j);
+						t.n_row = uint32_t(r);
+						t.n_rows = int32_t(r_lambda.n_BlockColumn_Column_Num(r)); // symmetric layout
+						t.n_cols = int32_t(r_lambda.n_BlockColumn_Column_Num(c));
+						t.b_transpose = nr > nc; // lands below the diagonal: store its transpose above
+						t.n_dest = 0;
+						const size_t n_dest_col = std::max(nr, nc), n_dest_row = std::min(nr, nc);
+						placed[fill[n_dest_col] ++] = std::make_pair(int32_t(n_dest_row), t);
+					}
 				}
+				int64_t n_value_num = 0;
+				for(size_t c = 0; c < n; ++ c) {
+					std::sort(placed.begin() + m_bcol_ptr[c], placed.begin() + m_bcol_ptr[c + 1],
+						[](const std::pair<int32_t, TGatherEntry> &a, const std::pair<int32_t, TGatherEntry> &b) {
+							return a.first < b.first; });
+					for(int64_t k = m_bcol_ptr[c]; k < m_bcol_ptr[c + 1]; ++ k) {
+						m_brow[k] = placed[k].first;
+						m_gather[k] = placed[k].second;
+						m_gather[k].n_dest = n_value_num;
+						n_value_num += int64_t(m_gather[k].n_rows) * m_gather[k].n_cols;
+					}
+				}
+				m_n_value_num = size_t(n_value_num);
 			}
-			m_n_value_num = size_t(n_value_num);
 		}
 		const double f_t1 = b_timing? f_Wall_Ms() : 0;
 		int n_result = slampp_hip_set_structure(m_p_solver, int64_t(n), &m_cumsum[0], &m_bcol_ptr[0],

@@ -150,6 +150,7 @@ struct slampp_hip_solver {
 	// (slampp_hip_host_staging / slampp_hip_upload_values_async; callers' own arrays are moved through it in chunks)
 	double *p_pin_values = 0, *p_pin_rhs = 0;
 	size_t n_pin_values = 0, n_pin_rhs = 0;
+	bool b_pin_values_registered = false, b_pin_rhs_registered = false; // malloc + hipHostRegister rather than hipHostMalloc
 	hipStream_t copy_stream = 0;
 	hipEvent_t copy_done = 0;
 	int64_t n_uploaded = 0; // values [0, n_uploaded) of the staging are already on their way to d_A
