@@ -21,11 +21,14 @@
 #include "solver.h"
 #include "dense_chol.h"
 #include "sparse_inverse.h"
+#include "schur_tiles.h"
 
 #include <algorithm>
 #include <cstring>
 
 namespace slampp {
+
+#include "schur_device.inl"
 
 struct CSchurState {
 	int DC, DP;
@@ -71,6 +74,7 @@ struct CSchurState {
 	CDevArray<double> d_S_unf;                 // dense reduced system: S as assembled (d_S is factored in place)
 	CDevArray<int64_t> d_changed;              // landmarks named for the next solve
 	int64_t n_changed = -1;                    // -1: none named (full rebuild)
+	CSchurTiles tiles;                         // landmark-major assembly of S (schur_tiles.hip)
 	CSchurState() :p_union_fn(0), p_union_context(0), b_union_dense(false), n_union(0), b_reduced_decided(false),
 		b_reduced_sparse(false), p_inner(0), n_in_blocks(0), p_sinv(0), b_sinv_tried(false) {}
 	~CSchurState();
@@ -98,7 +102,7 @@ size_t schur_device_bytes(const CSchurState *p)
 		p->d_m_invdiag.n_Bytes() + p->d_m_zero.n_Bytes() + p->d_m_Zs.n_Bytes() + p->d_cam_zoff.n_Bytes() +
 		p->d_pair_ptr.n_Bytes() + p->d_pair_tab.n_Bytes() + sparse_inverse_bytes(p->p_sinv) +
 		p->d_Cinv.n_Bytes() + p->d_t.n_Bytes() + p->d_invdiag.n_Bytes() + p->d_z.n_Bytes() + p->d_x.n_Bytes() +
-		p->d_A_prev.n_Bytes() + p->d_S_unf.n_Bytes() + p->d_changed.n_Bytes();
+		p->d_A_prev.n_Bytes() + p->d_S_unf.n_Bytes() + p->d_changed.n_Bytes() + p->tiles.n_Bytes();
 }
 
 void schur_invalidate_previous(CSchurState *p)
@@ -275,6 +279,7 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 		}
 
 		hipStream_t st = s.stream;
+		schur_tiles_build(S.tiles, s.n_schur_tiles, int(DC), int(DP), nc, np, ptr, brow, sb_row, sb_col, S.n_ablocks, st);
 		S.d_ptr.Upload(s.bcol_ptr, st);
 		S.d_brow.Upload(s.brow, st);
 		S.d_obs_pt.Upload(obs_pt, st);
@@ -333,62 +338,6 @@ __global__ void schur_scatter_A_kernel(const int64_t *ptr, const int32_t *brow, 
 		else
 			S[size_t(ld - 1) + size_t(gid) * ld] = eta[gid];
 	}
-}
-
-// small SPD inverse through its Cholesky factor; returns false on a non-positive pivot
-template <int D>
-__device__ __forceinline__ bool spd_inverse(const double *a /* column-major, upper triangle read */, double *inv)
-{
-	double L[D][D], X[D][D];
-	bool ok = true;
-	#pragma unroll
-	for(int j = 0; j < D; ++ j) {
-		double s = a[j + j * D];
-		#pragma unroll
-		for(int k = 0; k < D; ++ k)
-			if(k < j) s -= L[j][k] * L[j][k];
-		if(!(s > 0)) { ok = false; s = 1; }
-		const double d = sqrt(s);
-		L[j][j] = d;
-		#pragma unroll
-		for(int i = 0; i < D; ++ i) {
-			if(i > j) {
-				double t = a[j + i * D]; // element (j, i) of the upper triangle = (i, j)
-				#pragma unroll
-				for(int k = 0; k < D; ++ k)
-					if(k < j) t -= L[i][k] * L[j][k];
-				L[i][j] = t / d;
-			}
-		}
-	}
-	// X = L^-1 (lower)
-	#pragma unroll
-	for(int c = 0; c < D; ++ c) {
-		#pragma unroll
-		for(int r = 0; r < D; ++ r) {
-			if(r < c) X[r][c] = 0;
-			else if(r == c) X[r][c] = 1.0 / L[r][r];
-			else {
-				double t = 0;
-				#pragma unroll
-				for(int k = 0; k < D; ++ k)
-					if(k >= c && k < r) t += L[r][k] * X[k][c];
-				X[r][c] = -t / L[r][r];
-			}
-		}
-	}
-	// inv = X^T X
-	#pragma unroll
-	for(int c = 0; c < D; ++ c)
-		#pragma unroll
-		for(int r = 0; r < D; ++ r) {
-			double t = 0;
-			#pragma unroll
-			for(int k = 0; k < D; ++ k)
-				if(k >= r && k >= c) t += X[k][r] * X[k][c];
-			inv[r + c * D] = t;
-		}
-	return ok;
 }
 
 template <int DC, int DP>
@@ -583,12 +532,13 @@ template <int DC, int DP, int W>
 __global__ void __launch_bounds__(64 * W)
 schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *sb_row, const int32_t *sb_col,
 	const int32_t *ent_a, const int64_t *ent_uoff, const double *__restrict__ A, const double *__restrict__ W_,
-	double *S, int ld, const int64_t *__restrict__ p_dst)
+	double *S, int ld, const int64_t *__restrict__ p_dst, const int32_t *__restrict__ sb_map)
 {
 	enum { BLK = DC * DP, BATCH = 8 };
 	__shared__ double s_ops[W][BATCH][2 * BLK];
 	__shared__ double s_part[W][64];
-	const int64_t sb = blockIdx.x;
+	const int64_t n_list = blockIdx.x; // list n_list serves block sb of S (the same, unless only some landmarks go through lists)
+	const int64_t sb = sb_map? int64_t(sb_map[n_list]) : n_list;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const bool b_act = lane < DC * DC;
 	const int r = b_act? lane % DC : 0, q = b_act? lane / DC : 0;
@@ -611,7 +561,7 @@ schur_gather_S_kernel(int64_t n_sblocks, const int64_t *sb_ptr, const int32_t *s
 		frag_off[q4] = ent * (2 * BLK) + mm + t * DC;
 	}
 	const double *s_my = &s_ops[wave][0][0];
-	const int64_t e0 = sb_ptr[sb], e1 = sb_ptr[sb + 1];
+	const int64_t e0 = sb_ptr[n_list], e1 = sb_ptr[n_list + 1];
 	// this wave's entries: e0 + wave, e0 + wave + W, ...; processed in chunks of 64
 	for(int64_t base = e0 + wave; base < e1; base += int64_t(64) * W) {
 		const int64_t my = base + int64_t(lane) * W;
@@ -1087,25 +1037,45 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 		SLAMPP_HIP_CHECK(hipMemcpyAsync(S.d_A_prev.p(), A, size_t(S.n_ablocks) * DC * DC * sizeof(double), hipMemcpyDeviceToDevice, st));
 	s.Phase_End();
 
+	// Landmarks go through the tiles of schur_tiles.hip (read once each), through the contribution lists, or -- when only
+	// some of them fit the tiles -- both: the tiles take theirs, the lists the rest.
+	const CSchurTiles &T = S.tiles;
+	const bool b_tiles = T.b_enabled, b_lists_all = !b_tiles;
 	s.Phase_Begin("schur_points");
-	hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((S.np + 255) / 256)), dim3(256), 0, st,
-		S.d_ptr.p(), S.nc, S.np, ubase, A, S.d_Cinv.p(), s.d_flag.p());
-	hipLaunchKernelGGL((schur_obs_W_kernel<DC, DP>), dim3(unsigned((S.n_obs + 255) / 256)), dim3(256), 0, st,
-		S.n_obs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p());
+	if(b_lists_all || T.b_hybrid) {
+		hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((S.np + 255) / 256)), dim3(256), 0, st,
+			S.d_ptr.p(), S.nc, S.np, ubase, A, S.d_Cinv.p(), s.d_flag.p());
+		hipLaunchKernelGGL((schur_obs_W_kernel<DC, DP>), dim3(unsigned((S.n_obs + 255) / 256)), dim3(256), 0, st,
+			S.n_obs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p());
+	}
 	s.Phase_End();
 
+	if(b_tiles) {
+		s.Phase_Begin("schur_tiles");
+		// (C^-1 of every landmark is needed by the back-substitution; W only if the next solve may be an update)
+		schur_tiles_enqueue(T, DC, DP, S.d_ptr.p(), S.nc, ubase, A, rhs, n, S.d_Cinv.p(), (b_keep && !T.b_hybrid)? S.d_W.p() : 0,
+			!T.b_hybrid, S.d_sb_row.p(), S.d_sb_col.p(), p_S, ld, p_sb_dst, p_r, s.d_flag.p(), st);
+		s.Phase_End();
+	}
+
 	s.Phase_Begin("schur_gather");
-	if(S.n_sblocks > 0) {
-		// one wave per block of S for short contribution lists (dense S: 500k blocks x 10 contributions),
-		// 8 waves per block for long ones (C4's band structure: 4000 blocks x 1250 contributions: 1.18 -> 0.69 ms)
-		if(S.n_entries > 256 * S.n_sblocks)
-			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 8>), dim3(unsigned(S.n_sblocks)), dim3(512), 0, st,
-				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
-				S.d_W.p(), p_S, ld, p_sb_dst);
-		else
-			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 1>), dim3(unsigned(S.n_sblocks)), dim3(64), 0, st,
-				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
-				S.d_W.p(), p_S, ld, p_sb_dst);
+	{
+		const int64_t n_lists = b_lists_all? S.n_sblocks : T.n_xblocks, n_list_entries = b_lists_all? S.n_entries : T.n_xentries;
+		const int64_t *p_list_ptr = b_lists_all? S.d_sb_ptr.p() : T.d_xsb_ptr.p();
+		const int32_t *p_list_a = b_lists_all? S.d_ent_a.p() : T.d_xent_a.p(), *p_list_map = b_lists_all? 0 : T.d_xsb_map.p();
+		const int64_t *p_list_uoff = b_lists_all? S.d_ent_uoff.p() : T.d_xent_uoff.p();
+		if(n_lists > 0) {
+			// one wave per block of S for short contribution lists (dense S: 500k blocks x 10 contributions),
+			// 8 waves per block for long ones (C4's band structure: 4000 blocks x 1250 contributions: 1.18 -> 0.69 ms)
+			if(n_list_entries > 256 * n_lists)
+				hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 8>), dim3(unsigned(n_lists)), dim3(512), 0, st,
+					n_lists, p_list_ptr, S.d_sb_row.p(), S.d_sb_col.p(), p_list_a, p_list_uoff, A,
+					S.d_W.p(), p_S, ld, p_sb_dst, p_list_map);
+			else
+				hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 1>), dim3(unsigned(n_lists)), dim3(64), 0, st,
+					n_lists, p_list_ptr, S.d_sb_row.p(), S.d_sb_col.p(), p_list_a, p_list_uoff, A,
+					S.d_W.p(), p_S, ld, p_sb_dst, p_list_map);
+		}
 	}
 	s.Phase_End();
 	}
@@ -1113,8 +1083,12 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 	S.n_changed = -1;        // the list serves one solve
 
 	s.Phase_Begin("schur_rhs");
-	hipLaunchKernelGGL((schur_rhs_kernel<DC, DP>), dim3(unsigned(S.nc)), dim3(64), 0, st,
-		S.d_cam_ptr.p(), S.d_cam_obs.p(), S.d_obs_pt.p(), n, S.d_W.p(), rhs, p_S, ld, p_r);
+	if(b_update || !S.tiles.b_enabled) // (the tiles bring the right-hand side's share of their landmarks themselves)
+		hipLaunchKernelGGL((schur_rhs_kernel<DC, DP>), dim3(unsigned(S.nc)), dim3(64), 0, st,
+			S.d_cam_ptr.p(), S.d_cam_obs.p(), S.d_obs_pt.p(), n, S.d_W.p(), rhs, p_S, ld, p_r);
+	else if(S.tiles.b_hybrid)
+		hipLaunchKernelGGL((schur_rhs_kernel<DC, DP>), dim3(unsigned(S.nc)), dim3(64), 0, st,
+			S.tiles.d_xcam_ptr.p(), S.tiles.d_xcam_obs.p(), S.d_obs_pt.p(), n, S.d_W.p(), rhs, p_S, ld, p_r);
 	s.Phase_End();
 
 	if(s.p_allreduce) {
@@ -1298,11 +1272,11 @@ static void schur_enqueue_marginals_sparse_t(slampp_hip_solver &s, CSchurState &
 		if(S.n_entries > 256 * S.n_sblocks)
 			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 8>), dim3(unsigned(S.n_sblocks)), dim3(512), 0, st,
 				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
-				S.d_W.p(), p_S, S.Npad, S.d_sb_dst.p());
+				S.d_W.p(), p_S, S.Npad, S.d_sb_dst.p(), (const int32_t*)0);
 		else
 			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 1>), dim3(unsigned(S.n_sblocks)), dim3(64), 0, st,
 				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
-				S.d_W.p(), p_S, S.Npad, S.d_sb_dst.p());
+				S.d_W.p(), p_S, S.Npad, S.d_sb_dst.p(), (const int32_t*)0);
 	}
 	s.Phase_End();
 	if(s.p_allreduce) {
@@ -1367,11 +1341,11 @@ static void schur_enqueue_marginals_t(slampp_hip_solver &s, CSchurState &S, cons
 		if(S.n_entries > 256 * S.n_sblocks)
 			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 8>), dim3(unsigned(S.n_sblocks)), dim3(512), 0, st,
 				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
-				S.d_W.p(), p_S, ld, (const int64_t*)0);
+				S.d_W.p(), p_S, ld, (const int64_t*)0, (const int32_t*)0);
 		else
 			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 1>), dim3(unsigned(S.n_sblocks)), dim3(64), 0, st,
 				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
-				S.d_W.p(), p_S, ld, (const int64_t*)0);
+				S.d_W.p(), p_S, ld, (const int64_t*)0, (const int32_t*)0);
 	}
 	s.Phase_End();
 	if(s.p_allreduce) {

@@ -1,0 +1,980 @@
+// schur_tiles.hip -- landmark-major assembly of the reduced camera system S = A - U C^-1 U^T, r = x - U C^-1 l
+// (steps 4-9 of CLinearSolver_Schur::Solve_PosDef_Blocky, /root/reference/include/slam/LinearSolver_Schur.h:1730-1830:
+// InverseOf_BlockDiag, the two MultiplyToWith_FBS products, AddTo_FBS, PreMultiply_Add).
+//
+// The contribution lists of schur.hip read 288 bytes per (landmark, camera pair): a landmark seen by k cameras is read
+// k (k + 1) / 2 times -- 1.44 GB at C4 for 0.58 GB of blocks, and the list kernel ran at the HBM traffic those re-reads
+// generate.  Here every landmark is read once.  Landmarks are sorted by their first two cameras and cut into *tiles*
+// whose landmarks touch at most SCHUR_TILE_SLOTS distinct blocks of S; one wave owns a tile, keeps those blocks (and the
+// right-hand sides of their cameras) in LDS, and for each of its landmarks loads [U_1 .. U_k | C | l], inverts C,
+// forms W = U C^-1 and adds the k (k + 1) / 2 products U_b W_a^T into its LDS blocks -- one lane per (camera pair, row).
+// The tile's blocks then go to a partial array, and a second kernel sums the partials of every block of S in list order:
+// no atomics on memory, the sum order is fixed by the analysis (bit-reproducible, like the lists).
+// Landmarks with more cameras than a tile has room for, and tiles whose landmarks share too little (fewer than three
+// contributions per block: random visibility), stay with the contribution lists.
+#include "schur_tiles.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+namespace slampp {
+
+#include "schur_device.inl"
+
+constexpr int tile_max_k(int n_cap)
+{
+	int k = 1;
+	while((k + 1) * (k + 2) / 2 <= n_cap)
+		++ k;
+	return k;
+}
+
+__device__ __forceinline__ int64_t readlane64(int64_t v, int n_lane)
+{
+	return (int64_t(__builtin_amdgcn_readlane(int(v >> 32), n_lane)) << 32) | uint32_t(__builtin_amdgcn_readlane(int(v), n_lane));
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int n_lane)
+{
+	return __longlong_as_double(readlane64(__double_as_longlong(v), n_lane));
+}
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int DC, int DP, int CAP, int NL>
+__global__ void __launch_bounds__(64)
+schur_tile_kernel(const int32_t *__restrict__ tile_ptr, const int32_t *__restrict__ tile_lm,
+	const int64_t *__restrict__ tile_slot_ptr, const int64_t *__restrict__ pair_ptr, const uint8_t *__restrict__ lm_slot,
+	const int64_t *__restrict__ ptr, int64_t nc, int64_t ubase, const double *__restrict__ A, const double *__restrict__ eta,
+	int n, double *Cinv, double *W, int b_store, double *P, double *R, int *p_flag, int n_max_slots)
+{
+	enum { BLK = DC * DP, BB = DC * DC, MAXK = tile_max_k(CAP), GROUP = 4,
+		GCAP = (MAXK * BLK > 320)? (MAXK * BLK + 63) / 64 * 64 : 320 };
+	// LDS sized by the launch for the largest tile (a tile of ten blocks needs 3 kB, one of 64 blocks 21 kB: the waves a
+	// CU holds hide the latency of the landmark loads)
+	extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+	double *s_u = s_dyn, *s_w = s_u + GCAP;
+	double *s_acc = s_w + GCAP, *s_r = s_acc + n_max_slots * BB;
+	uint8_t *s_slot = (uint8_t*)(s_r + n_max_slots * DC), *s_tri = s_slot + 64;
+	const int lane = threadIdx.x;
+	const int64_t tile = blockIdx.x;
+	const int lm0 = tile_ptr[tile], lm1 = tile_ptr[tile + 1];
+	const int64_t slot0 = tile_slot_ptr[tile];
+	const int n_slots = int(tile_slot_ptr[tile + 1] - slot0);
+	for(int e = lane; e < n_slots * BB; e += 64)
+		s_acc[e] = 0;
+	for(int e = lane; e < n_slots * DC; e += 64)
+		s_r[e] = 0;
+	{
+		// pair j = b (b + 1) / 2 + a of a landmark's cameras a <= b
+		int b = 0;
+		while((b + 1) * (b + 2) / 2 <= lane)
+			++ b;
+		s_tri[lane] = uint8_t((lane - b * (b + 1) / 2) | (b << 4));
+	}
+	const int64_t ptr_nc = ptr[nc];
+	bool b_bad = false;
+	for(int base = lm0; base < lm1; base += 64) {
+		const int n_chunk = min(64, lm1 - base);
+		// lane L prepares landmark base + L: where its record sits, C^-1, l
+		int my_k = 0;
+		int64_t my_rec = 0, my_pp = 0, my_o0 = 0;
+		double ci[DP * DP], l[DP];
+		#pragma unroll
+		for(int i = 0; i < DP * DP; ++ i)
+			ci[i] = 0;
+		#pragma unroll
+		for(int i = 0; i < DP; ++ i)
+			l[i] = 0;
+		if(lane < n_chunk) {
+			const int64_t pt = tile_lm[base + lane];
+			const int64_t k0 = ptr[nc + pt], k1 = ptr[nc + pt + 1];
+			my_k = int(k1 - k0 - 1);
+			my_o0 = k0 - ptr_nc - pt;
+			my_rec = ubase + my_o0 * BLK + pt * (DP * DP);
+			my_pp = pair_ptr[pt];
+			double c[DP * DP];
+			const double *C = A + my_rec + int64_t(my_k) * BLK;
+			#pragma unroll
+			for(int i = 0; i < DP * DP; ++ i)
+				c[i] = C[i];
+			if(!spd_inverse<DP>(c, ci))
+				b_bad = true;
+			#pragma unroll
+			for(int i = 0; i < DP; ++ i)
+				l[i] = eta[n + pt * DP + i];
+			if(b_store) {
+				#pragma unroll
+				for(int i = 0; i < DP * DP; ++ i)
+					Cinv[pt * (DP * DP) + i] = ci[i];
+			}
+		}
+		// Landmarks are taken GROUP at a time: all their blocks are requested together, and the next group's while this
+		// one is multiplied (a landmark's products take a fraction of a memory latency and a CU holds ten of these waves:
+		// with one landmark in flight per wave the kernel ran at 1.5 TB/s).  The requests are straight-line code -- every
+		// lane of every slot loads, lanes and slots with nothing to fetch re-read the group's first address -- because the
+		// compiler puts a full s_waitcnt in front of a load it finds behind a branch.
+		double v[GROUP][NL];
+		uint8_t n_my_slot;
+		int n_group, n_next = 0; // landmarks of the group in flight; first landmark after it
+		auto Request = [&](int n_first) {
+			const int i0 = min(n_first, n_chunk - 1);
+			const int64_t rec0 = readlane64(my_rec, i0);
+			int n_doubles = 0, n_group_pairs = 0;
+			n_group = 0;
+			#pragma unroll
+			for(int g = 0; g < GROUP; ++ g) {
+				const int ig = min(n_first + g, n_chunk - 1);
+				const int k = __builtin_amdgcn_readlane(my_k, ig);
+				const int64_t rec = readlane64(my_rec, ig);
+				const bool b_in = n_group == g && n_first + g < n_chunk &&
+					(g == 0 || (n_doubles + k * BLK <= GCAP && n_group_pairs + k * (k + 1) / 2 <= 64));
+				#pragma unroll
+				for(int m = 0; m < NL; ++ m)
+					v[g][m] = A[(b_in && lane + 64 * m < k * BLK)? rec + lane + 64 * m : rec0];
+				n_doubles += b_in? k * BLK : 0;
+				n_group_pairs += b_in? k * (k + 1) / 2 : 0;
+				n_group += b_in;
+			}
+			// the slots of consecutive landmarks of a tile are consecutive
+			n_my_slot = lm_slot[readlane64(my_pp, i0) + ((lane < n_group_pairs)? lane : 0)];
+			n_next = n_first + n_group;
+		};
+		Request(0);
+		for(int i = 0; i < n_chunk;) {
+			const int n_cur_group = n_group;
+			{
+				int n_off = 0, n_slot_num = 0;
+				#pragma unroll
+				for(int g = 0; g < GROUP; ++ g) {
+					const int k = (g < n_cur_group)? __builtin_amdgcn_readlane(my_k, min(i + g, n_chunk - 1)) : 0;
+					#pragma unroll
+					for(int m = 0; m < NL; ++ m) {
+						if(lane + 64 * m < k * BLK)
+							s_u[n_off + lane + 64 * m] = v[g][m];
+					}
+					n_off += k * BLK;
+					n_slot_num += k * (k + 1) / 2;
+				}
+				if(lane < n_slot_num)
+					s_slot[lane] = n_my_slot;
+			}
+			wave_lds_fence();
+			Request(n_next); // (past the chunk's end: an empty group, its loads re-read one address)
+			int n_off = 0, n_pair_off = 0;
+			for(int g = 0; g < n_cur_group; ++ g) {
+				const int k = __builtin_amdgcn_readlane(my_k, i + g);
+				const int n_pairs = k * (k + 1) / 2;
+				const double *s_ug = s_u + n_off;
+				double *s_wg = s_w + n_off;
+				const uint8_t *s_slotg = s_slot + n_pair_off;
+				double c_i[DP * DP], l_i[DP];
+				#pragma unroll
+				for(int t = 0; t < DP * DP; ++ t)
+					c_i[t] = readlane_f64(ci[t], i + g);
+				#pragma unroll
+				for(int t = 0; t < DP; ++ t)
+					l_i[t] = readlane_f64(l[t], i + g);
+				const int64_t o0 = readlane64(my_o0, i + g);
+				// W_o = U_o C^-1 and the right-hand side's share W_o l: one lane per (observation, row)
+				if(lane < k * DC) {
+					const int o = lane / DC, r = lane - o * DC;
+					double u[DP], rv = 0;
+					#pragma unroll
+					for(int t = 0; t < DP; ++ t)
+						u[t] = s_ug[o * BLK + r + t * DC];
+					#pragma unroll
+					for(int q = 0; q < DP; ++ q) {
+						double w = 0;
+						#pragma unroll
+						for(int t = 0; t < DP; ++ t)
+							w += u[t] * c_i[t + q * DP];
+						s_wg[o * BLK + r + q * DC] = w;
+						if(W)
+							W[(o0 + o) * BLK + r + q * DC] = w;
+						rv += w * l_i[q];
+					}
+					const int n_slot = s_slotg[o * (o + 3) / 2]; // pair (o, o)
+					atomicAdd(&s_r[n_slot * DC + r], rv); // (cameras are distinct inside a landmark: no two lanes meet)
+				}
+				wave_lds_fence();
+				// the products U_b W_a^T: one lane per (pair, row of the block)
+				for(int n_first = 0; n_first < n_pairs * DC; n_first += 64) {
+					const int n_task = n_first + lane;
+					if(n_task < n_pairs * DC) {
+						const int j = n_task / DC, r = n_task - j * DC;
+						const int n_tri = s_tri[j], a = n_tri & 15, b = n_tri >> 4;
+						double u[DP];
+						#pragma unroll
+						for(int t = 0; t < DP; ++ t)
+							u[t] = s_ug[b * BLK + r + t * DC];
+						double *p_acc = &s_acc[int(s_slotg[j]) * BB + r];
+						const double *p_w = &s_wg[a * BLK];
+						#pragma unroll
+						for(int q = 0; q < DC; ++ q) {
+							double f = 0;
+							#pragma unroll
+							for(int t = 0; t < DP; ++ t)
+								f += u[t] * p_w[q + t * DC];
+							atomicAdd(p_acc + q * DC, f);
+						}
+					}
+				}
+				n_off += k * BLK;
+				n_pair_off += n_pairs;
+			}
+			wave_lds_fence(); // the next group overwrites the operands
+			i += n_cur_group;
+		}
+	}
+	if(b_bad)
+		atomicOr(p_flag, 1);
+	for(int e = lane; e < n_slots * BB; e += 64)
+		P[slot0 * BB + e] = s_acc[e];
+	for(int e = lane; e < n_slots * DC; e += 64)
+		R[slot0 * DC + e] = s_r[e];
+}
+
+// ---- runs: landmarks seen by exactly the same cameras ----
+// A run's products all land in the same k (k + 1) / 2 blocks of S, so they never leave the registers: for every landmark
+// the wave multiplies [U_1; ..; U_k] (6k x 3) by [W_1; ..; W_k]^T on the matrix cores (v_mfma_f64_16x16x4, one landmark =
+// one K step, the fourth k idle; the tiles above the diagonal are skipped) and only the sums over the run's landmarks
+// are written, as partial blocks.  Observations are handled OB = 64 / DC at a time: a job is (piece of a run of at most
+// 64 landmarks, block of OB row observations, block of OB column observations); up to OB cameras that is one job per
+// piece, a landmark seen by 30 cameras takes six.  The right-hand side's share U C^-1 l is one FMA per landmark and
+// row tile on the vector unit, reduced over the three k lanes at the end (diagonal jobs).
+// The blocks of GROUP landmarks are fetched with coalesced loads, the next group's while this one is multiplied,
+// and go through LDS into the fragment layout (lane = (row or column, k)).  Loading the fragments straight from memory
+// -- eight 8-byte gathers per landmark over its 576-byte record -- cost 176 L1 accesses per landmark and ran at
+// 216 us for C4; coalesced it is ten.
+template <int DC, int DP, int NT, bool b_diag>
+__global__ void __launch_bounds__(64)
+schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ run_lm, const int64_t *__restrict__ run_rec,
+	int64_t ubase, const double *__restrict__ A, const double *__restrict__ eta, int n, double *Cinv, double *W, int b_store,
+	double *P, double *R, int *p_flag)
+{
+	enum { BLK = DC * DP, BB = DC * DC, OB = 64 / DC, OBT = (NT * 16 / DC < OB)? NT * 16 / DC : OB, // observations per block here
+		SEG = OBT * BLK, NLD = (SEG + 63) / 64, GROUP = (NT <= 2)? 8 : 4 };
+	typedef double v4f64 __attribute__((ext_vector_type(4)));
+	__shared__ double s_ci[64 * DP * DP];
+	__shared__ double s_z[64 * DP];
+	__shared__ double s_u[GROUP][b_diag? SEG : 2 * SEG]; // [blocks of the row observations | of the column observations, if they are others]
+	const int lane = threadIdx.x, kk = lane >> 4, m16 = lane & 15;
+	const TRunJob job = jobs[blockIdx.x];
+	const int k = job.n_k, n_rb = job.n_rb, n_cb = job.n_cb, n_points = job.n_points;
+	const int n_len_a = min(OB, k - n_rb * OB) * BLK, n_len_b = min(OB, k - n_cb * OB) * BLK; // doubles of the two segments
+	// what this lane feeds the matrix cores: element (row, kk) of the U rows, element (kk, column) of the W columns
+	int n_off_a[NT], n_off_b[NT], n_obs_b[NT];
+	bool b_a[NT], b_b[NT];
+	#pragma unroll
+	for(int t = 0; t < NT; ++ t) {
+		const int n_line = t * 16 + m16, o = n_line / DC, e = n_line - o * DC;
+		b_a[t] = o < OB && n_rb * OB + o < k && kk < DP;
+		n_off_a[t] = b_a[t]? o * BLK + kk * DC + e : 0;
+		b_b[t] = o < OB && n_cb * OB + o < k && kk < DP;
+		n_off_b[t] = (b_b[t]? o * BLK + e : 0) + (b_diag? 0 : SEG);
+		n_obs_b[t] = n_cb * OB + o;
+	}
+	const int kc = (kk < DP)? kk : 0;
+	// lane L prepares landmark L of the piece: where its blocks are (the host wrote that down), C^-1 and C^-1 l
+	int64_t my_rec = 0, my_pt = 0;
+	if(lane < n_points) {
+		my_pt = run_lm[job.n_first + lane];
+		my_rec = run_rec[job.n_first + lane];
+	}
+	v4f64 acc[NT][NT];
+	double racc[NT];
+	#pragma unroll
+	for(int rt = 0; rt < NT; ++ rt) {
+		racc[rt] = 0;
+		#pragma unroll
+		for(int ct = 0; ct < NT; ++ ct)
+			acc[rt][ct] = v4f64{0, 0, 0, 0};
+	}
+	const bool b_store_w = W != 0 && b_diag;
+	// requests of a group: straight-line code (lanes past a segment's end and slots past the piece's end re-read a valid
+	// address), so that all of them are in flight together
+	double va[GROUP][NLD], vb[b_diag? 1 : GROUP][NLD];
+	const int64_t n_seg_a = int64_t(n_rb) * OB * BLK, n_seg_b = int64_t(n_cb) * OB * BLK;
+	auto Request = [&](int n_first) {
+		#pragma unroll
+		for(int g = 0; g < GROUP; ++ g) {
+			const double *p_rec = A + readlane64(my_rec, min(n_first + g, n_points - 1));
+			#pragma unroll
+			for(int m = 0; m < NLD; ++ m) {
+				va[g][m] = p_rec[n_seg_a + ((lane + 64 * m < n_len_a)? lane + 64 * m : 0)];
+				if(!b_diag)
+					vb[g][m] = p_rec[n_seg_b + ((lane + 64 * m < n_len_b)? lane + 64 * m : 0)];
+			}
+		}
+	};
+	Request(0); // (flies while the landmark blocks are inverted)
+	bool b_bad = false;
+	if(lane < n_points) {
+		const int64_t pt = my_pt;
+		double c[DP * DP], ci[DP * DP];
+		const double *C = A + my_rec + int64_t(k) * BLK;
+		#pragma unroll
+		for(int i = 0; i < DP * DP; ++ i)
+			c[i] = C[i];
+		if(!spd_inverse<DP>(c, ci))
+			b_bad = true;
+		#pragma unroll
+		for(int i = 0; i < DP * DP; ++ i)
+			s_ci[lane * (DP * DP) + i] = ci[i];
+		#pragma unroll
+		for(int t = 0; t < DP; ++ t) {
+			double z = 0;
+			#pragma unroll
+			for(int i = 0; i < DP; ++ i)
+				z += ci[t + i * DP] * eta[n + pt * DP + i];
+			s_z[lane * DP + t] = z; // C^-1 l
+		}
+		if(b_store && n_rb == 0 && n_cb == 0) {
+			#pragma unroll
+			for(int i = 0; i < DP * DP; ++ i)
+				Cinv[pt * (DP * DP) + i] = ci[i];
+		}
+	}
+	if(b_bad)
+		atomicOr(p_flag, 1);
+	for(int p0 = 0; p0 < n_points; p0 += GROUP) {
+		wave_lds_fence(); // the previous group's fragments have been read (and, the first time, s_ci / s_z written)
+		#pragma unroll
+		for(int g = 0; g < GROUP; ++ g) {
+			#pragma unroll
+			for(int m = 0; m < NLD; ++ m) {
+				if(lane + 64 * m < n_len_a)
+					s_u[g][lane + 64 * m] = va[g][m];
+				if(!b_diag && lane + 64 * m < n_len_b)
+					s_u[g][(b_diag? 0 : SEG) + lane + 64 * m] = vb[b_diag? 0 : g][m];
+			}
+		}
+		wave_lds_fence();
+		Request(p0 + GROUP); // (past the end: re-reads the last landmark)
+		#pragma unroll
+		for(int g = 0; g < GROUP; ++ g) {
+			const int p = min(p0 + g, n_points - 1);
+			const bool b_live = p0 + g < n_points;
+			double cik[DP], wb[NT], ua[NT];
+			#pragma unroll
+			for(int j = 0; j < DP; ++ j)
+				cik[j] = s_ci[p * (DP * DP) + j + kc * DP];
+			const double z = s_z[p * DP + kc];
+			#pragma unroll
+			for(int t = 0; t < NT; ++ t) {
+				const double u = s_u[g][n_off_a[t]];
+				ua[t] = (b_a[t] && b_live)? u : 0.0;
+				racc[t] += ua[t] * z;
+				double w = 0;
+				#pragma unroll
+				for(int j = 0; j < DP; ++ j)
+					w += s_u[g][n_off_b[t] + j * DC] * cik[j]; // W(q, kk) = sum_j U(q, j) C^-1(j, kk)
+				wb[t] = b_b[t]? w : 0.0;
+			}
+			#pragma unroll
+			for(int rt = 0; rt < NT; ++ rt) {
+				#pragma unroll
+				for(int ct = 0; ct < NT; ++ ct) {
+					if(ct <= rt || !b_diag)
+						acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[rt], wb[ct], acc[rt][ct], 0, 0, 0);
+				}
+			}
+			if(b_store_w && b_live) {
+				const int64_t o0 = (readlane64(my_rec, p) - ubase - readlane64(my_pt, p) * (DP * DP)) / BLK; // first observation of the landmark
+				#pragma unroll
+				for(int t = 0; t < NT; ++ t) {
+					if(b_b[t]) {
+						const int n_line = t * 16 + m16, o = n_line / DC, q = n_line - o * DC;
+						W[(o0 + n_obs_b[t]) * BLK + q + kk * DC] = wb[t];
+					}
+				}
+			}
+		}
+	}
+	// lane l holds the elements ((l >> 4) + 4 reg, l & 15) of every 16 x 16 tile
+	const int n_kb_c = min(OB, k - n_cb * OB); // observations of the column block
+	#pragma unroll
+	for(int rt = 0; rt < NT; ++ rt) {
+		#pragma unroll
+		for(int reg = 0; reg < 4; ++ reg) {
+			const int n_row = rt * 16 + 4 * reg + kk, ob = n_row / DC, r = n_row - ob * DC;
+			if(ob >= OB || n_rb * OB + ob >= k)
+				continue;
+			#pragma unroll
+			for(int ct = 0; ct < NT; ++ ct) {
+				const int n_col = ct * 16 + m16, oa = n_col / DC, q = n_col - oa * DC;
+				if(oa >= OB || n_cb * OB + oa >= k || (b_diag && oa > ob))
+					continue;
+				const int64_t n_slot = job.n_pbase + (b_diag? ob * (ob + 1) / 2 + oa : ob * n_kb_c + oa);
+				P[n_slot * BB + r + q * DC] = acc[rt][ct][reg];
+			}
+		}
+	}
+	if(b_diag) { // the right-hand side's share of row (rt, m16): the sum over the k lanes
+		#pragma unroll
+		for(int rt = 0; rt < NT; ++ rt) {
+			double f = racc[rt];
+			f += __shfl_down(f, 32);
+			f += __shfl_down(f, 16);
+			const int n_row = rt * 16 + m16, ob = n_row / DC, r = n_row - ob * DC;
+			if(kk == 0 && ob < OB && n_rb * OB + ob < k)
+				R[(job.n_pbase + ob * (ob + 3) / 2) * DC + r] = f;
+		}
+	}
+}
+
+// one wave per block of S that has partial blocks: S -= their sum, in list order; the diagonal blocks also bring the
+// partial right-hand sides of their camera (lanes DC^2 .. DC^2 + DC - 1)
+template <int DC>
+__global__ void __launch_bounds__(64)
+schur_tile_reduce_kernel(const int64_t *__restrict__ rb_ptr, const int32_t *__restrict__ rb_part,
+	const int32_t *__restrict__ rb_sb, const int32_t *__restrict__ sb_row, const int32_t *__restrict__ sb_col,
+	const double *__restrict__ P, const double *__restrict__ R, double *S, int ld, const int64_t *__restrict__ p_dst, double *p_r)
+{
+	enum { BB = DC * DC };
+	const int64_t i = blockIdx.x;
+	const int lane = threadIdx.x;
+	const int64_t sb = rb_sb[i];
+	const int64_t n_row = sb_row[sb], n_col = sb_col[sb];
+	const bool b_block = lane < BB, b_rhs = lane >= BB && lane < BB + DC && n_row == n_col;
+	if(!b_block && !b_rhs)
+		return;
+	double f = 0;
+	for(int64_t e = rb_ptr[i], e1 = rb_ptr[i + 1]; e < e1; ++ e) {
+		const int64_t n_part = rb_part[e];
+		f += b_block? P[n_part * BB + lane] : R[n_part * DC + (lane - BB)];
+	}
+	if(b_block) {
+		const int r = lane % DC, q = lane / DC;
+		const size_t idx = p_dst? size_t(p_dst[sb]) + q + r * DC : size_t(n_row * DC + r) + size_t(n_col * DC + q) * ld;
+		S[idx] -= f;
+	} else {
+		const int64_t c = n_row * DC + (lane - BB);
+		if(p_r)
+			p_r[c] -= f;
+		else
+			S[size_t(ld - 1) + size_t(c) * ld] -= f;
+	}
+}
+
+template <int DC, int DP>
+static void tiles_enqueue_t(const CSchurTiles &T, const int64_t *ptr, int64_t nc, int64_t ubase, const double *A, const double *eta,
+	int n, double *Cinv, double *p_W, bool b_store, const int32_t *sb_row, const int32_t *sb_col, double *S, int ld,
+	const int64_t *p_dst, double *p_r, int *p_flag, hipStream_t stream)
+{
+	{
+		const TRunJob *p_jobs = T.d_run_jobs.p();
+#define LAUNCH_RUNS(NT, DIAG) if(T.n_run_jobs[NT][DIAG]) hipLaunchKernelGGL((schur_run_kernel<DC, DP, NT, DIAG != 0>), \
+			dim3(unsigned(T.n_run_jobs[NT][DIAG])), dim3(64), 0, stream, p_jobs + T.n_run_job_first[NT][DIAG], T.d_run_lm.p(), \
+			T.d_run_rec.p(), ubase, A, eta, n, Cinv, p_W, int(b_store), T.d_P.p(), T.d_R.p(), p_flag)
+		LAUNCH_RUNS(1, 1);
+		LAUNCH_RUNS(2, 1);
+		LAUNCH_RUNS(3, 1);
+		LAUNCH_RUNS(4, 1);
+		LAUNCH_RUNS(1, 0);
+		LAUNCH_RUNS(2, 0);
+		LAUNCH_RUNS(3, 0);
+		LAUNCH_RUNS(4, 0);
+#undef LAUNCH_RUNS
+	}
+	if(T.n_tiles) {
+	enum { BLK = DC * DP, MAXK = tile_max_k(SCHUR_TILE_SLOTS), OPS = (MAXK * BLK > 320)? (MAXK * BLK + 63) / 64 * 64 : 320,
+		NL_MAX = (MAXK * BLK + 63) / 64 };
+	const size_t n_lds = (2 * OPS + size_t(T.n_max_slots) * (DC * DC + DC)) * sizeof(double) + 128;
+	const int n_loads = int((T.n_max_k * BLK + 63) / 64); // 64-lane loads that fetch the blocks of the largest landmark
+#define LAUNCH_TILES(NL) hipLaunchKernelGGL((schur_tile_kernel<DC, DP, SCHUR_TILE_SLOTS, (NL <= NL_MAX)? NL : NL_MAX>), \
+		dim3(unsigned(T.n_tiles)), dim3(64), n_lds, stream, T.d_tile_ptr.p(), T.d_tile_lm.p(), T.d_tile_slot_ptr.p(), \
+		T.d_pair_ptr.p(), T.d_lm_slot.p(), ptr, nc, ubase, A, eta, n, Cinv, p_W, int(b_store), T.d_P.p(), T.d_R.p(), p_flag, \
+		int(T.n_max_slots))
+	if(n_loads <= 1)
+		LAUNCH_TILES(1);
+	else if(n_loads == 2)
+		LAUNCH_TILES(2);
+	else if(n_loads == 3)
+		LAUNCH_TILES(3);
+	else
+		LAUNCH_TILES(4);
+#undef LAUNCH_TILES
+	}
+	hipLaunchKernelGGL((schur_tile_reduce_kernel<DC>), dim3(unsigned(T.n_rb)), dim3(64), 0, stream,
+		T.d_rb_ptr.p(), T.d_rb_part.p(), T.d_rb_sb.p(), sb_row, sb_col, T.d_P.p(), T.d_R.p(), S, ld, p_dst, p_r);
+}
+
+void schur_tiles_enqueue(const CSchurTiles &T, int DC, int DP, const int64_t *ptr, int64_t nc, int64_t ubase, const double *A,
+	const double *eta, int n, double *Cinv, double *p_W, bool b_store, const int32_t *sb_row, const int32_t *sb_col,
+	double *S, int ld, const int64_t *p_dst, double *p_r, int *p_flag, hipStream_t stream)
+{
+	if(DC == 6 && DP == 3)
+		tiles_enqueue_t<6, 3>(T, ptr, nc, ubase, A, eta, n, Cinv, p_W, b_store, sb_row, sb_col, S, ld, p_dst, p_r, p_flag, stream);
+	else if(DC == 7 && DP == 3)
+		tiles_enqueue_t<7, 3>(T, ptr, nc, ubase, A, eta, n, Cinv, p_W, b_store, sb_row, sb_col, S, ld, p_dst, p_r, p_flag, stream);
+	else
+		tiles_enqueue_t<3, 2>(T, ptr, nc, ubase, A, eta, n, Cinv, p_W, b_store, sb_row, sb_col, S, ld, p_dst, p_r, p_flag, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host analysis
+// ---------------------------------------------------------------------------------------------
+
+namespace {
+
+// the tile under construction: its blocks of S by key, in a small open-addressed table
+struct TSlotTable {
+	enum { SIZE = 256 }; // > 2 * SCHUR_TILE_SLOTS
+	int64_t keys[SIZE];
+	int16_t slots[SIZE];
+	int used[SIZE];
+	int n_used;
+	TSlotTable() :n_used(0) { for(int i = 0; i < SIZE; ++ i) slots[i] = -1; }
+	static size_t n_Hash(int64_t key) { return size_t((uint64_t(key) * 0x9E3779B97F4A7C15ull) >> 56) & (SIZE - 1); }
+	int n_Find(int64_t key) const
+	{
+		for(size_t h = n_Hash(key);; h = (h + 1) & (SIZE - 1)) {
+			if(slots[h] < 0)
+				return -1;
+			if(keys[h] == key)
+				return slots[h];
+		}
+	}
+	void Insert(int64_t key, int n_slot)
+	{
+		size_t h = n_Hash(key);
+		while(slots[h] >= 0)
+			h = (h + 1) & (SIZE - 1);
+		keys[h] = key;
+		slots[h] = int16_t(n_slot);
+		used[n_used ++] = int(h);
+	}
+	void Clear()
+	{
+		for(int i = 0; i < n_used; ++ i)
+			slots[used[i]] = -1;
+		n_used = 0;
+	}
+};
+
+struct TTileRun { // the tiles of one contiguous piece of the sorted landmark order
+	std::vector<int32_t> tile_size, tile_lm;  // landmarks per tile; the landmarks
+	std::vector<int32_t> tile_slots;          // blocks per tile
+	std::vector<int64_t> slot_key;            // their keys, tile after tile
+	std::vector<uint8_t> lm_slot;             // slots of the landmarks' pairs, landmark after landmark
+	std::vector<int32_t> rejected;            // landmarks left to the lists
+};
+
+void build_run(TTileRun &R, const int32_t *p_order, int64_t n_first, int64_t n_last, int n_mode, int64_t nc, const int64_t *ptr,
+	const int32_t *brow)
+{
+	const int n_cap = SCHUR_TILE_SLOTS, n_max_k = tile_max_k(SCHUR_TILE_SLOTS);
+	const int n_max_points = getenv("SLAMPP_TILE_POINTS")? std::max(1, atoi(getenv("SLAMPP_TILE_POINTS"))) : int(SCHUR_TILE_MAX_POINTS);
+	TSlotTable table;
+	std::vector<int32_t> cur_lm;
+	std::vector<int64_t> cur_keys;
+	std::vector<uint8_t> cur_slots;
+	int64_t n_cur_pairs = 0;
+	auto Close = [&]() {
+		if(cur_lm.empty())
+			return;
+		const bool b_good = n_mode > 0 || n_cur_pairs >= 3 * int64_t(cur_keys.size());
+		if(b_good) {
+			R.tile_size.push_back(int32_t(cur_lm.size()));
+			R.tile_lm.insert(R.tile_lm.end(), cur_lm.begin(), cur_lm.end());
+			R.tile_slots.push_back(int32_t(cur_keys.size()));
+			R.slot_key.insert(R.slot_key.end(), cur_keys.begin(), cur_keys.end());
+			R.lm_slot.insert(R.lm_slot.end(), cur_slots.begin(), cur_slots.end());
+		} else
+			R.rejected.insert(R.rejected.end(), cur_lm.begin(), cur_lm.end());
+		cur_lm.clear();
+		cur_keys.clear();
+		cur_slots.clear();
+		n_cur_pairs = 0;
+		table.Clear();
+	};
+	int64_t keys[SCHUR_TILE_SLOTS];
+	for(int64_t i = n_first; i < n_last; ++ i) {
+		const int32_t pt = p_order[i];
+		const int64_t k0 = ptr[nc + pt], k = ptr[nc + pt + 1] - k0 - 1;
+		if(k > n_max_k) {
+			R.rejected.push_back(pt);
+			continue;
+		}
+		const int n_pairs = int(k * (k + 1) / 2);
+		int n_new = 0;
+		for(int64_t b = 0, j = 0; b < k; ++ b) {
+			for(int64_t a = 0; a <= b; ++ a, ++ j) {
+				keys[j] = int64_t(brow[k0 + a]) * nc + brow[k0 + b]; // column = the smaller camera, row = the larger
+				n_new += table.n_Find(keys[j]) < 0;
+			}
+		}
+		if(int(cur_keys.size()) + n_new > n_cap || int(cur_lm.size()) >= n_max_points)
+			Close();
+		for(int j = 0; j < n_pairs; ++ j) {
+			int n_slot = table.n_Find(keys[j]);
+			if(n_slot < 0) {
+				n_slot = int(cur_keys.size());
+				table.Insert(keys[j], n_slot);
+				cur_keys.push_back(keys[j]);
+			}
+			cur_slots.push_back(uint8_t(n_slot));
+		}
+		cur_lm.push_back(pt);
+		n_cur_pairs += n_pairs;
+	}
+	Close();
+}
+
+} // namespace
+
+void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, int64_t np, const int64_t *ptr, const int32_t *brow,
+	const std::vector<int32_t> &sb_row, const std::vector<int32_t> &sb_col, int64_t n_ablocks, hipStream_t stream)
+{
+	if(n_mode == 0 || !np || np > INT32_MAX)
+		return;
+	// n_mode: -1 = runs of at least four landmarks, tiles where landmarks share blocks, both only if together they take
+	// half of the contributions; 1 = runs of two and every tile that can be formed; 2 = tiles only; 3 = runs only, of any length
+	const bool b_use_runs = n_mode != 2, b_use_tiles = n_mode != 3;
+	const int64_t n_min_run = (n_mode == 3)? 1 : (n_mode == 1)? 2 : 4;
+	const int OB = 64 / DC;
+	int64_t n_all_pairs = 0;
+	for(int64_t pt = 0; pt < np; ++ pt) {
+		const int64_t k = ptr[nc + pt + 1] - ptr[nc + pt] - 1;
+		n_all_pairs += k * (k + 1) / 2;
+	}
+	T.n_all_pairs = n_all_pairs;
+	std::vector<uint8_t> handled(np, 0); // landmarks that do not go through the contribution lists
+	std::vector<int64_t> slot_key;       // the block of S of every partial block: runs first, then tiles
+
+	// ---- runs: landmarks with identical camera lists, found by sorting hashes of the lists ----
+	std::vector<TRunJob> jobs;
+	std::vector<int32_t> run_lm;
+	int64_t n_run_pairs = 0;
+	if(b_use_runs) {
+		std::vector<uint64_t> hash(np);
+		for(int64_t pt = 0; pt < np; ++ pt) {
+			const int64_t k0 = ptr[nc + pt], k = ptr[nc + pt + 1] - k0 - 1;
+			uint64_t h = 0x9E3779B97F4A7C15ull * uint64_t(k + 1);
+			for(int64_t i = 0; i < k; ++ i) {
+				h ^= uint64_t(brow[k0 + i]) + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+				h *= 0xFF51AFD7ED558CCDull;
+			}
+			hash[pt] = h;
+		}
+		std::vector<int32_t> order(np), tmp(np);
+		for(int64_t i = 0; i < np; ++ i)
+			order[i] = int32_t(i);
+		{
+			std::vector<int64_t> cnt(65537);
+			for(int n_shift = 0; n_shift < 64; n_shift += 16) { // LSD radix sort: equal hashes stay in landmark order
+				std::fill(cnt.begin(), cnt.end(), 0);
+				for(int64_t i = 0; i < np; ++ i)
+					++ cnt[((hash[order[i]] >> n_shift) & 0xFFFF) + 1];
+				for(int d = 0; d < 65536; ++ d)
+					cnt[d + 1] += cnt[d];
+				for(int64_t i = 0; i < np; ++ i)
+					tmp[cnt[(hash[order[i]] >> n_shift) & 0xFFFF] ++] = order[i];
+				order.swap(tmp);
+			}
+		}
+		auto Same = [&](int32_t p, int32_t q) -> bool {
+			const int64_t kp0 = ptr[nc + p], kq0 = ptr[nc + q], k = ptr[nc + p + 1] - kp0 - 1;
+			if(ptr[nc + q + 1] - kq0 - 1 != k)
+				return false;
+			for(int64_t i = 0; i < k; ++ i) {
+				if(brow[kp0 + i] != brow[kq0 + i])
+					return false;
+			}
+			return true;
+		};
+		std::vector<TRunJob> jobs_nt[5][2];
+		for(int64_t i = 0; i < np;) {
+			int64_t j = i + 1;
+			while(j < np && hash[order[j]] == hash[order[i]] && Same(order[i], order[j]))
+				++ j;
+			const int32_t pt0 = order[i];
+			const int64_t k0 = ptr[nc + pt0], k = ptr[nc + pt0 + 1] - k0 - 1;
+			if(k >= 1 && j - i >= n_min_run) {
+				const int64_t n_blocks = (k + OB - 1) / OB;
+				for(int64_t f = i; f < j; f += 64) { // pieces of at most 64 landmarks
+					const int64_t n_piece = std::min<int64_t>(64, j - f);
+					const int64_t n_lm_first = int64_t(run_lm.size());
+					for(int64_t e = f; e < f + n_piece; ++ e) {
+						run_lm.push_back(order[e]);
+						handled[order[e]] = 1;
+					}
+					for(int64_t rb = 0; rb < n_blocks; ++ rb) {
+						const int64_t n_kb_r = std::min<int64_t>(OB, k - rb * OB);
+						for(int64_t cb = 0; cb <= rb; ++ cb) {
+							const int64_t n_kb_c = std::min<int64_t>(OB, k - cb * OB);
+							TRunJob job;
+							job.n_first = int32_t(n_lm_first);
+							job.n_points = int32_t(n_piece);
+							job.n_k = int32_t(k);
+							job.n_rb = int32_t(rb);
+							job.n_cb = int32_t(cb);
+							job.n_pad = 0;
+							job.n_pbase = int64_t(slot_key.size());
+							for(int64_t ob = 0; ob < n_kb_r; ++ ob) { // the order the kernel numbers its partial blocks in
+								for(int64_t oa = 0; oa < ((rb == cb)? ob + 1 : n_kb_c); ++ oa)
+									slot_key.push_back(int64_t(brow[k0 + cb * OB + oa]) * nc + brow[k0 + rb * OB + ob]);
+							}
+							const int n_lines = int(std::max(n_kb_r, n_kb_c)) * DC;
+							jobs_nt[(n_lines + 15) / 16][rb == cb].push_back(job);
+						}
+					}
+				}
+				n_run_pairs += (j - i) * k * (k + 1) / 2;
+			}
+			i = j;
+		}
+		for(int nt = 1; nt <= 4; ++ nt) {
+			for(int d = 0; d < 2; ++ d) {
+				T.n_run_job_first[nt][d] = int64_t(jobs.size());
+				T.n_run_jobs[nt][d] = int64_t(jobs_nt[nt][d].size());
+				jobs.insert(jobs.end(), jobs_nt[nt][d].begin(), jobs_nt[nt][d].end());
+			}
+		}
+	}
+	const int64_t n_run_slots = int64_t(slot_key.size()), n_run_points = int64_t(run_lm.size());
+
+	// ---- tiles: the other landmarks by (first camera, second camera) -- two counting sorts --, cut where a tile is full ----
+	std::vector<TTileRun> runs;
+	int64_t n_tiles = 0, n_tile_slots = 0, n_tile_points = 0, n_tile_pairs = 0;
+	if(b_use_tiles && n_run_points < np) {
+		std::vector<int32_t> order, tmp;
+		for(int64_t pt = 0; pt < np; ++ pt) {
+			if(!handled[pt])
+				order.push_back(int32_t(pt));
+		}
+		const int64_t n_rest = int64_t(order.size());
+		tmp.resize(n_rest);
+		{
+			std::vector<int64_t> cnt(nc + 1);
+			for(int n_pass = 0; n_pass < 2; ++ n_pass) {
+				std::fill(cnt.begin(), cnt.end(), 0);
+				auto Cam = [&](int64_t pt) -> int64_t {
+					const int64_t k0 = ptr[nc + pt], k = ptr[nc + pt + 1] - k0 - 1;
+					return (k == 0)? 0 : brow[k0 + ((n_pass == 0 && k > 1)? 1 : 0)]; // least significant first
+				};
+				for(int64_t i = 0; i < n_rest; ++ i)
+					++ cnt[Cam(order[i]) + 1];
+				for(int64_t c = 0; c < nc; ++ c)
+					cnt[c + 1] += cnt[c];
+				for(int64_t i = 0; i < n_rest; ++ i)
+					tmp[cnt[Cam(order[i])] ++] = order[i];
+				order.swap(tmp);
+			}
+		}
+		// built piecewise by a few threads (a piece boundary is a tile boundary)
+		const int n_pieces = int(std::max<int64_t>(1, std::min<int64_t>(8, n_rest / 32768)));
+		runs.resize(n_pieces);
+		std::vector<std::thread> threads;
+		for(int t = 0; t < n_pieces; ++ t) {
+			const int64_t n_first = n_rest * t / n_pieces, n_last = n_rest * (t + 1) / n_pieces;
+			auto Work = [&runs, &order, t, n_first, n_last, n_mode, nc, ptr, brow]() {
+				build_run(runs[t], order.data(), n_first, n_last, n_mode, nc, ptr, brow);
+			};
+			if(t + 1 < n_pieces)
+				threads.emplace_back(Work);
+			else
+				Work();
+		}
+		for(size_t t = 0; t < threads.size(); ++ t)
+			threads[t].join();
+		for(int t = 0; t < n_pieces; ++ t) {
+			n_tiles += int64_t(runs[t].tile_size.size());
+			n_tile_slots += int64_t(runs[t].slot_key.size());
+			n_tile_points += int64_t(runs[t].tile_lm.size());
+			n_tile_pairs += int64_t(runs[t].lm_slot.size());
+		}
+	}
+	const int64_t n_slots = n_run_slots + n_tile_slots;
+	if((!n_tiles && jobs.empty()) || (n_mode < 0 && 2 * (n_tile_pairs + n_run_pairs) < n_all_pairs) || n_slots > INT32_MAX) {
+		for(int nt = 0; nt <= 4; ++ nt)
+			T.n_run_jobs[nt][0] = T.n_run_jobs[nt][1] = T.n_run_job_first[nt][0] = T.n_run_job_first[nt][1] = 0;
+		return; // the lists keep everything
+	}
+	T.n_tiles = n_tiles;
+	T.n_slots = n_slots;
+	T.n_run_points = n_run_points;
+	T.n_tile_points = n_tile_points;
+	T.n_list_points = np - n_tile_points - n_run_points;
+	T.n_tile_pairs = n_tile_pairs + n_run_pairs;
+	for(size_t t = 0; t < runs.size(); ++ t) {
+		for(size_t i = 0; i < runs[t].tile_slots.size(); ++ i)
+			T.n_max_slots = std::max<int64_t>(T.n_max_slots, runs[t].tile_slots[i]);
+		for(size_t i = 0; i < runs[t].tile_lm.size(); ++ i) {
+			const int64_t pt = runs[t].tile_lm[i];
+			T.n_max_k = std::max<int64_t>(T.n_max_k, ptr[nc + pt + 1] - ptr[nc + pt] - 1);
+		}
+	}
+	if(getenv("SLAMPP_HIP_PLAN_TIMING")) {
+		fprintf(stderr, "[schur] of %lld landmarks %lld in runs (%zu jobs), %lld in %lld tiles (largest %lld blocks); %lld partial blocks; "
+			"%lld of %lld contributions\n", (long long)np, (long long)n_run_points, jobs.size(), (long long)n_tile_points,
+			(long long)n_tiles, (long long)T.n_max_slots, (long long)n_slots, (long long)T.n_tile_pairs, (long long)n_all_pairs);
+	}
+
+	std::vector<int32_t> tile_ptr(1, 0), tile_lm;
+	std::vector<int64_t> tile_slot_ptr(1, n_run_slots), pair_ptr(np + 1, 0);
+	std::vector<uint8_t> lm_slot;
+	tile_lm.reserve(n_tile_points);
+	slot_key.reserve(n_slots);
+	lm_slot.reserve(n_tile_pairs);
+	for(size_t t = 0; t < runs.size(); ++ t) {
+		const TTileRun &R = runs[t];
+		for(size_t i = 0; i < R.tile_size.size(); ++ i) {
+			tile_ptr.push_back(tile_ptr.back() + R.tile_size[i]);
+			tile_slot_ptr.push_back(tile_slot_ptr.back() + R.tile_slots[i]);
+		}
+		tile_lm.insert(tile_lm.end(), R.tile_lm.begin(), R.tile_lm.end());
+		slot_key.insert(slot_key.end(), R.slot_key.begin(), R.slot_key.end());
+		lm_slot.insert(lm_slot.end(), R.lm_slot.begin(), R.lm_slot.end());
+	}
+	{
+		// where a tile landmark's slots start: they were appended in tile order (only the start of a range is ever read)
+		int64_t n_off = 0;
+		for(size_t i = 0; i < tile_lm.size(); ++ i) {
+			const int64_t pt = tile_lm[i], k = ptr[nc + pt + 1] - ptr[nc + pt] - 1;
+			pair_ptr[pt] = n_off;
+			n_off += k * (k + 1) / 2;
+			handled[pt] = 1;
+		}
+		pair_ptr[np] = n_off;
+	}
+	// the partial blocks of every block of S: key -> block by binary search on the sorted block list
+	const int64_t n_sblocks = int64_t(sb_row.size());
+	std::vector<int64_t> sb_keys(n_sblocks);
+	for(int64_t i = 0; i < n_sblocks; ++ i)
+		sb_keys[i] = int64_t(sb_col[i]) * nc + sb_row[i];
+	std::vector<int32_t> slot_sb(n_slots);
+	std::vector<int64_t> sb_cnt(n_sblocks + 1, 0);
+	for(int64_t g = 0; g < n_slots; ++ g) {
+		const size_t k = size_t(std::lower_bound(sb_keys.begin(), sb_keys.end(), slot_key[g]) - sb_keys.begin());
+		if(k == sb_keys.size() || sb_keys[k] != slot_key[g])
+			throw std::logic_error("reduced camera system: a partial block is not in the block list");
+		slot_sb[g] = int32_t(k);
+		++ sb_cnt[k + 1];
+	}
+	std::vector<int64_t> rb_ptr(1, 0);
+	std::vector<int32_t> rb_sb, rb_part(n_slots);
+	{
+		std::vector<int64_t> start(n_sblocks, -1);
+		for(int64_t b = 0; b < n_sblocks; ++ b) {
+			if(sb_cnt[b + 1]) {
+				start[b] = rb_ptr.back();
+				rb_sb.push_back(int32_t(b));
+				rb_ptr.push_back(rb_ptr.back() + sb_cnt[b + 1]);
+			}
+		}
+		for(int64_t g = 0; g < n_slots; ++ g) // ascending partial index inside every list
+			rb_part[start[slot_sb[g]] ++] = int32_t(g);
+	}
+	T.n_rb = int64_t(rb_sb.size());
+
+	T.d_run_jobs.Upload(jobs, stream);
+	T.d_run_lm.Upload(run_lm, stream);
+	std::vector<int64_t> run_rec(run_lm.size());
+	for(size_t i = 0; i < run_lm.size(); ++ i) { // offset of the landmark's first U block in the values
+		const int64_t pt = run_lm[i], o0 = ptr[nc + pt] - ptr[nc] - pt;
+		run_rec[i] = n_ablocks * DC * DC + o0 * DC * DP + pt * DP * DP;
+	}
+	T.d_run_rec.Upload(run_rec, stream);
+	T.d_tile_ptr.Upload(tile_ptr, stream);
+	T.d_tile_lm.Upload(tile_lm, stream);
+	T.d_tile_slot_ptr.Upload(tile_slot_ptr, stream);
+	T.d_pair_ptr.Upload(pair_ptr, stream);
+	T.d_lm_slot.Upload(lm_slot, stream);
+	T.d_rb_ptr.Upload(rb_ptr, stream);
+	T.d_rb_part.Upload(rb_part, stream);
+	T.d_rb_sb.Upload(rb_sb, stream);
+	T.d_P.Alloc(size_t(n_slots) * DC * DC);
+	T.d_R.Alloc(size_t(n_slots) * DC);
+	const std::vector<uint8_t> &in_tile = handled;
+
+	// the landmarks that stay with the contribution lists: lists of their own, for the blocks of S they touch
+	std::vector<int64_t> xsb_ptr, xent_uoff, xcam_ptr;
+	std::vector<int32_t> xsb_map, xent_a, xcam_obs;
+	if(T.n_list_points > 0) {
+		T.b_hybrid = true;
+		const int64_t ubase = n_ablocks * DC * DC;
+		struct TE { int32_t sb, a, b; };
+		std::vector<TE> ents;
+		ents.reserve(size_t(n_all_pairs - n_tile_pairs));
+		std::vector<int64_t> cnt(n_sblocks + 1, 0);
+		xcam_ptr.assign(nc + 1, 0);
+		for(int64_t pt = 0; pt < np; ++ pt) {
+			if(in_tile[pt])
+				continue;
+			const int64_t k0 = ptr[nc + pt], o0 = k0 - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
+			for(int64_t a = o0; a < o1; ++ a) {
+				++ xcam_ptr[brow[k0 + (a - o0)] + 1];
+				for(int64_t b = a; b < o1; ++ b) {
+					const int64_t key = int64_t(brow[k0 + (a - o0)]) * nc + brow[k0 + (b - o0)];
+					const size_t k = size_t(std::lower_bound(sb_keys.begin(), sb_keys.end(), key) - sb_keys.begin());
+					TE e;
+					e.sb = int32_t(k);
+					e.a = int32_t(a);
+					e.b = int32_t(b);
+					ents.push_back(e);
+					++ cnt[k + 1];
+				}
+			}
+		}
+		std::vector<int64_t> start(n_sblocks, -1);
+		xsb_ptr.push_back(0);
+		for(int64_t b = 0; b < n_sblocks; ++ b) {
+			if(cnt[b + 1]) {
+				start[b] = xsb_ptr.back();
+				xsb_map.push_back(int32_t(b));
+				xsb_ptr.push_back(xsb_ptr.back() + cnt[b + 1]);
+			}
+		}
+		xent_a.resize(ents.size());
+		xent_uoff.resize(ents.size());
+		for(size_t i = 0; i < ents.size(); ++ i) { // (landmark, a, b) ascending inside every list, as in the full lists
+			const int64_t d = start[ents[i].sb] ++;
+			xent_a[d] = ents[i].a;
+			// the U block of observation b: the values hold [U .. U | C] per landmark, so its landmark's index is needed
+			xent_uoff[d] = int64_t(ents[i].b); // completed below
+		}
+		// observation -> landmark, for the offsets of the U blocks and the camera lists
+		for(int64_t c = 0; c < nc; ++ c)
+			xcam_ptr[c + 1] += xcam_ptr[c];
+		xcam_obs.resize(size_t(xcam_ptr[nc]));
+		std::vector<int64_t> fill(xcam_ptr.begin(), xcam_ptr.end() - 1);
+		std::vector<int32_t> obs_pt_of; // landmark of every observation of a list landmark (others unused)
+		obs_pt_of.assign(size_t(ptr[nc + np] - ptr[nc] - np), -1);
+		for(int64_t pt = 0; pt < np; ++ pt) {
+			if(in_tile[pt])
+				continue;
+			const int64_t k0 = ptr[nc + pt], o0 = k0 - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
+			for(int64_t o = o0; o < o1; ++ o) {
+				obs_pt_of[o] = int32_t(pt);
+				xcam_obs[fill[brow[k0 + (o - o0)]] ++] = int32_t(o);
+			}
+		}
+		for(size_t i = 0; i < xent_uoff.size(); ++ i) {
+			const int64_t b = xent_uoff[i];
+			xent_uoff[i] = ubase + b * DC * DP + int64_t(obs_pt_of[b]) * DP * DP;
+		}
+		T.n_xblocks = int64_t(xsb_map.size());
+		T.n_xentries = int64_t(xent_a.size());
+		T.d_xsb_ptr.Upload(xsb_ptr, stream);
+		T.d_xsb_map.Upload(xsb_map, stream);
+		T.d_xent_a.Upload(xent_a, stream);
+		T.d_xent_uoff.Upload(xent_uoff, stream);
+		T.d_xcam_ptr.Upload(xcam_ptr, stream);
+		T.d_xcam_obs.Upload(xcam_obs, stream);
+	}
+	SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // the host vectors live on this stack frame
+	T.b_enabled = true;
+}
+
+} // namespace slampp

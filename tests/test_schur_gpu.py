@@ -49,6 +49,55 @@ def test_parity_with_oracle(name):
     assert rel_inf(eta2, -0.5 * x_ref) < TOL
 
 
+@pytest.mark.parametrize("sparse", [0, 1])
+@pytest.mark.parametrize("tiles", [0, 1, 2, 3])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_landmark_tiles_and_contribution_lists_agree_with_oracle(name, tiles, sparse):
+    """The reduced system assembled landmark-major (schur_tiles.hip: every landmark read once; 1 = runs of landmarks with
+    the same cameras on the matrix cores + LDS tiles for the rest, 2 = tiles only, 3 = runs only, of any length), from the
+    contribution lists (0), or -- venice_ragged with tiles: landmarks seen by more than ten cameras do not fit a tile --
+    by both; into the dense buffer or the inner sparse solver's values."""
+    lam = CASES[name]()
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok
+    solver = CLinearSolver_Schur_HIP(schur_tiles=tiles, schur_sparse=sparse)
+    solver.set_option("profile", 1)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta)
+    assert rel_inf(eta, x_ref) < TOL
+    eta2 = 3.0 * lam.rhs
+    assert solver.Solve_PosDef_Blocky(lam, eta2)
+    assert rel_inf(eta2, 3.0 * x_ref) < TOL
+    phases = solver.profile()
+    assert ("schur_tiles" in phases) == bool(tiles), phases
+    if name == "venice_ragged" and tiles == 2:
+        assert phases["schur_gather"][1] > 0.0                  # the heavy landmarks went through the lists
+
+
+def test_tiles_chosen_where_landmarks_share_cameras():
+    """Default (auto): band visibility -> tiles; random visibility -> lists (a tile would hold one block per contribution)."""
+    for mode, expect in (("band", True), ("uniform", False)):
+        lam = synth.ba(200, 40000, k=4, mode=mode)
+        solver = CLinearSolver_Schur_HIP()
+        solver.set_option("profile", 1)
+        eta = lam.rhs.copy()
+        assert solver.Solve_PosDef(lam, eta)
+        assert ("schur_tiles" in solver.profile()) == expect, mode
+        ok, x_ref, _, _ = O.solve_schur(lam)
+        assert ok and rel_inf(eta, x_ref) < TOL
+
+
+def test_not_positive_definite_landmark_is_reported_from_a_tile():
+    lam = synth.ba(10, 100, k=3)
+    off = lam.block_value_offsets()
+    last = lam.n_blocks - 1
+    vals = lam.values.copy()
+    vals[off[last]:off[last + 1]] -= 50.0 * np.eye(3).ravel()
+    bad = dataclasses.replace(lam, values=vals)
+    eta = bad.rhs.copy()
+    assert CLinearSolver_Schur_HIP(schur_tiles=1).Solve_PosDef(bad, eta) is False
+
+
 def test_schur_and_sparse_paths_agree():
     lam = synth.ba(40, 2000, mode="venice", seed=3)
     a, b = lam.rhs.copy(), lam.rhs.copy()
