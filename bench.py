@@ -693,7 +693,25 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
                            "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS,
                            "traffic": tr, "traffic_source": traffic_file, "flops_per_factorization": st["factor_flops"],
                            "ms_per_factorization": prof["dense_chol"]}
-    if "schur_gather" in prof:
+    if "schur_tiles" in prof:
+        # landmark-major assembly (schur_tiles.hip): every landmark's column of Lambda is read once -- 144 B per observation,
+        # 72 B of C and 24 B of l per landmark --, C^-1 written (72 B), every block of S read and written once
+        nbytes = 144.0 * n_obs + (72.0 + 24.0 + 72.0) * n_pts + 2 * 8.0 * 36 * st["l_blocks"]
+        gb = nbytes / (prof["schur_tiles"] * 1e-3) / 1e9
+        tr = None
+        if traffic:
+            parts = [kernel_traffic(traffic, k_) for k_ in ("schur_run_kernel", "schur_tile_kernel", "schur_tile_reduce_kernel")]
+            tr = sum(p for p in parts if p) or None
+        out["roofline_schur_assembly"] = {
+            "bound": "hbm", "kernel": "schur_run_kernel (+ schur_tile_kernel for landmarks outside runs, + schur_tile_reduce_kernel): "
+                                      "S and r assembled landmark by landmark, one launch of each per step",
+            "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "traffic": tr,
+            "traffic_source": traffic_file,
+            "traffic_measured_in": "builder's rocprofv3 --pmc run (replayed from the committed file)",
+            "algorithmic_bytes_per_step": nbytes, "ms_per_step": prof["schur_tiles"]}
+        if not b_dense:
+            out["roofline"] = out["roofline_schur_assembly"]
+    if "schur_gather" in prof and prof["schur_gather"] > 0.02 and "schur_tiles" not in prof:
         gb = (288.0 * st["n_update_pairs"] + 2 * 8.0 * 36 * st["l_blocks"]) / (prof["schur_gather"] * 1e-3) / 1e9
         out["roofline_schur_gather"] = {"bound": "hbm", "kernel": "schur_gather_S_kernel", "achieved": gb, "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,

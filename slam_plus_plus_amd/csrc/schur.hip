@@ -342,11 +342,12 @@ __global__ void schur_scatter_A_kernel(const int64_t *ptr, const int32_t *brow, 
 
 template <int DC, int DP>
 __global__ void schur_point_inverse_kernel(const int64_t *ptr, int64_t nc, int64_t np, int64_t ubase,
-	const double *__restrict__ A, double *Cinv, int *p_flag)
+	const double *__restrict__ A, double *Cinv, int *p_flag, const int32_t *__restrict__ p_list = 0)
 {
-	const int64_t pt = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-	if(pt >= np)
+	const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(i >= np)
 		return;
+	const int64_t pt = p_list? int64_t(p_list[i]) : i; // (np: the length of the list, if there is one)
 	const int64_t o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
 	const double *C = A + ubase + o1 * (DC * DP) + pt * (DP * DP);
 	double c[DP * DP], inv[DP * DP];
@@ -362,11 +363,12 @@ __global__ void schur_point_inverse_kernel(const int64_t *ptr, int64_t nc, int64
 
 template <int DC, int DP>
 __global__ void schur_obs_W_kernel(int64_t n_obs, int64_t ubase, const int32_t *obs_pt,
-	const double *__restrict__ A, const double *__restrict__ Cinv, double *W)
+	const double *__restrict__ A, const double *__restrict__ Cinv, double *W, const int32_t *__restrict__ p_list = 0)
 {
-	const int64_t o = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-	if(o >= n_obs)
+	const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(i >= n_obs)
 		return;
+	const int64_t o = p_list? int64_t(p_list[i]) : i;
 	const int64_t pt = obs_pt[o];
 	const double *U = A + ubase + o * (DC * DP) + pt * (DP * DP);
 	double u[DC * DP], ci[DP * DP];
@@ -950,6 +952,10 @@ static void schur_try_sparse_reduced(slampp_hip_solver &s, CSchurState &S)
 	p_inner->n_device = s.n_device;
 	p_inner->stream = s.stream; // borrowed
 	p_inner->opt = s.opt;
+	p_inner->n_simt = s.n_simt;
+	p_inner->n_simt_width = s.n_simt_width;
+	p_inner->n_simt_stages = s.n_simt_stages;
+	p_inner->n_wide_min_tasks = s.n_wide_min_tasks;
 	if(nc <= 8192) // a small system is all latency: short sequential tasks (measured at 1000 cameras: 0.51 -> 0.43 ms)
 		p_inner->opt.subtree_size = std::min(p_inner->opt.subtree_size, 4);
 	p_inner->cumsum = cumsum;
@@ -1042,19 +1048,25 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 	const CSchurTiles &T = S.tiles;
 	const bool b_tiles = T.b_enabled, b_lists_all = !b_tiles;
 	s.Phase_Begin("schur_points");
-	if(b_lists_all || T.b_hybrid) {
+	if(b_lists_all) {
 		hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((S.np + 255) / 256)), dim3(256), 0, st,
-			S.d_ptr.p(), S.nc, S.np, ubase, A, S.d_Cinv.p(), s.d_flag.p());
+			S.d_ptr.p(), S.nc, S.np, ubase, A, S.d_Cinv.p(), s.d_flag.p(), (const int32_t*)0);
 		hipLaunchKernelGGL((schur_obs_W_kernel<DC, DP>), dim3(unsigned((S.n_obs + 255) / 256)), dim3(256), 0, st,
-			S.n_obs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p());
+			S.n_obs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p(), (const int32_t*)0);
+	} else if(T.b_hybrid) { // only the landmarks of the lists: the others get C^-1 (and W) where they are multiplied
+		hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((T.n_list_points + 255) / 256)), dim3(256), 0, st,
+			S.d_ptr.p(), S.nc, T.n_list_points, ubase, A, S.d_Cinv.p(), s.d_flag.p(), T.d_xpoints.p());
+		if(T.n_xobs)
+			hipLaunchKernelGGL((schur_obs_W_kernel<DC, DP>), dim3(unsigned((T.n_xobs + 255) / 256)), dim3(256), 0, st,
+				T.n_xobs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p(), T.d_xcam_obs.p());
 	}
 	s.Phase_End();
 
 	if(b_tiles) {
 		s.Phase_Begin("schur_tiles");
 		// (C^-1 of every landmark is needed by the back-substitution; W only if the next solve may be an update)
-		schur_tiles_enqueue(T, DC, DP, S.d_ptr.p(), S.nc, ubase, A, rhs, n, S.d_Cinv.p(), (b_keep && !T.b_hybrid)? S.d_W.p() : 0,
-			!T.b_hybrid, S.d_sb_row.p(), S.d_sb_col.p(), p_S, ld, p_sb_dst, p_r, s.d_flag.p(), st);
+		schur_tiles_enqueue(T, DC, DP, S.d_ptr.p(), S.nc, ubase, A, rhs, n, S.d_Cinv.p(), b_keep? S.d_W.p() : 0,
+			true, S.d_sb_row.p(), S.d_sb_col.p(), p_S, ld, p_sb_dst, p_r, s.d_flag.p(), st);
 		s.Phase_End();
 	}
 

@@ -32,7 +32,8 @@ struct CSchurTiles {
 	CDevArray<int64_t> d_rb_ptr;        // [n_rb + 1] partial blocks of every block of S that has some
 	CDevArray<int32_t> d_rb_part, d_rb_sb;
 	// the landmarks left to the contribution lists
-	int64_t n_xblocks = 0, n_xentries = 0;
+	int64_t n_xblocks = 0, n_xentries = 0, n_xobs = 0;
+	CDevArray<int32_t> d_xpoints;       // the landmarks themselves (T.n_list_points of them)
 	CDevArray<int64_t> d_xsb_ptr;       // [n_xblocks + 1]
 	CDevArray<int32_t> d_xsb_map;       // block of S of every list
 	CDevArray<int32_t> d_xent_a;
@@ -44,7 +45,7 @@ struct CSchurTiles {
 		return d_run_jobs.n_Bytes() + d_run_lm.n_Bytes() + d_run_rec.n_Bytes() + d_tile_ptr.n_Bytes() + d_tile_lm.n_Bytes() + d_tile_slot_ptr.n_Bytes() + d_pair_ptr.n_Bytes() +
 			d_lm_slot.n_Bytes() + d_P.n_Bytes() + d_R.n_Bytes() + d_rb_ptr.n_Bytes() + d_rb_part.n_Bytes() + d_rb_sb.n_Bytes() +
 			d_xsb_ptr.n_Bytes() + d_xsb_map.n_Bytes() + d_xent_a.n_Bytes() + d_xent_uoff.n_Bytes() + d_xcam_ptr.n_Bytes() +
-			d_xcam_obs.n_Bytes();
+			d_xcam_obs.n_Bytes() + d_xpoints.n_Bytes();
 	}
 };
 

@@ -693,6 +693,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 			}
 			return true;
 		};
+		const int64_t n_piece_max = getenv("SLAMPP_RUN_PIECE")? std::max(1, std::min(64, atoi(getenv("SLAMPP_RUN_PIECE")))) : 64;
 		std::vector<TRunJob> jobs_nt[5][2];
 		for(int64_t i = 0; i < np;) {
 			int64_t j = i + 1;
@@ -700,10 +701,11 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 				++ j;
 			const int32_t pt0 = order[i];
 			const int64_t k0 = ptr[nc + pt0], k = ptr[nc + pt0 + 1] - k0 - 1;
-			if(k >= 1 && j - i >= n_min_run) {
+			// (landmarks with more cameras than a tile holds have nowhere else to go but the lists: pairs of them already pay)
+			if(k >= 1 && j - i >= ((k > tile_max_k(SCHUR_TILE_SLOTS))? std::min<int64_t>(n_min_run, 2) : n_min_run)) {
 				const int64_t n_blocks = (k + OB - 1) / OB;
-				for(int64_t f = i; f < j; f += 64) { // pieces of at most 64 landmarks
-					const int64_t n_piece = std::min<int64_t>(64, j - f);
+				for(int64_t f = i; f < j; f += n_piece_max) { // pieces of at most 64 landmarks
+					const int64_t n_piece = std::min<int64_t>(n_piece_max, j - f);
 					const int64_t n_lm_first = int64_t(run_lm.size());
 					for(int64_t e = f; e < f + n_piece; ++ e) {
 						run_lm.push_back(order[e]);
@@ -964,6 +966,13 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 			const int64_t b = xent_uoff[i];
 			xent_uoff[i] = ubase + b * DC * DP + int64_t(obs_pt_of[b]) * DP * DP;
 		}
+		std::vector<int32_t> xpoints;
+		for(int64_t pt = 0; pt < np; ++ pt) {
+			if(!in_tile[pt])
+				xpoints.push_back(int32_t(pt));
+		}
+		T.d_xpoints.Upload(xpoints, stream);
+		T.n_xobs = int64_t(xcam_obs.size());
 		T.n_xblocks = int64_t(xsb_map.size());
 		T.n_xentries = int64_t(xent_a.size());
 		T.d_xsb_ptr.Upload(xsb_ptr, stream);
