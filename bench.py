@@ -613,7 +613,7 @@ def dataclasses_replace_points(lam, n_keep):
 
 def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", extras=True):
     """C4 (N=1) / landmark-sharded weak scaling (N>1): `--ba-cams` cameras, `--ba-points` points per GPU.
-    schur_sparse: -1 = the library decides how to factor the reduced camera system (sparse block path when under 3 %
+    schur_sparse: -1 = the library decides how to factor the reduced camera system (sparse block path when under 15 %
     of its blocks are nonzero, as with this workload's band visibility), 0 = force the dense MFMA factorization."""
     import torch
     from slam_plus_plus_amd import synth

@@ -84,7 +84,7 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
  * tile elimination tree, touching only structurally nonzero 64x64 tiles (1); -1 = the latter when it shortens the
  * chain of dependent launches, default),
  * "schur_sparse" (Schur mode: the reduced camera system S is factored by the sparse block path instead of the dense
- * one; -1 = when fewer than 3 % of its camera-camera blocks are nonzero (default), 0 = never, 1 = always; the
+ * one; -1 = when fewer than 15 % of its camera-camera blocks are nonzero (default), 0 = never, 1 = always; the
  * reference makes this choice at compile time: __SCHUR_USE_DENSE_SOLVER, include/slam/LinearSolver_Schur.h:48-55, "faster if ... dense enough"),
  * "schur_incremental" (Schur mode, 0 / 1: keep the assembled reduced system for slampp_hip_schur_set_changed_points),
  * "marginals_dense" (Schur mode: 1 = slampp_hip_schur_marginals always inverts the reduced system densely; 0 (default) =

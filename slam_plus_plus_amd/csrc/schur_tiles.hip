@@ -701,8 +701,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 				++ j;
 			const int32_t pt0 = order[i];
 			const int64_t k0 = ptr[nc + pt0], k = ptr[nc + pt0 + 1] - k0 - 1;
-			// (landmarks with more cameras than a tile holds have nowhere else to go but the lists: pairs of them already pay)
-			if(k >= 1 && j - i >= ((k > tile_max_k(SCHUR_TILE_SLOTS))? std::min<int64_t>(n_min_run, 2) : n_min_run)) {
+			if(k >= 1 && j - i >= n_min_run) {
 				const int64_t n_blocks = (k + OB - 1) / OB;
 				for(int64_t f = i; f < j; f += n_piece_max) { // pieces of at most 64 landmarks
 					const int64_t n_piece = std::min<int64_t>(n_piece_max, j - f);
