@@ -1,0 +1,228 @@
+// panel_kernel.hip -- separator tasks of the sparse block factorization as panels in LDS.
+//
+// factor_stage_kernel (sparse_kernels.hip) takes a separator column by column: package of the column, its update pairs'
+// operands from global memory, the 6 x 6 Cholesky, the blocks below it, out to global memory -- and the next column of
+// the same separator starts by reading some of those blocks back.  Three or four dependent round trips per column, 11 us
+// per column on the reduced camera system of C4 (separators of three columns, eight blocks each: 35 us per stage).
+// Most of that does not depend on the order of the columns: of a task's updates, only those whose operands the task
+// itself produces have to wait.  So here a workgroup
+// The host splits every update of the task into external ones (operands from earlier stages) and internal ones (operands
+// among the task's own blocks).  Then, per stage,
+//   1. panel_update_kernel applies the external updates of all the stage's tasks, one workgroup per factor block: near
+//      the root a separator receives hundreds of them (left-looking: everything its descendants owe it), and streamed
+//      by the task's own workgroup they were 4 - 42 us of its 10 - 50; spread over the chip they are a few.  Its waves
+//      take the block's entries in turn, operand blocks fetched whole, eight entries in flight per wave; partial sums
+//      are combined in a fixed order (no atomics); L(block) = Lambda(block) - sum waits in the factor's own storage;
+//   2. factor_panel_kernel fetches the task's *panel package* (columns, blocks, internal updates as slot numbers) and
+//      its blocks into an LDS image with one round of coalesced loads, and walks the columns inside the image: internal
+//      updates from LDS, diagonal block (wave 0), blocks below (all waves), two barriers and no memory round trip per
+//      column (2 us); finished blocks go to global memory as they are made.
+// Tasks whose columns are not consecutive, or that exceed the capacities, stay with factor_stage_kernel.
+// Own translation unit (see dense_tiles.hip for why).
+#include <hip/hip_runtime.h>
+#include "sparse_kernels.h"
+
+namespace slampp {
+
+#include "sparse_device.inl"
+
+template <int D, int CAP_BLK>
+__global__ void __launch_bounds__(64 * PANEL_W)
+factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict__ pkg_off, double *L, double *Linv, double *w,
+	int *p_flag, long long *p_timing)
+{
+	enum { W = PANEL_W, DD = D * D };
+	__shared__ longlong2 s_pkg[PANEL_UNITS];
+	__shared__ double s_L[CAP_BLK * DD];
+	__shared__ double s_w[PANEL_COLS * 8];
+	__shared__ double s_linv[64];
+	__shared__ double s_tile[W][64];
+	static_assert(64 * W <= PANEL_UNITS, "one speculative unit per thread");
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	long long *p_tm = 0; // development aid (SLAMPP_HIP_STAGE_TIMING): clock samples of workgroup 0
+	int n_tm = 0;
+	if(p_timing && blockIdx.x == 0 && tid == 0) {
+		p_tm = p_timing + 1 + 32 * atomicAdd((unsigned long long*)p_timing, 1ull);
+		p_tm[n_tm ++] = wall_clock64();
+	}
+#define PANEL_TICK() do { if(p_tm && n_tm < 32) p_tm[n_tm ++] = wall_clock64(); } while(0)
+	const int64_t n_off = pkg_off[blockIdx.x];
+	s_pkg[tid] = pkg[n_off + tid]; // before the size is known: the head and, for most tasks, everything
+	__syncthreads();
+	const TPanelHead hd = *reinterpret_cast<const TPanelHead*>(s_pkg);
+	for(int e = 64 * W + tid; e < hd.n_units; e += 64 * W)
+		s_pkg[e] = pkg[n_off + e];
+	const int n_cols = hd.n_cols, n_slots = hd.n_slots;
+	const TPanelCol *s_col = reinterpret_cast<const TPanelCol*>(s_pkg + 4);
+	const TPanelSlot *s_slot = reinterpret_cast<const TPanelSlot*>(s_pkg + 4 + 3 * n_cols);
+	const uint32_t *s_irow = reinterpret_cast<const uint32_t*>(s_pkg + 4 + 3 * n_cols + 2 * n_slots);
+	const uint32_t *s_ipair = s_irow + 4 * ((hd.n_int_rows + 3) / 4);
+	__syncthreads();
+	PANEL_TICK(); // package
+
+	const TLaneMap mm = lane_map(lane, D, D);
+	const bool b_y = lane >= Y_LANE0 && lane < Y_LANE0 + D;
+	const int yq = b_y? lane - Y_LANE0 : mm.q;
+	// the image: the task's blocks as panel_update_kernel left them (Lambda minus the external updates), y likewise
+	for(int s0 = wave; s0 < n_slots; s0 += 4 * W) {
+		double v[4];
+		#pragma unroll
+		for(int u = 0; u < 4; ++ u)
+			v[u] = L[s_slot[min(s0 + u * W, n_slots - 1)].loff + (mm.b_act? lane : 0)];
+		#pragma unroll
+		for(int u = 0; u < 4; ++ u) {
+			if(s0 + u * W < n_slots && mm.b_act)
+				s_L[(s0 + u * W) * DD + lane] = v[u];
+		}
+	}
+	if(tid < n_cols * D)
+		s_w[tid] = w[s_col[tid / D].cs_new + tid % D];
+	__syncthreads();
+	PANEL_TICK(); // image
+
+	// 2. the columns, inside the image
+	for(int ci = 0; ci < n_cols; ++ ci) {
+		const TPanelCol col = s_col[ci];
+		if(wave == 0) {
+			const double init = b_y? s_w[ci * D + yq] : (mm.b_act? s_L[col.slot0 * DD + lane] : 0.0);
+			double sum = 0;
+			for(int e = 0; e < col.inr; ++ e) {
+				const uint32_t en = s_irow[col.ir0 + e];
+				sum += row_product_image<D>(s_L + int(en & 0xffff) * DD, s_w + int(en >> 16) * D, mm.r, yq, b_y);
+			}
+			TColDesc cd; // (finish_diagonal_fixed reads where the inverse and y go)
+			cd.linv_off = col.linv_off;
+			cd.cs_new = col.cs_new;
+			const double acc = init - sum;
+			finish_diagonal_fixed<D>(cd, acc, acc, lane, b_y? 0 : mm.r, b_y? 0 : mm.q, mm.b_act, L, Linv, w, s_slot[col.slot0].loff,
+				p_flag, s_linv, s_L + col.slot0 * DD, s_w + ci * D);
+		}
+		__syncthreads();
+		PANEL_TICK(); // diagonal block
+		for(int kb = 1 + wave; kb < col.nb; kb += W) {
+			const int n_slot = col.slot0 + kb;
+			const TPanelSlot sd = s_slot[n_slot];
+			const double init = mm.b_act? s_L[n_slot * DD + lane] : 0.0;
+			double sum = 0;
+			for(int e = 0; e < sd.inp; ++ e) {
+				const uint32_t en = s_ipair[sd.ip0 + e];
+				sum += pair_product_image<D>(s_L + int(en & 0xffff) * DD, s_L + int(en >> 16) * DD, mm.r, mm.q);
+			}
+			finish_offdiagonal<D>(init - sum, lane, mm.r, mm.q, mm.b_act, D, L, sd.loff, s_tile[wave], s_linv, s_L + n_slot * DD);
+		}
+		__syncthreads(); // column ci and y_ci complete in the image
+		PANEL_TICK();
+	}
+}
+
+bool launch_factor_panel(int n_dim, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks, double *L, double *Linv, double *w,
+	int *p_flag, hipStream_t stream, long long *p_timing)
+{
+	if(n_tasks <= 0)
+		return true;
+	switch(n_dim) {
+	case 3:
+		hipLaunchKernelGGL((factor_panel_kernel<3, 256>), dim3(n_tasks), dim3(64 * PANEL_W), 0, stream, pkg, pkg_off, L, Linv, w,
+			p_flag, p_timing);
+		return true;
+	case 6:
+		hipLaunchKernelGGL((factor_panel_kernel<6, 96>), dim3(n_tasks), dim3(64 * PANEL_W), 0, stream, pkg, pkg_off, L, Linv, w,
+			p_flag, p_timing);
+		return true;
+	case 7:
+		hipLaunchKernelGGL((factor_panel_kernel<7, 72>), dim3(n_tasks), dim3(64 * PANEL_W), 0, stream, pkg, pkg_off, L, Linv, w,
+			p_flag, p_timing);
+		return true;
+	default:
+		return false;
+	}
+}
+
+// one workgroup of PANEL_UPD_W waves per factor block of the stage's panel tasks: wave v takes the entries v, v + W, ...
+// BATCH at a time (both operand blocks fetched whole, all requests of a batch before the first product), the partial sums
+// are added up in wave order, and the block goes out as Lambda - sum (a diagonal block with its right-hand side b - sum)
+template <int D>
+__global__ void __launch_bounds__(64 * PANEL_UPD_W)
+panel_update_kernel(const TUpdSlot *__restrict__ slots, const TUpdEnt *__restrict__ ents, const double *__restrict__ A, double *L,
+	const double *__restrict__ b, double *w)
+{
+	enum { W = PANEL_UPD_W, DD = D * D, BATCH = 8 };
+	__shared__ double s_ops[W][2 * BATCH * DD];
+	__shared__ double s_yv[W][BATCH * 8];
+	__shared__ double s_part[W][64];
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const TUpdSlot sl = slots[blockIdx.x];
+	const TLaneMap mm = lane_map(lane, D, D);
+	const bool b_diag = sl.kind != 0;
+	const bool b_y = b_diag && lane >= Y_LANE0 && lane < Y_LANE0 + D;
+	const int yq = b_y? lane - Y_LANE0 : mm.q;
+	// Lambda's element (requested now, used last)
+	double init = 0;
+	if(wave == 0)
+		init = b_y? b[sl.cs_src + yq] : (mm.b_act? lambda_element(A, sl.asrc, mm.r, mm.q, D, D, false) : 0.0);
+	double sum = 0;
+	const TUpdEnt *p_ent = ents + sl.e0;
+	for(int e0 = wave * BATCH; e0 < sl.ne; e0 += W * BATCH) {
+		const int n_here = min(int(BATCH), sl.ne - e0);
+		double va[BATCH], vb[BATCH];
+		#pragma unroll
+		for(int u = 0; u < BATCH; ++ u) {
+			const TUpdEnt en = p_ent[e0 + min(u, n_here - 1)]; // the tail repeats the last entry: its product is skipped below
+			va[u] = L[en.a_off + (mm.b_act? lane : 0)];
+			// the other operand: the block L(j,c) of a pair; for a row entry y_c in the right-hand side lanes (one load, the
+			// lane picks its address: a load behind a branch would wait for the others)
+			const double *p_other = b_diag? w + en.b_off + (b_y? yq : 0) : L + en.b_off + (mm.b_act? lane : 0);
+			vb[u] = *p_other;
+		}
+		#pragma unroll
+		for(int u = 0; u < BATCH; ++ u) {
+			if(mm.b_act) {
+				s_ops[wave][(2 * u) * DD + lane] = va[u];
+				if(!b_diag)
+					s_ops[wave][(2 * u + 1) * DD + lane] = vb[u];
+			}
+			if(b_y)
+				s_yv[wave][u * 8 + yq] = vb[u];
+		}
+		wave_sync();
+		#pragma unroll
+		for(int u = 0; u < BATCH; ++ u) {
+			if(u < n_here) { // wave-uniform
+				const double *pa = b_y? s_yv[wave] + u * 8 : s_ops[wave] + (2 * u) * DD + mm.r;
+				const double *pb = s_ops[wave] + (2 * u + (b_diag? 0 : 1)) * DD + yq; // (yq = q in the matrix lanes)
+				const int as = b_y? 1 : D;
+				#pragma unroll
+				for(int t = 0; t < D; ++ t)
+					sum += pa[t * as] * pb[t * D];
+			}
+		}
+		wave_sync();
+	}
+	s_part[wave][lane] = sum;
+	__syncthreads();
+	if(wave != 0)
+		return;
+	double total = 0;
+	#pragma unroll
+	for(int v = 0; v < W; ++ v)
+		total += s_part[v][lane];
+	if(b_y)
+		w[sl.cs_new + yq] = init - total;
+	else if(mm.b_act)
+		L[sl.loff + lane] = init - total;
+}
+
+void launch_panel_update(int n_dim, const TUpdSlot *slots, int n_slots, const TUpdEnt *ents, const double *A, double *L,
+	const double *b, double *w, hipStream_t stream)
+{
+	if(n_slots <= 0)
+		return;
+	if(n_dim == 3)
+		hipLaunchKernelGGL((panel_update_kernel<3>), dim3(n_slots), dim3(64 * PANEL_UPD_W), 0, stream, slots, ents, A, L, b, w);
+	else if(n_dim == 6)
+		hipLaunchKernelGGL((panel_update_kernel<6>), dim3(n_slots), dim3(64 * PANEL_UPD_W), 0, stream, slots, ents, A, L, b, w);
+	else
+		hipLaunchKernelGGL((panel_update_kernel<7>), dim3(n_slots), dim3(64 * PANEL_UPD_W), 0, stream, slots, ents, A, L, b, w);
+}
+
+} // namespace slampp

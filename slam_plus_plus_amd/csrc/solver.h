@@ -117,6 +117,15 @@ struct slampp_hip_solver {
 	// stage whose shape is too rare stay with the wave-per-task kernel (d_simt_rest lists them)
 	slampp::CDevArray<slampp::TSimtChunk> d_simt_chunks;
 	slampp::CDevArray<int32_t> d_simt_prog, d_simt_rest;
+	// separator tasks that run as panels in LDS (panel_kernel.hip): their packages, per stage the offsets of the packages and
+	// the tasks left to factor_stage_kernel
+	int n_panel = -1; // option "panel": -1 / 1 = where a task fits (default), 0 = never
+	slampp::CDevArray<longlong2> d_panel_pkg;
+	slampp::CDevArray<int64_t> d_panel_off;
+	slampp::CDevArray<int32_t> d_panel_rest;
+	slampp::CDevArray<slampp::TUpdSlot> d_panel_upd_slots; // the factor blocks of the panel tasks, stage by stage, and the
+	slampp::CDevArray<slampp::TUpdEnt> d_panel_upd_ents;   // updates they receive from earlier stages (panel_update_kernel)
+	std::vector<int32_t> panel_ptr, panel_rest_ptr, panel_upd_ptr; // [n_stages + 1] ranges of the lists (empty: no panels)
 	slampp::CDevArray<int64_t> d_simt_tab;
 	std::vector<int32_t> simt_chunk_ptr, simt_rest_ptr; // [n_bottom_stages + 1] each; empty = not in use
 	std::vector<int32_t> simt_lds_bytes; // per stage: the largest chunk table (it is staged in LDS)

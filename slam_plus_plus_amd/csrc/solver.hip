@@ -259,6 +259,7 @@ void slampp_hip_solver::Free_Device()
 {
 	d_cols.Free(); d_blks.Free(); d_rents.Free(); d_pairs.Free(); d_task_ptr.Free(); d_task_pkg.Free(); d_pkg.Free();
 	d_simt_chunks.Free(); d_simt_prog.Free(); d_simt_rest.Free(); d_simt_tab.Free();
+	d_panel_pkg.Free(); d_panel_off.Free(); d_panel_rest.Free(); d_panel_upd_slots.Free(); d_panel_upd_ents.Free();
 	simt_chunk_ptr.clear(); simt_rest_ptr.clear();
 	d_dense_blks.Free(); d_dense_cols.Free(); d_dense.Free(); d_dense_invdiag.Free(); d_dense_z.Free(); d_dense_x.Free();
 	n_dense_blks = n_dense_cols = n_dense_dim = n_dense_pad = 0;
@@ -291,6 +292,7 @@ size_t slampp_hip_solver::n_Device_Bytes() const
 		d_dense_z.n_Bytes() + d_dense_x.n_Bytes() + d_cols.n_Bytes() + d_blks.n_Bytes() + d_rents.n_Bytes() +
 		d_task_ptr.n_Bytes() + d_task_pkg.n_Bytes() + d_pkg.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
 		d_simt_chunks.n_Bytes() + d_simt_prog.n_Bytes() + d_simt_rest.n_Bytes() + d_simt_tab.n_Bytes() +
+		d_panel_pkg.n_Bytes() + d_panel_off.n_Bytes() + d_panel_rest.n_Bytes() + d_panel_upd_slots.n_Bytes() + d_panel_upd_ents.n_Bytes() +
 		d_rhs.n_Bytes() + d_L.n_Bytes() + d_Linv.n_Bytes() + d_w.n_Bytes() + d_cov.n_Bytes() + d_flag.n_Bytes() +
 		d_Z.n_Bytes() + d_diag_zoff.n_Bytes() + d_Zd.n_Bytes() + d_Zd_work.n_Bytes() + sparse_inverse_bytes(p_sinv) +
 		(p_schur? schur_device_bytes(p_schur) : 0);
@@ -546,6 +548,149 @@ void slampp_hip_solver::Analyze_Sparse()
 	}
 	n_dense_blks = int(dense_blks.size());
 	n_dense_cols = int(dense_cols.size());
+	// panel packages for the separator stages (panel_kernel.hip): a task qualifies if its columns' blocks are one range of
+	// the factor and everything fits the kernel's LDS; the updates it receives from earlier stages go to the lists of
+	// panel_update_kernel, block by block
+	std::vector<longlong2> panel_pkg;
+	std::vector<int64_t> panel_off;
+	std::vector<int32_t> panel_rest;
+	std::vector<TUpdSlot> upd_slots;
+	std::vector<TUpdEnt> upd_ents;
+	panel_ptr.clear();
+	panel_rest_ptr.clear();
+	panel_upd_ptr.clear();
+	if(n_panel && P.uniform_dim && (P.max_dim == 3 || P.max_dim == 6 || P.max_dim == 7)) {
+		const int n_stages = int(P.stage_ptr.size()) - 1, D = P.max_dim;
+		const int n_slot_cap = panel_slot_cap(D);
+		panel_ptr.assign(n_stages + 1, 0);
+		panel_rest_ptr.assign(n_stages + 1, 0);
+		panel_upd_ptr.assign(n_stages + 1, 0);
+		std::vector<int32_t> col_local(size_t(P.n), -1);
+		std::vector<uint32_t> irow, ipair;
+		std::vector<TPanelCol> pcols;
+		std::vector<TPanelSlot> pslots;
+		for(int s = 0; s < n_stages; ++ s) {
+			for(int t = P.stage_ptr[s]; s >= n_bottom_stages && t < P.stage_ptr[s + 1]; ++ t) {
+				const int64_t c_begin = P.task_ptr[t], c_end = P.task_ptr[t + 1];
+				const int n_cols = int(c_end - c_begin);
+				bool b_fits = n_cols >= 1 && n_cols <= int(PANEL_COLS);
+				const int64_t k_begin = b_fits? cols[c_begin].k0 : 0;
+				int64_t n_slots = 0, n_int_rows = 0, n_int_pairs = 0;
+				for(int64_t i = c_begin; b_fits && i < c_end; ++ i) {
+					b_fits = cols[i].k0 == k_begin + n_slots; // consecutive columns: one range of factor blocks
+					n_slots += cols[i].nb;
+				}
+				b_fits = b_fits && n_slots <= n_slot_cap;
+				for(int64_t i = c_begin; b_fits && i < c_end; ++ i) { // size of the package
+					const TColDesc &c = cols[i];
+					for(int64_t e = c.r0; e < c.r0 + c.nr; ++ e)
+						n_int_rows += P.rblk[e] >= k_begin && P.rblk[e] < k_begin + n_slots;
+					for(int64_t e = P.pptr[c.k0 + 1]; e < P.pptr[c.k0 + c.nb]; ++ e)
+						n_int_pairs += P.pa[e] >= k_begin && P.pa[e] < k_begin + n_slots;
+				}
+				const size_t n_units = 4 + 3 * size_t(n_cols) + 2 * size_t(n_slots) + size_t(n_int_rows + 3) / 4 + size_t(n_int_pairs + 3) / 4;
+				b_fits = b_fits && n_units <= size_t(PANEL_UNITS);
+				if(!b_fits) {
+					panel_rest.push_back(t);
+					continue;
+				}
+				irow.clear(); ipair.clear(); pcols.clear(); pslots.clear();
+				for(int64_t i = c_begin; i < c_end; ++ i)
+					col_local[P.task_cols[i]] = int32_t(i - c_begin);
+				for(int64_t i = c_begin; i < c_end; ++ i) {
+					const TColDesc &c = cols[i];
+					TPanelCol pc;
+					memset(&pc, 0, sizeof(pc));
+					pc.linv_off = c.linv_off;
+					pc.cs_new = c.cs_new;
+					pc.cs_src = c.cs_src;
+					pc.slot0 = int32_t(c.k0 - k_begin);
+					pc.nb = c.nb;
+					pc.ir0 = int32_t(irow.size());
+					TUpdSlot us;
+					memset(&us, 0, sizeof(us));
+					us.loff = blks[c.k0].loff;
+					us.asrc = blks[c.k0].asrc;
+					us.e0 = int64_t(upd_ents.size());
+					us.kind = 1;
+					us.cs_src = c.cs_src;
+					us.cs_new = c.cs_new;
+					for(int64_t e = c.r0; e < c.r0 + c.nr; ++ e) { // row entries of the diagonal block: blocks L(j,c)
+						const int64_t k = P.rblk[e];
+						if(k >= k_begin && k < k_begin + n_slots)
+							irow.push_back(uint32_t(k - k_begin) | (uint32_t(col_local[P.blk_col[k]]) << 16));
+						else
+							upd_ents.push_back(TUpdEnt{rents[e].off, int64_t(rents[e].ycs)});
+					}
+					us.ne = int32_t(int64_t(upd_ents.size()) - us.e0);
+					upd_slots.push_back(us);
+					pc.inr = int32_t(irow.size()) - pc.ir0;
+					pcols.push_back(pc);
+					for(int64_t k = c.k0; k < c.k0 + c.nb; ++ k) {
+						TPanelSlot ps;
+						memset(&ps, 0, sizeof(ps));
+						ps.loff = blks[k].loff;
+						ps.asrc = blks[k].asrc;
+						ps.ip0 = int32_t(ipair.size());
+						if(k > c.k0) { // (the diagonal block's updates are its row entries)
+							memset(&us, 0, sizeof(us));
+							us.loff = blks[k].loff;
+							us.asrc = blks[k].asrc;
+							us.e0 = int64_t(upd_ents.size());
+							for(int64_t e = P.pptr[k]; e < P.pptr[k + 1]; ++ e) {
+								const int64_t ka = P.pa[e], kb = P.pb[e];
+								if(ka >= k_begin && ka < k_begin + n_slots)
+									ipair.push_back(uint32_t(ka - k_begin) | (uint32_t(kb - k_begin) << 16));
+								else
+									upd_ents.push_back(TUpdEnt{P.loff[ka], P.loff[kb]});
+							}
+							us.ne = int32_t(int64_t(upd_ents.size()) - us.e0);
+							upd_slots.push_back(us);
+						}
+						ps.inp = int32_t(ipair.size()) - ps.ip0;
+						pslots.push_back(ps);
+					}
+				}
+				TPanelHead hd;
+				memset(&hd, 0, sizeof(hd));
+				hd.n_cols = n_cols;
+				hd.n_slots = int32_t(n_slots);
+				hd.n_units = int32_t(n_units);
+				hd.n_int_rows = int32_t(irow.size());
+				const size_t n_at = panel_pkg.size();
+				panel_pkg.resize(n_at + n_units, longlong2{0, 0});
+				char *p_dst = reinterpret_cast<char*>(&panel_pkg[n_at]);
+				memcpy(p_dst, &hd, sizeof(hd));
+				p_dst += 64;
+				memcpy(p_dst, pcols.data(), pcols.size() * sizeof(TPanelCol));
+				p_dst += pcols.size() * sizeof(TPanelCol);
+				memcpy(p_dst, pslots.data(), pslots.size() * sizeof(TPanelSlot));
+				p_dst += pslots.size() * sizeof(TPanelSlot);
+				if(!irow.empty())
+					memcpy(p_dst, irow.data(), irow.size() * sizeof(uint32_t));
+				p_dst += (irow.size() + 3) / 4 * 16;
+				if(!ipair.empty())
+					memcpy(p_dst, ipair.data(), ipair.size() * sizeof(uint32_t));
+				panel_off.push_back(int64_t(n_at));
+			}
+			panel_ptr[s + 1] = int32_t(panel_off.size());
+			panel_rest_ptr[s + 1] = int32_t(panel_rest.size());
+			panel_upd_ptr[s + 1] = int32_t(upd_slots.size());
+		}
+		static_assert(sizeof(TPanelHead) == 64 && sizeof(TPanelCol) == 48 && sizeof(TPanelSlot) == 32 && sizeof(TUpdSlot) == 64 &&
+			sizeof(TUpdEnt) == 16, "record sizes");
+		if(panel_off.empty()) {
+			panel_ptr.clear();
+			panel_rest_ptr.clear();
+			panel_upd_ptr.clear();
+		} else
+			panel_pkg.resize(panel_pkg.size() + 64 * PANEL_W, longlong2{0, 0}); // speculative reads past the last package
+	}
+	d_panel_upd_slots.Upload(upd_slots, stream);
+	d_panel_upd_ents.Upload(upd_ents, stream);
+	d_panel_pkg.Upload(panel_pkg, stream);
+	d_panel_off.Upload(panel_off, stream);
+	d_panel_rest.Upload(panel_rest, stream);
 	d_cols.Upload(cols, stream);
 	d_blks.Upload(blks, stream);
 	d_pairs.Upload(pairs, stream);
@@ -785,7 +930,20 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			} else if(s > 0 && s < n_bottom_stages && dplan.task_pkg)
 				launch_factor_wide(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
 					P.stage_ptr[s + 1] - P.stage_ptr[s], d_flag.p(), stream);
-			else
+			else if(s >= n_bottom_stages && !panel_ptr.empty()) {
+				// separators: as panels in LDS where they fit (the updates from earlier stages first, spread over the chip),
+				// column by column otherwise
+				launch_panel_update(P.max_dim, d_panel_upd_slots.p() + panel_upd_ptr[s], panel_upd_ptr[s + 1] - panel_upd_ptr[s],
+					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream);
+				launch_factor_panel(P.max_dim, d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s], panel_ptr[s + 1] - panel_ptr[s],
+					d_L.p(), d_Linv.p(), d_w.p(), d_flag.p(), stream, dplan.p_timing);
+				if(panel_rest_ptr[s + 1] > panel_rest_ptr[s]) {
+					TDevPlan t_rest = dplan;
+					t_rest.task_map = d_panel_rest.p();
+					launch_factor_stage(t_rest, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), panel_rest_ptr[s],
+						panel_rest_ptr[s + 1] - panel_rest_ptr[s], false, d_flag.p(), stream);
+				}
+			} else
 			launch_factor_stage(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
 				P.stage_ptr[s + 1] - P.stage_ptr[s], s < n_bottom_stages, d_flag.p(), stream);
 			if(s == 0 || (s == n_wide_end - 1 && b_profile >= 2) || s == n_stages - 1)
@@ -988,6 +1146,8 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 		p_solver->n_wide_min_tasks = int(n_value);
 	else if(s == "simt_width" && (n_value == 16 || n_value == 32 || n_value == 64))
 		p_solver->n_simt_width = int(n_value);
+	else if(s == "panel" && n_value >= -1 && n_value <= 1)
+		p_solver->n_panel = int(n_value);
 	else if(s == "simt_stages" && n_value >= 0)
 		p_solver->n_simt_stages = int(n_value);
 	else if(s == "profile") {

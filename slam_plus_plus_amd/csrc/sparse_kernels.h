@@ -52,6 +52,46 @@ struct TDenseCol { // 24 B
 	int32_t pos, dj;
 };
 
+// ---- panel packages (panel_kernel.hip): everything a separator task of consecutive columns needs, in one buffer ----
+// 16-byte units: head (4) | columns (3 each) | factor blocks of the task = slots of its LDS image (2 each) | internal row
+// entries and internal update pairs (4 per unit: operands that are slots of the image)
+enum { PANEL_W = 8, PANEL_COLS = 8, PANEL_UNITS = 1024, PANEL_UPD_W = 4 };
+struct TPanelHead { // 64 B
+	int32_t n_cols, n_slots, n_units, n_int_rows; // (internal row entries: the internal pairs follow them, unit-aligned)
+	int32_t pad[12];
+};
+struct TPanelCol { // 48 B
+	int64_t linv_off, cs_new, cs_src;
+	int32_t slot0, nb;  // the column's blocks are the slots slot0 .. slot0 + nb - 1 (diagonal block first)
+	int32_t ir0, inr;   // its internal row entries: (slot of L(j,c)) | (c's number in the task) << 16
+	int64_t pad;
+};
+struct TPanelSlot { // 32 B
+	int64_t loff, asrc; // as in TBlkDesc
+	int32_t ip0, inp;   // internal update pairs: (slot of L(i,c)) | (slot of L(j,c)) << 16
+	int64_t pad;
+};
+// the updates whose operands earlier stages produced are applied before the panels run, one workgroup per factor block
+// (panel_update_kernel): L(block) = Lambda(block) - sum, y_j = b_j - sum for diagonal blocks
+struct TUpdSlot { // 64 B
+	int64_t loff, asrc;
+	int64_t e0;           // first entry
+	int32_t ne, kind;     // number of entries; 1 = diagonal block (row entries L(j,c), with the right-hand side), 0 = below it (pairs)
+	int64_t cs_src, cs_new; // diagonal blocks: where b_j is read and y_j (so far) goes
+	int64_t pad[2];
+};
+struct TUpdEnt { // 16 B
+	int64_t a_off; // offset of L(i,c) (row entries: of L(j,c))
+	int64_t b_off; // offset of L(j,c) (row entries: scalar offset of y_c in the workspace)
+};
+inline int panel_slot_cap(int n_dim) { return (n_dim == 6)? 96 : (n_dim == 7)? 72 : 256; }
+
+// one workgroup per package (pkg_off: their offsets in pkg, in 16-byte units; pkg is padded by 64 * PANEL_W units)
+bool launch_factor_panel(int n_dim, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks, double *L,
+	double *Linv, double *w, int *p_flag, hipStream_t stream, long long *p_timing = 0);
+void launch_panel_update(int n_dim, const TUpdSlot *slots, int n_slots, const TUpdEnt *ents, const double *A, double *L,
+	const double *b, double *w, hipStream_t stream);
+
 // capacities of the staged path of the separator kernel (blocks, row entries, update pairs of a column): near the root,
 // and in the wide stages right above the leaves
 enum { UP_CHUNK = 16, UP_NR = 128, UP_NP = 512, WIDE_CHUNK = 8, WIDE_NR = 32, WIDE_NP = 48 };

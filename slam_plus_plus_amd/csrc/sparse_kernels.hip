@@ -110,7 +110,7 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 	__shared__ double s_yv[(W == 1 && D)? 64 : 1];          // and the y vectors of their row entries
 	static_assert(64 * W <= PKG_SPECULATIVE && 64 * W <= PKG_UNITS, "one speculative unit per thread");
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
-	const int task = task_begin + blockIdx.x;
+	const int task = p.task_map? p.task_map[task_begin + blockIdx.x] : task_begin + blockIdx.x;
 	long long *p_tm = 0;
 	int n_tm = 0;
 	if(p.p_timing && blockIdx.x == 0 && tid == 0) {

@@ -23,41 +23,6 @@ namespace slampp {
 
 #include "sparse_device.inl"
 
-// sum_t a[r + t D] b[q + t D] for matrix lanes, sum_t y[t] b[q + t D] for the right-hand side lanes
-template <int D>
-__device__ __forceinline__ double row_product_image(const double *blk, const double *yv, int r, int q, bool b_y)
-{
-	const double *a = b_y? yv : blk + r;
-	const int as = b_y? 1 : D;
-	double av[D], bv[D];
-	#pragma unroll
-	for(int t = 0; t < D; ++ t) {
-		av[t] = a[t * as];
-		bv[t] = blk[q + t * D];
-	}
-	double sum = 0;
-	#pragma unroll
-	for(int t = 0; t < D; ++ t)
-		sum += av[t] * bv[t];
-	return sum;
-}
-
-template <int D>
-__device__ __forceinline__ double pair_product_image(const double *a, const double *b, int r, int q)
-{
-	double av[D], bv[D];
-	#pragma unroll
-	for(int t = 0; t < D; ++ t) {
-		av[t] = a[r + t * D];
-		bv[t] = b[q + t * D];
-	}
-	double sum = 0;
-	#pragma unroll
-	for(int t = 0; t < D; ++ t)
-		sum += av[t] * bv[t];
-	return sum;
-}
-
 template <int D, int CAP_BLK>
 __global__ void __launch_bounds__(64)
 factor_subtree_image_kernel(TDevPlan p, const double *__restrict__ A, double *L, double *Linv,
