@@ -86,6 +86,12 @@ def kernel_traffic(traffic, needle):
     return None
 
 
+def kernel_traffic_sum(traffic, needle):
+    """Bytes per step of every kernel whose name holds the needle (template variants of one kernel: each runs once a step)."""
+    parts = [v["hbm_bytes_per_launch_corrected"] for name, v in traffic.items() if needle in name]
+    return sum(parts) if parts else None
+
+
 def per_kernel_bytes_sparse(plan, n_bottom_stages=1):
     """Algorithmic bytes each kernel of the sparse path moves per step, from the plan (our own
     factor structure): factor = 8 (nnz of the Lambda blocks read + nnz of the L columns written),
@@ -259,12 +265,14 @@ def run_c3(args, rank, world, local_rank, dist):
     prof = dict(prof_fine, **{k_: v_ for k_, v_ in prof.items() if k_ in ("factor_leaves", "backward")})
     n_stages, n_bottom = stats["n_stages"], stats["n_bottom_stages"]
     kb = per_kernel_bytes_sparse(solver.plan(), n_bottom)
-    launches = {"factor_leaves": 1, "factor_wide": max(n_bottom - 1, 1), "factor_upper": max(n_stages - n_bottom, 1),
+    # the separator stages are two launches each: the updates from earlier stages (one workgroup per factor block), then the
+    # tasks as panels in LDS
+    launches = {"factor_leaves": 1, "factor_wide": max(n_bottom - 1, 1), "factor_upper": 2 * max(n_stages - n_bottom, 1),
                 "forward": n_stages, "backward": n_stages}
     names = {"factor_leaves": "factor_simt_kernel", "factor_wide": "factor_stage_kernel<D, 1, 8, 32, 48>",
-             "factor_upper": "factor_stage_kernel<D, 8, 16, 128, 512>", "forward": "forward_stage_kernel",
+             "factor_upper": "panel_update_kernel + factor_panel_kernel", "forward": "forward_stage_kernel",
              "backward": "backward_stage_kernel"}
-    needles = {"factor_leaves": "factor_simt_kernel", "factor_wide": ", 1, 8, 32, 48>", "factor_upper": ", 8, 16, 128, 512>",
+    needles = {"factor_leaves": "factor_simt_kernel", "factor_wide": ", 1, 8, 32, 48>", "factor_upper": ("panel_update_kernel", "factor_panel_kernel"),
                "forward": "forward_stage_kernel", "backward": "backward_stage_kernel"}   # as rocprofv3 spells the kernels
     traffic, traffic_file = load_traffic("c3")
     kernels = []
@@ -277,7 +285,9 @@ def run_c3(args, rank, world, local_rank, dist):
                         "algorithmic_bytes_per_launch": kb[ph] / launches[ph],
                         "achieved_GBs": kb[ph] / (per_step_ms * 1e-3) / 1e9,
                         "timed_in": "timed region" if ph in ("factor_leaves", "backward") else "5 extra steps after it",
-                        "hbm_traffic_bytes_per_launch": kernel_traffic(traffic, needles[ph])})
+                        "hbm_traffic_bytes_per_launch": kernel_traffic(traffic, needles[ph]) if isinstance(needles[ph], str) else
+                        (lambda parts: (sum(parts) / len(parts)) if all(p is not None for p in parts) else None)(
+                            [kernel_traffic(traffic, n_) for n_ in needles[ph]])})
     kernels.sort(key=lambda k: -k["ms_per_step"])
     # the roofline object is for the kernel that moves the step's bytes: the leaf kernel reads nearly all of Lambda and
     # writes nearly all of L in ONE launch (the other phases are chains of 3 / 18 / 22 launches of 0.1-4 MB each, bound
@@ -700,7 +710,7 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
         gb = nbytes / (prof["schur_tiles"] * 1e-3) / 1e9
         tr = None
         if traffic:
-            parts = [kernel_traffic(traffic, k_) for k_ in ("schur_run_kernel", "schur_tile_kernel", "schur_tile_reduce_kernel")]
+            parts = [kernel_traffic_sum(traffic, k_) for k_ in ("schur_run_kernel", "schur_tile_kernel", "schur_tile_reduce_kernel")]
             tr = sum(p for p in parts if p) or None
         out["roofline_schur_assembly"] = {
             "bound": "hbm", "kernel": "schur_run_kernel (+ schur_tile_kernel for landmarks outside runs, + schur_tile_reduce_kernel): "
@@ -752,6 +762,7 @@ def main():
     ap.add_argument("--ba-steps", type=int, default=5)
     ap.add_argument("--poses", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ba-solve-only", action="store_true", help="leave out the legs beside the solve (host path, marginals, incremental update, assembly): the counter passes of tools/profile_round.sh, whose per-kernel averages should be the solve's")
     ap.add_argument("--ba-legs", default="band,uniform,venice", help="which visibility models the BA part runs (profiling runs one at a time)")
     args = ap.parse_args()
 
@@ -787,7 +798,7 @@ def main():
         out = run_c3(args, rank, world, local_rank, dist)
     legs = [m for m in args.ba_legs.split(",") if m]
     if args.workload in ("all", "ba"):
-        ba = run_ba(args, rank, world, local_rank, dist, mode=legs[0], extras=legs[0] == "band")
+        ba = run_ba(args, rank, world, local_rank, dist, mode=legs[0], extras=legs[0] == "band" and not args.ba_solve_only)
         if rank == 0:
             if out is None:   # BA only: promote it to the headline
                 out = {"metric": "BA Schur solve GFLOP/s (algorithmic flops / wall-clock)", "value": ba["GFLOP/s"],

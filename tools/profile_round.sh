@@ -13,7 +13,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ba_trac
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/c3_pmc_$C -- python3 $R/bench.py --workload c3 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/c3_pmc_$C.json 2> $OUT/c3_pmc_$C.err
   for LEG in band uniform venice; do
-    timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/ba_${LEG}_pmc_$C -- python3 $R/bench.py --workload ba --ba-legs $LEG --ba-steps 2 --no-cpu-baseline > $OUT/ba_${LEG}_pmc_$C.json 2> $OUT/ba_${LEG}_pmc_$C.err
+    timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/ba_${LEG}_pmc_$C -- python3 $R/bench.py --workload ba --ba-legs $LEG --ba-steps 2 --no-cpu-baseline --ba-solve-only > $OUT/ba_${LEG}_pmc_$C.json 2> $OUT/ba_${LEG}_pmc_$C.err
   done
 done
 cd $R
