@@ -87,6 +87,12 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
  * one; -1 = when fewer than 15 % of its camera-camera blocks are nonzero (default), 0 = never, 1 = always; the
  * reference makes this choice at compile time: __SCHUR_USE_DENSE_SOLVER, include/slam/LinearSolver_Schur.h:48-55, "faster if ... dense enough"),
  * "schur_incremental" (Schur mode, 0 / 1: keep the assembled reduced system for slampp_hip_schur_set_changed_points),
+ * "schur_tiles" (Schur mode: how S = A - U C^-1 U^T is assembled; -1 (default) = landmark by landmark -- runs of landmarks
+ * seen by the same cameras on the matrix cores, tiles of neighbouring landmarks in LDS -- when that takes at least half of
+ * the contributions, the per-block contribution lists for the rest; 0 = lists only; 1 / 2 / 3 = runs and tiles wherever
+ * possible / tiles only / runs of any length),
+ * "panel" (sparse path: -1 / 1 (default) = separator tasks are factored as panels in LDS, the updates from earlier stages
+ * applied per factor block by a launch of its own; 0 = column by column),
  * "marginals_dense" (Schur mode: 1 = slampp_hip_schur_marginals always inverts the reduced system densely; 0 (default) =
  * when the solves factor it by the sparse block path, the covariances take the blocks of S^-1 they need from a
  * sparse inverse subset on that factor's pattern) */
