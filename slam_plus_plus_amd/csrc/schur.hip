@@ -990,6 +990,73 @@ static void schur_try_sparse_reduced(slampp_hip_solver &s, CSchurState &S)
 	S.b_reduced_sparse = true;
 }
 
+// S -= U C^-1 U^T and r -= U C^-1 l for all landmarks, C^-1 (and W = U C^-1 for all observations, if b_store_W) left
+// behind: S is the dense buffer (ld) or, with p_sb_dst, the packed values of the inner solver (p_r its right-hand side)
+template <int DC, int DP>
+static void schur_assemble_t(slampp_hip_solver &s, CSchurState &S, const double *A, const double *rhs, double *p_S, int ld,
+	const int64_t *p_sb_dst, double *p_r, bool b_store_W)
+{
+	hipStream_t st = s.stream;
+	const int n = S.N;
+	const int64_t ubase = S.n_ablocks * DC * DC;
+	// Landmarks go through the tiles of schur_tiles.hip (read once each), through the contribution lists, or -- when only
+	// some of them fit the tiles -- both: the tiles take theirs, the lists the rest.
+	const CSchurTiles &T = S.tiles;
+	const bool b_tiles = T.b_enabled, b_lists_all = !b_tiles;
+	s.Phase_Begin("schur_points");
+	if(b_lists_all) {
+		hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((S.np + 255) / 256)), dim3(256), 0, st,
+			S.d_ptr.p(), S.nc, S.np, ubase, A, S.d_Cinv.p(), s.d_flag.p(), (const int32_t*)0);
+		hipLaunchKernelGGL((schur_obs_W_kernel<DC, DP>), dim3(unsigned((S.n_obs + 255) / 256)), dim3(256), 0, st,
+			S.n_obs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p(), (const int32_t*)0);
+	} else if(T.b_hybrid) { // only the landmarks of the lists: the others get C^-1 (and W) where they are multiplied
+		hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((T.n_list_points + 255) / 256)), dim3(256), 0, st,
+			S.d_ptr.p(), S.nc, T.n_list_points, ubase, A, S.d_Cinv.p(), s.d_flag.p(), T.d_xpoints.p());
+		if(T.n_xobs)
+			hipLaunchKernelGGL((schur_obs_W_kernel<DC, DP>), dim3(unsigned((T.n_xobs + 255) / 256)), dim3(256), 0, st,
+				T.n_xobs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p(), T.d_xcam_obs.p());
+	}
+	s.Phase_End();
+
+	if(b_tiles) {
+		s.Phase_Begin("schur_tiles");
+		// (C^-1 of every landmark is needed by the back-substitution; W only if the next solve may be an update)
+		schur_tiles_enqueue(T, DC, DP, S.d_ptr.p(), S.nc, ubase, A, rhs, n, S.d_Cinv.p(), b_store_W? S.d_W.p() : 0,
+			true, S.d_sb_row.p(), S.d_sb_col.p(), p_S, ld, p_sb_dst, p_r, s.d_flag.p(), st);
+		s.Phase_End();
+	}
+
+	s.Phase_Begin("schur_gather");
+	{
+		const int64_t n_lists = b_lists_all? S.n_sblocks : T.n_xblocks, n_list_entries = b_lists_all? S.n_entries : T.n_xentries;
+		const int64_t *p_list_ptr = b_lists_all? S.d_sb_ptr.p() : T.d_xsb_ptr.p();
+		const int32_t *p_list_a = b_lists_all? S.d_ent_a.p() : T.d_xent_a.p(), *p_list_map = b_lists_all? 0 : T.d_xsb_map.p();
+		const int64_t *p_list_uoff = b_lists_all? S.d_ent_uoff.p() : T.d_xent_uoff.p();
+		if(n_lists > 0) {
+			// one wave per block of S for short contribution lists (dense S: 500k blocks x 10 contributions),
+			// 8 waves per block for long ones (C4's band structure: 4000 blocks x 1250 contributions: 1.18 -> 0.69 ms)
+			if(n_list_entries > 256 * n_lists)
+				hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 8>), dim3(unsigned(n_lists)), dim3(512), 0, st,
+					n_lists, p_list_ptr, S.d_sb_row.p(), S.d_sb_col.p(), p_list_a, p_list_uoff, A,
+					S.d_W.p(), p_S, ld, p_sb_dst, p_list_map);
+			else
+				hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 1>), dim3(unsigned(n_lists)), dim3(64), 0, st,
+					n_lists, p_list_ptr, S.d_sb_row.p(), S.d_sb_col.p(), p_list_a, p_list_uoff, A,
+					S.d_W.p(), p_S, ld, p_sb_dst, p_list_map);
+		}
+	}
+	s.Phase_End();
+
+	s.Phase_Begin("schur_rhs");
+	if(!S.tiles.b_enabled) // (the tiles bring the right-hand side's share of their landmarks themselves)
+		hipLaunchKernelGGL((schur_rhs_kernel<DC, DP>), dim3(unsigned(S.nc)), dim3(64), 0, st,
+			S.d_cam_ptr.p(), S.d_cam_obs.p(), S.d_obs_pt.p(), n, S.d_W.p(), rhs, p_S, ld, p_r);
+	else if(S.tiles.b_hybrid)
+		hipLaunchKernelGGL((schur_rhs_kernel<DC, DP>), dim3(unsigned(S.nc)), dim3(64), 0, st,
+			S.tiles.d_xcam_ptr.p(), S.tiles.d_xcam_obs.p(), S.d_obs_pt.p(), n, S.d_W.p(), rhs, p_S, ld, p_r);
+	s.Phase_End();
+}
+
 template <int DC, int DP>
 static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *A, double *rhs)
 {
@@ -1045,65 +1112,17 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 		SLAMPP_HIP_CHECK(hipMemcpyAsync(S.d_A_prev.p(), A, size_t(S.n_ablocks) * DC * DC * sizeof(double), hipMemcpyDeviceToDevice, st));
 	s.Phase_End();
 
-	// Landmarks go through the tiles of schur_tiles.hip (read once each), through the contribution lists, or -- when only
-	// some of them fit the tiles -- both: the tiles take theirs, the lists the rest.
-	const CSchurTiles &T = S.tiles;
-	const bool b_tiles = T.b_enabled, b_lists_all = !b_tiles;
-	s.Phase_Begin("schur_points");
-	if(b_lists_all) {
-		hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((S.np + 255) / 256)), dim3(256), 0, st,
-			S.d_ptr.p(), S.nc, S.np, ubase, A, S.d_Cinv.p(), s.d_flag.p(), (const int32_t*)0);
-		hipLaunchKernelGGL((schur_obs_W_kernel<DC, DP>), dim3(unsigned((S.n_obs + 255) / 256)), dim3(256), 0, st,
-			S.n_obs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p(), (const int32_t*)0);
-	} else if(T.b_hybrid) { // only the landmarks of the lists: the others get C^-1 (and W) where they are multiplied
-		hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((T.n_list_points + 255) / 256)), dim3(256), 0, st,
-			S.d_ptr.p(), S.nc, T.n_list_points, ubase, A, S.d_Cinv.p(), s.d_flag.p(), T.d_xpoints.p());
-		if(T.n_xobs)
-			hipLaunchKernelGGL((schur_obs_W_kernel<DC, DP>), dim3(unsigned((T.n_xobs + 255) / 256)), dim3(256), 0, st,
-				T.n_xobs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p(), T.d_xcam_obs.p());
-	}
-	s.Phase_End();
-
-	if(b_tiles) {
-		s.Phase_Begin("schur_tiles");
-		// (C^-1 of every landmark is needed by the back-substitution; W only if the next solve may be an update)
-		schur_tiles_enqueue(T, DC, DP, S.d_ptr.p(), S.nc, ubase, A, rhs, n, S.d_Cinv.p(), b_keep? S.d_W.p() : 0,
-			true, S.d_sb_row.p(), S.d_sb_col.p(), p_S, ld, p_sb_dst, p_r, s.d_flag.p(), st);
-		s.Phase_End();
-	}
-
-	s.Phase_Begin("schur_gather");
-	{
-		const int64_t n_lists = b_lists_all? S.n_sblocks : T.n_xblocks, n_list_entries = b_lists_all? S.n_entries : T.n_xentries;
-		const int64_t *p_list_ptr = b_lists_all? S.d_sb_ptr.p() : T.d_xsb_ptr.p();
-		const int32_t *p_list_a = b_lists_all? S.d_ent_a.p() : T.d_xent_a.p(), *p_list_map = b_lists_all? 0 : T.d_xsb_map.p();
-		const int64_t *p_list_uoff = b_lists_all? S.d_ent_uoff.p() : T.d_xent_uoff.p();
-		if(n_lists > 0) {
-			// one wave per block of S for short contribution lists (dense S: 500k blocks x 10 contributions),
-			// 8 waves per block for long ones (C4's band structure: 4000 blocks x 1250 contributions: 1.18 -> 0.69 ms)
-			if(n_list_entries > 256 * n_lists)
-				hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 8>), dim3(unsigned(n_lists)), dim3(512), 0, st,
-					n_lists, p_list_ptr, S.d_sb_row.p(), S.d_sb_col.p(), p_list_a, p_list_uoff, A,
-					S.d_W.p(), p_S, ld, p_sb_dst, p_list_map);
-			else
-				hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 1>), dim3(unsigned(n_lists)), dim3(64), 0, st,
-					n_lists, p_list_ptr, S.d_sb_row.p(), S.d_sb_col.p(), p_list_a, p_list_uoff, A,
-					S.d_W.p(), p_S, ld, p_sb_dst, p_list_map);
-		}
-	}
-	s.Phase_End();
+	schur_assemble_t<DC, DP>(s, S, A, rhs, p_S, ld, p_sb_dst, p_r, b_keep);
 	}
 	S.b_prev_valid = b_keep; // (a solve that turns out not positive definite takes it back: slampp_hip_sync)
 	S.n_changed = -1;        // the list serves one solve
 
-	s.Phase_Begin("schur_rhs");
-	if(b_update || !S.tiles.b_enabled) // (the tiles bring the right-hand side's share of their landmarks themselves)
+	if(b_update) { // (a full assembly brings the reduced right-hand side itself)
+		s.Phase_Begin("schur_rhs");
 		hipLaunchKernelGGL((schur_rhs_kernel<DC, DP>), dim3(unsigned(S.nc)), dim3(64), 0, st,
 			S.d_cam_ptr.p(), S.d_cam_obs.p(), S.d_obs_pt.p(), n, S.d_W.p(), rhs, p_S, ld, p_r);
-	else if(S.tiles.b_hybrid)
-		hipLaunchKernelGGL((schur_rhs_kernel<DC, DP>), dim3(unsigned(S.nc)), dim3(64), 0, st,
-			S.tiles.d_xcam_ptr.p(), S.tiles.d_xcam_obs.p(), S.d_obs_pt.p(), n, S.d_W.p(), rhs, p_S, ld, p_r);
-	s.Phase_End();
+		s.Phase_End();
+	}
 
 	if(s.p_allreduce) {
 		s.Phase_Begin("allreduce");
@@ -1251,8 +1270,9 @@ static bool schur_setup_sparse_marginals(slampp_hip_solver &s, CSchurState &S)
 	S.d_pair_tab.Upload(pair_tab, s.stream);
 	S.d_m_Zs.Alloc(size_t(P.loff.back()));
 	if(!S.d_m_zero.p()) {
-		S.d_m_zero.Alloc(size_t(S.N));
-		SLAMPP_HIP_CHECK(hipMemsetAsync(S.d_m_zero.p(), 0, size_t(S.N) * sizeof(double), s.stream));
+		const size_t n_zero = size_t(S.N) + size_t(S.np) * S.DP; // a whole right-hand side of zeros (the assembly reads the landmarks' part too)
+		S.d_m_zero.Alloc(n_zero);
+		SLAMPP_HIP_CHECK(hipMemsetAsync(S.d_m_zero.p(), 0, n_zero * sizeof(double), s.stream));
 	}
 	SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream)); // the tables live on this stack frame
 	return true;
@@ -1267,7 +1287,6 @@ static void schur_enqueue_marginals_sparse_t(slampp_hip_solver &s, CSchurState &
 {
 	hipStream_t st = s.stream;
 	const int n = S.N;
-	const int64_t ubase = S.n_ablocks * DC * DC;
 	const size_t n_in_values = size_t(S.n_in_blocks) * DC * DC;
 	double *p_S = S.d_in_buf.p(), *p_r = S.d_in_buf.p() + n_in_values;
 	SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), st));
@@ -1278,21 +1297,9 @@ static void schur_enqueue_marginals_sparse_t(slampp_hip_solver &s, CSchurState &
 		hipLaunchKernelGGL((schur_scatter_A_kernel<DC>), dim3(unsigned((n_work + 255) / 256)), dim3(256), 0, st,
 			S.d_ptr.p(), S.d_brow.p(), S.nc, A, S.d_m_zero.p(), p_S, S.Npad, n, S.d_a_dst.p(), p_r);
 	}
-	hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((S.np + 255) / 256)), dim3(256), 0, st,
-		S.d_ptr.p(), S.nc, S.np, ubase, A, S.d_Cinv.p(), s.d_flag.p());
-	hipLaunchKernelGGL((schur_obs_W_kernel<DC, DP>), dim3(unsigned((S.n_obs + 255) / 256)), dim3(256), 0, st,
-		S.n_obs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p());
-	if(S.n_sblocks > 0) {
-		if(S.n_entries > 256 * S.n_sblocks)
-			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 8>), dim3(unsigned(S.n_sblocks)), dim3(512), 0, st,
-				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
-				S.d_W.p(), p_S, S.Npad, S.d_sb_dst.p(), (const int32_t*)0);
-		else
-			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 1>), dim3(unsigned(S.n_sblocks)), dim3(64), 0, st,
-				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
-				S.d_W.p(), p_S, S.Npad, S.d_sb_dst.p(), (const int32_t*)0);
-	}
 	s.Phase_End();
+	// (the covariance gather below reads W of every observation and C^-1 of every landmark)
+	schur_assemble_t<DC, DP>(s, S, A, S.d_m_zero.p(), p_S, S.Npad, S.d_sb_dst.p(), p_r, true);
 	if(s.p_allreduce) {
 		s.Phase_Begin("allreduce");
 		hipLaunchKernelGGL(schur_flag_poison_kernel, dim3(1), dim3(1), 0, st, s.d_flag.p(), p_r);
@@ -1320,7 +1327,6 @@ static void schur_enqueue_marginals_t(slampp_hip_solver &s, CSchurState &S, cons
 {
 	hipStream_t st = s.stream;
 	const int ld = S.Npad, n = S.N;
-	const int64_t ubase = S.n_ablocks * DC * DC;
 	// decided as for a solve: with the sparse reduced system the covariances go through the sparse inverse subset
 	if(s.p_allreduce && (S.p_union_fn != s.p_allreduce || S.p_union_context != s.p_allreduce_context))
 		schur_agree_on_union(s, S);
@@ -1334,8 +1340,9 @@ static void schur_enqueue_marginals_t(slampp_hip_solver &s, CSchurState &S, cons
 		S.d_m_S.Alloc(size_t(ld) * ld);
 		S.d_m_Z.Alloc(size_t(ld) * ld);
 		S.d_m_invdiag.Alloc(size_t(ld / dense_NB) * dense_NB * dense_NB);
-		S.d_m_zero.Alloc(size_t(n));
-		SLAMPP_HIP_CHECK(hipMemsetAsync(S.d_m_zero.p(), 0, size_t(n) * sizeof(double), st));
+		const size_t n_zero = size_t(n) + size_t(S.np) * DP; // a whole right-hand side of zeros
+		S.d_m_zero.Alloc(n_zero);
+		SLAMPP_HIP_CHECK(hipMemsetAsync(S.d_m_zero.p(), 0, n_zero * sizeof(double), st));
 	}
 	double *p_S = S.d_m_S.p();
 	SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), st));
@@ -1347,21 +1354,8 @@ static void schur_enqueue_marginals_t(slampp_hip_solver &s, CSchurState &S, cons
 		hipLaunchKernelGGL((schur_scatter_A_kernel<DC>), dim3(unsigned((n_work + 255) / 256)), dim3(256), 0, st,
 			S.d_ptr.p(), S.d_brow.p(), S.nc, A, S.d_m_zero.p(), p_S, ld, n, (const int64_t*)0, (double*)0);
 	}
-	hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((S.np + 255) / 256)), dim3(256), 0, st,
-		S.d_ptr.p(), S.nc, S.np, ubase, A, S.d_Cinv.p(), s.d_flag.p());
-	hipLaunchKernelGGL((schur_obs_W_kernel<DC, DP>), dim3(unsigned((S.n_obs + 255) / 256)), dim3(256), 0, st,
-		S.n_obs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p());
-	if(S.n_sblocks > 0) {
-		if(S.n_entries > 256 * S.n_sblocks)
-			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 8>), dim3(unsigned(S.n_sblocks)), dim3(512), 0, st,
-				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
-				S.d_W.p(), p_S, ld, (const int64_t*)0, (const int32_t*)0);
-		else
-			hipLaunchKernelGGL((schur_gather_S_kernel<DC, DP, 1>), dim3(unsigned(S.n_sblocks)), dim3(64), 0, st,
-				S.n_sblocks, S.d_sb_ptr.p(), S.d_sb_row.p(), S.d_sb_col.p(), S.d_ent_a.p(), S.d_ent_uoff.p(), A,
-				S.d_W.p(), p_S, ld, (const int64_t*)0, (const int32_t*)0);
-	}
 	s.Phase_End();
+	schur_assemble_t<DC, DP>(s, S, A, S.d_m_zero.p(), p_S, ld, (const int64_t*)0, (double*)0, true);
 	if(s.p_allreduce) {
 		s.Phase_Begin("allreduce");
 		hipLaunchKernelGGL(schur_flag_poison_kernel, dim3(1), dim3(1), 0, st, s.d_flag.p(), p_S + n);

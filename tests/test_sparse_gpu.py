@@ -282,3 +282,22 @@ def test_marginals_full_size():
             e[6 * c + j] = 1.0
             assert solver.Solve_PosDef_Blocky(lam, e)
             assert rel_inf(e[6 * c:6 * c + 6], cov[c][:, j]) < 1e-9
+
+
+@pytest.mark.parametrize("dims", [(6,), (3,), (7,)])
+def test_separator_panels_agree_with_the_column_kernel(dims):
+    """The separator stages as panels in LDS (panel_kernel.hip: external updates per factor block, then the task's columns
+    inside an LDS image) against the column-by-column kernel (option panel = 0) and the oracle; same plan, different
+    association of the sums."""
+    d = dims[0]
+    lam = synth.pose_chain(n=12000 if d == 6 else 6000, d=d, seed=21)
+    ok, x_ref = O.solve_sparse(lam)[:2]
+    assert ok
+    xs = []
+    for panel in (1, 0):
+        solver = CLinearSolver_HIP(panel=panel)
+        eta = lam.rhs.copy()
+        assert solver.Solve_PosDef(lam, eta)
+        assert rel_inf(eta, x_ref) < TOL
+        xs.append(eta)
+    assert rel_inf(xs[0], xs[1]) < 1e-11
