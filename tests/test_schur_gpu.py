@@ -579,3 +579,26 @@ def test_incremental_update_after_a_failed_solve_rebuilds():
     eta = lam2.rhs.copy()
     assert ok and solver.Solve_PosDef_Blocky(lam2, eta) and rel_inf(eta, x_ref) < TOL
     assert solver.profile().get("schur_gather", (0, 0))[0] == 1
+
+
+@pytest.mark.parametrize("tiles", [-1, 0, 1, 2, 3])
+def test_landmarks_without_observations(tiles):
+    """A landmark nobody sees any more (its block column holds C_p only): dl = C^-1 l, no contribution to S -- on every
+    assembly path."""
+    lam = synth.ba(30, 400, k=3, seed=5)
+    nc = lam.n_matrix_cut
+    off = lam.block_value_offsets()
+    drop = {3, 4, 5, 120, 399}                                    # landmarks whose observations are removed
+    keep_blk = np.ones(lam.n_blocks, dtype=bool)
+    for p in drop:
+        c = nc + p
+        keep_blk[lam.bcol_ptr[c]:lam.bcol_ptr[c + 1] - 1] = False     # all but the diagonal block
+    new_ptr = np.zeros_like(lam.bcol_ptr)
+    new_ptr[1:] = np.cumsum([keep_blk[lam.bcol_ptr[c]:lam.bcol_ptr[c + 1]].sum() for c in range(lam.n_bcols)])
+    vals = np.concatenate([lam.values[off[b]:off[b + 1]] for b in np.nonzero(keep_blk)[0]])
+    cut = synth.BlockSystem(lam.cumsum.copy(), new_ptr, lam.brow_idx[keep_blk].copy(), vals, lam.rhs.copy(), nc)
+    ok, x_ref, _, _ = O.solve_schur(cut)
+    assert ok
+    eta = cut.rhs.copy()
+    assert CLinearSolver_Schur_HIP(schur_tiles=tiles).Solve_PosDef(cut, eta)
+    assert rel_inf(eta, x_ref) < TOL
