@@ -61,6 +61,12 @@ static void Free_Pinned(double *p, bool b_registered)
 
 void slampp_hip_solver::Free_Staging()
 {
+	// registered memory is the caller-side malloc block itself: unlike hipHostFree, unregistering does not wait for copies
+	// that still read it (a handle destroyed right after an asynchronous call: memory access fault at a host address)
+	if(copy_stream)
+		(void)hipStreamSynchronize(copy_stream);
+	if(stream)
+		(void)hipStreamSynchronize(stream);
 	Free_Pinned(p_pin_values, b_pin_values_registered);
 	Free_Pinned(p_pin_rhs, b_pin_rhs_registered);
 	p_pin_values = p_pin_rhs = 0;
@@ -141,6 +147,11 @@ void slampp_hip_solver::Require_Staging()
 		SLAMPP_HIP_CHECK(hipEventCreateWithFlags(&copy_done, hipEventDisableTiming));
 	if(n_pin_values < size_t(n_values) || !p_pin_values)
 		n_uploaded = 0;
+	if((n_pin_values < size_t(n_values) && p_pin_values) || (n_pin_rhs < size_t(n_scalars) && p_pin_rhs)) {
+		(void)hipStreamSynchronize(copy_stream); // a buffer is about to be replaced: no copy may still read it
+		if(stream)
+			(void)hipStreamSynchronize(stream);
+	}
 	Grow_Pinned(p_pin_values, n_pin_values, b_pin_values_registered, size_t(n_values));
 	const double t1 = staging_wall_ms();
 	Grow_Pinned(p_pin_rhs, n_pin_rhs, b_pin_rhs_registered, size_t(n_scalars));
