@@ -505,7 +505,8 @@ static void tiles_enqueue_t(const CSchurTiles &T, const int64_t *ptr, int64_t nc
 		LAUNCH_TILES(4);
 #undef LAUNCH_TILES
 	}
-	hipLaunchKernelGGL((schur_tile_reduce_kernel<DC>), dim3(unsigned(T.n_rb)), dim3(64), 0, stream,
+	if(T.n_rb) // (landmarks nobody observes have no blocks of S to reduce)
+		hipLaunchKernelGGL((schur_tile_reduce_kernel<DC>), dim3(unsigned(T.n_rb)), dim3(64), 0, stream,
 		T.d_rb_ptr.p(), T.d_rb_part.p(), T.d_rb_sb.p(), sb_row, sb_col, T.d_P.p(), T.d_R.p(), S, ld, p_dst, p_r);
 }
 
