@@ -573,6 +573,10 @@ void slampp_hip_solver::Analyze_Sparse()
 	if(n_panel && P.uniform_dim && (P.max_dim == 3 || P.max_dim == 6 || P.max_dim == 7)) {
 		const int n_stages = int(P.stage_ptr.size()) - 1, D = P.max_dim;
 		const int n_slot_cap = panel_slot_cap(D);
+		// the leaf subtrees too, where they are so few that one round of workgroups takes them all: a small system's leaf
+		// stage is all latency, and eight waves on a subtree of four columns beat one (37 -> 19 us on the reduced camera
+		// system of C4; with 1 600 leaf tasks -- 10 000 poses -- the wave-per-task kernel wins again, 0.33 against 0.38 ms)
+		const bool b_leaf_panels = n_stages > 0 && n_simt <= 0 && P.stage_ptr[1] - P.stage_ptr[0] <= 512; // (one round of workgroups)
 		panel_ptr.assign(n_stages + 1, 0);
 		panel_rest_ptr.assign(n_stages + 1, 0);
 		panel_upd_ptr.assign(n_stages + 1, 0);
@@ -581,7 +585,7 @@ void slampp_hip_solver::Analyze_Sparse()
 		std::vector<TPanelCol> pcols;
 		std::vector<TPanelSlot> pslots;
 		for(int s = 0; s < n_stages; ++ s) {
-			for(int t = P.stage_ptr[s]; s >= n_bottom_stages && t < P.stage_ptr[s + 1]; ++ t) {
+			for(int t = P.stage_ptr[s]; (s >= n_bottom_stages || (s == 0 && b_leaf_panels)) && t < P.stage_ptr[s + 1]; ++ t) {
 				const int64_t c_begin = P.task_ptr[t], c_end = P.task_ptr[t + 1];
 				const int n_cols = int(c_end - c_begin);
 				bool b_fits = n_cols >= 1 && n_cols <= int(PANEL_COLS);
@@ -937,6 +941,18 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 					t_rest.task_map = d_simt_rest.p();
 					launch_factor_stage(t_rest, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), simt_rest_ptr[s], n_rest,
 						true, d_flag.p(), stream);
+				}
+			} else if(s == 0 && !panel_ptr.empty() && panel_ptr[1] > panel_ptr[0]) {
+				// few leaf subtrees: as panels (they receive no updates: the update launch just copies Lambda's blocks over)
+				launch_panel_update(P.max_dim, d_panel_upd_slots.p() + panel_upd_ptr[s], panel_upd_ptr[s + 1] - panel_upd_ptr[s],
+					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream);
+				launch_factor_panel(P.max_dim, d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s], panel_ptr[s + 1] - panel_ptr[s],
+					d_L.p(), d_Linv.p(), d_w.p(), d_flag.p(), stream, dplan.p_timing);
+				if(panel_rest_ptr[s + 1] > panel_rest_ptr[s]) {
+					TDevPlan t_rest = dplan;
+					t_rest.task_map = d_panel_rest.p();
+					launch_factor_stage(t_rest, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), panel_rest_ptr[s],
+						panel_rest_ptr[s + 1] - panel_rest_ptr[s], true, d_flag.p(), stream);
 				}
 			} else if(s > 0 && s < n_bottom_stages && dplan.task_pkg)
 				launch_factor_wide(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
