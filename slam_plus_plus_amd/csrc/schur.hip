@@ -958,8 +958,8 @@ static void schur_try_sparse_reduced(slampp_hip_solver &s, CSchurState &S)
 	p_inner->n_simt_width = s.n_simt_width;
 	p_inner->n_simt_stages = s.n_simt_stages;
 	p_inner->n_wide_min_tasks = s.n_wide_min_tasks;
-	if(nc <= 8192) // a small system is all latency: short sequential tasks (measured at 1000 cameras: 0.51 -> 0.43 ms)
-		p_inner->opt.subtree_size = std::min(p_inner->opt.subtree_size, 4);
+	// (a small system is all latency: round 1 cut its leaf subtrees to four columns for the wave-per-task kernel; as panels
+	// -- eight waves per subtree, 2 us per column -- the default of eight is faster again: 0.231 -> 0.220 ms at 1000 cameras)
 	p_inner->cumsum = cumsum;
 	p_inner->bcol_ptr = bcol_ptr;
 	p_inner->brow = brow;
