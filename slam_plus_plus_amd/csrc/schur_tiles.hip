@@ -446,18 +446,31 @@ schur_tile_reduce_kernel(const int64_t *__restrict__ rb_ptr, const int32_t *__re
 	const int64_t sb = rb_sb[i];
 	const int64_t n_row = sb_row[sb], n_col = sb_col[sb];
 	const bool b_block = lane < BB, b_rhs = lane >= BB && lane < BB + DC && n_row == n_col;
-	if(!b_block && !b_rhs)
-		return;
+	// the list's indices 64 at a time with one coalesced load, then eight partial blocks in flight at once (one after
+	// the other a block with 36 partials -- Venice-like visibility -- was 36 dependent round trips: 156 us for that kernel);
+	// the sum is still taken in list order
+	const int n_el = b_block? lane : (b_rhs? lane - BB : 0); // (the other lanes re-read a valid element)
+	const double *p_src = b_block? P : R;
+	const int n_stride = b_block? BB : DC;
 	double f = 0;
-	for(int64_t e = rb_ptr[i], e1 = rb_ptr[i + 1]; e < e1; ++ e) {
-		const int64_t n_part = rb_part[e];
-		f += b_block? P[n_part * BB + lane] : R[n_part * DC + (lane - BB)];
+	for(int64_t e0 = rb_ptr[i], e1 = rb_ptr[i + 1]; e0 < e1; e0 += 64) {
+		const int n_here = int(min(int64_t(64), e1 - e0));
+		const int n_my = rb_part[e0 + min(lane, n_here - 1)];
+		for(int j0 = 0; j0 < n_here; j0 += 8) {
+			double v[8];
+			#pragma unroll
+			for(int u = 0; u < 8; ++ u)
+				v[u] = p_src[int64_t(__builtin_amdgcn_readlane(n_my, min(j0 + u, n_here - 1))) * n_stride + n_el];
+			#pragma unroll
+			for(int u = 0; u < 8; ++ u)
+				f += (j0 + u < n_here)? v[u] : 0.0;
+		}
 	}
 	if(b_block) {
 		const int r = lane % DC, q = lane / DC;
 		const size_t idx = p_dst? size_t(p_dst[sb]) + q + r * DC : size_t(n_row * DC + r) + size_t(n_col * DC + q) * ld;
 		S[idx] -= f;
-	} else {
+	} else if(b_rhs) {
 		const int64_t c = n_row * DC + (lane - BB);
 		if(p_r)
 			p_r[c] -= f;
