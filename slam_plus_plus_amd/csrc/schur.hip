@@ -1003,7 +1003,9 @@ static void schur_assemble_t(slampp_hip_solver &s, CSchurState &S, const double 
 	// some of them fit the tiles -- both: the tiles take theirs, the lists the rest.
 	const CSchurTiles &T = S.tiles;
 	const bool b_tiles = T.b_enabled, b_lists_all = !b_tiles;
-	s.Phase_Begin("schur_points");
+	// (a phase that launches nothing records no events: an event pair costs microseconds of stream time)
+	if(b_lists_all || T.b_hybrid)
+		s.Phase_Begin("schur_points");
 	if(b_lists_all) {
 		hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((S.np + 255) / 256)), dim3(256), 0, st,
 			S.d_ptr.p(), S.nc, S.np, ubase, A, S.d_Cinv.p(), s.d_flag.p(), (const int32_t*)0);
@@ -1016,7 +1018,8 @@ static void schur_assemble_t(slampp_hip_solver &s, CSchurState &S, const double 
 			hipLaunchKernelGGL((schur_obs_W_kernel<DC, DP>), dim3(unsigned((T.n_xobs + 255) / 256)), dim3(256), 0, st,
 				T.n_xobs, ubase, S.d_obs_pt.p(), A, S.d_Cinv.p(), S.d_W.p(), T.d_xcam_obs.p());
 	}
-	s.Phase_End();
+	if(b_lists_all || T.b_hybrid)
+		s.Phase_End();
 
 	if(b_tiles) {
 		s.Phase_Begin("schur_tiles");
@@ -1026,8 +1029,8 @@ static void schur_assemble_t(slampp_hip_solver &s, CSchurState &S, const double 
 		s.Phase_End();
 	}
 
-	s.Phase_Begin("schur_gather");
-	{
+	if((b_lists_all? S.n_sblocks : T.n_xblocks) > 0) {
+		s.Phase_Begin("schur_gather");
 		const int64_t n_lists = b_lists_all? S.n_sblocks : T.n_xblocks, n_list_entries = b_lists_all? S.n_entries : T.n_xentries;
 		const int64_t *p_list_ptr = b_lists_all? S.d_sb_ptr.p() : T.d_xsb_ptr.p();
 		const int32_t *p_list_a = b_lists_all? S.d_ent_a.p() : T.d_xent_a.p(), *p_list_map = b_lists_all? 0 : T.d_xsb_map.p();
@@ -1044,17 +1047,19 @@ static void schur_assemble_t(slampp_hip_solver &s, CSchurState &S, const double 
 					n_lists, p_list_ptr, S.d_sb_row.p(), S.d_sb_col.p(), p_list_a, p_list_uoff, A,
 					S.d_W.p(), p_S, ld, p_sb_dst, p_list_map);
 		}
+		s.Phase_End();
 	}
-	s.Phase_End();
 
-	s.Phase_Begin("schur_rhs");
-	if(!S.tiles.b_enabled) // (the tiles bring the right-hand side's share of their landmarks themselves)
-		hipLaunchKernelGGL((schur_rhs_kernel<DC, DP>), dim3(unsigned(S.nc)), dim3(64), 0, st,
-			S.d_cam_ptr.p(), S.d_cam_obs.p(), S.d_obs_pt.p(), n, S.d_W.p(), rhs, p_S, ld, p_r);
-	else if(S.tiles.b_hybrid)
-		hipLaunchKernelGGL((schur_rhs_kernel<DC, DP>), dim3(unsigned(S.nc)), dim3(64), 0, st,
-			S.tiles.d_xcam_ptr.p(), S.tiles.d_xcam_obs.p(), S.d_obs_pt.p(), n, S.d_W.p(), rhs, p_S, ld, p_r);
-	s.Phase_End();
+	if(!S.tiles.b_enabled || S.tiles.b_hybrid) { // (the tiles bring the right-hand side's share of their landmarks themselves)
+		s.Phase_Begin("schur_rhs");
+		if(!S.tiles.b_enabled)
+			hipLaunchKernelGGL((schur_rhs_kernel<DC, DP>), dim3(unsigned(S.nc)), dim3(64), 0, st,
+				S.d_cam_ptr.p(), S.d_cam_obs.p(), S.d_obs_pt.p(), n, S.d_W.p(), rhs, p_S, ld, p_r);
+		else
+			hipLaunchKernelGGL((schur_rhs_kernel<DC, DP>), dim3(unsigned(S.nc)), dim3(64), 0, st,
+				S.tiles.d_xcam_ptr.p(), S.tiles.d_xcam_obs.p(), S.d_obs_pt.p(), n, S.d_W.p(), rhs, p_S, ld, p_r);
+		s.Phase_End();
+	}
 }
 
 template <int DC, int DP>

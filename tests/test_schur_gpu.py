@@ -548,15 +548,21 @@ def test_incremental_update_of_the_reduced_system_matches_full_recomputation(mod
         eta = lam.rhs.copy()
         assert solver.Solve_PosDef_Blocky(lam, eta)
         phases = solver.profile()
-        assert phases.get("schur_update", (0, 0))[0] == 1 and phases.get("schur_gather", (0, 0))[0] == 0   # it was an update
+        assert phases.get("schur_update", (0, 0))[0] == 1 and _rebuilds(phases) == 0   # it was an update
         assert rel_inf(eta, x_ref) < TOL, n_changed
     # without a list the next solve rebuilds; with the option off the call is refused
     eta = lam.rhs.copy()
     solver.profile(reset=True)
-    assert solver.Solve_PosDef_Blocky(lam, eta) and solver.profile().get("schur_gather", (0, 0))[0] == 1
+    assert solver.Solve_PosDef_Blocky(lam, eta) and _rebuilds(solver.profile()) == 1
     assert rel_inf(eta, x_ref) < TOL
     with pytest.raises(ValueError):
         CLinearSolver_Schur_HIP().Set_Changed_Landmarks([0])
+
+
+def _rebuilds(phases):
+    """How many full assemblies of the reduced system a profile holds: landmark-major (schur_tiles), from the contribution
+    lists (schur_gather), or both for one assembly when some landmarks fit neither runs nor tiles."""
+    return max(phases.get("schur_tiles", (0, 0))[0], phases.get("schur_gather", (0, 0))[0])
 
 
 def test_incremental_update_after_a_failed_solve_rebuilds():
@@ -578,7 +584,7 @@ def test_incremental_update_after_a_failed_solve_rebuilds():
     solver.Set_Changed_Landmarks([3, 4])
     eta = lam2.rhs.copy()
     assert ok and solver.Solve_PosDef_Blocky(lam2, eta) and rel_inf(eta, x_ref) < TOL
-    assert solver.profile().get("schur_gather", (0, 0))[0] == 1
+    assert _rebuilds(solver.profile()) == 1
 
 
 @pytest.mark.parametrize("tiles", [-1, 0, 1, 2, 3])
