@@ -225,7 +225,7 @@ def run_c3(args, rank, world, local_rank, dist):
         solver.factor_solve_device_async(vals.data_ptr(), bufs[k].data_ptr())
     if not solver.sync():
         raise SystemExit("warm-up solve failed: not positive definite")
-    solver.set_option("profile", 1)
+    solver.set_option("profile", 3)      # one event pair in the timed region: around the leaf kernel, the roofline's
     solver.profile(reset=True)
     torch.cuda.synchronize()
     if world > 1:
@@ -250,9 +250,9 @@ def run_c3(args, rank, world, local_rank, dist):
     x = bufs[-1].cpu().numpy()
     resid = float(np.abs(lam.to_scipy() @ x - lam.rhs).max() / np.abs(lam.rhs).max())
     ms_per_step = dt / args.steps * 1e3
-    prof = solver.profile()          # timed region: leaf kernel | rest of the factorization | backward (three event pairs)
-    # the finer split of the table below comes from a few extra, untimed steps: every event pair between two kernels
-    # costs microseconds, and the timed region should carry as few as the roofline needs
+    prof = solver.profile()          # timed region: one event pair, around the leaf kernel (option profile = 3)
+    # the split of the table below comes from a few extra, untimed steps: every event pair between two kernels costs
+    # microseconds of stream time, and the timed region carries only the one the roofline needs
     solver.set_option("profile", 2)
     solver.profile(reset=True)
     extra = [rhs0.clone() for _ in range(5)]
@@ -260,9 +260,9 @@ def run_c3(args, rank, world, local_rank, dist):
         solver.factor_solve_device_async(vals.data_ptr(), t_.data_ptr())
     solver.sync()
     prof_fine = solver.profile()
-    solver.set_option("profile", 1)
+    solver.set_option("profile", 3)
     solver.profile(reset=True)
-    prof = dict(prof_fine, **{k_: v_ for k_, v_ in prof.items() if k_ in ("factor_leaves", "backward")})
+    prof = dict(prof_fine, **{k_: v_ for k_, v_ in prof.items() if k_ in ("factor_leaves",)})
     n_stages, n_bottom = stats["n_stages"], stats["n_bottom_stages"]
     kb = per_kernel_bytes_sparse(solver.plan(), n_bottom)
     # the separator stages are two launches each: the updates from earlier stages (one workgroup per factor block), then the
@@ -284,7 +284,7 @@ def run_c3(args, rank, world, local_rank, dist):
                         "avg_launch_us": per_step_ms / launches[ph] * 1e3,
                         "algorithmic_bytes_per_launch": kb[ph] / launches[ph],
                         "achieved_GBs": kb[ph] / (per_step_ms * 1e-3) / 1e9,
-                        "timed_in": "timed region" if ph in ("factor_leaves", "backward") else "5 extra steps after it",
+                        "timed_in": "timed region" if ph == "factor_leaves" else "5 extra steps after it",
                         "hbm_traffic_bytes_per_launch": kernel_traffic(traffic, needles[ph]) if isinstance(needles[ph], str) else
                         (lambda parts: (sum(parts) / len(parts)) if all(p is not None for p in parts) else None)(
                             [kernel_traffic(traffic, n_) for n_ in needles[ph]])})
@@ -649,7 +649,7 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
         solver.factor_solve_device_async(vals.data_ptr(), bufs[i].data_ptr())
     if not solver.sync():
         raise SystemExit("BA warm-up solve failed")
-    solver.set_option("profile", 1)
+    solver.set_option("profile", 3)      # event pairs only around the kernels the rooflines are about
     solver.profile(reset=True)
     torch.cuda.synchronize()
     if world > 1:
@@ -677,6 +677,17 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
     schur_flops = n_pts * 58.0 + 108.0 * n_obs + 216.0 * st["n_update_pairs"] + 3 * 2.0 * 18 * n_obs
     dense_flops = st["factor_flops"] + st["solve_flops"]
     prof = {k_: v[1] / max(v[0], 1) for k_, v in solver.profile().items()}
+    # the other phases from three extra, untimed steps with every phase bracketed (an event pair costs microseconds)
+    solver.set_option("profile", 1)
+    solver.profile(reset=True)
+    extra_rhs = [torch.from_numpy(lam.rhs).to(dev) for _ in range(3)]
+    torch.cuda.synchronize()
+    for t_ in extra_rhs:
+        solver.factor_solve_device_async(vals.data_ptr(), t_.data_ptr())
+    solver.sync()
+    del extra_rhs
+    prof = dict({k_: v[1] / max(v[0], 1) for k_, v in solver.profile().items()}, **prof)
+    solver.profile(reset=True)
     b_dense = "dense_chol" in prof
     # the dense factor is redundant on every rank: counted once; with the sparse reduced solve its (much smaller) flop
     # count is not known here and is left out

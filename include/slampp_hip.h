@@ -76,7 +76,7 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
  * one dense matrix on the matrix cores; default: 24, or 16 / 36 where a model of the dependent launch chain clearly
  * prefers that; setting the option fixes the threshold; 0 = off), "dense_top_max_dim" (cap on its dimension, default 12288),
  * "dense_top_min_dim" (below this dimension there is no dense top, default 192),
- * "profile" (0 / 1 / 2, see slampp_hip_get_profile), "shard_primary" (multi-GPU BA: this rank adds A and eta_x),
+ * "profile" (0 / 1 / 2 / 3, see slampp_hip_get_profile), "shard_primary" (multi-GPU BA: this rank adds A and eta_x),
  * "shard_rank" / "shard_world" (multi-GPU BA, optional: who this rank is among the ranks behind the all-reduce
  * callback; lets them exchange their block lists, which scales with the nonzero blocks of S, instead of an indicator
  * over all camera pairs, which is limited to 16384 cameras),
@@ -212,7 +212,10 @@ int slampp_hip_get_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_
  * phase timers, LinearSolver_Schur.h:1681-1912, Timer.h:391): with option "profile" = 1 every phase
  * of factor_solve is bracketed by HIP events on the solver's stream; the totals are collected at
  * slampp_hip_sync().  Phases: factor_leaves, factor_rest (with "profile" = 2: factor_wide, factor_upper), forward, backward (sparse path);
- * schur_points, schur_gather, schur_rhs, dense_chol, dense_solve, backsubst (Schur path). */
+ * schur_init, schur_tiles (the landmark-major assembly) and / or schur_points, schur_gather, schur_rhs (contribution lists),
+ * reduced_sparse or dense_chol + dense_solve, backsubst (Schur path); a phase that launches nothing is left out.
+ * An event pair costs microseconds of stream time: "profile" = 3 keeps only the phase of the kernel that moves most of a
+ * step's bytes or flops (factor_leaves; schur_tiles / schur_gather; dense_chol) -- what a timed region should carry. */
 typedef struct slampp_hip_phase_time {
 	char name[32];
 	int64_t n_count;      /* times the phase ran */

@@ -313,6 +313,14 @@ void slampp_hip_solver::Phase_Begin(const char *p_s_label)
 {
 	if(!b_profile)
 		return;
+	if(b_profile == 3) { // only the phases of the kernels that move a step's bytes / flops: one event pair in a timed region
+		static const char *p_kept[] = {"factor_leaves", "schur_tiles", "schur_gather", "dense_chol"};
+		bool b_kept = false;
+		for(size_t i = 0; i < sizeof(p_kept) / sizeof(p_kept[0]); ++ i)
+			b_kept = b_kept || !strcmp(p_s_label, p_kept[i]);
+		if(!b_kept)
+			return;
+	}
 	int n_label = -1;
 	for(size_t i = 0; i < phase_names.size(); ++ i) {
 		if(phase_names[i] == p_s_label)
@@ -1178,7 +1186,7 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 	else if(s == "simt_stages" && n_value >= 0)
 		p_solver->n_simt_stages = int(n_value);
 	else if(s == "profile") {
-		p_solver->b_profile = int(n_value); // 0 = off, 1 = phases, 2 = the factorization split further (every event pair costs microseconds)
+		p_solver->b_profile = int(n_value); // 0 = off, 1 = phases, 2 = the factorization split further (every event pair costs microseconds), 3 = only the phase of the dominant kernel
 		return SLAMPP_HIP_OK; // does not invalidate the analysis
 	}
 	else
