@@ -4,14 +4,18 @@
 //
 // The contribution lists of schur.hip read 288 bytes per (landmark, camera pair): a landmark seen by k cameras is read
 // k (k + 1) / 2 times -- 1.44 GB at C4 for 0.58 GB of blocks, and the list kernel ran at the HBM traffic those re-reads
-// generate.  Here every landmark is read once.  Landmarks are sorted by their first two cameras and cut into *tiles*
-// whose landmarks touch at most SCHUR_TILE_SLOTS distinct blocks of S; one wave owns a tile, keeps those blocks (and the
-// right-hand sides of their cameras) in LDS, and for each of its landmarks loads [U_1 .. U_k | C | l], inverts C,
-// forms W = U C^-1 and adds the k (k + 1) / 2 products U_b W_a^T into its LDS blocks -- one lane per (camera pair, row).
-// The tile's blocks then go to a partial array, and a second kernel sums the partials of every block of S in list order:
-// no atomics on memory, the sum order is fixed by the analysis (bit-reproducible, like the lists).
-// Landmarks with more cameras than a tile has room for, and tiles whose landmarks share too little (fewer than three
-// contributions per block: random visibility), stay with the contribution lists.
+// generate.  Here every landmark is read once, by one of two kernels the host analysis (schur_tiles_build) picks:
+//   runs   landmarks seen by exactly the same cameras (at least four of them): their products all land in the same blocks
+//          of S, so a wave keeps the sums in matrix-core accumulators for a whole piece of the run (schur_run_kernel);
+//   tiles  the other landmarks, sorted by their first two cameras and cut where they touch more than SCHUR_TILE_SLOTS
+//          distinct blocks of S: a wave keeps a tile's blocks (and the right-hand sides of its cameras) in LDS and adds
+//          every landmark's k (k + 1) / 2 products U_b W_a^T into them, one lane per (camera pair, row) (schur_tile_kernel).
+// Either way the landmark's record [U_1 .. U_k | C | l] is loaded, C inverted, W = U C^-1 formed on the fly; the sums go
+// to a partial array, and a last kernel adds up the partial blocks of every block of S in list order: no atomics on
+// memory, the sum order is fixed by the analysis (bit-reproducible, like the lists).
+// Landmarks with more cameras than a tile has room for that are in no run, and tiles whose landmarks share too little
+// (fewer than three contributions per block: random visibility), stay with the contribution lists.
+// SLAMPP_TILE_POINTS / SLAMPP_RUN_PIECE (environment) are development knobs for the landmarks per tile / per run piece.
 #include "schur_tiles.h"
 
 #include <algorithm>
