@@ -24,11 +24,19 @@
 #include "schur_tiles.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace slampp {
 
 #include "schur_device.inl"
+
+static double schur_wall_ms()
+{
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 struct CSchurState {
 	int DC, DP;
@@ -181,6 +189,10 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 		if(S.n_obs > INT32_MAX)
 			throw std::domain_error("Schur path: too many observations");
 
+		const bool b_timing = getenv("SLAMPP_HIP_PLAN_TIMING") != 0;
+		double t_phase = schur_wall_ms();
+#define SCHUR_SETUP_PHASE(name) do { if(b_timing) { const double t_ = schur_wall_ms(); \
+		fprintf(stderr, "[schur setup] %-20s %8.2f ms\n", name, t_ - t_phase); t_phase = t_; } } while(0)
 		std::vector<int32_t> obs_pt(S.n_obs), obs_cam(S.n_obs);
 		std::vector<int64_t> cam_ptr(nc + 1, 0);
 		for(int64_t pt = 0; pt < np; ++ pt) {
@@ -200,11 +212,13 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 			for(int64_t o = 0; o < S.n_obs; ++ o)
 				cam_obs[fill[obs_cam[o]] ++] = int32_t(o);
 		}
+		SCHUR_SETUP_PHASE("observation lists");
 		// contributions to S grouped by block (row = camera of b, col = camera of a, a <= b within a point)
 		const int64_t ubase = S.n_ablocks * DC * DC;
 		std::vector<int64_t> sb_ptr;
 		std::vector<int32_t> sb_row, sb_col, ent_a;
 		std::vector<int64_t> ent_uoff;
+		bool b_tiles_built = false;
 		{
 			int64_t n_entries = 0;
 			for(int64_t pt = 0; pt < np; ++ pt) {
@@ -212,8 +226,6 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 				n_entries += k * (k + 1) / 2;
 			}
 			S.n_entries = n_entries;
-			ent_a.resize(n_entries);
-			ent_uoff.resize(n_entries);
 			if(nc * nc <= (int64_t(1) << 26)) { // counting sort on the dense key space
 				std::vector<int64_t> cnt(nc * nc + 1, 0);
 				for(int64_t pt = 0; pt < np; ++ pt) {
@@ -231,16 +243,28 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 					cnt[key + 1] += cnt[key];
 				}
 				sb_ptr.push_back(n_entries);
-				for(int64_t pt = 0; pt < np; ++ pt) {
-					const int64_t o0 = ptr[nc + pt] - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
-					for(int64_t a = o0; a < o1; ++ a)
-						for(int64_t b = a; b < o1; ++ b) {
-							const int64_t d = cnt[int64_t(obs_cam[a]) * nc + obs_cam[b]] ++;
-							ent_a[d] = int32_t(a);
-							ent_uoff[d] = ubase + b * DC * DP + pt * DP * DP;
-						}
+				SCHUR_SETUP_PHASE("blocks of S");
+				// the blocks of S are known: can the landmarks be taken one by one (schur_tiles.hip)?  Then the per-block
+				// contribution lists -- 12 bytes and a scattered write per contribution -- are not needed at all
+				schur_tiles_build(S.tiles, s.n_schur_tiles, int(DC), int(DP), nc, np, ptr, brow, sb_row, sb_col, S.n_ablocks, s.stream);
+				b_tiles_built = true;
+				SCHUR_SETUP_PHASE("runs and tiles");
+				if(!S.tiles.b_enabled) {
+					ent_a.resize(n_entries);
+					ent_uoff.resize(n_entries);
+					for(int64_t pt = 0; pt < np; ++ pt) {
+						const int64_t o0 = ptr[nc + pt] - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
+						for(int64_t a = o0; a < o1; ++ a)
+							for(int64_t b = a; b < o1; ++ b) {
+								const int64_t d = cnt[int64_t(obs_cam[a]) * nc + obs_cam[b]] ++;
+								ent_a[d] = int32_t(a);
+								ent_uoff[d] = ubase + b * DC * DP + pt * DP * DP;
+							}
+					}
 				}
 			} else { // comparison sort on (key, a, b)
+				ent_a.resize(n_entries);
+				ent_uoff.resize(n_entries);
 				struct TE { int64_t key; int32_t a, b; };
 				std::vector<TE> ents(n_entries);
 				int64_t e = 0;
@@ -278,8 +302,11 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 			}
 		}
 
+		SCHUR_SETUP_PHASE("contribution lists");
 		hipStream_t st = s.stream;
-		schur_tiles_build(S.tiles, s.n_schur_tiles, int(DC), int(DP), nc, np, ptr, brow, sb_row, sb_col, S.n_ablocks, st);
+		if(!b_tiles_built)
+			schur_tiles_build(S.tiles, s.n_schur_tiles, int(DC), int(DP), nc, np, ptr, brow, sb_row, sb_col, S.n_ablocks, st);
+		SCHUR_SETUP_PHASE("runs and tiles");
 		S.d_ptr.Upload(s.bcol_ptr, st);
 		S.d_brow.Upload(s.brow, st);
 		S.d_obs_pt.Upload(obs_pt, st);
@@ -296,6 +323,8 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 		s.d_flag.Alloc(1);
 		SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), s.stream)); // sync() before the first factorization reads it
 		SLAMPP_HIP_CHECK(hipStreamSynchronize(st));
+		SCHUR_SETUP_PHASE("uploads");
+#undef SCHUR_SETUP_PHASE
 	} catch(...) {
 		delete p;
 		throw;

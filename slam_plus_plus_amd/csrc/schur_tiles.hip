@@ -872,11 +872,25 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 	std::vector<int64_t> sb_keys(n_sblocks);
 	for(int64_t i = 0; i < n_sblocks; ++ i)
 		sb_keys[i] = int64_t(sb_col[i]) * nc + sb_row[i];
+	// (a table over all camera pairs where that is small: a binary search per partial block and per contribution of the
+	// list landmarks was a third of the analysis of the Venice-like leg)
+	std::vector<int32_t> key_sb;
+	if(nc * nc <= (int64_t(1) << 24)) {
+		key_sb.assign(size_t(nc * nc), -1);
+		for(int64_t i = 0; i < n_sblocks; ++ i)
+			key_sb[sb_keys[i]] = int32_t(i);
+	}
+	auto Block_Of = [&](int64_t n_key) -> size_t {
+		if(!key_sb.empty())
+			return (key_sb[n_key] >= 0)? size_t(key_sb[n_key]) : sb_keys.size();
+		const size_t k = size_t(std::lower_bound(sb_keys.begin(), sb_keys.end(), n_key) - sb_keys.begin());
+		return (k < sb_keys.size() && sb_keys[k] == n_key)? k : sb_keys.size();
+	};
 	std::vector<int32_t> slot_sb(n_slots);
 	std::vector<int64_t> sb_cnt(n_sblocks + 1, 0);
 	for(int64_t g = 0; g < n_slots; ++ g) {
-		const size_t k = size_t(std::lower_bound(sb_keys.begin(), sb_keys.end(), slot_key[g]) - sb_keys.begin());
-		if(k == sb_keys.size() || sb_keys[k] != slot_key[g])
+		const size_t k = Block_Of(slot_key[g]);
+		if(k == sb_keys.size())
 			throw std::logic_error("reduced camera system: a partial block is not in the block list");
 		slot_sb[g] = int32_t(k);
 		++ sb_cnt[k + 1];
@@ -936,7 +950,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 				++ xcam_ptr[brow[k0 + (a - o0)] + 1];
 				for(int64_t b = a; b < o1; ++ b) {
 					const int64_t key = int64_t(brow[k0 + (a - o0)]) * nc + brow[k0 + (b - o0)];
-					const size_t k = size_t(std::lower_bound(sb_keys.begin(), sb_keys.end(), key) - sb_keys.begin());
+					const size_t k = Block_Of(key);
 					TE e;
 					e.sb = int32_t(k);
 					e.a = int32_t(a);
