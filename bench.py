@@ -668,16 +668,9 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
         dt = float(t.item())
     if not ok:
         raise SystemExit("BA solve failed: not positive definite")
-    if rank != 0:
-        return None
-    ms = dt / steps * 1e3
-    n_obs, n_pts, N = st["n_observations"], st["n_points"], st["schur_dim"]
-    # SURVEY.md section 8d: per point with k observations 58 + 108 k + 216 k (k + 1) / 2 flops for the Schur
-    # products, 2 flops per stored scalar of U for each of the 3 SpMV passes, n^3/3 + ... for the dense factor
-    schur_flops = n_pts * 58.0 + 108.0 * n_obs + 216.0 * st["n_update_pairs"] + 3 * 2.0 * 18 * n_obs
-    dense_flops = st["factor_flops"] + st["solve_flops"]
-    prof = {k_: v[1] / max(v[0], 1) for k_, v in solver.profile().items()}
-    # the other phases from three extra, untimed steps with every phase bracketed (an event pair costs microseconds)
+    prof = {k_: v[1] / max(v[0], 1) for k_, v in solver.profile().items()}   # timed region: the roofline kernels' phases
+    # the other phases from three extra, untimed steps with every phase bracketed (an event pair costs microseconds);
+    # every rank runs them: the solve holds a collective
     solver.set_option("profile", 1)
     solver.profile(reset=True)
     extra_rhs = [torch.from_numpy(lam.rhs).to(dev) for _ in range(3)]
@@ -688,6 +681,14 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
     del extra_rhs
     prof = dict({k_: v[1] / max(v[0], 1) for k_, v in solver.profile().items()}, **prof)
     solver.profile(reset=True)
+    if rank != 0:
+        return None
+    ms = dt / steps * 1e3
+    n_obs, n_pts, N = st["n_observations"], st["n_points"], st["schur_dim"]
+    # SURVEY.md section 8d: per point with k observations 58 + 108 k + 216 k (k + 1) / 2 flops for the Schur
+    # products, 2 flops per stored scalar of U for each of the 3 SpMV passes, n^3/3 + ... for the dense factor
+    schur_flops = n_pts * 58.0 + 108.0 * n_obs + 216.0 * st["n_update_pairs"] + 3 * 2.0 * 18 * n_obs
+    dense_flops = st["factor_flops"] + st["solve_flops"]
     b_dense = "dense_chol" in prof
     # the dense factor is redundant on every rank: counted once; with the sparse reduced solve its (much smaller) flop
     # count is not known here and is left out
