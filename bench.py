@@ -707,7 +707,8 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
         tf = st["factor_flops"] / (prof["dense_chol"] * 1e-3) / 1e12
         n_panels = (N + 1 + 63) // 64
         tr = None
-        if traffic:   # HBM bytes of the whole factorization = sum over its three kernels of launches x bytes per launch
+        if traffic and all(any(k_ in n for n in traffic) for k_ in ("potrf_diag_kernel", "trsm_kernel", "syrk_kernel")):
+            # HBM bytes of the whole factorization = sum over its three kernels of launches x bytes per launch
             tr = sum((kernel_traffic(traffic, k_) or 0.0) * traffic[[n for n in traffic if k_ in n][0]]["launches"]
                      for k_ in ("potrf_diag_kernel", "trsm_kernel", "syrk_kernel")) / \
                 max(traffic[[n for n in traffic if "potrf_diag_kernel" in n][0]]["launches"] / n_panels, 1)
