@@ -907,12 +907,6 @@ static void schur_agree_on_union(slampp_hip_solver &s, CSchurState &S)
 	SLAMPP_HIP_CHECK(hipStreamSynchronize(st)); // un_row / un_col live on this stack frame
 }
 
-__global__ void schur_merge_flag_kernel(const int *p_from, int *p_to)
-{
-	if(*p_from)
-		atomicOr(p_to, *p_from);
-}
-
 // Landmark shards: a rank whose own landmarks gave a C_p that is not positive definite must not be the only one to
 // return false (the others would carry on into the next collective without it).  The status travels with the data:
 // that rank poisons the first entry of its partial reduced right-hand side before the exchange, and every rank looks
@@ -1218,8 +1212,8 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 	const double *p_dx;
 	if(b_sparse) {
 		s.Phase_Begin("reduced_sparse");
+		S.p_inner->p_flag_shared = s.d_flag.p();
 		S.p_inner->Enqueue_Sparse(p_S, p_r, true); // p_r: the reduced right-hand side on entry, dx on return
-		hipLaunchKernelGGL(schur_merge_flag_kernel, dim3(1), dim3(1), 0, st, S.p_inner->d_flag.p(), s.d_flag.p());
 		s.Phase_End();
 		p_dx = p_r;
 	} else {
@@ -1374,8 +1368,8 @@ static void schur_enqueue_marginals_sparse_t(slampp_hip_solver &s, CSchurState &
 		s.Phase_End();
 	}
 	s.Phase_Begin("marginals_factor");
+	S.p_inner->p_flag_shared = s.d_flag.p();
 	S.p_inner->Enqueue_Sparse(p_S, p_r, true, true); // numeric factorization only
-	hipLaunchKernelGGL(schur_merge_flag_kernel, dim3(1), dim3(1), 0, st, S.p_inner->d_flag.p(), s.d_flag.p());
 	s.Phase_End();
 	s.Phase_Begin("marginals_inverse");
 	sparse_inverse_enqueue(*S.p_sinv, S.p_inner->plan, S.p_inner->d_L.p(), S.p_inner->d_Linv.p(), S.d_m_Zs.p(), st);

@@ -154,6 +154,7 @@ struct slampp_hip_solver {
 	slampp::CDevArray<int64_t> d_damp_off; // (offset of the diagonal block's first element, dimension) per block column: apply_damping
 	bool b_damp_valid = false;
 	slampp::CDevArray<int> d_flag;
+	int *p_flag_shared = 0; // the reduced camera system's solver: the not-positive-definite flag of the solver it serves (not zeroed here)
 	int *p_host_flag; // pinned
 
 	// host entry points: pinned staging for Lambda's values and the right-hand side, a copy stream for the uploads

@@ -923,9 +923,11 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 {
 	const Plan &P = plan;
 	const int n_stages = int(P.stage_ptr.size()) - 1;
+	int *p_flag = p_flag_shared? p_flag_shared : d_flag.p(); // (the inner solver of a Schur solve reports into the outer one's flag)
 	if(b_factor) {
 		// numeric factorization with the forward substitution fused in
-		SLAMPP_HIP_CHECK(hipMemsetAsync(d_flag.p(), 0, sizeof(int), stream));
+		if(!p_flag_shared)
+			SLAMPP_HIP_CHECK(hipMemsetAsync(d_flag.p(), 0, sizeof(int), stream));
 		// the lane-per-task kernel reads blocks and vectors with 16-byte loads where the block dimension is even
 		const bool b_simt = !simt_chunk_ptr.empty() && (P.max_dim % 2 != 0 ||
 			((reinterpret_cast<uintptr_t>(p_values_dev) | reinterpret_cast<uintptr_t>(p_rhs_dev)) & 15) == 0);
@@ -943,44 +945,44 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			if(b_simt && s + 1 < int(simt_chunk_ptr.size())) {
 				const int n_chunks = simt_chunk_ptr[s + 1] - simt_chunk_ptr[s], n_rest = simt_rest_ptr[s + 1] - simt_rest_ptr[s];
 				launch_factor_simt(d_simt_chunks.p() + simt_chunk_ptr[s], n_chunks, n_simt_width, simt_lds_bytes[s], d_simt_prog.p(), d_simt_tab.p(), P.max_dim,
-					p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), d_flag.p(), stream, dplan.p_timing);
+					p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), p_flag, stream, dplan.p_timing);
 				if(n_rest > 0) {
 					TDevPlan t_rest = dplan;
 					t_rest.task_map = d_simt_rest.p();
 					launch_factor_stage(t_rest, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), simt_rest_ptr[s], n_rest,
-						true, d_flag.p(), stream);
+						true, p_flag, stream);
 				}
 			} else if(s == 0 && !panel_ptr.empty() && panel_ptr[1] > panel_ptr[0]) {
 				// few leaf subtrees: as panels (they receive no updates: the update launch just copies Lambda's blocks over)
 				launch_panel_update(P.max_dim, d_panel_upd_slots.p() + panel_upd_ptr[s], panel_upd_ptr[s + 1] - panel_upd_ptr[s],
 					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream);
 				launch_factor_panel(P.max_dim, d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s], panel_ptr[s + 1] - panel_ptr[s],
-					d_L.p(), d_Linv.p(), d_w.p(), d_flag.p(), stream, dplan.p_timing);
+					d_L.p(), d_Linv.p(), d_w.p(), p_flag, stream, dplan.p_timing);
 				if(panel_rest_ptr[s + 1] > panel_rest_ptr[s]) {
 					TDevPlan t_rest = dplan;
 					t_rest.task_map = d_panel_rest.p();
 					launch_factor_stage(t_rest, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), panel_rest_ptr[s],
-						panel_rest_ptr[s + 1] - panel_rest_ptr[s], true, d_flag.p(), stream);
+						panel_rest_ptr[s + 1] - panel_rest_ptr[s], true, p_flag, stream);
 				}
 			} else if(s > 0 && s < n_bottom_stages && dplan.task_pkg)
 				launch_factor_wide(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
-					P.stage_ptr[s + 1] - P.stage_ptr[s], d_flag.p(), stream);
+					P.stage_ptr[s + 1] - P.stage_ptr[s], p_flag, stream);
 			else if(s >= n_bottom_stages && !panel_ptr.empty()) {
 				// separators: as panels in LDS where they fit (the updates from earlier stages first, spread over the chip),
 				// column by column otherwise
 				launch_panel_update(P.max_dim, d_panel_upd_slots.p() + panel_upd_ptr[s], panel_upd_ptr[s + 1] - panel_upd_ptr[s],
 					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream);
 				launch_factor_panel(P.max_dim, d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s], panel_ptr[s + 1] - panel_ptr[s],
-					d_L.p(), d_Linv.p(), d_w.p(), d_flag.p(), stream, dplan.p_timing);
+					d_L.p(), d_Linv.p(), d_w.p(), p_flag, stream, dplan.p_timing);
 				if(panel_rest_ptr[s + 1] > panel_rest_ptr[s]) {
 					TDevPlan t_rest = dplan;
 					t_rest.task_map = d_panel_rest.p();
 					launch_factor_stage(t_rest, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), panel_rest_ptr[s],
-						panel_rest_ptr[s + 1] - panel_rest_ptr[s], false, d_flag.p(), stream);
+						panel_rest_ptr[s + 1] - panel_rest_ptr[s], false, p_flag, stream);
 				}
 			} else
 			launch_factor_stage(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
-				P.stage_ptr[s + 1] - P.stage_ptr[s], s < n_bottom_stages, d_flag.p(), stream);
+				P.stage_ptr[s + 1] - P.stage_ptr[s], s < n_bottom_stages, p_flag, stream);
 			if(s == 0 || (s == n_wide_end - 1 && b_profile >= 2) || s == n_stages - 1)
 				Phase_End();
 		}
@@ -1009,9 +1011,9 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			Phase_End();
 			Phase_Begin("dense_chol");
 			if(b_dense_tiles)
-				tile_cholesky(dense_tiles, d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), d_flag.p(), stream);
+				tile_cholesky(dense_tiles, d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), p_flag, stream);
 			else
-				dense_cholesky(d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), d_flag.p(), stream);
+				dense_cholesky(d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), p_flag, stream);
 			Phase_End();
 		} else {
 			Phase_Begin("dense_forward");
