@@ -26,19 +26,114 @@ namespace slampp {
 
 #include "sparse_device.inl"
 
-template <int D, int CAP_BLK>
-__global__ void __launch_bounds__(64 * PANEL_W)
-factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict__ pkg_off, double *L, double *Linv, double *w,
-	int *p_flag, long long *p_timing)
+// the updates of one factor block from stages further down: wave v of the n_waves waves that share the block takes the
+// entries v * BATCH .., (v + n_waves) * BATCH .., both operand blocks fetched whole, all requests of a batch before the
+// first product; the partial sums are added up in wave order (s_part), and the block goes out as Lambda - sum (a
+// diagonal block with its right-hand side b - sum).  Every wave of the workgroup must call it (one barrier inside).
+template <int D, int BATCH>
+__device__ __forceinline__ void panel_update_block(const TUpdSlot &sl, bool b_valid, const TUpdEnt *__restrict__ ents,
+	const double *__restrict__ A, double *L, const double *__restrict__ b, double *w, int n_sub_wave, int n_waves, int lane,
+	double *s_ops /* this wave's 2 BATCH blocks */, double *s_yv /* this wave's 8 BATCH doubles */, double *s_part /* the block's n_waves x 64 */)
 {
-	enum { W = PANEL_W, DD = D * D };
-	__shared__ longlong2 s_pkg[PANEL_UNITS];
-	__shared__ double s_L[CAP_BLK * DD];
-	__shared__ double s_w[PANEL_COLS * 8];
-	__shared__ double s_linv[64];
-	__shared__ double s_tile[W][64];
-	static_assert(64 * W <= PANEL_UNITS, "one speculative unit per thread");
+	enum { DD = D * D };
+	const TLaneMap mm = lane_map(lane, D, D);
+	const bool b_diag = sl.kind != 0;
+	const bool b_y = b_diag && lane >= Y_LANE0 && lane < Y_LANE0 + D;
+	const int yq = b_y? lane - Y_LANE0 : mm.q;
+	double init = 0; // Lambda's element (requested now, used last)
+	if(b_valid && n_sub_wave == 0)
+		init = b_y? b[sl.cs_src + yq] : (mm.b_act? lambda_element(A, sl.asrc, mm.r, mm.q, D, D, false) : 0.0);
+	double sum = 0;
+	const TUpdEnt *p_ent = ents + sl.e0;
+	const int ne = b_valid? sl.ne : 0;
+	for(int e0 = n_sub_wave * BATCH; e0 < ne; e0 += n_waves * BATCH) {
+		const int n_here = min(int(BATCH), ne - e0);
+		double va[BATCH], vb[BATCH];
+		#pragma unroll
+		for(int u = 0; u < BATCH; ++ u) {
+			const TUpdEnt en = p_ent[e0 + min(u, n_here - 1)]; // the tail repeats the last entry: its product is skipped below
+			va[u] = L[en.a_off + (mm.b_act? lane : 0)];
+			// the other operand: the block L(j,c) of a pair; for a row entry y_c in the right-hand side lanes (one load, the
+			// lane picks its address: a load behind a branch would wait for the others)
+			const double *p_other = b_diag? w + en.b_off + (b_y? yq : 0) : L + en.b_off + (mm.b_act? lane : 0);
+			vb[u] = *p_other;
+		}
+		#pragma unroll
+		for(int u = 0; u < BATCH; ++ u) {
+			if(mm.b_act) {
+				s_ops[(2 * u) * DD + lane] = va[u];
+				if(!b_diag)
+					s_ops[(2 * u + 1) * DD + lane] = vb[u];
+			}
+			if(b_y)
+				s_yv[u * 8 + yq] = vb[u];
+		}
+		wave_sync();
+		#pragma unroll
+		for(int u = 0; u < BATCH; ++ u) {
+			if(u < n_here) { // wave-uniform
+				const double *pa = b_y? s_yv + u * 8 : s_ops + (2 * u) * DD + mm.r;
+				const double *pb = s_ops + (2 * u + (b_diag? 0 : 1)) * DD + yq; // (yq = q in the matrix lanes)
+				const int as = b_y? 1 : D;
+				#pragma unroll
+				for(int t = 0; t < D; ++ t)
+					sum += pa[t * as] * pb[t * D];
+			}
+		}
+		wave_sync();
+	}
+	s_part[n_sub_wave * 64 + lane] = sum;
+	__syncthreads();
+	if(n_sub_wave != 0 || !b_valid)
+		return;
+	double total = 0;
+	for(int v = 0; v < n_waves; ++ v)
+		total += s_part[v * 64 + lane];
+	if(b_y)
+		w[sl.cs_new + yq] = init - total;
+	else if(mm.b_act)
+		L[sl.loff + lane] = init - total;
+}
+
+// LDS of the panel launches, in doubles: the panel role's package, image, vectors, tiles and operand staging; the update
+// role's staging fits inside
+template <int D, int CAP_BLK, bool b_fused>
+struct TPanelLds {
+	enum { DD = D * D, FRESH_BATCH = 4, UPD_BATCH = 8,
+		PKG = 0, IMAGE = PKG + 2 * PANEL_UNITS, VEC = IMAGE + CAP_BLK * DD, LINV = VEC + PANEL_COLS * 8, TILE = LINV + 64,
+		OPS = TILE + PANEL_W * 64, YV = OPS + (b_fused? PANEL_W * 2 * FRESH_BATCH * DD : 0), PANEL_END = YV + (b_fused? PANEL_W * FRESH_BATCH * 8 : 0),
+		U_OPS = 0, U_YV = U_OPS + PANEL_W * 2 * UPD_BATCH * DD, U_PART = U_YV + PANEL_W * UPD_BATCH * 8, UPD_END = b_fused? U_PART + PANEL_W * 64 : 0,
+		TOTAL = (PANEL_END > UPD_END)? PANEL_END : UPD_END };
+};
+
+// (b_fused: some stage of the plan has its updates from further down applied inside the launch of the stage below -- the
+// launch then holds update workgroups next to the panel ones, and the panel tasks bring in fresh updates themselves)
+template <int D, int CAP_BLK, bool b_fused>
+__global__ void __launch_bounds__(64 * PANEL_W)
+factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict__ pkg_off, int n_panels,
+	const TUpdSlot *__restrict__ upd_slots, int n_upd_slots, const TUpdEnt *__restrict__ upd_ents, const double *__restrict__ A,
+	const double *__restrict__ b, double *L, double *Linv, double *w, int *p_flag, long long *p_timing)
+{
+	typedef TPanelLds<D, CAP_BLK, b_fused> TLds;
+	enum { W = PANEL_W, DD = D * D, BATCH = TLds::FRESH_BATCH };
+	__shared__ __attribute__((aligned(16))) double s_raw[TLds::TOTAL];
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	if(b_fused && int(blockIdx.x) >= n_panels) {
+		// update role: the blocks of the next stage's panel tasks, two per workgroup (four waves each)
+		const int n_half = wave / PANEL_UPD_W, n_sub = wave % PANEL_UPD_W;
+		const int n_slot = 2 * (int(blockIdx.x) - n_panels) + n_half;
+		const bool b_valid = n_slot < n_upd_slots;
+		const TUpdSlot sl = upd_slots[b_valid? n_slot : n_upd_slots - 1];
+		panel_update_block<D, TLds::UPD_BATCH>(sl, b_valid, upd_ents, A, L, b, w, n_sub, PANEL_UPD_W, lane,
+			s_raw + TLds::U_OPS + wave * 2 * TLds::UPD_BATCH * DD, s_raw + TLds::U_YV + wave * TLds::UPD_BATCH * 8,
+			s_raw + TLds::U_PART + n_half * PANEL_UPD_W * 64);
+		return;
+	}
+	longlong2 *s_pkg = reinterpret_cast<longlong2*>(s_raw + TLds::PKG);
+	double *s_L = s_raw + TLds::IMAGE, *s_w = s_raw + TLds::VEC, *s_linv = s_raw + TLds::LINV;
+	double *s_tile = s_raw + TLds::TILE + wave * 64;
+	double *s_ops = s_raw + TLds::OPS + wave * 2 * BATCH * DD, *s_yv = s_raw + TLds::YV + wave * BATCH * 8;
+	static_assert(64 * W <= PANEL_UNITS, "one speculative unit per thread");
 	long long *p_tm = 0; // development aid (SLAMPP_HIP_STAGE_TIMING): clock samples of workgroup 0
 	int n_tm = 0;
 	if(p_timing && blockIdx.x == 0 && tid == 0) {
@@ -57,13 +152,15 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 	const TPanelSlot *s_slot = reinterpret_cast<const TPanelSlot*>(s_pkg + 4 + 3 * n_cols);
 	const uint32_t *s_irow = reinterpret_cast<const uint32_t*>(s_pkg + 4 + 3 * n_cols + 2 * n_slots);
 	const uint32_t *s_ipair = s_irow + 4 * ((hd.n_int_rows + 3) / 4);
+	const TPanelExt *s_ext = reinterpret_cast<const TPanelExt*>(s_pkg + hd.n_units) - hd.ext_ptr[W];
 	__syncthreads();
 	PANEL_TICK(); // package
 
 	const TLaneMap mm = lane_map(lane, D, D);
 	const bool b_y = lane >= Y_LANE0 && lane < Y_LANE0 + D;
 	const int yq = b_y? lane - Y_LANE0 : mm.q;
-	// the image: the task's blocks as panel_update_kernel left them (Lambda minus the external updates), y likewise
+	// the image: the task's blocks as the update role left them (Lambda minus the updates from further down), y likewise;
+	// every wave its own slots (v, v + W, ..: it brings in their fresh updates below)
 	for(int s0 = wave; s0 < n_slots; s0 += 4 * W) {
 		double v[4];
 		#pragma unroll
@@ -79,6 +176,51 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 		s_w[tid] = w[s_col[tid / D].cs_new + tid % D];
 	__syncthreads();
 	PANEL_TICK(); // image
+
+	// 1. fresh updates (operands from the stage right below: a handful per task): wave v owns the slots v, v + W, ..,
+	// streams the entries that target them BATCH at a time and subtracts the products from its slots -- fixed order
+	for(int e0 = hd.ext_ptr[wave], e1 = b_fused? hd.ext_ptr[wave + 1] : e0; e0 < e1; e0 += BATCH) {
+		double va[BATCH], vb[BATCH], vy[BATCH];
+		#pragma unroll
+		for(int u = 0; u < BATCH; ++ u) {
+			const TPanelExt en = s_ext[min(e0 + u, e1 - 1)]; // the tail repeats the last entry: its product is skipped below
+			va[u] = L[en.a_off + (mm.b_act? lane : 0)];
+			vb[u] = L[en.b_off + (mm.b_act? lane : 0)];
+			vy[u] = w[(b_y && en.kind)? en.ycs + yq : 0]; // (unconditional: a load behind a branch would wait for the others)
+		}
+		#pragma unroll
+		for(int u = 0; u < BATCH; ++ u) {
+			if(mm.b_act) {
+				s_ops[(2 * u) * DD + lane] = va[u];
+				s_ops[(2 * u + 1) * DD + lane] = vb[u];
+			}
+			if(b_y)
+				s_yv[u * 8 + yq] = vy[u];
+		}
+		wave_sync();
+		#pragma unroll
+		for(int u = 0; u < BATCH; ++ u) {
+			if(e0 + u < e1) { // wave-uniform
+				const TPanelExt en = s_ext[e0 + u];
+				const bool b_vec = en.kind && b_y; // the right-hand side rides along the diagonal block's row entries
+				const double *pa = b_vec? s_yv + u * 8 : s_ops + (2 * u) * DD + mm.r;
+				const double *pb = s_ops + (2 * u + 1) * DD + (en.kind? yq : mm.q);
+				const int as = b_vec? 1 : D;
+				double sum = 0;
+				#pragma unroll
+				for(int t = 0; t < D; ++ t)
+					sum += pa[t * as] * pb[t * D];
+				if(b_vec)
+					s_w[en.col * D + yq] -= sum;
+				else if(mm.b_act)
+					s_L[int(en.slot) * DD + lane] -= sum;
+			}
+		}
+		wave_sync();
+	}
+	if(b_fused)
+		__syncthreads();
+	PANEL_TICK(); // fresh updates
 
 	// 2. the columns, inside the image
 	for(int ci = 0; ci < n_cols; ++ ci) {
@@ -108,39 +250,46 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 				const uint32_t en = s_ipair[sd.ip0 + e];
 				sum += pair_product_image<D>(s_L + int(en & 0xffff) * DD, s_L + int(en >> 16) * DD, mm.r, mm.q);
 			}
-			finish_offdiagonal<D>(init - sum, lane, mm.r, mm.q, mm.b_act, D, L, sd.loff, s_tile[wave], s_linv, s_L + n_slot * DD);
+			finish_offdiagonal<D>(init - sum, lane, mm.r, mm.q, mm.b_act, D, L, sd.loff, s_tile, s_linv, s_L + n_slot * DD);
 		}
 		__syncthreads(); // column ci and y_ci complete in the image
 		PANEL_TICK();
 	}
 }
 
-bool launch_factor_panel(int n_dim, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks, double *L, double *Linv, double *w,
-	int *p_flag, hipStream_t stream, long long *p_timing)
+bool launch_factor_panel(int n_dim, bool b_fused, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks, const TUpdSlot *upd_slots,
+	int n_upd_slots, const TUpdEnt *upd_ents, const double *A, const double *b, double *L, double *Linv, double *w, int *p_flag,
+	hipStream_t stream, long long *p_timing)
 {
-	if(n_tasks <= 0)
+	if(!b_fused)
+		n_upd_slots = 0;
+	const int n_grid = n_tasks + (n_upd_slots + 1) / 2;
+	if(n_grid <= 0)
 		return true;
+#define LAUNCH_PANEL(D, CAP) do { if(b_fused) \
+		hipLaunchKernelGGL((factor_panel_kernel<D, CAP, true>), dim3(n_grid), dim3(64 * PANEL_W), 0, stream, pkg, pkg_off, n_tasks, \
+			upd_slots, n_upd_slots, upd_ents, A, b, L, Linv, w, p_flag, p_timing); \
+	else \
+		hipLaunchKernelGGL((factor_panel_kernel<D, CAP, false>), dim3(n_grid), dim3(64 * PANEL_W), 0, stream, pkg, pkg_off, n_tasks, \
+			upd_slots, n_upd_slots, upd_ents, A, b, L, Linv, w, p_flag, p_timing); } while(0)
 	switch(n_dim) {
 	case 3:
-		hipLaunchKernelGGL((factor_panel_kernel<3, 256>), dim3(n_tasks), dim3(64 * PANEL_W), 0, stream, pkg, pkg_off, L, Linv, w,
-			p_flag, p_timing);
+		LAUNCH_PANEL(3, 256);
 		return true;
 	case 6:
-		hipLaunchKernelGGL((factor_panel_kernel<6, 96>), dim3(n_tasks), dim3(64 * PANEL_W), 0, stream, pkg, pkg_off, L, Linv, w,
-			p_flag, p_timing);
+		LAUNCH_PANEL(6, 96);
 		return true;
 	case 7:
-		hipLaunchKernelGGL((factor_panel_kernel<7, 72>), dim3(n_tasks), dim3(64 * PANEL_W), 0, stream, pkg, pkg_off, L, Linv, w,
-			p_flag, p_timing);
+		LAUNCH_PANEL(7, 72);
 		return true;
 	default:
 		return false;
 	}
+#undef LAUNCH_PANEL
 }
 
-// one workgroup of PANEL_UPD_W waves per factor block of the stage's panel tasks: wave v takes the entries v, v + W, ...
-// BATCH at a time (both operand blocks fetched whole, all requests of a batch before the first product), the partial sums
-// are added up in wave order, and the block goes out as Lambda - sum (a diagonal block with its right-hand side b - sum)
+// the same updates as a launch of their own (the first panel stage: nothing below it to ride in): one workgroup of
+// PANEL_UPD_W waves per factor block
 template <int D>
 __global__ void __launch_bounds__(64 * PANEL_UPD_W)
 panel_update_kernel(const TUpdSlot *__restrict__ slots, const TUpdEnt *__restrict__ ents, const double *__restrict__ A, double *L,
@@ -150,66 +299,9 @@ panel_update_kernel(const TUpdSlot *__restrict__ slots, const TUpdEnt *__restric
 	__shared__ double s_ops[W][2 * BATCH * DD];
 	__shared__ double s_yv[W][BATCH * 8];
 	__shared__ double s_part[W][64];
-	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const TUpdSlot sl = slots[blockIdx.x];
-	const TLaneMap mm = lane_map(lane, D, D);
-	const bool b_diag = sl.kind != 0;
-	const bool b_y = b_diag && lane >= Y_LANE0 && lane < Y_LANE0 + D;
-	const int yq = b_y? lane - Y_LANE0 : mm.q;
-	// Lambda's element (requested now, used last)
-	double init = 0;
-	if(wave == 0)
-		init = b_y? b[sl.cs_src + yq] : (mm.b_act? lambda_element(A, sl.asrc, mm.r, mm.q, D, D, false) : 0.0);
-	double sum = 0;
-	const TUpdEnt *p_ent = ents + sl.e0;
-	for(int e0 = wave * BATCH; e0 < sl.ne; e0 += W * BATCH) {
-		const int n_here = min(int(BATCH), sl.ne - e0);
-		double va[BATCH], vb[BATCH];
-		#pragma unroll
-		for(int u = 0; u < BATCH; ++ u) {
-			const TUpdEnt en = p_ent[e0 + min(u, n_here - 1)]; // the tail repeats the last entry: its product is skipped below
-			va[u] = L[en.a_off + (mm.b_act? lane : 0)];
-			// the other operand: the block L(j,c) of a pair; for a row entry y_c in the right-hand side lanes (one load, the
-			// lane picks its address: a load behind a branch would wait for the others)
-			const double *p_other = b_diag? w + en.b_off + (b_y? yq : 0) : L + en.b_off + (mm.b_act? lane : 0);
-			vb[u] = *p_other;
-		}
-		#pragma unroll
-		for(int u = 0; u < BATCH; ++ u) {
-			if(mm.b_act) {
-				s_ops[wave][(2 * u) * DD + lane] = va[u];
-				if(!b_diag)
-					s_ops[wave][(2 * u + 1) * DD + lane] = vb[u];
-			}
-			if(b_y)
-				s_yv[wave][u * 8 + yq] = vb[u];
-		}
-		wave_sync();
-		#pragma unroll
-		for(int u = 0; u < BATCH; ++ u) {
-			if(u < n_here) { // wave-uniform
-				const double *pa = b_y? s_yv[wave] + u * 8 : s_ops[wave] + (2 * u) * DD + mm.r;
-				const double *pb = s_ops[wave] + (2 * u + (b_diag? 0 : 1)) * DD + yq; // (yq = q in the matrix lanes)
-				const int as = b_y? 1 : D;
-				#pragma unroll
-				for(int t = 0; t < D; ++ t)
-					sum += pa[t * as] * pb[t * D];
-			}
-		}
-		wave_sync();
-	}
-	s_part[wave][lane] = sum;
-	__syncthreads();
-	if(wave != 0)
-		return;
-	double total = 0;
-	#pragma unroll
-	for(int v = 0; v < W; ++ v)
-		total += s_part[v][lane];
-	if(b_y)
-		w[sl.cs_new + yq] = init - total;
-	else if(mm.b_act)
-		L[sl.loff + lane] = init - total;
+	panel_update_block<D, BATCH>(sl, true, ents, A, L, b, w, wave, W, lane, s_ops[wave], s_yv[wave], s_part[0]);
 }
 
 void launch_panel_update(int n_dim, const TUpdSlot *slots, int n_slots, const TUpdEnt *ents, const double *A, double *L,

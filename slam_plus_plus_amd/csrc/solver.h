@@ -126,6 +126,7 @@ struct slampp_hip_solver {
 	slampp::CDevArray<slampp::TUpdSlot> d_panel_upd_slots; // the factor blocks of the panel tasks, stage by stage, and the
 	slampp::CDevArray<slampp::TUpdEnt> d_panel_upd_ents;   // updates they receive from earlier stages (panel_update_kernel)
 	std::vector<int32_t> panel_ptr, panel_rest_ptr, panel_upd_ptr; // [n_stages + 1] ranges of the lists (empty: no panels)
+	std::vector<char> panel_ride; // [n_stages + 1] the stage's updates from further down are applied inside the launch of the stage below
 	slampp::CDevArray<int64_t> d_simt_tab;
 	std::vector<int32_t> simt_chunk_ptr, simt_rest_ptr; // [n_bottom_stages + 1] each; empty = not in use
 	std::vector<int32_t> simt_lds_bytes; // per stage: the largest chunk table (it is staged in LDS)

@@ -588,12 +588,41 @@ void slampp_hip_solver::Analyze_Sparse()
 		panel_ptr.assign(n_stages + 1, 0);
 		panel_rest_ptr.assign(n_stages + 1, 0);
 		panel_upd_ptr.assign(n_stages + 1, 0);
-		std::vector<int32_t> col_local(size_t(P.n), -1);
+		std::vector<int32_t> col_local(size_t(P.n), -1), col_stage(size_t(P.n), -1);
+		for(int s = 0; s < n_stages; ++ s) {
+			for(int64_t i = P.task_ptr[P.stage_ptr[s]]; i < P.task_ptr[P.stage_ptr[s + 1]]; ++ i)
+				col_stage[P.task_cols[i]] = s;
+		}
+		std::vector<TPanelExt> fresh;
 		std::vector<uint32_t> irow, ipair;
 		std::vector<TPanelCol> pcols;
 		std::vector<TPanelSlot> pslots;
+		panel_ride.assign(n_stages + 1, 0);
+		const int n_ride_max_fresh = getenv("SLAMPP_PANEL_RIDE_FRESH")? atoi(getenv("SLAMPP_PANEL_RIDE_FRESH")) : 64;
 		for(int s = 0; s < n_stages; ++ s) {
-			for(int t = P.stage_ptr[s]; (s >= n_bottom_stages || (s == 0 && b_leaf_panels)) && t < P.stage_ptr[s + 1]; ++ t) {
+			const bool b_panel_stage = s >= n_bottom_stages || (s == 0 && b_leaf_panels);
+			// Do this stage's updates from further down ride in the launch of the stage below?  Only if that is a panel launch,
+			// and only if what is then left to the tasks themselves -- the updates from the stage right below -- is little:
+			// a task brings those in with its own eight waves, on the stage's critical path (a launch saved is about 4 us)
+			if(b_panel_stage && s > 0 && panel_ptr[s] > panel_ptr[s - 1]) {
+				int64_t n_max_fresh = 0;
+				for(int t = P.stage_ptr[s]; t < P.stage_ptr[s + 1]; ++ t) {
+					int64_t n_fresh = 0;
+					for(int64_t i = P.task_ptr[t]; i < P.task_ptr[t + 1]; ++ i) {
+						const TColDesc &c = cols[i];
+						for(int64_t e = c.r0; e < c.r0 + c.nr; ++ e)
+							n_fresh += col_stage[P.blk_col[P.rblk[e]]] == s - 1;
+						for(int64_t e = P.pptr[c.k0 + 1]; e < P.pptr[c.k0 + c.nb]; ++ e)
+							n_fresh += col_stage[P.blk_col[P.pa[e]]] == s - 1;
+					}
+					n_max_fresh = std::max(n_max_fresh, n_fresh);
+				}
+				panel_ride[s] = n_max_fresh <= n_ride_max_fresh;
+				if(b_timing)
+					fprintf(stderr, "[setup] stage %d: %d tasks, at most %lld updates from the stage below: %s\n", s,
+						P.stage_ptr[s + 1] - P.stage_ptr[s], (long long)n_max_fresh, panel_ride[s]? "ride" : "own launch");
+			}
+			for(int t = P.stage_ptr[s]; b_panel_stage && t < P.stage_ptr[s + 1]; ++ t) {
 				const int64_t c_begin = P.task_ptr[t], c_end = P.task_ptr[t + 1];
 				const int n_cols = int(c_end - c_begin);
 				bool b_fits = n_cols >= 1 && n_cols <= int(PANEL_COLS);
@@ -604,20 +633,31 @@ void slampp_hip_solver::Analyze_Sparse()
 					n_slots += cols[i].nb;
 				}
 				b_fits = b_fits && n_slots <= n_slot_cap;
+				// the updates from stages further down are applied inside the launch of the stage below, if that is a panel
+				// launch: then what the stage right below contributes ("fresh") is left to the task itself
+				const bool b_ride = panel_ride[s] != 0;
+				int64_t n_fresh = 0;
 				for(int64_t i = c_begin; b_fits && i < c_end; ++ i) { // size of the package
 					const TColDesc &c = cols[i];
-					for(int64_t e = c.r0; e < c.r0 + c.nr; ++ e)
-						n_int_rows += P.rblk[e] >= k_begin && P.rblk[e] < k_begin + n_slots;
-					for(int64_t e = P.pptr[c.k0 + 1]; e < P.pptr[c.k0 + c.nb]; ++ e)
-						n_int_pairs += P.pa[e] >= k_begin && P.pa[e] < k_begin + n_slots;
+					for(int64_t e = c.r0; e < c.r0 + c.nr; ++ e) {
+						const bool b_int = P.rblk[e] >= k_begin && P.rblk[e] < k_begin + n_slots;
+						n_int_rows += b_int;
+						n_fresh += !b_int && b_ride && col_stage[P.blk_col[P.rblk[e]]] == s - 1;
+					}
+					for(int64_t e = P.pptr[c.k0 + 1]; e < P.pptr[c.k0 + c.nb]; ++ e) {
+						const bool b_int = P.pa[e] >= k_begin && P.pa[e] < k_begin + n_slots;
+						n_int_pairs += b_int;
+						n_fresh += !b_int && b_ride && col_stage[P.blk_col[P.pa[e]]] == s - 1;
+					}
 				}
-				const size_t n_units = 4 + 3 * size_t(n_cols) + 2 * size_t(n_slots) + size_t(n_int_rows + 3) / 4 + size_t(n_int_pairs + 3) / 4;
+				const size_t n_units = 4 + 3 * size_t(n_cols) + 2 * size_t(n_slots) + size_t(n_int_rows + 3) / 4 + size_t(n_int_pairs + 3) / 4 +
+					2 * size_t(n_fresh);
 				b_fits = b_fits && n_units <= size_t(PANEL_UNITS);
 				if(!b_fits) {
 					panel_rest.push_back(t);
 					continue;
 				}
-				irow.clear(); ipair.clear(); pcols.clear(); pslots.clear();
+				irow.clear(); ipair.clear(); pcols.clear(); pslots.clear(); fresh.clear();
 				for(int64_t i = c_begin; i < c_end; ++ i)
 					col_local[P.task_cols[i]] = int32_t(i - c_begin);
 				for(int64_t i = c_begin; i < c_end; ++ i) {
@@ -642,7 +682,16 @@ void slampp_hip_solver::Analyze_Sparse()
 						const int64_t k = P.rblk[e];
 						if(k >= k_begin && k < k_begin + n_slots)
 							irow.push_back(uint32_t(k - k_begin) | (uint32_t(col_local[P.blk_col[k]]) << 16));
-						else
+						else if(b_ride && col_stage[P.blk_col[k]] == s - 1) {
+							TPanelExt en;
+							memset(&en, 0, sizeof(en));
+							en.a_off = en.b_off = rents[e].off;
+							en.ycs = rents[e].ycs;
+							en.slot = uint16_t(pc.slot0);
+							en.kind = 1;
+							en.col = int32_t(i - c_begin);
+							fresh.push_back(en);
+						} else
 							upd_ents.push_back(TUpdEnt{rents[e].off, int64_t(rents[e].ycs)});
 					}
 					us.ne = int32_t(int64_t(upd_ents.size()) - us.e0);
@@ -664,7 +713,14 @@ void slampp_hip_solver::Analyze_Sparse()
 								const int64_t ka = P.pa[e], kb = P.pb[e];
 								if(ka >= k_begin && ka < k_begin + n_slots)
 									ipair.push_back(uint32_t(ka - k_begin) | (uint32_t(kb - k_begin) << 16));
-								else
+								else if(b_ride && col_stage[P.blk_col[ka]] == s - 1) {
+									TPanelExt en;
+									memset(&en, 0, sizeof(en));
+									en.a_off = P.loff[ka];
+									en.b_off = P.loff[kb];
+									en.slot = uint16_t(k - k_begin);
+									fresh.push_back(en);
+								} else
 									upd_ents.push_back(TUpdEnt{P.loff[ka], P.loff[kb]});
 							}
 							us.ne = int32_t(int64_t(upd_ents.size()) - us.e0);
@@ -680,6 +736,16 @@ void slampp_hip_solver::Analyze_Sparse()
 				hd.n_slots = int32_t(n_slots);
 				hd.n_units = int32_t(n_units);
 				hd.n_int_rows = int32_t(irow.size());
+				// fresh entries by the wave that owns their slot, inside a wave by slot, inside a slot in list order
+				std::stable_sort(fresh.begin(), fresh.end(), [](const TPanelExt &x, const TPanelExt &y) {
+					const int wx = x.slot % PANEL_W, wy = y.slot % PANEL_W;
+					return wx < wy || (wx == wy && x.slot < y.slot); });
+				for(size_t e = 0; e < fresh.size(); ++ e)
+					++ hd.ext_ptr[fresh[e].slot % PANEL_W + 1];
+				for(int v = 0; v < int(PANEL_W); ++ v)
+					hd.ext_ptr[v + 1] += hd.ext_ptr[v];
+				if(int64_t(fresh.size()) != n_fresh)
+					throw std::logic_error("panel package: fresh entries miscounted");
 				const size_t n_at = panel_pkg.size();
 				panel_pkg.resize(n_at + n_units, longlong2{0, 0});
 				char *p_dst = reinterpret_cast<char*>(&panel_pkg[n_at]);
@@ -694,13 +760,16 @@ void slampp_hip_solver::Analyze_Sparse()
 				p_dst += (irow.size() + 3) / 4 * 16;
 				if(!ipair.empty())
 					memcpy(p_dst, ipair.data(), ipair.size() * sizeof(uint32_t));
+				p_dst += (ipair.size() + 3) / 4 * 16;
+				if(!fresh.empty())
+					memcpy(p_dst, fresh.data(), fresh.size() * sizeof(TPanelExt));
 				panel_off.push_back(int64_t(n_at));
 			}
 			panel_ptr[s + 1] = int32_t(panel_off.size());
 			panel_rest_ptr[s + 1] = int32_t(panel_rest.size());
 			panel_upd_ptr[s + 1] = int32_t(upd_slots.size());
 		}
-		static_assert(sizeof(TPanelHead) == 64 && sizeof(TPanelCol) == 48 && sizeof(TPanelSlot) == 32 && sizeof(TUpdSlot) == 64 &&
+		static_assert(sizeof(TPanelHead) == 64 && sizeof(TPanelCol) == 48 && sizeof(TPanelSlot) == 32 && sizeof(TPanelExt) == 32 && sizeof(TUpdSlot) == 64 &&
 			sizeof(TUpdEnt) == 16, "record sizes");
 		if(panel_off.empty()) {
 			panel_ptr.clear();
@@ -933,6 +1002,29 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			((reinterpret_cast<uintptr_t>(p_values_dev) | reinterpret_cast<uintptr_t>(p_rhs_dev)) & 15) == 0);
 		// phases: the leaf subtrees (stage 0), the wide stages right above them, the separators further up
 		const int n_wide_end = std::min(n_bottom_stages, n_stages);
+		// A stage of panel tasks: the updates its blocks receive from stages further down were applied inside the launch of the
+		// stage below if that was a panel launch too (nothing there depends on them: they ride as extra workgroups), by a
+		// launch of their own otherwise; what the stage right below contributed is brought in by the tasks themselves.
+		bool b_panel_fused = false;
+		for(size_t i = 0; i < panel_ride.size(); ++ i)
+			b_panel_fused = b_panel_fused || panel_ride[i] != 0;
+		auto Launch_Panels = [&](int s, bool b_bottom) {
+			const int n_panels = panel_ptr[s + 1] - panel_ptr[s];
+			const bool b_rode = panel_ride[s] != 0;
+			if(!b_rode)
+				launch_panel_update(P.max_dim, d_panel_upd_slots.p() + panel_upd_ptr[s], panel_upd_ptr[s + 1] - panel_upd_ptr[s],
+					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream);
+			const int n_next = (s + 1 < n_stages && panel_ride[s + 1])? panel_upd_ptr[s + 2] - panel_upd_ptr[s + 1] : 0;
+			launch_factor_panel(P.max_dim, b_panel_fused, d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s], n_panels,
+				d_panel_upd_slots.p() + ((n_next > 0)? panel_upd_ptr[s + 1] : 0), n_next, d_panel_upd_ents.p(), p_values_dev, p_rhs_dev,
+				d_L.p(), d_Linv.p(), d_w.p(), p_flag, stream, dplan.p_timing);
+			if(panel_rest_ptr[s + 1] > panel_rest_ptr[s]) {
+				TDevPlan t_rest = dplan;
+				t_rest.task_map = d_panel_rest.p();
+				launch_factor_stage(t_rest, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), panel_rest_ptr[s],
+					panel_rest_ptr[s + 1] - panel_rest_ptr[s], b_bottom, p_flag, stream);
+			}
+		};
 		for(int s = 0; s < n_stages; ++ s) {
 			if(s == 0)
 				Phase_Begin("factor_leaves");
@@ -953,33 +1045,12 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 						true, p_flag, stream);
 				}
 			} else if(s == 0 && !panel_ptr.empty() && panel_ptr[1] > panel_ptr[0]) {
-				// few leaf subtrees: as panels (they receive no updates: the update launch just copies Lambda's blocks over)
-				launch_panel_update(P.max_dim, d_panel_upd_slots.p() + panel_upd_ptr[s], panel_upd_ptr[s + 1] - panel_upd_ptr[s],
-					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream);
-				launch_factor_panel(P.max_dim, d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s], panel_ptr[s + 1] - panel_ptr[s],
-					d_L.p(), d_Linv.p(), d_w.p(), p_flag, stream, dplan.p_timing);
-				if(panel_rest_ptr[s + 1] > panel_rest_ptr[s]) {
-					TDevPlan t_rest = dplan;
-					t_rest.task_map = d_panel_rest.p();
-					launch_factor_stage(t_rest, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), panel_rest_ptr[s],
-						panel_rest_ptr[s + 1] - panel_rest_ptr[s], true, p_flag, stream);
-				}
+				Launch_Panels(s, true); // few leaf subtrees: as panels (they receive no updates: the update just copies Lambda's blocks over)
 			} else if(s > 0 && s < n_bottom_stages && dplan.task_pkg)
 				launch_factor_wide(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
 					P.stage_ptr[s + 1] - P.stage_ptr[s], p_flag, stream);
 			else if(s >= n_bottom_stages && !panel_ptr.empty()) {
-				// separators: as panels in LDS where they fit (the updates from earlier stages first, spread over the chip),
-				// column by column otherwise
-				launch_panel_update(P.max_dim, d_panel_upd_slots.p() + panel_upd_ptr[s], panel_upd_ptr[s + 1] - panel_upd_ptr[s],
-					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream);
-				launch_factor_panel(P.max_dim, d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s], panel_ptr[s + 1] - panel_ptr[s],
-					d_L.p(), d_Linv.p(), d_w.p(), p_flag, stream, dplan.p_timing);
-				if(panel_rest_ptr[s + 1] > panel_rest_ptr[s]) {
-					TDevPlan t_rest = dplan;
-					t_rest.task_map = d_panel_rest.p();
-					launch_factor_stage(t_rest, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), panel_rest_ptr[s],
-						panel_rest_ptr[s + 1] - panel_rest_ptr[s], false, p_flag, stream);
-				}
+				Launch_Panels(s, false); // separators: as panels in LDS where they fit, column by column otherwise
 			} else
 			launch_factor_stage(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
 				P.stage_ptr[s + 1] - P.stage_ptr[s], s < n_bottom_stages, p_flag, stream);

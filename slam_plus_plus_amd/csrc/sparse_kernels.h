@@ -54,11 +54,12 @@ struct TDenseCol { // 24 B
 
 // ---- panel packages (panel_kernel.hip): everything a separator task of consecutive columns needs, in one buffer ----
 // 16-byte units: head (4) | columns (3 each) | factor blocks of the task = slots of its LDS image (2 each) | internal row
-// entries and internal update pairs (4 per unit: operands that are slots of the image)
+// entries and internal update pairs (4 per unit: operands that are slots of the image) | fresh entries (2 each: updates
+// whose operands the stage right below produced, sorted by the wave that brings them in)
 enum { PANEL_W = 8, PANEL_COLS = 8, PANEL_UNITS = 1024, PANEL_UPD_W = 4 };
 struct TPanelHead { // 64 B
 	int32_t n_cols, n_slots, n_units, n_int_rows; // (internal row entries: the internal pairs follow them, unit-aligned)
-	int32_t pad[12];
+	int32_t ext_ptr[12];                          // wave v brings in the fresh entries ext_ptr[v] .. ext_ptr[v + 1]
 };
 struct TPanelCol { // 48 B
 	int64_t linv_off, cs_new, cs_src;
@@ -71,8 +72,16 @@ struct TPanelSlot { // 32 B
 	int32_t ip0, inp;   // internal update pairs: (slot of L(i,c)) | (slot of L(j,c)) << 16
 	int64_t pad;
 };
-// the updates whose operands earlier stages produced are applied before the panels run, one workgroup per factor block
-// (panel_update_kernel): L(block) = Lambda(block) - sum, y_j = b_j - sum for diagonal blocks
+struct TPanelExt { // 32 B
+	int64_t a_off, b_off; // offsets of L(i,c), L(j,c) in the factor (row entries: both L(j,c))
+	int32_t ycs;          // row entries: scalar offset of y_c in the workspace
+	uint16_t slot, kind;  // target slot; 0 = update pair, 1 = row entry of the diagonal block
+	int32_t col;          // row entries: number of the target column in the task
+	int32_t pad;
+};
+// the updates whose operands stages further down produced are applied before the panels run, one half-workgroup per
+// factor block (L(block) = Lambda(block) - sum, y_j = b_j - sum for diagonal blocks) -- for the first panel stage by a
+// launch of their own, for every later one inside the launch of the stage below (nothing there depends on them)
 struct TUpdSlot { // 64 B
 	int64_t loff, asrc;
 	int64_t e0;           // first entry
@@ -87,8 +96,11 @@ struct TUpdEnt { // 16 B
 inline int panel_slot_cap(int n_dim) { return (n_dim == 6)? 96 : (n_dim == 7)? 72 : 256; }
 
 // one workgroup per package (pkg_off: their offsets in pkg, in 16-byte units; pkg is padded by 64 * PANEL_W units)
-bool launch_factor_panel(int n_dim, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks, double *L,
-	double *Linv, double *w, int *p_flag, hipStream_t stream, long long *p_timing = 0);
+// (upd_slots: the blocks of the NEXT stage's panel tasks, whose updates from below this stage ride in this launch)
+// (b_fused: the plan has such stages at all; without them the leaner kernel runs)
+bool launch_factor_panel(int n_dim, bool b_fused, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks, const TUpdSlot *upd_slots,
+	int n_upd_slots, const TUpdEnt *upd_ents, const double *A, const double *b, double *L, double *Linv, double *w, int *p_flag,
+	hipStream_t stream, long long *p_timing = 0);
 void launch_panel_update(int n_dim, const TUpdSlot *slots, int n_slots, const TUpdEnt *ents, const double *A, double *L,
 	const double *b, double *w, hipStream_t stream);
 
