@@ -265,14 +265,14 @@ def run_c3(args, rank, world, local_rank, dist):
     prof = dict(prof_fine, **{k_: v_ for k_, v_ in prof.items() if k_ in ("factor_leaves",)})
     n_stages, n_bottom = stats["n_stages"], stats["n_bottom_stages"]
     kb = per_kernel_bytes_sparse(solver.plan(), n_bottom)
-    # the separator stages are two launches each: the updates from earlier stages (one workgroup per factor block), then the
-    # tasks as panels in LDS
-    launches = {"factor_leaves": 1, "factor_wide": max(n_bottom - 1, 1), "factor_upper": 2 * max(n_stages - n_bottom, 1),
+    # the separator stages are one launch each -- the tasks as panels in LDS, next to them the updates the NEXT stage's blocks
+    # receive from further down (one half-workgroup per factor block) -- plus one launch of those updates for the first of them
+    launches = {"factor_leaves": 1, "factor_wide": max(n_bottom - 1, 1), "factor_upper": max(n_stages - n_bottom, 1) + 1,
                 "forward": n_stages, "backward": n_stages}
     names = {"factor_leaves": "factor_simt_kernel", "factor_wide": "factor_stage_kernel<D, 1, 8, 32, 48>",
-             "factor_upper": "panel_update_kernel + factor_panel_kernel", "forward": "forward_stage_kernel",
+             "factor_upper": "factor_panel_kernel (+ one panel_update_kernel launch)", "forward": "forward_stage_kernel",
              "backward": "backward_stage_kernel"}
-    needles = {"factor_leaves": "factor_simt_kernel", "factor_wide": ", 1, 8, 32, 48>", "factor_upper": ("panel_update_kernel", "factor_panel_kernel"),
+    needles = {"factor_leaves": "factor_simt_kernel", "factor_wide": ", 1, 8, 32, 48>", "factor_upper": "factor_panel_kernel",
                "forward": "forward_stage_kernel", "backward": "backward_stage_kernel"}   # as rocprofv3 spells the kernels
     traffic, traffic_file = load_traffic("c3")
     kernels = []
