@@ -401,6 +401,7 @@ def assembly_leg(solver, lam, dev, reps=20, rd=None, column_vertex_first=False):
     args = [t.data_ptr() for t in bufs] + [values.data_ptr(), eta.data_ptr(), es.unary_vertex, es.unary_factor, es.unary_error]
     asm.Refresh_Lambda_device(*args)
     solver.sync()
+    solver.set_option("profile", 1)        # (level 3 keeps only the solve's own kernels)
     solver.profile(reset=True)
     for _ in range(reps):
         asm.Refresh_Lambda_device(*args)

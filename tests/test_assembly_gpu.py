@@ -17,6 +17,19 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-12
 
 
+@pytest.fixture(autouse=True, params=["groups", "groups_of_3", "one_wave_kernels"])
+def assembly_path(request, monkeypatch):
+    """Every test runs through the vertex-group kernel (each edge record read once; the default), through it with
+    groups of at most three vertices (most edges cross groups; ragged last groups), and through the one-wave-per-block
+    kernels that take what the groups cannot (development switches of csrc/assembly.hip, read at setup)."""
+    monkeypatch.setenv("SLAMPP_ASM_GROUPS", "0" if request.param == "one_wave_kernels" else "1")
+    if request.param == "groups_of_3":
+        monkeypatch.setenv("SLAMPP_ASM_GROUP_VERTICES", "3")
+    else:
+        monkeypatch.delenv("SLAMPP_ASM_GROUP_VERTICES", raising=False)
+    return request.param
+
+
 def dev(a):
     return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
 
