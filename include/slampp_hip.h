@@ -93,6 +93,9 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
  * possible / tiles only / runs of any length),
  * "panel" (sparse path: -1 / 1 (default) = separator tasks are factored as panels in LDS, the updates from earlier stages
  * applied per factor block by a launch of its own; 0 = column by column),
+ * "assembly_groups" (slampp_hip_assembly_create: the most vertices one group of the Lambda assembly takes -- a group is a
+ * run of consecutive vertices whose edges fit in LDS together, so that every edge record is read once for its
+ * off-diagonal block and both diagonal blocks; default: as many as fit; 0 = no groups, one wave per block of Lambda),
  * "marginals_dense" (Schur mode: 1 = slampp_hip_schur_marginals always inverts the reduced system densely; 0 (default) =
  * when the solves factor it by the sparse block path, the covariances take the blocks of S^-1 they need from a
  * sparse inverse subset on that factor's pattern) */

@@ -168,8 +168,8 @@ CAssemblyState *assembly_setup(slampp_hip_solver &s, int64_t n_edges, const int6
 	std::vector<uint8_t> b_grouped(n, 0);
 	int n_grp_pkg_cap = 0, n_grp_cap_edges = 0;
 	{
-		const int n_mode = getenv("SLAMPP_ASM_GROUPS")? atoi(getenv("SLAMPP_ASM_GROUPS")) : 1; // development aid and tests: 0 = the one-wave kernels for everything
-		const int n_grp_vertices = getenv("SLAMPP_ASM_GROUP_VERTICES")? atoi(getenv("SLAMPP_ASM_GROUP_VERTICES")) : 1 << 20; // (as many as fit)
+		const int n_grp_vertices = s.n_assembly_groups; // option "assembly_groups": as many as fit by default, 0 = the one-wave kernels for everything
+		const int n_mode = n_grp_vertices > 0;
 		const TAsmGroupShape t_shape = asm_group_shape(rd, d0, d1);
 		const int n_cap_edges = 4 * t_shape.n_ew; // as many edges as the workgroup copies in one go: n_ew per wave
 		n_grp_cap_edges = n_cap_edges;

@@ -90,6 +90,7 @@ struct slampp_hip_solver {
 	int b_shard_primary;
 	int n_shard_rank, n_shard_world; // optional (-1, 0 = unknown): lets the ranks exchange block lists instead of an nc^2 indicator
 	int n_marginals_dense; // option marginals_dense: 1 = the covariances always through the dense inverse of the reduced system
+	int n_assembly_groups = 1 << 20; // option "assembly_groups": most vertices a group of the Lambda assembly takes (0: no groups, the one-wave kernels for everything)
 	int n_schur_tiles = -1; // option "schur_tiles": landmark-major assembly of S: -1 = where it pays, 0 = never, 1 = wherever possible
 	int n_schur_incremental = 0; // option "schur_incremental": keep the assembled reduced system for slampp_hip_schur_set_changed_points
 	int n_schur_sparse; // reduced camera system: -1 = sparse path when few of its blocks are nonzero, 0 = always dense, 1 = always sparse

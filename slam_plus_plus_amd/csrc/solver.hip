@@ -1234,6 +1234,10 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 		p_solver->n_shard_world = int(n_value);
 		return SLAMPP_HIP_OK;
 	}
+	else if(s == "assembly_groups" && n_value >= 0) {
+		p_solver->n_assembly_groups = int(std::min(n_value, int64_t(1 << 20)));
+		return SLAMPP_HIP_OK; // read by slampp_hip_assembly_create: does not invalidate the analysis
+	}
 	else if(s == "marginals_dense" && n_value >= 0 && n_value <= 1) {
 		p_solver->n_marginals_dense = int(n_value);
 		return SLAMPP_HIP_OK; // read by schur_marginals: does not invalidate the analysis

@@ -17,16 +17,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-12
 
 
+ASSEMBLY_GROUPS = None   # option "assembly_groups" of the solvers below; None: the library's default
+
+
 @pytest.fixture(autouse=True, params=["groups", "groups_of_3", "one_wave_kernels"])
 def assembly_path(request, monkeypatch):
     """Every test runs through the vertex-group kernel (each edge record read once; the default), through it with
     groups of at most three vertices (most edges cross groups; ragged last groups), and through the one-wave-per-block
-    kernels that take what the groups cannot (development switches of csrc/assembly.hip, read at setup)."""
-    monkeypatch.setenv("SLAMPP_ASM_GROUPS", "0" if request.param == "one_wave_kernels" else "1")
-    if request.param == "groups_of_3":
-        monkeypatch.setenv("SLAMPP_ASM_GROUP_VERTICES", "3")
-    else:
-        monkeypatch.delenv("SLAMPP_ASM_GROUP_VERTICES", raising=False)
+    kernels that take what the groups cannot (option "assembly_groups", read by slampp_hip_assembly_create)."""
+    monkeypatch.setitem(globals(), "ASSEMBLY_GROUPS", {"groups": None, "groups_of_3": 3, "one_wave_kernels": 0}[request.param])
     return request.param
 
 
@@ -39,6 +38,8 @@ def ptr(t):
 
 
 def assemble_on_gpu(solver, lam, es, accumulate_into=None):
+    if ASSEMBLY_GROUPS is not None:
+        solver.set_option("assembly_groups", ASSEMBLY_GROUPS)
     asm = CLambdaAssembly_HIP(solver, lam, es.v0, es.v1, es.rd)
     bufs = [dev(a) for a in (es.J0, es.J1, es.sigma_inv, es.err, es.weight)]
     if accumulate_into is None:
