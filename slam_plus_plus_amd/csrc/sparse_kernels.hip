@@ -457,32 +457,112 @@ backward_stage_kernel(TDevPlan p, const double *L, const double *Linv, double *w
 	const int64_t c_begin = p.task_ptr[task], c_end = p.task_ptr[task + 1];
 	if(c_end <= c_begin)
 		return;
+	if(D) {
+		// Fixed block size.  What a column step waits for should be x of the rows its blocks refer to and nothing else
+		// (the step before may just have written them): the column record, the record and the values of the lane group's
+		// first block, inv(L_jj) and y_j do not depend on any x and are requested a column (the records: two) ahead --
+		// a task's columns used to cost three dependent trips to memory each (record -> block record -> values)
+		enum { DN = D? D : 1 };
+		const int qq = (q < D)? q : 0;
+		// (scalars, not records: a record selected by a condition or copied as a whole goes through scratch memory,
+		// and a kernel with scratch takes 14 us longer to launch)
+		int64_t n_k0_next, n_linv, n_linv_next, n_cs, n_cs_next, n_src, n_src_next, n_loff, n_loff_next;
+		int n_nb, n_nb_next, n_xcs, n_xcs_next;
+		{
+			const TColDesc &r_cd = p.cols[c_end - 1], &r_cd_next = p.cols[max(c_end - 2, c_begin)];
+			n_nb = r_cd.nb; n_linv = r_cd.linv_off; n_cs = r_cd.cs_new; n_src = r_cd.cs_src;
+			n_k0_next = r_cd_next.k0; n_nb_next = r_cd_next.nb; n_linv_next = r_cd_next.linv_off; n_cs_next = r_cd_next.cs_new;
+			n_src_next = r_cd_next.cs_src;
+			const TBlkDesc &r_bd = p.blks[r_cd.k0 + min(1 + g, n_nb - 1)], &r_bd_next = p.blks[n_k0_next + min(1 + g, n_nb_next - 1)];
+			n_loff = r_bd.loff; n_xcs = r_bd.xcs;
+			n_loff_next = r_bd_next.loff; n_xcs_next = r_bd_next.xcs;
+		}
+		double lv[DN], li[DN], y;
+		#pragma unroll
+		for(int t = 0; t < DN; ++ t) {
+			lv[t] = L[n_loff + qq * D + t];
+			li[t] = Linv[n_linv + t + qq * D];
+		}
+		y = w[n_cs + qq];
+		for(int64_t c = c_end; c > c_begin; -- c) {
+			// x of the row of this lane group's block first (no branch around the request: the address is valid either way)
+			double xv[DN];
+			#pragma unroll
+			for(int t = 0; t < DN; ++ t)
+				xv[t] = w[n_xcs + t];
+			// requests for the columns after this one
+			const TColDesc &r_cd_after = p.cols[max(c - 3, c_begin)];
+			const int64_t n_k0_after = r_cd_after.k0, n_linv_after = r_cd_after.linv_off, n_cs_after = r_cd_after.cs_new,
+				n_src_after = r_cd_after.cs_src;
+			const int n_nb_after = r_cd_after.nb;
+			const TBlkDesc &r_bd_after = p.blks[n_k0_after + min(1 + g, n_nb_after - 1)];
+			const int64_t n_loff_after = r_bd_after.loff;
+			const int n_xcs_after = r_bd_after.xcs;
+			double lv_next[DN], li_next[DN];
+			#pragma unroll
+			for(int t = 0; t < DN; ++ t) {
+				lv_next[t] = L[n_loff_next + qq * D + t];
+				li_next[t] = Linv[n_linv_next + t + qq * D];
+			}
+			const double y_next = w[n_cs_next + qq]; // (y of another column: this column's store does not touch it)
+			// this column
+			double acc = 0;
+			#pragma unroll
+			for(int t = 0; t < DN; ++ t)
+				acc += lv[t] * xv[t];
+			acc = (1 + g < n_nb)? acc : 0.0;
+			if(n_nb > 9) { // (more than eight blocks below the diagonal: the rest as they come)
+				const int64_t n_k0 = p.cols[c - 1].k0;
+				for(int kb = 9 + g; kb < n_nb; kb += 8) {
+					const int64_t n_loff_k = p.blks[n_k0 + kb].loff;
+					const int n_xcs_k = p.blks[n_k0 + kb].xcs;
+					#pragma unroll
+					for(int t = 0; t < DN; ++ t)
+						acc += L[n_loff_k + qq * D + t] * w[n_xcs_k + t];
+				}
+			}
+			acc += __shfl_xor(acc, 8);
+			acc += __shfl_xor(acc, 16);
+			acc += __shfl_xor(acc, 32);
+			const double val = (q < D)? y - acc : 0; // every slot g holds the same totals
+			double x = 0;
+			#pragma unroll
+			for(int t = 0; t < DN; ++ t) {
+				const double vt = __shfl(val, t);
+				if(t >= qq)
+					x += li[t] * vt;
+			}
+			if(lane < D) {
+				w[n_cs + lane] = x;
+				x_out[n_src + lane] = x;
+			}
+			__syncthreads(); // x_j is where the next column's blocks look for it
+			n_nb = n_nb_next; n_linv = n_linv_next; n_cs = n_cs_next; n_src = n_src_next; n_loff = n_loff_next; n_xcs = n_xcs_next;
+			n_k0_next = n_k0_after; n_nb_next = n_nb_after; n_linv_next = n_linv_after; n_cs_next = n_cs_after; n_src_next = n_src_after;
+			n_loff_next = n_loff_after; n_xcs_next = n_xcs_after;
+			#pragma unroll
+			for(int t = 0; t < DN; ++ t) {
+				lv[t] = lv_next[t];
+				li[t] = li_next[t];
+			}
+			y = y_next;
+		}
+		return;
+	}
 	TColDesc cd_next = p.cols[c_end - 1];
 	for(int64_t c = c_end; c > c_begin; -- c) {
 		const TColDesc cd = cd_next;
 		if(c - 1 > c_begin)
 			cd_next = p.cols[c - 2]; // index data does not depend on the numbers: fetch it a column ahead
-		const int dj = D? D : cd.dj;
+		const int dj = cd.dj;
 		const int qq = (q < dj)? q : 0;
 		double acc = 0;
 		for(int kb = 1 + g; kb < cd.nb; kb += 8) {
 			const TBlkDesc bd = p.blks[cd.k0 + kb];
-			const int di = D? D : int(bd.np_di >> 24);
+			const int di = int(bd.np_di >> 24);
 			const double *Lb = L + bd.loff + qq * di, *x = w + bd.xcs;
-			if(D) {
-				double lv[D? D : 1], xv[D? D : 1];
-				#pragma unroll
-				for(int t = 0; t < D; ++ t) {
-					lv[t] = Lb[t];
-					xv[t] = x[t];
-				}
-				#pragma unroll
-				for(int t = 0; t < D; ++ t)
-					acc += lv[t] * xv[t];
-			} else {
-				for(int t = 0; t < di; ++ t)
-					acc += Lb[t] * x[t];
-			}
+			for(int t = 0; t < di; ++ t)
+				acc += Lb[t] * x[t];
 		}
 		acc += __shfl_xor(acc, 8);
 		acc += __shfl_xor(acc, 16);
@@ -490,19 +570,10 @@ backward_stage_kernel(TDevPlan p, const double *L, const double *Linv, double *w
 		const double val = (q < dj)? w[cd.cs_new + q] - acc : 0; // every slot g holds the same totals
 		const double *Li = Linv + cd.linv_off;
 		double x = 0;
-		if(D) {
-			#pragma unroll
-			for(int t = 0; t < D; ++ t) {
-				const double vt = __shfl(val, t);
-				if(t >= qq)
-					x += Li[t + qq * D] * vt;
-			}
-		} else {
-			for(int t = 0; t < dj; ++ t) {
-				const double vt = __shfl(val, t);
-				if(t >= qq)
-					x += Li[t + qq * dj] * vt;
-			}
+		for(int t = 0; t < dj; ++ t) {
+			const double vt = __shfl(val, t);
+			if(t >= qq)
+				x += Li[t + qq * dj] * vt;
 		}
 		__syncthreads(); // every lane has read y_j before it is overwritten
 		if(lane < dj) {
