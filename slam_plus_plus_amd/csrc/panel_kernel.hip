@@ -144,7 +144,11 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 	const int64_t n_off = pkg_off[blockIdx.x];
 	s_pkg[tid] = pkg[n_off + tid]; // before the size is known: the head and, for most tasks, everything
 	__syncthreads();
-	const TPanelHead hd = *reinterpret_cast<const TPanelHead*>(s_pkg);
+	// (the head field by field, its table read where it lies: a copy of the record indexed by the wave number lives in
+	// scratch memory, and a kernel that uses scratch takes longer to launch)
+	const TPanelHead *p_hd = reinterpret_cast<const TPanelHead*>(s_pkg);
+	struct { int n_cols, n_slots, n_units, n_int_rows; const int32_t *ext_ptr; } hd = {p_hd->n_cols, p_hd->n_slots, p_hd->n_units,
+		p_hd->n_int_rows, p_hd->ext_ptr};
 	for(int e = 64 * W + tid; e < hd.n_units; e += 64 * W)
 		s_pkg[e] = pkg[n_off + e];
 	const int n_cols = hd.n_cols, n_slots = hd.n_slots;
