@@ -458,54 +458,46 @@ backward_stage_kernel(TDevPlan p, const double *L, const double *Linv, double *w
 	if(c_end <= c_begin)
 		return;
 	if(D) {
-		// Fixed block size.  What a column step waits for should be x of the rows its blocks refer to and nothing else
-		// (the step before may just have written them): the column record, the record and the values of the lane group's
-		// first block, inv(L_jj) and y_j do not depend on any x and are requested a column (the records: two) ahead --
-		// a task's columns used to cost three dependent trips to memory each (record -> block record -> values)
+		// Fixed block size.  A column step should cost one trip to memory, not three (column record -> block record ->
+		// values): the records do not depend on any x, so they are requested ahead (the column's: two columns, the lane
+		// group's first block's: one), as scalars -- a record selected by a condition or copied as a whole goes through
+		// scratch memory, and a kernel with scratch takes 14 us longer to launch -- and everything a step multiplies (x of
+		// the block's row, which the step before may just have written, the block, inv(L_jj), y_j) is requested together
+		// at its start.  (Values requested a column ahead as well cost 30 more registers and a third of the waves per CU for
+		// nothing: C3's 22 backward launches 126 us that way, 122 us this way, 184 us with the three trips.)
 		enum { DN = D? D : 1 };
 		const int qq = (q < D)? q : 0;
-		// (scalars, not records: a record selected by a condition or copied as a whole goes through scratch memory,
-		// and a kernel with scratch takes 14 us longer to launch)
-		int64_t n_k0_next, n_linv, n_linv_next, n_cs, n_cs_next, n_src, n_src_next, n_loff, n_loff_next;
-		int n_nb, n_nb_next, n_xcs, n_xcs_next;
+		// column records: this column, the next one (c - 2), the one after (c - 3); block records: this column, the next one
+		int64_t n_linv, n_cs, n_src, n_k0_1, n_linv_1, n_cs_1, n_src_1, n_k0_2, n_linv_2, n_cs_2, n_src_2, n_loff, n_loff_1;
+		int n_nb, n_nb_1, n_nb_2, n_xcs, n_xcs_1;
 		{
-			const TColDesc &r_cd = p.cols[c_end - 1], &r_cd_next = p.cols[max(c_end - 2, c_begin)];
+			const TColDesc &r_cd = p.cols[c_end - 1], &r_cd_1 = p.cols[max(c_end - 2, c_begin)], &r_cd_2 = p.cols[max(c_end - 3, c_begin)];
 			n_nb = r_cd.nb; n_linv = r_cd.linv_off; n_cs = r_cd.cs_new; n_src = r_cd.cs_src;
-			n_k0_next = r_cd_next.k0; n_nb_next = r_cd_next.nb; n_linv_next = r_cd_next.linv_off; n_cs_next = r_cd_next.cs_new;
-			n_src_next = r_cd_next.cs_src;
-			const TBlkDesc &r_bd = p.blks[r_cd.k0 + min(1 + g, n_nb - 1)], &r_bd_next = p.blks[n_k0_next + min(1 + g, n_nb_next - 1)];
+			n_k0_1 = r_cd_1.k0; n_nb_1 = r_cd_1.nb; n_linv_1 = r_cd_1.linv_off; n_cs_1 = r_cd_1.cs_new; n_src_1 = r_cd_1.cs_src;
+			n_k0_2 = r_cd_2.k0; n_nb_2 = r_cd_2.nb; n_linv_2 = r_cd_2.linv_off; n_cs_2 = r_cd_2.cs_new; n_src_2 = r_cd_2.cs_src;
+			const TBlkDesc &r_bd = p.blks[r_cd.k0 + min(1 + g, n_nb - 1)], &r_bd_1 = p.blks[n_k0_1 + min(1 + g, n_nb_1 - 1)];
 			n_loff = r_bd.loff; n_xcs = r_bd.xcs;
-			n_loff_next = r_bd_next.loff; n_xcs_next = r_bd_next.xcs;
+			n_loff_1 = r_bd_1.loff; n_xcs_1 = r_bd_1.xcs;
 		}
-		double lv[DN], li[DN], y;
-		#pragma unroll
-		for(int t = 0; t < DN; ++ t) {
-			lv[t] = L[n_loff + qq * D + t];
-			li[t] = Linv[n_linv + t + qq * D];
-		}
-		y = w[n_cs + qq];
 		for(int64_t c = c_end; c > c_begin; -- c) {
-			// x of the row of this lane group's block first (no branch around the request: the address is valid either way)
-			double xv[DN];
+			// this step's numbers (no branch around the requests: the addresses are valid either way)
+			double xv[DN], lv[DN], li[DN];
 			#pragma unroll
 			for(int t = 0; t < DN; ++ t)
 				xv[t] = w[n_xcs + t];
-			// requests for the columns after this one
-			const TColDesc &r_cd_after = p.cols[max(c - 3, c_begin)];
-			const int64_t n_k0_after = r_cd_after.k0, n_linv_after = r_cd_after.linv_off, n_cs_after = r_cd_after.cs_new,
-				n_src_after = r_cd_after.cs_src;
-			const int n_nb_after = r_cd_after.nb;
-			const TBlkDesc &r_bd_after = p.blks[n_k0_after + min(1 + g, n_nb_after - 1)];
-			const int64_t n_loff_after = r_bd_after.loff;
-			const int n_xcs_after = r_bd_after.xcs;
-			double lv_next[DN], li_next[DN];
 			#pragma unroll
 			for(int t = 0; t < DN; ++ t) {
-				lv_next[t] = L[n_loff_next + qq * D + t];
-				li_next[t] = Linv[n_linv_next + t + qq * D];
+				lv[t] = L[n_loff + qq * D + t];
+				li[t] = Linv[n_linv + t + qq * D];
 			}
-			const double y_next = w[n_cs_next + qq]; // (y of another column: this column's store does not touch it)
-			// this column
+			const double y = w[n_cs + qq];
+			// records for later steps: the column three steps on, the block two steps on (its column's record is here already)
+			const TColDesc &r_cd_3 = p.cols[max(c - 4, c_begin)];
+			const int64_t n_k0_3 = r_cd_3.k0, n_linv_3 = r_cd_3.linv_off, n_cs_3 = r_cd_3.cs_new, n_src_3 = r_cd_3.cs_src;
+			const int n_nb_3 = r_cd_3.nb;
+			const TBlkDesc &r_bd_2 = p.blks[n_k0_2 + min(1 + g, n_nb_2 - 1)];
+			const int64_t n_loff_2 = r_bd_2.loff;
+			const int n_xcs_2 = r_bd_2.xcs;
 			double acc = 0;
 			#pragma unroll
 			for(int t = 0; t < DN; ++ t)
@@ -537,15 +529,11 @@ backward_stage_kernel(TDevPlan p, const double *L, const double *Linv, double *w
 				x_out[n_src + lane] = x;
 			}
 			__syncthreads(); // x_j is where the next column's blocks look for it
-			n_nb = n_nb_next; n_linv = n_linv_next; n_cs = n_cs_next; n_src = n_src_next; n_loff = n_loff_next; n_xcs = n_xcs_next;
-			n_k0_next = n_k0_after; n_nb_next = n_nb_after; n_linv_next = n_linv_after; n_cs_next = n_cs_after; n_src_next = n_src_after;
-			n_loff_next = n_loff_after; n_xcs_next = n_xcs_after;
-			#pragma unroll
-			for(int t = 0; t < DN; ++ t) {
-				lv[t] = lv_next[t];
-				li[t] = li_next[t];
-			}
-			y = y_next;
+			n_nb = n_nb_1; n_linv = n_linv_1; n_cs = n_cs_1; n_src = n_src_1;
+			n_k0_1 = n_k0_2; n_nb_1 = n_nb_2; n_linv_1 = n_linv_2; n_cs_1 = n_cs_2; n_src_1 = n_src_2;
+			n_k0_2 = n_k0_3; n_nb_2 = n_nb_3; n_linv_2 = n_linv_3; n_cs_2 = n_cs_3; n_src_2 = n_src_3;
+			n_loff = n_loff_1; n_xcs = n_xcs_1;
+			n_loff_1 = n_loff_2; n_xcs_1 = n_xcs_2;
 		}
 		return;
 	}
