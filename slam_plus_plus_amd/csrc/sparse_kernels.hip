@@ -191,25 +191,29 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 						init[i] = md.b_act? -lambda_element(A, s_blk[kb].asrc, md.r, md.q, D, D, false) : 0;
 				}
 				const int ne = cd.nr + cd.np;
-				for(int kb = 0; kb < cd.nb; ++ kb)
-					s_part[wave][kb][lane] = 0;
 				// every update (row entries of the diagonal block and pairs of the others alike) goes through one loop
 				if(W == 1) {
 					// one wave per column (the wide stages): the operand blocks are fetched whole, one coalesced 288-byte load
-					// each, eight entries = sixteen blocks in flight together, and multiplied out of LDS -- a lane fetching its
+					// each, four entries = eight blocks in flight together, and multiplied out of LDS -- a lane fetching its
 					// own twelve operands per entry kept the column 7-10 us in this loop (a sixth of the loads this way, and a
-					// twelfth of the cache lines they touch)
-					enum { BATCH = 8, DD = (D? D * D : 1) };
+					// twelfth of the cache lines they touch).  The next four entries are requested before these are
+					// multiplied; the sums start from minus the Lambda elements (they are here by the time the first operands
+					// are).  Four, not eight, at a time: 149 registers instead of 171, three waves per SIMD instead of two
+					// (C3's three wide stages 96 -> 86 us, at a million poses 1.23 -> 1.03 ms)
+					enum { BATCH = 4, DD = (D? D * D : 1) };
+					double va[BATCH], vb[BATCH], vy[BATCH];
+					#pragma unroll
+					for(int u = 0; u < BATCH; ++ u) {
+						const int e = max(min(u, ne - 1), 0); // the tail repeats the last entry: its product is skipped below
+						const longlong2 en = s_ent[e];
+						va[u] = (ne > 0)? L[en.x + (md.b_act? lane : 0)] : 0.0;
+						vb[u] = (ne > 0)? L[en.y + (md.b_act? lane : 0)] : 0.0;
+						vy[u] = (ne > 0 && b_y && s_tag[e] == 0)? w[s_ycs[e] + yq] : 0.0;
+					}
+					#pragma unroll
+					for(int i = 0; i < CH; ++ i)
+						if(i < cd.nb) s_part[0][i][lane] = init[i];
 					for(int e0 = 0; e0 < ne; e0 += BATCH) {
-						double va[BATCH], vb[BATCH], vy[BATCH];
-						#pragma unroll
-						for(int u = 0; u < BATCH; ++ u) {
-							const int e = min(e0 + u, ne - 1); // the tail repeats the last entry: its product is skipped below
-							const longlong2 en = s_ent[e];
-							va[u] = L[en.x + (md.b_act? lane : 0)];
-							vb[u] = L[en.y + (md.b_act? lane : 0)];
-							vy[u] = (b_y && s_tag[e] == 0)? w[s_ycs[e] + yq] : 0.0;
-						}
 						#pragma unroll
 						for(int u = 0; u < BATCH; ++ u) {
 							if(md.b_act) {
@@ -220,6 +224,14 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 								s_yv[u * 8 + yq] = vy[u];
 						}
 						wave_sync();
+						#pragma unroll
+						for(int u = 0; u < BATCH; ++ u) { // the next batch (clamped addresses, no branch around the requests)
+							const int e = min(e0 + BATCH + u, ne - 1);
+							const longlong2 en = s_ent[e];
+							va[u] = L[en.x + (md.b_act? lane : 0)];
+							vb[u] = L[en.y + (md.b_act? lane : 0)];
+							vy[u] = (b_y && s_tag[e] == 0)? w[s_ycs[e] + yq] : 0.0;
+						}
 						#pragma unroll
 						for(int u = 0; u < BATCH; ++ u) {
 							if(e0 + u < ne) { // wave-uniform
@@ -238,6 +250,8 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 						wave_sync();
 					}
 				} else {
+				for(int kb = 0; kb < cd.nb; ++ kb)
+					s_part[wave][kb][lane] = 0;
 				#pragma unroll 4
 				for(int e = wave; e < ne; e += W) {
 					const longlong2 en = s_ent[e];
@@ -259,10 +273,12 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 					s_part[wave][tag][lane] += sum;
 				}
 				}
-				#pragma unroll
-				for(int i = 0; i < (CH + W - 1) / W; ++ i) {
-					if(wave + i * W < cd.nb)
-						s_part[wave][wave + i * W][lane] += init[i];
+				if(W > 1) {
+					#pragma unroll
+					for(int i = 0; i < (CH + W - 1) / W; ++ i) {
+						if(wave + i * W < cd.nb)
+							s_part[wave][wave + i * W][lane] += init[i];
+					}
 				}
 			} else {
 			for(int e = tid; e < cd.np; e += 64 * W)
