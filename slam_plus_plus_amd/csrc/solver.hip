@@ -623,6 +623,7 @@ void slampp_hip_solver::Analyze_Sparse()
 					fprintf(stderr, "[setup] stage %d: %d tasks, at most %lld updates from the stage below: %s\n", s,
 						P.stage_ptr[s + 1] - P.stage_ptr[s], (long long)n_max_fresh, panel_ride[s]? "ride" : "own launch");
 			}
+			int64_t n_stage_max_slots = 0, n_stage_max_units = 0, n_stage_rest = 0; // (for the development print below)
 			for(int t = P.stage_ptr[s]; b_panel_stage && t < P.stage_ptr[s + 1]; ++ t) {
 				const int64_t c_begin = P.task_ptr[t], c_end = P.task_ptr[t + 1];
 				const int n_cols = int(c_end - c_begin);
@@ -654,6 +655,9 @@ void slampp_hip_solver::Analyze_Sparse()
 				const size_t n_units = 4 + 3 * size_t(n_cols) + 2 * size_t(n_slots) + size_t(n_int_rows + 3) / 4 + size_t(n_int_pairs + 3) / 4 +
 					2 * size_t(n_fresh);
 				b_fits = b_fits && n_units <= size_t(PANEL_UNITS);
+				n_stage_max_slots = std::max(n_stage_max_slots, n_slots);
+				n_stage_max_units = std::max(n_stage_max_units, int64_t(n_units));
+				n_stage_rest += !b_fits;
 				if(!b_fits) {
 					panel_rest.push_back(t);
 					continue;
@@ -767,6 +771,9 @@ void slampp_hip_solver::Analyze_Sparse()
 				panel_off.push_back(int64_t(n_at));
 			}
 			panel_ptr[s + 1] = int32_t(panel_off.size());
+			if(b_timing && b_panel_stage)
+				fprintf(stderr, "[setup] stage %d panels: at most %lld blocks and %lld package units per task, %lld tasks left to the column kernel\n",
+					s, (long long)n_stage_max_slots, (long long)n_stage_max_units, (long long)n_stage_rest);
 			panel_rest_ptr[s + 1] = int32_t(panel_rest.size());
 			panel_upd_ptr[s + 1] = int32_t(upd_slots.size());
 		}
