@@ -497,7 +497,7 @@ def cpu_baseline_ba(lam, flops, x_gpu):
                       f"{wall:.1f} s of CPU incl. load); OpenMP only in the block-diagonal inverse and one SpMV, dense LLT serial"}
 
 
-def incremental_leg(lam, dev, local_rank, torch, share=0.01, reps=5):
+def incremental_leg(lam, dev, local_rank, torch, share=0.01, reps=5, always=False):
     """Outside the timed region: option schur_incremental.  After a relinearization that moved `share` of the landmarks the
     reduced camera system is updated from the previous one (the reference's dog-leg solver does that from Omega = delta
     Lambda, NonlinearSolver_Lambda_DL.h:2301-) instead of rebuilt: the same solve both ways, same values."""
@@ -511,7 +511,7 @@ def incremental_leg(lam, dev, local_rank, torch, share=0.01, reps=5):
         k0, k1 = int(lam.bcol_ptr[nc + p_]), int(lam.bcol_ptr[nc + p_ + 1])
         vals2[off[k0]:off[k1 - 1]] *= 0.9
         vals2[off[k1 - 1]:off[k1]] += 0.5 * np.eye(3).ravel()
-    solver = CLinearSolver_Schur_HIP(device=local_rank, schur_incremental=1)
+    solver = CLinearSolver_Schur_HIP(device=local_rank, schur_incremental=2 if always else 1)   # 2: use the list however long it is
     solver.SymbolicDecomposition_Blocky(lam)
     v1, v2 = torch.from_numpy(lam.values).to(dev), torch.from_numpy(vals2).to(dev)
     rhs = torch.from_numpy(lam.rhs).to(dev)
@@ -534,6 +534,8 @@ def incremental_leg(lam, dev, local_rank, torch, share=0.01, reps=5):
     out["update_vs_full_rel_inf"] = float(np.abs(x_upd - x_full).max() / np.abs(x_full).max())
     out["changed_landmarks"] = int(len(points))
     out["ok"] = bool(ok)
+    out["note"] = ("option schur_incremental = 1: the list is used when it is the shorter way (up to 1/32 of the landmarks "
+                   "with the landmark-major assembly); a longer list is answered with the full rebuild")
     return out
 
 
@@ -759,7 +761,8 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
                 out["dropin_cpp"] = dropin_leg(lam, reps=3)
         if extras and schur_sparse != 0:
             out["marginals"] = marginals_leg(args, solver, lam, vals, dev, torch)
-            out["incremental_schur_update"] = incremental_leg(lam, dev, local_rank, torch)
+            out["incremental_schur_update"] = incremental_leg(lam, dev, local_rank, torch, share=0.01)       # the list is used
+            out["incremental_schur_update_10pct"] = incremental_leg(lam, dev, local_rank, torch, share=0.1)  # answered with a rebuild
             # Lambda of the same structure assembled on the device from 2-d projection residuals (one edge per observation)
             out["assembly"] = assembly_leg(solver, lam, dev, reps=5, rd=2, column_vertex_first=True)
     return out

@@ -86,7 +86,9 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
  * "schur_sparse" (Schur mode: the reduced camera system S is factored by the sparse block path instead of the dense
  * one; -1 = when fewer than 15 % of its camera-camera blocks are nonzero (default), 0 = never, 1 = always; the
  * reference makes this choice at compile time: __SCHUR_USE_DENSE_SOLVER, include/slam/LinearSolver_Schur.h:48-55, "faster if ... dense enough"),
- * "schur_incremental" (Schur mode, 0 / 1: keep the assembled reduced system for slampp_hip_schur_set_changed_points),
+ * "schur_incremental" (Schur mode, 0 / 1 / 2: keep the assembled reduced system for slampp_hip_schur_set_changed_points;
+ * 1 = a solve with a list of changed landmarks updates it when that is the shorter way -- up to 1 / 32 of the landmarks
+ * where S is assembled landmark by landmark, 1 / 4 where it comes from the contribution lists --, 2 = whenever a list is given),
  * "schur_tiles" (Schur mode: how S = A - U C^-1 U^T is assembled; -1 (default) = landmark by landmark -- runs of landmarks
  * seen by the same cameras on the matrix cores, tiles of neighbouring landmarks in LDS -- when that takes at least half of
  * the contributions, the per-block contribution lists for the rest; 0 = lists only; 1 / 2 / 3 = runs and tiles wherever

@@ -800,7 +800,7 @@ int main(int n_arg_num, const char **p_arg_list)
 				{ // incremental Schur complement: some landmarks and all cameras change, the HIP solver updates its reduced
 					// system from the previous solve, the reference solves the changed system from scratch
 					THipSchur hip_inc(base);
-					hip_inc.Set_Option("schur_incremental", 1);
+					hip_inc.Set_Option("schur_incremental", 2); // (2: update whenever a list is given, however long)
 					Eigen::VectorXd x_first = rhs;
 					bool b_ok_inc = hip_inc.Solve_PosDef(lambda, x_first);
 					CUberBlockMatrix lambda2;

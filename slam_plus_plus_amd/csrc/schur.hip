@@ -460,15 +460,11 @@ __global__ void schur_delta_A_kernel(const int64_t *ptr, const int32_t *brow, in
 }
 
 template <int DC, int DP>
-__global__ void schur_changed_points_kernel(const int64_t *__restrict__ changed, int64_t n_changed, const int64_t *ptr,
+__device__ void schur_changed_point_serial(int64_t pt, const int64_t *ptr,
 	const int32_t *brow, int64_t nc, int64_t ubase, const double *__restrict__ A, double *Cinv, double *W,
 	int64_t n_sblocks, const int32_t *__restrict__ sb_row, const int32_t *__restrict__ sb_col, double *S, int ld,
 	const int64_t *__restrict__ p_dst, int *p_flag)
 {
-	const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-	if(i >= n_changed)
-		return;
-	const int64_t pt = changed[i];
 	const int64_t k0 = ptr[nc + pt], o0 = k0 - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
 	double c_old[DP * DP], ci_old[DP * DP], c_new[DP * DP], ci_new[DP * DP];
 	#pragma unroll
@@ -546,6 +542,101 @@ __global__ void schur_changed_points_kernel(const int64_t *__restrict__ changed,
 	#pragma unroll
 	for(int t = 0; t < DP * DP; ++ t)
 		Cinv[pt * (DP * DP) + t] = ci_new[t];
+}
+
+
+// The contributions of the changed landmarks exchanged, one wave per landmark: its U and (old) W blocks in LDS, every
+// lane finds the block of S of one camera pair (a binary search: a dozen dependent trips to memory -- one thread per
+// landmark walked through k (k + 1) / 2 of them one after the other, 170 us for a list of any length), then a lane per
+// (pair, element) adds (W_b C W_a^T - U_b C_new^-1 U_a^T)(r, q) to S.  Landmarks seen by more than KMAX cameras: as before,
+// by the wave's first lane.
+template <int DC, int DP>
+__global__ void __launch_bounds__(64)
+schur_changed_points_kernel(const int64_t *__restrict__ changed, int64_t n_changed, const int64_t *ptr,
+	const int32_t *brow, int64_t nc, int64_t ubase, const double *__restrict__ A, double *Cinv, double *W,
+	int64_t n_sblocks, const int32_t *__restrict__ sb_row, const int32_t *__restrict__ sb_col, double *S, int ld,
+	const int64_t *__restrict__ p_dst, int *p_flag)
+{
+	enum { KMAX = 24, BLK = DC * DP, PMAX = KMAX * (KMAX + 1) / 2 };
+	__shared__ double s_U[KMAX * BLK], s_W[KMAX * BLK], s_wc[KMAX * BLK], s_wn[KMAX * BLK];
+	__shared__ int64_t s_dst[PMAX];
+	__shared__ int32_t s_cam[KMAX];
+	const int lane = threadIdx.x;
+	const int64_t pt = changed[blockIdx.x];
+	const int64_t k0 = ptr[nc + pt], o0 = k0 - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
+	const int k = int(o1 - o0);
+	if(k > KMAX) { // (wave-uniform)
+		if(lane == 0)
+			schur_changed_point_serial<DC, DP>(pt, ptr, brow, nc, ubase, A, Cinv, W, n_sblocks, sb_row, sb_col, S, ld, p_dst, p_flag);
+		return;
+	}
+	double c_old[DP * DP], ci_old[DP * DP], c_new[DP * DP], ci_new[DP * DP];
+	#pragma unroll
+	for(int t = 0; t < DP * DP; ++ t) {
+		ci_old[t] = Cinv[pt * (DP * DP) + t];
+		c_new[t] = A[ubase + o1 * BLK + pt * (DP * DP) + t];
+	}
+	for(int i = lane; i < k * BLK; i += 64) { // (a landmark's observations follow one another)
+		s_U[i] = A[ubase + o0 * BLK + pt * (DP * DP) + i];
+		s_W[i] = W[o0 * BLK + i];
+	}
+	if(lane < k)
+		s_cam[lane] = brow[k0 + lane];
+	spd_inverse<DP>(ci_old, c_old); // C of the previous solve
+	if(!spd_inverse<DP>(c_new, ci_new) && lane == 0)
+		atomicOr(p_flag, 1);
+	__syncthreads();
+	const int n_pairs = k * (k + 1) / 2;
+	for(int p = lane; p < n_pairs; p += 64) { // pair (b >= a) at b (b + 1) / 2 + a: the block (row cam_b, column cam_a) of S
+		int b = int((sqrtf(8.0f * float(p) + 1.0f) - 1.0f) * 0.5f);
+		while((b + 1) * (b + 2) / 2 <= p) ++ b;
+		while(b * (b + 1) / 2 > p) -- b;
+		const int a = p - b * (b + 1) / 2;
+		const int64_t cam_a = s_cam[a], cam_b = s_cam[b];
+		if(p_dst) { // binary search on the blocks' sorted keys column * nc + row
+			const int64_t key = cam_a * nc + cam_b;
+			int64_t lo = 0, hi = n_sblocks - 1;
+			while(lo < hi) {
+				const int64_t mid = (lo + hi) >> 1;
+				if(int64_t(sb_col[mid]) * nc + sb_row[mid] < key) lo = mid + 1; else hi = mid;
+			}
+			s_dst[p] = p_dst[lo];
+		} else
+			s_dst[p] = cam_b * DC + cam_a * DC * int64_t(ld);
+	}
+	for(int i = lane; i < k * BLK; i += 64) { // W_b C_old (old), U_b C^-1_new (the new W_b)
+		const int ob = i / BLK, e = i - ob * BLK, r = e % DC, q = e / DC;
+		double t_old = 0, t_new = 0;
+		#pragma unroll
+		for(int t = 0; t < DP; ++ t) {
+			t_old += s_W[ob * BLK + r + t * DC] * c_old[t + q * DP];
+			t_new += s_U[ob * BLK + r + t * DC] * ci_new[t + q * DP];
+		}
+		s_wc[i] = t_old;
+		s_wn[i] = t_new;
+	}
+	__syncthreads();
+	for(int i = lane; i < n_pairs * DC * DC; i += 64) {
+		const int p = i / (DC * DC), e = i - p * (DC * DC), q = e % DC, r = e / DC; // (q fastest: neighbouring lanes, neighbouring addresses)
+		int b = int((sqrtf(8.0f * float(p) + 1.0f) - 1.0f) * 0.5f);
+		while((b + 1) * (b + 2) / 2 <= p) ++ b;
+		while(b * (b + 1) / 2 > p) -- b;
+		const int a = p - b * (b + 1) / 2;
+		double f_old = 0, f_new = 0;
+		#pragma unroll
+		for(int t = 0; t < DP; ++ t) {
+			f_old += s_wc[b * BLK + r + t * DC] * s_W[a * BLK + q + t * DC]; // (W_b C W_a^T)(r, q)
+			f_new += s_wn[b * BLK + r + t * DC] * s_U[a * BLK + q + t * DC]; // (U_b C^-1 U_a^T)(r, q)
+		}
+		// S = A - sum U C^-1 U^T: the old term comes back, the new one goes
+		const int64_t n_at = p_dst? s_dst[p] + q + r * DC : s_dst[p] + r + q * int64_t(ld);
+		atomicAdd(S + n_at, f_old - f_new);
+	}
+	// every pair of the landmark has read the old W (from LDS): now it is replaced
+	for(int i = lane; i < k * BLK; i += 64)
+		W[o0 * BLK + i] = s_wn[i];
+	if(lane < DP * DP)
+		Cinv[pt * (DP * DP) + lane] = ci_new[lane];
 }
 
 // one workgroup of W waves per nonzero block of S: S(row, col) -= sum_e U_b W_a^T; contribution e is
@@ -1133,7 +1224,12 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 	// option "schur_incremental": what this solve assembles is kept (the dense system in a buffer of its own: the
 	// factorization works in place), and a solve that names the changed landmarks updates it instead of rebuilding it
 	const bool b_keep = s.n_schur_incremental != 0 && !s.p_allreduce && s.b_shard_primary;
-	const bool b_update = b_keep && S.b_prev_valid && S.n_changed >= 0;
+	// ... when that is the shorter way (option value 1; 2 = whenever a list is given): the update exchanges the listed
+	// landmarks' contributions with atomic adds (C4: 0.44 ms a solve at 500 landmarks, 0.46 at 5 000, 0.51 at 15 000, 0.69
+	// at 50 000) and rebuilds the reduced right-hand side; the landmark-major assembly rebuilds everything (0.55 ms a
+	// solve), the contribution lists take a millisecond longer (there the update still wins at 50 000: 4.6 against 5.5 ms)
+	const bool b_pays = s.n_schur_incremental >= 2 || S.n_changed * (S.tiles.b_enabled? 32 : 4) <= S.np;
+	const bool b_update = b_keep && S.b_prev_valid && S.n_changed >= 0 && b_pays;
 	if(b_keep) {
 		S.d_A_prev.Alloc(size_t(S.n_ablocks) * DC * DC);
 		if(!b_sparse)
@@ -1150,7 +1246,7 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 		hipLaunchKernelGGL((schur_delta_A_kernel<DC>), dim3(unsigned((n_work + 255) / 256)), dim3(256), 0, st,
 			S.d_ptr.p(), S.d_brow.p(), S.nc, A, S.d_A_prev.p(), rhs, p_S, ld, n, p_a_dst, p_r);
 		if(S.n_changed > 0)
-			hipLaunchKernelGGL((schur_changed_points_kernel<DC, DP>), dim3(unsigned((S.n_changed + 63) / 64)), dim3(64), 0, st,
+			hipLaunchKernelGGL((schur_changed_points_kernel<DC, DP>), dim3(unsigned(S.n_changed)), dim3(64), 0, st,
 				S.d_changed.p(), S.n_changed, S.d_ptr.p(), S.d_brow.p(), S.nc, ubase, A, S.d_Cinv.p(), S.d_W.p(), S.n_sblocks,
 				S.d_sb_row.p(), S.d_sb_col.p(), p_S, ld, p_sb_dst, s.d_flag.p());
 		s.Phase_End();

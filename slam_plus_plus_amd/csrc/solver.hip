@@ -1254,7 +1254,7 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 		p_solver->n_schur_sparse = int(n_value);
 	else if(s == "schur_tiles" && n_value >= -1 && n_value <= 3)
 		p_solver->n_schur_tiles = int(n_value);
-	else if(s == "schur_incremental" && n_value >= 0 && n_value <= 1)
+	else if(s == "schur_incremental" && n_value >= 0 && n_value <= 2)
 		p_solver->n_schur_incremental = int(n_value);
 	else if(s == "dense_top_tiles" && n_value >= -1 && n_value <= 1) {
 		p_solver->n_dense_top_tiles = int(n_value);

@@ -532,7 +532,7 @@ def test_incremental_update_of_the_reduced_system_matches_full_recomputation(mod
     solve of the changed system, over three relinearizations, the last one changing no landmark at all."""
     rng = np.random.default_rng(17)
     lam = synth.ba(120, 6000, k=4, mode=mode, seed=19)
-    solver = CLinearSolver_Schur_HIP(schur_incremental=1, schur_sparse=sparse, profile=1)
+    solver = CLinearSolver_Schur_HIP(schur_incremental=2, schur_sparse=sparse, profile=1)   # 2: update whenever a list is given
     eta = lam.rhs.copy()
     assert solver.Solve_PosDef(lam, eta)
     ok, x_ref, _, _ = O.solve_schur(lam)
@@ -557,6 +557,26 @@ def test_incremental_update_of_the_reduced_system_matches_full_recomputation(mod
     assert rel_inf(eta, x_ref) < TOL
     with pytest.raises(ValueError):
         CLinearSolver_Schur_HIP().Set_Changed_Landmarks([0])
+
+
+def test_incremental_update_only_where_it_pays():
+    """Option schur_incremental = 1: a list naming more than 1 / 32 of the landmarks (landmark-major assembly) is answered
+    with a full rebuild -- that is the shorter way --, a shorter list with the update; same solution either way."""
+    rng = np.random.default_rng(3)
+    lam = synth.ba(60, 6000, k=4, mode="band", seed=7)
+    solver = CLinearSolver_Schur_HIP(schur_incremental=1, profile=1)
+    assert solver.Solve_PosDef(lam, lam.rhs.copy())
+    n_pts = lam.n_bcols - lam.n_matrix_cut
+    for n_changed, b_update in ((400, False), (10, True)):
+        points = np.sort(rng.choice(n_pts, size=n_changed, replace=False))
+        lam = _relinearized(lam, points, rng)
+        ok, x_ref, _, _ = O.solve_schur(lam)
+        solver.profile(reset=True)
+        solver.Set_Changed_Landmarks(points)
+        eta = lam.rhs.copy()
+        assert ok and solver.Solve_PosDef_Blocky(lam, eta) and rel_inf(eta, x_ref) < TOL
+        phases = solver.profile()
+        assert (phases.get("schur_update", (0, 0))[0] == 1) == b_update and (_rebuilds(phases) == 0) == b_update
 
 
 def _rebuilds(phases):

@@ -7,5 +7,8 @@ from slam_plus_plus_amd import synth
 dev = torch.device("cuda:0")
 for mode in ("band", "uniform"):
     lam = synth.ba(1000, 500000, k=4, mode=mode)
-    for share in (0.001, 0.01, 0.1):
-        print(mode, share, json.dumps(bench.incremental_leg(lam, dev, 0, torch, share=share, reps=3)), flush=True)
+    for share in (0.001, 0.004, 0.01, 0.03, 0.1):
+        for always in (False, True):
+            r = bench.incremental_leg(lam, dev, 0, torch, share=share, reps=3, always=always)
+            r.pop("note", None)
+            print(mode, share, "always" if always else "when it pays", json.dumps(r), flush=True)
