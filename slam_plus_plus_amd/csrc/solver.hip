@@ -1,6 +1,9 @@
 // solver.hip -- C ABI of libslampp_hip.so (include/slampp_hip.h): handle, device memory,
 // orchestration of the sparse-Cholesky and Schur paths.  Host code only; kernels live in
 // sparse_kernels.hip / schur.hip / dense_chol.hip.
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include "solver.h"
 #include "sparse_inverse.h"
 
@@ -48,27 +51,37 @@ slampp_hip_solver::~slampp_hip_solver()
 		(void)hipStreamDestroy(stream);
 }
 
-static void Free_Pinned(double *p, bool b_registered)
+static size_t pinned_bytes(size_t n_doubles) // what Alloc_Pinned maps for that many doubles
+{
+	const size_t n_huge = size_t(2) << 20;
+	return (std::max<size_t>(n_doubles, 1) * sizeof(double) + n_huge - 1) / n_huge * n_huge;
+}
+
+static void Free_Pinned(double *p, bool b_registered, size_t n_doubles)
 {
 	if(!p)
 		return;
 	if(b_registered) {
-		(void)hipHostUnregister(p);
-		free(p);
+		// a mapping of its own, never the allocator's memory: pages the driver has pinned do not go back into a heap.  If
+		// the driver will not let go of them, the mapping stays (a leak of address space, not a block that two owners use)
+		if(hipHostUnregister(p) == hipSuccess)
+			(void)munmap(p, pinned_bytes(n_doubles));
+		else
+			(void)hipGetLastError();
 	} else
 		(void)hipHostFree(p);
 }
 
 void slampp_hip_solver::Free_Staging()
 {
-	// registered memory is the caller-side malloc block itself: unlike hipHostFree, unregistering does not wait for copies
+	// registered memory is a mapping of ours that the driver pinned: unlike hipHostFree, unregistering does not wait for copies
 	// that still read it (a handle destroyed right after an asynchronous call: memory access fault at a host address)
 	if(copy_stream)
 		(void)hipStreamSynchronize(copy_stream);
 	if(stream)
 		(void)hipStreamSynchronize(stream);
-	Free_Pinned(p_pin_values, b_pin_values_registered);
-	Free_Pinned(p_pin_rhs, b_pin_rhs_registered);
+	Free_Pinned(p_pin_values, b_pin_values_registered, n_pin_values);
+	Free_Pinned(p_pin_rhs, b_pin_rhs_registered, n_pin_rhs);
 	p_pin_values = p_pin_rhs = 0;
 	n_pin_values = n_pin_rhs = 0;
 	n_uploaded = 0;
@@ -81,10 +94,22 @@ void slampp_hip_solver::Free_Staging()
 static double *Alloc_Pinned(size_t n_doubles, bool &r_b_registered) // throw(std::bad_alloc, CDeviceError)
 {
 	const size_t n_huge = size_t(2) << 20;
-	const size_t n_bytes = (std::max<size_t>(n_doubles, 1) * sizeof(double) + n_huge - 1) / n_huge * n_huge;
+	const size_t n_bytes = pinned_bytes(n_doubles);
 	r_b_registered = false;
 	if(n_bytes >= 4 * n_huge) {
-		char *p = (char*)aligned_alloc(n_huge, n_bytes);
+		// an anonymous mapping aligned to the huge page size (mapped one huge page longer, the ends cut off)
+		char *p = 0;
+		{
+			void *p_map = mmap(0, n_bytes + n_huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+			if(p_map != MAP_FAILED) {
+				char *p_begin = (char*)p_map, *p_aligned = (char*)((uintptr_t(p_begin) + n_huge - 1) / n_huge * n_huge);
+				if(p_aligned > p_begin)
+					(void)munmap(p_begin, size_t(p_aligned - p_begin));
+				if(p_aligned + n_bytes < p_begin + n_bytes + n_huge)
+					(void)munmap(p_aligned + n_bytes, size_t((p_begin + n_bytes + n_huge) - (p_aligned + n_bytes)));
+				p = p_aligned;
+			}
+		}
 		if(p) {
 			(void)madvise(p, n_bytes, MADV_HUGEPAGE);
 			const size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8, std::thread::hardware_concurrency()), n_bytes / (8 * n_huge)));
@@ -107,7 +132,7 @@ static double *Alloc_Pinned(size_t n_doubles, bool &r_b_registered) // throw(std
 				return (double*)p;
 			}
 			(void)hipGetLastError();
-			free(p);
+			(void)munmap(p, n_bytes);
 		}
 	}
 	double *p = 0;
@@ -125,7 +150,7 @@ static void Grow_Pinned(double *&r_p, size_t &r_n, bool &r_b_registered, size_t 
 {
 	if(r_n >= n_doubles && r_p)
 		return;
-	Free_Pinned(r_p, r_b_registered);
+	Free_Pinned(r_p, r_b_registered, r_n);
 	r_p = 0;
 	r_n = 0;
 	r_p = Alloc_Pinned(n_doubles, r_b_registered);
@@ -1156,11 +1181,25 @@ int fail(slampp_hip_solver *p, int n_code, const char *p_s_msg)
 
 extern "C" {
 
+// development aid (SLAMPP_HIP_ABORT_TRACE=1): where an abort() came from, for the ones that say nothing
+static void abort_trace_handler(int n_signal)
+{
+	void *p_frames[64];
+	const int n_frames = backtrace(p_frames, 64);
+	static const char p_s_head[] = "[slampp_hip] abort: backtrace follows\n";
+	(void)!write(2, p_s_head, sizeof(p_s_head) - 1);
+	backtrace_symbols_fd(p_frames, n_frames, 2);
+	signal(n_signal, SIG_DFL);
+	raise(n_signal);
+}
+
 int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id)
 {
 	if(!pp_solver)
 		return SLAMPP_HIP_ERR_INVALID;
 	*pp_solver = 0;
+	static const bool b_trace = [] { if(getenv("SLAMPP_HIP_ABORT_TRACE")) { signal(SIGABRT, abort_trace_handler); return true; } return false; }();
+	(void)b_trace;
 	int n_count = 0;
 	if(hipGetDeviceCount(&n_count) != hipSuccess || n_count <= 0 || device_id < 0 || device_id >= n_count)
 		return SLAMPP_HIP_ERR_DEVICE; // no silent CPU fallback: without a GPU there is no solver
