@@ -57,6 +57,7 @@ class CLinearSolver_HIP_Base {
 protected:
 	slampp_hip_solver *m_p_solver; /**< @brief C ABI handle (owned; never copied) */
 	int m_n_device; /**< @brief HIP device ordinal (configuration, copied) */
+	std::vector<int> m_devices; /**< @brief HIP device ordinals of a multi-GPU solver (configuration, copied; empty = m_n_device alone) */
 	std::vector<std::pair<std::string, int64_t> > m_options; /**< @brief tuning knobs of slampp_hip_set_option (configuration, copied) */
 	bool m_b_structure_valid; /**< @brief ordering / symbolic analysis matches the last structure */
 	std::vector<int64_t> m_cumsum, m_bcol_ptr; /**< @brief structure handed to the library */
@@ -104,7 +105,10 @@ protected:
 	void Require_Handle() // throw(std::bad_alloc, std::runtime_error)
 	{
 		if(!m_p_solver) {
-			Throw_On_Error(slampp_hip_create(&m_p_solver, m_n_device));
+			if(m_devices.size() > 1) // BA systems are cut into landmark shards, one per device; pose graphs use the first one
+				Throw_On_Error(slampp_hip_create_multi(&m_p_solver, &m_devices[0], int(m_devices.size())));
+			else
+				Throw_On_Error(slampp_hip_create(&m_p_solver, m_n_device));
 			for(size_t i = 0, n = m_options.size(); i < n; ++ i)
 				Throw_On_Error(slampp_hip_set_option(m_p_solver, m_options[i].first.c_str(), m_options[i].second));
 		}
@@ -359,15 +363,23 @@ protected:
 		return true;
 	}
 
-	/** @brief b_Structure_Matches() and Gather_Values() in one: re-analyzes with analyze() if the structure changed */
+	/**
+	 *	@brief b_Structure_Matches() and Gather_Values() in one: re-analyzes with analyze() if the structure changed
+	 *	@return Returns true if the values of lambda are in the staging, false if analyze() left this object without an
+	 *		analysis of its own (the Schur class hands a lambda that lost its landmark part to its sparse solver:
+	 *		the caller then takes that route).
+	 */
 	template <class CAnalyze>
-	void Gather_Or_Reanalyze(const CUberBlockMatrix &r_lambda, CAnalyze analyze) // throw(std::bad_alloc, std::runtime_error)
+	bool Gather_Or_Reanalyze(const CUberBlockMatrix &r_lambda, CAnalyze analyze) // throw(std::bad_alloc, std::runtime_error)
 	{
 		if(!b_Structure_Matches(r_lambda) || !Gather_Values(r_lambda)) {
 			analyze();
+			if(!m_b_structure_valid)
+				return false;
 			if(!b_Structure_Matches(r_lambda) || !Gather_Values(r_lambda))
 				throw std::runtime_error("CLinearSolver_HIP: lambda changed while it was being read");
 		}
+		return true;
 	}
 
 	/**
@@ -402,6 +414,8 @@ protected:
 		if(n_result == SLAMPP_HIP_NOT_POSDEF)
 			return false;
 		Throw_On_Error(n_result);
+		if(m_devices.size() > 1 && n_Shard_Num() > 1)
+			++ n_Sharded_Solve_Counter();
 		double *p_x = &r_eta(0);
 		if(!m_order.empty()) {
 			#pragma omp parallel for schedule(static) num_threads(n_thread_num) if(n > 4096)
@@ -419,14 +433,49 @@ protected:
 	}
 
 public:
-	inline CLinearSolver_HIP_Base(int n_device = 0)
-		:m_p_solver(0), m_n_device(n_device), m_b_structure_valid(false), m_p_values(0), m_p_rhs(0), m_n_value_num(0)
+	/**
+	 *	@brief the device list of the environment: SLAMPP_HIP_DEVICES="0,1,2,3,4,5,6,7" makes every default-constructed
+	 *		solver a multi-GPU one, so that an unchanged application (slam_plus_plus -us ...) shards its BA systems over the
+	 *		node without a line of code; empty if the variable is not set or names fewer than two devices
+	 */
+	static std::vector<int> Devices_From_Environment()
+	{
+		std::vector<int> devices;
+		const char *p_s_list = getenv("SLAMPP_HIP_DEVICES");
+		while(p_s_list && *p_s_list) {
+			char *p_s_end;
+			const long n_device = strtol(p_s_list, &p_s_end, 10);
+			if(p_s_end == p_s_list)
+				break;
+			devices.push_back(int(n_device));
+			p_s_list = (*p_s_end == ',')? p_s_end + 1 : p_s_end;
+		}
+		if(devices.size() < 2)
+			devices.clear();
+		return devices;
+	}
+
+	/** @brief default constructor; n_device = -1 takes device 0, or the device list of SLAMPP_HIP_DEVICES if that is set */
+	inline CLinearSolver_HIP_Base(int n_device = -1)
+		:m_p_solver(0), m_n_device((n_device < 0)? 0 : n_device), m_b_structure_valid(false), m_p_values(0), m_p_rhs(0), m_n_value_num(0)
+	{
+		if(n_device < 0) {
+			m_devices = Devices_From_Environment();
+			if(!m_devices.empty())
+				m_n_device = m_devices[0];
+		}
+	}
+
+	/** @brief a solver over several devices of this process: BA systems (Schur) are cut into landmark shards, one per device */
+	inline CLinearSolver_HIP_Base(const std::vector<int> &r_devices)
+		:m_p_solver(0), m_n_device(r_devices.empty()? 0 : r_devices[0]), m_devices(r_devices), m_b_structure_valid(false),
+		m_p_values(0), m_p_rhs(0), m_n_value_num(0)
 	{}
 
 	/** @brief copy-constructor; copies the configuration, not the state */
 	inline CLinearSolver_HIP_Base(const CLinearSolver_HIP_Base &r_other)
-		:m_p_solver(0), m_n_device(r_other.m_n_device), m_options(r_other.m_options), m_b_structure_valid(false),
-		m_p_values(0), m_p_rhs(0), m_n_value_num(0)
+		:m_p_solver(0), m_n_device(r_other.m_n_device), m_devices(r_other.m_devices), m_options(r_other.m_options),
+		m_b_structure_valid(false), m_p_values(0), m_p_rhs(0), m_n_value_num(0)
 	{}
 
 	inline ~CLinearSolver_HIP_Base()
@@ -438,7 +487,10 @@ public:
 	/** @brief copy operator; copies the configuration, not the state */
 	inline CLinearSolver_HIP_Base &operator =(const CLinearSolver_HIP_Base &r_other)
 	{
+		if(m_p_solver && (m_n_device != r_other.m_n_device || m_devices != r_other.m_devices))
+			Free_Memory(); // the handle lives on the devices it was made for
 		m_n_device = r_other.m_n_device;
+		m_devices = r_other.m_devices;
 		m_options = r_other.m_options;
 		return *this;
 	}
@@ -485,10 +537,41 @@ public:
 		return n_counter;
 	}
 
-	/** @brief HIP device ordinal this solver runs on (part of the configuration) */
+	/** @brief number of solves all instances have run as landmark shards on more than one member (diagnostic) */
+	static size_t &n_Sharded_Solve_Counter()
+	{
+		static size_t n_counter = 0;
+		return n_counter;
+	}
+
+	/** @brief HIP device ordinal this solver runs on (part of the configuration; the first one of a device list) */
 	inline int n_Device() const
 	{
 		return m_n_device;
+	}
+
+	/** @brief the device list of a multi-GPU solver (empty = n_Device() alone) */
+	inline const std::vector<int> &r_Devices() const
+	{
+		return m_devices;
+	}
+
+	/**
+	 *	@brief members in use, their landmark ranges and the name of the exchange ("rccl (..)" / "peer") once a BA system
+	 *		was analyzed on a device list; 0 members = not sharded (one device, a pose graph, nothing analyzed yet)
+	 */
+	size_t n_Shard_Num(std::vector<int64_t> *p_point_bounds = 0, std::string *p_s_exchange = 0) const
+	{
+		int n_member_num = 0;
+		const char *p_s_name = "none";
+		int64_t p_bounds[17] = {0};
+		if(m_p_solver)
+			slampp_hip_group_info(m_p_solver, &n_member_num, p_bounds, 16, &p_s_name);
+		if(p_point_bounds)
+			p_point_bounds->assign(p_bounds, p_bounds + ((n_member_num)? n_member_num + 1 : 0));
+		if(p_s_exchange)
+			*p_s_exchange = p_s_name;
+		return size_t(n_member_num);
 	}
 
 	/** @brief clears the symbolic decomposition (the block structure of lambda is about to change) */
@@ -594,8 +677,16 @@ protected:
 public:
 	typedef CBlockwiseLinearSolverTag _Tag; /**< @brief solver type tag */
 
-	inline CLinearSolver_HIP(int n_device = 0)
-		:CLinearSolver_HIP_Base(n_device), m_factorizer(n_device)
+	inline CLinearSolver_HIP(int n_device = -1)
+		:CLinearSolver_HIP_Base(n_device), m_factorizer((n_device < 0)? 0 : n_device)
+	{}
+
+	/**
+	 *	@brief a solver over several devices: pose graphs run on the first (one elimination tree does not shard); a Schur
+	 *		solver made from this one -- as the nonlinear solvers make theirs, NonlinearSolver_Base.h:400 -- shards BA systems
+	 */
+	inline CLinearSolver_HIP(const std::vector<int> &r_devices)
+		:CLinearSolver_HIP_Base(r_devices), m_factorizer(r_devices.empty()? 0 : r_devices[0])
 	{}
 
 	/**
@@ -727,12 +818,17 @@ protected:
 	}
 
 public:
-	inline CLinearSolver_Schur_HIP(int n_device = 0)
+	inline CLinearSolver_Schur_HIP(int n_device = -1)
 		:CLinearSolver_HIP_Base(n_device), m_n_matrix_cut(size_t(-1)), m_sparse_fallback(n_device)
 	{}
 
+	/** @brief landmark shards on the listed devices (one process, one host thread per device inside the library) */
+	inline CLinearSolver_Schur_HIP(const std::vector<int> &r_devices)
+		:CLinearSolver_HIP_Base(r_devices), m_n_matrix_cut(size_t(-1)), m_sparse_fallback(r_devices.empty()? 0 : r_devices[0])
+	{}
+
 	/** @brief the reference's constructor signature (LinearSolver_Schur.h:1472): a base solver of another kind is unused */
-	inline CLinearSolver_Schur_HIP(const CBaseSolver &UNUSED(r_solver), int n_device = 0)
+	inline CLinearSolver_Schur_HIP(const CBaseSolver &UNUSED(r_solver), int n_device = -1)
 		:CLinearSolver_HIP_Base(n_device), m_n_matrix_cut(size_t(-1)), m_sparse_fallback(n_device)
 	{}
 
@@ -798,9 +894,8 @@ public:
 			SymbolicDecomposition_Blocky(r_lambda); // no ordering yet: calculate one (LinearSolver_Schur.h:1627-1628)
 		if(m_n_matrix_cut == 0 || m_n_matrix_cut == r_lambda.n_BlockColumn_Num())
 			return m_sparse_fallback.Solve_PosDef_Blocky(r_lambda, r_eta); // (checks its own cached structure)
-		Gather_Or_Reanalyze(r_lambda, [&]() { SymbolicDecomposition_Blocky(r_lambda); }); // nonconforming ordering: a new one
-		if(m_n_matrix_cut == 0 || m_n_matrix_cut == r_lambda.n_BlockColumn_Num())
-			return m_sparse_fallback.Solve_PosDef_Blocky(r_lambda, r_eta);
+		if(!Gather_Or_Reanalyze(r_lambda, [&]() { SymbolicDecomposition_Blocky(r_lambda); })) // nonconforming ordering: a new one
+			return m_sparse_fallback.Solve_PosDef_Blocky(r_lambda, r_eta); // lambda lost its landmark part between two calls
 		return Solve_Gathered(r_lambda, r_eta);
 	}
 

@@ -64,6 +64,57 @@ typedef struct slampp_hip_stats {
 /* lifecycle -- stands in for the solver object's ctor / dtor / Free_Memory()
  * (LinearSolver_CholMod.h:148-167).  device_id: HIP device ordinal. */
 int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id);
+
+/* One handle over several devices of this process (SURVEY.md section 8b proposed create(device_ids*, n_dev); section 8e:
+ * BA shards by landmark).  The reference's nonlinear solvers call their linear solver from one thread of one process
+ * (include/slam/NonlinearSolver_Base.h:344-346,400,438; NonlinearSolver_Lambda_LM.h:1543-1552), so this is how a BA
+ * solve reaches GPUs 1..n-1 behind the unchanged CLinearSolver_* calls: in SCHUR mode slampp_hip_analyze cuts the
+ * landmarks into n contiguous shards balanced by observation count (slampp_hip_landmark_shard), every device gets an
+ * internal solver and a host thread of its own, slampp_hip_factor_solve / _schur_marginals / _solve_marginal_poses send
+ * each member its landmark columns of Lambda straight from the caller's (pinned) arrays over its own PCIe link, the
+ * partial reduced camera systems are summed by an all-reduce inside the library -- RCCL bound at run time (dlopen of
+ * librccl.so, ncclCommInitAll over the device list, rings over xGMI), or a direct exchange through peer pointers where
+ * RCCL is absent or a device is listed twice (option "group_exchange": 0 = that choice, 1 = RCCL or fail, 2 = peer
+ * pointers; environment SLAMPP_HIP_GROUP_EXCHANGE=rccl|peer) -- and every member writes its landmarks' part of the
+ * solution into the caller's vector.  In SPARSE mode (pose graphs: one elimination tree, nothing to shard) the handle
+ * is a plain solver on p_device_ids[0].  n_devices = 1 is slampp_hip_create.  The entry points that take device
+ * pointers (…_device, …_device_async, slampp_hip_sync) apply to one device and return SLAMPP_HIP_ERR_INVALID on a
+ * handle that is solving with shards; slampp_hip_set_allreduce likewise (the exchange is the library's).  A device may
+ * be listed more than once (that is how the 1-GPU test boxes run two members). */
+int slampp_hip_create_multi(slampp_hip_solver **pp_solver, const int *p_device_ids, int n_devices);
+
+/* what a handle made by slampp_hip_create_multi is doing: members in use (0 = not sharded: one device, sparse mode, or
+ * not analyzed yet), the landmark range [p_point_bounds[r], p_point_bounds[r + 1]) of every member (n + 1 entries, may
+ * be NULL) and the exchange in use ("rccl (<library>)" / "peer" / "none"; valid until the next analyze) */
+int slampp_hip_group_info(const slampp_hip_solver *p_solver, int *p_member_num, int64_t *p_point_bounds, int n_max_members,
+	const char **pp_s_exchange);
+
+/* the exchange of slampp_hip_create_multi by itself, for deployment checks and tests: one member per listed device,
+ * every member fills n_count doubles with a pattern of its own, the buffers are summed twice through the members'
+ * all-reduce (n_exchange as the option "group_exchange": 0 / 1 = RCCL / 2 = peer pointers; 1 also runs with a single
+ * device: the RCCL calls themselves) and every member checks every entry.  p_s_exchange_out receives the name of the
+ * exchange used (or what went wrong). */
+int slampp_hip_group_exchange_selftest(const int *p_device_ids, int n_devices, int n_exchange, int64_t n_count,
+	char *p_s_exchange_out, int n_max_chars);
+
+/* the landmark shard a rank of a multi-GPU BA solve holds, host code only (no GPU, no handle): rank n_rank of n_world
+ * keeps block columns [0, n_matrix_cut) -- the cameras -- and a contiguous range of the landmark block columns balanced
+ * by observation count; first call with the three pointers NULL for the sizes.  The shard's packed values are values
+ * [0, n_camera_values) followed by values [n_value_begin, n_value_end) of the full system, its right-hand side entries
+ * [0, n_camera_scalars) followed by [n_scalar_begin, n_scalar_end); the camera blocks and the camera part of eta are
+ * added by one rank only (option "shard_primary").  The same rule as slam_plus_plus_amd/sharding.py. */
+typedef struct slampp_hip_shard_view {
+	int64_t n_bcols, n_blocks;
+	int64_t n_camera_values, n_value_begin, n_value_end;
+	int64_t n_camera_scalars, n_scalar_begin, n_scalar_end;
+	int64_t n_point_begin, n_point_end;
+	int64_t *p_bcol_cumsum;   /* [n_bcols + 1] */
+	int64_t *p_bcol_ptr;      /* [n_bcols + 1] */
+	int32_t *p_brow_idx;      /* [n_blocks] */
+} slampp_hip_shard_view;
+int slampp_hip_landmark_shard(int64_t n_bcols, const int64_t *p_bcol_cumsum, const int64_t *p_bcol_ptr,
+	const int32_t *p_brow_idx, int64_t n_matrix_cut, int n_rank, int n_world, slampp_hip_shard_view *p_view);
+
 void slampp_hip_destroy(slampp_hip_solver *p_solver);
 int slampp_hip_free_memory(slampp_hip_solver *p_solver);
 const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);

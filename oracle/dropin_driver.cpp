@@ -623,6 +623,24 @@ int main(int n_arg_num, const char **p_arg_list)
 			// held by the damping alone; 1e-7 between two correct solvers after four LM steps, chi2 equal to 12 digits)
 			n_fail += !(f_err < 1e-5 && fabs(f_chi2_ref - f_chi2_hip) <= 1e-10 * fabs(f_chi2_ref) && n_it_ref == n_it_hip &&
 				n_hip_calls_during_ref == 0 && n_hip_calls >= n_it_hip && n_it_hip > 0);
+			// and once more with a device list that comes from the environment, as an unchanged application would get it
+			// (SLAMPP_HIP_DEVICES; the test box has one GPU: two members on device 0 unless SLAMPP_DROPIN_DEVICES says
+			// otherwise): the LM solver's Schur solver is built from its CLinearSolver_HIP and takes the list over
+			// (NonlinearSolver_Base.h:400), every Schur solve runs as landmark shards inside the library
+			const char *p_s_devices = getenv("SLAMPP_DROPIN_DEVICES")? getenv("SLAMPP_DROPIN_DEVICES") : "0,0";
+			setenv("SLAMPP_HIP_DEVICES", p_s_devices, 1);
+			CLinearSolver_HIP_Base::n_Sharded_Solve_Counter() = 0;
+			double f_chi2_multi;
+			size_t n_it_multi;
+			std::vector<double> multi = Optimize_BA_LM<CLinearSolver_HIP>(24, 1500, 6, 99, f_chi2_multi, n_it_multi, 4, 0.0);
+			unsetenv("SLAMPP_HIP_DEVICES");
+			const size_t n_sharded = CLinearSolver_HIP_Base::n_Sharded_Solve_Counter();
+			const double f_err_multi = f_RelInf(multi, ref);
+			printf("\"ba_lm_schur_devices\": {\"devices\": \"%s\", \"chi2_ref\": %.12g, \"chi2_hip\": %.12g, \"iterations_hip\": %d, "
+				"\"state_rel_inf\": %.3g, \"sharded_solves\": %d}, ", p_s_devices, f_chi2_ref, f_chi2_multi, int(n_it_multi), f_err_multi,
+				int(n_sharded));
+			n_fail += !(f_err_multi < 1e-5 && fabs(f_chi2_ref - f_chi2_multi) <= 1e-10 * fabs(f_chi2_ref) && n_it_multi == n_it_ref &&
+				n_sharded >= n_it_multi);
 		}
 		{ // block diagonal of the covariance of a pose graph: the reference's recipe (NonlinearSolver_Lambda.h:696-760) next to Marginals()
 			typedef MakeTypelist_Safe((Eigen::Matrix<double, 6, 6>)) TBs;

@@ -1,0 +1,1007 @@
+// group.hip -- one BA system on several GPUs of ONE process: the landmark shards of SURVEY.md section 8e behind a single
+// handle (slampp_hip_create_multi), so that the reference's nonlinear solvers -- one thread of one process,
+// /root/reference/include/slam/NonlinearSolver_Base.h:344-346,400,438; NonlinearSolver_Lambda_LM.h:1543-1552 -- reach
+// every device of the node through the same CLinearSolver_* calls as they reach one.
+//
+//   * the shard splitter (slampp_hip_landmark_shard, host code, no GPU): every member keeps all cameras and a
+//     contiguous range of landmarks balanced by observation count -- the partition the reference's own GPU code
+//     relies on (C is block diagonal: src/slam/LinearSolver_Schur_GPU.cpp:2417, LinearSolver_Schur.h:1721);
+//   * one internal solver handle per device, driven by one host thread per device (HIP's current device is a
+//     per-thread setting): a member receives its own landmark columns of Lambda straight from the caller's pinned
+//     staging over its own PCIe link, member 0 ("shard_primary") also the camera blocks and the camera part of eta;
+//   * the one exchange step, a sum all-reduce of the packed blocks of S and the reduced right-hand side, through
+//     the members' all-reduce callbacks: RCCL bound at run time (dlopen: ncclCommInitAll over the device list, one
+//     communicator per member, ncclAllReduce on the member's own stream -- RCCL rings run over xGMI) or, where RCCL
+//     is absent or two members share a device (the 1-GPU test boxes), a direct exchange through peer pointers: member
+//     r sums slice r of all members' buffers, then collects the other slices -- on the xGMI mesh every link carries
+//     1/P of the buffer in each phase; sums run in member order, every member ends with the same bits;
+//   * dx is computed redundantly, dl shard-locally, each member writes its landmarks' part of the solution straight
+//     into the caller's vector.
+#include "solver.h"
+
+#include <dlfcn.h>
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+namespace slampp {
+
+enum { GROUP_MAX_MEMBERS = 16 };
+enum { EXCHANGE_AUTO = 0, EXCHANGE_RCCL = 1, EXCHANGE_PEER = 2 };
+
+// ---- the shard splitter -------------------------------------------------------------------------------------------
+
+// landmark ranges [b[r], b[r + 1]) balanced by observation count (slam_plus_plus_amd/sharding.py: shard_bounds is the
+// same rule; tests/test_sharding_host.py holds the two against each other); no range is empty while there are at
+// least as many landmarks as shards
+void shard_bounds(int64_t n_bcols, int64_t n_cut, const int64_t *p_bcol_ptr, int n_world, std::vector<int64_t> &r_bounds)
+{
+	const int64_t n_pts = n_bcols - n_cut;
+	std::vector<int64_t> cum(size_t(n_pts) + 1, 0);
+	for(int64_t p = 0; p < n_pts; ++ p)
+		cum[p + 1] = cum[p] + (p_bcol_ptr[n_cut + p + 1] - p_bcol_ptr[n_cut + p] - 1); // blocks of the column but its diagonal one
+	r_bounds.assign(size_t(n_world) + 1, 0);
+	r_bounds[n_world] = n_pts;
+	for(int r = 1; r < n_world; ++ r) {
+		const double f_target = double(cum[n_pts]) * double(r) / double(n_world);
+		const int64_t n_pos = int64_t(std::lower_bound(cum.begin(), cum.end(), f_target,
+			[](int64_t n_value, double f) { return double(n_value) < f; }) - cum.begin());
+		r_bounds[r] = std::max(r_bounds[r - 1], std::min(n_pos, n_pts));
+	}
+	if(n_pts >= n_world) {
+		for(int r = 1; r < n_world; ++ r)
+			r_bounds[r] = std::max(r_bounds[r], r_bounds[r - 1] + 1);
+		for(int r = n_world - 1; r >= 1; -- r)
+			r_bounds[r] = std::min(r_bounds[r], r_bounds[r + 1] - 1);
+	}
+}
+
+struct TShardStructure {
+	std::vector<int64_t> cumsum, bcol_ptr;
+	std::vector<int32_t> brow;
+	int64_t n_camera_values;  // packed values of the camera block columns [0, n_cut)
+	int64_t n_value_begin, n_value_end;   // this shard's landmark columns in the full packed values
+	int64_t n_camera_scalars; // dimension of the camera part
+	int64_t n_scalar_begin, n_scalar_end; // this shard's landmarks in the full right-hand side
+	int64_t n_point_begin, n_point_end;
+};
+
+void landmark_shard(int64_t n_bcols, const int64_t *p_cumsum, const int64_t *p_bcol_ptr, const int32_t *p_brow, int64_t n_cut,
+	int n_rank, int n_world, TShardStructure &r_out) // throw(std::bad_alloc, std::invalid_argument)
+{
+	if(n_cut <= 0 || n_cut >= n_bcols || n_world < 1 || n_rank < 0 || n_rank >= n_world)
+		throw std::invalid_argument("landmark_shard: n_matrix_cut must split the block columns, rank must be below world");
+	std::vector<int64_t> bounds;
+	shard_bounds(n_bcols, n_cut, p_bcol_ptr, n_world, bounds);
+	const int64_t p0 = bounds[n_rank], p1 = bounds[n_rank + 1];
+	auto value_offset_of_column = [&](int64_t n_column_begin, int64_t n_column_end) {
+		int64_t n_values = 0;
+		for(int64_t c = n_column_begin; c < n_column_end; ++ c) {
+			int64_t n_height = 0;
+			for(int64_t k = p_bcol_ptr[c]; k < p_bcol_ptr[c + 1]; ++ k)
+				n_height += p_cumsum[p_brow[k] + 1] - p_cumsum[p_brow[k]];
+			n_values += n_height * (p_cumsum[c + 1] - p_cumsum[c]);
+		}
+		return n_values;
+	};
+	r_out.n_camera_values = value_offset_of_column(0, n_cut);
+	r_out.n_value_begin = r_out.n_camera_values + value_offset_of_column(n_cut, n_cut + p0);
+	r_out.n_value_end = r_out.n_value_begin + value_offset_of_column(n_cut + p0, n_cut + p1);
+	r_out.n_camera_scalars = p_cumsum[n_cut];
+	r_out.n_scalar_begin = p_cumsum[n_cut + p0];
+	r_out.n_scalar_end = p_cumsum[n_cut + p1];
+	r_out.n_point_begin = p0;
+	r_out.n_point_end = p1;
+	const int64_t n_own = p1 - p0, n_a_blocks = p_bcol_ptr[n_cut], k0 = p_bcol_ptr[n_cut + p0], k1 = p_bcol_ptr[n_cut + p1];
+	r_out.cumsum.resize(size_t(n_cut + n_own) + 1);
+	r_out.bcol_ptr.resize(size_t(n_cut + n_own) + 1);
+	for(int64_t c = 0; c <= n_cut; ++ c) {
+		r_out.cumsum[c] = p_cumsum[c];
+		r_out.bcol_ptr[c] = p_bcol_ptr[c];
+	}
+	for(int64_t p = 0; p < n_own; ++ p) {
+		r_out.cumsum[n_cut + p + 1] = p_cumsum[n_cut + p0 + p + 1] - p_cumsum[n_cut + p0] + p_cumsum[n_cut];
+		r_out.bcol_ptr[n_cut + p + 1] = p_bcol_ptr[n_cut + p0 + p + 1] - k0 + n_a_blocks;
+	}
+	r_out.brow.resize(size_t(n_a_blocks + (k1 - k0)));
+	std::copy(p_brow, p_brow + n_a_blocks, r_out.brow.begin());
+	for(int64_t p = 0; p < n_own; ++ p) {
+		for(int64_t k = p_bcol_ptr[n_cut + p0 + p]; k < p_bcol_ptr[n_cut + p0 + p + 1]; ++ k) {
+			const int32_t n_row = p_brow[k]; // the landmarks' own (diagonal) blocks carry global row numbers
+			r_out.brow[size_t(n_a_blocks + (k - k0))] = (n_row >= n_cut)? int32_t(n_row - p0) : n_row;
+		}
+	}
+}
+
+// ---- RCCL, bound at run time --------------------------------------------------------------------------------------
+
+struct CRccl {
+	typedef int (*TCommInitAll)(void **pp_comms, int n_devices, const int *p_device_list);
+	typedef int (*TCommDestroy)(void *p_comm);
+	typedef int (*TAllReduce)(const void *p_send, void *p_recv, size_t n_count, int n_data_type, int n_op, void *p_comm, hipStream_t stream);
+	typedef const char *(*TGetErrorString)(int n_result);
+	enum { nccl_Float64 = 8, nccl_Sum = 0 }; // rccl.h: ncclDataType_t, ncclRedOp_t
+
+	void *p_library;
+	TCommInitAll CommInitAll;
+	TCommDestroy CommDestroy;
+	TAllReduce AllReduce;
+	TGetErrorString GetErrorString;
+	std::string s_where;
+
+	// process-wide: a loaded library, nothing else.  A Python caller has torch's RCCL in the process already (bound to the
+	// same HIP runtime this library binds to): that copy first; then the system's.
+	static CRccl *p_Get()
+	{
+		static CRccl *p_instance = [] () -> CRccl* {
+			std::vector<std::pair<std::string, int> > candidates;
+			if(const char *p_s_env = getenv("SLAMPP_HIP_RCCL_LIB"))
+				candidates.push_back(std::make_pair(std::string(p_s_env), RTLD_NOW | RTLD_LOCAL));
+			candidates.push_back(std::make_pair(std::string("librccl.so"), RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD));
+			candidates.push_back(std::make_pair(std::string("librccl.so.1"), RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD));
+			candidates.push_back(std::make_pair(std::string("librccl.so.1"), RTLD_NOW | RTLD_LOCAL));
+			candidates.push_back(std::make_pair(std::string("librccl.so"), RTLD_NOW | RTLD_LOCAL));
+			candidates.push_back(std::make_pair(std::string("/opt/rocm/lib/librccl.so.1"), RTLD_NOW | RTLD_LOCAL));
+			for(size_t i = 0; i < candidates.size(); ++ i) {
+				void *p_lib = dlopen(candidates[i].first.c_str(), candidates[i].second);
+				if(!p_lib)
+					continue;
+				CRccl *p = new CRccl;
+				p->p_library = p_lib;
+				p->CommInitAll = (TCommInitAll)dlsym(p_lib, "ncclCommInitAll");
+				p->CommDestroy = (TCommDestroy)dlsym(p_lib, "ncclCommDestroy");
+				p->AllReduce = (TAllReduce)dlsym(p_lib, "ncclAllReduce");
+				p->GetErrorString = (TGetErrorString)dlsym(p_lib, "ncclGetErrorString");
+				p->s_where = candidates[i].first;
+				if(p->CommInitAll && p->CommDestroy && p->AllReduce && p->GetErrorString)
+					return p;
+				delete p;
+				(void)dlclose(p_lib);
+			}
+			return 0;
+		}();
+		return p_instance;
+	}
+};
+
+// ---- host threads, one per member ---------------------------------------------------------------------------------
+
+class CMemberThreads {
+	std::vector<std::thread> m_threads;
+	std::mutex m_mutex;
+	std::condition_variable m_job_ready, m_job_done;
+	std::function<int(int)> m_job;
+	std::vector<int> m_results;
+	std::vector<uint64_t> m_seen;
+	uint64_t m_n_generation;
+	int m_n_pending;
+	bool m_b_quit;
+
+public:
+	CMemberThreads(const std::vector<int> &r_devices) // throw(std::bad_alloc, std::system_error)
+		:m_results(r_devices.size(), 0), m_seen(r_devices.size(), 0), m_n_generation(0), m_n_pending(0), m_b_quit(false)
+	{
+		try {
+			for(size_t i = 0; i < r_devices.size(); ++ i) {
+				const int n_device = r_devices[i], n_member = int(i);
+				m_threads.emplace_back([this, n_device, n_member]() {
+					(void)hipSetDevice(n_device);
+					for(;;) {
+						std::function<int(int)> job;
+						{
+							std::unique_lock<std::mutex> lock(m_mutex);
+							m_job_ready.wait(lock, [&]() { return m_b_quit || m_seen[n_member] != m_n_generation; });
+							if(m_b_quit)
+								return;
+							m_seen[n_member] = m_n_generation;
+							job = m_job;
+						}
+						int n_result;
+						try {
+							n_result = job(n_member);
+						} catch(std::bad_alloc&) {
+							n_result = SLAMPP_HIP_ERR_ALLOC;
+						} catch(std::exception&) {
+							n_result = SLAMPP_HIP_ERR_DEVICE;
+						}
+						{
+							std::lock_guard<std::mutex> lock(m_mutex);
+							m_results[n_member] = n_result;
+							if(!-- m_n_pending)
+								m_job_done.notify_all();
+						}
+					}
+				});
+			}
+		} catch(...) {
+			Quit();
+			throw;
+		}
+	}
+
+	~CMemberThreads()
+	{
+		Quit();
+	}
+
+	void Quit()
+	{
+		{
+			std::lock_guard<std::mutex> lock(m_mutex);
+			m_b_quit = true;
+		}
+		m_job_ready.notify_all();
+		for(size_t i = 0; i < m_threads.size(); ++ i) {
+			if(m_threads[i].joinable())
+				m_threads[i].join();
+		}
+		m_threads.clear();
+	}
+
+	// runs job(member) on every member's thread at once, returns when all are back; the first result that is not OK
+	// (an error before "not positive definite")
+	int n_Run(std::function<int(int)> job)
+	{
+		std::unique_lock<std::mutex> lock(m_mutex);
+		m_job = job;
+		m_n_pending = int(m_threads.size());
+		++ m_n_generation;
+		m_job_ready.notify_all();
+		m_job_done.wait(lock, [&]() { return m_n_pending == 0; });
+		int n_result = SLAMPP_HIP_OK;
+		for(size_t i = 0; i < m_results.size(); ++ i) {
+			if(m_results[i] < 0 && n_result >= 0)
+				n_result = m_results[i];
+			else if(m_results[i] > 0 && n_result == SLAMPP_HIP_OK)
+				n_result = m_results[i];
+		}
+		return n_result;
+	}
+
+	const std::vector<int> &r_Results() const
+	{
+		return m_results;
+	}
+};
+
+// a barrier the members' threads meet at inside the peer exchange; a member that fails on its way there calls Abort()
+// so that the others do not wait for it forever
+class CAbortableBarrier {
+	std::mutex m_mutex;
+	std::condition_variable m_all_here;
+	int m_n_members, m_n_waiting;
+	uint64_t m_n_generation;
+	bool m_b_aborted;
+
+public:
+	CAbortableBarrier()
+		:m_n_members(1), m_n_waiting(0), m_n_generation(0), m_b_aborted(false)
+	{}
+
+	void Reset(int n_members)
+	{
+		std::lock_guard<std::mutex> lock(m_mutex);
+		m_n_members = n_members;
+		m_n_waiting = 0;
+		m_b_aborted = false;
+	}
+
+	bool b_Wait() // false: aborted
+	{
+		std::unique_lock<std::mutex> lock(m_mutex);
+		if(m_b_aborted)
+			return false;
+		const uint64_t n_generation = m_n_generation;
+		if(++ m_n_waiting == m_n_members) {
+			m_n_waiting = 0;
+			++ m_n_generation;
+			m_all_here.notify_all();
+			return true;
+		}
+		m_all_here.wait(lock, [&]() { return m_b_aborted || m_n_generation != n_generation; });
+		return !m_b_aborted;
+	}
+
+	void Abort()
+	{
+		{
+			std::lock_guard<std::mutex> lock(m_mutex);
+			m_b_aborted = true;
+		}
+		m_all_here.notify_all();
+	}
+};
+
+// ---- the direct exchange through peer pointers --------------------------------------------------------------------
+
+struct TPeerBuffers {
+	double *p[GROUP_MAX_MEMBERS];
+};
+
+// buffer[me][i] = sum over the members, in member order, for i in this member's slice
+__global__ void group_reduce_slice_kernel(TPeerBuffers t_buffers, int n_members, int n_me, size_t n_begin, size_t n_end)
+{
+	for(size_t i = n_begin + size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_end; i += size_t(gridDim.x) * blockDim.x) {
+		double f_sum = 0;
+		for(int k = 0; k < n_members; ++ k)
+			f_sum += t_buffers.p[k][i];
+		t_buffers.p[n_me][i] = f_sum;
+	}
+}
+
+// the other members' finished slices into this member's buffer
+__global__ void group_gather_slices_kernel(TPeerBuffers t_buffers, int n_members, int n_me, size_t n_count)
+{
+	for(int k = 0; k < n_members; ++ k) {
+		if(k == n_me)
+			continue;
+		const size_t n_begin = n_count * size_t(k) / size_t(n_members), n_end = n_count * size_t(k + 1) / size_t(n_members);
+		const double *__restrict__ p_src = t_buffers.p[k];
+		double *__restrict__ p_dst = t_buffers.p[n_me];
+		for(size_t i = n_begin + size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_end; i += size_t(gridDim.x) * blockDim.x)
+			p_dst[i] = p_src[i];
+	}
+}
+
+// ---- the group ----------------------------------------------------------------------------------------------------
+
+struct CDeviceGroup;
+
+struct TMemberContext {
+	CDeviceGroup *p_group;
+	int n_member;
+};
+
+struct TMemberShard {
+	TShardStructure t_structure;
+	double *p_values_dev, *p_rhs_dev, *p_cov_dev; // on the member's device
+	size_t n_values_dev, n_rhs_dev, n_cov_dev;
+	TMemberShard() :p_values_dev(0), p_rhs_dev(0), p_cov_dev(0), n_values_dev(0), n_rhs_dev(0), n_cov_dev(0) {}
+};
+
+struct CDeviceGroup {
+	std::vector<int> devices;
+	std::vector<slampp_hip_solver*> members;
+	std::vector<TMemberContext> contexts;
+	std::vector<TMemberShard> shards;
+	CMemberThreads *p_threads;
+	int n_active; // members that hold landmarks (all of them unless the system has fewer landmarks than the list has devices)
+	int n_exchange_option, n_exchange; // EXCHANGE_*: as asked for, as resolved
+	std::vector<void*> comms; // RCCL communicators, one per active member
+	CAbortableBarrier barrier;
+	TPeerBuffers t_peer_buffers;
+	size_t peer_counts[GROUP_MAX_MEMBERS];
+	std::string s_exchange_name;
+
+	CDeviceGroup() :p_threads(0), n_active(0), n_exchange_option(EXCHANGE_AUTO), n_exchange(EXCHANGE_PEER) {}
+};
+
+static void grow_device(double *&r_p, size_t &r_n, size_t n_doubles) // on the calling thread's device; throws
+{
+	if(r_p && r_n >= n_doubles)
+		return;
+	if(r_p)
+		(void)hipFree(r_p);
+	r_p = 0;
+	r_n = 0;
+	const hipError_t e = hipMalloc((void**)&r_p, std::max<size_t>(n_doubles, 1) * sizeof(double));
+	if(e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+		(void)hipGetLastError();
+		r_p = 0;
+		throw std::bad_alloc();
+	}
+	if(e != hipSuccess) {
+		r_p = 0;
+		throw CDeviceError(std::string("hipMalloc: ") + hipGetErrorString(e));
+	}
+	r_n = n_doubles;
+}
+
+static int group_allreduce_callback(void *p_context, double *p_dev, size_t n_count, void *p_hip_stream)
+{
+	TMemberContext &t = *(TMemberContext*)p_context;
+	CDeviceGroup &g = *t.p_group;
+	const int r = t.n_member, n_members = g.n_active;
+	hipStream_t stream = (hipStream_t)p_hip_stream;
+	if(g.n_exchange == EXCHANGE_RCCL) {
+		CRccl *p_rccl = CRccl::p_Get();
+		const int n_result = p_rccl->AllReduce(p_dev, p_dev, n_count, CRccl::nccl_Float64, CRccl::nccl_Sum, g.comms[r], stream);
+		if(n_result != 0) {
+			fprintf(stderr, "libslampp_hip: ncclAllReduce failed on member %d: %s\n", r, p_rccl->GetErrorString(n_result));
+			return 1;
+		}
+		return 0;
+	}
+	// peer pointers: everybody's partial buffer complete and announced; slice r summed here; the other slices collected;
+	// nobody moves on (and writes its buffer again) before everybody has read what it needs
+	g.t_peer_buffers.p[r] = p_dev;
+	g.peer_counts[r] = n_count;
+	if(hipStreamSynchronize(stream) != hipSuccess) {
+		g.barrier.Abort();
+		return 1;
+	}
+	if(!g.barrier.b_Wait())
+		return 1;
+	for(int k = 0; k < n_members; ++ k) {
+		if(g.peer_counts[k] != n_count) {
+			g.barrier.Abort();
+			return 1; // the members do not agree on what they exchange
+		}
+	}
+	const TPeerBuffers t_buffers = g.t_peer_buffers;
+	const size_t n_begin = n_count * size_t(r) / size_t(n_members), n_end = n_count * size_t(r + 1) / size_t(n_members);
+	if(n_end > n_begin) {
+		const unsigned n_grid = unsigned(std::min<size_t>((n_end - n_begin + 255) / 256, 2048));
+		hipLaunchKernelGGL(group_reduce_slice_kernel, dim3(n_grid), dim3(256), 0, stream, t_buffers, n_members, r, n_begin, n_end);
+	}
+	if(hipStreamSynchronize(stream) != hipSuccess) {
+		g.barrier.Abort();
+		return 1;
+	}
+	if(!g.barrier.b_Wait())
+		return 1;
+	{
+		const unsigned n_grid = unsigned(std::min<size_t>((n_count / size_t(n_members) + 255) / 256 + 1, 2048));
+		hipLaunchKernelGGL(group_gather_slices_kernel, dim3(n_grid), dim3(256), 0, stream, t_buffers, n_members, r, n_count);
+	}
+	if(hipStreamSynchronize(stream) != hipSuccess) {
+		g.barrier.Abort();
+		return 1;
+	}
+	return g.barrier.b_Wait()? 0 : 1;
+}
+
+CDeviceGroup *group_create(const int *p_device_ids, int n_devices) // throw(std::bad_alloc, std::invalid_argument, CDeviceError)
+{
+	if(!p_device_ids || n_devices < 1 || n_devices > GROUP_MAX_MEMBERS)
+		throw std::invalid_argument("a device group takes 1 to 16 devices");
+	int n_count = 0;
+	if(hipGetDeviceCount(&n_count) != hipSuccess || n_count <= 0)
+		throw CDeviceError("no HIP device");
+	CDeviceGroup *p_group = new CDeviceGroup;
+	CDeviceGroup &g = *p_group;
+	try {
+		g.devices.assign(p_device_ids, p_device_ids + n_devices);
+		for(int i = 0; i < n_devices; ++ i) {
+			if(g.devices[i] < 0 || g.devices[i] >= n_count)
+				throw std::invalid_argument("device group: no such device");
+		}
+		g.members.assign(size_t(n_devices), (slampp_hip_solver*)0);
+		g.shards.resize(size_t(n_devices));
+		g.contexts.resize(size_t(n_devices));
+		for(int i = 0; i < n_devices; ++ i) {
+			g.contexts[i].p_group = p_group;
+			g.contexts[i].n_member = i;
+			const int n_result = slampp_hip_create(&g.members[i], g.devices[i]);
+			if(n_result == SLAMPP_HIP_ERR_ALLOC)
+				throw std::bad_alloc();
+			if(n_result != SLAMPP_HIP_OK)
+				throw CDeviceError("device group: cannot create a member");
+		}
+		g.p_threads = new CMemberThreads(g.devices);
+	} catch(...) {
+		group_destroy(p_group);
+		throw;
+	}
+	return p_group;
+}
+
+static void group_release_exchange(CDeviceGroup &g)
+{
+	if(!g.comms.empty()) {
+		if(CRccl *p_rccl = CRccl::p_Get()) {
+			for(size_t i = 0; i < g.comms.size(); ++ i) {
+				if(g.comms[i])
+					(void)p_rccl->CommDestroy(g.comms[i]);
+			}
+		}
+		g.comms.clear();
+	}
+}
+
+void group_destroy(CDeviceGroup *p_group)
+{
+	if(!p_group)
+		return;
+	CDeviceGroup &g = *p_group;
+	if(g.p_threads) {
+		g.p_threads->n_Run([&g](int r) -> int { // every member's memory goes on its own thread (its own device)
+			TMemberShard &t = g.shards[r];
+			if(t.p_values_dev) (void)hipFree(t.p_values_dev);
+			if(t.p_rhs_dev) (void)hipFree(t.p_rhs_dev);
+			if(t.p_cov_dev) (void)hipFree(t.p_cov_dev);
+			t.p_values_dev = t.p_rhs_dev = t.p_cov_dev = 0;
+			return SLAMPP_HIP_OK;
+		});
+	}
+	group_release_exchange(g);
+	delete g.p_threads;
+	g.p_threads = 0;
+	for(size_t i = 0; i < g.members.size(); ++ i)
+		slampp_hip_destroy(g.members[i]);
+	delete p_group;
+}
+
+int group_set_option(CDeviceGroup &g, const char *p_s_name, int64_t n_value)
+{
+	if(!strcmp(p_s_name, "group_exchange")) {
+		if(n_value < EXCHANGE_AUTO || n_value > EXCHANGE_PEER)
+			return SLAMPP_HIP_ERR_INVALID;
+		g.n_exchange_option = int(n_value);
+		return SLAMPP_HIP_OK;
+	}
+	if(!strcmp(p_s_name, "shard_primary") || !strcmp(p_s_name, "shard_rank") || !strcmp(p_s_name, "shard_world"))
+		return SLAMPP_HIP_OK; // the group decides those for its members
+	int n_result = SLAMPP_HIP_OK;
+	for(size_t i = 0; i < g.members.size() && n_result == SLAMPP_HIP_OK; ++ i)
+		n_result = slampp_hip_set_option(g.members[i], p_s_name, n_value);
+	return n_result;
+}
+
+const char *group_exchange_name(const CDeviceGroup &g)
+{
+	return g.s_exchange_name.c_str();
+}
+
+int group_member_num(const CDeviceGroup &g)
+{
+	return g.n_active;
+}
+
+slampp_hip_solver *group_member(CDeviceGroup &g, int n_member)
+{
+	return (n_member >= 0 && n_member < int(g.members.size()))? g.members[n_member] : 0;
+}
+
+static void group_resolve_exchange(CDeviceGroup &g) // throw(CDeviceError)
+{
+	group_release_exchange(g);
+	const int n = g.n_active;
+	bool b_distinct = true;
+	for(int i = 0; i < n; ++ i) {
+		for(int j = 0; j < i; ++ j)
+			b_distinct = b_distinct && g.devices[i] != g.devices[j];
+	}
+	int n_want = g.n_exchange_option;
+	if(const char *p_s_env = getenv("SLAMPP_HIP_GROUP_EXCHANGE")) {
+		if(!strcmp(p_s_env, "rccl"))
+			n_want = EXCHANGE_RCCL;
+		else if(!strcmp(p_s_env, "peer"))
+			n_want = EXCHANGE_PEER;
+	}
+	const bool b_one_member_rccl = n == 1 && n_want == EXCHANGE_RCCL; // (the exchange self-test: the RCCL calls themselves, on a 1-GPU box)
+	CRccl *p_rccl = (n_want != EXCHANGE_PEER && (n > 1 || b_one_member_rccl))? CRccl::p_Get() : 0;
+	if(n_want == EXCHANGE_RCCL) {
+		if(!p_rccl)
+			throw CDeviceError("device group: RCCL was asked for (group_exchange = 1) and librccl.so cannot be loaded");
+		if(!b_distinct)
+			throw CDeviceError("device group: RCCL needs distinct devices (group_exchange = 1 with a device listed twice)");
+	}
+	if((n > 1 || b_one_member_rccl) && p_rccl && b_distinct) {
+		g.comms.assign(size_t(n), (void*)0);
+		const int n_result = p_rccl->CommInitAll(&g.comms[0], n, &g.devices[0]);
+		if(n_result != 0) {
+			g.comms.clear();
+			if(n_want == EXCHANGE_RCCL)
+				throw CDeviceError(std::string("device group: ncclCommInitAll failed: ") + p_rccl->GetErrorString(n_result));
+			fprintf(stderr, "libslampp_hip: ncclCommInitAll failed (%s): the members exchange through peer pointers instead\n",
+				p_rccl->GetErrorString(n_result));
+		} else {
+			g.n_exchange = EXCHANGE_RCCL;
+			g.s_exchange_name = "rccl (" + p_rccl->s_where + ")";
+			return;
+		}
+	}
+	g.n_exchange = EXCHANGE_PEER;
+	g.s_exchange_name = (n > 1)? "peer" : "none (one member)";
+	for(int i = 0; i < n; ++ i) { // every member reads every other member's buffer
+		for(int j = 0; j < n; ++ j) {
+			if(g.devices[i] == g.devices[j])
+				continue;
+			int b_can = 0;
+			if(hipDeviceCanAccessPeer(&b_can, g.devices[i], g.devices[j]) != hipSuccess || !b_can)
+				throw CDeviceError("device group: the devices cannot read each other's memory and RCCL is not available");
+			(void)hipSetDevice(g.devices[i]);
+			const hipError_t e = hipDeviceEnablePeerAccess(g.devices[j], 0);
+			if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+				throw CDeviceError(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+			(void)hipGetLastError();
+		}
+	}
+}
+
+// splits the front handle's structure into landmark shards and analyzes every member (Schur mode) on its own thread
+void group_analyze(slampp_hip_solver &r_front, int64_t n_cut) // throws
+{
+	CDeviceGroup &g = *r_front.p_group;
+	const int64_t n_bcols = int64_t(r_front.cumsum.size()) - 1, n_points = n_bcols - n_cut;
+	const int n_active = int(std::min<int64_t>(int64_t(g.members.size()), n_points));
+	g.n_active = n_active;
+	for(int r = 0; r < n_active; ++ r) {
+		landmark_shard(n_bcols, &r_front.cumsum[0], &r_front.bcol_ptr[0], r_front.brow.empty()? 0 : &r_front.brow[0], n_cut,
+			r, n_active, g.shards[r].t_structure);
+	}
+	group_resolve_exchange(g);
+	(void)hipSetDevice(r_front.n_device);
+	g.barrier.Reset(n_active);
+	std::vector<std::string> errors(g.members.size());
+	const int n_result = g.p_threads->n_Run([&](int r) -> int {
+		slampp_hip_solver *p_member = g.members[r];
+		if(r >= n_active)
+			return slampp_hip_free_memory(p_member);
+		const TShardStructure &t = g.shards[r].t_structure;
+		int n_status = slampp_hip_set_option(p_member, "shard_primary", r == 0);
+		if(n_status == SLAMPP_HIP_OK)
+			n_status = slampp_hip_set_option(p_member, "shard_rank", r);
+		if(n_status == SLAMPP_HIP_OK)
+			n_status = slampp_hip_set_option(p_member, "shard_world", n_active);
+		if(n_status == SLAMPP_HIP_OK) {
+			n_status = slampp_hip_set_structure(p_member, int64_t(t.cumsum.size()) - 1, &t.cumsum[0], &t.bcol_ptr[0],
+				t.brow.empty()? 0 : &t.brow[0]);
+		}
+		if(n_status == SLAMPP_HIP_OK)
+			n_status = slampp_hip_analyze(p_member, SLAMPP_HIP_MODE_SCHUR, n_cut);
+		if(n_status == SLAMPP_HIP_OK) {
+			n_status = slampp_hip_set_allreduce(p_member, (n_active > 1)? group_allreduce_callback : (slampp_hip_allreduce_fn)0,
+				&g.contexts[r]);
+		}
+		if(n_status == SLAMPP_HIP_OK) {
+			TMemberShard &t_shard = g.shards[r];
+			grow_device(t_shard.p_values_dev, t_shard.n_values_dev, size_t(t.n_camera_values + (t.n_value_end - t.n_value_begin)));
+			grow_device(t_shard.p_rhs_dev, t_shard.n_rhs_dev, size_t(t.n_camera_scalars + (t.n_scalar_end - t.n_scalar_begin)));
+			if(r != 0) { // a member that is not the primary never reads the camera blocks or the camera part of eta: zeros, once
+				if(hipMemset(t_shard.p_values_dev, 0, size_t(t.n_camera_values) * sizeof(double)) != hipSuccess ||
+				   hipMemset(t_shard.p_rhs_dev, 0, size_t(t.n_camera_scalars) * sizeof(double)) != hipSuccess)
+					n_status = SLAMPP_HIP_ERR_DEVICE;
+			}
+		}
+		if(n_status != SLAMPP_HIP_OK)
+			errors[r] = slampp_hip_last_error(p_member);
+		return n_status;
+	});
+	if(n_result == SLAMPP_HIP_ERR_ALLOC)
+		throw std::bad_alloc();
+	if(n_result != SLAMPP_HIP_OK) {
+		std::string s_what = "device group: analysis of a member failed";
+		for(size_t r = 0; r < errors.size(); ++ r) {
+			if(!errors[r].empty())
+				s_what += " (member " + std::to_string(r) + ": " + errors[r] + ")";
+		}
+		if(n_result == SLAMPP_HIP_ERR_UNSUPPORTED)
+			throw std::domain_error(s_what);
+		if(n_result == SLAMPP_HIP_ERR_INVALID)
+			throw std::invalid_argument(s_what);
+		throw CDeviceError(s_what);
+	}
+}
+
+static int group_finish(slampp_hip_solver &r_front, CDeviceGroup &g, int n_result, const std::vector<std::string> &r_errors)
+{
+	(void)hipSetDevice(r_front.n_device);
+	if(n_result == SLAMPP_HIP_OK)
+		return n_result;
+	if(n_result == SLAMPP_HIP_NOT_POSDEF) {
+		r_front.s_error = "matrix is not positive definite";
+		return n_result;
+	}
+	r_front.s_error = "device group:";
+	for(size_t r = 0; r < r_errors.size(); ++ r) {
+		if(!r_errors[r].empty())
+			r_front.s_error += " member " + std::to_string(r) + ": " + r_errors[r] + ";";
+	}
+	g.barrier.Reset(g.n_active); // (an aborted exchange leaves the barrier closed)
+	return n_result;
+}
+
+enum { GROUP_SOLVE = 0, GROUP_MARGINAL_POSES = 1 };
+
+// p_values / p_rhs_inout: the FULL system's packed values and right-hand side on the host (pinned staging or any array)
+static int group_solve_kind(slampp_hip_solver &r_front, const double *p_values, double *p_rhs_inout, int n_kind)
+{
+	CDeviceGroup &g = *r_front.p_group;
+	const int n_active = g.n_active;
+	std::vector<std::string> errors(g.members.size());
+	const double f_t0 = wall_ms();
+	std::vector<double> upload_ms(g.members.size(), 0.0), solve_ms(g.members.size(), 0.0);
+	const int n_result = g.p_threads->n_Run([&](int r) -> int {
+		if(r >= n_active)
+			return SLAMPP_HIP_OK;
+		slampp_hip_solver *p_member = g.members[r];
+		TMemberShard &t_shard = g.shards[r];
+		const TShardStructure &t = t_shard.t_structure;
+		hipStream_t stream = p_member->stream;
+		const size_t n_own_values = size_t(t.n_value_end - t.n_value_begin), n_own_scalars = size_t(t.n_scalar_end - t.n_scalar_begin);
+		int n_status = SLAMPP_HIP_OK;
+		const double f_m0 = wall_ms();
+		hipError_t e = hipSuccess;
+		if(r == 0 && n_kind == GROUP_SOLVE) { // the primary adds A and the camera part of eta
+			e = hipMemcpyAsync(t_shard.p_values_dev, p_values, size_t(t.n_camera_values) * sizeof(double), hipMemcpyHostToDevice, stream);
+			if(e == hipSuccess)
+				e = hipMemcpyAsync(t_shard.p_rhs_dev, p_rhs_inout, size_t(t.n_camera_scalars) * sizeof(double), hipMemcpyHostToDevice, stream);
+		}
+		if(e == hipSuccess)
+			e = hipMemcpyAsync(t_shard.p_values_dev + t.n_camera_values, p_values + t.n_value_begin, n_own_values * sizeof(double),
+				hipMemcpyHostToDevice, stream);
+		if(e == hipSuccess)
+			e = hipMemcpyAsync(t_shard.p_rhs_dev + t.n_camera_scalars, p_rhs_inout + t.n_scalar_begin, n_own_scalars * sizeof(double),
+				hipMemcpyHostToDevice, stream);
+		if(e != hipSuccess) {
+			errors[r] = std::string("upload: ") + hipGetErrorString(e);
+			g.barrier.Abort();
+			return SLAMPP_HIP_ERR_DEVICE;
+		}
+		upload_ms[r] = wall_ms() - f_m0;
+		n_status = (n_kind == GROUP_SOLVE)? slampp_hip_factor_solve_device_async(p_member, t_shard.p_values_dev, t_shard.p_rhs_dev) :
+			slampp_hip_solve_marginal_poses_device_async(p_member, t_shard.p_values_dev, t_shard.p_rhs_dev);
+		if(n_status == SLAMPP_HIP_OK) {
+			// the solution comes back behind the solve: every member its own landmarks, the primary the cameras as well
+			e = hipMemcpyAsync(p_rhs_inout + t.n_scalar_begin, t_shard.p_rhs_dev + t.n_camera_scalars, n_own_scalars * sizeof(double),
+				hipMemcpyDeviceToHost, stream);
+			if(e == hipSuccess && r == 0)
+				e = hipMemcpyAsync(p_rhs_inout, t_shard.p_rhs_dev, size_t(t.n_camera_scalars) * sizeof(double), hipMemcpyDeviceToHost, stream);
+			if(e != hipSuccess) {
+				errors[r] = std::string("download: ") + hipGetErrorString(e);
+				n_status = SLAMPP_HIP_ERR_DEVICE;
+			}
+		}
+		if(n_status == SLAMPP_HIP_OK)
+			n_status = slampp_hip_sync(p_member);
+		else
+			g.barrier.Abort(); // the others may be waiting for this member in the exchange
+		if(n_status < 0 && errors[r].empty())
+			errors[r] = slampp_hip_last_error(p_member);
+		solve_ms[r] = wall_ms() - f_m0;
+		return n_status;
+	});
+	r_front.times.upload_ms = *std::max_element(upload_ms.begin(), upload_ms.end());
+	r_front.times.schur_ms = *std::max_element(solve_ms.begin(), solve_ms.end());
+	r_front.times.total_ms = wall_ms() - f_t0;
+	return group_finish(r_front, g, n_result, errors);
+}
+
+int group_factor_solve(slampp_hip_solver &r_front, const double *p_values, double *p_rhs_inout)
+{
+	return group_solve_kind(r_front, p_values, p_rhs_inout, GROUP_SOLVE);
+}
+
+int group_solve_marginal_poses(slampp_hip_solver &r_front, const double *p_values, double *p_rhs_inout)
+{
+	const int n_result = group_solve_kind(r_front, p_values, p_rhs_inout, GROUP_MARGINAL_POSES);
+	if(n_result == SLAMPP_HIP_OK) // (no member was given the camera part: it comes back as the zeros the call defines)
+		memset(p_rhs_inout, 0, size_t(r_front.cumsum[size_t(r_front.n_matrix_cut)]) * sizeof(double));
+	return n_result;
+}
+
+// block-diagonal covariances: every member its own landmarks, the primary the cameras
+int group_schur_marginals(slampp_hip_solver &r_front, const double *p_values, double *p_cam_cov, double *p_point_cov)
+{
+	CDeviceGroup &g = *r_front.p_group;
+	const int n_active = g.n_active;
+	const int64_t n_cut = r_front.n_matrix_cut;
+	const int64_t dc = r_front.cumsum[1] - r_front.cumsum[0], dp = r_front.cumsum[size_t(n_cut) + 1] - r_front.cumsum[size_t(n_cut)];
+	const size_t n_cam_doubles = size_t(n_cut * dc * dc);
+	std::vector<std::string> errors(g.members.size());
+	const int n_result = g.p_threads->n_Run([&](int r) -> int {
+		if(r >= n_active)
+			return SLAMPP_HIP_OK;
+		slampp_hip_solver *p_member = g.members[r];
+		TMemberShard &t_shard = g.shards[r];
+		const TShardStructure &t = t_shard.t_structure;
+		hipStream_t stream = p_member->stream;
+		const size_t n_own_values = size_t(t.n_value_end - t.n_value_begin);
+		const size_t n_own_doubles = size_t((t.n_point_end - t.n_point_begin) * dp * dp);
+		const bool b_cams = r == 0 && p_cam_cov != 0;
+		try {
+			grow_device(t_shard.p_cov_dev, t_shard.n_cov_dev, n_cam_doubles + n_own_doubles);
+		} catch(std::exception &r_exc) {
+			errors[r] = r_exc.what();
+			g.barrier.Abort();
+			return SLAMPP_HIP_ERR_ALLOC;
+		}
+		hipError_t e = hipSuccess;
+		if(r == 0)
+			e = hipMemcpyAsync(t_shard.p_values_dev, p_values, size_t(t.n_camera_values) * sizeof(double), hipMemcpyHostToDevice, stream);
+		if(e == hipSuccess)
+			e = hipMemcpyAsync(t_shard.p_values_dev + t.n_camera_values, p_values + t.n_value_begin, n_own_values * sizeof(double),
+				hipMemcpyHostToDevice, stream);
+		if(e != hipSuccess) {
+			errors[r] = std::string("upload: ") + hipGetErrorString(e);
+			g.barrier.Abort();
+			return SLAMPP_HIP_ERR_DEVICE;
+		}
+		int n_status = slampp_hip_schur_marginals_device_async(p_member, t_shard.p_values_dev, b_cams? t_shard.p_cov_dev : 0,
+			(p_point_cov || !b_cams)? t_shard.p_cov_dev + n_cam_doubles : 0);
+		if(n_status == SLAMPP_HIP_OK)
+			n_status = slampp_hip_sync(p_member);
+		else
+			g.barrier.Abort();
+		if(n_status == SLAMPP_HIP_OK) {
+			if(b_cams)
+				e = hipMemcpyAsync(p_cam_cov, t_shard.p_cov_dev, n_cam_doubles * sizeof(double), hipMemcpyDeviceToHost, stream);
+			if(e == hipSuccess && p_point_cov)
+				e = hipMemcpyAsync(p_point_cov + size_t(t.n_point_begin * dp * dp), t_shard.p_cov_dev + n_cam_doubles,
+					n_own_doubles * sizeof(double), hipMemcpyDeviceToHost, stream);
+			if(e == hipSuccess)
+				e = hipStreamSynchronize(stream);
+			if(e != hipSuccess) {
+				errors[r] = std::string("download: ") + hipGetErrorString(e);
+				n_status = SLAMPP_HIP_ERR_DEVICE;
+			}
+		}
+		if(n_status < 0 && errors[r].empty())
+			errors[r] = slampp_hip_last_error(p_member);
+		return n_status;
+	});
+	return group_finish(r_front, g, n_result, errors);
+}
+
+int group_free_memory(CDeviceGroup &g)
+{
+	group_release_exchange(g);
+	return g.p_threads->n_Run([&g](int r) -> int {
+		TMemberShard &t = g.shards[r];
+		if(t.p_values_dev) (void)hipFree(t.p_values_dev);
+		if(t.p_rhs_dev) (void)hipFree(t.p_rhs_dev);
+		if(t.p_cov_dev) (void)hipFree(t.p_cov_dev);
+		t.p_values_dev = t.p_rhs_dev = t.p_cov_dev = 0;
+		t.n_values_dev = t.n_rhs_dev = t.n_cov_dev = 0;
+		return slampp_hip_free_memory(g.members[r]);
+	});
+}
+
+void group_fill_stats(CDeviceGroup &g, slampp_hip_stats &r_stats)
+{
+	slampp_hip_stats t_sum;
+	memset(&t_sum, 0, sizeof(t_sum));
+	for(int r = 0; r < g.n_active; ++ r) {
+		slampp_hip_stats t;
+		if(slampp_hip_get_stats(g.members[r], &t) != SLAMPP_HIP_OK)
+			continue;
+		if(r == 0) {
+			r_stats.n_cams = t.n_cams;
+			r_stats.schur_dim = t.schur_dim;
+			r_stats.l_blocks = t.l_blocks;
+			r_stats.factor_flops = t.factor_flops;
+			r_stats.solve_flops = t.solve_flops;
+		}
+		t_sum.n_points += t.n_points;
+		t_sum.n_observations += t.n_observations;
+		t_sum.n_update_pairs += t.n_update_pairs;
+		t_sum.device_bytes += t.device_bytes;
+	}
+	r_stats.n_points = t_sum.n_points;
+	r_stats.n_observations = t_sum.n_observations;
+	r_stats.n_update_pairs = t_sum.n_update_pairs;
+	r_stats.device_bytes += t_sum.device_bytes;
+	for(int r = 0; r < g.n_active; ++ r) {
+		const TMemberShard &t = g.shards[r];
+		r_stats.device_bytes += int64_t((t.n_values_dev + t.n_rhs_dev + t.n_cov_dev) * sizeof(double));
+	}
+}
+
+// the exchange by itself: every member fills a buffer with a pattern of its own, the buffers are summed through the
+// members' callback, every member checks every entry
+int group_exchange_selftest(const int *p_device_ids, int n_devices, int n_exchange, size_t n_count, std::string &r_s_what)
+{
+	CDeviceGroup *p_group = group_create(p_device_ids, n_devices);
+	CDeviceGroup &g = *p_group;
+	int n_result = SLAMPP_HIP_OK;
+	try {
+		g.n_active = n_devices;
+		g.n_exchange_option = n_exchange;
+		group_resolve_exchange(g);
+		g.barrier.Reset(n_devices);
+		r_s_what = g.s_exchange_name;
+		std::vector<double> expect(n_count);
+		for(size_t i = 0; i < n_count; ++ i) {
+			double f_sum = 0;
+			for(int r = 0; r < n_devices; ++ r)
+				f_sum += double(r + 1) * double(i % 7 + 1) + 0.25 * double(r);
+			expect[i] = f_sum;
+		}
+		n_result = g.p_threads->n_Run([&](int r) -> int {
+			std::vector<double> mine(n_count);
+			for(size_t i = 0; i < n_count; ++ i)
+				mine[i] = double(r + 1) * double(i % 7 + 1) + 0.25 * double(r);
+			hipStream_t stream = g.members[r]->stream;
+			double *p_dev = 0;
+			if(hipMalloc((void**)&p_dev, std::max<size_t>(n_count, 1) * sizeof(double)) != hipSuccess) {
+				g.barrier.Abort();
+				return SLAMPP_HIP_ERR_ALLOC;
+			}
+			int n_status = SLAMPP_HIP_OK;
+			if(hipMemcpyAsync(p_dev, mine.data(), n_count * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) {
+				g.barrier.Abort();
+				n_status = SLAMPP_HIP_ERR_DEVICE;
+			}
+			for(int n_pass = 0; n_pass < 2 && n_status == SLAMPP_HIP_OK; ++ n_pass) { // twice: the second pass sums the sums
+				if(group_allreduce_callback(&g.contexts[r], p_dev, n_count, (void*)stream) != 0)
+					n_status = SLAMPP_HIP_ERR_DEVICE;
+			}
+			if(n_status == SLAMPP_HIP_OK && (hipMemcpyAsync(mine.data(), p_dev, n_count * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+			   hipStreamSynchronize(stream) != hipSuccess))
+				n_status = SLAMPP_HIP_ERR_DEVICE;
+			(void)hipFree(p_dev);
+			for(size_t i = 0; i < n_count && n_status == SLAMPP_HIP_OK; ++ i) {
+				if(mine[i] != expect[i] * double(n_devices)) // (small integers and quarters: exact in any order)
+					n_status = SLAMPP_HIP_ERR_DEVICE;
+			}
+			return n_status;
+		});
+	} catch(...) {
+		group_destroy(p_group);
+		throw;
+	}
+	group_destroy(p_group);
+	return n_result;
+}
+
+} // namespace slampp
+
+using namespace slampp;
+
+extern "C" {
+
+int slampp_hip_group_exchange_selftest(const int *p_device_ids, int n_devices, int n_exchange, int64_t n_count,
+	char *p_s_exchange_out, int n_max_chars)
+{
+	if(!p_device_ids || n_devices < 1 || n_count < 0 || n_exchange < EXCHANGE_AUTO || n_exchange > EXCHANGE_PEER)
+		return SLAMPP_HIP_ERR_INVALID;
+	std::string s_what;
+	int n_result;
+	try {
+		n_result = group_exchange_selftest(p_device_ids, n_devices, n_exchange, size_t(n_count), s_what);
+	} catch(std::bad_alloc&) {
+		return SLAMPP_HIP_ERR_ALLOC;
+	} catch(std::invalid_argument&) {
+		return SLAMPP_HIP_ERR_INVALID;
+	} catch(std::exception &r_exc) {
+		s_what = r_exc.what();
+		n_result = SLAMPP_HIP_ERR_DEVICE;
+	}
+	if(p_s_exchange_out && n_max_chars > 0) {
+		strncpy(p_s_exchange_out, s_what.c_str(), size_t(n_max_chars) - 1);
+		p_s_exchange_out[n_max_chars - 1] = 0;
+	}
+	return n_result;
+}
+
+int slampp_hip_landmark_shard(int64_t n_bcols, const int64_t *p_bcol_cumsum, const int64_t *p_bcol_ptr,
+	const int32_t *p_brow_idx, int64_t n_matrix_cut, int n_rank, int n_world, slampp_hip_shard_view *p_view)
+{
+	if(!p_bcol_cumsum || !p_bcol_ptr || !p_view || n_bcols <= 0 || (p_bcol_ptr[n_bcols] > 0 && !p_brow_idx))
+		return SLAMPP_HIP_ERR_INVALID;
+	try {
+		TShardStructure t;
+		landmark_shard(n_bcols, p_bcol_cumsum, p_bcol_ptr, p_brow_idx, n_matrix_cut, n_rank, n_world, t);
+		p_view->n_bcols = int64_t(t.cumsum.size()) - 1;
+		p_view->n_blocks = int64_t(t.brow.size());
+		p_view->n_camera_values = t.n_camera_values;
+		p_view->n_value_begin = t.n_value_begin;
+		p_view->n_value_end = t.n_value_end;
+		p_view->n_camera_scalars = t.n_camera_scalars;
+		p_view->n_scalar_begin = t.n_scalar_begin;
+		p_view->n_scalar_end = t.n_scalar_end;
+		p_view->n_point_begin = t.n_point_begin;
+		p_view->n_point_end = t.n_point_end;
+		if(p_view->p_bcol_cumsum)
+			std::copy(t.cumsum.begin(), t.cumsum.end(), p_view->p_bcol_cumsum);
+		if(p_view->p_bcol_ptr)
+			std::copy(t.bcol_ptr.begin(), t.bcol_ptr.end(), p_view->p_bcol_ptr);
+		if(p_view->p_brow_idx)
+			std::copy(t.brow.begin(), t.brow.end(), p_view->p_brow_idx);
+		return SLAMPP_HIP_OK;
+	} catch(std::bad_alloc&) {
+		return SLAMPP_HIP_ERR_ALLOC;
+	} catch(std::exception&) {
+		return SLAMPP_HIP_ERR_INVALID;
+	}
+}
+
+} // extern "C"

@@ -137,8 +137,10 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 	long long *p_tm = 0; // development aid (SLAMPP_HIP_STAGE_TIMING): clock samples of workgroup 0
 	int n_tm = 0;
 	if(p_timing && blockIdx.x == 0 && tid == 0) {
-		p_tm = p_timing + 1 + 32 * atomicAdd((unsigned long long*)p_timing, 1ull);
-		p_tm[n_tm ++] = wall_clock64();
+		const unsigned long long n_tm_record = atomicAdd((unsigned long long*)p_timing, 1ull);
+		p_tm = (n_tm_record < 4096)? p_timing + 1 + 32 * n_tm_record : 0; // the buffer holds 4096 launch records: later launches go unrecorded
+		if(p_tm)
+			p_tm[n_tm ++] = wall_clock64();
 	}
 #define PANEL_TICK() do { if(p_tm && n_tm < 32) p_tm[n_tm ++] = wall_clock64(); } while(0)
 	const int64_t n_off = pkg_off[blockIdx.x];

@@ -121,8 +121,10 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 	long long *p_tm = 0; // development aid (SLAMPP_HIP_STAGE_TIMING): clock samples of a wave in the middle of the grid
 	int n_tm = 0;
 	if(p_timing && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {
-		p_tm = p_timing + 1 + 32 * atomicAdd((unsigned long long*)p_timing, 1ull);
-		p_tm[n_tm ++] = wall_clock64();
+		const unsigned long long n_tm_record = atomicAdd((unsigned long long*)p_timing, 1ull);
+		p_tm = (n_tm_record < 4096)? p_timing + 1 + 32 * n_tm_record : 0; // the buffer holds 4096 launch records: later launches go unrecorded
+		if(p_tm)
+			p_tm[n_tm ++] = wall_clock64();
 	}
 #define SIMT_TICK() do { if(p_tm && n_tm < 32) p_tm[n_tm ++] = wall_clock64(); } while(0)
 	const int32_t *P = prog + ch.prog_off;                 // wave-uniform: scalar loads

@@ -70,6 +70,7 @@ public:
 };
 
 struct CSchurState; // schur.hip
+struct CDeviceGroup; // group.hip
 struct CSparseInverse; // sparse_inverse.hip
 struct CAssemblyState; // assembly.hip
 
@@ -104,6 +105,21 @@ struct slampp_hip_solver {
 	int64_t n_values, n_scalars;
 
 	// sparse path
+	// Block columns wider than the kernels take (8) are cut into pieces of at most 8: the scalar matrix is the same, the
+	// right-hand side and the solution are untouched, and the packed values are regrouped on the device (one gather
+	// through d_refine_map) in front of every factorization.  The reference's solvers take any block size.
+	bool b_refined = false;
+	int64_t n_refined_values = 0;
+	std::vector<int64_t> refined_cumsum, refined_bcol_ptr;
+	std::vector<int32_t> refined_brow;
+	slampp::CDevArray<int64_t> d_refine_map;
+	slampp::CDevArray<double> d_refined;
+	void Refine_Structure(); // throws
+	// Schur mode asked for a structure the Schur kernels do not take (landmark-landmark blocks: C not block diagonal, the
+	// reference's InverseOf_Symmteric_FBS branch, LinearSolver_Schur.h:1721-1726; block sizes other than (6,3), (7,3), (3,2);
+	// no landmark part at all, :1635-1638): the same system goes through the sparse block path, which solves it all the same
+	bool b_schur_fallback = false;
+	int n_schur_fallback_option = 1; // option "schur_fallback": 0 = report SLAMPP_HIP_ERR_UNSUPPORTED instead
 	slampp::Plan plan;
 	int n_bottom_stages; // leading stages launched with one wave per task
 	slampp::TDevPlan dplan;
@@ -172,6 +188,12 @@ struct slampp_hip_solver {
 	void Upload_Values(const double *p_values); // throws; leaves `stream` waiting for the copy
 
 	slampp::CSchurState *p_schur;
+	// slampp_hip_create_multi: the members on the listed devices (group.hip); b_group_active = the current analysis is a
+	// sharded one (Schur mode), and this handle itself holds the structure and the pinned staging only
+	slampp::CDeviceGroup *p_group = 0;
+	bool b_group_active = false;
+	std::vector<int> group_devices; // the device list (empty: a single-device handle); the group comes up with the first Schur-mode analysis
+	std::vector<std::pair<std::string, int64_t> > group_options; // options set so far, for members created later
 	std::vector<slampp_hip_assembly*> assemblies; // live Lambda assemblies created from this solver
 
 	slampp_hip_allreduce_fn p_allreduce;
@@ -218,6 +240,21 @@ size_t schur_device_bytes(const CSchurState *p);
 void schur_invalidate_previous(CSchurState *p); // the kept reduced system no longer matches what the caller last solved
 void schur_set_changed_points(slampp_hip_solver &s, const int64_t *p_points, int64_t n_points); // throws
 void schur_fill_stats(const CSchurState *p, slampp_hip_stats &st);
+
+// several devices behind one handle (group.hip)
+CDeviceGroup *group_create(const int *p_device_ids, int n_devices); // throws
+void group_destroy(CDeviceGroup *p_group);
+int group_set_option(CDeviceGroup &g, const char *p_s_name, int64_t n_value);
+void group_analyze(slampp_hip_solver &r_front, int64_t n_cut); // throws
+int group_factor_solve(slampp_hip_solver &r_front, const double *p_values, double *p_rhs_inout);
+int group_solve_marginal_poses(slampp_hip_solver &r_front, const double *p_values, double *p_rhs_inout);
+int group_schur_marginals(slampp_hip_solver &r_front, const double *p_values, double *p_cam_cov, double *p_point_cov);
+int group_free_memory(CDeviceGroup &g);
+void group_fill_stats(CDeviceGroup &g, slampp_hip_stats &r_stats);
+const char *group_exchange_name(const CDeviceGroup &g);
+int group_member_num(const CDeviceGroup &g);
+slampp_hip_solver *group_member(CDeviceGroup &g, int n_member);
+void shard_bounds(int64_t n_bcols, int64_t n_cut, const int64_t *p_bcol_ptr, int n_world, std::vector<int64_t> &r_bounds);
 
 // Lambda assembly (assembly.hip)
 CAssemblyState *assembly_setup(slampp_hip_solver &s, int64_t n_edges, const int64_t *v0, const int64_t *v1, int rd); // throws

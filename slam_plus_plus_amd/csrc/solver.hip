@@ -57,6 +57,21 @@ static size_t pinned_bytes(size_t n_doubles) // what Alloc_Pinned maps for that 
 	return (std::max<size_t>(n_doubles, 1) * sizeof(double) + n_huge - 1) / n_huge * n_huge;
 }
 
+// worker threads that are joined on every way out of the scope that started them: a std::thread destroyed while
+// joinable is std::terminate (a wordless abort), and that is what an exception thrown between two emplace_back calls --
+// std::system_error when the process is out of threads -- would otherwise leave behind
+struct CJoiningThreads {
+	std::vector<std::thread> v;
+	~CJoiningThreads() { Join(); }
+	void Join()
+	{
+		for(size_t i = 0; i < v.size(); ++ i) {
+			if(v[i].joinable())
+				v[i].join();
+		}
+	}
+};
+
 static void Free_Pinned(double *p, bool b_registered, size_t n_doubles)
 {
 	if(!p)
@@ -64,10 +79,17 @@ static void Free_Pinned(double *p, bool b_registered, size_t n_doubles)
 	if(b_registered) {
 		// a mapping of its own, never the allocator's memory: pages the driver has pinned do not go back into a heap.  If
 		// the driver will not let go of them, the mapping stays (a leak of address space, not a block that two owners use)
-		if(hipHostUnregister(p) == hipSuccess)
+		const hipError_t e = hipHostUnregister(p);
+		if(e == hipSuccess)
 			(void)munmap(p, pinned_bytes(n_doubles));
-		else
+		else {
 			(void)hipGetLastError();
+			static std::atomic<bool> b_said(false);
+			if(!b_said.exchange(true)) {
+				fprintf(stderr, "libslampp_hip: hipHostUnregister failed (%s): %zu bytes of pinned staging stay mapped "
+					"(said once per process)\n", hipGetErrorString(e), pinned_bytes(n_doubles));
+			}
+		}
 	} else
 		(void)hipHostFree(p);
 }
@@ -113,20 +135,23 @@ static double *Alloc_Pinned(size_t n_doubles, bool &r_b_registered) // throw(std
 		if(p) {
 			(void)madvise(p, n_bytes, MADV_HUGEPAGE);
 			const size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8, std::thread::hardware_concurrency()), n_bytes / (8 * n_huge)));
-			std::vector<std::thread> threads;
-			for(size_t t = 0; t < n_threads; ++ t) {
-				const size_t n_begin = n_bytes / n_huge * t / n_threads * n_huge, n_end = n_bytes / n_huge * (t + 1) / n_threads * n_huge;
-				auto touch = [p, n_begin, n_end]() {
-					for(size_t i = n_begin; i < n_end; i += 4096)
-						((volatile char*)p)[i] = 0;
-				};
-				if(t + 1 < n_threads)
-					threads.emplace_back(touch);
-				else
-					touch();
+			try {
+				CJoiningThreads threads;
+				for(size_t t = 0; t < n_threads; ++ t) {
+					const size_t n_begin = n_bytes / n_huge * t / n_threads * n_huge, n_end = n_bytes / n_huge * (t + 1) / n_threads * n_huge;
+					auto touch = [p, n_begin, n_end]() {
+						for(size_t i = n_begin; i < n_end; i += 4096)
+							((volatile char*)p)[i] = 0;
+					};
+					if(t + 1 < n_threads)
+						threads.v.emplace_back(touch);
+					else
+						touch();
+				}
+				threads.Join();
+			} catch(std::system_error&) {
+				// no more threads to be had: the registration below touches the pages itself
 			}
-			for(size_t t = 0; t < threads.size(); ++ t)
-				threads[t].join();
 			if(hipHostRegister(p, n_bytes, hipHostRegisterDefault) == hipSuccess) {
 				r_b_registered = true;
 				return (double*)p;
@@ -181,8 +206,10 @@ void slampp_hip_solver::Require_Staging()
 	const double t1 = staging_wall_ms();
 	Grow_Pinned(p_pin_rhs, n_pin_rhs, b_pin_rhs_registered, size_t(n_scalars));
 	const double t2 = staging_wall_ms();
-	d_A.Alloc(size_t(n_values));
-	d_rhs.Alloc(size_t(n_scalars));
+	if(!b_group_active) { // (with landmark shards the values go from the staging straight to the members' devices)
+		d_A.Alloc(size_t(n_values));
+		d_rhs.Alloc(size_t(n_scalars));
+	}
 	if(b_timing) {
 		fprintf(stderr, "[staging] values %.2f ms (%s), rhs %.2f ms, device arrays %.2f ms\n", t1 - t0,
 			b_pin_values_registered? "registered" : "hipHostMalloc", t2 - t1, staging_wall_ms() - t2);
@@ -209,9 +236,9 @@ static void Staged_Upload(double *p_dev, double *p_pin, const double *p_src, siz
 	std::vector<std::atomic<int> > done(n_chunks);
 	for(size_t c = 0; c < n_chunks; ++ c)
 		done[c].store(0);
-	std::vector<std::thread> workers;
+	CJoiningThreads workers; // joined before `done` goes, whichever way this scope is left
 	for(int t = 0; t < n_threads; ++ t) {
-		workers.emplace_back([=, &done]() {
+		workers.v.emplace_back([=, &done]() {
 			for(size_t c = 0; c < n_chunks; ++ c) {
 				const size_t b = c * n_chunk, e = std::min(n, b + n_chunk), n_piece = (e - b + n_threads - 1) / n_threads;
 				const size_t pb = std::min(e, b + t * n_piece), pe = std::min(e, pb + n_piece);
@@ -229,8 +256,7 @@ static void Staged_Upload(double *p_dev, double *p_pin, const double *p_src, siz
 		if(n_err == hipSuccess)
 			n_err = hipMemcpyAsync(p_dev + b, p_pin + b, (e - b) * sizeof(double), hipMemcpyHostToDevice, copy_stream);
 	}
-	for(std::thread &r_t : workers)
-		r_t.join();
+	workers.Join();
 	SLAMPP_HIP_CHECK(n_err);
 }
 
@@ -243,15 +269,14 @@ static void Parallel_Copy(double *p_dst, const double *p_src, size_t n)
 		memcpy(p_dst, p_src, n * sizeof(double));
 		return;
 	}
-	std::vector<std::thread> workers;
+	CJoiningThreads workers;
 	const size_t n_piece = (n + n_threads - 1) / n_threads;
 	for(int t = 0; t < n_threads; ++ t) {
 		const size_t b = std::min(n, t * n_piece), e = std::min(n, b + n_piece);
 		if(e > b)
-			workers.emplace_back([=]() { memcpy(p_dst + b, p_src + b, (e - b) * sizeof(double)); });
+			workers.v.emplace_back([=]() { memcpy(p_dst + b, p_src + b, (e - b) * sizeof(double)); });
 	}
-	for(std::thread &r_t : workers)
-		r_t.join();
+	workers.Join();
 }
 
 // Lambda's values to d_A.  From the library's own pinned staging (the header class gathers the blocks of a
@@ -306,6 +331,7 @@ void slampp_hip_solver::Free_Device()
 	n_dense_gaps = 0;
 	d_A.Free(); d_rhs.Free(); d_L.Free(); d_Linv.Free(); d_w.Free(); d_flag.Free();
 	d_cov.Free(); d_damp_off.Free(); d_timing.Free();
+	d_refine_map.Free(); d_refined.Free();
 	b_damp_valid = false;
 	dplan.p_timing = 0;
 	n_uploaded = 0;
@@ -397,6 +423,66 @@ void slampp_hip_solver::Phase_Collect()
 	phase_pending.clear();
 }
 
+// Cuts block columns wider than 8 into pieces (as equal as possible, at most 8 wide) and builds the map from the
+// refined packed values to the caller's: block (r, c) becomes the pieces (r_i, c_j), a diagonal block the pieces with
+// i <= j (the upper triangle, as everywhere).  Nothing to do -- and nothing allocated -- for the usual 3 / 6 / 7.
+void slampp_hip_solver::Refine_Structure()
+{
+	const int64_t n = int64_t(cumsum.size()) - 1;
+	b_refined = false;
+	for(int64_t c = 0; c < n && !b_refined; ++ c)
+		b_refined = cumsum[c + 1] - cumsum[c] > 8;
+	if(!b_refined) {
+		refined_cumsum.clear(); refined_bcol_ptr.clear(); refined_brow.clear();
+		d_refine_map.Free(); d_refined.Free();
+		n_refined_values = 0;
+		return;
+	}
+	std::vector<int64_t> first_piece(size_t(n) + 1, 0); // pieces of block column c: [first_piece[c], first_piece[c + 1])
+	refined_cumsum.assign(1, 0);
+	for(int64_t c = 0; c < n; ++ c) {
+		const int64_t w = cumsum[c + 1] - cumsum[c], n_pieces = (w + 7) / 8;
+		for(int64_t i = 0; i < n_pieces; ++ i)
+			refined_cumsum.push_back(cumsum[c] + w * (i + 1) / n_pieces);
+		first_piece[c + 1] = first_piece[c] + n_pieces;
+	}
+	const int64_t n_refined = first_piece[n];
+	refined_bcol_ptr.assign(size_t(n_refined) + 1, 0);
+	refined_brow.clear();
+	std::vector<int64_t> map;
+	int64_t n_src_off = 0; // offset of the caller's block (r, c) in the packed values
+	std::vector<int64_t> col_src_off; // per block of column c: its offset
+	for(int64_t c = 0; c < n; ++ c) {
+		const int64_t w = cumsum[c + 1] - cumsum[c];
+		col_src_off.clear();
+		for(int64_t k = bcol_ptr[c]; k < bcol_ptr[c + 1]; ++ k) {
+			col_src_off.push_back(n_src_off);
+			n_src_off += (cumsum[brow[k] + 1] - cumsum[brow[k]]) * w;
+		}
+		for(int64_t pj = first_piece[c]; pj < first_piece[c + 1]; ++ pj) { // refined column pj: rows ascend with the caller's blocks
+			const int64_t n_col0 = refined_cumsum[pj] - cumsum[c], n_pw = refined_cumsum[pj + 1] - refined_cumsum[pj];
+			for(int64_t k = bcol_ptr[c]; k < bcol_ptr[c + 1]; ++ k) {
+				const int64_t r = brow[k], h = cumsum[r + 1] - cumsum[r];
+				for(int64_t pi = first_piece[r]; pi < first_piece[r + 1]; ++ pi) {
+					if(pi > pj)
+						break; // below the diagonal of a diagonal block
+					const int64_t n_row0 = refined_cumsum[pi] - cumsum[r], n_ph = refined_cumsum[pi + 1] - refined_cumsum[pi];
+					refined_brow.push_back(int32_t(pi));
+					for(int64_t b = 0; b < n_pw; ++ b) {
+						for(int64_t a = 0; a < n_ph; ++ a)
+							map.push_back(col_src_off[size_t(k - bcol_ptr[c])] + (n_row0 + a) + (n_col0 + b) * h);
+					}
+				}
+			}
+			refined_bcol_ptr[pj + 1] = int64_t(refined_brow.size());
+		}
+	}
+	n_refined_values = int64_t(map.size());
+	d_refine_map.Upload(map, stream);
+	d_refined.Alloc(map.size());
+	SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // map lives on this stack frame
+}
+
 void slampp_hip_solver::Analyze_Sparse()
 {
 	if(p_sinv) { // lists of the previous plan
@@ -408,13 +494,14 @@ void slampp_hip_solver::Analyze_Sparse()
 	double t_phase = wall_ms();
 #define SETUP_PHASE(name) do { if(b_timing) { const double t_ = wall_ms(); \
 	fprintf(stderr, "[setup] %-12s %8.2f ms\n", name, t_ - t_phase); t_phase = t_; } } while(0)
-	std::string s_err = build_plan(int64_t(cumsum.size()) - 1, cumsum.data(), bcol_ptr.data(),
-		brow.data(), opt, plan);
+	Refine_Structure();
+	std::string s_err = b_refined? build_plan(int64_t(refined_cumsum.size()) - 1, refined_cumsum.data(), refined_bcol_ptr.data(),
+		refined_brow.data(), opt, plan) : build_plan(int64_t(cumsum.size()) - 1, cumsum.data(), bcol_ptr.data(), brow.data(), opt, plan);
 	SETUP_PHASE("build_plan");
 	if(!s_err.empty())
 		throw std::invalid_argument(s_err);
 	if(plan.max_dim > 8)
-		throw std::domain_error("block dimensions above 8 are not supported by the sparse path");
+		throw std::logic_error("a block column wider than 8 survived the refinement");
 	const Plan &P = plan;
 	const int64_t n_lblocks = int64_t(P.lrow.size());
 	// the bottom stage and the wide stages right above it (more tasks than the 8-wave kernel keeps
@@ -1026,6 +1113,10 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 	const Plan &P = plan;
 	const int n_stages = int(P.stage_ptr.size()) - 1;
 	int *p_flag = p_flag_shared? p_flag_shared : d_flag.p(); // (the inner solver of a Schur solve reports into the outer one's flag)
+	if(b_factor && b_refined) { // wide block columns were cut into pieces: the values regrouped accordingly
+		launch_gather_values(d_refine_map.p(), n_refined_values, p_values_dev, d_refined.p(), stream);
+		p_values_dev = d_refined.p();
+	}
 	if(b_factor) {
 		// numeric factorization with the forward substitution fused in
 		if(!p_flag_shared)
@@ -1182,6 +1273,8 @@ int fail(slampp_hip_solver *p, int n_code, const char *p_s_msg)
 extern "C" {
 
 // development aid (SLAMPP_HIP_ABORT_TRACE=1): where an abort() came from, for the ones that say nothing
+static struct sigaction g_abort_previous; // whoever had SIGABRT before us (pytest's faulthandler, torch): called after the trace
+
 static void abort_trace_handler(int n_signal)
 {
 	void *p_frames[64];
@@ -1189,8 +1282,21 @@ static void abort_trace_handler(int n_signal)
 	static const char p_s_head[] = "[slampp_hip] abort: backtrace follows\n";
 	(void)!write(2, p_s_head, sizeof(p_s_head) - 1);
 	backtrace_symbols_fd(p_frames, n_frames, 2);
-	signal(n_signal, SIG_DFL);
+	(void)sigaction(n_signal, &g_abort_previous, 0); // hand the signal back: the host's handler (or the default) runs next
 	raise(n_signal);
+}
+
+static void abort_trace_install() // strictly opt-in, once per process
+{
+	void *p_frames[4];
+	(void)backtrace(p_frames, 4); // the first call loads libgcc's unwinder and may allocate: not something to do inside the handler
+	struct sigaction t_action;
+	memset(&t_action, 0, sizeof(t_action));
+	t_action.sa_handler = abort_trace_handler;
+	sigemptyset(&t_action.sa_mask);
+	memset(&g_abort_previous, 0, sizeof(g_abort_previous));
+	g_abort_previous.sa_handler = SIG_DFL;
+	(void)sigaction(SIGABRT, &t_action, &g_abort_previous);
 }
 
 int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id)
@@ -1198,7 +1304,7 @@ int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id)
 	if(!pp_solver)
 		return SLAMPP_HIP_ERR_INVALID;
 	*pp_solver = 0;
-	static const bool b_trace = [] { if(getenv("SLAMPP_HIP_ABORT_TRACE")) { signal(SIGABRT, abort_trace_handler); return true; } return false; }();
+	static const bool b_trace = [] { if(getenv("SLAMPP_HIP_ABORT_TRACE")) { abort_trace_install(); return true; } return false; }();
 	(void)b_trace;
 	int n_count = 0;
 	if(hipGetDeviceCount(&n_count) != hipSuccess || n_count <= 0 || device_id < 0 || device_id >= n_count)
@@ -1217,9 +1323,62 @@ int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id)
 	return SLAMPP_HIP_OK;
 }
 
+int slampp_hip_create_multi(slampp_hip_solver **pp_solver, const int *p_device_ids, int n_devices)
+{
+	if(!pp_solver || !p_device_ids || n_devices < 1)
+		return SLAMPP_HIP_ERR_INVALID;
+	const int n_result = slampp_hip_create(pp_solver, p_device_ids[0]);
+	if(n_result != SLAMPP_HIP_OK || n_devices == 1)
+		return n_result;
+	slampp_hip_solver *p_front = *pp_solver;
+	int n_count = 0;
+	(void)hipGetDeviceCount(&n_count);
+	bool b_valid = n_devices <= 16;
+	for(int i = 0; i < n_devices && b_valid; ++ i)
+		b_valid = p_device_ids[i] >= 0 && p_device_ids[i] < n_count;
+	if(!b_valid) {
+		slampp_hip_destroy(p_front);
+		*pp_solver = 0;
+		return SLAMPP_HIP_ERR_INVALID;
+	}
+	// the members (a solver, a stream and a host thread per device) come up with the first Schur-mode analysis: a
+	// handle that only ever sees pose graphs stays a plain solver on the first device
+	p_front->group_devices.assign(p_device_ids, p_device_ids + n_devices);
+	return SLAMPP_HIP_OK;
+}
+
+int slampp_hip_group_info(const slampp_hip_solver *p_solver, int *p_member_num, int64_t *p_point_bounds, int n_max_members,
+	const char **pp_s_exchange)
+{
+	if(!p_solver)
+		return SLAMPP_HIP_ERR_INVALID;
+	const slampp_hip_solver &s = *p_solver;
+	const int n_members = (s.p_group && s.b_group_active && s.b_analyzed)? group_member_num(*s.p_group) : 0;
+	if(p_member_num)
+		*p_member_num = n_members;
+	if(pp_s_exchange)
+		*pp_s_exchange = n_members? group_exchange_name(*s.p_group) : "none";
+	if(p_point_bounds && n_members) {
+		if(n_max_members < n_members)
+			return SLAMPP_HIP_ERR_INVALID;
+		try {
+			std::vector<int64_t> bounds;
+			shard_bounds(int64_t(s.cumsum.size()) - 1, s.n_matrix_cut, &s.bcol_ptr[0], n_members, bounds);
+			std::copy(bounds.begin(), bounds.end(), p_point_bounds);
+		} catch(std::bad_alloc&) {
+			return SLAMPP_HIP_ERR_ALLOC;
+		}
+	}
+	return SLAMPP_HIP_OK;
+}
+
 void slampp_hip_destroy(slampp_hip_solver *p_solver)
 {
 	if(p_solver) {
+		if(p_solver->p_group) {
+			group_destroy(p_solver->p_group);
+			p_solver->p_group = 0;
+		}
 		(void)hipSetDevice(p_solver->n_device);
 		(void)hipStreamSynchronize(p_solver->stream);
 		for(slampp_hip_assembly *p_assembly : p_solver->assemblies) { // orphaned, not freed: the caller owns the handles
@@ -1234,6 +1393,14 @@ void slampp_hip_destroy(slampp_hip_solver *p_solver)
 int slampp_hip_free_memory(slampp_hip_solver *p_solver)
 {
 	return guarded(p_solver, [&]() -> int {
+		if(p_solver->p_group) {
+			const int n_group_result = group_free_memory(*p_solver->p_group);
+			p_solver->b_group_active = false;
+			p_solver->b_analyzed = p_solver->b_analyzed && p_solver->n_mode == SLAMPP_HIP_MODE_SPARSE;
+			SLAMPP_HIP_CHECK(hipSetDevice(p_solver->n_device));
+			if(n_group_result != SLAMPP_HIP_OK)
+				return fail(p_solver, n_group_result, "device group: a member could not free its memory");
+		}
 		SLAMPP_HIP_CHECK(hipStreamSynchronize(p_solver->stream));
 		p_solver->Free_Device();
 		if(p_solver->copy_stream)
@@ -1254,7 +1421,24 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 	if(!p_solver || !p_s_name)
 		return SLAMPP_HIP_ERR_INVALID;
 	const std::string s(p_s_name);
-	if(s == "leaf_size" && n_value >= 1)
+	if(p_solver->p_group) { // the members take the same options (the front handle keeps them for the sparse mode)
+		const int n_group_result = group_set_option(*p_solver->p_group, p_s_name, n_value);
+		(void)hipSetDevice(p_solver->n_device);
+		if(n_group_result != SLAMPP_HIP_OK)
+			return fail(p_solver, n_group_result, "unknown option or value out of range");
+	}
+	if(!p_solver->group_devices.empty()) { // (and members that do not exist yet will be given them)
+		size_t i = 0;
+		while(i < p_solver->group_options.size() && p_solver->group_options[i].first != s)
+			++ i;
+		if(i == p_solver->group_options.size())
+			p_solver->group_options.push_back(std::make_pair(s, n_value));
+		else
+			p_solver->group_options[i].second = n_value;
+	}
+	if(s == "group_exchange" && n_value >= 0 && n_value <= 2) {
+		// (without a device list there is nothing to exchange: accepted, so that one configuration serves both)
+	} else if(s == "leaf_size" && n_value >= 1)
 		p_solver->opt.leaf_size = int(n_value);
 	else if(s == "subtree_size" && n_value >= 1)
 		p_solver->opt.subtree_size = int(n_value);
@@ -1291,6 +1475,8 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 	}
 	else if(s == "schur_sparse" && n_value >= -1 && n_value <= 1)
 		p_solver->n_schur_sparse = int(n_value);
+	else if(s == "schur_fallback" && n_value >= 0 && n_value <= 1)
+		p_solver->n_schur_fallback_option = int(n_value);
 	else if(s == "schur_tiles" && n_value >= -1 && n_value <= 3)
 		p_solver->n_schur_tiles = int(n_value);
 	else if(s == "schur_incremental" && n_value >= 0 && n_value <= 2)
@@ -1407,6 +1593,8 @@ int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix
 		if(s.copy_stream)
 			SLAMPP_HIP_CHECK(hipStreamSynchronize(s.copy_stream));
 		s.Free_Device();
+		s.b_group_active = false;
+		s.b_schur_fallback = false;
 		memset(&s.times, 0, sizeof(s.times));
 		s.n_mode = n_mode;
 		s.n_matrix_cut = n_matrix_cut;
@@ -1417,9 +1605,38 @@ int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix
 			s.times.symbolic_ms = wall_ms() - t0 - s.plan.order_ms;
 		} else {
 			const int64_t n = int64_t(s.cumsum.size()) - 1;
-			if(n_matrix_cut <= 0 || n_matrix_cut >= n)
+			const bool b_no_landmarks = n_matrix_cut <= 0 || n_matrix_cut >= n;
+			if(b_no_landmarks && !s.n_schur_fallback_option)
 				return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "analyze: n_matrix_cut must split the block columns");
-			s.p_schur = schur_analyze(s);
+			try {
+				if(b_no_landmarks)
+					throw std::domain_error("no landmark part");
+				if(!s.group_devices.empty() && !s.p_group) {
+					s.p_group = group_create(&s.group_devices[0], int(s.group_devices.size()));
+					for(size_t i = 0; i < s.group_options.size(); ++ i) {
+						if(group_set_option(*s.p_group, s.group_options[i].first.c_str(), s.group_options[i].second) != SLAMPP_HIP_OK)
+							throw std::invalid_argument("device group: a member refused an option this handle had accepted");
+					}
+				}
+				if(s.p_group) {
+					group_analyze(s, n_matrix_cut); // landmark shards on the listed devices; this handle keeps structure and staging
+					s.b_group_active = true;
+					SLAMPP_HIP_CHECK(hipSetDevice(s.n_device));
+				} else
+					s.p_schur = schur_analyze(s);
+			} catch(std::domain_error&) {
+				// a structure the Schur kernels do not take, which the reference nevertheless solves (LinearSolver_Schur.h:1635-1638,
+				// 1721-1726): the sparse block path on the whole of Lambda gives the same solution
+				if(!s.n_schur_fallback_option)
+					throw;
+				(void)hipSetDevice(s.n_device);
+				s.Free_Device();
+				s.b_group_active = false;
+				s.b_schur_fallback = true;
+				s.n_mode = SLAMPP_HIP_MODE_SPARSE; // from here on this is a sparse-mode handle that remembers why
+				s.Analyze_Sparse();
+				s.times.order_ms = s.plan.order_ms;
+			}
 			s.times.symbolic_ms = wall_ms() - t0;
 		}
 		s.b_analyzed = true;
@@ -1434,6 +1651,8 @@ int slampp_hip_factor_solve_device_async(slampp_hip_solver *p_solver, const doub
 		slampp_hip_solver &s = *p_solver;
 		if(!s.b_analyzed)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factor_solve: analyze was not called");
+		if(s.b_group_active)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factor_solve_device: this handle solves with landmark shards on several devices: host entry points only");
 		if(!p_values_dev || !p_rhs_inout_dev)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factor_solve: null pointer");
 		if(s.n_mode == SLAMPP_HIP_MODE_SPARSE)
@@ -1449,6 +1668,8 @@ int slampp_hip_sync(slampp_hip_solver *p_solver)
 {
 	return guarded(p_solver, [&]() -> int {
 		slampp_hip_solver &s = *p_solver;
+		if(s.b_group_active)
+			return SLAMPP_HIP_OK; // the host entry points of a sharded handle return with everything finished
 		*s.p_host_flag = 0;
 		if(s.d_flag.p())
 			SLAMPP_HIP_CHECK(hipMemcpyAsync(s.p_host_flag, s.d_flag.p(), sizeof(int), hipMemcpyDeviceToHost, s.stream));
@@ -1505,6 +1726,8 @@ int slampp_hip_factor_solve(slampp_hip_solver *p_solver, const double *p_values,
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factor_solve: analyze was not called");
 		if(!p_values || !p_rhs_inout)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factor_solve: null pointer");
+		if(s.b_group_active)
+			return SLAMPP_HIP_OK;
 		s.Upload_Values(p_values);
 		Upload_Rhs_And_Join(s, p_rhs_inout);
 		return SLAMPP_HIP_OK;
@@ -1512,6 +1735,13 @@ int slampp_hip_factor_solve(slampp_hip_solver *p_solver, const double *p_values,
 	if(n_result != SLAMPP_HIP_OK)
 		return n_result;
 	slampp_hip_solver &s = *p_solver;
+	if(s.b_group_active) {
+		n_result = guarded(p_solver, [&]() -> int { return group_factor_solve(s, p_values, p_rhs_inout); });
+		s.n_uploaded = 0;
+		if(p_times)
+			*p_times = s.times;
+		return n_result;
+	}
 	const double t1 = wall_ms(); // (the last chunks may still be on the bus: the solve is enqueued behind them)
 	s.times.upload_ms = t1 - t0;
 	n_result = slampp_hip_factor_solve_device_async(p_solver, s.d_A.p(), s.d_rhs.p());
@@ -1556,6 +1786,11 @@ int slampp_hip_upload_values_async(slampp_hip_solver *p_solver, int64_t n_first,
 {
 	return guarded(p_solver, [&]() -> int {
 		slampp_hip_solver &s = *p_solver;
+		if(s.b_group_active) {
+			if(!s.p_pin_values)
+				return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "upload_values: host_staging was not called");
+			return SLAMPP_HIP_OK; // every member fetches its own columns from the staging when the solve is called
+		}
 		if(!s.p_pin_values || !s.d_A.p())
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "upload_values: host_staging was not called");
 		if(n_first == 0)
@@ -1575,6 +1810,8 @@ int slampp_hip_schur_set_changed_points(slampp_hip_solver *p_solver, const int64
 {
 	return guarded(p_solver, [&]() -> int {
 		slampp_hip_solver &s = *p_solver;
+		if((s.b_group_active || s.b_schur_fallback) && s.b_analyzed)
+			return SLAMPP_HIP_OK; // landmark shards rebuild the reduced system (as the header comment says): the list is a hint
 		if(!s.b_analyzed || s.n_mode != SLAMPP_HIP_MODE_SCHUR || !s.p_schur)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "schur_set_changed_points: analyze (Schur mode) was not called");
 		if(!s.n_schur_incremental)
@@ -1596,6 +1833,8 @@ int slampp_hip_solve_marginal_poses_device_async(slampp_hip_solver *p_solver, co
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "solve_marginal_poses: analyze was not called");
 		if(s.n_mode != SLAMPP_HIP_MODE_SCHUR)
 			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "solve_marginal_poses: needs the Schur mode (cameras and landmarks)");
+		if(s.b_group_active)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "solve_marginal_poses_device: this handle solves with landmark shards on several devices: host entry points only");
 		if(!p_values_dev || !p_rhs_inout_dev)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "solve_marginal_poses: null pointer");
 		schur_enqueue_marginal_poses(s, p_values_dev, p_rhs_inout_dev);
@@ -1612,6 +1851,8 @@ int slampp_hip_marginals_device_async(slampp_hip_solver *p_solver, const double 
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "marginals: analyze was not called");
 		if(s.n_mode != SLAMPP_HIP_MODE_SPARSE)
 			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "marginals: sparse mode only (Schur mode: slampp_hip_schur_marginals)");
+		if(s.b_refined)
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "marginals: needs one block size (3, 6 or 7)");
 		if(!p_values_dev || !p_block_diag_dev)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "marginals: null pointer");
 		const Plan &P = s.plan;
@@ -1698,6 +1939,8 @@ int slampp_hip_schur_marginals_device_async(slampp_hip_solver *p_solver, const d
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "schur_marginals: analyze was not called");
 		if(s.n_mode != SLAMPP_HIP_MODE_SCHUR)
 			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "schur_marginals: needs the Schur mode (cameras and landmarks)");
+		if(s.b_group_active)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "schur_marginals_device: this handle solves with landmark shards on several devices: host entry points only");
 		if(!p_values_dev || (!p_cam_cov_dev && !p_point_cov_dev))
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "schur_marginals: null pointer");
 		schur_enqueue_marginals(s, p_values_dev, p_cam_cov_dev, p_point_cov_dev);
@@ -1717,6 +1960,8 @@ int slampp_hip_schur_marginals(slampp_hip_solver *p_solver, const double *p_valu
 			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "schur_marginals: needs the Schur mode (cameras and landmarks)");
 		if(!p_values || (!p_cam_cov && !p_point_cov))
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "schur_marginals: null pointer");
+		if(s.b_group_active)
+			return group_schur_marginals(s, p_values, p_cam_cov, p_point_cov);
 		const int64_t nc = s.n_matrix_cut, np = int64_t(s.cumsum.size()) - 1 - nc;
 		const int64_t dc = s.cumsum[1] - s.cumsum[0], dp = s.cumsum[nc + 1] - s.cumsum[nc];
 		n_cam_doubles = size_t(nc * dc * dc);
@@ -1726,7 +1971,7 @@ int slampp_hip_schur_marginals(slampp_hip_solver *p_solver, const double *p_valu
 		Upload_Values_And_Join(s, p_values);
 		return SLAMPP_HIP_OK;
 	});
-	if(n_result != SLAMPP_HIP_OK)
+	if(n_result != SLAMPP_HIP_OK || p_solver->b_group_active)
 		return n_result;
 	slampp_hip_solver &s = *p_solver;
 	n_result = slampp_hip_schur_marginals_device_async(p_solver, s.d_A.p(), p_cam_cov? s.d_cov.p() : 0,
@@ -1755,13 +2000,15 @@ int slampp_hip_solve_marginal_poses(slampp_hip_solver *p_solver, const double *p
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "solve_marginal_poses: analyze was not called");
 		if(!p_values || !p_rhs_inout)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "solve_marginal_poses: null pointer");
+		if(s.b_group_active)
+			return group_solve_marginal_poses(s, p_values, p_rhs_inout);
 		s.d_A.Alloc(size_t(s.n_values));
 		s.d_rhs.Alloc(size_t(s.n_scalars));
 		s.Upload_Values(p_values);
 		Upload_Rhs_And_Join(s, p_rhs_inout);
 		return SLAMPP_HIP_OK;
 	});
-	if(n_result != SLAMPP_HIP_OK)
+	if(n_result != SLAMPP_HIP_OK || p_solver->b_group_active)
 		return n_result;
 	slampp_hip_solver &s = *p_solver;
 	n_result = slampp_hip_solve_marginal_poses_device_async(p_solver, s.d_A.p(), s.d_rhs.p());
@@ -1785,6 +2032,8 @@ int slampp_hip_factorize(slampp_hip_solver *p_solver, const double *p_values, do
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factorize: analyze was not called");
 		if(s.n_mode != SLAMPP_HIP_MODE_SPARSE)
 			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "factorize: the sparse mode only");
+		if(s.b_refined)
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "factorize: block columns wider than 8 are factored in pieces, the factor does not have the caller's block layout");
 		if(s.n_dense_dim)
 			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "factorize: set the option dense_top_nb to 0 (the dense top keeps its part of the factor in another layout)");
 		if(!p_values || !p_factor_out)
@@ -1857,6 +2106,8 @@ int slampp_hip_get_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_
 	} else if(s.b_analyzed && s.p_schur)
 		schur_fill_stats(s.p_schur, *p_stats);
 	p_stats->device_bytes = int64_t(s.n_Device_Bytes());
+	if(s.b_analyzed && s.b_group_active)
+		group_fill_stats(*s.p_group, *p_stats); // the members' landmark shards, summed
 	return SLAMPP_HIP_OK;
 }
 
@@ -1865,6 +2116,8 @@ int slampp_hip_get_profile(slampp_hip_solver *p_solver, slampp_hip_phase_time *p
 {
 	if(!p_solver || !p_phase_num)
 		return SLAMPP_HIP_ERR_INVALID;
+	if(p_solver->b_group_active) // the phases of member 0 (the primary: the one that also adds the camera blocks)
+		return slampp_hip_get_profile(group_member(*p_solver->p_group, 0), p_phases, n_max_phases, p_phase_num, b_reset);
 	slampp_hip_solver &s = *p_solver;
 	*p_phase_num = int(s.phase_names.size());
 	for(int i = 0; i < *p_phase_num && i < n_max_phases && p_phases; ++ i) {
@@ -1884,6 +2137,8 @@ int slampp_hip_set_allreduce(slampp_hip_solver *p_solver, slampp_hip_allreduce_f
 {
 	if(!p_solver)
 		return SLAMPP_HIP_ERR_INVALID;
+	if(!p_solver->group_devices.empty() && p_fn)
+		return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "set_allreduce: a handle over several devices exchanges inside the library");
 	p_solver->p_allreduce = p_fn;
 	p_solver->p_allreduce_context = p_context;
 	return SLAMPP_HIP_OK;

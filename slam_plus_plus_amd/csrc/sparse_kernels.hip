@@ -114,8 +114,10 @@ factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double 
 	long long *p_tm = 0;
 	int n_tm = 0;
 	if(p.p_timing && blockIdx.x == 0 && tid == 0) {
-		p_tm = p.p_timing + 1 + 32 * atomicAdd((unsigned long long*)p.p_timing, 1ull);
-		p_tm[n_tm ++] = wall_clock64();
+		const unsigned long long n_tm_record = atomicAdd((unsigned long long*)p.p_timing, 1ull);
+		p_tm = (n_tm_record < 4096)? p.p_timing + 1 + 32 * n_tm_record : 0; // the buffer holds 4096 launch records: later launches go unrecorded
+		if(p_tm)
+			p_tm[n_tm ++] = wall_clock64();
 	}
 #define STAGE_TICK() do { if(p_tm && n_tm < 32) p_tm[n_tm ++] = wall_clock64(); } while(0)
 	const int64_t c_begin = p.task_ptr[task], c_end = p.task_ptr[task + 1];
@@ -710,6 +712,21 @@ void launch_dense_scatter(const TDenseCol *cols, int n_cols, const double *x_den
 	if(n_cols > 0)
 		hipLaunchKernelGGL(dense_scatter_kernel, dim3((n_cols * 8 + 255) / 256), dim3(256), 0, stream, cols, n_cols,
 			x_dense, w, x_out);
+}
+
+// values of a structure whose wide block columns were cut into pieces (solver.hip: Refine_Structure): dst[i] = src[map[i]]
+__global__ void gather_values_kernel(const int64_t *__restrict__ p_map, int64_t n, const double *__restrict__ p_src,
+	double *__restrict__ p_dst)
+{
+	for(int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+		p_dst[i] = p_src[p_map[i]];
+}
+
+void launch_gather_values(const int64_t *p_map, int64_t n, const double *p_src, double *p_dst, hipStream_t stream)
+{
+	if(n > 0)
+		hipLaunchKernelGGL(gather_values_kernel, dim3(unsigned(std::min<int64_t>((n + 255) / 256, 8192))), dim3(256), 0, stream,
+			p_map, n, p_src, p_dst);
 }
 
 } // namespace slampp

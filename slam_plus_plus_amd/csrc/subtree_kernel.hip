@@ -47,8 +47,10 @@ factor_subtree_image_kernel(TDevPlan p, const double *__restrict__ A, double *L,
 	long long *p_tm = 0; // development aid (SLAMPP_HIP_STAGE_TIMING): clock samples of a workgroup in the middle of the grid
 	int n_tm = 0;
 	if(p.p_timing && blockIdx.x == gridDim.x / 2 && lane == 0) {
-		p_tm = p.p_timing + 1 + 32 * atomicAdd((unsigned long long*)p.p_timing, 1ull);
-		p_tm[n_tm ++] = wall_clock64();
+		const unsigned long long n_tm_record = atomicAdd((unsigned long long*)p.p_timing, 1ull);
+		p_tm = (n_tm_record < 4096)? p.p_timing + 1 + 32 * n_tm_record : 0; // the buffer holds 4096 launch records: later launches go unrecorded
+		if(p_tm)
+			p_tm[n_tm ++] = wall_clock64();
 	}
 #define SUBTREE_TICK() do { if(p_tm && n_tm < 32) p_tm[n_tm ++] = wall_clock64(); } while(0)
 	const int64_t c_begin = p.task_ptr[task], c_end = p.task_ptr[task + 1];

@@ -62,6 +62,13 @@ class PlanView(C.Structure):
         ("p_dense_pos", C.c_void_p), ("dense_dim", C.c_int64)]
 
 
+class ShardView(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "n_bcols", "n_blocks", "n_camera_values", "n_value_begin", "n_value_end", "n_camera_scalars", "n_scalar_begin",
+        "n_scalar_end", "n_point_begin", "n_point_end")] + [
+        ("p_bcol_cumsum", C.c_void_p), ("p_bcol_ptr", C.c_void_p), ("p_brow_idx", C.c_void_p)]
+
+
 class PhaseTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("n_count", C.c_int64), ("f_total_ms", C.c_double)]
 
@@ -72,6 +79,10 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 _P = C.c_void_p
 ABI = {
     "slampp_hip_create": (C.c_int, [C.POINTER(_P), C.c_int]),
+    "slampp_hip_create_multi": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int), C.c_int]),
+    "slampp_hip_group_info": (C.c_int, [_P, C.POINTER(C.c_int), _P, C.c_int, C.POINTER(C.c_char_p)]),
+    "slampp_hip_group_exchange_selftest": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int64, C.c_char_p, C.c_int]),
+    "slampp_hip_landmark_shard": (C.c_int, [C.c_int64, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.POINTER(ShardView)]),
     "slampp_hip_destroy": (None, [_P]),
     "slampp_hip_free_memory": (C.c_int, [_P]),
     "slampp_hip_last_error": (C.c_char_p, [_P]),
@@ -164,6 +175,36 @@ def _fetch_plan(getter) -> dict:
     return out
 
 
+def group_exchange_selftest(devices, exchange: int = 0, count: int = 1 << 16):
+    """(status, name of the exchange used): the all-reduce of a multi-device handle by itself (slampp_hip_group_exchange_selftest)."""
+    lib = load_library()
+    ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+    buf = C.create_string_buffer(256)
+    rc = lib.slampp_hip_group_exchange_selftest(ids, len(devices), int(exchange), int(count), buf, 256)
+    return rc, buf.value.decode()
+
+
+def landmark_shard_structure(lam, rank: int, world: int) -> dict:
+    """The library's own shard splitter (slampp_hip_landmark_shard; host code, no GPU): structure arrays and value /
+    right-hand side ranges of the landmark shard ``rank`` of ``world`` holds."""
+    lib = load_library()
+    cs = np.ascontiguousarray(lam.cumsum, dtype=np.int64)
+    bp = np.ascontiguousarray(lam.bcol_ptr, dtype=np.int64)
+    br = np.ascontiguousarray(lam.brow_idx, dtype=np.int32)
+    v = ShardView()
+    args = (lam.n_bcols, _ptr(cs), _ptr(bp), _ptr(br), int(lam.n_matrix_cut), int(rank), int(world))
+    if lib.slampp_hip_landmark_shard(*args, C.byref(v)) != OK:
+        raise ValueError("slampp_hip_landmark_shard refused the arguments")
+    out = {"cumsum": np.zeros(v.n_bcols + 1, dtype=np.int64), "bcol_ptr": np.zeros(v.n_bcols + 1, dtype=np.int64),
+           "brow_idx": np.zeros(v.n_blocks, dtype=np.int32)}
+    v.p_bcol_cumsum, v.p_bcol_ptr, v.p_brow_idx = (out[k].ctypes.data for k in ("cumsum", "bcol_ptr", "brow_idx"))
+    if lib.slampp_hip_landmark_shard(*args, C.byref(v)) != OK:
+        raise ValueError("slampp_hip_landmark_shard refused the arguments")
+    for k, _ in ShardView._fields_[:10]:
+        out[k] = int(getattr(v, k))
+    return out
+
+
 def host_plan(lam, leaf_size: int = 0, subtree_size: int = 0, dense_top_nb: int = -1):
     """Ordering + symbolic analysis + schedule on the host only (no GPU): (plan dict, stats dict).
     ``dense_top_nb`` < 0 = the library default, 0 = no dense top."""
@@ -193,13 +234,28 @@ class _SolverBase:
 
     _mode = MODE_SPARSE
 
-    def __init__(self, device: int = 0, **options):
+    def __init__(self, device: int = 0, devices=None, **options):
+        """``devices``: a list of HIP device ordinals -- one handle over several GPUs of this process
+        (slampp_hip_create_multi): a BA system is cut into landmark shards, one per listed device, and the reduced camera
+        system is summed inside the library (RCCL, or peer pointers); pose graphs run on ``devices[0]``."""
         self._lib = load_library()
         self._h = C.c_void_p()
-        rc = self._lib.slampp_hip_create(C.byref(self._h), int(device))
+        self._devices = None if devices is None else [int(d) for d in devices]
+        if self._devices is not None:
+            if not self._devices:
+                raise ValueError("devices must name at least one device")
+            ids = (C.c_int * len(self._devices))(*self._devices)
+            rc = self._lib.slampp_hip_create_multi(C.byref(self._h), ids, len(self._devices))
+            device = self._devices[0]
+        else:
+            rc = self._lib.slampp_hip_create(C.byref(self._h), int(device))
+        if rc == ERR_INVALID:
+            self._h = None
+            raise ValueError(f"slampp_hip_create_multi(devices={self._devices}) refused the device list")
         if rc != OK:
             self._h = None
             raise RuntimeError(f"slampp_hip_create(device={device}) failed ({rc}): no usable HIP device")
+        self._device = int(device)
         self._options = dict(options)
         for k, v in options.items():
             self._check(self._lib.slampp_hip_set_option(self._h, k.encode(), int(v)))
@@ -214,7 +270,17 @@ class _SolverBase:
         return type(self)(**self._ctor_args())
 
     def _ctor_args(self):
-        return dict(self._options)
+        return dict(self._options, device=self._device, devices=self._devices)
+
+    def group_info(self) -> dict:
+        """Members in use, their landmark ranges and the exchange of a handle made with ``devices=[...]``
+        (``{"members": 0, ...}`` while the handle is not solving with shards)."""
+        n = C.c_int(0)
+        name = C.c_char_p()
+        bounds = np.zeros(17, dtype=np.int64)
+        self._check(self._lib.slampp_hip_group_info(self._h, C.byref(n), _ptr(bounds), 16, C.byref(name)))
+        return {"members": n.value, "point_bounds": bounds[:n.value + 1].tolist() if n.value else [],
+                "exchange": (name.value or b"").decode()}
 
     def __del__(self):
         try:
@@ -251,14 +317,30 @@ class _SolverBase:
         self._analyzed = False
 
     def _key(self, lam):
-        # the same array objects as last time (what an iteration loop passes): no need to hash 10^6 indices again
-        ident = (id(lam.bcol_ptr), id(lam.brow_idx), id(lam.cumsum))
-        if getattr(self, "_key_ident", None) == ident and self._key_arrays[0] is lam.bcol_ptr:
+        """Identity of the block structure.  The same array objects as last time (what an iteration loop passes) are not
+        hashed again -- 10^6 indices per call --, but they are not trusted blindly either: a caller that edits the index
+        arrays in place (same objects, same shapes) would otherwise have the old analysis applied to a new pattern, a wrong
+        answer without an error.  So the fast path compares a strided sample of each array (1024 entries + both ends)
+        with what was there when the key was taken; a system that carries a ``structure_version`` counter is keyed on that
+        as well.  An edit that misses every sampled entry still needs ``Clear_SymbolicDecomposition()``, as in the
+        reference (LinearSolverTags.h:112-120)."""
+        arrays = (lam.bcol_ptr, lam.brow_idx, lam.cumsum)
+        ident = tuple(id(a) for a in arrays) + (getattr(lam, "structure_version", None),)
+        if getattr(self, "_key_ident", None) == ident and all(a is b for a, b in zip(self._key_arrays, arrays)) and \
+                all(np.array_equal(self._sample(a), s) for a, s in zip(arrays, self._key_samples)):
             return self._key_value
         key = (lam.n_bcols, lam.n_blocks, int(lam.cumsum[-1]),
                hash(lam.bcol_ptr.tobytes()), hash(lam.brow_idx.tobytes()), hash(lam.cumsum.tobytes()))
-        self._key_ident, self._key_arrays, self._key_value = ident, (lam.bcol_ptr, lam.brow_idx, lam.cumsum), key
+        self._key_ident, self._key_arrays, self._key_value = ident, arrays, key
+        self._key_samples = tuple(self._sample(a).copy() for a in arrays)
         return key
+
+    @staticmethod
+    def _sample(a: np.ndarray) -> np.ndarray:
+        n = a.shape[0]
+        if n <= 2048:
+            return a
+        return np.concatenate([a[::max(n // 1024, 1)], a[-2:]])
 
     def _n_matrix_cut(self, lam) -> int:
         return 0
@@ -412,10 +494,10 @@ class CLinearSolver_Schur_HIP(_SolverBase):
     _Tag = "CBlockwiseLinearSolverTag"
     _mode = MODE_SCHUR
 
-    def __init__(self, base_solver=None, device: int = 0, **options):
+    def __init__(self, base_solver=None, device: int = 0, devices=None, **options):
         # the reference's constructor takes (and ignores) a base solver instance
         # (LinearSolver_Schur.h:1472-1474); accepted for signature parity
-        super().__init__(device=device, **options)
+        super().__init__(device=device, devices=devices, **options)
         self._cut_override = None
 
     def _n_matrix_cut(self, lam) -> int:
@@ -427,7 +509,10 @@ class CLinearSolver_Schur_HIP(_SolverBase):
         wide = dims == dims.max()
         n_cut = int(np.count_nonzero(wide))
         if n_cut == 0 or n_cut == len(dims) or not np.all(wide[:n_cut]):
-            raise NotImplementedError("guided ordering: cameras must precede landmarks in Lambda")
+            # no landmark part (the reference hands such a system to its base solver, LinearSolver_Schur.h:1635-1638), or
+            # cameras and landmarks interleaved (the C++ header permutes them; this mirror does not): cut 0 sends the
+            # whole of Lambda through the sparse block path, which gives the same solution
+            return 0
         return n_cut
 
     def SymbolicDecomposition_Blocky(self, lam, b_force_guided_ordering: bool = False) -> bool:

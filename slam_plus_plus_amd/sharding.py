@@ -24,8 +24,13 @@ def shard_bounds(lam: BlockSystem, world: int) -> np.ndarray:
     cum = np.concatenate([[0], np.cumsum(obs)])
     targets = cum[-1] * np.arange(1, world) / world
     inner = np.searchsorted(cum, targets, side="left")
-    b = np.concatenate([[0], inner, [n_pts]]).astype(np.int64)
-    return np.maximum.accumulate(b)
+    b = np.maximum.accumulate(np.minimum(np.concatenate([[0], inner, [n_pts]]), n_pts).astype(np.int64))
+    if n_pts >= world:      # no rank without landmarks (csrc/group.hip: shard_bounds applies the same rule)
+        for r in range(1, world):
+            b[r] = max(b[r], b[r - 1] + 1)
+        for r in range(world - 1, 0, -1):
+            b[r] = min(b[r], b[r + 1] - 1)
+    return b
 
 
 def landmark_shard(lam: BlockSystem, rank: int, world: int) -> tuple[BlockSystem, slice]:

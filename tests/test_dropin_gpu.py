@@ -59,6 +59,11 @@ def test_reference_nonlinear_solver_with_hip_linear_solver(tmp_path):
     k = r["ba_lm_schur"]
     assert k["iterations_ref"] == k["iterations_hip"] > 0 and k["hip_schur_solves"] >= k["iterations_hip"], k
     assert abs(k["chi2_ref"] - k["chi2_hip"]) <= 1e-10 * abs(k["chi2_ref"]) and k["state_rel_inf"] < 1e-5, k
+    # the same run with a device list taken from the environment (SLAMPP_HIP_DEVICES, here "0,0": two members on the one GPU
+    # of the test box): every Schur solve of the unchanged LM solver ran as landmark shards inside the library
+    k = r["ba_lm_schur_devices"]
+    assert k["sharded_solves"] >= k["iterations_hip"] > 0 and k["state_rel_inf"] < 1e-5, k
+    assert abs(k["chi2_ref"] - k["chi2_hip"]) <= 1e-10 * abs(k["chi2_ref"]), k
     assert out.returncode == 0 and r["failures"] == 0, r
 
 

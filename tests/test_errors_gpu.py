@@ -35,12 +35,6 @@ def test_malformed_structure_is_rejected_with_an_exception():
     assert solver.Solve_PosDef(lam, eta) and rel_inf(eta, O.solve_sparse(lam)[1]) < 1e-10
 
 
-def test_block_dimension_above_eight_is_unsupported_not_wrong():
-    lam = synth.pose_chain(n=12, d=9, loop_every=5, loop_min=2, loop_max=4)
-    with pytest.raises(NotImplementedError):
-        CLinearSolver_HIP().Solve_PosDef(lam, lam.rhs.copy())
-
-
 def test_free_memory_and_reuse_and_copy_semantics():
     lam_a, lam_b = synth.sphere(12, 12, seed=1), synth.pose_chain(n=700, d=3, seed=2)
     solver = CLinearSolver_HIP(leaf_size=8)
@@ -64,11 +58,12 @@ def test_structure_change_without_notice_is_detected_by_the_python_mirror():
     assert rel_inf(eb, O.solve_sparse(b)[1]) < 1e-10
 
 
-def test_schur_solver_falls_back_to_nothing_silently():
-    """A pose-only system has no landmark part: the Schur class must say so, not return numbers."""
+def test_schur_fallback_can_be_switched_off():
+    """Option schur_fallback = 0: a structure the Schur kernels do not take is an error again (the default solves it
+    through the sparse block path, tests/test_fallback_gpu.py)."""
     lam = synth.pose_chain(n=30, d=6)
     with pytest.raises((NotImplementedError, ValueError)):
-        CLinearSolver_Schur_HIP().Solve_PosDef(lam, lam.rhs.copy())
+        CLinearSolver_Schur_HIP(schur_fallback=0).Solve_PosDef(lam, lam.rhs.copy())
 
 
 def test_nan_in_lambda_is_reported_as_failure():

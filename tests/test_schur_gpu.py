@@ -129,13 +129,6 @@ def test_indefinite_reduced_system_returns_false():
     assert CLinearSolver_Schur_HIP().Solve_PosDef(bad, eta) is False
 
 
-def test_unsupported_structure_raises():
-    lam = synth.pose_chain(n=50, d=6)                 # no landmark part at all
-    solver = CLinearSolver_Schur_HIP()
-    with pytest.raises((NotImplementedError, ValueError)):
-        solver.Solve_PosDef(lam, lam.rhs.copy())
-
-
 def test_full_size_c4_residual_and_linearity():
     """BASELINE config C4 (1k cams x 500k points): size-independent checks -- the residual of the
     full system and linearity in eta."""
