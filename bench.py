@@ -12,9 +12,12 @@ are in DESIGN.md, never here.
   python bench.py --workload ba                             # C4: 1k cams x 500k points, Schur path
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: the pose-graph factorization does not shard (one elimination tree) -> N independent
-replicas, "scaling": "weak".  The BA workload shards landmarks over the ranks (weak: a fixed
-number of points per GPU) with one RCCL all-reduce of the reduced camera system per step.
+Multi-GPU (N > 1): the headline is STRONG scaling of one fixed BA system -- BASELINE config 5, 2 000 cameras x
+2 000 000 landmarks (and, beside it, the north star's 1 000 x 1 000 000) -- cut into N landmark shards
+(slam_plus_plus_amd/sharding.py, the rule of the library's own splitter), one rank per GPU, one RCCL all-reduce of the
+packed blocks of the reduced camera system per step; "scaling": "strong".  The N = 1 line carries the same two systems
+on one GPU (`ba_c5`, `ba_1k_1m`), so the curve has its first point.  The pose-graph factorization does not shard (one
+elimination tree): at N > 1 it runs as N independent replicas and is reported beside the headline (`pose_graph_replicas`).
 
 One JSON line on stdout (rank 0).  `value` = algorithmic GFLOP/s of the whole job; `ms_per_step` =
 wall-clock per Lambda solve; `roofline` = dominant kernel against HBM peak, timed with HIP events
@@ -624,17 +627,53 @@ def dataclasses_replace_points(lam, n_keep):
                        lam.values[:off[nb]].copy(), lam.rhs[:int(lam.cumsum[n])].copy(), nc)
 
 
-def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", extras=True):
-    """C4 (N=1) / landmark-sharded weak scaling (N>1): `--ba-cams` cameras, `--ba-points` points per GPU.
+def shared_system(tag, make, rank, world, dist):
+    """One fixed system for all ranks: rank 0 builds it (the generator is a minute of numpy at 2 M landmarks), the others
+    map its arrays from /dev/shm and copy out only what their shard needs."""
+    if world == 1:
+        return make()
+    from slam_plus_plus_amd.synth import BlockSystem
+    base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir(),
+                        f"slampp_bench_{os.environ.get('MASTER_PORT', '0')}_{tag}")
+    names = ("cumsum", "bcol_ptr", "brow_idx", "values", "rhs")
+    lam = None
+    if rank == 0:
+        lam = make()
+        for n_ in names:
+            np.save(f"{base}_{n_}.npy", getattr(lam, n_))
+        with open(f"{base}_cut.txt", "w") as f:
+            f.write(str(int(lam.n_matrix_cut)))
+    dist.barrier()
+    if rank != 0:
+        arrays = [np.load(f"{base}_{n_}.npy", mmap_mode="r") for n_ in names]
+        lam = BlockSystem(*arrays, int(open(f"{base}_cut.txt").read()), tag)
+    dist.barrier()
+    if rank == 0:    # (the others hold their mappings open: the names can go)
+        for n_ in names:
+            os.unlink(f"{base}_{n_}.npy")
+        os.unlink(f"{base}_cut.txt")
+    return lam
+
+
+def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", extras=True, cams=None, points=None, label=None):
+    """One BA system of `cams` cameras x `points` landmarks in total (default: C4, --ba-cams x --ba-points), solved
+    through the Schur complement.  N > 1: the SAME system cut into N landmark shards, one per rank (strong scaling), the
+    partial reduced camera systems summed by one RCCL all-reduce per step.
     schur_sparse: -1 = the library decides how to factor the reduced camera system (sparse block path when under 15 %
-    of its blocks are nonzero, as with this workload's band visibility), 0 = force the dense MFMA factorization."""
+    of its blocks are nonzero), 0 = force the dense MFMA factorization."""
     import torch
-    from slam_plus_plus_amd import synth
+    from slam_plus_plus_amd import synth, sharding
     from slam_plus_plus_amd.hip_solver import CLinearSolver_Schur_HIP
 
     dev = torch.device(f"cuda:{local_rank}")
     k = 4
-    lam = synth.ba(args.ba_cams, args.ba_points, k=k, mode=mode, seed=777 + rank, cam_damping=0.1 / world)
+    n_cams, n_points_total = cams or args.ba_cams, points or args.ba_points
+    lam_full = shared_system(f"ba_{n_cams}x{n_points_total}_{mode}",
+                             lambda: synth.ba(n_cams, n_points_total, k=k, mode=mode, seed=777), rank, world, dist)
+    if world > 1:
+        lam, own = sharding.landmark_shard(lam_full, rank, world)   # A and eta_x as 1 / world on every rank: the sum is the system
+    else:
+        lam, own = lam_full, slice(int(lam_full.cumsum[lam_full.n_matrix_cut]), lam_full.n_scalars)
     solver = CLinearSolver_Schur_HIP(device=local_rank, schur_sparse=schur_sparse)
     t0 = time.perf_counter()
     solver.SymbolicDecomposition_Blocky(lam)
@@ -684,27 +723,54 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
     del extra_rhs
     prof = dict({k_: v[1] / max(v[0], 1) for k_, v in solver.profile().items()}, **prof)
     solver.profile(reset=True)
+    red = solver.reduced_stats()
+    x_local = bufs[-1].cpu().numpy()
+    totals = np.array([st["n_points"], st["n_observations"], st["n_update_pairs"]], dtype=np.float64)
+    phases_by_rank, parity = [prof], None
+    if world > 1:
+        # the whole system's counts, every rank's phases, and the parity guard of the sharded solution: the residual of the
+        # FULL system, assembled from every rank's landmarks (rank 0 holds the full matrix: it built it)
+        t = torch.from_numpy(totals).to(dev)
+        dist.all_reduce(t)
+        totals = t.cpu().numpy()
+        phases_by_rank = [None] * world
+        dist.all_gather_object(phases_by_rank, prof)
+        pieces = [None] * world
+        dist.all_gather_object(pieces, (own.start, own.stop, x_local[int(lam_full.cumsum[lam_full.n_matrix_cut]):]))
+        if rank == 0:
+            x_full = np.empty(lam_full.n_scalars)
+            x_full[:int(lam_full.cumsum[lam_full.n_matrix_cut])] = x_local[:int(lam_full.cumsum[lam_full.n_matrix_cut])]
+            for a_, b_, piece in pieces:
+                x_full[a_:b_] = piece
+            parity = float(np.abs(lam_full.to_scipy() @ x_full - lam_full.rhs).max() / np.abs(lam_full.rhs).max())
     if rank != 0:
         return None
     ms = dt / steps * 1e3
-    n_obs, n_pts, N = st["n_observations"], st["n_points"], st["schur_dim"]
+    n_pts, n_obs, n_pairs, N = int(totals[0]), int(totals[1]), int(totals[2]), st["schur_dim"]
     # per point with k observations 58 + 108 k + 216 k (k + 1) / 2 flops for the Schur
     # products, 2 flops per stored scalar of U for each of the 3 SpMV passes, n^3/3 + ... for the dense factor
-    schur_flops = n_pts * 58.0 + 108.0 * n_obs + 216.0 * st["n_update_pairs"] + 3 * 2.0 * 18 * n_obs
+    schur_flops = n_pts * 58.0 + 108.0 * n_obs + 216.0 * n_pairs + 3 * 2.0 * 18 * n_obs   # the whole system's (all shards)
     dense_flops = st["factor_flops"] + st["solve_flops"]
     b_dense = "dense_chol" in prof
-    # the dense factor is redundant on every rank: counted once; with the sparse reduced solve its (much smaller) flop
-    # count is not known here and is left out
-    flops = schur_flops * world + (dense_flops if b_dense else 0.0)
+    # the factorization of the reduced system is redundant on every rank: counted once -- n^3/3 for the dense one, the inner
+    # plan's own count (sum of squared column counts under our ordering + 4 nnz(L)) for the sparse one
+    reduced_flops = dense_flops if b_dense else red["factor_flops"] + red["solve_flops"]
+    flops = schur_flops + reduced_flops
     out = {
-        "workload": f"{'C4' if world == 1 else 'landmark-sharded'}: BA {args.ba_cams} cams x {args.ba_points * world} points "
-                    f"({args.ba_points}/GPU), {'2..30 (mean 5.3)' if mode == 'venice' else k} obs/point, {mode} visibility; Schur complement + "
+        "workload": f"{label or ('C4' if (n_cams, n_points_total) == (1000, 500_000) else 'BA')}: BA {n_cams} cams x {n_points_total} points"
+                    f"{'' if world == 1 else f' as {world} landmark shards (one fixed system: strong scaling)'}, "
+                    f"{'2..30 (mean 5.3)' if mode == 'venice' else k} obs/point, {mode} visibility; Schur complement + "
                     f"{'dense (MFMA)' if b_dense else 'sparse block'} factorization of the reduced system, per step",
         "reduced_system": "dense" if b_dense else "sparse",
-        "ms_per_step": ms, "points_per_s": n_pts * world / (dt / steps), "GFLOP/s": flops / (dt / steps) / 1e9,
-        "n_gpus": world, "steps": steps, "schur_dim": N, "n_observations_per_gpu": n_obs, "analyze_ms_cold": analyze_ms,
-        "phases_ms": prof, "n_camera_pair_blocks": st["l_blocks"], "n_contributions": st["n_update_pairs"],
+        "ms_per_step": ms, "points_per_s": n_pts / (dt / steps), "GFLOP/s": flops / (dt / steps) / 1e9,
+        "n_gpus": world, "steps": steps, "schur_dim": N, "n_observations": n_obs, "analyze_ms_cold": analyze_ms,
+        "phases_ms": prof, "n_camera_pair_blocks": st["l_blocks"], "n_contributions": n_pairs,
+        "algorithmic_flops": {"schur": schur_flops, "reduced_system": reduced_flops},
     }
+    if world > 1:
+        out["phases_ms_by_rank"] = phases_by_rank
+        out["solve_residual_rel_inf"] = parity
+        out["exchange"] = "torch.distributed all_reduce (RCCL) of the packed blocks of S + the reduced right-hand side, on the solver's stream"
     traffic, traffic_file = load_traffic("ba" if mode == "band" else "ba_" + mode)
     if "dense_chol" in prof:
         tf = st["factor_flops"] / (prof["dense_chol"] * 1e-3) / 1e12
@@ -722,7 +788,8 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
     if "schur_tiles" in prof:
         # landmark-major assembly (schur_tiles.hip): every landmark's column of Lambda is read once -- 144 B per observation,
         # 72 B of C and 24 B of l per landmark --, C^-1 written (72 B), every block of S read and written once
-        nbytes = 144.0 * n_obs + (72.0 + 24.0 + 72.0) * n_pts + 2 * 8.0 * 36 * st["l_blocks"]
+        # (per launch = this rank's shard)
+        nbytes = 144.0 * st["n_observations"] + (72.0 + 24.0 + 72.0) * st["n_points"] + 2 * 8.0 * 36 * st["l_blocks"]
         gb = nbytes / (prof["schur_tiles"] * 1e-3) / 1e9
         tr = None
         if traffic:
@@ -747,6 +814,23 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
                                         "ms_per_launch": prof["schur_gather"]}
         if not b_dense:   # then the gather is the dominant kernel of the step
             out["roofline"] = out["roofline_schur_gather"]
+    if "reduced_sparse" in prof and red["l_nnz"] > 0:
+        # the reduced camera system through the sparse block path (inner plan: its own nested dissection, a dense top on the
+        # matrix cores where it has one).  Priced both ways: SURVEY 8d bytes (8 (nnz + lnz) for the factor, 16 lnz + 32 n for
+        # the substitutions) against HBM, and the inner plan's flops against the fp64 MFMA peak -- with a dense top the
+        # flops are what the phase is made of, without one it is a chain of small launches and neither roof is near
+        r_bytes = 8.0 * (red["nnz_upper"] + red["l_nnz"]) + 16.0 * red["l_nnz"] + 32.0 * red["n_scalars"]
+        r_flops = red["factor_flops"] + red["solve_flops"]
+        t_s = prof["reduced_sparse"] * 1e-3
+        b_top = red["schur_dim"] > 0
+        out["roofline_reduced_sparse"] = {
+            "bound": "mfma" if b_top else "hbm", "kernel": "reduced camera system: sparse block Cholesky + substitutions "
+            f"({red['n_stages']} stages{', dense top of dimension %d on the matrix cores' % red['schur_dim'] if b_top else ''})",
+            "achieved": (r_flops / t_s / 1e12) if b_top else (r_bytes / t_s / 1e9),
+            "peak": F64_MFMA_PEAK_TFLOPS if b_top else HBM_PEAK_GBS, "unit": "TFLOP/s" if b_top else "GB/s",
+            "frac": (r_flops / t_s / 1e12 / F64_MFMA_PEAK_TFLOPS) if b_top else (r_bytes / t_s / 1e9 / HBM_PEAK_GBS),
+            "traffic": None, "algorithmic_flops": r_flops, "algorithmic_bytes": r_bytes, "ms_per_step": prof["reduced_sparse"],
+            "l_nnz": red["l_nnz"], "dense_top_dim": red["schur_dim"]}
     if world == 1:
         x = bufs[-1].cpu().numpy()
         out["solve_residual_rel_inf"] = float(np.abs(lam.to_scipy() @ x - lam.rhs).max() / np.abs(lam.rhs).max())
@@ -775,12 +859,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="all", choices=["all", "c3", "ba"])
     ap.add_argument("--ba-cams", type=int, default=1000)
-    ap.add_argument("--ba-points", type=int, default=500_000, help="landmarks per GPU")
+    ap.add_argument("--ba-points", type=int, default=500_000, help="landmarks of the C4 system")
     ap.add_argument("--ba-steps", type=int, default=5)
     ap.add_argument("--poses", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ba-solve-only", action="store_true", help="leave out the legs beside the solve (host path, marginals, incremental update, assembly): the counter passes of tools/profile_round.sh, whose per-kernel averages should be the solve's")
-    ap.add_argument("--ba-legs", default="band,uniform,venice", help="which visibility models the BA part runs (profiling runs one at a time)")
+    ap.add_argument("--ba-legs", default="venice,band,uniform", help="which visibility models the C4 part runs, the first as `ba_schur` (profiling runs one at a time)")
+    ap.add_argument("--c5-cams", type=int, default=2000)
+    ap.add_argument("--c5-points", type=int, default=2_000_000, help="landmarks of the fixed system `--gpus N` shards (BASELINE config 5)")
+    ap.add_argument("--c5-mode", default="band", choices=["band", "venice", "uniform"])
+    ap.add_argument("--target-cams", type=int, default=1000)
+    ap.add_argument("--target-points", type=int, default=1_000_000, help="the north star's 1k-camera / 1M-point system, reported beside C5")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -811,31 +900,57 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     out = None
-    if args.workload in ("all", "c3"):
-        out = run_c3(args, rank, world, local_rank, dist)
     legs = [m for m in args.ba_legs.split(",") if m]
-    if args.workload in ("all", "ba"):
-        ba = run_ba(args, rank, world, local_rank, dist, mode=legs[0], extras=legs[0] == "band" and not args.ba_solve_only)
-        if rank == 0:
+
+    def promote(ba, scaling):
+        return {"metric": "BA Schur solve GFLOP/s (algorithmic flops / wall-clock)", "value": ba["GFLOP/s"],
+                "unit": "GFLOP/s", "n_gpus": world, "steps": ba["steps"], "warmup": 1, "ms_per_step": ba["ms_per_step"],
+                "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": ba["workload"], "parallelism": "1 GPU" if world == 1 else
+                           f"{world} landmark shards of one fixed system, one rank per GPU, RCCL all-reduce of the reduced camera system"},
+                "roofline": ba.get("roofline"), "cpu_baseline": ba.get("cpu_baseline")}
+
+    if world > 1:
+        # N > 1: strong scaling of the fixed C5 system (BASELINE config 5), the north star's 1k x 1M beside it; the pose
+        # graph (does not shard) as N replicas, reported but not the headline
+        strong = [(key, c, p) for key, c, p in (("ba_c5", args.c5_cams, args.c5_points), ("ba_1k_1m", args.target_cams, args.target_points))
+                  if args.workload in ("all", "ba")]
+        for i, (key, c, p) in enumerate(strong):
+            leg = run_ba(args, rank, world, local_rank, dist, mode=args.c5_mode, extras=False, cams=c, points=p,
+                         label="C5" if key == "ba_c5" else "north-star target")
+            if rank == 0:
+                if out is None:
+                    out = promote(leg, "strong")
+                out[key] = leg
+        if args.workload in ("all", "c3"):
+            c3 = run_c3(args, rank, world, local_rank, dist)
+            if rank == 0:
+                if out is None:
+                    out = c3
+                else:
+                    out["pose_graph_replicas"] = {k_: c3[k_] for k_ in ("metric", "value", "unit", "ms_per_step", "scaling", "config")}
+    else:
+        if args.workload in ("all", "c3"):
+            out = run_c3(args, rank, world, local_rank, dist)
+        if args.workload in ("all", "ba"):
+            # BASELINE config 4 is "Venice-style": that leg is `ba_schur`; band and uniform visibility (SURVEY.md section 8d:
+            # "band (sparse S) or uniformly (dense S -- report both)") ride beside it
+            first = legs[0]
+            ba = run_ba(args, rank, world, local_rank, dist, mode=first, extras=not args.ba_solve_only)
             if out is None:   # BA only: promote it to the headline
-                out = {"metric": "BA Schur solve GFLOP/s (algorithmic flops / wall-clock)", "value": ba["GFLOP/s"],
-                       "unit": "GFLOP/s", "n_gpus": world, "steps": ba["steps"], "warmup": 1, "ms_per_step": ba["ms_per_step"],
-                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                       "config": {"workload": ba["workload"]}, "roofline": ba.get("roofline"),
-                       "cpu_baseline": ba.get("cpu_baseline")}
+                out = promote(ba, "weak")
             out["ba_schur"] = ba
-        if world == 1 and args.workload == "all":
-            out["other_configs"] = run_small_configs(args, local_rank)
-        if world == 1:
-            # SURVEY.md section 8d, "band (sparse S) or uniformly (dense S -- report both)": uniform visibility makes every
-            # camera pair a block of S (500 k short contribution lists, the dense MFMA factorization); the Venice-like
-            # mode has ragged lists (2..30 observations per landmark)
-            for key, mode in (("ba_schur_uniform_dense_S", "uniform"), ("ba_schur_venice", "venice")):
-                if mode not in legs[1:]:
-                    continue
-                leg = run_ba(args, rank, world, local_rank, dist, mode=mode, extras=False)
-                if rank == 0:
-                    out[key] = leg
+            if args.workload == "all":
+                out["other_configs"] = run_small_configs(args, local_rank)
+            for key, mode in (("ba_schur_band", "band"), ("ba_schur_uniform_dense_S", "uniform"), ("ba_schur_venice", "venice")):
+                if mode in legs[1:]:
+                    out[key] = run_ba(args, rank, world, local_rank, dist, mode=mode, extras=False)
+            if args.workload == "all" and not args.ba_solve_only:
+                # the N = 1 points of the strong-scaling curves `bench.py --gpus N` reports
+                out["ba_c5"] = run_ba(args, rank, world, local_rank, dist, mode=args.c5_mode, extras=False, cams=args.c5_cams,
+                                      points=args.c5_points, label="C5")
+                out["ba_1k_1m"] = run_ba(args, rank, world, local_rank, dist, mode=args.c5_mode, extras=False, cams=args.target_cams,
+                                         points=args.target_points, label="north-star target")
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0 and out is not None:

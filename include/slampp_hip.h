@@ -264,6 +264,13 @@ void *slampp_hip_stream(slampp_hip_solver *p_solver); /* the hipStream_t every k
 
 int slampp_hip_get_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_stats);
 
+/* Schur mode, after the first solve: the same figures for the inner solver that factors the reduced camera system by the
+ * sparse block path (its factor's nonzeros and flops under our ordering, stages, the dimension of its dense top in
+ * schur_dim) -- what the roofline of the "reduced_sparse" phase is priced with; all zero when the reduced system is
+ * factored densely (then slampp_hip_get_stats has n^3/3).  A handle over several devices answers for member 0 (the
+ * reduced system is the same on every member). */
+int slampp_hip_get_reduced_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_stats);
+
 /* device-side phase timing (the counterpart of the reference's __SCHUR_PROFILING / CTimerSampler
  * phase timers, LinearSolver_Schur.h:1681-1912, Timer.h:391): with option "profile" = 1 every phase
  * of factor_solve is bracketed by HIP events on the solver's stream; the totals are collected at

@@ -114,6 +114,8 @@ void landmark_shard(int64_t n_bcols, const int64_t *p_cumsum, const int64_t *p_b
 	for(int64_t p = 0; p < n_own; ++ p) {
 		for(int64_t k = p_bcol_ptr[n_cut + p0 + p]; k < p_bcol_ptr[n_cut + p0 + p + 1]; ++ k) {
 			const int32_t n_row = p_brow[k]; // the landmarks' own (diagonal) blocks carry global row numbers
+			if(n_row >= n_cut && n_row != n_cut + p0 + p)
+				throw std::domain_error("landmark-landmark blocks present (C is not block diagonal): landmarks are not independent units");
 			r_out.brow[size_t(n_a_blocks + (k - k0))] = (n_row >= n_cut)? int32_t(n_row - p0) : n_row;
 		}
 	}
@@ -999,6 +1001,8 @@ int slampp_hip_landmark_shard(int64_t n_bcols, const int64_t *p_bcol_cumsum, con
 		return SLAMPP_HIP_OK;
 	} catch(std::bad_alloc&) {
 		return SLAMPP_HIP_ERR_ALLOC;
+	} catch(std::domain_error&) {
+		return SLAMPP_HIP_ERR_UNSUPPORTED;
 	} catch(std::exception&) {
 		return SLAMPP_HIP_ERR_INVALID;
 	}

@@ -135,6 +135,13 @@ void schur_set_changed_points(slampp_hip_solver &s, const int64_t *p_points, int
 	S.n_changed = n_points;
 }
 
+// stats of the inner solver that factors the reduced camera system by the sparse block path; false while there is none
+// (dense reduced system, or no solve has decided yet)
+bool schur_reduced_stats(const CSchurState *p, slampp_hip_stats &st)
+{
+	return p && p->b_reduced_decided && p->b_reduced_sparse && p->p_inner && slampp_hip_get_stats(p->p_inner, &st) == SLAMPP_HIP_OK;
+}
+
 void schur_fill_stats(const CSchurState *p, slampp_hip_stats &st)
 {
 	st.n_cams = p->nc;

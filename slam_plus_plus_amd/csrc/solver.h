@@ -240,6 +240,7 @@ size_t schur_device_bytes(const CSchurState *p);
 void schur_invalidate_previous(CSchurState *p); // the kept reduced system no longer matches what the caller last solved
 void schur_set_changed_points(slampp_hip_solver &s, const int64_t *p_points, int64_t n_points); // throws
 void schur_fill_stats(const CSchurState *p, slampp_hip_stats &st);
+bool schur_reduced_stats(const CSchurState *p, slampp_hip_stats &st);
 
 // several devices behind one handle (group.hip)
 CDeviceGroup *group_create(const int *p_device_ids, int n_devices); // throws

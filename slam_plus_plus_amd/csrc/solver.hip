@@ -2111,6 +2111,20 @@ int slampp_hip_get_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_
 	return SLAMPP_HIP_OK;
 }
 
+int slampp_hip_get_reduced_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_stats)
+{
+	if(!p_solver || !p_stats)
+		return SLAMPP_HIP_ERR_INVALID;
+	memset(p_stats, 0, sizeof(*p_stats));
+	if(p_solver->b_group_active && p_solver->p_group)
+		return slampp_hip_get_reduced_stats(group_member(*p_solver->p_group, 0), p_stats);
+	if(!p_solver->b_analyzed || p_solver->n_mode != SLAMPP_HIP_MODE_SCHUR)
+		return SLAMPP_HIP_ERR_INVALID;
+	if(!schur_reduced_stats(p_solver->p_schur, *p_stats))
+		memset(p_stats, 0, sizeof(*p_stats)); // dense reduced system (or none yet): all zero
+	return SLAMPP_HIP_OK;
+}
+
 int slampp_hip_get_profile(slampp_hip_solver *p_solver, slampp_hip_phase_time *p_phases, int n_max_phases,
 	int *p_phase_num, int b_reset)
 {

@@ -107,6 +107,7 @@ ABI = {
     "slampp_hip_sync": (C.c_int, [_P]),
     "slampp_hip_stream": (_P, [_P]),
     "slampp_hip_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "slampp_hip_get_reduced_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "slampp_hip_get_profile": (C.c_int, [_P, C.POINTER(PhaseTime), C.c_int, C.POINTER(C.c_int), C.c_int]),
     "slampp_hip_set_allreduce": (C.c_int, [_P, ALLREDUCE_FN, _P]),
     "slampp_hip_assembly_create": (C.c_int, [_P, C.POINTER(_P), C.c_int64, _P, _P, C.c_int]),
@@ -409,6 +410,12 @@ class _SolverBase:
     def stats(self) -> dict:
         st = Stats()
         self._check(self._lib.slampp_hip_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def reduced_stats(self) -> dict:
+        """Schur mode, after a solve: stats of the inner sparse solver of the reduced camera system (all zero: dense)."""
+        st = Stats()
+        self._check(self._lib.slampp_hip_get_reduced_stats(self._h, C.byref(st)))
         return st.as_dict()
 
     def set_option(self, name: str, value: int) -> None:

@@ -294,12 +294,14 @@ def ba(n_cams: int = 1000, n_pts: int = 500_000, k: int = 4, mode: str = "band",
     off = np.zeros(nb + 1, dtype=np.int64)
     np.cumsum(sz, out=off[1:])
     vals = np.empty(int(off[-1]))
-    vals[:n_cams * cd * cd] = Acc.transpose(0, 2, 1).ravel()
-    for c in range(pd_):            # element (r, c) of a block sits at c * rows + r (column-major)
-        for r in range(pd_):
-            vals[off[diag_pos] + (c * pd_ + r)] = Cpp[:, r, c]
-        for r in range(cd):
-            vals[off[off_pos] + (c * cd + r)] = U_s[:, r, c]
+    n_a = n_cams * cd * cd
+    vals[:n_a] = Acc.transpose(0, 2, 1).ravel()
+    # the landmark columns: per point its U blocks (sorted by camera: U_s is in storage order), then its C block; blocks
+    # are column-major.  One masked assignment per kind instead of a scatter per block element.
+    scalar_is_u = np.repeat(mask[n_cams:], sz[n_cams:])
+    pts = vals[n_a:]
+    pts[scalar_is_u] = U_s.transpose(0, 2, 1).ravel()
+    pts[~scalar_is_u] = Cpp.transpose(0, 2, 1).ravel()
     cumsum = np.concatenate([np.arange(n_cams + 1, dtype=np.int64) * cd,
                              n_cams * cd + np.arange(1, n_pts + 1, dtype=np.int64) * pd_])
     rhs = rng.standard_normal(int(cumsum[-1]))

@@ -2,6 +2,7 @@
 over gloo: SLAMPP_BENCH_ONE_DEVICE) -- every rank has to walk through the same solves, the BA solve holds a collective."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -10,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--poses", "3000", "--ba-cams", "60", "--ba-points", "4000", "--steps", "3", "--warmup", "1", "--ba-steps", "2",
-         "--no-cpu-baseline", "--ba-legs", "band"]
+         "--no-cpu-baseline", "--ba-legs", "band", "--c5-cams", "60", "--c5-points", "6000", "--target-cams", "40", "--target-points", "3000"]
 
 
 def last_json(text):
@@ -34,12 +35,36 @@ def test_bench_line(workload):
         assert d["solve_residual_rel_inf"] < 1e-9
 
 
-def test_bench_two_ranks_on_one_device():
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_ranks_on_one_device_strong_scaling(world):
+    """`--gpus N`: one fixed BA system cut into N landmark shards (strong scaling), every rank's phases with the all-reduce in
+    them, and the residual of the FULL system assembled from the ranks' pieces -- the parity guard of the sharded solve."""
     env = dict(os.environ, SLAMPP_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + SMALL
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["ba_schur"]["n_gpus"] == 2 and "allreduce" in d["ba_schur"]["phases_ms"]
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["value"] > 0
+    assert "C5" in d["config"]["workload"] and "60 cams x 6000 points" in d["config"]["workload"]
+    for key in ("ba_c5", "ba_1k_1m"):
+        leg = d[key]
+        assert leg["n_gpus"] == world and len(leg["phases_ms_by_rank"]) == world
+        assert all("allreduce" in ph for ph in leg["phases_ms_by_rank"])
+        assert leg["solve_residual_rel_inf"] < 1e-9, leg["solve_residual_rel_inf"]
+    assert d["pose_graph_replicas"]["scaling"] == "weak"
+
+
+def test_bench_default_run_carries_the_n1_points_of_the_scaling_curves():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 1 and "C3" in d["config"]["workload"]
+    for key in ("ba_schur", "ba_c5", "ba_1k_1m"):
+        assert d[key]["n_gpus"] == 1 and d[key]["solve_residual_rel_inf"] < 1e-9, key
