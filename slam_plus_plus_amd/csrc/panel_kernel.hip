@@ -100,7 +100,7 @@ __device__ __forceinline__ void panel_update_block(const TUpdSlot &sl, bool b_va
 template <int D, int CAP_BLK, bool b_fused>
 struct TPanelLds {
 	enum { DD = D * D, FRESH_BATCH = 4, UPD_BATCH = 8,
-		PKG = 0, IMAGE = PKG + 2 * PANEL_UNITS, VEC = IMAGE + CAP_BLK * DD, LINV = VEC + PANEL_COLS * 8, TILE = LINV + 64,
+		PKG = 0, IMAGE = PKG + 2 * PANEL_UNITS, VEC = IMAGE + CAP_BLK * DD, LINV = VEC + PANEL_COLS * 8, TILE = LINV + PANEL_COLS * 64,
 		OPS = TILE + PANEL_W * 64, YV = OPS + (b_fused? PANEL_W * 2 * FRESH_BATCH * DD : 0), PANEL_END = YV + (b_fused? PANEL_W * FRESH_BATCH * 8 : 0),
 		U_OPS = 0, U_YV = U_OPS + PANEL_W * 2 * UPD_BATCH * DD, U_PART = U_YV + PANEL_W * UPD_BATCH * 8, UPD_END = b_fused? U_PART + PANEL_W * 64 : 0,
 		TOTAL = (PANEL_END > UPD_END)? PANEL_END : UPD_END };
@@ -228,10 +228,16 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 		__syncthreads();
 	PANEL_TICK(); // fresh updates
 
-	// 2. the columns, inside the image
-	for(int ci = 0; ci < n_cols; ++ ci) {
-		const TPanelCol col = s_col[ci];
-		if(wave == 0) {
+	// 2. the columns, inside the image, level by level: the columns of one level of a tall task do not depend on each
+	// other (a chain is one column per level) -- their diagonal blocks go to one wave each, their blocks below in turn
+	// over all waves; two barriers and no memory round trip per level
+	for(int ci0 = 0; ci0 < n_cols;) {
+		const int n_sub = s_col[ci0].sub;
+		int ci1 = ci0 + 1;
+		while(ci1 < n_cols && s_col[ci1].sub == n_sub)
+			++ ci1;
+		for(int ci = ci0 + wave; ci < ci1; ci += W) {
+			const TPanelCol col = s_col[ci];
 			const double init = b_y? s_w[ci * D + yq] : (mm.b_act? s_L[col.slot0 * DD + lane] : 0.0);
 			double sum = 0;
 			for(int e = 0; e < col.inr; ++ e) {
@@ -243,23 +249,29 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 			cd.cs_new = col.cs_new;
 			const double acc = init - sum;
 			finish_diagonal_fixed<D>(cd, acc, acc, lane, b_y? 0 : mm.r, b_y? 0 : mm.q, mm.b_act, L, Linv, w, s_slot[col.slot0].loff,
-				p_flag, s_linv, s_L + col.slot0 * DD, s_w + ci * D);
+				p_flag, s_linv + ci * 64, s_L + col.slot0 * DD, s_w + ci * D);
 		}
 		__syncthreads();
-		PANEL_TICK(); // diagonal block
-		for(int kb = 1 + wave; kb < col.nb; kb += W) {
-			const int n_slot = col.slot0 + kb;
-			const TPanelSlot sd = s_slot[n_slot];
-			const double init = mm.b_act? s_L[n_slot * DD + lane] : 0.0;
-			double sum = 0;
-			for(int e = 0; e < sd.inp; ++ e) {
-				const uint32_t en = s_ipair[sd.ip0 + e];
-				sum += pair_product_image<D>(s_L + int(en & 0xffff) * DD, s_L + int(en >> 16) * DD, mm.r, mm.q);
+		PANEL_TICK(); // diagonal blocks of the level
+		int n_before = 0; // blocks below the diagonal in the level's columns before this one: block n of the level goes to wave n mod W
+		for(int ci = ci0; ci < ci1; ++ ci) {
+			const int n_slot0 = s_col[ci].slot0, n_nb = s_col[ci].nb;
+			for(int kb = 1 + ((wave - n_before) % W + W) % W; kb < n_nb; kb += W) {
+				const int n_slot = n_slot0 + kb;
+				const TPanelSlot sd = s_slot[n_slot];
+				const double init = mm.b_act? s_L[n_slot * DD + lane] : 0.0;
+				double sum = 0;
+				for(int e = 0; e < sd.inp; ++ e) {
+					const uint32_t en = s_ipair[sd.ip0 + e];
+					sum += pair_product_image<D>(s_L + int(en & 0xffff) * DD, s_L + int(en >> 16) * DD, mm.r, mm.q);
+				}
+				finish_offdiagonal<D>(init - sum, lane, mm.r, mm.q, mm.b_act, D, L, sd.loff, s_tile, s_linv + ci * 64, s_L + n_slot * DD);
 			}
-			finish_offdiagonal<D>(init - sum, lane, mm.r, mm.q, mm.b_act, D, L, sd.loff, s_tile, s_linv, s_L + n_slot * DD);
+			n_before += n_nb - 1;
 		}
-		__syncthreads(); // column ci and y_ci complete in the image
+		__syncthreads(); // the level's columns and their y complete in the image
 		PANEL_TICK();
+		ci0 = ci1;
 	}
 }
 

@@ -396,8 +396,11 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 }
 
 static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const int64_t *bcol_ptr,
-	const int32_t *brow, const PlanOptions &opt, Plan &P)
+	const int32_t *brow, const PlanOptions &r_opt, Plan &P)
 {
+	PlanOptions opt = r_opt;
+	if(const char *p_s_height = getenv("SLAMPP_HIP_TASK_HEIGHT")) // development aid: overrides the option
+		opt.task_height = std::min(std::max(atoi(p_s_height), 1), 3);
 	P = Plan();
 	if(n_bcols <= 0 || n_bcols > INT32_MAX / 2)
 		return "invalid number of block columns";
@@ -752,6 +755,86 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 		}
 		int32_t n_tasks = 0;
 		std::vector<int32_t> root_task(n, -1);
+		P.col_sub.assign(n, 0);
+		if(opt.task_height >= 2) {
+			// Tall tasks.  Every separator column gets a (stage, level inside the stage): one level above the highest of its
+			// separator children, a new stage every task_height levels; columns of one stage that are joined by tree edges
+			// form one task -- a slice of the elimination tree: its columns of one level are independent of each other, its
+			// leaf subtrees below were eliminated by earlier stages.  A slice that would outgrow the panel kernel's
+			// capacities is cut: the column starts the next stage instead.
+			const int h = std::min(opt.task_height, 3);
+			std::vector<int32_t> col_stage(n, 0), grp(n, -1), grp_cols(n, 0), grp_blocks(n, 0);
+			auto find = [&](int32_t v) { while(grp[v] != v) { grp[v] = grp[grp[v]]; v = grp[v]; } return v; };
+			std::vector<int32_t> top_first_child(n, -1), top_next_sibling(n, -1);
+			for(int32_t j = n - 1; j >= 0; -- j) { // (descending: the lists come out ascending)
+				const int32_t p = par[j];
+				if(!in_dense[j] && troot[j] < 0 && p >= 0) {
+					top_next_sibling[j] = top_first_child[p];
+					top_first_child[p] = j;
+				}
+			}
+			for(int32_t j = 0; j < n; ++ j) {
+				if(in_dense[j])
+					continue;
+				if(troot[j] >= 0) {
+					int32_t &r = root_task[troot[j]];
+					if(r < 0) {
+						r = n_tasks ++;
+						task_level.push_back(0);
+					}
+					task_of[j] = r;
+					continue;
+				}
+				int32_t s = 1, u = 0;
+				for(int32_t c = top_first_child[j]; c >= 0; c = top_next_sibling[c]) {
+					int32_t sc = col_stage[c], uc = P.col_sub[c] + 1;
+					if(uc >= h) {
+						++ sc;
+						uc = 0;
+					}
+					if(sc > s || (sc == s && uc > u)) {
+						s = sc;
+						u = uc;
+					}
+				}
+				grp[j] = j;
+				grp_cols[j] = 1;
+				grp_blocks[j] = int32_t(P.lptr[j + 1] - P.lptr[j]);
+				if(u > 0) { // some children are in this stage: join their slices, if the result still fits
+					int64_t n_cols_total = 1, n_blocks_total = grp_blocks[j];
+					for(int32_t c = top_first_child[j]; c >= 0; c = top_next_sibling[c]) {
+						if(col_stage[c] == s) { // (distinct children are in distinct slices: a slice has one root)
+							const int32_t g = find(c);
+							n_cols_total += grp_cols[g];
+							n_blocks_total += grp_blocks[g];
+						}
+					}
+					if(n_cols_total > opt.task_max_cols || n_blocks_total > opt.task_max_blocks) {
+						++ s;
+						u = 0;
+					} else {
+						for(int32_t c = top_first_child[j]; c >= 0; c = top_next_sibling[c]) {
+							if(col_stage[c] == s)
+								grp[find(c)] = j;
+						}
+						grp_cols[j] = int32_t(n_cols_total);
+						grp_blocks[j] = int32_t(n_blocks_total);
+					}
+				}
+				col_stage[j] = s;
+				P.col_sub[j] = u;
+			}
+			for(int32_t j = 0; j < n; ++ j) { // task ids ascend with the first column of the slice
+				if(in_dense[j] || troot[j] >= 0)
+					continue;
+				const int32_t g = find(j);
+				if(root_task[g] < 0) {
+					root_task[g] = n_tasks ++;
+					task_level.push_back(col_stage[j]);
+				}
+				task_of[j] = root_task[g];
+			}
+		} else {
 		for(int32_t j = 0; j < n; ++ j) {
 			if(in_dense[j])
 				continue;
@@ -793,6 +876,7 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 					b_changed = true;
 				}
 			}
+		}
 		}
 		int32_t n_stages = 0;
 		for(int32_t t = 0; t < n_tasks; ++ t)

@@ -38,6 +38,10 @@ struct Plan {
 	std::vector<int32_t> stage_ptr;   // [n_stages+1]
 	std::vector<int64_t> task_ptr;    // [n_tasks+1]
 	std::vector<int32_t> task_cols;   // [n - number of dense-top columns]
+	// tall tasks (PlanOptions::task_height > 1): a separator task is a slice of the elimination tree up to task_height
+	// levels high; col_sub[j] = the level of column j inside its task (columns of one level do not depend on each other,
+	// a column's children in the task have lower levels).  All zero otherwise.
+	std::vector<int32_t> col_sub;     // [n]
 	// dense top: an upper set of the elimination tree (the big separators of 2-D-like graphs) is not
 	// eliminated block by block; its Schur complement is assembled into one dense matrix and handed to
 	// the dense MFMA Cholesky (dense_chol.hip).  dense_pos[j] = scalar offset of column j there, or -1.
@@ -58,6 +62,10 @@ struct PlanOptions {
 	int nd_balance_pct = 15;  // a separator must leave at least this share (percent) of the vertices on either side; small
 	                          // separators beat balanced halves here: 15 is 5-15 % faster than 25 on pose chains of 30k-300k poses
 	int subtree_size = 8;     // a subtree of at most this many columns is one sequential task (8: best from 2k to 100k poses)
+	int task_height = 1;      // separator tasks above the leaf subtrees: 1 = maximal chains of single children (one tree level
+	                          // per stage), 2 / 3 = slices of the elimination tree that many levels high (a stage, i.e. a
+	                          // launch, then covers that many levels: the launches of a chain-like graph are its critical path)
+	int task_max_cols = 8, task_max_blocks = 96; // what such a slice may hold (the panel kernel's capacities)
 	int dense_top_nb = 24;    // columns with this many blocks or more (and their ancestors) form the dense top; 0 = off
 	bool dense_top_auto = true; // when that gives a dense top, also try 16 and 36 and keep the plan whose estimated chain
 	                            // of dependent launches is shortest (the caller did not ask for a specific threshold)

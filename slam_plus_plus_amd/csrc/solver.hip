@@ -495,6 +495,12 @@ void slampp_hip_solver::Analyze_Sparse()
 #define SETUP_PHASE(name) do { if(b_timing) { const double t_ = wall_ms(); \
 	fprintf(stderr, "[setup] %-12s %8.2f ms\n", name, t_ - t_phase); t_phase = t_; } } while(0)
 	Refine_Structure();
+	{ // a tall task must fit the panel kernel: its columns and the blocks of its LDS image
+		const std::vector<int64_t> &r_cs = b_refined? refined_cumsum : cumsum;
+		const int n_dim0 = int(r_cs[1] - r_cs[0]);
+		opt.task_max_cols = int(PANEL_COLS);
+		opt.task_max_blocks = panel_slot_cap(n_dim0);
+	}
 	std::string s_err = b_refined? build_plan(int64_t(refined_cumsum.size()) - 1, refined_cumsum.data(), refined_bcol_ptr.data(),
 		refined_brow.data(), opt, plan) : build_plan(int64_t(cumsum.size()) - 1, cumsum.data(), bcol_ptr.data(), brow.data(), opt, plan);
 	SETUP_PHASE("build_plan");
@@ -507,9 +513,13 @@ void slampp_hip_solver::Analyze_Sparse()
 	// the bottom stage and the wide stages right above it (more tasks than the 8-wave kernel keeps
 	// resident at 2 workgroups per CU) run one wave per task: there throughput beats single-column latency
 	n_bottom_stages = 1;
-	while(n_bottom_stages < int(P.stage_ptr.size()) - 1 &&
+	bool b_tall_tasks = false;
+	for(size_t j = 0; j < P.col_sub.size() && !b_tall_tasks; ++ j)
+		b_tall_tasks = P.col_sub[j] != 0;
+	const bool b_panels_possible = n_panel && P.uniform_dim && (P.max_dim == 3 || P.max_dim == 6 || P.max_dim == 7);
+	while(!(b_tall_tasks && b_panels_possible) && n_bottom_stages < int(P.stage_ptr.size()) - 1 &&
 	   P.stage_ptr[n_bottom_stages + 1] - P.stage_ptr[n_bottom_stages] > n_wide_min_tasks)
-		++ n_bottom_stages;
+		++ n_bottom_stages; // (tall tasks -- slices of the tree several levels high -- run as panels whatever their number)
 
 	if(P.cs_new[P.n] >= INT32_MAX)
 		throw std::domain_error("systems with 2^31 or more scalar unknowns are not supported by the sparse path");
@@ -702,6 +712,8 @@ void slampp_hip_solver::Analyze_Sparse()
 		panel_rest_ptr.assign(n_stages + 1, 0);
 		panel_upd_ptr.assign(n_stages + 1, 0);
 		std::vector<int32_t> col_local(size_t(P.n), -1), col_stage(size_t(P.n), -1);
+		std::vector<int32_t> slot_of(size_t(n_lblocks), -1); // factor block -> slot of the task being packed (else -1)
+		std::vector<int64_t> order; // the task's columns (indices into cols) level by level
 		for(int s = 0; s < n_stages; ++ s) {
 			for(int64_t i = P.task_ptr[P.stage_ptr[s]]; i < P.task_ptr[P.stage_ptr[s + 1]]; ++ i)
 				col_stage[P.task_cols[i]] = s;
@@ -740,13 +752,37 @@ void slampp_hip_solver::Analyze_Sparse()
 				const int64_t c_begin = P.task_ptr[t], c_end = P.task_ptr[t + 1];
 				const int n_cols = int(c_end - c_begin);
 				bool b_fits = n_cols >= 1 && n_cols <= int(PANEL_COLS);
-				const int64_t k_begin = b_fits? cols[c_begin].k0 : 0;
-				int64_t n_slots = 0, n_int_rows = 0, n_int_pairs = 0;
-				for(int64_t i = c_begin; b_fits && i < c_end; ++ i) {
-					b_fits = cols[i].k0 == k_begin + n_slots; // consecutive columns: one range of factor blocks
-					n_slots += cols[i].nb;
+				// the package lists the task's columns level by level (a tall task: Plan::col_sub; a chain: one column per
+				// level, in order), the slots of the LDS image are their blocks in that order
+				order.clear();
+				for(int64_t i = c_begin; i < c_end; ++ i)
+					order.push_back(i);
+				bool b_tall = false;
+				for(int64_t i = c_begin; i < c_end; ++ i)
+					b_tall = b_tall || P.col_sub[P.task_cols[i]] != 0;
+				if(b_tall) {
+					std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+						return P.col_sub[P.task_cols[a]] < P.col_sub[P.task_cols[b]]; });
 				}
+				int64_t n_slots = 0, n_int_rows = 0, n_int_pairs = 0;
+				for(size_t o = 0; b_fits && o < order.size(); ++ o)
+					n_slots += cols[order[o]].nb;
 				b_fits = b_fits && n_slots <= n_slot_cap;
+				if(b_fits) {
+					int32_t n_slot = 0;
+					for(size_t o = 0; o < order.size(); ++ o) {
+						const TColDesc &c = cols[order[o]];
+						for(int64_t k = c.k0; k < c.k0 + c.nb; ++ k)
+							slot_of[k] = n_slot ++;
+					}
+				}
+				auto Release_Slots = [&]() {
+					for(size_t o = 0; o < order.size(); ++ o) {
+						const TColDesc &c = cols[order[o]];
+						for(int64_t k = c.k0; k < c.k0 + c.nb; ++ k)
+							slot_of[k] = -1;
+					}
+				};
 				// the updates from stages further down are applied inside the launch of the stage below, if that is a panel
 				// launch: then what the stage right below contributes ("fresh") is left to the task itself
 				const bool b_ride = panel_ride[s] != 0;
@@ -754,12 +790,12 @@ void slampp_hip_solver::Analyze_Sparse()
 				for(int64_t i = c_begin; b_fits && i < c_end; ++ i) { // size of the package
 					const TColDesc &c = cols[i];
 					for(int64_t e = c.r0; e < c.r0 + c.nr; ++ e) {
-						const bool b_int = P.rblk[e] >= k_begin && P.rblk[e] < k_begin + n_slots;
+						const bool b_int = slot_of[P.rblk[e]] >= 0;
 						n_int_rows += b_int;
 						n_fresh += !b_int && b_ride && col_stage[P.blk_col[P.rblk[e]]] == s - 1;
 					}
 					for(int64_t e = P.pptr[c.k0 + 1]; e < P.pptr[c.k0 + c.nb]; ++ e) {
-						const bool b_int = P.pa[e] >= k_begin && P.pa[e] < k_begin + n_slots;
+						const bool b_int = slot_of[P.pa[e]] >= 0;
 						n_int_pairs += b_int;
 						n_fresh += !b_int && b_ride && col_stage[P.blk_col[P.pa[e]]] == s - 1;
 					}
@@ -771,21 +807,25 @@ void slampp_hip_solver::Analyze_Sparse()
 				n_stage_max_units = std::max(n_stage_max_units, int64_t(n_units));
 				n_stage_rest += !b_fits;
 				if(!b_fits) {
+					if(n_slots <= n_slot_cap && n_cols >= 1 && n_cols <= int(PANEL_COLS))
+						Release_Slots();
 					panel_rest.push_back(t);
 					continue;
 				}
 				irow.clear(); ipair.clear(); pcols.clear(); pslots.clear(); fresh.clear();
-				for(int64_t i = c_begin; i < c_end; ++ i)
-					col_local[P.task_cols[i]] = int32_t(i - c_begin);
-				for(int64_t i = c_begin; i < c_end; ++ i) {
+				for(size_t o = 0; o < order.size(); ++ o)
+					col_local[P.task_cols[order[o]]] = int32_t(o);
+				for(size_t o = 0; o < order.size(); ++ o) {
+					const int64_t i = order[o];
 					const TColDesc &c = cols[i];
 					TPanelCol pc;
 					memset(&pc, 0, sizeof(pc));
 					pc.linv_off = c.linv_off;
 					pc.cs_new = c.cs_new;
 					pc.cs_src = c.cs_src;
-					pc.slot0 = int32_t(c.k0 - k_begin);
+					pc.slot0 = slot_of[c.k0];
 					pc.nb = c.nb;
+					pc.sub = b_tall? P.col_sub[P.task_cols[i]] : int32_t(o); // (a chain: every column a level of its own)
 					pc.ir0 = int32_t(irow.size());
 					TUpdSlot us;
 					memset(&us, 0, sizeof(us));
@@ -797,8 +837,8 @@ void slampp_hip_solver::Analyze_Sparse()
 					us.cs_new = c.cs_new;
 					for(int64_t e = c.r0; e < c.r0 + c.nr; ++ e) { // row entries of the diagonal block: blocks L(j,c)
 						const int64_t k = P.rblk[e];
-						if(k >= k_begin && k < k_begin + n_slots)
-							irow.push_back(uint32_t(k - k_begin) | (uint32_t(col_local[P.blk_col[k]]) << 16));
+						if(slot_of[k] >= 0)
+							irow.push_back(uint32_t(slot_of[k]) | (uint32_t(col_local[P.blk_col[k]]) << 16));
 						else if(b_ride && col_stage[P.blk_col[k]] == s - 1) {
 							TPanelExt en;
 							memset(&en, 0, sizeof(en));
@@ -806,7 +846,7 @@ void slampp_hip_solver::Analyze_Sparse()
 							en.ycs = rents[e].ycs;
 							en.slot = uint16_t(pc.slot0);
 							en.kind = 1;
-							en.col = int32_t(i - c_begin);
+							en.col = int32_t(o);
 							fresh.push_back(en);
 						} else
 							upd_ents.push_back(TUpdEnt{rents[e].off, int64_t(rents[e].ycs)});
@@ -828,14 +868,14 @@ void slampp_hip_solver::Analyze_Sparse()
 							us.e0 = int64_t(upd_ents.size());
 							for(int64_t e = P.pptr[k]; e < P.pptr[k + 1]; ++ e) {
 								const int64_t ka = P.pa[e], kb = P.pb[e];
-								if(ka >= k_begin && ka < k_begin + n_slots)
-									ipair.push_back(uint32_t(ka - k_begin) | (uint32_t(kb - k_begin) << 16));
+								if(slot_of[ka] >= 0)
+									ipair.push_back(uint32_t(slot_of[ka]) | (uint32_t(slot_of[kb]) << 16));
 								else if(b_ride && col_stage[P.blk_col[ka]] == s - 1) {
 									TPanelExt en;
 									memset(&en, 0, sizeof(en));
 									en.a_off = P.loff[ka];
 									en.b_off = P.loff[kb];
-									en.slot = uint16_t(k - k_begin);
+									en.slot = uint16_t(slot_of[k]);
 									fresh.push_back(en);
 								} else
 									upd_ents.push_back(TUpdEnt{P.loff[ka], P.loff[kb]});
@@ -881,6 +921,7 @@ void slampp_hip_solver::Analyze_Sparse()
 				if(!fresh.empty())
 					memcpy(p_dst, fresh.data(), fresh.size() * sizeof(TPanelExt));
 				panel_off.push_back(int64_t(n_at));
+				Release_Slots();
 			}
 			panel_ptr[s + 1] = int32_t(panel_off.size());
 			if(b_timing && b_panel_stage)
@@ -1442,6 +1483,8 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 		p_solver->opt.leaf_size = int(n_value);
 	else if(s == "subtree_size" && n_value >= 1)
 		p_solver->opt.subtree_size = int(n_value);
+	else if(s == "task_height" && n_value >= 1 && n_value <= 3)
+		p_solver->opt.task_height = int(n_value);
 	else if(s == "natural_order")
 		p_solver->opt.natural_order = (n_value != 0);
 	else if(s == "nd_balance" && n_value >= 1 && n_value <= 49)

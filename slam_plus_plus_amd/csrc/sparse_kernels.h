@@ -52,7 +52,7 @@ struct TDenseCol { // 24 B
 	int32_t pos, dj;
 };
 
-// ---- panel packages (panel_kernel.hip): everything a separator task of consecutive columns needs, in one buffer ----
+// ---- panel packages (panel_kernel.hip): everything a separator task needs, in one buffer ----
 // 16-byte units: head (4) | columns (3 each) | factor blocks of the task = slots of its LDS image (2 each) | internal row
 // entries and internal update pairs (4 per unit: operands that are slots of the image) | fresh entries (2 each: updates
 // whose operands the stage right below produced, sorted by the wave that brings them in)
@@ -65,7 +65,7 @@ struct TPanelCol { // 48 B
 	int64_t linv_off, cs_new, cs_src;
 	int32_t slot0, nb;  // the column's blocks are the slots slot0 .. slot0 + nb - 1 (diagonal block first)
 	int32_t ir0, inr;   // its internal row entries: (slot of L(j,c)) | (c's number in the task) << 16
-	int64_t pad;
+	int32_t sub, pad;   // level of the column inside a tall task (Plan::col_sub): the package lists the columns level by level
 };
 struct TPanelSlot { // 32 B
 	int64_t loff, asrc; // as in TBlkDesc
