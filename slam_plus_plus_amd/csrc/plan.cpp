@@ -756,85 +756,7 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 		int32_t n_tasks = 0;
 		std::vector<int32_t> root_task(n, -1);
 		P.col_sub.assign(n, 0);
-		if(opt.task_height >= 2) {
-			// Tall tasks.  Every separator column gets a (stage, level inside the stage): one level above the highest of its
-			// separator children, a new stage every task_height levels; columns of one stage that are joined by tree edges
-			// form one task -- a slice of the elimination tree: its columns of one level are independent of each other, its
-			// leaf subtrees below were eliminated by earlier stages.  A slice that would outgrow the panel kernel's
-			// capacities is cut: the column starts the next stage instead.
-			const int h = std::min(opt.task_height, 3);
-			std::vector<int32_t> col_stage(n, 0), grp(n, -1), grp_cols(n, 0), grp_blocks(n, 0);
-			auto find = [&](int32_t v) { while(grp[v] != v) { grp[v] = grp[grp[v]]; v = grp[v]; } return v; };
-			std::vector<int32_t> top_first_child(n, -1), top_next_sibling(n, -1);
-			for(int32_t j = n - 1; j >= 0; -- j) { // (descending: the lists come out ascending)
-				const int32_t p = par[j];
-				if(!in_dense[j] && troot[j] < 0 && p >= 0) {
-					top_next_sibling[j] = top_first_child[p];
-					top_first_child[p] = j;
-				}
-			}
-			for(int32_t j = 0; j < n; ++ j) {
-				if(in_dense[j])
-					continue;
-				if(troot[j] >= 0) {
-					int32_t &r = root_task[troot[j]];
-					if(r < 0) {
-						r = n_tasks ++;
-						task_level.push_back(0);
-					}
-					task_of[j] = r;
-					continue;
-				}
-				int32_t s = 1, u = 0;
-				for(int32_t c = top_first_child[j]; c >= 0; c = top_next_sibling[c]) {
-					int32_t sc = col_stage[c], uc = P.col_sub[c] + 1;
-					if(uc >= h) {
-						++ sc;
-						uc = 0;
-					}
-					if(sc > s || (sc == s && uc > u)) {
-						s = sc;
-						u = uc;
-					}
-				}
-				grp[j] = j;
-				grp_cols[j] = 1;
-				grp_blocks[j] = int32_t(P.lptr[j + 1] - P.lptr[j]);
-				if(u > 0) { // some children are in this stage: join their slices, if the result still fits
-					int64_t n_cols_total = 1, n_blocks_total = grp_blocks[j];
-					for(int32_t c = top_first_child[j]; c >= 0; c = top_next_sibling[c]) {
-						if(col_stage[c] == s) { // (distinct children are in distinct slices: a slice has one root)
-							const int32_t g = find(c);
-							n_cols_total += grp_cols[g];
-							n_blocks_total += grp_blocks[g];
-						}
-					}
-					if(n_cols_total > opt.task_max_cols || n_blocks_total > opt.task_max_blocks) {
-						++ s;
-						u = 0;
-					} else {
-						for(int32_t c = top_first_child[j]; c >= 0; c = top_next_sibling[c]) {
-							if(col_stage[c] == s)
-								grp[find(c)] = j;
-						}
-						grp_cols[j] = int32_t(n_cols_total);
-						grp_blocks[j] = int32_t(n_blocks_total);
-					}
-				}
-				col_stage[j] = s;
-				P.col_sub[j] = u;
-			}
-			for(int32_t j = 0; j < n; ++ j) { // task ids ascend with the first column of the slice
-				if(in_dense[j] || troot[j] >= 0)
-					continue;
-				const int32_t g = find(j);
-				if(root_task[g] < 0) {
-					root_task[g] = n_tasks ++;
-					task_level.push_back(col_stage[j]);
-				}
-				task_of[j] = root_task[g];
-			}
-		} else {
+		{
 		for(int32_t j = 0; j < n; ++ j) {
 			if(in_dense[j])
 				continue;
@@ -877,6 +799,108 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 				}
 			}
 		}
+		}
+		if(opt.task_height >= 2) {
+			// Tall tasks, above the wide stages.  A stage with more tasks than the chip holds at once is bound by
+			// throughput, and one wave per column serves it best; from the first stage with at most task_wide_min tasks on, a
+			// stage is a launch on the critical path, and there every separator column gets a (stage, level inside the
+			// stage): one level above the highest of its separator children, a new stage every task_height levels; columns of
+			// one stage that are joined by tree edges form one task -- a slice of the elimination tree: its columns of one
+			// level are independent of each other, everything below the slice was eliminated by earlier stages.  A slice that
+			// would outgrow the panel kernel's capacities is cut: the column starts the next stage instead.
+			int32_t n_levels = 0;
+			for(int32_t t = 0; t < n_tasks; ++ t)
+				n_levels = std::max(n_levels, task_level[t] + 1);
+			std::vector<int32_t> level_tasks(n_levels + 1, 0);
+			for(int32_t t = 0; t < n_tasks; ++ t)
+				++ level_tasks[task_level[t]];
+			int32_t n_first_tall = 1;
+			while(n_first_tall < n_levels && level_tasks[n_first_tall] > opt.task_wide_min)
+				++ n_first_tall;
+			const int h = std::min(opt.task_height, 3);
+			std::vector<int32_t> col_stage(n, 0), grp(n, -1), grp_cols(n, 0), grp_blocks(n, 0);
+			std::vector<char> b_tall(n, 0);
+			for(int32_t j = 0; j < n; ++ j) {
+				if(!in_dense[j]) {
+					col_stage[j] = task_level[task_of[j]];
+					b_tall[j] = troot[j] < 0 && col_stage[j] >= n_first_tall;
+				}
+			}
+			auto find = [&](int32_t v) { while(grp[v] != v) { grp[v] = grp[grp[v]]; v = grp[v]; } return v; };
+			std::vector<int32_t> top_first_child(n, -1), top_next_sibling(n, -1);
+			for(int32_t j = n - 1; j >= 0; -- j) { // (descending: the lists come out ascending)
+				const int32_t p = par[j];
+				if(!in_dense[j] && troot[j] < 0 && p >= 0) {
+					top_next_sibling[j] = top_first_child[p];
+					top_first_child[p] = j;
+				}
+			}
+			for(int32_t j = 0; j < n; ++ j) {
+				if(in_dense[j] || !b_tall[j])
+					continue;
+				int32_t s = n_first_tall, u = 0;
+				for(int32_t c = top_first_child[j]; c >= 0; c = top_next_sibling[c]) {
+					int32_t sc = col_stage[c], uc = b_tall[c]? P.col_sub[c] + 1 : h; // (a column of the stages below: the next stage at the earliest)
+					if(uc >= h) {
+						++ sc;
+						uc = 0;
+					}
+					if(sc > s || (sc == s && uc > u)) {
+						s = sc;
+						u = uc;
+					}
+				}
+				grp[j] = j;
+				grp_cols[j] = 1;
+				grp_blocks[j] = int32_t(P.lptr[j + 1] - P.lptr[j]);
+				if(u > 0) { // some children are in this stage: join their slices, if the result still fits
+					int64_t n_cols_total = 1, n_blocks_total = grp_blocks[j];
+					for(int32_t c = top_first_child[j]; c >= 0; c = top_next_sibling[c]) {
+						if(b_tall[c] && col_stage[c] == s) { // (distinct children are in distinct slices: a slice has one root)
+							const int32_t g = find(c);
+							n_cols_total += grp_cols[g];
+							n_blocks_total += grp_blocks[g];
+						}
+					}
+					if(n_cols_total > opt.task_max_cols || n_blocks_total > opt.task_max_blocks) {
+						++ s;
+						u = 0;
+					} else {
+						for(int32_t c = top_first_child[j]; c >= 0; c = top_next_sibling[c]) {
+							if(b_tall[c] && col_stage[c] == s)
+								grp[find(c)] = j;
+						}
+						grp_cols[j] = int32_t(n_cols_total);
+						grp_blocks[j] = int32_t(n_blocks_total);
+					}
+				}
+				col_stage[j] = s;
+				P.col_sub[j] = u;
+			}
+			// the tasks again: those of the stages below as they were, one per slice above (ids ascend with the first column)
+			std::vector<int32_t> new_task(n_tasks, -1), slice_task(n, -1), new_level;
+			int32_t n_new_tasks = 0;
+			for(int32_t j = 0; j < n; ++ j) {
+				if(in_dense[j])
+					continue;
+				if(!b_tall[j]) {
+					int32_t &r = new_task[task_of[j]];
+					if(r < 0) {
+						r = n_new_tasks ++;
+						new_level.push_back(task_level[task_of[j]]);
+					}
+					task_of[j] = r;
+				} else {
+					int32_t &r = slice_task[find(j)];
+					if(r < 0) {
+						r = n_new_tasks ++;
+						new_level.push_back(col_stage[j]);
+					}
+					task_of[j] = r;
+				}
+			}
+			n_tasks = n_new_tasks;
+			task_level.swap(new_level);
 		}
 		int32_t n_stages = 0;
 		for(int32_t t = 0; t < n_tasks; ++ t)

@@ -498,6 +498,7 @@ void slampp_hip_solver::Analyze_Sparse()
 	{ // a tall task must fit the panel kernel: its columns and the blocks of its LDS image
 		const std::vector<int64_t> &r_cs = b_refined? refined_cumsum : cumsum;
 		const int n_dim0 = int(r_cs[1] - r_cs[0]);
+		opt.task_wide_min = n_wide_min_tasks;
 		opt.task_max_cols = int(PANEL_COLS);
 		opt.task_max_blocks = panel_slot_cap(n_dim0);
 	}
@@ -513,13 +514,9 @@ void slampp_hip_solver::Analyze_Sparse()
 	// the bottom stage and the wide stages right above it (more tasks than the 8-wave kernel keeps
 	// resident at 2 workgroups per CU) run one wave per task: there throughput beats single-column latency
 	n_bottom_stages = 1;
-	bool b_tall_tasks = false;
-	for(size_t j = 0; j < P.col_sub.size() && !b_tall_tasks; ++ j)
-		b_tall_tasks = P.col_sub[j] != 0;
-	const bool b_panels_possible = n_panel && P.uniform_dim && (P.max_dim == 3 || P.max_dim == 6 || P.max_dim == 7);
-	while(!(b_tall_tasks && b_panels_possible) && n_bottom_stages < int(P.stage_ptr.size()) - 1 &&
+	while(n_bottom_stages < int(P.stage_ptr.size()) - 1 &&
 	   P.stage_ptr[n_bottom_stages + 1] - P.stage_ptr[n_bottom_stages] > n_wide_min_tasks)
-		++ n_bottom_stages; // (tall tasks -- slices of the tree several levels high -- run as panels whatever their number)
+		++ n_bottom_stages; // (tall tasks, Plan::col_sub, begin above these: the same threshold)
 
 	if(P.cs_new[P.n] >= INT32_MAX)
 		throw std::domain_error("systems with 2^31 or more scalar unknowns are not supported by the sparse path");
