@@ -322,6 +322,8 @@ def run_c3(args, rank, world, local_rank, dist):
                                 "frac": (counts["factor_bytes"] + counts["solve_bytes"]) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                                 "launches_per_step": int(sum(k["launches_per_step"] for k in kernels))},
     }
+    if args.c3_solve_only:     # (the profiling passes: per-kernel averages of the solve alone)
+        return out
     out["assembly"] = assembly_leg(solver, lam, dev)
     if world == 1:
         out["marginals"] = marginals_leg_c3(args, solver, lam, vals, dev, torch)
@@ -428,8 +430,12 @@ def run_small_configs(args, local_rank):
     from oracle import oracle_lib as O
     dev = torch.device(f"cuda:{local_rank}")
     out = {}
-    for key, name, lam in (("C1", "Manhattan3500 SE(2) look-alike, 3x3 blocks", synth.manhattan(3500)),
-                           ("C2", "Sphere2500 SE(3) look-alike, 6x6 blocks", synth.sphere(50, 50))):
+    which = [k_ for k_ in args.small_configs.split(",") if k_]
+    for key, name, make in (("C1", "Manhattan3500 SE(2) look-alike, 3x3 blocks", lambda: synth.manhattan(3500)),
+                            ("C2", "Sphere2500 SE(3) look-alike, 6x6 blocks", lambda: synth.sphere(50, 50))):
+        if key not in which:
+            continue
+        lam = make()
         solver = CLinearSolver_HIP(device=local_rank)
         t0 = time.perf_counter()
         solver.SymbolicDecomposition_Blocky(lam)
@@ -446,9 +452,44 @@ def run_small_configs(args, local_rank):
         solver.sync()
         ms = (time.perf_counter() - t0) / reps * 1e3
         x = bufs[-1].cpu().numpy()
+        st = solver.stats()
         rec = {"workload": f"{name}, n={lam.n_scalars}", "ms_per_solve": ms, "analyze_ms_cold": analyze_ms,
-               "dense_top_dim": solver.stats()["schur_dim"],
+               "dense_top_dim": st["schur_dim"], "n_stages": st["n_stages"],
                "solve_residual_rel_inf": float(np.abs(lam.to_scipy() @ x - lam.rhs).max() / np.abs(lam.rhs).max())}
+        # the split of the step (five extra solves with every phase bracketed by events) and its roofline: the big separators
+        # of a 2-D-like graph are factored as one dense matrix on the matrix cores (the "dense top": the flops of its columns
+        # under our ordering, sum of squared column counts, against the fp64 MFMA peak); the block-by-block part below it is
+        # a chain of small launches and is priced against HBM on its SURVEY 8d bytes
+        solver.set_option("profile", 2)
+        solver.profile(reset=True)
+        extra = [torch.from_numpy(lam.rhs).to(dev) for _ in range(5)]
+        for t_ in extra:
+            solver.factor_solve_device_async(vals.data_ptr(), t_.data_ptr())
+        solver.sync()
+        prof = {k_: v[1] / max(v[0], 1) for k_, v in solver.profile().items()}
+        rec["phases_ms"] = prof
+        plan = solver.plan()
+        dim = plan["dim"].astype(np.int64)
+        lptr, lrow, dpos = plan["lptr"], plan["lrow"].astype(np.int64), plan["dense_pos"]
+        col_of = np.repeat(np.arange(len(dim)), np.diff(lptr))
+        below = np.bincount(col_of, weights=dim[lrow], minlength=len(dim)) - dim      # scalar rows below the diagonal block
+        t_ = np.arange(1, dim.max() + 1)
+        col_flops = np.array([np.sum((below[j] + t_[:dim[j]]) ** 2) for j in range(len(dim))], dtype=np.float64)
+        col_lnz = dim * (dim + 1) // 2 + dim * below
+        top = dpos >= 0
+        if "dense_chol" in prof and top.any():
+            tf = float(col_flops[top].sum()) / (prof["dense_chol"] * 1e-3) / 1e12
+            rec["roofline"] = {"bound": "mfma", "kernel": "dense top: tile-scheduled Cholesky on the matrix cores (tile_potrf / tile_trsm / tile_update, "
+                               "or potrf_diag / trsm / syrk)", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / F64_MFMA_PEAK_TFLOPS, "traffic": None, "algorithmic_flops": float(col_flops[top].sum()),
+                               "ms": prof["dense_chol"], "dense_top_dim": int(st["schur_dim"])}
+        sparse_ms = sum(prof.get(k_, 0.0) for k_ in ("factor_leaves", "factor_wide", "factor_upper", "factor_rest"))
+        if sparse_ms > 0:
+            nbytes = 8.0 * (float(st["nnz_upper"]) + float(col_lnz[~top].sum()))
+            rec["roofline_block_part"] = {"bound": "hbm", "kernel": "block-by-block elimination below the dense top (leaf subtrees + separator panels)",
+                                          "achieved": nbytes / (sparse_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": nbytes / (sparse_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                          "algorithmic_bytes": nbytes, "ms": sparse_ms}
         if not args.no_cpu_baseline and O.have_reference():
             with tempfile.TemporaryDirectory() as td:
                 path = os.path.join(td, "p.bin")
@@ -857,12 +898,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="all", choices=["all", "c3", "ba"])
+    ap.add_argument("--workload", default="all", choices=["all", "c3", "ba", "small"])
+    ap.add_argument("--small-configs", default="C1,C2", help="which of BASELINE configs[0] / configs[1] run_small_configs takes")
     ap.add_argument("--ba-cams", type=int, default=1000)
     ap.add_argument("--ba-points", type=int, default=500_000, help="landmarks of the C4 system")
     ap.add_argument("--ba-steps", type=int, default=5)
     ap.add_argument("--poses", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--c3-solve-only", action="store_true", help="leave out the legs beside the C3 solve (assembly, marginals, host path): tools/profile_round.sh")
     ap.add_argument("--ba-solve-only", action="store_true", help="leave out the legs beside the solve (host path, marginals, incremental update, assembly): the counter passes of tools/profile_round.sh, whose per-kernel averages should be the solve's")
     ap.add_argument("--ba-legs", default="venice,band,uniform", help="which visibility models the C4 part runs, the first as `ba_schur` (profiling runs one at a time)")
     ap.add_argument("--c5-cams", type=int, default=2000)
@@ -932,6 +975,13 @@ def main():
     else:
         if args.workload in ("all", "c3"):
             out = run_c3(args, rank, world, local_rank, dist)
+        if args.workload == "small":
+            small = run_small_configs(args, local_rank)
+            first = small[sorted(small)[-1]]
+            out = {"metric": "Lambda solve ms (numeric factor + 2 substitutions)", "value": first["ms_per_solve"], "unit": "ms",
+                   "n_gpus": 1, "steps": 20, "warmup": 1, "ms_per_step": first["ms_per_solve"], "higher_is_better": False,
+                   "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": first["workload"]}, "roofline": first.get("roofline"), "other_configs": small}
         if args.workload in ("all", "ba"):
             # BASELINE config 4 is "Venice-style": that leg is `ba_schur`; band and uniform visibility (SURVEY.md section 8d:
             # "band (sparse S) or uniformly (dense S -- report both)") ride beside it

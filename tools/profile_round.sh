@@ -1,27 +1,45 @@
 #!/bin/bash
-# Collects the round's profiles on the GPU box (run through gpurun): kernel-trace stats for both workloads and,
-# in separate passes, the HBM traffic counters.  Usage: tools/profile_round.sh <tag>   (writes under gpurun_out/<tag>/)
+# Collects the round's profiles on the GPU box (run through gpurun), ONE WORKLOAD PER FILE -- a per-kernel average over
+# mixed workloads is no kernel's number: kernel-trace stats per leg, then, in separate passes without tracing, the HBM
+# traffic counters (FETCH_SIZE and WRITE_SIZE do not fit one pass) and the matrix-core counters of the MFMA-bound legs.
+# Usage: tools/profile_round.sh <tag>   (writes under gpurun_out/<tag>/; copy the summaries to profiles/)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_trace -- python3 $R/bench.py --workload c3 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/c3_trace.json 2> $OUT/c3_trace.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ba_trace -- python3 $R/bench.py --workload ba --ba-steps 5 --no-cpu-baseline > $OUT/ba_trace.json 2> $OUT/ba_trace.err
-# the counter passes run one BA visibility model at a time: the per-kernel averages of a mixed run would blend workloads
-for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/c3_pmc_$C -- python3 $R/bench.py --workload c3 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/c3_pmc_$C.json 2> $OUT/c3_pmc_$C.err
-  for LEG in band uniform venice; do
-    timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/ba_${LEG}_pmc_$C -- python3 $R/bench.py --workload ba --ba-legs $LEG --ba-steps 2 --no-cpu-baseline --ba-solve-only > $OUT/ba_${LEG}_pmc_$C.json 2> $OUT/ba_${LEG}_pmc_$C.err
+# leg name -> bench.py arguments (the solve alone: no host-path / marginals / assembly legs launching the same kernels)
+declare -A LEG
+LEG[c3]="--workload c3 --steps 20 --warmup 3 --no-cpu-baseline --c3-solve-only"
+LEG[ba_venice]="--workload ba --ba-legs venice --ba-steps 5 --no-cpu-baseline --ba-solve-only"
+LEG[ba_band]="--workload ba --ba-legs band --ba-steps 5 --no-cpu-baseline --ba-solve-only"
+LEG[ba_uniform]="--workload ba --ba-legs uniform --ba-steps 5 --no-cpu-baseline --ba-solve-only"
+LEG[c2]="--workload small --small-configs C2 --no-cpu-baseline"
+LEG[c1]="--workload small --small-configs C1 --no-cpu-baseline"
+for L in c3 ba_venice ba_band ba_uniform c2 c1; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${L}_trace -- python3 $R/bench.py ${LEG[$L]} > $OUT/${L}_bench_under_rocprof.json 2> $OUT/${L}_trace.err
+  f=$(find $OUT/${L}_trace -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $OUT/${L}_kernel_stats.csv
+done
+for L in c3 ba_venice ba_band ba_uniform; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/${L}_pmc_$C -- python3 $R/bench.py ${LEG[$L]} > $OUT/${L}_pmc_$C.json 2> $OUT/${L}_pmc_$C.err
   done
 done
+# matrix cores: instructions (MOPS) and busy cycles of the MFMA pipe next to the shader's busy cycles, per kernel
+for L in ba_uniform ba_venice c2; do
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $OUT/${L}_pmc_mfma -- python3 $R/bench.py ${LEG[$L]} > $OUT/${L}_pmc_mfma.json 2> $OUT/${L}_pmc_mfma.err
+done
 cd $R
-python3 tools/parse_pmc.py $OUT/c3_pmc_FETCH_SIZE $OUT/c3_pmc_WRITE_SIZE $OUT/c3_traffic.json
-python3 tools/parse_pmc.py $OUT/ba_band_pmc_FETCH_SIZE $OUT/ba_band_pmc_WRITE_SIZE $OUT/ba_traffic.json
-python3 tools/parse_pmc.py $OUT/ba_uniform_pmc_FETCH_SIZE $OUT/ba_uniform_pmc_WRITE_SIZE $OUT/ba_uniform_traffic.json
-python3 tools/parse_pmc.py $OUT/ba_venice_pmc_FETCH_SIZE $OUT/ba_venice_pmc_WRITE_SIZE $OUT/ba_venice_traffic.json
-for f in $(find $OUT/c3_trace $OUT/ba_trace -name "*kernel_stats.csv"); do echo $f; head -8 $f | cut -c1-150; done
-# keep the merged artefacts small: drop the per-dispatch CSVs of the counter passes
-find $OUT -name "*counter_collection.csv" -size +2M -delete
-find $OUT -name "*kernel_trace.csv" -size +4M -delete
+for L in c3 ba_venice ba_band ba_uniform; do
+  python3 tools/parse_pmc.py $OUT/${L}_pmc_FETCH_SIZE $OUT/${L}_pmc_WRITE_SIZE $OUT/${L}_traffic.json > $OUT/${L}_traffic.txt
+done
+for L in ba_uniform ba_venice c2; do
+  python3 tools/parse_mfma.py $OUT/${L}_pmc_mfma $OUT/${L}_kernel_stats.csv $OUT/${L}_mfma.json > $OUT/${L}_mfma.txt
+done
+for L in c3 ba_venice ba_band ba_uniform c2 c1; do echo "== $L"; head -9 $OUT/${L}_kernel_stats.csv | cut -c1-160; done
+# keep the merged artefacts small: the summaries stay, the per-dispatch CSVs go
+find $OUT -name "*counter_collection.csv" -delete
+find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*agent_info.csv" -delete
