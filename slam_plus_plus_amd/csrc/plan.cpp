@@ -323,19 +323,30 @@ double plan_chain_estimate_us(const Plan &P)
 	// of the tile schedule 34 us, a tile of the dense schedule 26 us, four tiles of the dense backward substitution 11 us
 	double f_us = 0;
 	const int n_stages = int(P.stage_ptr.size()) - 1;
+	// (round 3, tasks as panels in LDS: a launch of the factorization about 4.5 us, of the backward substitution 3.5; inside a
+	// task 2.3 us per level -- the columns of one level run side by side --, its block products spread over eight waves,
+	// the backward substitution a microsecond per column, one after the other)
 	for(int s = 0; s < n_stages; ++ s) {
 		double f_longest = 0;
 		for(int32_t t = P.stage_ptr[s]; t < P.stage_ptr[s + 1]; ++ t) {
-			double f_task = 0;
+			int64_t n_products = 0;
+			int n_levels = 0, n_cols = int(P.task_ptr[t + 1] - P.task_ptr[t]);
+			bool b_tall = false;
 			for(int64_t c = P.task_ptr[t]; c < P.task_ptr[t + 1]; ++ c) {
 				const int32_t j = P.task_cols[c];
-				const int64_t n_products = (P.pptr[P.lptr[j + 1]] - P.pptr[P.lptr[j] + 1]) + (P.rptr[j + 1] - P.rptr[j]);
-				f_task += 5.0 + 0.08 * double(n_products) + 0.15 * double(P.lptr[j + 1] - P.lptr[j]) + 3.0;
+				n_products += (P.pptr[P.lptr[j + 1]] - P.pptr[P.lptr[j] + 1]) + (P.rptr[j + 1] - P.rptr[j]);
+				if(!P.col_sub.empty()) {
+					n_levels = std::max(n_levels, int(P.col_sub[j]) + 1);
+					b_tall = b_tall || P.col_sub[j] != 0;
+				}
 			}
+			if(!b_tall)
+				n_levels = n_cols; // a chain (or a leaf subtree): one column after the other
+			const double f_task = 2.3 * n_levels + 0.01 * double(n_products) + 1.0 * n_cols;
 			f_longest = std::max(f_longest, f_task);
 		}
 		const bool b_wide = P.stage_ptr[s + 1] - P.stage_ptr[s] > 1024;
-		f_us += f_longest * (b_wide? 1.25 : 1.0) + 4.0;
+		f_us += f_longest * (b_wide? 2.5 : 1.0) + 8.0;
 	}
 	if(P.dense_dim) {
 		std::vector<char> nz;
@@ -354,6 +365,10 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 	const int32_t *brow, const PlanOptions &opt, Plan &P)
 {
 	std::string s_err = build_plan_once(n_bcols, cumsum, bcol_ptr, brow, opt, P);
+	if(s_err.empty() && !opt.dense_top_auto && getenv("SLAMPP_HIP_PLAN_TIMING") != 0) {
+		fprintf(stderr, "[plan] dense_top_nb %d, balance %d %%: dense dim %d, chain estimate %.0f us (as asked for)\n", opt.dense_top_nb,
+			opt.nd_balance_pct, P.dense_dim, plan_chain_estimate_us(P));
+	}
 	if(!s_err.empty() || !opt.dense_top_auto || !P.dense_dim)
 		return s_err;
 	// A dense top: a 2-D-like graph.  Where the line between block-by-block elimination and the dense factorization
@@ -367,31 +382,61 @@ std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bc
 		fprintf(stderr, "[plan] dense_top_nb %d, balance %d %%: dense dim %d, chain estimate %.0f us\n", opt.dense_top_nb,
 			opt.nd_balance_pct, P.dense_dim, f_best);
 	}
+	// candidates: the balance first (25 / 35 / 45 % at the threshold asked for), then a lower and a higher threshold at the
+	// balance that came out best -- the tile levels of the dense top are what the chain is made of (33 us each: a
+	// diagonal tile, its panel, the updates), and how many there are depends on where the dissection cuts (measured,
+	// reduced camera system of the Venice-like leg: 2.34 ms at 25 %, 1.63 ms at 45 %; the model said 2.27 and 1.40)
 	const int n_balanced = std::max(opt.nd_balance_pct, 25);
-	const int p_candidates[][2] = {{opt.dense_top_nb, n_balanced}, {opt.dense_top_nb * 2 / 3, n_balanced},
-		{opt.dense_top_nb * 3 / 2, n_balanced}};
-	for(int i = (n_balanced == opt.nd_balance_pct)? 1 : 0; i < 3; ++ i) {
+	int n_best_balance = opt.nd_balance_pct, n_best_nb = opt.dense_top_nb;
+	auto Try = [&](int n_nb, int n_balance, double f_margin) {
 		PlanOptions t_opt = opt;
-		t_opt.dense_top_nb = p_candidates[i][0];
-		t_opt.nd_balance_pct = p_candidates[i][1];
+		t_opt.dense_top_nb = n_nb;
+		t_opt.nd_balance_pct = n_balance;
 		Plan t_plan;
-		if(t_opt.dense_top_nb < 4 || !build_plan_once(n_bcols, cumsum, bcol_ptr, brow, t_opt, t_plan).empty())
-			continue;
+		if(n_nb < 4 || !build_plan_once(n_bcols, cumsum, bcol_ptr, brow, t_opt, t_plan).empty())
+			return;
 		const double f_us = plan_chain_estimate_us(t_plan);
 		if(b_print) {
-			fprintf(stderr, "[plan] dense_top_nb %d, balance %d %%: dense dim %d, chain estimate %.0f us\n", t_opt.dense_top_nb,
-				t_opt.nd_balance_pct, t_plan.dense_dim, f_us);
+			fprintf(stderr, "[plan] dense_top_nb %d, balance %d %%: dense dim %d, chain estimate %.0f us\n", n_nb, n_balance,
+				t_plan.dense_dim, f_us);
 		}
-		// the balanced base replaces the first plan unless it is clearly worse; the other thresholds must be clearly
-		// better (the model is rough, and rougher for the heavy columns a higher threshold leaves to the block kernels)
-		const double f_margin = (i == 0)? 1.10 : (i == 2)? 0.85 : 0.95;
 		if(t_plan.dense_dim && f_us < f_best * f_margin) {
-			f_best = (i == 0)? f_us : std::min(f_best, f_us);
+			f_best = std::min(f_best * std::max(f_margin, 1.0), f_us);
+			n_best_balance = n_balance;
+			n_best_nb = n_nb;
 			t_plan.order_ms += P.order_ms;
 			t_plan.symbolic_ms += P.symbolic_ms;
 			std::swap(P, t_plan);
+		} else {
+			P.order_ms += t_plan.order_ms; // (the time went into this analysis all the same)
+			P.symbolic_ms += t_plan.symbolic_ms;
 		}
+	};
+	// the balanced base replaces the first plan unless it is clearly worse; everything else must be clearly better (the
+	// model is rough, and rougher for the heavy columns a higher threshold leaves to the block kernels)
+	if(n_balanced != opt.nd_balance_pct)
+		Try(opt.dense_top_nb, n_balanced, 1.10);
+	const int p_nb[3] = {opt.dense_top_nb, opt.dense_top_nb * 2 / 3, opt.dense_top_nb * 3 / 2};
+	const double p_nb_margin[3] = {0.95, 0.95, 0.90};
+	if(n_bcols <= 20000) { // a small graph (the 2-D-like ones of the configs, a reduced camera system): the whole grid, a few ms a plan
+		for(int i = 0; i < 3; ++ i) {
+			if(i > 0 && P.task_cols.empty())
+				break; // everything is in the dense top already: the threshold no longer matters
+			for(int n_balance = 25; n_balance <= 45; n_balance += 10) {
+				if((i > 0 || n_balance > n_balanced) && n_balance >= n_balanced)
+					Try(p_nb[i], n_balance, p_nb_margin[i]);
+			}
+		}
+	} else { // a large one: the balance first, then the threshold at the balance that came out best
+		for(int n_balance = 35; n_balance <= 45; n_balance += 10) {
+			if(n_balance > n_balanced)
+				Try(opt.dense_top_nb, n_balance, 0.95);
+		}
+		const int n_balance_chosen = n_best_balance;
+		Try(p_nb[1], n_balance_chosen, p_nb_margin[1]);
+		Try(p_nb[2], n_balance_chosen, p_nb_margin[2]);
 	}
+	(void)n_best_nb;
 	return s_err;
 }
 
@@ -401,6 +446,8 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 	PlanOptions opt = r_opt;
 	if(const char *p_s_height = getenv("SLAMPP_HIP_TASK_HEIGHT")) // development aid: overrides the option
 		opt.task_height = std::min(std::max(atoi(p_s_height), 1), 3);
+	if(const char *p_s_balance = getenv("SLAMPP_HIP_ND_BALANCE")) // development aid: likewise
+		opt.nd_balance_pct = std::min(std::max(atoi(p_s_balance), 1), 49);
 	P = Plan();
 	if(n_bcols <= 0 || n_bcols > INT32_MAX / 2)
 		return "invalid number of block columns";
