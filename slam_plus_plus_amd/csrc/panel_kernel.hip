@@ -95,45 +95,33 @@ __device__ __forceinline__ void panel_update_block(const TUpdSlot &sl, bool b_va
 		L[sl.loff + lane] = init - total;
 }
 
-// LDS of the panel launches, in doubles: the panel role's package, image, vectors, tiles and operand staging; the update
-// role's staging fits inside
-template <int D, int CAP_BLK, bool b_fused>
-struct TPanelLds {
-	enum { DD = D * D, FRESH_BATCH = 4, UPD_BATCH = 8,
-		PKG = 0, IMAGE = PKG + 2 * PANEL_UNITS, VEC = IMAGE + CAP_BLK * DD, LINV = VEC + PANEL_COLS * 8, TILE = LINV + PANEL_COLS * 64,
-		OPS = TILE + PANEL_W * 64, YV = OPS + (b_fused? PANEL_W * 2 * FRESH_BATCH * DD : 0), PANEL_END = YV + (b_fused? PANEL_W * FRESH_BATCH * 8 : 0),
-		U_OPS = 0, U_YV = U_OPS + PANEL_W * 2 * UPD_BATCH * DD, U_PART = U_YV + PANEL_W * UPD_BATCH * 8, UPD_END = b_fused? U_PART + PANEL_W * 64 : 0,
-		TOTAL = (PANEL_END > UPD_END)? PANEL_END : UPD_END };
-};
-
 // (b_fused: some stage of the plan has its updates from further down applied inside the launch of the stage below -- the
 // launch then holds update workgroups next to the panel ones, and the panel tasks bring in fresh updates themselves)
-template <int D, int CAP_BLK, bool b_fused>
-__global__ void __launch_bounds__(64 * PANEL_W)
-factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict__ pkg_off, int n_panels,
+template <int D, int W, bool b_fused>
+__global__ void __launch_bounds__(64 * W)
+factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict__ pkg_off, int n_panels, TPanelLaunch t_cfg,
 	const TUpdSlot *__restrict__ upd_slots, int n_upd_slots, const TUpdEnt *__restrict__ upd_ents, const double *__restrict__ A,
 	const double *__restrict__ b, double *L, double *Linv, double *w, int *p_flag, long long *p_timing)
 {
-	typedef TPanelLds<D, CAP_BLK, b_fused> TLds;
-	enum { W = PANEL_W, DD = D * D, BATCH = TLds::FRESH_BATCH };
-	__shared__ __attribute__((aligned(16))) double s_raw[TLds::TOTAL];
+	enum { DD = D * D, BATCH = PANEL_FRESH_BATCH, UPD_BATCH = PANEL_UPD_BATCH, N_UPD_GROUPS = W / PANEL_UPD_W };
+	extern __shared__ __attribute__((aligned(16))) double s_raw[];
+	const TPanelLds t_lds = panel_lds(D, b_fused, t_cfg);
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 	if(b_fused && int(blockIdx.x) >= n_panels) {
-		// update role: the blocks of the next stage's panel tasks, two per workgroup (four waves each)
-		const int n_half = wave / PANEL_UPD_W, n_sub = wave % PANEL_UPD_W;
-		const int n_slot = 2 * (int(blockIdx.x) - n_panels) + n_half;
+		// update role: the blocks of the next stage's panel tasks, one per group of PANEL_UPD_W waves
+		const int n_group = wave / PANEL_UPD_W, n_sub = wave % PANEL_UPD_W;
+		const int n_slot = N_UPD_GROUPS * (int(blockIdx.x) - n_panels) + n_group;
 		const bool b_valid = n_slot < n_upd_slots;
 		const TUpdSlot sl = upd_slots[b_valid? n_slot : n_upd_slots - 1];
-		panel_update_block<D, TLds::UPD_BATCH>(sl, b_valid, upd_ents, A, L, b, w, n_sub, PANEL_UPD_W, lane,
-			s_raw + TLds::U_OPS + wave * 2 * TLds::UPD_BATCH * DD, s_raw + TLds::U_YV + wave * TLds::UPD_BATCH * 8,
-			s_raw + TLds::U_PART + n_half * PANEL_UPD_W * 64);
+		panel_update_block<D, UPD_BATCH>(sl, b_valid, upd_ents, A, L, b, w, n_sub, PANEL_UPD_W, lane,
+			s_raw + wave * 2 * UPD_BATCH * DD, s_raw + W * 2 * UPD_BATCH * DD + wave * UPD_BATCH * 8,
+			s_raw + W * 2 * UPD_BATCH * DD + W * UPD_BATCH * 8 + n_group * PANEL_UPD_W * 64);
 		return;
 	}
-	longlong2 *s_pkg = reinterpret_cast<longlong2*>(s_raw + TLds::PKG);
-	double *s_L = s_raw + TLds::IMAGE, *s_w = s_raw + TLds::VEC, *s_linv = s_raw + TLds::LINV;
-	double *s_tile = s_raw + TLds::TILE + wave * 64;
-	double *s_ops = s_raw + TLds::OPS + wave * 2 * BATCH * DD, *s_yv = s_raw + TLds::YV + wave * BATCH * 8;
-	static_assert(64 * W <= PANEL_UNITS, "one speculative unit per thread");
+	longlong2 *s_pkg = reinterpret_cast<longlong2*>(s_raw);
+	double *s_L = s_raw + t_lds.IMAGE, *s_w = s_raw + t_lds.VEC, *s_linv = s_raw + t_lds.LINV;
+	double *s_tile = s_raw + t_lds.TILE + wave * 64;
+	double *s_ops = s_raw + t_lds.OPS + wave * 2 * BATCH * DD, *s_yv = s_raw + t_lds.YV + wave * BATCH * 8;
 	long long *p_tm = 0; // development aid (SLAMPP_HIP_STAGE_TIMING): clock samples of workgroup 0
 	int n_tm = 0;
 	if(p_timing && blockIdx.x == 0 && tid == 0) {
@@ -169,9 +157,15 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 	// every wave its own slots (v, v + W, ..: it brings in their fresh updates below)
 	for(int s0 = wave; s0 < n_slots; s0 += 4 * W) {
 		double v[4];
-		#pragma unroll
-		for(int u = 0; u < 4; ++ u)
-			v[u] = L[s_slot[min(s0 + u * W, n_slots - 1)].loff + (mm.b_act? lane : 0)];
+		if(t_cfg.b_from_lambda) { // (wave-uniform)
+			#pragma unroll
+			for(int u = 0; u < 4; ++ u)
+				v[u] = mm.b_act? lambda_element(A, s_slot[min(s0 + u * W, n_slots - 1)].asrc, mm.r, mm.q, D, D, false) : 0.0;
+		} else {
+			#pragma unroll
+			for(int u = 0; u < 4; ++ u)
+				v[u] = L[s_slot[min(s0 + u * W, n_slots - 1)].loff + (mm.b_act? lane : 0)];
+		}
 		#pragma unroll
 		for(int u = 0; u < 4; ++ u) {
 			if(s0 + u * W < n_slots && mm.b_act)
@@ -179,7 +173,7 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 		}
 	}
 	if(tid < n_cols * D)
-		s_w[tid] = w[s_col[tid / D].cs_new + tid % D];
+		s_w[tid] = t_cfg.b_from_lambda? b[s_col[tid / D].cs_src + tid % D] : w[s_col[tid / D].cs_new + tid % D];
 	__syncthreads();
 	PANEL_TICK(); // image
 
@@ -249,7 +243,7 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 			cd.cs_new = col.cs_new;
 			const double acc = init - sum;
 			finish_diagonal_fixed<D>(cd, acc, acc, lane, b_y? 0 : mm.r, b_y? 0 : mm.q, mm.b_act, L, Linv, w, s_slot[col.slot0].loff,
-				p_flag, s_linv + ci * 64, s_L + col.slot0 * DD, s_w + ci * D);
+				p_flag, s_linv + (ci - ci0) * 64, s_L + col.slot0 * DD, s_w + ci * D);
 		}
 		__syncthreads();
 		PANEL_TICK(); // diagonal blocks of the level
@@ -265,7 +259,7 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 					const uint32_t en = s_ipair[sd.ip0 + e];
 					sum += pair_product_image<D>(s_L + int(en & 0xffff) * DD, s_L + int(en >> 16) * DD, mm.r, mm.q);
 				}
-				finish_offdiagonal<D>(init - sum, lane, mm.r, mm.q, mm.b_act, D, L, sd.loff, s_tile, s_linv + ci * 64, s_L + n_slot * DD);
+				finish_offdiagonal<D>(init - sum, lane, mm.r, mm.q, mm.b_act, D, L, sd.loff, s_tile, s_linv + (ci - ci0) * 64, s_L + n_slot * DD);
 			}
 			n_before += n_nb - 1;
 		}
@@ -275,35 +269,44 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 	}
 }
 
-bool launch_factor_panel(int n_dim, bool b_fused, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks, const TUpdSlot *upd_slots,
-	int n_upd_slots, const TUpdEnt *upd_ents, const double *A, const double *b, double *L, double *Linv, double *w, int *p_flag,
-	hipStream_t stream, long long *p_timing)
+bool launch_factor_panel(int n_dim, bool b_fused, const TPanelLaunch &r_cfg, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks,
+	const TUpdSlot *upd_slots, int n_upd_slots, const TUpdEnt *upd_ents, const double *A, const double *b, double *L, double *Linv, double *w,
+	int *p_flag, hipStream_t stream, long long *p_timing)
 {
 	if(!b_fused)
 		n_upd_slots = 0;
-	const int n_grid = n_tasks + (n_upd_slots + 1) / 2;
+	const int W = r_cfg.n_waves, n_groups = W / PANEL_UPD_W;
+	const int n_grid = n_tasks + (n_upd_slots + n_groups - 1) / n_groups;
 	if(n_grid <= 0)
 		return true;
-#define LAUNCH_PANEL(D, CAP) do { if(b_fused) \
-		hipLaunchKernelGGL((factor_panel_kernel<D, CAP, true>), dim3(n_grid), dim3(64 * PANEL_W), 0, stream, pkg, pkg_off, n_tasks, \
-			upd_slots, n_upd_slots, upd_ents, A, b, L, Linv, w, p_flag, p_timing); \
-	else \
-		hipLaunchKernelGGL((factor_panel_kernel<D, CAP, false>), dim3(n_grid), dim3(64 * PANEL_W), 0, stream, pkg, pkg_off, n_tasks, \
+	const size_t n_lds_bytes = size_t(panel_lds(n_dim, b_fused, r_cfg).TOTAL) * sizeof(double);
+	// (beyond 64 KB of dynamic LDS a kernel has to be told once)
+#define LAUNCH_PANEL_INSTANCE(D, WW, F) do { \
+		static bool b_attribute_set = false; \
+		if(!b_attribute_set) { \
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_panel_kernel<D, WW, F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+			b_attribute_set = true; \
+		} \
+		hipLaunchKernelGGL((factor_panel_kernel<D, WW, F>), dim3(n_grid), dim3(64 * WW), n_lds_bytes, stream, pkg, pkg_off, n_tasks, r_cfg, \
 			upd_slots, n_upd_slots, upd_ents, A, b, L, Linv, w, p_flag, p_timing); } while(0)
+#define LAUNCH_PANEL(D) do { \
+		if(W == 4) { if(b_fused) LAUNCH_PANEL_INSTANCE(D, 4, true); else LAUNCH_PANEL_INSTANCE(D, 4, false); } \
+		else { if(b_fused) LAUNCH_PANEL_INSTANCE(D, 8, true); else LAUNCH_PANEL_INSTANCE(D, 8, false); } } while(0)
 	switch(n_dim) {
 	case 3:
-		LAUNCH_PANEL(3, 256);
+		LAUNCH_PANEL(3);
 		return true;
 	case 6:
-		LAUNCH_PANEL(6, 96);
+		LAUNCH_PANEL(6);
 		return true;
 	case 7:
-		LAUNCH_PANEL(7, 72);
+		LAUNCH_PANEL(7);
 		return true;
 	default:
 		return false;
 	}
 #undef LAUNCH_PANEL
+#undef LAUNCH_PANEL_INSTANCE
 }
 
 // the same updates as a launch of their own (the first panel stage: nothing below it to ride in): one workgroup of

@@ -143,12 +143,13 @@ struct slampp_hip_solver {
 	slampp::CDevArray<slampp::TUpdSlot> d_panel_upd_slots; // the factor blocks of the panel tasks, stage by stage, and the
 	slampp::CDevArray<slampp::TUpdEnt> d_panel_upd_ents;   // updates they receive from earlier stages (panel_update_kernel)
 	std::vector<int32_t> panel_ptr, panel_rest_ptr, panel_upd_ptr; // [n_stages + 1] ranges of the lists (empty: no panels)
+	std::vector<slampp::TPanelLaunch> panel_cfg; // [n_stages] waves per task and LDS capacities of the stage's panel launch
 	std::vector<char> panel_ride; // [n_stages + 1] the stage's updates from further down are applied inside the launch of the stage below
 	slampp::CDevArray<int64_t> d_simt_tab;
 	std::vector<int32_t> simt_chunk_ptr, simt_rest_ptr; // [n_bottom_stages + 1] each; empty = not in use
 	std::vector<int32_t> simt_lds_bytes; // per stage: the largest chunk table (it is staged in LDS)
 	int n_simt = -1; // option "simt": 1 / -1 = use it where it applies (default), 0 = never
-	int n_wide_min_tasks = 1024; // option "wide_min_tasks": stages with more tasks than this run one wave per task
+	int n_wide_min_tasks = 8192; // option "wide_min_tasks": stages with more tasks than this run one wave per task, one tree level per stage (throughput); below, tasks are slices of the tree in LDS (C3: its 7 513-task stage 0.433 -> 0.404 ms as slices; a million poses: 2.31 ms with the 75 000-task stages wide, 2.36 as slices)
 	int n_simt_width = 32; // option "simt_width": tasks per wave (16, 32, 64)
 	int n_simt_stages = 1; // option "simt_stages": how many of the bottom stages it takes (the stages above the leaves hold
 	                       // single separator columns whose operands other waves wrote: no gain there, measured)

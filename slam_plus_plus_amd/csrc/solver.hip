@@ -498,6 +498,8 @@ void slampp_hip_solver::Analyze_Sparse()
 	{ // a tall task must fit the panel kernel: its columns and the blocks of its LDS image
 		const std::vector<int64_t> &r_cs = b_refined? refined_cumsum : cumsum;
 		const int n_dim0 = int(r_cs[1] - r_cs[0]);
+		if(const char *p_s_wide = getenv("SLAMPP_HIP_WIDE_MIN")) // development aid: overrides the option "wide_min_tasks"
+			n_wide_min_tasks = std::max(atoi(p_s_wide), 1);
 		opt.task_wide_min = n_wide_min_tasks;
 		opt.task_max_cols = int(PANEL_COLS);
 		opt.task_max_blocks = panel_slot_cap(n_dim0);
@@ -720,13 +722,23 @@ void slampp_hip_solver::Analyze_Sparse()
 		std::vector<TPanelCol> pcols;
 		std::vector<TPanelSlot> pslots;
 		panel_ride.assign(n_stages + 1, 0);
+		panel_cfg.assign(size_t(n_stages) + 1, TPanelLaunch{int32_t(PANEL_W), int32_t(64 * PANEL_W), 1, 1, 1, 0});
 		const int n_ride_max_fresh = getenv("SLAMPP_PANEL_RIDE_FRESH")? atoi(getenv("SLAMPP_PANEL_RIDE_FRESH")) : 64;
 		for(int s = 0; s < n_stages; ++ s) {
 			const bool b_panel_stage = s >= n_bottom_stages || (s == 0 && b_leaf_panels);
 			// Do this stage's updates from further down ride in the launch of the stage below?  Only if that is a panel launch,
 			// and only if what is then left to the tasks themselves -- the updates from the stage right below -- is little:
 			// a task brings those in with its own eight waves, on the stage's critical path (a launch saved is about 4 us)
-			if(b_panel_stage && s > 0 && panel_ptr[s] > panel_ptr[s - 1]) {
+			// Waves per task: eight where the stage is a launch on the critical path, four where it holds more tasks than the
+			// chip takes at once (more workgroups per CU: throughput).
+			const int n_stage_waves = (b_panel_stage && P.stage_ptr[s + 1] - P.stage_ptr[s] > 512)? 4 : int(PANEL_W);
+			panel_cfg[s].n_waves = n_stage_waves;
+			panel_cfg[s].n_cap_units = 64 * n_stage_waves; // (one speculative unit per thread)
+			// The first stage above a leaf stage that is not a panel launch: everything its tasks receive comes from that one
+			// stage, nothing from further down -- the tasks bring it in themselves and no update launch is needed (if it fits
+			// the packages: the tall tasks of a wide stage receive some fifty products each)
+			const bool b_first_above_leaves = b_panel_stage && s == 1 && panel_ptr[1] == panel_ptr[0];
+			if(b_panel_stage && s > 0 && (panel_ptr[s] > panel_ptr[s - 1] || b_first_above_leaves)) {
 				int64_t n_max_fresh = 0;
 				for(int t = P.stage_ptr[s]; t < P.stage_ptr[s + 1]; ++ t) {
 					int64_t n_fresh = 0;
@@ -739,7 +751,8 @@ void slampp_hip_solver::Analyze_Sparse()
 					}
 					n_max_fresh = std::max(n_max_fresh, n_fresh);
 				}
-				panel_ride[s] = n_max_fresh <= n_ride_max_fresh;
+				panel_ride[s] = n_max_fresh <= (b_first_above_leaves? 320 : n_ride_max_fresh);
+				panel_cfg[s].b_from_lambda = panel_ride[s] && b_first_above_leaves;
 				if(b_timing)
 					fprintf(stderr, "[setup] stage %d: %d tasks, at most %lld updates from the stage below: %s\n", s,
 						P.stage_ptr[s + 1] - P.stage_ptr[s], (long long)n_max_fresh, panel_ride[s]? "ride" : "own launch");
@@ -891,13 +904,25 @@ void slampp_hip_solver::Analyze_Sparse()
 				hd.n_units = int32_t(n_units);
 				hd.n_int_rows = int32_t(irow.size());
 				// fresh entries by the wave that owns their slot, inside a wave by slot, inside a slot in list order
-				std::stable_sort(fresh.begin(), fresh.end(), [](const TPanelExt &x, const TPanelExt &y) {
-					const int wx = x.slot % PANEL_W, wy = y.slot % PANEL_W;
+				std::stable_sort(fresh.begin(), fresh.end(), [n_stage_waves](const TPanelExt &x, const TPanelExt &y) {
+					const int wx = x.slot % n_stage_waves, wy = y.slot % n_stage_waves;
 					return wx < wy || (wx == wy && x.slot < y.slot); });
 				for(size_t e = 0; e < fresh.size(); ++ e)
-					++ hd.ext_ptr[fresh[e].slot % PANEL_W + 1];
-				for(int v = 0; v < int(PANEL_W); ++ v)
+					++ hd.ext_ptr[fresh[e].slot % n_stage_waves + 1];
+				for(int v = 0; v < n_stage_waves; ++ v)
 					hd.ext_ptr[v + 1] += hd.ext_ptr[v];
+				{ // what the stage's launch must hold
+					TPanelLaunch &r_cfg = panel_cfg[s];
+					r_cfg.n_cap_units = std::max(r_cfg.n_cap_units, int32_t(n_units));
+					r_cfg.n_cap_blk = std::max(r_cfg.n_cap_blk, int32_t(n_slots));
+					r_cfg.n_cap_cols = std::max(r_cfg.n_cap_cols, int32_t(n_cols));
+					int n_level_cols = 0, n_level = -1;
+					for(size_t o = 0; o < pcols.size(); ++ o) {
+						n_level_cols = (pcols[o].sub == n_level)? n_level_cols + 1 : 1;
+						n_level = pcols[o].sub;
+						r_cfg.n_cap_lvl = std::max(r_cfg.n_cap_lvl, int32_t(n_level_cols));
+					}
+				}
 				if(int64_t(fresh.size()) != n_fresh)
 					throw std::logic_error("panel package: fresh entries miscounted");
 				const size_t n_at = panel_pkg.size();
@@ -1177,7 +1202,7 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 				launch_panel_update(P.max_dim, d_panel_upd_slots.p() + panel_upd_ptr[s], panel_upd_ptr[s + 1] - panel_upd_ptr[s],
 					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream);
 			const int n_next = (s + 1 < n_stages && panel_ride[s + 1])? panel_upd_ptr[s + 2] - panel_upd_ptr[s + 1] : 0;
-			launch_factor_panel(P.max_dim, b_panel_fused, d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s], n_panels,
+			launch_factor_panel(P.max_dim, b_panel_fused, panel_cfg[s], d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s], n_panels,
 				d_panel_upd_slots.p() + ((n_next > 0)? panel_upd_ptr[s + 1] : 0), n_next, d_panel_upd_ents.p(), p_values_dev, p_rhs_dev,
 				d_L.p(), d_Linv.p(), d_w.p(), p_flag, stream, dplan.p_timing);
 			if(panel_rest_ptr[s + 1] > panel_rest_ptr[s]) {

@@ -95,10 +95,42 @@ struct TUpdEnt { // 16 B
 };
 inline int panel_slot_cap(int n_dim) { return (n_dim == 6)? 96 : (n_dim == 7)? 72 : 256; }
 
+// How one stage's panel launch is shaped (decided per stage by the host): waves per task -- 8 where a stage is a launch on
+// the critical path (latency of one task), 4 where it holds more tasks than the chip takes at once (throughput: more
+// workgroups per CU) -- and the capacities its LDS is laid out for, the largest of the stage's tasks: package units,
+// blocks of the image, columns, columns of one level.
+struct TPanelLaunch {
+	int32_t n_waves, n_cap_units, n_cap_blk, n_cap_cols, n_cap_lvl;
+	int32_t b_from_lambda; // the tasks read their blocks from Lambda (and b): no update role has prepared Lambda - sum in the factor's
+	                       // storage -- the first stage above a leaf stage, whose every update is a fresh one
+};
+enum { PANEL_FRESH_BATCH = 4, PANEL_UPD_BATCH = 8 };
+// LDS of a panel launch, in doubles: offsets of the panel role's regions (package, image, vectors, inverses of the
+// level's diagonal blocks, one tile per wave, operand staging of the fresh updates) and the total, which also covers
+// the update role's staging (riders: the next stage's updates from further down, PANEL_UPD_W waves per factor block)
+struct TPanelLds {
+	int IMAGE, VEC, LINV, TILE, OPS, YV, TOTAL;
+};
+inline __host__ __device__ TPanelLds panel_lds(int D, bool b_fused, const TPanelLaunch &c)
+{
+	const int DD = D * D, W = c.n_waves;
+	TPanelLds l;
+	l.IMAGE = 2 * c.n_cap_units;
+	l.VEC = l.IMAGE + c.n_cap_blk * DD;
+	l.LINV = l.VEC + c.n_cap_cols * 8;
+	l.TILE = l.LINV + c.n_cap_lvl * 64;
+	l.OPS = l.TILE + W * 64;
+	l.YV = l.OPS + (b_fused? W * 2 * PANEL_FRESH_BATCH * DD : 0);
+	const int n_panel_end = l.YV + (b_fused? W * PANEL_FRESH_BATCH * 8 : 0);
+	const int n_upd_end = b_fused? W * 2 * PANEL_UPD_BATCH * DD + W * PANEL_UPD_BATCH * 8 + W * 64 : 0;
+	l.TOTAL = (n_panel_end > n_upd_end)? n_panel_end : n_upd_end;
+	return l;
+}
+
 // one workgroup per package (pkg_off: their offsets in pkg, in 16-byte units; pkg is padded by 64 * PANEL_W units)
 // (upd_slots: the blocks of the NEXT stage's panel tasks, whose updates from below this stage ride in this launch)
 // (b_fused: the plan has such stages at all; without them the leaner kernel runs)
-bool launch_factor_panel(int n_dim, bool b_fused, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks, const TUpdSlot *upd_slots,
+bool launch_factor_panel(int n_dim, bool b_fused, const TPanelLaunch &r_cfg, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks, const TUpdSlot *upd_slots,
 	int n_upd_slots, const TUpdEnt *upd_ents, const double *A, const double *b, double *L, double *Linv, double *w, int *p_flag,
 	hipStream_t stream, long long *p_timing = 0);
 void launch_panel_update(int n_dim, const TUpdSlot *slots, int n_slots, const TUpdEnt *ents, const double *A, double *L,

@@ -11,8 +11,8 @@ for name in which:
     lam = systems[name]()
     vals = torch.from_numpy(lam.values).cuda()
     x_ref = None
-    for h in (1, 2, 3):
-        s = CLinearSolver_HIP(task_height=h)
+    for h, wide in ((1, 1024), (3, 1024), (3, 1 << 30), (2, 1 << 30)):
+        s = CLinearSolver_HIP(task_height=h, wide_min_tasks=wide)
         s.SymbolicDecomposition_Blocky(lam)
         st = s.stats()
         bufs = [torch.from_numpy(lam.rhs).cuda() for _ in range(41)]
@@ -31,6 +31,6 @@ for name in which:
         res = np.abs(lam.to_scipy() @ x - lam.rhs).max() / np.abs(lam.rhs).max()
         if x_ref is None:
             x_ref = x
-        print(f"{name} task_height={h}: stages={st['n_stages']} tasks={st['n_tasks']} warm={dt:.3f} ms resid={res:.1e} "
+        print(f"{name} task_height={h} wide_min={wide}: stages={st['n_stages']} tasks={st['n_tasks']} warm={dt:.3f} ms resid={res:.1e} "
               f"vs h=1 {np.abs(x - x_ref).max() / np.abs(x_ref).max():.1e}  " +
               "  ".join(f"{k}={ms / max(c, 1) * 1e3:.0f}us" for k, (c, ms) in s.profile().items()), flush=True)
