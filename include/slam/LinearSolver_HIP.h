@@ -109,6 +109,7 @@ protected:
 				Throw_On_Error(slampp_hip_create_multi(&m_p_solver, &m_devices[0], int(m_devices.size())));
 			else
 				Throw_On_Error(slampp_hip_create(&m_p_solver, m_n_device));
+			Throw_On_Error(slampp_hip_set_option(m_p_solver, "staging_ahead", 1)); // lambda arrives in host memory: the pinned staging comes up beside the analysis
 			for(size_t i = 0, n = m_options.size(); i < n; ++ i)
 				Throw_On_Error(slampp_hip_set_option(m_p_solver, m_options[i].first.c_str(), m_options[i].second));
 		}

@@ -152,6 +152,14 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
  * "assembly_groups" (slampp_hip_assembly_create: the most vertices one group of the Lambda assembly takes -- a group is a
  * run of consecutive vertices whose edges fit in LDS together, so that every edge record is read once for its
  * off-diagonal block and both diagonal blocks; default: as many as fit; 0 = no groups, one wave per block of Lambda),
+ * "staging_ahead" (0 / 1: slampp_hip_analyze also brings up the pinned host staging of slampp_hip_host_staging, on a host
+ * thread of its own next to the ordering and the symbolic analysis -- for callers that will hand over host arrays (the header
+ * class sets it); callers that keep Lambda on the device leave it off and never pay for the staging),
+ * "schur_fallback" (Schur mode, default 1: a structure the Schur kernels do not take -- no landmark part, landmark-landmark
+ * blocks, block sizes other than (6,3), (7,3), (3,2) -- is solved through the sparse block path, as the reference solves it
+ * (LinearSolver_Schur.h:1635-1638, 1721-1726); 0 = slampp_hip_analyze reports SLAMPP_HIP_ERR_UNSUPPORTED / _INVALID instead),
+ * "group_exchange" (handles made by slampp_hip_create_multi, see there), "wide_min_tasks" (default 8192: stages with more tasks
+ * run one wave per single-column task; below that, tasks are slices of the elimination tree, option "task_height"),
  * "marginals_dense" (Schur mode: 1 = slampp_hip_schur_marginals always inverts the reduced system densely; 0 (default) =
  * when the solves factor it by the sparse block path, the covariances take the blocks of S^-1 they need from a
  * sparse inverse subset on that factor's pattern) */

@@ -538,8 +538,9 @@ int group_set_option(CDeviceGroup &g, const char *p_s_name, int64_t n_value)
 		g.n_exchange_option = int(n_value);
 		return SLAMPP_HIP_OK;
 	}
-	if(!strcmp(p_s_name, "shard_primary") || !strcmp(p_s_name, "shard_rank") || !strcmp(p_s_name, "shard_world"))
-		return SLAMPP_HIP_OK; // the group decides those for its members
+	if(!strcmp(p_s_name, "shard_primary") || !strcmp(p_s_name, "shard_rank") || !strcmp(p_s_name, "shard_world") ||
+	   !strcmp(p_s_name, "staging_ahead"))
+		return SLAMPP_HIP_OK; // the group decides those for its members (which never take host arrays: no staging of their own)
 	int n_result = SLAMPP_HIP_OK;
 	for(size_t i = 0; i < g.members.size() && n_result == SLAMPP_HIP_OK; ++ i)
 		n_result = slampp_hip_set_option(g.members[i], p_s_name, n_value);

@@ -119,6 +119,7 @@ struct slampp_hip_solver {
 	// reference's InverseOf_Symmteric_FBS branch, LinearSolver_Schur.h:1721-1726; block sizes other than (6,3), (7,3), (3,2);
 	// no landmark part at all, :1635-1638): the same system goes through the sparse block path, which solves it all the same
 	bool b_schur_fallback = false;
+	int n_staging_ahead = 0; // option "staging_ahead": slampp_hip_analyze brings up the pinned host staging on a thread of its own
 	int n_schur_fallback_option = 1; // option "schur_fallback": 0 = report SLAMPP_HIP_ERR_UNSUPPORTED instead
 	slampp::Plan plan;
 	int n_bottom_stages; // leading stages launched with one wave per task
@@ -153,7 +154,11 @@ struct slampp_hip_solver {
 	int n_simt_width = 32; // option "simt_width": tasks per wave (16, 32, 64)
 	int n_simt_stages = 1; // option "simt_stages": how many of the bottom stages it takes (the stages above the leaves hold
 	                       // single separator columns whose operands other waves wrote: no gain there, measured)
-	void Build_Simt(); // throws
+	void Build_Simt(); // throws; host work only
+	void Upload_Simt(); // throws
+	std::vector<slampp::TSimtChunk> simt_host_chunks; // what Build_Simt() made, until Upload_Simt() has sent it
+	std::vector<int32_t> simt_host_prog, simt_host_rest;
+	std::vector<int64_t> simt_host_tab;
 	// dense top of the sparse path (plan.h): assembled Schur complement + dense factor workspaces
 	slampp::CDevArray<slampp::TDenseBlk> d_dense_blks;
 	slampp::CDevArray<slampp::TDenseCol> d_dense_cols;

@@ -519,6 +519,18 @@ void slampp_hip_solver::Analyze_Sparse()
 	while(n_bottom_stages < int(P.stage_ptr.size()) - 1 &&
 	   P.stage_ptr[n_bottom_stages + 1] - P.stage_ptr[n_bottom_stages] > n_wide_min_tasks)
 		++ n_bottom_stages; // (tall tasks, Plan::col_sub, begin above these: the same threshold)
+	// the shape grouping of the leaf kernel (13 ms of host work at 100 000 poses, plan in, tables out) runs beside the
+	// records, packages and uploads below
+	std::exception_ptr p_simt_error;
+	struct TJoin { std::thread t; ~TJoin() { if(t.joinable()) t.join(); } } t_simt_thread;
+	const double t_simt = wall_ms();
+	t_simt_thread.t = std::thread([this, &p_simt_error]() {
+		try {
+			Build_Simt();
+		} catch(...) {
+			p_simt_error = std::current_exception();
+		}
+	});
 
 	if(P.cs_new[P.n] >= INT32_MAX)
 		throw std::domain_error("systems with 2^31 or more scalar unknowns are not supported by the sparse path");
@@ -1000,10 +1012,13 @@ void slampp_hip_solver::Analyze_Sparse()
 	dplan.p_timing = 0;
 	dplan.task_map = 0;
 	{
-		const double t_simt = wall_ms();
-		Build_Simt();
+		const double t_wait = wall_ms();
+		t_simt_thread.t.join();
+		if(p_simt_error)
+			std::rethrow_exception(p_simt_error);
+		Upload_Simt();
 		if(b_timing)
-			fprintf(stderr, "[setup] %-12s %8.2f ms\n", "shapes", wall_ms() - t_simt);
+			fprintf(stderr, "[setup] %-12s %8.2f ms since it was started, %.2f ms of them waited for\n", "shapes", wall_ms() - t_simt, wall_ms() - t_wait);
 	}
 	if(getenv("SLAMPP_HIP_STAGE_TIMING")) { // development aid: clock samples of the upper-stage kernel, printed at sync
 		d_timing.Alloc(1 + 32 * 4096);
@@ -1015,11 +1030,14 @@ void slampp_hip_solver::Analyze_Sparse()
 // Sorts the tasks of the wide bottom stages by shape for the lane-per-task kernel (simt_kernel.hip; the formats are
 // described in sparse_kernels.h).  A shape is the task's whole program -- counts and operand indices, the operands
 // numbered in order of first use -- so two tasks of one shape differ in nothing but where their blocks live.
+// host part of the lane-per-task tables (no HIP call: runs on a thread of its own next to the rest of the analysis);
+// Upload_Simt() sends what it built
 void slampp_hip_solver::Build_Simt()
 {
 	simt_chunk_ptr.clear();
 	simt_rest_ptr.clear();
 	simt_lds_bytes.clear();
+	simt_host_chunks.clear(); simt_host_prog.clear(); simt_host_tab.clear(); simt_host_rest.clear();
 	const Plan &P = plan;
 	if(!n_simt || !P.uniform_dim || (P.max_dim != 3 && P.max_dim != 6 && P.max_dim != 7))
 		return;
@@ -1029,9 +1047,9 @@ void slampp_hip_solver::Build_Simt()
 		return;
 	enum { MIN_GROUP = 1, MAX_PROG = 4096, MAX_TABLE_BYTES = 40960 }; // (rare shapes run with few busy lanes, beside the others: cheaper than a launch of their own)
 	const int n_stages = int(P.stage_ptr.size()) - 1;
-	std::vector<TSimtChunk> chunks;
-	std::vector<int32_t> prog_all, rest;
-	std::vector<int64_t> tab;
+	std::vector<TSimtChunk> &chunks = simt_host_chunks;
+	std::vector<int32_t> &prog_all = simt_host_prog, &rest = simt_host_rest;
+	std::vector<int64_t> &tab = simt_host_tab;
 	struct TTask { int32_t n_task; std::vector<int32_t> ops; std::vector<int32_t> ys; };
 	std::vector<int32_t> op_index(P.lrow.size(), -1), y_index(size_t(P.n), -1);
 	simt_chunk_ptr.push_back(0);
@@ -1158,11 +1176,21 @@ void slampp_hip_solver::Build_Simt()
 		simt_rest_ptr.clear();
 		return;
 	}
-	d_simt_chunks.Upload(chunks, stream);
-	d_simt_prog.Upload(prog_all, stream);
-	d_simt_tab.Upload(tab, stream);
-	d_simt_rest.Upload(rest, stream);
-	SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // the vectors above die here
+}
+
+void slampp_hip_solver::Upload_Simt()
+{
+	const Plan &P = plan;
+	if(simt_host_chunks.empty())
+		return;
+	d_simt_chunks.Upload(simt_host_chunks, stream);
+	d_simt_prog.Upload(simt_host_prog, stream);
+	d_simt_tab.Upload(simt_host_tab, stream);
+	d_simt_rest.Upload(simt_host_rest, stream);
+	SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // (the host copies are no longer needed)
+	{ std::vector<TSimtChunk> e; simt_host_chunks.swap(e); }
+	{ std::vector<int32_t> e0, e1; simt_host_prog.swap(e0); simt_host_rest.swap(e1); }
+	{ std::vector<int64_t> e; simt_host_tab.swap(e); }
 	if(getenv("SLAMPP_HIP_PLAN_TIMING")) {
 		for(size_t s = 0; s + 1 < simt_chunk_ptr.size(); ++ s) {
 			fprintf(stderr, "[setup] stage %zu: %d tasks -> %d chunks of 64 lanes, %d tasks left to the wave-per-task kernel\n", s,
@@ -1540,6 +1568,10 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 	}
 	else if(s == "schur_sparse" && n_value >= -1 && n_value <= 1)
 		p_solver->n_schur_sparse = int(n_value);
+	else if(s == "staging_ahead" && n_value >= 0 && n_value <= 1) {
+		p_solver->n_staging_ahead = int(n_value);
+		return SLAMPP_HIP_OK; // read by analyze: does not invalidate anything
+	}
 	else if(s == "schur_fallback" && n_value >= 0 && n_value <= 1)
 		p_solver->n_schur_fallback_option = int(n_value);
 	else if(s == "schur_tiles" && n_value >= -1 && n_value <= 3)
@@ -1664,6 +1696,21 @@ int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix
 		s.n_mode = n_mode;
 		s.n_matrix_cut = n_matrix_cut;
 		const double t0 = wall_ms();
+		// option "staging_ahead" (callers that will hand over host arrays: the header class, the host entry points): the
+		// pinned staging for Lambda's values -- 10 ms of page faults and registration at C3's 58 MB, more at C4's 336 MB --
+		// comes up on a thread of its own while this one orders and analyzes
+		std::exception_ptr p_staging_error;
+		struct TJoin { std::thread t; ~TJoin() { if(t.joinable()) t.join(); } } t_staging_thread;
+		if(s.n_staging_ahead && s.group_devices.empty() && !getenv("SLAMPP_HIP_NO_STAGING_AHEAD")) { // (the variable: a development aid)
+			t_staging_thread.t = std::thread([&s, &p_staging_error]() {
+				try {
+					SLAMPP_HIP_CHECK(hipSetDevice(s.n_device));
+					s.Require_Staging();
+				} catch(...) {
+					p_staging_error = std::current_exception();
+				}
+			});
+		}
 		if(n_mode == SLAMPP_HIP_MODE_SPARSE) {
 			s.Analyze_Sparse();
 			s.times.order_ms = s.plan.order_ms;
@@ -1703,6 +1750,11 @@ int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix
 				s.times.order_ms = s.plan.order_ms;
 			}
 			s.times.symbolic_ms = wall_ms() - t0;
+		}
+		if(t_staging_thread.t.joinable()) {
+			t_staging_thread.t.join();
+			if(p_staging_error)
+				std::rethrow_exception(p_staging_error);
 		}
 		s.b_analyzed = true;
 		return SLAMPP_HIP_OK;

@@ -363,6 +363,7 @@ class _SolverBase:
         if eta.dtype != np.float64 or not eta.flags.c_contiguous or eta.shape != (lam.n_scalars,):
             raise ValueError("eta must be a contiguous float64 vector of the system's dimension")
         if not self._analyzed or self._structure_key != self._key(lam):
+            self._check(self._lib.slampp_hip_set_option(self._h, b"staging_ahead", 1))   # host arrays: the staging beside the analysis
             self.SymbolicDecomposition_Blocky(lam)
         vals = np.ascontiguousarray(lam.values, dtype=np.float64)
         if vals.shape != (self._n_values,):
