@@ -24,6 +24,15 @@ void dense_prepare_gaps(double *M, int n_pad, const int32_t *p_positions_dev, in
 // Sets *p_flag |= 1 if a pivot of a row < n is not positive.
 void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag, hipStream_t stream);
 
+// The pieces of dense_cholesky() for a factorization whose outer panels (OUTER = 4 tiles = 256 columns) are spread over
+// several devices (group.hip: panel b belongs to member b mod P):
+//   dense_factor_panel   factors the tile columns [t0, t1) of M, which must be up to date with every earlier panel:
+//                        per tile potrf + inverse, panel solve, update of the panel's remaining columns;
+//   dense_update_panels  applies the finished tile columns [k0, k1) to the lower tiles of the tile columns [c0, c1).
+enum { dense_OUTER_TILES = 4 };
+void dense_factor_panel(double *M, int n_pad, int n, int t0, int t1, double *p_invdiag, int *p_flag, hipStream_t stream);
+void dense_update_panels(double *M, int n_pad, int k0, int k1, int c0, int c1, hipStream_t stream);
+
 // Tile-sparse variant for the dense top of the sparse path: the separators assembled into one dense matrix still
 // form a tree, so many 64 x 64 tiles are structurally zero and tile columns in different subtrees are independent.
 // The schedule (built once per structure from the set of nonzero tiles) groups the tile columns by their height in

@@ -250,6 +250,25 @@ void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag,
 	}
 }
 
+void dense_factor_panel(double *M, int n_pad, int n, int t0, int t1, double *p_invdiag, int *p_flag, hipStream_t stream)
+{
+	const int n_blocks = n_pad / NB;
+	const TSyrkJob t_none = {0, 0, 0, 0, 0, 0};
+	for(int kb = t0; kb < t1; ++ kb) {
+		double *invL = p_invdiag + size_t(kb) * NB * NB;
+		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, stream, M, n_pad, kb, n, invL, p_flag, n_blocks, t_none, t_none, t_none);
+		const int n_below = n_blocks - kb - 1;
+		if(n_below > 0)
+			hipLaunchKernelGGL(trsm_kernel, dim3(n_below), dim3(256), 0, stream, M, n_pad, kb, invL, 0);
+		launch_syrk(M, n_pad, n_blocks, kb, kb + 1, kb + 1, t1, stream); // the rest of this panel's columns
+	}
+}
+
+void dense_update_panels(double *M, int n_pad, int k0, int k1, int c0, int c1, hipStream_t stream)
+{
+	launch_syrk(M, n_pad, n_pad / NB, k0, k1, c0, c1, stream);
+}
+
 // ---- backward substitution x = L^-T y, right-looking ----
 __global__ void dense_backsolve_init_kernel(const double *M, int ld, int n, double *z)
 {

@@ -18,6 +18,7 @@
 //   * dx is computed redundantly, dl shard-locally, each member writes its landmarks' part of the solution straight
 //     into the caller's vector.
 #include "solver.h"
+#include "dense_chol.h"
 
 #include <dlfcn.h>
 #include <algorithm>
@@ -318,6 +319,12 @@ public:
 		}
 		m_all_here.notify_all();
 	}
+
+	bool b_Aborted()
+	{
+		std::lock_guard<std::mutex> lock(m_mutex);
+		return m_b_aborted;
+	}
 };
 
 // ---- the direct exchange through peer pointers --------------------------------------------------------------------
@@ -351,6 +358,64 @@ __global__ void group_gather_slices_kernel(TPeerBuffers t_buffers, int n_members
 	}
 }
 
+// ---- the dense reduced camera system factored by all members together (option "schur_distributed") ------------------
+// SURVEY.md section 8f rank 2, first half; the reference factors S once, serially (src/slam/LinearSolver_Schur.cpp:2314-2331)
+// and falls back to a sparse solver when it does not fit (include/slam/LinearSolver_Schur.h:1844-1853).
+//
+// The matrix is cut into outer panels of 256 columns (4 tiles), panel b belongs to member b mod P.
+//   1. reduce-scatter by panels: every member sums, for its own panels, the members' partial S -- peer reads, in member
+//      order, into its own buffer;
+//   2. right-looking factorization, owner computes: the owner of panel b factors it (diagonal tiles, panel solve) and
+//      writes the finished columns and the inverses of their diagonal tiles into every other member's buffer; each
+//      member then applies panel b to the panels it owns (K = 256 updates on the matrix cores), the owner of panel
+//      b + 1 to that one first, which it factors and sends before it goes on with the others (look-ahead);
+//   3. every member then holds the whole factor (its own panels and the received ones): the substitutions run as
+//      before, redundantly.
+// Members meet through events: "my partial S is assembled" (one per member), "panel b is in your buffer" (one per
+// panel, recorded on the owner's stream, waited for on the others'); a host-side sequence number makes sure a wait is
+// only enqueued after the record it refers to.  Summation and elimination orders are fixed: every member gets the same bits.
+
+// columns of the panels this member owns: the sum over the members' buffers, rows from the column's diagonal tile down
+__global__ void group_reduce_columns_kernel(TPeerBuffers t_S, int n_members, int n_me, int n_pad)
+{
+	const int j = blockIdx.x, n_panel = (j / int(dense_NB)) / int(dense_OUTER_TILES);
+	if(n_panel % n_members != n_me)
+		return;
+	const size_t n_col = size_t(j) * n_pad;
+	for(int i = (j / int(dense_NB)) * int(dense_NB) + threadIdx.x; i < n_pad; i += blockDim.x) {
+		double f_sum = 0;
+		for(int k = 0; k < n_members; ++ k)
+			f_sum += t_S.p[k][n_col + i];
+		t_S.p[n_me][n_col + i] = f_sum;
+	}
+}
+
+// the finished tile columns [t0, t1) and the inverses of their diagonal tiles into the other members' buffers
+__global__ void group_send_panel_kernel(TPeerBuffers t_S, TPeerBuffers t_inv, int n_members, int n_me, int n_pad, int t0, int t1)
+{
+	const int n_cols = (t1 - t0) * int(dense_NB);
+	if(int(blockIdx.x) < n_cols) {
+		const int j = t0 * int(dense_NB) + blockIdx.x;
+		const size_t n_col = size_t(j) * n_pad;
+		for(int i = t0 * int(dense_NB) + threadIdx.x; i < n_pad; i += blockDim.x) {
+			const double f = t_S.p[n_me][n_col + i];
+			for(int k = 0; k < n_members; ++ k) {
+				if(k != n_me)
+					t_S.p[k][n_col + i] = f;
+			}
+		}
+	} else {
+		const size_t n_tile = size_t(t0 + (int(blockIdx.x) - n_cols)) * dense_NB * dense_NB;
+		for(int e = threadIdx.x; e < int(dense_NB) * int(dense_NB); e += blockDim.x) {
+			const double f = t_inv.p[n_me][n_tile + e];
+			for(int k = 0; k < n_members; ++ k) {
+				if(k != n_me)
+					t_inv.p[k][n_tile + e] = f;
+			}
+		}
+	}
+}
+
 // ---- the group ----------------------------------------------------------------------------------------------------
 
 struct CDeviceGroup;
@@ -379,9 +444,21 @@ struct CDeviceGroup {
 	CAbortableBarrier barrier;
 	TPeerBuffers t_peer_buffers;
 	size_t peer_counts[GROUP_MAX_MEMBERS];
+	// distributed dense factorization: the members' S and inverse-tile buffers, events, and how far the owners have got
+	TPeerBuffers t_factor_S, t_factor_inv;
+	int factor_dims[GROUP_MAX_MEMBERS][2];
+	hipEvent_t ev_assembled[GROUP_MAX_MEMBERS];
+	std::vector<hipEvent_t> ev_panel; // [n_outer], each created on its owner's device
+	std::mutex ev_mutex;
+	std::atomic<int64_t> n_panel_sequence; // solve number * 65536 + panels recorded so far in that solve
+	int64_t n_factor_calls[GROUP_MAX_MEMBERS];
 	std::string s_exchange_name;
 
-	CDeviceGroup() :p_threads(0), n_active(0), n_exchange_option(EXCHANGE_AUTO), n_exchange(EXCHANGE_PEER) {}
+	CDeviceGroup() :p_threads(0), n_active(0), n_exchange_option(EXCHANGE_AUTO), n_exchange(EXCHANGE_PEER), n_panel_sequence(0)
+	{
+		memset(ev_assembled, 0, sizeof(ev_assembled));
+		memset(n_factor_calls, 0, sizeof(n_factor_calls));
+	}
 };
 
 static void grow_device(double *&r_p, size_t &r_n, size_t n_doubles) // on the calling thread's device; throws
@@ -459,6 +536,89 @@ static int group_allreduce_callback(void *p_context, double *p_dev, size_t n_cou
 	return g.barrier.b_Wait()? 0 : 1;
 }
 
+// all-reduce + redundant factorization replaced: see the comment above group_reduce_columns_kernel
+static int group_dense_factor_callback(void *p_context, double *p_S, int n_pad, int n, double *p_invdiag, int *p_flag, void *p_hip_stream)
+{
+	TMemberContext &t = *(TMemberContext*)p_context;
+	CDeviceGroup &g = *t.p_group;
+	const int r = t.n_member, P = g.n_active;
+	hipStream_t stream = (hipStream_t)p_hip_stream;
+	const int n_tiles = n_pad / int(dense_NB), n_outer = (n_tiles + int(dense_OUTER_TILES) - 1) / int(dense_OUTER_TILES);
+	const int64_t n_solve = ++ g.n_factor_calls[r]; // (the members call in step: the same number on each of them)
+	auto fail = [&g]() { g.barrier.Abort(); return 1; };
+	// events: this member's "assembled" event and the events of the panels it owns (created on its own device)
+	if(!g.ev_assembled[r] && hipEventCreateWithFlags(&g.ev_assembled[r], hipEventDisableTiming) != hipSuccess)
+		return fail();
+	{
+		std::lock_guard<std::mutex> lock(g.ev_mutex); // (the vector may grow under another member's hands)
+		if(int(g.ev_panel.size()) < n_outer)
+			g.ev_panel.resize(size_t(n_outer), (hipEvent_t)0);
+		for(int b = r; b < n_outer; b += P) {
+			if(!g.ev_panel[b] && hipEventCreateWithFlags(&g.ev_panel[b], hipEventDisableTiming) != hipSuccess)
+				return fail();
+		}
+	}
+	g.t_factor_S.p[r] = p_S;
+	g.t_factor_inv.p[r] = p_invdiag;
+	g.factor_dims[r][0] = n_pad;
+	g.factor_dims[r][1] = n;
+	if(hipEventRecord(g.ev_assembled[r], stream) != hipSuccess)
+		return fail();
+	if(!g.barrier.b_Wait()) // everybody's pointers are in the tables, everybody's "assembled" event is recorded
+		return 1;
+	for(int k = 0; k < P; ++ k) {
+		if(g.factor_dims[k][0] != n_pad || g.factor_dims[k][1] != n)
+			return fail(); // the members do not agree on the reduced system
+		if(k != r && hipStreamWaitEvent(stream, g.ev_assembled[k], 0) != hipSuccess)
+			return fail();
+	}
+	const TPeerBuffers t_S = g.t_factor_S, t_inv = g.t_factor_inv;
+	hipLaunchKernelGGL(group_reduce_columns_kernel, dim3(unsigned(n_pad)), dim3(256), 0, stream, t_S, P, r, n_pad);
+	auto t0_of = [&](int b) { return b * int(dense_OUTER_TILES); };
+	auto t1_of = [&](int b) { return std::min((b + 1) * int(dense_OUTER_TILES), n_tiles); };
+	auto factor_and_send = [&](int b) -> bool {
+		dense_factor_panel(p_S, n_pad, n, t0_of(b), t1_of(b), p_invdiag, p_flag, stream);
+		if(P > 1) {
+			const int n_grid = (t1_of(b) - t0_of(b)) * int(dense_NB) + (t1_of(b) - t0_of(b));
+			hipLaunchKernelGGL(group_send_panel_kernel, dim3(unsigned(n_grid)), dim3(256), 0, stream, t_S, t_inv, P, r, n_pad, t0_of(b), t1_of(b));
+		}
+		if(hipEventRecord(g.ev_panel[b], stream) != hipSuccess)
+			return false;
+		g.n_panel_sequence.store(n_solve * 65536 + b + 1); // (panels are recorded in order, one owner after the other)
+		return true;
+	};
+	bool b_ahead = false; // this member has factored the next panel already (look-ahead)
+	for(int b = 0; b < n_outer; ++ b) {
+		if(b % P == r) {
+			if(!b_ahead && !factor_and_send(b))
+				return fail();
+			b_ahead = false;
+		} else {
+			while(g.n_panel_sequence.load() < n_solve * 65536 + b + 1) { // the owner has recorded the event: now it can be waited for
+				if(g.barrier.b_Aborted())
+					return 1;
+				std::this_thread::yield();
+			}
+			if(hipStreamWaitEvent(stream, g.ev_panel[b], 0) != hipSuccess)
+				return fail();
+		}
+		for(int c = b + 1 + ((r - (b + 1)) % P + P) % P; c < n_outer; c += P) { // the panels this member owns, beyond b
+			dense_update_panels(p_S, n_pad, t0_of(b), t1_of(b), t0_of(c), t1_of(c), stream);
+			if(c == b + 1) { // the next panel is this member's: out with it before the others are brought up to date
+				if(!factor_and_send(c))
+					return fail();
+				b_ahead = true;
+			}
+		}
+	}
+	if(hipGetLastError() != hipSuccess)
+		return fail();
+	// nobody's buffers may be taken apart (the next solve's assembly) while a member still reads them: every member has
+	// waited for every panel, which its owner sent after it had read what it needed; the last readers are the owners'
+	// reduce-scatter kernels, which precede their first panel
+	return 0;
+}
+
 CDeviceGroup *group_create(const int *p_device_ids, int n_devices) // throw(std::bad_alloc, std::invalid_argument, CDeviceError)
 {
 	if(!p_device_ids || n_devices < 1 || n_devices > GROUP_MAX_MEMBERS)
@@ -523,6 +683,14 @@ void group_destroy(CDeviceGroup *p_group)
 		});
 	}
 	group_release_exchange(g);
+	for(int r = 0; r < GROUP_MAX_MEMBERS; ++ r) {
+		if(g.ev_assembled[r])
+			(void)hipEventDestroy(g.ev_assembled[r]);
+	}
+	for(size_t b = 0; b < g.ev_panel.size(); ++ b) {
+		if(g.ev_panel[b])
+			(void)hipEventDestroy(g.ev_panel[b]);
+	}
 	delete g.p_threads;
 	g.p_threads = 0;
 	for(size_t i = 0; i < g.members.size(); ++ i)
@@ -653,6 +821,8 @@ void group_analyze(slampp_hip_solver &r_front, int64_t n_cut) // throws
 		if(n_status == SLAMPP_HIP_OK) {
 			n_status = slampp_hip_set_allreduce(p_member, (n_active > 1)? group_allreduce_callback : (slampp_hip_allreduce_fn)0,
 				&g.contexts[r]);
+			p_member->p_dense_factor = (n_active > 1)? group_dense_factor_callback : (slampp_hip_solver::TDenseFactorFn)0;
+			p_member->p_dense_factor_context = &g.contexts[r];
 		}
 		if(n_status == SLAMPP_HIP_OK) {
 			TMemberShard &t_shard = g.shards[r];

@@ -1286,7 +1286,14 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 		s.Phase_End();
 	}
 
-	if(s.p_allreduce) {
+	// option "schur_distributed" (members of a device group, dense reduced system): reduce-scatter + joint factorization
+	const bool b_distributed = s.p_allreduce && !b_sparse && s.n_schur_distributed != 0 && s.p_dense_factor != 0;
+	if(b_distributed) {
+		s.Phase_Begin("dense_chol_distributed");
+		if(s.p_dense_factor(s.p_dense_factor_context, p_S, ld, n, S.d_invdiag.p(), s.d_flag.p(), (void*)st) != 0)
+			throw CDeviceError("distributed factorization of the reduced camera system failed");
+		s.Phase_End();
+	} else if(s.p_allreduce) {
 		s.Phase_Begin("allreduce");
 		double *p_rhs0 = b_sparse? p_r : p_S + n; // dense: the right-hand side is row n of S
 		hipLaunchKernelGGL(schur_flag_poison_kernel, dim3(1), dim3(1), 0, st, s.d_flag.p(), p_rhs0);
@@ -1320,13 +1327,15 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 		s.Phase_End();
 		p_dx = p_r;
 	} else {
-		s.Phase_Begin("dense_chol");
-		if(b_keep) { // the assembled system stays as it is; its copy is factored
-			SLAMPP_HIP_CHECK(hipMemcpyAsync(S.d_S.p(), p_S, size_t(ld) * ld * sizeof(double), hipMemcpyDeviceToDevice, st));
-			p_S = S.d_S.p();
+		if(!b_distributed) {
+			s.Phase_Begin("dense_chol");
+			if(b_keep) { // the assembled system stays as it is; its copy is factored
+				SLAMPP_HIP_CHECK(hipMemcpyAsync(S.d_S.p(), p_S, size_t(ld) * ld * sizeof(double), hipMemcpyDeviceToDevice, st));
+				p_S = S.d_S.p();
+			}
+			dense_cholesky(p_S, ld, n, S.d_invdiag.p(), s.d_flag.p(), st);
+			s.Phase_End();
 		}
-		dense_cholesky(p_S, ld, n, S.d_invdiag.p(), s.d_flag.p(), st);
-		s.Phase_End();
 		s.Phase_Begin("dense_solve");
 		dense_backsolve(p_S, ld, n, S.d_invdiag.p(), S.d_z.p(), S.d_x.p(), st);
 		s.Phase_End();

@@ -204,6 +204,14 @@ struct slampp_hip_solver {
 
 	slampp_hip_allreduce_fn p_allreduce;
 	void *p_allreduce_context;
+	// members of a device group (group.hip), option "schur_distributed": the dense reduced camera system is not summed on
+	// every member and factored by each of them, but reduce-scattered by outer panels and factored by all of them together
+	// (panel b by member b mod P, finished panels sent to the other members' copies, which then hold the whole factor);
+	// in place on p_S, same contract as dense_cholesky() on the summed matrix.  Internal: not part of the C ABI.
+	typedef int (*TDenseFactorFn)(void *p_context, double *p_S, int n_pad, int n, double *p_invdiag, int *p_flag, void *p_hip_stream);
+	TDenseFactorFn p_dense_factor = 0;
+	void *p_dense_factor_context = 0;
+	int n_schur_distributed = 0; // option "schur_distributed"
 
 	slampp_hip_times times;
 

@@ -1574,6 +1574,10 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 	}
 	else if(s == "schur_fallback" && n_value >= 0 && n_value <= 1)
 		p_solver->n_schur_fallback_option = int(n_value);
+	else if(s == "schur_distributed" && n_value >= 0 && n_value <= 1) {
+		p_solver->n_schur_distributed = int(n_value);
+		return SLAMPP_HIP_OK; // read at every solve
+	}
 	else if(s == "schur_tiles" && n_value >= -1 && n_value <= 3)
 		p_solver->n_schur_tiles = int(n_value);
 	else if(s == "schur_incremental" && n_value >= 0 && n_value <= 2)

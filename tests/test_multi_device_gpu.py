@@ -97,6 +97,38 @@ def test_marginals_and_marginal_poses_through_shards(oracle_solutions, name):
     assert np.all(e2[:n_x] == 0) and rel_inf(e2[n_x:], e1[n_x:]) < TOL
 
 
+@pytest.mark.parametrize("members", [2, 3])
+def test_distributed_dense_factorization_of_the_reduced_system(built, members):
+    """Option schur_distributed: the dense reduced camera system is reduce-scattered by outer panels of 256 columns and
+    factored by all members together (panel b by member b mod P, finished panels sent to the other members' copies) instead
+    of summed everywhere and factored by everyone.  Same solution as the single handle, 1e-10; the members' phases say
+    which way they went."""
+    from slam_plus_plus_amd import synth
+    from slam_plus_plus_amd.hip_solver import CLinearSolver_Schur_HIP
+    from oracle import oracle_lib as O
+    lam = synth.ba(210, 5000, k=4, mode="uniform", seed=13)        # n = 1260: 20 tiles, 5 outer panels
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok
+    single = CLinearSolver_Schur_HIP(device=0, schur_sparse=0)
+    e1 = lam.rhs.copy()
+    assert single.Solve_PosDef(lam, e1) and rel_inf(e1, x_ref) < TOL
+    multi = CLinearSolver_Schur_HIP(devices=[0] * members, schur_sparse=0, schur_distributed=1, profile=1)
+    for _ in range(3):                                             # the events and the sequence numbers are reused
+        e2 = lam.rhs.copy()
+        assert multi.Solve_PosDef_Blocky(lam, e2)
+        assert rel_inf(e2, x_ref) < TOL and rel_inf(e2, e1) < TOL
+    phases = multi.profile()
+    assert "dense_chol_distributed" in phases and "dense_chol" not in phases and "allreduce" not in phases, phases
+    # not positive definite: the owner of the failing panel says so, the handle returns false, and works afterwards
+    off = lam.block_value_offsets()
+    vals = lam.values.copy()
+    vals[off[150]:off[150] + 36] = -np.eye(6).ravel()             # camera 150's diagonal block
+    bad = type(lam)(lam.cumsum, lam.bcol_ptr, lam.brow_idx, vals, lam.rhs, lam.n_matrix_cut)
+    assert multi.Solve_PosDef_Blocky(bad, bad.rhs.copy()) is False
+    e3 = lam.rhs.copy()
+    assert multi.Solve_PosDef_Blocky(lam, e3) and rel_inf(e3, x_ref) < TOL
+
+
 def test_pose_graph_on_a_multi_device_handle_runs_on_the_first_device(built):
     from slam_plus_plus_amd import synth
     from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP
