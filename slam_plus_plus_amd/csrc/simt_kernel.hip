@@ -91,6 +91,18 @@ __device__ __forceinline__ void store_block(double *p, const double (&m)[D][D]) 
 	}
 }
 
+// rows [r0, r0 + D / 2) of a block: v[c][i] = p[r0 + i + c D] (two lanes per task: each takes half the rows)
+template <int D>
+__device__ __forceinline__ void load_half_rows(const double *__restrict__ p, int r0, double (&v)[D][D / 2])
+{
+	#pragma unroll
+	for(int c = 0; c < D; ++ c) {
+		#pragma unroll
+		for(int i = 0; i < D / 2; ++ i)
+			v[c][i] = p[r0 + i + c * D];
+	}
+}
+
 // position of the next column's header in the program, given the position right behind this column's touch list
 __device__ __forceinline__ int pc_next_column(const int32_t *P, int pc, int nb, int nr)
 {
@@ -100,7 +112,8 @@ __device__ __forceinline__ int pc_next_column(const int32_t *P, int pc, int nb, 
 	return pc;
 }
 
-template <int D, int W> // W = tasks (busy lanes) per wave
+template <int D, int W, int LPT> // W = tasks per wave, LPT = lanes per task (1, or 2 for even D: the lanes of a pair compute the
+// diagonal block of a column both, and each half the rows of the blocks below it -- no traffic between them)
 __global__ void __launch_bounds__(64)
 factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restrict__ prog, const long long *__restrict__ tab,
 	const double *__restrict__ A, double *L, double *Linv, const double *__restrict__ b, double *w, int *p_flag,
@@ -116,8 +129,11 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 			s_tab[i] = tab[ch.tab_off + i];
 		__syncthreads();
 	}
-	if(int(threadIdx.x) >= W)
+	if(int(threadIdx.x) >= W * LPT)
 		return; // (no barrier below)
+	const int n_half = (LPT == 2)? int(threadIdx.x) & 1 : 0; // which half of the rows below the diagonal this lane takes
+	enum { DH = (LPT == 2)? D / 2 : D };
+	const int r0 = n_half * DH;
 	long long *p_tm = 0; // development aid (SLAMPP_HIP_STAGE_TIMING): clock samples of a wave in the middle of the grid
 	int n_tm = 0;
 	if(p_timing && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {
@@ -128,7 +144,7 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 	}
 #define SIMT_TICK() do { if(p_tm && n_tm < 32) p_tm[n_tm ++] = wall_clock64(); } while(0)
 	const int32_t *P = prog + ch.prog_off;                 // wave-uniform: scalar loads
-	const long long *T = s_tab + threadIdx.x;              // field f of this lane's task at T[W f]
+	const long long *T = s_tab + threadIdx.x / LPT;        // field f of this lane's task at T[W f]
 	const int n_cols = P[0], n_blocks = P[1], n_ops = P[2];
 	const int f_blk = 4 * n_cols, f_op = f_blk + n_blocks, f_y = f_op + n_ops;
 	int pc = 4, blk0 = 0;
@@ -247,32 +263,48 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 			}
 			#pragma unroll
 			for(int r = 0; r < D; ++ r) {
-				w[cs_new + r] = yn[r];
+				if(n_half == 0)
+					w[cs_new + r] = yn[r];
 				#pragma unroll
 				for(int q = r + 1; q < D; ++ q)
 					a[r][q] = 0.0; // the factor block is stored whole, zeros above its diagonal
 			}
-			store_block<D>(L + l_base, a);
-			store_block<D>(Linv + linv_off, x);
+			if(n_half == 0) { // (the lanes of a pair hold the same numbers)
+				store_block<D>(L + l_base, a);
+				store_block<D>(Linv + linv_off, x);
+			}
 		}
 		SIMT_TICK(); // diagonal block
-		// sub-diagonal blocks: L(i,j) = (Lambda(i,j) - sum L(i,c) L(j,c)^T) inv(L_jj)^T
+		// sub-diagonal blocks: L(i,j) = (Lambda(i,j) - sum L(i,c) L(j,c)^T) inv(L_jj)^T; with two lanes per task each lane
+		// its DH rows of the block (inv(L_jj) is in its own registers: x above)
 		for(int kb = 1; kb < nb; ++ kb) {
 			const int np = P[pc ++];
 			const long long enc = T[W * (f_blk + blk0 + kb)];
-			double acc[D][D];
+			double acc[DH][D];
 			{
 				const double *src = A + ((enc < 0)? 0 : (enc >> 1));
 				const bool b_trans = (enc & 1) != 0, b_have = enc >= 0;
-				double v[D][D]; // v[c][r] = stored element (r, c)
-				#pragma unroll
-				for(int c = 0; c < D; ++ c)
-					load_column<D>(src + c * D, v[c]);
-				#pragma unroll
-				for(int r = 0; r < D; ++ r) {
+				if constexpr(LPT == 1) {
+					double v[D][D]; // v[c][r] = stored element (r, c)
 					#pragma unroll
-					for(int q = 0; q < D; ++ q)
-						acc[r][q] = b_have? (b_trans? v[r][q] : v[q][r]) : 0.0;
+					for(int c = 0; c < D; ++ c)
+						load_column<D>(src + c * D, v[c]);
+					#pragma unroll
+					for(int r = 0; r < DH; ++ r) {
+						#pragma unroll
+						for(int q = 0; q < D; ++ q)
+							acc[r][q] = b_have? (b_trans? v[r][q] : v[q][r]) : 0.0;
+					}
+				} else {
+					// element (r0 + i, q) of the block: stored at (r0 + i) + q D, or transposed at q + (r0 + i) D
+					#pragma unroll
+					for(int i = 0; i < DH; ++ i) {
+						#pragma unroll
+						for(int q = 0; q < D; ++ q) {
+							const double f = src[b_trans? q + (r0 + i) * D : (r0 + i) + q * D];
+							acc[i][q] = b_have? f : 0.0;
+						}
+					}
 				}
 			}
 			{
@@ -283,8 +315,18 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 				}
 				for(int e = 0; e < np; ++ e) {
 					pc += 2;
-					double ca[D][D], cb[D][D];
-					load_block<D>(L + off_a, ca);
+					double ca[D][DH], cb[D][D]; // ca[t][i] = L(i,c) element (r0 + i, t)
+					if constexpr(LPT == 1) {
+						double full[D][D];
+						load_block<D>(L + off_a, full);
+						#pragma unroll
+						for(int t = 0; t < D; ++ t) {
+							#pragma unroll
+							for(int i = 0; i < DH; ++ i)
+								ca[t][i] = full[t][i];
+						}
+					} else
+						load_half_rows<D>(L + off_a, r0, ca);
 					load_block<D>(L + off_b, cb);
 					if(e + 1 < np) {
 						off_a = T[W * (f_op + P[pc])];
@@ -293,28 +335,37 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 					#pragma unroll
 					for(int t = 0; t < D; ++ t) {
 						#pragma unroll
-						for(int r = 0; r < D; ++ r) {
+						for(int i = 0; i < DH; ++ i) {
 							#pragma unroll
 							for(int q = 0; q < D; ++ q)
-								acc[r][q] -= ca[t][r] * cb[t][q];
+								acc[i][q] -= ca[t][i] * cb[t][q];
 						}
 					}
 				}
 			}
-			double xi[D][D], out[D][D]; // xi[c][r] = element (r, c) of inv(L_jj), as this lane stored it above
-			load_block<D>(Linv + linv_off, xi);
+			// out = acc inv(L_jj)^T: out[i][q] = sum_{t <= q} acc[i][t] x[q][t] (x[r][c] = element (r, c) of the inverse)
+			double *p_out = L + l_base + kb * DD;
 			#pragma unroll
-			for(int r = 0; r < D; ++ r) {
+			for(int q = 0; q < D; ++ q) {
+				double out[DH];
 				#pragma unroll
-				for(int q = 0; q < D; ++ q) {
+				for(int i = 0; i < DH; ++ i) {
 					double sum = 0;
 					#pragma unroll
 					for(int t = 0; t <= q; ++ t)
-						sum += acc[r][t] * xi[t][q];
-					out[r][q] = sum;
+						sum += acc[i][t] * x[q][t];
+					out[i] = sum;
+				}
+				if(DH % 2 == 0 && D % 2 == 0) {
+					#pragma unroll
+					for(int i = 0; i < DH; i += 2)
+						*reinterpret_cast<double2*>(p_out + r0 + i + q * D) = double2{out[i], out[i + 1]};
+				} else {
+					#pragma unroll
+					for(int i = 0; i < DH; ++ i)
+						p_out[r0 + i + q * D] = out[i];
 				}
 			}
-			store_block<D>(L + l_base + kb * DD, out);
 			SIMT_TICK(); // one sub-diagonal block
 		}
 		blk0 += nb;
@@ -331,10 +382,17 @@ bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, int n_width, int
 	if(n_chunks <= 0)
 		return true;
 	const long long *t = reinterpret_cast<const long long*>(tab);
-#define SIMT_LAUNCH(D_, W_) hipLaunchKernelGGL((factor_simt_kernel<D_, W_>), dim3(n_chunks), dim3(64), n_lds_bytes, stream, chunks, prog, t, \
+#define SIMT_LAUNCH(D_, W_, LPT_) hipLaunchKernelGGL((factor_simt_kernel<D_, W_, LPT_>), dim3(n_chunks), dim3(64), n_lds_bytes, stream, chunks, prog, t, \
 	A, L, Linv, b, w, p_flag, p_timing)
-#define SIMT_WIDTHS(D_) do { if(n_width == 16) SIMT_LAUNCH(D_, 16); else if(n_width == 32) SIMT_LAUNCH(D_, 32); \
-	else SIMT_LAUNCH(D_, 64); } while(0)
+	// (two lanes per task where the block dimension is even and a wave holds at most 32 tasks)
+#define SIMT_WIDTHS(D_) do { if(n_width == 16) { if(b_pairs && D_ % 2 == 0) SIMT_LAUNCH(D_, 16, (D_ % 2 == 0)? 2 : 1); else SIMT_LAUNCH(D_, 16, 1); } \
+	else if(n_width == 32) { if(b_pairs && D_ % 2 == 0) SIMT_LAUNCH(D_, 32, (D_ % 2 == 0)? 2 : 1); else SIMT_LAUNCH(D_, 32, 1); } \
+	else SIMT_LAUNCH(D_, 64, 1); } while(0)
+	// Two lanes per task is a third more work per task (both lanes of a pair do the column's diagonal block) for half the
+	// dependent chain of the blocks below it: it pays while the launch leaves the chip's SIMDs short of waves (C3: 497
+	// waves on 1 024 SIMDs, 120 -> 100 us) and costs where they are full (a million poses: 716 -> 779 us).
+	static const int n_pairs_env = getenv("SLAMPP_HIP_SIMT_PAIRS")? atoi(getenv("SLAMPP_HIP_SIMT_PAIRS")) : -1; // development aid
+	const bool b_pairs = (n_pairs_env >= 0)? n_pairs_env != 0 : n_chunks <= 2048;
 	switch(n_dim) {
 	case 3:
 		SIMT_WIDTHS(3);
