@@ -103,7 +103,7 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 	const TUpdSlot *__restrict__ upd_slots, int n_upd_slots, const TUpdEnt *__restrict__ upd_ents, const double *__restrict__ A,
 	const double *__restrict__ b, double *L, double *Linv, double *w, int *p_flag, long long *p_timing)
 {
-	enum { DD = D * D, BATCH = PANEL_FRESH_BATCH, UPD_BATCH = PANEL_UPD_BATCH, N_UPD_GROUPS = W / PANEL_UPD_W };
+	enum { DD = D * D, BATCH = panel_fresh_batch(W), UPD_BATCH = PANEL_UPD_BATCH, N_UPD_GROUPS = W / PANEL_UPD_W };
 	extern __shared__ __attribute__((aligned(16))) double s_raw[];
 	const TPanelLds t_lds = panel_lds(D, b_fused, t_cfg);
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;

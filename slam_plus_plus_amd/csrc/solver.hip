@@ -735,7 +735,7 @@ void slampp_hip_solver::Analyze_Sparse()
 		std::vector<TPanelSlot> pslots;
 		panel_ride.assign(n_stages + 1, 0);
 		panel_cfg.assign(size_t(n_stages) + 1, TPanelLaunch{int32_t(PANEL_W), int32_t(64 * PANEL_W), 1, 1, 1, 0});
-		const int n_ride_max_fresh = getenv("SLAMPP_PANEL_RIDE_FRESH")? atoi(getenv("SLAMPP_PANEL_RIDE_FRESH")) : 64;
+		const int n_ride_max_fresh = getenv("SLAMPP_PANEL_RIDE_FRESH")? atoi(getenv("SLAMPP_PANEL_RIDE_FRESH")) : 96;
 		for(int s = 0; s < n_stages; ++ s) {
 			const bool b_panel_stage = s >= n_bottom_stages || (s == 0 && b_leaf_panels);
 			// Do this stage's updates from further down ride in the launch of the stage below?  Only if that is a panel launch,
@@ -749,25 +749,42 @@ void slampp_hip_solver::Analyze_Sparse()
 			// The first stage above a leaf stage that is not a panel launch: everything its tasks receive comes from that one
 			// stage, nothing from further down -- the tasks bring it in themselves and no update launch is needed (if it fits
 			// the packages: the tall tasks of a wide stage receive some fifty products each)
+			// ... Or do the tasks bring in everything themselves (mode 2: they read Lambda and all their updates, no update role
+			// has prepared their blocks)?  Where the launch below is no panel launch (the first stage above lane-per-task
+			// leaves: everything comes from that one stage), and where it is so crowded -- more workgroups than the chip holds at
+			// once -- that riders only make it longer (C3: 5 816 riders in the 2 420-task stage cost it 20 us; the 625 tasks
+			// above them take their ~150 products each in 6) -- if it fits the packages.
 			const bool b_first_above_leaves = b_panel_stage && s == 1 && panel_ptr[1] == panel_ptr[0];
+			// (measured at C3 and not kept as the default: without its 5 816 riders the 2 420-task launch takes the same 67 us --
+			// its own tasks fill the chip for that long --, and the stage above, bringing in ~150 products a task, 32 instead of 23)
+			const bool b_below_crowded = getenv("SLAMPP_PANEL_SELF_ABOVE_CROWDED") != 0 && b_panel_stage && s > 0 && panel_ptr[s] - panel_ptr[s - 1] > 1024;
 			if(b_panel_stage && s > 0 && (panel_ptr[s] > panel_ptr[s - 1] || b_first_above_leaves)) {
-				int64_t n_max_fresh = 0;
+				int64_t n_max_fresh = 0, n_max_external = 0;
 				for(int t = P.stage_ptr[s]; t < P.stage_ptr[s + 1]; ++ t) {
-					int64_t n_fresh = 0;
+					int64_t n_fresh = 0, n_external = 0;
 					for(int64_t i = P.task_ptr[t]; i < P.task_ptr[t + 1]; ++ i) {
 						const TColDesc &c = cols[i];
-						for(int64_t e = c.r0; e < c.r0 + c.nr; ++ e)
+						for(int64_t e = c.r0; e < c.r0 + c.nr; ++ e) {
 							n_fresh += col_stage[P.blk_col[P.rblk[e]]] == s - 1;
-						for(int64_t e = P.pptr[c.k0 + 1]; e < P.pptr[c.k0 + c.nb]; ++ e)
+							n_external += col_stage[P.blk_col[P.rblk[e]]] < s;
+						}
+						for(int64_t e = P.pptr[c.k0 + 1]; e < P.pptr[c.k0 + c.nb]; ++ e) {
 							n_fresh += col_stage[P.blk_col[P.pa[e]]] == s - 1;
+							n_external += col_stage[P.blk_col[P.pa[e]]] < s;
+						}
 					}
 					n_max_fresh = std::max(n_max_fresh, n_fresh);
+					n_max_external = std::max(n_max_external, n_external);
 				}
-				panel_ride[s] = n_max_fresh <= (b_first_above_leaves? 320 : n_ride_max_fresh);
-				panel_cfg[s].b_from_lambda = panel_ride[s] && b_first_above_leaves;
+				if((b_first_above_leaves || b_below_crowded) && n_max_external <= 320)
+					panel_ride[s] = 2;
+				else if(panel_ptr[s] > panel_ptr[s - 1])
+					panel_ride[s] = n_max_fresh <= n_ride_max_fresh;
+				panel_cfg[s].b_from_lambda = panel_ride[s] == 2;
 				if(b_timing)
-					fprintf(stderr, "[setup] stage %d: %d tasks, at most %lld updates from the stage below: %s\n", s,
-						P.stage_ptr[s + 1] - P.stage_ptr[s], (long long)n_max_fresh, panel_ride[s]? "ride" : "own launch");
+					fprintf(stderr, "[setup] stage %d: %d tasks, at most %lld updates from the stage below, %lld in all: %s\n", s,
+						P.stage_ptr[s + 1] - P.stage_ptr[s], (long long)n_max_fresh, (long long)n_max_external,
+						(panel_ride[s] == 2)? "the tasks bring them in" : panel_ride[s]? "ride" : "own launch");
 			}
 			int64_t n_stage_max_slots = 0, n_stage_max_units = 0, n_stage_rest = 0; // (for the development print below)
 			for(int t = P.stage_ptr[s]; b_panel_stage && t < P.stage_ptr[s + 1]; ++ t) {
@@ -807,19 +824,19 @@ void slampp_hip_solver::Analyze_Sparse()
 				};
 				// the updates from stages further down are applied inside the launch of the stage below, if that is a panel
 				// launch: then what the stage right below contributes ("fresh") is left to the task itself
-				const bool b_ride = panel_ride[s] != 0;
+				const bool b_ride = panel_ride[s] != 0, b_self = panel_ride[s] == 2;
 				int64_t n_fresh = 0;
 				for(int64_t i = c_begin; b_fits && i < c_end; ++ i) { // size of the package
 					const TColDesc &c = cols[i];
 					for(int64_t e = c.r0; e < c.r0 + c.nr; ++ e) {
 						const bool b_int = slot_of[P.rblk[e]] >= 0;
 						n_int_rows += b_int;
-						n_fresh += !b_int && b_ride && col_stage[P.blk_col[P.rblk[e]]] == s - 1;
+						n_fresh += !b_int && b_ride && (b_self || col_stage[P.blk_col[P.rblk[e]]] == s - 1);
 					}
 					for(int64_t e = P.pptr[c.k0 + 1]; e < P.pptr[c.k0 + c.nb]; ++ e) {
 						const bool b_int = slot_of[P.pa[e]] >= 0;
 						n_int_pairs += b_int;
-						n_fresh += !b_int && b_ride && col_stage[P.blk_col[P.pa[e]]] == s - 1;
+						n_fresh += !b_int && b_ride && (b_self || col_stage[P.blk_col[P.pa[e]]] == s - 1);
 					}
 				}
 				const size_t n_units = 4 + 3 * size_t(n_cols) + 2 * size_t(n_slots) + size_t(n_int_rows + 3) / 4 + size_t(n_int_pairs + 3) / 4 +
@@ -861,7 +878,7 @@ void slampp_hip_solver::Analyze_Sparse()
 						const int64_t k = P.rblk[e];
 						if(slot_of[k] >= 0)
 							irow.push_back(uint32_t(slot_of[k]) | (uint32_t(col_local[P.blk_col[k]]) << 16));
-						else if(b_ride && col_stage[P.blk_col[k]] == s - 1) {
+						else if(b_ride && (b_self || col_stage[P.blk_col[k]] == s - 1)) {
 							TPanelExt en;
 							memset(&en, 0, sizeof(en));
 							en.a_off = en.b_off = rents[e].off;
@@ -892,7 +909,7 @@ void slampp_hip_solver::Analyze_Sparse()
 								const int64_t ka = P.pa[e], kb = P.pb[e];
 								if(slot_of[ka] >= 0)
 									ipair.push_back(uint32_t(slot_of[ka]) | (uint32_t(slot_of[kb]) << 16));
-								else if(b_ride && col_stage[P.blk_col[ka]] == s - 1) {
+								else if(b_ride && (b_self || col_stage[P.blk_col[ka]] == s - 1)) {
 									TPanelExt en;
 									memset(&en, 0, sizeof(en));
 									en.a_off = P.loff[ka];
@@ -1229,7 +1246,7 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			if(!b_rode)
 				launch_panel_update(P.max_dim, d_panel_upd_slots.p() + panel_upd_ptr[s], panel_upd_ptr[s + 1] - panel_upd_ptr[s],
 					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream);
-			const int n_next = (s + 1 < n_stages && panel_ride[s + 1])? panel_upd_ptr[s + 2] - panel_upd_ptr[s + 1] : 0;
+			const int n_next = (s + 1 < n_stages && panel_ride[s + 1] == 1)? panel_upd_ptr[s + 2] - panel_upd_ptr[s + 1] : 0;
 			launch_factor_panel(P.max_dim, b_panel_fused, panel_cfg[s], d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s], n_panels,
 				d_panel_upd_slots.p() + ((n_next > 0)? panel_upd_ptr[s + 1] : 0), n_next, d_panel_upd_ents.p(), p_values_dev, p_rhs_dev,
 				d_L.p(), d_Linv.p(), d_w.p(), p_flag, stream, dplan.p_timing);

@@ -104,7 +104,10 @@ struct TPanelLaunch {
 	int32_t b_from_lambda; // the tasks read their blocks from Lambda (and b): no update role has prepared Lambda - sum in the factor's
 	                       // storage -- the first stage above a leaf stage, whose every update is a fresh one
 };
-enum { PANEL_FRESH_BATCH = 4, PANEL_UPD_BATCH = 8 };
+enum { PANEL_UPD_BATCH = 8 };
+// fresh products a wave has in flight: four at eight waves per task, eight at four (the same operand staging per workgroup;
+// the first slice stage above the leaves brings in ~100 products per task, each batch a trip to L2)
+inline __host__ __device__ constexpr int panel_fresh_batch(int n_waves) { return (n_waves == 4)? 8 : 4; }
 // LDS of a panel launch, in doubles: offsets of the panel role's regions (package, image, vectors, inverses of the
 // level's diagonal blocks, one tile per wave, operand staging of the fresh updates) and the total, which also covers
 // the update role's staging (riders: the next stage's updates from further down, PANEL_UPD_W waves per factor block)
@@ -120,8 +123,8 @@ inline __host__ __device__ TPanelLds panel_lds(int D, bool b_fused, const TPanel
 	l.LINV = l.VEC + c.n_cap_cols * 8;
 	l.TILE = l.LINV + c.n_cap_lvl * 64;
 	l.OPS = l.TILE + W * 64;
-	l.YV = l.OPS + (b_fused? W * 2 * PANEL_FRESH_BATCH * DD : 0);
-	const int n_panel_end = l.YV + (b_fused? W * PANEL_FRESH_BATCH * 8 : 0);
+	l.YV = l.OPS + (b_fused? W * 2 * panel_fresh_batch(W) * DD : 0);
+	const int n_panel_end = l.YV + (b_fused? W * panel_fresh_batch(W) * 8 : 0);
 	const int n_upd_end = b_fused? W * 2 * PANEL_UPD_BATCH * DD + W * PANEL_UPD_BATCH * 8 + W * 64 : 0;
 	l.TOTAL = (n_panel_end > n_upd_end)? n_panel_end : n_upd_end;
 	return l;
