@@ -270,10 +270,12 @@ def run_c3(args, rank, world, local_rank, dist):
     kb = per_kernel_bytes_sparse(solver.plan(), n_bottom)
     # the separator stages are one launch each -- the tasks as panels in LDS, next to them the updates the NEXT stage's blocks
     # receive from further down (one half-workgroup per factor block) -- plus one launch of those updates for the first of them
-    launches = {"factor_leaves": 1, "factor_wide": max(n_bottom - 1, 1), "factor_upper": max(n_stages - n_bottom, 1) + 1,
+    # (the first panel stage has an update launch of its own only when it sits above wide one-wave-per-column stages; right
+    # above the lane-per-task leaves its tasks bring in their updates themselves)
+    launches = {"factor_leaves": 1, "factor_wide": max(n_bottom - 1, 1), "factor_upper": max(n_stages - n_bottom, 1) + (1 if n_bottom > 1 else 0),
                 "forward": n_stages, "backward": n_stages}
     names = {"factor_leaves": "factor_simt_kernel", "factor_wide": "factor_stage_kernel<D, 1, 8, 32, 48>",
-             "factor_upper": "factor_panel_kernel (+ one panel_update_kernel launch)", "forward": "forward_stage_kernel",
+             "factor_upper": "factor_panel_kernel (slices of the elimination tree, one launch per stage)", "forward": "forward_stage_kernel",
              "backward": "backward_stage_kernel"}
     needles = {"factor_leaves": "factor_simt_kernel", "factor_wide": ", 1, 8, 32, 48>", "factor_upper": "factor_panel_kernel",
                "forward": "forward_stage_kernel", "backward": "backward_stage_kernel"}   # as rocprofv3 spells the kernels
@@ -496,6 +498,17 @@ def run_small_configs(args, local_rank):
                 lam.save(path)
                 r = O.reference_solve(path, "cholmod_auto", "-", reps=5)
             rec["reference_cholmod_ms"] = float(np.median(r["times_ms"]))
+            # ... and the reference's fastest solver with its analysis cached (CLinearSolver_UberBlock::Solve_PosDef_Blocky,
+            # calls after the first): the like-for-like of the GPU's warm step
+            try:
+                with tempfile.TemporaryDirectory() as td:
+                    path = os.path.join(td, "p.bin")
+                    lam.save(path)
+                    ub = O.reference_solve(path, "uberblock", "-", reps=5)
+                rec["reference_native_block_solver_ms"] = {"first_call": float(ub["times_ms"][0]), "warm": float(min(ub["times_ms"][1:]))}
+                rec["speedup_vs_reference_native_warm"] = float(min(ub["times_ms"][1:])) / ms
+            except Exception as e:
+                rec["reference_native_error"] = str(e)[:200]
         out[key] = rec
     return out
 
