@@ -43,8 +43,9 @@ struct CTileSchedule {
 	int n_tiles;                       // tiles per dimension
 	int n_levels;
 	std::vector<int> level_potrf_ptr, level_trsm_ptr, level_tgt_ptr; // [n_levels + 1] each
+	std::vector<int> level_urgent_end; // [n_levels] the level's targets up to here are the next level's diagonal tiles (an update launch of their own); the rest rides in the next level's first launch
 	int *d_potrf;                      // tile columns, level by level
-	int2 *d_trsm;                      // (row tile, column tile)
+	int4 *d_trsm;                      // (row tile, column tile, 1 = the workgroup also updates the diagonal tile of its row, -)
 	int4 *d_tgt;                       // (row tile, column tile, first source, one past the last source)
 	int *d_src;                        // source tile columns of the targets
 	CTileSchedule() :n_tiles(0), n_levels(0), d_potrf(0), d_trsm(0), d_tgt(0), d_src(0) {}

@@ -25,42 +25,9 @@ void dense_prepare_gaps(double *M, int n_pad, const int32_t *p_positions_dev, in
 }
 
 // ---- tile-sparse, level-scheduled variant (see dense_chol.h) ----
-__global__ void __launch_bounds__(256)
-tile_potrf_kernel(double *M, int ld, int n, double *p_invdiag, int *p_flag, const int *__restrict__ p_tiles)
-{
-	__shared__ double s_buf[POTRF_LDS_DOUBLES];
-	const int kb = p_tiles[blockIdx.x];
-	potrf_diag_body<true, true>(M, ld, kb, n, p_invdiag + size_t(kb) * NB * NB, p_flag, s_buf);
-}
-
-__global__ void __launch_bounds__(256)
-tile_trsm_kernel(double *M, int ld, const double *p_invdiag, const int2 *__restrict__ p_pairs)
-{
-	__shared__ double Ps[NB * NB];
-	__shared__ double Qs[NB * NB];
-	const int2 t_pair = p_pairs[blockIdx.x];
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int row0 = t_pair.x * NB, col0 = t_pair.y * NB;
-	load_tile(Ps, M, ld, row0, col0);
-	load_tile(Qs, p_invdiag + size_t(t_pair.y) * NB * NB, NB, 0, 0);
-	__syncthreads();
-	v4f64 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-	tile_product(Ps, Qs, wave, lane, acc);
-	const int lo = lane & 15, hi = lane >> 4;
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			M[size_t(row0 + 16 * c + lo) + size_t(col0 + 16 * wave + hi + 4 * reg) * ld] = acc[c][reg];
-}
-
 // target tile (ti, tj) -= sum over its source tile columns kt of L(ti, kt) L(tj, kt)^T
-__global__ void __launch_bounds__(256)
-tile_update_kernel(double *M, int ld, const int4 *__restrict__ p_targets, const int *__restrict__ p_sources)
+__device__ __forceinline__ void tile_update_body(double *M, int ld, const int4 t_tgt, const int *__restrict__ p_sources, double *Ps, double *Qs)
 {
-	__shared__ double Ps[NB * NB];
-	__shared__ double Qs[NB * NB];
-	const int4 t_tgt = p_targets[blockIdx.x];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int row0 = t_tgt.x * NB, colq = t_tgt.y * NB;
 	const int lo = lane & 15, hi = lane >> 4;
@@ -95,6 +62,79 @@ tile_update_kernel(double *M, int ld, const int4 *__restrict__ p_targets, const 
 			M[size_t(row0 + 16 * c + lo) + size_t(colq + 16 * wave + hi + 4 * reg) * ld] = cv[c][reg] - acc[c][reg];
 }
 
+// the diagonal tiles of a level; behind them ride the updates of the level before that nothing in this level waits for
+// (everything but the diagonal tiles of this level's columns): the launch every level has to wait for keeps one CU
+// busy per tile, the riders give the rest of the chip its share of the level's work
+__global__ void __launch_bounds__(256)
+tile_potrf_kernel(double *M, int ld, int n, double *p_invdiag, int *p_flag, const int *__restrict__ p_tiles, int n_potrf,
+	const int4 *__restrict__ p_riders, const int *__restrict__ p_sources)
+{
+	__shared__ double s_buf[(int(POTRF_LDS_DOUBLES) > 2 * NB * NB)? int(POTRF_LDS_DOUBLES) : 2 * NB * NB];
+	if(int(blockIdx.x) >= n_potrf) {
+		tile_update_body(M, ld, p_riders[int(blockIdx.x) - n_potrf], p_sources, s_buf, s_buf + NB * NB);
+		return;
+	}
+	const int kb = p_tiles[blockIdx.x];
+	potrf_diag_body<true, true>(M, ld, kb, n, p_invdiag + size_t(kb) * NB * NB, p_flag, s_buf);
+}
+
+// L(i,j) = A(i,j) inv(L_jj)^T; with t_pair.z set the workgroup also applies its tile to the diagonal tile of its row,
+// A(i,i) -= L(i,j) L(i,j)^T -- the one update the next level's diagonal tile is waiting for, where this tile is its
+// only source in this level (a chain of tile columns: the top of every separator tree)
+__global__ void __launch_bounds__(256)
+tile_trsm_kernel(double *M, int ld, const double *p_invdiag, const int4 *__restrict__ p_pairs)
+{
+	__shared__ double Ps[NB * NB];
+	__shared__ double Qs[NB * NB];
+	const int4 t_pair = p_pairs[blockIdx.x];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int row0 = t_pair.x * NB, col0 = t_pair.y * NB;
+	load_tile(Ps, M, ld, row0, col0);
+	load_tile(Qs, p_invdiag + size_t(t_pair.y) * NB * NB, NB, 0, 0);
+	const int lo = lane & 15, hi = lane >> 4;
+	const bool b_diag = t_pair.z != 0; // workgroup-uniform
+	double cv[4][4];
+	if(b_diag) { // the diagonal tile is requested now, its latency hides behind the two products
+		#pragma unroll
+		for(int c = 0; c < 4; ++ c)
+			#pragma unroll
+			for(int reg = 0; reg < 4; ++ reg)
+				cv[c][reg] = M[size_t(row0 + 16 * c + lo) + size_t(row0 + 16 * wave + hi + 4 * reg) * ld];
+	}
+	__syncthreads();
+	v4f64 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+	tile_product(Ps, Qs, wave, lane, acc);
+	#pragma unroll
+	for(int c = 0; c < 4; ++ c)
+		#pragma unroll
+		for(int reg = 0; reg < 4; ++ reg)
+			M[size_t(row0 + 16 * c + lo) + size_t(col0 + 16 * wave + hi + 4 * reg) * ld] = acc[c][reg];
+	if(!b_diag)
+		return;
+	__syncthreads(); // every wave is done with Ps
+	#pragma unroll
+	for(int c = 0; c < 4; ++ c)
+		#pragma unroll
+		for(int reg = 0; reg < 4; ++ reg)
+			Ps[lds_at(16 * wave + hi + 4 * reg, 16 * c + lo)] = acc[c][reg]; // L(i,j) as an operand: [k = column][row]
+	__syncthreads();
+	v4f64 upd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+	tile_product(Ps, Ps, wave, lane, upd);
+	#pragma unroll
+	for(int c = 0; c < 4; ++ c)
+		#pragma unroll
+		for(int reg = 0; reg < 4; ++ reg)
+			M[size_t(row0 + 16 * c + lo) + size_t(row0 + 16 * wave + hi + 4 * reg) * ld] = cv[c][reg] - upd[c][reg];
+}
+
+__global__ void __launch_bounds__(256)
+tile_update_kernel(double *M, int ld, const int4 *__restrict__ p_targets, const int *__restrict__ p_sources)
+{
+	__shared__ double Ps[NB * NB];
+	__shared__ double Qs[NB * NB];
+	tile_update_body(M, ld, p_targets[blockIdx.x], p_sources, Ps, Qs);
+}
+
 void CTileSchedule::Free()
 {
 	if(d_potrf) (void)hipFree(d_potrf);
@@ -125,23 +165,25 @@ bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hi
 	n_tiles = T;
 	n_levels = n_max_height + 1;
 	std::vector<int> potrf;
-	std::vector<int2> trsm;
-	std::vector<int4> tgt;
+	std::vector<int4> trsm; // (row tile, column tile, also updates the diagonal tile of its row, -)
+	std::vector<int4> tgt;  // per level: first the urgent targets (diagonal tiles of the next level's columns), then the others
 	std::vector<int> src;
 	level_potrf_ptr.assign(1, 0);
 	level_trsm_ptr.assign(1, 0);
 	level_tgt_ptr.assign(1, 0);
-	std::vector<int> tgt_of(size_t(T) * T, -1); // per level: index of the target record of a tile
+	level_urgent_end.clear();
+	std::vector<int> tgt_of(size_t(T) * T, -1); // per level: index (in `found`) of the target record of a tile
 	for(int l = 0; l < n_levels; ++ l) {
-		const size_t n_tgt0 = tgt.size();
-		std::vector<std::vector<int> > sources; // per target of this level
+		std::vector<int2> found;                 // targets of this level
+		std::vector<std::vector<int> > sources;  // per target
+		const size_t n_trsm0 = trsm.size();
 		for(int j = 0; j < T; ++ j) {
 			if(height[j] != l)
 				continue;
 			potrf.push_back(j);
 			for(int i = j + 1; i < T; ++ i) {
 				if(nz[size_t(i) + size_t(j) * T])
-					trsm.push_back(int2{i, j});
+					trsm.push_back(int4{i, j, 0, 0});
 			}
 			for(int i2 = j + 1; i2 < T; ++ i2) {
 				if(!nz[size_t(i2) + size_t(j) * T])
@@ -150,25 +192,52 @@ bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hi
 					if(!nz[size_t(i1) + size_t(j) * T])
 						continue;
 					int &r_idx = tgt_of[size_t(i1) + size_t(i2) * T];
-					if(r_idx < int(n_tgt0)) { // not seen in this level yet (stale indices of earlier levels are smaller)
-						r_idx = int(n_tgt0 + sources.size());
-						tgt.push_back(int4{i1, i2, 0, 0});
+					if(r_idx < 0) {
+						r_idx = int(found.size());
+						found.push_back(int2{i1, i2});
 						sources.push_back(std::vector<int>());
 					}
-					sources[r_idx - n_tgt0].push_back(j);
+					sources[r_idx].push_back(j);
 				}
 			}
 		}
-		for(size_t k = 0; k < sources.size(); ++ k) {
-			tgt[n_tgt0 + k].z = int(src.size());
-			src.insert(src.end(), sources[k].begin(), sources[k].end());
-			tgt[n_tgt0 + k].w = int(src.size());
+		// what the next level's diagonal tiles wait for: with a single source, the panel solve of that source does it
+		// on its way; with several, an update launch of its own; everything else rides in the next level's first launch
+		std::vector<int> urgent, deferred;
+		for(size_t k = 0; k < found.size(); ++ k) {
+			const int i1 = found[k].x, i2 = found[k].y;
+			tgt_of[size_t(i1) + size_t(i2) * T] = -1; // (for the next level)
+			const bool b_next_diag = i1 == i2 && height[i1] == l + 1;
+			if(b_next_diag && sources[k].size() == 1) {
+				bool b_found = false;
+				for(size_t p = n_trsm0; p < trsm.size() && !b_found; ++ p) {
+					if(trsm[p].x == i1 && trsm[p].y == sources[k][0]) {
+						trsm[p].z = 1;
+						b_found = true;
+					}
+				}
+				if(!b_found)
+					return false; // (cannot happen: the source tile is a panel tile of this level)
+			} else
+				(b_next_diag? urgent : deferred).push_back(int(k));
+		}
+		for(int n_pass = 0; n_pass < 2; ++ n_pass) {
+			const std::vector<int> &r_list = n_pass? deferred : urgent;
+			for(size_t q = 0; q < r_list.size(); ++ q) {
+				const int k = r_list[q];
+				int4 t = {found[k].x, found[k].y, int(src.size()), 0};
+				src.insert(src.end(), sources[k].begin(), sources[k].end());
+				t.w = int(src.size());
+				tgt.push_back(t);
+			}
+			if(!n_pass)
+				level_urgent_end.push_back(int(tgt.size()));
 		}
 		level_potrf_ptr.push_back(int(potrf.size()));
 		level_trsm_ptr.push_back(int(trsm.size()));
 		level_tgt_ptr.push_back(int(tgt.size()));
 	}
-	const size_t n_b0 = potrf.size() * sizeof(int), n_b1 = (trsm.size() + 1) * sizeof(int2),
+	const size_t n_b0 = potrf.size() * sizeof(int), n_b1 = (trsm.size() + 1) * sizeof(int4),
 		n_b2 = (tgt.size() + 1) * sizeof(int4), n_b3 = (src.size() + 1) * sizeof(int);
 	if(hipMalloc((void**)&d_potrf, n_b0) != hipSuccess || hipMalloc((void**)&d_trsm, n_b1) != hipSuccess ||
 	   hipMalloc((void**)&d_tgt, n_b2) != hipSuccess || hipMalloc((void**)&d_src, n_b3) != hipSuccess) {
@@ -178,7 +247,7 @@ bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hi
 	}
 	bool b_ok = hipMemcpyAsync(d_potrf, potrf.data(), n_b0, hipMemcpyHostToDevice, stream) == hipSuccess;
 	if(!trsm.empty())
-		b_ok = b_ok && hipMemcpyAsync(d_trsm, trsm.data(), trsm.size() * sizeof(int2), hipMemcpyHostToDevice, stream) == hipSuccess;
+		b_ok = b_ok && hipMemcpyAsync(d_trsm, trsm.data(), trsm.size() * sizeof(int4), hipMemcpyHostToDevice, stream) == hipSuccess;
 	if(!tgt.empty())
 		b_ok = b_ok && hipMemcpyAsync(d_tgt, tgt.data(), tgt.size() * sizeof(int4), hipMemcpyHostToDevice, stream) == hipSuccess;
 	if(!src.empty())
@@ -197,17 +266,24 @@ bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hi
 
 void tile_cholesky(const CTileSchedule &r_s, double *M, int n_pad, int n, double *p_invdiag, int *p_flag, hipStream_t stream)
 {
+	int r0 = 0, r1 = 0; // the targets that ride in this level's first launch: the previous level's, but its urgent ones
 	for(int l = 0; l < r_s.n_levels; ++ l) {
 		const int p0 = r_s.level_potrf_ptr[l], p1 = r_s.level_potrf_ptr[l + 1];
 		const int t0 = r_s.level_trsm_ptr[l], t1 = r_s.level_trsm_ptr[l + 1];
-		const int g0 = r_s.level_tgt_ptr[l], g1 = r_s.level_tgt_ptr[l + 1];
-		if(p1 > p0)
-			hipLaunchKernelGGL(tile_potrf_kernel, dim3(p1 - p0), dim3(256), 0, stream, M, n_pad, n, p_invdiag, p_flag, r_s.d_potrf + p0);
+		const int g0 = r_s.level_tgt_ptr[l], gu = r_s.level_urgent_end[l], g1 = r_s.level_tgt_ptr[l + 1];
+		if(p1 > p0 || r1 > r0) {
+			hipLaunchKernelGGL(tile_potrf_kernel, dim3((p1 - p0) + (r1 - r0)), dim3(256), 0, stream, M, n_pad, n, p_invdiag, p_flag,
+				r_s.d_potrf + p0, p1 - p0, r_s.d_tgt + r0, r_s.d_src);
+		}
 		if(t1 > t0)
 			hipLaunchKernelGGL(tile_trsm_kernel, dim3(t1 - t0), dim3(256), 0, stream, M, n_pad, p_invdiag, r_s.d_trsm + t0);
-		if(g1 > g0)
-			hipLaunchKernelGGL(tile_update_kernel, dim3(g1 - g0), dim3(256), 0, stream, M, n_pad, r_s.d_tgt + g0, r_s.d_src);
+		if(gu > g0)
+			hipLaunchKernelGGL(tile_update_kernel, dim3(gu - g0), dim3(256), 0, stream, M, n_pad, r_s.d_tgt + g0, r_s.d_src);
+		r0 = gu;
+		r1 = g1;
 	}
+	if(r1 > r0) // (the last level's own: nothing follows it to ride in)
+		hipLaunchKernelGGL(tile_update_kernel, dim3(r1 - r0), dim3(256), 0, stream, M, n_pad, r_s.d_tgt + r0, r_s.d_src);
 }
 
 } // namespace slampp
