@@ -78,6 +78,78 @@ __device__ __forceinline__ double dense_read_lane(double v, int n_lane)
 	return __hiloint2double(hi, lo);
 }
 
+// DPP row broadcast of a double: every lane gets the value of lane N of its own row of 16 lanes (gfx90a+ row_newbcast,
+// the one DPP control the 64-bit ALU takes).  The fused form, acc += bcast_N(src) * mul in one v_fmac_f64_dpp, is not
+// something the compiler forms by itself (it keeps a v_mov_b64_dpp + v_fmac_f64), hence the inline assembly; the hazard
+// recogniser does not look inside inline assembly, so the two wait states a DPP read needs after a VALU write of the same
+// register are the caller's to provide: b_guard puts an s_nop 1 in front (callers set it where src may be fresh).
+template <int N>
+__device__ __forceinline__ double dpp_row_bcast(double v)
+{
+	double r;
+	asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(N));
+	return r;
+}
+template <int N, bool b_guard>
+__device__ __forceinline__ void dpp_fmac_row_bcast(double &r_acc, double src, double mul)
+{
+	if constexpr(b_guard)
+		asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(r_acc) : "v"(src), "v"(mul), "n"(N));
+	else
+		asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(r_acc) : "v"(src), "v"(mul), "n"(N));
+}
+
+// One column step of the 64 x 16 panel of a diagonal tile, and the ones after it (K = 0 .. 15, unrolled by recursion: the
+// broadcast lanes are immediates).  a[] is the lane's own row of the panel (lane = row of the tile), d[] the row
+// (lane & 15) of the panel's 16 x 16 diagonal block, which every row of 16 lanes keeps a copy of and updates along: that
+// is what lets the multipliers a(c,k), c > k, come by DPP from lane c of the lane's own row instead of through scalar
+// registers (two v_readlane_b32 and an FMA per trailing column on a wave that issues an instruction every ~5 cycles was
+// the cost of a step; now it is two v_fmac_f64_dpp, one for a[], one for the copy).  The update is the L D L^T form,
+// a(r,c) -= a(r,k) a(c,k) / d_k; the pivots go to r_mine (lane & 15 == k keeps d_k) for the scaling after the panel.
+template <int K, int C>
+__device__ __forceinline__ void potrf_panel_update(double (&a)[16], double (&d)[16], double ntd, double nta)
+{
+	if constexpr(C < 16) {
+		dpp_fmac_row_bcast<C, C == K + 1>(d[C], d[K], ntd);
+		dpp_fmac_row_bcast<C, false>(a[C], d[K], nta);
+		potrf_panel_update<K, C + 1>(a, d, ntd, nta);
+	}
+}
+template <int K>
+__device__ __forceinline__ void potrf_panel_steps(double (&a)[16], double (&d)[16], double &r_mine, bool &r_b_bad, int g, int n_valid)
+{
+	double piv = dpp_row_bcast<K>(d[K]);
+	const bool b_neg = !(piv > 0);
+	r_b_bad = r_b_bad || (b_neg && K < n_valid); // (n_valid: columns of the panel inside the matrix; past it rides the right-hand side row)
+	piv = b_neg? 1.0 : piv;
+	r_mine = (g == K)? piv : r_mine;
+	double rw = __builtin_amdgcn_rcp(piv); // 1 / d_k
+	rw = __builtin_fma(__builtin_fma(-piv, rw, 1.0), rw, rw);
+	rw = __builtin_fma(__builtin_fma(-piv, rw, 1.0), rw, rw);
+	const double ntd = -(d[K] * rw), nta = -(a[K] * rw);
+	potrf_panel_update<K, K + 1>(a, d, ntd, nta);
+	if constexpr(K < 15)
+		potrf_panel_steps<K + 1>(a, d, r_mine, r_b_bad, g, n_valid);
+}
+template <int K>
+__device__ __forceinline__ void potrf_panel_scale(double (&a)[16], double rs)
+{
+	a[K] *= dpp_row_bcast<K>(rs); // L(r, c0 + k) = a(r,k) / sqrt(d_k)
+	if constexpr(K < 15)
+		potrf_panel_scale<K + 1>(a, rs);
+}
+
+#ifdef POTRF_STAMPS
+__device__ long long g_potrf_stamps[32];
+#endif
+// (the lane number in a scalar register: wave-uniform, not a compile-time constant)
+__device__ __forceinline__ double dense_read_lane_var(double v, int n_lane)
+{
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), n_lane);
+	const int hi = __builtin_amdgcn_readlane(__double2hiint(v), n_lane);
+	return __hiloint2double(hi, lo);
+}
+
 enum { PL = NB + 1, TL = NB / 2 + 1 };
 
 // D[m][n] += sum_{k < K} A[m][k] B[k][n] for one 16 x 16 tile; A[m][k] = p_A[m * a_m + k * a_k], B[k][n] =
@@ -156,50 +228,48 @@ __device__ __forceinline__ void potrf_diag_body(double *M, int ld, int kb, int n
 		s_rd[t] = 1.0 / M[size_t(o + t) + size_t(o + t) * ld];
 	__syncthreads();
 	bool b_bad = false;
+#ifdef POTRF_STAMPS // tools/bench_potrf.hip: where the time of a tile goes (wave 0, lane 0)
+#define POTRF_STAMP(i) do { if(t == 0) { g_potrf_stamps[2 * (i)] = clock64(); g_potrf_stamps[2 * (i) + 1] = wall_clock64(); } } while(0)
+#else
+#define POTRF_STAMP(i) do {} while(0)
+#endif
+	POTRF_STAMP(0);
 	if(b_chol) {
 		for(int J = 0; J < NB / 16; ++ J) {
 			const int c0 = 16 * J;
 			if(wave == 0) {
-				const int r = lane;
-				double a[16];
+				// (the sixteen column steps are one dependent chain -- pivot, reciprocal, update of the next column, next
+				// pivot -- and one wave walks it: see potrf_panel_steps for what a step costs and why it is laid out so.
+				// A pivot that is not positive raises the flag if it is inside the matrix and is taken as 1 either way)
+				const int r = lane, g = lane & 15;
+				double a[16], d[16];
 				#pragma unroll
-				for(int c = 0; c < 16; ++ c)
+				for(int c = 0; c < 16; ++ c) {
 					a[c] = s_L[(c0 + c) * PL + r];
-				// The sixteen column steps are one dependent chain (pivot -> scaling -> update of the next column -> next
-				// pivot), so it is kept short: the trailing columns are updated in the L D L^T form, a(r,c) -= a(r,k) a(c,k) / d_k,
-				// which needs the reciprocal of the pivot only (v_rcp + two Newton steps, five dependent operations) and
-				// the column k as it stands (its v_readlane broadcasts do not wait for anything); the reciprocal square root
-				// that turns column k into L(:,k) = a(:,k) / sqrt(d_k) is computed beside the chain, not on it
-				#pragma unroll
-				for(int k = 0; k < 16; ++ k) {
-					double piv = dense_read_lane(a[k], c0 + k);
-					const bool b_neg = !(piv > 0);
-					b_bad = b_bad || (b_neg && o + c0 + k < n);
-					piv = b_neg? 1.0 : piv;
-					double rw = __builtin_amdgcn_rcp(piv); // 1 / d_k
-					rw = __builtin_fma(__builtin_fma(-piv, rw, 1.0), rw, rw);
-					rw = __builtin_fma(__builtin_fma(-piv, rw, 1.0), rw, rw);
-					const double tk = a[k] * rw; // a(r,k) / d_k
-					#pragma unroll
-					for(int c = k + 1; c < 16; ++ c)
-						a[c] -= tk * dense_read_lane(a[k], c0 + c);
-					double rs = __builtin_amdgcn_rsq(piv);
-					const double h = 0.5 * piv;
-					rs = rs * (1.5 - h * rs * rs);
-					rs = rs * (1.5 - h * rs * rs);
-					a[k] *= rs; // L(r, c0 + k), meaningful for r >= c0 + k
-					if(r == c0 + k)
-						s_rd[c0 + k] = rs;
+					d[c] = s_L[(c0 + c) * PL + c0 + g];
 				}
+				double mine = 1.0;
+				potrf_panel_steps<0>(a, d, mine, b_bad, g, n - o - c0);
+				// the reciprocal square roots of the sixteen pivots, one per lane of a row, beside the chain rather than on it
+				double rs = __builtin_amdgcn_rsq(mine);
+				const double h = 0.5 * mine;
+				rs = rs * (1.5 - h * rs * rs);
+				rs = rs * (1.5 - h * rs * rs);
+				potrf_panel_scale<0>(a, rs);
+				if(lane < 16)
+					s_rd[c0 + lane] = rs;
 				#pragma unroll
 				for(int c = 0; c < 16; ++ c)
 					s_L[(c0 + c) * PL + r] = (r >= c0 + c)? a[c] : 0.0;
 			}
+			POTRF_STAMP(1 + 3 * J);
 			__syncthreads();
+			POTRF_STAMP(2 + 3 * J);
 			// the next panel's columns first: tiles (ti, J + 1), ti = J + 1 .. 3, one per wave
 			if(J + 1 + wave < NB / 16)
 				potrf_update_tile(s_L, c0, J + 1 + wave, J + 1, lane);
 			__syncthreads();
+			POTRF_STAMP(3 + 3 * J);
 			// columns further right and the inverse of this diagonal block: waves 1-3, next to wave 0's next panel
 			if(wave > 0) {
 				int n_idx = 0;
@@ -214,6 +284,7 @@ __device__ __forceinline__ void potrf_diag_body(double *M, int ld, int kb, int n
 			}
 		}
 		__syncthreads();
+		POTRF_STAMP(13);
 	} else if(b_inverse) {
 		if(wave < NB / 16)
 			potrf_invert_block16(s_L, s_rd, s_X, 16 * wave, lane);
@@ -227,6 +298,7 @@ __device__ __forceinline__ void potrf_diag_body(double *M, int ld, int kb, int n
 		if(c <= r)
 			M[size_t(o + r) + size_t(o + c) * ld] = s_L[c * PL + r];
 	}
+	POTRF_STAMP(14);
 	if(!b_inverse)
 		return;
 	const int lo = lane & 15, hi = lane >> 4;

@@ -1763,6 +1763,8 @@ int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix
 				if(!s.n_schur_fallback_option)
 					throw;
 				(void)hipSetDevice(s.n_device);
+				if(t_staging_thread.t.joinable())
+					t_staging_thread.t.join(); // (it allocates the device arrays Free_Device() is about to free)
 				s.Free_Device();
 				s.b_group_active = false;
 				s.b_schur_fallback = true;

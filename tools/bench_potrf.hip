@@ -29,6 +29,32 @@ int main()
 			float ms; hipEventElapsedTime(&ms, e0, e1); if(ms < best) best = ms;
 		}
 		printf("variant chol=%d inv=%d: %.2f us\n", variant < 2, variant % 2 == 0, best * 1e3);
+#ifdef POTRF_STAMPS
+		if(variant < 2) {
+			long long st[32];
+			hipMemcpyFromSymbol(st, HIP_SYMBOL(slampp::g_potrf_stamps), sizeof(st));
+			for(int i = 1; i < 15; ++ i)
+				printf("  stamp %2d: +%6lld cycles, +%6lld ns\n", i, st[2 * i] - st[2 * (i - 1)], (st[2 * i + 1] - st[2 * (i - 1) + 1]) * 10);
+		}
+#endif
+		if(variant == 0) { // against a host Cholesky, and inv * L = I
+			std::vector<double> L(n * n), X(n * n), R = h;
+			hipMemcpy(L.data(), M, sizeof(double) * n * n, hipMemcpyDeviceToHost);
+			hipMemcpy(X.data(), inv, sizeof(double) * n * n, hipMemcpyDeviceToHost);
+			for(int k = 0; k < n; ++ k) {
+				R[k + k * ld] = sqrt(R[k + k * ld]);
+				for(int i = k + 1; i < n; ++ i) R[i + k * ld] /= R[k + k * ld];
+				for(int j = k + 1; j < n; ++ j) for(int i = j; i < n; ++ i) R[i + j * ld] -= R[i + k * ld] * R[j + k * ld];
+			}
+			double e_L = 0, e_X = 0;
+			for(int j = 0; j < n; ++ j) for(int i = j; i < n; ++ i) e_L = fmax(e_L, fabs(L[i + j * ld] - R[i + j * ld]));
+			for(int i = 0; i < n; ++ i) for(int j = 0; j <= i; ++ j) {
+				double f = 0;
+				for(int k = j; k <= i; ++ k) f += X[i + k * ld] * R[k + j * ld];
+				e_X = fmax(e_X, fabs(f - (i == j)));
+			}
+			printf("  max |L - L_host| = %g, max |X L - I| = %g\n", e_L, e_X);
+		}
 	}
 	return 0;
 }
