@@ -110,26 +110,38 @@ template <int K, int C>
 __device__ __forceinline__ void potrf_panel_update(double (&a)[16], double (&d)[16], double ntd, double nta)
 {
 	if constexpr(C < 16) {
-		dpp_fmac_row_bcast<C, C == K + 1>(d[C], d[K], ntd);
+		dpp_fmac_row_bcast<C, false>(d[C], d[K], ntd);
 		dpp_fmac_row_bcast<C, false>(a[C], d[K], nta);
 		potrf_panel_update<K, C + 1>(a, d, ntd, nta);
 	}
 }
+// 1 / max(d_k, tiny) for the pivot in lane K of every row of 16 lanes; the raw pivot goes to r_mine in that lane.  No
+// compare-and-select here: a VALU compare into scalar registers and a select from them cost ~70 cycles on this chain
+// (tools/bench_potrf.hip), the v_max_f64 costs 8.  A pivot that is not positive (a matrix that is not positive definite;
+// or the right-hand side row, whose "pivot" is 1 - y^T y) thus becomes 1e-300 instead of the 1 it used to become:
+// finite garbage in a row nobody reads either way, and the flag is raised from r_mine after the panel.
 template <int K>
-__device__ __forceinline__ void potrf_panel_steps(double (&a)[16], double (&d)[16], double &r_mine, bool &r_b_bad, int g, int n_valid)
+__device__ __forceinline__ double potrf_panel_pivot(const double (&d)[16], double &r_mine, int g)
 {
-	double piv = dpp_row_bcast<K>(d[K]);
-	const bool b_neg = !(piv > 0);
-	r_b_bad = r_b_bad || (b_neg && K < n_valid); // (n_valid: columns of the panel inside the matrix; past it rides the right-hand side row)
-	piv = b_neg? 1.0 : piv;
-	r_mine = (g == K)? piv : r_mine;
-	double rw = __builtin_amdgcn_rcp(piv); // 1 / d_k
+	const double piv_raw = dpp_row_bcast<K>(d[K]);
+	r_mine = (g == K)? piv_raw : r_mine;
+	const double piv = __builtin_fmax(piv_raw, 1e-300);
+	double rw = __builtin_amdgcn_rcp(piv);
 	rw = __builtin_fma(__builtin_fma(-piv, rw, 1.0), rw, rw);
 	rw = __builtin_fma(__builtin_fma(-piv, rw, 1.0), rw, rw);
+	return rw;
+}
+template <int K>
+__device__ __forceinline__ void potrf_panel_steps(double (&a)[16], double (&d)[16], double rw, double &r_mine, int g)
+{
 	const double ntd = -(d[K] * rw), nta = -(a[K] * rw);
-	potrf_panel_update<K, K + 1>(a, d, ntd, nta);
-	if constexpr(K < 15)
-		potrf_panel_steps<K + 1>(a, d, r_mine, r_b_bad, g, n_valid);
+	if constexpr(K < 15) {
+		dpp_fmac_row_bcast<K + 1, true>(d[K + 1], d[K], ntd);
+		const double rw_next = potrf_panel_pivot<K + 1>(d, r_mine, g); // the chain goes on from the next column; the others follow beside it
+		dpp_fmac_row_bcast<K + 1, false>(a[K + 1], d[K], nta);
+		potrf_panel_update<K, K + 2>(a, d, ntd, nta);
+		potrf_panel_steps<K + 1>(a, d, rw_next, r_mine, g);
+	}
 }
 template <int K>
 __device__ __forceinline__ void potrf_panel_scale(double (&a)[16], double rs)
@@ -240,7 +252,7 @@ __device__ __forceinline__ void potrf_diag_body(double *M, int ld, int kb, int n
 			if(wave == 0) {
 				// (the sixteen column steps are one dependent chain -- pivot, reciprocal, update of the next column, next
 				// pivot -- and one wave walks it: see potrf_panel_steps for what a step costs and why it is laid out so.
-				// A pivot that is not positive raises the flag if it is inside the matrix and is taken as 1 either way)
+				// A pivot that is not positive raises the flag if it is inside the matrix: see potrf_panel_pivot)
 				const int r = lane, g = lane & 15;
 				double a[16], d[16];
 				#pragma unroll
@@ -248,8 +260,11 @@ __device__ __forceinline__ void potrf_diag_body(double *M, int ld, int kb, int n
 					a[c] = s_L[(c0 + c) * PL + r];
 					d[c] = s_L[(c0 + c) * PL + c0 + g];
 				}
-				double mine = 1.0;
-				potrf_panel_steps<0>(a, d, mine, b_bad, g, n - o - c0);
+				double mine_raw = 1.0;
+				const double rw_first = potrf_panel_pivot<0>(d, mine_raw, g);
+				potrf_panel_steps<0>(a, d, rw_first, mine_raw, g);
+				b_bad = b_bad || (!(mine_raw > 0) && c0 + g < n - o); // (past n rides the right-hand side row)
+				const double mine = __builtin_fmax(mine_raw, 1e-300);
 				// the reciprocal square roots of the sixteen pivots, one per lane of a row, beside the chain rather than on it
 				double rs = __builtin_amdgcn_rsq(mine);
 				const double h = 0.5 * mine;
@@ -290,7 +305,7 @@ __device__ __forceinline__ void potrf_diag_body(double *M, int ld, int kb, int n
 			potrf_invert_block16(s_L, s_rd, s_X, 16 * wave, lane);
 		__syncthreads();
 	}
-	if(b_bad && lane == 0)
+	if(__any(b_bad) && lane == 0)
 		atomicOr(p_flag, 1);
 	#pragma unroll
 	for(int i = 0; i < NB * NB / 256; ++ i) {

@@ -49,48 +49,42 @@ __global__ void lat_kernel(double *p_out, long long *p_cycles, double x0)
 		: "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");)
 	t1 = clock64();
 	if(lane == 0) p_cycles[4] = t1 - t0;
-	// 5: chain readlane -> fma -> readlane of the result ... (the pivot hand-over)
+	// 5: dependent v_mov_b64_dpp row_newbcast
 	double u = a0;
 	t0 = clock64();
-	#pragma unroll
-	for(int i = 0; i < 16; ++ i) {
-		const int lo = __builtin_amdgcn_readlane(__double2loint(u), 3), hi = __builtin_amdgcn_readlane(__double2hiint(u), 3);
-		u = __builtin_fma(__hiloint2double(hi, lo), c, u);
-	}
+	REP64(asm volatile("s_nop 1\n v_mov_b64_dpp %0, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(u));)
 	t1 = clock64();
 	if(lane == 0) p_cycles[5] = t1 - t0;
-	// 6: LDS broadcast instead of readlane: ds_write_b64 own value, ds_read_b64 of one address, fma (dependent chain)
-	__shared__ double s_x[64];
+	// 6: independent v_fmac_f64_dpp (4 accumulators)
+	t0 = clock64();
+	REP16(asm volatile("v_fmac_f64_dpp %0, %4, %5 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %1, %4, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+		"v_fmac_f64_dpp %2, %4, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %3, %4, %5 row_newbcast:4 row_mask:0xf bank_mask:0xf"
+		: "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)
+	t1 = clock64();
+	if(lane == 0) p_cycles[6] = t1 - t0;
+	// 7: dependent v_fmac_f64_dpp (the accumulator is the next one's broadcast source)
 	double v = a1;
 	t0 = clock64();
-	for(int i = 0; i < 16; ++ i) {
-		s_x[lane] = v;
-		__builtin_amdgcn_s_waitcnt(0xc07f);
-		const double m = s_x[i];
-		v = __builtin_fma(m, c, v);
-	}
-	t1 = clock64();
-	if(lane == 0) p_cycles[6] = t1 - t0; // 16 round trips
-	// 7: dependent rcp + two Newton steps + mul (the chain of one column step without the broadcasts)
-	double pv = a2;
-	t0 = clock64();
-	for(int i = 0; i < 16; ++ i) {
-		double rw = __builtin_amdgcn_rcp(pv);
-		rw = __builtin_fma(__builtin_fma(-pv, rw, 1.0), rw, rw);
-		rw = __builtin_fma(__builtin_fma(-pv, rw, 1.0), rw, rw);
-		pv = __builtin_fma(pv, rw, c); // next "pivot" depends on it
-	}
+	REP64(asm volatile("s_nop 1\n v_fmac_f64_dpp %0, %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(v) : "v"(c));)
 	t1 = clock64();
 	if(lane == 0) p_cycles[7] = t1 - t0;
-	// 8: one DPP move (row_shr:1) + fma, dependent
-	int w = __double2loint(a3);
+	// 8: the chain of one column step: bcast -> cmp/select -> rcp -> 2 Newton -> mul -> fmac_dpp (x16)
+	double pv = a2 + 2.0, w = 0.0;
 	t0 = clock64();
-	REP64(w = __builtin_amdgcn_update_dpp(0, w, 0x111, 0xf, 0xf, false);)
+	REP16(asm volatile("s_nop 1\n v_mov_b64_dpp %1, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+		"v_max_f64 %1, %1, %1\n v_max_f64 %1, %1, %1\n"
+		"v_rcp_f64 %2, %1\n v_fma_f64 %1, -%0, %2, 1.0\n v_fmac_f64 %2, %1, %2\n v_fma_f64 %1, -%0, %2, 1.0\n v_fmac_f64 %2, %1, %2\n"
+		"v_mul_f64 %1, %0, -%2\n s_nop 1\n v_fmac_f64_dpp %0, %0, %1 row_newbcast:4 row_mask:0xf bank_mask:0xf"
+		: "+v"(pv), "=&v"(w), "=&v"(u));)
 	t1 = clock64();
 	if(lane == 0) p_cycles[8] = t1 - t0;
-	// 9: ds_bpermute dependent chain
+	// 9: LDS write + poll from the same wave (round trip seen by a consumer is at least this)
+	__shared__ double s_x[64];
 	t0 = clock64();
-	REP16(w = __builtin_amdgcn_ds_bpermute(12, w);)
+	for(int i = 0; i < 16; ++ i) {
+		((__attribute__((address_space(3))) volatile double*)s_x)[lane] = v + i;
+		v += ((__attribute__((address_space(3))) volatile double*)s_x)[i];
+	}
 	t1 = clock64();
 	if(lane == 0) p_cycles[9] = t1 - t0;
 	p_out[lane] = a + a0 + a1 + a2 + a3 + u + v + pv + w;
@@ -105,9 +99,9 @@ int main()
 	long long h[16];
 	hipMemcpy(h, p_cycles, sizeof(h), hipMemcpyDeviceToHost);
 	const char *names[] = {"dependent v_fma_f64", "independent v_fma_f64", "dependent v_rcp_f64", "(2 readlane + fma), interleaved",
-		"(2 readlane + fma), grouped by 4", "readlane -> fma -> readlane chain", "LDS write + broadcast read + fma chain",
-		"rcp + 2 Newton + fma chain", "dependent DPP move", "dependent ds_bpermute"};
-	const int counts[] = {64, 64, 64, 64, 64, 16, 16, 16, 64, 16};
+		"(2 readlane + fma), grouped by 4", "dependent v_mov_b64_dpp (+ s_nop 1)", "independent v_fmac_f64_dpp",
+		"dependent v_fmac_f64_dpp (+ s_nop 1)", "column step chain (bcast..fmac_dpp)", "LDS volatile write + read round trip"};
+	const int counts[] = {64, 64, 64, 64, 64, 64, 64, 64, 16, 16};
 	for(int i = 0; i < 10; ++ i)
 		printf("%-42s %6lld cycles / %d = %.1f each\n", names[i], h[i], counts[i], double(h[i]) / counts[i]);
 	return 0;
