@@ -22,23 +22,7 @@ void dense_prepare_gaps(double *M, int n_pad, const int32_t *p_positions_dev, in
 // L(n_pad-1, 0:n) = y^T = (L^-1 rhs)^T (forward substitution fused into the panel updates).
 // p_invdiag: workspace (n_pad / 64) * 64 * 64 doubles, receives inv(L_kk) of every diagonal tile.
 // Sets *p_flag |= 1 if a pivot of a row < n is not positive.
-//
-// With a CDenseLookahead the K = 256 updates of everything two outer panels ahead and further run on a second, lower
-// priority stream next to the chain of the panel in between (see the schedule in dense_chol.hip); every one of them has
-// been waited for on `stream` when the call returns, so to the caller the work is on `stream` as before.
-struct CDenseLookahead {
-	hipStream_t side = nullptr;       // lower priority than any stream the caller passes
-	std::vector<hipEvent_t> events;   // two per outer panel, made as needed
-	bool b_failed = false;            // a stream or an event could not be made: dense_cholesky() stays on one stream
-	CDenseLookahead() = default;
-	~CDenseLookahead() { Destroy(); }
-	CDenseLookahead(const CDenseLookahead&) = delete;
-	CDenseLookahead &operator =(const CDenseLookahead&) = delete;
-	bool b_Prepare(size_t n_events);  // on the calling thread's current device
-	void Destroy();
-};
-void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag, hipStream_t stream,
-	CDenseLookahead *p_lookahead = nullptr);
+void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag, hipStream_t stream);
 
 // The pieces of dense_cholesky() for a factorization whose outer panels (OUTER = 4 tiles = 256 columns) are spread over
 // several devices (group.hip: panel b belongs to member b mod P):

@@ -15,12 +15,6 @@
 // This is the MFMA-bound kernel of the path: n^3/3 flops (72 GFLOP at 1k cameras).
 #include <hip/hip_runtime.h>
 #include "dense_chol.h"
-#include <cstdlib>
-#include <stdexcept>
-#include <string>
-
-#define SLAMPP_DENSE_CHECK(call) do { const hipError_t n_err_ = (call); if(n_err_ != hipSuccess) \
-	throw std::runtime_error(std::string(#call) + ": " + hipGetErrorString(n_err_)); } while(0)
 
 namespace slampp {
 #include "dense_device.inl"
@@ -211,48 +205,6 @@ static inline void launch_syrk(double *M, int n_pad, int n_blocks, int k0, int k
 		hipLaunchKernelGGL(syrk_kernel, dim3(n_tiles), dim3(256), 0, stream, M, n_pad, n_blocks, k0, k1, c0, c1);
 }
 
-bool CDenseLookahead::b_Prepare(size_t n_events)
-{
-	if(b_failed)
-		return false;
-	if(!side) {
-		int n_least = 0, n_greatest = 0;
-		if(hipDeviceGetStreamPriorityRange(&n_least, &n_greatest) != hipSuccess ||
-		   hipStreamCreateWithPriority(&side, hipStreamNonBlocking, n_least) != hipSuccess) {
-			(void)hipGetLastError();
-			side = nullptr;
-			b_failed = true;
-			return false;
-		}
-	}
-	while(events.size() < n_events) {
-		hipEvent_t ev;
-		if(hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-			(void)hipGetLastError();
-			b_failed = true;
-			return false;
-		}
-		events.push_back(ev);
-	}
-	return true;
-}
-
-void CDenseLookahead::Destroy()
-{
-	for(hipEvent_t ev : events)
-		(void)hipEventDestroy(ev);
-	events.clear();
-	if(side)
-		(void)hipStreamDestroy(side);
-	side = nullptr;
-}
-
-static bool b_lookahead_enabled()
-{
-	static const bool b_on = []() { const char *p = getenv("SLAMPP_HIP_DENSE_LOOKAHEAD"); return p && atoi(p) != 0; }(); // off unless asked for: see DESIGN.md 4.2 (measured slower: the chain's launches wait for slots behind the far update's workgroups)
-	return b_on;
-}
-
 // Schedule.  The matrix is cut into outer panels of OUTER_TILES 64-wide tiles; panel b is factored by the chain
 // potrf -> trsm per tile, the trsm also updating the next diagonal tile.  Every other update does not run after that
 // chain but beside it.  As extra workgroups of the potrf launches (which would otherwise keep one CU busy and 255 idle):
@@ -260,25 +212,18 @@ static bool b_lookahead_enabled()
 //                                             diagonal tile that tile's trsm has done; for tile 0 of the panel the tile
 //                                             before is the last one of panel b - 1, whose 64-wide update ends here),
 //   potrf of tile k >= 1 of panel b  carries  the 64-wide update of panel b + 1 by tile k - 1,
-//   potrf of tile 0 of panel b       carries  the K = 256 update of panel b + 1 by panel b - 1.
-// Nothing separates two chains: the potrf -> trsm -> potrf sequence runs through the panel boundaries.  And the bulk of
-// the flops,
-// the K = 256 update of the panels >= b + 2 by panel b - 1 ("far"):
-//   with a look-ahead stream   one launch there, started when panel b - 1 is complete, so it has the whole chain of
-//                              panel b to itself and the chip (the chain's launches take the CUs they need ahead of it:
-//                              the side stream has the lowest priority); the chain of panel b + 1, whose potrf of tile 0
-//                              is the next writer of those panels, waits for it.  While the far updates are the longer
-//                              of the two (the first few panels of a large matrix) the factorization runs at their
-//                              pace, afterwards at the chain's; neither waits for the other's ragged last round of
-//                              workgroups four times per panel, which is what the one-stream form costs;
-//   without                    a quarter of it rides in each potrf launch of panel b.
-// Launches on one stream serialize the writers of every target tile, the two events per panel do it across the streams,
-// and inside one launch no two workgroups share a target.
-void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag, hipStream_t stream, CDenseLookahead *p_lookahead)
+//   potrf of tile 0 of panel b       carries  the K = 256 update of panel b + 1 by panel b - 1,
+//   every potrf of panel b           carries  a quarter of the K = 256 update of the panels >= b + 2 by panel b - 1 (the
+//                                             bulk of the flops).
+// Nothing separates two chains: the potrf -> trsm -> potrf sequence runs through the panel boundaries.  Launches on one
+// stream serialize the writers of every target tile, and inside one launch no two workgroups share a target.
+// (A second, lowest-priority stream for the K = 256 updates, two events per panel, was measured again in round 3 with
+// this schedule: 3.75 against 3.49 ms at n = 6 000 -- while that launch runs, the chain's own launches wait for
+// workgroup slots behind it, 19 -> 75 us per potrf launch -- DESIGN.md section 4.2.)
+void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag, hipStream_t stream)
 {
 	const int n_blocks = n_pad / NB;
 	const int n_outer = (n_blocks + OUTER_TILES - 1) / OUTER_TILES;
-	const bool b_side = p_lookahead && n_outer > 3 && b_lookahead_enabled() && p_lookahead->b_Prepare(2 * size_t(n_outer));
 	for(int b = 0; b < n_outer; ++ b) {
 		const int t0 = b * OUTER_TILES, t1 = (t0 + OUTER_TILES < n_blocks)? t0 + OUTER_TILES : n_blocks;
 		const int u0 = t1, u1 = (u0 + OUTER_TILES < n_blocks)? u0 + OUTER_TILES : n_blocks; // panel b + 1
@@ -286,17 +231,6 @@ void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag,
 		const int p0 = t0 - OUTER_TILES, p1 = t0;                                            // panel b - 1
 		const int n_next_tiles = n_syrk_tiles(n_blocks, u0, u1);
 		const int n_far_tiles = (b > 0)? n_syrk_tiles(n_blocks, v0, n_blocks) : 0;
-		if(b_side) {
-			hipEvent_t *p_ev = p_lookahead->events.data();
-			if(n_far_tiles > 0) { // panel b - 1 is complete on the chain's stream: its far update starts
-				SLAMPP_DENSE_CHECK(hipEventRecord(p_ev[2 * b], stream));
-				SLAMPP_DENSE_CHECK(hipStreamWaitEvent(p_lookahead->side, p_ev[2 * b], 0));
-				hipLaunchKernelGGL(syrk_kernel, dim3(n_far_tiles), dim3(256), 0, p_lookahead->side, M, n_pad, n_blocks, p0, p1, v0, n_blocks);
-				SLAMPP_DENSE_CHECK(hipEventRecord(p_ev[2 * b + 1], p_lookahead->side));
-			}
-			if(b > 1 && n_syrk_tiles(n_blocks, t1, n_blocks) > 0) // the far update by panel b - 2 wrote panel b + 1 onwards: this chain writes there next
-				SLAMPP_DENSE_CHECK(hipStreamWaitEvent(stream, p_ev[2 * (b - 1) + 1], 0));
-		}
 		for(int kb = t0; kb < t1; ++ kb) {
 			const int k = kb - t0, m = t1 - t0;
 			TSyrkJob t_inner = {0, 0, 0, 0, 0, 0}, t_near = {0, 0, 0, 0, 0, 0}, t_far = {0, 0, 0, 0, 0, 0};
@@ -306,7 +240,7 @@ void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag,
 				t_near = TSyrkJob{kb - 1, kb, u0, u1, 0, n_next_tiles};
 			else if(b > 0)
 				t_near = TSyrkJob{p0, p1, u0, u1, 0, n_next_tiles};
-			if(n_far_tiles > 0 && !b_side) {
+			if(n_far_tiles > 0) {
 				const int n_begin = int(int64_t(n_far_tiles) * k / m), n_end = int(int64_t(n_far_tiles) * (k + 1) / m);
 				t_far = TSyrkJob{p0, p1, v0, n_blocks, n_begin, n_end - n_begin};
 			}

@@ -1333,7 +1333,7 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 				SLAMPP_HIP_CHECK(hipMemcpyAsync(S.d_S.p(), p_S, size_t(ld) * ld * sizeof(double), hipMemcpyDeviceToDevice, st));
 				p_S = S.d_S.p();
 			}
-			dense_cholesky(p_S, ld, n, S.d_invdiag.p(), s.d_flag.p(), st, &s.dense_lookahead);
+			dense_cholesky(p_S, ld, n, S.d_invdiag.p(), s.d_flag.p(), st);
 			s.Phase_End();
 		}
 		s.Phase_Begin("dense_solve");
@@ -1536,7 +1536,7 @@ static void schur_enqueue_marginals_t(slampp_hip_solver &s, CSchurState &S, cons
 		s.Phase_End();
 	}
 	s.Phase_Begin("marginals_factor");
-	dense_cholesky(p_S, ld, n, S.d_m_invdiag.p(), s.d_flag.p(), st, &s.dense_lookahead);
+	dense_cholesky(p_S, ld, n, S.d_m_invdiag.p(), s.d_flag.p(), st);
 	s.Phase_End();
 	s.Phase_Begin("marginals_inverse");
 	dense_inverse_from_factor(p_S, ld, S.d_m_invdiag.p(), S.d_m_Z.p(), st);

@@ -163,7 +163,6 @@ struct slampp_hip_solver {
 	slampp::CDevArray<slampp::TDenseBlk> d_dense_blks;
 	slampp::CDevArray<slampp::TDenseCol> d_dense_cols;
 	slampp::CDevArray<double> d_dense, d_dense_invdiag, d_dense_z, d_dense_x;
-	slampp::CDenseLookahead dense_lookahead; // second stream of dense_cholesky() (this handle's dense top, or the dense reduced system of its Schur path)
 	slampp::CDevArray<int32_t> d_dense_gaps; // positions inside the dense top that no column maps to (alignment padding)
 	int n_dense_gaps;
 	slampp::CTileSchedule dense_tiles; // level schedule over the nonzero tiles of the dense top (dense_chol.h)

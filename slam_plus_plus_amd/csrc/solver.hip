@@ -1316,7 +1316,7 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			if(b_dense_tiles)
 				tile_cholesky(dense_tiles, d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), p_flag, stream);
 			else
-				dense_cholesky(d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), p_flag, stream, &dense_lookahead);
+				dense_cholesky(d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), p_flag, stream);
 			Phase_End();
 		} else {
 			Phase_Begin("dense_forward");
