@@ -466,97 +466,14 @@ __global__ void schur_delta_A_kernel(const int64_t *ptr, const int32_t *brow, in
 	}
 }
 
-template <int DC, int DP>
-__device__ void schur_changed_point_serial(int64_t pt, const int64_t *ptr,
-	const int32_t *brow, int64_t nc, int64_t ubase, const double *__restrict__ A, double *Cinv, double *W,
-	int64_t n_sblocks, const int32_t *__restrict__ sb_row, const int32_t *__restrict__ sb_col, double *S, int ld,
-	const int64_t *__restrict__ p_dst, int *p_flag)
-{
-	const int64_t k0 = ptr[nc + pt], o0 = k0 - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
-	double c_old[DP * DP], ci_old[DP * DP], c_new[DP * DP], ci_new[DP * DP];
-	#pragma unroll
-	for(int t = 0; t < DP * DP; ++ t)
-		ci_old[t] = Cinv[pt * (DP * DP) + t];
-	spd_inverse<DP>(ci_old, c_old); // C of the previous solve
-	const double *C = A + ubase + o1 * (DC * DP) + pt * (DP * DP);
-	#pragma unroll
-	for(int t = 0; t < DP * DP; ++ t)
-		c_new[t] = C[t];
-	if(!spd_inverse<DP>(c_new, ci_new))
-		atomicOr(p_flag, 1);
-	for(int64_t ob = o0; ob < o1; ++ ob) { // row block: the later (larger) camera
-		const double *Ub = A + ubase + ob * (DC * DP) + pt * (DP * DP);
-		const double *Wb = W + ob * (DC * DP);
-		double wc[DC * DP], wn[DC * DP]; // W_b C_old (old), U_b C^-1_new (new W_b)
-		#pragma unroll
-		for(int q = 0; q < DP; ++ q) {
-			#pragma unroll
-			for(int r = 0; r < DC; ++ r) {
-				double t_old = 0, t_new = 0;
-				#pragma unroll
-				for(int k = 0; k < DP; ++ k) {
-					t_old += Wb[r + k * DC] * c_old[k + q * DP];
-					t_new += Ub[r + k * DC] * ci_new[k + q * DP];
-				}
-				wc[r + q * DC] = t_old;
-				wn[r + q * DC] = t_new;
-			}
-		}
-		const int64_t cam_b = brow[k0 + (ob - o0)];
-		for(int64_t oa = o0; oa <= ob; ++ oa) {
-			const double *Ua = A + ubase + oa * (DC * DP) + pt * (DP * DP);
-			const double *Wa = W + oa * (DC * DP); // (the previous solve's: W is rewritten after the last pair, below)
-			const int64_t cam_a = brow[k0 + (oa - o0)];
-			// the block (row cam_b, column cam_a) of S: binary search on the blocks' sorted keys column * nc + row
-			const int64_t key = cam_a * nc + cam_b;
-			int64_t lo = 0, hi = n_sblocks - 1;
-			while(lo < hi) {
-				const int64_t mid = (lo + hi) >> 1;
-				if(int64_t(sb_col[mid]) * nc + sb_row[mid] < key) lo = mid + 1; else hi = mid;
-			}
-			#pragma unroll
-			for(int q = 0; q < DC; ++ q) {
-				#pragma unroll
-				for(int r = 0; r < DC; ++ r) {
-					double f_old = 0, f_new = 0;
-					#pragma unroll
-					for(int t = 0; t < DP; ++ t) {
-						f_old += wc[r + t * DC] * Wa[q + t * DC]; // (W_b C W_a^T)(r, q)
-						f_new += wn[r + t * DC] * Ua[q + t * DC]; // (U_b C^-1 U_a^T)(r, q)
-					}
-					const size_t idx = p_dst? size_t(p_dst[lo]) + q + r * DC :
-						size_t(cam_b * DC + r) + size_t(cam_a * DC + q) * ld;
-					atomicAdd(S + idx, f_old - f_new); // S = A - sum U C^-1 U^T: the old term comes back, the new one goes
-				}
-			}
-		}
-	}
-	// every pair of the landmark has read the old W: now it is replaced
-	for(int64_t ob = o0; ob < o1; ++ ob) {
-		const double *Ub = A + ubase + ob * (DC * DP) + pt * (DP * DP);
-		#pragma unroll
-		for(int q = 0; q < DP; ++ q) {
-			#pragma unroll
-			for(int r = 0; r < DC; ++ r) {
-				double t_new = 0;
-				#pragma unroll
-				for(int k = 0; k < DP; ++ k)
-					t_new += Ub[r + k * DC] * ci_new[k + q * DP];
-				W[ob * (DC * DP) + r + q * DC] = t_new;
-			}
-		}
-	}
-	#pragma unroll
-	for(int t = 0; t < DP * DP; ++ t)
-		Cinv[pt * (DP * DP) + t] = ci_new[t];
-}
-
-
-// The contributions of the changed landmarks exchanged, one wave per landmark: its U and (old) W blocks in LDS, every
-// lane finds the block of S of one camera pair (a binary search: a dozen dependent trips to memory -- one thread per
-// landmark walked through k (k + 1) / 2 of them one after the other, 170 us for a list of any length), then a lane per
-// (pair, element) adds (W_b C W_a^T - U_b C_new^-1 U_a^T)(r, q) to S.  Landmarks seen by more than KMAX cameras: as before,
-// by the wave's first lane.
+// The contributions of the changed landmarks exchanged, one wave per landmark.  Its observations are taken T = 32 at a
+// time: for a tile of "row" observations b the products W_b C (old) and U_b C_new^-1 (the new W_b) go to LDS, then for
+// every tile of "column" observations a up to it their U and (old) W blocks; every lane finds the block of S of one
+// camera pair (a binary search: a dozen dependent trips to memory), then a lane per (pair, element) adds
+// (W_b C W_a^T - U_b C_new^-1 U_a^T)(r, q) to S.  A landmark seen by at most 32 cameras -- nearly all of them -- is one
+// tile against itself.  (Until round 3 a landmark with more than 24 observations was walked by the wave's first lane
+// alone, k (k + 1) / 2 searches one after the other: 30 such landmarks among 5 000 changed ones of the Venice-like C4
+// made the update 6.3 ms, against 1.0 ms for assembling everything again.)
 template <int DC, int DP>
 __global__ void __launch_bounds__(64)
 schur_changed_points_kernel(const int64_t *__restrict__ changed, int64_t n_changed, const int64_t *ptr,
@@ -564,84 +481,123 @@ schur_changed_points_kernel(const int64_t *__restrict__ changed, int64_t n_chang
 	int64_t n_sblocks, const int32_t *__restrict__ sb_row, const int32_t *__restrict__ sb_col, double *S, int ld,
 	const int64_t *__restrict__ p_dst, int *p_flag)
 {
-	enum { KMAX = 24, BLK = DC * DP, PMAX = KMAX * (KMAX + 1) / 2 };
-	__shared__ double s_U[KMAX * BLK], s_W[KMAX * BLK], s_wc[KMAX * BLK], s_wn[KMAX * BLK];
+	enum { T = 32, BLK = DC * DP, PMAX = T * T };
+	__shared__ double s_U[2][T * BLK], s_W[2][T * BLK]; // [0]: the column tile, [1]: the row tile
+	__shared__ double s_wc[T * BLK], s_wn[T * BLK];     // of the row tile
 	__shared__ int64_t s_dst[PMAX];
-	__shared__ int32_t s_cam[KMAX];
+	__shared__ int32_t s_cam[2][T];
 	const int lane = threadIdx.x;
 	const int64_t pt = changed[blockIdx.x];
 	const int64_t k0 = ptr[nc + pt], o0 = k0 - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
 	const int k = int(o1 - o0);
-	if(k > KMAX) { // (wave-uniform)
-		if(lane == 0)
-			schur_changed_point_serial<DC, DP>(pt, ptr, brow, nc, ubase, A, Cinv, W, n_sblocks, sb_row, sb_col, S, ld, p_dst, p_flag);
-		return;
-	}
 	double c_old[DP * DP], ci_old[DP * DP], c_new[DP * DP], ci_new[DP * DP];
 	#pragma unroll
 	for(int t = 0; t < DP * DP; ++ t) {
 		ci_old[t] = Cinv[pt * (DP * DP) + t];
 		c_new[t] = A[ubase + o1 * BLK + pt * (DP * DP) + t];
 	}
-	for(int i = lane; i < k * BLK; i += 64) { // (a landmark's observations follow one another)
-		s_U[i] = A[ubase + o0 * BLK + pt * (DP * DP) + i];
-		s_W[i] = W[o0 * BLK + i];
-	}
-	if(lane < k)
-		s_cam[lane] = brow[k0 + lane];
 	spd_inverse<DP>(ci_old, c_old); // C of the previous solve
 	if(!spd_inverse<DP>(c_new, ci_new) && lane == 0)
 		atomicOr(p_flag, 1);
-	__syncthreads();
-	const int n_pairs = k * (k + 1) / 2;
-	for(int p = lane; p < n_pairs; p += 64) { // pair (b >= a) at b (b + 1) / 2 + a: the block (row cam_b, column cam_a) of S
-		int b = int((sqrtf(8.0f * float(p) + 1.0f) - 1.0f) * 0.5f);
-		while((b + 1) * (b + 2) / 2 <= p) ++ b;
-		while(b * (b + 1) / 2 > p) -- b;
-		const int a = p - b * (b + 1) / 2;
-		const int64_t cam_a = s_cam[a], cam_b = s_cam[b];
-		if(p_dst) { // binary search on the blocks' sorted keys column * nc + row
-			const int64_t key = cam_a * nc + cam_b;
-			int64_t lo = 0, hi = n_sblocks - 1;
-			while(lo < hi) {
-				const int64_t mid = (lo + hi) >> 1;
-				if(int64_t(sb_col[mid]) * nc + sb_row[mid] < key) lo = mid + 1; else hi = mid;
+	const int n_tiles = (k + T - 1) / T;
+	for(int tb = 0; tb < n_tiles; ++ tb) {
+		const int b0 = tb * T, kb = (k - b0 < T)? k - b0 : T;
+		__syncthreads(); // (the tile before is done with)
+		for(int i = lane; i < kb * BLK; i += 64) { // (a landmark's observations follow one another)
+			s_U[1][i] = A[ubase + (o0 + b0) * BLK + pt * (DP * DP) + i];
+			s_W[1][i] = W[(o0 + b0) * BLK + i];
+		}
+		if(lane < kb)
+			s_cam[1][lane] = brow[k0 + b0 + lane];
+		__syncthreads();
+		for(int i = lane; i < kb * BLK; i += 64) { // W_b C_old (old), U_b C^-1_new (the new W_b)
+			const int ob = i / BLK, e = i - ob * BLK, r = e % DC, q = e / DC;
+			double t_old = 0, t_new = 0;
+			#pragma unroll
+			for(int t = 0; t < DP; ++ t) {
+				t_old += s_W[1][ob * BLK + r + t * DC] * c_old[t + q * DP];
+				t_new += s_U[1][ob * BLK + r + t * DC] * ci_new[t + q * DP];
 			}
-			s_dst[p] = p_dst[lo];
-		} else
-			s_dst[p] = cam_b * DC + cam_a * DC * int64_t(ld);
-	}
-	for(int i = lane; i < k * BLK; i += 64) { // W_b C_old (old), U_b C^-1_new (the new W_b)
-		const int ob = i / BLK, e = i - ob * BLK, r = e % DC, q = e / DC;
-		double t_old = 0, t_new = 0;
-		#pragma unroll
-		for(int t = 0; t < DP; ++ t) {
-			t_old += s_W[ob * BLK + r + t * DC] * c_old[t + q * DP];
-			t_new += s_U[ob * BLK + r + t * DC] * ci_new[t + q * DP];
+			s_wc[i] = t_old;
+			s_wn[i] = t_new;
 		}
-		s_wc[i] = t_old;
-		s_wn[i] = t_new;
+		for(int ta = 0; ta <= tb; ++ ta) {
+			const int a0 = ta * T, ka = (ta == tb)? kb : T;
+			const int n_side = (ta == tb)? 1 : 0; // the column tile: the row tile itself on the diagonal
+			__syncthreads(); // (s_wc / s_wn are there; the column tile and the destinations before are done with)
+			if(ta != tb) {
+				for(int i = lane; i < ka * BLK; i += 64) {
+					s_U[0][i] = A[ubase + (o0 + a0) * BLK + pt * (DP * DP) + i];
+					s_W[0][i] = W[(o0 + a0) * BLK + i];
+				}
+				if(lane < ka)
+					s_cam[0][lane] = brow[k0 + a0 + lane];
+				__syncthreads();
+			}
+			const int n_pairs = (ta == tb)? kb * (kb + 1) / 2 : kb * ka;
+			for(int p = lane; p < n_pairs; p += 64) { // pair (b >= a): the block (row cam_b, column cam_a) of S
+				int a, b;
+				if(ta == tb) { // at b (b + 1) / 2 + a
+					b = int((sqrtf(8.0f * float(p) + 1.0f) - 1.0f) * 0.5f);
+					while((b + 1) * (b + 2) / 2 <= p) ++ b;
+					while(b * (b + 1) / 2 > p) -- b;
+					a = p - b * (b + 1) / 2;
+				} else {
+					b = p / ka;
+					a = p - b * ka;
+				}
+				const int64_t cam_a = s_cam[n_side][a], cam_b = s_cam[1][b];
+				if(p_dst) { // binary search on the blocks' sorted keys column * nc + row
+					const int64_t key = cam_a * nc + cam_b;
+					int64_t lo = 0, hi = n_sblocks - 1;
+					while(lo < hi) {
+						const int64_t mid = (lo + hi) >> 1;
+						if(int64_t(sb_col[mid]) * nc + sb_row[mid] < key) lo = mid + 1; else hi = mid;
+					}
+					s_dst[p] = p_dst[lo];
+				} else
+					s_dst[p] = cam_b * DC + cam_a * DC * int64_t(ld);
+			}
+			__syncthreads();
+			for(int i = lane; i < n_pairs * DC * DC; i += 64) {
+				const int p = i / (DC * DC), e = i - p * (DC * DC), q = e % DC, r = e / DC; // (q fastest: neighbouring lanes, neighbouring addresses)
+				int a, b;
+				if(ta == tb) {
+					b = int((sqrtf(8.0f * float(p) + 1.0f) - 1.0f) * 0.5f);
+					while((b + 1) * (b + 2) / 2 <= p) ++ b;
+					while(b * (b + 1) / 2 > p) -- b;
+					a = p - b * (b + 1) / 2;
+				} else {
+					b = p / ka;
+					a = p - b * ka;
+				}
+				double f_old = 0, f_new = 0;
+				#pragma unroll
+				for(int t = 0; t < DP; ++ t) {
+					f_old += s_wc[b * BLK + r + t * DC] * s_W[n_side][a * BLK + q + t * DC]; // (W_b C W_a^T)(r, q)
+					f_new += s_wn[b * BLK + r + t * DC] * s_U[n_side][a * BLK + q + t * DC]; // (U_b C^-1 U_a^T)(r, q)
+				}
+				// S = A - sum U C^-1 U^T: the old term comes back, the new one goes
+				const int64_t n_at = p_dst? s_dst[p] + q + r * DC : s_dst[p] + r + q * int64_t(ld);
+				atomicAdd(S + n_at, f_old - f_new);
+			}
+		}
 	}
+	// every pair of the landmark has read the old W: now it is replaced
 	__syncthreads();
-	for(int i = lane; i < n_pairs * DC * DC; i += 64) {
-		const int p = i / (DC * DC), e = i - p * (DC * DC), q = e % DC, r = e / DC; // (q fastest: neighbouring lanes, neighbouring addresses)
-		int b = int((sqrtf(8.0f * float(p) + 1.0f) - 1.0f) * 0.5f);
-		while((b + 1) * (b + 2) / 2 <= p) ++ b;
-		while(b * (b + 1) / 2 > p) -- b;
-		const int a = p - b * (b + 1) / 2;
-		double f_old = 0, f_new = 0;
-		#pragma unroll
-		for(int t = 0; t < DP; ++ t) {
-			f_old += s_wc[b * BLK + r + t * DC] * s_W[a * BLK + q + t * DC]; // (W_b C W_a^T)(r, q)
-			f_new += s_wn[b * BLK + r + t * DC] * s_U[a * BLK + q + t * DC]; // (U_b C^-1 U_a^T)(r, q)
+	if(n_tiles == 1) {
+		for(int i = lane; i < k * BLK; i += 64)
+			W[o0 * BLK + i] = s_wn[i];
+	} else {
+		for(int i = lane; i < k * BLK; i += 64) {
+			const int ob = i / BLK, e = i - ob * BLK, r = e % DC, q = e / DC;
+			double t_new = 0;
+			#pragma unroll
+			for(int t = 0; t < DP; ++ t)
+				t_new += A[ubase + (o0 + ob) * BLK + pt * (DP * DP) + r + t * DC] * ci_new[t + q * DP];
+			W[o0 * BLK + i] = t_new;
 		}
-		// S = A - sum U C^-1 U^T: the old term comes back, the new one goes
-		const int64_t n_at = p_dst? s_dst[p] + q + r * DC : s_dst[p] + r + q * int64_t(ld);
-		atomicAdd(S + n_at, f_old - f_new);
 	}
-	// every pair of the landmark has read the old W (from LDS): now it is replaced
-	for(int i = lane; i < k * BLK; i += 64)
-		W[o0 * BLK + i] = s_wn[i];
 	if(lane < DP * DP)
 		Cinv[pt * (DP * DP) + lane] = ci_new[lane];
 }

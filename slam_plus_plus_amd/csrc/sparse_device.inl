@@ -1,5 +1,7 @@
 // sparse_device.inl -- device helpers shared by the kernels of the sparse path (sparse_kernels.hip, subtree_kernel.hip);
 // included inside namespace slampp.
+#ifndef SLAMPP_SPARSE_DEVICE_INL
+#define SLAMPP_SPARSE_DEVICE_INL // (included inside namespace slampp; the guard lets several of the .hip files be compiled as one translation unit)
 
 static const int64_t PAIR_OFF_MASK = (int64_t(1) << 48) - 1; // pair.x = offset | position of the target block in its column << 48 | dim << 56
 enum { Y_LANE0 = 56 }; // lanes 56.. carry the right-hand side of the column when its dimension is <= 7
@@ -395,3 +397,5 @@ __device__ __forceinline__ double pair_product_image(const double *a, const doub
 	return sum;
 }
 
+
+#endif // SLAMPP_SPARSE_DEVICE_INL

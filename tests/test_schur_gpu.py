@@ -552,6 +552,31 @@ def test_incremental_update_of_the_reduced_system_matches_full_recomputation(mod
         CLinearSolver_Schur_HIP().Set_Changed_Landmarks([0])
 
 
+@pytest.mark.parametrize("sparse", [0, 1])
+@pytest.mark.parametrize("n_obs", [30, 40, 70])
+def test_incremental_update_of_landmarks_seen_by_many_cameras(n_obs, sparse):
+    """The update kernel takes a landmark's observations 32 at a time: one tile against itself (30), two and three tiles
+    (40, 70) -- every landmark of these systems; against the oracle's full solve of the changed system."""
+    rng = np.random.default_rng(23)
+    lam = synth.ba(90, 400, k=n_obs, mode="uniform", seed=29)
+    solver = CLinearSolver_Schur_HIP(schur_incremental=2, schur_sparse=sparse, profile=1)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta)
+    n_pts = lam.n_bcols - lam.n_matrix_cut
+    for n_changed in (37, 2):
+        points = np.sort(rng.choice(n_pts, size=n_changed, replace=False))
+        lam = _relinearized(lam, points, rng)
+        ok, x_ref, _, _ = O.solve_schur(lam)
+        assert ok
+        solver.profile(reset=True)
+        solver.Set_Changed_Landmarks(points)
+        eta = lam.rhs.copy()
+        assert solver.Solve_PosDef_Blocky(lam, eta)
+        phases = solver.profile()
+        assert phases.get("schur_update", (0, 0))[0] == 1 and _rebuilds(phases) == 0   # it was an update
+        assert rel_inf(eta, x_ref) < TOL, n_changed
+
+
 def test_incremental_update_only_where_it_pays():
     """Option schur_incremental = 1: a list naming more than 1 / 32 of the landmarks (landmark-major assembly) is answered
     with a full rebuild -- that is the shorter way --, a shorter list with the update; same solution either way."""
