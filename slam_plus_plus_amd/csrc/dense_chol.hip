@@ -357,6 +357,8 @@ void dense_forwardsolve(double *M, int n_pad, const double *p_invdiag, hipStream
 // z_jb -= sum over the panel's tiles kb of L(kb,jb)^T x_kb.  Everything a workgroup will need (up to 14 tiles,
 // 8 values of each per thread) is requested before the first dependent step, so the chain of small products
 // runs out of registers: one memory latency per launch, a quarter of the launches of a tile-by-tile substitution.
+// A thread's eight values of a tile row are four 16-byte pairs, 2 part + 16 i: the eight threads of a row read whole
+// 128-byte lines (as 8-byte loads at part + 8 i they touched every line twice: half the load instructions now).
 __global__ void __launch_bounds__(512)
 dense_backsolve_panel_kernel(const double *M, int ld, int t0, int t1, const double *p_invdiag, double *z, double *x)
 {
@@ -370,22 +372,31 @@ dense_backsolve_panel_kernel(const double *M, int ld, int t0, int t1, const doub
 	#pragma unroll
 	for(int a = 0; a < OUTER_TILES; ++ a) {
 		if(a < m) {
-			const double *invL = p_invdiag + size_t(t0 + a) * NB * NB + c * NB + part;
+			const double *invL = p_invdiag + size_t(t0 + a) * NB * NB + c * NB + 2 * part;
 			#pragma unroll
-			for(int i = 0; i < PER; ++ i)
-				vi[a][i] = invL[PARTS * i];
+			for(int i = 0; i < PER; i += 2) {
+				const v2f64 v = *reinterpret_cast<const v2f64*>(invL + PARTS * i);
+				vi[a][i] = v.x;
+				vi[a][i + 1] = v.y;
+			}
 			#pragma unroll
 			for(int b = 0; b < a; ++ b) {
-				const double *col = M + size_t((t0 + a) * NB + part) + size_t((t0 + b) * NB + c) * ld;
+				const double *col = M + size_t((t0 + a) * NB + 2 * part) + size_t((t0 + b) * NB + c) * ld;
 				#pragma unroll
-				for(int i = 0; i < PER; ++ i)
-					vl[a * (a - 1) / 2 + b][i] = col[PARTS * i];
+				for(int i = 0; i < PER; i += 2) {
+					const v2f64 v = *reinterpret_cast<const v2f64*>(col + PARTS * i);
+					vl[a * (a - 1) / 2 + b][i] = v.x;
+					vl[a * (a - 1) / 2 + b][i + 1] = v.y;
+				}
 			}
 			if(b_strip) {
-				const double *col = M + size_t((t0 + a) * NB + part) + size_t(jb * NB + c) * ld;
+				const double *col = M + size_t((t0 + a) * NB + 2 * part) + size_t(jb * NB + c) * ld;
 				#pragma unroll
-				for(int i = 0; i < PER; ++ i)
-					vs[a][i] = col[PARTS * i];
+				for(int i = 0; i < PER; i += 2) {
+					const v2f64 v = *reinterpret_cast<const v2f64*>(col + PARTS * i);
+					vs[a][i] = v.x;
+					vs[a][i + 1] = v.y;
+				}
 			}
 		}
 	}
@@ -399,7 +410,7 @@ dense_backsolve_panel_kernel(const double *M, int ld, int t0, int t1, const doub
 			double sum = 0; // x_kb[c] = sum_r inv(L_kk)[r][c] z_kb[r]; PARTS lanes per entry
 			#pragma unroll
 			for(int i = 0; i < PER; ++ i)
-				sum += vi[a][i] * zk[part + PARTS * i];
+				sum += vi[a][i] * zk[2 * part + PARTS * (i & ~1) + (i & 1)];
 			sum += __shfl_xor(sum, 1);
 			sum += __shfl_xor(sum, 2);
 			sum += __shfl_xor(sum, 4);
@@ -412,7 +423,7 @@ dense_backsolve_panel_kernel(const double *M, int ld, int t0, int t1, const doub
 				double upd = 0;
 				#pragma unroll
 				for(int i = 0; i < PER; ++ i)
-					upd += vl[a * (a - 1) / 2 + b][i] * zk[part + PARTS * i];
+					upd += vl[a * (a - 1) / 2 + b][i] * zk[2 * part + PARTS * (i & ~1) + (i & 1)];
 				upd += __shfl_xor(upd, 1);
 				upd += __shfl_xor(upd, 2);
 				upd += __shfl_xor(upd, 4);
@@ -434,7 +445,7 @@ dense_backsolve_panel_kernel(const double *M, int ld, int t0, int t1, const doub
 		if(a < m) {
 			#pragma unroll
 			for(int i = 0; i < PER; ++ i)
-				sum += vs[a][i] * s_z[a * NB + part + PARTS * i];
+				sum += vs[a][i] * s_z[a * NB + 2 * part + PARTS * (i & ~1) + (i & 1)];
 		}
 	}
 	sum += __shfl_xor(sum, 1);
