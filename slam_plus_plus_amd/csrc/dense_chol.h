@@ -66,6 +66,9 @@ private:
 void tile_cholesky(const CTileSchedule &r_schedule, double *M, int n_pad, int n, double *p_invdiag, int *p_flag,
 	hipStream_t stream);
 
+// zeroes the schedule's tiles of M (every tile a factorization by the schedule or an assembly into its pattern writes)
+void tile_zero(const CTileSchedule &r_schedule, double *M, int n_pad, hipStream_t stream);
+
 // x = L^-T y with y taken from row n_pad-1 of the factor; p_z: workspace n_pad doubles; p_x: n_pad doubles, x in [0, n)
 void dense_backsolve(const double *M, int n_pad, int n, const double *p_invdiag, double *p_z, double *p_x, hipStream_t stream);
 

@@ -167,6 +167,7 @@ struct slampp_hip_solver {
 	int n_dense_gaps;
 	slampp::CTileSchedule dense_tiles; // level schedule over the nonzero tiles of the dense top (dense_chol.h)
 	bool b_dense_tiles;                // use it (its dependent chain is clearly shorter than the tile count)
+	bool b_dense_clean;                // the tiles of d_dense outside the schedule are zero (a full memset has run since it was allocated and only the schedule's tiles have been written): a step zeroes the schedule's tiles only
 	int n_dense_top_tiles;             // option: -1 = decide per structure, 0 = always the dense schedule, 1 = always the tile schedule
 	int n_dense_blks, n_dense_cols, n_dense_dim, n_dense_pad;
 	slampp::CDevArray<double> d_A, d_rhs, d_L, d_Linv, d_w, d_cov;
