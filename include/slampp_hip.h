@@ -267,7 +267,8 @@ int slampp_hip_schur_marginals_device_async(slampp_hip_solver *p_solver, const d
 	double *p_cam_cov_dev, double *p_point_cov_dev);
 
 /* enqueue-only variants for benchmarking / stream capture: no host synchronisation, no status
- * read-back; slampp_hip_sync() waits and returns OK / NOT_POSDEF / error for everything enqueued */
+ * read-back; slampp_hip_sync() waits and returns OK / NOT_POSDEF / error for everything enqueued since the
+ * previous slampp_hip_sync() (NOT_POSDEF if any of those factorizations was not positive definite) */
 int slampp_hip_factor_solve_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,
 	double *p_rhs_inout_dev);
 int slampp_hip_sync(slampp_hip_solver *p_solver);

@@ -1201,7 +1201,6 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 	double *p_S = b_sparse? S.d_in_buf.p() : ((b_keep)? S.d_S_unf.p() : S.d_S.p()); // where the blocks go
 	double *p_r = b_sparse? S.d_in_buf.p() + n_in_values : 0;   // the reduced right-hand side, if it is a vector of its own
 	const int64_t *p_sb_dst = b_sparse? S.d_sb_dst.p() : 0, *p_a_dst = b_sparse? S.d_a_dst.p() : 0;
-	SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), st));
 
 	if(b_update) {
 		s.Phase_Begin("schur_update");
@@ -1336,7 +1335,6 @@ static void schur_enqueue_marginal_t(slampp_hip_solver &s, CSchurState &S, const
 {
 	hipStream_t st = s.stream;
 	const int64_t ubase = S.n_ablocks * DC * DC;
-	SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), st));
 	s.Phase_Begin("landmarks_only");
 	hipLaunchKernelGGL((schur_point_inverse_kernel<DC, DP>), dim3(unsigned((S.np + 255) / 256)), dim3(256), 0, st,
 		S.d_ptr.p(), S.nc, S.np, ubase, A, S.d_Cinv.p(), s.d_flag.p());
@@ -1416,7 +1414,6 @@ static void schur_enqueue_marginals_sparse_t(slampp_hip_solver &s, CSchurState &
 	const int n = S.N;
 	const size_t n_in_values = size_t(S.n_in_blocks) * DC * DC;
 	double *p_S = S.d_in_buf.p(), *p_r = S.d_in_buf.p() + n_in_values;
-	SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), st));
 	s.Phase_Begin("marginals_assemble");
 	SLAMPP_HIP_CHECK(hipMemsetAsync(p_S, 0, (n_in_values + size_t(n)) * sizeof(double), st));
 	if(s.b_shard_primary) {
@@ -1472,7 +1469,6 @@ static void schur_enqueue_marginals_t(slampp_hip_solver &s, CSchurState &S, cons
 		SLAMPP_HIP_CHECK(hipMemsetAsync(S.d_m_zero.p(), 0, n_zero * sizeof(double), st));
 	}
 	double *p_S = S.d_m_S.p();
-	SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), st));
 	s.Phase_Begin("marginals_assemble");
 	SLAMPP_HIP_CHECK(hipMemsetAsync(p_S, 0, size_t(ld) * ld * sizeof(double), st));
 	dense_prepare_padding(p_S, ld, n, st);

@@ -1228,8 +1228,9 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 	}
 	if(b_factor) {
 		// numeric factorization with the forward substitution fused in
-		if(!p_flag_shared)
-			SLAMPP_HIP_CHECK(hipMemsetAsync(d_flag.p(), 0, sizeof(int), stream));
+		// (the flag is zero here: set to zero when it was allocated and again by every slampp_hip_sync() that found it raised.
+		// A memset per solve erased an earlier solve's failure before slampp_hip_sync() could report it: the call answers for
+		// everything enqueued since the last one)
 		// the lane-per-task kernel reads blocks and vectors with 16-byte loads where the block dimension is even
 		const bool b_simt = !simt_chunk_ptr.empty() && (P.max_dim % 2 != 0 ||
 			((reinterpret_cast<uintptr_t>(p_values_dev) | reinterpret_cast<uintptr_t>(p_rhs_dev)) & 15) == 0);
@@ -1834,6 +1835,7 @@ int slampp_hip_sync(slampp_hip_solver *p_solver)
 			SLAMPP_HIP_CHECK(hipMemset(s.d_timing.p(), 0, tm.size() * sizeof(long long)));
 		}
 		if(*s.p_host_flag) {
+			SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), s.stream)); // (what was enqueued since the last sync has been answered for)
 			s.b_factored = false;
 			schur_invalidate_previous(s.p_schur); // nothing to update from
 			return fail(p_solver, SLAMPP_HIP_NOT_POSDEF, "matrix is not positive definite");

@@ -83,6 +83,31 @@ def test_not_positive_definite_returns_false():
     assert solver.Solve_PosDef(lam, eta) is False
 
 
+def test_sync_answers_for_every_solve_enqueued_since_the_last_one():
+    """slampp_hip_sync() returns NOT_POSDEF if any factorization enqueued since the last sync was not positive definite,
+    not only the last one (a per-solve reset of the flag used to erase an earlier failure); and the flag is clean again
+    afterwards."""
+    import torch
+    lam = synth.pose_chain(n=400, seed=5)
+    off = lam.block_value_offsets()
+    k = int(lam.bcol_ptr[200 + 1] - 1)                              # a diagonal block in the middle
+    vals_bad = lam.values.copy()
+    vals_bad[off[k]:off[k + 1]] -= 1e4 * np.eye(6).ravel()
+    dev = torch.device("cuda:0")
+    solver = CLinearSolver_HIP()
+    solver.SymbolicDecomposition_Blocky(lam)
+    good, bad = torch.from_numpy(lam.values).to(dev), torch.from_numpy(vals_bad).to(dev)
+    b1, b2, b3 = (torch.from_numpy(lam.rhs).to(dev) for _ in range(3))
+    solver.factor_solve_device_async(bad.data_ptr(), b1.data_ptr())
+    solver.factor_solve_device_async(good.data_ptr(), b2.data_ptr())
+    assert solver.sync() is False                                    # the first of the two failed
+    solver.factor_solve_device_async(good.data_ptr(), b3.data_ptr())
+    assert solver.sync() is True
+    ok, x_ref, _ = O.solve_sparse(lam)
+    assert ok and rel_inf(b3.cpu().numpy(), x_ref) < TOL
+    assert rel_inf(b2.cpu().numpy(), x_ref) < TOL                   # (the good solve between them was a solve all the same)
+
+
 def test_residual_full_size_c3():
     """BASELINE config C3 (100k-pose SE(3)): too big for the scalar oracle to be quick, so check the
     size-independent property ||Lambda x - eta|| / ||eta|| and linearity in eta."""
