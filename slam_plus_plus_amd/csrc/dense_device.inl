@@ -154,14 +154,6 @@ __device__ __forceinline__ void potrf_panel_scale(double (&a)[16], double rs)
 #ifdef POTRF_STAMPS
 __device__ long long g_potrf_stamps[32];
 #endif
-// (the lane number in a scalar register: wave-uniform, not a compile-time constant)
-__device__ __forceinline__ double dense_read_lane_var(double v, int n_lane)
-{
-	const int lo = __builtin_amdgcn_readlane(__double2loint(v), n_lane);
-	const int hi = __builtin_amdgcn_readlane(__double2hiint(v), n_lane);
-	return __hiloint2double(hi, lo);
-}
-
 enum { PL = NB + 1, TL = NB / 2 + 1 };
 
 // D[m][n] += sum_{k < K} A[m][k] B[k][n] for one 16 x 16 tile; A[m][k] = p_A[m * a_m + k * a_k], B[k][n] =
