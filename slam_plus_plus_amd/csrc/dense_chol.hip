@@ -46,50 +46,11 @@ potrf_diag_variant(double *M, int ld, int kb, int n, double *invL, int *p_flag)
 // With b_update_next the workgroup of the first row tile also applies this step's update to the next diagonal
 // tile, A(kb+1,kb+1) -= L(kb+1,kb) L(kb+1,kb)^T, so that the next potrf can follow this launch directly (the rest of
 // the 64-wide update rides in that potrf's launch).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 trsm_kernel(double *M, int ld, int kb, const double *invL, int b_update_next)
 {
-	__shared__ double Ps[NB * NB];
-	__shared__ double Qs[NB * NB];
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int row0 = (kb + 1 + blockIdx.x) * NB, col0 = kb * NB;
-	load_tile(Ps, M, ld, row0, col0);
-	load_tile(Qs, invL, NB, 0, 0);
-	const int lo = lane & 15, hi = lane >> 4;
-	const bool b_diag = b_update_next && blockIdx.x == 0; // workgroup-uniform
-	double cv[4][4];
-	if(b_diag) { // the next diagonal tile is requested now, its latency hides behind the two products
-		#pragma unroll
-		for(int c = 0; c < 4; ++ c)
-			#pragma unroll
-			for(int reg = 0; reg < 4; ++ reg)
-				cv[c][reg] = M[size_t(row0 + 16 * c + lo) + size_t(row0 + 16 * wave + hi + 4 * reg) * ld];
-	}
-	__syncthreads();
-	v4f64 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-	tile_product(Ps, Qs, wave, lane, acc);
-	// every thread has read its operands out of LDS; the tile in global memory can be overwritten
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			M[size_t(row0 + 16 * c + lo) + size_t(col0 + 16 * wave + hi + 4 * reg) * ld] = acc[c][reg];
-	if(!b_diag)
-		return;
-	__syncthreads(); // every wave is done with Ps
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			Ps[lds_at(16 * wave + hi + 4 * reg, 16 * c + lo)] = acc[c][reg]; // L(kb+1,kb) as an operand: [k = column][row]
-	__syncthreads();
-	v4f64 upd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-	tile_product(Ps, Ps, wave, lane, upd);
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			M[size_t(row0 + 16 * c + lo) + size_t(row0 + 16 * wave + hi + 4 * reg) * ld] = cv[c][reg] - upd[c][reg];
+	__shared__ double s_buf[2 * NB * NB];
+	trsm_tile_body8(M, ld, (kb + 1 + int(blockIdx.x)) * NB, kb * NB, invL, b_update_next && blockIdx.x == 0, s_buf, s_buf + NB * NB);
 }
 
 // ---- symmetric update: A(ti,tj) -= sum over K tiles kt in [k0, k1) of L(ti,kt) L(tj,kt)^T ----
@@ -253,7 +214,7 @@ void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag,
 				M, n_pad, kb, n, invL, p_flag, n_blocks, t_far, t_near, t_inner);
 			const int n_below = n_blocks - kb - 1;
 			if(n_below > 0)
-				hipLaunchKernelGGL(trsm_kernel, dim3(n_below), dim3(256), 0, stream, M, n_pad, kb, invL, 1);
+				hipLaunchKernelGGL(trsm_kernel, dim3(n_below), dim3(512), 0, stream, M, n_pad, kb, invL, 1);
 		}
 	}
 }
@@ -267,7 +228,7 @@ void dense_factor_panel(double *M, int n_pad, int n, int t0, int t1, double *p_i
 		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, stream, M, n_pad, kb, n, invL, p_flag, n_blocks, t_none, t_none, t_none);
 		const int n_below = n_blocks - kb - 1;
 		if(n_below > 0)
-			hipLaunchKernelGGL(trsm_kernel, dim3(n_below), dim3(256), 0, stream, M, n_pad, kb, invL, 0);
+			hipLaunchKernelGGL(trsm_kernel, dim3(n_below), dim3(512), 0, stream, M, n_pad, kb, invL, 0);
 		launch_syrk(M, n_pad, n_blocks, kb, kb + 1, kb + 1, t1, stream); // the rest of this panel's columns
 	}
 }

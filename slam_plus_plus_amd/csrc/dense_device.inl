@@ -61,6 +61,81 @@ __device__ __forceinline__ void load_tile(double *Ts, const double *M, int ld, i
 	stage_tile(Ts, t_regs);
 }
 
+// ---- panel solve of one tile by eight waves ----
+// L(i,j) = A(i,j) inv(L_jj)^T for the tile at (row0, col0); with b_diag the workgroup also applies its tile to the
+// diagonal tile of its row, A(i,i) -= L(i,j) L(i,j)^T (the one update the next diagonal tile waits for).  512 threads:
+// a 64 x 64 x 64 product is 64 MFMAs of 64 cycles per wave with four waves, 1.7 us on one CU whatever else is idle; the
+// workgroup with the diagonal tile does two of them one after the other and is what the launch lasts as long as.
+// Eight waves (column block wave & 3, row half wave >> 2) halve both.
+__device__ __forceinline__ void load_tile8(double *Ts, const double *M, int ld, int row0, int col0)
+{
+	const int r = (threadIdx.x & 31) * 2, c0 = threadIdx.x >> 5;
+	v2f64 v[NB / 16];
+	#pragma unroll
+	for(int i = 0; i < NB / 16; ++ i)
+		v[i] = *reinterpret_cast<const v2f64*>(M + size_t(row0 + r) + size_t(col0 + c0 + 16 * i) * ld);
+	#pragma unroll
+	for(int i = 0; i < NB / 16; ++ i)
+		*reinterpret_cast<v2f64*>(Ts + lds_at(c0 + 16 * i, r)) = v[i];
+}
+
+__device__ __forceinline__ void tile_product8(const double *Ps, const double *Qs, int wave, int lane, v4f64 acc[2])
+{
+	const int lo = lane & 15, hi = lane >> 4, cw = wave & 3, rh = wave >> 2;
+	#pragma unroll
+	for(int ks = 0; ks < NB / 4; ++ ks) {
+		const int k = ks * 4 + hi;
+		const double a = Qs[lds_at(k, 16 * cw + lo)];
+		#pragma unroll
+		for(int c2 = 0; c2 < 2; ++ c2) {
+			const double b = Ps[lds_at(k, 16 * (2 * rh + c2) + lo)];
+			acc[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c2], 0, 0, 0);
+		}
+	}
+}
+
+__device__ __forceinline__ void trsm_tile_body8(double *M, int ld, int row0, int col0, const double *invL, bool b_diag,
+	double *Ps, double *Qs)
+{
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int lo = lane & 15, hi = lane >> 4, cw = wave & 3, rh = wave >> 2;
+	load_tile8(Ps, M, ld, row0, col0);
+	load_tile8(Qs, invL, NB, 0, 0);
+	double cv[2][4];
+	if(b_diag) { // (workgroup-uniform) the diagonal tile is requested now, its latency hides behind the two products
+		#pragma unroll
+		for(int c2 = 0; c2 < 2; ++ c2)
+			#pragma unroll
+			for(int reg = 0; reg < 4; ++ reg)
+				cv[c2][reg] = M[size_t(row0 + 16 * (2 * rh + c2) + lo) + size_t(row0 + 16 * cw + hi + 4 * reg) * ld];
+	}
+	__syncthreads();
+	v4f64 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+	tile_product8(Ps, Qs, wave, lane, acc);
+	// every thread has read its operands out of LDS; the tile in global memory can be overwritten
+	#pragma unroll
+	for(int c2 = 0; c2 < 2; ++ c2)
+		#pragma unroll
+		for(int reg = 0; reg < 4; ++ reg)
+			M[size_t(row0 + 16 * (2 * rh + c2) + lo) + size_t(col0 + 16 * cw + hi + 4 * reg) * ld] = acc[c2][reg];
+	if(!b_diag)
+		return;
+	__syncthreads(); // every wave is done with Ps
+	#pragma unroll
+	for(int c2 = 0; c2 < 2; ++ c2)
+		#pragma unroll
+		for(int reg = 0; reg < 4; ++ reg)
+			Ps[lds_at(16 * cw + hi + 4 * reg, 16 * (2 * rh + c2) + lo)] = acc[c2][reg]; // L(i,j) as an operand: [k = column][row]
+	__syncthreads();
+	v4f64 upd[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+	tile_product8(Ps, Ps, wave, lane, upd);
+	#pragma unroll
+	for(int c2 = 0; c2 < 2; ++ c2)
+		#pragma unroll
+		for(int reg = 0; reg < 4; ++ reg)
+			M[size_t(row0 + 16 * (2 * rh + c2) + lo) + size_t(row0 + 16 * cw + hi + 4 * reg) * ld] = cv[c2][reg] - upd[c2][reg];
+}
+
 // ---- diagonal tile: Cholesky + inverse ----
 // Cholesky, blocked by 16 columns: wave 0 factors a 64 x 16 panel in registers (thread r = row r; pivots and
 // the scaled pivot column travel by v_readlane with constant lane numbers -- no LDS, no barrier inside the

@@ -81,50 +81,12 @@ tile_potrf_kernel(double *M, int ld, int n, double *p_invdiag, int *p_flag, cons
 // L(i,j) = A(i,j) inv(L_jj)^T; with t_pair.z set the workgroup also applies its tile to the diagonal tile of its row,
 // A(i,i) -= L(i,j) L(i,j)^T -- the one update the next level's diagonal tile is waiting for, where this tile is its
 // only source in this level (a chain of tile columns: the top of every separator tree)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 tile_trsm_kernel(double *M, int ld, const double *p_invdiag, const int4 *__restrict__ p_pairs)
 {
-	__shared__ double Ps[NB * NB];
-	__shared__ double Qs[NB * NB];
+	__shared__ double s_buf[2 * NB * NB];
 	const int4 t_pair = p_pairs[blockIdx.x];
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int row0 = t_pair.x * NB, col0 = t_pair.y * NB;
-	load_tile(Ps, M, ld, row0, col0);
-	load_tile(Qs, p_invdiag + size_t(t_pair.y) * NB * NB, NB, 0, 0);
-	const int lo = lane & 15, hi = lane >> 4;
-	const bool b_diag = t_pair.z != 0; // workgroup-uniform
-	double cv[4][4];
-	if(b_diag) { // the diagonal tile is requested now, its latency hides behind the two products
-		#pragma unroll
-		for(int c = 0; c < 4; ++ c)
-			#pragma unroll
-			for(int reg = 0; reg < 4; ++ reg)
-				cv[c][reg] = M[size_t(row0 + 16 * c + lo) + size_t(row0 + 16 * wave + hi + 4 * reg) * ld];
-	}
-	__syncthreads();
-	v4f64 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-	tile_product(Ps, Qs, wave, lane, acc);
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			M[size_t(row0 + 16 * c + lo) + size_t(col0 + 16 * wave + hi + 4 * reg) * ld] = acc[c][reg];
-	if(!b_diag)
-		return;
-	__syncthreads(); // every wave is done with Ps
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			Ps[lds_at(16 * wave + hi + 4 * reg, 16 * c + lo)] = acc[c][reg]; // L(i,j) as an operand: [k = column][row]
-	__syncthreads();
-	v4f64 upd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-	tile_product(Ps, Ps, wave, lane, upd);
-	#pragma unroll
-	for(int c = 0; c < 4; ++ c)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			M[size_t(row0 + 16 * c + lo) + size_t(row0 + 16 * wave + hi + 4 * reg) * ld] = cv[c][reg] - upd[c][reg];
+	trsm_tile_body8(M, ld, t_pair.x * NB, t_pair.y * NB, p_invdiag + size_t(t_pair.y) * NB * NB, t_pair.z != 0, s_buf, s_buf + NB * NB);
 }
 
 __global__ void __launch_bounds__(256)
@@ -302,7 +264,7 @@ void tile_cholesky(const CTileSchedule &r_s, double *M, int n_pad, int n, double
 				r_s.d_potrf + p0, p1 - p0, r_s.d_tgt + r0, r_s.d_src);
 		}
 		if(t1 > t0)
-			hipLaunchKernelGGL(tile_trsm_kernel, dim3(t1 - t0), dim3(256), 0, stream, M, n_pad, p_invdiag, r_s.d_trsm + t0);
+			hipLaunchKernelGGL(tile_trsm_kernel, dim3(t1 - t0), dim3(512), 0, stream, M, n_pad, p_invdiag, r_s.d_trsm + t0);
 		if(gu > g0)
 			hipLaunchKernelGGL(tile_update_kernel, dim3(gu - g0), dim3(256), 0, stream, M, n_pad, r_s.d_tgt + g0, r_s.d_src);
 		r0 = gu;
