@@ -1014,6 +1014,13 @@ def main():
                                       points=args.c5_points, label="C5")
                 out["ba_1k_1m"] = run_ba(args, rank, world, local_rank, dist, mode=args.c5_mode, extras=False, cams=args.target_cams,
                                          points=args.target_points, label="north-star target")
+                # ... spelled out: `--gpus N`, N > 1, reports THIS metric on THIS system as its `value` (the pose graph of the N = 1
+                # headline does not shard), so the efficiency of the curve is value(N) / strong_scaling_n1.value, not / `value`
+                out["strong_scaling_n1"] = {"metric": "BA Schur solve GFLOP/s (algorithmic flops / wall-clock)",
+                                            "value": out["ba_c5"].get("GFLOP/s"), "unit": "GFLOP/s",
+                                            "ms_per_step": out["ba_c5"].get("ms_per_step"),
+                                            "workload": out["ba_c5"].get("workload"),
+                                            "note": "the N = 1 point of the curve bench.py --gpus N (N > 1) reports as `value`"}
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0 and out is not None:
