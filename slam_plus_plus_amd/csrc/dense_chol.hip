@@ -328,7 +328,8 @@ __global__ void __launch_bounds__(512)
 dense_backsolve_panel_kernel(const double *M, int ld, int t0, int t1, const double *p_invdiag, double *z, double *x)
 {
 	enum { PARTS = 8, PER = NB / PARTS, N_PAIRS = OUTER_TILES * (OUTER_TILES - 1) / 2 };
-	__shared__ double s_z[OUTER_TILES * NB]; // z of the panel, overwritten by x tile by tile
+	__shared__ double s_z[OUTER_TILES * NB]; // z of the panel
+	__shared__ double s_x[OUTER_TILES * NB]; // x of the panel, tile by tile (an array of its own: nobody waits for the readers of z)
 	const int t = threadIdx.x, c = t / PARTS, part = t % PARTS;
 	const int jb = blockIdx.x;
 	const int m = t1 - t0;
@@ -379,16 +380,16 @@ dense_backsolve_panel_kernel(const double *M, int ld, int t0, int t1, const doub
 			sum += __shfl_xor(sum, 1);
 			sum += __shfl_xor(sum, 2);
 			sum += __shfl_xor(sum, 4);
-			__syncthreads(); // everyone has read z_kb
+			double *xk = s_x + a * NB;
 			if(part == 0)
-				zk[c] = sum;
+				xk[c] = sum;
 			__syncthreads();
 			#pragma unroll
 			for(int b = 0; b < a; ++ b) { // z_j -= L(kb, j)^T x_kb inside the panel
 				double upd = 0;
 				#pragma unroll
 				for(int i = 0; i < PER; ++ i)
-					upd += vl[a * (a - 1) / 2 + b][i] * zk[2 * part + PARTS * (i & ~1) + (i & 1)];
+					upd += vl[a * (a - 1) / 2 + b][i] * xk[2 * part + PARTS * (i & ~1) + (i & 1)];
 				upd += __shfl_xor(upd, 1);
 				upd += __shfl_xor(upd, 2);
 				upd += __shfl_xor(upd, 4);
@@ -400,7 +401,7 @@ dense_backsolve_panel_kernel(const double *M, int ld, int t0, int t1, const doub
 	}
 	if(jb == 0) {
 		for(int i = t; i < m * NB; i += 512)
-			x[t0 * NB + i] = s_z[i];
+			x[t0 * NB + i] = s_x[i];
 	}
 	if(!b_strip)
 		return; // the only workgroup of the first panel just publishes
@@ -410,7 +411,7 @@ dense_backsolve_panel_kernel(const double *M, int ld, int t0, int t1, const doub
 		if(a < m) {
 			#pragma unroll
 			for(int i = 0; i < PER; ++ i)
-				sum += vs[a][i] * s_z[a * NB + 2 * part + PARTS * (i & ~1) + (i & 1)];
+				sum += vs[a][i] * s_x[a * NB + 2 * part + PARTS * (i & ~1) + (i & 1)];
 		}
 	}
 	sum += __shfl_xor(sum, 1);
