@@ -991,6 +991,7 @@ void slampp_hip_solver::Analyze_Sparse()
 		} else
 			panel_pkg.resize(panel_pkg.size() + 64 * PANEL_W, longlong2{0, 0}); // speculative reads past the last package
 	}
+	SETUP_PHASE("packages");
 	d_panel_upd_slots.Upload(upd_slots, stream);
 	d_panel_upd_ents.Upload(upd_ents, stream);
 	d_panel_pkg.Upload(panel_pkg, stream);
