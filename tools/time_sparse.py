@@ -11,7 +11,7 @@ lam = synth.pose_chain(n=n)
 A = lam.to_scipy()
 dev = torch.device("cuda:0")
 vals = torch.from_numpy(lam.values).to(dev)
-for leaf, sub in [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2), (1, 1), (64, 64), (4, 16), (8, 32)]:
+for leaf, sub in [tuple(int(x) for x in a.split(",")) for a in (sys.argv[2:] or ["32,32", "16,16", "8,8", "4,4", "2,2", "1,1", "64,64", "4,16", "8,32"])]:
     s = CLinearSolver_HIP(leaf_size=leaf, subtree_size=sub)
     t0 = time.perf_counter(); s.SymbolicDecomposition_Blocky(lam); t_an = time.perf_counter() - t0
     st = s.stats()
