@@ -89,6 +89,14 @@ def kernel_traffic(traffic, needle):
     return None
 
 
+def kernel_traffic_mean(traffic, needle):
+    """Bytes per launch over every kernel whose name holds the needle, weighted by their launches (template variants of one
+    kernel with different launch counts: the four- and eight-wave slice kernels of one step)."""
+    parts = [(v["hbm_bytes_per_launch_corrected"], v["launches"]) for name, v in traffic.items() if needle in name]
+    n_launches = sum(n for _, n in parts)
+    return (sum(b * n for b, n in parts) / n_launches) if n_launches else None
+
+
 def kernel_traffic_sum(traffic, needle):
     """Bytes per step of every kernel whose name holds the needle (template variants of one kernel: each runs once a step)."""
     parts = [v["hbm_bytes_per_launch_corrected"] for name, v in traffic.items() if needle in name]
@@ -290,7 +298,7 @@ def run_c3(args, rank, world, local_rank, dist):
                         "algorithmic_bytes_per_launch": kb[ph] / launches[ph],
                         "achieved_GBs": kb[ph] / (per_step_ms * 1e-3) / 1e9,
                         "timed_in": "timed region" if ph == "factor_leaves" else "5 extra steps after it",
-                        "hbm_traffic_bytes_per_launch": kernel_traffic(traffic, needles[ph]) if isinstance(needles[ph], str) else
+                        "hbm_traffic_bytes_per_launch": kernel_traffic_mean(traffic, needles[ph]) if isinstance(needles[ph], str) else
                         (lambda parts: (sum(parts) / len(parts)) if all(p is not None for p in parts) else None)(
                             [kernel_traffic(traffic, n_) for n_ in needles[ph]])})
     kernels.sort(key=lambda k: -k["ms_per_step"])
