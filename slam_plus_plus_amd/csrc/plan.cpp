@@ -445,7 +445,7 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 {
 	PlanOptions opt = r_opt;
 	if(const char *p_s_height = getenv("SLAMPP_HIP_TASK_HEIGHT")) // development aid: overrides the option
-		opt.task_height = std::min(std::max(atoi(p_s_height), 1), 3);
+		opt.task_height = std::min(std::max(atoi(p_s_height), 1), 8);
 	if(const char *p_s_balance = getenv("SLAMPP_HIP_ND_BALANCE")) // development aid: likewise
 		opt.nd_balance_pct = std::min(std::max(atoi(p_s_balance), 1), 49);
 	P = Plan();
@@ -864,7 +864,7 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 			int32_t n_first_tall = 1;
 			while(n_first_tall < n_levels && level_tasks[n_first_tall] > opt.task_wide_min)
 				++ n_first_tall;
-			const int h = std::min(opt.task_height, 3);
+			const int h = std::min(opt.task_height, 8);
 			std::vector<int32_t> col_stage(n, 0), grp(n, -1), grp_cols(n, 0), grp_blocks(n, 0);
 			std::vector<char> b_tall(n, 0);
 			for(int32_t j = 0; j < n; ++ j) {

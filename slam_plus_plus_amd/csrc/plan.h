@@ -62,9 +62,11 @@ struct PlanOptions {
 	int nd_balance_pct = 15;  // a separator must leave at least this share (percent) of the vertices on either side; small
 	                          // separators beat balanced halves here: 15 is 5-15 % faster than 25 on pose chains of 30k-300k poses
 	int subtree_size = 8;     // a subtree of at most this many columns is one sequential task (8: best from 2k to 100k poses)
-	int task_height = 3;      // separator tasks above the leaf subtrees: 1 = maximal chains of single children (one tree level
-	                          // per stage), 2 / 3 = slices of the elimination tree that many levels high (a stage, i.e. a
-	                          // launch, then covers that many levels: the launches of a chain-like graph are its critical path)
+	int task_height = 4;      // separator tasks above the leaf subtrees: 1 = maximal chains of single children (one tree level
+	                          // per stage), 2 .. 8 = slices of the elimination tree up to that many levels high (a stage, i.e. a
+	                          // launch, then covers that many levels: the launches of a chain-like graph are its critical path;
+	                          // C3: 3 / 4 / 5 / 6 levels 0.374 / 0.366 / 0.366 / 0.373 ms -- a slice is cut at the panel kernel's
+	                          // capacities anyway, so more than four levels are chains of single columns)
 	int task_wide_min = 1024; // ... above the wide stages: a stage with more tasks than this stays one level high (throughput, not latency)
 	int task_max_cols = 8, task_max_blocks = 96; // what such a slice may hold (the panel kernel's capacities)
 	int dense_top_nb = 24;    // columns with this many blocks or more (and their ancestors) form the dense top; 0 = off

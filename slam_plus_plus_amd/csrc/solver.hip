@@ -1558,7 +1558,7 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 		p_solver->opt.leaf_size = int(n_value);
 	else if(s == "subtree_size" && n_value >= 1)
 		p_solver->opt.subtree_size = int(n_value);
-	else if(s == "task_height" && n_value >= 1 && n_value <= 3)
+	else if(s == "task_height" && n_value >= 1 && n_value <= 8)
 		p_solver->opt.task_height = int(n_value);
 	else if(s == "natural_order")
 		p_solver->opt.natural_order = (n_value != 0);
