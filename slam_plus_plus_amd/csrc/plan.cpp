@@ -446,6 +446,10 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 	PlanOptions opt = r_opt;
 	if(const char *p_s_height = getenv("SLAMPP_HIP_TASK_HEIGHT")) // development aid: overrides the option
 		opt.task_height = std::min(std::max(atoi(p_s_height), 1), 8);
+	if(const char *p_s_cols = getenv("SLAMPP_HIP_TASK_MAX_COLS")) // development aids: likewise
+		opt.task_max_cols = std::min(std::max(atoi(p_s_cols), 1), 64);
+	if(const char *p_s_blocks = getenv("SLAMPP_HIP_TASK_MAX_BLOCKS"))
+		opt.task_max_blocks = std::min(std::max(atoi(p_s_blocks), 1), 1024);
 	if(const char *p_s_balance = getenv("SLAMPP_HIP_ND_BALANCE")) // development aid: likewise
 		opt.nd_balance_pct = std::min(std::max(atoi(p_s_balance), 1), 49);
 	P = Plan();
