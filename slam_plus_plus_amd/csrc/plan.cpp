@@ -320,7 +320,8 @@ double plan_chain_estimate_us(const Plan &P)
 	// measured on MI355X: a separator column costs about 5 us plus 0.08 us per block product (8 us at the
 	// 40 products of a pose-chain separator; 12 vector-memory instructions per product bound it) in the multi-wave
 	// stage kernel, a quarter more in the one-wave kernel, the backward substitution about 3 us per column; a level
-	// of the tile schedule 34 us, a tile of the dense schedule 26 us, four tiles of the dense backward substitution 11 us
+	// of the tile schedule 27 us (34 until the end of round 3), a tile of the dense schedule 26 us, four tiles of the dense
+	// backward substitution 10 us
 	double f_us = 0;
 	const int n_stages = int(P.stage_ptr.size()) - 1;
 	// (round 3, tasks as panels in LDS: a launch of the factorization about 4.5 us, of the backward substitution 3.5; inside a
@@ -353,7 +354,7 @@ double plan_chain_estimate_us(const Plan &P)
 		const int T = dense_top_tile_pattern(P, nz);
 		const std::vector<int> height = tile_symbolic(T, nz);
 		const int n_levels = *std::max_element(height.begin(), height.end()) + 1;
-		f_us += std::min(34.0 * n_levels, 26.0 * T) + 11.0 * ((T + 3) / 4) + 60.0;
+		f_us += std::min(27.0 * n_levels, 26.0 * T) + 10.0 * ((T + 3) / 4) + 60.0;
 	}
 	return f_us;
 }
