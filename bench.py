@@ -49,6 +49,9 @@ F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (vendor figure quoted in 
 C3_REF = {"n": 600_000, "nnz_triu": 7_271_928, "lnz": 8_360_436, "fl": 122_411_332.0}
 
 
+_KEEP = {}
+
+
 def host_cores():
     from oracle import oracle_lib as O
     return O.host_cores()
@@ -152,7 +155,8 @@ def cpu_baseline_c3(lam, counts, x_gpu, budget_reps=12):
             x_ref = np.fromfile(xp, dtype=np.float64)
             out = {"value": counts["flops"] / (ms * 1e-3) / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "reference",
                    "ms_per_solve": ms, "sample": f"{budget_reps} x CLinearSolver_CholMod(CHOLMOD_AUTO, AMD)::Solve_PosDef "
-                   f"on the same 100k-pose system (median; {wall:.1f} s of CPU incl. load); Cholesky/solves are serial in the reference",
+                   f"on the same 100k-pose system (median; {wall:.1f} s of CPU incl. load); serial in the reference; built -O3 -march=x86-64-v3 "
+                   "(the reference's own flag is -march=native; the binary has to run on another host)",
                    "x_gpu_vs_reference_rel_inf": float(np.abs(x_gpu - x_ref).max() / np.abs(x_ref).max())}
             try:
                 ph = subprocess.run([O.REF_HARNESS, "cholmod_phases", path, "auto", "3"], capture_output=True, text=True, timeout=300,
@@ -302,10 +306,23 @@ def run_c3(args, rank, world, local_rank, dist):
                         (lambda parts: (sum(parts) / len(parts)) if all(p is not None for p in parts) else None)(
                             [kernel_traffic(traffic, n_) for n_ in needles[ph]])})
     kernels.sort(key=lambda k: -k["ms_per_step"])
-    # the roofline object is for the kernel that moves the step's bytes: the leaf kernel reads nearly all of Lambda and
-    # writes nearly all of L in ONE launch (the other phases are chains of 3 / 18 / 22 launches of 0.1-4 MB each, bound
-    # by their dependent latency; they are all in `kernels`, and `roofline_whole_step` prices the step as a whole)
-    dom = max(kernels, key=lambda k: k["algorithmic_bytes_per_launch"])
+    gpu_ms = sum(k["ms_per_step"] for k in kernels)
+    for k in kernels:
+        k["share_of_step_time"] = k["ms_per_step"] / gpu_ms if gpu_ms > 0 else None
+    # two roofline objects: `roofline` is for the kernel the step spends most of its time in (since round 3 the panel kernel of
+    # the separator slices: a chain of launches of 0.1-4 MB each, bound by dependent latency, and priced as what it is);
+    # `roofline_leaf_kernel` for the one that moves the step's bytes -- the leaf kernel reads nearly all of Lambda and writes
+    # nearly all of L in ONE launch.  `roofline_whole_step` prices the step as a whole.
+    def roofline_of(k):
+        return {"bound": "hbm", "kernel": k["kernel"], "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": k["achieved_GBs"] / HBM_PEAK_GBS,
+                "traffic": k["hbm_traffic_bytes_per_launch"], "traffic_source": traffic_file,
+                "traffic_measured_in": "builder's rocprofv3 --pmc run of this command (replayed from the committed file, not measured in this run)",
+                "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"],
+                "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"], "share_of_step_time": k["share_of_step_time"],
+                "timed_in": k["timed_in"]}
+    dom = kernels[0]
+    leaf = max(kernels, key=lambda k: k["algorithmic_bytes_per_launch"])
     out = {
         "metric": "Lambda solve GFLOP/s (algorithmic factor+solve flops / wall-clock), 100k-pose SE(3)",
         "value": counts["flops"] * world / (dt / args.steps) / 1e9, "unit": "GFLOP/s",
@@ -320,12 +337,7 @@ def run_c3(args, rank, world, local_rank, dist):
                         "solve_bytes": counts["solve_bytes"], "source": counts["source"]},
         "own_ordering": {"l_nnz": stats["l_nnz"], "factor_flops": stats["factor_flops"], "n_stages": n_stages,
                          "n_tasks": stats["n_tasks"], "analyze_ms_cold": analyze_ms},
-        "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS,
-                     "traffic": dom["hbm_traffic_bytes_per_launch"], "traffic_source": traffic_file,
-                     "traffic_measured_in": "builder's rocprofv3 --pmc run of this command (replayed from the committed file, not measured in this run)",
-                     "avg_launch_us": dom["avg_launch_us"], "launches_per_step": dom["launches_per_step"],
-                     "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
+        "roofline": roofline_of(dom), "roofline_leaf_kernel": roofline_of(leaf),
         "kernels": kernels,
         "roofline_whole_step": {"bound": "hbm", "achieved": (counts["factor_bytes"] + counts["solve_bytes"]) / (dt / args.steps) / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -732,6 +744,8 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
     n_cams, n_points_total = cams or args.ba_cams, points or args.ba_points
     lam_full = shared_system(f"ba_{n_cams}x{n_points_total}_{mode}",
                              lambda: synth.ba(n_cams, n_points_total, k=k, mode=mode, seed=777), rank, world, dist)
+    if world > 1 and rank == 0 and label == "C5":
+        _KEEP["C5"] = lam_full      # the device group leg solves the same system after the ranks are done
     if world > 1:
         lam, own = sharding.landmark_shard(lam_full, rank, world)   # A and eta_x as 1 / world on every rank: the sum is the system
     else:
@@ -870,8 +884,22 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
             "traffic_source": traffic_file,
             "traffic_measured_in": "builder's rocprofv3 --pmc run (replayed from the committed file)" if traffic_file else None,
             "algorithmic_bytes_per_step": nbytes, "ms_per_step": prof["schur_tiles"]}
+        # ... and over EVERY assembly kernel of the step (run / tile / reduce kernels + what the contribution lists of the
+        # landmarks in no run or tile cost: C^-1, W, gather, right-hand side), on the same algorithmic bytes: what the
+        # reference's steps a13-a18 (LinearSolver_Schur.h:1743-1767) cost here as a whole
+        asm_ms = sum(prof.get(k_, 0.0) for k_ in ("schur_tiles", "schur_gather", "schur_points", "schur_rhs", "schur_init"))
+        tr_all = None
+        if traffic:
+            parts = [kernel_traffic_sum(traffic, k_) for k_ in ("schur_run_kernel", "schur_tile_kernel", "schur_tile_reduce_kernel", "schur_gather_S_kernel",
+                                                                "schur_obs_W_kernel", "schur_rhs_kernel", "schur_point_inverse_kernel", "schur_scatter_A_kernel",
+                                                                "schur_wide_kernel")]
+            tr_all = sum(p for p in parts if p) or None
+        out["roofline_schur_assembly_all"] = {
+            "bound": "hbm", "kernel": "every kernel of the assembly of S and r (landmark-major runs / tiles / reduction + contribution lists)",
+            "achieved": nbytes / (asm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": tr_all, "traffic_source": traffic_file, "algorithmic_bytes_per_step": nbytes, "ms_per_step": asm_ms}
         if not b_dense:
-            out["roofline"] = out["roofline_schur_assembly"]
+            out["roofline"] = out["roofline_schur_assembly_all"]
     if "schur_gather" in prof and prof["schur_gather"] > 0.02 and "schur_tiles" not in prof:
         gb = (288.0 * st["n_update_pairs"] + 2 * 8.0 * 36 * st["l_blocks"]) / (prof["schur_gather"] * 1e-3) / 1e9
         out["roofline_schur_gather"] = {"bound": "hbm", "kernel": "schur_gather_S_kernel", "achieved": gb, "peak": HBM_PEAK_GBS,
@@ -920,6 +948,186 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
     return out
 
 
+def _r(v, sig=4):
+    """Numbers of the compact line: four significant digits."""
+    if isinstance(v, bool) or v is None or isinstance(v, (str, int)):
+        return v
+    if isinstance(v, float):
+        return float(f"{v:.{sig}g}")
+    if isinstance(v, dict):
+        return {k_: _r(x, sig) for k_, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, sig) for x in v]
+    return v
+
+
+def _short_roofline(r):
+    if not r:
+        return None
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "share_of_step_time", "avg_launch_us", "launches_per_step")
+    out = {k_: r[k_] for k_ in keep if k_ in r}
+    if isinstance(out.get("kernel"), str) and len(out["kernel"]) > 90:
+        out["kernel"] = out["kernel"][:87] + "..."
+    return out
+
+
+def _leg_summary(leg):
+    """One BA / small-config leg of the full record as {ms_per_step, frac, bound, ...}."""
+    if not leg:
+        return None
+    r = leg.get("roofline") or {}
+    s = {"ms_per_step": leg.get("ms_per_step", leg.get("ms_per_solve")), "bound": r.get("bound"), "frac": r.get("frac")}
+    if leg.get("roofline_reduced_sparse"):
+        s["reduced_solve_ms"] = leg["roofline_reduced_sparse"].get("ms_per_step")
+    if leg.get("roofline_schur_assembly_all"):
+        s["assembly_frac_all_kernels"] = leg["roofline_schur_assembly_all"].get("frac")
+    if leg.get("solve_residual_rel_inf") is not None:
+        s["resid"] = leg["solve_residual_rel_inf"]
+    if leg.get("cpu_baseline"):
+        s["cpu_ref_ms"] = leg["cpu_baseline"].get("ms_per_solve")
+        s["x_vs_ref"] = leg["cpu_baseline"].get("x_gpu_vs_reference_rel_inf")
+    if leg.get("reference_cholmod_ms") is not None:
+        s["cpu_ref_ms"] = leg["reference_cholmod_ms"]
+    if leg.get("analyze_ms_cold") is not None:
+        s["analyze_ms_cold"] = leg["analyze_ms_cold"]
+    if leg.get("host_path"):
+        s["host_warm_ms"] = leg["host_path"].get("warm_host_ms")
+    if leg.get("dropin_cpp") and isinstance(leg["dropin_cpp"], dict) and "hip_warm_ms_median" in leg["dropin_cpp"]:
+        s["dropin_warm_ms"] = leg["dropin_cpp"]["hip_warm_ms_median"]
+    return s
+
+
+COMPACT_LIMIT = 8000     # bytes: the driver's record keeps an 8 KB tail, and round 3's 21.5 KB line was not parsed
+
+
+def compact_line(out, full_path):
+    """The ONE stdout line: the contract's keys, `roofline`, `cpu_baseline`, what a caller with host arrays pays, and one
+    {ms_per_step, frac} entry per other leg.  Everything else lives in the side file `full`."""
+    line = {k_: out.get(k_) for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                      "scaling", "vs_baseline", "dtype", "data", "config")}
+    line["roofline"] = _short_roofline(out.get("roofline"))
+    for k_ in ("roofline_leaf_kernel", "roofline_whole_step"):
+        if out.get(k_):
+            line[k_] = _short_roofline(out[k_])
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k_: cb[k_] for k_ in ("value", "unit", "cores", "kind", "ms_per_solve", "numeric_only_ms") if k_ in cb}
+        line["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:160]
+        if "native_block_solver_ms" in cb:
+            line["cpu_baseline"]["native_block_solver_warm_ms"] = cb["native_block_solver_ms"].get("warm")
+            line["cpu_baseline"]["native_block_solver_first_call_ms"] = cb["native_block_solver_ms"].get("first_call")
+        if cb.get("ms_per_solve") and out.get("ms_per_step"):
+            line["speedup_vs_cpu_baseline"] = cb["ms_per_solve"] / out["ms_per_step"]
+    else:
+        line["cpu_baseline"] = None
+    for k_ in ("solve_residual_rel_inf", "solve_x_vs_reference_rel_inf", "exchange", "rccl_ranks"):
+        if out.get(k_) is not None:
+            line[k_] = out[k_]
+    # SURVEY 8d's "warm" and "cold": a caller with host arrays / a CUberBlockMatrix (PCIe inclusive; never `value`)
+    hp, dc = out.get("host_path"), out.get("dropin_cpp")
+    if hp:
+        line["ms_per_step_host_warm"] = hp.get("warm_host_ms")
+        line["ms_cold"] = hp.get("cold_ms")
+    if isinstance(dc, dict) and "hip_warm_ms_median" in dc:
+        line["ms_per_step_dropin_warm"] = dc.get("hip_warm_ms_median")
+        line["ms_dropin_first_call"] = dc.get("hip_cold_ms")
+    if out.get("own_ordering"):
+        line["analyze_ms_cold"] = out["own_ordering"].get("analyze_ms_cold")
+    legs = {}
+    for key in ("ba_schur", "ba_schur_band", "ba_schur_uniform_dense_S", "ba_schur_venice", "ba_c5", "ba_1k_1m"):
+        if out.get(key):
+            legs[key] = _leg_summary(out[key])
+    for key, rec in (out.get("other_configs") or {}).items():
+        legs[key] = _leg_summary(rec)
+    if out.get("pose_graph_replicas"):
+        legs["pose_graph_replicas"] = {"ms_per_step": out["pose_graph_replicas"].get("ms_per_step"), "value": out["pose_graph_replicas"].get("value")}
+    if out.get("device_group"):
+        g = out["device_group"]
+        legs["device_group"] = {k_: g.get(k_) for k_ in ("members", "exchange", "rccl_ranks", "warm_host_ms", "single_device_warm_host_ms",
+                                                          "speedup_vs_single_device", "resid")}
+    if legs:
+        line["legs"] = legs
+    for k_ in ("strong_scaling_n1", "scaling_model"):
+        if out.get(k_):
+            line[k_] = {a: b for a, b in out[k_].items() if a not in ("workload", "note", "metric")}
+    line["full"] = full_path
+    text = json.dumps(_r(line))
+    if len(text) >= COMPACT_LIMIT:       # never again an unparseable headline: shed the optional parts, keep the contract
+        for k_ in ("legs", "scaling_model", "roofline_whole_step", "roofline_leaf_kernel"):
+            line.pop(k_, None)
+            text = json.dumps(_r(line))
+            if len(text) < COMPACT_LIMIT:
+                break
+    assert len(text) < COMPACT_LIMIT, len(text)
+    return text
+
+
+def scaling_model(leg):
+    """Amdahl model of the landmark-sharded solve from the one-GPU phases of the same system: assembly and the landmarks'
+    back-substitution shard, the reduced camera system's solve is repeated on every rank (the exchange adds an all-reduce of
+    the packed blocks, not modelled)."""
+    ph = leg.get("phases_ms") or {}
+    serial = sum(ph.get(k_, 0.0) for k_ in ("reduced_sparse", "dense_chol", "dense_solve", "schur_init"))
+    total = leg["ms_per_step"]
+    sharded = max(total - serial, 0.0)
+    return {"workload": leg.get("workload"), "serial_ms": serial, "sharded_ms": sharded,
+            "predicted_speedup": {str(n_): total / (serial + sharded / n_) for n_ in (2, 4, 8)},
+            "note": "serial = reduced camera system (every rank factors the same S); sharded = Schur assembly + landmark back-substitution"}
+
+
+def device_group_leg(args, n_members, one_device, lam=None):
+    """The path a drop-in SLAM++ binary takes with SLAMPP_HIP_DEVICES=0,..,N-1: ONE process, one handle made by
+    slampp_hip_create_multi over N devices, host arrays in, solution out (PCIe inclusive).  Next to it the same call on a
+    one-device handle.  Reference counterpart: one caller thread, NonlinearSolver_Lambda_LM.h:1543-1552."""
+    from slam_plus_plus_amd import synth
+    from slam_plus_plus_amd.hip_solver import CLinearSolver_Schur_HIP
+    if lam is None:
+        lam = synth.ba(args.c5_cams, args.c5_points, k=4, mode=args.c5_mode, seed=777)
+    devices = [0] * n_members if one_device else list(range(n_members))
+    out = {"workload": f"C5: BA {args.c5_cams} cams x {args.c5_points} points through slampp_hip_create_multi({devices}), host arrays in and out",
+           "devices": devices}
+    keep = {}
+    for name, devs in (("single", [devices[0]]), ("group", devices)):
+        solver = CLinearSolver_Schur_HIP(device=devs[0]) if name == "single" else CLinearSolver_Schur_HIP(devices=devs)
+        r = host_path_leg(lambda: solver, lam, reps=args.group_reps)
+        eta = lam.rhs.copy()
+        ok = solver.Solve_PosDef_Blocky(lam, eta)
+        r["resid"] = float(np.abs(lam.to_scipy() @ eta - lam.rhs).max() / np.abs(lam.rhs).max()) if ok else None
+        if name == "group":
+            info = solver.group_info()
+            r.update(members=info["members"], exchange=info["exchange"])
+        keep[name] = r
+        del solver
+    g = keep["group"]
+    ex = g.get("exchange") or ""
+    out.update(members=g.get("members"), exchange=ex, rccl_ranks=(g.get("members") if ex.startswith("rccl") else 0),
+               warm_host_ms=g["warm_host_ms"], cold_ms=g["cold_ms"], resid=g["resid"], last_call_ms=g["last_call_ms"],
+               single_device_warm_host_ms=keep["single"]["warm_host_ms"], single_device_cold_ms=keep["single"]["cold_ms"],
+               speedup_vs_single_device=keep["single"]["warm_host_ms"] / g["warm_host_ms"], ok=bool(g["ok"]))
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks ourselves (torch.distributed.run, one per
+    GPU) as a child -- nothing in this process has touched the GPU -- and leave with its code.  Fewer than N devices: exit
+    non-zero, never a silent one-GPU run."""
+    import socket
+    import torch
+    one_device = os.environ.get("SLAMPP_BENCH_ONE_DEVICE") == "1"
+    n_dev = torch.cuda.device_count()      # counting devices does not initialise the GPU on this image
+    if n_dev < (1 if one_device else args.gpus):
+        log(f"bench.py --gpus {args.gpus}: {n_dev} HIP device(s) visible; refusing to report {args.gpus} GPUs from fewer")
+        return 2
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    log("bench.py: starting", args.gpus, "ranks:", " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -940,10 +1148,19 @@ def main():
     ap.add_argument("--c5-mode", default="band", choices=["band", "venice", "uniform"])
     ap.add_argument("--target-cams", type=int, default=1000)
     ap.add_argument("--target-points", type=int, default=1_000_000, help="the north star's 1k-camera / 1M-point system, reported beside C5")
+    ap.add_argument("--full-json", default=None, help="where the full record goes (default gpurun_out/bench_full_n<N>.json); the stdout line is the compact one")
+    ap.add_argument("--group-reps", type=int, default=3, help="warm solves of the in-library device group leg (--gpus N, N > 1)")
+    ap.add_argument("--no-group-leg", action="store_true", help="leave out the one-process device group leg at N > 1")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} started as one of {world} ranks: the launcher's --nproc-per-node and --gpus must agree")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # development aid: SLAMPP_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 with the gloo backend, so that the
     # multi-rank control flow (rendezvous, block-list agreement, max-over-ranks timing) can be run on a 1-GPU box
@@ -952,6 +1169,8 @@ def main():
         local_rank = 0
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
+    if not one_device and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py --gpus {world}: {torch.cuda.device_count()} HIP device(s) visible")
     dist = None
     # SLAMPP_BENCH_FORCE_DIST=1 exercises the RCCL plumbing (process group + all-reduce callback) with one rank
     if world > 1 or os.environ.get("SLAMPP_BENCH_FORCE_DIST") == "1":
@@ -1035,15 +1254,36 @@ def main():
                                             "ms_per_step": out["ba_c5"].get("ms_per_step"),
                                             "workload": out["ba_c5"].get("workload"),
                                             "note": "the N = 1 point of the curve bench.py --gpus N (N > 1) reports as `value`"}
+    if rank == 0 and world == 1 and out is not None and out.get("ba_c5"):
+        out["scaling_model"] = scaling_model(out["ba_c5"])
     if dist is not None:
         dist.destroy_process_group()
-    if rank == 0 and out is not None:
+    if rank != 0:
+        return
+    if world > 1 and out is not None and args.workload in ("all", "ba") and not args.no_group_leg:
+        # the same fixed C5 system through ONE handle over the N devices (what SLAMPP_HIP_DEVICES gives an unchanged SLAM++
+        # binary), after the process group is gone: the other ranks have left their devices
+        time.sleep(1.0)
+        try:
+            out["device_group"] = device_group_leg(args, world, one_device, lam=_KEEP.get("C5"))
+            out["exchange_in_library"] = out["device_group"]["exchange"]
+        except Exception as e:
+            out["device_group"] = {"error": str(e)[:300]}
+    if out is not None:
         try:    # RCCL prints its version banner through C stdio: get it out before the one JSON line, not after it
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        full_path = args.full_json or os.path.join("gpurun_out", f"bench_full_n{world}.json")
+        try:
+            os.makedirs(os.path.dirname(os.path.join(ROOT, full_path)) or ".", exist_ok=True)
+            with open(os.path.join(ROOT, full_path), "w") as f:
+                json.dump(out, f)
+        except OSError as e:
+            log("bench.py: could not write", full_path, e)
+            full_path = None
+        print(compact_line(out, full_path), flush=True)
 
 
 if __name__ == "__main__":

@@ -446,8 +446,13 @@ public:
 		while(p_s_list && *p_s_list) {
 			char *p_s_end;
 			const long n_device = strtol(p_s_list, &p_s_end, 10);
-			if(p_s_end == p_s_list)
-				break;
+			if(p_s_end == p_s_list || n_device < 0 || n_device > 1023 || (*p_s_end && *p_s_end != ',')) {
+				// not a list of device ordinals: refuse all of it rather than run on devices the user did not name
+				fprintf(stderr, "warning: SLAMPP_HIP_DEVICES=\"%s\" is not a comma-separated list of HIP device ordinals: ignored\n",
+					getenv("SLAMPP_HIP_DEVICES"));
+				devices.clear();
+				return devices;
+			}
 			devices.push_back(int(n_device));
 			p_s_list = (*p_s_end == ',')? p_s_end + 1 : p_s_end;
 		}
@@ -679,7 +684,7 @@ public:
 	typedef CBlockwiseLinearSolverTag _Tag; /**< @brief solver type tag */
 
 	inline CLinearSolver_HIP(int n_device = -1)
-		:CLinearSolver_HIP_Base(n_device), m_factorizer((n_device < 0)? 0 : n_device)
+		:CLinearSolver_HIP_Base(n_device), m_factorizer(n_Device()) // (the resolved device: the first of SLAMPP_HIP_DEVICES when n_device < 0)
 	{}
 
 	/**
@@ -687,7 +692,7 @@ public:
 	 *		solver made from this one -- as the nonlinear solvers make theirs, NonlinearSolver_Base.h:400 -- shards BA systems
 	 */
 	inline CLinearSolver_HIP(const std::vector<int> &r_devices)
-		:CLinearSolver_HIP_Base(r_devices), m_factorizer(r_devices.empty()? 0 : r_devices[0])
+		:CLinearSolver_HIP_Base(r_devices), m_factorizer(n_Device())
 	{}
 
 	/**

@@ -35,7 +35,7 @@ enum {
 	SLAMPP_HIP_ERR_INVALID = -1,        /* bad argument / call order */
 	SLAMPP_HIP_ERR_ALLOC = -2,          /* host or device out of memory (reference: std::bad_alloc) */
 	SLAMPP_HIP_ERR_DEVICE = -3,         /* HIP runtime error (reference: std::runtime_error, LinearSolver_Schur.h:1196-1209) */
-	SLAMPP_HIP_ERR_UNSUPPORTED = -4     /* structure outside what this build handles (e.g. block dimension > 8) */
+	SLAMPP_HIP_ERR_UNSUPPORTED = -4     /* an operation outside what this build handles for this structure (block columns wider than 8 are cut into pieces at analysis time and solved; see slampp_hip_factorize / slampp_hip_marginals for what they still need) */
 };
 
 enum {
@@ -88,6 +88,14 @@ int slampp_hip_create_multi(slampp_hip_solver **pp_solver, const int *p_device_i
  * be NULL) and the exchange in use ("rccl (<library>)" / "peer" / "none"; valid until the next analyze) */
 int slampp_hip_group_info(const slampp_hip_solver *p_solver, int *p_member_num, int64_t *p_point_bounds, int n_max_members,
 	const char **pp_s_exchange);
+
+/* how many exchanges (all-reduces of the reduced camera system) the members of a device group have gone into since the
+ * handle was made.  Failure agreement: before a collective is enqueued the members meet at a host barrier with their
+ * status, for RCCL and peer pointers alike; when one of them failed on its way there (allocation, upload, device error)
+ * NOBODY enqueues -- the call returns that member's error, this count does not move, the next solve runs normally.  The
+ * option "group_fail_member" = r + 1 makes member r fail that way (0 = off; a test hook).  The reference has no
+ * counterpart: it is one thread on one device (include/slam/NonlinearSolver_Lambda_LM.h:1543-1552). */
+int slampp_hip_group_exchange_count(const slampp_hip_solver *p_solver, int64_t *p_n_enqueued);
 
 /* the exchange of slampp_hip_create_multi by itself, for deployment checks and tests: one member per listed device,
  * every member fills n_count doubles with a pattern of its own, the buffers are summed twice through the members'

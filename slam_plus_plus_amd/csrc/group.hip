@@ -127,6 +127,7 @@ void landmark_shard(int64_t n_bcols, const int64_t *p_cumsum, const int64_t *p_b
 struct CRccl {
 	typedef int (*TCommInitAll)(void **pp_comms, int n_devices, const int *p_device_list);
 	typedef int (*TCommDestroy)(void *p_comm);
+	typedef int (*TCommAbort)(void *p_comm);
 	typedef int (*TAllReduce)(const void *p_send, void *p_recv, size_t n_count, int n_data_type, int n_op, void *p_comm, hipStream_t stream);
 	typedef const char *(*TGetErrorString)(int n_result);
 	enum { nccl_Float64 = 8, nccl_Sum = 0 }; // rccl.h: ncclDataType_t, ncclRedOp_t
@@ -134,6 +135,7 @@ struct CRccl {
 	void *p_library;
 	TCommInitAll CommInitAll;
 	TCommDestroy CommDestroy;
+	TCommAbort CommAbort; // (may be null: an old library)
 	TAllReduce AllReduce;
 	TGetErrorString GetErrorString;
 	std::string s_where;
@@ -159,6 +161,7 @@ struct CRccl {
 				p->p_library = p_lib;
 				p->CommInitAll = (TCommInitAll)dlsym(p_lib, "ncclCommInitAll");
 				p->CommDestroy = (TCommDestroy)dlsym(p_lib, "ncclCommDestroy");
+				p->CommAbort = (TCommAbort)dlsym(p_lib, "ncclCommAbort");
 				p->AllReduce = (TAllReduce)dlsym(p_lib, "ncclAllReduce");
 				p->GetErrorString = (TGetErrorString)dlsym(p_lib, "ncclGetErrorString");
 				p->s_where = candidates[i].first;
@@ -453,8 +456,13 @@ struct CDeviceGroup {
 	std::atomic<int64_t> n_panel_sequence; // solve number * 65536 + panels recorded so far in that solve
 	int64_t n_factor_calls[GROUP_MAX_MEMBERS];
 	std::string s_exchange_name;
+	bool b_peer_access; // every member can read and write every other member's device memory (peer access enabled, or one device)
+	std::atomic<bool> b_exchange_broken; // a collective failed after the members had agreed to enqueue it: the communicators are aborted and made anew
+	std::atomic<int64_t> n_collectives_enqueued; // exchanges the members went into (all of them, or none: see group_members_agree)
+	int n_fail_member; // test hook (option "group_fail_member"): this member + 1 fails on its way to the exchange
 
-	CDeviceGroup() :p_threads(0), n_active(0), n_exchange_option(EXCHANGE_AUTO), n_exchange(EXCHANGE_PEER), n_panel_sequence(0)
+	CDeviceGroup() :p_threads(0), n_active(0), n_exchange_option(EXCHANGE_AUTO), n_exchange(EXCHANGE_PEER), n_panel_sequence(0),
+		b_peer_access(false), b_exchange_broken(false), n_collectives_enqueued(0), n_fail_member(0)
 	{
 		memset(ev_assembled, 0, sizeof(ev_assembled));
 		memset(n_factor_calls, 0, sizeof(n_factor_calls));
@@ -482,6 +490,35 @@ static void grow_device(double *&r_p, size_t &r_n, size_t n_doubles) // on the c
 	r_n = n_doubles;
 }
 
+// Failure agreement, the same for both exchanges: before anything that another member would wait for is enqueued (an
+// ncclAllReduce parks the stream until every rank has joined; a peer reduction reads the others' buffers) the members
+// meet at the host barrier.  A member that failed on its way here (allocation, upload, device error) has called
+// barrier.Abort() instead: the barrier lets everybody through with `false`, and NOBODY enqueues.  group_finish() opens the
+// barrier again for the next solve.
+static bool group_members_agree(CDeviceGroup &g)
+{
+	return g.barrier.b_Wait();
+}
+
+// a collective that failed after the agreement: the other members' streams may be parked in it.  Abort every communicator
+// (that is what releases them) and have the next solve make new ones.
+static void group_break_exchange(CDeviceGroup &g)
+{
+	bool b_expected = false;
+	if(!g.b_exchange_broken.compare_exchange_strong(b_expected, true))
+		return;
+	CRccl *p_rccl = CRccl::p_Get();
+	if(p_rccl && p_rccl->CommAbort) {
+		for(size_t i = 0; i < g.comms.size(); ++ i) {
+			if(g.comms[i]) {
+				(void)p_rccl->CommAbort(g.comms[i]);
+				g.comms[i] = 0;
+			}
+		}
+	}
+	g.barrier.Abort();
+}
+
 static int group_allreduce_callback(void *p_context, double *p_dev, size_t n_count, void *p_hip_stream)
 {
 	TMemberContext &t = *(TMemberContext*)p_context;
@@ -489,10 +526,22 @@ static int group_allreduce_callback(void *p_context, double *p_dev, size_t n_cou
 	const int r = t.n_member, n_members = g.n_active;
 	hipStream_t stream = (hipStream_t)p_hip_stream;
 	if(g.n_exchange == EXCHANGE_RCCL) {
+		g.peer_counts[r] = n_count;
+		if(!group_members_agree(g)) // one member is not coming: nobody enqueues
+			return 1;
+		for(int k = 0; k < n_members; ++ k) {
+			if(g.peer_counts[k] != n_count) {
+				g.barrier.Abort();
+				return 1; // the members do not agree on what they exchange
+			}
+		}
 		CRccl *p_rccl = CRccl::p_Get();
+		if(r == 0)
+			++ g.n_collectives_enqueued;
 		const int n_result = p_rccl->AllReduce(p_dev, p_dev, n_count, CRccl::nccl_Float64, CRccl::nccl_Sum, g.comms[r], stream);
 		if(n_result != 0) {
 			fprintf(stderr, "libslampp_hip: ncclAllReduce failed on member %d: %s\n", r, p_rccl->GetErrorString(n_result));
+			group_break_exchange(g);
 			return 1;
 		}
 		return 0;
@@ -505,7 +554,7 @@ static int group_allreduce_callback(void *p_context, double *p_dev, size_t n_cou
 		g.barrier.Abort();
 		return 1;
 	}
-	if(!g.barrier.b_Wait())
+	if(!group_members_agree(g))
 		return 1;
 	for(int k = 0; k < n_members; ++ k) {
 		if(g.peer_counts[k] != n_count) {
@@ -513,6 +562,8 @@ static int group_allreduce_callback(void *p_context, double *p_dev, size_t n_cou
 			return 1; // the members do not agree on what they exchange
 		}
 	}
+	if(r == 0)
+		++ g.n_collectives_enqueued;
 	const TPeerBuffers t_buffers = g.t_peer_buffers;
 	const size_t n_begin = n_count * size_t(r) / size_t(n_members), n_end = n_count * size_t(r + 1) / size_t(n_members);
 	if(n_end > n_begin) {
@@ -594,9 +645,12 @@ static int group_dense_factor_callback(void *p_context, double *p_S, int n_pad, 
 				return fail();
 			b_ahead = false;
 		} else {
-			while(g.n_panel_sequence.load() < n_solve * 65536 + b + 1) { // the owner has recorded the event: now it can be waited for
+			const double f_wait_t0 = wall_ms();
+			for(int n_spin = 0; g.n_panel_sequence.load() < n_solve * 65536 + b + 1; ++ n_spin) { // the owner has recorded the event: now it can be waited for
 				if(g.barrier.b_Aborted())
 					return 1;
+				if(!(n_spin & 1023) && wall_ms() - f_wait_t0 > 120e3) // two minutes for one panel: the owner is not coming
+					return fail();
 				std::this_thread::yield();
 			}
 			if(hipStreamWaitEvent(stream, g.ev_panel[b], 0) != hipSuccess)
@@ -706,6 +760,12 @@ int group_set_option(CDeviceGroup &g, const char *p_s_name, int64_t n_value)
 		g.n_exchange_option = int(n_value);
 		return SLAMPP_HIP_OK;
 	}
+	if(!strcmp(p_s_name, "group_fail_member")) { // test hook: member n_value - 1 fails on its way to the exchange (0: nobody)
+		if(n_value < 0 || n_value > int64_t(g.members.size()))
+			return SLAMPP_HIP_ERR_INVALID;
+		g.n_fail_member = int(n_value);
+		return SLAMPP_HIP_OK;
+	}
 	if(!strcmp(p_s_name, "shard_primary") || !strcmp(p_s_name, "shard_rank") || !strcmp(p_s_name, "shard_world") ||
 	   !strcmp(p_s_name, "staging_ahead"))
 		return SLAMPP_HIP_OK; // the group decides those for its members (which never take host arrays: no staging of their own)
@@ -720,6 +780,11 @@ const char *group_exchange_name(const CDeviceGroup &g)
 	return g.s_exchange_name.c_str();
 }
 
+int64_t group_exchange_count(const CDeviceGroup &g)
+{
+	return g.n_collectives_enqueued.load();
+}
+
 int group_member_num(const CDeviceGroup &g)
 {
 	return g.n_active;
@@ -730,15 +795,46 @@ slampp_hip_solver *group_member(CDeviceGroup &g, int n_member)
 	return (n_member >= 0 && n_member < int(g.members.size()))? g.members[n_member] : 0;
 }
 
+// peer access between every pair of distinct member devices -- whatever exchange is chosen: the distributed factorization
+// reads and writes the other members' buffers through raw pointers also when the all-reduce is RCCL's (relying on whatever
+// mappings RCCL made internally would be a memory fault waiting to happen).  false: some pair cannot.
+static bool group_enable_peer_access(CDeviceGroup &g, std::string &r_s_why)
+{
+	const int n = g.n_active;
+	for(int i = 0; i < n; ++ i) {
+		for(int j = 0; j < n; ++ j) {
+			if(g.devices[i] == g.devices[j])
+				continue;
+			int b_can = 0;
+			if(hipDeviceCanAccessPeer(&b_can, g.devices[i], g.devices[j]) != hipSuccess || !b_can) {
+				(void)hipGetLastError();
+				r_s_why = "device " + std::to_string(g.devices[i]) + " cannot access device " + std::to_string(g.devices[j]);
+				return false;
+			}
+			(void)hipSetDevice(g.devices[i]);
+			const hipError_t e = hipDeviceEnablePeerAccess(g.devices[j], 0);
+			(void)hipGetLastError();
+			if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+				r_s_why = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e);
+				return false;
+			}
+		}
+	}
+	return true;
+}
+
 static void group_resolve_exchange(CDeviceGroup &g) // throw(CDeviceError)
 {
 	group_release_exchange(g);
+	g.b_exchange_broken = false;
 	const int n = g.n_active;
 	bool b_distinct = true;
 	for(int i = 0; i < n; ++ i) {
 		for(int j = 0; j < i; ++ j)
 			b_distinct = b_distinct && g.devices[i] != g.devices[j];
 	}
+	std::string s_no_peer;
+	g.b_peer_access = group_enable_peer_access(g, s_no_peer);
 	int n_want = g.n_exchange_option;
 	if(const char *p_s_env = getenv("SLAMPP_HIP_GROUP_EXCHANGE")) {
 		if(!strcmp(p_s_env, "rccl"))
@@ -769,22 +865,10 @@ static void group_resolve_exchange(CDeviceGroup &g) // throw(CDeviceError)
 			return;
 		}
 	}
+	if(!g.b_peer_access)
+		throw CDeviceError("device group: the devices cannot read each other's memory (" + s_no_peer + ") and RCCL is not available");
 	g.n_exchange = EXCHANGE_PEER;
 	g.s_exchange_name = (n > 1)? "peer" : "none (one member)";
-	for(int i = 0; i < n; ++ i) { // every member reads every other member's buffer
-		for(int j = 0; j < n; ++ j) {
-			if(g.devices[i] == g.devices[j])
-				continue;
-			int b_can = 0;
-			if(hipDeviceCanAccessPeer(&b_can, g.devices[i], g.devices[j]) != hipSuccess || !b_can)
-				throw CDeviceError("device group: the devices cannot read each other's memory and RCCL is not available");
-			(void)hipSetDevice(g.devices[i]);
-			const hipError_t e = hipDeviceEnablePeerAccess(g.devices[j], 0);
-			if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
-				throw CDeviceError(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
-			(void)hipGetLastError();
-		}
-	}
 }
 
 // splits the front handle's structure into landmark shards and analyzes every member (Schur mode) on its own thread
@@ -821,7 +905,9 @@ void group_analyze(slampp_hip_solver &r_front, int64_t n_cut) // throws
 		if(n_status == SLAMPP_HIP_OK) {
 			n_status = slampp_hip_set_allreduce(p_member, (n_active > 1)? group_allreduce_callback : (slampp_hip_allreduce_fn)0,
 				&g.contexts[r]);
-			p_member->p_dense_factor = (n_active > 1)? group_dense_factor_callback : (slampp_hip_solver::TDenseFactorFn)0;
+			// (the distributed factorization works through peer pointers whatever the all-reduce is: without peer access the
+			// option schur_distributed is ignored and every member factors the summed system itself)
+			p_member->p_dense_factor = (n_active > 1 && g.b_peer_access)? group_dense_factor_callback : (slampp_hip_solver::TDenseFactorFn)0;
 			p_member->p_dense_factor_context = &g.contexts[r];
 		}
 		if(n_status == SLAMPP_HIP_OK) {
@@ -869,7 +955,27 @@ static int group_finish(slampp_hip_solver &r_front, CDeviceGroup &g, int n_resul
 			r_front.s_error += " member " + std::to_string(r) + ": " + r_errors[r] + ";";
 	}
 	g.barrier.Reset(g.n_active); // (an aborted exchange leaves the barrier closed)
+	// the members count their calls of the distributed factorization and order their event waits by that count: one that
+	// failed before it got there is a call behind the others.  Nobody is inside a solve now: everybody back to zero.
+	memset(g.n_factor_calls, 0, sizeof(g.n_factor_calls));
+	g.n_panel_sequence = 0;
 	return n_result;
+}
+
+// before a solve: a collective that failed in the last one took the communicators with it
+static int group_repair_exchange(slampp_hip_solver &r_front, CDeviceGroup &g)
+{
+	if(!g.b_exchange_broken)
+		return SLAMPP_HIP_OK;
+	try {
+		group_resolve_exchange(g);
+		g.barrier.Reset(g.n_active);
+		(void)hipSetDevice(r_front.n_device);
+	} catch(std::exception &r_exc) {
+		r_front.s_error = std::string("device group: the exchange could not be set up again: ") + r_exc.what();
+		return SLAMPP_HIP_ERR_DEVICE;
+	}
+	return SLAMPP_HIP_OK;
 }
 
 enum { GROUP_SOLVE = 0, GROUP_MARGINAL_POSES = 1 };
@@ -879,6 +985,8 @@ static int group_solve_kind(slampp_hip_solver &r_front, const double *p_values, 
 {
 	CDeviceGroup &g = *r_front.p_group;
 	const int n_active = g.n_active;
+	if(const int n_repair = group_repair_exchange(r_front, g))
+		return n_repair;
 	std::vector<std::string> errors(g.members.size());
 	const double f_t0 = wall_ms();
 	std::vector<double> upload_ms(g.members.size(), 0.0), solve_ms(g.members.size(), 0.0);
@@ -893,6 +1001,11 @@ static int group_solve_kind(slampp_hip_solver &r_front, const double *p_values, 
 		int n_status = SLAMPP_HIP_OK;
 		const double f_m0 = wall_ms();
 		hipError_t e = hipSuccess;
+		if(g.n_fail_member == r + 1) { // test hook: what an allocation or device error on the way to the exchange does
+			errors[r] = "injected failure (option group_fail_member)";
+			g.barrier.Abort();
+			return SLAMPP_HIP_ERR_DEVICE;
+		}
 		if(r == 0 && n_kind == GROUP_SOLVE) { // the primary adds A and the camera part of eta
 			e = hipMemcpyAsync(t_shard.p_values_dev, p_values, size_t(t.n_camera_values) * sizeof(double), hipMemcpyHostToDevice, stream);
 			if(e == hipSuccess)
@@ -959,6 +1072,8 @@ int group_schur_marginals(slampp_hip_solver &r_front, const double *p_values, do
 	const int64_t n_cut = r_front.n_matrix_cut;
 	const int64_t dc = r_front.cumsum[1] - r_front.cumsum[0], dp = r_front.cumsum[size_t(n_cut) + 1] - r_front.cumsum[size_t(n_cut)];
 	const size_t n_cam_doubles = size_t(n_cut * dc * dc);
+	if(const int n_repair = group_repair_exchange(r_front, g))
+		return n_repair;
 	std::vector<std::string> errors(g.members.size());
 	const int n_result = g.p_threads->n_Run([&](int r) -> int {
 		if(r >= n_active)

@@ -269,6 +269,7 @@ int group_free_memory(CDeviceGroup &g);
 void group_fill_stats(CDeviceGroup &g, slampp_hip_stats &r_stats);
 const char *group_exchange_name(const CDeviceGroup &g);
 int group_member_num(const CDeviceGroup &g);
+int64_t group_exchange_count(const CDeviceGroup &g);
 slampp_hip_solver *group_member(CDeviceGroup &g, int n_member);
 void shard_bounds(int64_t n_bcols, int64_t n_cut, const int64_t *p_bcol_ptr, int n_world, std::vector<int64_t> &r_bounds);
 

@@ -1532,7 +1532,8 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver)
 	return p_solver? p_solver->s_error.c_str() : "null solver handle";
 }
 
-int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int64_t n_value)
+// the option itself, on this handle (and on the members of its device group, if they exist)
+static int set_option_checked(slampp_hip_solver *p_solver, const char *p_s_name, int64_t n_value)
 {
 	if(!p_solver || !p_s_name)
 		return SLAMPP_HIP_ERR_INVALID;
@@ -1543,18 +1544,11 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 		if(n_group_result != SLAMPP_HIP_OK)
 			return fail(p_solver, n_group_result, "unknown option or value out of range");
 	}
-	if(!p_solver->group_devices.empty()) { // (and members that do not exist yet will be given them)
-		size_t i = 0;
-		while(i < p_solver->group_options.size() && p_solver->group_options[i].first != s)
-			++ i;
-		if(i == p_solver->group_options.size())
-			p_solver->group_options.push_back(std::make_pair(s, n_value));
-		else
-			p_solver->group_options[i].second = n_value;
-	}
 	if(s == "group_exchange" && n_value >= 0 && n_value <= 2) {
 		// (without a device list there is nothing to exchange: accepted, so that one configuration serves both)
-	} else if(s == "leaf_size" && n_value >= 1)
+	} else if(s == "group_fail_member" && n_value >= 0 && n_value <= 16)
+		return SLAMPP_HIP_OK; // test hook of the device group (group.hip): nothing on a single-device handle
+	else if(s == "leaf_size" && n_value >= 1)
 		p_solver->opt.leaf_size = int(n_value);
 	else if(s == "subtree_size" && n_value >= 1)
 		p_solver->opt.subtree_size = int(n_value);
@@ -1628,6 +1622,32 @@ int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int
 	else
 		return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "unknown option or value out of range");
 	p_solver->b_analyzed = false; // options take effect at the next analyze
+	return SLAMPP_HIP_OK;
+}
+
+int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int64_t n_value)
+{
+	const int n_result = set_option_checked(p_solver, p_s_name, n_value);
+	// recorded for members that do not exist yet -- only once the handle has accepted it: a refused option that was
+	// recorded anyway would be replayed into the group at the first Schur-mode analysis and fail every analysis after it
+	if(n_result == SLAMPP_HIP_OK && !p_solver->group_devices.empty()) {
+		const std::string s(p_s_name);
+		size_t i = 0;
+		while(i < p_solver->group_options.size() && p_solver->group_options[i].first != s)
+			++ i;
+		if(i == p_solver->group_options.size())
+			p_solver->group_options.push_back(std::make_pair(s, n_value));
+		else
+			p_solver->group_options[i].second = n_value;
+	}
+	return n_result;
+}
+
+int slampp_hip_group_exchange_count(const slampp_hip_solver *p_solver, int64_t *p_n_enqueued)
+{
+	if(!p_solver || !p_n_enqueued)
+		return SLAMPP_HIP_ERR_INVALID;
+	*p_n_enqueued = p_solver->p_group? group_exchange_count(*p_solver->p_group) : 0;
 	return SLAMPP_HIP_OK;
 }
 

@@ -81,6 +81,7 @@ ABI = {
     "slampp_hip_create": (C.c_int, [C.POINTER(_P), C.c_int]),
     "slampp_hip_create_multi": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int), C.c_int]),
     "slampp_hip_group_info": (C.c_int, [_P, C.POINTER(C.c_int), _P, C.c_int, C.POINTER(C.c_char_p)]),
+    "slampp_hip_group_exchange_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "slampp_hip_group_exchange_selftest": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int64, C.c_char_p, C.c_int]),
     "slampp_hip_landmark_shard": (C.c_int, [C.c_int64, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.POINTER(ShardView)]),
     "slampp_hip_destroy": (None, [_P]),
@@ -252,7 +253,8 @@ class _SolverBase:
             rc = self._lib.slampp_hip_create(C.byref(self._h), int(device))
         if rc == ERR_INVALID:
             self._h = None
-            raise ValueError(f"slampp_hip_create_multi(devices={self._devices}) refused the device list")
+            raise ValueError(f"slampp_hip_create_multi(devices={self._devices}) refused the device list" if self._devices is not None
+                             else f"slampp_hip_create(device={device}) refused the device ordinal")
         if rc != OK:
             self._h = None
             raise RuntimeError(f"slampp_hip_create(device={device}) failed ({rc}): no usable HIP device")
@@ -282,6 +284,12 @@ class _SolverBase:
         self._check(self._lib.slampp_hip_group_info(self._h, C.byref(n), _ptr(bounds), 16, C.byref(name)))
         return {"members": n.value, "point_bounds": bounds[:n.value + 1].tolist() if n.value else [],
                 "exchange": (name.value or b"").decode()}
+
+    def exchange_count(self) -> int:
+        """Exchanges the members of a device group have gone into (slampp_hip_group_exchange_count): all of them or none."""
+        n = C.c_int64(0)
+        self._check(self._lib.slampp_hip_group_exchange_count(self._h, C.byref(n)))
+        return int(n.value)
 
     def __del__(self):
         try:

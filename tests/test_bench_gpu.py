@@ -14,17 +14,31 @@ SMALL = ["--poses", "3000", "--ba-cams", "60", "--ba-points", "4000", "--steps",
          "--no-cpu-baseline", "--ba-legs", "band", "--c5-cams", "60", "--c5-points", "6000", "--target-cams", "40", "--target-points", "3000"]
 
 
-def last_json(text):
+def last_json(text, full=True):
+    """The compact stdout line (checked: under 8 KB, carries the contract's keys) merged over the full record it points to."""
     lines = [l for l in text.splitlines() if l.startswith("{")]
     assert lines, text[-2000:]
-    return json.loads(lines[-1])
+    assert len(lines[-1]) < 8000, len(lines[-1])
+    line = json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "full"):
+        assert k in line, k
+    if not full:
+        return line
+    d = json.load(open(os.path.join(ROOT, line["full"])))
+    for k in ("metric", "n_gpus", "scaling"):
+        assert d[k] == line[k], k
+    assert abs(d["value"] - line["value"]) <= 1e-3 * abs(d["value"])
+    return d
 
 
 @pytest.mark.parametrize("workload", ["c3", "ba"])
 def test_bench_line(workload):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload] + SMALL,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--full-json", f"gpurun_out/test_bench_{workload}.json"] + SMALL,
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
+    line = last_json(r.stdout, full=False)
+    assert line["roofline"]["frac"] > 0 and line["ms_per_step"] > 0
     d = last_json(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config", "roofline"):
         assert k in d, k
@@ -47,10 +61,15 @@ def test_bench_ranks_on_one_device_strong_scaling(world):
     them, and the residual of the FULL system assembled from the ranks' pieces -- the parity guard of the sharded solve."""
     env = dict(os.environ, SLAMPP_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + SMALL
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--full-json",
+           f"gpurun_out/test_bench_ranks{world}.json"] + SMALL
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
+    line = last_json(r.stdout, full=False)
+    assert line["legs"]["device_group"]["members"] == world and line["legs"]["device_group"]["resid"] < 1e-9
     d = last_json(r.stdout)
+    g = d["device_group"]     # one process, one handle over `world` members (here: all on device 0, peer exchange)
+    assert g["ok"] and g["members"] == world and g["exchange"] and g["resid"] < 1e-9, g
     assert d["n_gpus"] == world and d["scaling"] == "strong" and d["value"] > 0
     assert "C5" in d["config"]["workload"] and "60 cams x 6000 points" in d["config"]["workload"]
     for key in ("ba_c5", "ba_1k_1m"):
@@ -62,9 +81,35 @@ def test_bench_ranks_on_one_device_strong_scaling(world):
 
 
 def test_bench_default_run_carries_the_n1_points_of_the_scaling_curves():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-json", "gpurun_out/test_bench_default.json"] + SMALL,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
+    line = last_json(r.stdout, full=False)
+    assert set(("ba_schur", "ba_c5", "ba_1k_1m")) <= set(line["legs"]) and line["scaling_model"]["serial_ms"] > 0
+    assert set(line["scaling_model"]["predicted_speedup"]) == {"2", "4", "8"}
     d = last_json(r.stdout)
     assert d["n_gpus"] == 1 and "C3" in d["config"]["workload"]
     for key in ("ba_schur", "ba_c5", "ba_1k_1m"):
         assert d[key]["n_gpus"] == 1 and d[key]["solve_residual_rel_inf"] < 1e-9, key
+
+
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` by itself: the ranks are started by bench.py (here both on device 0: SLAMPP_BENCH_ONE_DEVICE), the
+    line says n_gpus 2 -- never a silent one-GPU run."""
+    env = dict(os.environ, SLAMPP_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "ba", "--full-json",
+                        "gpurun_out/test_bench_spawn2.json"] + SMALL, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = last_json(r.stdout, full=False)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+
+
+def test_bench_refuses_more_gpus_than_there_are():
+    import torch
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SLAMPP_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1)] + SMALL, capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout[-500:]

@@ -23,9 +23,22 @@ from slam_plus_plus_amd import sharding, synth
 from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP, CLinearSolver_Schur_HIP
 from oracle import oracle_lib as O
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
 needs_reference = pytest.mark.skipif(not O.have_reference(), reason="oracle/_ref/ref_harness is not built")
+
+
+def test_the_compiled_reference_travelled_with_the_repository():
+    """The full-size tests below compare with the LIVE reference (oracle/_ref/ref_harness, built in the build container by
+    __graft_entry__.build() from /root/reference and shipped to the GPU box as a binary: git-ignored, not gpurun-ignored).
+    Where it is missing they skip -- and a skip is easy to overlook, so this test is loud about it: it fails unless
+    SLAMPP_ALLOW_NO_REFERENCE=1 says that a checkout without the reference's binaries is what was meant."""
+    if os.environ.get("SLAMPP_ALLOW_NO_REFERENCE") == "1":
+        pytest.skip("SLAMPP_ALLOW_NO_REFERENCE=1")
+    missing = [f for f in ("ref_harness", "dropin_driver") if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", f))]
+    assert not missing, f"oracle/_ref/{missing} not present: run __graft_entry__.build() where /root/reference exists, or set SLAMPP_ALLOW_NO_REFERENCE=1"
 
 
 def rel_inf(x, ref):

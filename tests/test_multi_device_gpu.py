@@ -129,6 +129,70 @@ def test_distributed_dense_factorization_of_the_reduced_system(built, members):
     assert multi.Solve_PosDef_Blocky(lam, e3) and rel_inf(e3, x_ref) < TOL
 
 
+@pytest.mark.parametrize("name", ["band", "band_sparse_S"])
+@pytest.mark.parametrize("fail_member", [0, 1, 2])
+def test_failure_agreement_nobody_enqueues_when_a_member_fails(oracle_solutions, name, fail_member):
+    """A member that fails on its way to the exchange (allocation, upload, device error; injected here with the option
+    group_fail_member) must not leave the others parked in a collective: the members meet at a host barrier with their status
+    before anything is enqueued -- group_members_agree() in csrc/group.hip, the one function both the RCCL and the peer branch
+    of the callback call first -- and when one is missing NOBODY enqueues.  The call returns the member's error, the exchange
+    counter does not move, and the very next solve is right."""
+    from slam_plus_plus_amd.hip_solver import CLinearSolver_Schur_HIP
+    lam, x_ref = oracle_solutions[name]
+    multi = CLinearSolver_Schur_HIP(devices=[0, 0, 0])
+    eta = lam.rhs.copy()
+    assert multi.Solve_PosDef(lam, eta) and rel_inf(eta, x_ref) < TOL
+    n_before = multi.exchange_count()
+    assert n_before >= 1
+    multi.set_option("group_fail_member", fail_member + 1)
+    with pytest.raises(RuntimeError, match="injected failure"):
+        multi.Solve_PosDef_Blocky(lam, lam.rhs.copy())
+    assert multi.exchange_count() == n_before            # nobody went into the collective
+    multi.set_option("group_fail_member", 0)
+    for _ in range(2):
+        eta = lam.rhs.copy()
+        assert multi.Solve_PosDef_Blocky(lam, eta) and rel_inf(eta, x_ref) < TOL
+    assert multi.exchange_count() > n_before
+
+
+def test_failure_agreement_with_the_distributed_factorization(built):
+    """The same with schur_distributed: the members order their event waits by a call count, and one that failed before it got
+    to the factorization is a call behind -- the counts go back to zero with every failed solve."""
+    from slam_plus_plus_amd import synth
+    from slam_plus_plus_amd.hip_solver import CLinearSolver_Schur_HIP
+    from oracle import oracle_lib as O
+    lam = synth.ba(210, 5000, k=4, mode="uniform", seed=13)
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok
+    multi = CLinearSolver_Schur_HIP(devices=[0, 0], schur_sparse=0, schur_distributed=1)
+    eta = lam.rhs.copy()
+    assert multi.Solve_PosDef(lam, eta) and rel_inf(eta, x_ref) < TOL
+    for fail in (2, 1):
+        multi.set_option("group_fail_member", fail)
+        with pytest.raises(RuntimeError, match="injected failure"):
+            multi.Solve_PosDef_Blocky(lam, lam.rhs.copy())
+        multi.set_option("group_fail_member", 0)
+        for _ in range(2):
+            eta = lam.rhs.copy()
+            assert multi.Solve_PosDef_Blocky(lam, eta) and rel_inf(eta, x_ref) < TOL
+
+
+def test_a_refused_option_is_not_replayed_into_the_group(oracle_solutions):
+    """An option the front handle refuses must not be remembered for the members (they come up with the first Schur-mode
+    analysis and are given the options set so far): that used to fail every analysis after it."""
+    from slam_plus_plus_amd.hip_solver import CLinearSolver_Schur_HIP
+    lam, x_ref = oracle_solutions["band"]
+    multi = CLinearSolver_Schur_HIP(devices=[0, 0])
+    with pytest.raises(ValueError):
+        multi.set_option("no_such_option", 1)
+    with pytest.raises(ValueError):
+        multi.set_option("schur_tiles", 99)
+    multi.set_option("schur_tiles", 1)
+    eta = lam.rhs.copy()
+    assert multi.Solve_PosDef(lam, eta) and rel_inf(eta, x_ref) < TOL
+    assert multi.group_info()["members"] == 2
+
+
 def test_pose_graph_on_a_multi_device_handle_runs_on_the_first_device(built):
     from slam_plus_plus_amd import synth
     from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP
@@ -198,3 +262,22 @@ def test_two_distinct_devices_rccl_and_peer(oracle_solutions):
             assert info["members"] == len(devs)
             assert info["exchange"].startswith("rccl" if exchange != 2 else "peer"), info
             assert rel_inf(eta, x_ref) < TOL
+            # failure agreement on real devices, RCCL included: a member that does not come leaves nobody parked
+            n_before = multi.exchange_count()
+            multi.set_option("group_fail_member", len(devs))
+            with pytest.raises(RuntimeError, match="injected failure"):
+                multi.Solve_PosDef_Blocky(lam, lam.rhs.copy())
+            assert multi.exchange_count() == n_before
+            multi.set_option("group_fail_member", 0)
+            eta = lam.rhs.copy()
+            assert multi.Solve_PosDef_Blocky(lam, eta) and rel_inf(eta, x_ref) < TOL
+    # the distributed dense factorization over distinct devices (peer pointers under either exchange)
+    from slam_plus_plus_amd import synth
+    from oracle import oracle_lib as O
+    lam = synth.ba(210, 5000, k=4, mode="uniform", seed=13)
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    for exchange in (1, 2):
+        multi = CLinearSolver_Schur_HIP(devices=devs, group_exchange=exchange, schur_sparse=0, schur_distributed=1)
+        for _ in range(2):
+            eta = lam.rhs.copy()
+            assert ok and multi.Solve_PosDef_Blocky(lam, eta) and rel_inf(eta, x_ref) < TOL

@@ -1,6 +1,8 @@
 """Pins the CPU oracle (oracle/slampp_oracle.c) against the golden vectors produced by the compiled
 reference (tests/golden/make_golden.py): the reference's CHOLMOD (supernodal and simplicial), CSparse,
 native block solver and Schur solver outputs on the same inputs.  No GPU needed."""
+import os
+
 import numpy as np
 import pytest
 
@@ -124,3 +126,13 @@ def test_schur_marginals_restatement(name):
         assert rel_inf(cams[c], full[6 * c:6 * c + 6, 6 * c:6 * c + 6]) < 1e-11
     for p in (0, len(pts) - 1):
         assert rel_inf(pts[p], full[nx + 3 * p:nx + 3 * p + 3, nx + 3 * p:nx + 3 * p + 3]) < 1e-11
+
+
+def test_reference_binaries_are_built_where_the_reference_sources_are():
+    """Loud, not a silent skip: with /root/reference present (the build container) the compiled reference must exist --
+    the pinned-oracle tests above and the GPU box's full-size tests depend on it."""
+    if not os.path.isdir("/root/reference/src/slam"):
+        pytest.skip("no /root/reference here (the GPU box): nothing to build from")
+    for f in ("ref_harness", "dropin_driver"):
+        assert os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", f)), \
+            f"oracle/_ref/{f} missing: python -c 'import __graft_entry__ as g; g.build()'"
