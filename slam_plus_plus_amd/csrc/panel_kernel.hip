@@ -97,7 +97,79 @@ __device__ __forceinline__ void panel_update_block(const TUpdSlot &sl, bool b_va
 
 // (b_fused: some stage of the plan has its updates from further down applied inside the launch of the stage below -- the
 // launch then holds update workgroups next to the panel ones, and the panel tasks bring in fresh updates themselves)
-template <int D, int W, bool b_fused>
+// one block column of a level as rows (column_rows_steps, sparse_device.inl): chunk n_chunk of its rows below the diagonal
+// block -- CAP of them per wave: the lanes 0 .. D - 1 of every row of 16 lanes hold the diagonal block, every chunk factors
+// it again (the rows below and the right-hand side come out of the same steps); chunk 0 writes it -- to p_diag_out, not
+// into the image, where the other chunks of the column (other waves, any order) read the block as it was.  Results go to
+// LDS only; panel_copy_out sends them to memory, off the chain.
+template <int D>
+__device__ __forceinline__ void panel_column_rows(const TPanelCol col, int ci, int n_chunk, int lane, double *s_L, double *s_w, double *p_diag_out,
+	int *p_flag)
+{
+	enum { DD = D * D, OTHER = 16 - D, CAP = 4 * OTHER };
+	const int g = lane & 15, R = lane >> 4;
+	const int n_other = (col.nb - 1) * D + 1; // rows of the blocks below the diagonal + the right-hand side
+	const bool b_diag = g < D;
+	const int o = n_chunk * CAP + R * OTHER + (g - D);
+	const bool b_rhs = !b_diag && o == n_other - 1, b_row = !b_diag && o < n_other - 1;
+	const int kb = b_row? 1 + o / D : 0, r = b_diag? g : (b_row? o % D : 0);
+	double *p_blk = s_L + (col.slot0 + kb) * DD + r, *p_y = s_w + ci * D;
+	double a[D], piv_raw[D];
+	#pragma unroll
+	for(int t = 0; t < D; ++ t)
+		a[t] = b_rhs? p_y[t] : p_blk[D * t];
+	column_rows_steps<D, 0>(a, piv_raw);
+	if(b_diag) {
+		if(R == 0 && n_chunk == 0) {
+			#pragma unroll
+			for(int t = 0; t < D; ++ t)
+				p_diag_out[r + D * t] = (t <= r)? a[t] : 0.0;
+		}
+	} else if(b_row) {
+		#pragma unroll
+		for(int t = 0; t < D; ++ t)
+			p_blk[D * t] = a[t];
+	} else if(b_rhs) {
+		#pragma unroll
+		for(int t = 0; t < D; ++ t)
+			p_y[t] = a[t];
+	}
+	if(lane == 0 && n_chunk == 0) {
+		bool b_bad = false;
+		#pragma unroll
+		for(int t = 0; t < D; ++ t)
+			b_bad = b_bad || !(piv_raw[t] > 0); // also catches NaN
+		if(b_bad)
+			atomicOr(p_flag, 1);
+	}
+}
+
+// the finished columns ci0 .. ci1 - 1 of the image out to memory: their blocks as they lie (a lane per element, one
+// coalesced store each), inv(L_jj) computed here -- nothing in the factorization waits for it any more -- and y_j.
+template <int D, int W>
+__device__ __forceinline__ void panel_copy_out(const TPanelCol *s_col, const TPanelSlot *s_slot, int ci0, int ci1, int wave, int lane,
+	const TLaneMap mm, const double *s_L, const double *s_w, const double *s_diag, double *s_tile, double *L, double *Linv, double *w)
+{
+	enum { DD = D * D };
+	int n_item = 0;
+	for(int ci = ci0; ci < ci1; ++ ci) {
+		const int n_slot0 = s_col[ci].slot0, n_nb = s_col[ci].nb;
+		for(int kb = 0; kb < n_nb; ++ kb, ++ n_item) {
+			if((W - 1) - n_item % W != wave)
+				continue;
+			const double v = mm.b_act? (kb? s_L[(n_slot0 + kb) * DD + lane] : s_diag[ci * 64 + lane]) : 0.0;
+			if(mm.b_act)
+				L[s_slot[n_slot0 + kb].loff + lane] = v;
+			if(!kb) {
+				invert_diagonal_fixed<D>(v, lane, mm.r, mm.q, mm.b_act, Linv, s_col[ci].linv_off, s_tile);
+				if(lane < D)
+					w[s_col[ci].cs_new + lane] = s_w[ci * D + lane];
+			}
+		}
+	}
+}
+
+template <int D, int W, bool b_fused, bool b_rows>
 __global__ void __launch_bounds__(64 * W)
 factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict__ pkg_off, int n_panels, TPanelLaunch t_cfg,
 	const TUpdSlot *__restrict__ upd_slots, int n_upd_slots, const TUpdEnt *__restrict__ upd_ents, const double *__restrict__ A,
@@ -223,8 +295,74 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 	PANEL_TICK(); // fresh updates
 
 	// 2. the columns, inside the image, level by level: the columns of one level of a tall task do not depend on each
-	// other (a chain is one column per level) -- their diagonal blocks go to one wave each, their blocks below in turn
-	// over all waves; two barriers and no memory round trip per level
+	// other (a chain is one column per level)
+	if constexpr(b_rows) {
+		// round 4: (A) every block of the level's columns, diagonal ones included, gets its internal updates -- products of
+		// blocks of earlier levels, out of the image, a lane per element, the blocks dealt over all waves --; (B) one wave per
+		// column (and chunk of 40 rows) factors the whole block column as rows, diagonal block, blocks below and right-hand side
+		// in the same six steps; meanwhile the other waves send the level before to memory and invert its diagonal blocks.
+		enum { CAP = 4 * (16 - D) };
+		// (the finished diagonal blocks wait in s_linv: the image keeps the blocks as they were for the other chunks of their columns)
+		for(int ci0 = 0; ci0 < n_cols;) {
+			const int n_sub = s_col[ci0].sub;
+			int ci1 = ci0 + 1;
+			while(ci1 < n_cols && s_col[ci1].sub == n_sub)
+				++ ci1;
+			int n_before = 0;
+			for(int ci = ci0; ci < ci1; ++ ci) {
+				const TPanelCol col = s_col[ci];
+				for(int kb = ((wave - n_before) % W + W) % W; kb < col.nb; kb += W) {
+					if(!kb) {
+						if(!col.inr)
+							continue;
+						const double init = b_y? s_w[ci * D + yq] : (mm.b_act? s_L[col.slot0 * DD + lane] : 0.0);
+						double sum = 0;
+						for(int e = 0; e < col.inr; ++ e) {
+							const uint32_t en = s_irow[col.ir0 + e];
+							sum += row_product_image<D>(s_L + int(en & 0xffff) * DD, s_w + int(en >> 16) * D, mm.r, yq, b_y);
+						}
+						if(b_y)
+							s_w[ci * D + yq] = init - sum;
+						else if(mm.b_act)
+							s_L[col.slot0 * DD + lane] = init - sum;
+					} else {
+						const int n_slot = col.slot0 + kb;
+						const int ip0 = s_slot[n_slot].ip0, inp = s_slot[n_slot].inp;
+						if(!inp)
+							continue;
+						const double init = mm.b_act? s_L[n_slot * DD + lane] : 0.0;
+						double sum = 0;
+						for(int e = 0; e < inp; ++ e) {
+							const uint32_t en = s_ipair[ip0 + e];
+							sum += pair_product_image<D>(s_L + int(en & 0xffff) * DD, s_L + int(en >> 16) * DD, mm.r, mm.q);
+						}
+						if(mm.b_act)
+							s_L[n_slot * DD + lane] = init - sum;
+					}
+				}
+				n_before += col.nb;
+			}
+			__syncthreads();
+			PANEL_TICK(); // internal updates of the level
+			int n_pair = 0;
+			for(int ci = ci0; ci < ci1; ++ ci) {
+				const int n_chunks = ((s_col[ci].nb - 1) * D + 1 + CAP - 1) / CAP;
+				for(int n_chunk = 0; n_chunk < n_chunks; ++ n_chunk, ++ n_pair) {
+					if(n_pair % W == wave)
+						panel_column_rows<D>(s_col[ci], ci, n_chunk, lane, s_L, s_w, s_linv + ci * 64, p_flag);
+				}
+			}
+			__syncthreads(); // the level's columns and their y complete in the image
+			PANEL_TICK();
+			ci0 = ci1;
+		}
+		// everything out to memory, and the inverses of the diagonal blocks: by all waves, after the chain
+		panel_copy_out<D, W>(s_col, s_slot, 0, n_cols, wave, lane, mm, s_L, s_w, s_linv, s_tile, L, Linv, w);
+		PANEL_TICK();
+		return;
+	}
+	// (the block-wise form of rounds 2 and 3, kept for comparison: option "panel_rows" = 0) their diagonal blocks go to one
+	// wave each, their blocks below in turn over all waves; two barriers and no memory round trip per level
 	for(int ci0 = 0; ci0 < n_cols;) {
 		const int n_sub = s_col[ci0].sub;
 		int ci1 = ci0 + 1;
@@ -269,7 +407,7 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 	}
 }
 
-bool launch_factor_panel(int n_dim, bool b_fused, const TPanelLaunch &r_cfg, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks,
+bool launch_factor_panel(int n_dim, bool b_fused, bool b_rows, const TPanelLaunch &r_cfg, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks,
 	const TUpdSlot *upd_slots, int n_upd_slots, const TUpdEnt *upd_ents, const double *A, const double *b, double *L, double *Linv, double *w,
 	int *p_flag, hipStream_t stream, long long *p_timing)
 {
@@ -281,17 +419,18 @@ bool launch_factor_panel(int n_dim, bool b_fused, const TPanelLaunch &r_cfg, con
 		return true;
 	const size_t n_lds_bytes = size_t(panel_lds(n_dim, b_fused, r_cfg).TOTAL) * sizeof(double);
 	// (beyond 64 KB of dynamic LDS a kernel has to be told once)
-#define LAUNCH_PANEL_INSTANCE(D, WW, F) do { \
+#define LAUNCH_PANEL_INSTANCE(D, WW, F, RW) do { \
 		static bool b_attribute_set = false; \
 		if(!b_attribute_set) { \
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_panel_kernel<D, WW, F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_panel_kernel<D, WW, F, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
 			b_attribute_set = true; \
 		} \
-		hipLaunchKernelGGL((factor_panel_kernel<D, WW, F>), dim3(n_grid), dim3(64 * WW), n_lds_bytes, stream, pkg, pkg_off, n_tasks, r_cfg, \
+		hipLaunchKernelGGL((factor_panel_kernel<D, WW, F, RW>), dim3(n_grid), dim3(64 * WW), n_lds_bytes, stream, pkg, pkg_off, n_tasks, r_cfg, \
 			upd_slots, n_upd_slots, upd_ents, A, b, L, Linv, w, p_flag, p_timing); } while(0)
+#define LAUNCH_PANEL_F(D, WW, F) do { if(b_rows) LAUNCH_PANEL_INSTANCE(D, WW, F, true); else LAUNCH_PANEL_INSTANCE(D, WW, F, false); } while(0)
 #define LAUNCH_PANEL(D) do { \
-		if(W == 4) { if(b_fused) LAUNCH_PANEL_INSTANCE(D, 4, true); else LAUNCH_PANEL_INSTANCE(D, 4, false); } \
-		else { if(b_fused) LAUNCH_PANEL_INSTANCE(D, 8, true); else LAUNCH_PANEL_INSTANCE(D, 8, false); } } while(0)
+		if(W == 4) { if(b_fused) LAUNCH_PANEL_F(D, 4, true); else LAUNCH_PANEL_F(D, 4, false); } \
+		else { if(b_fused) LAUNCH_PANEL_F(D, 8, true); else LAUNCH_PANEL_F(D, 8, false); } } while(0)
 	switch(n_dim) {
 	case 3:
 		LAUNCH_PANEL(3);
@@ -306,6 +445,7 @@ bool launch_factor_panel(int n_dim, bool b_fused, const TPanelLaunch &r_cfg, con
 		return false;
 	}
 #undef LAUNCH_PANEL
+#undef LAUNCH_PANEL_F
 #undef LAUNCH_PANEL_INSTANCE
 }
 

@@ -1066,6 +1066,7 @@ static void schur_try_sparse_reduced(slampp_hip_solver &s, CSchurState &S)
 	p_inner->n_simt_width = s.n_simt_width;
 	p_inner->n_simt_stages = s.n_simt_stages;
 	p_inner->n_wide_min_tasks = s.n_wide_min_tasks;
+	p_inner->n_panel_rows = s.n_panel_rows;
 	// (a small system is all latency: round 1 cut its leaf subtrees to four columns for the wave-per-task kernel; as panels
 	// -- eight waves per subtree, 2 us per column -- the default of eight is faster again: 0.231 -> 0.220 ms at 1000 cameras)
 	p_inner->cumsum = cumsum;
@@ -1278,6 +1279,7 @@ static void schur_enqueue_t(slampp_hip_solver &s, CSchurState &S, const double *
 	if(b_sparse) {
 		s.Phase_Begin("reduced_sparse");
 		S.p_inner->p_flag_shared = s.d_flag.p();
+		S.p_inner->n_panel_rows = s.n_panel_rows; // (read at every launch)
 		S.p_inner->Enqueue_Sparse(p_S, p_r, true); // p_r: the reduced right-hand side on entry, dx on return
 		s.Phase_End();
 		p_dx = p_r;

@@ -138,6 +138,7 @@ struct slampp_hip_solver {
 	// separator tasks that run as panels in LDS (panel_kernel.hip): their packages, per stage the offsets of the packages and
 	// the tasks left to factor_stage_kernel
 	int n_panel = -1; // option "panel": -1 / 1 = where a task fits (default), 0 = never
+	int n_panel_rows = 0; // option "panel_rows": 1 = the panel tasks factor a block column as rows (round 4: measured no faster), 0 = block by block
 	slampp::CDevArray<longlong2> d_panel_pkg;
 	slampp::CDevArray<int64_t> d_panel_off;
 	slampp::CDevArray<int32_t> d_panel_rest;

@@ -1250,7 +1250,7 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 				launch_panel_update(P.max_dim, d_panel_upd_slots.p() + panel_upd_ptr[s], panel_upd_ptr[s + 1] - panel_upd_ptr[s],
 					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream);
 			const int n_next = (s + 1 < n_stages && panel_ride[s + 1] == 1)? panel_upd_ptr[s + 2] - panel_upd_ptr[s + 1] : 0;
-			launch_factor_panel(P.max_dim, b_panel_fused, panel_cfg[s], d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s], n_panels,
+			launch_factor_panel(P.max_dim, b_panel_fused, n_panel_rows != 0, panel_cfg[s], d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s], n_panels,
 				d_panel_upd_slots.p() + ((n_next > 0)? panel_upd_ptr[s + 1] : 0), n_next, d_panel_upd_ents.p(), p_values_dev, p_rhs_dev,
 				d_L.p(), d_Linv.p(), d_w.p(), p_flag, stream, dplan.p_timing);
 			if(panel_rest_ptr[s + 1] > panel_rest_ptr[s]) {
@@ -1613,6 +1613,10 @@ static int set_option_checked(slampp_hip_solver *p_solver, const char *p_s_name,
 		p_solver->n_simt_width = int(n_value);
 	else if(s == "panel" && n_value >= -1 && n_value <= 1)
 		p_solver->n_panel = int(n_value);
+	else if(s == "panel_rows" && n_value >= 0 && n_value <= 1) {
+		p_solver->n_panel_rows = int(n_value);
+		return SLAMPP_HIP_OK; // read at every launch
+	}
 	else if(s == "simt_stages" && n_value >= 0)
 		p_solver->n_simt_stages = int(n_value);
 	else if(s == "profile") {

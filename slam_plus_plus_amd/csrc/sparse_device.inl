@@ -241,6 +241,86 @@ __device__ __forceinline__ void finish_diagonal_fixed(const TColDesc &cd, double
 	}
 }
 
+
+// ---- a block column as rows (panel_kernel.hip, round 4) ------------------------------------------------------------------
+// DPP row broadcast of a double: every lane gets the value of lane N of its own row of 16 lanes (row_newbcast, the one DPP
+// control the 64-bit ALU takes).  The fused multiply-add with a broadcast operand is inline assembly (the compiler keeps a
+// v_mov_b64_dpp + v_fmac_f64), and the two wait states a DPP read needs after a VALU write of the same register are the
+// caller's to provide (b_guard: an s_nop 1 in front): the hazard recogniser does not look inside inline assembly.
+template <int N>
+__device__ __forceinline__ double dpp16_bcast(double v)
+{
+	double r;
+	asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(N));
+	return r;
+}
+template <int N, bool b_guard>
+__device__ __forceinline__ void dpp16_fmac(double &r_acc, double src, double mul) // acc += (src of lane N of the row) * mul
+{
+	if constexpr(b_guard)
+		asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(r_acc) : "v"(src), "v"(mul), "n"(N));
+	else
+		asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(r_acc) : "v"(src), "v"(mul), "n"(N));
+}
+
+// Cholesky of a block column held one scalar ROW per lane: lanes 0 .. D - 1 of every row of 16 lanes hold the rows of the
+// diagonal block (four identical copies), the other lanes rows of the blocks below it -- and the right-hand side b_j^T,
+// which is just one more row: the same column operations turn it into y_j^T (the forward substitution is free).  Step k:
+// pivot from lane k, s = 1 / sqrt, a[k] *= s, a[q] -= a[k] * (a[k] of lane q) for q > k -- one v_fmac_f64_dpp each, no LDS,
+// no scalar registers, no inverse of the diagonal block on the chain (the blocks below come out of the same steps, where
+// the block-wise form first inverts L_jj and then multiplies: 1.7 - 2.0 + 0.5 - 1.1 us a tree level; this: ~0.35).
+template <int D, int K, int Q>
+__device__ __forceinline__ void column_rows_trailing(double (&a)[D], double nt)
+{
+	if constexpr(Q < D) {
+		dpp16_fmac<Q, (Q == K + 1)>(a[Q], a[K], nt);
+		column_rows_trailing<D, K, Q + 1>(a, nt);
+	}
+}
+template <int D, int K>
+__device__ __forceinline__ void column_rows_steps(double (&a)[D], double (&piv_raw)[D])
+{
+	if constexpr(K < D) {
+		const double pr = dpp16_bcast<K>(a[K]);
+		piv_raw[K] = pr; // looked at after the chain (a compare and select on it costs ~70 cycles per step)
+		const double s = rsqrt_newton(__builtin_fmax(pr, 1e-300)); // not positive: finite garbage in a block nobody reads, flag raised by the caller
+		const double nt = a[K] * -s;
+		a[K] *= s;
+		column_rows_trailing<D, K, K + 1>(a, nt);
+		column_rows_steps<D, K + 1>(a, piv_raw);
+	}
+}
+
+// inverse of a finished diagonal block (element per lane in a, lower triangle) by the calling wave: Linv and nothing else --
+// off the factorization's chain, for the backward substitution and the covariances
+template <int D>
+__device__ __forceinline__ void invert_diagonal_fixed(double a, int lane, int r, int q, bool b_act, double *Linv, int64_t linv_off, double *s_linv)
+{
+	const int c = lane;
+	double x[D];
+	#pragma unroll
+	for(int rr = 0; rr < D; ++ rr) {
+		const double d = read_lane(a, rr + rr * D);
+		double rd = __builtin_amdgcn_rcp(d);
+		rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
+		rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
+		double sum = 0;
+		#pragma unroll
+		for(int t = 0; t < rr; ++ t)
+			sum += read_lane(a, rr + t * D) * x[t];
+		x[rr] = (((rr == c)? 1.0 : 0.0) - sum) * rd;
+	}
+	wave_sync();
+	if(lane < D) {
+		#pragma unroll
+		for(int rr = 0; rr < D; ++ rr)
+			s_linv[rr + 8 * lane] = x[rr];
+	}
+	wave_sync();
+	if(b_act)
+		Linv[linv_off + lane] = s_linv[r + 8 * q];
+}
+
 // dimension-8 columns have no spare lanes for the right-hand side: a second pass by lanes 0..7
 __device__ __forceinline__ void finish_rhs_wide(const TColDesc &cd, int lane, const TDevPlan &p, const double *L,
 	const double *b, double *w, const double *s_linv)

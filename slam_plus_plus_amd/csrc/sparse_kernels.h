@@ -121,7 +121,7 @@ inline __host__ __device__ TPanelLds panel_lds(int D, bool b_fused, const TPanel
 	l.IMAGE = 2 * c.n_cap_units;
 	l.VEC = l.IMAGE + c.n_cap_blk * DD;
 	l.LINV = l.VEC + c.n_cap_cols * 8;
-	l.TILE = l.LINV + c.n_cap_lvl * 64;
+	l.TILE = l.LINV + c.n_cap_cols * 64; // (block-wise walk: the inverses of a level's diagonal blocks; row-wise walk: every column's finished diagonal block)
 	l.OPS = l.TILE + W * 64;
 	l.YV = l.OPS + (b_fused? W * 2 * panel_fresh_batch(W) * DD : 0);
 	const int n_panel_end = l.YV + (b_fused? W * panel_fresh_batch(W) * 8 : 0);
@@ -133,7 +133,7 @@ inline __host__ __device__ TPanelLds panel_lds(int D, bool b_fused, const TPanel
 // one workgroup per package (pkg_off: their offsets in pkg, in 16-byte units; pkg is padded by 64 * PANEL_W units)
 // (upd_slots: the blocks of the NEXT stage's panel tasks, whose updates from below this stage ride in this launch)
 // (b_fused: the plan has such stages at all; without them the leaner kernel runs)
-bool launch_factor_panel(int n_dim, bool b_fused, const TPanelLaunch &r_cfg, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks, const TUpdSlot *upd_slots,
+bool launch_factor_panel(int n_dim, bool b_fused, bool b_rows, const TPanelLaunch &r_cfg, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks, const TUpdSlot *upd_slots,
 	int n_upd_slots, const TUpdEnt *upd_ents, const double *A, const double *b, double *L, double *Linv, double *w, int *p_flag,
 	hipStream_t stream, long long *p_timing = 0);
 void launch_panel_update(int n_dim, const TUpdSlot *slots, int n_slots, const TUpdEnt *ents, const double *A, double *L,

@@ -326,3 +326,30 @@ def test_separator_panels_agree_with_the_column_kernel(dims):
         assert rel_inf(eta, x_ref) < TOL
         xs.append(eta)
     assert rel_inf(xs[0], xs[1]) < 1e-11
+
+
+@pytest.mark.parametrize("case", ["chain6", "chain3", "chain7", "sphere", "manhattan"])
+def test_panel_tasks_as_rows_agree_with_the_block_wise_walk(case):
+    """Option panel_rows = 1 (round 4; not the default: measured no faster): a level's block columns factored as rows -- one
+    scalar row of the diagonal block, of the blocks below it, or the right-hand side per lane, multipliers by DPP row
+    broadcast, no inverse of the diagonal block on the chain -- against the block-wise walk and the oracle.  The 2-D-like
+    graphs have columns with more rows than one wave holds (several chunks per column, other waves, any order)."""
+    lam = {"chain6": lambda: synth.pose_chain(n=12000, d=6, seed=21), "chain3": lambda: synth.pose_chain(n=6000, d=3, seed=22),
+           "chain7": lambda: synth.pose_chain(n=6000, d=7, seed=23), "sphere": lambda: synth.sphere(50, 50),
+           "manhattan": lambda: synth.manhattan(3500)}[case]()
+    ok, x_ref = O.solve_sparse(lam)[:2]
+    assert ok
+    xs = []
+    for rows in (1, 0):
+        solver = CLinearSolver_HIP(panel_rows=rows)
+        eta = lam.rhs.copy()
+        assert solver.Solve_PosDef(lam, eta)
+        assert rel_inf(eta, x_ref) < TOL
+        xs.append(eta)
+    assert rel_inf(xs[0], xs[1]) < 1e-10
+    bad = type(lam)(lam.cumsum, lam.bcol_ptr, lam.brow_idx, lam.values.copy(), lam.rhs, lam.n_matrix_cut)
+    off = bad.block_value_offsets()
+    k = int(bad.bcol_ptr[bad.n_bcols // 2 + 1]) - 1          # a diagonal block in the middle: not positive definite
+    d = int(bad.cumsum[1])
+    bad.values[off[k]:off[k] + d * d] = -np.eye(d).ravel()
+    assert CLinearSolver_HIP(panel_rows=1).Solve_PosDef(bad, bad.rhs.copy()) is False
