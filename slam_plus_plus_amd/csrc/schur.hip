@@ -1436,7 +1436,9 @@ static void schur_enqueue_marginals_sparse_t(slampp_hip_solver &s, CSchurState &
 	}
 	s.Phase_Begin("marginals_factor");
 	S.p_inner->p_flag_shared = s.d_flag.p();
+	S.p_inner->b_leaf_linv_wanted = true; // (the inverse subset multiplies by inv(L_jj) of every column)
 	S.p_inner->Enqueue_Sparse(p_S, p_r, true, true); // numeric factorization only
+	S.p_inner->Ensure_Leaf_Inverses();
 	s.Phase_End();
 	s.Phase_Begin("marginals_inverse");
 	sparse_inverse_enqueue(*S.p_sinv, S.p_inner->plan, S.p_inner->d_L.p(), S.p_inner->d_Linv.p(), S.d_m_Zs.p(), st);

@@ -112,8 +112,9 @@ __device__ __forceinline__ int pc_next_column(const int32_t *P, int pc, int nb, 
 	return pc;
 }
 
-template <int D, int W, int LPT> // W = tasks per wave, LPT = lanes per task (1, or 2 for even D: the lanes of a pair compute the
-// diagonal block of a column both, and each half the rows of the blocks below it -- no traffic between them)
+template <int D, int W, int LPT, bool b_linv> // W = tasks per wave, LPT = lanes per task (1, or 2 for even D: the lanes of a pair compute the
+// diagonal block of a column both, and each half the rows of the blocks below it -- no traffic between them); b_linv: inv(L_jj)
+// goes to memory as well (36 of a column's ~100 doubles at C3; the solve itself no longer reads it: backward_simt_kernel)
 __global__ void __launch_bounds__(64)
 factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restrict__ prog, const long long *__restrict__ tab,
 	const double *__restrict__ A, double *L, double *Linv, const double *__restrict__ b, double *w, int *p_flag,
@@ -271,7 +272,8 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 			}
 			if(n_half == 0) { // (the lanes of a pair hold the same numbers)
 				store_block<D>(L + l_base, a);
-				store_block<D>(Linv + linv_off, x);
+				if constexpr(b_linv)
+					store_block<D>(Linv + linv_off, x);
 			}
 		}
 		SIMT_TICK(); // diagonal block
@@ -382,8 +384,9 @@ bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, int n_width, int
 	if(n_chunks <= 0)
 		return true;
 	const long long *t = reinterpret_cast<const long long*>(tab);
-#define SIMT_LAUNCH(D_, W_, LPT_) hipLaunchKernelGGL((factor_simt_kernel<D_, W_, LPT_>), dim3(n_chunks), dim3(64), n_lds_bytes, stream, chunks, prog, t, \
-	A, L, Linv, b, w, p_flag, p_timing)
+#define SIMT_LAUNCH(D_, W_, LPT_) do { if(Linv) hipLaunchKernelGGL((factor_simt_kernel<D_, W_, LPT_, true>), dim3(n_chunks), dim3(64), n_lds_bytes, stream, chunks, prog, t, \
+	A, L, Linv, b, w, p_flag, p_timing); else hipLaunchKernelGGL((factor_simt_kernel<D_, W_, LPT_, false>), dim3(n_chunks), dim3(64), n_lds_bytes, stream, chunks, prog, t, \
+	A, L, Linv, b, w, p_flag, p_timing); } while(0)
 	// (two lanes per task where the block dimension is even and a wave holds at most 32 tasks)
 #define SIMT_WIDTHS(D_) do { if(n_width == 16) { if(b_pairs && D_ % 2 == 0) SIMT_LAUNCH(D_, 16, (D_ % 2 == 0)? 2 : 1); else SIMT_LAUNCH(D_, 16, 1); } \
 	else if(n_width == 32) { if(b_pairs && D_ % 2 == 0) SIMT_LAUNCH(D_, 32, (D_ % 2 == 0)? 2 : 1); else SIMT_LAUNCH(D_, 32, 1); } \
@@ -408,6 +411,174 @@ bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, int n_width, int
 	}
 #undef SIMT_WIDTHS
 #undef SIMT_LAUNCH
+}
+
+// Backward substitution of the same tasks, one lane per task: x_j = L_jj^-T (y_j - sum_i L(i,j)^T x_i), columns last to first.
+// The wave-per-task kernel (backward_stage_kernel) pays a trip to memory per column with 36 lanes busy, 15 894 workgroups for
+// C3's leaf subtrees (40 us); here a lane walks its task's columns with its own blocks, the next column's lines requested a
+// column ahead, and solves with L_jj^T itself (six dependent steps, reciprocals taken before the chain) -- inv(L_jj) is not
+// read, which is what lets the factorization stop writing it.  x of rows inside the task is what the lane stored a moment
+// ago (program order of one thread), x of rows above it what earlier launches stored.
+template <int D, int W>
+__global__ void __launch_bounds__(64)
+backward_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restrict__ prog, const long long *__restrict__ tab,
+	const double *__restrict__ L, double *w, double *x_out)
+{
+	enum { DD = D * D };
+	extern __shared__ long long s_tab[];
+	const TSimtChunk ch = chunks[blockIdx.x];
+	const int32_t *P = prog + ch.prog_off; // wave-uniform: scalar loads
+	const int n_cols = P[0], n_below = P[1];
+	{
+		const int n_entries = (3 * n_cols + n_below) * W;
+		for(int i = threadIdx.x; i < n_entries; i += 64)
+			s_tab[i] = tab[ch.tab_off + i];
+		__syncthreads();
+	}
+	if(int(threadIdx.x) >= W)
+		return; // (no barrier below)
+	const long long *T = s_tab + threadIdx.x;
+	int n_blk_end = n_below;
+	double f_touched = 0;
+	for(int ci = n_cols - 1; ci >= 0; -- ci) {
+		const int nb = P[2 + ci];
+		const long long l_base = T[W * (3 * ci)], cs_new = T[W * (3 * ci + 1)], cs_src = T[W * (3 * ci + 2)];
+		const int n_blk0 = n_blk_end - (nb - 1);
+		if(ci > 0) { // the next column's blocks: a load per cache line, a column of arithmetic ahead of their use
+			const int nb_next = P[2 + ci - 1];
+			const double *p_next = L + T[W * (3 * (ci - 1))];
+			for(int kb = 0; kb < nb_next; ++ kb)
+				f_touched += p_next[kb * DD] + p_next[kb * DD + 16] + p_next[kb * DD + DD - 1];
+		}
+		double acc[D], a[D][D];
+		load_column<D>(w + cs_new, acc); // y_j
+		load_block<D>(L + l_base, a);    // a[q][r] = L_jj(r, q)
+		double rd[D];
+		#pragma unroll
+		for(int q = 0; q < D; ++ q) {
+			const double d = a[q][q];
+			double r = __builtin_amdgcn_rcp(d);
+			r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+			r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+			rd[q] = r;
+		}
+		for(int kb = 1; kb < nb; ++ kb) {
+			const long long xcs = T[W * (3 * n_cols + n_blk0 + kb - 1)];
+			double c[D][D], xi[D];
+			load_block<D>(L + l_base + kb * DD, c); // c[q][r] = L(i,j)(r, q)
+			load_column<D>(w + xcs, xi);
+			#pragma unroll
+			for(int q = 0; q < D; ++ q) {
+				#pragma unroll
+				for(int r = 0; r < D; ++ r)
+					acc[q] -= c[q][r] * xi[r];
+			}
+		}
+		double x[D];
+		#pragma unroll
+		for(int q = D - 1; q >= 0; -- q) {
+			double sum = acc[q];
+			#pragma unroll
+			for(int r = q + 1; r < D; ++ r)
+				sum -= a[q][r] * x[r];
+			x[q] = sum * rd[q];
+		}
+		if(D % 2 == 0) {
+			#pragma unroll
+			for(int q = 0; q < D; q += 2) {
+				*reinterpret_cast<double2*>(w + cs_new + q) = double2{x[q], x[q + 1]};
+				*reinterpret_cast<double2*>(x_out + cs_src + q) = double2{x[q], x[q + 1]};
+			}
+		} else {
+			#pragma unroll
+			for(int q = 0; q < D; ++ q) {
+				w[cs_new + q] = x[q];
+				x_out[cs_src + q] = x[q];
+			}
+		}
+		n_blk_end = n_blk0;
+	}
+	if(f_touched == 1.2345e301) // (never: the sum only has to be used)
+		w[0] = f_touched;
+}
+
+bool launch_backward_simt(const TSimtChunk *chunks, int n_chunks, int n_width, int n_lds_bytes, const int32_t *prog, const int64_t *tab,
+	int n_dim, const double *L, double *w, double *x_out, hipStream_t stream)
+{
+	if(n_chunks <= 0)
+		return true;
+	const long long *t = reinterpret_cast<const long long*>(tab);
+#define BWD_LAUNCH(D_, W_) hipLaunchKernelGGL((backward_simt_kernel<D_, W_>), dim3(n_chunks), dim3(64), n_lds_bytes, stream, chunks, prog, t, L, w, x_out)
+#define BWD_WIDTHS(D_) do { if(n_width == 16) BWD_LAUNCH(D_, 16); else if(n_width == 32) BWD_LAUNCH(D_, 32); else BWD_LAUNCH(D_, 64); } while(0)
+	switch(n_dim) {
+	case 3:
+		BWD_WIDTHS(3);
+		return true;
+	case 6:
+		BWD_WIDTHS(6);
+		return true;
+	case 7:
+		BWD_WIDTHS(7);
+		return true;
+	default:
+		return false;
+	}
+#undef BWD_WIDTHS
+#undef BWD_LAUNCH
+}
+
+// inv(L_jj) from L_jj, a thread per column (forward substitution on the identity)
+template <int D>
+__global__ void invert_diagonals_kernel(TDevPlan p, int64_t col_begin, int64_t col_end, const double *__restrict__ L, double *Linv)
+{
+	const int64_t c = col_begin + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if(c >= col_end)
+		return;
+	const TColDesc &cd = p.cols[c];
+	const double *a = L + p.blks[cd.k0].loff; // element (r, q) at r + q D
+	double x[D][D]; // x[r][c]
+	#pragma unroll
+	for(int q = 0; q < D; ++ q) {
+		#pragma unroll
+		for(int r = 0; r < D; ++ r) {
+			if(r < q)
+				x[r][q] = 0.0;
+			else {
+				double sum = (r == q)? 1.0 : 0.0;
+				#pragma unroll
+				for(int t = q; t < r; ++ t)
+					sum -= a[r + t * D] * x[t][q];
+				x[r][q] = sum / a[r + r * D];
+			}
+		}
+	}
+	double *p_out = Linv + cd.linv_off;
+	#pragma unroll
+	for(int q = 0; q < D; ++ q) {
+		#pragma unroll
+		for(int r = 0; r < D; ++ r)
+			p_out[r + q * D] = x[r][q];
+	}
+}
+
+bool launch_invert_diagonals(const TDevPlan &p, int64_t col_begin, int64_t col_end, const double *L, double *Linv, hipStream_t stream)
+{
+	if(col_end <= col_begin)
+		return true;
+	const unsigned n_grid = unsigned((col_end - col_begin + 127) / 128);
+	switch(p.uniform_dim) {
+	case 3:
+		hipLaunchKernelGGL((invert_diagonals_kernel<3>), dim3(n_grid), dim3(128), 0, stream, p, col_begin, col_end, L, Linv);
+		return true;
+	case 6:
+		hipLaunchKernelGGL((invert_diagonals_kernel<6>), dim3(n_grid), dim3(128), 0, stream, p, col_begin, col_end, L, Linv);
+		return true;
+	case 7:
+		hipLaunchKernelGGL((invert_diagonals_kernel<7>), dim3(n_grid), dim3(128), 0, stream, p, col_begin, col_end, L, Linv);
+		return true;
+	default:
+		return false;
+	}
 }
 
 } // namespace slampp

@@ -148,6 +148,21 @@ struct slampp_hip_solver {
 	std::vector<slampp::TPanelLaunch> panel_cfg; // [n_stages] waves per task and LDS capacities of the stage's panel launch
 	std::vector<char> panel_ride; // [n_stages + 1] the stage's updates from further down are applied inside the launch of the stage below
 	slampp::CDevArray<int64_t> d_simt_tab;
+	// the same chunks for the backward substitution (backward_simt_kernel): per shape [n_cols, blocks below the diagonals, nb per column],
+	// per lane (offset of the column's first factor block, scalar offset in the workspace, in the caller's vector) per column and
+	// the workspace offset of every sub-diagonal block's row
+	slampp::CDevArray<slampp::TSimtChunk> d_simt_bwd_chunks;
+	slampp::CDevArray<int32_t> d_simt_bwd_prog;
+	slampp::CDevArray<int64_t> d_simt_bwd_tab;
+	std::vector<int32_t> simt_bwd_lds_bytes;
+	std::vector<slampp::TSimtChunk> simt_host_bwd_chunks;
+	std::vector<int32_t> simt_host_bwd_prog;
+	std::vector<int64_t> simt_host_bwd_tab;
+	// inv(L_jj) of the columns the lane-per-task kernel factors is not on the solve's path any more (its backward kernel solves with
+	// L_jj^T): stored only once something has asked for it (another right-hand side, covariances) -- from then on always
+	bool b_leaf_linv_wanted = false, b_leaf_linv_valid = true;
+	int n_simt_backward = 0; // option "simt_backward": 1 = the leaf subtrees' backward substitution a lane per task as well and no inv(L_jj) stored for them (round 4: measured slower, 97 against 90 us at C3); 0 = a wave per task
+	void Ensure_Leaf_Inverses();
 	std::vector<int32_t> simt_chunk_ptr, simt_rest_ptr; // [n_bottom_stages + 1] each; empty = not in use
 	std::vector<int32_t> simt_lds_bytes; // per stage: the largest chunk table (it is staged in LDS)
 	int n_simt = -1; // option "simt": 1 / -1 = use it where it applies (default), 0 = never

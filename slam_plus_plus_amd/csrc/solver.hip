@@ -321,6 +321,8 @@ void slampp_hip_solver::Free_Device()
 {
 	d_cols.Free(); d_blks.Free(); d_rents.Free(); d_pairs.Free(); d_task_ptr.Free(); d_task_pkg.Free(); d_pkg.Free();
 	d_simt_chunks.Free(); d_simt_prog.Free(); d_simt_rest.Free(); d_simt_tab.Free();
+	d_simt_bwd_chunks.Free(); d_simt_bwd_prog.Free(); d_simt_bwd_tab.Free();
+	b_leaf_linv_valid = true;
 	d_panel_pkg.Free(); d_panel_off.Free(); d_panel_rest.Free(); d_panel_upd_slots.Free(); d_panel_upd_ents.Free();
 	simt_chunk_ptr.clear(); simt_rest_ptr.clear();
 	d_dense_blks.Free(); d_dense_cols.Free(); d_dense.Free(); d_dense_invdiag.Free(); d_dense_z.Free(); d_dense_x.Free();
@@ -355,6 +357,7 @@ size_t slampp_hip_solver::n_Device_Bytes() const
 		d_dense_z.n_Bytes() + d_dense_x.n_Bytes() + d_cols.n_Bytes() + d_blks.n_Bytes() + d_rents.n_Bytes() +
 		d_task_ptr.n_Bytes() + d_task_pkg.n_Bytes() + d_pkg.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
 		d_simt_chunks.n_Bytes() + d_simt_prog.n_Bytes() + d_simt_rest.n_Bytes() + d_simt_tab.n_Bytes() +
+		d_simt_bwd_chunks.n_Bytes() + d_simt_bwd_prog.n_Bytes() + d_simt_bwd_tab.n_Bytes() +
 		d_panel_pkg.n_Bytes() + d_panel_off.n_Bytes() + d_panel_rest.n_Bytes() + d_panel_upd_slots.n_Bytes() + d_panel_upd_ents.n_Bytes() +
 		d_rhs.n_Bytes() + d_L.n_Bytes() + d_Linv.n_Bytes() + d_w.n_Bytes() + d_cov.n_Bytes() + d_flag.n_Bytes() +
 		d_Z.n_Bytes() + d_diag_zoff.n_Bytes() + d_Zd.n_Bytes() + d_Zd_work.n_Bytes() + sparse_inverse_bytes(p_sinv) +
@@ -1057,6 +1060,8 @@ void slampp_hip_solver::Build_Simt()
 	simt_rest_ptr.clear();
 	simt_lds_bytes.clear();
 	simt_host_chunks.clear(); simt_host_prog.clear(); simt_host_tab.clear(); simt_host_rest.clear();
+	simt_bwd_lds_bytes.clear();
+	simt_host_bwd_chunks.clear(); simt_host_bwd_prog.clear(); simt_host_bwd_tab.clear();
 	const Plan &P = plan;
 	if(!n_simt || !P.uniform_dim || (P.max_dim != 3 && P.max_dim != 6 && P.max_dim != 7))
 		return;
@@ -1076,7 +1081,7 @@ void slampp_hip_solver::Build_Simt()
 	const size_t W = size_t(n_simt_width);
 	for(int s = 0; s < n_bottom_stages && s < n_stages && s < n_simt_stages; ++ s) {
 		std::map<std::vector<int32_t>, std::vector<TTask> > groups;
-		int32_t n_stage_lds = 0;
+		int32_t n_stage_lds = 0, n_stage_bwd_lds = 0;
 		for(int32_t t = P.stage_ptr[s]; t < P.stage_ptr[s + 1]; ++ t) {
 			std::vector<int32_t> prog(4, 0);
 			TTask tt;
@@ -1152,6 +1157,17 @@ void slampp_hip_solver::Build_Simt()
 			const int n_cols = prog[0], n_blocks = prog[1], n_ops = prog[2], n_ys = prog[3];
 			const int n_fields = 4 * n_cols + n_blocks + n_ops + n_ys;
 			n_stage_lds = std::max(n_stage_lds, int32_t(n_fields * W * 8));
+			// the shape's backward program: n_cols, blocks below the diagonals, nb per column
+			const int32_t n_bwd_prog_off = int32_t(simt_host_bwd_prog.size());
+			const int n_bwd_fields = 3 * n_cols + (n_blocks - n_cols);
+			n_stage_bwd_lds = std::max(n_stage_bwd_lds, int32_t(n_bwd_fields * W * 8));
+			simt_host_bwd_prog.push_back(n_cols);
+			simt_host_bwd_prog.push_back(n_blocks - n_cols);
+			{
+				const TTask &tt = tasks[0];
+				for(int64_t i = P.task_ptr[tt.n_task]; i < P.task_ptr[tt.n_task + 1]; ++ i)
+					simt_host_bwd_prog.push_back(int32_t(P.lptr[P.task_cols[i] + 1] - P.lptr[P.task_cols[i]]));
+			}
 			for(size_t n_first = 0; n_first < tasks.size(); n_first += W) {
 				const size_t n_in_chunk = std::min<size_t>(W, tasks.size() - n_first);
 				TSimtChunk ch;
@@ -1183,18 +1199,60 @@ void slampp_hip_solver::Build_Simt()
 					if(f != n_fields)
 						throw std::logic_error("lane-per-task tables: field count mismatch");
 				}
+				TSimtChunk ch_bwd;
+				ch_bwd.prog_off = n_bwd_prog_off;
+				ch_bwd.n_tasks = int32_t(n_in_chunk);
+				ch_bwd.tab_off = int64_t(simt_host_bwd_tab.size());
+				simt_host_bwd_chunks.push_back(ch_bwd);
+				simt_host_bwd_tab.resize(simt_host_bwd_tab.size() + size_t(n_bwd_fields) * W);
+				int64_t *p_bwd = &simt_host_bwd_tab[size_t(ch_bwd.tab_off)];
+				for(int n_lane = 0; n_lane < int(W); ++ n_lane) {
+					const TTask &tt = tasks[n_first + std::min<size_t>(n_lane, n_in_chunk - 1)];
+					int f = 0;
+					for(int64_t i = P.task_ptr[tt.n_task]; i < P.task_ptr[tt.n_task + 1]; ++ i) {
+						const int32_t j = P.task_cols[i];
+						p_bwd[W * (f ++) + n_lane] = P.loff[P.lptr[j]];
+						p_bwd[W * (f ++) + n_lane] = P.cs_new[j];
+						p_bwd[W * (f ++) + n_lane] = P.cs_src[j];
+					}
+					for(int64_t i = P.task_ptr[tt.n_task]; i < P.task_ptr[tt.n_task + 1]; ++ i) {
+						const int32_t j = P.task_cols[i];
+						for(int64_t k = P.lptr[j] + 1; k < P.lptr[j + 1]; ++ k) {
+							if(P.loff[k] != P.loff[P.lptr[j]] + (k - P.lptr[j]) * int64_t(P.max_dim) * P.max_dim)
+								throw std::logic_error("lane-per-task tables: the blocks of a column are not contiguous");
+							p_bwd[W * (f ++) + n_lane] = P.cs_new[P.lrow[k]];
+						}
+					}
+					if(f != n_bwd_fields)
+						throw std::logic_error("lane-per-task tables: backward field count mismatch");
+				}
 			}
 		}
 		std::sort(rest.begin() + simt_rest_ptr.back(), rest.end());
 		simt_chunk_ptr.push_back(int32_t(chunks.size()));
 		simt_rest_ptr.push_back(int32_t(rest.size()));
 		simt_lds_bytes.push_back(n_stage_lds);
+		simt_bwd_lds_bytes.push_back(n_stage_bwd_lds);
 	}
 	if(chunks.empty()) {
 		simt_chunk_ptr.clear();
 		simt_rest_ptr.clear();
 		return;
 	}
+}
+
+// inv(L_jj) of the columns of the lane-per-task stages, where the factorization left them out: computed from the factor, once
+// per factorization, and stored by every factorization from now on
+void slampp_hip_solver::Ensure_Leaf_Inverses()
+{
+	b_leaf_linv_wanted = true;
+	if(b_leaf_linv_valid || simt_chunk_ptr.empty())
+		return;
+	const Plan &P = plan;
+	const int n_simt_stages_used = int(simt_chunk_ptr.size()) - 1;
+	const int64_t n_col_end = P.task_ptr[size_t(P.stage_ptr[size_t(n_simt_stages_used)])];
+	launch_invert_diagonals(dplan, 0, n_col_end, d_L.p(), d_Linv.p(), stream);
+	b_leaf_linv_valid = true;
 }
 
 void slampp_hip_solver::Upload_Simt()
@@ -1206,7 +1264,13 @@ void slampp_hip_solver::Upload_Simt()
 	d_simt_prog.Upload(simt_host_prog, stream);
 	d_simt_tab.Upload(simt_host_tab, stream);
 	d_simt_rest.Upload(simt_host_rest, stream);
+	d_simt_bwd_chunks.Upload(simt_host_bwd_chunks, stream);
+	d_simt_bwd_prog.Upload(simt_host_bwd_prog, stream);
+	d_simt_bwd_tab.Upload(simt_host_bwd_tab, stream);
 	SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // (the host copies are no longer needed)
+	{ std::vector<TSimtChunk> e; simt_host_bwd_chunks.swap(e); }
+	{ std::vector<int32_t> e; simt_host_bwd_prog.swap(e); }
+	{ std::vector<int64_t> e; simt_host_bwd_tab.swap(e); }
 	{ std::vector<TSimtChunk> e; simt_host_chunks.swap(e); }
 	{ std::vector<int32_t> e0, e1; simt_host_prog.swap(e0); simt_host_rest.swap(e1); }
 	{ std::vector<int64_t> e; simt_host_tab.swap(e); }
@@ -1227,6 +1291,13 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 		launch_gather_values(d_refine_map.p(), n_refined_values, p_values_dev, d_refined.p(), stream);
 		p_values_dev = d_refined.p();
 	}
+	// (the backward kernel of the lane-per-task stages writes x with 16-byte stores where the block dimension is even)
+	const bool b_simt_bwd = n_simt_backward && !simt_chunk_ptr.empty() && d_simt_bwd_chunks.p() &&
+		(P.max_dim % 2 != 0 || (reinterpret_cast<uintptr_t>(p_rhs_dev) & 15) == 0);
+	if(b_factor)
+		b_leaf_linv_valid = true; // (every factor kernel but the lane-per-task one stores its inverses; that one answers below)
+	else
+		Ensure_Leaf_Inverses(); // another right-hand side: the forward kernel multiplies by inv(L_jj)
 	if(b_factor) {
 		// numeric factorization with the forward substitution fused in
 		// (the flag is zero here: set to zero when it was allocated and again by every slampp_hip_sync() that found it raised.
@@ -1271,8 +1342,10 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 				Phase_Begin("factor_upper");
 			if(b_simt && s + 1 < int(simt_chunk_ptr.size())) {
 				const int n_chunks = simt_chunk_ptr[s + 1] - simt_chunk_ptr[s], n_rest = simt_rest_ptr[s + 1] - simt_rest_ptr[s];
+				const bool b_store_linv = b_leaf_linv_wanted || !n_simt_backward; // (the wave-per-task backward kernel reads the inverses)
 				launch_factor_simt(d_simt_chunks.p() + simt_chunk_ptr[s], n_chunks, n_simt_width, simt_lds_bytes[s], d_simt_prog.p(), d_simt_tab.p(), P.max_dim,
-					p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), p_flag, stream, dplan.p_timing);
+					p_values_dev, d_L.p(), b_store_linv? d_Linv.p() : 0, p_rhs_dev, d_w.p(), p_flag, stream, dplan.p_timing);
+				b_leaf_linv_valid = b_leaf_linv_valid && b_store_linv;
 				if(n_rest > 0) {
 					TDevPlan t_rest = dplan;
 					t_rest.task_map = d_simt_rest.p();
@@ -1340,6 +1413,21 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 	}
 	Phase_Begin("backward");
 	for(int s = n_stages; s > 0; -- s) {
+		if(b_simt_bwd && s < int(simt_chunk_ptr.size())) {
+			// a lane-per-task stage: its chunks by backward_simt_kernel (no inverses read), the tasks of rare shapes by the
+			// wave-per-task kernel (their factor kernel stored the inverses)
+			const int n_chunks = simt_chunk_ptr[s] - simt_chunk_ptr[s - 1], n_rest = simt_rest_ptr[s] - simt_rest_ptr[s - 1];
+			launch_backward_simt(d_simt_bwd_chunks.p() + simt_chunk_ptr[s - 1], n_chunks, n_simt_width, simt_bwd_lds_bytes[s - 1],
+				d_simt_bwd_prog.p(), d_simt_bwd_tab.p(), P.max_dim, d_L.p(), d_w.p(), p_rhs_dev, stream);
+			if(n_rest > 0) {
+				TDevPlan t_rest = dplan;
+				t_rest.task_map = d_simt_rest.p();
+				launch_backward_stage(t_rest, d_L.p(), d_Linv.p(), d_w.p(), p_rhs_dev, simt_rest_ptr[s - 1], n_rest, stream);
+			}
+			continue;
+		}
+		if(s < int(simt_chunk_ptr.size()))
+			Ensure_Leaf_Inverses(); // (the wave-per-task kernel on a lane-per-task stage: unaligned caller vector)
 		launch_backward_stage(dplan, d_L.p(), d_Linv.p(), d_w.p(), p_rhs_dev, P.stage_ptr[s - 1],
 			P.stage_ptr[s] - P.stage_ptr[s - 1], stream);
 	}
@@ -1619,6 +1707,10 @@ static int set_option_checked(slampp_hip_solver *p_solver, const char *p_s_name,
 	}
 	else if(s == "simt_stages" && n_value >= 0)
 		p_solver->n_simt_stages = int(n_value);
+	else if(s == "simt_backward" && n_value >= 0 && n_value <= 1) {
+		p_solver->n_simt_backward = int(n_value);
+		return SLAMPP_HIP_OK; // read at every solve
+	}
 	else if(s == "profile") {
 		p_solver->b_profile = int(n_value); // 0 = off, 1 = phases, 2 = the factorization split further (every event pair costs microseconds), 3 = only the phase of the dominant kernel
 		return SLAMPP_HIP_OK; // does not invalidate the analysis
@@ -2054,7 +2146,9 @@ int slampp_hip_marginals_device_async(slampp_hip_solver *p_solver, const double 
 		s.d_rhs.Alloc(size_t(s.n_scalars));
 		SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_rhs.p(), 0, size_t(s.n_scalars) * sizeof(double), s.stream));
 		// (with a dense top the whole factor + solve runs: the top is factored on the way; opens its own phases)
+		s.b_leaf_linv_wanted = true; // (the inverse subset multiplies by inv(L_jj) of every column)
 		s.Enqueue_Sparse(p_values_dev, s.d_rhs.p(), true, s.n_dense_dim == 0);
+		s.Ensure_Leaf_Inverses();
 		s.Phase_Begin("marginals_inverse");
 		if(s.n_dense_dim) { // the top's inverse from a copy of its factor (the factor itself stays for solve_again)
 			SLAMPP_HIP_CHECK(hipMemcpyAsync(s.d_Zd_work.p(), s.d_dense.p(), size_t(s.n_dense_pad) * s.n_dense_pad * sizeof(double),

@@ -188,8 +188,16 @@ struct TSimtChunk { // 16 B
 bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, int n_width /* tasks per wave: 16, 32 or 64 */,
 	int n_lds_bytes /* the largest table of the chunks: fields x width x 8 */,
 	const int32_t *prog, const int64_t *tab, int n_dim,
-	const double *A, double *L, double *Linv, const double *b, double *w, int *p_flag, hipStream_t stream,
+	const double *A, double *L, double *Linv /* null: inv(L_jj) is not stored */, const double *b, double *w, int *p_flag, hipStream_t stream,
 	long long *p_timing = 0 /* development aid, as TDevPlan::p_timing */);
+// backward substitution of the same tasks, a lane per task (chunk programs: n_cols, number of sub-diagonal blocks, nb per
+// column; tables: per column offset of its first factor block, scalar offsets in the workspace and in the caller's vector,
+// then the workspace offset of every sub-diagonal block's row): x_j from L_jj^T directly, no inverse
+bool launch_backward_simt(const TSimtChunk *chunks, int n_chunks, int n_width, int n_lds_bytes, const int32_t *prog, const int64_t *tab,
+	int n_dim, const double *L, double *w, double *x_out, hipStream_t stream);
+// inv(L_jj) of the columns cols[col_begin .. col_end) (schedule order) from their factor blocks: for callers that need the
+// inverses the lane-per-task factorization did not store (another right-hand side, covariances)
+bool launch_invert_diagonals(const TDevPlan &p, int64_t col_begin, int64_t col_end, const double *L, double *Linv, hipStream_t stream);
 
 // numeric factorization of one stage, with the forward substitution y = L^-1 b fused in
 // (b is read at its original position, y written to the permuted workspace w)

@@ -471,7 +471,7 @@ backward_stage_kernel(TDevPlan p, const double *L, const double *Linv, double *w
 	double *__restrict__ x_out, int task_begin)
 {
 	const int lane = threadIdx.x, g = lane >> 3, q = lane & 7;
-	const int task = task_begin + blockIdx.x;
+	const int task = p.task_map? p.task_map[task_begin + blockIdx.x] : task_begin + blockIdx.x;
 	const int64_t c_begin = p.task_ptr[task], c_end = p.task_ptr[task + 1];
 	if(c_end <= c_begin)
 		return;

@@ -353,3 +353,26 @@ def test_panel_tasks_as_rows_agree_with_the_block_wise_walk(case):
     d = int(bad.cumsum[1])
     bad.values[off[k]:off[k] + d * d] = -np.eye(d).ravel()
     assert CLinearSolver_HIP(panel_rows=1).Solve_PosDef(bad, bad.rhs.copy()) is False
+
+
+@pytest.mark.parametrize("d", [6, 3, 7])
+def test_lane_per_task_backward_substitution_and_lazy_inverses(d):
+    """Option simt_backward = 1 (round 4; not the default: measured slower): the leaf subtrees' backward substitution by
+    backward_simt_kernel, which solves with L_jj^T itself, and a factorization that no longer stores inv(L_jj) for those columns
+    -- until something asks for them: another right-hand side with the kept factor (the forward kernel multiplies by the
+    inverses) and the covariances get them from a fix-up pass, and every later factorization stores them again."""
+    lam = synth.pose_chain(n=9000, d=d, seed=31)
+    ok, x_ref = O.solve_sparse(lam)[:2]
+    assert ok
+    solver = CLinearSolver_HIP(simt_backward=1, simt=1)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta) and rel_inf(eta, x_ref) < TOL
+    again = 3.0 * lam.rhs
+    assert solver.Solve_Again(again) and rel_inf(again, 3.0 * x_ref) < TOL        # inverses computed from the factor, late
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef_Blocky(lam, eta) and rel_inf(eta, x_ref) < TOL     # ... and stored by the factorization now
+    again = -lam.rhs
+    assert solver.Solve_Again(again) and rel_inf(again, -x_ref) < TOL
+    cov = CLinearSolver_HIP(simt_backward=1, simt=1).Marginals(lam)
+    cov_ref = CLinearSolver_HIP(simt_backward=0).Marginals(lam)
+    assert rel_inf(cov, cov_ref) < 1e-10
