@@ -19,9 +19,11 @@ struct CSchurTiles {
 	bool b_enabled = false;  // some landmarks go through the tiles
 	bool b_hybrid = false;   // ... and some through the contribution lists (the x-lists below)
 	int64_t n_tiles = 0, n_slots = 0, n_tile_points = 0, n_list_points = 0, n_tile_pairs = 0, n_all_pairs = 0, n_rb = 0, n_max_slots = 0, n_max_k = 0;
-	int64_t n_run_points = 0, n_run_jobs[5][2] = {}, n_run_job_first[5][2] = {}; // jobs by (16-line tiles per side, row block == column block)
+	int64_t n_run_points = 0, n_run_jobs[5][2][2] = {}, n_run_job_first[5][2][2] = {}; // jobs by (16-line tiles per side, row block == column block, some landmarks end before the run's list)
 	CDevArray<TRunJob> d_run_jobs;
 	CDevArray<int32_t> d_run_lm;        // landmarks of the runs, piece after piece
+	CDevArray<int32_t> d_run_k;         // ... their own number of observations (a run's landmarks may end before its list does)
+	int64_t n_prefix_points = 0;        // landmarks in runs whose lists are prefixes of the run's, not the run's
 	CDevArray<int64_t> d_run_rec;       // ... and where their blocks start in the values
 	CDevArray<int32_t> d_tile_ptr;      // [n_tiles + 1] into d_tile_lm
 	CDevArray<int32_t> d_tile_lm;       // landmarks of the tiles, in processing order
@@ -42,7 +44,7 @@ struct CSchurTiles {
 	CDevArray<int32_t> d_xcam_obs;
 	size_t n_Bytes() const
 	{
-		return d_run_jobs.n_Bytes() + d_run_lm.n_Bytes() + d_run_rec.n_Bytes() + d_tile_ptr.n_Bytes() + d_tile_lm.n_Bytes() + d_tile_slot_ptr.n_Bytes() + d_pair_ptr.n_Bytes() +
+		return d_run_jobs.n_Bytes() + d_run_lm.n_Bytes() + d_run_k.n_Bytes() + d_run_rec.n_Bytes() + d_tile_ptr.n_Bytes() + d_tile_lm.n_Bytes() + d_tile_slot_ptr.n_Bytes() + d_pair_ptr.n_Bytes() +
 			d_lm_slot.n_Bytes() + d_P.n_Bytes() + d_R.n_Bytes() + d_rb_ptr.n_Bytes() + d_rb_part.n_Bytes() + d_rb_sb.n_Bytes() +
 			d_xsb_ptr.n_Bytes() + d_xsb_map.n_Bytes() + d_xent_a.n_Bytes() + d_xent_uoff.n_Bytes() + d_xcam_ptr.n_Bytes() +
 			d_xcam_obs.n_Bytes() + d_xpoints.n_Bytes();

@@ -191,9 +191,14 @@ schur_tile_kernel(const int32_t *__restrict__ tile_ptr, const int32_t *__restric
 				for(int t = 0; t < DP; ++ t)
 					l_i[t] = readlane_f64(l[t], i + g);
 				const int64_t o0 = readlane64(my_o0, i + g);
-				// W_o = U_o C^-1 and the right-hand side's share W_o l: one lane per (observation, row)
-				if(lane < k * DC) {
-					const int o = lane / DC, r = lane - o * DC;
+				// W_o = U_o C^-1 and the right-hand side's share W_o l: one lane per (observation, row) -- ten observations of a
+				// seven-dimensional camera are 70 rows: a second round (until round 4 the rows past 64 were left out: a wrong S
+				// for Sim(3) landmarks seen by exactly ten cameras that went through a tile)
+				for(int n_row0 = 0; n_row0 < k * DC; n_row0 += 64) {
+					const int n_row = n_row0 + lane;
+					if(n_row >= k * DC)
+						continue;
+					const int o = n_row / DC, r = n_row - o * DC;
 					double u[DP], rv = 0;
 					#pragma unroll
 					for(int t = 0; t < DP; ++ t)
@@ -262,14 +267,16 @@ schur_tile_kernel(const int32_t *__restrict__ tile_ptr, const int32_t *__restric
 // and go through LDS into the fragment layout (lane = (row or column, k)).  Loading the fragments straight from memory
 // -- eight 8-byte gathers per landmark over its 576-byte record -- cost 176 L1 accesses per landmark and ran at
 // 216 us for C4; coalesced it is ten.
-template <int DC, int DP, int NT, bool b_diag>
+template <int DC, int DP, int NT, bool b_diag, bool b_prefix> // b_prefix: some landmarks of the job end before the run's list does
 __global__ void __launch_bounds__(64)
 schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ run_lm, const int64_t *__restrict__ run_rec,
-	int64_t ubase, const double *__restrict__ A, const double *__restrict__ eta, int n, double *Cinv, double *W, int b_store,
+	const int32_t *__restrict__ run_k, int64_t ubase, const double *__restrict__ A, const double *__restrict__ eta, int n, double *Cinv, double *W, int b_store,
 	double *P, double *R, int *p_flag)
 {
 	enum { BLK = DC * DP, BB = DC * DC, OB = 64 / DC, OBT = (NT * 16 / DC < OB)? NT * 16 / DC : OB, // observations per block here
-		SEG = OBT * BLK, NLD = (SEG + 63) / 64, GROUP = (NT <= 2)? 8 : 4 };
+		SEG = OBT * BLK, NLD = (SEG + 63) / 64,
+		GROUP = (NT <= 2)? 8 : (b_diag? 4 : 2) }; // (off-diagonal jobs of three or four tiles a side keep 16 accumulator tiles: with four landmarks in
+	// flight the requested values were parked in accumulator registers one by one, a wait behind every load -- round 4)
 	typedef double v4f64 __attribute__((ext_vector_type(4)));
 	__shared__ double s_ci[64 * DP * DP];
 	__shared__ double s_z[64 * DP];
@@ -279,7 +286,7 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 	const int k = job.n_k, n_rb = job.n_rb, n_cb = job.n_cb, n_points = job.n_points;
 	const int n_len_a = min(OB, k - n_rb * OB) * BLK, n_len_b = min(OB, k - n_cb * OB) * BLK; // doubles of the two segments
 	// what this lane feeds the matrix cores: element (row, kk) of the U rows, element (kk, column) of the W columns
-	int n_off_a[NT], n_off_b[NT], n_obs_b[NT];
+	int n_off_a[NT], n_off_b[NT], n_obs_a[NT], n_obs_b[NT];
 	bool b_a[NT], b_b[NT];
 	#pragma unroll
 	for(int t = 0; t < NT; ++ t) {
@@ -288,14 +295,19 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 		n_off_a[t] = b_a[t]? o * BLK + kk * DC + e : 0;
 		b_b[t] = o < OB && n_cb * OB + o < k && kk < DP;
 		n_off_b[t] = (b_b[t]? o * BLK + e : 0) + (b_diag? 0 : SEG);
+		n_obs_a[t] = n_rb * OB + o;
 		n_obs_b[t] = n_cb * OB + o;
 	}
 	const int kc = (kk < DP)? kk : 0;
 	// lane L prepares landmark L of the piece: where its blocks are (the host wrote that down), C^-1 and C^-1 l
+	// (round 4: a run may also hold landmarks whose camera list is a PREFIX of the run's -- tracks born at the same camera and
+	// lost at different ones --: my_k is the landmark's own number of observations, what lies beyond it reads as zero)
 	int64_t my_rec = 0, my_pt = 0;
+	int my_k = k;
 	if(lane < n_points) {
 		my_pt = run_lm[job.n_first + lane];
 		my_rec = run_rec[job.n_first + lane];
+		my_k = run_k[job.n_first + lane];
 	}
 	v4f64 acc[NT][NT];
 	double racc[NT];
@@ -314,12 +326,18 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 	auto Request = [&](int n_first) {
 		#pragma unroll
 		for(int g = 0; g < GROUP; ++ g) {
-			const double *p_rec = A + readlane64(my_rec, min(n_first + g, n_points - 1));
+			// (b_prefix: a landmark may end before the run's list does.  Its loads stay inside its own record -- U blocks and the C
+			// block behind them -- and what they bring from beyond its last observation is never multiplied: the operands are
+			// masked where they are read out of LDS.  A select on a value just requested, tried first, made the compiler wait
+			// for every load in turn: 24 round trips per group instead of one.)
+			const int n_lm = min(n_first + g, n_points - 1);
+			const double *p_rec = A + readlane64(my_rec, n_lm);
+			const int n_last = b_prefix? __builtin_amdgcn_readlane(my_k, n_lm) * BLK + DP * DP - 1 : 0x7fffffff;
 			#pragma unroll
 			for(int m = 0; m < NLD; ++ m) {
-				va[g][m] = p_rec[n_seg_a + ((lane + 64 * m < n_len_a)? lane + 64 * m : 0)];
+				va[g][m] = p_rec[min(int(n_seg_a) + ((lane + 64 * m < n_len_a)? lane + 64 * m : 0), n_last)];
 				if(!b_diag)
-					vb[g][m] = p_rec[n_seg_b + ((lane + 64 * m < n_len_b)? lane + 64 * m : 0)];
+					vb[g][m] = p_rec[min(int(n_seg_b) + ((lane + 64 * m < n_len_b)? lane + 64 * m : 0), n_last)];
 			}
 		}
 	};
@@ -328,7 +346,7 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 	if(lane < n_points) {
 		const int64_t pt = my_pt;
 		double c[DP * DP], ci[DP * DP];
-		const double *C = A + my_rec + int64_t(k) * BLK;
+		const double *C = A + my_rec + int64_t(my_k) * BLK;
 		#pragma unroll
 		for(int i = 0; i < DP * DP; ++ i)
 			c[i] = C[i];
@@ -371,6 +389,7 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 		for(int g = 0; g < GROUP; ++ g) {
 			const int p = min(p0 + g, n_points - 1);
 			const bool b_live = p0 + g < n_points;
+			const int n_k_own = b_prefix? __builtin_amdgcn_readlane(my_k, p) : k; // observations of this landmark
 			double cik[DP], wb[NT], ua[NT];
 			#pragma unroll
 			for(int j = 0; j < DP; ++ j)
@@ -379,13 +398,13 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 			#pragma unroll
 			for(int t = 0; t < NT; ++ t) {
 				const double u = s_u[g][n_off_a[t]];
-				ua[t] = (b_a[t] && b_live)? u : 0.0;
+				ua[t] = (b_a[t] && b_live && (!b_prefix || n_obs_a[t] < n_k_own))? u : 0.0;
 				racc[t] += ua[t] * z;
 				double w = 0;
 				#pragma unroll
 				for(int j = 0; j < DP; ++ j)
 					w += s_u[g][n_off_b[t] + j * DC] * cik[j]; // W(q, kk) = sum_j U(q, j) C^-1(j, kk)
-				wb[t] = b_b[t]? w : 0.0;
+				wb[t] = (b_b[t] && (!b_prefix || n_obs_b[t] < n_k_own))? w : 0.0;
 			}
 			#pragma unroll
 			for(int rt = 0; rt < NT; ++ rt) {
@@ -399,7 +418,7 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 				const int64_t o0 = (readlane64(my_rec, p) - ubase - readlane64(my_pt, p) * (DP * DP)) / BLK; // first observation of the landmark
 				#pragma unroll
 				for(int t = 0; t < NT; ++ t) {
-					if(b_b[t]) {
+					if(b_b[t] && n_obs_b[t] < n_k_own) {
 						const int n_line = t * 16 + m16, o = n_line / DC, q = n_line - o * DC;
 						W[(o0 + n_obs_b[t]) * BLK + q + kk * DC] = wb[t];
 					}
@@ -493,17 +512,19 @@ static void tiles_enqueue_t(const CSchurTiles &T, const int64_t *ptr, int64_t nc
 {
 	{
 		const TRunJob *p_jobs = T.d_run_jobs.p();
-#define LAUNCH_RUNS(NT, DIAG) if(T.n_run_jobs[NT][DIAG]) hipLaunchKernelGGL((schur_run_kernel<DC, DP, NT, DIAG != 0>), \
-			dim3(unsigned(T.n_run_jobs[NT][DIAG])), dim3(64), 0, stream, p_jobs + T.n_run_job_first[NT][DIAG], T.d_run_lm.p(), \
-			T.d_run_rec.p(), ubase, A, eta, n, Cinv, p_W, int(b_store), T.d_P.p(), T.d_R.p(), p_flag)
-		LAUNCH_RUNS(1, 1);
-		LAUNCH_RUNS(2, 1);
-		LAUNCH_RUNS(3, 1);
-		LAUNCH_RUNS(4, 1);
-		LAUNCH_RUNS(1, 0);
-		LAUNCH_RUNS(2, 0);
-		LAUNCH_RUNS(3, 0);
-		LAUNCH_RUNS(4, 0);
+#define LAUNCH_RUNS(NT, DIAG, PFX) if(T.n_run_jobs[NT][DIAG][PFX]) hipLaunchKernelGGL((schur_run_kernel<DC, DP, NT, DIAG != 0, PFX != 0>), \
+			dim3(unsigned(T.n_run_jobs[NT][DIAG][PFX])), dim3(64), 0, stream, p_jobs + T.n_run_job_first[NT][DIAG][PFX], T.d_run_lm.p(), \
+			T.d_run_rec.p(), T.d_run_k.p(), ubase, A, eta, n, Cinv, p_W, int(b_store), T.d_P.p(), T.d_R.p(), p_flag)
+#define LAUNCH_RUNS_D(NT, DIAG) do { LAUNCH_RUNS(NT, DIAG, 0); LAUNCH_RUNS(NT, DIAG, 1); } while(0)
+		LAUNCH_RUNS_D(1, 1);
+		LAUNCH_RUNS_D(2, 1);
+		LAUNCH_RUNS_D(3, 1);
+		LAUNCH_RUNS_D(4, 1);
+		LAUNCH_RUNS_D(1, 0);
+		LAUNCH_RUNS_D(2, 0);
+		LAUNCH_RUNS_D(3, 0);
+		LAUNCH_RUNS_D(4, 0);
+#undef LAUNCH_RUNS_D
 #undef LAUNCH_RUNS
 	}
 	if(T.n_tiles) {
@@ -679,7 +700,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 
 	// ---- runs: landmarks with identical camera lists, found by sorting hashes of the lists ----
 	std::vector<TRunJob> jobs;
-	std::vector<int32_t> run_lm;
+	std::vector<int32_t> run_lm, run_k;
 	int64_t n_run_pairs = 0;
 	if(b_use_runs) {
 		std::vector<uint64_t> hash(np);
@@ -721,52 +742,136 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 			return true;
 		};
 		const int64_t n_piece_max = getenv("SLAMPP_RUN_PIECE")? std::max(1, std::min(64, atoi(getenv("SLAMPP_RUN_PIECE")))) : 64;
-		std::vector<TRunJob> jobs_nt[5][2];
+		std::vector<TRunJob> jobs_nt[5][2][2];
+		// the jobs of one run: `members` (positions in `order`), longest camera list first -- every other member's list is that
+		// list or a prefix of it; pieces of at most 64 landmarks, a job per pair of observation blocks, over the piece's
+		// landmarks that reach into the row block (they are the first ones: sorted by length)
+		auto Emit_Run = [&](const int32_t *p_members, int64_t n_members) {
+			// (pieces of 32 where a job keeps ten or sixteen accumulator tiles -- nine cameras and up at 6 x 6 --: those jobs are
+			// the long ones, and more of them spread better: 164 + 123 -> 130 + 103 us for the two widest kernels of the
+			// Venice-like C4, for 18 us more in the reduction of the partial blocks)
+			const int64_t k_run = ptr[nc + p_members[0] + 1] - ptr[nc + p_members[0]] - 1;
+			const int64_t n_piece_len = (std::min<int64_t>(k_run, OB) * DC > 48 && !getenv("SLAMPP_RUN_PIECE"))? 32 : n_piece_max;
+			for(int64_t f = 0; f < n_members; f += n_piece_len) {
+				const int64_t n_piece = std::min<int64_t>(n_piece_len, n_members - f);
+				const int32_t pt0 = p_members[f];
+				const int64_t k0 = ptr[nc + pt0], k = ptr[nc + pt0 + 1] - k0 - 1; // the piece's longest list
+				const int64_t n_blocks = (k + OB - 1) / OB;
+				const int64_t n_lm_first = int64_t(run_lm.size());
+				for(int64_t e = f; e < f + n_piece; ++ e) {
+					const int32_t pt = p_members[e];
+					run_lm.push_back(pt);
+					run_k.push_back(int32_t(ptr[nc + pt + 1] - ptr[nc + pt] - 1));
+					handled[pt] = 1;
+					n_run_pairs += int64_t(run_k.back()) * (run_k.back() + 1) / 2;
+				}
+				for(int64_t rb = 0; rb < n_blocks; ++ rb) {
+					const int64_t n_kb_r = std::min<int64_t>(OB, k - rb * OB);
+					int64_t n_reach = 0; // landmarks of the piece with observations in row block rb
+					while(n_reach < n_piece && run_k[size_t(n_lm_first + n_reach)] > rb * OB)
+						++ n_reach;
+					for(int64_t cb = 0; cb <= rb; ++ cb) {
+						const int64_t n_kb_c = std::min<int64_t>(OB, k - cb * OB);
+						TRunJob job;
+						job.n_first = int32_t(n_lm_first);
+						job.n_points = int32_t(n_reach);
+						job.n_k = int32_t(k);
+						job.n_rb = int32_t(rb);
+						job.n_cb = int32_t(cb);
+						job.n_pad = 0;
+						job.n_pbase = int64_t(slot_key.size());
+						for(int64_t ob = 0; ob < n_kb_r; ++ ob) { // the order the kernel numbers its partial blocks in
+							for(int64_t oa = 0; oa < ((rb == cb)? ob + 1 : n_kb_c); ++ oa)
+								slot_key.push_back(int64_t(brow[k0 + cb * OB + oa]) * nc + brow[k0 + rb * OB + ob]);
+						}
+						const int n_lines = int(std::max(n_kb_r, n_kb_c)) * DC;
+						const bool b_job_prefix = run_k[size_t(n_lm_first + n_reach - 1)] < k; // (sorted: the last one is the shortest)
+						jobs_nt[(n_lines + 15) / 16][rb == cb][b_job_prefix].push_back(job);
+					}
+				}
+			}
+		};
+		// Round 4: a run is a CHAIN of such classes -- landmarks seen by exactly the same cameras -- in which every class's camera
+		// list continues the one before it (tracks born at the same camera and lost at different ones; identical lists are the
+		// special case).  A landmark reads as zero beyond its own last observation (run_k), so the chain's partial blocks are
+		// those of its longest list, written once per piece of 64 landmarks instead of once per class: at the Venice-like C4
+		// the classes of the long tracks have 2 - 17 members and 66 - 465 blocks of S each.  Chains of short lists break
+		// where the matrix-core tiles of a job would grow (16 lines a tile): a landmark of two cameras does not pay for ten.
+		struct TClass { int64_t n_first, n_count; };
+		std::vector<TClass> classes;
 		for(int64_t i = 0; i < np;) {
 			int64_t j = i + 1;
 			while(j < np && hash[order[j]] == hash[order[i]] && Same(order[i], order[j]))
 				++ j;
-			const int32_t pt0 = order[i];
-			const int64_t k0 = ptr[nc + pt0], k = ptr[nc + pt0 + 1] - k0 - 1;
-			if(k >= 1 && j - i >= n_min_run) {
-				const int64_t n_blocks = (k + OB - 1) / OB;
-				for(int64_t f = i; f < j; f += n_piece_max) { // pieces of at most 64 landmarks
-					const int64_t n_piece = std::min<int64_t>(n_piece_max, j - f);
-					const int64_t n_lm_first = int64_t(run_lm.size());
-					for(int64_t e = f; e < f + n_piece; ++ e) {
-						run_lm.push_back(order[e]);
-						handled[order[e]] = 1;
-					}
-					for(int64_t rb = 0; rb < n_blocks; ++ rb) {
-						const int64_t n_kb_r = std::min<int64_t>(OB, k - rb * OB);
-						for(int64_t cb = 0; cb <= rb; ++ cb) {
-							const int64_t n_kb_c = std::min<int64_t>(OB, k - cb * OB);
-							TRunJob job;
-							job.n_first = int32_t(n_lm_first);
-							job.n_points = int32_t(n_piece);
-							job.n_k = int32_t(k);
-							job.n_rb = int32_t(rb);
-							job.n_cb = int32_t(cb);
-							job.n_pad = 0;
-							job.n_pbase = int64_t(slot_key.size());
-							for(int64_t ob = 0; ob < n_kb_r; ++ ob) { // the order the kernel numbers its partial blocks in
-								for(int64_t oa = 0; oa < ((rb == cb)? ob + 1 : n_kb_c); ++ oa)
-									slot_key.push_back(int64_t(brow[k0 + cb * OB + oa]) * nc + brow[k0 + rb * OB + ob]);
-							}
-							const int n_lines = int(std::max(n_kb_r, n_kb_c)) * DC;
-							jobs_nt[(n_lines + 15) / 16][rb == cb].push_back(job);
-						}
-					}
-				}
-				n_run_pairs += (j - i) * k * (k + 1) / 2;
-			}
+			if(ptr[nc + order[i] + 1] - ptr[nc + order[i]] - 1 >= 1)
+				classes.push_back(TClass{i, j - i});
 			i = j;
+		}
+		auto List_Less = [&](int32_t p, int32_t q) -> bool { // lexicographic: a list sorts right before its continuations
+			const int64_t kp0 = ptr[nc + p], kq0 = ptr[nc + q], kp = ptr[nc + p + 1] - kp0 - 1, kq = ptr[nc + q + 1] - kq0 - 1;
+			for(int64_t i = 0; i < std::min(kp, kq); ++ i) {
+				if(brow[kp0 + i] != brow[kq0 + i])
+					return brow[kp0 + i] < brow[kq0 + i];
+			}
+			return kp < kq;
+		};
+		auto Is_Prefix = [&](int32_t p, int32_t q) -> bool { // the list of p starts the list of q
+			const int64_t kp0 = ptr[nc + p], kq0 = ptr[nc + q], kp = ptr[nc + p + 1] - kp0 - 1, kq = ptr[nc + q + 1] - kq0 - 1;
+			if(kp > kq)
+				return false;
+			for(int64_t i = 0; i < kp; ++ i) {
+				if(brow[kp0 + i] != brow[kq0 + i])
+					return false;
+			}
+			return true;
+		};
+		auto Tile_Class = [&](int32_t p) -> int { // 16-line tiles a side of the landmark's (first) job
+			const int64_t k = ptr[nc + p + 1] - ptr[nc + p] - 1;
+			return int((std::min<int64_t>(k, OB) * DC + 15) / 16);
+		};
+		const bool b_chains = !getenv("SLAMPP_NO_PREFIX_RUNS");
+		if(b_chains) {
+			std::sort(classes.begin(), classes.end(), [&](const TClass &a, const TClass &b) {
+				const int32_t p = order[a.n_first], q = order[b.n_first];
+				return List_Less(p, q) || (!List_Less(q, p) && a.n_first < b.n_first); });
+		}
+		std::vector<int32_t> members;
+		for(size_t c0 = 0; c0 < classes.size();) {
+			size_t c1 = c0 + 1;
+			int64_t n_members = classes[c0].n_count;
+			while(b_chains && c1 < classes.size() && Tile_Class(order[classes[c1].n_first]) == Tile_Class(order[classes[c0].n_first]) &&
+			   Is_Prefix(order[classes[c1 - 1].n_first], order[classes[c1].n_first])) {
+				n_members += classes[c1].n_count;
+				++ c1;
+			}
+			const int64_t k_longest = ptr[nc + order[classes[c1 - 1].n_first] + 1] - ptr[nc + order[classes[c1 - 1].n_first]] - 1;
+			// (a lone long track is no better off here than in the lists; two of them already share their partial blocks)
+			if(n_members >= ((k_longest > OB && n_min_run > 2)? 2 : n_min_run)) {
+				members.clear();
+				for(size_t c = c1; c > c0; -- c) { // longest list first
+					for(int64_t e = 0; e < classes[c - 1].n_count; ++ e)
+						members.push_back(order[classes[c - 1].n_first + e]);
+				}
+				Emit_Run(members.data(), int64_t(members.size()));
+				if(c1 - c0 > 1)
+					T.n_prefix_points += n_members;
+			}
+			c0 = c1;
 		}
 		for(int nt = 1; nt <= 4; ++ nt) {
 			for(int d = 0; d < 2; ++ d) {
-				T.n_run_job_first[nt][d] = int64_t(jobs.size());
-				T.n_run_jobs[nt][d] = int64_t(jobs_nt[nt][d].size());
-				jobs.insert(jobs.end(), jobs_nt[nt][d].begin(), jobs_nt[nt][d].end());
+				// one launch per (tiles a side, diagonal): where some jobs of a class have landmarks that end early, all its jobs
+				// run the masking instance (its masks do nothing for the others; ten launches of a few thousand waves each, one
+				// after the other, cost more in ragged ends than the masks do)
+				if(!jobs_nt[nt][d][1].empty()) {
+					jobs_nt[nt][d][1].insert(jobs_nt[nt][d][1].end(), jobs_nt[nt][d][0].begin(), jobs_nt[nt][d][0].end());
+					jobs_nt[nt][d][0].clear();
+				}
+				for(int x = 0; x < 2; ++ x) {
+					T.n_run_job_first[nt][d][x] = int64_t(jobs.size());
+					T.n_run_jobs[nt][d][x] = int64_t(jobs_nt[nt][d][x].size());
+					jobs.insert(jobs.end(), jobs_nt[nt][d][x].begin(), jobs_nt[nt][d][x].end());
+				}
 			}
 		}
 	}
@@ -827,8 +932,8 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 	BUILD_PHASE("tiles");
 	const int64_t n_slots = n_run_slots + n_tile_slots;
 	if((!n_tiles && jobs.empty()) || (n_mode < 0 && 2 * (n_tile_pairs + n_run_pairs) < n_all_pairs) || n_slots > INT32_MAX) {
-		for(int nt = 0; nt <= 4; ++ nt)
-			T.n_run_jobs[nt][0] = T.n_run_jobs[nt][1] = T.n_run_job_first[nt][0] = T.n_run_job_first[nt][1] = 0;
+		memset(T.n_run_jobs, 0, sizeof(T.n_run_jobs));
+		memset(T.n_run_job_first, 0, sizeof(T.n_run_job_first));
 		return; // the lists keep everything
 	}
 	T.n_tiles = n_tiles;
@@ -925,6 +1030,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 
 	T.d_run_jobs.Upload(jobs, stream);
 	T.d_run_lm.Upload(run_lm, stream);
+	T.d_run_k.Upload(run_k, stream);
 	std::vector<int64_t> run_rec(run_lm.size());
 	for(size_t i = 0; i < run_lm.size(); ++ i) { // offset of the landmark's first U block in the values
 		const int64_t pt = run_lm[i], o0 = ptr[nc + pt] - ptr[nc] - pt;

@@ -228,14 +228,14 @@ def ba(n_cams: int = 1000, n_pts: int = 500_000, k: int = 4, mode: str = "band",
        damping: float = 0.1, seed: int = 777, cam_dim: int = 6, pt_dim: int = 3,
        cam_damping: float | None = None) -> BlockSystem:
     """C4/C5 look-alike.  Every point is seen by ``k`` cameras (``mode='venice'``: k drawn from a
-    clipped geometric distribution, mean about 5.3).  Cameras of a point: ``band`` = c0 + 7j mod nc
+    clipped geometric distribution, mean about 5.3; ``'tracks'``: longer ones, mean about 11, consecutive cameras).  Cameras of a point: ``band`` = c0 + 7j mod nc
     (sparse S), ``uniform`` = k distinct random cameras (dense S).  Per observation
     Jc in R^{2x6}, Jp in R^{2x3} ~ N(0,1):  A_cc += Jc^T Jc, C_pp += Jp^T Jp, U_cp = Jc^T Jp;
     ``damping``*I on every diagonal block.  ``cam_damping`` overrides the
     damping of the camera blocks (landmark shards of one system each carry 1/world of it)."""
     rng = np.random.default_rng(seed)
-    if mode == "venice":
-        kk = np.clip(rng.geometric(0.19, size=n_pts) + 1, 2, min(30, n_cams))
+    if mode in ("venice", "tracks"):
+        kk = np.clip(rng.geometric(0.19 if mode == "venice" else 0.08, size=n_pts) + 1, 2, min(30, n_cams))
     else:
         kk = np.full(n_pts, min(k, n_cams), dtype=np.int64)
     n_obs = int(kk.sum())
@@ -250,6 +250,11 @@ def ba(n_cams: int = 1000, n_pts: int = 500_000, k: int = 4, mode: str = "band",
         strata = max(int(strata), 1)
         cam_of = (j_in_pt * strata + rng.integers(0, strata, size=n_obs)
                   + np.repeat(rng.integers(0, n_cams, size=n_pts), kk)) % n_cams
+    elif mode == "tracks":
+        # feature tracks: a point is seen by kk consecutive cameras from the one it was first seen in (every fifth camera
+        # starts tracks) -- the lists of the tracks born at one camera are prefixes of the longest of them
+        c0 = np.minimum(5 * rng.integers(0, max(n_cams // 5, 1), size=n_pts), n_cams - kk)
+        cam_of = c0[pt_of] + j_in_pt
     else:
         c0 = rng.integers(0, n_cams, size=n_pts)
         cam_of = (c0[pt_of] + 7 * j_in_pt) % n_cams

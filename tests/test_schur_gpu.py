@@ -29,6 +29,9 @@ CASES = {
     "n126": lambda: synth.ba(21, 800, k=4),                                          # N = 126 -> padded to 128
     "n192_tile_multiple": lambda: synth.ba(32, 1000, k=4),                            # N = 192 -> a whole extra tile
     "two_cams": lambda: synth.ba(2, 50, k=2),
+    # feature tracks over consecutive cameras, 2 - 30 of them: the tracks born at one camera form prefix runs (round 4)
+    "tracks_prefix_runs": lambda: synth.ba(150, 3000, mode="tracks", seed=9),
+    "tracks_sim3": lambda: synth.ba(90, 1200, mode="tracks", cam_dim=7, pt_dim=3, seed=10),
 }
 
 
@@ -646,3 +649,43 @@ def test_landmarks_without_observations(tiles):
     eta = cut.rhs.copy()
     assert CLinearSolver_Schur_HIP(schur_tiles=tiles).Solve_PosDef(cut, eta)
     assert rel_inf(eta, x_ref) < TOL
+
+
+@pytest.mark.parametrize("sparse", [0, 1])
+def test_prefix_runs_take_the_long_tracks_off_the_contribution_lists(sparse, monkeypatch):
+    """Landmarks seen by more cameras than a tile takes (11 - 30) whose camera lists continue one another -- tracks born at
+    the same camera, lost at different ones -- are assembled as ONE run on the matrix cores, each reading as zero beyond its
+    own end (schur_run_kernel, run_k), instead of through the contribution lists: same solution as the oracle and as the
+    lists; the lists' gather kernel has nothing left to do; the W the incremental update works from is stored for them."""
+    lam = synth.ba(150, 3000, mode="tracks", seed=9)
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok
+    solver = CLinearSolver_Schur_HIP(schur_sparse=sparse, profile=1)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta) and rel_inf(eta, x_ref) < TOL
+    phases = solver.profile()
+    assert "schur_tiles" in phases, phases
+    monkeypatch.setenv("SLAMPP_NO_PREFIX_RUNS", "1")
+    lists = CLinearSolver_Schur_HIP(schur_sparse=sparse, profile=1)
+    eta2 = lam.rhs.copy()
+    assert lists.Solve_PosDef(lam, eta2) and rel_inf(eta2, x_ref) < TOL and rel_inf(eta, eta2) < 1e-11
+    monkeypatch.delenv("SLAMPP_NO_PREFIX_RUNS")
+    t_with = phases.get("schur_gather", (0, 0.0))[1] / max(phases.get("schur_gather", (1, 0))[0], 1)
+    t_without = lists.profile()["schur_gather"][1] / lists.profile()["schur_gather"][0]
+    assert t_with < 0.5 * t_without, (t_with, t_without)            # the long tracks were the lists' work
+    # the incremental update of the reduced system reads the W the run kernel stored for those landmarks
+    inc = CLinearSolver_Schur_HIP(schur_sparse=sparse, schur_incremental=2)
+    eta = lam.rhs.copy()
+    assert inc.Solve_PosDef(lam, eta)
+    k = np.diff(lam.bcol_ptr)[lam.n_matrix_cut:] - 1
+    points = np.nonzero(k > 10)[0][::7]
+    vals = lam.values.copy()
+    off = lam.block_value_offsets()
+    for p_ in points:
+        k1 = int(lam.bcol_ptr[lam.n_matrix_cut + p_ + 1])
+        vals[off[k1 - 1]:off[k1]] += 0.7 * np.eye(3).ravel()
+    lam2 = dataclasses.replace(lam, values=vals)
+    ok, x2, _, _ = O.solve_schur(lam2)
+    inc.Set_Changed_Landmarks(points)
+    eta = lam2.rhs.copy()
+    assert ok and inc.Solve_PosDef_Blocky(lam2, eta) and rel_inf(eta, x2) < TOL
