@@ -608,8 +608,7 @@ public:
 	inline CLinearSolver_HIP_Factorizer(int n_device = 0)
 		:CLinearSolver_HIP_Base(n_device)
 	{
-		Set_Option("natural_order", 1);
-		Set_Option("dense_top_nb", 0);
+		Set_Option("natural_order", 1); // (big separators of the caller's order are factored on the matrix cores and handed back like the rest)
 	}
 
 	/**
@@ -625,19 +624,14 @@ public:
 		// the cached analysis is reused only if every block of lambda is where it was (verified while gathering)
 		Gather_Or_Reanalyze(r_lambda, [&]() {
 			Analyze(r_lambda, SLAMPP_HIP_MODE_SPARSE, 0, 0);
-			slampp_hip_plan_view t_view;
-			memset(&t_view, 0, sizeof(t_view));
-			Throw_On_Error(slampp_hip_get_plan(m_p_solver, &t_view)); // sizes
-			m_l_perm.resize(size_t(t_view.n_bcols)); m_l_dim.resize(size_t(t_view.n_bcols));
-			m_l_ptr.resize(size_t(t_view.n_bcols) + 1);
-			m_l_row.resize(size_t(t_view.l_blocks)); m_l_off.resize(size_t(t_view.l_blocks));
-			m_l_values.resize(size_t(t_view.l_values));
-			t_view.p_perm = m_l_perm.empty()? 0 : &m_l_perm[0];
-			t_view.p_dim = m_l_dim.empty()? 0 : &m_l_dim[0];
-			t_view.p_lptr = &m_l_ptr[0];
-			t_view.p_lrow = m_l_row.empty()? 0 : &m_l_row[0];
-			t_view.p_loff = m_l_off.empty()? 0 : &m_l_off[0];
-			Throw_On_Error(slampp_hip_get_plan(m_p_solver, &t_view)); // contents
+			int64_t n_bcols = 0, n_l_blocks = 0, n_l_values = 0;
+			Throw_On_Error(slampp_hip_factor_structure(m_p_solver, &n_bcols, &n_l_blocks, &n_l_values, 0, 0, 0, 0, 0)); // sizes
+			m_l_perm.resize(size_t(n_bcols)); m_l_dim.resize(size_t(n_bcols));
+			m_l_ptr.resize(size_t(n_bcols) + 1);
+			m_l_row.resize(size_t(n_l_blocks)); m_l_off.resize(size_t(n_l_blocks));
+			m_l_values.resize(size_t(n_l_values));
+			Throw_On_Error(slampp_hip_factor_structure(m_p_solver, &n_bcols, &n_l_blocks, &n_l_values, m_l_perm.empty()? 0 : &m_l_perm[0],
+				m_l_dim.empty()? 0 : &m_l_dim[0], &m_l_ptr[0], m_l_row.empty()? 0 : &m_l_row[0], m_l_off.empty()? 0 : &m_l_off[0])); // contents
 			for(size_t i = 0, m = m_l_perm.size(); i < m; ++ i) {
 				if(size_t(m_l_perm[i]) != i)
 					throw std::runtime_error("CLinearSolver_HIP: the factorization did not keep the caller's order");

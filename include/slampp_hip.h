@@ -220,11 +220,20 @@ int slampp_hip_solve_again(slampp_hip_solver *p_solver, double *p_rhs_inout);
 
 /* Numeric factorization only, the factor handed back to the host -- for CLinearSolverTag-style callers that keep
  * the factor themselves (the reference's Factorize_PosDef_Blocky, LinearSolver_CholMod.cpp:362-544, used by its
- * L / FastL solvers on a matrix they have ordered: set the option "natural_order" to 1 for that, and "dense_top_nb"
- * to 0).  p_factor_out receives l_values doubles (slampp_hip_plan_view): the lower factor L of the permuted Lambda,
- * block-CSC as described by the view's lptr / lrow / loff, blocks column-major, the diagonal block first in each
- * column.  Returns SLAMPP_HIP_NOT_POSDEF if a pivot is not positive. */
+ * L / FastL solvers on a matrix they have ordered: set the option "natural_order" to 1 for that).  p_factor_out
+ * receives l_values doubles: the lower factor L of the permuted Lambda, block-CSC over the CALLER's block columns as
+ * slampp_hip_factor_structure describes it (perm, dim, lptr / lrow / loff), blocks column-major, the diagonal block
+ * first in each column.  Like the reference's it takes any matrix: big separators are factored as one dense matrix on
+ * the matrix cores (the "dense top") and their columns handed back in the same block layout; block columns wider than
+ * 8 are factored in pieces and put together again (those only in the caller's own order: natural_order = 1).
+ * Returns SLAMPP_HIP_NOT_POSDEF if a pivot is not positive. */
 int slampp_hip_factorize(slampp_hip_solver *p_solver, const double *p_values, double *p_factor_out);
+/* ... and the block structure of that factor (after slampp_hip_analyze, sparse mode): sizes through the first three
+ * pointers, arrays where the pointers are not NULL -- perm[new] = old and dim[new] over the caller's n_bcols block
+ * columns, lptr [n_bcols + 1], lrow / loff [l_blocks].  Stands in for the structure the reference's factor comes back
+ * in, a CUberBlockMatrix (LinearSolver_CholMod.cpp:520-544: From_Sparse into r_factor). */
+int slampp_hip_factor_structure(const slampp_hip_solver *p_solver, int64_t *p_n_bcols, int64_t *p_l_blocks, int64_t *p_l_values,
+	int32_t *p_perm, int32_t *p_dim, int64_t *p_lptr, int32_t *p_lrow, int64_t *p_loff);
 
 /* Schur mode, option "schur_incremental" = 1 (set before slampp_hip_analyze): the next factor_solve updates the reduced
  * camera system the previous factor_solve of this handle assembled instead of rebuilding it -- the reference's dog-leg

@@ -177,6 +177,7 @@ struct slampp_hip_solver {
 	std::vector<int64_t> simt_host_tab;
 	// dense top of the sparse path (plan.h): assembled Schur complement + dense factor workspaces
 	slampp::CDevArray<slampp::TDenseBlk> d_dense_blks;
+	slampp::CDevArray<int64_t> d_dense_blk_loff; // where each of those blocks lives in the factor's block layout (slampp_hip_factorize)
 	slampp::CDevArray<slampp::TDenseCol> d_dense_cols;
 	slampp::CDevArray<double> d_dense, d_dense_invdiag, d_dense_z, d_dense_x;
 	slampp::CDevArray<int32_t> d_dense_gaps; // positions inside the dense top that no column maps to (alignment padding)

@@ -325,7 +325,7 @@ void slampp_hip_solver::Free_Device()
 	b_leaf_linv_valid = true;
 	d_panel_pkg.Free(); d_panel_off.Free(); d_panel_rest.Free(); d_panel_upd_slots.Free(); d_panel_upd_ents.Free();
 	simt_chunk_ptr.clear(); simt_rest_ptr.clear();
-	d_dense_blks.Free(); d_dense_cols.Free(); d_dense.Free(); d_dense_invdiag.Free(); d_dense_z.Free(); d_dense_x.Free();
+	d_dense_blks.Free(); d_dense_blk_loff.Free(); d_dense_cols.Free(); d_dense.Free(); d_dense_invdiag.Free(); d_dense_z.Free(); d_dense_x.Free();
 	n_dense_blks = n_dense_cols = n_dense_dim = n_dense_pad = 0;
 	dense_tiles.Free();
 	b_dense_tiles = false;
@@ -634,6 +634,7 @@ void slampp_hip_solver::Analyze_Sparse()
 	n_dense_pad = n_dense_dim? dense_padded_dim(n_dense_dim) : 0;
 	std::vector<TDenseBlk> dense_blks;
 	std::vector<TDenseCol> dense_cols;
+	std::vector<int64_t> dense_blk_loff;
 	if(n_dense_dim) {
 		for(int32_t j = 0; j < P.n; ++ j) {
 			if(P.dense_pos[j] < 0)
@@ -660,9 +661,11 @@ void slampp_hip_solver::Analyze_Sparse()
 				} else
 					b.nr = -1;
 				dense_blks.push_back(b);
+				dense_blk_loff.push_back(P.loff[k]);
 			}
 		}
 		d_dense_blks.Upload(dense_blks, stream);
+		d_dense_blk_loff.Upload(dense_blk_loff, stream);
 		d_dense_cols.Upload(dense_cols, stream);
 		{
 			std::vector<char> covered(n_dense_dim, 0);
@@ -1373,7 +1376,7 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 		}
 		Phase_End();
 	}
-	if(b_factor_only) { // (only without a dense top: the caller wants every column of L)
+	if(b_factor_only && !n_dense_dim) { // (the caller wants every column of L: here they all are)
 		SLAMPP_HIP_CHECK(hipGetLastError());
 		return;
 	}
@@ -1399,6 +1402,11 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			else
 				dense_cholesky(d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), p_flag, stream);
 			Phase_End();
+			if(b_factor_only) { // the dense top's columns back into the factor's block layout, and no substitutions
+				launch_dense_gather_factor(d_dense_blks.p(), d_dense_blk_loff.p(), n_dense_blks, d_dense.p(), ld, d_L.p(), stream);
+				SLAMPP_HIP_CHECK(hipGetLastError());
+				return;
+			}
 		} else {
 			Phase_Begin("dense_forward");
 			launch_dense_assemble(dplan, d_dense_blks.p(), n_dense_blks, 0, d_L.p(), p_rhs_dev, d_w.p(),
@@ -2291,6 +2299,111 @@ int slampp_hip_solve_marginal_poses(slampp_hip_solver *p_solver, const double *p
 	return n_result;
 }
 
+// The factor's block structure in the CALLER's block columns (what slampp_hip_factorize fills).  Without wide columns that is
+// the plan's own; where block columns wider than 8 were cut into pieces (Refine_Structure) the pieces are put together
+// again: block (I, J) of the caller's columns exists where any of its pieces does.  Needs the pieces of a column next to
+// each other and in order, which the caller's own order (option natural_order; what Factorize_PosDef_Blocky asks for:
+// the matrix comes pre-ordered, LinearSolver_CholMod.cpp:362-544) guarantees.
+namespace {
+
+struct TCoarseFactor {
+	std::vector<int32_t> perm, dim, lrow;
+	std::vector<int64_t> lptr, loff; // loff[l_blocks] = number of values
+	std::vector<int32_t> piece_col, piece_off; // refined column -> caller's column, scalar offset inside it
+};
+
+bool coarse_factor_structure(const slampp_hip_solver &s, TCoarseFactor &r_out, std::string &r_s_why)
+{
+	const Plan &P = s.plan;
+	const int64_t n = int64_t(s.cumsum.size()) - 1, n_refined = int64_t(s.refined_cumsum.size()) - 1;
+	r_out.piece_col.assign(size_t(n_refined), 0);
+	r_out.piece_off.assign(size_t(n_refined), 0);
+	{
+		int64_t c = 0;
+		for(int64_t p = 0; p < n_refined; ++ p) {
+			while(s.refined_cumsum[p] >= s.cumsum[c + 1])
+				++ c;
+			r_out.piece_col[p] = int32_t(c);
+			r_out.piece_off[p] = int32_t(s.refined_cumsum[p] - s.cumsum[c]);
+		}
+	}
+	for(int64_t p = 0; p < n_refined; ++ p) {
+		if(P.perm[p] != p) {
+			r_s_why = "factorize: block columns wider than 8 are factored in pieces: the factor has the caller's block layout only in the caller's own order (option natural_order = 1)";
+			return false;
+		}
+	}
+	r_out.perm.resize(size_t(n));
+	r_out.dim.resize(size_t(n));
+	for(int64_t c = 0; c < n; ++ c) {
+		r_out.perm[c] = int32_t(c);
+		r_out.dim[c] = int32_t(s.cumsum[c + 1] - s.cumsum[c]);
+	}
+	r_out.lptr.assign(1, 0);
+	r_out.lrow.clear();
+	r_out.loff.clear();
+	std::vector<int32_t> rows;
+	int64_t n_off = 0, p = 0;
+	for(int64_t c = 0; c < n; ++ c) {
+		rows.clear();
+		for(; p < n_refined && r_out.piece_col[p] == c; ++ p) {
+			for(int64_t k = P.lptr[p]; k < P.lptr[p + 1]; ++ k)
+				rows.push_back(r_out.piece_col[P.lrow[k]]);
+		}
+		std::sort(rows.begin(), rows.end());
+		rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+		for(size_t i = 0; i < rows.size(); ++ i) { // (ascending: the diagonal block first)
+			r_out.lrow.push_back(rows[i]);
+			r_out.loff.push_back(n_off);
+			n_off += int64_t(r_out.dim[rows[i]]) * r_out.dim[c];
+		}
+		r_out.lptr.push_back(int64_t(r_out.lrow.size()));
+	}
+	r_out.loff.push_back(n_off);
+	return true;
+}
+
+} // anonymous namespace
+
+int slampp_hip_factor_structure(const slampp_hip_solver *p_solver, int64_t *p_n_bcols, int64_t *p_l_blocks, int64_t *p_l_values,
+	int32_t *p_perm, int32_t *p_dim, int64_t *p_lptr, int32_t *p_lrow, int64_t *p_loff)
+{
+	if(!p_solver || !p_solver->b_analyzed || p_solver->n_mode != SLAMPP_HIP_MODE_SPARSE)
+		return SLAMPP_HIP_ERR_INVALID;
+	const slampp_hip_solver &s = *p_solver;
+	const Plan &P = s.plan;
+	try {
+		if(!s.b_refined) {
+			if(p_n_bcols) *p_n_bcols = P.n;
+			if(p_l_blocks) *p_l_blocks = int64_t(P.lrow.size());
+			if(p_l_values) *p_l_values = P.loff[P.lrow.size()];
+			if(p_perm) std::copy(P.perm.begin(), P.perm.end(), p_perm);
+			if(p_dim) std::copy(P.dim.begin(), P.dim.end(), p_dim);
+			if(p_lptr) std::copy(P.lptr.begin(), P.lptr.end(), p_lptr);
+			if(p_lrow) std::copy(P.lrow.begin(), P.lrow.end(), p_lrow);
+			if(p_loff) std::copy(P.loff.begin(), P.loff.begin() + P.lrow.size(), p_loff);
+			return SLAMPP_HIP_OK;
+		}
+		TCoarseFactor t;
+		std::string s_why;
+		if(!coarse_factor_structure(s, t, s_why)) {
+			const_cast<slampp_hip_solver*>(p_solver)->s_error = s_why;
+			return SLAMPP_HIP_ERR_UNSUPPORTED;
+		}
+		if(p_n_bcols) *p_n_bcols = int64_t(t.dim.size());
+		if(p_l_blocks) *p_l_blocks = int64_t(t.lrow.size());
+		if(p_l_values) *p_l_values = t.loff.back();
+		if(p_perm) std::copy(t.perm.begin(), t.perm.end(), p_perm);
+		if(p_dim) std::copy(t.dim.begin(), t.dim.end(), p_dim);
+		if(p_lptr) std::copy(t.lptr.begin(), t.lptr.end(), p_lptr);
+		if(p_lrow) std::copy(t.lrow.begin(), t.lrow.end(), p_lrow);
+		if(p_loff) std::copy(t.loff.begin(), t.loff.end() - 1, p_loff);
+		return SLAMPP_HIP_OK;
+	} catch(std::bad_alloc&) {
+		return SLAMPP_HIP_ERR_ALLOC;
+	}
+}
+
 int slampp_hip_factorize(slampp_hip_solver *p_solver, const double *p_values, double *p_factor_out)
 {
 	int n_result = guarded(p_solver, [&]() -> int {
@@ -2299,18 +2412,20 @@ int slampp_hip_factorize(slampp_hip_solver *p_solver, const double *p_values, do
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factorize: analyze was not called");
 		if(s.n_mode != SLAMPP_HIP_MODE_SPARSE)
 			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "factorize: the sparse mode only");
-		if(s.b_refined)
-			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "factorize: block columns wider than 8 are factored in pieces, the factor does not have the caller's block layout");
-		if(s.n_dense_dim)
-			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "factorize: set the option dense_top_nb to 0 (the dense top keeps its part of the factor in another layout)");
 		if(!p_values || !p_factor_out)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factorize: null pointer");
+		if(s.b_refined) {
+			for(size_t p = 0; p < s.plan.perm.size(); ++ p) {
+				if(s.plan.perm[p] != int32_t(p))
+					return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "factorize: block columns wider than 8 are factored in pieces: the factor has the caller's block layout only in the caller's own order (option natural_order = 1)");
+			}
+		}
 		s.d_A.Alloc(size_t(s.n_values));
 		s.d_rhs.Alloc(size_t(s.n_scalars));
 		Upload_Values_And_Join(s, p_values);
 		SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_rhs.p(), 0, size_t(s.n_scalars) * sizeof(double), s.stream)); // the fused forward substitution runs on zeros
-		s.Enqueue_Sparse(s.d_A.p(), s.d_rhs.p(), true, true);
-		s.b_factored = true;
+		s.Enqueue_Sparse(s.d_A.p(), s.d_rhs.p(), true, true); // (a dense top factors its columns on the matrix cores and hands them back into the block layout)
+		s.b_factored = s.n_dense_dim == 0; // (with a dense top the substitutions' vectors were not brought along: no solve_again from this)
 		return SLAMPP_HIP_OK;
 	});
 	if(n_result != SLAMPP_HIP_OK)
@@ -2320,9 +2435,38 @@ int slampp_hip_factorize(slampp_hip_solver *p_solver, const double *p_values, do
 		return n_result;
 	return guarded(p_solver, [&]() -> int {
 		slampp_hip_solver &s = *p_solver;
-		const size_t n_l_values = size_t(s.plan.loff[s.plan.lrow.size()]);
-		SLAMPP_HIP_CHECK(hipMemcpyAsync(p_factor_out, s.d_L.p(), n_l_values * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+		const Plan &P = s.plan;
+		const size_t n_l_values = size_t(P.loff[P.lrow.size()]);
+		if(!s.b_refined) {
+			SLAMPP_HIP_CHECK(hipMemcpyAsync(p_factor_out, s.d_L.p(), n_l_values * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+			SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+			return SLAMPP_HIP_OK;
+		}
+		// the pieces of the wide columns put together again: piece block (pi, pj) is a sub-block of the caller's block (I, J)
+		TCoarseFactor t;
+		std::string s_why;
+		if(!coarse_factor_structure(s, t, s_why))
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, s_why.c_str());
+		std::vector<double> pieces(n_l_values);
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(pieces.data(), s.d_L.p(), n_l_values * sizeof(double), hipMemcpyDeviceToHost, s.stream));
 		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+		std::fill(p_factor_out, p_factor_out + t.loff.back(), 0.0);
+		for(int64_t pj = 0; pj < int64_t(P.n); ++ pj) {
+			const int32_t J = t.piece_col[pj];
+			const int n_col0 = t.piece_off[pj], w = P.dim[pj];
+			for(int64_t k = P.lptr[pj]; k < P.lptr[pj + 1]; ++ k) {
+				const int32_t pi = P.lrow[k], I = t.piece_col[pi];
+				const int n_row0 = t.piece_off[pi], h = P.dim[pi], H = t.dim[I];
+				const int32_t *p_first = &t.lrow[size_t(t.lptr[J])], *p_last = &t.lrow[size_t(t.lptr[J + 1])];
+				const int64_t n_blk = t.lptr[J] + (std::lower_bound(p_first, p_last, I) - p_first);
+				double *p_dst = p_factor_out + t.loff[size_t(n_blk)];
+				const double *p_src = &pieces[size_t(P.loff[k])];
+				for(int b = 0; b < w; ++ b) {
+					for(int a = 0; a < h; ++ a)
+						p_dst[(n_row0 + a) + size_t(n_col0 + b) * H] = p_src[a + size_t(b) * h];
+				}
+			}
+		}
 		return SLAMPP_HIP_OK;
 	});
 }

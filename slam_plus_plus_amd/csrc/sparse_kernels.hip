@@ -706,6 +706,27 @@ void launch_dense_assemble(const TDevPlan &p, const TDenseBlk *blks, int n_blks,
 			p, blks, A, L, b, w, Dm, ld, int(b_rhs_only)));
 }
 
+// the dense top's part of the factor back into the factor's block layout (slampp_hip_factorize: the caller wants every
+// column of L): block e of the dense-top columns from the dense matrix, zeros above the diagonal of a diagonal block
+__global__ void __launch_bounds__(64)
+dense_gather_factor_kernel(const TDenseBlk *__restrict__ blks, const int64_t *__restrict__ loffs, const double *__restrict__ Dm, int ld,
+	double *__restrict__ L)
+{
+	const TDenseBlk bd = blks[blockIdx.x];
+	const int lane = threadIdx.x;
+	if(lane >= bd.di * bd.dj)
+		return;
+	const int r = lane % bd.di, q = lane / bd.di;
+	const bool b_diag = bd.nr >= 0;
+	L[loffs[blockIdx.x] + lane] = (b_diag && r < q)? 0.0 : Dm[bd.dst + r + size_t(q) * ld];
+}
+
+void launch_dense_gather_factor(const TDenseBlk *blks, const int64_t *loffs, int n_blks, const double *Dm, int ld, double *L, hipStream_t stream)
+{
+	if(n_blks > 0)
+		hipLaunchKernelGGL(dense_gather_factor_kernel, dim3(n_blks), dim3(64), 0, stream, blks, loffs, Dm, ld, L);
+}
+
 void launch_dense_scatter(const TDenseCol *cols, int n_cols, const double *x_dense, double *w, double *x_out,
 	hipStream_t stream)
 {

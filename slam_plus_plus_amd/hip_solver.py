@@ -96,6 +96,7 @@ ABI = {
     "slampp_hip_upload_values_async": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "slampp_hip_solve_again": (C.c_int, [_P, _P]),
     "slampp_hip_factorize": (C.c_int, [_P, _P, _P]),
+    "slampp_hip_factor_structure": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P, _P, _P, _P, _P]),
     "slampp_hip_schur_set_changed_points": (C.c_int, [_P, _P, C.c_int64]),
     "slampp_hip_solve_marginal_poses": (C.c_int, [_P, _P, _P]),
     "slampp_hip_solve_marginal_poses_device_async": (C.c_int, [_P, _P, _P]),
@@ -405,12 +406,26 @@ class _SolverBase:
         rhs = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_double)), shape=(int(st.n_scalars),))
         return values, rhs
 
+    def factor_structure(self) -> dict:
+        """Block structure of the factor slampp_hip_factorize hands back, over the caller's block columns
+        (slampp_hip_factor_structure): ``perm``, ``dim``, ``lptr``, ``lrow``, ``loff``, ``l_values``."""
+        n, nb, nv = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.slampp_hip_factor_structure(self._h, C.byref(n), C.byref(nb), C.byref(nv), None, None, None, None, None))
+        out = {"perm": np.zeros(n.value, dtype=np.int32), "dim": np.zeros(n.value, dtype=np.int32),
+               "lptr": np.zeros(n.value + 1, dtype=np.int64), "lrow": np.zeros(nb.value, dtype=np.int32),
+               "loff": np.zeros(nb.value, dtype=np.int64)}
+        self._check(self._lib.slampp_hip_factor_structure(self._h, C.byref(n), C.byref(nb), C.byref(nv), _ptr(out["perm"]), _ptr(out["dim"]),
+                                                          _ptr(out["lptr"]), _ptr(out["lrow"]), _ptr(out["loff"])))
+        out["l_values"] = int(nv.value)
+        return out
+
     def factorize(self, lam):
-        """Numeric factor only (sparse mode, no dense top): ``(ok, plan, l_values)`` -- the lower factor of the permuted
-        Lambda in the plan's block-CSC layout (``plan['lptr']``, ``['lrow']``, ``['loff']``, ``['perm']``, ``['dim']``)."""
+        """Numeric factor only (sparse mode): ``(ok, structure, l_values)`` -- the lower factor of the permuted Lambda in
+        block-CSC over the caller's block columns (``structure['lptr']``, ``['lrow']``, ``['loff']``, ``['perm']``, ``['dim']``:
+        factor_structure()); a dense top's columns and the pieces of block columns wider than 8 come back in that layout too."""
         if not self._analyzed or self._structure_key != self._key(lam):
             self.SymbolicDecomposition_Blocky(lam)
-        plan = self.plan()
+        plan = self.factor_structure()
         vals = np.ascontiguousarray(lam.values, dtype=np.float64)
         out = np.zeros(int(plan["l_values"]))
         ok = self._check(self._lib.slampp_hip_factorize(self._h, _ptr(vals), _ptr(out)))

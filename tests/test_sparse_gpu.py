@@ -174,12 +174,68 @@ def test_factorize_returns_the_cholesky_factor(name, natural):
     assert np.abs(Lm - Lref).max() < 1e-11 * np.abs(Lref).max()
 
 
-def test_factorize_not_posdef_and_dense_top_refused():
+def test_factorize_not_posdef():
     lam = synth.indefinite(40, 6, seed=5)
     ok, _, _ = CLinearSolver_HIP(natural_order=1, dense_top_nb=0).factorize(lam)
     assert not ok
-    with pytest.raises(NotImplementedError):
-        CLinearSolver_HIP().factorize(synth.sphere(30, 30))      # a dense top keeps part of the factor elsewhere
+
+
+@pytest.mark.parametrize("tiles", [-1, 0])
+@pytest.mark.parametrize("name", ["sphere", "manhattan", "grid"])
+def test_factorize_hands_back_the_dense_top_too(name, tiles):
+    """Round 4: the reference's Factorize_PosDef_Blocky takes any matrix (LinearSolver_CholMod.cpp:362-544); so does
+    slampp_hip_factorize now -- the big separators of a 2-D-like graph are factored as one dense matrix on the matrix cores
+    and their columns come back in the same block layout as the rest (until round 3: refused, dense_top_nb = 0 required)."""
+    lam = {"sphere": lambda: synth.sphere(30, 30), "manhattan": lambda: synth.manhattan(3500),
+           "grid": lambda: synth.sphere(24, 40, seed=8)}[name]()
+    solver = CLinearSolver_HIP(dense_top_tiles=tiles)
+    ok, st, l_values = solver.factorize(lam)
+    assert ok and solver.stats()["schur_dim"] > 0            # there IS a dense top
+    Lm, cs_new = dense_factor(lam, st, l_values)
+    A = lam.to_scipy().toarray()
+    idx = np.concatenate([np.arange(lam.cumsum[o], lam.cumsum[o + 1]) for o in st["perm"]])
+    Lref = np.linalg.cholesky(A[np.ix_(idx, idx)])
+    assert np.abs(np.triu(Lm, 1)).max() == 0.0
+    assert np.abs(Lm - Lref).max() < 1e-10 * np.abs(Lref).max()
+    eta = lam.rhs.copy()                                      # ... and the handle still solves
+    assert solver.Solve_PosDef_Blocky(lam, eta)
+    assert np.abs(lam.to_scipy() @ eta - lam.rhs).max() < 1e-9 * np.abs(lam.rhs).max()
+
+
+@pytest.mark.parametrize("dims", [(11, 3), (9, 9), (25, 6), (16, 2)])
+def test_factorize_puts_the_pieces_of_wide_block_columns_together_again(dims):
+    """Block columns wider than 8 (cameras with their intrinsics in the vertex: 11) are factored in pieces of at most 8; the
+    factor comes back in the CALLER's blocks (natural order: what Factorize_PosDef_Blocky asks for)."""
+    rng = np.random.default_rng(sum(dims))
+    n = 60
+    d = np.where(rng.random(n) < 0.4, dims[0], dims[1])
+    cs = np.concatenate([[0], np.cumsum(d)]).astype(np.int64)
+    a, b = rng.integers(0, n, 90), rng.integers(0, n, 90)
+    pairs = set(zip(range(n - 1), range(1, n))) | {(min(x, y), max(x, y)) for x, y in zip(a, b) if x != y}
+    M = np.zeros((cs[-1], cs[-1]))
+    for r, c in pairs:
+        B = 0.3 * rng.standard_normal((d[r], d[c]))
+        M[cs[r]:cs[r + 1], cs[c]:cs[c + 1]] = B
+        M[cs[c]:cs[c + 1], cs[r]:cs[r + 1]] = B.T
+    M += np.eye(cs[-1]) * (np.abs(M).sum(axis=1).max() + 1.0)      # well inside the positive definite cone
+    bcol_ptr, brow, vals = [0], [], []
+    for c in range(n):
+        for r in range(c + 1):
+            if r == c or (r, c) in pairs:
+                brow.append(r)
+                vals.append(M[cs[r]:cs[r + 1], cs[c]:cs[c + 1]].T.ravel())
+        bcol_ptr.append(len(brow))
+    lam = synth.BlockSystem(cs, np.asarray(bcol_ptr, dtype=np.int64), np.asarray(brow, dtype=np.int32), np.concatenate(vals),
+                            rng.standard_normal(int(cs[-1])), 0)
+    solver = CLinearSolver_HIP(natural_order=1)
+    ok, st, l_values = solver.factorize(lam)
+    assert ok and np.array_equal(st["perm"], np.arange(n)) and np.array_equal(st["dim"], d)
+    Lm, _ = dense_factor(lam, st, l_values)
+    Lref = np.linalg.cholesky(lam.to_scipy().toarray())
+    assert np.abs(np.triu(Lm, 1)).max() == 0.0
+    assert np.abs(Lm - Lref).max() < 1e-11 * np.abs(Lref).max()
+    with pytest.raises(NotImplementedError):                 # the pieces of a column are only together in the caller's order
+        CLinearSolver_HIP(natural_order=0).factorize(lam)
 
 
 def random_system(seed):
