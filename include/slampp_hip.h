@@ -350,6 +350,18 @@ int slampp_hip_assemble_device_async(slampp_hip_assembly *p_assembly, const doub
 	const double *p_sigma_inv_dev, const double *p_error_dev, const double *p_weight_dev, int64_t n_unary_vertex,
 	const double *p_unary_factor, const double *p_unary_error, double *p_values_dev, double *p_eta_dev, int b_accumulate);
 
+/* Every edge type of a graph in one call, as the reference's Refresh_Lambda reduces them all
+ * (include/slam/NonlinearSolver_Lambda_Base.h:1659-1688: one loop per edge pool of the typelist): n_sets homogeneous
+ * edge sets of the same Lambda -- pose-pose and pose-landmark edges, say -- each with its own assembly handle and
+ * device arrays as above.  Lambda and eta start from zero (b_accumulate != 0: from what the arrays hold), every set is
+ * added in the order given (fixed order: bit-reproducible), the unary factor with the first.  Enqueue-only. */
+typedef struct slampp_hip_edge_set {
+	slampp_hip_assembly *p_assembly;
+	const double *p_J0_dev, *p_J1_dev, *p_sigma_inv_dev, *p_error_dev, *p_weight_dev; /* as slampp_hip_assemble_device_async */
+} slampp_hip_edge_set;
+int slampp_hip_assemble_sets_device_async(const slampp_hip_edge_set *p_sets, int n_sets, int64_t n_unary_vertex,
+	const double *p_unary_factor, const double *p_unary_error, double *p_values_dev, double *p_eta_dev, int b_accumulate);
+
 /* Multi-GPU BA (new functionality, no reference counterpart -- SURVEY.md section 8e): every rank
  * holds a landmark shard (its own points + all cameras); the partial reduced camera systems
  * [S | rhs] are summed over ranks by this callback (RCCL all-reduce over xGMI) between the Schur

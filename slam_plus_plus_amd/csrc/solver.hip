@@ -2658,6 +2658,35 @@ int slampp_hip_assemble_device_async(slampp_hip_assembly *p_assembly, const doub
 	});
 }
 
+int slampp_hip_assemble_sets_device_async(const slampp_hip_edge_set *p_sets, int n_sets, int64_t n_unary_vertex,
+	const double *p_unary_factor, const double *p_unary_error, double *p_values_dev, double *p_eta_dev, int b_accumulate)
+{
+	if(!p_sets || n_sets < 1 || !p_sets[0].p_assembly || !p_sets[0].p_assembly->p_solver)
+		return SLAMPP_HIP_ERR_INVALID;
+	slampp_hip_solver *p_solver = p_sets[0].p_assembly->p_solver;
+	return guarded(p_solver, [&]() -> int {
+		for(int i = 0; i < n_sets; ++ i) {
+			if(!p_sets[i].p_assembly || p_sets[i].p_assembly->p_solver != p_solver)
+				throw std::invalid_argument("assemble_sets: the edge sets belong to different solvers (or one was destroyed)");
+			if(p_sets[i].p_assembly->b_stale)
+				throw std::invalid_argument("assemble_sets: set_structure was called after an assembly was created");
+		}
+		if(!p_values_dev || !p_eta_dev)
+			throw std::invalid_argument("assemble_sets: null device pointer");
+		slampp_hip_solver &s = *p_solver;
+		if(!b_accumulate) { // a block of Lambda may receive edges of one type only: everything starts from zero, every set adds
+			SLAMPP_HIP_CHECK(hipMemsetAsync(p_values_dev, 0, size_t(s.n_values) * sizeof(double), s.stream));
+			SLAMPP_HIP_CHECK(hipMemsetAsync(p_eta_dev, 0, size_t(s.n_scalars) * sizeof(double), s.stream));
+		}
+		for(int i = 0; i < n_sets; ++ i) {
+			assembly_enqueue(*p_sets[i].p_assembly->p_state, p_sets[i].p_J0_dev, p_sets[i].p_J1_dev, p_sets[i].p_sigma_inv_dev,
+				p_sets[i].p_error_dev, p_sets[i].p_weight_dev, i? -1 : n_unary_vertex, i? 0 : p_unary_factor, i? 0 : p_unary_error,
+				p_values_dev, p_eta_dev, 1);
+		}
+		return SLAMPP_HIP_OK;
+	});
+}
+
 int slampp_hip_get_plan(const slampp_hip_solver *p_solver, slampp_hip_plan_view *p_view)
 {
 	if(!p_solver || !p_view || !p_solver->b_analyzed || p_solver->n_mode != SLAMPP_HIP_MODE_SPARSE)

@@ -69,6 +69,11 @@ class ShardView(C.Structure):
         ("p_bcol_cumsum", C.c_void_p), ("p_bcol_ptr", C.c_void_p), ("p_brow_idx", C.c_void_p)]
 
 
+class EdgeSetPtrs(C.Structure):
+    _fields_ = [("p_assembly", C.c_void_p), ("p_J0_dev", C.c_void_p), ("p_J1_dev", C.c_void_p), ("p_sigma_inv_dev", C.c_void_p),
+                ("p_error_dev", C.c_void_p), ("p_weight_dev", C.c_void_p)]
+
+
 class PhaseTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("n_count", C.c_int64), ("f_total_ms", C.c_double)]
 
@@ -115,6 +120,7 @@ ABI = {
     "slampp_hip_assembly_create": (C.c_int, [_P, C.POINTER(_P), C.c_int64, _P, _P, C.c_int]),
     "slampp_hip_assembly_destroy": (None, [_P]),
     "slampp_hip_assemble_device_async": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, C.c_int]),
+    "slampp_hip_assemble_sets_device_async": (C.c_int, [C.POINTER(EdgeSetPtrs), C.c_int, C.c_int64, _P, _P, _P, _P, C.c_int]),
     "slampp_hip_get_plan": (C.c_int, [_P, C.POINTER(PlanView)]),
     "slampp_hip_plan_create": (C.c_int, [C.POINTER(_P), C.c_int64, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
     "slampp_hip_plan_get": (C.c_int, [_P, C.POINTER(PlanView), C.POINTER(Stats)]),
@@ -630,3 +636,20 @@ class CLambdaAssembly_HIP:
         self._solver._check(self._lib.slampp_hip_assemble_device_async(
             self._a, J0_ptr, J1_ptr, sigma_inv_ptr, error_ptr, weight_ptr or None, int(unary_vertex),
             None if uf is None else _ptr(uf), None if ue is None else _ptr(ue), values_ptr, eta_ptr, int(bool(accumulate))))
+
+
+def Refresh_Lambda_sets_device(assemblies, pointer_sets, values_ptr: int, eta_ptr: int, unary_vertex: int = 0, unary_factor=None,
+                               unary_error=None, accumulate: bool = False) -> None:
+    """Every edge type of one Lambda in one call (slampp_hip_assemble_sets_device_async): ``assemblies`` a list of
+    CLambdaAssembly_HIP of the same solver, ``pointer_sets`` their (J0, J1, sigma_inv, error, weight) device pointers."""
+    sets = (EdgeSetPtrs * len(assemblies))()
+    for i, (a, ptrs) in enumerate(zip(assemblies, pointer_sets)):
+        sets[i].p_assembly = a._a
+        sets[i].p_J0_dev, sets[i].p_J1_dev, sets[i].p_sigma_inv_dev, sets[i].p_error_dev = [int(p) for p in ptrs[:4]]
+        sets[i].p_weight_dev = int(ptrs[4]) if len(ptrs) > 4 and ptrs[4] else None
+    uf = None if unary_factor is None else np.ascontiguousarray(unary_factor, dtype=np.float64)
+    ue = None if unary_error is None else np.ascontiguousarray(unary_error, dtype=np.float64)
+    solver = assemblies[0]._solver
+    solver._check(solver._lib.slampp_hip_assemble_sets_device_async(
+        sets, len(assemblies), int(unary_vertex), None if uf is None else _ptr(uf), None if ue is None else _ptr(ue),
+        values_ptr, eta_ptr, int(bool(accumulate))))

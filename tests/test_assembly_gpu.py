@@ -145,6 +145,54 @@ def test_two_edge_sets_accumulate():
     assert rel_inf(eta.cpu().numpy(), x_ref) < 1e-10
 
 
+def test_every_edge_type_in_one_call():
+    """slampp_hip_assemble_sets_device_async: odometry edges (SE(3), 6-d residuals), loop closures (a second pose-pose set) and
+    pose-landmark edges (3-d residuals) of one graph in ONE call, as the reference's Refresh_Lambda reduces every edge pool
+    of its typelist (NonlinearSolver_Lambda_Base.h:1659-1688); the arrays start as NaN: the call owns their initial state."""
+    from slam_plus_plus_amd.hip_solver import Refresh_Lambda_sets_device
+    n_poses, n_lm = 300, 700
+    rng = np.random.default_rng(18)
+    dims = np.concatenate([np.full(n_poses, 6), np.full(n_lm, 3)])
+    a0, a1 = np.arange(n_poses - 1), np.arange(1, n_poses)
+    c0 = rng.integers(0, n_poses - 20, 60)
+    c1 = c0 + rng.integers(5, 20, 60)
+    b0 = rng.integers(0, n_poses, 3 * n_lm)
+    b1 = np.repeat(np.arange(n_lm), 3) + n_poses
+    lam = synth.structure_from_edges(dims, np.concatenate([a0, c0, b0]), np.concatenate([a1, c1, b1]))
+    sets = [synth.random_edge_set(dims, a0, a1, rd=6, seed=1, anchor=0), synth.random_edge_set(dims, c0, c1, rd=6, seed=2, anchor=0),
+            synth.random_edge_set(dims, b0, b1, rd=3, seed=3, anchor=0)]
+    for es in sets[1:]:
+        es.unary_factor = None
+    ref_v, ref_e = np.zeros(lam.values.shape[0]), np.zeros(lam.n_scalars)
+    for es in sets:
+        v, e = O.assemble_lambda(lam, es)
+        ref_v += v
+        ref_e += e
+    solver = CLinearSolver_HIP()
+    if ASSEMBLY_GROUPS is not None:
+        solver.set_option("assembly_groups", ASSEMBLY_GROUPS)
+    asms = [CLambdaAssembly_HIP(solver, lam, es.v0, es.v1, es.rd) for es in sets]
+    bufs = [[dev(a) for a in (es.J0, es.J1, es.sigma_inv, es.err, es.weight)] for es in sets]
+    values = torch.full((lam.values.shape[0],), float("nan"), dtype=torch.float64, device="cuda")
+    eta = torch.full((lam.n_scalars,), float("nan"), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    Refresh_Lambda_sets_device(asms, [[ptr(b) for b in bs] for bs in bufs], values.data_ptr(), eta.data_ptr(), sets[0].unary_vertex,
+                               sets[0].unary_factor, sets[0].unary_error)
+    assert solver.sync()
+    assert rel_inf(values.cpu().numpy(), ref_v) < TOL and rel_inf(eta.cpu().numpy(), ref_e) < TOL
+    # a second call with b_accumulate adds the same again
+    Refresh_Lambda_sets_device(asms[1:], [[ptr(b) for b in bs] for bs in bufs[1:]], values.data_ptr(), eta.data_ptr(), accumulate=True)
+    assert solver.sync()
+    extra_v = sum(O.assemble_lambda(lam, es)[0] for es in sets[1:])
+    assert rel_inf(values.cpu().numpy(), ref_v + extra_v) < TOL
+    lam.values, lam.rhs = ref_v, ref_e
+    ok, x_ref, _ = O.solve_sparse(lam)
+    Refresh_Lambda_sets_device(asms, [[ptr(b) for b in bs] for bs in bufs], values.data_ptr(), eta.data_ptr(), sets[0].unary_vertex,
+                               sets[0].unary_factor, sets[0].unary_error)
+    assert ok and solver.factor_solve_device(values.data_ptr(), eta.data_ptr())
+    assert rel_inf(eta.cpu().numpy(), x_ref) < 1e-10
+
+
 def test_errors():
     lam, es, _ = load_assembly("assembly_se2_n40")
     solver = CLinearSolver_HIP()
