@@ -262,7 +262,9 @@ int slampp_hip_solve_marginal_poses_device_async(slampp_hip_solver *p_solver, co
  * recursion run from the root of the elimination tree downwards; p_block_diag receives one dim x dim column-major block
  * per block column, in the order of slampp_hip_set_structure.  Where the plan has a dense top, its part of the
  * inverse is the dense inverse of the top's Schur complement (matrix cores), and the recursion continues below it.
- * Needs one block size (3, 6 or 7): SLAMPP_HIP_ERR_UNSUPPORTED otherwise. */
+ * One block size (3, 6 or 7: unrolled kernels), or -- like the reference's, Marginals.h:1694, which takes any -- a mix of
+ * block sizes up to 8 (poses and landmarks in one graph): block c is d_c x d_c, the blocks follow each other; that
+ * one without a dense top (option dense_top_nb = 0).  Block columns wider than 8: SLAMPP_HIP_ERR_UNSUPPORTED. */
 int slampp_hip_marginals(slampp_hip_solver *p_solver, const double *p_values, double *p_block_diag);
 int slampp_hip_marginals_device_async(slampp_hip_solver *p_solver, const double *p_values_dev, double *p_block_diag_dev);
 

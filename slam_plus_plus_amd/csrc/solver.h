@@ -193,6 +193,8 @@ struct slampp_hip_solver {
 	slampp::CDevArray<double> d_Z;         // laid out like d_L
 	slampp::CDevArray<double> d_Zd, d_Zd_work; // inverse of the dense top's Schur complement, and the copy of its factor that gets inverted
 	slampp::CDevArray<int64_t> d_diag_zoff; // offset of every block column's diagonal block in it, original order
+	slampp::CDevArray<int32_t> d_diag_dim;  // mixed block sizes: every caller's column's dimension
+	slampp::CDevArray<int64_t> d_diag_out_off; // ... and where its block goes in the output
 	slampp::CDevArray<int64_t> d_damp_off; // (offset of the diagonal block's first element, dimension) per block column: apply_damping
 	bool b_damp_valid = false;
 	slampp::CDevArray<int> d_flag;

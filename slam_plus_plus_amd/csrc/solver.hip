@@ -342,7 +342,7 @@ void slampp_hip_solver::Free_Device()
 		p_sinv = 0;
 	}
 	b_sinv_tried = false;
-	d_Z.Free(); d_diag_zoff.Free(); d_Zd.Free(); d_Zd_work.Free();
+	d_Z.Free(); d_diag_zoff.Free(); d_diag_dim.Free(); d_diag_out_off.Free(); d_Zd.Free(); d_Zd_work.Free();
 	if(p_schur) {
 		schur_destroy(p_schur);
 		p_schur = 0;
@@ -2125,7 +2125,7 @@ int slampp_hip_marginals_device_async(slampp_hip_solver *p_solver, const double 
 		if(s.n_mode != SLAMPP_HIP_MODE_SPARSE)
 			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "marginals: sparse mode only (Schur mode: slampp_hip_schur_marginals)");
 		if(s.b_refined)
-			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "marginals: needs one block size (3, 6 or 7)");
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "marginals: block columns wider than 8 are factored in pieces: no covariance blocks in the caller's layout");
 		if(!p_values_dev || !p_block_diag_dev)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "marginals: null pointer");
 		const Plan &P = s.plan;
@@ -2139,6 +2139,18 @@ int slampp_hip_marginals_device_async(slampp_hip_solver *p_solver, const double 
 					zoff[c] = (P.dense_dim && P.dense_pos[j] >= 0)? -int64_t(P.dense_pos[j]) - 1 : P.loff[P.lptr[j]];
 				}
 				s.d_diag_zoff.Upload(zoff, s.stream);
+				if(!P.uniform_dim) { // mixed block sizes: where every caller's column's block goes, and how big it is
+					std::vector<int32_t> dims(size_t(P.n));
+					std::vector<int64_t> out_off(size_t(P.n));
+					int64_t n_at = 0;
+					for(int32_t c = 0; c < P.n; ++ c) {
+						dims[c] = int32_t(s.cumsum[c + 1] - s.cumsum[c]);
+						out_off[c] = n_at;
+						n_at += int64_t(dims[c]) * dims[c];
+					}
+					s.d_diag_dim.Upload(dims, s.stream);
+					s.d_diag_out_off.Upload(out_off, s.stream);
+				}
 				s.d_Z.Alloc(size_t(P.loff.back()));
 				if(s.n_dense_dim) {
 					s.d_Zd.Alloc(size_t(s.n_dense_pad) * s.n_dense_pad);
@@ -2148,7 +2160,7 @@ int slampp_hip_marginals_device_async(slampp_hip_solver *p_solver, const double 
 			}
 		}
 		if(!s.p_sinv)
-			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "marginals: needs one block size (3, 6 or 7)");
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "marginals: mixed block sizes are taken without a dense top only (set the option dense_top_nb to 0), block sizes above 8 not at all");
 		// the fused forward substitution reads a right-hand side, and with a dense top it rides through that factorization
 		// as a row of the matrix: zeros (a NaN there would spread through 0 x NaN in the tile products)
 		s.d_rhs.Alloc(size_t(s.n_scalars));
@@ -2166,7 +2178,10 @@ int slampp_hip_marginals_device_async(slampp_hip_solver *p_solver, const double 
 		}
 		sparse_inverse_enqueue(*s.p_sinv, P, s.d_L.p(), s.d_Linv.p(), s.d_Z.p(), s.stream, s.d_Zd.p(), s.n_dense_pad);
 		s.Phase_End();
-		inverse_diag_blocks_launch(P.n, P.max_dim, s.d_diag_zoff.p(), s.d_Z.p(), s.d_Zd.p(), s.n_dense_pad, p_block_diag_dev, s.stream);
+		if(P.uniform_dim)
+			inverse_diag_blocks_launch(P.n, P.max_dim, s.d_diag_zoff.p(), s.d_Z.p(), s.d_Zd.p(), s.n_dense_pad, p_block_diag_dev, s.stream);
+		else
+			inverse_diag_blocks_any_launch(P.n, s.d_diag_dim.p(), s.d_diag_zoff.p(), s.d_diag_out_off.p(), s.d_Z.p(), p_block_diag_dev, s.stream);
 		SLAMPP_HIP_CHECK(hipGetLastError());
 		s.b_factored = true; // the factor of these values is in place
 		return SLAMPP_HIP_OK;

@@ -8,8 +8,8 @@ namespace slampp {
 
 struct CSparseInverse;
 
-// lists for a plan with one block size (3, 6, 7) and -- unless allowed -- no dense top; 0 if the plan is not of that
-// kind; throws
+// lists for a plan with one block size (3, 6, 7) and -- unless allowed -- no dense top, or with any mix of block sizes up
+// to 8 and no dense top; 0 if the plan is not of that kind; throws
 CSparseInverse *sparse_inverse_setup(const Plan &P, hipStream_t stream, bool b_allow_dense_top = false);
 void sparse_inverse_destroy(CSparseInverse *p);
 size_t sparse_inverse_bytes(const CSparseInverse *p);
@@ -21,6 +21,9 @@ void sparse_inverse_enqueue(const CSparseInverse &r_inv, const Plan &P, const do
 // one d x d block per block column: Z + p_where[c], or for p_where[c] = -(position + 1) the dense top's inverse at it
 void inverse_diag_blocks_launch(int64_t n, int d, const int64_t *p_where, const double *Z, const double *Zd, int ld, double *out,
 	hipStream_t stream);
+// ... mixed block sizes: block c has p_dim[c] rows, lives at Z + p_where[c] and goes to out + p_out_off[c]
+void inverse_diag_blocks_any_launch(int64_t n, const int32_t *p_dim, const int64_t *p_where, const int64_t *p_out_off, const double *Z,
+	double *out, hipStream_t stream);
 // replaces the right-hand side row of a copy of the dense top's factor by an identity row
 void dense_top_clear_rhs_row(double *M, int ld, hipStream_t stream);
 // offset of the factor block (i, k), i >= k, in L / Z, or -1

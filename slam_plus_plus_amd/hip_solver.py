@@ -508,16 +508,23 @@ def _block_diagonal_marginals(self, lam):
     """Block diagonal of the covariance Lambda^-1 ([n, d, d]), as CMarginals::Calculate_DenseMarginals_Recurrent_FBS
     (.., mpart_Diagonal) gives the reference's nonlinear solvers (NonlinearSolver_Lambda.h:700-760): factorization and a
     sparse inverse subset on the factor's pattern (below a dense inverse of the plan's dense top, if it has one).  One block
-    size (3, 6 or 7)."""
+    size (3, 6 or 7) -> an array; a mix of block sizes up to 8 (no dense top) -> a list of blocks."""
     if not self._analyzed or self._structure_key != self._key(lam):
         self.SymbolicDecomposition_Blocky(lam)
     dims = np.diff(lam.cumsum)
-    d = int(dims[0])
-    out = np.empty((len(dims), d, d), dtype=np.float64)
     vals = np.ascontiguousarray(lam.values, dtype=np.float64)
-    if not self._check(self._lib.slampp_hip_marginals(self._h, _ptr(vals), _ptr(out))):
+    if np.all(dims == dims[0]):
+        d = int(dims[0])
+        out = np.empty((len(dims), d, d), dtype=np.float64)
+        if not self._check(self._lib.slampp_hip_marginals(self._h, _ptr(vals), _ptr(out))):
+            raise ArithmeticError("Marginals: the system is not positive definite")
+        return out.transpose(0, 2, 1).copy()      # blocks come column-major
+    # mixed block sizes: a list of d_c x d_c blocks
+    flat = np.empty(int((dims.astype(np.int64) ** 2).sum()), dtype=np.float64)
+    if not self._check(self._lib.slampp_hip_marginals(self._h, _ptr(vals), _ptr(flat))):
         raise ArithmeticError("Marginals: the system is not positive definite")
-    return out.transpose(0, 2, 1).copy()      # blocks come column-major
+    off = np.concatenate([[0], np.cumsum(dims.astype(np.int64) ** 2)])
+    return [flat[off[c]:off[c + 1]].reshape(int(dims[c]), int(dims[c])).T.copy() for c in range(len(dims))]
 
 
 CLinearSolver_HIP.Marginals = _block_diagonal_marginals

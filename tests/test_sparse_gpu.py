@@ -316,8 +316,17 @@ def test_marginals_random_structures(seed):
     dims = np.diff(lam.cumsum)
     solver = CLinearSolver_HIP(**opts)
     if len(set(dims.tolist())) > 1 or int(dims[0]) not in (3, 6, 7):
-        with pytest.raises(NotImplementedError):
-            solver.Marginals(lam)
+        # any mix of block sizes up to 8 (round 4) -- with a dense top in the plan only the fixed block sizes
+        full = np.linalg.inv(lam.to_scipy().toarray())
+        try:
+            cov = solver.Marginals(lam)
+        except NotImplementedError:
+            assert solver.stats()["schur_dim"] > 0
+            return
+        cs = lam.cumsum
+        blocks = cov if isinstance(cov, list) else list(cov)
+        for c in range(lam.n_bcols):
+            assert np.abs(blocks[c] - full[cs[c]:cs[c + 1], cs[c]:cs[c + 1]]).max() < TOL * np.abs(full).max()
         return
     d = int(dims[0])
     full = np.linalg.inv(lam.to_scipy().toarray())
@@ -432,3 +441,40 @@ def test_lane_per_task_backward_substitution_and_lazy_inverses(d):
     cov = CLinearSolver_HIP(simt_backward=1, simt=1).Marginals(lam)
     cov_ref = CLinearSolver_HIP(simt_backward=0).Marginals(lam)
     assert rel_inf(cov, cov_ref) < 1e-10
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_marginals_mixed_block_sizes(seed):
+    """Round 4: covariance blocks of graphs with more than one block size -- poses and landmarks, SE(2) and SE(3) vertices --
+    as the reference's CMarginals::Calculate_DenseMarginals_Recurrent_FBS computes for any block matrix (Marginals.h:1694):
+    the inverse subset's generic kernel against the diagonal blocks of the dense inverse."""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(30, 200))
+    dims = rng.choice([2, 3, 6, 7, 8] if seed % 2 else [3, 6], size=n)
+    chords = int(rng.integers(n // 2, 2 * n))
+    a, b = rng.integers(0, n, chords), rng.integers(0, n, chords)
+    pairs = set(zip(range(n - 1), range(1, n))) | {(min(x, y), max(x, y)) for x, y in zip(a, b) if x != y}
+    cs = np.concatenate([[0], np.cumsum(dims)]).astype(np.int64)
+    M = np.zeros((cs[-1], cs[-1]))
+    for r, c in pairs:
+        B = 0.4 * rng.standard_normal((dims[r], dims[c]))
+        M[cs[r]:cs[r + 1], cs[c]:cs[c + 1]] = B
+        M[cs[c]:cs[c + 1], cs[r]:cs[r + 1]] = B.T
+    M += np.eye(cs[-1]) * (np.abs(M).sum(axis=1).max() * 0.6 + 1.0)
+    assert np.linalg.eigvalsh(M).min() > 0
+    bcol_ptr, brow, vals = [0], [], []
+    for c in range(n):
+        for r in range(c + 1):
+            if r == c or (r, c) in pairs:
+                brow.append(r)
+                vals.append(M[cs[r]:cs[r + 1], cs[c]:cs[c + 1]].T.ravel())
+        bcol_ptr.append(len(brow))
+    lam = synth.BlockSystem(cs, np.asarray(bcol_ptr, dtype=np.int64), np.asarray(brow, dtype=np.int32), np.concatenate(vals),
+                            rng.standard_normal(int(cs[-1])), 0)
+    cov = CLinearSolver_HIP(dense_top_nb=0).Marginals(lam)
+    Minv = np.linalg.inv(M)
+    assert isinstance(cov, list) and len(cov) == n
+    scale = np.abs(Minv).max()
+    for c in range(n):
+        assert cov[c].shape == (dims[c], dims[c])
+        assert np.abs(cov[c] - Minv[cs[c]:cs[c + 1], cs[c]:cs[c + 1]]).max() < 1e-10 * scale
