@@ -742,7 +742,8 @@ public:
 	 *		solver calculated") -- here lambda is all that is needed
 	 *
 	 *	@param[out] r_marginals is filled with one diagonal block per block column of lambda, in lambda's order
-	 *	@param[in] r_lambda is the system matrix (symmetric layout, upper triangle stored, one block size: 3, 6 or 7)
+	 *	@param[in] r_lambda is the system matrix (symmetric layout, upper triangle stored; one block size of 3, 6 or 7, or any
+	 *		mix of block sizes up to 8 in a structure without big separators)
 	 *
 	 *	@return Returns true on success, false if lambda is not positive definite.
 	 *	@note This function throws std::bad_alloc and std::runtime_error.
@@ -750,18 +751,24 @@ public:
 	bool Marginals(CUberBlockMatrix &r_marginals, const CUberBlockMatrix &r_lambda) // throw(std::bad_alloc, std::runtime_error)
 	{
 		Gather_Or_Reanalyze(r_lambda, [&]() { SymbolicDecomposition_Blocky(r_lambda); });
-		const size_t n = r_lambda.n_BlockColumn_Num(), d = r_lambda.n_BlockColumn_Column_Num(0);
-		std::vector<double> cov(n * d * d);
-		const int n_result = slampp_hip_marginals(m_p_solver, m_p_values, &cov[0]);
+		const size_t n = r_lambda.n_BlockColumn_Num();
+		size_t n_doubles = 0; // (any mix of block sizes: block i is d_i x d_i, the blocks follow each other)
+		for(size_t i = 0; i < n; ++ i)
+			n_doubles += r_lambda.n_BlockColumn_Column_Num(i) * r_lambda.n_BlockColumn_Column_Num(i);
+		std::vector<double> cov(n_doubles);
+		const int n_result = slampp_hip_marginals(m_p_solver, m_p_values, cov.empty()? 0 : &cov[0]);
 		if(n_result == SLAMPP_HIP_NOT_POSDEF)
 			return false;
 		Throw_On_Error(n_result);
 		r_marginals.Clear();
+		size_t n_at = 0;
 		for(size_t i = 0; i < n; ++ i) {
+			const size_t d = r_lambda.n_BlockColumn_Column_Num(i);
 			double *p_dest = r_marginals.p_GetBlock_Log(i, i, d, d, true, false);
 			if(!p_dest)
 				throw std::runtime_error("CLinearSolver_HIP: cannot write the marginals");
-			std::copy(&cov[i * d * d], &cov[(i + 1) * d * d], p_dest);
+			std::copy(&cov[n_at], &cov[n_at + d * d], p_dest);
+			n_at += d * d;
 		}
 		return true;
 	}
