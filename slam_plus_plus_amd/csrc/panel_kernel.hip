@@ -169,11 +169,42 @@ __device__ __forceinline__ void panel_copy_out(const TPanelCol *s_col, const TPa
 	}
 }
 
+// the blocks the task hands up (TPanelOut): sums of products of its own finished blocks, out of the image; a wave per block
+template <int D, int W>
+__device__ __forceinline__ void panel_hand_up(const longlong2 *s_out, int n_out, int wave, int lane, const TLaneMap mm, bool b_y, int yq,
+	const double *s_L, const double *s_w, double *H)
+{
+	enum { DD = D * D };
+	const TPanelOut *s_rec = reinterpret_cast<const TPanelOut*>(s_out);
+	const uint32_t *s_opair = reinterpret_cast<const uint32_t*>(s_out + n_out);
+	for(int o = wave; o < n_out; o += W) {
+		const TPanelOut rec = s_rec[o];
+		const bool b_diag = (rec.dst >> 62) != 0;
+		const int64_t n_dst = rec.dst & ((int64_t(1) << 62) - 1);
+		double sum = 0;
+		if(b_diag) {
+			for(int e = 0; e < rec.onp; ++ e) {
+				const uint32_t en = s_opair[rec.op0 + e];
+				sum += row_product_image<D>(s_L + int(en & 0xffff) * DD, s_w + int(en >> 16) * D, mm.r, yq, b_y);
+			}
+			if(b_y)
+				H[n_dst + DD + yq] = sum;
+		} else {
+			for(int e = 0; e < rec.onp; ++ e) {
+				const uint32_t en = s_opair[rec.op0 + e];
+				sum += pair_product_image<D>(s_L + int(en & 0xffff) * DD, s_L + int(en >> 16) * DD, mm.r, mm.q);
+			}
+		}
+		if(mm.b_act)
+			H[n_dst + lane] = sum;
+	}
+}
+
 template <int D, int W, bool b_fused, bool b_rows>
 __global__ void __launch_bounds__(64 * W)
-factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict__ pkg_off, int n_panels, TPanelLaunch t_cfg,
-	const TUpdSlot *__restrict__ upd_slots, int n_upd_slots, const TUpdEnt *__restrict__ upd_ents, const double *__restrict__ A,
-	const double *__restrict__ b, double *L, double *Linv, double *w, int *p_flag, long long *p_timing)
+factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict__ pkg_off, const int64_t *__restrict__ out_off, int n_panels,
+	TPanelLaunch t_cfg, const TUpdSlot *__restrict__ upd_slots, int n_upd_slots, const TUpdEnt *__restrict__ upd_ents, const double *__restrict__ A,
+	const double *__restrict__ b, double *L, double *Linv, double *w, double *H, int *p_flag, long long *p_timing)
 {
 	enum { DD = D * D, BATCH = panel_fresh_batch(W), UPD_BATCH = PANEL_UPD_BATCH, N_UPD_GROUPS = W / PANEL_UPD_W };
 	extern __shared__ __attribute__((aligned(16))) double s_raw[];
@@ -213,6 +244,14 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 		p_hd->n_int_rows, p_hd->ext_ptr};
 	for(int e = 64 * W + tid; e < hd.n_units; e += 64 * W)
 		s_pkg[e] = pkg[n_off + e];
+	// what the task hands up to the next stage's tasks: the list is needed at the very end, so it is requested now
+	const int n_out = p_hd->ext_ptr[10], n_out_units = p_hd->ext_ptr[11];
+	longlong2 *s_out = reinterpret_cast<longlong2*>(s_raw + t_lds.OUT);
+	if(n_out_units > 0) {
+		const int64_t n_out_off = out_off[blockIdx.x];
+		for(int e = tid; e < n_out_units; e += 64 * W)
+			s_out[e] = pkg[n_out_off + e];
+	}
 	const int n_cols = hd.n_cols, n_slots = hd.n_slots;
 	const TPanelCol *s_col = reinterpret_cast<const TPanelCol*>(s_pkg + 4);
 	const TPanelSlot *s_slot = reinterpret_cast<const TPanelSlot*>(s_pkg + 4 + 3 * n_cols);
@@ -225,6 +264,25 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 	const TLaneMap mm = lane_map(lane, D, D);
 	const bool b_y = lane >= Y_LANE0 && lane < Y_LANE0 + D;
 	const int yq = b_y? lane - Y_LANE0 : mm.q;
+	// The first blocks handed up by the stage below (this wave's: they target its slots) are requested here, together with the
+	// image: a read of something the launch before has written is two or three microseconds whatever its size, and the
+	// image's blocks are such reads too -- one trip for both.
+	enum { UPB = 8 };
+	int n_ext0 = hd.ext_ptr[wave];
+	const int n_ext1 = b_fused? hd.ext_ptr[wave + 1] : n_ext0;
+	int n_up_first = 0;
+	double va_up[UPB], vy_up[UPB];
+	if(b_fused) {
+		while(n_up_first < UPB && n_ext0 + n_up_first < n_ext1 && s_ext[n_ext0 + n_up_first].kind >= 2)
+			++ n_up_first;
+		#pragma unroll
+		for(int u = 0; u < UPB; ++ u) {
+			const TPanelExt en = s_ext[n_ext0 + min(u, max(n_up_first - 1, 0))];
+			const int64_t n_at = n_up_first? en.a_off : 0;
+			va_up[u] = H[n_at + (mm.b_act? lane : 0)];
+			vy_up[u] = H[n_at + DD + (b_y? yq : 0)];
+		}
+	}
 	// the image: the task's blocks as the update role left them (Lambda minus the updates from further down), y likewise;
 	// every wave its own slots (v, v + W, ..: it brings in their fresh updates below)
 	for(int s0 = wave; s0 < n_slots; s0 += 4 * W) {
@@ -251,7 +309,48 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 
 	// 1. fresh updates (operands from the stage right below: a handful per task): wave v owns the slots v, v + W, ..,
 	// streams the entries that target them BATCH at a time and subtracts the products from its slots -- fixed order
-	for(int e0 = hd.ext_ptr[wave], e1 = b_fused? hd.ext_ptr[wave + 1] : e0; e0 < e1; e0 += BATCH) {
+	// (a) the blocks handed up by the tasks of the stage below (kinds 2 / 3: the host lists them first): they come as they are,
+	// one load each -- eight in flight, subtracted straight from the image; the first eight are here already
+	if(b_fused) {
+		#pragma unroll
+		for(int u = 0; u < UPB; ++ u) {
+			if(u < n_up_first) { // wave-uniform
+				const TPanelExt en = s_ext[n_ext0 + u];
+				if(b_y && en.kind == 3)
+					s_w[en.col * D + yq] -= vy_up[u];
+				else if(mm.b_act)
+					s_L[int(en.slot) * DD + lane] -= va_up[u];
+			}
+		}
+		n_ext0 += n_up_first;
+	}
+	for(;;) {
+		int n_up = 0;
+		while(n_up < UPB && n_ext0 + n_up < n_ext1 && s_ext[n_ext0 + n_up].kind >= 2)
+			++ n_up;
+		if(!n_up)
+			break;
+		double va[UPB], vy[UPB];
+		#pragma unroll
+		for(int u = 0; u < UPB; ++ u) {
+			const TPanelExt en = s_ext[n_ext0 + min(u, n_up - 1)];
+			va[u] = H[en.a_off + (mm.b_act? lane : 0)];
+			vy[u] = H[en.a_off + DD + (b_y? yq : 0)];
+		}
+		#pragma unroll
+		for(int u = 0; u < UPB; ++ u) {
+			if(u < n_up) { // wave-uniform
+				const TPanelExt en = s_ext[n_ext0 + u];
+				if(b_y && en.kind == 3)
+					s_w[en.col * D + yq] -= vy[u];
+				else if(mm.b_act)
+					s_L[int(en.slot) * DD + lane] -= va[u];
+			}
+		}
+		n_ext0 += n_up;
+	}
+	// (b) products whose operands this task fetches itself
+	for(int e0 = n_ext0, e1 = n_ext1; e0 < e1; e0 += BATCH) {
 		double va[BATCH], vb[BATCH], vy[BATCH];
 		#pragma unroll
 		for(int u = 0; u < BATCH; ++ u) {
@@ -359,6 +458,8 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 		// everything out to memory, and the inverses of the diagonal blocks: by all waves, after the chain
 		panel_copy_out<D, W>(s_col, s_slot, 0, n_cols, wave, lane, mm, s_L, s_w, s_linv, s_tile, L, Linv, w);
 		PANEL_TICK();
+		// (the finished diagonal blocks live in s_linv in this walk, not in the image: nothing handed up reads a diagonal block)
+		panel_hand_up<D, W>(s_out, n_out, wave, lane, mm, b_y, yq, s_L, s_w, H);
 		return;
 	}
 	// (the block-wise form of rounds 2 and 3, kept for comparison: option "panel_rows" = 0) their diagonal blocks go to one
@@ -405,11 +506,13 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 		PANEL_TICK();
 		ci0 = ci1;
 	}
+	panel_hand_up<D, W>(s_out, n_out, wave, lane, mm, b_y, yq, s_L, s_w, H);
+	PANEL_TICK();
 }
 
-bool launch_factor_panel(int n_dim, bool b_fused, bool b_rows, const TPanelLaunch &r_cfg, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks,
-	const TUpdSlot *upd_slots, int n_upd_slots, const TUpdEnt *upd_ents, const double *A, const double *b, double *L, double *Linv, double *w,
-	int *p_flag, hipStream_t stream, long long *p_timing)
+bool launch_factor_panel(int n_dim, bool b_fused, bool b_rows, const TPanelLaunch &r_cfg, const longlong2 *pkg, const int64_t *pkg_off, const int64_t *out_off,
+	int n_tasks, const TUpdSlot *upd_slots, int n_upd_slots, const TUpdEnt *upd_ents, const double *A, const double *b, double *L, double *Linv, double *w,
+	double *H, int *p_flag, hipStream_t stream, long long *p_timing)
 {
 	if(!b_fused)
 		n_upd_slots = 0;
@@ -425,8 +528,8 @@ bool launch_factor_panel(int n_dim, bool b_fused, bool b_rows, const TPanelLaunc
 			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_panel_kernel<D, WW, F, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
 			b_attribute_set = true; \
 		} \
-		hipLaunchKernelGGL((factor_panel_kernel<D, WW, F, RW>), dim3(n_grid), dim3(64 * WW), n_lds_bytes, stream, pkg, pkg_off, n_tasks, r_cfg, \
-			upd_slots, n_upd_slots, upd_ents, A, b, L, Linv, w, p_flag, p_timing); } while(0)
+		hipLaunchKernelGGL((factor_panel_kernel<D, WW, F, RW>), dim3(n_grid), dim3(64 * WW), n_lds_bytes, stream, pkg, pkg_off, out_off, n_tasks, r_cfg, \
+			upd_slots, n_upd_slots, upd_ents, A, b, L, Linv, w, H, p_flag, p_timing); } while(0)
 #define LAUNCH_PANEL_F(D, WW, F) do { if(b_rows) LAUNCH_PANEL_INSTANCE(D, WW, F, true); else LAUNCH_PANEL_INSTANCE(D, WW, F, false); } while(0)
 #define LAUNCH_PANEL(D) do { \
 		if(W == 4) { if(b_fused) LAUNCH_PANEL_F(D, 4, true); else LAUNCH_PANEL_F(D, 4, false); } \

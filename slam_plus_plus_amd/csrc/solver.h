@@ -140,7 +140,10 @@ struct slampp_hip_solver {
 	int n_panel = -1; // option "panel": -1 / 1 = where a task fits (default), 0 = never
 	int n_panel_rows = 0; // option "panel_rows": 1 = the panel tasks factor a block column as rows (round 4: measured no faster), 0 = block by block
 	slampp::CDevArray<longlong2> d_panel_pkg;
-	slampp::CDevArray<int64_t> d_panel_off;
+	slampp::CDevArray<int64_t> d_panel_off, d_panel_out_off;
+	slampp::CDevArray<double> d_handup; // the blocks the panel tasks hand up to the next stage's (TPanelOut)
+	bool b_any_hand_up = false;
+	int n_panel_handup = 1; // option "panel_handup": 1 = a panel task computes what it owes the next stage's tasks out of its own image (round 4), 0 = they fetch the operands
 	slampp::CDevArray<int32_t> d_panel_rest;
 	slampp::CDevArray<slampp::TUpdSlot> d_panel_upd_slots; // the factor blocks of the panel tasks, stage by stage, and the
 	slampp::CDevArray<slampp::TUpdEnt> d_panel_upd_ents;   // updates they receive from earlier stages (panel_update_kernel)

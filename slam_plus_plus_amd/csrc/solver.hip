@@ -323,7 +323,7 @@ void slampp_hip_solver::Free_Device()
 	d_simt_chunks.Free(); d_simt_prog.Free(); d_simt_rest.Free(); d_simt_tab.Free();
 	d_simt_bwd_chunks.Free(); d_simt_bwd_prog.Free(); d_simt_bwd_tab.Free();
 	b_leaf_linv_valid = true;
-	d_panel_pkg.Free(); d_panel_off.Free(); d_panel_rest.Free(); d_panel_upd_slots.Free(); d_panel_upd_ents.Free();
+	d_panel_pkg.Free(); d_panel_off.Free(); d_panel_out_off.Free(); d_handup.Free(); d_panel_rest.Free(); d_panel_upd_slots.Free(); d_panel_upd_ents.Free();
 	simt_chunk_ptr.clear(); simt_rest_ptr.clear();
 	d_dense_blks.Free(); d_dense_blk_loff.Free(); d_dense_cols.Free(); d_dense.Free(); d_dense_invdiag.Free(); d_dense_z.Free(); d_dense_x.Free();
 	n_dense_blks = n_dense_cols = n_dense_dim = n_dense_pad = 0;
@@ -358,7 +358,7 @@ size_t slampp_hip_solver::n_Device_Bytes() const
 		d_task_ptr.n_Bytes() + d_task_pkg.n_Bytes() + d_pkg.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
 		d_simt_chunks.n_Bytes() + d_simt_prog.n_Bytes() + d_simt_rest.n_Bytes() + d_simt_tab.n_Bytes() +
 		d_simt_bwd_chunks.n_Bytes() + d_simt_bwd_prog.n_Bytes() + d_simt_bwd_tab.n_Bytes() +
-		d_panel_pkg.n_Bytes() + d_panel_off.n_Bytes() + d_panel_rest.n_Bytes() + d_panel_upd_slots.n_Bytes() + d_panel_upd_ents.n_Bytes() +
+		d_panel_pkg.n_Bytes() + d_panel_off.n_Bytes() + d_panel_out_off.n_Bytes() + d_handup.n_Bytes() + d_panel_rest.n_Bytes() + d_panel_upd_slots.n_Bytes() + d_panel_upd_ents.n_Bytes() +
 		d_rhs.n_Bytes() + d_L.n_Bytes() + d_Linv.n_Bytes() + d_w.n_Bytes() + d_cov.n_Bytes() + d_flag.n_Bytes() +
 		d_Z.n_Bytes() + d_diag_zoff.n_Bytes() + d_Zd.n_Bytes() + d_Zd_work.n_Bytes() + sparse_inverse_bytes(p_sinv) +
 		(p_schur? schur_device_bytes(p_schur) : 0);
@@ -712,13 +712,15 @@ void slampp_hip_solver::Analyze_Sparse()
 	// the factor and everything fits the kernel's LDS; the updates it receives from earlier stages go to the lists of
 	// panel_update_kernel, block by block
 	std::vector<longlong2> panel_pkg;
-	std::vector<int64_t> panel_off;
+	std::vector<int64_t> panel_off, panel_out_off; // (panel_out_off: per package the offset of its hand-up list, or -1)
+	int64_t n_handup_doubles = 0;
 	std::vector<int32_t> panel_rest;
 	std::vector<TUpdSlot> upd_slots;
 	std::vector<TUpdEnt> upd_ents;
 	panel_ptr.clear();
 	panel_rest_ptr.clear();
 	panel_upd_ptr.clear();
+	b_any_hand_up = false;
 	if(n_panel && P.uniform_dim && (P.max_dim == 3 || P.max_dim == 6 || P.max_dim == 7)) {
 		const int n_stages = int(P.stage_ptr.size()) - 1, D = P.max_dim;
 		const int n_slot_cap = panel_slot_cap(D);
@@ -731,6 +733,13 @@ void slampp_hip_solver::Analyze_Sparse()
 		panel_upd_ptr.assign(n_stages + 1, 0);
 		std::vector<int32_t> col_local(size_t(P.n), -1), col_stage(size_t(P.n), -1);
 		std::vector<int32_t> slot_of(size_t(n_lblocks), -1); // factor block -> slot of the task being packed (else -1)
+		// round 4, hand-ups (TPanelOut): the slot every factor block has in the image of its own task, once that task's package
+		// exists (-1: the task went to the column kernel), the package of every column's task, and per package what it hands up
+		std::vector<int32_t> img_slot(size_t(n_lblocks), -1), col_package(size_t(P.n), -1);
+		struct THandUp { std::vector<TPanelOut> recs; std::vector<uint32_t> pairs; };
+		std::vector<THandUp> hand_up; // indexed by package
+		std::map<std::pair<int32_t, int64_t>, int32_t> out_of; // (source package, target factor block) -> record of that package
+		const bool b_hand_up = n_panel_handup != 0;
 		std::vector<int64_t> order; // the task's columns (indices into cols) level by level
 		for(int s = 0; s < n_stages; ++ s) {
 			for(int64_t i = P.task_ptr[P.stage_ptr[s]]; i < P.task_ptr[P.stage_ptr[s + 1]]; ++ i)
@@ -772,12 +781,14 @@ void slampp_hip_solver::Analyze_Sparse()
 					for(int64_t i = P.task_ptr[t]; i < P.task_ptr[t + 1]; ++ i) {
 						const TColDesc &c = cols[i];
 						for(int64_t e = c.r0; e < c.r0 + c.nr; ++ e) {
-							n_fresh += col_stage[P.blk_col[P.rblk[e]]] == s - 1;
-							n_external += col_stage[P.blk_col[P.rblk[e]]] < s;
+							const bool b_up = b_hand_up && img_slot[P.rblk[e]] >= 0 && col_stage[P.blk_col[P.rblk[e]]] == s - 1;
+							n_fresh += !b_up && col_stage[P.blk_col[P.rblk[e]]] == s - 1;
+							n_external += !b_up && col_stage[P.blk_col[P.rblk[e]]] < s;
 						}
 						for(int64_t e = P.pptr[c.k0 + 1]; e < P.pptr[c.k0 + c.nb]; ++ e) {
-							n_fresh += col_stage[P.blk_col[P.pa[e]]] == s - 1;
-							n_external += col_stage[P.blk_col[P.pa[e]]] < s;
+							const bool b_up = b_hand_up && img_slot[P.pa[e]] >= 0 && col_stage[P.blk_col[P.pa[e]]] == s - 1;
+							n_fresh += !b_up && col_stage[P.blk_col[P.pa[e]]] == s - 1;
+							n_external += !b_up && col_stage[P.blk_col[P.pa[e]]] < s;
 						}
 					}
 					n_max_fresh = std::max(n_max_fresh, n_fresh);
@@ -833,19 +844,39 @@ void slampp_hip_solver::Analyze_Sparse()
 				// launch: then what the stage right below contributes ("fresh") is left to the task itself
 				const bool b_ride = panel_ride[s] != 0, b_self = panel_ride[s] == 2;
 				int64_t n_fresh = 0;
+				// an update whose operands a task of the stage right below keeps in its image is handed up by that task (one
+				// ready-made block per source task and target block) instead of fetched and multiplied here
+				auto Handed_Up = [&](int64_t n_operand_blk) {
+					return b_hand_up && !b_self && s > 0 && img_slot[n_operand_blk] >= 0 && col_stage[P.blk_col[n_operand_blk]] == s - 1;
+				};
+				std::vector<std::pair<int32_t, int64_t> > up_keys; // (source package, target block) of this task's hand-ups, in order of first use
+				auto Count_Up = [&](int64_t n_operand_blk, int64_t n_target_blk) {
+					const std::pair<int32_t, int64_t> key(col_package[P.blk_col[n_operand_blk]], n_target_blk);
+					if(std::find(up_keys.begin(), up_keys.end(), key) == up_keys.end())
+						up_keys.push_back(key);
+				};
 				for(int64_t i = c_begin; b_fits && i < c_end; ++ i) { // size of the package
 					const TColDesc &c = cols[i];
 					for(int64_t e = c.r0; e < c.r0 + c.nr; ++ e) {
 						const bool b_int = slot_of[P.rblk[e]] >= 0;
 						n_int_rows += b_int;
-						n_fresh += !b_int && b_ride && (b_self || col_stage[P.blk_col[P.rblk[e]]] == s - 1);
+						if(!b_int && Handed_Up(P.rblk[e]))
+							Count_Up(P.rblk[e], c.k0);
+						else
+							n_fresh += !b_int && b_ride && (b_self || col_stage[P.blk_col[P.rblk[e]]] == s - 1);
 					}
-					for(int64_t e = P.pptr[c.k0 + 1]; e < P.pptr[c.k0 + c.nb]; ++ e) {
-						const bool b_int = slot_of[P.pa[e]] >= 0;
-						n_int_pairs += b_int;
-						n_fresh += !b_int && b_ride && (b_self || col_stage[P.blk_col[P.pa[e]]] == s - 1);
+					for(int64_t k = c.k0 + 1; k < c.k0 + c.nb; ++ k) {
+						for(int64_t e = P.pptr[k]; e < P.pptr[k + 1]; ++ e) {
+							const bool b_int = slot_of[P.pa[e]] >= 0;
+							n_int_pairs += b_int;
+							if(!b_int && Handed_Up(P.pa[e]))
+								Count_Up(P.pa[e], k);
+							else
+								n_fresh += !b_int && b_ride && (b_self || col_stage[P.blk_col[P.pa[e]]] == s - 1);
+						}
 					}
 				}
+				n_fresh += int64_t(up_keys.size());
 				const size_t n_units = 4 + 3 * size_t(n_cols) + 2 * size_t(n_slots) + size_t(n_int_rows + 3) / 4 + size_t(n_int_pairs + 3) / 4 +
 					2 * size_t(n_fresh);
 				b_fits = b_fits && n_units <= size_t(PANEL_UNITS);
@@ -861,6 +892,34 @@ void slampp_hip_solver::Analyze_Sparse()
 				irow.clear(); ipair.clear(); pcols.clear(); pslots.clear(); fresh.clear();
 				for(size_t o = 0; o < order.size(); ++ o)
 					col_local[P.task_cols[order[o]]] = int32_t(o);
+				// one more operand pair for the block the source task hands up for target block n_target (a new record there, and
+				// the entry here that subtracts it, when it is the first)
+				auto Hand_Up = [&](int64_t ka, int64_t kb, int64_t n_target, int32_t n_col_here, int32_t n_slot_here, bool b_diag) {
+					const int32_t n_src = col_package[P.blk_col[ka]];
+					const std::pair<int32_t, int64_t> key(n_src, n_target);
+					std::map<std::pair<int32_t, int64_t>, int32_t>::iterator it = out_of.find(key);
+					THandUp &r_up = hand_up[size_t(n_src)];
+					if(it == out_of.end()) {
+						TPanelOut rec;
+						rec.op0 = -1; // (the pairs of a record are collected apart and laid out when the list is written)
+						rec.onp = 0;
+						rec.dst = n_handup_doubles | (int64_t(b_diag) << 62);
+						it = out_of.insert(std::make_pair(key, int32_t(r_up.recs.size()))).first;
+						r_up.recs.push_back(rec);
+						TPanelExt en;
+						memset(&en, 0, sizeof(en));
+						en.a_off = n_handup_doubles;
+						en.slot = uint16_t(n_slot_here);
+						en.kind = b_diag? 3 : 2;
+						en.col = n_col_here;
+						fresh.push_back(en);
+						n_handup_doubles += P.max_dim * P.max_dim + 8;
+					}
+					// (record index in the high half: the pairs are sorted by record when the list is written)
+					r_up.pairs.push_back(uint32_t(it->second));
+					r_up.pairs.push_back(b_diag? (uint32_t(img_slot[ka]) | (uint32_t(col_local[P.blk_col[ka]]) << 16)) :
+						(uint32_t(img_slot[ka]) | (uint32_t(img_slot[kb]) << 16)));
+				};
 				for(size_t o = 0; o < order.size(); ++ o) {
 					const int64_t i = order[o];
 					const TColDesc &c = cols[i];
@@ -885,6 +944,8 @@ void slampp_hip_solver::Analyze_Sparse()
 						const int64_t k = P.rblk[e];
 						if(slot_of[k] >= 0)
 							irow.push_back(uint32_t(slot_of[k]) | (uint32_t(col_local[P.blk_col[k]]) << 16));
+						else if(Handed_Up(k))
+							Hand_Up(k, k, c.k0, int32_t(o), pc.slot0, true);
 						else if(b_ride && (b_self || col_stage[P.blk_col[k]] == s - 1)) {
 							TPanelExt en;
 							memset(&en, 0, sizeof(en));
@@ -916,6 +977,8 @@ void slampp_hip_solver::Analyze_Sparse()
 								const int64_t ka = P.pa[e], kb = P.pb[e];
 								if(slot_of[ka] >= 0)
 									ipair.push_back(uint32_t(slot_of[ka]) | (uint32_t(slot_of[kb]) << 16));
+								else if(Handed_Up(ka))
+									Hand_Up(ka, kb, k, 0, slot_of[k], false);
 								else if(b_ride && (b_self || col_stage[P.blk_col[ka]] == s - 1)) {
 									TPanelExt en;
 									memset(&en, 0, sizeof(en));
@@ -940,9 +1003,10 @@ void slampp_hip_solver::Analyze_Sparse()
 				hd.n_units = int32_t(n_units);
 				hd.n_int_rows = int32_t(irow.size());
 				// fresh entries by the wave that owns their slot, inside a wave by slot, inside a slot in list order
+				// (of a wave's entries the handed-up blocks first: the kernel takes them eight at a time)
 				std::stable_sort(fresh.begin(), fresh.end(), [n_stage_waves](const TPanelExt &x, const TPanelExt &y) {
-					const int wx = x.slot % n_stage_waves, wy = y.slot % n_stage_waves;
-					return wx < wy || (wx == wy && x.slot < y.slot); });
+					const int wx = x.slot % n_stage_waves, wy = y.slot % n_stage_waves, ux = x.kind < 2, uy = y.kind < 2;
+					return wx < wy || (wx == wy && (ux < uy || (ux == uy && x.slot < y.slot))); });
 				for(size_t e = 0; e < fresh.size(); ++ e)
 					++ hd.ext_ptr[fresh[e].slot % n_stage_waves + 1];
 				for(int v = 0; v < n_stage_waves; ++ v)
@@ -978,17 +1042,59 @@ void slampp_hip_solver::Analyze_Sparse()
 				p_dst += (ipair.size() + 3) / 4 * 16;
 				if(!fresh.empty())
 					memcpy(p_dst, fresh.data(), fresh.size() * sizeof(TPanelExt));
+				for(size_t o = 0; o < order.size(); ++ o) {
+					const TColDesc &c = cols[order[o]];
+					for(int64_t k = c.k0; k < c.k0 + c.nb; ++ k)
+						img_slot[k] = slot_of[k];
+					col_package[P.task_cols[order[o]]] = int32_t(panel_off.size());
+				}
 				panel_off.push_back(int64_t(n_at));
+				panel_out_off.push_back(-1);
+				hand_up.push_back(THandUp());
 				Release_Slots();
 			}
 			panel_ptr[s + 1] = int32_t(panel_off.size());
+			// the hand-up lists of the stage below (its packages exist already: the lists go behind this stage's, the heads are told)
+			for(int32_t n_pkg = (s > 0)? panel_ptr[s - 1] : 0; s > 0 && n_pkg < panel_ptr[s]; ++ n_pkg) {
+				THandUp &r_up = hand_up[size_t(n_pkg)];
+				if(r_up.recs.empty())
+					continue;
+				const size_t n_out = r_up.recs.size(), n_pairs = r_up.pairs.size() / 2;
+				std::vector<uint32_t> sorted(n_pairs);
+				{
+					std::vector<int32_t> count(n_out + 1, 0);
+					for(size_t e = 0; e < n_pairs; ++ e)
+						++ count[r_up.pairs[2 * e] + 1];
+					for(size_t o = 0; o < n_out; ++ o) {
+						r_up.recs[o].op0 = count[o];
+						r_up.recs[o].onp = count[o + 1];
+						count[o + 1] += count[o];
+					}
+					std::vector<int32_t> fill(count.begin(), count.end() - 1);
+					for(size_t e = 0; e < n_pairs; ++ e) // (stable: the pairs of a record keep their order)
+						sorted[size_t(fill[r_up.pairs[2 * e]] ++)] = r_up.pairs[2 * e + 1];
+				}
+				const size_t n_units = n_out + (n_pairs + 3) / 4;
+				const size_t n_at = panel_pkg.size();
+				panel_pkg.resize(n_at + n_units, longlong2{0, 0});
+				memcpy(&panel_pkg[n_at], r_up.recs.data(), n_out * sizeof(TPanelOut));
+				memcpy(&panel_pkg[n_at + n_out], sorted.data(), n_pairs * sizeof(uint32_t));
+				panel_out_off[size_t(n_pkg)] = int64_t(n_at);
+				TPanelHead *p_head = reinterpret_cast<TPanelHead*>(&panel_pkg[size_t(panel_off[size_t(n_pkg)])]);
+				p_head->ext_ptr[10] = int32_t(n_out);
+				p_head->ext_ptr[11] = int32_t(n_units);
+				panel_cfg[s - 1].n_cap_out = std::max(panel_cfg[s - 1].n_cap_out, int32_t(n_units));
+				b_any_hand_up = true;
+				{ THandUp t_empty; std::swap(r_up, t_empty); }
+			}
+			out_of.clear();
 			if(b_timing && b_panel_stage)
 				fprintf(stderr, "[setup] stage %d panels: at most %lld blocks and %lld package units per task, %lld tasks left to the column kernel\n",
 					s, (long long)n_stage_max_slots, (long long)n_stage_max_units, (long long)n_stage_rest);
 			panel_rest_ptr[s + 1] = int32_t(panel_rest.size());
 			panel_upd_ptr[s + 1] = int32_t(upd_slots.size());
 		}
-		static_assert(sizeof(TPanelHead) == 64 && sizeof(TPanelCol) == 48 && sizeof(TPanelSlot) == 32 && sizeof(TPanelExt) == 32 && sizeof(TUpdSlot) == 64 &&
+		static_assert(sizeof(TPanelOut) == 16 && sizeof(TPanelHead) == 64 && sizeof(TPanelCol) == 48 && sizeof(TPanelSlot) == 32 && sizeof(TPanelExt) == 32 && sizeof(TUpdSlot) == 64 &&
 			sizeof(TUpdEnt) == 16, "record sizes");
 		if(panel_off.empty()) {
 			panel_ptr.clear();
@@ -1002,6 +1108,8 @@ void slampp_hip_solver::Analyze_Sparse()
 	d_panel_upd_ents.Upload(upd_ents, stream);
 	d_panel_pkg.Upload(panel_pkg, stream);
 	d_panel_off.Upload(panel_off, stream);
+	d_panel_out_off.Upload(panel_out_off, stream);
+	d_handup.Alloc(size_t(std::max<int64_t>(n_handup_doubles, 1)));
 	d_panel_rest.Upload(panel_rest, stream);
 	d_cols.Upload(cols, stream);
 	d_blks.Upload(blks, stream);
@@ -1317,6 +1425,7 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 		bool b_panel_fused = false;
 		for(size_t i = 0; i < panel_ride.size(); ++ i)
 			b_panel_fused = b_panel_fused || panel_ride[i] != 0;
+		b_panel_fused = b_panel_fused || b_any_hand_up; // (the handed-up blocks come in through the fresh entries' loop)
 		auto Launch_Panels = [&](int s, bool b_bottom) {
 			const int n_panels = panel_ptr[s + 1] - panel_ptr[s];
 			const bool b_rode = panel_ride[s] != 0;
@@ -1324,9 +1433,10 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 				launch_panel_update(P.max_dim, d_panel_upd_slots.p() + panel_upd_ptr[s], panel_upd_ptr[s + 1] - panel_upd_ptr[s],
 					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream);
 			const int n_next = (s + 1 < n_stages && panel_ride[s + 1] == 1)? panel_upd_ptr[s + 2] - panel_upd_ptr[s + 1] : 0;
-			launch_factor_panel(P.max_dim, b_panel_fused, n_panel_rows != 0, panel_cfg[s], d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s], n_panels,
+			launch_factor_panel(P.max_dim, b_panel_fused, n_panel_rows != 0, panel_cfg[s], d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s],
+				d_panel_out_off.p() + panel_ptr[s], n_panels,
 				d_panel_upd_slots.p() + ((n_next > 0)? panel_upd_ptr[s + 1] : 0), n_next, d_panel_upd_ents.p(), p_values_dev, p_rhs_dev,
-				d_L.p(), d_Linv.p(), d_w.p(), p_flag, stream, dplan.p_timing);
+				d_L.p(), d_Linv.p(), d_w.p(), d_handup.p(), p_flag, stream, dplan.p_timing);
 			if(panel_rest_ptr[s + 1] > panel_rest_ptr[s]) {
 				TDevPlan t_rest = dplan;
 				t_rest.task_map = d_panel_rest.p();
@@ -1709,6 +1819,8 @@ static int set_option_checked(slampp_hip_solver *p_solver, const char *p_s_name,
 		p_solver->n_simt_width = int(n_value);
 	else if(s == "panel" && n_value >= -1 && n_value <= 1)
 		p_solver->n_panel = int(n_value);
+	else if(s == "panel_handup" && n_value >= 0 && n_value <= 1)
+		p_solver->n_panel_handup = int(n_value);
 	else if(s == "panel_rows" && n_value >= 0 && n_value <= 1) {
 		p_solver->n_panel_rows = int(n_value);
 		return SLAMPP_HIP_OK; // read at every launch

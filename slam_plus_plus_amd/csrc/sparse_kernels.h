@@ -60,6 +60,17 @@ enum { PANEL_W = 8, PANEL_COLS = 8, PANEL_UNITS = 1024, PANEL_UPD_W = 4 };
 struct TPanelHead { // 64 B
 	int32_t n_cols, n_slots, n_units, n_int_rows; // (internal row entries: the internal pairs follow them, unit-aligned)
 	int32_t ext_ptr[12];                          // wave v brings in the fresh entries ext_ptr[v] .. ext_ptr[v + 1]
+	                                              // ext_ptr[10], [11]: blocks this task hands up to the next stage's tasks, units of their list
+};
+// Round 4: what a task owes the tasks of the NEXT stage -- the products of its own finished blocks that update their
+// blocks -- it computes itself, out of its LDS image at the end of its walk, and hands up as ready-made blocks (one per
+// pair of tasks and target block: D x D doubles, then D of the right-hand side's share for a diagonal block); the task
+// above subtracts them from its image with one round of coalesced loads, where it used to fetch both operands of every
+// such product from memory itself ("fresh" entries: 4 - 10 us of a stage at C3, 90 - 126 products per task in the reduced
+// camera system of a band-visibility BA problem, whose stages also kept a launch of their own for those updates).
+struct TPanelOut { // 16 B
+	int32_t op0, onp;   // its operand pairs in the list behind the records: (slot of L(i,c)) | (slot of L(j,c)) << 16; for kind 1 (slot of L(j,c)) | (c's number in the task) << 16
+	int64_t dst;        // where it goes in the hand-up buffer, | kind << 62 (1 = a diagonal block: the right-hand side's share follows it)
 };
 struct TPanelCol { // 48 B
 	int64_t linv_off, cs_new, cs_src;
@@ -73,9 +84,10 @@ struct TPanelSlot { // 32 B
 	int64_t pad;
 };
 struct TPanelExt { // 32 B
-	int64_t a_off, b_off; // offsets of L(i,c), L(j,c) in the factor (row entries: both L(j,c))
+	int64_t a_off, b_off; // offsets of L(i,c), L(j,c) in the factor (row entries: both L(j,c)); kind 2 / 3: a_off = offset in the hand-up buffer
 	int32_t ycs;          // row entries: scalar offset of y_c in the workspace
-	uint16_t slot, kind;  // target slot; 0 = update pair, 1 = row entry of the diagonal block
+	uint16_t slot, kind;  // target slot; 0 = update pair, 1 = row entry of the diagonal block, 2 = a block handed up by a task of
+	                      // the stage below (subtracted as it is), 3 = such a block for a diagonal block (with its right-hand side share)
 	int32_t col;          // row entries: number of the target column in the task
 	int32_t pad;
 };
@@ -101,6 +113,7 @@ inline int panel_slot_cap(int n_dim) { return (n_dim == 6)? 96 : (n_dim == 7)? 7
 // blocks of the image, columns, columns of one level.
 struct TPanelLaunch {
 	int32_t n_waves, n_cap_units, n_cap_blk, n_cap_cols, n_cap_lvl;
+	int32_t n_cap_out;     // units of the largest hand-up list of the stage's tasks
 	int32_t b_from_lambda; // the tasks read their blocks from Lambda (and b): no update role has prepared Lambda - sum in the factor's
 	                       // storage -- the first stage above a leaf stage, whose every update is a fresh one
 };
@@ -112,7 +125,7 @@ inline __host__ __device__ constexpr int panel_fresh_batch(int n_waves) { return
 // level's diagonal blocks, one tile per wave, operand staging of the fresh updates) and the total, which also covers
 // the update role's staging (riders: the next stage's updates from further down, PANEL_UPD_W waves per factor block)
 struct TPanelLds {
-	int IMAGE, VEC, LINV, TILE, OPS, YV, TOTAL;
+	int IMAGE, VEC, LINV, TILE, OPS, YV, OUT, TOTAL;
 };
 inline __host__ __device__ TPanelLds panel_lds(int D, bool b_fused, const TPanelLaunch &c)
 {
@@ -124,7 +137,8 @@ inline __host__ __device__ TPanelLds panel_lds(int D, bool b_fused, const TPanel
 	l.TILE = l.LINV + c.n_cap_cols * 64; // (block-wise walk: the inverses of a level's diagonal blocks; row-wise walk: every column's finished diagonal block)
 	l.OPS = l.TILE + W * 64;
 	l.YV = l.OPS + (b_fused? W * 2 * panel_fresh_batch(W) * DD : 0);
-	const int n_panel_end = l.YV + (b_fused? W * panel_fresh_batch(W) * 8 : 0);
+	l.OUT = l.YV + (b_fused? W * panel_fresh_batch(W) * 8 : 0);
+	const int n_panel_end = l.OUT + 2 * c.n_cap_out;
 	const int n_upd_end = b_fused? W * 2 * PANEL_UPD_BATCH * DD + W * PANEL_UPD_BATCH * 8 + W * 64 : 0;
 	l.TOTAL = (n_panel_end > n_upd_end)? n_panel_end : n_upd_end;
 	return l;
@@ -133,9 +147,10 @@ inline __host__ __device__ TPanelLds panel_lds(int D, bool b_fused, const TPanel
 // one workgroup per package (pkg_off: their offsets in pkg, in 16-byte units; pkg is padded by 64 * PANEL_W units)
 // (upd_slots: the blocks of the NEXT stage's panel tasks, whose updates from below this stage ride in this launch)
 // (b_fused: the plan has such stages at all; without them the leaner kernel runs)
-bool launch_factor_panel(int n_dim, bool b_fused, bool b_rows, const TPanelLaunch &r_cfg, const longlong2 *pkg, const int64_t *pkg_off, int n_tasks, const TUpdSlot *upd_slots,
-	int n_upd_slots, const TUpdEnt *upd_ents, const double *A, const double *b, double *L, double *Linv, double *w, int *p_flag,
-	hipStream_t stream, long long *p_timing = 0);
+// (out_off: per task the offset of its hand-up list in pkg, or -1; H: the hand-up buffer)
+bool launch_factor_panel(int n_dim, bool b_fused, bool b_rows, const TPanelLaunch &r_cfg, const longlong2 *pkg, const int64_t *pkg_off, const int64_t *out_off,
+	int n_tasks, const TUpdSlot *upd_slots, int n_upd_slots, const TUpdEnt *upd_ents, const double *A, const double *b, double *L, double *Linv, double *w,
+	double *H, int *p_flag, hipStream_t stream, long long *p_timing = 0);
 void launch_panel_update(int n_dim, const TUpdSlot *slots, int n_slots, const TUpdEnt *ents, const double *A, double *L,
 	const double *b, double *w, hipStream_t stream);
 

@@ -478,3 +478,39 @@ def test_marginals_mixed_block_sizes(seed):
     for c in range(n):
         assert cov[c].shape == (dims[c], dims[c])
         assert np.abs(cov[c] - Minv[cs[c]:cs[c + 1], cs[c]:cs[c + 1]]).max() < 1e-10 * scale
+
+
+@pytest.mark.parametrize("case", ["chain6", "chain3", "chain7", "sphere", "band_S"])
+def test_panel_tasks_hand_their_contributions_up(case):
+    """Option panel_handup (round 4, the default): a panel task computes what it owes the tasks of the next stage -- the products
+    of its own finished blocks -- out of its LDS image and hands them up as ready-made blocks; the task above subtracts them
+    with the loads that fetch its image, instead of fetching both operands of every such product itself.  Same answer as
+    with the option off, and as the oracle's."""
+    if case == "band_S":       # shaped like the reduced camera system of a band-visibility BA problem: separators of three columns
+        n, d = 600, 6
+        rng = np.random.default_rng(5)
+        cols = [sorted({max(c - j, 0) for j in (0, 1, 2, 3)}) for c in range(n)]
+        bcol_ptr = np.concatenate([[0], np.cumsum([len(r) for r in cols])]).astype(np.int64)
+        brow = np.concatenate(cols).astype(np.int32)
+        vals = []
+        for c in range(n):
+            for r in cols[c]:
+                B = 0.1 * rng.standard_normal((d, d))
+                vals.append(((B + B.T) * 0.05 + 4.0 * np.eye(d)).T.ravel() if r == c else B.T.ravel())
+        lam = synth.BlockSystem(np.arange(n + 1, dtype=np.int64) * d, bcol_ptr, brow, np.concatenate(vals), rng.standard_normal(n * d), 0)
+        opts = {"subtree_size": 4, "simt": 0}
+    else:
+        lam = {"chain6": lambda: synth.pose_chain(n=12000, d=6, seed=21), "chain3": lambda: synth.pose_chain(n=6000, d=3, seed=22),
+               "chain7": lambda: synth.pose_chain(n=6000, d=7, seed=23), "sphere": lambda: synth.sphere(50, 50)}[case]()
+        opts = {}
+    ok, x_ref = O.solve_sparse(lam)[:2]
+    assert ok
+    xs = []
+    for up in (1, 0):
+        solver = CLinearSolver_HIP(panel_handup=up, **opts)
+        for _ in range(2):                                   # (the hand-up buffer is written anew by every factorization)
+            eta = lam.rhs.copy()
+            assert solver.Solve_PosDef_Blocky(lam, eta)
+            assert rel_inf(eta, x_ref) < TOL
+        xs.append(eta)
+    assert rel_inf(xs[0], xs[1]) < 1e-10

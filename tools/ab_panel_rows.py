@@ -1,4 +1,5 @@
-"""Dev helper (round 4): the panel tasks' level walk as rows (option panel_rows = 1) against the block-wise form (0): C3, C2,
+"""Dev helper (round 4): an option of the panel tasks on (1) and off (0) -- AB_OPTION=panel_rows (the level walk as rows; the
+default) or panel_handup (tasks hand their contributions up; takes effect at analysis: a solver per setting) -- on C3, C2,
 C1 and the reduced camera systems of the BA legs, same process, alternating."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,13 +9,18 @@ from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP, CLinearSolver_Schur
 dev = torch.device("cuda:0")
 
 
+OPTION = os.environ.get("AB_OPTION", "panel_rows")
+
+
 def run(name, lam, cls, reps=20):
-    s = cls()
-    s.SymbolicDecomposition_Blocky(lam)
     vals = torch.from_numpy(lam.values).to(dev)
     out = {}
+    solvers = {}
     for rows in (0, 1, 0, 1):
-        s.set_option("panel_rows", rows)
+        if rows not in solvers:
+            solvers[rows] = cls(**{OPTION: rows})
+            solvers[rows].SymbolicDecomposition_Blocky(lam)
+        s = solvers[rows]
         s.set_option("profile", 0)
         bufs = [torch.from_numpy(lam.rhs).to(dev) for _ in range(2 * reps + 1)]
         torch.cuda.synchronize()
@@ -31,7 +37,7 @@ def run(name, lam, cls, reps=20):
         s.sync()
         x = bufs[-1].cpu().numpy()
         res = np.abs(lam.to_scipy() @ x - lam.rhs).max() / np.abs(lam.rhs).max()
-        print(f"{name:14s} panel_rows={rows}  {dt*1e3:.3f} ms  resid {res:.1e}  " +
+        print(f"{name:14s} {OPTION}={rows}  {dt*1e3:.3f} ms  resid {res:.1e}  " +
               "  ".join(f"{k}={ms/max(c,1)*1e3:.0f}" for k, (c, ms) in s.profile().items()), flush=True)
 
 
