@@ -138,7 +138,9 @@ struct slampp_hip_solver {
 	// separator tasks that run as panels in LDS (panel_kernel.hip): their packages, per stage the offsets of the packages and
 	// the tasks left to factor_stage_kernel
 	int n_panel = -1; // option "panel": -1 / 1 = where a task fits (default), 0 = never
-	int n_panel_rows = 0; // option "panel_rows": 1 = the panel tasks factor a block column as rows (round 4: measured no faster), 0 = block by block
+	int n_panel_rows = -1; // option "panel_rows": 1 = the panel tasks factor a block column as rows (round 4), 0 = block by block, -1 = rows where the
+	                       // blocks are 6 x 6 or 7 x 7 (with the hand-ups on: C3 206 -> 196 us of separator launches, band reduced system 216 -> 208;
+	                       // 3 x 3 blocks -- C1 -- 124 -> 140: their block-wise levels are cheaper than two passes over the image)
 	slampp::CDevArray<longlong2> d_panel_pkg;
 	slampp::CDevArray<int64_t> d_panel_off, d_panel_out_off;
 	slampp::CDevArray<double> d_handup; // the blocks the panel tasks hand up to the next stage's (TPanelOut)

@@ -740,6 +740,7 @@ void slampp_hip_solver::Analyze_Sparse()
 		std::vector<THandUp> hand_up; // indexed by package
 		std::map<std::pair<int32_t, int64_t>, int32_t> out_of; // (source package, target factor block) -> record of that package
 		const bool b_hand_up = n_panel_handup != 0;
+		const int n_handup_max_tasks = getenv("SLAMPP_HANDUP_MAX_TASKS")? atoi(getenv("SLAMPP_HANDUP_MAX_TASKS")) : (1 << 30); // (measured at C3: handing up from the 2 420-task stage as well 224 -> 208 us for the separator launches, from the narrow stages only 224 -> 214)
 		std::vector<int64_t> order; // the task's columns (indices into cols) level by level
 		for(int s = 0; s < n_stages; ++ s) {
 			for(int64_t i = P.task_ptr[P.stage_ptr[s]]; i < P.task_ptr[P.stage_ptr[s + 1]]; ++ i)
@@ -760,6 +761,10 @@ void slampp_hip_solver::Analyze_Sparse()
 			// Waves per task: eight where the stage is a launch on the critical path, four where it holds more tasks than the
 			// chip takes at once (more workgroups per CU: throughput).
 			const int n_stage_waves = (b_panel_stage && P.stage_ptr[s + 1] - P.stage_ptr[s] > 512)? 4 : int(PANEL_W);
+			// hand-ups from the stage below (development knob SLAMPP_HANDUP_MAX_TASKS: only from stages of at most that many tasks --
+			// a stage that fills the chip several times over is bound by throughput, and what its tasks compute for the stage
+			// above they compute instead of the next task's columns: C3's 2 420-task launch 70 -> 92 us; the stage above gains more)
+			const bool b_hand_up_stage = b_hand_up && s > 0 && P.stage_ptr[s] - P.stage_ptr[s - 1] <= n_handup_max_tasks;
 			panel_cfg[s].n_waves = n_stage_waves;
 			panel_cfg[s].n_cap_units = 64 * n_stage_waves; // (one speculative unit per thread)
 			// The first stage above a leaf stage that is not a panel launch: everything its tasks receive comes from that one
@@ -781,12 +786,12 @@ void slampp_hip_solver::Analyze_Sparse()
 					for(int64_t i = P.task_ptr[t]; i < P.task_ptr[t + 1]; ++ i) {
 						const TColDesc &c = cols[i];
 						for(int64_t e = c.r0; e < c.r0 + c.nr; ++ e) {
-							const bool b_up = b_hand_up && img_slot[P.rblk[e]] >= 0 && col_stage[P.blk_col[P.rblk[e]]] == s - 1;
+							const bool b_up = b_hand_up_stage && img_slot[P.rblk[e]] >= 0 && col_stage[P.blk_col[P.rblk[e]]] == s - 1;
 							n_fresh += !b_up && col_stage[P.blk_col[P.rblk[e]]] == s - 1;
 							n_external += !b_up && col_stage[P.blk_col[P.rblk[e]]] < s;
 						}
 						for(int64_t e = P.pptr[c.k0 + 1]; e < P.pptr[c.k0 + c.nb]; ++ e) {
-							const bool b_up = b_hand_up && img_slot[P.pa[e]] >= 0 && col_stage[P.blk_col[P.pa[e]]] == s - 1;
+							const bool b_up = b_hand_up_stage && img_slot[P.pa[e]] >= 0 && col_stage[P.blk_col[P.pa[e]]] == s - 1;
 							n_fresh += !b_up && col_stage[P.blk_col[P.pa[e]]] == s - 1;
 							n_external += !b_up && col_stage[P.blk_col[P.pa[e]]] < s;
 						}
@@ -847,7 +852,7 @@ void slampp_hip_solver::Analyze_Sparse()
 				// an update whose operands a task of the stage right below keeps in its image is handed up by that task (one
 				// ready-made block per source task and target block) instead of fetched and multiplied here
 				auto Handed_Up = [&](int64_t n_operand_blk) {
-					return b_hand_up && !b_self && s > 0 && img_slot[n_operand_blk] >= 0 && col_stage[P.blk_col[n_operand_blk]] == s - 1;
+					return b_hand_up_stage && !b_self && img_slot[n_operand_blk] >= 0 && col_stage[P.blk_col[n_operand_blk]] == s - 1;
 				};
 				std::vector<std::pair<int32_t, int64_t> > up_keys; // (source package, target block) of this task's hand-ups, in order of first use
 				auto Count_Up = [&](int64_t n_operand_blk, int64_t n_target_blk) {
@@ -1433,7 +1438,7 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 				launch_panel_update(P.max_dim, d_panel_upd_slots.p() + panel_upd_ptr[s], panel_upd_ptr[s + 1] - panel_upd_ptr[s],
 					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream);
 			const int n_next = (s + 1 < n_stages && panel_ride[s + 1] == 1)? panel_upd_ptr[s + 2] - panel_upd_ptr[s + 1] : 0;
-			launch_factor_panel(P.max_dim, b_panel_fused, n_panel_rows != 0, panel_cfg[s], d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s],
+			launch_factor_panel(P.max_dim, b_panel_fused, (n_panel_rows < 0)? P.max_dim >= 6 : n_panel_rows != 0, panel_cfg[s], d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s],
 				d_panel_out_off.p() + panel_ptr[s], n_panels,
 				d_panel_upd_slots.p() + ((n_next > 0)? panel_upd_ptr[s + 1] : 0), n_next, d_panel_upd_ents.p(), p_values_dev, p_rhs_dev,
 				d_L.p(), d_Linv.p(), d_w.p(), d_handup.p(), p_flag, stream, dplan.p_timing);
@@ -1821,7 +1826,7 @@ static int set_option_checked(slampp_hip_solver *p_solver, const char *p_s_name,
 		p_solver->n_panel = int(n_value);
 	else if(s == "panel_handup" && n_value >= 0 && n_value <= 1)
 		p_solver->n_panel_handup = int(n_value);
-	else if(s == "panel_rows" && n_value >= 0 && n_value <= 1) {
+	else if(s == "panel_rows" && n_value >= -1 && n_value <= 1) {
 		p_solver->n_panel_rows = int(n_value);
 		return SLAMPP_HIP_OK; // read at every launch
 	}

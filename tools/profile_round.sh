@@ -4,7 +4,7 @@
 # traffic counters (FETCH_SIZE and WRITE_SIZE do not fit one pass) and the matrix-core counters of the MFMA-bound legs.
 # Usage: tools/profile_round.sh <tag>   (writes under gpurun_out/<tag>/; copy the summaries to profiles/)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -18,18 +18,18 @@ LEG[ba_uniform]="--workload ba --ba-legs uniform --ba-steps 5 --no-cpu-baseline 
 LEG[c2]="--workload small --small-configs C2 --no-cpu-baseline"
 LEG[c1]="--workload small --small-configs C1 --no-cpu-baseline"
 for L in c3 ba_venice ba_band ba_uniform c2 c1; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${L}_trace -- python3 $R/bench.py ${LEG[$L]} > $OUT/${L}_bench_under_rocprof.json 2> $OUT/${L}_trace.err
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${L}_trace -- python3 $R/bench.py ${LEG[$L]} --full-json gpurun_out/$TAG/${L}_bench_full_under_rocprof.json > $OUT/${L}_bench_under_rocprof.json 2> $OUT/${L}_trace.err
   f=$(find $OUT/${L}_trace -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${L}_kernel_stats.csv
 done
 for L in c3 ba_venice ba_band ba_uniform; do
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/${L}_pmc_$C -- python3 $R/bench.py ${LEG[$L]} > $OUT/${L}_pmc_$C.json 2> $OUT/${L}_pmc_$C.err
+    timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/${L}_pmc_$C -- python3 $R/bench.py ${LEG[$L]} --full-json gpurun_out/$TAG/scratch_full.json > $OUT/${L}_pmc_$C.json 2> $OUT/${L}_pmc_$C.err
   done
 done
 # matrix cores: instructions (MOPS) and busy cycles of the MFMA pipe next to the shader's busy cycles, per kernel
 for L in ba_uniform ba_venice c2; do
-  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $OUT/${L}_pmc_mfma -- python3 $R/bench.py ${LEG[$L]} > $OUT/${L}_pmc_mfma.json 2> $OUT/${L}_pmc_mfma.err
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $OUT/${L}_pmc_mfma -- python3 $R/bench.py ${LEG[$L]} --full-json gpurun_out/$TAG/scratch_full.json > $OUT/${L}_pmc_mfma.json 2> $OUT/${L}_pmc_mfma.err
 done
 cd $R
 for L in c3 ba_venice ba_band ba_uniform; do
