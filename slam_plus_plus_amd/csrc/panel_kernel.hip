@@ -169,15 +169,17 @@ __device__ __forceinline__ void panel_copy_out(const TPanelCol *s_col, const TPa
 	}
 }
 
-// the blocks the task hands up (TPanelOut): sums of products of its own finished blocks, out of the image; a wave per block
-template <int D, int W>
-__device__ __forceinline__ void panel_hand_up(const longlong2 *s_out, int n_out, int wave, int lane, const TLaneMap mm, bool b_y, int yq,
-	const double *s_L, const double *s_w, double *H)
+// the blocks the task hands up (TPanelOut): sums of products of its own finished blocks, out of the image; a wave per block:
+// records [n_first, n_last) of the list, record n_first + i by wave n_wave0 + i mod n_waves_here (the waves a level's column
+// work leaves idle take the records whose operands are final already; what is left is done by all waves at the end)
+template <int D>
+__device__ __forceinline__ void panel_hand_up(const longlong2 *s_out, int n_out, int n_first, int n_last, int n_rank, int n_ranks, int lane,
+	const TLaneMap mm, bool b_y, int yq, const double *s_L, const double *s_w, double *H)
 {
 	enum { DD = D * D };
-	const TPanelOut *s_rec = reinterpret_cast<const TPanelOut*>(s_out);
-	const uint32_t *s_opair = reinterpret_cast<const uint32_t*>(s_out + n_out);
-	for(int o = wave; o < n_out; o += W) {
+	const TPanelOut *s_rec = reinterpret_cast<const TPanelOut*>(s_out + 3);
+	const uint32_t *s_opair = reinterpret_cast<const uint32_t*>(s_out + 3 + n_out);
+	for(int o = n_first + n_rank; o < n_last; o += n_ranks) {
 		const TPanelOut rec = s_rec[o];
 		const bool b_diag = (rec.dst >> 62) != 0;
 		const int64_t n_dst = rec.dst & ((int64_t(1) << 62) - 1);
@@ -401,6 +403,7 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 		// column (and chunk of 40 rows) factors the whole block column as rows, diagonal block, blocks below and right-hand side
 		// in the same six steps; meanwhile the other waves send the level before to memory and invert its diagonal blocks.
 		enum { CAP = 4 * (16 - D) };
+		int n_level = 0, n_out_done = 0;
 		// (the finished diagonal blocks wait in s_linv: the image keeps the blocks as they were for the other chunks of their columns)
 		for(int ci0 = 0; ci0 < n_cols;) {
 			const int n_sub = s_col[ci0].sub;
@@ -451,6 +454,16 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 						panel_column_rows<D>(s_col[ci], ci, n_chunk, lane, s_L, s_w, s_linv + ci * 64, p_flag);
 				}
 			}
+			// the waves without a column here hand up what the levels before this one have finished (at most three blocks a wave:
+			// the level's column work takes about as long)
+			if(n_out > 0 && n_level > 0 && n_pair < W) {
+				const int n_ready = reinterpret_cast<const int32_t*>(s_out)[min(n_level - 1, 11)], n_idle = W - n_pair;
+				const int n_take = min(n_ready - n_out_done, 3 * n_idle);
+				if(wave >= n_pair && n_take > 0)
+					panel_hand_up<D>(s_out, n_out, n_out_done, n_out_done + n_take, wave - n_pair, n_idle, lane, mm, b_y, yq, s_L, s_w, H);
+				n_out_done += max(n_take, 0);
+			}
+			++ n_level;
 			__syncthreads(); // the level's columns and their y complete in the image
 			PANEL_TICK();
 			ci0 = ci1;
@@ -459,7 +472,7 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 		panel_copy_out<D, W>(s_col, s_slot, 0, n_cols, wave, lane, mm, s_L, s_w, s_linv, s_tile, L, Linv, w);
 		PANEL_TICK();
 		// (the finished diagonal blocks live in s_linv in this walk, not in the image: nothing handed up reads a diagonal block)
-		panel_hand_up<D, W>(s_out, n_out, wave, lane, mm, b_y, yq, s_L, s_w, H);
+		panel_hand_up<D>(s_out, n_out, n_out_done, n_out, wave, W, lane, mm, b_y, yq, s_L, s_w, H);
 		return;
 	}
 	// (the block-wise form of rounds 2 and 3, kept for comparison: option "panel_rows" = 0) their diagonal blocks go to one
@@ -506,7 +519,7 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 		PANEL_TICK();
 		ci0 = ci1;
 	}
-	panel_hand_up<D, W>(s_out, n_out, wave, lane, mm, b_y, yq, s_L, s_w, H);
+	panel_hand_up<D>(s_out, n_out, 0, n_out, wave, W, lane, mm, b_y, yq, s_L, s_w, H);
 	PANEL_TICK();
 }
 

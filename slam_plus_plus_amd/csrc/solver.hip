@@ -735,7 +735,7 @@ void slampp_hip_solver::Analyze_Sparse()
 		std::vector<int32_t> slot_of(size_t(n_lblocks), -1); // factor block -> slot of the task being packed (else -1)
 		// round 4, hand-ups (TPanelOut): the slot every factor block has in the image of its own task, once that task's package
 		// exists (-1: the task went to the column kernel), the package of every column's task, and per package what it hands up
-		std::vector<int32_t> img_slot(size_t(n_lblocks), -1), col_package(size_t(P.n), -1);
+		std::vector<int32_t> img_slot(size_t(n_lblocks), -1), col_package(size_t(P.n), -1), col_level(size_t(P.n), 0); // (col_level: which of its task's levels a column is in)
 		struct THandUp { std::vector<TPanelOut> recs; std::vector<uint32_t> pairs; };
 		std::vector<THandUp> hand_up; // indexed by package
 		std::map<std::pair<int32_t, int64_t>, int32_t> out_of; // (source package, target factor block) -> record of that package
@@ -920,7 +920,8 @@ void slampp_hip_solver::Analyze_Sparse()
 						fresh.push_back(en);
 						n_handup_doubles += P.max_dim * P.max_dim + 8;
 					}
-					// (record index in the high half: the pairs are sorted by record when the list is written)
+					// (until the list is written, onp holds the last of the source task's levels the record's operands come from)
+					r_up.recs[size_t(it->second)].onp = std::max(r_up.recs[size_t(it->second)].onp, col_level[P.blk_col[ka]]);
 					r_up.pairs.push_back(uint32_t(it->second));
 					r_up.pairs.push_back(b_diag? (uint32_t(img_slot[ka]) | (uint32_t(col_local[P.blk_col[ka]]) << 16)) :
 						(uint32_t(img_slot[ka]) | (uint32_t(img_slot[kb]) << 16)));
@@ -1047,11 +1048,14 @@ void slampp_hip_solver::Analyze_Sparse()
 				p_dst += (ipair.size() + 3) / 4 * 16;
 				if(!fresh.empty())
 					memcpy(p_dst, fresh.data(), fresh.size() * sizeof(TPanelExt));
-				for(size_t o = 0; o < order.size(); ++ o) {
+				for(size_t o = 0, n_level = 0; o < order.size(); ++ o) {
 					const TColDesc &c = cols[order[o]];
 					for(int64_t k = c.k0; k < c.k0 + c.nb; ++ k)
 						img_slot[k] = slot_of[k];
 					col_package[P.task_cols[order[o]]] = int32_t(panel_off.size());
+					if(o > 0 && pcols[o].sub != pcols[o - 1].sub)
+						++ n_level;
+					col_level[P.task_cols[order[o]]] = int32_t(n_level);
 				}
 				panel_off.push_back(int64_t(n_at));
 				panel_out_off.push_back(-1);
@@ -1064,26 +1068,42 @@ void slampp_hip_solver::Analyze_Sparse()
 				THandUp &r_up = hand_up[size_t(n_pkg)];
 				if(r_up.recs.empty())
 					continue;
+				// the list: [12 x int32: records whose operands are final after level 0, 1, ...][records, in that order][their pairs] --
+				// the waves a level's column work leaves idle take the records that are ready, the rest is done at the end
 				const size_t n_out = r_up.recs.size(), n_pairs = r_up.pairs.size() / 2;
+				enum { OUT_LEVELS = 12 };
+				std::vector<int32_t> rec_order(n_out), rec_new(n_out), level_end(OUT_LEVELS, 0);
+				for(size_t o = 0; o < n_out; ++ o)
+					rec_order[o] = int32_t(o);
+				std::stable_sort(rec_order.begin(), rec_order.end(), [&](int32_t a, int32_t b) { return r_up.recs[size_t(a)].onp < r_up.recs[size_t(b)].onp; });
+				for(size_t o = 0; o < n_out; ++ o) {
+					rec_new[size_t(rec_order[o])] = int32_t(o);
+					for(int l = std::min(r_up.recs[size_t(rec_order[o])].onp, int32_t(OUT_LEVELS) - 1); l < int(OUT_LEVELS); ++ l)
+						++ level_end[size_t(l)];
+				}
+				std::vector<TPanelOut> recs_sorted(n_out);
+				for(size_t o = 0; o < n_out; ++ o)
+					recs_sorted[o] = r_up.recs[size_t(rec_order[o])];
 				std::vector<uint32_t> sorted(n_pairs);
 				{
 					std::vector<int32_t> count(n_out + 1, 0);
 					for(size_t e = 0; e < n_pairs; ++ e)
-						++ count[r_up.pairs[2 * e] + 1];
+						++ count[size_t(rec_new[r_up.pairs[2 * e]]) + 1];
 					for(size_t o = 0; o < n_out; ++ o) {
-						r_up.recs[o].op0 = count[o];
-						r_up.recs[o].onp = count[o + 1];
+						recs_sorted[o].op0 = count[o];
+						recs_sorted[o].onp = count[o + 1];
 						count[o + 1] += count[o];
 					}
 					std::vector<int32_t> fill(count.begin(), count.end() - 1);
 					for(size_t e = 0; e < n_pairs; ++ e) // (stable: the pairs of a record keep their order)
-						sorted[size_t(fill[r_up.pairs[2 * e]] ++)] = r_up.pairs[2 * e + 1];
+						sorted[size_t(fill[size_t(rec_new[r_up.pairs[2 * e]])] ++)] = r_up.pairs[2 * e + 1];
 				}
-				const size_t n_units = n_out + (n_pairs + 3) / 4;
+				const size_t n_units = 3 + n_out + (n_pairs + 3) / 4;
 				const size_t n_at = panel_pkg.size();
 				panel_pkg.resize(n_at + n_units, longlong2{0, 0});
-				memcpy(&panel_pkg[n_at], r_up.recs.data(), n_out * sizeof(TPanelOut));
-				memcpy(&panel_pkg[n_at + n_out], sorted.data(), n_pairs * sizeof(uint32_t));
+				memcpy(&panel_pkg[n_at], level_end.data(), OUT_LEVELS * sizeof(int32_t));
+				memcpy(&panel_pkg[n_at + 3], recs_sorted.data(), n_out * sizeof(TPanelOut));
+				memcpy(&panel_pkg[n_at + 3 + n_out], sorted.data(), n_pairs * sizeof(uint32_t));
 				panel_out_off[size_t(n_pkg)] = int64_t(n_at);
 				TPanelHead *p_head = reinterpret_cast<TPanelHead*>(&panel_pkg[size_t(panel_off[size_t(n_pkg)])]);
 				p_head->ext_ptr[10] = int32_t(n_out);
