@@ -406,8 +406,13 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 					w += s_u[g][n_off_b[t] + j * DC] * cik[j]; // W(q, kk) = sum_j U(q, j) C^-1(j, kk)
 				wb[t] = (b_b[t] && (!b_prefix || n_obs_b[t] < n_k_own))? w : 0.0;
 			}
+			// (b_prefix: a landmark that ends inside the row block fills only the first tiles of rows -- and, on the diagonal, of
+			// columns --: the others would multiply zeros, and these kernels spend 27 - 36 % of the fp64 matrix peak as it is)
+			const int n_rt_own = b_prefix? (min(n_k_own - n_rb * OB, int(OB)) * DC + 15) / 16 : NT;
 			#pragma unroll
 			for(int rt = 0; rt < NT; ++ rt) {
+				if(b_prefix && rt >= n_rt_own) // (wave-uniform)
+					continue;
 				#pragma unroll
 				for(int ct = 0; ct < NT; ++ ct) {
 					if(ct <= rt || !b_diag)
