@@ -506,6 +506,10 @@ void slampp_hip_solver::Analyze_Sparse()
 		opt.task_wide_min = n_wide_min_tasks;
 		opt.task_max_cols = int(PANEL_COLS);
 		opt.task_max_blocks = panel_slot_cap(n_dim0);
+		// the top of the tree as one task (option "panel_top"): what one workgroup's LDS holds next to the package and the staging
+		const bool b_top = n_panel_top != 0 && n_panel != 0 && (n_dim0 == 3 || n_dim0 == 6 || n_dim0 == 7);
+		opt.task_top_cols = b_top? int(PANEL_TOP_COLS) : 0;
+		opt.task_top_blocks = b_top? panel_top_slot_cap(n_dim0) : 0;
 	}
 	std::string s_err = b_refined? build_plan(int64_t(refined_cumsum.size()) - 1, refined_cumsum.data(), refined_bcol_ptr.data(),
 		refined_brow.data(), opt, plan) : build_plan(int64_t(cumsum.size()) - 1, cumsum.data(), bcol_ptr.data(), brow.data(), opt, plan);
@@ -813,7 +817,8 @@ void slampp_hip_solver::Analyze_Sparse()
 			for(int t = P.stage_ptr[s]; b_panel_stage && t < P.stage_ptr[s + 1]; ++ t) {
 				const int64_t c_begin = P.task_ptr[t], c_end = P.task_ptr[t + 1];
 				const int n_cols = int(c_end - c_begin);
-				bool b_fits = n_cols >= 1 && n_cols <= int(PANEL_COLS);
+				const bool b_top_task = n_cols > int(PANEL_COLS); // (only the merged top of the tree outgrows a slice: Plan, task_top_cols)
+				bool b_fits = n_cols >= 1 && n_cols <= (opt.task_top_cols? std::max(int(PANEL_COLS), opt.task_top_cols) : int(PANEL_COLS));
 				// the package lists the task's columns level by level (a tall task: Plan::col_sub; a chain: one column per
 				// level, in order), the slots of the LDS image are their blocks in that order
 				order.clear();
@@ -829,7 +834,7 @@ void slampp_hip_solver::Analyze_Sparse()
 				int64_t n_slots = 0, n_int_rows = 0, n_int_pairs = 0;
 				for(size_t o = 0; b_fits && o < order.size(); ++ o)
 					n_slots += cols[order[o]].nb;
-				b_fits = b_fits && n_slots <= n_slot_cap;
+				b_fits = b_fits && n_slots <= (b_top_task? std::max(n_slot_cap, opt.task_top_blocks) : n_slot_cap);
 				if(b_fits) {
 					int32_t n_slot = 0;
 					for(size_t o = 0; o < order.size(); ++ o) {
@@ -884,12 +889,17 @@ void slampp_hip_solver::Analyze_Sparse()
 				n_fresh += int64_t(up_keys.size());
 				const size_t n_units = 4 + 3 * size_t(n_cols) + 2 * size_t(n_slots) + size_t(n_int_rows + 3) / 4 + size_t(n_int_pairs + 3) / 4 +
 					2 * size_t(n_fresh);
-				b_fits = b_fits && n_units <= size_t(PANEL_UNITS);
+				b_fits = b_fits && n_units <= size_t(b_top_task? PANEL_TOP_UNITS : PANEL_UNITS);
+				if(b_fits && b_top_task) { // (the top task's LDS is sized by the task itself: does it fit a CU's, with room for its hand-up list?)
+					TPanelLaunch t_cfg = {int32_t(PANEL_W), int32_t(std::max<size_t>(n_units, 64 * PANEL_W)), int32_t(n_slots), n_cols, n_cols, 0, 0};
+					b_fits = size_t(panel_lds(D, true, t_cfg).TOTAL) * sizeof(double) <= 150 * 1024;
+				}
 				n_stage_max_slots = std::max(n_stage_max_slots, n_slots);
 				n_stage_max_units = std::max(n_stage_max_units, int64_t(n_units));
 				n_stage_rest += !b_fits;
 				if(!b_fits) {
-					if(n_slots <= n_slot_cap && n_cols >= 1 && n_cols <= int(PANEL_COLS))
+					if(n_slots <= (b_top_task? std::max(n_slot_cap, opt.task_top_blocks) : n_slot_cap) && n_cols >= 1 &&
+					   n_cols <= (opt.task_top_cols? std::max(int(PANEL_COLS), opt.task_top_cols) : int(PANEL_COLS)))
 						Release_Slots();
 					panel_rest.push_back(t);
 					continue;
@@ -1846,6 +1856,8 @@ static int set_option_checked(slampp_hip_solver *p_solver, const char *p_s_name,
 		p_solver->n_panel = int(n_value);
 	else if(s == "panel_handup" && n_value >= 0 && n_value <= 1)
 		p_solver->n_panel_handup = int(n_value);
+	else if(s == "panel_top" && n_value >= 0 && n_value <= 1)
+		p_solver->n_panel_top = int(n_value);
 	else if(s == "panel_rows" && n_value >= -1 && n_value <= 1) {
 		p_solver->n_panel_rows = int(n_value);
 		return SLAMPP_HIP_OK; // read at every launch

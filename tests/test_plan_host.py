@@ -100,3 +100,29 @@ def test_structure_errors_are_reported():
     bad = dataclasses.replace(lam, brow_idx=lam.brow_idx[::-1].copy())   # rows not sorted / not upper
     with pytest.raises(ValueError):
         host_plan(bad)
+
+
+@pytest.mark.parametrize("make", [
+    lambda: synth.pose_chain(n=5000, d=6, seed=21),
+    lambda: synth.pose_chain(n=3000, d=3, seed=25),
+    lambda: synth.manhattan(2000, seed=23),
+], ids=["chain5000", "chain3000_se2", "manhattan2000"])
+def test_top_of_the_tree_as_one_task(make, monkeypatch):
+    """Round 4 (PlanOptions::task_top_cols / task_top_blocks, what the solver sets with option panel_top): as many of the
+    last stages as fit the capacities together become ONE task -- fewer stages, the same columns, and a schedule the CPU
+    replay still accepts (every operand produced in an earlier stage or earlier in the same task) with the same solution."""
+    lam = make()
+    ok, x_ref, _ = O.solve_sparse(lam)
+    plan0, st0 = host_plan(lam, dense_top_nb=0)
+    monkeypatch.setenv("SLAMPP_HIP_TASK_TOP", "48,224")
+    plan1, st1 = host_plan(lam, dense_top_nb=0)
+    monkeypatch.delenv("SLAMPP_HIP_TASK_TOP")
+    check_plan_invariants(lam, plan1)
+    assert st1["n_stages"] < st0["n_stages"] and st1["n_stages"] >= 2
+    assert np.array_equal(plan0["perm"], plan1["perm"]) and np.array_equal(plan0["lrow"], plan1["lrow"])   # only the schedule differs
+    last = slice(int(plan1["task_ptr"][plan1["stage_ptr"][-2]]), None)
+    assert plan1["stage_ptr"][-1] - plan1["stage_ptr"][-2] == 1                   # one task at the top ...
+    n_top = len(plan1["task_cols"][last])
+    assert 8 < n_top <= 48                                                         # ... bigger than a slice, within the capacity
+    status, x = O.exec_plan(lam, plan1)
+    assert ok and status == 0 and rel_inf(x, x_ref) < TOL
