@@ -67,10 +67,13 @@ void tile_cholesky(const CTileSchedule &r_schedule, double *M, int n_pad, int n,
 	hipStream_t stream);
 
 // zeroes the schedule's tiles of M (every tile a factorization by the schedule or an assembly into its pattern writes)
-void tile_zero(const CTileSchedule &r_schedule, double *M, int n_pad, hipStream_t stream);
+// p_unit (optional, n_pad bytes): positions whose diagonal entry is 1 afterwards (padding, alignment gaps)
+void tile_zero(const CTileSchedule &r_schedule, double *M, int n_pad, hipStream_t stream, const uint8_t *p_unit = 0);
 
 // x = L^-T y with y taken from row n_pad-1 of the factor; p_z: workspace n_pad doubles; p_x: n_pad doubles, x in [0, n)
-void dense_backsolve(const double *M, int n_pad, int n, const double *p_invdiag, double *p_z, double *p_x, hipStream_t stream);
+// p_dst (optional, n_pad entries): where entry i of x also goes -- p_w[p_dst[i].x] and p_x_out[p_dst[i].y]; .x < 0: nowhere
+void dense_backsolve(const double *M, int n_pad, int n, const double *p_invdiag, double *p_z, double *p_x, hipStream_t stream,
+	const longlong2 *p_dst = 0, double *p_w = 0, double *p_x_out = 0);
 
 // y = L^-1 r for another right-hand side with a kept factor: r sits in row n_pad-1 (columns < n) and is
 // replaced by y, ready for dense_backsolve

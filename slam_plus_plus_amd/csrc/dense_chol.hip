@@ -239,13 +239,6 @@ void dense_update_panels(double *M, int n_pad, int k0, int k1, int c0, int c1, h
 }
 
 // ---- backward substitution x = L^-T y, right-looking ----
-__global__ void dense_backsolve_init_kernel(const double *M, int ld, int n, double *z)
-{
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if(i < ld)
-		z[i] = (i < n)? M[size_t(ld - 1) + size_t(i) * ld] : 0.0;
-}
-
 // ---- stand-alone forward substitution y = L^-1 r with a kept factor (another right-hand side) ----
 // r is taken from row ld-1 of M (where dense_assemble leaves it), y is written back there, so that
 // dense_backsolve finds it where the fused factorization would have put it
@@ -325,8 +318,13 @@ void dense_forwardsolve(double *M, int n_pad, const double *p_invdiag, hipStream
 // A thread's eight values of a tile row are four 16-byte pairs, 2 part + 16 i: the eight threads of a row read whole
 // 128-byte lines (as 8-byte loads at part + 8 i they touched every line twice: half the load instructions now).
 __global__ void __launch_bounds__(512)
-dense_backsolve_panel_kernel(const double *M, int ld, int t0, int t1, const double *p_invdiag, double *z, double *x)
+dense_backsolve_panel_kernel(const double *M, int ld, int t0, int t1, const double *p_invdiag, double *z, double *x, int n_first,
+	const longlong2 *__restrict__ p_dst, double *p_w, double *p_x_out)
 {
+	// n_first >= 0: the first launch of a substitution (the last panel) takes z = y out of row ld-1 of the factor (columns
+	// < n_first; zero beyond) instead of from z -- what a launch of its own used to copy.  p_dst (optional): where entry i of
+	// the dense system goes in the solver's vectors (.x in w, .y in the caller's x; < 0 for padding): the publishing
+	// workgroup stores there as well, and no scatter launch follows the substitution.
 	enum { PARTS = 8, PER = NB / PARTS, N_PAIRS = OUTER_TILES * (OUTER_TILES - 1) / 2 };
 	__shared__ double s_z[OUTER_TILES * NB]; // z of the panel
 	__shared__ double s_x[OUTER_TILES * NB]; // x of the panel, tile by tile (an array of its own: nobody waits for the readers of z)
@@ -366,8 +364,16 @@ dense_backsolve_panel_kernel(const double *M, int ld, int t0, int t1, const doub
 			}
 		}
 	}
-	for(int i = t; i < m * NB; i += 512)
-		s_z[i] = z[t0 * NB + i];
+	const bool b_first = n_first >= 0;
+	for(int i = t; i < m * NB; i += 512) {
+		const int q = t0 * NB + i;
+		s_z[i] = b_first? ((q < n_first)? M[size_t(ld - 1) + size_t(q) * ld] : 0.0) : z[q];
+	}
+	double z_in = 0; // the strip's own entry, requested with everything else
+	if(b_strip && part == 0) {
+		const int q = jb * NB + c;
+		z_in = b_first? ((q < n_first)? M[size_t(ld - 1) + size_t(q) * ld] : 0.0) : z[q];
+	}
 	__syncthreads();
 	#pragma unroll
 	for(int a = OUTER_TILES - 1; a >= 0; -- a) {
@@ -400,8 +406,17 @@ dense_backsolve_panel_kernel(const double *M, int ld, int t0, int t1, const doub
 		}
 	}
 	if(jb == 0) {
-		for(int i = t; i < m * NB; i += 512)
-			x[t0 * NB + i] = s_x[i];
+		for(int i = t; i < m * NB; i += 512) {
+			const double v = s_x[i];
+			x[t0 * NB + i] = v;
+			if(p_dst) {
+				const longlong2 d = p_dst[t0 * NB + i];
+				if(d.x >= 0) {
+					p_w[d.x] = v;
+					p_x_out[d.y] = v;
+				}
+			}
+		}
 	}
 	if(!b_strip)
 		return; // the only workgroup of the first panel just publishes
@@ -418,17 +433,17 @@ dense_backsolve_panel_kernel(const double *M, int ld, int t0, int t1, const doub
 	sum += __shfl_xor(sum, 2);
 	sum += __shfl_xor(sum, 4);
 	if(part == 0)
-		z[jb * NB + c] -= sum;
+		z[jb * NB + c] = z_in - sum;
 }
 
-void dense_backsolve(const double *M, int n_pad, int n, const double *p_invdiag, double *p_z, double *p_x, hipStream_t stream)
+void dense_backsolve(const double *M, int n_pad, int n, const double *p_invdiag, double *p_z, double *p_x, hipStream_t stream,
+	const longlong2 *p_dst, double *p_w, double *p_x_out)
 {
 	const int n_blocks = n_pad / NB;
-	hipLaunchKernelGGL(dense_backsolve_init_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, stream, M, n_pad, n, p_z);
 	for(int t1 = n_blocks; t1 > 0; t1 -= OUTER_TILES) {
 		const int t0 = (t1 > OUTER_TILES)? t1 - OUTER_TILES : 0;
 		hipLaunchKernelGGL(dense_backsolve_panel_kernel, dim3(t0 > 0? t0 : 1), dim3(512), 0, stream, M, n_pad, t0, t1, p_invdiag,
-			p_z, p_x);
+			p_z, p_x, (t1 == n_blocks)? n : -1, p_dst, p_w, p_x_out);
 	}
 }
 

@@ -229,7 +229,8 @@ bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hi
 // zeroes the tiles of the schedule (the diagonal ones whole): what a step's assembly adds into; the other tiles are
 // never written by anything that works from the schedule, so once zero they stay zero
 __global__ void __launch_bounds__(256)
-tile_zero_kernel(double *M, int ld, const int *__restrict__ p_potrf, int n_potrf, const int4 *__restrict__ p_trsm)
+tile_zero_kernel(double *M, int ld, const int *__restrict__ p_potrf, int n_potrf, const int4 *__restrict__ p_trsm,
+	const uint8_t *__restrict__ p_unit)
 {
 	int ti, tj;
 	if(int(blockIdx.x) < n_potrf)
@@ -240,16 +241,24 @@ tile_zero_kernel(double *M, int ld, const int *__restrict__ p_potrf, int n_potrf
 		tj = t.y;
 	}
 	const int r = (threadIdx.x & 31) * 2, c0 = threadIdx.x >> 5;
-	const v2f64 zero = {0, 0};
 	#pragma unroll
-	for(int i = 0; i < NB / 8; ++ i)
-		*reinterpret_cast<v2f64*>(M + size_t(ti * NB + r) + size_t(tj * NB + c0 + 8 * i) * ld) = zero;
+	for(int i = 0; i < NB / 8; ++ i) {
+		const int c = c0 + 8 * i;
+		v2f64 v = {0, 0};
+		if(ti == tj && p_unit && (c >> 1) == (r >> 1) && p_unit[tj * NB + c]) { // the identity of padding and gaps (own launches once)
+			if(c & 1)
+				v.y = 1.0;
+			else
+				v.x = 1.0;
+		}
+		*reinterpret_cast<v2f64*>(M + size_t(ti * NB + r) + size_t(tj * NB + c) * ld) = v;
+	}
 }
 
-void tile_zero(const CTileSchedule &r_s, double *M, int n_pad, hipStream_t stream)
+void tile_zero(const CTileSchedule &r_s, double *M, int n_pad, hipStream_t stream, const uint8_t *p_unit)
 {
 	const int n_potrf = r_s.level_potrf_ptr.back(), n_trsm = r_s.level_trsm_ptr.back();
-	hipLaunchKernelGGL(tile_zero_kernel, dim3(n_potrf + n_trsm), dim3(256), 0, stream, M, n_pad, r_s.d_potrf, n_potrf, r_s.d_trsm);
+	hipLaunchKernelGGL(tile_zero_kernel, dim3(n_potrf + n_trsm), dim3(256), 0, stream, M, n_pad, r_s.d_potrf, n_potrf, r_s.d_trsm, p_unit);
 }
 
 void tile_cholesky(const CTileSchedule &r_s, double *M, int n_pad, int n, double *p_invdiag, int *p_flag, hipStream_t stream)

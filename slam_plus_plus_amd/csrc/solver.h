@@ -186,10 +186,11 @@ struct slampp_hip_solver {
 	// dense top of the sparse path (plan.h): assembled Schur complement + dense factor workspaces
 	slampp::CDevArray<slampp::TDenseBlk> d_dense_blks;
 	slampp::CDevArray<int64_t> d_dense_blk_loff; // where each of those blocks lives in the factor's block layout (slampp_hip_factorize)
-	slampp::CDevArray<slampp::TDenseCol> d_dense_cols;
 	slampp::CDevArray<double> d_dense, d_dense_invdiag, d_dense_z, d_dense_x;
 	slampp::CDevArray<int32_t> d_dense_gaps; // positions inside the dense top that no column maps to (alignment padding)
 	int n_dense_gaps;
+	slampp::CDevArray<uint8_t> d_dense_unit;   // per position of the padded dense top: 1 = padding or gap (identity on the diagonal)
+	slampp::CDevArray<longlong2> d_dense_dst;  // per position: where x goes (.x in w, .y in the caller's vector; < 0: nowhere)
 	slampp::CTileSchedule dense_tiles; // level schedule over the nonzero tiles of the dense top (dense_chol.h)
 	bool b_dense_tiles;                // use it (its dependent chain is clearly shorter than the tile count)
 	bool b_dense_clean;                // the tiles of d_dense outside the schedule are zero (a full memset has run since it was allocated and only the schedule's tiles have been written): a step zeroes the schedule's tiles only

@@ -325,11 +325,11 @@ void slampp_hip_solver::Free_Device()
 	b_leaf_linv_valid = true;
 	d_panel_pkg.Free(); d_panel_off.Free(); d_panel_out_off.Free(); d_handup.Free(); d_panel_rest.Free(); d_panel_upd_slots.Free(); d_panel_upd_ents.Free();
 	simt_chunk_ptr.clear(); simt_rest_ptr.clear();
-	d_dense_blks.Free(); d_dense_blk_loff.Free(); d_dense_cols.Free(); d_dense.Free(); d_dense_invdiag.Free(); d_dense_z.Free(); d_dense_x.Free();
+	d_dense_blks.Free(); d_dense_blk_loff.Free(); d_dense.Free(); d_dense_invdiag.Free(); d_dense_z.Free(); d_dense_x.Free();
 	n_dense_blks = n_dense_cols = n_dense_dim = n_dense_pad = 0;
 	dense_tiles.Free();
 	b_dense_tiles = false;
-	d_dense_gaps.Free();
+	d_dense_gaps.Free(); d_dense_unit.Free(); d_dense_dst.Free();
 	n_dense_gaps = 0;
 	d_A.Free(); d_rhs.Free(); d_L.Free(); d_Linv.Free(); d_w.Free(); d_flag.Free();
 	d_cov.Free(); d_damp_off.Free(); d_timing.Free();
@@ -353,7 +353,7 @@ void slampp_hip_solver::Free_Device()
 
 size_t slampp_hip_solver::n_Device_Bytes() const
 {
-	return d_dense_blks.n_Bytes() + d_dense_cols.n_Bytes() + d_dense.n_Bytes() + d_dense_invdiag.n_Bytes() + dense_tiles.n_Bytes() +
+	return d_dense_blks.n_Bytes() + d_dense_unit.n_Bytes() + d_dense_dst.n_Bytes() + d_dense.n_Bytes() + d_dense_invdiag.n_Bytes() + dense_tiles.n_Bytes() +
 		d_dense_z.n_Bytes() + d_dense_x.n_Bytes() + d_cols.n_Bytes() + d_blks.n_Bytes() + d_rents.n_Bytes() +
 		d_task_ptr.n_Bytes() + d_task_pkg.n_Bytes() + d_pkg.n_Bytes() + d_pairs.n_Bytes() + d_A.n_Bytes() +
 		d_simt_chunks.n_Bytes() + d_simt_prog.n_Bytes() + d_simt_rest.n_Bytes() + d_simt_tab.n_Bytes() +
@@ -670,7 +670,6 @@ void slampp_hip_solver::Analyze_Sparse()
 		}
 		d_dense_blks.Upload(dense_blks, stream);
 		d_dense_blk_loff.Upload(dense_blk_loff, stream);
-		d_dense_cols.Upload(dense_cols, stream);
 		{
 			std::vector<char> covered(n_dense_dim, 0);
 			for(size_t k = 0; k < dense_cols.size(); ++ k)
@@ -682,7 +681,20 @@ void slampp_hip_solver::Analyze_Sparse()
 			}
 			n_dense_gaps = int(gaps.size());
 			d_dense_gaps.Upload(gaps, stream);
-			SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // gaps lives in this scope
+			// the same as a byte per position (with the padding behind the last column: tile_zero writes the identity there
+			// while it zeroes the diagonal tiles), and where every entry of the dense system's x goes in the solver's vectors
+			// (the last launch of the substitution stores there: no scatter launch)
+			std::vector<uint8_t> unit(n_dense_pad, uint8_t(1));
+			std::vector<longlong2> dst(n_dense_pad, longlong2{-1, -1});
+			for(size_t k = 0; k < dense_cols.size(); ++ k) {
+				for(int q = 0; q < dense_cols[k].dj; ++ q) {
+					unit[dense_cols[k].pos + q] = 0;
+					dst[dense_cols[k].pos + q] = longlong2{(long long)(dense_cols[k].cs_new + q), (long long)(dense_cols[k].cs_src + q)};
+				}
+			}
+			d_dense_unit.Upload(unit, stream);
+			d_dense_dst.Upload(dst, stream);
+			SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // the vectors live in this scope
 		}
 		d_dense.Alloc(size_t(n_dense_pad) * n_dense_pad);
 		b_dense_clean = false;
@@ -1530,14 +1542,14 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 		const int ld = n_dense_pad;
 		if(b_factor) {
 			Phase_Begin("dense_assemble");
-			if(b_dense_tiles && b_dense_clean)
-				tile_zero(dense_tiles, d_dense.p(), ld, stream); // (334 MB at the Venice-like C4's reduced system, 40 % of it in the schedule)
+			if(b_dense_tiles && b_dense_clean) // (334 MB at the Venice-like C4's reduced system, 40 % of it in the schedule)
+				tile_zero(dense_tiles, d_dense.p(), ld, stream, d_dense_unit.p()); // with the identity of padding and gaps
 			else {
 				SLAMPP_HIP_CHECK(hipMemsetAsync(d_dense.p(), 0, size_t(ld) * ld * sizeof(double), stream));
 				b_dense_clean = b_dense_tiles;
+				dense_prepare_padding(d_dense.p(), ld, n_dense_dim, stream);
+				dense_prepare_gaps(d_dense.p(), ld, d_dense_gaps.p(), n_dense_gaps, stream);
 			}
-			dense_prepare_padding(d_dense.p(), ld, n_dense_dim, stream);
-			dense_prepare_gaps(d_dense.p(), ld, d_dense_gaps.p(), n_dense_gaps, stream);
 			launch_dense_assemble(dplan, d_dense_blks.p(), n_dense_blks, p_values_dev, d_L.p(), p_rhs_dev, d_w.p(),
 				d_dense.p(), ld, false, stream);
 			Phase_End();
@@ -1560,8 +1572,8 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			Phase_End();
 		}
 		Phase_Begin("dense_solve");
-		dense_backsolve(d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), d_dense_z.p(), d_dense_x.p(), stream);
-		launch_dense_scatter(d_dense_cols.p(), n_dense_cols, d_dense_x.p(), d_w.p(), p_rhs_dev, stream);
+		dense_backsolve(d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), d_dense_z.p(), d_dense_x.p(), stream,
+			d_dense_dst.p(), d_w.p(), p_rhs_dev); // (x goes to w and to the caller's vector as each panel publishes it)
 		Phase_End();
 	}
 	Phase_Begin("backward");

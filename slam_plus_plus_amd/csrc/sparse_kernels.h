@@ -241,9 +241,6 @@ void launch_backward_stage(const TDevPlan &p, const double *L, const double *Lin
 void launch_dense_assemble(const TDevPlan &p, const TDenseBlk *blks, int n_blks, const double *A, const double *L,
 	const double *b, const double *w, double *Dm, int ld, bool b_rhs_only, hipStream_t stream);
 void launch_dense_gather_factor(const TDenseBlk *blks, const int64_t *loffs, int n_blks, const double *Dm, int ld, double *L, hipStream_t stream);
-// x of the dense-top columns from the dense solver's vector into the workspace and the caller's vector
 void launch_gather_values(const int64_t *p_map, int64_t n, const double *p_src, double *p_dst, hipStream_t stream);
-void launch_dense_scatter(const TDenseCol *cols, int n_cols, const double *x_dense, double *w, double *x_out,
-	hipStream_t stream);
 
 } // namespace slampp

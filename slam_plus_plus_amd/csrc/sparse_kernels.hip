@@ -635,21 +635,6 @@ dense_assemble_kernel(TDevPlan p, const TDenseBlk *__restrict__ blks, const doub
 	}
 }
 
-__global__ void dense_scatter_kernel(const TDenseCol *__restrict__ cols, int n_cols, const double *__restrict__ x,
-	double *w, double *x_out)
-{
-	const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-	const int c = gid >> 3, q = gid & 7;
-	if(c < n_cols) {
-		const TDenseCol cd = cols[c];
-		if(q < cd.dj) {
-			const double v = x[cd.pos + q];
-			w[cd.cs_new + q] = v;
-			x_out[cd.cs_src + q] = v;
-		}
-	}
-}
-
 // ---- launchers ----
 #define DISPATCH_DIM(D_runtime, CALL) do { switch(D_runtime) { \
 	case 3: { enum { D = 3 }; CALL; } break; \
@@ -725,14 +710,6 @@ void launch_dense_gather_factor(const TDenseBlk *blks, const int64_t *loffs, int
 {
 	if(n_blks > 0)
 		hipLaunchKernelGGL(dense_gather_factor_kernel, dim3(n_blks), dim3(64), 0, stream, blks, loffs, Dm, ld, L);
-}
-
-void launch_dense_scatter(const TDenseCol *cols, int n_cols, const double *x_dense, double *w, double *x_out,
-	hipStream_t stream)
-{
-	if(n_cols > 0)
-		hipLaunchKernelGGL(dense_scatter_kernel, dim3((n_cols * 8 + 255) / 256), dim3(256), 0, stream, cols, n_cols,
-			x_dense, w, x_out);
 }
 
 // values of a structure whose wide block columns were cut into pieces (solver.hip: Refine_Structure): dst[i] = src[map[i]]
