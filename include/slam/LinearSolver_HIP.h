@@ -311,12 +311,14 @@ protected:
 		const long n_block_num = long(m_gather.size());
 		const int n_thread_num = n_Copy_Thread_Num();
 		double *p_values = m_p_values;
-		const int64_t n_chunk_values = int64_t(2) << 20; // 16 MB: chunk k is on the bus while chunk k + 1 is gathered
+		int64_t n_chunk_values = int64_t(1) << 17; // chunk k is on the bus while chunk k + 1 is gathered: 1 MB first (the bus
+		// waits for the first chunk: 16 MB were 0.3 ms of gathering before the first byte moved), doubling up to 16 MB
 		long n_first = 0;
 		int64_t n_sent = 0;
 		while(n_first < n_block_num) {
 			long n_last = n_first;
 			const int64_t n_limit = m_gather[n_first].n_dest + n_chunk_values;
+			n_chunk_values = std::min<int64_t>(n_chunk_values * 2, int64_t(2) << 20);
 			if(int64_t(m_n_value_num) <= n_limit)
 				n_last = n_block_num;
 			else {

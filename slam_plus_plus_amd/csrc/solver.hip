@@ -15,6 +15,9 @@
 #include <cstring>
 #include <map>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <sys/mman.h>
 
 using namespace slampp;
@@ -216,67 +219,159 @@ void slampp_hip_solver::Require_Staging()
 	}
 }
 
+// Copy workers that outlive the call (round 4).  Staged_Upload() and Parallel_Copy() used to start eight threads per call
+// and join them: 0.1 - 0.2 ms each way on a 2 ms solve (C3 from host arrays).  One pool per process, made at first use and
+// never taken down (its threads sleep on a condition variable between calls; after a job they spin for a moment first,
+// since the next copy of a solve loop is usually microseconds away).  One job at a time: a caller that finds the pool
+// taken (the member threads of a device group upload side by side) gets false and starts threads of its own as before.
+class CCopyPool {
+	std::mutex m_mutex;
+	std::condition_variable m_wake;
+	std::function<void(int)> m_job;
+	std::atomic<uint64_t> m_n_generation{0};
+	std::atomic<int> m_n_running{0};
+	std::atomic<bool> m_b_taken{false};
+	int m_n_threads = 0;
+public:
+	static CCopyPool &r_Get()
+	{
+		static CCopyPool *p_pool = new CCopyPool(); // (leaked on purpose: no destructor runs against sleeping threads at exit)
+		return *p_pool;
+	}
+	int n_Threads() const { return m_n_threads; }
+	// f(t) on every worker, t = 0 .. n_Threads() - 1; returns at once (Wait() joins), false if the pool is busy or has no threads
+	bool Start(std::function<void(int)> f)
+	{
+		if(!m_n_threads || m_b_taken.exchange(true))
+			return false;
+		{
+			std::lock_guard<std::mutex> lock(m_mutex);
+			m_job = std::move(f);
+			m_n_running.store(m_n_threads, std::memory_order_relaxed);
+			m_n_generation.fetch_add(1, std::memory_order_release);
+		}
+		m_wake.notify_all();
+		return true;
+	}
+	void Wait()
+	{
+		while(m_n_running.load(std::memory_order_acquire) > 0)
+			std::this_thread::yield();
+		m_b_taken.store(false, std::memory_order_release);
+	}
+private:
+	CCopyPool()
+	{
+		const unsigned n_hw = std::thread::hardware_concurrency();
+		const int n_want = int(std::min<unsigned>(8, std::max<unsigned>(n_hw, 1)));
+		try {
+			for(int t = 0; t < n_want; ++ t) {
+				std::thread([this, t]() { Work(t); }).detach();
+				++ m_n_threads;
+			}
+		} catch(std::system_error&) {
+			// fewer threads, or none (Start() then says no)
+		}
+	}
+	void Work(int t)
+	{
+		uint64_t n_seen = 0;
+		for(;;) {
+			// a moment of spinning (the next job of a solve loop), then sleep
+			const auto t_spin_end = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+			while(m_n_generation.load(std::memory_order_acquire) == n_seen && std::chrono::steady_clock::now() < t_spin_end)
+				std::this_thread::yield();
+			if(m_n_generation.load(std::memory_order_acquire) == n_seen) {
+				std::unique_lock<std::mutex> lock(m_mutex);
+				m_wake.wait(lock, [&]() { return m_n_generation.load(std::memory_order_acquire) != n_seen; });
+			}
+			n_seen = m_n_generation.load(std::memory_order_acquire);
+			if(t < m_n_threads) // (a thread made before a later one failed to start still counts: m_n_threads only grows in the constructor)
+				m_job(t);
+			m_n_running.fetch_sub(1, std::memory_order_release);
+		}
+	}
+};
+
+// the chunks of a staged transfer: small first (the bus waits for the first chunk's copy: C3's 58 MB at 54 GB/s are 1.07 ms
+// on the bus, and a first chunk of 8 MB was 0.25 ms of memcpy before the first byte moved), doubling up to n_max
+static std::vector<size_t> staged_chunk_ends(size_t n, size_t n_first, size_t n_max)
+{
+	std::vector<size_t> ends;
+	size_t b = 0, n_chunk = n_first;
+	while(b < n) {
+		b = std::min(n, b + n_chunk);
+		ends.push_back(b);
+		n_chunk = std::min(n_max, n_chunk * 2);
+	}
+	return ends;
+}
+
 // A caller's array to the device through pinned staging, in chunks: the DMA engines cannot be pointed at pageable
 // memory, and one thread's memcpy is slower than PCIe -- a few host threads copy chunk c + 1 while chunk c is on the bus.
 static void Staged_Upload(double *p_dev, double *p_pin, const double *p_src, size_t n, hipStream_t copy_stream)
 {
-	const size_t n_chunk = size_t((n <= (size_t(16) << 20))? 1 : 4) << 20; // doubles: 32 MB; 8 MB where the first chunk's copy is a
-	// tenth of the transfer (the bus waits for it: C3's 58 MB 2.56 -> 2.36 ms per call; no gain for C4's 336 MB)
-	const size_t n_chunks = (n + n_chunk - 1) / n_chunk;
-	const unsigned n_hw = std::thread::hardware_concurrency();
-	const int n_threads = (n < (size_t(1) << 19))? 1 : int(std::min<unsigned>(8, std::max<unsigned>(n_hw, 1)));
-	if(n_threads == 1) {
-		for(size_t c = 0; c < n_chunks; ++ c) {
-			const size_t b = c * n_chunk, e = std::min(n, b + n_chunk);
-			memcpy(p_pin + b, p_src + b, (e - b) * sizeof(double));
-			SLAMPP_HIP_CHECK(hipMemcpyAsync(p_dev + b, p_pin + b, (e - b) * sizeof(double), hipMemcpyHostToDevice, copy_stream));
-		}
+	if(n < (size_t(1) << 19)) { // (4 MB: one thread, one transfer)
+		memcpy(p_pin, p_src, n * sizeof(double));
+		SLAMPP_HIP_CHECK(hipMemcpyAsync(p_dev, p_pin, n * sizeof(double), hipMemcpyHostToDevice, copy_stream));
 		return;
 	}
+	const std::vector<size_t> ends = staged_chunk_ends(n, size_t(1) << 17, size_t((n <= (size_t(16) << 20))? 1 : 4) << 20); // 1 MB first; 8 / 32 MB at most
+	const size_t n_chunks = ends.size();
 	std::vector<std::atomic<int> > done(n_chunks);
 	for(size_t c = 0; c < n_chunks; ++ c)
 		done[c].store(0);
-	CJoiningThreads workers; // joined before `done` goes, whichever way this scope is left
-	for(int t = 0; t < n_threads; ++ t) {
-		workers.v.emplace_back([=, &done]() {
-			for(size_t c = 0; c < n_chunks; ++ c) {
-				const size_t b = c * n_chunk, e = std::min(n, b + n_chunk), n_piece = (e - b + n_threads - 1) / n_threads;
-				const size_t pb = std::min(e, b + t * n_piece), pe = std::min(e, pb + n_piece);
-				if(pe > pb)
-					memcpy(p_pin + pb, p_src + pb, (pe - pb) * sizeof(double));
-				done[c].fetch_add(1, std::memory_order_release);
-			}
-		});
+	CCopyPool &r_pool = CCopyPool::r_Get();
+	int n_threads = r_pool.n_Threads();
+	auto copy_share = [=, &done, &ends](int t, int n_of) {
+		for(size_t c = 0; c < n_chunks; ++ c) {
+			const size_t b = c? ends[c - 1] : 0, e = ends[c], n_piece = (e - b + n_of - 1) / n_of;
+			const size_t pb = std::min(e, b + t * n_piece), pe = std::min(e, pb + n_piece);
+			if(pe > pb)
+				memcpy(p_pin + pb, p_src + pb, (pe - pb) * sizeof(double));
+			done[c].fetch_add(1, std::memory_order_release);
+		}
+	};
+	CJoiningThreads workers; // (only if the pool is taken) joined before `done` goes, whichever way this scope is left
+	const bool b_pool = r_pool.Start([=](int t) { copy_share(t, n_threads); });
+	if(!b_pool) {
+		n_threads = int(std::min<unsigned>(8, std::max<unsigned>(std::thread::hardware_concurrency(), 1)));
+		for(int t = 0; t < n_threads; ++ t)
+			workers.v.emplace_back([=]() { copy_share(t, n_threads); });
 	}
 	hipError_t n_err = hipSuccess;
 	for(size_t c = 0; c < n_chunks; ++ c) {
 		while(done[c].load(std::memory_order_acquire) < n_threads)
 			std::this_thread::yield();
-		const size_t b = c * n_chunk, e = std::min(n, b + n_chunk);
+		const size_t b = c? ends[c - 1] : 0, e = ends[c];
 		if(n_err == hipSuccess)
 			n_err = hipMemcpyAsync(p_dev + b, p_pin + b, (e - b) * sizeof(double), hipMemcpyHostToDevice, copy_stream);
 	}
-	workers.Join();
+	if(b_pool)
+		r_pool.Wait();
+	else
+		workers.Join();
 	SLAMPP_HIP_CHECK(n_err);
 }
 
 // the way back: DMA into the pinned staging (already enqueued and waited for by the caller), then out of it
 static void Parallel_Copy(double *p_dst, const double *p_src, size_t n)
 {
-	const unsigned n_hw = std::thread::hardware_concurrency();
-	const int n_threads = (n < (size_t(1) << 19))? 1 : int(std::min<unsigned>(8, std::max<unsigned>(n_hw, 1)));
-	if(n_threads == 1) {
+	if(n < (size_t(1) << 17)) { // (1 MB)
 		memcpy(p_dst, p_src, n * sizeof(double));
 		return;
 	}
-	CJoiningThreads workers;
-	const size_t n_piece = (n + n_threads - 1) / n_threads;
-	for(int t = 0; t < n_threads; ++ t) {
+	CCopyPool &r_pool = CCopyPool::r_Get();
+	const int n_threads = r_pool.n_Threads();
+	const size_t n_piece = n_threads? (n + n_threads - 1) / n_threads : n;
+	if(r_pool.Start([=](int t) {
 		const size_t b = std::min(n, t * n_piece), e = std::min(n, b + n_piece);
 		if(e > b)
-			workers.v.emplace_back([=]() { memcpy(p_dst + b, p_src + b, (e - b) * sizeof(double)); });
-	}
-	workers.Join();
+			memcpy(p_dst + b, p_src + b, (e - b) * sizeof(double));
+	}))
+		r_pool.Wait();
+	else
+		memcpy(p_dst, p_src, n * sizeof(double)); // (the pool is another caller's for the moment)
 }
 
 // Lambda's values to d_A.  From the library's own pinned staging (the header class gathers the blocks of a
