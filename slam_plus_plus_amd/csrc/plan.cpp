@@ -102,6 +102,16 @@ private:
 			m_set[v] = id;
 			m_level[v] = -1;
 		}
+		TIndexCut t_cut;
+		const TIndexCut *p_cut = 0; // a cut by number that stands unless the level structure finds a narrower one
+		if(Find_Index_Cut(S, id, t_cut)) {
+			enum { n_small = 256 };
+			if(S.size() >= size_t(n_small) || t_cut.n_sep <= 2) {
+				Apply_Index_Cut(S, id, n_out, n_depth, t_cut);
+				return;
+			}
+			p_cut = &t_cut;
+		}
 		// split into connected components first (iteratively, flat storage: the landmark part
 		// of a BA system has 500k single-vertex components), then order each one
 		std::vector<int32_t> queue, comp_verts;
@@ -113,7 +123,7 @@ private:
 				continue; // already in an earlier component
 			BFS(S[s], id, queue);
 			if(queue.size() == S.size()) {
-				Order_Connected(S, id, n_out, n_depth, queue); // the whole subset is one component
+				Order_Connected(S, id, n_out, n_depth, queue, p_cut); // the whole subset is one component
 				return;
 			}
 			comp_verts.insert(comp_verts.end(), queue.begin(), queue.end());
@@ -140,6 +150,113 @@ private:
 		}
 	}
 
+	// A cut by vertex number, tried before any traversal (round 4: the ordering was the largest part of C3's first call --
+	// four to five breadth-first passes per level of the recursion, and at the top levels of a chain-like graph a frontier
+	// is one to three vertices: nothing for threads to share).  The vertices of a pose graph are numbered along the
+	// trajectory: the vertices below some number against those above it are a cut, and where few edges cross it -- the
+	// odometry edge and the loop closures that span it -- the lower endpoints of those edges are a separator.  Every
+	// position of the middle third is priced in one pass over the subset's edges (no dependence between vertices) and
+	// the narrowest taken, the one nearest the middle among equals.  It also turned out the better ordering, not only
+	// the cheaper one: level structures from a peripheral vertex of a chain with loop closures give lopsided halves
+	// (C3: elimination tree 30 -> 20 levels, 10 -> 8 stages, 0.373 -> 0.333 ms a solve; a chain with a loop closure every
+	// ten poses: 804 -> 301 Mflop).  Taken only if it is narrow (max_sep vertices): a graph whose numbering says nothing
+	// about its shape (a grid numbered row by row: the cut is a whole row) falls through to the level structures; and
+	// below n_small vertices a cut of three or four only stands if it is narrower than what the level structure finds (the
+	// reduced camera system of the band-visibility BA leg: same width either way, but the cut by number left tasks of
+	// seven columns where the level structure leaves four, and its stages took 6 % longer).
+	struct TIndexCut {
+		size_t n_half; // position of the first vertex of the upper part
+		int32_t n_sep; // vertices of the lower part with a neighbour in the upper part
+	};
+
+	bool Find_Index_Cut(const std::vector<int32_t> &S, int32_t id, TIndexCut &r_cut)
+	{
+		static const int min_size = getenv("ND_MIN")? atoi(getenv("ND_MIN")) : 64, max_sep = getenv("ND_SEP")? atoi(getenv("ND_SEP")) : 4; // (development knobs)
+		const size_t n_size = S.size();
+		if(n_size < size_t(min_size) || n_size <= size_t(m_leaf) * 4 || !std::is_sorted(S.begin(), S.end()))
+			return false;
+		// how many vertices below position p have a neighbour at or above it, for every p of the middle third: a vertex at
+		// position k whose highest neighbour sits at position r counts for p in (k, r] -- a difference array.  m_level is
+		// free here (all -1): it holds the positions for the pass
+		for(size_t k = 0; k < n_size; ++ k)
+			m_level[S[k]] = int32_t(k);
+		const size_t n_lo = n_size * 35 / 100, n_hi = n_size - n_lo; // candidates: n_lo < p <= n_hi
+		std::vector<int32_t> diff(n_size + 2, 0);
+		for(size_t k = 0; k < n_hi; ++ k) {
+			const int32_t v = S[k];
+			int32_t r = -1;
+			for(int64_t e = m_ptr[v]; e < m_ptr[v + 1]; ++ e) {
+				const int32_t w = m_adj[e];
+				if(w > v && m_set[w] == id)
+					r = std::max(r, m_level[w]);
+			}
+			if(r > int32_t(k)) {
+				++ diff[k + 1];
+				-- diff[size_t(r) + 1];
+			}
+		}
+		for(size_t k = 0; k < n_size; ++ k)
+			m_level[S[k]] = -1;
+		size_t n_half = 0;
+		int32_t n_best = INT32_MAX, n_run = 0;
+		for(size_t p_ = 1; p_ <= n_hi; ++ p_) {
+			n_run += diff[p_];
+			if(p_ > n_lo) {
+				const size_t n_off = (p_ > n_size / 2)? p_ - n_size / 2 : n_size / 2 - p_;
+				const size_t n_best_off = (n_half > n_size / 2)? n_half - n_size / 2 : n_size / 2 - n_half;
+				if(n_run < n_best || (n_run == n_best && n_off < n_best_off)) {
+					n_best = n_run;
+					n_half = p_;
+				}
+			}
+		}
+		if(n_best > max_sep || n_best <= 0)
+			return false; // too wide for a cut found without looking at the graph's shape -- or no edge at all across it (two
+			// components, or more: the traversal sorts them out)
+		r_cut.n_half = n_half;
+		r_cut.n_sep = n_best;
+		return true;
+	}
+
+	void Apply_Index_Cut(std::vector<int32_t> &S, int32_t id, size_t n_out, int n_depth, const TIndexCut &r_cut)
+	{
+		const size_t n_half = r_cut.n_half;
+		const int32_t n_mid = S[n_half]; // lower: numbers below n_mid
+		std::vector<int32_t> sep;
+		for(size_t k = 0; k < n_half; ++ k) {
+			const int32_t v = S[k];
+			for(int64_t e = m_ptr[v]; e < m_ptr[v + 1]; ++ e) {
+				const int32_t w = m_adj[e];
+				if(w >= n_mid && m_set[w] == id) {
+					sep.push_back(v);
+					break;
+				}
+			}
+		}
+		std::vector<int32_t> lower, upper(S.begin() + n_half, S.end());
+		lower.reserve(n_half);
+		for(size_t k = 0, q = 0; k < n_half; ++ k) {
+			if(q < sep.size() && sep[q] == S[k])
+				++ q;
+			else
+				lower.push_back(S[k]);
+		}
+		{
+			std::vector<int32_t> empty;
+			S.swap(empty);
+		}
+		const size_t n_lower = lower.size(), n_upper = upper.size();
+		std::copy(sep.begin(), sep.end(), m_out.begin() + n_out + n_lower + n_upper);
+		if(n_depth < parallel_max_depth && std::min(n_lower, n_upper) >= size_t(parallel_min_size)) {
+			std::thread other([&]() { Order(upper, n_out + n_lower, n_depth + 1); });
+			Order(lower, n_out, n_depth + 1);
+			other.join();
+		} else {
+			Order(lower, n_out, n_depth + 1);
+			Order(upper, n_out + n_lower, n_depth + 1);
+		}
+	}
+
 	// Cuthill-McKee-like order of a small connected subset
 	void Order_Leaf(const std::vector<int32_t> &S, int32_t id, size_t n_out, std::vector<int32_t> &r_queue)
 	{
@@ -152,7 +269,8 @@ private:
 	}
 
 	// r_queue: scratch; on entry it holds a BFS of S (levels set) from an arbitrary root
-	void Order_Connected(std::vector<int32_t> &S, int32_t id, size_t n_out, int n_depth, std::vector<int32_t> &r_queue)
+	void Order_Connected(std::vector<int32_t> &S, int32_t id, size_t n_out, int n_depth, std::vector<int32_t> &r_queue,
+		const TIndexCut *p_cut = 0)
 	{
 		if(S.size() <= size_t(m_leaf)) {
 			Order_Leaf(S, id, n_out, r_queue);
@@ -179,6 +297,11 @@ private:
 			n_levels = n_new;
 		}
 		if(n_levels < 3) { // clique-like: no level separates anything
+			if(p_cut) {
+				Reset_Levels(S);
+				Apply_Index_Cut(S, id, n_out, n_depth, *p_cut);
+				return;
+			}
 			std::copy(r_queue.begin(), r_queue.end(), m_out.begin() + n_out);
 			return;
 		}
@@ -233,6 +356,11 @@ private:
 				}
 				(b_sep? sep : lower).push_back(v);
 			}
+		}
+		if(p_cut && int32_t(sep.size()) > p_cut->n_sep) { // the cut by number is narrower
+			Reset_Levels(S);
+			Apply_Index_Cut(S, id, n_out, n_depth, *p_cut);
+			return;
 		}
 		{
 			std::vector<int32_t> empty;
@@ -504,6 +632,8 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 		}
 	}
 
+	if(getenv("SLAMPP_HIP_PLAN_TIMING"))
+		fprintf(stderr, "[plan] graph          %6.2f ms\n", now_ms() - t0);
 	// ---- ordering ----
 	if(opt.natural_order) {
 		P.perm.resize(n);

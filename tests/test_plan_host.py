@@ -104,9 +104,9 @@ def test_structure_errors_are_reported():
 
 @pytest.mark.parametrize("make", [
     lambda: synth.pose_chain(n=5000, d=6, seed=21),
-    lambda: synth.pose_chain(n=3000, d=3, seed=25),
+    lambda: synth.pose_chain(n=5000, d=3, seed=25, loop_every=10),
     lambda: synth.manhattan(2000, seed=23),
-], ids=["chain5000", "chain3000_se2", "manhattan2000"])
+], ids=["chain5000", "chain5000_se2_loops", "manhattan2000"])
 def test_top_of_the_tree_as_one_task(make, monkeypatch):
     """Round 4 (PlanOptions::task_top_cols / task_top_blocks, what the solver sets with option panel_top): as many of the
     last stages as fit the capacities together become ONE task -- fewer stages, the same columns, and a schedule the CPU
@@ -125,4 +125,19 @@ def test_top_of_the_tree_as_one_task(make, monkeypatch):
     n_top = len(plan1["task_cols"][last])
     assert 8 < n_top <= 48                                                         # ... bigger than a slice, within the capacity
     status, x = O.exec_plan(lam, plan1)
+    assert ok and status == 0 and rel_inf(x, x_ref) < TOL
+
+
+@pytest.mark.parametrize("n,every", [(10000, 50), (20000, 50), (8000, 10)])
+def test_pose_chains_are_cut_by_vertex_number(n, every):
+    """Round 4: where few edges cross "the vertices below some number", that cut is the bisection (plan.cpp,
+    Find_Index_Cut): no traversal at the top levels of the recursion, and halves as even as the numbering allows --
+    level structures from a peripheral vertex left the elimination tree of a 10k-pose chain 26 levels deep, 7 stages.
+    The plan must replay to the reference's solution like any other."""
+    lam = synth.pose_chain(n=n, d=6, seed=31, loop_every=every)
+    plan, st = host_plan(lam, dense_top_nb=0)
+    check_plan_invariants(lam, plan)
+    assert st["etree_height"] <= (1.6 if every == 50 else 3.2) * np.log2(n)
+    ok, x_ref, _ = O.solve_sparse(lam)
+    status, x = O.exec_plan(lam, plan)
     assert ok and status == 0 and rel_inf(x, x_ref) < TOL
