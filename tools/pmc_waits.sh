@@ -2,6 +2,8 @@
 # dev helper: where the waves of a BA leg's kernels wait (SQ counters, one rocprofv3 --pmc pass per set; no tracing)
 R=$PWD
 MODE=${1:-venice}
+CMD="python3 $R/tools/time_ba.py 1000 500000 $MODE"
+if [ "$MODE" = "c3" ]; then CMD="python3 $R/tools/time_c3.py"; fi
 OUT=$R/gpurun_out/pmc_waits
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -11,7 +13,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE
            "SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU SQ_WAVES"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $SET --output-format csv -d $OUT/p$i -- python3 $R/tools/time_ba.py 1000 500000 $MODE > $OUT/p$i.txt 2>&1
+  timeout 600 rocprofv3 --pmc $SET --output-format csv -d $OUT/p$i -- $CMD > $OUT/p$i.txt 2>&1
 done
 cd $R
 python3 - <<'PY'
