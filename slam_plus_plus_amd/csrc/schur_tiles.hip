@@ -708,16 +708,36 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 	std::vector<int32_t> run_lm, run_k;
 	int64_t n_run_pairs = 0;
 	if(b_use_runs) {
-		std::vector<uint64_t> hash(np);
-		for(int64_t pt = 0; pt < np; ++ pt) {
-			const int64_t k0 = ptr[nc + pt], k = ptr[nc + pt + 1] - k0 - 1;
-			uint64_t h = 0x9E3779B97F4A7C15ull * uint64_t(k + 1);
-			for(int64_t i = 0; i < k; ++ i) {
-				h ^= uint64_t(brow[k0 + i]) + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-				h *= 0xFF51AFD7ED558CCDull;
+		// (the passes over the landmarks that do not depend on each other run on a few threads: at C5's two million landmarks
+		// telling the classes apart was 98 ms of a 250 ms analysis on one core, a cache miss per list)
+		auto For_Landmark_Ranges = [np](int64_t n_begin, const std::function<void(int64_t, int64_t)> &r_work) {
+			const int64_t n = np - n_begin;
+			const int n_workers = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, std::max(1u, std::thread::hardware_concurrency())), n / 65536)));
+			std::vector<std::thread> threads;
+			for(int t = 0; t < n_workers; ++ t) {
+				const int64_t n_first = n_begin + n * t / n_workers, n_last = n_begin + n * (t + 1) / n_workers;
+				if(t + 1 < n_workers)
+					threads.emplace_back(r_work, n_first, n_last);
+				else
+					r_work(n_first, n_last);
 			}
-			hash[pt] = h;
-		}
+			for(size_t t = 0; t < threads.size(); ++ t)
+				threads[t].join();
+		};
+		std::vector<uint64_t> hash(np);
+		std::vector<int32_t> k_of(np); // observations per landmark (8 MB that stay in the caches better than two reads of ptr[] per use)
+		For_Landmark_Ranges(0, [&](int64_t n_first, int64_t n_last) {
+			for(int64_t pt = n_first; pt < n_last; ++ pt) {
+				const int64_t k0 = ptr[nc + pt], k = ptr[nc + pt + 1] - k0 - 1;
+				k_of[pt] = int32_t(k);
+				uint64_t h = 0x9E3779B97F4A7C15ull * uint64_t(k + 1);
+				for(int64_t i = 0; i < k; ++ i) {
+					h ^= uint64_t(brow[k0 + i]) + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+					h *= 0xFF51AFD7ED558CCDull;
+				}
+				hash[pt] = h;
+			}
+		});
 		BUILD_PHASE("hashes");
 		std::vector<int32_t> order(np), tmp(np);
 		for(int64_t i = 0; i < np; ++ i)
@@ -755,7 +775,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 			// (pieces of 32 where a job keeps ten or sixteen accumulator tiles -- nine cameras and up at 6 x 6 --: those jobs are
 			// the long ones, and more of them spread better: 164 + 123 -> 130 + 103 us for the two widest kernels of the
 			// Venice-like C4, for 18 us more in the reduction of the partial blocks)
-			const int64_t k_run = ptr[nc + p_members[0] + 1] - ptr[nc + p_members[0]] - 1;
+			const int64_t k_run = k_of[p_members[0]];
 			const int64_t n_piece_len = (std::min<int64_t>(k_run, OB) * DC > 48 && !getenv("SLAMPP_RUN_PIECE"))? 32 : n_piece_max;
 			for(int64_t f = 0; f < n_members; f += n_piece_len) {
 				const int64_t n_piece = std::min<int64_t>(n_piece_len, n_members - f);
@@ -766,7 +786,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 				for(int64_t e = f; e < f + n_piece; ++ e) {
 					const int32_t pt = p_members[e];
 					run_lm.push_back(pt);
-					run_k.push_back(int32_t(ptr[nc + pt + 1] - ptr[nc + pt] - 1));
+					run_k.push_back(k_of[pt]);
 					handled[pt] = 1;
 					n_run_pairs += int64_t(run_k.back()) * (run_k.back() + 1) / 2;
 				}
@@ -804,9 +824,16 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 		// where the matrix-core tiles of a job would grow (16 lines a tile): a landmark of two cameras does not pay for ten.
 		struct TClass { int64_t n_first, n_count; };
 		std::vector<TClass> classes;
+		std::vector<uint8_t> same_as_previous(np, 0); // order[i] is seen by the cameras of order[i - 1]
+		For_Landmark_Ranges(1, [&](int64_t n_first, int64_t n_last) {
+			for(int64_t i = n_first; i < n_last; ++ i)
+				same_as_previous[i] = hash[order[i]] == hash[order[i - 1]] && Same(order[i - 1], order[i]);
+		});
+		run_lm.reserve(np);
+		run_k.reserve(np);
 		for(int64_t i = 0; i < np;) {
 			int64_t j = i + 1;
-			while(j < np && hash[order[j]] == hash[order[i]] && Same(order[i], order[j]))
+			while(j < np && same_as_previous[j])
 				++ j;
 			if(ptr[nc + order[i] + 1] - ptr[nc + order[i]] - 1 >= 1)
 				classes.push_back(TClass{i, j - i});
