@@ -11,7 +11,8 @@ npts = int(sys.argv[2]) if len(sys.argv) > 2 else 500000
 mode = sys.argv[3] if len(sys.argv) > 3 else "band"
 t0 = time.perf_counter(); lam = synth.ba(nc, npts, k=4, mode=mode); print("gen %.1fs" % (time.perf_counter() - t0), flush=True)
 dev = torch.device("cuda:0")
-s = CLinearSolver_Schur_HIP(schur_sparse=int(os.environ.get("SCHUR_SPARSE", "-1")), schur_tiles=int(os.environ.get("SCHUR_TILES", "-1")))  # 0 forces the dense reduced system
+extra = {a.split("=")[0]: int(a.split("=")[1]) for a in os.environ.get("SOLVER_OPTS", "").split(",") if a}  # e.g. SOLVER_OPTS=subtree_size=16
+s = CLinearSolver_Schur_HIP(schur_sparse=int(os.environ.get("SCHUR_SPARSE", "-1")), schur_tiles=int(os.environ.get("SCHUR_TILES", "-1")), **extra)  # 0 forces the dense reduced system
 t0 = time.perf_counter(); s.SymbolicDecomposition_Blocky(lam); print("analyze %.1f ms" % ((time.perf_counter() - t0) * 1e3), s.stats(), flush=True)
 vals = torch.from_numpy(lam.values).to(dev)
 reps = 5
