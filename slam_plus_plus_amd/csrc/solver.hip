@@ -4,6 +4,7 @@
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
+#include <pthread.h>
 #include "solver.h"
 #include "sparse_inverse.h"
 
@@ -235,7 +236,20 @@ class CCopyPool {
 public:
 	static CCopyPool &r_Get()
 	{
-		static CCopyPool *p_pool = new CCopyPool(); // (leaked on purpose: no destructor runs against sleeping threads at exit)
+		// (leaked on purpose: no destructor runs against sleeping threads at exit.  A child of fork() inherits the object but
+		// none of its threads -- a job given to them would never run --: the child starts with no pool and makes its own)
+		static std::mutex t_make;
+		static const int n_registered = pthread_atfork(0, 0, []() { p_Instance().store(0); });
+		(void)n_registered;
+		CCopyPool *p_pool = p_Instance().load(std::memory_order_acquire);
+		if(!p_pool) {
+			std::lock_guard<std::mutex> lock(t_make);
+			p_pool = p_Instance().load(std::memory_order_acquire);
+			if(!p_pool) {
+				p_pool = new CCopyPool();
+				p_Instance().store(p_pool, std::memory_order_release);
+			}
+		}
 		return *p_pool;
 	}
 	int n_Threads() const { return m_n_threads; }
@@ -260,6 +274,11 @@ public:
 		m_b_taken.store(false, std::memory_order_release);
 	}
 private:
+	static std::atomic<CCopyPool*> &p_Instance()
+	{
+		static std::atomic<CCopyPool*> p_instance(0);
+		return p_instance;
+	}
 	CCopyPool()
 	{
 		const unsigned n_hw = std::thread::hardware_concurrency();
