@@ -7,7 +7,7 @@ from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 lam = synth.pose_chain(n=n)
 dev = torch.device("cuda:0")
-s = CLinearSolver_HIP()
+s = CLinearSolver_HIP(**{a.split("=")[0]: int(a.split("=")[1]) for a in os.environ.get("SOLVER_OPTS", "").split(",") if a})  # e.g. SOLVER_OPTS=simt_width=16
 s.SymbolicDecomposition_Blocky(lam)
 vals = torch.from_numpy(lam.values).to(dev)
 reps = 20
