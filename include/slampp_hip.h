@@ -200,7 +200,7 @@ int slampp_hip_factor_solve(slampp_hip_solver *p_solver, const double *p_values,
  * *pp_values receives room for the packed values, *pp_rhs for the right-hand side / solution (either may be NULL).
  * Passing exactly these pointers to slampp_hip_factor_solve / _factorize / _marginals / _schur_marginals /
  * _solve_marginal_poses makes the transfers single DMA copies without a staging pass; any other host array is moved
- * through the same staging in 32 MB chunks by a few host threads while the previous chunk is on the bus.  Valid until
+ * through the same staging in chunks (1 MB first, doubling up to 32 MB) by a few host threads while the previous chunk is on the bus.  Valid until
  * the next slampp_hip_set_structure / _free_memory / _destroy (call again after set_structure). */
 int slampp_hip_host_staging(slampp_hip_solver *p_solver, double **pp_values, double **pp_rhs);
 
