@@ -208,19 +208,20 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 	TPanelLaunch t_cfg, const TUpdSlot *__restrict__ upd_slots, int n_upd_slots, const TUpdEnt *__restrict__ upd_ents, const double *__restrict__ A,
 	const double *__restrict__ b, double *L, double *Linv, double *w, double *H, int *p_flag, long long *p_timing)
 {
-	enum { DD = D * D, BATCH = panel_fresh_batch(W), UPD_BATCH = PANEL_UPD_BATCH, N_UPD_GROUPS = W / PANEL_UPD_W };
+	enum { DD = D * D, BATCH = panel_fresh_batch(W), UPD_BATCH = PANEL_UPD_BATCH, UPD_W = (W < int(PANEL_UPD_W))? W : int(PANEL_UPD_W), // (two waves per task: two per update block)
+		N_UPD_GROUPS = W / UPD_W };
 	extern __shared__ __attribute__((aligned(16))) double s_raw[];
 	const TPanelLds t_lds = panel_lds(D, b_fused, t_cfg);
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 	if(b_fused && int(blockIdx.x) >= n_panels) {
 		// update role: the blocks of the next stage's panel tasks, one per group of PANEL_UPD_W waves
-		const int n_group = wave / PANEL_UPD_W, n_sub = wave % PANEL_UPD_W;
+		const int n_group = wave / UPD_W, n_sub = wave % UPD_W;
 		const int n_slot = N_UPD_GROUPS * (int(blockIdx.x) - n_panels) + n_group;
 		const bool b_valid = n_slot < n_upd_slots;
 		const TUpdSlot sl = upd_slots[b_valid? n_slot : n_upd_slots - 1];
-		panel_update_block<D, UPD_BATCH>(sl, b_valid, upd_ents, A, L, b, w, n_sub, PANEL_UPD_W, lane,
+		panel_update_block<D, UPD_BATCH>(sl, b_valid, upd_ents, A, L, b, w, n_sub, UPD_W, lane,
 			s_raw + wave * 2 * UPD_BATCH * DD, s_raw + W * 2 * UPD_BATCH * DD + wave * UPD_BATCH * 8,
-			s_raw + W * 2 * UPD_BATCH * DD + W * UPD_BATCH * 8 + n_group * PANEL_UPD_W * 64);
+			s_raw + W * 2 * UPD_BATCH * DD + W * UPD_BATCH * 8 + n_group * UPD_W * 64);
 		return;
 	}
 	longlong2 *s_pkg = reinterpret_cast<longlong2*>(s_raw);
@@ -529,7 +530,7 @@ bool launch_factor_panel(int n_dim, bool b_fused, bool b_rows, const TPanelLaunc
 {
 	if(!b_fused)
 		n_upd_slots = 0;
-	const int W = r_cfg.n_waves, n_groups = W / PANEL_UPD_W;
+	const int W = r_cfg.n_waves, n_groups = W / std::min(W, int(PANEL_UPD_W)); // (two waves per task: two waves per update block as well)
 	const int n_grid = n_tasks + (n_upd_slots + n_groups - 1) / n_groups;
 	if(n_grid <= 0)
 		return true;
@@ -545,7 +546,8 @@ bool launch_factor_panel(int n_dim, bool b_fused, bool b_rows, const TPanelLaunc
 			upd_slots, n_upd_slots, upd_ents, A, b, L, Linv, w, H, p_flag, p_timing); } while(0)
 #define LAUNCH_PANEL_F(D, WW, F) do { if(b_rows) LAUNCH_PANEL_INSTANCE(D, WW, F, true); else LAUNCH_PANEL_INSTANCE(D, WW, F, false); } while(0)
 #define LAUNCH_PANEL(D) do { \
-		if(W == 4) { if(b_fused) LAUNCH_PANEL_F(D, 4, true); else LAUNCH_PANEL_F(D, 4, false); } \
+		if(W == 2) { if(b_fused) LAUNCH_PANEL_F(D, 2, true); else LAUNCH_PANEL_F(D, 2, false); } \
+		else if(W == 4) { if(b_fused) LAUNCH_PANEL_F(D, 4, true); else LAUNCH_PANEL_F(D, 4, false); } \
 		else { if(b_fused) LAUNCH_PANEL_F(D, 8, true); else LAUNCH_PANEL_F(D, 8, false); } } while(0)
 	switch(n_dim) {
 	case 3:

@@ -889,9 +889,14 @@ void slampp_hip_solver::Analyze_Sparse()
 			// and only if what is then left to the tasks themselves -- the updates from the stage right below -- is little:
 			// a task brings those in with its own eight waves, on the stage's critical path (a launch saved is about 4 us)
 			// Waves per task: eight where the stage is a launch on the critical path, four where it holds more tasks than the
-			// chip takes at once (more workgroups per CU: throughput).
-			static const int n_w4_min_tasks = getenv("SLAMPP_PANEL_W4_MIN")? atoi(getenv("SLAMPP_PANEL_W4_MIN")) : 512; // development knob
-			const int n_stage_waves = (b_panel_stage && P.stage_ptr[s + 1] - P.stage_ptr[s] > n_w4_min_tasks)? 4 : int(PANEL_W);
+			// chip takes at once (more workgroups per CU: throughput), two where it holds them several times over.
+			// (round 4: two where it holds them several times over -- C3's 2 151-task launch 91 -> 78 us, the step 0.330 -> 0.318 ms;
+			// a million poses 2.185 -> 2.146; one wave per task is slower again, 169 against 147 us for C3's slice launches, and two
+			// waves for the 303-task launch as well 153: the development knobs below moved the lines)
+			static const int n_w4_min_tasks = getenv("SLAMPP_PANEL_W4_MIN")? atoi(getenv("SLAMPP_PANEL_W4_MIN")) : 512;
+			static const int n_w2_min_tasks = getenv("SLAMPP_PANEL_W2_MIN")? atoi(getenv("SLAMPP_PANEL_W2_MIN")) : 1024;
+			const int n_stage_waves = (b_panel_stage && P.stage_ptr[s + 1] - P.stage_ptr[s] > n_w2_min_tasks)? 2 :
+				(b_panel_stage && P.stage_ptr[s + 1] - P.stage_ptr[s] > n_w4_min_tasks)? 4 : int(PANEL_W);
 			// hand-ups from the stage below (development knob SLAMPP_HANDUP_MAX_TASKS: only from stages of at most that many tasks --
 			// a stage that fills the chip several times over is bound by throughput, and what its tasks compute for the stage
 			// above they compute instead of the next task's columns: C3's 2 420-task launch 70 -> 92 us; the stage above gains more)
