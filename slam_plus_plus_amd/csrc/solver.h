@@ -169,7 +169,7 @@ struct slampp_hip_solver {
 	// inv(L_jj) of the columns the lane-per-task kernel factors is not on the solve's path any more (its backward kernel solves with
 	// L_jj^T): stored only once something has asked for it (another right-hand side, covariances) -- from then on always
 	bool b_leaf_linv_wanted = false, b_leaf_linv_valid = true;
-	int n_simt_backward = 0; // option "simt_backward": 1 = the leaf subtrees' backward substitution a lane per task as well and no inv(L_jj) stored for them (round 4: measured slower, 97 against 90 us at C3); 0 = a wave per task
+	int n_simt_backward = -1; // option "simt_backward": 1 = the leaf subtrees' backward substitution a lane per task as well and no inv(L_jj) stored for them; 0 = a wave per task; -1 (default) = by the number of leaf subtrees (round 4, after the new ordering: slower below ~12 000 of them, 1.6 % faster at C3, 7 % at a million poses)
 	void Ensure_Leaf_Inverses();
 	std::vector<int32_t> simt_chunk_ptr, simt_rest_ptr; // [n_bottom_stages + 1] each; empty = not in use
 	std::vector<int32_t> simt_lds_bytes; // per stage: the largest chunk table (it is staged in LDS)

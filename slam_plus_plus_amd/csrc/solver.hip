@@ -1570,7 +1570,10 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 		p_values_dev = d_refined.p();
 	}
 	// (the backward kernel of the lane-per-task stages writes x with 16-byte stores where the block dimension is even)
-	const bool b_simt_bwd = n_simt_backward && !simt_chunk_ptr.empty() && d_simt_bwd_chunks.p() &&
+	// (option simt_backward, -1 = by size: with the leaf subtrees of 20 000 poses the lane-per-task backward kernel costs 14 us of
+	// 179, at 100 000 -- 15 928 subtrees -- the step is 0.318 -> 0.313 ms, at 300 000 0.853 -> 0.805, at a million 2.11 -> 1.96)
+	const bool b_simt_backward_wanted = (n_simt_backward < 0)? P.stage_ptr.size() > 1 && P.stage_ptr[1] - P.stage_ptr[0] >= 12288 : n_simt_backward != 0;
+	const bool b_simt_bwd = b_simt_backward_wanted && !simt_chunk_ptr.empty() && d_simt_bwd_chunks.p() &&
 		(P.max_dim % 2 != 0 || (reinterpret_cast<uintptr_t>(p_rhs_dev) & 15) == 0);
 	if(b_factor)
 		b_leaf_linv_valid = true; // (every factor kernel but the lane-per-task one stores its inverses; that one answers below)
@@ -1622,7 +1625,7 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 				Phase_Begin("factor_upper");
 			if(b_simt && s + 1 < int(simt_chunk_ptr.size())) {
 				const int n_chunks = simt_chunk_ptr[s + 1] - simt_chunk_ptr[s], n_rest = simt_rest_ptr[s + 1] - simt_rest_ptr[s];
-				const bool b_store_linv = b_leaf_linv_wanted || !n_simt_backward; // (the wave-per-task backward kernel reads the inverses)
+				const bool b_store_linv = b_leaf_linv_wanted || !b_simt_backward_wanted; // (the wave-per-task backward kernel reads the inverses)
 				launch_factor_simt(d_simt_chunks.p() + simt_chunk_ptr[s], n_chunks, n_simt_width, simt_lds_bytes[s], d_simt_prog.p(), d_simt_tab.p(), P.max_dim,
 					p_values_dev, d_L.p(), b_store_linv? d_Linv.p() : 0, p_rhs_dev, d_w.p(), p_flag, stream, dplan.p_timing);
 				b_leaf_linv_valid = b_leaf_linv_valid && b_store_linv;
@@ -1996,7 +1999,7 @@ static int set_option_checked(slampp_hip_solver *p_solver, const char *p_s_name,
 	}
 	else if(s == "simt_stages" && n_value >= 0)
 		p_solver->n_simt_stages = int(n_value);
-	else if(s == "simt_backward" && n_value >= 0 && n_value <= 1) {
+	else if(s == "simt_backward" && n_value >= -1 && n_value <= 1) {
 		p_solver->n_simt_backward = int(n_value);
 		return SLAMPP_HIP_OK; // read at every solve
 	}

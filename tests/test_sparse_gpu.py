@@ -422,7 +422,7 @@ def test_panel_tasks_as_rows_agree_with_the_block_wise_walk(case):
 
 @pytest.mark.parametrize("d", [6, 3, 7])
 def test_lane_per_task_backward_substitution_and_lazy_inverses(d):
-    """Option simt_backward = 1 (round 4; not the default: measured slower): the leaf subtrees' backward substitution by
+    """Option simt_backward = 1 (round 4; the default from ~12 000 leaf subtrees on): the leaf subtrees' backward substitution by
     backward_simt_kernel, which solves with L_jj^T itself, and a factorization that no longer stores inv(L_jj) for those columns
     -- until something asks for them: another right-hand side with the kept factor (the forward kernel multiplies by the
     inverses) and the covariances get them from a fix-up pass, and every later factorization stores them again."""
