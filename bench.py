@@ -288,9 +288,9 @@ def run_c3(args, rank, world, local_rank, dist):
                 "forward": n_stages, "backward": n_stages}
     names = {"factor_leaves": "factor_simt_kernel", "factor_wide": "factor_stage_kernel<D, 1, 8, 32, 48>",
              "factor_upper": "factor_panel_kernel (slices of the elimination tree, one launch per stage)", "forward": "forward_stage_kernel",
-             "backward": "backward_stage_kernel"}
+             "backward": "backward_stage_kernel (+ backward_simt_kernel for the leaf subtrees where there are many)"}
     needles = {"factor_leaves": "factor_simt_kernel", "factor_wide": ", 1, 8, 32, 48>", "factor_upper": "factor_panel_kernel",
-               "forward": "forward_stage_kernel", "backward": "backward_stage_kernel"}   # as rocprofv3 spells the kernels
+               "forward": "forward_stage_kernel", "backward": "::backward_s"}   # as rocprofv3 spells the kernels (backward_stage_ / backward_simt_)
     traffic, traffic_file = load_traffic("c3")
     kernels = []
     for ph, (cnt, tot_ms) in prof.items():
