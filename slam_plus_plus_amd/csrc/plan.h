@@ -62,11 +62,14 @@ struct PlanOptions {
 	int nd_balance_pct = 15;  // a separator must leave at least this share (percent) of the vertices on either side; small
 	                          // separators beat balanced halves here: 15 is 5-15 % faster than 25 on pose chains of 30k-300k poses
 	int subtree_size = 8;     // a subtree of at most this many columns is one sequential task (8: best from 2k to 100k poses)
-	int task_height = 4;      // separator tasks above the leaf subtrees: 1 = maximal chains of single children (one tree level
+	int task_height = 6;      // separator tasks above the leaf subtrees: 1 = maximal chains of single children (one tree level
 	                          // per stage), 2 .. 8 = slices of the elimination tree up to that many levels high (a stage, i.e. a
 	                          // launch, then covers that many levels: the launches of a chain-like graph are its critical path;
-	                          // C3: 3 / 4 / 5 / 6 levels 0.374 / 0.366 / 0.366 / 0.373 ms -- a slice is cut at the panel kernel's
-	                          // capacities anyway, so more than four levels are chains of single columns)
+	                          // round 3, C3: 3 / 4 / 5 / 6 levels 0.374 / 0.366 / 0.366 / 0.373 ms; re-measured at the end of round 4
+	                          // -- block columns as rows, hand-ups, the balanced tree of the cut by vertex number --: 3 / 4 / 5 / 6 / 8
+	                          // 0.316 / 0.314 / 0.307 / 0.306 / 0.307 ms, the reduced camera system of the band leg 213 / 206 / 198 us at
+	                          // 4 / 5 / 6, C5's 242 / 235 / 235; a slice is cut at the panel kernel's capacities anyway -- 8 columns,
+	                          // 96 blocks: 10 / 96 and 12 / 128 leave the panel path, 6 / 64 is 7 % slower at C3)
 	int task_wide_min = 1024; // ... above the wide stages: a stage with more tasks than this stays one level high (throughput, not latency)
 	int task_max_cols = 8, task_max_blocks = 96; // what such a slice may hold (the panel kernel's capacities)
 	int task_top_cols = 0, task_top_blocks = 0;  // > 0: the stages at the top of the tree that fit these together become ONE task (a launch saved per

@@ -10,13 +10,14 @@ dev = torch.device("cuda:0")
 
 
 OPTION = os.environ.get("AB_OPTION", "panel_rows")
+VALUES = [int(v) for v in os.environ.get("AB_VALUES", "0,1,0,1").split(",")]  # e.g. AB_OPTION=task_height AB_VALUES=4,5,6,4,5,6
 
 
 def run(name, lam, cls, reps=20):
     vals = torch.from_numpy(lam.values).to(dev)
     out = {}
     solvers = {}
-    for rows in (0, 1, 0, 1):
+    for rows in VALUES:
         if rows not in solvers:
             solvers[rows] = cls(**{OPTION: rows})
             solvers[rows].SymbolicDecomposition_Blocky(lam)
