@@ -128,7 +128,7 @@ int slampp_hip_free_memory(slampp_hip_solver *p_solver);
 const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
 
 /* tuning knobs: "natural_order" (0/1: keep the caller's block order instead of nested dissection, default 0),
- * "leaf_size" (nested-dissection leaf, default 4), "nd_balance" (percent of the vertices a separator
+ * "leaf_size" (nested-dissection leaf, default 3), "nd_balance" (percent of the vertices a separator
  * must leave on either side, default 15), "subtree_size" (max columns one
  * wave eliminates sequentially, default 8), "task_height" (1 .. 8, default 6: above the wide stages a separator task is
  * a slice of the elimination tree this many levels high -- a launch then covers that many levels of the tree, the levels of

@@ -58,7 +58,7 @@ struct Plan {
 struct PlanOptions {
 	bool natural_order = false; // no fill-reducing ordering: the caller's order is kept (Factorize_PosDef_Blocky: the factor
 	                            // goes back to a caller that has ordered the matrix itself)
-	int leaf_size = 4;        // nested dissection stops at subgraphs of this many block columns
+	int leaf_size = 3;        // nested dissection stops at subgraphs of this many block columns (round 4: 4 -> 3, C3 0.306 -> 0.302 ms, C1 0.673 -> 0.668; 2 measures the same)
 	int nd_balance_pct = 15;  // a separator must leave at least this share (percent) of the vertices on either side; small
 	                          // separators beat balanced halves here: 15 is 5-15 % faster than 25 on pose chains of 30k-300k poses
 	int subtree_size = 8;     // a subtree of at most this many columns is one sequential task (8: best from 2k to 100k poses)
