@@ -61,6 +61,10 @@ struct PlanOptions {
 	int leaf_size = 3;        // nested dissection stops at subgraphs of this many block columns (round 4: 4 -> 3, C3 0.306 -> 0.302 ms, C1 0.673 -> 0.668; 2 measures the same)
 	int nd_balance_pct = 15;  // a separator must leave at least this share (percent) of the vertices on either side; small
 	                          // separators beat balanced halves here: 15 is 5-15 % faster than 25 on pose chains of 30k-300k poses
+	int nd_other_bank = 0;    // 1: where a level structure cuts, the separator is the narrower of the cut's two banks (the vertices of level
+	                          // m with a neighbour in level m + 1, or those of level m + 1 with a neighbour in level m) instead of always
+	                          // the first; a candidate of the plan search where there is a dense top (round 4: the Venice-like reduced
+	                          // camera system 1.12 -> 1.00 ms; C1 and C2 are better off without, and the chain model says so)
 	int subtree_size = 8;     // a subtree of at most this many columns is one sequential task (8: best from 2k to 100k poses)
 	int task_height = 6;      // separator tasks above the leaf subtrees: 1 = maximal chains of single children (one tree level
 	                          // per stage), 2 .. 8 = slices of the elimination tree up to that many levels high (a stage, i.e. a
@@ -101,6 +105,6 @@ std::string build_plan(int64_t n_bcols, const int64_t *bcol_cumsum, const int64_
 // fill-reducing, parallelism-exposing ordering of the block graph: nested dissection with
 // BFS level-structure separators; perm[new] = old
 void nested_dissection(int32_t n, const std::vector<int64_t> &adj_ptr, const std::vector<int32_t> &adj,
-	int leaf_size, std::vector<int32_t> &perm, int n_balance_pct = 15);
+	int leaf_size, std::vector<int32_t> &perm, int n_balance_pct = 15, bool b_other_bank = false);
 
 } // namespace slampp
