@@ -170,7 +170,15 @@ const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
  * run one wave per single-column task; below that, tasks are slices of the elimination tree, option "task_height"),
  * "marginals_dense" (Schur mode: 1 = slampp_hip_schur_marginals always inverts the reduced system densely; 0 (default) =
  * when the solves factor it by the sparse block path, the covariances take the blocks of S^-1 they need from a
- * sparse inverse subset on that factor's pattern) */
+ * sparse inverse subset on that factor's pattern),
+ * "panel_rows" (sparse path, -1 (default) / 0 / 1: a level of a separator task is walked block column by block column as
+ * rows -- lanes of a 16-lane row per matrix row --; -1 = where the blocks are 6 x 6 or larger),
+ * "panel_handup" (0 / 1, default 1: a separator task also computes what the next stage's tasks need from its blocks and
+ * hands it up in one buffer), "panel_top" (0 / 1, default 0: the last stages that fit one workgroup's LDS together as one
+ * task; measured slower), "simt" / "simt_width" / "simt_stages" (the lane-per-task kernels of the wide bottom stages),
+ * "simt_backward" (-1 (default) / 0 / 1: the leaf subtrees' backward substitution a lane per task as well, and no inv(L_jj)
+ * stored for them by the factorization -- whoever needs those later (another right-hand side, covariances) has them
+ * computed from the factor; -1 = from 12 288 leaf subtrees on) */
 int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int64_t n_value);
 
 /* structure of Lambda -- stands in for what the reference's wrappers read through
