@@ -123,8 +123,9 @@ struct TPanelLaunch {
 };
 enum { PANEL_UPD_BATCH = 8 };
 // fresh products a wave has in flight: four at eight waves per task, eight at four (the same operand staging per workgroup;
+// at two waves per task four again: the launch is crowded, and 4.6 KB less LDS per workgroup is a workgroup more per CU -- C3 141 -> 139 us;
 // the first slice stage above the leaves brings in ~100 products per task, each batch a trip to L2)
-inline __host__ __device__ constexpr int panel_fresh_batch(int n_waves) { return (n_waves <= 4)? 8 : 4; }
+inline __host__ __device__ constexpr int panel_fresh_batch(int n_waves) { return (n_waves == 4)? 8 : 4; }
 // LDS of a panel launch, in doubles: offsets of the panel role's regions (package, image, vectors, inverses of the
 // level's diagonal blocks, one tile per wave, operand staging of the fresh updates) and the total, which also covers
 // the update role's staging (riders: the next stage's updates from further down, PANEL_UPD_W waves per factor block)
