@@ -37,6 +37,9 @@
  *       robust weight at that linearization point.  <prefix>.lambda.bin (SPPLAM01, rhs = eta),
  *       <prefix>.edges.bin ("SPPASM01": int64 n_verts, n_edges, d, rd; int64 v0[], v1[]; double J0[], J1[]
  *       (rd x d column-major per edge), SigmaInv[] (rd x rd), err[] (rd), weight[]; unary factor d x d, unary error d)
+ *   ref_harness lambda_dump ba_lm <n_cams> <seed> <out_prefix> <n_points> <n_obs_per_point> <n_solve>
+ *       a BA scene in the reference's CVertexCam / CVertexXYZ / CEdgeP2C3D (oracle/ba_scene.h) under its
+ *       CNonlinearSolver_Lambda_LM, Schur complement off: the damped Lambda and eta of the n_solve-th linear solve
  *   ref_harness dump_mm <problem> <out.mtx> <out.bla>
  *       writes Lambda with the reference's Save_MatrixMarket / Save_BlockLayout, as its -dsm option does
  *   ref_harness load_mm <in.mtx> <in.bla> <problem>
@@ -71,7 +74,9 @@
 #include "slam/SE2_Types.h"
 #include "slam/SE3_Types.h"
 #include "slam/Timer.h"
+#include "slam/NonlinearSolver_Lambda_LM.h"
 #include <random>
+#include "ba_scene.h"
 
 struct TProblem {
 	int64_t n_bcols, n_blocks, n_scalars, n_values, n_matrix_cut;
@@ -487,6 +492,7 @@ struct TRecordedSystem {
 	std::vector<double> values, eta;
 };
 static TRecordedSystem g_recorded;
+static int g_n_record_skip = 0; // record the system of the (g_n_record_skip + 1)-th call
 
 class CLinearSolver_Recorder {
 public:
@@ -500,7 +506,7 @@ public:
 	void Free_Memory() { m_inner.Free_Memory(); }
 	bool Solve_PosDef(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta)
 	{
-		if(!g_recorded.b_have) {
+		if(!g_recorded.b_have && g_n_record_skip -- <= 0) {
 			TRecordedSystem &r = g_recorded;
 			const size_t n = r_lambda.n_BlockColumn_Num();
 			r.cumsum.assign(1, 0);
@@ -523,6 +529,46 @@ public:
 		return m_inner.Solve_PosDef(r_lambda, r_eta);
 	}
 };
+
+static bool Write_Recorded(const std::string &r_s_file, int64_t n_matrix_cut)
+{
+	FILE *f = fopen(r_s_file.c_str(), "wb");
+	if(!f) return false;
+	const TRecordedSystem &r = g_recorded;
+	int64_t hdr[8] = {int64_t(r.cumsum.size()) - 1, int64_t(r.brow.size()), r.cumsum.back(), int64_t(r.values.size()), n_matrix_cut, 0, 0, 0};
+	fwrite("SPPLAM01", 1, 8, f);
+	fwrite(hdr, 8, 8, f);
+	fwrite(&r.cumsum[0], 8, r.cumsum.size(), f);
+	fwrite(&r.bcol_ptr[0], 8, r.bcol_ptr.size(), f);
+	fwrite(&r.brow[0], 8, r.brow.size(), f);
+	fwrite(&r.values[0], 8, r.values.size(), f);
+	fwrite(&r.eta[0], 8, r.eta.size(), f);
+	fclose(f);
+	return true;
+}
+
+/* ref_harness lambda_dump ba_lm <n_cams> <seed> <out_prefix> <n_points> <n_obs_per_point> <n_solve>:
+ * the reference's CNonlinearSolver_Lambda_LM (include/slam/NonlinearSolver_Lambda_LM.h:1512-1700; Schur complement
+ * off, so its linear solver sees the whole damped Lambda) on a scene of CVertexCam / CVertexXYZ / CEdgeP2C3D; records
+ * the system of its n_solve-th linear solve (0 = the first: initial damping; later ones carry the damping LM has
+ * arrived at) with the cameras first, n_matrix_cut = n_cams */
+static int Lambda_Dump_BA_LM(size_t n_cams, size_t n_points, size_t n_obs_per_point, unsigned n_seed,
+	int n_solve, const std::string &r_s_prefix)
+{
+	TBASystem system;
+	CNonlinearSolver_Lambda_LM<TBASystem, CLinearSolver_Recorder> solver(system, TIncrementalSolveSetting(),
+		TMarginalsComputationPolicy(), false, CLinearSolver_Recorder(), false);
+	Build_BA_Scene(system, n_cams, n_points, n_obs_per_point, n_seed);
+	g_recorded.b_have = false;
+	g_n_record_skip = n_solve;
+	solver.Optimize(size_t(n_solve) + 1, 0);
+	if(!g_recorded.b_have || !Write_Recorded(r_s_prefix + ".lambda.bin", int64_t(n_cams)))
+		return 1;
+	printf("{\"ok\": true, \"n_verts\": %ld, \"n_edges\": %ld, \"n_blocks\": %ld, \"chi2\": %.9g}\n",
+		(long)system.r_Vertex_Pool().n_Size(), (long)system.r_Edge_Pool().n_Size(), (long)g_recorded.brow.size(),
+		solver.f_Chi_Squared_Error_Denorm());
+	return 0;
+}
 
 struct TEdgeDump {
 	std::vector<int64_t> v0, v1;
@@ -598,22 +644,8 @@ static int Lambda_Dump(size_t n_poses, unsigned n_seed, const std::string &r_s_p
 	system.r_Edge_Pool().For_Each(CDumpEdges<n_dim>(dump)); // at the initial linearization point
 	g_recorded.b_have = false;
 	solver.Optimize(1, 0); // one iteration: Lambda and eta of the initial point go to the recorder
-	if(!g_recorded.b_have)
+	if(!g_recorded.b_have || !Write_Recorded(r_s_prefix + ".lambda.bin", 0))
 		return 1;
-	{
-		FILE *f = fopen((r_s_prefix + ".lambda.bin").c_str(), "wb");
-		if(!f) return 1;
-		const TRecordedSystem &r = g_recorded;
-		int64_t hdr[8] = {int64_t(r.cumsum.size()) - 1, int64_t(r.brow.size()), r.cumsum.back(), int64_t(r.values.size()), 0, 0, 0, 0};
-		fwrite("SPPLAM01", 1, 8, f);
-		fwrite(hdr, 8, 8, f);
-		fwrite(&r.cumsum[0], 8, r.cumsum.size(), f);
-		fwrite(&r.bcol_ptr[0], 8, r.bcol_ptr.size(), f);
-		fwrite(&r.brow[0], 8, r.brow.size(), f);
-		fwrite(&r.values[0], 8, r.values.size(), f);
-		fwrite(&r.eta[0], 8, r.eta.size(), f);
-		fclose(f);
-	}
 	{
 		FILE *f = fopen((r_s_prefix + ".edges.bin").c_str(), "wb");
 		if(!f) return 1;
@@ -646,6 +678,10 @@ static int Main_LambdaDump(int argc, char **argv)
 	const std::string s_kind = argv[2];
 	const size_t n_poses = size_t(atol(argv[3]));
 	const unsigned n_seed = unsigned(atol(argv[4]));
+	if(s_kind == "ba_lm") {
+		if(argc < 9) return 2;
+		return Lambda_Dump_BA_LM(n_poses, size_t(atol(argv[6])), size_t(atol(argv[7])), n_seed, atoi(argv[8]), argv[5]);
+	}
 	if(s_kind == "se2") {
 		typedef CFlatSystem<CVertexPose2D, MakeTypelist(CVertexPose2D), CEdgePose2D, MakeTypelist(CEdgePose2D)> CSystemType;
 		return Lambda_Dump<CSystemType, CEdgePose2D, 3>(n_poses, n_seed, argv[5]);

@@ -120,12 +120,15 @@ def _segment_sum(idx: np.ndarray, blocks: np.ndarray, n: int) -> np.ndarray:
 
 
 def _assemble_pose_graph(n: int, d: int, ei: np.ndarray, ej: np.ndarray, rng, sigma: float,
-                         prior: float, name: str) -> BlockSystem:
-    """Lambda = sum over edges [Ja Jb]^T [Ja Jb] + prior*I on pose 0, eta ~ N(0,1).
+                         prior: float, name: str, info_decades: float = 0.0) -> BlockSystem:
+    """Lambda = sum over edges [Ja Jb]^T W [Ja Jb] + prior*I on pose 0, eta ~ N(0,1).
 
     Ja = I + sigma*G, Jb = -I + sigma*G are near-orthogonal relative-pose Jacobians,
     which keeps Lambda well conditioned (SURVEY.md section 7 'Conditioning vs the 1e-10 bar').
-    """
+    The conditioning sweep (tests/golden/make_golden.py, ``cond_*``) leaves that regime on purpose: a weak
+    ``prior`` (the gauge is then held by almost nothing), ``sigma`` up to 0.3 and, with ``info_decades`` = s > 0,
+    an information matrix W = diag(10^u), u ~ U(-s, s) per edge and residual row (translations against rotations,
+    odometry against loop closures: real pose graphs mix precisions over many decades).  W = I otherwise."""
     assert np.all(ei < ej)
     key = ei.astype(np.int64) * n + ej
     _, first = np.unique(key, return_index=True)      # drop duplicate edges, keep a stable order
@@ -135,9 +138,14 @@ def _assemble_pose_graph(n: int, d: int, ei: np.ndarray, ej: np.ndarray, rng, si
     eye = np.eye(d)
     Ja = eye[None] + sigma * rng.standard_normal((E, d, d))
     Jb = -eye[None] + sigma * rng.standard_normal((E, d, d))
-    Hii = np.einsum("eki,ekj->eij", Ja, Ja)
-    Hij = np.einsum("eki,ekj->eij", Ja, Jb)
-    Hjj = np.einsum("eki,ekj->eij", Jb, Jb)
+    if info_decades > 0:
+        w = 10.0 ** rng.uniform(-info_decades, info_decades, size=(E, d))
+        WJa, WJb = w[:, :, None] * Ja, w[:, :, None] * Jb
+    else:
+        WJa, WJb = Ja, Jb
+    Hii = np.einsum("eki,ekj->eij", Ja, WJa)
+    Hij = np.einsum("eki,ekj->eij", Ja, WJb)
+    Hjj = np.einsum("eki,ekj->eij", Jb, WJb)
     diag = _segment_sum(np.concatenate([ei, ej]), np.concatenate([Hii, Hjj]), n)
     diag[0] += prior * eye
     # block-CSC: column j holds its off-diagonal blocks (rows i < j, sorted) then the diagonal block
@@ -164,7 +172,7 @@ def _assemble_pose_graph(n: int, d: int, ei: np.ndarray, ej: np.ndarray, rng, si
 
 def pose_chain(n: int = 100_000, d: int = 6, loop_every: int = 50, loop_min: int = 26,
                loop_max: int = 50, sigma: float = 0.02, prior: float = 100.0,
-               seed: int = 12345) -> BlockSystem:
+               seed: int = 12345, info_decades: float = 0.0) -> BlockSystem:
     """C3 look-alike: odometry chain (i, i+1) + one loop closure per ``loop_every`` poses to a
     pose ``loop_min..loop_max`` back.  n=100000, d=6 gives 201 998 upper blocks."""
     rng = np.random.default_rng(seed)
@@ -175,7 +183,7 @@ def pose_chain(n: int = 100_000, d: int = 6, loop_every: int = 50, loop_min: int
     ok = li >= 0
     ei = np.concatenate([ci, li[ok]])
     ej = np.concatenate([ci + 1, ends[ok]])
-    return _assemble_pose_graph(n, d, ei, ej, rng, sigma, prior, f"pose_chain_n{n}_d{d}")
+    return _assemble_pose_graph(n, d, ei, ej, rng, sigma, prior, f"pose_chain_n{n}_d{d}", info_decades)
 
 
 def sphere(n_rings: int = 50, per_ring: int = 50, d: int = 6, sigma: float = 0.02,
@@ -226,13 +234,18 @@ def manhattan(n: int = 3500, d: int = 3, world: int = 30, sigma: float = 0.02,
 
 def ba(n_cams: int = 1000, n_pts: int = 500_000, k: int = 4, mode: str = "band",
        damping: float = 0.1, seed: int = 777, cam_dim: int = 6, pt_dim: int = 3,
-       cam_damping: float | None = None) -> BlockSystem:
+       cam_damping: float | None = None, baseline: float | None = None,
+       rot_scale: float | None = None) -> BlockSystem:
     """C4/C5 look-alike.  Every point is seen by ``k`` cameras (``mode='venice'``: k drawn from a
     clipped geometric distribution, mean about 5.3; ``'tracks'``: longer ones, mean about 11, consecutive cameras).  Cameras of a point: ``band`` = c0 + 7j mod nc
     (sparse S), ``uniform`` = k distinct random cameras (dense S).  Per observation
     Jc in R^{2x6}, Jp in R^{2x3} ~ N(0,1):  A_cc += Jc^T Jc, C_pp += Jp^T Jp, U_cp = Jc^T Jp;
     ``damping``*I on every diagonal block.  ``cam_damping`` overrides the
-    damping of the camera blocks (landmark shards of one system each carry 1/world of it)."""
+    damping of the camera blocks (landmark shards of one system each carry 1/world of it).
+    The conditioning sweep (``cond_ba_*`` fixtures) adds: ``baseline`` = b: every camera sees a point through nearly the
+    same Jp (one per point + b * noise: a small baseline, C_pp within b^2 of rank 2 and held by the damping);
+    ``rot_scale`` = r: the last three columns of Jc times r (rotations in radians against translations: focal-length-sized
+    entries), and the Jc of a point's cameras drawn around one common Jacobian (near-collinear cameras)."""
     rng = np.random.default_rng(seed)
     if mode in ("venice", "tracks"):
         kk = np.clip(rng.geometric(0.19 if mode == "venice" else 0.08, size=n_pts) + 1, 2, min(30, n_cams))
@@ -267,6 +280,11 @@ def ba(n_cams: int = 1000, n_pts: int = 500_000, k: int = 4, mode: str = "band",
     cd, pd_ = cam_dim, pt_dim
     Jc = rng.standard_normal((n_obs, 2, cd))
     Jp = rng.standard_normal((n_obs, 2, pd_))
+    if baseline is not None:
+        Jp = rng.standard_normal((n_pts, 2, pd_))[pt_of] + baseline * Jp
+    if rot_scale is not None:
+        Jc = rng.standard_normal((n_pts, 2, cd))[pt_of] + 0.25 * Jc
+        Jc[:, :, cd - 3:] *= rot_scale
     Acc = _segment_sum(cam_of, np.einsum("oki,okj->oij", Jc, Jc), n_cams)
     Cpp = _segment_sum(pt_of, np.einsum("oki,okj->oij", Jp, Jp), n_pts)
     Ucp = np.einsum("oki,okj->oij", Jc, Jp)                 # [n_obs, 6, 3]

@@ -25,6 +25,16 @@ reference's own solver classes on those inputs:
                                        the CHOLMOD solution of that system
     dump_*.mtx / .bla / .npz         : a system written by the reference's Save_MatrixMarket / Save_BlockLayout (the format of
                                        its -dsm option), next to the arrays it was written from
+    cond_*.npz                       : the conditioning sweep ('Conditioning vs the 1e-10 bar'): pose chains
+                                       and BA systems at cond_2(Lambda) of about 1e6 / 1e9 / 1e12, two systems that are
+                                       indefinite by twice their smallest eigenvalue, and the damped Lambda the reference's own
+                                       CNonlinearSolver_Lambda_LM hands to its linear solver on 200 CVertexCam cameras
+                                       (`ref_harness lambda_dump ba_lm`, the solve at which its damping is lowest).  Per
+                                       system: the five reference solvers' solutions and verdicts (ok_*), ``spread`` = the
+                                       largest rel-inf distance between two of them, ``cond2`` (dense eigenvalues),
+                                       ``cond_proxy`` = (max / min diagonal entry of the Cholesky factor)^2, and ``x_true``:
+                                       a dense solve refined with residuals in 60-digit arithmetic (mpmath), the
+                                       yardstick the forward errors ``err_true_*`` of the five are measured against
 Fixtures are data only; no reference source text is stored.
 """
 import json
@@ -54,7 +64,130 @@ CASES = {
 }
 
 
-def run(args):
+def _shift_diag(lam, eps):
+    """Lambda - eps * I (on a copy)."""
+    import dataclasses
+    off = lam.block_value_offsets()
+    v = lam.values.copy()
+    for j in range(lam.n_bcols):
+        b = int(lam.bcol_ptr[j + 1] - 1)
+        d = int(lam.cumsum[j + 1] - lam.cumsum[j])
+        v[off[b]:off[b + 1]].reshape(d, d)[...] -= eps * np.eye(d)
+    return dataclasses.replace(lam, values=v)
+
+
+def _indefinite_by(lam, factor):
+    """Lambda - factor * lambda_min * I: indefinite by a margin of the size of its own smallest eigenvalue."""
+    w = np.linalg.eigvalsh(lam.to_scipy().toarray())
+    return _shift_diag(lam, factor * w[0])
+
+
+_CHAIN = dict(n=120, d=6, loop_every=10, loop_min=4, loop_max=9)
+COND_CASES = {
+    "cond_chain6_1e6": lambda: synth.pose_chain(seed=201, sigma=0.1, prior=1.0, info_decades=1.8, **_CHAIN),
+    "cond_chain6_1e9": lambda: synth.pose_chain(seed=202, sigma=0.3, prior=1e-4, info_decades=1.5, **_CHAIN),
+    "cond_chain6_1e12": lambda: synth.pose_chain(seed=203, sigma=0.3, prior=1e-8, info_decades=4.0, **_CHAIN),
+    "cond_chain3_1e7": lambda: synth.pose_chain(n=200, d=3, loop_every=12, loop_min=5, loop_max=11, seed=205, sigma=0.3,
+                                                prior=1e-4, info_decades=1.7),
+    "cond_ba_1e6": lambda: synth.ba(40, 400, k=3, mode="band", seed=211, damping=1e-6, baseline=0.05),
+    "cond_ba_1e9": lambda: synth.ba(40, 400, mode="venice", seed=212, damping=1e-6, baseline=0.02, rot_scale=20),
+    "cond_ba_1e12": lambda: synth.ba(40, 400, k=2, mode="band", seed=213, damping=1e-6, baseline=1e-3, rot_scale=100),
+    "cond_chain6_1e9_indefinite": lambda: _indefinite_by(COND_CASES["cond_chain6_1e9"](), 2.0),
+    "cond_ba_1e9_indefinite": lambda: _indefinite_by(COND_CASES["cond_ba_1e9"](), 2.0),
+}
+BA_LM_DUMP = ("cond_ba_lm_200cams", 200, 1000, 4, 11, 6)   # name, cameras, points, observations per point, seed, n_solve
+LLT_SOLVERS = ("cholmod_super", "csparse", "uberblock")     # the oracles whose not-PD verdict counts (SURVEY.md appendix A)
+
+
+def refined_solution(lam):
+    """A dense solve refined with residuals in 60-digit arithmetic (mpmath) until the correction is below 1e-25 of
+    the solution: the exact solution of the system as stored, rounded to doubles; (x, cond2, cond_proxy).  x is None if
+    the refinement does not contract (cond * 1e-16 >= 1)."""
+    A = lam.to_scipy().toarray()
+    w = np.linalg.eigvalsh(A)
+    cond2 = float(abs(w[-1]) / abs(w[0])) if w[0] != 0 else np.inf
+    try:
+        Lc = np.linalg.cholesky(A)
+        dg = np.diag(Lc)
+        proxy = float((dg.max() / dg.min()) ** 2)
+    except np.linalg.LinAlgError:
+        proxy = np.nan
+    import mpmath as mp
+    import scipy.linalg as sl
+    mp.mp.dps = 60
+    lu = sl.lu_factor(A)
+    coo = lam.to_scipy().tocoo()
+    rows, cols = coo.row.tolist(), coo.col.tolist()
+    vals = [mp.mpf(float(v)) for v in coo.data]
+    b = [mp.mpf(float(v)) for v in lam.rhs]
+    x = [mp.mpf(float(v)) for v in sl.lu_solve(lu, lam.rhs)]
+    step = np.inf
+    for _ in range(40):   # every pass gains about -log10(cond * 1e-16) digits
+        r = list(b)
+        for i, j, v in zip(rows, cols, vals):
+            r[i] -= v * x[j]
+        dx = sl.lu_solve(lu, np.array([float(v) for v in r]))
+        x = [xi + mp.mpf(float(d)) for xi, d in zip(x, dx)]
+        xf = np.array([float(v) for v in x])
+        step = float(np.abs(dx).max() / np.abs(xf).max())
+        if step < 1e-25:
+            break
+    return (xf if step < 1e-20 else None), cond2, proxy
+
+
+def rel_inf(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def cond_record(lam):
+    rec = {"cumsum": lam.cumsum, "bcol_ptr": lam.bcol_ptr, "brow_idx": lam.brow_idx, "values": lam.values,
+           "rhs": lam.rhs, "n_matrix_cut": np.int64(lam.n_matrix_cut)}
+    xs = {}
+    with tempfile.TemporaryDirectory() as td:
+        prob = os.path.join(td, "p.bin")
+        lam.save(prob)
+        for s in ["cholmod_super", "cholmod_simp", "csparse", "uberblock"] + (["schur"] if lam.n_matrix_cut else []):
+            xf = os.path.join(td, f"x_{s}.bin")
+            r = run(["solve", prob, s, xf, "1"], check=False)
+            rec[f"ok_{s}"] = np.bool_(r["ok"])
+            if r["ok"]:
+                xs[s] = rec[f"x_{s}"] = np.fromfile(xf)
+    x_true, cond2, proxy = refined_solution(lam)
+    rec["cond2"], rec["cond_proxy"] = np.float64(cond2), np.float64(proxy)
+    llt_ok = all(bool(rec[f"ok_{s}"]) for s in LLT_SOLVERS)
+    rec["positive_definite"] = np.bool_(llt_ok)
+    if llt_ok:   # solutions of an indefinite system (simplicial CHOLMOD's LDL^T "succeeds") are not compared
+        names = sorted(xs)
+        rec["spread"] = np.float64(max(rel_inf(xs[a], xs[b]) for a in names for b in names if a != b))
+        if x_true is not None:
+            rec["x_true"] = x_true
+            for s in names:
+                rec[f"err_true_{s}"] = np.float64(rel_inf(xs[s], x_true))
+    return rec
+
+
+def make_cond_fixtures():
+    for name, make in COND_CASES.items():
+        lam = make()
+        rec = cond_record(lam)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **rec)
+        print(f"{name}: n={lam.n_scalars} cond2={float(rec['cond2']):.2e} proxy={float(rec['cond_proxy']):.2e} "
+              f"spread={float(rec.get('spread', np.nan)):.2e}", {k[3:]: bool(v) for k, v in rec.items() if k.startswith("ok_")},
+              {k[9:]: f"{float(v):.1e}" for k, v in rec.items() if k.startswith("err_true_")})
+    name, n_cams, n_pts, k, seed, n_solve = BA_LM_DUMP
+    with tempfile.TemporaryDirectory() as td:
+        prefix = os.path.join(td, "lm")
+        run(["lambda_dump", "ba_lm", str(n_cams), str(seed), prefix, str(n_pts), str(k), str(n_solve)])
+        lam = synth.BlockSystem.load(prefix + ".lambda.bin")
+    rec = cond_record(lam)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: n={lam.n_scalars} blocks={lam.n_blocks} cond2={float(rec['cond2']):.2e} spread={float(rec['spread']):.2e} "
+          f"-> {os.path.getsize(path) / 1024:.1f} KiB", {k[9:]: f"{float(v):.1e}" for k, v in rec.items() if k.startswith("err_true_")})
+
+
+def run(args, check=True):
     out = subprocess.run([HARNESS] + args, capture_output=True, text=True)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if not line:
@@ -65,6 +198,8 @@ def run(args):
 def main():
     if not os.path.exists(HARNESS):
         raise SystemExit("build the reference first: make -f oracle/Makefile.ref -j8")
+    if len(sys.argv) > 1 and sys.argv[1] == "cond":
+        return make_cond_fixtures()
     for name, make in CASES.items():
         lam = make()
         rec = {"cumsum": lam.cumsum, "bcol_ptr": lam.bcol_ptr, "brow_idx": lam.brow_idx, "values": lam.values,
@@ -125,6 +260,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), cumsum=lam.cumsum, bcol_ptr=lam.bcol_ptr,
                             brow_idx=lam.brow_idx, values=lam.values, rhs=lam.rhs, n_matrix_cut=np.int64(lam.n_matrix_cut))
         print(f"{name}: {os.path.getsize(mtx) / 1024:.1f} KiB .mtx")
+    make_cond_fixtures()
 
 
 if __name__ == "__main__":

@@ -14,7 +14,32 @@ def _names():
 
 def golden_names():
     """Linear systems with the reference solvers' solutions."""
-    return [n for n in _names() if not n.startswith(("assembly_", "dump_"))]
+    return [n for n in _names() if not n.startswith(("assembly_", "dump_", "cond_"))]
+
+
+def cond_names():
+    """The conditioning sweep: systems at cond 1e6 .. 1e12, barely indefinite ones, the reference's own LM-damped BA Lambda."""
+    return [n for n in _names() if n.startswith("cond_")]
+
+
+LLT_ORACLES = ("cholmod_super", "csparse", "uberblock")   # simplicial CHOLMOD is LDL^T and "solves" indefinite systems
+
+
+def load_cond(name):
+    """(BlockSystem, dict): x_* / ok_* / err_true_* of the five reference solvers, spread, cond2, cond_proxy, x_true,
+    positive_definite (the LL^T oracles' common verdict)."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    lam = BlockSystem(z["cumsum"].astype(np.int64), z["bcol_ptr"].astype(np.int64), z["brow_idx"].astype(np.int32),
+                      z["values"], z["rhs"], int(z["n_matrix_cut"]), name)
+    ref = {k: z[k] for k in z.files if k.startswith(("x_", "ok_", "err_true_", "spread", "cond", "positive_definite"))}
+    return lam, ref
+
+
+def cond_bounds(ref):
+    """(bound on rel-inf distance to x_cholmod_super, bound on the forward error against x_true): ten times what the
+    reference's own solvers show among themselves -- and the north star's 1e-10 where that is tighter than they are."""
+    worst_true = max(float(v) for k, v in ref.items() if k.startswith("err_true_"))
+    return max(10.0 * float(ref["spread"]), 1e-10), max(10.0 * worst_true, 1e-10)
 
 
 def dump_names():

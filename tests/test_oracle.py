@@ -136,3 +136,60 @@ def test_reference_binaries_are_built_where_the_reference_sources_are():
     for f in ("ref_harness", "dropin_driver"):
         assert os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", f)), \
             f"oracle/_ref/{f} missing: python -c 'import __graft_entry__ as g; g.build()'"
+
+
+# ---- the conditioning sweep (tests/golden/cond_*.npz): what the reference's own solvers do on hard inputs ----------
+
+def test_cond_set_is_present():
+    from golden_util import cond_names
+    names = cond_names()
+    assert {"cond_chain6_1e6", "cond_chain6_1e9", "cond_chain6_1e12", "cond_ba_1e6", "cond_ba_1e9", "cond_ba_1e12",
+            "cond_ba_lm_200cams", "cond_chain6_1e9_indefinite", "cond_ba_1e9_indefinite"} <= set(names)
+
+
+def _cond_cases(pd):
+    from golden_util import cond_names, load_cond
+    return [n for n in cond_names() if bool(load_cond(n)[1]["positive_definite"]) == pd]
+
+
+@pytest.mark.parametrize("name", _cond_cases(True))
+def test_cond_fixture_is_what_it_says(name):
+    """The fixtures' own bookkeeping: targets hit, the spread grows with the condition number, the refined solution
+    is closer to every reference solver than they are to each other."""
+    from golden_util import load_cond
+    lam, ref = load_cond(name)
+    target = {"1e6": 1e6, "1e7": 1e7, "1e9": 1e9, "1e12": 1e12}.get(name.rsplit("_", 1)[-1])
+    if target:
+        assert 0.3 * target < float(ref["cond2"]) < 10 * target
+    assert float(ref["cond_proxy"]) <= float(ref["cond2"]) * 1.0001       # a lower bound of cond_2
+    errs = [float(v) for k, v in ref.items() if k.startswith("err_true_")]
+    assert len(errs) >= 4 and max(errs) <= 2 * float(ref["spread"]) and max(errs) < float(ref["cond2"]) * 1e-15
+    assert lam.n_matrix_cut == 0 or "x_schur" in ref
+
+
+@pytest.mark.parametrize("name", _cond_cases(True))
+def test_oracle_on_ill_conditioned_systems(name):
+    """The restatement is held to what the reference's solvers show among themselves: ten times their spread against
+    CHOLMOD's solution, ten times their worst forward error against the refined solution (1e-10 where they are better)."""
+    from golden_util import load_cond, cond_bounds
+    lam, ref = load_cond(name)
+    b_ref, b_true = cond_bounds(ref)
+    ok, x, _ = O.solve_sparse(lam)
+    assert ok
+    assert rel_inf(x, ref["x_cholmod_super"]) < b_ref and rel_inf(x, ref["x_true"]) < b_true
+    if lam.n_matrix_cut:
+        ok, xs, _, _ = O.solve_schur(lam)
+        assert ok
+        assert rel_inf(xs, ref["x_schur"]) < b_ref and rel_inf(xs, ref["x_true"]) < b_true
+
+
+@pytest.mark.parametrize("name", _cond_cases(False))
+def test_oracle_verdict_on_barely_indefinite_systems(name):
+    """Indefinite by twice the smallest eigenvalue of a cond-1e9 system: CHOLMOD supernodal, CSparse and the native solver
+    all say no (simplicial CHOLMOD's LDL^T and, for BA, the Schur solver on top of it say yes: SURVEY.md appendix A)."""
+    from golden_util import load_cond, LLT_ORACLES
+    lam, ref = load_cond(name)
+    assert not any(bool(ref[f"ok_{s}"]) for s in LLT_ORACLES) and bool(ref["ok_cholmod_simp"])
+    assert O.solve_sparse(lam)[0] is False
+    if lam.n_matrix_cut:
+        assert O.solve_schur(lam)[0] is False
