@@ -48,7 +48,12 @@ struct CTileSchedule {
 	int4 *d_trsm;                      // (row tile, column tile, 1 = the workgroup also updates the diagonal tile of its row, -)
 	int4 *d_tgt;                       // (row tile, column tile, first source, one past the last source)
 	int *d_src;                        // source tile columns of the targets
-	CTileSchedule() :n_tiles(0), n_levels(0), d_potrf(0), d_trsm(0), d_tgt(0), d_src(0) {}
+	// backward substitution by the same levels, top down (tile_backsolve): launch q solves the tile columns of height
+	// n_levels - 1 - q ("diagonal" records) and carries the x of the launch before it to every column further down
+	std::vector<int> back_diag_ptr, back_carry_ptr; // [n_levels + 1] each, by launch
+	int4 *d_back_diag;                 // (tile column k, its ancestor of height + 1 or -1, 1 = z_k is still y, -)
+	int4 *d_back_carry;                // (source tile column j, target tile column k: z_k -= L(j,k)^T x_j, 1 = z_k is still y, -)
+	CTileSchedule() :n_tiles(0), n_levels(0), d_potrf(0), d_trsm(0), d_tgt(0), d_src(0), d_back_diag(0), d_back_carry(0) {}
 	~CTileSchedule() { Free(); }
 	CTileSchedule(const CTileSchedule&) = delete;
 	CTileSchedule &operator =(const CTileSchedule&) = delete;
@@ -65,6 +70,14 @@ private:
 // same contract as dense_cholesky(), on the tiles of the schedule only
 void tile_cholesky(const CTileSchedule &r_schedule, double *M, int n_pad, int n, double *p_invdiag, int *p_flag,
 	hipStream_t stream);
+
+// x = L^-T y by the levels of the schedule, top down: same contract as dense_backsolve() below, for a factor made by
+// tile_cholesky() with this schedule.  One launch per level; every nonzero tile of the factor is read once, by one
+// workgroup; what a level's columns wait for is one 64 x 64 product with the inverse of their diagonal tile and, where
+// the column's nearest ancestor was solved by the launch before, one with that ancestor's tile -- everything else has been
+// carried into z by earlier launches, one workgroup (one writer, a fixed order of sums) per tile.
+void tile_backsolve(const CTileSchedule &r_schedule, const double *M, int n_pad, int n, const double *p_invdiag, double *p_z,
+	double *p_x, hipStream_t stream, const longlong2 *p_dst = 0, double *p_w = 0, double *p_x_out = 0);
 
 // zeroes the schedule's tiles of M (every tile a factorization by the schedule or an assembly into its pattern writes)
 // p_unit (optional, n_pad bytes): positions whose diagonal entry is 1 afterwards (padding, alignment gaps)

@@ -103,7 +103,9 @@ void CTileSchedule::Free()
 	if(d_trsm) (void)hipFree(d_trsm);
 	if(d_tgt) (void)hipFree(d_tgt);
 	if(d_src) (void)hipFree(d_src);
-	d_potrf = 0; d_trsm = 0; d_tgt = 0; d_src = 0;
+	if(d_back_diag) (void)hipFree(d_back_diag);
+	if(d_back_carry) (void)hipFree(d_back_carry);
+	d_potrf = 0; d_trsm = 0; d_tgt = 0; d_src = 0; d_back_diag = 0; d_back_carry = 0;
 	n_bytes = 0;
 	n_levels = 0;
 	n_tiles = 0;
@@ -199,10 +201,42 @@ bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hi
 		level_trsm_ptr.push_back(int(trsm.size()));
 		level_tgt_ptr.push_back(int(tgt.size()));
 	}
+	// the backward substitution, top down.  The ancestors of a tile column (the rows of its nonzero tiles) all have
+	// different heights (two of them are linked by fill), so a column gets at most one contribution per launch: from the
+	// ancestor of height h + 1 by the launch of height h -- in the column's own workgroup if h is its own height, by a
+	// carrying workgroup otherwise.  z_k starts as y_k, which lives in the last row of the factor: the first workgroup to
+	// touch z_k takes it from there
+	std::vector<int4> back_diag, back_carry;
+	back_diag_ptr.assign(1, 0);
+	back_carry_ptr.assign(1, 0);
+	{
+		std::vector<char> touched(T, 0);
+		for(int h = n_max_height; h >= 0; -- h) {
+			for(int k = 0; k < T; ++ k) {
+				if(height[k] > h)
+					continue;
+				int n_up = -1; // the ancestor of height h + 1
+				for(int j = k + 1; j < T && n_up < 0; ++ j) {
+					if(nz[size_t(j) + size_t(k) * T] && height[j] == h + 1)
+						n_up = j;
+				}
+				if(height[k] == h)
+					back_diag.push_back(int4{k, n_up, !touched[k], 0});
+				else if(n_up >= 0) {
+					back_carry.push_back(int4{n_up, k, !touched[k], 0});
+					touched[k] = 1;
+				}
+			}
+			back_diag_ptr.push_back(int(back_diag.size()));
+			back_carry_ptr.push_back(int(back_carry.size()));
+		}
+	}
+	const size_t n_b4 = back_diag.size() * sizeof(int4), n_b5 = (back_carry.size() + 1) * sizeof(int4);
 	const size_t n_b0 = potrf.size() * sizeof(int), n_b1 = (trsm.size() + 1) * sizeof(int4),
 		n_b2 = (tgt.size() + 1) * sizeof(int4), n_b3 = (src.size() + 1) * sizeof(int);
 	if(hipMalloc((void**)&d_potrf, n_b0) != hipSuccess || hipMalloc((void**)&d_trsm, n_b1) != hipSuccess ||
-	   hipMalloc((void**)&d_tgt, n_b2) != hipSuccess || hipMalloc((void**)&d_src, n_b3) != hipSuccess) {
+	   hipMalloc((void**)&d_tgt, n_b2) != hipSuccess || hipMalloc((void**)&d_src, n_b3) != hipSuccess ||
+	   hipMalloc((void**)&d_back_diag, n_b4) != hipSuccess || hipMalloc((void**)&d_back_carry, n_b5) != hipSuccess) {
 		(void)hipGetLastError();
 		Free();
 		return false;
@@ -214,13 +248,16 @@ bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hi
 		b_ok = b_ok && hipMemcpyAsync(d_tgt, tgt.data(), tgt.size() * sizeof(int4), hipMemcpyHostToDevice, stream) == hipSuccess;
 	if(!src.empty())
 		b_ok = b_ok && hipMemcpyAsync(d_src, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice, stream) == hipSuccess;
+	b_ok = b_ok && hipMemcpyAsync(d_back_diag, back_diag.data(), n_b4, hipMemcpyHostToDevice, stream) == hipSuccess;
+	if(!back_carry.empty())
+		b_ok = b_ok && hipMemcpyAsync(d_back_carry, back_carry.data(), back_carry.size() * sizeof(int4), hipMemcpyHostToDevice, stream) == hipSuccess;
 	b_ok = b_ok && hipStreamSynchronize(stream) == hipSuccess; // the host vectors live on this stack frame
 	if(!b_ok) {
 		(void)hipGetLastError();
 		Free();
 		return false;
 	}
-	n_bytes = n_b0 + n_b1 + n_b2 + n_b3;
+	n_bytes = n_b0 + n_b1 + n_b2 + n_b3 + n_b4 + n_b5;
 	n_tiles = T;
 	n_levels = n_max_height + 1;
 	return true;
@@ -281,6 +318,101 @@ void tile_cholesky(const CTileSchedule &r_s, double *M, int n_pad, int n, double
 	}
 	if(r1 > r0) // (the last level's own: nothing follows it to ride in)
 		hipLaunchKernelGGL(tile_update_kernel, dim3(r1 - r0), dim3(256), 0, stream, M, n_pad, r_s.d_tgt + r0, r_s.d_src);
+}
+
+// One launch of the backward substitution by levels (tile_backsolve).  Thread (c, part) = (t / 8, t % 8) holds the eight
+// entries 2 part + 16 i + {0, 1} of column c of a tile, fetched as four 16-byte pairs: the eight threads of a column read
+// whole 128-byte lines.  Everything a workgroup needs is requested before the first dependent step.
+__global__ void __launch_bounds__(512)
+tile_backsolve_kernel(const double *M, int ld, int n, const double *p_invdiag, double *z, double *x,
+	const int4 *__restrict__ p_diag, int n_diag, const int4 *__restrict__ p_carry,
+	const longlong2 *__restrict__ p_dst, double *p_w, double *p_x_out)
+{
+	enum { PARTS = 8, PER = NB / PARTS };
+	__shared__ double s_x[NB];
+	__shared__ double s_z[NB];
+	const int t = threadIdx.x, c = t / PARTS, part = t % PARTS;
+	const bool b_diag = int(blockIdx.x) < n_diag;
+	const int4 rec = b_diag? p_diag[blockIdx.x] : p_carry[int(blockIdx.x) - n_diag];
+	const int j = b_diag? rec.y : rec.x, k = b_diag? rec.x : rec.y; // z_k -= L(j,k)^T x_j (j < 0: nothing to subtract)
+	double vl[PER], vi[PER];
+	if(j >= 0) {
+		const double *col = M + size_t(j * NB + 2 * part) + size_t(k * NB + c) * ld;
+		#pragma unroll
+		for(int i = 0; i < PER; i += 2) {
+			const v2f64 v = *reinterpret_cast<const v2f64*>(col + PARTS * i);
+			vl[i] = v.x;
+			vl[i + 1] = v.y;
+		}
+	}
+	if(b_diag) {
+		const double *invL = p_invdiag + size_t(k) * NB * NB + c * NB + 2 * part;
+		#pragma unroll
+		for(int i = 0; i < PER; i += 2) {
+			const v2f64 v = *reinterpret_cast<const v2f64*>(invL + PARTS * i);
+			vi[i] = v.x;
+			vi[i + 1] = v.y;
+		}
+	}
+	double z_in = 0;
+	if(t < NB) {
+		const int q = k * NB + t;
+		z_in = rec.z? ((q < n)? M[size_t(ld - 1) + size_t(q) * ld] : 0.0) : z[q];
+		s_x[t] = (j >= 0)? x[j * NB + t] : 0.0;
+	}
+	__syncthreads();
+	double upd = 0;
+	if(j >= 0) {
+		#pragma unroll
+		for(int i = 0; i < PER; ++ i)
+			upd += vl[i] * s_x[2 * part + PARTS * (i & ~1) + (i & 1)];
+		upd += __shfl_xor(upd, 1);
+		upd += __shfl_xor(upd, 2);
+		upd += __shfl_xor(upd, 4);
+	}
+	// (c, part = 0) holds the sum of column c; the thread that fetched z_in[c] is thread c: hand over through LDS
+	if(part == 0)
+		s_z[c] = upd;
+	__syncthreads();
+	if(!b_diag) {
+		if(t < NB)
+			z[k * NB + t] = z_in - s_z[t];
+		return;
+	}
+	if(t < NB)
+		s_x[t] = z_in - s_z[t]; // z_k, complete (s_x is free: every read of x_j is behind the barrier above)
+	__syncthreads();
+	double sum = 0; // x_k[c] = sum_r inv(L_kk)[r][c] z_k[r]
+	#pragma unroll
+	for(int i = 0; i < PER; ++ i)
+		sum += vi[i] * s_x[2 * part + PARTS * (i & ~1) + (i & 1)];
+	sum += __shfl_xor(sum, 1);
+	sum += __shfl_xor(sum, 2);
+	sum += __shfl_xor(sum, 4);
+	if(part == 0) {
+		const int q = k * NB + c;
+		x[q] = sum;
+		if(p_dst) {
+			const longlong2 d = p_dst[q];
+			if(d.x >= 0) {
+				p_w[d.x] = sum;
+				p_x_out[d.y] = sum;
+			}
+		}
+	}
+}
+
+void tile_backsolve(const CTileSchedule &r_s, const double *M, int n_pad, int n, const double *p_invdiag, double *p_z,
+	double *p_x, hipStream_t stream, const longlong2 *p_dst, double *p_w, double *p_x_out)
+{
+	for(int q = 0; q < r_s.n_levels; ++ q) {
+		const int d0 = r_s.back_diag_ptr[q], d1 = r_s.back_diag_ptr[q + 1];
+		const int c0 = r_s.back_carry_ptr[q], c1 = r_s.back_carry_ptr[q + 1];
+		if(d1 - d0 + c1 - c0 > 0) {
+			hipLaunchKernelGGL(tile_backsolve_kernel, dim3((d1 - d0) + (c1 - c0)), dim3(512), 0, stream, M, n_pad, n, p_invdiag,
+				p_z, p_x, r_s.d_back_diag + d0, d1 - d0, r_s.d_back_carry + c0, p_dst, p_w, p_x_out);
+		}
+	}
 }
 
 } // namespace slampp

@@ -1695,6 +1695,10 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			Phase_End();
 		}
 		Phase_Begin("dense_solve");
+		if(b_dense_tiles) // by the levels of the tile schedule, reading its nonzero tiles only
+			tile_backsolve(dense_tiles, d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), d_dense_z.p(), d_dense_x.p(), stream,
+				d_dense_dst.p(), d_w.p(), p_rhs_dev);
+		else
 		dense_backsolve(d_dense.p(), ld, n_dense_dim, d_dense_invdiag.p(), d_dense_z.p(), d_dense_x.p(), stream,
 			d_dense_dst.p(), d_w.p(), p_rhs_dev); // (x goes to w and to the caller's vector as each panel publishes it)
 		Phase_End();

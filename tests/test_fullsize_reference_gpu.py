@@ -221,3 +221,80 @@ def test_c5_two_landmark_shards_match_single_handle():
     x[:n_x] = results[0][0][:n_x]
     assert rel_inf(results[1][0][:n_x], results[0][0][:n_x]) < 1e-13
     assert rel_inf(x, single) < TOL
+
+
+# ---- full size, ill conditioned: the bar is what the compiled reference's own solvers show among themselves ------------------
+
+def reference_solutions(lam, solvers):
+    """{solver: x or None (the solver returned false)} of the compiled reference on one system."""
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "p.bin")
+        lam.save(p)
+        for s in solvers:
+            xp = os.path.join(td, f"x_{s}.bin")
+            r = O.reference_solve(p, s, xp, reps=1, timeout=1800)
+            out[s] = np.fromfile(xp, dtype=np.float64) if r["ok"] else None
+    return out
+
+
+def spread_of(xs):
+    xs = [x for x in xs.values() if x is not None]
+    return max(rel_inf(a, b) for a in xs for b in xs if a is not b)
+
+
+C3_HARD = {   # 100k poses; sigma, weak prior and information matrices spread over 2 x info_decades decades (synth.pose_chain)
+    "spread_1e-8": dict(sigma=0.1, prior=1e-2, info_decades=2.5, seed=302),
+    "spread_1e-7": dict(sigma=0.15, prior=1e-3, info_decades=2.0, seed=303),
+}
+
+
+@needs_reference
+@pytest.mark.parametrize("case", sorted(C3_HARD))
+def test_c3_ill_conditioned_within_the_reference_solvers_spread(case):
+    """C3's structure with the conditioning real pose graphs have: CHOLMOD (supernodal), CSparse and the reference's native
+    block solver differ by 1e-8 .. 1e-7 on these systems (measured in the build container; re-measured here, live); the
+    HIP path must be within ten times their spread of CHOLMOD -- 1e-10 is not a bar any Cholesky solver meets here."""
+    lam = synth.pose_chain(**C3_HARD[case])
+    refs = reference_solutions(lam, ["cholmod_super", "csparse", "uberblock"])
+    assert all(x is not None for x in refs.values())
+    spread = spread_of(refs)
+    eta = lam.rhs.copy()
+    assert CLinearSolver_HIP().Solve_PosDef(lam, eta)
+    err = rel_inf(eta, refs["cholmod_super"])
+    print(f"C3 {case}: inter-oracle spread {spread:.2e}, HIP vs CHOLMOD {err:.2e}")
+    assert 1e-10 < spread < 1e-5                                  # (the case is what it claims to be)
+    assert err < 10 * spread
+
+
+@needs_reference
+def test_c3_numerically_singular_verdict_matches_the_llt_oracles():
+    """sigma = 0.3 at 100k poses: Lambda is positive semi-definite by construction and singular to working precision; all
+    three LL^T oracles return false, and so must the HIP path (not a solution of garbage)."""
+    lam = synth.pose_chain(sigma=0.3, prior=1e-4, info_decades=1.5, seed=302)
+    refs = reference_solutions(lam, ["cholmod_super", "csparse", "uberblock"])
+    assert all(x is None for x in refs.values())
+    assert CLinearSolver_HIP().Solve_PosDef(lam, lam.rhs.copy()) is False
+
+
+@needs_reference
+def test_c4_venice_ill_conditioned_within_the_reference_solvers_spread():
+    """C4's Venice-like system with damping 1e-6, small baselines and rotation columns twenty times the translation ones:
+    the reference's Schur solver against its own CHOLMOD on the whole of Lambda gives the spread (on a 100k-landmark cut:
+    CHOLMOD on the full system is a minute of CPU); the HIP Schur path is held to ten times that on the cut and on the full
+    system (there against the reference's Schur solver alone)."""
+    lam = synth.ba(1000, 500_000, mode="venice", damping=1e-6, baseline=0.05, rot_scale=20, seed=778)
+    cut = cut_landmarks(lam, 100_000)
+    refs = reference_solutions(cut, ["schur", "cholmod_super"])
+    assert all(x is not None for x in refs.values())
+    spread = spread_of(refs)
+    eta = cut.rhs.copy()
+    assert CLinearSolver_Schur_HIP().Solve_PosDef(cut, eta)
+    err_cut = rel_inf(eta, refs["schur"])
+    x_ref = reference_solution(lam, "schur")
+    eta = lam.rhs.copy()
+    assert CLinearSolver_Schur_HIP().Solve_PosDef(lam, eta)
+    err = rel_inf(eta, x_ref)
+    print(f"C4 Venice-like, ill conditioned: spread (Schur vs CHOLMOD, 100k landmarks) {spread:.2e}, HIP vs Schur {err_cut:.2e} (cut) {err:.2e} (full)")
+    bound = max(10 * spread, 1e-10)
+    assert err_cut < bound and err < bound
