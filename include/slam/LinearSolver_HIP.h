@@ -439,7 +439,8 @@ public:
 	/**
 	 *	@brief the device list of the environment: SLAMPP_HIP_DEVICES="0,1,2,3,4,5,6,7" makes every default-constructed
 	 *		solver a multi-GPU one, so that an unchanged application (slam_plus_plus -us ...) shards its BA systems over the
-	 *		node without a line of code; empty if the variable is not set or names fewer than two devices
+	 *		node without a line of code; a single ordinal (SLAMPP_HIP_DEVICES="3") selects that device for every
+	 *		default-constructed solver; empty if the variable is not set
 	 */
 	static std::vector<int> Devices_From_Environment()
 	{
@@ -458,8 +459,6 @@ public:
 			devices.push_back(int(n_device));
 			p_s_list = (*p_s_end == ',')? p_s_end + 1 : p_s_end;
 		}
-		if(devices.size() < 2)
-			devices.clear();
 		return devices;
 	}
 
@@ -471,6 +470,8 @@ public:
 			m_devices = Devices_From_Environment();
 			if(!m_devices.empty())
 				m_n_device = m_devices[0];
+			if(m_devices.size() < 2)
+				m_devices.clear(); // one ordinal: a one-device handle on THAT device (until round 5 it was dropped: device 0)
 		}
 	}
 

@@ -598,6 +598,27 @@ int main(int n_arg_num, const char **p_arg_list)
 				int(n_sharded));
 			n_fail += !(f_err_multi < 1e-5 && fabs(f_chi2_ref - f_chi2_multi) <= 1e-10 * fabs(f_chi2_ref) && n_it_multi == n_it_ref &&
 				n_sharded >= n_it_multi);
+			// a list of ONE ordinal selects that device (until round 5 it was dropped and device 0 taken): "0" solves on one
+			// device without shards; an ordinal the machine does not have fails with the library's error, it does not quietly
+			// run on device 0
+			setenv("SLAMPP_HIP_DEVICES", "0", 1);
+			CLinearSolver_HIP_Base::n_Sharded_Solve_Counter() = 0;
+			double f_chi2_one;
+			size_t n_it_one;
+			std::vector<double> one = Optimize_BA_LM<CLinearSolver_HIP>(24, 1500, 6, 99, f_chi2_one, n_it_one, 4, 0.0);
+			const bool b_one_ok = f_RelInf(one, ref) < 1e-5 && CLinearSolver_HIP_Base::n_Sharded_Solve_Counter() == 0;
+			setenv("SLAMPP_HIP_DEVICES", "1023", 1);
+			bool b_refused = false;
+			try {
+				double f_chi2_bad;
+				size_t n_it_bad;
+				Optimize_BA_LM<CLinearSolver_HIP>(8, 100, 3, 99, f_chi2_bad, n_it_bad, 1, 0.0);
+			} catch(std::exception &r_exc) {
+				b_refused = true;
+			}
+			unsetenv("SLAMPP_HIP_DEVICES");
+			printf("\"devices_env_one_ordinal\": {\"device_0_ok\": %d, \"device_1023_refused\": %d}, ", int(b_one_ok), int(b_refused));
+			n_fail += !(b_one_ok && b_refused);
 		}
 		{ // block diagonal of the covariance of a pose graph: the reference's recipe (NonlinearSolver_Lambda.h:696-760) next to Marginals()
 			typedef MakeTypelist_Safe((Eigen::Matrix<double, 6, 6>)) TBs;

@@ -48,7 +48,10 @@ def solve_sparse(lam, perm=None):
     rc = lib().oracle_solve_sparse(C.c_int64(lam.n_bcols), _p(cs), _p(bp), _p(br), _p(vals), _p(x), _p(pm), _p(stats))
     if rc < 0:
         raise ValueError("oracle_solve_sparse: bad input")
-    return rc == 0, x, {"r_blocks": int(stats[0]), "r_values": int(stats[1])}
+    out = {"r_blocks": int(stats[0]), "r_values": int(stats[1])}
+    if rc == 0 and stats[2] > 0:   # (max / min diagonal entry of R)^2 <= cond_2(Lambda): the conditioning proxy of the reports
+        out["cond_proxy"] = float((stats[3] / stats[2]) ** 2)
+    return rc == 0, x, out
 
 
 def solve_schur(lam, n_cut=None, want_S=False):

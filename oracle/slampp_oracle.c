@@ -432,6 +432,21 @@ int oracle_solve_sparse(int64_t n, const int64_t *cs, const int64_t *ptr, const 
 	if(stats_out) {
 		stats_out[0] = (double)R.nblocks;
 		stats_out[1] = (double)R.nvals;
+		stats_out[2] = stats_out[3] = 0; /* smallest / largest diagonal entry of R: (max / min)^2 is a lower bound of cond_2(Lambda) */
+		if(!result) {
+			double f_min = 1e300, f_max = 0;
+			for(i = 0; i < n; ++ i) {
+				const int64_t d = P.cs[i + 1] - P.cs[i];
+				const double *p_diag = R.val + R.off[R.ptr[i + 1] - 1];
+				for(t = 0; t < d; ++ t) {
+					const double f = p_diag[t + t * d];
+					f_min = (f < f_min)? f : f_min;
+					f_max = (f > f_max)? f : f_max;
+				}
+			}
+			stats_out[2] = f_min;
+			stats_out[3] = f_max;
+		}
 	}
 	factor_free(&R);
 	bm_free(&P);

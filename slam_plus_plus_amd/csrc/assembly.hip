@@ -1048,7 +1048,7 @@ void assembly_enqueue(CAssemblyState &a, const double *J0, const double *J1, con
 #undef GROUPS_RESIDENT
 		const unsigned n_grid = unsigned(std::min(a.n_groups, int64_t(n_cus) * n_resident));
 		long long *p_timing = 0;
-		static const bool b_timing = getenv("SLAMPP_ASM_TIMING") != 0; // development aid
+		const bool b_timing = getenv("SLAMPP_HIP_ASM_TIMING") != 0; // development aid (prints only)
 		if(b_timing) {
 			SLAMPP_HIP_CHECK(hipMalloc(&p_timing, (64 * 32 + 2 * n_grid) * sizeof(long long)));
 			SLAMPP_HIP_CHECK(hipMemsetAsync(p_timing, 0, (64 * 32 + 2 * n_grid) * sizeof(long long), st));

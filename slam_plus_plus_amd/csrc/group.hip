@@ -426,6 +426,7 @@ struct CDeviceGroup;
 struct TMemberContext {
 	CDeviceGroup *p_group;
 	int n_member;
+	unsigned n_exchange_calls = 0; // this member's all-reduce calls so far (their parity picks the slot of its count)
 };
 
 struct TMemberShard {
@@ -442,11 +443,12 @@ struct CDeviceGroup {
 	std::vector<TMemberShard> shards;
 	CMemberThreads *p_threads;
 	int n_active; // members that hold landmarks (all of them unless the system has fewer landmarks than the list has devices)
+	const double *p_checked_staging = 0, *p_checked_staging_rhs = 0; // the front's staging as group_check_staging last saw it fit
 	int n_exchange_option, n_exchange; // EXCHANGE_*: as asked for, as resolved
 	std::vector<void*> comms; // RCCL communicators, one per active member
 	CAbortableBarrier barrier;
 	TPeerBuffers t_peer_buffers;
-	size_t peer_counts[GROUP_MAX_MEMBERS];
+	size_t peer_counts[2][GROUP_MAX_MEMBERS]; // [parity of the call][member]: a fast member writing the next call's count must not overwrite what a slow one is still comparing
 	// distributed dense factorization: the members' S and inverse-tile buffers, events, and how far the owners have got
 	TPeerBuffers t_factor_S, t_factor_inv;
 	int factor_dims[GROUP_MAX_MEMBERS][2];
@@ -457,6 +459,7 @@ struct CDeviceGroup {
 	int64_t n_factor_calls[GROUP_MAX_MEMBERS];
 	std::string s_exchange_name;
 	bool b_peer_access; // every member can read and write every other member's device memory (peer access enabled, or one device)
+	bool b_comms_aborted = false; // the handles in comms were given to ncclCommAbort (group_break_exchange): not to be destroyed again
 	std::atomic<bool> b_exchange_broken; // a collective failed after the members had agreed to enqueue it: the communicators are aborted and made anew
 	std::atomic<int64_t> n_collectives_enqueued; // exchanges the members went into (all of them, or none: see group_members_agree)
 	int n_fail_member; // test hook (option "group_fail_member"): this member + 1 fails on its way to the exchange
@@ -501,7 +504,10 @@ static bool group_members_agree(CDeviceGroup &g)
 }
 
 // a collective that failed after the agreement: the other members' streams may be parked in it.  Abort every communicator
-// (that is what releases them) and have the next solve make new ones.
+// (that is what releases them; ncclCommAbort is the call RCCL offers for use from another thread) and have the next solve
+// make new ones.  The handles stay in g.comms: other members may be about to read theirs -- a call on an aborted
+// communicator returns an error, a call on a null one would not return --; group_repair_exchange, where every member
+// thread has joined, destroys and replaces them.
 static void group_break_exchange(CDeviceGroup &g)
 {
 	bool b_expected = false;
@@ -510,11 +516,10 @@ static void group_break_exchange(CDeviceGroup &g)
 	CRccl *p_rccl = CRccl::p_Get();
 	if(p_rccl && p_rccl->CommAbort) {
 		for(size_t i = 0; i < g.comms.size(); ++ i) {
-			if(g.comms[i]) {
+			if(g.comms[i])
 				(void)p_rccl->CommAbort(g.comms[i]);
-				g.comms[i] = 0;
-			}
 		}
+		g.b_comms_aborted = true; // (aborted handles are released already: nothing left to destroy)
 	}
 	g.barrier.Abort();
 }
@@ -525,12 +530,13 @@ static int group_allreduce_callback(void *p_context, double *p_dev, size_t n_cou
 	CDeviceGroup &g = *t.p_group;
 	const int r = t.n_member, n_members = g.n_active;
 	hipStream_t stream = (hipStream_t)p_hip_stream;
+	const unsigned n_slot = (t.n_exchange_calls ++) & 1; // (the members call in step: one cannot be two calls ahead of another -- the barrier below)
 	if(g.n_exchange == EXCHANGE_RCCL) {
-		g.peer_counts[r] = n_count;
-		if(!group_members_agree(g)) // one member is not coming: nobody enqueues
+		g.peer_counts[n_slot][r] = n_count;
+		if(!group_members_agree(g) || g.b_exchange_broken) // one member is not coming: nobody enqueues
 			return 1;
 		for(int k = 0; k < n_members; ++ k) {
-			if(g.peer_counts[k] != n_count) {
+			if(g.peer_counts[n_slot][k] != n_count) {
 				g.barrier.Abort();
 				return 1; // the members do not agree on what they exchange
 			}
@@ -549,7 +555,7 @@ static int group_allreduce_callback(void *p_context, double *p_dev, size_t n_cou
 	// peer pointers: everybody's partial buffer complete and announced; slice r summed here; the other slices collected;
 	// nobody moves on (and writes its buffer again) before everybody has read what it needs
 	g.t_peer_buffers.p[r] = p_dev;
-	g.peer_counts[r] = n_count;
+	g.peer_counts[n_slot][r] = n_count;
 	if(hipStreamSynchronize(stream) != hipSuccess) {
 		g.barrier.Abort();
 		return 1;
@@ -557,7 +563,7 @@ static int group_allreduce_callback(void *p_context, double *p_dev, size_t n_cou
 	if(!group_members_agree(g))
 		return 1;
 	for(int k = 0; k < n_members; ++ k) {
-		if(g.peer_counts[k] != n_count) {
+		if(g.peer_counts[n_slot][k] != n_count) {
 			g.barrier.Abort();
 			return 1; // the members do not agree on what they exchange
 		}
@@ -713,11 +719,12 @@ static void group_release_exchange(CDeviceGroup &g)
 	if(!g.comms.empty()) {
 		if(CRccl *p_rccl = CRccl::p_Get()) {
 			for(size_t i = 0; i < g.comms.size(); ++ i) {
-				if(g.comms[i])
+				if(g.comms[i] && !g.b_comms_aborted) // (ncclCommAbort has freed an aborted one)
 					(void)p_rccl->CommDestroy(g.comms[i]);
 			}
 		}
 		g.comms.clear();
+		g.b_comms_aborted = false;
 	}
 }
 
@@ -959,6 +966,8 @@ static int group_finish(slampp_hip_solver &r_front, CDeviceGroup &g, int n_resul
 	// failed before it got there is a call behind the others.  Nobody is inside a solve now: everybody back to zero.
 	memset(g.n_factor_calls, 0, sizeof(g.n_factor_calls));
 	g.n_panel_sequence = 0;
+	for(size_t i = 0; i < g.contexts.size(); ++ i)
+		g.contexts[i].n_exchange_calls = 0; // (the same for the slots of the exchanged counts)
 	return n_result;
 }
 
@@ -1049,6 +1058,64 @@ static int group_solve_kind(slampp_hip_solver &r_front, const double *p_values, 
 	r_front.times.schur_ms = *std::max_element(solve_ms.begin(), solve_ms.end());
 	r_front.times.total_ms = wall_ms() - f_t0;
 	return group_finish(r_front, g, n_result, errors);
+}
+
+// The members read the front handle's staging by DMA from their own devices.  Memory pinned without the Portable flag is
+// pinned for the device that was current when it was pinned; another device's hipMemcpyAsync would then treat it as
+// pageable (a staged copy on the calling thread: still correct, a fraction of the rate, and no longer asynchronous) or,
+// on some configurations, refuse it.  Checked once per staging allocation, on every member's own thread and device:
+// the pointer must be registered host memory there, and one double must make the round trip.
+int group_check_staging(slampp_hip_solver &r_front, double *p_values, double *p_rhs)
+{
+	CDeviceGroup &g = *r_front.p_group;
+	if(g.p_checked_staging == p_values && g.p_checked_staging_rhs == p_rhs)
+		return SLAMPP_HIP_OK;
+	if(!p_values || !p_rhs)
+		return SLAMPP_HIP_OK; // (nothing allocated yet)
+	std::vector<std::string> errors(g.members.size());
+	const double f_probe = p_rhs[0];
+	const int n_result = g.p_threads->n_Run([&](int r) -> int {
+		if(r >= g.n_active)
+			return SLAMPP_HIP_OK;
+		hipPointerAttribute_t t_attr;
+		hipError_t e = hipPointerGetAttributes(&t_attr, p_values);
+		if(e != hipSuccess || t_attr.type != hipMemoryTypeHost) {
+			(void)hipGetLastError();
+			errors[r] = "device " + std::to_string(g.devices[r]) + " does not see the host staging as pinned memory (" +
+				((e != hipSuccess)? std::string(hipGetErrorString(e)) : std::string("memory type ") + std::to_string(int(t_attr.type))) + ")";
+			return SLAMPP_HIP_ERR_DEVICE;
+		}
+		double *p_dev = 0, f_back = 0;
+		hipStream_t stream = g.members[r]->stream;
+		e = hipMalloc((void**)&p_dev, sizeof(double));
+		if(e == hipSuccess)
+			e = hipMemcpyAsync(p_dev, p_rhs, sizeof(double), hipMemcpyHostToDevice, stream);
+		if(e == hipSuccess)
+			e = hipMemcpyAsync(&f_back, p_dev, sizeof(double), hipMemcpyDeviceToHost, stream);
+		if(e == hipSuccess)
+			e = hipStreamSynchronize(stream);
+		if(p_dev)
+			(void)hipFree(p_dev);
+		if(e != hipSuccess || memcmp(&f_back, &f_probe, sizeof(double))) {
+			(void)hipGetLastError();
+			errors[r] = "device " + std::to_string(g.devices[r]) + " cannot copy from the host staging (" +
+				((e != hipSuccess)? std::string(hipGetErrorString(e)) : std::string("the value read back differs")) + ")";
+			return SLAMPP_HIP_ERR_DEVICE;
+		}
+		return SLAMPP_HIP_OK;
+	});
+	if(n_result != SLAMPP_HIP_OK) {
+		r_front.s_error = "device group: ";
+		for(size_t r = 0; r < errors.size(); ++ r) {
+			if(!errors[r].empty())
+				r_front.s_error += errors[r] + "; ";
+		}
+		r_front.s_error += "the members upload their shards from that memory";
+		return SLAMPP_HIP_ERR_DEVICE;
+	}
+	g.p_checked_staging = p_values;
+	g.p_checked_staging_rhs = p_rhs;
+	return SLAMPP_HIP_OK;
 }
 
 int group_factor_solve(slampp_hip_solver &r_front, const double *p_values, double *p_rhs_inout)

@@ -535,6 +535,8 @@ bool launch_factor_panel(int n_dim, bool b_fused, bool b_rows, const TPanelLaunc
 	if(n_grid <= 0)
 		return true;
 	const size_t n_lds_bytes = size_t(panel_lds(n_dim, b_fused, r_cfg).TOTAL) * sizeof(double);
+	if(n_lds_bytes > PANEL_LDS_BUDGET)
+		return false; // (the analysis keeps every stage inside the budget: solver.hip, the hand-up lists; a launch past it would fail with a device error on a valid system)
 	// (beyond 64 KB of dynamic LDS a kernel has to be told once)
 #define LAUNCH_PANEL_INSTANCE(D, WW, F, RW) do { \
 		static bool b_attribute_set = false; \

@@ -173,7 +173,7 @@ private:
 
 	bool Find_Index_Cut(const std::vector<int32_t> &S, int32_t id, TIndexCut &r_cut)
 	{
-		static const int min_size = getenv("ND_MIN")? atoi(getenv("ND_MIN")) : 64, max_sep = getenv("ND_SEP")? atoi(getenv("ND_SEP")) : 4; // (development knobs)
+		const int min_size = dev_knob("SLAMPP_HIP_DEV_ND_MIN", 64), max_sep = dev_knob("SLAMPP_HIP_DEV_ND_SEP", 4); // (development knobs, plan.h)
 		const size_t n_size = S.size();
 		if(n_size < size_t(min_size) || n_size <= size_t(m_leaf) * 4 || !std::is_sorted(S.begin(), S.end()))
 			return false;

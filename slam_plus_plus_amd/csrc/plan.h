@@ -4,11 +4,21 @@
 // (/root/reference/include/slam/LinearSolver_UberBlock.h:285-310) while its CHOLMOD wrapper
 // orders the 6x larger scalar graph (/root/reference/src/slam/LinearSolver_CholMod.cpp:294-300).
 #pragma once
+#include <cstdlib>
 #include <cstdint>
 #include <string>
 #include <vector>
 
 namespace slampp {
+
+// Development knobs: integers read from the environment, and only when SLAMPP_HIP_DEV=1 is set there as well -- the
+// environment of the host application must not be able to change the ordering or the plan of every handle by accident
+// (until round 5 some of these were plain names: ND_MIN, ND_SEP).  Read at every use, never cached: the tools that sweep
+// them set them between two analyses of one process.
+inline bool dev_knobs_on() { const char *p = getenv("SLAMPP_HIP_DEV"); return p && atoi(p) != 0; }
+inline bool dev_knob_set(const char *p_s_name) { return dev_knobs_on() && getenv(p_s_name) != 0; }
+inline int dev_knob(const char *p_s_name, int n_default) { return dev_knob_set(p_s_name)? atoi(getenv(p_s_name)) : n_default; }
+
 
 struct Plan {
 	int32_t n = 0;                    // block columns

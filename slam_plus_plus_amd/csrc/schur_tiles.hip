@@ -15,7 +15,7 @@
 // memory, the sum order is fixed by the analysis (bit-reproducible, like the lists).
 // Landmarks with more cameras than a tile has room for that are in no run, and tiles whose landmarks share too little
 // (fewer than three contributions per block: random visibility), stay with the contribution lists.
-// SLAMPP_TILE_POINTS / SLAMPP_RUN_PIECE (environment) are development knobs for the landmarks per tile / per run piece.
+// SLAMPP_HIP_DEV_TILE_POINTS / SLAMPP_HIP_DEV_RUN_PIECE (environment, with SLAMPP_HIP_DEV=1: plan.h) are development knobs for the landmarks per tile / per run piece.
 #include "schur_tiles.h"
 
 #include <algorithm>
@@ -621,7 +621,7 @@ void build_run(TTileRun &R, const int32_t *p_order, int64_t n_first, int64_t n_l
 	const int32_t *brow)
 {
 	const int n_cap = SCHUR_TILE_SLOTS, n_max_k = tile_max_k(SCHUR_TILE_SLOTS);
-	const int n_max_points = getenv("SLAMPP_TILE_POINTS")? std::max(1, atoi(getenv("SLAMPP_TILE_POINTS"))) : int(SCHUR_TILE_MAX_POINTS);
+	const int n_max_points = std::max(1, dev_knob("SLAMPP_HIP_DEV_TILE_POINTS", int(SCHUR_TILE_MAX_POINTS)));
 	TSlotTable table;
 	std::vector<int32_t> cur_lm;
 	std::vector<int64_t> cur_keys;
@@ -766,7 +766,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 			}
 			return true;
 		};
-		const int64_t n_piece_max = getenv("SLAMPP_RUN_PIECE")? std::max(1, std::min(64, atoi(getenv("SLAMPP_RUN_PIECE")))) : 64;
+		const int64_t n_piece_max = std::max(1, std::min(64, dev_knob("SLAMPP_HIP_DEV_RUN_PIECE", 64)));
 		std::vector<TRunJob> jobs_nt[5][2][2];
 		// the jobs of one run: `members` (positions in `order`), longest camera list first -- every other member's list is that
 		// list or a prefix of it; pieces of at most 64 landmarks, a job per pair of observation blocks, over the piece's
@@ -776,7 +776,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 			// the long ones, and more of them spread better: 164 + 123 -> 130 + 103 us for the two widest kernels of the
 			// Venice-like C4, for 18 us more in the reduction of the partial blocks)
 			const int64_t k_run = k_of[p_members[0]];
-			const int64_t n_piece_len = (std::min<int64_t>(k_run, OB) * DC > 48 && !getenv("SLAMPP_RUN_PIECE"))? 32 : n_piece_max;
+			const int64_t n_piece_len = (std::min<int64_t>(k_run, OB) * DC > 48 && !dev_knob_set("SLAMPP_HIP_DEV_RUN_PIECE"))? 32 : n_piece_max;
 			for(int64_t f = 0; f < n_members; f += n_piece_len) {
 				const int64_t n_piece = std::min<int64_t>(n_piece_len, n_members - f);
 				const int32_t pt0 = p_members[f];
@@ -861,7 +861,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 			const int64_t k = ptr[nc + p + 1] - ptr[nc + p] - 1;
 			return int((std::min<int64_t>(k, OB) * DC + 15) / 16);
 		};
-		const bool b_chains = !getenv("SLAMPP_NO_PREFIX_RUNS");
+		const bool b_chains = !dev_knob_set("SLAMPP_HIP_DEV_NO_PREFIX_RUNS");
 		if(b_chains) {
 			std::sort(classes.begin(), classes.end(), [&](const TClass &a, const TClass &b) {
 				const int32_t p = order[a.n_first], q = order[b.n_first];

@@ -291,6 +291,9 @@ void group_destroy(CDeviceGroup *p_group);
 int group_set_option(CDeviceGroup &g, const char *p_s_name, int64_t n_value);
 void group_analyze(slampp_hip_solver &r_front, int64_t n_cut); // throws
 int group_factor_solve(slampp_hip_solver &r_front, const double *p_values, double *p_rhs_inout);
+// the front handle's pinned staging as every member's device sees it: registered host memory, and one double makes the
+// trip to the member's device and back; SLAMPP_HIP_ERR_DEVICE with the member and the reason in the front's error otherwise
+int group_check_staging(slampp_hip_solver &r_front, double *p_values, double *p_rhs);
 int group_solve_marginal_poses(slampp_hip_solver &r_front, const double *p_values, double *p_rhs_inout);
 int group_schur_marginals(slampp_hip_solver &r_front, const double *p_values, double *p_cam_cov, double *p_point_cov);
 int group_free_memory(CDeviceGroup &g);

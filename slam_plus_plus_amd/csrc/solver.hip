@@ -113,7 +113,9 @@ void slampp_hip_solver::Free_Staging()
 	n_uploaded = 0;
 }
 
-// Pinned host memory.  hipHostMalloc pays 0.2 ms per MB (62 ms for the 336 MB of C4's values, measured): nearly all of
+// Pinned host memory, pinned for EVERY device of the process (the Portable flags): the members of a device group DMA
+// their shards out of the front handle's staging, each over its own link (group.hip checks that they can, see
+// group_check_staging).  hipHostMalloc pays 0.2 ms per MB (62 ms for the 336 MB of C4's values, measured): nearly all of
 // it is the kernel handing out and clearing 4 kB pages one at a time.  The same memory as 2 MB pages (madvise, where
 // transparent huge pages are on or on request), first touched by a few threads and then registered, costs 1 - 5 ms
 // and moves at the same 54 GB/s; without huge pages it is still no slower than hipHostMalloc.
@@ -156,7 +158,7 @@ static double *Alloc_Pinned(size_t n_doubles, bool &r_b_registered) // throw(std
 			} catch(std::system_error&) {
 				// no more threads to be had: the registration below touches the pages itself
 			}
-			if(hipHostRegister(p, n_bytes, hipHostRegisterDefault) == hipSuccess) {
+			if(hipHostRegister(p, n_bytes, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess) {
 				r_b_registered = true;
 				return (double*)p;
 			}
@@ -165,7 +167,7 @@ static double *Alloc_Pinned(size_t n_doubles, bool &r_b_registered) // throw(std
 		}
 	}
 	double *p = 0;
-	const hipError_t e = hipHostMalloc((void**)&p, n_bytes, hipHostMallocDefault);
+	const hipError_t e = hipHostMalloc((void**)&p, n_bytes, hipHostMallocPortable | hipHostMallocMapped);
 	if(e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
 		(void)hipGetLastError();
 		throw std::bad_alloc();
@@ -847,6 +849,16 @@ void slampp_hip_solver::Analyze_Sparse()
 	std::vector<int32_t> panel_rest;
 	std::vector<TUpdSlot> upd_slots;
 	std::vector<TUpdEnt> upd_ents;
+	// (a second pass, without hand-ups, if a stage's hand-up list would take its workgroups past the LDS of a CU: the list
+	// rides in the dynamic LDS request on top of the task's image, and nothing else bounds its length -- advisor, round 4)
+	for(bool b_hand_up_allowed = n_panel_handup != 0;;) {
+	panel_pkg.clear();
+	panel_off.clear();
+	panel_out_off.clear();
+	n_handup_doubles = 0;
+	panel_rest.clear();
+	upd_slots.clear();
+	upd_ents.clear();
 	panel_ptr.clear();
 	panel_rest_ptr.clear();
 	panel_upd_ptr.clear();
@@ -869,8 +881,8 @@ void slampp_hip_solver::Analyze_Sparse()
 		struct THandUp { std::vector<TPanelOut> recs; std::vector<uint32_t> pairs; };
 		std::vector<THandUp> hand_up; // indexed by package
 		std::map<std::pair<int32_t, int64_t>, int32_t> out_of; // (source package, target factor block) -> record of that package
-		const bool b_hand_up = n_panel_handup != 0;
-		const int n_handup_max_tasks = getenv("SLAMPP_HANDUP_MAX_TASKS")? atoi(getenv("SLAMPP_HANDUP_MAX_TASKS")) : (1 << 30); // (measured at C3: handing up from the 2 420-task stage as well 224 -> 208 us for the separator launches, from the narrow stages only 224 -> 214)
+		const bool b_hand_up = b_hand_up_allowed;
+		const int n_handup_max_tasks = dev_knob("SLAMPP_HIP_DEV_HANDUP_MAX_TASKS", 1 << 30); // (measured at C3: handing up from the 2 420-task stage as well 224 -> 208 us for the separator launches, from the narrow stages only 224 -> 214)
 		std::vector<int64_t> order; // the task's columns (indices into cols) level by level
 		for(int s = 0; s < n_stages; ++ s) {
 			for(int64_t i = P.task_ptr[P.stage_ptr[s]]; i < P.task_ptr[P.stage_ptr[s + 1]]; ++ i)
@@ -882,7 +894,7 @@ void slampp_hip_solver::Analyze_Sparse()
 		std::vector<TPanelSlot> pslots;
 		panel_ride.assign(n_stages + 1, 0);
 		panel_cfg.assign(size_t(n_stages) + 1, TPanelLaunch{int32_t(PANEL_W), int32_t(64 * PANEL_W), 1, 1, 1, 0});
-		const int n_ride_max_fresh = getenv("SLAMPP_PANEL_RIDE_FRESH")? atoi(getenv("SLAMPP_PANEL_RIDE_FRESH")) : 96;
+		const int n_ride_max_fresh = dev_knob("SLAMPP_HIP_DEV_PANEL_RIDE_FRESH", 96);
 		for(int s = 0; s < n_stages; ++ s) {
 			const bool b_panel_stage = s >= n_bottom_stages || (s == 0 && b_leaf_panels);
 			// Do this stage's updates from further down ride in the launch of the stage below?  Only if that is a panel launch,
@@ -893,11 +905,11 @@ void slampp_hip_solver::Analyze_Sparse()
 			// (round 4: two where it holds them several times over -- C3's 2 151-task launch 91 -> 78 us, the step 0.330 -> 0.318 ms;
 			// a million poses 2.185 -> 2.146; one wave per task is slower again, 169 against 147 us for C3's slice launches, and two
 			// waves for the 303-task launch as well 153: the development knobs below moved the lines)
-			static const int n_w4_min_tasks = getenv("SLAMPP_PANEL_W4_MIN")? atoi(getenv("SLAMPP_PANEL_W4_MIN")) : 512;
-			static const int n_w2_min_tasks = getenv("SLAMPP_PANEL_W2_MIN")? atoi(getenv("SLAMPP_PANEL_W2_MIN")) : 1024;
+			const int n_w4_min_tasks = dev_knob("SLAMPP_HIP_DEV_PANEL_W4_MIN", 512);
+			const int n_w2_min_tasks = dev_knob("SLAMPP_HIP_DEV_PANEL_W2_MIN", 1024);
 			const int n_stage_waves = (b_panel_stage && P.stage_ptr[s + 1] - P.stage_ptr[s] > n_w2_min_tasks)? 2 :
 				(b_panel_stage && P.stage_ptr[s + 1] - P.stage_ptr[s] > n_w4_min_tasks)? 4 : int(PANEL_W);
-			// hand-ups from the stage below (development knob SLAMPP_HANDUP_MAX_TASKS: only from stages of at most that many tasks --
+			// hand-ups from the stage below (development knob SLAMPP_HIP_DEV_HANDUP_MAX_TASKS: only from stages of at most that many tasks --
 			// a stage that fills the chip several times over is bound by throughput, and what its tasks compute for the stage
 			// above they compute instead of the next task's columns: C3's 2 420-task launch 70 -> 92 us; the stage above gains more)
 			const bool b_hand_up_stage = b_hand_up && s > 0 && P.stage_ptr[s] - P.stage_ptr[s - 1] <= n_handup_max_tasks;
@@ -914,7 +926,7 @@ void slampp_hip_solver::Analyze_Sparse()
 			const bool b_first_above_leaves = b_panel_stage && s == 1 && panel_ptr[1] == panel_ptr[0];
 			// (measured at C3 and not kept as the default: without its 5 816 riders the 2 420-task launch takes the same 67 us --
 			// its own tasks fill the chip for that long --, and the stage above, bringing in ~150 products a task, 32 instead of 23)
-			const bool b_below_crowded = getenv("SLAMPP_PANEL_SELF_ABOVE_CROWDED") != 0 && b_panel_stage && s > 0 && panel_ptr[s] - panel_ptr[s - 1] > 1024;
+			const bool b_below_crowded = dev_knob_set("SLAMPP_HIP_DEV_PANEL_SELF_ABOVE_CROWDED") && b_panel_stage && s > 0 && panel_ptr[s] - panel_ptr[s - 1] > 1024;
 			if(b_panel_stage && s > 0 && (panel_ptr[s] > panel_ptr[s - 1] || b_first_above_leaves)) {
 				int64_t n_max_fresh = 0, n_max_external = 0;
 				for(int t = P.stage_ptr[s]; t < P.stage_ptr[s + 1]; ++ t) {
@@ -1270,13 +1282,20 @@ void slampp_hip_solver::Analyze_Sparse()
 		} else
 			panel_pkg.resize(panel_pkg.size() + 64 * PANEL_W, longlong2{0, 0}); // speculative reads past the last package
 	}
+	bool b_lds_fits = true;
+	for(size_t i = 0; i < panel_cfg.size() && !panel_off.empty(); ++ i)
+		b_lds_fits = b_lds_fits && size_t(panel_lds(P.max_dim, true, panel_cfg[i]).TOTAL) * sizeof(double) <= PANEL_LDS_BUDGET;
+	if(b_lds_fits || !b_hand_up_allowed)
+		break;
+	b_hand_up_allowed = false;
+	}
 	SETUP_PHASE("packages");
 	d_panel_upd_slots.Upload(upd_slots, stream);
 	d_panel_upd_ents.Upload(upd_ents, stream);
 	d_panel_pkg.Upload(panel_pkg, stream);
 	d_panel_off.Upload(panel_off, stream);
 	d_panel_out_off.Upload(panel_out_off, stream);
-	d_handup.Alloc(size_t(std::max<int64_t>(n_handup_doubles, 1)));
+	d_handup.Alloc(size_t(std::max<int64_t>(n_handup_doubles, int64_t(P.max_dim) * P.max_dim + 8))); // (every wave of a fused panel launch prefetches one block + 8 from offset 0, hand-ups or not)
 	d_panel_rest.Upload(panel_rest, stream);
 	d_cols.Upload(cols, stream);
 	d_blks.Upload(blks, stream);
@@ -1603,10 +1622,11 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 				launch_panel_update(P.max_dim, d_panel_upd_slots.p() + panel_upd_ptr[s], panel_upd_ptr[s + 1] - panel_upd_ptr[s],
 					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream);
 			const int n_next = (s + 1 < n_stages && panel_ride[s + 1] == 1)? panel_upd_ptr[s + 2] - panel_upd_ptr[s + 1] : 0;
-			launch_factor_panel(P.max_dim, b_panel_fused, (n_panel_rows < 0)? P.max_dim >= 6 : n_panel_rows != 0, panel_cfg[s], d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s],
+			if(!launch_factor_panel(P.max_dim, b_panel_fused, (n_panel_rows < 0)? P.max_dim >= 6 : n_panel_rows != 0, panel_cfg[s], d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s],
 				d_panel_out_off.p() + panel_ptr[s], n_panels,
 				d_panel_upd_slots.p() + ((n_next > 0)? panel_upd_ptr[s + 1] : 0), n_next, d_panel_upd_ents.p(), p_values_dev, p_rhs_dev,
-				d_L.p(), d_Linv.p(), d_w.p(), d_handup.p(), p_flag, stream, dplan.p_timing);
+				d_L.p(), d_Linv.p(), d_w.p(), d_handup.p(), p_flag, stream, dplan.p_timing))
+				throw CDeviceError("panel launch refused: block size or LDS request outside what the analysis planned for");
 			if(panel_rest_ptr[s + 1] > panel_rest_ptr[s]) {
 				TDevPlan t_rest = dplan;
 				t_rest.task_map = d_panel_rest.p();
@@ -2335,6 +2355,10 @@ int slampp_hip_host_staging(slampp_hip_solver *p_solver, double **pp_values, dou
 		if(!s.b_has_structure)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "host_staging: set_structure was not called");
 		s.Require_Staging();
+		if(s.b_group_active && s.p_group) { // every member must be able to DMA from it: checked once per allocation
+			if(const int n_check = group_check_staging(s, s.p_pin_values, s.p_pin_rhs))
+				return n_check;
+		}
 		if(pp_values)
 			*pp_values = s.p_pin_values;
 		if(pp_rhs)

@@ -246,21 +246,24 @@ __device__ __forceinline__ void finish_diagonal_fixed(const TColDesc &cd, double
 // DPP row broadcast of a double: every lane gets the value of lane N of its own row of 16 lanes (row_newbcast, the one DPP
 // control the 64-bit ALU takes).  The fused multiply-add with a broadcast operand is inline assembly (the compiler keeps a
 // v_mov_b64_dpp + v_fmac_f64), and the two wait states a DPP read needs after a VALU write of the same register are the
-// caller's to provide (b_guard: an s_nop 1 in front): the hazard recogniser does not look inside inline assembly.
+// caller's to provide (b_guard: an s_nop 1 in front): the hazard recogniser does not look inside inline assembly.  The
+// statements are volatile: they keep the order they are written in, so an unguarded one can never be moved in front of the
+// guarded one that follows the write of its source (the scheduler was free to do that with the trailing columns' FMAs,
+// which do not depend on each other -- advisor, round 4).
 template <int N>
 __device__ __forceinline__ double dpp16_bcast(double v)
 {
 	double r;
-	asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(N));
+	asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(N));
 	return r;
 }
 template <int N, bool b_guard>
 __device__ __forceinline__ void dpp16_fmac(double &r_acc, double src, double mul) // acc += (src of lane N of the row) * mul
 {
 	if constexpr(b_guard)
-		asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(r_acc) : "v"(src), "v"(mul), "n"(N));
+		asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(r_acc) : "v"(src), "v"(mul), "n"(N));
 	else
-		asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(r_acc) : "v"(src), "v"(mul), "n"(N));
+		asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(r_acc) : "v"(src), "v"(mul), "n"(N));
 }
 
 // Cholesky of a block column held one scalar ROW per lane: lanes 0 .. D - 1 of every row of 16 lanes hold the rows of the

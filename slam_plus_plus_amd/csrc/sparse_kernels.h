@@ -132,6 +132,7 @@ inline __host__ __device__ constexpr int panel_fresh_batch(int n_waves) { return
 struct TPanelLds {
 	int IMAGE, VEC, LINV, TILE, OPS, YV, OUT, TOTAL;
 };
+enum { PANEL_LDS_BUDGET = 156 * 1024 }; // dynamic LDS a panel launch may ask for (gfx950: 160 KB per CU; the kernel's static arrays take the rest)
 inline __host__ __device__ TPanelLds panel_lds(int D, bool b_fused, const TPanelLaunch &c)
 {
 	const int DD = D * D, W = c.n_waves;

@@ -20,7 +20,9 @@ def test_compact_line_of_every_committed_full_record():
         if "metric" not in d:
             continue
         if d.get("ba_c5") and d["ba_c5"].get("phases_ms"):
-            d["scaling_model"] = bench.scaling_model(d["ba_c5"])
+            d["scaling_model"] = {key: bench.scaling_model(d[key], d[key].get("n_values", 145e6), d[key].get("n_scalars", 6e6),
+                                                           d[key].get("n_exchange_doubles", 3e5))
+                                  for key in ("ba_c5", "ba_1k_1m") if d.get(key)}
         text = bench.compact_line(d, "gpurun_out/bench_full_n1.json")
         assert len(text) < bench.COMPACT_LIMIT and "\n" not in text
         line = json.loads(text)
@@ -28,6 +30,9 @@ def test_compact_line_of_every_committed_full_record():
                   "dtype", "data", "config", "roofline", "cpu_baseline"):
             assert k in line, (f, k)
         assert line["roofline"]["frac"] > 0 and line["value"] > 0
+        if "scaling_model" in line:   # both readings of the north star's 8-GPU target, for every strong-scaling system
+            for m in line["scaling_model"].values():
+                assert "host_arrays" in m and m["host_arrays"]["8"] > m["device_resident"]["8"] > 1.0
 
 
 def test_compact_line_sheds_optional_parts_rather_than_grow():

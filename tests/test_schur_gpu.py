@@ -665,11 +665,13 @@ def test_prefix_runs_take_the_long_tracks_off_the_contribution_lists(sparse, mon
     assert solver.Solve_PosDef(lam, eta) and rel_inf(eta, x_ref) < TOL
     phases = solver.profile()
     assert "schur_tiles" in phases, phases
-    monkeypatch.setenv("SLAMPP_NO_PREFIX_RUNS", "1")
+    monkeypatch.setenv("SLAMPP_HIP_DEV", "1")                        # development knobs are read only with this set (csrc/plan.h)
+    monkeypatch.setenv("SLAMPP_HIP_DEV_NO_PREFIX_RUNS", "1")
     lists = CLinearSolver_Schur_HIP(schur_sparse=sparse, profile=1)
     eta2 = lam.rhs.copy()
     assert lists.Solve_PosDef(lam, eta2) and rel_inf(eta2, x_ref) < TOL and rel_inf(eta, eta2) < 1e-11
-    monkeypatch.delenv("SLAMPP_NO_PREFIX_RUNS")
+    monkeypatch.delenv("SLAMPP_HIP_DEV_NO_PREFIX_RUNS")
+    monkeypatch.delenv("SLAMPP_HIP_DEV")
     t_with = phases.get("schur_gather", (0, 0.0))[1] / max(phases.get("schur_gather", (1, 0))[0], 1)
     t_without = lists.profile()["schur_gather"][1] / lists.profile()["schur_gather"][0]
     assert t_with < 0.5 * t_without, (t_with, t_without)            # the long tracks were the lists' work
