@@ -127,58 +127,53 @@ void slampp_hip_destroy(slampp_hip_solver *p_solver);
 int slampp_hip_free_memory(slampp_hip_solver *p_solver);
 const char *slampp_hip_last_error(const slampp_hip_solver *p_solver);
 
-/* tuning knobs: "natural_order" (0/1: keep the caller's block order instead of nested dissection, default 0),
- * "leaf_size" (nested-dissection leaf, default 3), "nd_balance" (percent of the vertices a separator
- * must leave on either side, default 15), "subtree_size" (max columns one
- * wave eliminates sequentially, default 8), "task_height" (1 .. 8, default 6: above the wide stages a separator task is
- * a slice of the elimination tree this many levels high -- a launch then covers that many levels of the tree, the levels of
- * a slice run in parallel inside one workgroup, its blocks staying in LDS; 1 = one level per launch),
- * "dense_nb" (dense panel width, default 64),
- * "dense_top_nb" (sparse path: block columns with at least this many blocks, and their ancestors, are factored as
- * one dense matrix on the matrix cores; default: 24, or 16 / 36 where a model of the dependent launch chain clearly
- * prefers that; setting the option fixes the threshold; 0 = off), "dense_top_max_dim" (cap on its dimension, default 12288),
- * "dense_top_min_dim" (below this dimension there is no dense top, default 192),
- * "profile" (0 / 1 / 2 / 3, see slampp_hip_get_profile), "shard_primary" (multi-GPU BA: this rank adds A and eta_x),
- * "shard_rank" / "shard_world" (multi-GPU BA, optional: who this rank is among the ranks behind the all-reduce
- * callback; lets them exchange their block lists, which scales with the nonzero blocks of S, instead of an indicator
- * over all camera pairs, which is limited to 16384 cameras),
- * "dense_top_tiles" (sparse path: the dense top is factored tile column by tile column (0), or by the levels of its
- * tile elimination tree, touching only structurally nonzero 64x64 tiles (1); -1 = the latter when it shortens the
- * chain of dependent launches, default),
- * "schur_sparse" (Schur mode: the reduced camera system S is factored by the sparse block path instead of the dense
- * one; -1 = when fewer than 15 % of its camera-camera blocks are nonzero (default), 0 = never, 1 = always; the
- * reference makes this choice at compile time: __SCHUR_USE_DENSE_SOLVER, include/slam/LinearSolver_Schur.h:48-55, "faster if ... dense enough"),
- * "schur_incremental" (Schur mode, 0 / 1 / 2: keep the assembled reduced system for slampp_hip_schur_set_changed_points;
- * 1 = a solve with a list of changed landmarks updates it when that is the shorter way -- up to 1 / 32 of the landmarks
- * where S is assembled landmark by landmark, 1 / 4 where it comes from the contribution lists --, 2 = whenever a list is given),
- * "schur_tiles" (Schur mode: how S = A - U C^-1 U^T is assembled; -1 (default) = landmark by landmark -- runs of landmarks
- * seen by the same cameras on the matrix cores, tiles of neighbouring landmarks in LDS -- when that takes at least half of
- * the contributions, the per-block contribution lists for the rest; 0 = lists only; 1 / 2 / 3 = runs and tiles wherever
- * possible / tiles only / runs of any length),
- * "panel" (sparse path: -1 / 1 (default) = separator tasks are factored as panels in LDS, the updates from earlier stages
- * applied per factor block by a launch of its own; 0 = column by column),
- * "assembly_groups" (slampp_hip_assembly_create: the most vertices one group of the Lambda assembly takes -- a group is a
- * run of consecutive vertices whose edges fit in LDS together, so that every edge record is read once for its
- * off-diagonal block and both diagonal blocks; default: as many as fit; 0 = no groups, one wave per block of Lambda),
- * "staging_ahead" (0 / 1: slampp_hip_analyze also brings up the pinned host staging of slampp_hip_host_staging, on a host
- * thread of its own next to the ordering and the symbolic analysis -- for callers that will hand over host arrays (the header
- * class sets it); callers that keep Lambda on the device leave it off and never pay for the staging),
- * "schur_fallback" (Schur mode, default 1: a structure the Schur kernels do not take -- no landmark part, landmark-landmark
- * blocks, block sizes other than (6,3), (7,3), (3,2) -- is solved through the sparse block path, as the reference solves it
- * (LinearSolver_Schur.h:1635-1638, 1721-1726); 0 = slampp_hip_analyze reports SLAMPP_HIP_ERR_UNSUPPORTED / _INVALID instead),
- * "group_exchange" (handles made by slampp_hip_create_multi, see there), "wide_min_tasks" (default 8192: stages with more tasks
- * run one wave per single-column task; below that, tasks are slices of the elimination tree, option "task_height"),
- * "marginals_dense" (Schur mode: 1 = slampp_hip_schur_marginals always inverts the reduced system densely; 0 (default) =
- * when the solves factor it by the sparse block path, the covariances take the blocks of S^-1 they need from a
- * sparse inverse subset on that factor's pattern),
- * "panel_rows" (sparse path, -1 (default) / 0 / 1: a level of a separator task is walked block column by block column as
- * rows -- lanes of a 16-lane row per matrix row --; -1 = where the blocks are 6 x 6 or larger),
- * "panel_handup" (0 / 1, default 1: a separator task also computes what the next stage's tasks need from its blocks and
- * hands it up in one buffer), "panel_top" (0 / 1, default 0: the last stages that fit one workgroup's LDS together as one
- * task; measured slower), "simt" / "simt_width" / "simt_stages" (the lane-per-task kernels of the wide bottom stages),
- * "simt_backward" (-1 (default) / 0 / 1: the leaf subtrees' backward substitution a lane per task as well, and no inv(L_jj)
- * stored for them by the factorization -- whoever needs those later (another right-hand side, covariances) has them
- * computed from the factor; -1 = from 12 288 leaf subtrees on) */
+/* Options (19).  All but the ones marked (*) take effect at the next slampp_hip_analyze.
+ *
+ * ordering / schedule of the sparse block path
+ *   "natural_order"      0 / 1: keep the caller's block order instead of nested dissection (default 0; what
+ *                        Factorize_PosDef_Blocky needs: the reference factors the matrix as it is ordered)
+ *   "leaf_size"          nested-dissection leaf, in block columns (default 3)
+ *   "subtree_size"       most columns one wave eliminates sequentially at the bottom of the tree (default 8)
+ *   "task_height"        1 .. 8 (default 6): above the wide stages a separator task is a slice of the elimination tree this
+ *                        many levels high; a launch covers that many levels, the slice's blocks stay in LDS
+ *   "dense_top_nb"       block columns with at least this many blocks, and their ancestors, are factored as one dense matrix on
+ *                        the matrix cores (default 24, or 16 / 36 where a model of the dependent launch chain prefers that;
+ *                        setting the option fixes the threshold; 0 = off)
+ *   "dense_top_max_dim"  cap on its dimension (default 12288)
+ *   "dense_top_min_dim"  below this dimension there is no dense top (default 192)
+ * Schur mode
+ *   "schur_sparse"       how the reduced camera system S is factored: -1 (default) = by the sparse block path when fewer than
+ *                        15 % of its camera-camera blocks are nonzero, 0 = dense on the matrix cores, 1 = sparse (the reference
+ *                        chooses at compile time: __SCHUR_USE_DENSE_SOLVER, include/slam/LinearSolver_Schur.h:48-55)
+ *   "schur_tiles"        how S = A - U C^-1 U^T is assembled: -1 (default) = landmark by landmark (runs of landmarks seen by the
+ *                        same cameras on the matrix cores, tiles of neighbouring landmarks in LDS) where that takes at least
+ *                        half of the contributions, per-block contribution lists for the rest; 0 = lists only; 1 / 2 / 3 =
+ *                        runs and tiles wherever possible / tiles only / runs of any length
+ *   "schur_incremental"  0 / 1 / 2: keep the assembled S for slampp_hip_schur_set_changed_points; 1 = a solve with a list of
+ *                        changed landmarks updates it when that is the shorter way, 2 = whenever a list is given
+ *   "schur_fallback"     default 1: a structure the Schur kernels do not take (no landmark part, landmark-landmark blocks,
+ *                        block sizes other than (6,3), (7,3), (3,2)) is solved by the sparse block path, as the reference
+ *                        solves it (LinearSolver_Schur.h:1635-1638, 1721-1726); 0 = slampp_hip_analyze reports
+ *                        SLAMPP_HIP_ERR_UNSUPPORTED / _INVALID instead
+ *   "marginals_dense"    (*) 1 = slampp_hip_schur_marginals always inverts S densely; 0 (default) = a sparse inverse subset on
+ *                        the factor's pattern when the solves factor S by the sparse block path
+ * several GPUs
+ *   "shard_primary"      process-per-GPU sharding: this rank adds A and eta_x (default 1)
+ *   "shard_rank", "shard_world"  (*) optional: who this rank is among the ranks behind the all-reduce callback; lets them
+ *                        exchange their block lists instead of an indicator over all camera pairs (limited to 16384 cameras)
+ *   "group_exchange"     handles made by slampp_hip_create_multi, see there
+ * host side
+ *   "staging_ahead"      (*) 0 / 1: slampp_hip_analyze also brings up the pinned host staging of slampp_hip_host_staging on a
+ *                        thread of its own next to the ordering (callers that hand over host arrays: the header class sets it)
+ *   "assembly_groups"    (*) slampp_hip_assembly_create: the most vertices one group of the Lambda assembly takes (default: as
+ *                        many as fit in LDS; 0 = no groups, one wave per block of Lambda)
+ *   "profile"            (*) 0 / 1 / 2 / 3, see slampp_hip_get_profile
+ *
+ * Anything else set_option knows ("panel", "panel_rows", "panel_handup", "simt", "simt_width", "simt_stages",
+ * "simt_backward", "wide_min_tasks", "nd_balance", "dense_nb", "dense_top_tiles", "schur_distributed", "group_fail_member")
+ * is a development option: an alternative the defaults were measured against, or a test hook.  They are refused with
+ * SLAMPP_HIP_ERR_INVALID unless the process runs with SLAMPP_HIP_DEV=1, and are described where they are implemented
+ * (csrc/solver.h). */
 int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int64_t n_value);
 
 /* structure of Lambda -- stands in for what the reference's wrappers read through

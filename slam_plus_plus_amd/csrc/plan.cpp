@@ -616,21 +616,11 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 	const int32_t *brow, const PlanOptions &r_opt, Plan &P)
 {
 	PlanOptions opt = r_opt;
-	if(const char *p_s_height = getenv("SLAMPP_HIP_TASK_HEIGHT")) // development aid: overrides the option
-		opt.task_height = std::min(std::max(atoi(p_s_height), 1), 8);
-	if(const char *p_s_cols = getenv("SLAMPP_HIP_TASK_MAX_COLS")) // development aids: likewise
-		opt.task_max_cols = std::min(std::max(atoi(p_s_cols), 1), 64);
-	if(const char *p_s_blocks = getenv("SLAMPP_HIP_TASK_MAX_BLOCKS"))
-		opt.task_max_blocks = std::min(std::max(atoi(p_s_blocks), 1), 1024);
-	if(const char *p_s_top = getenv("SLAMPP_HIP_TASK_TOP")) { // "cols,blocks": the top of the tree as one task (tests of the host plan without a solver)
-		int n_top_cols = 0, n_top_blocks = 0;
-		if(sscanf(p_s_top, "%d,%d", &n_top_cols, &n_top_blocks) == 2) {
-			opt.task_top_cols = std::max(n_top_cols, 0);
-			opt.task_top_blocks = std::max(n_top_blocks, 0);
-		}
-	}
-	if(const char *p_s_balance = getenv("SLAMPP_HIP_ND_BALANCE")) // development aid: likewise
-		opt.nd_balance_pct = std::min(std::max(atoi(p_s_balance), 1), 49);
+	// development aids (environment, with SLAMPP_HIP_DEV=1: plan.h): override the options of the same names
+	opt.task_height = std::min(std::max(dev_knob("SLAMPP_HIP_DEV_TASK_HEIGHT", opt.task_height), 1), 8);
+	opt.task_max_cols = std::min(std::max(dev_knob("SLAMPP_HIP_DEV_TASK_MAX_COLS", opt.task_max_cols), 1), 64);
+	opt.task_max_blocks = std::min(std::max(dev_knob("SLAMPP_HIP_DEV_TASK_MAX_BLOCKS", opt.task_max_blocks), 1), 1024);
+	opt.nd_balance_pct = std::min(std::max(dev_knob("SLAMPP_HIP_DEV_ND_BALANCE", opt.nd_balance_pct), 1), 49);
 	P = Plan();
 	if(n_bcols <= 0 || n_bcols > INT32_MAX / 2)
 		return "invalid number of block columns";
@@ -1108,46 +1098,6 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 				}
 				col_stage[j] = s;
 				P.col_sub[j] = u;
-			}
-			// Round 4: the top of the tree as one task.  The last stages hold 1, 2, 4, ... slices: each of them a launch of the
-			// factorization and one of the backward substitution, almost all fixed cost (boundary, package, image: ~6 + ~4 us
-			// against 1.5 us a level).  As many of the last stages as fit the top capacities together become one slice, its levels
-			// numbered through (a column's children are in an earlier stage or an earlier level of its own: still below it).
-			if(opt.task_top_cols > 0 && opt.task_top_blocks > 0) {
-				int32_t s_max = -1;
-				for(int32_t j = 0; j < n; ++ j) {
-					if(!in_dense[j] && b_tall[j])
-						s_max = std::max(s_max, col_stage[j]);
-				}
-				if(s_max >= n_first_tall) {
-					std::vector<int64_t> st_cols(size_t(s_max) + 1, 0), st_blocks(size_t(s_max) + 1, 0);
-					for(int32_t j = 0; j < n; ++ j) {
-						if(!in_dense[j] && b_tall[j]) {
-							++ st_cols[col_stage[j]];
-							st_blocks[col_stage[j]] += P.lptr[j + 1] - P.lptr[j];
-						}
-					}
-					int32_t s_star = s_max + 1;
-					int64_t n_cols_top = 0, n_blocks_top = 0;
-					while(s_star > n_first_tall && n_cols_top + st_cols[s_star - 1] <= opt.task_top_cols &&
-					   n_blocks_top + st_blocks[s_star - 1] <= opt.task_top_blocks) {
-						-- s_star;
-						n_cols_top += st_cols[s_star];
-						n_blocks_top += st_blocks[s_star];
-					}
-					if(s_max + 1 - s_star >= 2) {
-						int32_t n_root = -1;
-						for(int32_t j = 0; j < n; ++ j) {
-							if(in_dense[j] || !b_tall[j] || col_stage[j] < s_star)
-								continue;
-							if(n_root < 0)
-								n_root = j;
-							grp[j] = n_root;
-							P.col_sub[j] += (col_stage[j] - s_star) * h;
-							col_stage[j] = s_star;
-						}
-					}
-				}
 			}
 			// the tasks again: those of the stages below as they were, one per slice above (ids ascend with the first column)
 			std::vector<int32_t> new_task(n_tasks, -1), slice_task(n, -1), new_level;

@@ -86,8 +86,6 @@ struct PlanOptions {
 	                          // 96 blocks: 10 / 96 and 12 / 128 leave the panel path, 6 / 64 is 7 % slower at C3)
 	int task_wide_min = 1024; // ... above the wide stages: a stage with more tasks than this stays one level high (throughput, not latency)
 	int task_max_cols = 8, task_max_blocks = 96; // what such a slice may hold (the panel kernel's capacities)
-	int task_top_cols = 0, task_top_blocks = 0;  // > 0: the stages at the top of the tree that fit these together become ONE task (a launch saved per
-	                                             // merged stage: near the root a stage is a handful of tasks and all fixed cost)
 	int dense_top_nb = 24;    // columns with this many blocks or more (and their ancestors) form the dense top; 0 = off
 	bool dense_top_auto = true; // when that gives a dense top, also try 16 and 36 and keep the plan whose estimated chain
 	                            // of dependent launches is shortest (the caller did not ask for a specific threshold)

@@ -394,7 +394,7 @@ bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, int n_width, int
 	// Two lanes per task is a third more work per task (both lanes of a pair do the column's diagonal block) for half the
 	// dependent chain of the blocks below it: it pays while the launch leaves the chip's SIMDs short of waves (C3: 497
 	// waves on 1 024 SIMDs, 120 -> 100 us) and costs where they are full (a million poses: 716 -> 779 us).
-	static const int n_pairs_env = getenv("SLAMPP_HIP_SIMT_PAIRS")? atoi(getenv("SLAMPP_HIP_SIMT_PAIRS")) : -1; // development aid
+	const int n_pairs_env = dev_knob("SLAMPP_HIP_DEV_SIMT_PAIRS", -1); // development aid (plan.h)
 	const bool b_pairs = (n_pairs_env >= 0)? n_pairs_env != 0 : n_chunks <= 2048;
 	switch(n_dim) {
 	case 3:

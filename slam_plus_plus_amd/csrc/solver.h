@@ -145,9 +145,6 @@ struct slampp_hip_solver {
 	slampp::CDevArray<int64_t> d_panel_off, d_panel_out_off;
 	slampp::CDevArray<double> d_handup; // the blocks the panel tasks hand up to the next stage's (TPanelOut)
 	bool b_any_hand_up = false;
-	int n_panel_top = 0; // option "panel_top": 1 = the last stages of the tree that fit one workgroup's LDS together are one task (round 4: measured
-	                     // slower -- the updates between the merged stages, spread over tasks and update workgroups before, become one workgroup's
-	                     // internal updates: band reduced system 212 -> 226 us, C3 unchanged), 0 = a launch per stage
 	int n_panel_handup = 1; // option "panel_handup": 1 = a panel task computes what it owes the next stage's tasks out of its own image (round 4), 0 = they fetch the operands
 	slampp::CDevArray<int32_t> d_panel_rest;
 	slampp::CDevArray<slampp::TUpdSlot> d_panel_upd_slots; // the factor blocks of the panel tasks, stage by stage, and the
@@ -313,3 +310,8 @@ void assembly_enqueue(CAssemblyState &a, const double *J0, const double *J1, con
 size_t assembly_device_bytes(const CAssemblyState *p);
 
 } // namespace slampp
+
+// staging.hip: the transfers the host entry points of capi.hip are made of
+void Parallel_Copy(double *p_dst, const double *p_src, size_t n);             // a host copy on a few threads (the solution back into the caller's array)
+void Upload_Rhs_And_Join(slampp_hip_solver &s, const double *p_rhs);          // eta through the staging; the main stream then waits for the copy stream
+void Upload_Values_And_Join(slampp_hip_solver &s, const double *p_values);    // Lambda's packed values likewise

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "plan.h" // (dev_knob)
 
 namespace slampp {
 
@@ -106,10 +107,6 @@ struct TUpdEnt { // 16 B
 	int64_t b_off; // offset of L(j,c) (row entries: scalar offset of y_c in the workspace)
 };
 inline int panel_slot_cap(int n_dim) { return (n_dim == 6)? 96 : (n_dim == 7)? 72 : 256; }
-// ... of the one task the top stages of the tree are merged into (Plan: task_top_cols / task_top_blocks): the image alone may take
-// 64 KB of the CU's 160
-enum { PANEL_TOP_COLS = 48, PANEL_TOP_UNITS = 3072 };
-inline int panel_top_slot_cap(int n_dim) { return (n_dim == 6)? 224 : (n_dim == 7)? 160 : 640; }
 
 // How one stage's panel launch is shaped (decided per stage by the host): waves per task -- 8 where a stage is a launch on
 // the critical path (latency of one task), 4 where it holds more tasks than the chip takes at once (throughput: more

@@ -32,7 +32,7 @@ namespace slampp {
 #include "sparse_device.inl"
 
 // ---- bottom stage: whole elimination subtrees, one wave each (touches most of Lambda and L) ----
-// First version, through global memory; used for mixed block sizes (D = 0) and, with SLAMPP_HIP_SUBTREE_V1 set, for
+// First version, through global memory; used for mixed block sizes (D = 0) and, with SLAMPP_HIP_DEV_SUBTREE_V1 set (and SLAMPP_HIP_DEV=1), for
 // A/B timing against subtree_kernel.hip, which took over the fixed block sizes.  With 8 waves per SIMD resident it is
 // bound by instruction issue, not by memory latency (the LDS version runs at the same speed: DESIGN.md section 4.1),
 // so it keeps the instruction count per column low: one block, one update at a time.
@@ -648,7 +648,7 @@ void launch_factor_stage(const TDevPlan &p, const double *A, double *L, double *
 	if(n_tasks <= 0)
 		return;
 	if(b_bottom_stage) { // one wave per task (the host decides which stages: solver.hip, n_bottom_stages)
-		static const bool b_first_version = getenv("SLAMPP_HIP_SUBTREE_V1") != 0; // development aid: A/B timing
+		const bool b_first_version = dev_knob_set("SLAMPP_HIP_DEV_SUBTREE_V1"); // development aid: A/B timing (plan.h)
 		if(!b_first_version && launch_factor_subtree_image(p, A, L, Linv, b, w, task_begin, n_tasks, p_flag, stream))
 			return;
 		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_subtree_kernel<D>), dim3(n_tasks), dim3(64), 0, stream,

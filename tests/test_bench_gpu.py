@@ -85,8 +85,15 @@ def test_bench_default_run_carries_the_n1_points_of_the_scaling_curves():
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     line = last_json(r.stdout, full=False)
-    assert set(("ba_schur", "ba_c5", "ba_1k_1m")) <= set(line["legs"]) and line["scaling_model"]["serial_ms"] > 0
-    assert set(line["scaling_model"]["predicted_speedup"]) == {"2", "4", "8"}
+    assert set(("ba_schur", "ba_c5", "ba_1k_1m")) <= set(line["legs"])
+    # the model of BOTH strong-scaling systems, device-resident and from host arrays (where the 8 PCIe links are)
+    assert set(line["scaling_model"]) == {"ba_c5", "ba_1k_1m"}
+    for m in line["scaling_model"].values():
+        assert m["serial_ms"] > 0 and set(m["device_resident"]) == set(m["host_arrays"]) == {"2", "4", "8"}
+        assert m["host_arrays"]["8"] > m["device_resident"]["8"]
+    assert line["cond_proxy"] > 1 and 0 < line["inter_oracle_spread"] < 1e-9 and line["solve_x_vs_reference_rel_inf"] < 1e-10
+    assert set(line["speedup_vs_reference"]) == {"numeric_phases_device_resident", "dropin_caller_vs_cholmod_per_call",
+                                                 "dropin_caller_vs_reference_best_warm"}
     d = last_json(r.stdout)
     assert d["n_gpus"] == 1 and "C3" in d["config"]["workload"]
     for key in ("ba_schur", "ba_c5", "ba_1k_1m"):
@@ -104,6 +111,8 @@ def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     line = last_json(r.stdout, full=False)
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["rccl_ranks"] == 2 and line["dist_backend"] == "gloo"      # (gloo: only under SLAMPP_BENCH_ONE_DEVICE=1)
+    assert line["host_path_speedup_vs_single_device"] > 0 and "host_path" in line["north_star_4x_read_on"]
 
 
 def test_bench_refuses_more_gpus_than_there_are():

@@ -58,76 +58,6 @@ def test_plan_replay_detects_indefinite():
     assert status == 1
 
 
-@pytest.mark.parametrize("make", [
-    lambda: synth.pose_chain(n=5000, d=6, seed=21),
-    lambda: synth.sphere(40, 40, seed=22),
-    lambda: synth.manhattan(2000, seed=23),
-    lambda: synth.ba(30, 3000, mode="venice", seed=24),     # mixed block sizes, many single-vertex components
-], ids=["chain5000", "sphere1600", "manhattan2000", "ba_mixed"])
-def test_plan_replay_matches_oracle_medium(make):
-    lam = make()
-    if lam.n_matrix_cut:   # cameras-first natural order fills in completely under the sparse oracle: use the Schur one
-        ok, x_ref, _, _ = O.solve_schur(lam)
-    else:
-        ok, x_ref, _ = O.solve_sparse(lam)
-    for dense_nb in (-1, 0):          # default dense top (active on the 2-D-like graphs) and none
-        plan, stats = host_plan(lam, dense_top_nb=dense_nb)
-        check_plan_invariants(lam, plan)
-        status, x = O.exec_plan(lam, plan)
-        assert ok and status == 0 and rel_inf(x, x_ref) < TOL
-
-
-def test_dense_top_is_used_where_separators_are_big_and_not_on_chains():
-    _, st_grid = host_plan(synth.sphere(40, 40, seed=22))
-    _, st_chain = host_plan(synth.pose_chain(n=5000, d=6, seed=21))
-    assert st_grid["schur_dim"] >= 192 and st_chain["schur_dim"] == 0
-
-
-def test_nested_dissection_exposes_parallelism_on_a_chain():
-    """The point of the ordering: a 20k-pose chain must not become a 20k-deep elimination path
-    (AMD's tree for a chain is essentially a path, SURVEY.md section 7 'hard parts')."""
-    lam = synth.pose_chain(n=20000, d=6, seed=31)
-    _, stats = host_plan(lam)
-    assert stats["etree_height"] < 100
-    assert stats["n_stages"] < 40
-    # fill stays close to what a banded/AMD ordering gives (about 2 blocks per column + loop closures)
-    assert stats["l_blocks"] < 4.0 * lam.n_bcols
-
-
-def test_structure_errors_are_reported():
-    lam = synth.pose_chain(n=10, d=6)
-    import dataclasses
-    bad = dataclasses.replace(lam, brow_idx=lam.brow_idx[::-1].copy())   # rows not sorted / not upper
-    with pytest.raises(ValueError):
-        host_plan(bad)
-
-
-@pytest.mark.parametrize("make", [
-    lambda: synth.pose_chain(n=5000, d=6, seed=21),
-    lambda: synth.pose_chain(n=5000, d=3, seed=25, loop_every=10),
-    lambda: synth.manhattan(2000, seed=23),
-], ids=["chain5000", "chain5000_se2_loops", "manhattan2000"])
-def test_top_of_the_tree_as_one_task(make, monkeypatch):
-    """Round 4 (PlanOptions::task_top_cols / task_top_blocks, what the solver sets with option panel_top): as many of the
-    last stages as fit the capacities together become ONE task -- fewer stages, the same columns, and a schedule the CPU
-    replay still accepts (every operand produced in an earlier stage or earlier in the same task) with the same solution."""
-    lam = make()
-    ok, x_ref, _ = O.solve_sparse(lam)
-    plan0, st0 = host_plan(lam, dense_top_nb=0)
-    monkeypatch.setenv("SLAMPP_HIP_TASK_TOP", "48,224")
-    plan1, st1 = host_plan(lam, dense_top_nb=0)
-    monkeypatch.delenv("SLAMPP_HIP_TASK_TOP")
-    check_plan_invariants(lam, plan1)
-    assert st1["n_stages"] < st0["n_stages"] and st1["n_stages"] >= 2
-    assert np.array_equal(plan0["perm"], plan1["perm"]) and np.array_equal(plan0["lrow"], plan1["lrow"])   # only the schedule differs
-    last = slice(int(plan1["task_ptr"][plan1["stage_ptr"][-2]]), None)
-    assert plan1["stage_ptr"][-1] - plan1["stage_ptr"][-2] == 1                   # one task at the top ...
-    n_top = len(plan1["task_cols"][last])
-    assert 8 < n_top <= 48                                                         # ... bigger than a slice, within the capacity
-    status, x = O.exec_plan(lam, plan1)
-    assert ok and status == 0 and rel_inf(x, x_ref) < TOL
-
-
 @pytest.mark.parametrize("n,every", [(10000, 50), (20000, 50), (8000, 10)])
 def test_pose_chains_are_cut_by_vertex_number(n, every):
     """Round 4: where few edges cross "the vertices below some number", that cut is the bisection (plan.cpp,
