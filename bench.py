@@ -357,6 +357,8 @@ def run_c3(args, rank, world, local_rank, dist):
         return out
     out["assembly"] = assembly_leg(solver, lam, dev)
     if world == 1:
+        out["replicas_one_gpu"] = replicas_leg(lam, counts, dev, local_rank, torch)
+    if world == 1:
         out["marginals"] = marginals_leg_c3(args, solver, lam, vals, dev, torch)
     if world == 1:
         out["host_path"] = host_path_leg(lambda: CLinearSolver_HIP(device=local_rank), lam)
@@ -366,6 +368,50 @@ def run_c3(args, rank, world, local_rank, dist):
         out["inter_oracle_spread"] = out["cpu_baseline"].get("inter_oracle_spread")
         out["cond_proxy"] = out["cpu_baseline"].get("cond_proxy")
         out["dropin_cpp"] = dropin_leg(lam)
+    return out
+
+
+def replicas_leg(lam, counts, dev, local_rank, torch, ks=(1, 2, 4, 8), steps=10):
+    """SURVEY.md section 8(e), second row: pose graphs do not shard -- "replicas only (multiple independent problems /
+    damping values per GPU)".  K independent solves of the SAME structure on ONE device, each on a handle (and HIP stream)
+    of its own: what an LM loop trying K damping values at once, or K robots' graphs, would enqueue
+    (/root/reference/include/slam/NonlinearSolver_Lambda_LM.h:967-1001, 1660-1676: the reference re-damps and re-solves one after
+    the other).  A single C3 solve is a chain of 12 dependent launches that fills a fraction of the chip; K chains side by
+    side is the throughput the device has for this workload.  Reported: aggregate GFLOP/s and the whole-step HBM fraction
+    on SURVEY 8d's algorithmic bytes, per K."""
+    from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP
+    k_max = max(ks)
+    solvers = [CLinearSolver_HIP(device=local_rank) for _ in range(k_max)]
+    for s_ in solvers:
+        s_.SymbolicDecomposition_Blocky(lam)
+    vals = [torch.from_numpy(lam.values).to(dev) for _ in range(k_max)]     # K value sets (damped copies, in the LM reading)
+    torch.cuda.synchronize()
+    for k_, v_ in enumerate(vals):
+        solvers[k_].apply_damping_device_async(v_.data_ptr(), 1e-3 * k_, 0, lam.n_bcols)
+        solvers[k_].sync()
+    rhs0 = torch.from_numpy(lam.rhs).to(dev)
+    out = {"workload": f"K concurrent solves of the C3 structure on one device, a handle and a stream each; K value sets (damping 1e-3 k)", "by_k": {}}
+    bytes_step = counts["factor_bytes"] + counts["solve_bytes"]
+    for K in ks:
+        bufs = [[rhs0.clone() for _ in range(steps + 1)] for _ in range(K)]
+        torch.cuda.synchronize()
+        for k_ in range(K):
+            solvers[k_].factor_solve_device_async(vals[k_].data_ptr(), bufs[k_][0].data_ptr())
+        assert all(solvers[k_].sync() for k_ in range(K))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(1, steps + 1):
+            for k_ in range(K):
+                solvers[k_].factor_solve_device_async(vals[k_].data_ptr(), bufs[k_][i].data_ptr())
+        ok = all(solvers[k_].sync() for k_ in range(K))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        x = bufs[K - 1][-1].cpu().numpy()
+        out["by_k"][str(K)] = {"ok": bool(ok), "ms_per_round": dt * 1e3, "solves_per_s": K / dt,
+                                "GFLOP/s": K * counts["flops"] / dt / 1e9, "hbm_frac_whole_step": K * bytes_step / dt / 1e9 / HBM_PEAK_GBS,
+                                "finite": bool(np.isfinite(x).all())}
+    # parity of the last replica of the widest round against its own system's residual (its values are damped: a system of its own)
+    out["speedup_k8_vs_k1"] = out["by_k"][str(k_max)]["solves_per_s"] / out["by_k"]["1"]["solves_per_s"] if "1" in out["by_k"] else None
     return out
 
 
@@ -1070,6 +1116,10 @@ def compact_line(out, full_path):
             legs[key] = _leg_summary(out[key])
     for key, rec in (out.get("other_configs") or {}).items():
         legs[key] = _leg_summary(rec)
+    if out.get("replicas_one_gpu"):
+        r1 = out["replicas_one_gpu"]
+        legs["replicas_one_gpu"] = {k_: {"ms": v_["ms_per_round"], "GFLOP/s": v_["GFLOP/s"], "hbm_frac": v_["hbm_frac_whole_step"]}
+                                    for k_, v_ in r1["by_k"].items()}
     if out.get("pose_graph_replicas"):
         legs["pose_graph_replicas"] = {"ms_per_step": out["pose_graph_replicas"].get("ms_per_step"), "value": out["pose_graph_replicas"].get("value")}
     if out.get("device_group"):
