@@ -410,8 +410,37 @@ def replicas_leg(lam, counts, dev, local_rank, torch, ks=(1, 2, 4, 8), steps=10)
         out["by_k"][str(K)] = {"ok": bool(ok), "ms_per_round": dt * 1e3, "solves_per_s": K / dt,
                                 "GFLOP/s": K * counts["flops"] / dt / 1e9, "hbm_frac_whole_step": K * bytes_step / dt / 1e9 / HBM_PEAK_GBS,
                                 "finite": bool(np.isfinite(x).all())}
-    # parity of the last replica of the widest round against its own system's residual (its values are damped: a system of its own)
     out["speedup_k8_vs_k1"] = out["by_k"][str(k_max)]["solves_per_s"] / out["by_k"]["1"]["solves_per_s"] if "1" in out["by_k"] else None
+    # ... and the same K value sets through ONE handle in ONE pass of launches (slampp_hip_factor_solve_batch_device_async):
+    # the chain of dependent launches as long as for one system, every launch K times as wide
+    del solvers[1:]
+    solver = solvers[0]
+    n_v, n_s = lam.values.shape[0] + lam.values.shape[0] % 2, lam.n_scalars + lam.n_scalars % 2
+    vb = torch.zeros(k_max * n_v, dtype=torch.float64, device=dev)
+    for k_ in range(k_max):
+        vb[k_ * n_v:k_ * n_v + lam.values.shape[0]] = vals[k_]
+    del vals
+    out["batched"] = {}
+    for K in ks:
+        rb = [torch.zeros(K * n_s, dtype=torch.float64, device=dev) for _ in range(steps + 1)]
+        for r_ in rb:
+            for k_ in range(K):
+                r_[k_ * n_s:k_ * n_s + lam.n_scalars] = rhs0
+        torch.cuda.synchronize()
+        solver.factor_solve_batch_device_async(K, vb.data_ptr(), n_v, rb[0].data_ptr(), n_s)
+        ok = all(solver.sync_batch(K))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(1, steps + 1):
+            solver.factor_solve_batch_device_async(K, vb.data_ptr(), n_v, rb[i].data_ptr(), n_s)
+        ok = ok and all(solver.sync_batch(K))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        # parity guard: the last member's solution against the residual of ITS system (damped by 1e-3 (K - 1))
+        x = rb[-1][(K - 1) * n_s:(K - 1) * n_s + lam.n_scalars].cpu().numpy()
+        resid = float(np.abs(lam.to_scipy() @ x + 1e-3 * (K - 1) * x - lam.rhs).max() / np.abs(lam.rhs).max())
+        out["batched"][str(K)] = {"ok": bool(ok), "ms_per_round": dt * 1e3, "solves_per_s": K / dt, "GFLOP/s": K * counts["flops"] / dt / 1e9,
+                                  "hbm_frac_whole_step": K * bytes_step / dt / 1e9 / HBM_PEAK_GBS, "last_member_resid": resid}
     return out
 
 
@@ -1120,6 +1149,9 @@ def compact_line(out, full_path):
         r1 = out["replicas_one_gpu"]
         legs["replicas_one_gpu"] = {k_: {"ms": v_["ms_per_round"], "GFLOP/s": v_["GFLOP/s"], "hbm_frac": v_["hbm_frac_whole_step"]}
                                     for k_, v_ in r1["by_k"].items()}
+        if r1.get("batched"):
+            legs["replicas_batched"] = {k_: {"ms": v_["ms_per_round"], "GFLOP/s": v_["GFLOP/s"], "hbm_frac": v_["hbm_frac_whole_step"],
+                                             "resid": v_["last_member_resid"]} for k_, v_ in r1["batched"].items()}
     if out.get("pose_graph_replicas"):
         legs["pose_graph_replicas"] = {"ms_per_step": out["pose_graph_replicas"].get("ms_per_step"), "value": out["pose_graph_replicas"].get("value")}
     if out.get("device_group"):

@@ -602,10 +602,30 @@ public:
  *		its own library handle, configured to keep the caller's order and to factor every column block by block
  */
 class CLinearSolver_HIP_Factorizer : public CLinearSolver_HIP_Base {
+public:
+	/**
+	 *	@brief where the time of Factorize() goes, summed over the calls of the process (all instances: the nonlinear
+	 *		solvers work on copies of the solver they are given): the analysis of a new structure (ordering is the
+	 *		caller's; symbolic factorization, schedule, uploads of the plan), the gather of lambda's blocks, the library
+	 *		call (values up, numeric factorization, factor down), and the scatter of the factor into r_factor
+	 */
+	struct TTimes {
+		size_t n_calls, n_analyses;
+		double f_analyze_ms, f_gather_ms, f_factorize_ms, f_scatter_ms;
+	};
+	static TTimes &t_Times() { static TTimes t = {0, 0, 0, 0, 0, 0}; return t; }
+
 protected:
 	std::vector<int32_t> m_l_perm, m_l_dim, m_l_row; /**< @brief structure of the factor (slampp_hip_plan_view) */
 	std::vector<int64_t> m_l_ptr, m_l_off;
 	std::vector<double> m_l_values;
+
+	static double f_Now_Ms()
+	{
+		timespec t;
+		clock_gettime(CLOCK_MONOTONIC, &t);
+		return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+	}
 
 public:
 	inline CLinearSolver_HIP_Factorizer(int n_device = 0)
@@ -622,10 +642,16 @@ public:
 		size_t n_dest_row_id, size_t n_dest_column_id, bool b_upper_factor) // throw(std::bad_alloc, std::runtime_error)
 	{
 		const size_t n = r_lambda.n_BlockColumn_Num();
+		TTimes &r_times = t_Times();
+		++ r_times.n_calls;
+		const double f_t0 = f_Now_Ms();
+		double f_analysis = 0;
 		// the reference's counterpart is stateless (it re-analyzes on every call, LinearSolver_CholMod.cpp:396-423) and
 		// FastL hands it different parts of R without announcing a new structure (NonlinearSolver_FastL.h:2131, 2388):
 		// the cached analysis is reused only if every block of lambda is where it was (verified while gathering)
 		Gather_Or_Reanalyze(r_lambda, [&]() {
+			const double f_a0 = f_Now_Ms();
+			++ r_times.n_analyses;
 			Analyze(r_lambda, SLAMPP_HIP_MODE_SPARSE, 0, 0);
 			int64_t n_bcols = 0, n_l_blocks = 0, n_l_values = 0;
 			Throw_On_Error(slampp_hip_factor_structure(m_p_solver, &n_bcols, &n_l_blocks, &n_l_values, 0, 0, 0, 0, 0)); // sizes
@@ -639,10 +665,16 @@ public:
 				if(size_t(m_l_perm[i]) != i)
 					throw std::runtime_error("CLinearSolver_HIP: the factorization did not keep the caller's order");
 			}
+			f_analysis += f_Now_Ms() - f_a0;
 		});
 		if(m_l_ptr.size() != n + 1)
 			throw std::runtime_error("CLinearSolver_HIP: the factor's structure does not match lambda");
+		const double f_t1 = f_Now_Ms();
 		const int n_result = slampp_hip_factorize(m_p_solver, m_p_values, m_l_values.empty()? 0 : &m_l_values[0]);
+		const double f_t2 = f_Now_Ms();
+		r_times.f_analyze_ms += f_analysis;
+		r_times.f_gather_ms += f_t1 - f_t0 - f_analysis;
+		r_times.f_factorize_ms += f_t2 - f_t1;
 		if(n_result == SLAMPP_HIP_NOT_POSDEF)
 			return false;
 		Throw_On_Error(n_result);
@@ -665,6 +697,7 @@ public:
 				}
 			}
 		}
+		r_times.f_scatter_ms += f_Now_Ms() - f_t2;
 		return true;
 	}
 };

@@ -294,6 +294,21 @@ int slampp_hip_schur_marginals_device_async(slampp_hip_solver *p_solver, const d
 int slampp_hip_factor_solve_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,
 	double *p_rhs_inout_dev);
 int slampp_hip_sync(slampp_hip_solver *p_solver);
+
+/* K value sets of the analyzed structure in ONE pass of launches -- K damping values of one Lambda, K graphs of one shape --,
+ * sparse mode: member k reads p_values_dev + k * n_values_stride and overwrites p_rhs_inout_dev + k * n_rhs_stride with its
+ * solution (strides in doubles, at least the length of one member's array; 16-byte aligned bases and even strides let the
+ * members share launches, anything else is solved one member after the other with the same result).  The chain of dependent
+ * launches is as long as for one system and every launch K times as wide: a pose-graph solve fills a fraction of the
+ * chip, K of them fill it.  Stands where the reference's LM loop re-damps and re-solves one value after the other
+ * (NonlinearSolver_Lambda_LM.h:967-1001, 1660-1676); SURVEY section 8(e): pose graphs do not shard, "replicas only
+ * (multiple independent problems / damping values per GPU)".  slampp_hip_sync_batch waits and reports per member:
+ * p_status[k] = SLAMPP_HIP_OK or SLAMPP_HIP_NOT_POSDEF (a member that is not positive definite does not disturb the
+ * others).  The handle's own factor (slampp_hip_solve_again, covariances) is not touched by a batch of more than one. */
+#define SLAMPP_HIP_MAX_BATCH 64
+int slampp_hip_factor_solve_batch_device_async(slampp_hip_solver *p_solver, int n_batch, const double *p_values_dev,
+	int64_t n_values_stride, double *p_rhs_inout_dev, int64_t n_rhs_stride);
+int slampp_hip_sync_batch(slampp_hip_solver *p_solver, int *p_status /* [n_batch] */, int n_batch);
 void *slampp_hip_stream(slampp_hip_solver *p_solver); /* the hipStream_t every kernel is launched on */
 
 int slampp_hip_get_stats(const slampp_hip_solver *p_solver, slampp_hip_stats *p_stats);

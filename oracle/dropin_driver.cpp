@@ -148,6 +148,41 @@ public:
 	}
 };
 
+// dropin_driver time-fastl: every Factorize_PosDef_Blocky call of a FastL run timed, with the size of the part of R it was
+// given (block columns of r_lambda) -- the same wrapper around the reference's CHOLMOD solver and around CLinearSolver_HIP
+struct TFactorizeCall { size_t n_block_columns, n_blocks; double f_ms; };
+template <class CBase>
+class CTimedFactorize : public CBase {
+public:
+	static std::vector<TFactorizeCall> &r_Calls() { static std::vector<TFactorizeCall> v; return v; }
+	static double &f_Solve_Ms() { static double f = 0; return f; }
+
+	bool Factorize_PosDef_Blocky(CUberBlockMatrix &r_factor, const CUberBlockMatrix &r_lambda,
+		std::vector<size_t> &r_workspace, size_t n_dest_row_id = 0, size_t n_dest_column_id = 0, bool b_upper_factor = true)
+	{
+		const double f_t0 = f_Wall_Ms();
+		const bool b_result = CBase::Factorize_PosDef_Blocky(r_factor, r_lambda, r_workspace, n_dest_row_id, n_dest_column_id, b_upper_factor);
+		TFactorizeCall t = {r_lambda.n_BlockColumn_Num(), r_lambda.n_Block_Num(), f_Wall_Ms() - f_t0};
+		r_Calls().push_back(t);
+		return b_result;
+	}
+
+	bool Solve_PosDef(const CUberBlockMatrix &r_lambda, Eigen::VectorXd &r_eta)
+	{
+		const double f_t0 = f_Wall_Ms();
+		const bool b_result = CBase::Solve_PosDef(r_lambda, r_eta);
+		f_Solve_Ms() += f_Wall_Ms() - f_t0;
+		return b_result;
+	}
+
+	static double f_Wall_Ms()
+	{
+		timespec t;
+		clock_gettime(CLOCK_MONOTONIC, &t);
+		return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+	}
+};
+
 // the same graph through the reference's incremental solver (-fL): it keeps the factor R itself and asks its linear
 // solver for Solve_PosDef() and Factorize_PosDef_Blocky() (NonlinearSolver_FastL.h:1724, 2131, 2388)
 template <class CSystemType, class CLinearSolverType>
@@ -436,6 +471,66 @@ int main(int n_arg_num, const char **p_arg_list)
 			printf("ba lm max %d: chi2 %.15g iterations %d\n", n_max, f_chi2_a, int(n_it));
 		}
 		return 0;
+	}
+	if(n_arg_num > 1 && !strcmp(p_arg_list[1], "time-fastl")) {
+		// dropin_driver time-fastl <n_poses> [loops_every_step]: the reference's CNonlinearSolver_FastL, incremental (a nonlinear
+		// solve each 5 vertices, loop closures to older poses), once on CLinearSolver_CholMod and once on CLinearSolver_HIP: per
+		// Factorize_PosDef_Blocky call the wall time by size of the part of R it was handed, and for HIP the split analysis /
+		// gather / library call (upload, numeric factorization, factor back) / scatter into the CUberBlockMatrix
+		// (callers: NonlinearSolver_FastL.h:2131, 2388; reference implementation LinearSolver_CholMod.cpp:362-544)
+		typedef MakeTypelist(CVertexPose3D) TVertexTypelist;
+		typedef MakeTypelist(CEdgePose3D) TEdgeTypelist;
+		typedef CFlatSystem<CVertexPose3D, TVertexTypelist, CEdgePose3D, TEdgeTypelist> CSystemType;
+		const size_t n_poses = (n_arg_num > 2)? size_t(atol(p_arg_list[2])) : 2000;
+		const bool b_every = n_arg_num > 3 && atoi(p_arg_list[3]) != 0;
+		try {
+			typedef CTimedFactorize<CLinearSolver_CholMod> TRef;
+			typedef CTimedFactorize<CLinearSolver_HIP> THip;
+			double f_chi2_ref, f_chi2_hip;
+			double f_t0 = TRef::f_Wall_Ms();
+			std::vector<double> ref = Optimize_SE3_FastL<CSystemType, TRef>(n_poses, 78, f_chi2_ref, true, b_every);
+			const double f_total_ref = TRef::f_Wall_Ms() - f_t0;
+			f_t0 = TRef::f_Wall_Ms();
+			std::vector<double> hip = Optimize_SE3_FastL<CSystemType, THip>(n_poses, 78, f_chi2_hip, true, b_every);
+			const double f_total_hip = TRef::f_Wall_Ms() - f_t0;
+			const std::vector<TFactorizeCall> &r_a = TRef::r_Calls(), &r_b = THip::r_Calls();
+			// the two runs make the same calls as long as FastL takes the same decisions; binned by size either way
+			const size_t p_edges[] = {0, 8, 32, 128, 512, 2048, 8192, size_t(-1)};
+			printf("{\"n_poses\": %d, \"loops_every_step\": %d, \"chi2_ref\": %.12g, \"chi2_hip\": %.12g, \"state_rel_inf\": %.3g, "
+				"\"run_total_ms\": {\"cholmod\": %.1f, \"hip\": %.1f}, \"solve_posdef_ms\": {\"cholmod\": %.1f, \"hip\": %.1f}, \"factorize_calls\": "
+				"{\"cholmod\": %d, \"hip\": %d}, \"by_block_columns\": [", int(n_poses), int(b_every), f_chi2_ref, f_chi2_hip, f_RelInf(hip, ref),
+				f_total_ref, f_total_hip, TRef::f_Solve_Ms(), THip::f_Solve_Ms(), int(r_a.size()), int(r_b.size()));
+			bool b_first = true;
+			for(int n_bin = 0; n_bin < 7; ++ n_bin) {
+				double p_sum[2] = {0, 0};
+				size_t p_num[2] = {0, 0};
+				std::vector<double> p_all[2];
+				for(int n_side = 0; n_side < 2; ++ n_side) {
+					const std::vector<TFactorizeCall> &r_c = n_side? r_b : r_a;
+					for(size_t i = 0; i < r_c.size(); ++ i) {
+						if(r_c[i].n_block_columns > p_edges[n_bin] && r_c[i].n_block_columns <= p_edges[n_bin + 1]) {
+							p_sum[n_side] += r_c[i].f_ms;
+							++ p_num[n_side];
+							p_all[n_side].push_back(r_c[i].f_ms);
+						}
+					}
+					std::sort(p_all[n_side].begin(), p_all[n_side].end());
+				}
+				if(!p_num[0] && !p_num[1])
+					continue;
+				printf("%s{\"columns_from\": %ld, \"columns_to\": %ld, \"calls\": [%d, %d], \"median_ms\": [%.4f, %.4f], \"total_ms\": [%.2f, %.2f]}",
+					b_first? "" : ", ", long(p_edges[n_bin] + 1), (p_edges[n_bin + 1] == size_t(-1))? -1L : long(p_edges[n_bin + 1]), int(p_num[0]), int(p_num[1]),
+					p_all[0].empty()? 0.0 : p_all[0][p_all[0].size() / 2], p_all[1].empty()? 0.0 : p_all[1][p_all[1].size() / 2], p_sum[0], p_sum[1]);
+				b_first = false;
+			}
+			const CLinearSolver_HIP_Factorizer::TTimes &r_t = CLinearSolver_HIP_Factorizer::t_Times();
+			printf("], \"hip_split_ms\": {\"calls\": %d, \"analyses\": %d, \"analyze\": %.2f, \"gather\": %.2f, \"upload_factor_download\": %.2f, "
+				"\"scatter\": %.2f}}\n", int(r_t.n_calls), int(r_t.n_analyses), r_t.f_analyze_ms, r_t.f_gather_ms, r_t.f_factorize_ms, r_t.f_scatter_ms);
+			return 0;
+		} catch(std::exception &r_exc) {
+			fprintf(stderr, "error: %s\n", r_exc.what());
+			return 3;
+		}
 	}
 	if(n_arg_num > 1 && !strcmp(p_arg_list[1], "time")) {
 		try {

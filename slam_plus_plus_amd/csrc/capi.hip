@@ -563,6 +563,101 @@ int slampp_hip_sync(slampp_hip_solver *p_solver)
 	});
 }
 
+// K value sets of the analyzed structure, factored and solved by the same launches (blockIdx.y = member): the chain of
+// dependent launches is as long as for one system, every launch K times as wide.  Stands where the reference's LM loop
+// re-damps and re-solves one value after the other (NonlinearSolver_Lambda_LM.h:967-1001, 1660-1676) and for SURVEY.md
+// section 8(e)'s "replicas only (multiple independent problems / damping values per GPU)" of the pose-graph path.
+int slampp_hip_factor_solve_batch_device_async(slampp_hip_solver *p_solver, int n_batch, const double *p_values_dev,
+	int64_t n_values_stride, double *p_rhs_inout_dev, int64_t n_rhs_stride)
+{
+	return guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!s.b_analyzed)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factor_solve_batch: analyze was not called");
+		if(s.b_group_active || s.n_mode != SLAMPP_HIP_MODE_SPARSE)
+			return fail(p_solver, SLAMPP_HIP_ERR_UNSUPPORTED, "factor_solve_batch: the sparse block path of a one-device handle only");
+		if(!p_values_dev || !p_rhs_inout_dev || n_batch < 1 || n_batch > SLAMPP_HIP_MAX_BATCH)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factor_solve_batch: null pointer, or a batch of fewer than 1 / more than SLAMPP_HIP_MAX_BATCH members");
+		if(n_batch > 1 && (n_values_stride < s.n_values || n_rhs_stride < s.n_scalars))
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "factor_solve_batch: the members' values / vectors overlap (stride below their length)");
+		const Plan &P = s.plan;
+		if(!s.d_batch_flag.p() || s.d_batch_flag.n() < size_t(SLAMPP_HIP_MAX_BATCH)) {
+			s.d_batch_flag.Alloc(SLAMPP_HIP_MAX_BATCH);
+			SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_batch_flag.p(), 0, SLAMPP_HIP_MAX_BATCH * sizeof(int), s.stream));
+		}
+		if(!s.p_host_batch_flag)
+			SLAMPP_HIP_CHECK(hipHostMalloc((void**)&s.p_host_batch_flag, SLAMPP_HIP_MAX_BATCH * sizeof(int), hipHostMallocDefault));
+		s.n_batch_pending = std::max(s.n_batch_pending, n_batch);
+		int *p_flag_before = s.p_flag_shared;
+		const bool b_linv_valid_before = s.b_leaf_linv_valid;
+		// the wide launches need what the kernels of one member assume of their bases (16-byte loads where the block dimension
+		// is even) to hold for every member, and take neither a dense top (one dense matrix per handle) nor regrouped values
+		const bool b_aligned = ((reinterpret_cast<uintptr_t>(p_values_dev) | reinterpret_cast<uintptr_t>(p_rhs_inout_dev)) & 15) == 0 &&
+			(n_values_stride | n_rhs_stride) % 2 == 0;
+		if(n_batch == 1 || s.n_dense_dim || s.b_refined || !b_aligned) {
+			// one member after the other, each answering into its own flag (the factor of a member is overwritten by the next:
+			// its solution has been written by then, the stream orders them)
+			for(int k = 0; k < n_batch; ++ k) {
+				s.p_flag_shared = s.d_batch_flag.p() + k;
+				s.Enqueue_Sparse(p_values_dev + int64_t(k) * n_values_stride, p_rhs_inout_dev + int64_t(k) * n_rhs_stride, true);
+			}
+			s.p_flag_shared = p_flag_before;
+			s.b_factored = true; // (the last member's factor is the one kept)
+			return SLAMPP_HIP_OK;
+		}
+		auto Round = [](size_t n) { return (n + 31) / 32 * 32; }; // (256 bytes: every member's base is aligned like the first)
+		TBatch t = {n_batch, n_values_stride, int64_t(Round(s.d_L.n())), int64_t(Round(s.d_Linv.n())), n_rhs_stride, int64_t(Round(s.d_w.n())),
+			int64_t(Round(s.d_handup.n()))};
+		s.d_batch_L.Alloc(size_t(t.l) * n_batch);
+		s.d_batch_Linv.Alloc(size_t(t.linv) * n_batch);
+		s.d_batch_w.Alloc(size_t(t.w) * n_batch);
+		s.d_batch_handup.Alloc(size_t(t.h) * n_batch);
+		(void)P;
+		// the members' arrays stand in for the handle's own while the launches are enqueued (the kernels get pointers, not
+		// the arrays); the handle's own factor -- what solve_again and the covariances work from -- stays what it was
+		s.d_L.Swap(s.d_batch_L); s.d_Linv.Swap(s.d_batch_Linv); s.d_w.Swap(s.d_batch_w); s.d_handup.Swap(s.d_batch_handup);
+		s.p_flag_shared = s.d_batch_flag.p();
+		s.t_batch = t;
+		try {
+			s.Enqueue_Sparse(p_values_dev, p_rhs_inout_dev, true);
+		} catch(...) {
+			s.t_batch = t_No_Batch();
+			s.p_flag_shared = p_flag_before;
+			s.d_L.Swap(s.d_batch_L); s.d_Linv.Swap(s.d_batch_Linv); s.d_w.Swap(s.d_batch_w); s.d_handup.Swap(s.d_batch_handup);
+			s.b_leaf_linv_valid = b_linv_valid_before;
+			throw;
+		}
+		s.t_batch = t_No_Batch();
+		s.p_flag_shared = p_flag_before;
+		s.d_L.Swap(s.d_batch_L); s.d_Linv.Swap(s.d_batch_Linv); s.d_w.Swap(s.d_batch_w); s.d_handup.Swap(s.d_batch_handup);
+		s.b_leaf_linv_valid = b_linv_valid_before;
+		return SLAMPP_HIP_OK;
+	});
+}
+
+int slampp_hip_sync_batch(slampp_hip_solver *p_solver, int *p_status, int n_batch)
+{
+	return guarded(p_solver, [&]() -> int {
+		slampp_hip_solver &s = *p_solver;
+		if(!p_status || n_batch < 1 || n_batch > SLAMPP_HIP_MAX_BATCH)
+			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "sync_batch: null pointer or bad member count");
+		const int n = std::max(n_batch, s.n_batch_pending);
+		if(s.d_batch_flag.p() && s.p_host_batch_flag)
+			SLAMPP_HIP_CHECK(hipMemcpyAsync(s.p_host_batch_flag, s.d_batch_flag.p(), size_t(n) * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+		s.Phase_Collect();
+		bool b_any = false;
+		for(int k = 0; k < n_batch; ++ k) {
+			p_status[k] = (s.p_host_batch_flag && s.d_batch_flag.p() && s.p_host_batch_flag[k])? SLAMPP_HIP_NOT_POSDEF : SLAMPP_HIP_OK;
+			b_any = b_any || p_status[k] != SLAMPP_HIP_OK;
+		}
+		if(b_any || s.n_batch_pending > n_batch) // (answered for: the next batch starts clean)
+			SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_batch_flag.p(), 0, SLAMPP_HIP_MAX_BATCH * sizeof(int), s.stream));
+		s.n_batch_pending = 0;
+		return SLAMPP_HIP_OK;
+	});
+}
+
 void *slampp_hip_stream(slampp_hip_solver *p_solver)
 {
 	return p_solver? (void*)p_solver->stream : 0;

@@ -206,8 +206,9 @@ template <int D, int W, bool b_fused, bool b_rows>
 __global__ void __launch_bounds__(64 * W)
 factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict__ pkg_off, const int64_t *__restrict__ out_off, int n_panels,
 	TPanelLaunch t_cfg, const TUpdSlot *__restrict__ upd_slots, int n_upd_slots, const TUpdEnt *__restrict__ upd_ents, const double *__restrict__ A,
-	const double *__restrict__ b, double *L, double *Linv, double *w, double *H, int *p_flag, long long *p_timing)
-{
+	const double *__restrict__ b, double *L, double *Linv, double *w, double *H, int *p_flag, long long *p_timing, TBatch t_batch)
+{	{ const int64_t n_member = blockIdx.y; A += n_member * t_batch.a; b += n_member * t_batch.b; L += n_member * t_batch.l; Linv += n_member * t_batch.linv; w += n_member * t_batch.w; H += n_member * t_batch.h; p_flag += n_member; } // (TBatch: sparse_kernels.h)
+
 	enum { DD = D * D, BATCH = panel_fresh_batch(W), UPD_BATCH = PANEL_UPD_BATCH, UPD_W = (W < int(PANEL_UPD_W))? W : int(PANEL_UPD_W), // (two waves per task: two per update block)
 		N_UPD_GROUPS = W / UPD_W };
 	extern __shared__ __attribute__((aligned(16))) double s_raw[];
@@ -526,7 +527,7 @@ factor_panel_kernel(const longlong2 *__restrict__ pkg, const int64_t *__restrict
 
 bool launch_factor_panel(int n_dim, bool b_fused, bool b_rows, const TPanelLaunch &r_cfg, const longlong2 *pkg, const int64_t *pkg_off, const int64_t *out_off,
 	int n_tasks, const TUpdSlot *upd_slots, int n_upd_slots, const TUpdEnt *upd_ents, const double *A, const double *b, double *L, double *Linv, double *w,
-	double *H, int *p_flag, hipStream_t stream, long long *p_timing)
+	double *H, int *p_flag, hipStream_t stream, long long *p_timing, const TBatch &t_batch)
 {
 	if(!b_fused)
 		n_upd_slots = 0;
@@ -544,8 +545,8 @@ bool launch_factor_panel(int n_dim, bool b_fused, bool b_rows, const TPanelLaunc
 			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_panel_kernel<D, WW, F, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
 			b_attribute_set = true; \
 		} \
-		hipLaunchKernelGGL((factor_panel_kernel<D, WW, F, RW>), dim3(n_grid), dim3(64 * WW), n_lds_bytes, stream, pkg, pkg_off, out_off, n_tasks, r_cfg, \
-			upd_slots, n_upd_slots, upd_ents, A, b, L, Linv, w, H, p_flag, p_timing); } while(0)
+		hipLaunchKernelGGL((factor_panel_kernel<D, WW, F, RW>), dim3(n_grid, t_batch.n), dim3(64 * WW), n_lds_bytes, stream, pkg, pkg_off, out_off, n_tasks, r_cfg, \
+			upd_slots, n_upd_slots, upd_ents, A, b, L, Linv, w, H, p_flag, p_timing, t_batch); } while(0)
 #define LAUNCH_PANEL_F(D, WW, F) do { if(b_rows) LAUNCH_PANEL_INSTANCE(D, WW, F, true); else LAUNCH_PANEL_INSTANCE(D, WW, F, false); } while(0)
 #define LAUNCH_PANEL(D) do { \
 		if(W == 2) { if(b_fused) LAUNCH_PANEL_F(D, 2, true); else LAUNCH_PANEL_F(D, 2, false); } \
@@ -574,8 +575,9 @@ bool launch_factor_panel(int n_dim, bool b_fused, bool b_rows, const TPanelLaunc
 template <int D>
 __global__ void __launch_bounds__(64 * PANEL_UPD_W)
 panel_update_kernel(const TUpdSlot *__restrict__ slots, const TUpdEnt *__restrict__ ents, const double *__restrict__ A, double *L,
-	const double *__restrict__ b, double *w)
-{
+	const double *__restrict__ b, double *w, TBatch t_batch)
+{	{ const int64_t n_member = blockIdx.y; A += n_member * t_batch.a; L += n_member * t_batch.l; b += n_member * t_batch.b; w += n_member * t_batch.w; } // (TBatch: sparse_kernels.h)
+
 	enum { W = PANEL_UPD_W, DD = D * D, BATCH = 8 };
 	__shared__ double s_ops[W][2 * BATCH * DD];
 	__shared__ double s_yv[W][BATCH * 8];
@@ -586,16 +588,16 @@ panel_update_kernel(const TUpdSlot *__restrict__ slots, const TUpdEnt *__restric
 }
 
 void launch_panel_update(int n_dim, const TUpdSlot *slots, int n_slots, const TUpdEnt *ents, const double *A, double *L,
-	const double *b, double *w, hipStream_t stream)
+	const double *b, double *w, hipStream_t stream, const TBatch &t_batch)
 {
 	if(n_slots <= 0)
 		return;
 	if(n_dim == 3)
-		hipLaunchKernelGGL((panel_update_kernel<3>), dim3(n_slots), dim3(64 * PANEL_UPD_W), 0, stream, slots, ents, A, L, b, w);
+		hipLaunchKernelGGL((panel_update_kernel<3>), dim3(n_slots, t_batch.n), dim3(64 * PANEL_UPD_W), 0, stream, slots, ents, A, L, b, w, t_batch);
 	else if(n_dim == 6)
-		hipLaunchKernelGGL((panel_update_kernel<6>), dim3(n_slots), dim3(64 * PANEL_UPD_W), 0, stream, slots, ents, A, L, b, w);
+		hipLaunchKernelGGL((panel_update_kernel<6>), dim3(n_slots, t_batch.n), dim3(64 * PANEL_UPD_W), 0, stream, slots, ents, A, L, b, w, t_batch);
 	else
-		hipLaunchKernelGGL((panel_update_kernel<7>), dim3(n_slots), dim3(64 * PANEL_UPD_W), 0, stream, slots, ents, A, L, b, w);
+		hipLaunchKernelGGL((panel_update_kernel<7>), dim3(n_slots, t_batch.n), dim3(64 * PANEL_UPD_W), 0, stream, slots, ents, A, L, b, w, t_batch);
 }
 
 } // namespace slampp

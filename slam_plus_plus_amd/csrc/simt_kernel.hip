@@ -118,8 +118,9 @@ template <int D, int W, int LPT, bool b_linv> // W = tasks per wave, LPT = lanes
 __global__ void __launch_bounds__(64)
 factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restrict__ prog, const long long *__restrict__ tab,
 	const double *__restrict__ A, double *L, double *Linv, const double *__restrict__ b, double *w, int *p_flag,
-	long long *p_timing)
-{
+	long long *p_timing, TBatch t_batch)
+{	{ const int64_t n_member = blockIdx.y; A += n_member * t_batch.a; L += n_member * t_batch.l; Linv = Linv? Linv + n_member * t_batch.linv : Linv; b += n_member * t_batch.b; w += n_member * t_batch.w; p_flag += n_member; } // (TBatch: sparse_kernels.h)
+
 	enum { DD = D * D };
 	extern __shared__ long long s_tab[]; // the chunk's table of per-lane offsets: fetched once, in one go, instead of a
 	// trip to memory in front of every operand
@@ -379,14 +380,14 @@ factor_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restr
 }
 
 bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, int n_width, int n_lds_bytes, const int32_t *prog, const int64_t *tab, int n_dim,
-	const double *A, double *L, double *Linv, const double *b, double *w, int *p_flag, hipStream_t stream, long long *p_timing)
+	const double *A, double *L, double *Linv, const double *b, double *w, int *p_flag, hipStream_t stream, long long *p_timing, const TBatch &t_batch)
 {
 	if(n_chunks <= 0)
 		return true;
 	const long long *t = reinterpret_cast<const long long*>(tab);
-#define SIMT_LAUNCH(D_, W_, LPT_) do { if(Linv) hipLaunchKernelGGL((factor_simt_kernel<D_, W_, LPT_, true>), dim3(n_chunks), dim3(64), n_lds_bytes, stream, chunks, prog, t, \
-	A, L, Linv, b, w, p_flag, p_timing); else hipLaunchKernelGGL((factor_simt_kernel<D_, W_, LPT_, false>), dim3(n_chunks), dim3(64), n_lds_bytes, stream, chunks, prog, t, \
-	A, L, Linv, b, w, p_flag, p_timing); } while(0)
+#define SIMT_LAUNCH(D_, W_, LPT_) do { if(Linv) hipLaunchKernelGGL((factor_simt_kernel<D_, W_, LPT_, true>), dim3(n_chunks, t_batch.n), dim3(64), n_lds_bytes, stream, chunks, prog, t, \
+	A, L, Linv, b, w, p_flag, p_timing, t_batch); else hipLaunchKernelGGL((factor_simt_kernel<D_, W_, LPT_, false>), dim3(n_chunks, t_batch.n), dim3(64), n_lds_bytes, stream, chunks, prog, t, \
+	A, L, Linv, b, w, p_flag, p_timing, t_batch); } while(0)
 	// (two lanes per task where the block dimension is even and a wave holds at most 32 tasks)
 #define SIMT_WIDTHS(D_) do { if(n_width == 16) { if(b_pairs && D_ % 2 == 0) SIMT_LAUNCH(D_, 16, (D_ % 2 == 0)? 2 : 1); else SIMT_LAUNCH(D_, 16, 1); } \
 	else if(n_width == 32) { if(b_pairs && D_ % 2 == 0) SIMT_LAUNCH(D_, 32, (D_ % 2 == 0)? 2 : 1); else SIMT_LAUNCH(D_, 32, 1); } \
@@ -422,8 +423,9 @@ bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, int n_width, int
 template <int D, int W>
 __global__ void __launch_bounds__(64)
 backward_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restrict__ prog, const long long *__restrict__ tab,
-	const double *__restrict__ L, double *w, double *x_out)
-{
+	const double *__restrict__ L, double *w, double *x_out, TBatch t_batch)
+{	{ const int64_t n_member = blockIdx.y; L += n_member * t_batch.l; w += n_member * t_batch.w; x_out += n_member * t_batch.b; } // (TBatch: sparse_kernels.h)
+
 	enum { DD = D * D };
 	extern __shared__ long long s_tab[];
 	const TSimtChunk ch = chunks[blockIdx.x];
@@ -503,12 +505,12 @@ backward_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__res
 }
 
 bool launch_backward_simt(const TSimtChunk *chunks, int n_chunks, int n_width, int n_lds_bytes, const int32_t *prog, const int64_t *tab,
-	int n_dim, const double *L, double *w, double *x_out, hipStream_t stream)
+	int n_dim, const double *L, double *w, double *x_out, hipStream_t stream, const TBatch &t_batch)
 {
 	if(n_chunks <= 0)
 		return true;
 	const long long *t = reinterpret_cast<const long long*>(tab);
-#define BWD_LAUNCH(D_, W_) hipLaunchKernelGGL((backward_simt_kernel<D_, W_>), dim3(n_chunks), dim3(64), n_lds_bytes, stream, chunks, prog, t, L, w, x_out)
+#define BWD_LAUNCH(D_, W_) hipLaunchKernelGGL((backward_simt_kernel<D_, W_>), dim3(n_chunks, t_batch.n), dim3(64), n_lds_bytes, stream, chunks, prog, t, L, w, x_out, t_batch)
 #define BWD_WIDTHS(D_) do { if(n_width == 16) BWD_LAUNCH(D_, 16); else if(n_width == 32) BWD_LAUNCH(D_, 32); else BWD_LAUNCH(D_, 64); } while(0)
 	switch(n_dim) {
 	case 3:

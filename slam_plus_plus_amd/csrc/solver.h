@@ -10,6 +10,7 @@
 
 #include "../../include/slampp_hip.h"
 #include "plan.h"
+#include <utility>
 #include "sparse_kernels.h"
 #include "dense_chol.h"
 
@@ -66,6 +67,7 @@ public:
 	}
 	T *p() const { return m_p; }
 	size_t n() const { return m_n; }
+	void Swap(CDevArray &r_other) { std::swap(m_p, r_other.m_p); std::swap(m_n, r_other.m_n); }
 	size_t n_Bytes() const { return m_p? m_n * sizeof(T) : 0; }
 };
 
@@ -166,6 +168,14 @@ struct slampp_hip_solver {
 	// inv(L_jj) of the columns the lane-per-task kernel factors is not on the solve's path any more (its backward kernel solves with
 	// L_jj^T): stored only once something has asked for it (another right-hand side, covariances) -- from then on always
 	bool b_leaf_linv_wanted = false, b_leaf_linv_valid = true;
+	// K value sets in the same launches (slampp_hip_factor_solve_batch_device_async): the members' factors, inverses,
+	// workspaces and hand-up buffers side by side (swapped in for d_L .. d_handup while the batch is enqueued), a flag per
+	// member, and what Enqueue_Sparse hands to every launch
+	slampp::TBatch t_batch = slampp::t_No_Batch();
+	slampp::CDevArray<double> d_batch_L, d_batch_Linv, d_batch_w, d_batch_handup;
+	slampp::CDevArray<int> d_batch_flag;
+	int *p_host_batch_flag = 0; // pinned, SLAMPP_HIP_MAX_BATCH ints
+	int n_batch_pending = 0;    // members of the batches enqueued since the last slampp_hip_sync_batch (the largest)
 	int n_simt_backward = -1; // option "simt_backward": 1 = the leaf subtrees' backward substitution a lane per task as well and no inv(L_jj) stored for them; 0 = a wave per task; -1 (default) = by the number of leaf subtrees (round 4, after the new ordering: slower below ~12 000 of them, 1.6 % faster at C3, 7 % at a million poses)
 	void Ensure_Leaf_Inverses();
 	std::vector<int32_t> simt_chunk_ptr, simt_rest_ptr; // [n_bottom_stages + 1] each; empty = not in use

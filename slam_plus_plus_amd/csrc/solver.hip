@@ -48,6 +48,8 @@ slampp_hip_solver::~slampp_hip_solver()
 		(void)hipEventDestroy(event_pool[i]);
 	if(p_host_flag)
 		(void)hipHostFree(p_host_flag);
+	if(p_host_batch_flag)
+		(void)hipHostFree(p_host_batch_flag);
 	Free_Staging();
 	if(copy_done)
 		(void)hipEventDestroy(copy_done);

@@ -38,7 +38,7 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 	// 179, at 100 000 -- 15 928 subtrees -- the step is 0.318 -> 0.313 ms, at 300 000 0.853 -> 0.805, at a million 2.11 -> 1.96)
 	const bool b_simt_backward_wanted = (n_simt_backward < 0)? P.stage_ptr.size() > 1 && P.stage_ptr[1] - P.stage_ptr[0] >= 12288 : n_simt_backward != 0;
 	const bool b_simt_bwd = b_simt_backward_wanted && !simt_chunk_ptr.empty() && d_simt_bwd_chunks.p() &&
-		(P.max_dim % 2 != 0 || (reinterpret_cast<uintptr_t>(p_rhs_dev) & 15) == 0);
+		(P.max_dim % 2 != 0 || ((reinterpret_cast<uintptr_t>(p_rhs_dev) & 15) == 0 && t_batch.b % 2 == 0));
 	if(b_factor)
 		b_leaf_linv_valid = true; // (every factor kernel but the lane-per-task one stores its inverses; that one answers below)
 	else
@@ -50,7 +50,7 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 		// everything enqueued since the last one)
 		// the lane-per-task kernel reads blocks and vectors with 16-byte loads where the block dimension is even
 		const bool b_simt = !simt_chunk_ptr.empty() && (P.max_dim % 2 != 0 ||
-			((reinterpret_cast<uintptr_t>(p_values_dev) | reinterpret_cast<uintptr_t>(p_rhs_dev)) & 15) == 0);
+			(((reinterpret_cast<uintptr_t>(p_values_dev) | reinterpret_cast<uintptr_t>(p_rhs_dev)) & 15) == 0 && (t_batch.a | t_batch.b) % 2 == 0));
 		// phases: the leaf subtrees (stage 0), the wide stages right above them, the separators further up
 		const int n_wide_end = std::min(n_bottom_stages, n_stages);
 		// A stage of panel tasks: the updates its blocks receive from stages further down were applied inside the launch of the
@@ -65,18 +65,18 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			const bool b_rode = panel_ride[s] != 0;
 			if(!b_rode)
 				launch_panel_update(P.max_dim, d_panel_upd_slots.p() + panel_upd_ptr[s], panel_upd_ptr[s + 1] - panel_upd_ptr[s],
-					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream);
+					d_panel_upd_ents.p(), p_values_dev, d_L.p(), p_rhs_dev, d_w.p(), stream, t_batch);
 			const int n_next = (s + 1 < n_stages && panel_ride[s + 1] == 1)? panel_upd_ptr[s + 2] - panel_upd_ptr[s + 1] : 0;
 			if(!launch_factor_panel(P.max_dim, b_panel_fused, (n_panel_rows < 0)? P.max_dim >= 6 : n_panel_rows != 0, panel_cfg[s], d_panel_pkg.p(), d_panel_off.p() + panel_ptr[s],
 				d_panel_out_off.p() + panel_ptr[s], n_panels,
 				d_panel_upd_slots.p() + ((n_next > 0)? panel_upd_ptr[s + 1] : 0), n_next, d_panel_upd_ents.p(), p_values_dev, p_rhs_dev,
-				d_L.p(), d_Linv.p(), d_w.p(), d_handup.p(), p_flag, stream, dplan.p_timing))
+				d_L.p(), d_Linv.p(), d_w.p(), d_handup.p(), p_flag, stream, dplan.p_timing, t_batch))
 				throw CDeviceError("panel launch refused: block size or LDS request outside what the analysis planned for");
 			if(panel_rest_ptr[s + 1] > panel_rest_ptr[s]) {
 				TDevPlan t_rest = dplan;
 				t_rest.task_map = d_panel_rest.p();
 				launch_factor_stage(t_rest, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), panel_rest_ptr[s],
-					panel_rest_ptr[s + 1] - panel_rest_ptr[s], b_bottom, p_flag, stream);
+					panel_rest_ptr[s + 1] - panel_rest_ptr[s], b_bottom, p_flag, stream, t_batch);
 			}
 		};
 		for(int s = 0; s < n_stages; ++ s) {
@@ -92,24 +92,24 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 				const int n_chunks = simt_chunk_ptr[s + 1] - simt_chunk_ptr[s], n_rest = simt_rest_ptr[s + 1] - simt_rest_ptr[s];
 				const bool b_store_linv = b_leaf_linv_wanted || !b_simt_backward_wanted; // (the wave-per-task backward kernel reads the inverses)
 				launch_factor_simt(d_simt_chunks.p() + simt_chunk_ptr[s], n_chunks, n_simt_width, simt_lds_bytes[s], d_simt_prog.p(), d_simt_tab.p(), P.max_dim,
-					p_values_dev, d_L.p(), b_store_linv? d_Linv.p() : 0, p_rhs_dev, d_w.p(), p_flag, stream, dplan.p_timing);
+					p_values_dev, d_L.p(), b_store_linv? d_Linv.p() : 0, p_rhs_dev, d_w.p(), p_flag, stream, dplan.p_timing, t_batch);
 				b_leaf_linv_valid = b_leaf_linv_valid && b_store_linv;
 				if(n_rest > 0) {
 					TDevPlan t_rest = dplan;
 					t_rest.task_map = d_simt_rest.p();
 					launch_factor_stage(t_rest, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), simt_rest_ptr[s], n_rest,
-						true, p_flag, stream);
+						true, p_flag, stream, t_batch);
 				}
 			} else if(s == 0 && !panel_ptr.empty() && panel_ptr[1] > panel_ptr[0]) {
 				Launch_Panels(s, true); // few leaf subtrees: as panels (they receive no updates: the update just copies Lambda's blocks over)
 			} else if(s > 0 && s < n_bottom_stages && dplan.task_pkg)
 				launch_factor_wide(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
-					P.stage_ptr[s + 1] - P.stage_ptr[s], p_flag, stream);
+					P.stage_ptr[s + 1] - P.stage_ptr[s], p_flag, stream, t_batch);
 			else if(s >= n_bottom_stages && !panel_ptr.empty()) {
 				Launch_Panels(s, false); // separators: as panels in LDS where they fit, column by column otherwise
 			} else
 			launch_factor_stage(dplan, p_values_dev, d_L.p(), d_Linv.p(), p_rhs_dev, d_w.p(), P.stage_ptr[s],
-				P.stage_ptr[s + 1] - P.stage_ptr[s], s < n_bottom_stages, p_flag, stream);
+				P.stage_ptr[s + 1] - P.stage_ptr[s], s < n_bottom_stages, p_flag, stream, t_batch);
 			if(s == 0 || (s == n_wide_end - 1 && b_profile >= 2) || s == n_stages - 1)
 				Phase_End();
 		}
@@ -175,18 +175,18 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			// wave-per-task kernel (their factor kernel stored the inverses)
 			const int n_chunks = simt_chunk_ptr[s] - simt_chunk_ptr[s - 1], n_rest = simt_rest_ptr[s] - simt_rest_ptr[s - 1];
 			launch_backward_simt(d_simt_bwd_chunks.p() + simt_chunk_ptr[s - 1], n_chunks, n_simt_width, simt_bwd_lds_bytes[s - 1],
-				d_simt_bwd_prog.p(), d_simt_bwd_tab.p(), P.max_dim, d_L.p(), d_w.p(), p_rhs_dev, stream);
+				d_simt_bwd_prog.p(), d_simt_bwd_tab.p(), P.max_dim, d_L.p(), d_w.p(), p_rhs_dev, stream, t_batch);
 			if(n_rest > 0) {
 				TDevPlan t_rest = dplan;
 				t_rest.task_map = d_simt_rest.p();
-				launch_backward_stage(t_rest, d_L.p(), d_Linv.p(), d_w.p(), p_rhs_dev, simt_rest_ptr[s - 1], n_rest, stream);
+				launch_backward_stage(t_rest, d_L.p(), d_Linv.p(), d_w.p(), p_rhs_dev, simt_rest_ptr[s - 1], n_rest, stream, t_batch);
 			}
 			continue;
 		}
 		if(s < int(simt_chunk_ptr.size()))
 			Ensure_Leaf_Inverses(); // (the wave-per-task kernel on a lane-per-task stage: unaligned caller vector)
 		launch_backward_stage(dplan, d_L.p(), d_Linv.p(), d_w.p(), p_rhs_dev, P.stage_ptr[s - 1],
-			P.stage_ptr[s] - P.stage_ptr[s - 1], stream);
+			P.stage_ptr[s] - P.stage_ptr[s - 1], stream, t_batch);
 	}
 	Phase_End();
 	SLAMPP_HIP_CHECK(hipGetLastError());

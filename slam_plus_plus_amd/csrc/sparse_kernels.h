@@ -6,6 +6,18 @@
 
 namespace slampp {
 
+// K value sets of ONE structure factored and solved by the same launches (slampp_hip_factor_solve_batch_device_async; the
+// reference's LM loop tries its damping values one after the other: NonlinearSolver_Lambda_LM.h:967-1001, 1660-1676): the
+// kernels of the sparse block path take their member from blockIdx.y and step their base pointers by these strides (in
+// doubles; the not-positive-definite flag is one int per member).  n = 1, strides 0: an ordinary solve.
+struct TBatch {
+	int n;
+	int64_t a, l, linv, b, w, h; // Lambda's values, the factor, the inverses of its diagonal blocks, the caller's vector, the workspace, the hand-up buffer
+};
+inline TBatch t_No_Batch() { TBatch t = {1, 0, 0, 0, 0, 0, 0}; return t; }
+
+
+
 // One record per block column / factor block / row entry, packed so that a kernel gets everything
 // it needs about an item with one (wave-uniform, broadcast) load instead of a chain of dependent
 // index loads -- the path is latency-bound, every dependent load on it costs about a microsecond.
@@ -153,9 +165,9 @@ inline __host__ __device__ TPanelLds panel_lds(int D, bool b_fused, const TPanel
 // (out_off: per task the offset of its hand-up list in pkg, or -1; H: the hand-up buffer)
 bool launch_factor_panel(int n_dim, bool b_fused, bool b_rows, const TPanelLaunch &r_cfg, const longlong2 *pkg, const int64_t *pkg_off, const int64_t *out_off,
 	int n_tasks, const TUpdSlot *upd_slots, int n_upd_slots, const TUpdEnt *upd_ents, const double *A, const double *b, double *L, double *Linv, double *w,
-	double *H, int *p_flag, hipStream_t stream, long long *p_timing = 0);
+	double *H, int *p_flag, hipStream_t stream, long long *p_timing = 0, const TBatch &t_batch = t_No_Batch());
 void launch_panel_update(int n_dim, const TUpdSlot *slots, int n_slots, const TUpdEnt *ents, const double *A, double *L,
-	const double *b, double *w, hipStream_t stream);
+	const double *b, double *w, hipStream_t stream, const TBatch &t_batch = t_No_Batch());
 
 // capacities of the staged path of the separator kernel (blocks, row entries, update pairs of a column): near the root,
 // and in the wide stages right above the leaves
@@ -207,12 +219,12 @@ bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, int n_width /* t
 	int n_lds_bytes /* the largest table of the chunks: fields x width x 8 */,
 	const int32_t *prog, const int64_t *tab, int n_dim,
 	const double *A, double *L, double *Linv /* null: inv(L_jj) is not stored */, const double *b, double *w, int *p_flag, hipStream_t stream,
-	long long *p_timing = 0 /* development aid, as TDevPlan::p_timing */);
+	long long *p_timing = 0 /* development aid, as TDevPlan::p_timing */, const TBatch &t_batch = t_No_Batch());
 // backward substitution of the same tasks, a lane per task (chunk programs: n_cols, number of sub-diagonal blocks, nb per
 // column; tables: per column offset of its first factor block, scalar offsets in the workspace and in the caller's vector,
 // then the workspace offset of every sub-diagonal block's row): x_j from L_jj^T directly, no inverse
 bool launch_backward_simt(const TSimtChunk *chunks, int n_chunks, int n_width, int n_lds_bytes, const int32_t *prog, const int64_t *tab,
-	int n_dim, const double *L, double *w, double *x_out, hipStream_t stream);
+	int n_dim, const double *L, double *w, double *x_out, hipStream_t stream, const TBatch &t_batch = t_No_Batch());
 // inv(L_jj) of the columns cols[col_begin .. col_end) (schedule order) from their factor blocks: for callers that need the
 // inverses the lane-per-task factorization did not store (another right-hand side, covariances)
 bool launch_invert_diagonals(const TDevPlan &p, int64_t col_begin, int64_t col_end, const double *L, double *Linv, hipStream_t stream);
@@ -220,20 +232,20 @@ bool launch_invert_diagonals(const TDevPlan &p, int64_t col_begin, int64_t col_e
 // numeric factorization of one stage, with the forward substitution y = L^-1 b fused in
 // (b is read at its original position, y written to the permuted workspace w)
 void launch_factor_stage(const TDevPlan &p, const double *A, double *L, double *Linv, const double *b,
-	double *w, int task_begin, int n_tasks, bool b_bottom_stage, int *p_flag, hipStream_t stream);
+	double *w, int task_begin, int n_tasks, bool b_bottom_stage, int *p_flag, hipStream_t stream, const TBatch &t_batch = t_No_Batch());
 // bottom stages out of LDS (subtree_kernel.hip); returns false if the block dimension has no such kernel
 bool launch_factor_subtree_image(const TDevPlan &p, const double *A, double *L, double *Linv, const double *b,
-	double *w, int task_begin, int n_tasks, int *p_flag, hipStream_t stream);
+	double *w, int task_begin, int n_tasks, int *p_flag, hipStream_t stream, const TBatch &t_batch = t_No_Batch());
 // the wide stages right above the leaves: thousands of single separator columns whose operands other launches produced;
 // the separator kernel with one wave per column and small capacities (needs the column packages of those tasks)
 void launch_factor_wide(const TDevPlan &p, const double *A, double *L, double *Linv, const double *b,
-	double *w, int task_begin, int n_tasks, int *p_flag, hipStream_t stream);
+	double *w, int task_begin, int n_tasks, int *p_flag, hipStream_t stream, const TBatch &t_batch = t_No_Batch());
 // stand-alone forward substitution (another right-hand side with a kept factor)
 void launch_forward_stage(const TDevPlan &p, const double *L, const double *Linv, const double *b,
 	double *w, int task_begin, int n_tasks, hipStream_t stream);
 // backward substitution x = L^-T y, scattering x to its original position
 void launch_backward_stage(const TDevPlan &p, const double *L, const double *Linv, double *w,
-	double *x_out, int task_begin, int n_tasks, hipStream_t stream);
+	double *x_out, int task_begin, int n_tasks, hipStream_t stream, const TBatch &t_batch = t_No_Batch());
 
 // dense top (see plan.h): Schur complement of the block-eliminated part onto the dense-top columns,
 // written into the lower triangle of the dense matrix Dm (leading dimension ld, right-hand side in row ld-1)

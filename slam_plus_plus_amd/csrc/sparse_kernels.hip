@@ -39,8 +39,9 @@ namespace slampp {
 template <int D>
 __global__ void __launch_bounds__(64)
 factor_subtree_kernel(TDevPlan p, const double *__restrict__ A, double *L, double *Linv,
-	const double *__restrict__ b, double *w, int task_begin, int *p_flag)
-{
+	const double *__restrict__ b, double *w, int task_begin, int *p_flag, TBatch t_batch)
+{	{ const int64_t n_member = blockIdx.y; A += n_member * t_batch.a; L += n_member * t_batch.l; Linv += n_member * t_batch.linv; b += n_member * t_batch.b; w += n_member * t_batch.w; p_flag += n_member; } // (TBatch: sparse_kernels.h)
+
 	__shared__ double s_linv[64];  // inv(L_jj), element (r,c) at r + 8 c
 	__shared__ double s_rdiag[8];  // 1 / L_jj(k,k)
 	__shared__ double s_tile[64];
@@ -92,8 +93,9 @@ factor_subtree_kernel(TDevPlan p, const double *__restrict__ A, double *L, doubl
 template <int D, int W, int CH, int NR, int NP>
 __global__ void __launch_bounds__(64 * W)
 factor_stage_kernel(TDevPlan p, const double *__restrict__ A, double *L, double *Linv,
-	const double *__restrict__ b, double *w, int task_begin, int *p_flag)
-{
+	const double *__restrict__ b, double *w, int task_begin, int *p_flag, TBatch t_batch)
+{	{ const int64_t n_member = blockIdx.y; A += n_member * t_batch.a; L += n_member * t_batch.l; Linv += n_member * t_batch.linv; b += n_member * t_batch.b; w += n_member * t_batch.w; p_flag += n_member; } // (TBatch: sparse_kernels.h)
+
 	__shared__ double s_linv[64];
 	__shared__ double s_rdiag[8];
 	__shared__ double s_tile[W][64];
@@ -468,8 +470,9 @@ forward_stage_kernel(TDevPlan p, const double *L, const double *Linv, const doub
 template <int D>
 __global__ void __launch_bounds__(64)
 backward_stage_kernel(TDevPlan p, const double *L, const double *Linv, double *w,
-	double *__restrict__ x_out, int task_begin)
-{
+	double *__restrict__ x_out, int task_begin, TBatch t_batch)
+{	{ const int64_t n_member = blockIdx.y; L += n_member * t_batch.l; Linv += n_member * t_batch.linv; w += n_member * t_batch.w; x_out += n_member * t_batch.b; } // (TBatch: sparse_kernels.h)
+
 	const int lane = threadIdx.x, g = lane >> 3, q = lane & 7;
 	const int task = p.task_map? p.task_map[task_begin + blockIdx.x] : task_begin + blockIdx.x;
 	const int64_t c_begin = p.task_ptr[task], c_end = p.task_ptr[task + 1];
@@ -643,28 +646,28 @@ dense_assemble_kernel(TDevPlan p, const TDenseBlk *__restrict__ blks, const doub
 	default: { enum { D = 0 }; CALL; } break; } } while(0)
 
 void launch_factor_stage(const TDevPlan &p, const double *A, double *L, double *Linv, const double *b,
-	double *w, int task_begin, int n_tasks, bool b_bottom_stage, int *p_flag, hipStream_t stream)
+	double *w, int task_begin, int n_tasks, bool b_bottom_stage, int *p_flag, hipStream_t stream, const TBatch &t_batch)
 {
 	if(n_tasks <= 0)
 		return;
 	if(b_bottom_stage) { // one wave per task (the host decides which stages: solver.hip, n_bottom_stages)
 		const bool b_first_version = dev_knob_set("SLAMPP_HIP_DEV_SUBTREE_V1"); // development aid: A/B timing (plan.h)
-		if(!b_first_version && launch_factor_subtree_image(p, A, L, Linv, b, w, task_begin, n_tasks, p_flag, stream))
+		if(!b_first_version && launch_factor_subtree_image(p, A, L, Linv, b, w, task_begin, n_tasks, p_flag, stream, t_batch))
 			return;
-		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_subtree_kernel<D>), dim3(n_tasks), dim3(64), 0, stream,
-			p, A, L, Linv, b, w, task_begin, p_flag));
+		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_subtree_kernel<D>), dim3(n_tasks, t_batch.n), dim3(64), 0, stream,
+			p, A, L, Linv, b, w, task_begin, p_flag, t_batch));
 	} else {
-		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_stage_kernel<D, 8, CHUNK, UP_NR, UP_NP>), dim3(n_tasks), dim3(512), 0, stream,
-			p, A, L, Linv, b, w, task_begin, p_flag));
+		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_stage_kernel<D, 8, CHUNK, UP_NR, UP_NP>), dim3(n_tasks, t_batch.n), dim3(512), 0, stream,
+			p, A, L, Linv, b, w, task_begin, p_flag, t_batch));
 	}
 }
 
 void launch_factor_wide(const TDevPlan &p, const double *A, double *L, double *Linv, const double *b,
-	double *w, int task_begin, int n_tasks, int *p_flag, hipStream_t stream)
+	double *w, int task_begin, int n_tasks, int *p_flag, hipStream_t stream, const TBatch &t_batch)
 {
 	if(n_tasks > 0)
-		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_stage_kernel<D, 1, WIDE_CHUNK, WIDE_NR, WIDE_NP>), dim3(n_tasks), dim3(64), 0, stream,
-			p, A, L, Linv, b, w, task_begin, p_flag));
+		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((factor_stage_kernel<D, 1, WIDE_CHUNK, WIDE_NR, WIDE_NP>), dim3(n_tasks, t_batch.n), dim3(64), 0, stream,
+			p, A, L, Linv, b, w, task_begin, p_flag, t_batch));
 }
 
 void launch_forward_stage(const TDevPlan &p, const double *L, const double *Linv, const double *b,
@@ -676,11 +679,11 @@ void launch_forward_stage(const TDevPlan &p, const double *L, const double *Linv
 }
 
 void launch_backward_stage(const TDevPlan &p, const double *L, const double *Linv, double *w,
-	double *x_out, int task_begin, int n_tasks, hipStream_t stream)
+	double *x_out, int task_begin, int n_tasks, hipStream_t stream, const TBatch &t_batch)
 {
 	if(n_tasks > 0)
-		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((backward_stage_kernel<D>), dim3(n_tasks), dim3(64), 0, stream,
-			p, L, Linv, w, x_out, task_begin));
+		DISPATCH_DIM(p.uniform_dim, hipLaunchKernelGGL((backward_stage_kernel<D>), dim3(n_tasks, t_batch.n), dim3(64), 0, stream,
+			p, L, Linv, w, x_out, task_begin, t_batch));
 }
 
 void launch_dense_assemble(const TDevPlan &p, const TDenseBlk *blks, int n_blks, const double *A, const double *L,

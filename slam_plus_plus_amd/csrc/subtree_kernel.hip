@@ -26,8 +26,9 @@ namespace slampp {
 template <int D, int CAP_BLK>
 __global__ void __launch_bounds__(64)
 factor_subtree_image_kernel(TDevPlan p, const double *__restrict__ A, double *L, double *Linv,
-	const double *__restrict__ b, double *w, int task_begin, int *p_flag)
-{
+	const double *__restrict__ b, double *w, int task_begin, int *p_flag, TBatch t_batch)
+{	{ const int64_t n_member = blockIdx.y; A += n_member * t_batch.a; L += n_member * t_batch.l; Linv += n_member * t_batch.linv; b += n_member * t_batch.b; w += n_member * t_batch.w; p_flag += n_member; } // (TBatch: sparse_kernels.h)
+
 	enum { DD = D * D, CAP_COL = 8, CAP_PAIR = 2 * CAP_BLK, CAP_RENT = CAP_BLK };
 	__shared__ double s_linv[64];
 	__shared__ double s_tile[64];
@@ -165,20 +166,20 @@ factor_subtree_image_kernel(TDevPlan p, const double *__restrict__ A, double *L,
 }
 
 bool launch_factor_subtree_image(const TDevPlan &p, const double *A, double *L, double *Linv, const double *b,
-	double *w, int task_begin, int n_tasks, int *p_flag, hipStream_t stream)
+	double *w, int task_begin, int n_tasks, int *p_flag, hipStream_t stream, const TBatch &t_batch)
 {
 	switch(p.uniform_dim) {
 	case 3:
-		hipLaunchKernelGGL((factor_subtree_image_kernel<3, 64>), dim3(n_tasks), dim3(64), 0, stream, p, A, L, Linv, b, w,
-			task_begin, p_flag);
+		hipLaunchKernelGGL((factor_subtree_image_kernel<3, 64>), dim3(n_tasks, t_batch.n), dim3(64), 0, stream, p, A, L, Linv, b, w,
+			task_begin, p_flag, t_batch);
 		return true;
 	case 6:
-		hipLaunchKernelGGL((factor_subtree_image_kernel<6, 24>), dim3(n_tasks), dim3(64), 0, stream, p, A, L, Linv, b, w,
-			task_begin, p_flag);
+		hipLaunchKernelGGL((factor_subtree_image_kernel<6, 24>), dim3(n_tasks, t_batch.n), dim3(64), 0, stream, p, A, L, Linv, b, w,
+			task_begin, p_flag, t_batch);
 		return true;
 	case 7:
-		hipLaunchKernelGGL((factor_subtree_image_kernel<7, 20>), dim3(n_tasks), dim3(64), 0, stream, p, A, L, Linv, b, w,
-			task_begin, p_flag);
+		hipLaunchKernelGGL((factor_subtree_image_kernel<7, 20>), dim3(n_tasks, t_batch.n), dim3(64), 0, stream, p, A, L, Linv, b, w,
+			task_begin, p_flag, t_batch);
 		return true;
 	default:
 		return false;

@@ -126,6 +126,8 @@ ABI = {
     "slampp_hip_schur_marginals_device_async": (C.c_int, [_P, _P, _P, _P]),
     "slampp_hip_factor_solve_device_async": (C.c_int, [_P, _P, _P]),
     "slampp_hip_sync": (C.c_int, [_P]),
+    "slampp_hip_factor_solve_batch_device_async": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.c_int64]),
+    "slampp_hip_sync_batch": (C.c_int, [_P, C.POINTER(C.c_int), C.c_int]),
     "slampp_hip_stream": (_P, [_P]),
     "slampp_hip_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "slampp_hip_get_reduced_stats": (C.c_int, [_P, C.POINTER(Stats)]),
@@ -483,6 +485,17 @@ class _SolverBase:
 
     def factor_solve_device_async(self, values_ptr: int, rhs_ptr: int) -> None:
         self._check(self._lib.slampp_hip_factor_solve_device_async(self._h, values_ptr, rhs_ptr))
+
+    def factor_solve_batch_device_async(self, n_batch: int, values_ptr: int, values_stride: int, rhs_ptr: int, rhs_stride: int) -> None:
+        """K value sets of the analyzed structure in one pass of launches (slampp_hip_factor_solve_batch_device_async): member k
+        reads values_ptr + 8 k values_stride and overwrites rhs_ptr + 8 k rhs_stride (strides in doubles)."""
+        self._check(self._lib.slampp_hip_factor_solve_batch_device_async(self._h, int(n_batch), values_ptr, int(values_stride), rhs_ptr, int(rhs_stride)))
+
+    def sync_batch(self, n_batch: int):
+        """Waits for the batches enqueued so far; one bool per member: False = that member's matrix is not positive definite."""
+        st = (C.c_int * int(n_batch))()
+        self._check(self._lib.slampp_hip_sync_batch(self._h, st, int(n_batch)))
+        return [v == 0 for v in st]
 
     def sync(self) -> bool:
         return self._check(self._lib.slampp_hip_sync(self._h))

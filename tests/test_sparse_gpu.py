@@ -514,3 +514,103 @@ def test_panel_tasks_hand_their_contributions_up(case):
             assert rel_inf(eta, x_ref) < TOL
         xs.append(eta)
     assert rel_inf(xs[0], xs[1]) < 1e-10
+
+
+# ---- K value sets in one pass of launches (slampp_hip_factor_solve_batch_device_async; SURVEY.md section 8e: "replicas only
+# (multiple independent problems / damping values per GPU)"; the reference's LM loop re-damps and re-solves one value after
+# the other, NonlinearSolver_Lambda_LM.h:967-1001, 1660-1676) -------------------------------------------------------------------
+
+def _damped(lam, alpha):
+    """Lambda + alpha I on a copy (what ApplyDamping of the reference's LM solver does, NonlinearSolver_Lambda_LM.h:228-239)."""
+    import dataclasses
+    off = lam.block_value_offsets()
+    v = lam.values.copy()
+    for j in range(lam.n_bcols):
+        k = int(lam.bcol_ptr[j + 1] - 1)
+        d = int(lam.cumsum[j + 1] - lam.cumsum[j])
+        v[off[k]:off[k + 1]].reshape(d, d)[...] += alpha * np.eye(d)
+    return dataclasses.replace(lam, values=v)
+
+
+BATCH_CASES = {
+    "chain6": (lambda: synth.pose_chain(n=3000, d=6, seed=41), {}),                    # lane-per-task leaves, slices of the tree as panels
+    "chain3": (lambda: synth.pose_chain(n=2500, d=3, seed=42), {}),
+    "chain7_columns": (lambda: synth.pose_chain(n=1200, d=7, seed=43), {"panel": 0}),  # separators column by column
+    "chain6_waves": (lambda: synth.pose_chain(n=2000, d=6, seed=44), {"simt": 0}),     # a wave per leaf subtree
+    "sphere_dense_top": (lambda: synth.sphere(24, 24, seed=45), {}),                   # a dense top: the members one after the other
+    "mixed_sizes": (lambda: synth.ba(30, 1500, seed=46), {}),                          # 6 / 3 blocks through the sparse path
+}
+
+
+@pytest.mark.parametrize("pad", [0, 6, 3])     # member strides: tight, padded and even, odd (16-byte loads impossible: one by one)
+@pytest.mark.parametrize("name", sorted(BATCH_CASES))
+def test_batch_of_damped_systems_matches_the_oracle_member_by_member(name, pad):
+    import torch
+    make, opts = BATCH_CASES[name]
+    lam = make()
+    alphas = [0.0, 1e-3, 0.5, 7.0, 1e-6]
+    members = [_damped(lam, a) for a in alphas]
+    K = len(members)
+    sv, sr = lam.values.shape[0] + pad, lam.n_scalars + pad
+    sv += sv % 2 if pad != 3 else (1 - sv % 2)     # even strides, or (pad == 3) odd ones on purpose
+    sr += sr % 2 if pad != 3 else (1 - sr % 2)
+    vals = torch.zeros(K * sv, dtype=torch.float64, device="cuda")
+    rhs = torch.zeros(K * sr, dtype=torch.float64, device="cuda")
+    for k, m in enumerate(members):
+        vals[k * sv:k * sv + m.values.shape[0]] = torch.from_numpy(m.values).cuda()
+        rhs[k * sr:k * sr + m.n_scalars] = torch.from_numpy((k + 1.0) * m.rhs).cuda()
+    torch.cuda.synchronize()
+    solver = CLinearSolver_HIP(**opts)
+    assert solver.SymbolicDecomposition_Blocky(lam)
+    solver.factor_solve_batch_device_async(K, vals.data_ptr(), sv, rhs.data_ptr(), sr)
+    assert solver.sync_batch(K) == [True] * K
+    x = rhs.cpu().numpy()
+    for k, m in enumerate(members):
+        ok, x_ref, _ = O.solve_sparse(m)
+        assert ok and rel_inf(x[k * sr:k * sr + m.n_scalars], (k + 1.0) * x_ref) < TOL, (name, k)
+    # the handle still solves single systems afterwards (its own factor was not the batch's)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef_Blocky(lam, eta) and rel_inf(eta, O.solve_sparse(lam)[1]) < TOL
+
+
+def test_batch_member_that_is_not_positive_definite_fails_alone():
+    import torch
+    lam = synth.pose_chain(n=2000, d=6, seed=47)
+    bad = _damped(lam, -40.0)
+    assert O.solve_sparse(bad)[0] is False
+    members = [lam, bad, _damped(lam, 0.25)]
+    K, sv, sr = 3, lam.values.shape[0] + lam.values.shape[0] % 2, lam.n_scalars
+    vals = torch.stack([torch.from_numpy(np.pad(m.values, (0, sv - m.values.shape[0]))) for m in members]).cuda().contiguous()
+    rhs = torch.stack([torch.from_numpy(m.rhs) for m in members]).cuda().contiguous()
+    solver = CLinearSolver_HIP()
+    assert solver.SymbolicDecomposition_Blocky(lam)
+    for _ in range(2):                         # twice: the flags of the first round must not leak into the second
+        r = rhs.clone()
+        torch.cuda.synchronize()
+        solver.factor_solve_batch_device_async(K, vals.data_ptr(), sv, r.data_ptr(), sr)
+        assert solver.sync_batch(K) == [True, False, True]
+        x = r.cpu().numpy()
+        for k in (0, 2):
+            assert rel_inf(x[k], O.solve_sparse(members[k])[1]) < TOL
+    good = torch.stack([torch.from_numpy(m.values) for m in (lam, lam)]).cuda().contiguous()
+    if good.shape[1] % 2 == 0:
+        r = rhs[:2].clone()
+        torch.cuda.synchronize()
+        solver.factor_solve_batch_device_async(2, good.data_ptr(), good.shape[1], r.data_ptr(), sr)
+        assert solver.sync_batch(2) == [True, True]
+
+
+def test_batch_is_refused_where_it_does_not_apply():
+    from slam_plus_plus_amd.hip_solver import CLinearSolver_Schur_HIP
+    ba = synth.ba(20, 600, seed=3)
+    schur = CLinearSolver_Schur_HIP()
+    assert schur.SymbolicDecomposition_Blocky(ba)
+    with pytest.raises(Exception):
+        schur.factor_solve_batch_device_async(2, 8, ba.values.shape[0], 8, ba.n_scalars)
+    lam = synth.pose_chain(n=50, d=6)
+    solver = CLinearSolver_HIP()
+    assert solver.SymbolicDecomposition_Blocky(lam)
+    with pytest.raises(Exception):
+        solver.factor_solve_batch_device_async(2, 8, lam.values.shape[0] - 1, 8, lam.n_scalars)   # overlapping members
+    with pytest.raises(Exception):
+        solver.factor_solve_batch_device_async(65, 8, lam.values.shape[0], 8, lam.n_scalars)      # more than SLAMPP_HIP_MAX_BATCH
