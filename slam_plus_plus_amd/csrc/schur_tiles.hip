@@ -267,7 +267,13 @@ schur_tile_kernel(const int32_t *__restrict__ tile_ptr, const int32_t *__restric
 // and go through LDS into the fragment layout (lane = (row or column, k)).  Loading the fragments straight from memory
 // -- eight 8-byte gathers per landmark over its 576-byte record -- cost 176 L1 accesses per landmark and ran at
 // 216 us for C4; coalesced it is ten.
-template <int DC, int DP, int NT, bool b_diag, bool b_prefix> // b_prefix: some landmarks of the job end before the run's list does
+// b_quad (round 5): FOUR landmarks per matrix-core step instead of one.  The K dimension of v_mfma_f64_16x16x4 held the
+// three coordinates of ONE landmark (and an idle fourth slot): per landmark the wave read C^-1, formed W's column and issued
+// a full set of tiles, 131 vector instructions beside 10 matrix ones.  With K = four landmarks -- lane (m16, kk) works on
+// landmark kk of a quad, and the three coordinates are three rounds of tiles, S += sum_j U(:, j) W(:, j)^T -- no slot is idle
+// (9 matrix instructions per tile set and quad instead of 12), the lanes of different kk no longer read the same U values
+// four times, and C^-1, C^-1 l and the masks are fetched once per quad and lane.
+template <int DC, int DP, int NT, bool b_diag, bool b_prefix, bool b_quad = false> // b_prefix: some landmarks of the job end before the run's list does
 __global__ void __launch_bounds__(64)
 schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ run_lm, const int64_t *__restrict__ run_rec,
 	const int32_t *__restrict__ run_k, int64_t ubase, const double *__restrict__ A, const double *__restrict__ eta, int n, double *Cinv, double *W, int b_store,
@@ -281,6 +287,9 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 	__shared__ double s_ci[64 * DP * DP];
 	__shared__ double s_z[64 * DP];
 	__shared__ double s_u[GROUP][b_diag? SEG : 2 * SEG]; // [blocks of the row observations | of the column observations, if they are others]
+	__shared__ int s_kown[b_quad? 64 : 1];       // b_quad: every landmark's own number of observations (0 past the piece's end) ...
+	__shared__ int64_t s_o0[b_quad? 64 : 1];     // ... and its first observation (where its W goes)
+	static_assert(!b_quad || GROUP % 4 == 0, "quads of landmarks");
 	const int lane = threadIdx.x, kk = lane >> 4, m16 = lane & 15;
 	const TRunJob job = jobs[blockIdx.x];
 	const int k = job.n_k, n_rb = job.n_rb, n_cb = job.n_cb, n_points = job.n_points;
@@ -291,9 +300,9 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 	#pragma unroll
 	for(int t = 0; t < NT; ++ t) {
 		const int n_line = t * 16 + m16, o = n_line / DC, e = n_line - o * DC;
-		b_a[t] = o < OB && n_rb * OB + o < k && kk < DP;
-		n_off_a[t] = b_a[t]? o * BLK + kk * DC + e : 0;
-		b_b[t] = o < OB && n_cb * OB + o < k && kk < DP;
+		b_a[t] = o < OB && n_rb * OB + o < k && (b_quad || kk < DP);
+		n_off_a[t] = b_a[t]? o * BLK + (b_quad? 0 : kk * DC) + e : 0; // (b_quad: element (row, 0); the lane reads all three columns)
+		b_b[t] = o < OB && n_cb * OB + o < k && (b_quad || kk < DP);
 		n_off_b[t] = (b_b[t]? o * BLK + e : 0) + (b_diag? 0 : SEG);
 		n_obs_a[t] = n_rb * OB + o;
 		n_obs_b[t] = n_cb * OB + o;
@@ -371,6 +380,10 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 	}
 	if(b_bad)
 		atomicOr(p_flag, 1);
+	if constexpr(b_quad) {
+		s_kown[lane] = (lane < n_points)? my_k : 0;
+		s_o0[lane] = (lane < n_points)? (my_rec - ubase - my_pt * (DP * DP)) / BLK : 0;
+	}
 	for(int p0 = 0; p0 < n_points; p0 += GROUP) {
 		wave_lds_fence(); // the previous group's fragments have been read (and, the first time, s_ci / s_z written)
 		#pragma unroll
@@ -385,47 +398,125 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 		}
 		wave_lds_fence();
 		Request(p0 + GROUP); // (past the end: re-reads the last landmark)
-		#pragma unroll
-		for(int g = 0; g < GROUP; ++ g) {
-			const int p = min(p0 + g, n_points - 1);
-			const bool b_live = p0 + g < n_points;
-			const int n_k_own = b_prefix? __builtin_amdgcn_readlane(my_k, p) : k; // observations of this landmark
-			double cik[DP], wb[NT], ua[NT];
+		if constexpr(b_quad) {
 			#pragma unroll
-			for(int j = 0; j < DP; ++ j)
-				cik[j] = s_ci[p * (DP * DP) + j + kc * DP];
-			const double z = s_z[p * DP + kc];
-			#pragma unroll
-			for(int t = 0; t < NT; ++ t) {
-				const double u = s_u[g][n_off_a[t]];
-				ua[t] = (b_a[t] && b_live && (!b_prefix || n_obs_a[t] < n_k_own))? u : 0.0;
-				racc[t] += ua[t] * z;
-				double w = 0;
+			for(int q0 = 0; q0 < GROUP; q0 += 4) {
+				if(p0 + q0 >= n_points) // (wave-uniform: the whole quad lies past the piece's end)
+					break;
+				const int g = q0 + kk;                        // this lane's landmark of the quad
+				const int p = min(p0 + g, n_points - 1);
+				const int n_k_lane = (p0 + g < n_points)? (b_prefix? s_kown[p] : k) : 0; // observations of this lane's landmark (0: no landmark)
+				double ci[DP * DP], z[DP];
+				#pragma unroll
+				for(int i = 0; i < DP * DP; ++ i)
+					ci[i] = s_ci[p * (DP * DP) + i];
 				#pragma unroll
 				for(int j = 0; j < DP; ++ j)
-					w += s_u[g][n_off_b[t] + j * DC] * cik[j]; // W(q, kk) = sum_j U(q, j) C^-1(j, kk)
-				wb[t] = (b_b[t] && (!b_prefix || n_obs_b[t] < n_k_own))? w : 0.0;
-			}
-			// (b_prefix: a landmark that ends inside the row block fills only the first tiles of rows -- and, on the diagonal, of
-			// columns --: the others would multiply zeros, and these kernels spend 27 - 36 % of the fp64 matrix peak as it is)
-			const int n_rt_own = b_prefix? (min(n_k_own - n_rb * OB, int(OB)) * DC + 15) / 16 : NT;
-			#pragma unroll
-			for(int rt = 0; rt < NT; ++ rt) {
-				if(b_prefix && rt >= n_rt_own) // (wave-uniform)
-					continue;
-				#pragma unroll
-				for(int ct = 0; ct < NT; ++ ct) {
-					if(ct <= rt || !b_diag)
-						acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[rt], wb[ct], acc[rt][ct], 0, 0, 0);
-				}
-			}
-			if(b_store_w && b_live) {
-				const int64_t o0 = (readlane64(my_rec, p) - ubase - readlane64(my_pt, p) * (DP * DP)) / BLK; // first observation of the landmark
+					z[j] = s_z[p * DP + j];
+				const double *su = &s_u[0][0] + g * (b_diag? SEG : 2 * SEG);
+				double ua[NT][DP], wb[NT][DP];
+				bool b_wb[NT];
 				#pragma unroll
 				for(int t = 0; t < NT; ++ t) {
-					if(b_b[t] && n_obs_b[t] < n_k_own) {
-						const int n_line = t * 16 + m16, o = n_line / DC, q = n_line - o * DC;
-						W[(o0 + n_obs_b[t]) * BLK + q + kk * DC] = wb[t];
+					const bool b_row = b_a[t] && n_obs_a[t] < n_k_lane;
+					double u[DP], v[DP];
+					#pragma unroll
+					for(int j = 0; j < DP; ++ j) {
+						u[j] = su[n_off_a[t] + j * DC];
+						ua[t][j] = b_row? u[j] : 0.0;
+						racc[t] += ua[t][j] * z[j];
+					}
+					#pragma unroll
+					for(int j = 0; j < DP; ++ j)
+						v[j] = b_diag? u[j] : su[n_off_b[t] + j * DC];
+					b_wb[t] = b_b[t] && n_obs_b[t] < n_k_lane;
+					#pragma unroll
+					for(int jj = 0; jj < DP; ++ jj) {
+						double w = 0;
+						#pragma unroll
+						for(int i = 0; i < DP; ++ i)
+							w += v[i] * ci[i + jj * DP]; // W(q, jj) = sum_i U(q, i) C^-1(i, jj)
+						wb[t][jj] = b_wb[t]? w : 0.0;
+					}
+				}
+				// (b_prefix: the longest landmark of the quad says how many row tiles are not all zeros)
+				int n_k_quad = k;
+				if(b_prefix) {
+					n_k_quad = 0;
+					#pragma unroll
+					for(int i = 0; i < 4; ++ i)
+						n_k_quad = max(n_k_quad, (p0 + q0 + i < n_points)? __builtin_amdgcn_readlane(my_k, min(p0 + q0 + i, n_points - 1)) : 0);
+				}
+				const int n_rt_own = b_prefix? (min(n_k_quad - n_rb * OB, int(OB)) * DC + 15) / 16 : NT;
+				#pragma unroll
+				for(int j = 0; j < DP; ++ j) {
+					#pragma unroll
+					for(int rt = 0; rt < NT; ++ rt) {
+						if(b_prefix && rt >= n_rt_own) // (wave-uniform)
+							continue;
+						#pragma unroll
+						for(int ct = 0; ct < NT; ++ ct) {
+							if(ct <= rt || !b_diag)
+								acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[rt][j], wb[ct][j], acc[rt][ct], 0, 0, 0);
+						}
+					}
+				}
+				if(b_store_w) {
+					const int64_t o0 = s_o0[p];
+					#pragma unroll
+					for(int t = 0; t < NT; ++ t) {
+						if(b_wb[t]) {
+							const int n_line = t * 16 + m16, o = n_line / DC, q = n_line - o * DC;
+							#pragma unroll
+							for(int jj = 0; jj < DP; ++ jj)
+								W[(o0 + n_obs_b[t]) * BLK + q + jj * DC] = wb[t][jj];
+						}
+					}
+				}
+			}
+		} else {
+			#pragma unroll
+			for(int g = 0; g < GROUP; ++ g) {
+				const int p = min(p0 + g, n_points - 1);
+				const bool b_live = p0 + g < n_points;
+				const int n_k_own = b_prefix? __builtin_amdgcn_readlane(my_k, p) : k; // observations of this landmark
+				double cik[DP], wb[NT], ua[NT];
+				#pragma unroll
+				for(int j = 0; j < DP; ++ j)
+					cik[j] = s_ci[p * (DP * DP) + j + kc * DP];
+				const double z = s_z[p * DP + kc];
+				#pragma unroll
+				for(int t = 0; t < NT; ++ t) {
+					const double u = s_u[g][n_off_a[t]];
+					ua[t] = (b_a[t] && b_live && (!b_prefix || n_obs_a[t] < n_k_own))? u : 0.0;
+					racc[t] += ua[t] * z;
+					double w = 0;
+					#pragma unroll
+					for(int j = 0; j < DP; ++ j)
+						w += s_u[g][n_off_b[t] + j * DC] * cik[j]; // W(q, kk) = sum_j U(q, j) C^-1(j, kk)
+					wb[t] = (b_b[t] && (!b_prefix || n_obs_b[t] < n_k_own))? w : 0.0;
+				}
+				// (b_prefix: a landmark that ends inside the row block fills only the first tiles of rows -- and, on the diagonal, of
+				// columns --: the others would multiply zeros, and these kernels spend 27 - 36 % of the fp64 matrix peak as it is)
+				const int n_rt_own = b_prefix? (min(n_k_own - n_rb * OB, int(OB)) * DC + 15) / 16 : NT;
+				#pragma unroll
+				for(int rt = 0; rt < NT; ++ rt) {
+					if(b_prefix && rt >= n_rt_own) // (wave-uniform)
+						continue;
+					#pragma unroll
+					for(int ct = 0; ct < NT; ++ ct) {
+						if(ct <= rt || !b_diag)
+							acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[rt], wb[ct], acc[rt][ct], 0, 0, 0);
+					}
+				}
+				if(b_store_w && b_live) {
+					const int64_t o0 = (readlane64(my_rec, p) - ubase - readlane64(my_pt, p) * (DP * DP)) / BLK; // first observation of the landmark
+					#pragma unroll
+					for(int t = 0; t < NT; ++ t) {
+						if(b_b[t] && n_obs_b[t] < n_k_own) {
+							const int n_line = t * 16 + m16, o = n_line / DC, q = n_line - o * DC;
+							W[(o0 + n_obs_b[t]) * BLK + q + kk * DC] = wb[t];
+						}
 					}
 				}
 			}
@@ -517,9 +608,15 @@ static void tiles_enqueue_t(const CSchurTiles &T, const int64_t *ptr, int64_t nc
 {
 	{
 		const TRunJob *p_jobs = T.d_run_jobs.p();
-#define LAUNCH_RUNS(NT, DIAG, PFX) if(T.n_run_jobs[NT][DIAG][PFX]) hipLaunchKernelGGL((schur_run_kernel<DC, DP, NT, DIAG != 0, PFX != 0>), \
+		const bool b_quad = !dev_knob_set("SLAMPP_HIP_DEV_NO_QUAD_RUNS"); // (development: the one-landmark-per-step form, for A/B timing)
+		const bool b_quad_wide = dev_knob_set("SLAMPP_HIP_DEV_QUAD_WIDE"); // (development: quads also for the diagonal jobs of three and four tiles a side)
+#define LAUNCH_RUNS_Q(NT, DIAG, PFX, QUAD) hipLaunchKernelGGL((schur_run_kernel<DC, DP, NT, DIAG != 0, PFX != 0, QUAD>), \
 			dim3(unsigned(T.n_run_jobs[NT][DIAG][PFX])), dim3(64), 0, stream, p_jobs + T.n_run_job_first[NT][DIAG][PFX], T.d_run_lm.p(), \
 			T.d_run_rec.p(), T.d_run_k.p(), ubase, A, eta, n, Cinv, p_W, int(b_store), T.d_P.p(), T.d_R.p(), p_flag)
+		// (quads of landmarks where a job keeps at most two tiles a side -- eight landmarks staged at a time; the jobs of three
+		// and four tiles stage four or two and stay with one landmark per step)
+#define LAUNCH_RUNS(NT, DIAG, PFX) do { if(T.n_run_jobs[NT][DIAG][PFX]) { if((NT <= 2 || (DIAG && b_quad_wide)) && b_quad) LAUNCH_RUNS_Q(NT, DIAG, PFX, (NT <= 2 || DIAG)); \
+			else LAUNCH_RUNS_Q(NT, DIAG, PFX, false); } } while(0)
 #define LAUNCH_RUNS_D(NT, DIAG) do { LAUNCH_RUNS(NT, DIAG, 0); LAUNCH_RUNS(NT, DIAG, 1); } while(0)
 		LAUNCH_RUNS_D(1, 1);
 		LAUNCH_RUNS_D(2, 1);
@@ -531,6 +628,7 @@ static void tiles_enqueue_t(const CSchurTiles &T, const int64_t *ptr, int64_t nc
 		LAUNCH_RUNS_D(4, 0);
 #undef LAUNCH_RUNS_D
 #undef LAUNCH_RUNS
+#undef LAUNCH_RUNS_Q
 	}
 	if(T.n_tiles) {
 	enum { BLK = DC * DP, MAXK = tile_max_k(SCHUR_TILE_SLOTS), OPS = (MAXK * BLK > 320)? (MAXK * BLK + 63) / 64 * 64 : 320,
