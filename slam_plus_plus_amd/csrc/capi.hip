@@ -436,7 +436,10 @@ int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix
 		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
 		if(s.copy_stream)
 			SLAMPP_HIP_CHECK(hipStreamSynchronize(s.copy_stream));
-		s.Free_Device();
+		{
+			CKeepDeviceMemory t_keep; // (a re-analysis: the arrays cease to exist, their memory waits for the new plan's)
+			s.Free_Device();
+		}
 		s.b_group_active = false;
 		s.b_schur_fallback = false;
 		memset(&s.times, 0, sizeof(s.times));

@@ -609,12 +609,12 @@ static void tiles_enqueue_t(const CSchurTiles &T, const int64_t *ptr, int64_t nc
 	{
 		const TRunJob *p_jobs = T.d_run_jobs.p();
 		const bool b_quad = !dev_knob_set("SLAMPP_HIP_DEV_NO_QUAD_RUNS"); // (development: the one-landmark-per-step form, for A/B timing)
-		const bool b_quad_wide = dev_knob_set("SLAMPP_HIP_DEV_QUAD_WIDE"); // (development: quads also for the diagonal jobs of three and four tiles a side)
+		const bool b_quad_wide = !dev_knob_set("SLAMPP_HIP_DEV_NO_QUAD_WIDE"); // (quads also for the diagonal jobs of three and four tiles a side, four landmarks staged at a time: Venice-like C4 1.545 -> 1.486 ms; the off-diagonal ones stage two and stay as they were)
 #define LAUNCH_RUNS_Q(NT, DIAG, PFX, QUAD) hipLaunchKernelGGL((schur_run_kernel<DC, DP, NT, DIAG != 0, PFX != 0, QUAD>), \
 			dim3(unsigned(T.n_run_jobs[NT][DIAG][PFX])), dim3(64), 0, stream, p_jobs + T.n_run_job_first[NT][DIAG][PFX], T.d_run_lm.p(), \
 			T.d_run_rec.p(), T.d_run_k.p(), ubase, A, eta, n, Cinv, p_W, int(b_store), T.d_P.p(), T.d_R.p(), p_flag)
-		// (quads of landmarks where a job keeps at most two tiles a side -- eight landmarks staged at a time; the jobs of three
-		// and four tiles stage four or two and stay with one landmark per step)
+		// (quads of landmarks wherever a job stages a multiple of four landmarks at a time: all but the off-diagonal jobs of
+		// three and four tiles a side, which stage two)
 #define LAUNCH_RUNS(NT, DIAG, PFX) do { if(T.n_run_jobs[NT][DIAG][PFX]) { if((NT <= 2 || (DIAG && b_quad_wide)) && b_quad) LAUNCH_RUNS_Q(NT, DIAG, PFX, (NT <= 2 || DIAG)); \
 			else LAUNCH_RUNS_Q(NT, DIAG, PFX, false); } } while(0)
 #define LAUNCH_RUNS_D(NT, DIAG) do { LAUNCH_RUNS(NT, DIAG, 0); LAUNCH_RUNS(NT, DIAG, 1); } while(0)

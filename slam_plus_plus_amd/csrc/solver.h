@@ -30,23 +30,35 @@ inline double wall_ms()
 }
 
 // owning device array
+// CDevArray::Free() keeps the memory while this is set (thread-local: a handle is used from one thread at a time, the members
+// of a device group each from their own)
+extern thread_local bool g_b_keep_device_memory;
+
 template <class T>
 class CDevArray {
 	T *m_p;
-	size_t m_n;
+	size_t m_n, m_cap; // elements in use (0: the array does not exist for its users), elements allocated
 public:
-	CDevArray() :m_p(0), m_n(0) {}
-	~CDevArray() { Free(); }
+	CDevArray() :m_p(0), m_n(0), m_cap(0) {}
+	~CDevArray() { Release(); }
 	CDevArray(const CDevArray&) = delete;
 	CDevArray &operator =(const CDevArray&) = delete;
-	void Free() { if(m_p) (void)hipFree(m_p); m_p = 0; m_n = 0; }
+	// gives the memory back
+	void Release() { if(m_p) (void)hipFree(m_p); m_p = 0; m_n = 0; m_cap = 0; }
+	// The array ceases to exist for its users -- p() is null, n() zero -- but keeps its memory for the next Alloc().  A
+	// re-analysis frees and allocates some fifty arrays; hipFree synchronizes the device and hipMalloc is no cheaper: at
+	// the small systems FastL hands Factorize_PosDef_Blocky (a new part of R at almost every call) that was most of an
+	// analysis (round 5: DESIGN.md section 10).  slampp_hip_free_memory() and the destructor Release().
+	void Free() { m_n = 0; if(!g_b_keep_device_memory) Release(); }
 	void Alloc(size_t n) // throw(std::bad_alloc, CDeviceError)
 	{
-		if(n <= m_n && m_p)
-			return;
-		Free();
 		if(!n)
 			n = 1;
+		if(n <= m_cap && m_p) {
+			m_n = std::max(m_n, n); // (growing in place; a user that asks for less keeps what it has, as before)
+			return;
+		}
+		Release();
 		hipError_t e = hipMalloc((void**)&m_p, n * sizeof(T));
 		if(e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
 			(void)hipGetLastError();
@@ -57,7 +69,7 @@ public:
 			m_p = 0;
 			throw CDeviceError(std::string("hipMalloc: ") + hipGetErrorString(e));
 		}
-		m_n = n;
+		m_n = m_cap = n;
 	}
 	void Upload(const std::vector<T> &v, hipStream_t s)
 	{
@@ -65,10 +77,17 @@ public:
 		if(!v.empty())
 			SLAMPP_HIP_CHECK(hipMemcpyAsync(m_p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
 	}
-	T *p() const { return m_p; }
+	T *p() const { return m_n? m_p : 0; }
 	size_t n() const { return m_n; }
-	void Swap(CDevArray &r_other) { std::swap(m_p, r_other.m_p); std::swap(m_n, r_other.m_n); }
 	size_t n_Bytes() const { return m_p? m_n * sizeof(T) : 0; }
+	void Swap(CDevArray &r_other) { std::swap(m_p, r_other.m_p); std::swap(m_n, r_other.m_n); std::swap(m_cap, r_other.m_cap); }
+};
+
+// while one of these lives on a thread, the device arrays freed on that thread keep their memory (a re-analysis)
+struct CKeepDeviceMemory {
+	bool b_before;
+	CKeepDeviceMemory() :b_before(g_b_keep_device_memory) { g_b_keep_device_memory = true; }
+	~CKeepDeviceMemory() { g_b_keep_device_memory = b_before; }
 };
 
 struct CSchurState; // schur.hip

@@ -25,6 +25,10 @@
 
 using namespace slampp;
 
+namespace slampp {
+thread_local bool g_b_keep_device_memory = false;
+}
+
 slampp_hip_solver::slampp_hip_solver()
 	:n_device(0), stream(0), n_dense_nb(64), b_shard_primary(1), n_shard_rank(-1), n_shard_world(0), n_marginals_dense(0), n_schur_sparse(-1), b_has_structure(false),
 	b_analyzed(false), b_factored(false), n_mode(SLAMPP_HIP_MODE_SPARSE), n_matrix_cut(0),

@@ -691,3 +691,21 @@ def test_prefix_runs_take_the_long_tracks_off_the_contribution_lists(sparse, mon
     inc.Set_Changed_Landmarks(points)
     eta = lam2.rhs.copy()
     assert ok and inc.Solve_PosDef_Blocky(lam2, eta) and rel_inf(eta, x2) < TOL
+
+
+@pytest.mark.parametrize("knob", ["SLAMPP_HIP_DEV_NO_QUAD_RUNS", "SLAMPP_HIP_DEV_NO_QUAD_WIDE"])
+@pytest.mark.parametrize("mode", ["band", "venice", "tracks"])
+def test_run_kernel_one_landmark_per_step_and_quads_agree(mode, knob, monkeypatch):
+    """Round 5: the run kernel takes four landmarks per matrix-core step (K = landmark, three rounds for the coordinates)
+    where a job stages a multiple of four; the development knobs bring back the one-landmark-per-step form (all jobs / the
+    diagonal jobs of three and four tiles a side).  Same S, same solution, both against the oracle."""
+    lam = synth.ba(150, 6000, k=4, mode=mode, seed=21)
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok
+    eta = lam.rhs.copy()
+    assert CLinearSolver_Schur_HIP().Solve_PosDef(lam, eta) and rel_inf(eta, x_ref) < TOL
+    monkeypatch.setenv("SLAMPP_HIP_DEV", "1")
+    monkeypatch.setenv(knob, "1")
+    eta2 = lam.rhs.copy()
+    assert CLinearSolver_Schur_HIP().Solve_PosDef(lam, eta2) and rel_inf(eta2, x_ref) < TOL
+    assert rel_inf(eta2, eta) < 1e-11
