@@ -152,7 +152,10 @@ protected:
 			const int n_thread_num = n_Copy_Thread_Num();
 			const long n_col_num = long(n);
 			int n_unsorted = 0;
-			#pragma omp parallel for schedule(static) num_threads(n_thread_num) reduction(+:n_unsorted)
+			// (threads from 16 384 block columns on only: a team woken for a few hundred columns costs more than the loop, and
+			// under a CPU quota -- containers -- a burst of spinning threads can stall the process for a scheduler period:
+			// FastL's small parts of R took 90 ms here instead of 0.05, round 5)
+			#pragma omp parallel for schedule(static) num_threads(n_thread_num) reduction(+:n_unsorted) if(n_col_num >= 16384)
 			for(long c = 0; c < n_col_num; ++ c) {
 				const size_t m = r_lambda.n_BlockColumn_Block_Num(c);
 				m_col_block_num[c] = uint32_t(m);
@@ -184,7 +187,7 @@ protected:
 				const size_t n_block_num = size_t(m_bcol_ptr[n]);
 				m_brow.resize(n_block_num);
 				m_gather.resize(n_block_num);
-				#pragma omp parallel for schedule(static) num_threads(n_thread_num)
+				#pragma omp parallel for schedule(static) num_threads(n_thread_num) if(n_col_num >= 16384)
 				for(long c = 0; c < n_col_num; ++ c) {
 					int64_t n_dest = value_ptr[c];
 					const int32_t n_width = int32_t(m_col_width[c]);
@@ -333,7 +336,7 @@ protected:
 				n_last = n_lo;
 			}
 			int n_mismatch = 0;
-			#pragma omp parallel for schedule(static) reduction(+:n_mismatch) num_threads(n_thread_num) if(n_last - n_first > 512)
+			#pragma omp parallel for schedule(static) reduction(+:n_mismatch) num_threads(n_thread_num) if(n_last - n_first > 8192)
 			for(long k = n_first; k < n_last; ++ k) {
 				const TGatherEntry &t = m_gather[k];
 				if(r_lambda.n_Block_Row(t.n_col, t.n_blk) != t.n_row) {

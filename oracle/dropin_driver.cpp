@@ -156,6 +156,9 @@ class CTimedFactorize : public CBase {
 public:
 	static std::vector<TFactorizeCall> &r_Calls() { static std::vector<TFactorizeCall> v; return v; }
 	static double &f_Solve_Ms() { static double f = 0; return f; }
+	static bool &b_Verify() { static bool b = false; return b; }          // check every factor against CHOLMOD's of the same matrix
+	static double &f_Worst_Factor() { static double f = 0; return f; }   // ... the largest ||R - R_cholmod||_F / ||R_cholmod||_F seen
+	static size_t &n_Verdict_Mismatches() { static size_t n = 0; return n; }
 
 	bool Factorize_PosDef_Blocky(CUberBlockMatrix &r_factor, const CUberBlockMatrix &r_lambda,
 		std::vector<size_t> &r_workspace, size_t n_dest_row_id = 0, size_t n_dest_column_id = 0, bool b_upper_factor = true)
@@ -164,6 +167,23 @@ public:
 		const bool b_result = CBase::Factorize_PosDef_Blocky(r_factor, r_lambda, r_workspace, n_dest_row_id, n_dest_column_id, b_upper_factor);
 		TFactorizeCall t = {r_lambda.n_BlockColumn_Num(), r_lambda.n_Block_Num(), f_Wall_Ms() - f_t0};
 		r_Calls().push_back(t);
+		if(b_Verify()) { // the same matrix through a solver of this type and through CHOLMOD, into matrices of their own
+			CUberBlockMatrix R_own, R_ref;
+			r_lambda.CopyLayoutTo(R_own);
+			r_lambda.CopyLayoutTo(R_ref);
+			std::vector<size_t> workspace;
+			CBase own_solver;
+			CLinearSolver_CholMod ref_solver;
+			const bool b_own = own_solver.Factorize_PosDef_Blocky(R_own, r_lambda, workspace, 0, 0, true);
+			const bool b_ref = ref_solver.Factorize_PosDef_Blocky(R_ref, r_lambda, workspace, 0, 0, true);
+			if(b_own != b_ref || b_own != b_result)
+				++ n_Verdict_Mismatches();
+			else if(b_ref) {
+				const double f_ref_norm = R_ref.f_Norm();
+				R_ref.AddTo(R_own, -1.0); // R_own -= R_ref
+				f_Worst_Factor() = std::max(f_Worst_Factor(), R_own.f_Norm() / f_ref_norm);
+			}
+		}
 		return b_result;
 	}
 
@@ -483,9 +503,11 @@ int main(int n_arg_num, const char **p_arg_list)
 		typedef CFlatSystem<CVertexPose3D, TVertexTypelist, CEdgePose3D, TEdgeTypelist> CSystemType;
 		const size_t n_poses = (n_arg_num > 2)? size_t(atol(p_arg_list[2])) : 2000;
 		const bool b_every = n_arg_num > 3 && atoi(p_arg_list[3]) != 0;
+		const bool b_verify = n_arg_num > 4 && !strcmp(p_arg_list[4], "verify"); // (timings then include the check: use it for the check)
 		try {
 			typedef CTimedFactorize<CLinearSolver_CholMod> TRef;
 			typedef CTimedFactorize<CLinearSolver_HIP> THip;
+			THip::b_Verify() = b_verify;
 			double f_chi2_ref, f_chi2_hip;
 			double f_t0 = TRef::f_Wall_Ms();
 			std::vector<double> ref = Optimize_SE3_FastL<CSystemType, TRef>(n_poses, 78, f_chi2_ref, true, b_every);
@@ -524,7 +546,10 @@ int main(int n_arg_num, const char **p_arg_list)
 				b_first = false;
 			}
 			const CLinearSolver_HIP_Factorizer::TTimes &r_t = CLinearSolver_HIP_Factorizer::t_Times();
-			printf("], \"hip_split_ms\": {\"calls\": %d, \"analyses\": %d, \"analyze\": %.2f, \"gather\": %.2f, \"upload_factor_download\": %.2f, "
+			printf("]");
+			if(b_verify)
+				printf(", \"verify\": {\"factor_rel_fro_max\": %.3g, \"verdict_mismatches\": %d}", THip::f_Worst_Factor(), int(THip::n_Verdict_Mismatches()));
+			printf(", \"hip_split_ms\": {\"calls\": %d, \"analyses\": %d, \"analyze\": %.2f, \"gather\": %.2f, \"upload_factor_download\": %.2f, "
 				"\"scatter\": %.2f}}\n", int(r_t.n_calls), int(r_t.n_analyses), r_t.f_analyze_ms, r_t.f_gather_ms, r_t.f_factorize_ms, r_t.f_scatter_ms);
 			return 0;
 		} catch(std::exception &r_exc) {

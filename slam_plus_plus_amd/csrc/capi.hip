@@ -451,7 +451,8 @@ int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix
 		// comes up on a thread of its own while this one orders and analyzes
 		std::exception_ptr p_staging_error;
 		struct TJoin { std::thread t; ~TJoin() { if(t.joinable()) t.join(); } } t_staging_thread;
-		if(s.n_staging_ahead && s.group_devices.empty() && !dev_knob_set("SLAMPP_HIP_DEV_NO_STAGING_AHEAD")) { // (the variable: a development aid, plan.h)
+		// (a thread only where the staging is worth one: below 8 MB of values it is pinned on this thread, by whoever asks for it)
+		if(s.n_staging_ahead && s.group_devices.empty() && s.n_values >= (int64_t(1) << 20) && !dev_knob_set("SLAMPP_HIP_DEV_NO_STAGING_AHEAD")) { // (the variable: a development aid, plan.h)
 			t_staging_thread.t = std::thread([&s, &p_staging_error]() {
 				try {
 					SLAMPP_HIP_CHECK(hipSetDevice(s.n_device));

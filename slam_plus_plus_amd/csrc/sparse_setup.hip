@@ -120,13 +120,18 @@ void slampp_hip_solver::Analyze_Sparse()
 	std::exception_ptr p_simt_error;
 	struct TJoin { std::thread t; ~TJoin() { if(t.joinable()) t.join(); } } t_simt_thread;
 	const double t_simt = wall_ms();
-	t_simt_thread.t = std::thread([this, &p_simt_error]() {
-		try {
-			Build_Simt();
-		} catch(...) {
-			p_simt_error = std::current_exception();
-		}
-	});
+	const bool b_small = P.n < 8192; // (small systems -- FastL's parts of R, reduced camera systems -- do their host work on this thread: a thread is ~0.1 ms to start, and threads that spin under a CPU quota cost a scheduler period now and then)
+	if(b_small)
+		Build_Simt();
+	else {
+		t_simt_thread.t = std::thread([this, &p_simt_error]() {
+			try {
+				Build_Simt();
+			} catch(...) {
+				p_simt_error = std::current_exception();
+			}
+		});
+	}
 
 	if(P.cs_new[P.n] >= INT32_MAX)
 		throw std::domain_error("systems with 2^31 or more scalar unknowns are not supported by the sparse path");
@@ -222,6 +227,34 @@ void slampp_hip_solver::Analyze_Sparse()
 		pkg.resize(pkg.size() + PKG_SPECULATIVE, longlong2{0, 0});
 	}
 	SETUP_PHASE("records");
+	// the records go to the device beside the host work that follows (the packages of the separator tasks: ~10 ms each at C3,
+	// and an upload from a std::vector is a staged copy that keeps its thread): a thread of its own, joined before the rest
+	// of the uploads.  The vectors it reads are not written from here on.
+	std::exception_ptr p_upload_error;
+	struct TJoinUpload { std::thread t; ~TJoinUpload() { if(t.joinable()) t.join(); } } t_upload_thread;
+	auto Upload_Records = [&]() {
+		try {
+			SLAMPP_HIP_CHECK(hipSetDevice(n_device));
+			d_cols.Upload(cols, stream);
+			d_blks.Upload(blks, stream);
+			d_pairs.Upload(pairs, stream);
+			d_rents.Upload(rents, stream);
+			d_task_ptr.Upload(P.task_ptr, stream);
+			if(!pkg.empty()) {
+				d_pkg.Upload(pkg, stream);
+				d_task_pkg.Upload(task_pkg, stream);
+			} else {
+				d_pkg.Free();
+				d_task_pkg.Free();
+			}
+		} catch(...) {
+			p_upload_error = std::current_exception();
+		}
+	};
+	if(b_small)
+		Upload_Records();
+	else
+		t_upload_thread.t = std::thread(Upload_Records);
 	// dense top
 	n_dense_dim = P.dense_dim;
 	n_dense_pad = n_dense_dim? dense_padded_dim(n_dense_dim) : 0;
@@ -764,18 +797,10 @@ void slampp_hip_solver::Analyze_Sparse()
 	d_panel_out_off.Upload(panel_out_off, stream);
 	d_handup.Alloc(size_t(std::max<int64_t>(n_handup_doubles, int64_t(P.max_dim) * P.max_dim + 8))); // (every wave of a fused panel launch prefetches one block + 8 from offset 0, hand-ups or not)
 	d_panel_rest.Upload(panel_rest, stream);
-	d_cols.Upload(cols, stream);
-	d_blks.Upload(blks, stream);
-	d_pairs.Upload(pairs, stream);
-	d_rents.Upload(rents, stream);
-	d_task_ptr.Upload(P.task_ptr, stream);
-	if(!pkg.empty()) {
-		d_pkg.Upload(pkg, stream);
-		d_task_pkg.Upload(task_pkg, stream);
-	} else {
-		d_pkg.Free();
-		d_task_pkg.Free();
-	}
+	if(t_upload_thread.t.joinable())
+		t_upload_thread.t.join();
+	if(p_upload_error)
+		std::rethrow_exception(p_upload_error);
 	SETUP_PHASE("uploads");
 	d_L.Alloc(size_t(P.loff[n_lblocks]));
 	d_Linv.Alloc(size_t(P.linv_off[P.n]));
@@ -799,7 +824,8 @@ void slampp_hip_solver::Analyze_Sparse()
 	dplan.task_map = 0;
 	{
 		const double t_wait = wall_ms();
-		t_simt_thread.t.join();
+		if(t_simt_thread.t.joinable())
+			t_simt_thread.t.join();
 		if(p_simt_error)
 			std::rethrow_exception(p_simt_error);
 		Upload_Simt();

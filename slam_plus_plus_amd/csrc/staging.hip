@@ -150,11 +150,15 @@ static void Grow_Pinned(double *&r_p, size_t &r_n, bool &r_b_registered, size_t 
 {
 	if(r_n >= n_doubles && r_p)
 		return;
+	// a staging that has to grow grows to twice its size at least (the reference's workspaces do the same, e.g.
+	// LinearSolver_CholMod.cpp:898-901): an incremental solver hands over systems a few blocks larger at every call, and
+	// pinning is milliseconds each time
+	const size_t n_new = (r_p && r_n)? std::max(n_doubles, 2 * r_n) : n_doubles;
 	Free_Pinned(r_p, r_b_registered, r_n);
 	r_p = 0;
 	r_n = 0;
-	r_p = Alloc_Pinned(n_doubles, r_b_registered);
-	r_n = n_doubles;
+	r_p = Alloc_Pinned(n_new, r_b_registered);
+	r_n = n_new;
 }
 
 static double staging_wall_ms()
