@@ -515,10 +515,17 @@ int main(int n_arg_num, const char **p_arg_list)
 			f_t0 = TRef::f_Wall_Ms();
 			std::vector<double> hip = Optimize_SE3_FastL<CSystemType, THip>(n_poses, 78, f_chi2_hip, true, b_every);
 			const double f_total_hip = TRef::f_Wall_Ms() - f_t0;
+			// a second solver of the reference's own, for scale: FastL decides from thresholds on dx which parts of R to redo and
+			// when to relinearize, so two correct linear solvers need not take the same path through a long incremental run
+			typedef CTimedFactorize<CLinearSolver_CSparse> TRef2;
+			double f_chi2_ref2;
+			std::vector<double> ref2 = Optimize_SE3_FastL<CSystemType, TRef2>(n_poses, 78, f_chi2_ref2, true, b_every);
 			const std::vector<TFactorizeCall> &r_a = TRef::r_Calls(), &r_b = THip::r_Calls();
 			// the two runs make the same calls as long as FastL takes the same decisions; binned by size either way
 			const size_t p_edges[] = {0, 8, 32, 128, 512, 2048, 8192, size_t(-1)};
-			printf("{\"n_poses\": %d, \"loops_every_step\": %d, \"chi2_ref\": %.12g, \"chi2_hip\": %.12g, \"state_rel_inf\": %.3g, "
+			printf("{\"reference_csparse_vs_cholmod\": {\"chi2_csparse\": %.12g, \"state_rel_inf\": %.3g, \"factorize_calls_csparse\": %d}, ",
+				f_chi2_ref2, f_RelInf(ref2, ref), int(TRef2::r_Calls().size()));
+			printf("\"n_poses\": %d, \"loops_every_step\": %d, \"chi2_ref\": %.12g, \"chi2_hip\": %.12g, \"state_rel_inf\": %.3g, "
 				"\"run_total_ms\": {\"cholmod\": %.1f, \"hip\": %.1f}, \"solve_posdef_ms\": {\"cholmod\": %.1f, \"hip\": %.1f}, \"factorize_calls\": "
 				"{\"cholmod\": %d, \"hip\": %d}, \"by_block_columns\": [", int(n_poses), int(b_every), f_chi2_ref, f_chi2_hip, f_RelInf(hip, ref),
 				f_total_ref, f_total_hip, TRef::f_Solve_Ms(), THip::f_Solve_Ms(), int(r_a.size()), int(r_b.size()));

@@ -1167,11 +1167,13 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 		run_rec[i] = n_ablocks * DC * DC + o0 * DC * DP + pt * DP * DP;
 	}
 	T.d_run_rec.Upload(run_rec, stream);
-	T.d_tile_ptr.Upload(tile_ptr, stream);
-	T.d_tile_lm.Upload(tile_lm, stream);
-	T.d_tile_slot_ptr.Upload(tile_slot_ptr, stream);
-	T.d_pair_ptr.Upload(pair_ptr, stream);
-	T.d_lm_slot.Upload(lm_slot, stream);
+	if(T.n_tiles) { // (the tile kernel's tables: 16 bytes per landmark that nobody reads where every landmark is in a run -- 32 MB of C5's cold call)
+		T.d_tile_ptr.Upload(tile_ptr, stream);
+		T.d_tile_lm.Upload(tile_lm, stream);
+		T.d_tile_slot_ptr.Upload(tile_slot_ptr, stream);
+		T.d_pair_ptr.Upload(pair_ptr, stream);
+		T.d_lm_slot.Upload(lm_slot, stream);
+	}
 	T.d_rb_ptr.Upload(rb_ptr, stream);
 	T.d_rb_part.Upload(rb_part, stream);
 	T.d_rb_sb.Upload(rb_sb, stream);

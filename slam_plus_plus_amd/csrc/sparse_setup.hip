@@ -81,6 +81,39 @@ void slampp_hip_solver::Refine_Structure()
 	SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // map lives on this stack frame
 }
 
+// index ranges on a few threads (the record loops of the cold path: every entry written once, from the plan alone)
+template <class F>
+static void Parallel_Ranges(int64_t n, int64_t n_min_per_thread, F f)
+{
+	const int n_threads = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4, std::max(1u, std::thread::hardware_concurrency())), n / std::max<int64_t>(n_min_per_thread, 1))));
+	if(n_threads <= 1) {
+		f(int64_t(0), n);
+		return;
+	}
+	std::vector<std::thread> threads;
+	std::exception_ptr p_error;
+	std::mutex t_mutex;
+	for(int t = 0; t < n_threads; ++ t) {
+		const int64_t b = n * t / n_threads, e = n * (t + 1) / n_threads;
+		auto job = [&, b, e]() {
+			try {
+				f(b, e);
+			} catch(...) {
+				std::lock_guard<std::mutex> t_lock(t_mutex);
+				p_error = std::current_exception();
+			}
+		};
+		if(t + 1 < n_threads)
+			threads.emplace_back(job);
+		else
+			job();
+	}
+	for(size_t t = 0; t < threads.size(); ++ t)
+		threads[t].join();
+	if(p_error)
+		std::rethrow_exception(p_error);
+}
+
 void slampp_hip_solver::Analyze_Sparse()
 {
 	if(p_sinv) { // lists of the previous plan
@@ -156,7 +189,8 @@ void slampp_hip_solver::Analyze_Sparse()
 		c.np = int32_t(std::min<int64_t>(np, INT32_MAX));
 	}
 	std::vector<TBlkDesc> blks(n_lblocks);
-	for(int64_t k = 0; k < n_lblocks; ++ k) {
+	Parallel_Ranges(n_lblocks, 65536, [&](int64_t k_begin, int64_t k_end) {
+	for(int64_t k = k_begin; k < k_end; ++ k) {
 		TBlkDesc &b = blks[k];
 		const int64_t np = P.pptr[k + 1] - P.pptr[k];
 		if(np >= (int64_t(1) << 24))
@@ -169,10 +203,12 @@ void slampp_hip_solver::Analyze_Sparse()
 		b.np_di = uint32_t(np) | (uint32_t(P.dim[P.lrow[k]]) << 24);
 		b.xcs = int32_t(P.cs_new[P.lrow[k]]);
 	}
+	});
 	if(P.loff[n_lblocks] >= (int64_t(1) << 48))
 		throw std::domain_error("the factor has 2^48 or more values");
 	std::vector<longlong2> pairs(P.pa.size());
-	for(int64_t k = 0; k < n_lblocks; ++ k) { // pairs are stored block by block
+	Parallel_Ranges(n_lblocks, 65536, [&](int64_t k_begin, int64_t k_end) {
+	for(int64_t k = k_begin; k < k_end; ++ k) { // pairs are stored block by block
 		const int64_t n_pos = std::min<int64_t>(k - P.lptr[P.blk_col[k]], 255); // position of the target block in its column
 		for(int64_t e = P.pptr[k]; e < P.pptr[k + 1]; ++ e) {
 			const int64_t dc = P.dim[P.blk_col[P.pa[e]]];
@@ -180,6 +216,7 @@ void slampp_hip_solver::Analyze_Sparse()
 			pairs[e].y = P.loff[P.pb[e]];
 		}
 	}
+	});
 	std::vector<TRowEnt> rents(P.rblk.size());
 	for(size_t e = 0; e < P.rblk.size(); ++ e) {
 		const int32_t c = P.blk_col[P.rblk[e]];

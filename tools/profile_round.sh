@@ -4,7 +4,7 @@
 # traffic counters (FETCH_SIZE and WRITE_SIZE do not fit one pass) and the matrix-core counters of the MFMA-bound legs.
 # Usage: tools/profile_round.sh <tag>   (writes under gpurun_out/<tag>/; copy the summaries to profiles/)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -22,6 +22,10 @@ for L in c3 ba_venice ba_band ba_uniform c2 c1; do
   f=$(find $OUT/${L}_trace -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${L}_kernel_stats.csv
 done
+# K = 8 value sets of the C3 structure in one pass of launches: which kernels widen and which lengthen
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_batch8_trace -- python3 $R/tools/time_batch.py 8 10 > $OUT/c3_batch8_run.txt 2> $OUT/c3_batch8_trace.err
+f=$(find $OUT/c3_batch8_trace -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp $f $OUT/c3_batch8_kernel_stats.csv
 for L in c3 ba_venice ba_band ba_uniform; do
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/${L}_pmc_$C -- python3 $R/bench.py ${LEG[$L]} --full-json gpurun_out/$TAG/scratch_full.json > $OUT/${L}_pmc_$C.json 2> $OUT/${L}_pmc_$C.err
