@@ -336,7 +336,7 @@ protected:
 				n_last = n_lo;
 			}
 			int n_mismatch = 0;
-			#pragma omp parallel for schedule(static) reduction(+:n_mismatch) num_threads(n_thread_num) if(n_last - n_first > 8192)
+			#pragma omp parallel for schedule(static) reduction(+:n_mismatch) num_threads(n_thread_num) if(n_block_num >= 16384 && n_last - n_first > 512)
 			for(long k = n_first; k < n_last; ++ k) {
 				const TGatherEntry &t = m_gather[k];
 				if(r_lambda.n_Block_Row(t.n_col, t.n_blk) != t.n_row) {
