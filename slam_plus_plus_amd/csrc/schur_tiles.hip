@@ -609,6 +609,8 @@ static void tiles_enqueue_t(const CSchurTiles &T, const int64_t *ptr, int64_t nc
 	{
 		const TRunJob *p_jobs = T.d_run_jobs.p();
 		const bool b_quad = !dev_knob_set("SLAMPP_HIP_DEV_NO_QUAD_RUNS"); // (development: the one-landmark-per-step form, for A/B timing)
+		// (the off-diagonal jobs of three and four tiles a side stage two landmarks; with four staged and quads they need 286
+		// registers, one wave per SIMD instead of two: Venice-like C4 1.513 against 1.502 ms, not kept)
 		const bool b_quad_wide = !dev_knob_set("SLAMPP_HIP_DEV_NO_QUAD_WIDE"); // (quads also for the diagonal jobs of three and four tiles a side, four landmarks staged at a time: Venice-like C4 1.545 -> 1.486 ms; the off-diagonal ones stage two and stay as they were)
 #define LAUNCH_RUNS_Q(NT, DIAG, PFX, QUAD) hipLaunchKernelGGL((schur_run_kernel<DC, DP, NT, DIAG != 0, PFX != 0, QUAD>), \
 			dim3(unsigned(T.n_run_jobs[NT][DIAG][PFX])), dim3(64), 0, stream, p_jobs + T.n_run_job_first[NT][DIAG][PFX], T.d_run_lm.p(), \
