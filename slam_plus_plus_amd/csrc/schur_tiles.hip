@@ -292,7 +292,8 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 	static_assert(!b_quad || GROUP % 4 == 0, "quads of landmarks");
 	const int lane = threadIdx.x, kk = lane >> 4, m16 = lane & 15;
 	const TRunJob job = jobs[blockIdx.x];
-	const int k = job.n_k, n_rb = job.n_rb, n_cb = job.n_cb, n_points = job.n_points;
+	const int k = job.n_k, n_rb = job.n_rb, n_cb = job.n_cb, n_points_all = job.n_points;
+	int n_points = min(n_points_all, 64), n_sub_first = job.n_first; // (round 5) a job takes its landmarks 64 at a time -- lane L prepares landmark L of a sub-piece -- and keeps its sums across sub-pieces: longer pieces, fewer partial blocks
 	const int n_len_a = min(OB, k - n_rb * OB) * BLK, n_len_b = min(OB, k - n_cb * OB) * BLK; // doubles of the two segments
 	// what this lane feeds the matrix cores: element (row, kk) of the U rows, element (kk, column) of the W columns
 	int n_off_a[NT], n_off_b[NT], n_obs_a[NT], n_obs_b[NT];
@@ -313,11 +314,6 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 	// lost at different ones --: my_k is the landmark's own number of observations, what lies beyond it reads as zero)
 	int64_t my_rec = 0, my_pt = 0;
 	int my_k = k;
-	if(lane < n_points) {
-		my_pt = run_lm[job.n_first + lane];
-		my_rec = run_rec[job.n_first + lane];
-		my_k = run_k[job.n_first + lane];
-	}
 	v4f64 acc[NT][NT];
 	double racc[NT];
 	#pragma unroll
@@ -350,8 +346,19 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 			}
 		}
 	};
-	Request(0); // (flies while the landmark blocks are inverted)
 	bool b_bad = false;
+	for(int n_sub = 0; n_sub < n_points_all; n_sub += 64) {
+	n_points = min(n_points_all - n_sub, 64);
+	n_sub_first = job.n_first + n_sub;
+	my_rec = 0; my_pt = 0; my_k = k;
+	if(lane < n_points) {
+		my_pt = run_lm[n_sub_first + lane];
+		my_rec = run_rec[n_sub_first + lane];
+		my_k = run_k[n_sub_first + lane];
+	}
+	if(n_sub)
+		wave_lds_fence(); // the last group of the sub-piece before has been read: s_ci, s_z (and the quads' tables) can go
+	Request(0); // (flies while the landmark blocks are inverted)
 	if(lane < n_points) {
 		const int64_t pt = my_pt;
 		double c[DP * DP], ci[DP * DP];
@@ -378,8 +385,6 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 				Cinv[pt * (DP * DP) + i] = ci[i];
 		}
 	}
-	if(b_bad)
-		atomicOr(p_flag, 1);
 	if constexpr(b_quad) {
 		s_kown[lane] = (lane < n_points)? my_k : 0;
 		s_o0[lane] = (lane < n_points)? (my_rec - ubase - my_pt * (DP * DP)) / BLK : 0;
@@ -522,6 +527,9 @@ schur_run_kernel(const TRunJob *__restrict__ jobs, const int32_t *__restrict__ r
 			}
 		}
 	}
+	} // (sub-pieces)
+	if(b_bad)
+		atomicOr(p_flag, 1);
 	// lane l holds the elements ((l >> 4) + 4 reg, l & 15) of every 16 x 16 tile
 	const int n_kb_c = min(OB, k - n_cb * OB); // observations of the column block
 	#pragma unroll
@@ -871,12 +879,29 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 		// the jobs of one run: `members` (positions in `order`), longest camera list first -- every other member's list is that
 		// list or a prefix of it; pieces of at most 64 landmarks, a job per pair of observation blocks, over the piece's
 		// landmarks that reach into the row block (they are the first ones: sorted by length)
+		// how many jobs the landmarks would make at the base piece length (landmark-weighted: a landmark of k cameras is in
+		// nb (nb + 1) / 2 jobs, nb = ceil(k / OB)), against what keeps the chip's wave slots busy for a few rounds
+		int64_t n_piece_mult = 1;
+		{
+			double f_jobs = 0;
+			for(int64_t pt = 0; pt < np; ++ pt) {
+				const int64_t nb = (k_of[pt] + OB - 1) / OB;
+				f_jobs += double(nb * (nb + 1) / 2) / ((std::min<int64_t>(k_of[pt], OB) * DC > 48)? 32.0 : 64.0);
+			}
+			const int64_t n_jobs_wanted = 6144; // (two rounds of the 3 072 waves the run kernels keep resident at three per SIMD)
+			n_piece_mult = (f_jobs >= 4 * n_jobs_wanted)? 4 : (f_jobs >= 2 * n_jobs_wanted)? 2 : 1;
+			if(dev_knob_set("SLAMPP_HIP_DEV_RUN_PIECE_MULT")) // (development: 1 = pieces of at most 64 as before)
+				n_piece_mult = std::max(1, std::min(4, dev_knob("SLAMPP_HIP_DEV_RUN_PIECE_MULT", 1)));
+		}
 		auto Emit_Run = [&](const int32_t *p_members, int64_t n_members) {
 			// (pieces of 32 where a job keeps ten or sixteen accumulator tiles -- nine cameras and up at 6 x 6 --: those jobs are
 			// the long ones, and more of them spread better: 164 + 123 -> 130 + 103 us for the two widest kernels of the
 			// Venice-like C4, for 18 us more in the reduction of the partial blocks)
+			// Round 5: a job takes its landmarks 64 at a time and keeps its sums across those sub-pieces, so a piece may be
+			// longer than a wave is wide: where the system has jobs to spare (n_piece_mult, below) pieces are two or four
+			// times as long and leave half or a quarter of the partial blocks behind
 			const int64_t k_run = k_of[p_members[0]];
-			const int64_t n_piece_len = (std::min<int64_t>(k_run, OB) * DC > 48 && !dev_knob_set("SLAMPP_HIP_DEV_RUN_PIECE"))? 32 : n_piece_max;
+			const int64_t n_piece_len = ((std::min<int64_t>(k_run, OB) * DC > 48 && !dev_knob_set("SLAMPP_HIP_DEV_RUN_PIECE"))? 32 : n_piece_max) * n_piece_mult;
 			for(int64_t f = 0; f < n_members; f += n_piece_len) {
 				const int64_t n_piece = std::min<int64_t>(n_piece_len, n_members - f);
 				const int32_t pt0 = p_members[f];

@@ -709,3 +709,19 @@ def test_run_kernel_one_landmark_per_step_and_quads_agree(mode, knob, monkeypatc
     eta2 = lam.rhs.copy()
     assert CLinearSolver_Schur_HIP().Solve_PosDef(lam, eta2) and rel_inf(eta2, x_ref) < TOL
     assert rel_inf(eta2, eta) < 1e-11
+
+
+@pytest.mark.parametrize("mult", [1, 2, 4])
+@pytest.mark.parametrize("mode", ["band", "venice", "tracks"])
+def test_run_pieces_longer_than_a_wave(mode, mult, monkeypatch):
+    """Round 5: a job of the run kernel takes its landmarks 64 at a time and keeps its sums across those sub-pieces; pieces of
+    2 x and 4 x the base length (chosen by the analysis where there are jobs to spare, forced here) leave fewer partial blocks
+    and the same S."""
+    lam = synth.ba(60, 40000, k=4, mode=mode, seed=23)     # runs of hundreds of landmarks: several sub-pieces per job
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok
+    monkeypatch.setenv("SLAMPP_HIP_DEV", "1")
+    monkeypatch.setenv("SLAMPP_HIP_DEV_RUN_PIECE_MULT", str(mult))
+    for opts in ({}, {"schur_incremental": 2}):            # (the second keeps W: the stores of every sub-piece)
+        eta = lam.rhs.copy()
+        assert CLinearSolver_Schur_HIP(**opts).Solve_PosDef(lam, eta) and rel_inf(eta, x_ref) < TOL, (mult, opts)

@@ -1,6 +1,7 @@
 """Dev helper (round 4): an option of the panel tasks on (1) and off (0) -- AB_OPTION=panel_rows (the level walk as rows; the
 default) or panel_handup (tasks hand their contributions up; takes effect at analysis: a solver per setting) -- on C3, C2,
 C1 and the reduced camera systems of the BA legs, same process, alternating."""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,7 @@
 """Dev tool: reads a rocprofv3 kernel_trace.csv of a run of the dense (uniform-visibility) BA leg and prints, for the last
 dense factorization in it, the dispatches of the chain (potrf_diag_kernel / trsm_kernel) and of the look-ahead stream
 (syrk_kernel) on one time axis: start, duration, queue.  Usage: python tools/dense_timeline.py <dir with *kernel_trace.csv> [n_rows]"""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import csv, glob, sys
 
 def main():

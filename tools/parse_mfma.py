@@ -12,6 +12,7 @@ Per kernel and launch: the counters as reported (summed over the chip's shader e
                      matrix peak.
 The two utilisation figures are independent: the first needs no unit assumption, the second is checked against the
 algorithmic flop count bench.py prices the phase with (README of profiles/)."""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import csv, glob, json, re, sys, collections
 
 PEAK_TFLOPS = 78.6

@@ -7,6 +7,7 @@ WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide 
 read, so it is doubled; WRITE_SIZE is exact for streaming stores.  The guide calibrates the factor 2
 on 16-B-per-lane streams; these kernels read 8 B per lane, so both the raw and the corrected figure
 are kept."""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import csv, glob, json, re, sys, collections
 
 

@@ -1,5 +1,6 @@
 """Dev helper: in-kernel clock samples of the panel / upper-stage factor kernels (workgroup 0 of every launch) at C3.
 usage: SLAMPP_HIP_STAGE_TIMING=1 python tools/stage_timing.py [option=value ...]"""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import sys, os
 os.environ.setdefault("SLAMPP_HIP_STAGE_TIMING", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,6 @@
 """Dev tool: the dispatches of the last solve step in a rocprofv3 kernel_trace.csv, in order: start, duration, grid, kernel.
 Usage: python tools/step_timeline.py <dir with *kernel_trace.csv> <name of the step's first kernel (substring)> [n_rows]"""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import csv, glob, sys
 
 def main():

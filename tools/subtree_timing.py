@@ -1,6 +1,7 @@
 """Dev helper: in-kernel clock samples of the bottom-stage kernel (SLAMPP_HIP_STAGE_TIMING=1): a workgroup in the
 middle of the grid samples after its column records, block records, Lambda blocks, then after the diagonal and the
 sub-diagonal blocks of every column."""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import sys, os
 os.environ["SLAMPP_HIP_STAGE_TIMING"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

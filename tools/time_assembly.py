@@ -1,5 +1,6 @@
 """Dev helper: device time of the Lambda / eta assembly on a C3-sized SE(3) graph (100k poses), against the
 bytes it has to move, and the same edge set through the reference-like CPU oracle for scale."""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,6 +1,7 @@
 """Dev helper: device time of the Lambda / eta assembly of a BA system (C4 shape: 1000 cameras x 500k points, 4
 observations per point, edges point -> camera with 2-d residuals), parity against the CPU oracle, then the Schur solve
 on the assembled values without leaving the device."""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,6 @@
 """Dev helper: the sparse block path on a matrix shaped like C4's reduced camera system (1000 block columns of 6, blocks at
 circular distances 7, 14, 21): plan summary, per-kernel trace is left to rocprofv3."""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

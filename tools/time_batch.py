@@ -1,5 +1,6 @@
 """Dev helper: K value sets of the C3 structure in one pass of launches (slampp_hip_factor_solve_batch_device_async);
 under `rocprofv3 --kernel-trace --stats` this is the per-kernel picture of a batch (profiles/r05_c3_batch8_kernel_stats.csv)."""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

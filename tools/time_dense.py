@@ -1,4 +1,5 @@
 """Dev helper: BA with a dense reduced system (uniform visibility): phase times, dense factorization TFLOP/s."""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,6 @@
 """Dev helper: one handle over several members (slampp_hip_create_multi) against the single handle, host entry points;
 on a 1-GPU box the members share device 0 (no xGMI in these numbers: the bookkeeping, the events and the exchange code)."""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,6 @@
 """Dev helper: what a caller pays at C3 -- host arrays through slampp_hip_factor_solve (bench.host_path_leg), and, if the
 compiled reference travelled, a CUberBlockMatrix through LinearSolver_HIP.h (bench.dropin_leg)."""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

@@ -1,5 +1,6 @@
 """Dev helper: what an analysis costs on small systems in the caller's order (what FastL's Factorize_PosDef_Blocky pays per
 call when the part of R it hands over changed): SLAMPP_HIP_PLAN_TIMING=1 prints the phases to stderr."""
+import os as _os; _os.environ.setdefault("SLAMPP_HIP_DEV", "1")  # development options and knobs are refused without it (csrc/plan.h)
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
