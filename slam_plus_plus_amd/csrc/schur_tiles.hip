@@ -879,27 +879,15 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 		// the jobs of one run: `members` (positions in `order`), longest camera list first -- every other member's list is that
 		// list or a prefix of it; pieces of at most 64 landmarks, a job per pair of observation blocks, over the piece's
 		// landmarks that reach into the row block (they are the first ones: sorted by length)
-		// how many jobs the landmarks would make at the base piece length (landmark-weighted: a landmark of k cameras is in
-		// nb (nb + 1) / 2 jobs, nb = ceil(k / OB)), against what keeps the chip's wave slots busy for a few rounds
-		int64_t n_piece_mult = 1;
-		{
-			double f_jobs = 0;
-			for(int64_t pt = 0; pt < np; ++ pt) {
-				const int64_t nb = (k_of[pt] + OB - 1) / OB;
-				f_jobs += double(nb * (nb + 1) / 2) / ((std::min<int64_t>(k_of[pt], OB) * DC > 48)? 32.0 : 64.0);
-			}
-			const int64_t n_jobs_wanted = 6144; // (two rounds of the 3 072 waves the run kernels keep resident at three per SIMD)
-			n_piece_mult = (f_jobs >= 4 * n_jobs_wanted)? 4 : (f_jobs >= 2 * n_jobs_wanted)? 2 : 1;
-			if(dev_knob_set("SLAMPP_HIP_DEV_RUN_PIECE_MULT")) // (development: 1 = pieces of at most 64 as before)
-				n_piece_mult = std::max(1, std::min(4, dev_knob("SLAMPP_HIP_DEV_RUN_PIECE_MULT", 1)));
-		}
+		// Longer pieces (a job takes its landmarks 64 at a time and keeps its sums across those sub-pieces) leave half or a
+		// quarter of the partial blocks behind -- and were measured no faster (round 5: Venice-like C4 1.491 / 1.519 / 1.569 ms
+		// at 1 / 2 / 4 times the base length: the longest jobs set the length of a launch; C5 1.197 / 1.223 / 1.183): the
+		// kernel can, the analysis does not ask for it (development knob, tests/test_schur_gpu.py)
+		const int64_t n_piece_mult = dev_knob_set("SLAMPP_HIP_DEV_RUN_PIECE_MULT")? std::max(1, std::min(4, dev_knob("SLAMPP_HIP_DEV_RUN_PIECE_MULT", 1))) : 1;
 		auto Emit_Run = [&](const int32_t *p_members, int64_t n_members) {
 			// (pieces of 32 where a job keeps ten or sixteen accumulator tiles -- nine cameras and up at 6 x 6 --: those jobs are
 			// the long ones, and more of them spread better: 164 + 123 -> 130 + 103 us for the two widest kernels of the
 			// Venice-like C4, for 18 us more in the reduction of the partial blocks)
-			// Round 5: a job takes its landmarks 64 at a time and keeps its sums across those sub-pieces, so a piece may be
-			// longer than a wave is wide: where the system has jobs to spare (n_piece_mult, below) pieces are two or four
-			// times as long and leave half or a quarter of the partial blocks behind
 			const int64_t k_run = k_of[p_members[0]];
 			const int64_t n_piece_len = ((std::min<int64_t>(k_run, OB) * DC > 48 && !dev_knob_set("SLAMPP_HIP_DEV_RUN_PIECE"))? 32 : n_piece_max) * n_piece_mult;
 			for(int64_t f = 0; f < n_members; f += n_piece_len) {

@@ -715,8 +715,8 @@ def test_run_kernel_one_landmark_per_step_and_quads_agree(mode, knob, monkeypatc
 @pytest.mark.parametrize("mode", ["band", "venice", "tracks"])
 def test_run_pieces_longer_than_a_wave(mode, mult, monkeypatch):
     """Round 5: a job of the run kernel takes its landmarks 64 at a time and keeps its sums across those sub-pieces; pieces of
-    2 x and 4 x the base length (chosen by the analysis where there are jobs to spare, forced here) leave fewer partial blocks
-    and the same S."""
+    2 x and 4 x the base length (a development knob: measured no faster) leave fewer partial blocks and
+    the same S."""
     lam = synth.ba(60, 40000, k=4, mode=mode, seed=23)     # runs of hundreds of landmarks: several sub-pieces per job
     ok, x_ref, _, _ = O.solve_schur(lam)
     assert ok
