@@ -43,7 +43,9 @@ struct CTileSchedule {
 	int n_tiles;                       // tiles per dimension
 	int n_levels;
 	std::vector<int> level_potrf_ptr, level_trsm_ptr, level_tgt_ptr; // [n_levels + 1] each
-	std::vector<int> level_urgent_end; // [n_levels] the level's targets up to here are the next level's diagonal tiles (an update launch of their own); the rest rides in the next level's first launch
+	std::vector<int> level_urgent_end; // [n_levels] the level's targets up to here are the next level's diagonal tiles (an update launch of their own)
+	std::vector<int> rider_ptr;        // [n_levels + 1] into d_riders: the updates that ride in a level's diagonal launch (any launch between their sources' level and their deadline: dense_tiles.hip)
+	int4 *d_riders;                    // (row tile, column tile, first source, one past the last source)
 	int *d_potrf;                      // tile columns, level by level
 	int4 *d_trsm;                      // (row tile, column tile, 1 = the workgroup also updates the diagonal tile of its row, -)
 	int4 *d_tgt;                       // (row tile, column tile, first source, one past the last source)
@@ -53,7 +55,7 @@ struct CTileSchedule {
 	std::vector<int> back_diag_ptr, back_carry_ptr; // [n_levels + 1] each, by launch
 	int4 *d_back_diag;                 // (tile column k, its ancestor of height + 1 or -1, 1 = z_k is still y, -)
 	int4 *d_back_carry;                // (source tile column j, target tile column k: z_k -= L(j,k)^T x_j, 1 = z_k is still y, -)
-	CTileSchedule() :n_tiles(0), n_levels(0), d_potrf(0), d_trsm(0), d_tgt(0), d_src(0), d_back_diag(0), d_back_carry(0) {}
+	CTileSchedule() :n_tiles(0), n_levels(0), d_riders(0), d_potrf(0), d_trsm(0), d_tgt(0), d_src(0), d_back_diag(0), d_back_carry(0) {}
 	~CTileSchedule() { Free(); }
 	CTileSchedule(const CTileSchedule&) = delete;
 	CTileSchedule &operator =(const CTileSchedule&) = delete;

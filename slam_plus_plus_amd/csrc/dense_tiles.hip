@@ -6,6 +6,8 @@
 #include "dense_chol.h"
 #include "plan.h"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace slampp {
 
@@ -105,7 +107,8 @@ void CTileSchedule::Free()
 	if(d_src) (void)hipFree(d_src);
 	if(d_back_diag) (void)hipFree(d_back_diag);
 	if(d_back_carry) (void)hipFree(d_back_carry);
-	d_potrf = 0; d_trsm = 0; d_tgt = 0; d_src = 0; d_back_diag = 0; d_back_carry = 0;
+	if(d_riders) (void)hipFree(d_riders);
+	d_potrf = 0; d_trsm = 0; d_tgt = 0; d_src = 0; d_back_diag = 0; d_back_carry = 0; d_riders = 0;
 	n_bytes = 0;
 	n_levels = 0;
 	n_tiles = 0;
@@ -137,6 +140,11 @@ bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hi
 	level_tgt_ptr.assign(1, 0);
 	level_urgent_end.clear();
 	std::vector<int> tgt_of(size_t(T) * T, -1); // per level: index (in `found`) of the target record of a tile
+	// updates nothing in the next level waits for ("riders": extra workgroups of the diagonal-tile launches): per target tile
+	// its deadline -- the last diagonal launch it may ride in -- and its sources (level they become available after, column)
+	struct TPending { int i1, i2, n_deadline; size_t n_done; std::vector<int2> sources; };
+	std::vector<TPending> pending;
+	std::vector<int> pending_of(size_t(T) * T, -1);
 	for(int l = 0; l < n_levels; ++ l) {
 		std::vector<int2> found;                 // targets of this level
 		std::vector<std::vector<int> > sources;  // per target
@@ -185,21 +193,87 @@ bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hi
 			} else
 				(b_next_diag? urgent : deferred).push_back(int(k));
 		}
-		for(int n_pass = 0; n_pass < 2; ++ n_pass) {
-			const std::vector<int> &r_list = n_pass? deferred : urgent;
-			for(size_t q = 0; q < r_list.size(); ++ q) {
-				const int k = r_list[q];
-				int4 t = {found[k].x, found[k].y, int(src.size()), 0};
-				src.insert(src.end(), sources[k].begin(), sources[k].end());
-				t.w = int(src.size());
-				tgt.push_back(t);
+		for(size_t q = 0; q < urgent.size(); ++ q) {
+			const int k = urgent[q];
+			int4 t = {found[k].x, found[k].y, int(src.size()), 0};
+			src.insert(src.end(), sources[k].begin(), sources[k].end());
+			t.w = int(src.size());
+			tgt.push_back(t);
+		}
+		level_urgent_end.push_back(int(tgt.size()));
+		for(size_t q = 0; q < deferred.size(); ++ q) { // not wanted by the next level: to the pool of riders, scheduled below
+			const int k = deferred[q], i1 = found[k].x, i2 = found[k].y;
+			int &r_id = pending_of[size_t(i1) + size_t(i2) * T];
+			if(r_id < 0) {
+				r_id = int(pending.size());
+				// a sub-diagonal tile is read by the panel solves of its column's level (launched after that level's diagonal
+				// tiles: it may still ride with those), a diagonal tile by the diagonal launch of its level
+				pending.push_back(TPending{i1, i2, (i1 == i2)? height[i2] - 1 : height[i2], 0, std::vector<int2>()});
 			}
-			if(!n_pass)
-				level_urgent_end.push_back(int(tgt.size()));
+			for(size_t e = 0; e < sources[k].size(); ++ e)
+				pending[r_id].sources.push_back(int2{l, sources[k][e]});
 		}
 		level_potrf_ptr.push_back(int(potrf.size()));
 		level_trsm_ptr.push_back(int(trsm.size()));
 		level_tgt_ptr.push_back(int(tgt.size()));
+	}
+	// The riders, launch by launch.  Until round 5 every update rode in the very next diagonal launch: at the Venice-like C4's
+	// reduced system the first launches carried 300 - 600 jobs of several source tiles each and lasted 25 - 50 us where the
+	// diagonal tile needs 13 (150 us of a 0.79 ms solve), while from the tenth level on the chip idled beside one tile.  Now an
+	// update may ride in any diagonal launch between the level that produced its sources and its deadline: every launch
+	// takes what is due, then the most urgent of the rest up to a budget of source tiles, at most TILE_RIDER_CHUNK sources
+	// of a target at a time (a job lasts as long as its list) -- one job per target and launch, sources in level order: the
+	// sums keep a fixed order.
+	enum { TILE_RIDER_CHUNK = 4, TILE_RIDER_BUDGET = 1024 };
+	std::vector<int4> riders;
+	rider_ptr.assign(2, 0); // (no riders in the first level's launch)
+	{
+		std::vector<int> order(pending.size());
+		for(size_t i = 0; i < order.size(); ++ i)
+			order[i] = int(i);
+		std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pending[a].n_deadline < pending[b].n_deadline; });
+		for(int lv = 1; lv < n_levels; ++ lv) {
+			int n_budget = TILE_RIDER_BUDGET;
+			for(int n_pass = 0; n_pass < 2; ++ n_pass) { // what is due first, then by deadline
+				for(size_t q = 0; q < order.size(); ++ q) {
+					TPending &r_p = pending[order[q]];
+					const bool b_due = r_p.n_deadline <= lv;
+					if(b_due != !n_pass || r_p.n_done == r_p.sources.size() || r_p.n_done == size_t(-1))
+						continue;
+					size_t n_avail = 0; // sources of levels below this launch's, not applied yet
+					while(r_p.n_done + n_avail < r_p.sources.size() && r_p.sources[r_p.n_done + n_avail].x < lv)
+						++ n_avail;
+					if(!n_avail)
+						continue;
+					if(!b_due) {
+						if(n_budget <= 0)
+							continue;
+						n_avail = std::min<size_t>(n_avail, size_t(TILE_RIDER_CHUNK));
+					}
+					int4 t = {r_p.i1, r_p.i2, int(src.size()), 0};
+					for(size_t e = 0; e < n_avail; ++ e)
+						src.push_back(r_p.sources[r_p.n_done + e].y);
+					t.w = int(src.size());
+					riders.push_back(t);
+					r_p.n_done += n_avail;
+					n_budget -= int(n_avail);
+				}
+			}
+			if(getenv("SLAMPP_HIP_PLAN_TIMING")) { // development aid: what rides where
+				int n_src_here = 0;
+				for(size_t i = size_t(rider_ptr.back()); i < riders.size(); ++ i)
+					n_src_here += riders[i].w - riders[i].z;
+				fprintf(stderr, "[tiles] level %2d: %3d diagonal tiles, %4d riders with %5d source tiles\n", lv,
+					level_potrf_ptr[lv + 1] - level_potrf_ptr[lv], int(riders.size()) - rider_ptr.back(), n_src_here);
+			}
+			rider_ptr.push_back(int(riders.size()));
+		}
+		if(n_levels < 2)
+			rider_ptr.assign(size_t(n_levels) + 1, 0);
+		for(size_t i = 0; i < pending.size(); ++ i) {
+			if(pending[i].n_done != pending[i].sources.size())
+				return false; // (cannot happen: a source's level is below its target's deadline)
+		}
 	}
 	// the backward substitution, top down.  The ancestors of a tile column (the rows of its nonzero tiles) all have
 	// different heights (two of them are linked by fill), so a column gets at most one contribution per launch: from the
@@ -231,12 +305,13 @@ bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hi
 			back_carry_ptr.push_back(int(back_carry.size()));
 		}
 	}
-	const size_t n_b4 = back_diag.size() * sizeof(int4), n_b5 = (back_carry.size() + 1) * sizeof(int4);
+	const size_t n_b4 = back_diag.size() * sizeof(int4), n_b5 = (back_carry.size() + 1) * sizeof(int4), n_b6 = (riders.size() + 1) * sizeof(int4);
 	const size_t n_b0 = potrf.size() * sizeof(int), n_b1 = (trsm.size() + 1) * sizeof(int4),
 		n_b2 = (tgt.size() + 1) * sizeof(int4), n_b3 = (src.size() + 1) * sizeof(int);
 	if(hipMalloc((void**)&d_potrf, n_b0) != hipSuccess || hipMalloc((void**)&d_trsm, n_b1) != hipSuccess ||
 	   hipMalloc((void**)&d_tgt, n_b2) != hipSuccess || hipMalloc((void**)&d_src, n_b3) != hipSuccess ||
-	   hipMalloc((void**)&d_back_diag, n_b4) != hipSuccess || hipMalloc((void**)&d_back_carry, n_b5) != hipSuccess) {
+	   hipMalloc((void**)&d_back_diag, n_b4) != hipSuccess || hipMalloc((void**)&d_back_carry, n_b5) != hipSuccess ||
+	   hipMalloc((void**)&d_riders, n_b6) != hipSuccess) {
 		(void)hipGetLastError();
 		Free();
 		return false;
@@ -248,6 +323,8 @@ bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hi
 		b_ok = b_ok && hipMemcpyAsync(d_tgt, tgt.data(), tgt.size() * sizeof(int4), hipMemcpyHostToDevice, stream) == hipSuccess;
 	if(!src.empty())
 		b_ok = b_ok && hipMemcpyAsync(d_src, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice, stream) == hipSuccess;
+	if(!riders.empty())
+		b_ok = b_ok && hipMemcpyAsync(d_riders, riders.data(), riders.size() * sizeof(int4), hipMemcpyHostToDevice, stream) == hipSuccess;
 	b_ok = b_ok && hipMemcpyAsync(d_back_diag, back_diag.data(), n_b4, hipMemcpyHostToDevice, stream) == hipSuccess;
 	if(!back_carry.empty())
 		b_ok = b_ok && hipMemcpyAsync(d_back_carry, back_carry.data(), back_carry.size() * sizeof(int4), hipMemcpyHostToDevice, stream) == hipSuccess;
@@ -257,7 +334,7 @@ bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hi
 		Free();
 		return false;
 	}
-	n_bytes = n_b0 + n_b1 + n_b2 + n_b3 + n_b4 + n_b5;
+	n_bytes = n_b0 + n_b1 + n_b2 + n_b3 + n_b4 + n_b5 + n_b6;
 	n_tiles = T;
 	n_levels = n_max_height + 1;
 	return true;
@@ -300,24 +377,20 @@ void tile_zero(const CTileSchedule &r_s, double *M, int n_pad, hipStream_t strea
 
 void tile_cholesky(const CTileSchedule &r_s, double *M, int n_pad, int n, double *p_invdiag, int *p_flag, hipStream_t stream)
 {
-	int r0 = 0, r1 = 0; // the targets that ride in this level's first launch: the previous level's, but its urgent ones
 	for(int l = 0; l < r_s.n_levels; ++ l) {
 		const int p0 = r_s.level_potrf_ptr[l], p1 = r_s.level_potrf_ptr[l + 1];
 		const int t0 = r_s.level_trsm_ptr[l], t1 = r_s.level_trsm_ptr[l + 1];
-		const int g0 = r_s.level_tgt_ptr[l], gu = r_s.level_urgent_end[l], g1 = r_s.level_tgt_ptr[l + 1];
+		const int g0 = r_s.level_tgt_ptr[l], gu = r_s.level_urgent_end[l];
+		const int r0 = r_s.rider_ptr[l], r1 = r_s.rider_ptr[l + 1]; // the updates that ride in this level's diagonal launch
 		if(p1 > p0 || r1 > r0) {
 			hipLaunchKernelGGL(tile_potrf_kernel, dim3((p1 - p0) + (r1 - r0)), dim3(256), 0, stream, M, n_pad, n, p_invdiag, p_flag,
-				r_s.d_potrf + p0, p1 - p0, r_s.d_tgt + r0, r_s.d_src);
+				r_s.d_potrf + p0, p1 - p0, r_s.d_riders + r0, r_s.d_src);
 		}
 		if(t1 > t0)
 			hipLaunchKernelGGL(tile_trsm_kernel, dim3(t1 - t0), dim3(512), 0, stream, M, n_pad, p_invdiag, r_s.d_trsm + t0);
 		if(gu > g0)
 			hipLaunchKernelGGL(tile_update_kernel, dim3(gu - g0), dim3(256), 0, stream, M, n_pad, r_s.d_tgt + g0, r_s.d_src);
-		r0 = gu;
-		r1 = g1;
 	}
-	if(r1 > r0) // (the last level's own: nothing follows it to ride in)
-		hipLaunchKernelGGL(tile_update_kernel, dim3(r1 - r0), dim3(256), 0, stream, M, n_pad, r_s.d_tgt + r0, r_s.d_src);
 }
 
 // One launch of the backward substitution by levels (tile_backsolve).  Thread (c, part) = (t / 8, t % 8) holds the eight
