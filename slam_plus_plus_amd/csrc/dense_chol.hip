@@ -15,6 +15,7 @@
 // This is the MFMA-bound kernel of the path: n^3/3 flops (72 GFLOP at 1k cameras).
 #include <hip/hip_runtime.h>
 #include "dense_chol.h"
+#include "plan.h" // dev_knob
 
 namespace slampp {
 #include "dense_device.inl"
@@ -124,12 +125,129 @@ syrk_kernel(double *M, int ld, int n_blocks, int k0, int k1, int c0, int c1)
 	syrk_tile(M, ld, n_blocks, k0, k1, c0, c1, int(blockIdx.x), s_buf, s_buf + NB * NB);
 }
 
+// ---- the same update for a 128 x 128 target (2 x 2 tiles) per workgroup ----
+// A 64 x 64 job fetches two operand tiles per tile product: 8 flop per byte, and the K = 256 update of the trailing matrix --
+// the bulk of the flops -- ran at 30-34 TFLOP/s inside the schedule (tools/dense_launch_trace.sh).  Four target tiles share
+// their operands: the same 64 KB of LDS now hold a 128-row slab of each operand panel for 32 columns of K, and a step of
+// 32 columns is two tile products' worth of matrix-core work per 64 KB fetched instead of one.  Wave w owns the target's
+// columns 32 w .. 32 w + 31, all 128 rows: sixteen 16 x 16 accumulators, which start as the target itself (the products
+// are subtracted by negating one operand fragment) so that nothing but the store follows the K loop.
+// The targets are the lower triangle of the 2-tile grid over the tile rows / columns [c0, c0 + 2 T2); on its diagonal the
+// upper-right tile is above the matrix's diagonal and is not stored.
+#ifndef SLAMPP_WIDE_K
+#define SLAMPP_WIDE_K 32 // (tools/bench_syrk.hip: 16 measured 1-2 % slower)
+#endif
+enum { WIDE = 2 * NB, WIDE_K = SLAMPP_WIDE_K };
+
+__device__ __forceinline__ int lds_at_wide(int k, int row) { return k * WIDE + (row ^ ((k & 1) << 4)); }
+
+struct TWideRegs {
+	v2f64 v[WIDE * WIDE_K / 2 / 256];
+};
+
+// rows row0 .. row0 + 127 of the columns col0 .. col0 + 31: thread t moves rows 2 (t & 63), +1 of columns t >> 6, + 4, ...
+__device__ __forceinline__ void fetch_wide(TWideRegs &t_regs, const double *M, int ld, int row0, int col0)
+{
+	const int r = (threadIdx.x & 63) * 2, c0 = threadIdx.x >> 6;
+	#pragma unroll
+	for(int i = 0; i < WIDE * WIDE_K / 2 / 256; ++ i)
+		t_regs.v[i] = *reinterpret_cast<const v2f64*>(M + size_t(row0 + r) + size_t(col0 + c0 + 4 * i) * ld);
+}
+
+__device__ __forceinline__ void stage_wide(double *Ts, const TWideRegs &t_regs)
+{
+	const int r = (threadIdx.x & 63) * 2, c0 = threadIdx.x >> 6;
+	#pragma unroll
+	for(int i = 0; i < WIDE * WIDE_K / 2 / 256; ++ i)
+		*reinterpret_cast<v2f64*>(Ts + lds_at_wide(c0 + 4 * i, r)) = t_regs.v[i];
+}
+
+__device__ __forceinline__ void syrk_wide_tile(double *M, int ld, int k0, int k1, int c0, int T2, int tile, double *Ps, double *Qs)
+{
+	// linear index -> (J, I), column by column of the 2-tile grid, rows J .. T2-1 (closed form on the reversed index)
+	const int total = T2 * (T2 + 1) / 2, rev = total - 1 - tile;
+	int m = int((sqrt(8.0 * double(rev) + 1.0) - 1.0) * 0.5);
+	while((m + 1) * (m + 2) / 2 <= rev) ++ m;
+	while(m * (m + 1) / 2 > rev) -- m;
+	const int J = T2 - 1 - m, I = J + (m - (rev - m * (m + 1) / 2));
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63; // (scalar: the column offsets of the target stay out of the vector registers)
+	const int lo = lane & 15, hi = lane >> 4;
+	const int row0 = (c0 + 2 * I) * NB, colq = (c0 + 2 * J) * NB;
+	const bool b_diag = I == J;              // (workgroup-uniform) both operands are the same rows: one slab
+	const int c_first = (b_diag && wave >= 2)? 4 : 0; // (wave-uniform) the tile above the diagonal: computed along (whatever that part of the array holds; one job in T2 / 2), never stored
+	TWideRegs t_p, t_q;
+	fetch_wide(t_p, M, ld, row0, k0 * NB);
+	if(!b_diag)
+		fetch_wide(t_q, M, ld, colq, k0 * NB);
+	v4f64 acc[2][8];
+	size_t n_tgt = size_t(row0 + lo) + size_t(colq + 32 * wave + hi) * ld; // the lane's first target element
+	#pragma unroll
+	for(int m2 = 0; m2 < 2; ++ m2) {
+		#pragma unroll
+		for(int reg = 0; reg < 4; ++ reg) {
+			const double *p_col = M + n_tgt + size_t(16 * m2 + 4 * reg) * ld;
+			#pragma unroll
+			for(int c = 0; c < 8; ++ c)
+				acc[m2][c][reg] = p_col[16 * c];
+		}
+	}
+	const double *Qr = b_diag? Ps : Qs;
+	const int n_steps = (k1 - k0) * (NB / WIDE_K);
+	for(int s = 0; s < n_steps; ++ s) {
+		if(s > 0)
+			__syncthreads(); // the previous slabs have been consumed
+		stage_wide(Ps, t_p);
+		if(!b_diag)
+			stage_wide(Qs, t_q);
+		__syncthreads();
+		if(s + 1 < n_steps) { // the next slabs travel while the matrix cores work on these
+			fetch_wide(t_p, M, ld, row0, k0 * NB + (s + 1) * WIDE_K);
+			if(!b_diag)
+				fetch_wide(t_q, M, ld, colq, k0 * NB + (s + 1) * WIDE_K);
+		}
+		#pragma unroll
+		for(int ks = 0; ks < WIDE_K / 4; ++ ks) {
+			const int k = ks * 4 + hi;
+			const double a0 = -Qr[lds_at_wide(k, 32 * wave + lo)], a1 = -Qr[lds_at_wide(k, 32 * wave + 16 + lo)];
+			#pragma unroll
+			for(int c = 0; c < 8; ++ c) {
+				const double b = Ps[lds_at_wide(k, 16 * c + lo)];
+				acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][c], 0, 0, 0);
+				acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][c], 0, 0, 0);
+			}
+		}
+	}
+	// (the store addresses are formed here, from values the compiler cannot trace back: kept from before the loop they
+	// were 34 spilled registers)
+	int n_ld = ld;
+	asm volatile("" : "+v"(n_tgt), "+s"(n_ld));
+	#pragma unroll
+	for(int m2 = 0; m2 < 2; ++ m2) {
+		#pragma unroll
+		for(int reg = 0; reg < 4; ++ reg) {
+			double *p_col = M + n_tgt + size_t(16 * m2 + 4 * reg) * n_ld;
+			#pragma unroll
+			for(int c = 0; c < 8; ++ c) {
+				if(c >= c_first)
+					p_col[16 * c] = acc[m2][c][reg];
+			}
+		}
+	}
+}
+
+__global__ void __launch_bounds__(256, 2)
+syrk_wide_kernel(double *M, int ld, int k0, int k1, int c0, int T2)
+{
+	__shared__ double s_buf[2 * WIDE * WIDE_K];
+	syrk_wide_tile(M, ld, k0, k1, c0, T2, int(blockIdx.x), s_buf, s_buf + WIDE * WIDE_K);
+}
+
 // workgroup 0 factors and inverts the diagonal tile kb; the others run tiles of up to three symmetric updates
 // that do not depend on it (see the schedule in dense_cholesky): the single-workgroup step that every panel
 // has to wait for gives the rest of the chip something to do
-__global__ void __launch_bounds__(256)
-potrf_diag_kernel(double *M, int ld, int kb, int n, double *invL, int *p_flag, int n_blocks, TSyrkJob t_job_a, TSyrkJob t_job_b,
-	TSyrkJob t_job_c)
+__global__ void __launch_bounds__(256, 2)
+potrf_diag_kernel(double *M, int ld, int kb, int n, double *invL, int *p_flag, int n_blocks, TSyrkJob t_job_w, TSyrkJob t_job_a,
+	TSyrkJob t_job_b, TSyrkJob t_job_c)
 {
 	__shared__ double s_buf[(int(POTRF_LDS_DOUBLES) > 2 * NB * NB)? int(POTRF_LDS_DOUBLES) : 2 * NB * NB];
 	if(blockIdx.x == 0) {
@@ -137,6 +255,11 @@ potrf_diag_kernel(double *M, int ld, int kb, int n, double *invL, int *p_flag, i
 		return;
 	}
 	int idx = int(blockIdx.x) - 1;
+	if(idx < t_job_w.n_tiles) { // 128 x 128 targets: c0 = the first tile of the 2-tile grid, c1 = its size
+		syrk_wide_tile(M, ld, t_job_w.k0, t_job_w.k1, t_job_w.c0, t_job_w.c1, t_job_w.tile0 + idx, s_buf, s_buf + WIDE * WIDE_K);
+		return;
+	}
+	idx -= t_job_w.n_tiles;
 	TSyrkJob t_job = t_job_a;
 	if(idx >= t_job_a.n_tiles) {
 		idx -= t_job_a.n_tiles;
@@ -175,7 +298,7 @@ static inline void launch_syrk(double *M, int n_pad, int n_blocks, int k0, int k
 //   potrf of tile k >= 1 of panel b  carries  the 64-wide update of panel b + 1 by tile k - 1,
 //   potrf of tile 0 of panel b       carries  the K = 256 update of panel b + 1 by panel b - 1,
 //   every potrf of panel b           carries  a quarter of the K = 256 update of the panels >= b + 2 by panel b - 1 (the
-//                                             bulk of the flops).
+//                                             bulk of the flops; as 128 x 128 targets while at least 96 tiles trail).
 // Nothing separates two chains: the potrf -> trsm -> potrf sequence runs through the panel boundaries.  Launches on one
 // stream serialize the writers of every target tile, and inside one launch no two workgroups share a target.
 // (A second, lowest-priority stream for the K = 256 updates, two events per panel, was measured again in round 3 with
@@ -185,16 +308,26 @@ void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag,
 {
 	const int n_blocks = n_pad / NB;
 	const int n_outer = (n_blocks + OUTER_TILES - 1) / OUTER_TILES;
+	const int n_wide_min_tiles = dev_knob("SLAMPP_HIP_DEV_WIDE_MIN_TILES", 96); // (development: 2 puts every far update on the 128 x 128 jobs)
 	for(int b = 0; b < n_outer; ++ b) {
 		const int t0 = b * OUTER_TILES, t1 = (t0 + OUTER_TILES < n_blocks)? t0 + OUTER_TILES : n_blocks;
 		const int u0 = t1, u1 = (u0 + OUTER_TILES < n_blocks)? u0 + OUTER_TILES : n_blocks; // panel b + 1
 		const int v0 = u1;                                                                   // panel b + 2 onwards
 		const int p0 = t0 - OUTER_TILES, p1 = t0;                                            // panel b - 1
 		const int n_next_tiles = n_syrk_tiles(n_blocks, u0, u1);
-		const int n_far_tiles = (b > 0)? n_syrk_tiles(n_blocks, v0, n_blocks) : 0;
+		// the K = 256 update of the panels >= b + 2: 128 x 128 targets where the trailing matrix is large enough to give every
+		// CU several of them (tools/bench_syrk.hip: 50.8 against 44.0 TFLOP/s at 180 trailing tiles, 47.1 / 44.9 at 100, even
+		// at 84, 30 / 35 at 38 -- a job is then a quarter of the launch's length); with an odd number of trailing tiles the
+		// first tile column stays with the 64 x 64 jobs
+		const int n_far_T = (b > 0 && v0 < n_blocks)? n_blocks - v0 : 0;
+		const bool b_wide = n_far_T >= n_wide_min_tiles && n_far_T >= 2;
+		const int n_wide_T2 = b_wide? n_far_T / 2 : 0, n_wide_c0 = n_blocks - 2 * n_wide_T2;
+		const int n_wide_tiles = n_wide_T2 * (n_wide_T2 + 1) / 2;
+		const int n_far_c1 = b_wide? n_wide_c0 : n_blocks; // (the 64 x 64 jobs' share: nothing, or the odd first tile column)
+		const int n_far_tiles = (n_far_T > 0)? n_syrk_tiles(n_blocks, v0, n_far_c1) : 0;
 		for(int kb = t0; kb < t1; ++ kb) {
 			const int k = kb - t0, m = t1 - t0;
-			TSyrkJob t_inner = {0, 0, 0, 0, 0, 0}, t_near = {0, 0, 0, 0, 0, 0}, t_far = {0, 0, 0, 0, 0, 0};
+			TSyrkJob t_inner = {0, 0, 0, 0, 0, 0}, t_near = {0, 0, 0, 0, 0, 0}, t_far = {0, 0, 0, 0, 0, 0}, t_wide = {0, 0, 0, 0, 0, 0};
 			if(kb > 0) // tile kb - 1's 64-wide update of this panel (tile 0 = (kb, kb): done by that tile's trsm); for k = 0 it comes from the panel before
 				t_inner = TSyrkJob{kb - 1, kb, kb, t1, 1, n_syrk_tiles(n_blocks, kb, t1) - 1};
 			if(k > 0)
@@ -203,15 +336,19 @@ void dense_cholesky(double *M, int n_pad, int n, double *p_invdiag, int *p_flag,
 				t_near = TSyrkJob{p0, p1, u0, u1, 0, n_next_tiles};
 			if(n_far_tiles > 0) {
 				const int n_begin = int(int64_t(n_far_tiles) * k / m), n_end = int(int64_t(n_far_tiles) * (k + 1) / m);
-				t_far = TSyrkJob{p0, p1, v0, n_blocks, n_begin, n_end - n_begin};
+				t_far = TSyrkJob{p0, p1, v0, n_far_c1, n_begin, n_end - n_begin};
+			}
+			if(n_wide_tiles > 0) {
+				const int n_begin = int(int64_t(n_wide_tiles) * k / m), n_end = int(int64_t(n_wide_tiles) * (k + 1) / m);
+				t_wide = TSyrkJob{p0, p1, n_wide_c0, n_wide_T2, n_begin, n_end - n_begin};
 			}
 			double *invL = p_invdiag + size_t(kb) * NB * NB;
 			// (the longest jobs first -- K = 256 before K = 64 --: the workgroups are started in index order, and a launch ends
 			// with its last job; 3.43 -> 3.26 ms at n = 6 000.  Sizing the four shares of the far update so that the launches
 			// carry the same number of K tiles -- the launch of tile 0 also has the K = 256 update of the next panel --
 			// changed nothing: 3.27)
-			hipLaunchKernelGGL(potrf_diag_kernel, dim3(1 + t_inner.n_tiles + t_near.n_tiles + t_far.n_tiles), dim3(256), 0, stream,
-				M, n_pad, kb, n, invL, p_flag, n_blocks, t_far, t_near, t_inner);
+			hipLaunchKernelGGL(potrf_diag_kernel, dim3(1 + t_wide.n_tiles + t_inner.n_tiles + t_near.n_tiles + t_far.n_tiles), dim3(256), 0, stream,
+				M, n_pad, kb, n, invL, p_flag, n_blocks, t_wide, t_far, t_near, t_inner);
 			const int n_below = n_blocks - kb - 1;
 			if(n_below > 0)
 				hipLaunchKernelGGL(trsm_kernel, dim3(n_below), dim3(512), 0, stream, M, n_pad, kb, invL, 1);
@@ -225,7 +362,7 @@ void dense_factor_panel(double *M, int n_pad, int n, int t0, int t1, double *p_i
 	const TSyrkJob t_none = {0, 0, 0, 0, 0, 0};
 	for(int kb = t0; kb < t1; ++ kb) {
 		double *invL = p_invdiag + size_t(kb) * NB * NB;
-		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, stream, M, n_pad, kb, n, invL, p_flag, n_blocks, t_none, t_none, t_none);
+		hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, stream, M, n_pad, kb, n, invL, p_flag, n_blocks, t_none, t_none, t_none, t_none);
 		const int n_below = n_blocks - kb - 1;
 		if(n_below > 0)
 			hipLaunchKernelGGL(trsm_kernel, dim3(n_below), dim3(512), 0, stream, M, n_pad, kb, invL, 0);

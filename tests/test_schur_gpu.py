@@ -725,3 +725,23 @@ def test_run_pieces_longer_than_a_wave(mode, mult, monkeypatch):
     for opts in ({}, {"schur_incremental": 2}):            # (the second keeps W: the stores of every sub-piece)
         eta = lam.rhs.copy()
         assert CLinearSolver_Schur_HIP(**opts).Solve_PosDef(lam, eta) and rel_inf(eta, x_ref) < TOL, (mult, opts)
+
+
+@pytest.mark.parametrize("n_cams", [150, 160, 231])
+def test_dense_factorization_with_128_row_update_jobs(n_cams, monkeypatch):
+    """Round 5: the K = 256 update of the trailing matrix as 128 x 128 targets (csrc/dense_chol.hip, syrk_wide_tile) --
+    taken by itself only from 96 trailing tiles on (n > 6 600); the development knob puts every far update on them: an odd
+    number of trailing tiles (150 cameras: 15 tiles, the first tile column stays with the 64 x 64 jobs), an even one (160:
+    16 tiles), several outer panels (231: 22 tiles).  Same solution as the 64 x 64 jobs, both against the oracle."""
+    lam = synth.ba(n_cams, 4000, k=4, mode="uniform", seed=37)
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok
+    eta = lam.rhs.copy()
+    assert CLinearSolver_Schur_HIP(schur_sparse=0).Solve_PosDef(lam, eta) and rel_inf(eta, x_ref) < TOL
+    monkeypatch.setenv("SLAMPP_HIP_DEV", "1")
+    monkeypatch.setenv("SLAMPP_HIP_DEV_WIDE_MIN_TILES", "2")
+    solver = CLinearSolver_Schur_HIP(schur_sparse=0, profile=1)
+    eta2 = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta2) and rel_inf(eta2, x_ref) < TOL
+    assert "dense_chol" in solver.profile()
+    assert rel_inf(eta2, eta) < 1e-11
