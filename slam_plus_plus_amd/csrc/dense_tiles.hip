@@ -224,7 +224,7 @@ bool CTileSchedule::Build(int n_tile_num, const std::vector<char> &r_nonzero, hi
 	// takes what is due, then the most urgent of the rest up to a budget of source tiles, at most TILE_RIDER_CHUNK sources
 	// of a target at a time (a job lasts as long as its list) -- one job per target and launch, sources in level order: the
 	// sums keep a fixed order.
-	enum { TILE_RIDER_CHUNK = 4, TILE_RIDER_BUDGET = 1024 };
+	const int TILE_RIDER_CHUNK = dev_knob("SLAMPP_HIP_DEV_RIDER_CHUNK", 4), TILE_RIDER_BUDGET = dev_knob("SLAMPP_HIP_DEV_RIDER_BUDGET", 1024);
 	std::vector<int4> riders;
 	rider_ptr.assign(2, 0); // (no riders in the first level's launch)
 	{

@@ -1099,6 +1099,7 @@ static void schur_try_sparse_reduced(slampp_hip_solver &s, CSchurState &S)
 	p_inner->n_wide_min_tasks = s.n_wide_min_tasks;
 	p_inner->n_panel_rows = s.n_panel_rows;
 	p_inner->n_panel_handup = s.n_panel_handup;
+	p_inner->n_dense_top_tiles = s.n_dense_top_tiles;
 	// (a small system is all latency: round 1 cut its leaf subtrees to four columns for the wave-per-task kernel; as panels
 	// -- eight waves per subtree, 2 us per column -- the default of eight is faster again: 0.231 -> 0.220 ms at 1000 cameras)
 	p_inner->cumsum = cumsum;
