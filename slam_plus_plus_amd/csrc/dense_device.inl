@@ -79,61 +79,103 @@ __device__ __forceinline__ void load_tile8(double *Ts, const double *M, int ld, 
 		*reinterpret_cast<v2f64*>(Ts + lds_at(c0 + 16 * i, r)) = v[i];
 }
 
-__device__ __forceinline__ void tile_product8(const double *Ps, const double *Qs, int wave, int lane, v4f64 acc[2])
+// The two products of a panel solve are not full ones: inv(L_jj) is lower triangular (Q[c][k] = 0 for k > c: column block cb
+// of the result needs the K blocks 0 .. cb only, 40 of the 64 block products of 16 x 16 x 16) and of the symmetric update only
+// the 10 lower blocks are kept -- 160 matrix instructions instead of 256 each, and at the 105 clocks the fp64 matrix pipe
+// takes per instruction (tools/micro/mfma_f64_peak.hip) that is 1.75 instead of 2.8 us on the four SIMDs of the one CU that a
+// tile's workgroup runs on, for the launch the whole level waits for.  Balanced over the eight waves (w and w + 4 share a
+// SIMD):
+//   solve    wave w: row block w & 3, column blocks {0, 3} (w < 4) or {1, 2}: 1 + 4 = 2 + 3 = 5 block products each;
+//   update   the lower blocks in the order (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) (3,0) (3,1) | (3,2) (3,3): wave w takes block w
+//            whole (16 instructions); the last two are split by K halves over the waves 0 .. 3 (8 more instructions: the two
+//            waves of a SIMD have 24 + 16 = 40), and the halves meet in LDS.
+template <int CB>
+__device__ __forceinline__ void tri_block_product(const double *Ps, const double *Qs, int rb, int lo, int hi, v4f64 &r_acc)
 {
-	const int lo = lane & 15, hi = lane >> 4, cw = wave & 3, rh = wave >> 2;
 	#pragma unroll
-	for(int ks = 0; ks < NB / 4; ++ ks) {
+	for(int ks = 0; ks < 4 * (CB + 1); ++ ks) { // K blocks 0 .. CB
 		const int k = ks * 4 + hi;
-		const double a = Qs[lds_at(k, 16 * cw + lo)];
-		#pragma unroll
-		for(int c2 = 0; c2 < 2; ++ c2) {
-			const double b = Ps[lds_at(k, 16 * (2 * rh + c2) + lo)];
-			acc[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c2], 0, 0, 0);
-		}
+		r_acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Qs[lds_at(k, 16 * CB + lo)], Ps[lds_at(k, 16 * rb + lo)], r_acc, 0, 0, 0);
+	}
+}
+
+// K steps [ks0, ks1) of the lower block (rb, cb) of T T^T, T in LDS as [k][row]
+__device__ __forceinline__ void sym_block_product(const double *Ts, int rb, int cb, int ks0, int ks1, int lo, int hi, v4f64 &r_acc)
+{
+	#pragma unroll 8
+	for(int ks = ks0; ks < ks1; ++ ks) {
+		const int k = ks * 4 + hi;
+		r_acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ts[lds_at(k, 16 * cb + lo)], Ts[lds_at(k, 16 * rb + lo)], r_acc, 0, 0, 0);
 	}
 }
 
 __device__ __forceinline__ void trsm_tile_body8(double *M, int ld, int row0, int col0, const double *invL, bool b_diag,
 	double *Ps, double *Qs)
 {
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int lo = lane & 15, hi = lane >> 4, cw = wave & 3, rh = wave >> 2;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const int lo = lane & 15, hi = lane >> 4, rb = wave & 3;
+	const bool b_outer = wave < 4; // column blocks {0, 3}; the others {1, 2}
+	const int cb0 = b_outer? 0 : 1, cb1 = b_outer? 3 : 2;
 	load_tile8(Ps, M, ld, row0, col0);
 	load_tile8(Qs, invL, NB, 0, 0);
-	double cv[2][4];
+	// the update's blocks: wave w the w-th lower block; (3,2) and (3,3) by halves of K on the waves 0, 1 and 2, 3
+	const int n_blk_r = (wave < 1)? 0 : (wave < 3)? 1 : (wave < 6)? 2 : 3, n_blk_c = wave - n_blk_r * (n_blk_r + 1) / 2;
+	double cv[4], cv_h[4];
 	if(b_diag) { // (workgroup-uniform) the diagonal tile is requested now, its latency hides behind the two products
 		#pragma unroll
-		for(int c2 = 0; c2 < 2; ++ c2)
+		for(int reg = 0; reg < 4; ++ reg)
+			cv[reg] = M[size_t(row0 + 16 * n_blk_r + lo) + size_t(row0 + 16 * n_blk_c + hi + 4 * reg) * ld];
+		if(wave < 4 && !(wave & 1)) { // waves 0 and 2 store the split blocks (3,2) and (3,3)
 			#pragma unroll
 			for(int reg = 0; reg < 4; ++ reg)
-				cv[c2][reg] = M[size_t(row0 + 16 * (2 * rh + c2) + lo) + size_t(row0 + 16 * cw + hi + 4 * reg) * ld];
+				cv_h[reg] = M[size_t(row0 + 48 + lo) + size_t(row0 + 16 * (2 + (wave >> 1)) + hi + 4 * reg) * ld];
+		}
 	}
 	__syncthreads();
 	v4f64 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-	tile_product8(Ps, Qs, wave, lane, acc);
+	if(b_outer) {
+		tri_block_product<0>(Ps, Qs, rb, lo, hi, acc[0]);
+		tri_block_product<3>(Ps, Qs, rb, lo, hi, acc[1]);
+	} else {
+		tri_block_product<1>(Ps, Qs, rb, lo, hi, acc[0]);
+		tri_block_product<2>(Ps, Qs, rb, lo, hi, acc[1]);
+	}
 	// every thread has read its operands out of LDS; the tile in global memory can be overwritten
 	#pragma unroll
-	for(int c2 = 0; c2 < 2; ++ c2)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			M[size_t(row0 + 16 * (2 * rh + c2) + lo) + size_t(col0 + 16 * cw + hi + 4 * reg) * ld] = acc[c2][reg];
+	for(int reg = 0; reg < 4; ++ reg) {
+		M[size_t(row0 + 16 * rb + lo) + size_t(col0 + 16 * cb0 + hi + 4 * reg) * ld] = acc[0][reg];
+		M[size_t(row0 + 16 * rb + lo) + size_t(col0 + 16 * cb1 + hi + 4 * reg) * ld] = acc[1][reg];
+	}
 	if(!b_diag)
 		return;
 	__syncthreads(); // every wave is done with Ps
 	#pragma unroll
-	for(int c2 = 0; c2 < 2; ++ c2)
-		#pragma unroll
-		for(int reg = 0; reg < 4; ++ reg)
-			Ps[lds_at(16 * cw + hi + 4 * reg, 16 * (2 * rh + c2) + lo)] = acc[c2][reg]; // L(i,j) as an operand: [k = column][row]
+	for(int reg = 0; reg < 4; ++ reg) {
+		Ps[lds_at(16 * cb0 + hi + 4 * reg, 16 * rb + lo)] = acc[0][reg]; // L(i,j) as an operand: [k = column][row]
+		Ps[lds_at(16 * cb1 + hi + 4 * reg, 16 * rb + lo)] = acc[1][reg];
+	}
 	__syncthreads();
-	v4f64 upd[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-	tile_product8(Ps, Ps, wave, lane, upd);
+	v4f64 upd = {0, 0, 0, 0}, upd_h = {0, 0, 0, 0};
+	sym_block_product(Ps, n_blk_r, n_blk_c, 0, NB / 4, lo, hi, upd);
+	if(wave < 4) {
+		const int n_half = wave & 1; // block (3, 2 + (wave >> 1)), K half wave & 1
+		sym_block_product(Ps, 3, 2 + (wave >> 1), n_half * (NB / 8), (n_half + 1) * (NB / 8), lo, hi, upd_h);
+		if(n_half) {
+			#pragma unroll
+			for(int reg = 0; reg < 4; ++ reg)
+				Qs[(wave >> 1) * 256 + reg * 64 + lane] = upd_h[reg]; // (Qs is free: the inverse was last read before the barriers above)
+		}
+	}
 	#pragma unroll
-	for(int c2 = 0; c2 < 2; ++ c2)
+	for(int reg = 0; reg < 4; ++ reg)
+		M[size_t(row0 + 16 * n_blk_r + lo) + size_t(row0 + 16 * n_blk_c + hi + 4 * reg) * ld] = cv[reg] - upd[reg];
+	__syncthreads();
+	if(wave < 4 && !(wave & 1)) {
 		#pragma unroll
 		for(int reg = 0; reg < 4; ++ reg)
-			M[size_t(row0 + 16 * (2 * rh + c2) + lo) + size_t(row0 + 16 * cw + hi + 4 * reg) * ld] = cv[c2][reg] - upd[c2][reg];
+			M[size_t(row0 + 48 + lo) + size_t(row0 + 16 * (2 + (wave >> 1)) + hi + 4 * reg) * ld] =
+				cv_h[reg] - (upd_h[reg] + Qs[(wave >> 1) * 256 + reg * 64 + lane]);
+	}
 }
 
 // ---- diagonal tile: Cholesky + inverse ----
