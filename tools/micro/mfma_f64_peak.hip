@@ -35,6 +35,45 @@ __global__ void __launch_bounds__(256) mfma_loop_distinct(double *out, int n_ite
 		out[threadIdx.x] = s;
 }
 
+// the vector unit's v_fma_f64 for comparison: N independent accumulators per lane
+template <int N>
+__global__ void __launch_bounds__(256) fma_loop(double *out, int n_iter, double a0, double b0)
+{
+	double acc[N];
+	#pragma unroll
+	for(int i = 0; i < N; ++ i)
+		acc[i] = threadIdx.x + i;
+	const double a = a0 + 1e-9 * threadIdx.x, b = b0;
+	for(int it = 0; it < n_iter; ++ it) {
+		#pragma unroll
+		for(int i = 0; i < N; ++ i)
+			acc[i] = __builtin_fma(acc[i], a, b);
+	}
+	double s = 0;
+	#pragma unroll
+	for(int i = 0; i < N; ++ i)
+		s += acc[i];
+	if(s == 12345.678)
+		out[threadIdx.x] = s;
+}
+
+template <int N>
+static void run_fma(double *out, int n_wgs)
+{
+	hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	const int n_iter = 16384;
+	float best = 1e9f;
+	for(int rep = 0; rep < 5; ++ rep) {
+		(void)hipEventRecord(e0);
+		hipLaunchKernelGGL(fma_loop<N>, dim3(n_wgs), dim3(256), 0, 0, out, n_iter, 0.999, 0.5);
+		(void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+		float ms; (void)hipEventElapsedTime(&ms, e0, e1); if(ms < best) best = ms;
+	}
+	const double flops = double(n_wgs) * 256 * n_iter * N * 2.0;
+	printf("v_fma_f64: %d accumulators per lane, %d workgroups of 4 waves: %.1f us, %.1f TFLOP/s, %.2f clocks at 2.4 GHz per instruction per SIMD\n", N, n_wgs,
+		best * 1e3, flops / best / 1e9, best * 1e-3 * 2.4e9 / (double(n_wgs) * 4 * n_iter * N / 1024.0));
+}
+
 template <int N>
 __global__ void __launch_bounds__(256) mfma_loop(double *out, int n_iter, double a0, double b0)
 {
@@ -99,5 +138,10 @@ int main()
 	run<8, true>(out, 512, "distinct operands, 2 waves/SIMD");
 	run<16, true>(out, 512, "distinct operands, 2 waves/SIMD");
 	run<8, true>(out, 1024, "distinct operands, 4 waves/SIMD");
+	run_fma<8>(out, 256);
+	run_fma<8>(out, 512);
+	run_fma<8>(out, 1024);
+	run_fma<16>(out, 1024);
+	run_fma<8>(out, 2048);
 	return 0;
 }
