@@ -218,7 +218,7 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 			for(size_t t = 0; t < threads.size(); ++ t)
 				threads[t].join();
 		};
-		std::vector<int32_t> obs_pt(S.n_obs), obs_cam(S.n_obs);
+		raw_vector<int32_t> obs_pt(S.n_obs), obs_cam(S.n_obs); // (written in full by the pass below)
 		std::vector<int64_t> cam_ptr(nc + 1, 0);
 		std::vector<std::vector<int64_t> > cam_count(n_setup_workers, std::vector<int64_t>(size_t(nc), 0));
 		For_Landmark_Ranges([&](int t, int64_t n_first, int64_t n_last) {
@@ -242,7 +242,7 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 			}
 			cam_ptr[c + 1] = n_sum;
 		}
-		std::vector<int32_t> cam_obs(S.n_obs);
+		raw_vector<int32_t> cam_obs(S.n_obs);
 		For_Landmark_Ranges([&](int t, int64_t n_first, int64_t n_last) {
 			std::vector<int64_t> &r_fill = cam_count[t];
 			const int64_t o_first = ptr[nc + n_first] - ptr[nc] - n_first, o_last = ptr[nc + n_last] - ptr[nc] - n_last;
@@ -263,24 +263,37 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 				n_entries += k * (k + 1) / 2;
 			}
 			S.n_entries = n_entries;
-			if(nc * nc <= (int64_t(1) << 26)) { // counting sort on the dense key space
-				std::vector<int64_t> cnt(nc * nc + 1, 0);
-				for(int64_t pt = 0; pt < np; ++ pt) { // (one thread: with atomic adds from eight, C5's band structure -- every landmark on
-					// the same few thousand counters -- took 88 ms instead of 19)
-					const int64_t o0 = ptr[nc + pt] - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
-					for(int64_t a = o0; a < o1; ++ a)
-						for(int64_t b = a; b < o1; ++ b)
-							++ cnt[int64_t(obs_cam[a]) * nc + obs_cam[b] + 1];
-				}
-				for(int64_t key = 0; key < nc * nc; ++ key) {
-					if(cnt[key + 1]) {
-						sb_ptr.push_back(cnt[key]);
+			if(nc * nc <= (int64_t(1) << 26)) { // the dense key space
+				// Which blocks of S exist: a bit per camera pair, a bitmap per thread over its range of landmarks, OR-ed at the end
+				// (round 5; counting the contributions of every block was 19 ms on one core at C5 -- with atomic adds from eight,
+				// every landmark of the band structure on the same few thousand counters, 88 ms --, and the counts are only needed
+				// where the landmarks cannot be taken one by one: below)
+				const int64_t n_words = (nc * nc + 63) / 64;
+				std::vector<std::vector<uint64_t> > pair_bits(n_setup_workers, std::vector<uint64_t>(size_t(n_words), 0));
+				For_Landmark_Ranges([&](int t, int64_t n_first, int64_t n_last) {
+					std::vector<uint64_t> &r_bits = pair_bits[t];
+					for(int64_t pt = n_first; pt < n_last; ++ pt) {
+						const int64_t o0 = ptr[nc + pt] - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
+						for(int64_t a = o0; a < o1; ++ a) {
+							const int64_t n_base = int64_t(obs_cam[a]) * nc;
+							for(int64_t b = a; b < o1; ++ b) {
+								const int64_t key = n_base + obs_cam[b];
+								r_bits[size_t(key >> 6)] |= uint64_t(1) << (key & 63);
+							}
+						}
+					}
+				});
+				for(int64_t w = 0; w < n_words; ++ w) {
+					uint64_t n_word = 0;
+					for(int t = 0; t < n_setup_workers; ++ t)
+						n_word |= pair_bits[t][size_t(w)];
+					for(; n_word; n_word &= n_word - 1) {
+						const int64_t key = w * 64 + __builtin_ctzll(n_word);
 						sb_col.push_back(int32_t(key / nc));
 						sb_row.push_back(int32_t(key % nc));
 					}
-					cnt[key + 1] += cnt[key];
 				}
-				sb_ptr.push_back(n_entries);
+				pair_bits.clear();
 				SCHUR_SETUP_PHASE("blocks of S");
 				// the blocks of S are known: can the landmarks be taken one by one (schur_tiles.hip)?  Then the per-block
 				// contribution lists -- 12 bytes and a scattered write per contribution -- are not needed at all
@@ -288,6 +301,22 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 				b_tiles_built = true;
 				SCHUR_SETUP_PHASE("runs and tiles");
 				if(!S.tiles.b_enabled) {
+					// the lists of every block after all: the contributions counted (one thread), then placed
+					std::vector<int64_t> cnt(nc * nc + 1, 0);
+					for(int64_t pt = 0; pt < np; ++ pt) {
+						const int64_t o0 = ptr[nc + pt] - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
+						for(int64_t a = o0; a < o1; ++ a)
+							for(int64_t b = a; b < o1; ++ b)
+								++ cnt[int64_t(obs_cam[a]) * nc + obs_cam[b] + 1];
+					}
+					for(int64_t key = 0; key < nc * nc; ++ key) {
+						if(cnt[key + 1])
+							sb_ptr.push_back(cnt[key]);
+						cnt[key + 1] += cnt[key];
+					}
+					sb_ptr.push_back(n_entries);
+					if(sb_ptr.size() != sb_row.size() + 1)
+						throw std::logic_error("reduced camera system: the block list and the contribution counts disagree");
 					ent_a.resize(n_entries);
 					ent_uoff.resize(n_entries);
 					for(int64_t pt = 0; pt < np; ++ pt) {
@@ -360,6 +389,7 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 		S.d_t.Alloc(size_t(S.n_obs) * DP);
 		s.d_flag.Alloc(1);
 		SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_flag.p(), 0, sizeof(int), s.stream)); // sync() before the first factorization reads it
+		schur_tiles_join(S.tiles); // (the run tables, uploaded beside everything since the runs were found)
 		SLAMPP_HIP_CHECK(hipStreamSynchronize(st));
 		SCHUR_SETUP_PHASE("uploads");
 #undef SCHUR_SETUP_PHASE

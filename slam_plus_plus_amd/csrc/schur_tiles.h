@@ -3,6 +3,9 @@
 #include "solver.h"
 #include <cstdint>
 #include <vector>
+#include <thread>
+#include <memory>
+#include <exception>
 
 namespace slampp {
 
@@ -13,6 +16,16 @@ struct TRunJob { // one wave of the run kernel
 	int32_t n_k, n_rb, n_cb;   // cameras of the run's landmarks; observation blocks of the rows and of the columns
 	int32_t n_pad;
 	int64_t n_pbase;           // first partial block
+};
+
+// the run tables on their way to the device beside the rest of the analysis (schur_tiles_build starts it, schur_tiles_join
+// waits for it): the thread owns what it reads
+struct TRunUpload {
+	std::thread t;
+	std::vector<TRunJob> jobs;
+	std::vector<int32_t> run_lm, run_k;
+	std::exception_ptr p_error;
+	~TRunUpload() { if(t.joinable()) t.join(); }
 };
 
 struct CSchurTiles {
@@ -49,10 +62,14 @@ struct CSchurTiles {
 			d_xsb_ptr.n_Bytes() + d_xsb_map.n_Bytes() + d_xent_a.n_Bytes() + d_xent_uoff.n_Bytes() + d_xcam_ptr.n_Bytes() +
 			d_xcam_obs.n_Bytes() + d_xpoints.n_Bytes();
 	}
+	std::shared_ptr<TRunUpload> p_run_upload; // (the last member: destroyed -- joined -- before the arrays it fills)
 };
 
 // host analysis: n_mode -1 = runs and tiles when together they take at least half of the contributions, 0 = never,
 // 1 = wherever possible, 2 = tiles only, 3 = runs only (of any length).  sb_row / sb_col: the blocks of S sorted by (col, row), as the contribution lists have them.
+// waits for the run tables to be on the device (throws what the upload threw); before the first use of the tiles and before
+// the analysis that built them returns
+void schur_tiles_join(CSchurTiles &T);
 void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, int64_t np, const int64_t *ptr, const int32_t *brow,
 	const std::vector<int32_t> &sb_row, const std::vector<int32_t> &sb_col, int64_t n_ablocks, hipStream_t stream);
 

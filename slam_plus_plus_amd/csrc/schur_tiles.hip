@@ -664,6 +664,18 @@ static void tiles_enqueue_t(const CSchurTiles &T, const int64_t *ptr, int64_t nc
 		T.d_rb_ptr.p(), T.d_rb_part.p(), T.d_rb_sb.p(), sb_row, sb_col, T.d_P.p(), T.d_R.p(), S, ld, p_dst, p_r);
 }
 
+void schur_tiles_join(CSchurTiles &T)
+{
+	if(!T.p_run_upload)
+		return;
+	std::shared_ptr<TRunUpload> p_up;
+	p_up.swap(T.p_run_upload);
+	if(p_up->t.joinable())
+		p_up->t.join();
+	if(p_up->p_error)
+		std::rethrow_exception(p_up->p_error);
+}
+
 void schur_tiles_enqueue(const CSchurTiles &T, int DC, int DP, const int64_t *ptr, int64_t nc, int64_t ubase, const double *A,
 	const double *eta, int n, double *Cinv, double *p_W, bool b_store, const int32_t *sb_row, const int32_t *sb_col,
 	double *S, int ld, const int64_t *p_dst, double *p_r, int *p_flag, hipStream_t stream)
@@ -832,34 +844,69 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 			for(size_t t = 0; t < threads.size(); ++ t)
 				threads[t].join();
 		};
-		std::vector<uint64_t> hash(np);
-		std::vector<int32_t> k_of(np); // observations per landmark (8 MB that stay in the caches better than two reads of ptr[] per use)
+		raw_vector<uint64_t> hash(np), hash2(np); // (hash2: a second, independent hash of the same list -- see "same lists" below; raw_vector: not zero-filled, solver.h)
+		raw_vector<int32_t> k_of(np); // observations per landmark (8 MB that stay in the caches better than two reads of ptr[] per use)
 		For_Landmark_Ranges(0, [&](int64_t n_first, int64_t n_last) {
 			for(int64_t pt = n_first; pt < n_last; ++ pt) {
 				const int64_t k0 = ptr[nc + pt], k = ptr[nc + pt + 1] - k0 - 1;
 				k_of[pt] = int32_t(k);
-				uint64_t h = 0x9E3779B97F4A7C15ull * uint64_t(k + 1);
+				uint64_t h = 0x9E3779B97F4A7C15ull * uint64_t(k + 1), h2 = 0xCBF29CE484222325ull ^ uint64_t(k);
 				for(int64_t i = 0; i < k; ++ i) {
 					h ^= uint64_t(brow[k0 + i]) + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
 					h *= 0xFF51AFD7ED558CCDull;
+					h2 = (h2 ^ (uint64_t(brow[k0 + i]) + 0x632BE59BD9B4E019ull * uint64_t(i + 1))) * 0x100000001B3ull;
+					h2 ^= h2 >> 29;
 				}
 				hash[pt] = h;
+				hash2[pt] = h2;
 			}
 		});
 		BUILD_PHASE("hashes");
-		std::vector<int32_t> order(np), tmp(np);
+		raw_vector<int32_t> order(np), tmp(np);
 		for(int64_t i = 0; i < np; ++ i)
 			order[i] = int32_t(i);
 		{
-			std::vector<int64_t> cnt(65537);
-			for(int n_shift = 0; n_shift < 64; n_shift += 16) { // LSD radix sort: equal hashes stay in landmark order
-				std::fill(cnt.begin(), cnt.end(), 0);
-				for(int64_t i = 0; i < np; ++ i)
-					++ cnt[((hash[order[i]] >> n_shift) & 0xFFFF) + 1];
-				for(int d = 0; d < 65536; ++ d)
-					cnt[d + 1] += cnt[d];
-				for(int64_t i = 0; i < np; ++ i)
-					tmp[cnt[(hash[order[i]] >> n_shift) & 0xFFFF] ++] = order[i];
+			// LSD radix sort, 16 bits a pass: equal hashes stay in landmark order.  Every pass on a few threads (round 5: 21 ms of
+			// C5's analysis on one): a thread counts the digits of its range of the current order, the ranges' counts are laid
+			// out digit by digit and thread by thread -- where a serial pass would have put the elements --, and every thread
+			// moves its own range.
+			const int n_sort_workers = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, std::max(1u, std::thread::hardware_concurrency())), np / 65536)));
+			std::vector<std::vector<int64_t> > cnt(n_sort_workers, std::vector<int64_t>(65536));
+			auto For_Sort_Ranges = [&](const std::function<void(int, int64_t, int64_t)> &r_work) {
+				std::vector<std::thread> threads;
+				for(int t = 0; t < n_sort_workers; ++ t) {
+					const int64_t n_first = np * t / n_sort_workers, n_last = np * (t + 1) / n_sort_workers;
+					if(t + 1 < n_sort_workers)
+						threads.emplace_back(r_work, t, n_first, n_last);
+					else
+						r_work(t, n_first, n_last);
+				}
+				for(size_t t = 0; t < threads.size(); ++ t)
+					threads[t].join();
+			};
+			// (by the upper 48 bits: three passes.  Two lists that differ only in the lowest 16 bits of this hash -- 1e-2 such
+			// pairs among two million -- may come out interleaved; the runs are then cut where "same lists" below says so: a few
+			// more, shorter runs, never a wrong one)
+			for(int n_shift = 16; n_shift < 64; n_shift += 16) {
+				For_Sort_Ranges([&](int t, int64_t n_first, int64_t n_last) {
+					std::vector<int64_t> &r_cnt = cnt[t];
+					std::fill(r_cnt.begin(), r_cnt.end(), 0);
+					for(int64_t i = n_first; i < n_last; ++ i)
+						++ r_cnt[(hash[order[i]] >> n_shift) & 0xFFFF];
+				});
+				int64_t n_sum = 0;
+				for(int d = 0; d < 65536; ++ d) {
+					for(int t = 0; t < n_sort_workers; ++ t) {
+						const int64_t n_here = cnt[t][d];
+						cnt[t][d] = n_sum;
+						n_sum += n_here;
+					}
+				}
+				For_Sort_Ranges([&](int t, int64_t n_first, int64_t n_last) {
+					std::vector<int64_t> &r_cnt = cnt[t];
+					for(int64_t i = n_first; i < n_last; ++ i)
+						tmp[r_cnt[(hash[order[i]] >> n_shift) & 0xFFFF] ++] = order[i];
+				});
 				order.swap(tmp);
 			}
 		}
@@ -884,11 +931,11 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 		// at 1 / 2 / 4 times the base length: the longest jobs set the length of a launch; C5 1.197 / 1.223 / 1.183): the
 		// kernel can, the analysis does not ask for it (development knob, tests/test_schur_gpu.py)
 		const int64_t n_piece_mult = dev_knob_set("SLAMPP_HIP_DEV_RUN_PIECE_MULT")? std::max(1, std::min(4, dev_knob("SLAMPP_HIP_DEV_RUN_PIECE_MULT", 1))) : 1;
-		auto Emit_Run = [&](const int32_t *p_members, int64_t n_members) {
+		auto Emit_Run = [&](const int32_t *p_members, const int32_t *p_members_k, int64_t n_members) {
 			// (pieces of 32 where a job keeps ten or sixteen accumulator tiles -- nine cameras and up at 6 x 6 --: those jobs are
 			// the long ones, and more of them spread better: 164 + 123 -> 130 + 103 us for the two widest kernels of the
 			// Venice-like C4, for 18 us more in the reduction of the partial blocks)
-			const int64_t k_run = k_of[p_members[0]];
+			const int64_t k_run = p_members_k[0];
 			const int64_t n_piece_len = ((std::min<int64_t>(k_run, OB) * DC > 48 && !dev_knob_set("SLAMPP_HIP_DEV_RUN_PIECE"))? 32 : n_piece_max) * n_piece_mult;
 			for(int64_t f = 0; f < n_members; f += n_piece_len) {
 				const int64_t n_piece = std::min<int64_t>(n_piece_len, n_members - f);
@@ -896,13 +943,13 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 				const int64_t k0 = ptr[nc + pt0], k = ptr[nc + pt0 + 1] - k0 - 1; // the piece's longest list
 				const int64_t n_blocks = (k + OB - 1) / OB;
 				const int64_t n_lm_first = int64_t(run_lm.size());
-				for(int64_t e = f; e < f + n_piece; ++ e) {
-					const int32_t pt = p_members[e];
-					run_lm.push_back(pt);
-					run_k.push_back(k_of[pt]);
-					handled[pt] = 1;
-					n_run_pairs += int64_t(run_k.back()) * (run_k.back() + 1) / 2;
-				}
+				// (the landmarks' lengths come with the members, class by class, and `handled` is set in a pass of its own below:
+				// a read of k_of[] and a write of handled[] per landmark, both in hash order, were most of the 20 ms this loop took
+				// at C5's two million landmarks)
+				run_lm.insert(run_lm.end(), p_members + f, p_members + f + n_piece);
+				run_k.insert(run_k.end(), p_members_k + f, p_members_k + f + n_piece);
+				for(int64_t e = f; e < f + n_piece; ++ e)
+					n_run_pairs += int64_t(p_members_k[e]) * (p_members_k[e] + 1) / 2;
 				for(int64_t rb = 0; rb < n_blocks; ++ rb) {
 					const int64_t n_kb_r = std::min<int64_t>(OB, k - rb * OB);
 					int64_t n_reach = 0; // landmarks of the piece with observations in row block rb
@@ -937,11 +984,22 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 		// where the matrix-core tiles of a job would grow (16 lines a tile): a landmark of two cameras does not pay for ten.
 		struct TClass { int64_t n_first, n_count; };
 		std::vector<TClass> classes;
-		std::vector<uint8_t> same_as_previous(np, 0); // order[i] is seen by the cameras of order[i - 1]
+		raw_vector<uint8_t> same_as_previous(np); // order[i] is seen by the cameras of order[i - 1]
+		if(np)
+			same_as_previous[0] = 0;
+		// Two neighbours of the sorted order have the same cameras if both 64-bit hashes and the lengths agree: 128 bits over at
+		// most a few million lists (two different lists agreeing in both: below 1e-25 an analysis).  Reading the two lists
+		// themselves -- four dependent cache misses per landmark, in hash order -- was 20 ms of C5's analysis on eight threads;
+		// systems under 262 144 landmarks (where it costs nothing) still do (SLAMPP_HIP_DEV_RUN_HASH_ONLY, a development knob:
+		// the hashes alone there too, for the tests).
+		const bool b_compare_lists = np < (int64_t(1) << 18) && !dev_knob_set("SLAMPP_HIP_DEV_RUN_HASH_ONLY");
 		For_Landmark_Ranges(1, [&](int64_t n_first, int64_t n_last) {
-			for(int64_t i = n_first; i < n_last; ++ i)
-				same_as_previous[i] = hash[order[i]] == hash[order[i - 1]] && Same(order[i - 1], order[i]);
+			for(int64_t i = n_first; i < n_last; ++ i) {
+				const int32_t p = order[i - 1], q = order[i];
+				same_as_previous[i] = hash[q] == hash[p] && hash2[q] == hash2[p] && k_of[q] == k_of[p] && (!b_compare_lists || Same(p, q));
+			}
 		});
+		BUILD_PHASE("  same lists");
 		run_lm.reserve(np);
 		run_k.reserve(np);
 		for(int64_t i = 0; i < np;) {
@@ -974,13 +1032,15 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 			const int64_t k = ptr[nc + p + 1] - ptr[nc + p] - 1;
 			return int((std::min<int64_t>(k, OB) * DC + 15) / 16);
 		};
+		BUILD_PHASE("  classes");
 		const bool b_chains = !dev_knob_set("SLAMPP_HIP_DEV_NO_PREFIX_RUNS");
 		if(b_chains) {
 			std::sort(classes.begin(), classes.end(), [&](const TClass &a, const TClass &b) {
 				const int32_t p = order[a.n_first], q = order[b.n_first];
 				return List_Less(p, q) || (!List_Less(q, p) && a.n_first < b.n_first); });
 		}
-		std::vector<int32_t> members;
+		BUILD_PHASE("  class order");
+		std::vector<int32_t> members, members_k;
 		for(size_t c0 = 0; c0 < classes.size();) {
 			size_t c1 = c0 + 1;
 			int64_t n_members = classes[c0].n_count;
@@ -993,16 +1053,23 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 			// (a lone long track is no better off here than in the lists; two of them already share their partial blocks)
 			if(n_members >= ((k_longest > OB && n_min_run > 2)? 2 : n_min_run)) {
 				members.clear();
+				members_k.clear();
 				for(size_t c = c1; c > c0; -- c) { // longest list first
-					for(int64_t e = 0; e < classes[c - 1].n_count; ++ e)
-						members.push_back(order[classes[c - 1].n_first + e]);
+					const TClass &r_class = classes[c - 1];
+					members.insert(members.end(), order.begin() + r_class.n_first, order.begin() + r_class.n_first + r_class.n_count);
+					members_k.insert(members_k.end(), size_t(r_class.n_count), k_of[order[r_class.n_first]]);
 				}
-				Emit_Run(members.data(), int64_t(members.size()));
+				Emit_Run(members.data(), members_k.data(), int64_t(members.size()));
 				if(c1 - c0 > 1)
 					T.n_prefix_points += n_members;
 			}
 			c0 = c1;
 		}
+		For_Landmark_Ranges(np - int64_t(run_lm.size()), [&](int64_t n_first, int64_t n_last) { // (ranges of the run list: np - its length .. np)
+			for(int64_t i = n_first - (np - int64_t(run_lm.size())); i < n_last - (np - int64_t(run_lm.size())); ++ i)
+				handled[run_lm[i]] = 1;
+		});
+		BUILD_PHASE("  emit");
 		for(int nt = 1; nt <= 4; ++ nt) {
 			for(int d = 0; d < 2; ++ d) {
 				// one launch per (tiles a side, diagonal): where some jobs of a class have landmarks that end early, all its jobs
@@ -1081,6 +1148,54 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 		memset(T.n_run_job_first, 0, sizeof(T.n_run_job_first));
 		return; // the lists keep everything
 	}
+	// the run tables go to the device from here on, beside the rest of this analysis and of the caller's (round 5: 19 ms of C5's
+	// cold call -- 50 MB out of pageable vectors --; schur_tiles_join waits for them).  The thread owns what it reads.
+	{
+		int n_device = 0;
+		SLAMPP_HIP_CHECK(hipGetDevice(&n_device));
+		T.p_run_upload = std::make_shared<TRunUpload>();
+		TRunUpload *p_up = T.p_run_upload.get();
+		p_up->jobs.swap(jobs);
+		p_up->run_lm.swap(run_lm);
+		p_up->run_k.swap(run_k);
+		CSchurTiles *p_tiles = &T;
+		auto Upload_Runs = [p_up, p_tiles, n_device, stream, ptr, nc, n_ablocks, DC, DP]() {
+			try {
+				SLAMPP_HIP_CHECK(hipSetDevice(n_device));
+				p_tiles->d_run_jobs.Upload(p_up->jobs, stream);
+				p_tiles->d_run_lm.Upload(p_up->run_lm, stream);
+				p_tiles->d_run_k.Upload(p_up->run_k, stream);
+				raw_vector<int64_t> run_rec(p_up->run_lm.size());
+				{ // offset of every landmark's first U block in the values (a read of ptr[] per landmark, in hash order: a few threads)
+					const int64_t n = int64_t(run_rec.size());
+					const int n_workers = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4, std::max(1u, std::thread::hardware_concurrency())), n / 65536)));
+					int64_t *p_rec = run_rec.data();
+					const int32_t *p_lm = p_up->run_lm.data();
+					auto Fill = [=](int64_t n_first, int64_t n_last) {
+						for(int64_t i = n_first; i < n_last; ++ i) {
+							const int64_t pt = p_lm[i], o0 = ptr[nc + pt] - ptr[nc] - pt;
+							p_rec[i] = n_ablocks * DC * DC + o0 * DC * DP + pt * DP * DP;
+						}
+					};
+					std::vector<std::thread> threads;
+					for(int t = 0; t + 1 < n_workers; ++ t)
+						threads.emplace_back(Fill, n * t / n_workers, n * (t + 1) / n_workers);
+					Fill(n * (n_workers - 1) / n_workers, n);
+					for(size_t t = 0; t < threads.size(); ++ t)
+						threads[t].join();
+				}
+				p_tiles->d_run_rec.Upload(run_rec, stream);
+				SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // (run_rec lives in this scope)
+			} catch(...) {
+				p_up->p_error = std::current_exception();
+			}
+		};
+		if(p_up->run_lm.size() >= (size_t(1) << 18))
+			p_up->t = std::thread(Upload_Runs);
+		else
+			Upload_Runs(); // (a small system: a thread's start-up is what it would save)
+	}
+	const size_t n_run_jobs_all = T.p_run_upload->jobs.size();
 	T.n_tiles = n_tiles;
 	T.n_slots = n_slots;
 	T.n_run_points = n_run_points;
@@ -1097,7 +1212,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 	}
 	if(getenv("SLAMPP_HIP_PLAN_TIMING")) {
 		fprintf(stderr, "[schur] of %lld landmarks %lld in runs (%zu jobs), %lld in %lld tiles (largest %lld blocks); %lld partial blocks; "
-			"%lld of %lld contributions\n", (long long)np, (long long)n_run_points, jobs.size(), (long long)n_tile_points,
+			"%lld of %lld contributions\n", (long long)np, (long long)n_run_points, n_run_jobs_all, (long long)n_tile_points,
 			(long long)n_tiles, (long long)T.n_max_slots, (long long)n_slots, (long long)T.n_tile_pairs, (long long)n_all_pairs);
 	}
 
@@ -1173,15 +1288,6 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 	T.n_rb = int64_t(rb_sb.size());
 	BUILD_PHASE("partial block lists");
 
-	T.d_run_jobs.Upload(jobs, stream);
-	T.d_run_lm.Upload(run_lm, stream);
-	T.d_run_k.Upload(run_k, stream);
-	std::vector<int64_t> run_rec(run_lm.size());
-	for(size_t i = 0; i < run_lm.size(); ++ i) { // offset of the landmark's first U block in the values
-		const int64_t pt = run_lm[i], o0 = ptr[nc + pt] - ptr[nc] - pt;
-		run_rec[i] = n_ablocks * DC * DC + o0 * DC * DP + pt * DP * DP;
-	}
-	T.d_run_rec.Upload(run_rec, stream);
 	if(T.n_tiles) { // (the tile kernel's tables: 16 bytes per landmark that nobody reads where every landmark is in a run -- 32 MB of C5's cold call)
 		T.d_tile_ptr.Upload(tile_ptr, stream);
 		T.d_tile_lm.Upload(tile_lm, stream);

@@ -7,6 +7,7 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <memory>
 
 #include "../../include/slampp_hip.h"
 #include "plan.h"
@@ -71,7 +72,8 @@ public:
 		}
 		m_n = m_cap = n;
 	}
-	void Upload(const std::vector<T> &v, hipStream_t s)
+	template <class CAlloc>
+	void Upload(const std::vector<T, CAlloc> &v, hipStream_t s)
 	{
 		Alloc(v.size());
 		if(!v.empty())
@@ -82,6 +84,19 @@ public:
 	size_t n_Bytes() const { return m_p? m_n * sizeof(T) : 0; }
 	void Swap(CDevArray &r_other) { std::swap(m_p, r_other.m_p); std::swap(m_n, r_other.m_n); std::swap(m_cap, r_other.m_cap); }
 };
+
+// allocator for the big work arrays of the analysis that are written in full before they are read: std::vector<T>(n)
+// zero-fills -- 32 MB on one thread, a page fault every 4 KB: 5 ms, and C5's analysis made six of them --; with this
+// allocator the elements are left as they are and the pages are first touched by the (threaded) loops that fill them
+template <class T>
+struct CNoInitAlloc : std::allocator<T> {
+	template <class U> struct rebind { typedef CNoInitAlloc<U> other; };
+	CNoInitAlloc() {}
+	template <class U> CNoInitAlloc(const CNoInitAlloc<U>&) {}
+	template <class U> void construct(U *p) { ::new((void*)p) U; } // default-initialization: nothing for arithmetic types
+	template <class U, class... CArgs> void construct(U *p, CArgs&&... args) { ::new((void*)p) U(std::forward<CArgs>(args)...); }
+};
+template <class T> using raw_vector = std::vector<T, CNoInitAlloc<T> >;
 
 // while one of these lives on a thread, the device arrays freed on that thread keep their memory (a re-analysis)
 struct CKeepDeviceMemory {

@@ -745,3 +745,26 @@ def test_dense_factorization_with_128_row_update_jobs(n_cams, monkeypatch):
     assert solver.Solve_PosDef(lam, eta2) and rel_inf(eta2, x_ref) < TOL
     assert "dense_chol" in solver.profile()
     assert rel_inf(eta2, eta) < 1e-11
+
+
+@pytest.mark.parametrize("mode", ["band", "venice", "tracks"])
+def test_runs_found_by_the_hashes_alone(mode, monkeypatch):
+    """Round 5: from 262 144 landmarks on, two landmarks are taken to be seen by the same cameras when both 64-bit hashes of
+    their camera lists and the lengths agree (the lists themselves are no longer read side by side: csrc/schur_tiles.hip, "same
+    lists"); smaller systems still compare the lists.  The development knob takes the hashes alone here too: same runs, same
+    solution, against the oracle."""
+    lam = synth.ba(120, 20000, k=5, mode=mode, seed=41)
+    ok, x_ref, _, _ = O.solve_schur(lam)
+    assert ok
+    a = CLinearSolver_Schur_HIP()
+    a.SymbolicDecomposition_Blocky(lam)
+    eta = lam.rhs.copy()
+    assert a.Solve_PosDef_Blocky(lam, eta) and rel_inf(eta, x_ref) < TOL
+    monkeypatch.setenv("SLAMPP_HIP_DEV", "1")
+    monkeypatch.setenv("SLAMPP_HIP_DEV_RUN_HASH_ONLY", "1")
+    b = CLinearSolver_Schur_HIP()
+    b.SymbolicDecomposition_Blocky(lam)
+    eta2 = lam.rhs.copy()
+    assert b.Solve_PosDef_Blocky(lam, eta2) and rel_inf(eta2, x_ref) < TOL
+    assert np.array_equal(eta, eta2)                       # the same jobs in the same order: bit for bit
+    assert a.stats()["device_bytes"] == b.stats()["device_bytes"]
