@@ -16,7 +16,7 @@ def once(tag, make, lam):
     eta = lam.rhs.copy(); ok = s.Solve_PosDef_Blocky(lam, eta) and ok; t4 = time.perf_counter()
     print("%-28s create %7.2f ms, analyze %7.2f, first solve %7.2f, second solve %7.2f  ok=%s" % (tag, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, ok), flush=True)
 
-lam = synth.pose_chain(200, dim=6, loops=20, seed=1)
+lam = synth.pose_chain(200, seed=1)
 once("pose chain, first handle", CLinearSolver_HIP, lam)
 once("pose chain, second handle", CLinearSolver_HIP, lam)
 ba = synth.ba(20, 400, k=4, mode="band", seed=1)
