@@ -171,7 +171,7 @@ void slampp_hip_solver::Analyze_Sparse()
 
 	// packed device records (see sparse_kernels.h)
 	const int32_t n_sched = int32_t(P.task_cols.size()); // all columns but those of the dense top
-	std::vector<TColDesc> cols(n_sched); // in schedule order
+	raw_vector<TColDesc> cols(n_sched); // in schedule order (raw_vector: not zero-filled -- solver.h; every record is written in full below)
 	for(int32_t i = 0; i < n_sched; ++ i) {
 		const int32_t j = P.task_cols[i];
 		TColDesc &c = cols[i];
@@ -188,7 +188,7 @@ void slampp_hip_solver::Analyze_Sparse()
 		const int64_t np = P.pptr[P.lptr[j + 1]] - c.p0;
 		c.np = int32_t(std::min<int64_t>(np, INT32_MAX));
 	}
-	std::vector<TBlkDesc> blks(n_lblocks);
+	raw_vector<TBlkDesc> blks(n_lblocks);
 	Parallel_Ranges(n_lblocks, 65536, [&](int64_t k_begin, int64_t k_end) {
 	for(int64_t k = k_begin; k < k_end; ++ k) {
 		TBlkDesc &b = blks[k];
@@ -206,7 +206,7 @@ void slampp_hip_solver::Analyze_Sparse()
 	});
 	if(P.loff[n_lblocks] >= (int64_t(1) << 48))
 		throw std::domain_error("the factor has 2^48 or more values");
-	std::vector<longlong2> pairs(P.pa.size());
+	raw_vector<longlong2> pairs(P.pa.size());
 	Parallel_Ranges(n_lblocks, 65536, [&](int64_t k_begin, int64_t k_end) {
 	for(int64_t k = k_begin; k < k_end; ++ k) { // pairs are stored block by block
 		const int64_t n_pos = std::min<int64_t>(k - P.lptr[P.blk_col[k]], 255); // position of the target block in its column
@@ -217,7 +217,7 @@ void slampp_hip_solver::Analyze_Sparse()
 		}
 	}
 	});
-	std::vector<TRowEnt> rents(P.rblk.size());
+	raw_vector<TRowEnt> rents(P.rblk.size());
 	for(size_t e = 0; e < P.rblk.size(); ++ e) {
 		const int32_t c = P.blk_col[P.rblk[e]];
 		rents[e].off = P.loff[P.rblk[e]];
