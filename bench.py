@@ -41,6 +41,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (vendor figure quoted in SURVEY.md section 8d)
+# what a loop of nothing but v_mfma_f64_16x16x4 sustains on this chip (tools/micro/mfma_f64_peak.hip, profiles/r05_mfma_f64_peak.txt:
+# 105 clocks per instruction per SIMD at 2.4 GHz; the vector unit's v_fma_f64 63-70): printed beside `peak`, never instead of it
+F64_MFMA_SUSTAINED_TFLOPS = 47.8
 
 # Algorithmic work of the default C3 instance (synth.pose_chain(), seed 12345), counted by the
 # reference's own CHOLMOD (AMD ordering) with oracle/_ref/ref_harness cholmod_phases in the build
@@ -957,7 +960,7 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
                 max(traffic[[n for n in traffic if "potrf_diag_kernel" in n][0]]["launches"] / n_panels, 1)
         out["roofline"] = {"bound": "mfma", "kernel": "dense_cholesky (potrf_diag_kernel with the updates riding + trsm_kernel, one factorization)",
                            "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS,
-                           "traffic": tr, "traffic_source": traffic_file, "flops_per_factorization": st["factor_flops"],
+                           "sustained_matrix_rate_measured": F64_MFMA_SUSTAINED_TFLOPS, "traffic": tr, "traffic_source": traffic_file, "flops_per_factorization": st["factor_flops"],
                            "ms_per_factorization": prof["dense_chol"]}
     if "schur_tiles" in prof:
         # landmark-major assembly (schur_tiles.hip): every landmark's column of Lambda is read once -- 144 B per observation,
