@@ -820,8 +820,10 @@ __global__ void __launch_bounds__(64)
 schur_obs_t_kernel(int64_t n_obs, int64_t ubase, int64_t nc, const int64_t *ptr, const int32_t *brow,
 	const int32_t *obs_pt, const double *__restrict__ A, const double *__restrict__ dx, double *T)
 {
-	enum { BLK = DC * DP, PIECE = 64 * BLK + 24 * DP * DP }; // room for 24 C blocks in between (64 observations of landmarks with three or more each)
-	__shared__ double s_u[PIECE];
+	enum { BLK = DC * DP, PIECE = 64 * BLK + 24 * DP * DP, // room for 24 C blocks in between (64 observations of landmarks with three or more each)
+		N_LOADS = (PIECE + 2 + 127) / 128 }; // 16-byte requests per lane that bring a whole piece (one double of slack at either end)
+	typedef double v2f64 __attribute__((ext_vector_type(2)));
+	__shared__ __attribute__((aligned(16))) double s_u[N_LOADS * 128];
 	const int lane = threadIdx.x;
 	const int64_t o_first = int64_t(blockIdx.x) * 64;
 	const int64_t o = min(o_first + lane, n_obs - 1); // (the tail repeats the last observation)
@@ -831,18 +833,19 @@ schur_obs_t_kernel(int64_t n_obs, int64_t ubase, int64_t nc, const int64_t *ptr,
 	const int64_t n_off_last = (int64_t(__builtin_amdgcn_readlane(int(n_off >> 32), 63)) << 32) | uint32_t(__builtin_amdgcn_readlane(int(n_off), 63));
 	const int64_t n_piece = n_off_last - n_off_first + BLK;
 	const bool b_staged = n_piece <= PIECE; // (wave-uniform; many one- or two-camera landmarks in a row: every lane fetches its own block)
+	// (round 5) the whole piece is requested at once, in 16-byte pieces -- up to eleven per lane in flight -- and the camera's dx
+	// beside it: the loop of eight 8-byte requests, wait, store took up to three round trips a wave, and the gather of dx a
+	// fourth behind them.  A landmark's blocks start at an odd double where an odd number of 3 x 3 blocks precedes them: the
+	// piece is fetched from the even double at or before its first one (n_shift), which stays inside the values.
+	const int n_shift = int((ubase + n_off_first) & 1);
+	const int n_piece_al = (int(n_piece) + n_shift + 1) & ~1; // doubles fetched: from the even double before the piece to the one after it
+	v2f64 v[N_LOADS];
 	if(b_staged) {
-		const double *p_src = A + ubase + n_off_first;
-		for(int e0 = 0; e0 < int(n_piece); e0 += 64 * 8) { // eight requests in flight per lane
-			double v[8];
-			#pragma unroll
-			for(int u = 0; u < 8; ++ u)
-				v[u] = p_src[min(e0 + 64 * u + lane, int(n_piece) - 1)];
-			#pragma unroll
-			for(int u = 0; u < 8; ++ u) {
-				if(e0 + 64 * u + lane < int(n_piece))
-					s_u[e0 + 64 * u + lane] = v[u];
-			}
+		const double *p_src = A + (ubase + n_off_first - n_shift);
+		#pragma unroll
+		for(int u = 0; u < N_LOADS; ++ u) {
+			const int e = 2 * (64 * u + lane);
+			v[u] = *reinterpret_cast<const v2f64*>(p_src + ((e < n_piece_al)? e : 0)); // (past the end: the first pair again)
 		}
 	}
 	const int64_t cam = brow[ptr[nc] + o + pt]; // block index of observation o = ptr[nc] + o + (number of C blocks before it)
@@ -850,10 +853,18 @@ schur_obs_t_kernel(int64_t n_obs, int64_t ubase, int64_t nc, const int64_t *ptr,
 	#pragma unroll
 	for(int i = 0; i < DC; ++ i)
 		x[i] = dx[cam * DC + i];
+	if(b_staged) {
+		#pragma unroll
+		for(int u = 0; u < N_LOADS; ++ u) {
+			const int e = 2 * (64 * u + lane);
+			if(e < n_piece_al)
+				*reinterpret_cast<v2f64*>(s_u + e) = v[u];
+		}
+	}
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-	const double *U = b_staged? s_u + (n_off - n_off_first) : A + ubase + n_off;
+	const double *U = b_staged? s_u + (n_off - n_off_first) + n_shift : A + ubase + n_off;
 	if(o_first + lane < n_obs) {
 		#pragma unroll
 		for(int t = 0; t < DP; ++ t) {
