@@ -575,6 +575,61 @@ schur_tile_reduce_kernel(const int64_t *__restrict__ rb_ptr, const int32_t *__re
 	const int lane = threadIdx.x;
 	const int64_t sb = rb_sb[i];
 	const int64_t n_row = sb_row[sb], n_col = sb_col[sb];
+	if constexpr(DC == 6) {
+		// (round 5) 16 bytes a lane: 18 lanes hold a partial block, so one request brings THREE of them (lanes 0 .. 53) and the three
+		// partial right-hand sides of a diagonal block beside them (lanes 54 .. 62, 3 lanes each): a third of the requests of the
+		// one-element-a-lane form below, and three times the bytes in flight.  Every lane group adds up every third partial block
+		// of the list, in list order; the three sums meet at the end: still a fixed order.
+		typedef double v2f64 __attribute__((ext_vector_type(2)));
+		const bool b_blk = lane < 54, b_rhs_lane = lane >= 54 && lane < 63 && n_row == n_col;
+		const int g = b_blk? lane / 18 : (lane - 54) / 3, q = b_blk? lane - 18 * g : (lane - 54) - 3 * g; // partial block of the request, pair of elements
+		const double *p_src = b_blk? P + 2 * q : R + 2 * ((lane < 63)? q : 0);
+		const int n_stride = b_blk? BB : DC;
+		v2f64 f = {0, 0};
+		for(int64_t e0 = rb_ptr[i], e1 = rb_ptr[i + 1]; e0 < e1; e0 += 64) {
+			const int n_here = int(min(int64_t(64), e1 - e0));
+			const int n_my = rb_part[e0 + min(lane, n_here - 1)];
+			for(int j0 = 0; j0 < n_here; j0 += 24) {
+				v2f64 v[8];
+				#pragma unroll
+				for(int u = 0; u < 8; ++ u) {
+					const int j = j0 + 3 * u;
+					const int i0 = __builtin_amdgcn_readlane(n_my, min(j, n_here - 1)), i1 = __builtin_amdgcn_readlane(n_my, min(j + 1, n_here - 1)),
+						i2 = __builtin_amdgcn_readlane(n_my, min(j + 2, n_here - 1));
+					const int n_idx = (g == 0)? i0 : (g == 1)? i1 : i2;
+					v[u] = *reinterpret_cast<const v2f64*>(p_src + int64_t(n_idx) * n_stride);
+				}
+				#pragma unroll
+				for(int u = 0; u < 8; ++ u) {
+					if(j0 + 3 * u + g < n_here)
+						f += v[u];
+				}
+			}
+		}
+		// lane q of the first group collects the other two (the right-hand side lanes likewise, three lanes apart)
+		const int n_from1 = b_blk? lane + 18 : lane + 3, n_from2 = b_blk? lane + 36 : lane + 6;
+		const double f1x = __shfl(f.x, n_from1 & 63), f1y = __shfl(f.y, n_from1 & 63), f2x = __shfl(f.x, n_from2 & 63), f2y = __shfl(f.y, n_from2 & 63);
+		f.x = (f.x + f1x) + f2x;
+		f.y = (f.y + f1y) + f2y;
+		if(lane < 18) {
+			#pragma unroll
+			for(int h = 0; h < 2; ++ h) {
+				const int n_el = 2 * lane + h, r = n_el % DC, qc = n_el / DC;
+				const size_t idx = p_dst? size_t(p_dst[sb]) + qc + r * DC : size_t(n_row * DC + r) + size_t(n_col * DC + qc) * ld;
+				S[idx] -= h? f.y : f.x;
+			}
+		} else if(b_rhs_lane && lane < 57) {
+			#pragma unroll
+			for(int h = 0; h < 2; ++ h) {
+				const int64_t c = n_row * DC + 2 * (lane - 54) + h;
+				if(p_r)
+					p_r[c] -= h? f.y : f.x;
+				else
+					S[size_t(ld - 1) + size_t(c) * ld] -= h? f.y : f.x;
+			}
+		}
+		return;
+	}
 	const bool b_block = lane < BB, b_rhs = lane >= BB && lane < BB + DC && n_row == n_col;
 	// the list's indices 64 at a time with one coalesced load, then eight partial blocks in flight at once (one after
 	// the other a block with 36 partials -- Venice-like visibility -- was 36 dependent round trips: 156 us for that kernel);
