@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <numeric>
 
 namespace slampp {
@@ -34,19 +36,27 @@ class CNestedDissection {
 	const int m_leaf;
 	const int m_n_balance_pct; // a separator must leave at least this share of the vertices on either side
 	const bool m_b_other_bank; // the separator of a level cut: the narrower of its two banks (PlanOptions::nd_other_bank)
+	const int m_n_cut_min_size, m_n_cut_max_sep; // development knobs of the cut by vertex number, read once (plan.h)
 	std::vector<int32_t> m_set;    // id of the subset a vertex currently belongs to
 	std::vector<int32_t> m_level;  // BFS level (valid for the subset being processed)
 	std::vector<int32_t> &m_out;   // perm[new] = old; every call fills its own range
 	std::atomic<int32_t> m_next_id;
-	enum { parallel_min_size = 4096, parallel_max_depth = 6 };
+	// halves of at least this many vertices each run side by side, down to this depth of the recursion (threads start in
+	// ~0.1 ms on the hosts of MI355X boxes: a few thousand vertices are worth one; a small graph -- the 2-D-like ones of the
+	// configs, a reduced camera system -- is ordered several times over by the plan search, side by side as well)
+	const size_t parallel_min_size;
+	const int parallel_max_depth;
 
 public:
 	CNestedDissection(int32_t n, const std::vector<int64_t> &ptr, const std::vector<int32_t> &adj,
 		int leaf, int n_balance_pct, std::vector<int32_t> &out, bool b_other_bank = false)
 		:m_n(n), m_ptr(ptr), m_adj(adj), m_leaf(std::max(leaf, 1)), m_n_balance_pct(std::min(std::max(n_balance_pct, 1), 49)),
 		m_b_other_bank(b_other_bank),
+		m_n_cut_min_size(dev_knob("SLAMPP_HIP_DEV_ND_MIN", 64)), m_n_cut_max_sep(dev_knob("SLAMPP_HIP_DEV_ND_SEP", 4)),
 		m_set(n, -1), m_level(n, -1),
-		m_out(out), m_next_id(0)
+		m_out(out), m_next_id(0),
+		parallel_min_size(size_t(std::max(dev_knob("SLAMPP_HIP_DEV_ND_PAR_MIN", (n <= 8192)? 768 : 2048), 16))),
+		parallel_max_depth(dev_knob("SLAMPP_HIP_DEV_ND_PAR_DEPTH", (n <= 8192)? 2 : 6))
 	{
 		m_out.assign(n, -1);
 	}
@@ -173,7 +183,7 @@ private:
 
 	bool Find_Index_Cut(const std::vector<int32_t> &S, int32_t id, TIndexCut &r_cut)
 	{
-		const int min_size = dev_knob("SLAMPP_HIP_DEV_ND_MIN", 64), max_sep = dev_knob("SLAMPP_HIP_DEV_ND_SEP", 4); // (development knobs, plan.h)
+		const int min_size = m_n_cut_min_size, max_sep = m_n_cut_max_sep;
 		const size_t n_size = S.size();
 		if(n_size < size_t(min_size) || n_size <= size_t(m_leaf) * 4 || !std::is_sorted(S.begin(), S.end()))
 			return false;
@@ -249,7 +259,7 @@ private:
 		}
 		const size_t n_lower = lower.size(), n_upper = upper.size();
 		std::copy(sep.begin(), sep.end(), m_out.begin() + n_out + n_lower + n_upper);
-		if(n_depth < parallel_max_depth && std::min(n_lower, n_upper) >= size_t(parallel_min_size)) {
+		if(n_depth < parallel_max_depth && std::min(n_lower, n_upper) >= parallel_min_size) {
 			std::thread other([&]() { Order(upper, n_out + n_lower, n_depth + 1); });
 			Order(lower, n_out, n_depth + 1);
 			other.join();
@@ -399,7 +409,7 @@ private:
 		}
 		const size_t n_lower = lower.size(), n_upper = upper.size();
 		std::copy(sep.begin(), sep.end(), m_out.begin() + n_out + n_lower + n_upper);
-		if(n_depth < parallel_max_depth && std::min(n_lower, n_upper) >= size_t(parallel_min_size)) {
+		if(n_depth < parallel_max_depth && std::min(n_lower, n_upper) >= parallel_min_size) {
 			std::thread other([&]() { Order(upper, n_out + n_lower, n_depth + 1); });
 			Order(lower, n_out, n_depth + 1);
 			other.join();
@@ -494,7 +504,7 @@ double plan_chain_estimate_us(const Plan &P)
 			bool b_tall = false;
 			for(int64_t c = P.task_ptr[t]; c < P.task_ptr[t + 1]; ++ c) {
 				const int32_t j = P.task_cols[c];
-				n_products += (P.pptr[P.lptr[j + 1]] - P.pptr[P.lptr[j] + 1]) + (P.rptr[j + 1] - P.rptr[j]);
+				n_products += P.col_products[j] + (P.rptr[j + 1] - P.rptr[j]); // (col_products: the pairs of the column's off-diagonal blocks, pptr[lptr[j + 1]] - pptr[lptr[j] + 1])
 				if(!P.col_sub.empty()) {
 					n_levels = std::max(n_levels, int(P.col_sub[j]) + 1);
 					b_tall = b_tall || P.col_sub[j] != 0;
@@ -518,120 +528,32 @@ double plan_chain_estimate_us(const Plan &P)
 	return f_us;
 }
 
-static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const int64_t *bcol_ptr,
-	const int32_t *brow, const PlanOptions &opt, Plan &P);
+// The analysis in three parts, so that the plan search below can share what its candidates have in common: the block graph
+// (once per structure), ordering + symbolic factorization (once per ordering), dense top + update lists + schedule (once
+// per candidate).
 
-std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bcol_ptr,
-	const int32_t *brow, const PlanOptions &opt, Plan &P)
-{
-	std::string s_err = build_plan_once(n_bcols, cumsum, bcol_ptr, brow, opt, P);
-	if(s_err.empty() && !opt.dense_top_auto && getenv("SLAMPP_HIP_PLAN_TIMING") != 0) {
-		fprintf(stderr, "[plan] dense_top_nb %d, balance %d %%: dense dim %d, chain estimate %.0f us (as asked for)\n", opt.dense_top_nb,
-			opt.nd_balance_pct, P.dense_dim, plan_chain_estimate_us(P));
-	}
-	if(!s_err.empty() || !opt.dense_top_auto || !P.dense_dim)
-		return s_err;
-	// A dense top: a 2-D-like graph.  Where the line between block-by-block elimination and the dense factorization
-	// is best drawn depends on the graph (Manhattan-like: lower, sphere-like: higher), and its separators are long
-	// enough that balanced halves beat the smallest separator (the opposite of pose chains, whose separators are one
-	// or two vertices and for which the default of 15 % is tuned).  Rebuild with 25 % as the base, then try a lower
-	// and a higher threshold; keep what the chain model clearly prefers.
-	const bool b_print = getenv("SLAMPP_HIP_PLAN_TIMING") != 0;
-	double f_best = plan_chain_estimate_us(P);
-	if(b_print) {
-		fprintf(stderr, "[plan] dense_top_nb %d, balance %d %%: dense dim %d, chain estimate %.0f us\n", opt.dense_top_nb,
-			opt.nd_balance_pct, P.dense_dim, f_best);
-	}
-	// candidates: the balance first (25 / 35 / 45 % at the threshold asked for), then a lower and a higher threshold at the
-	// balance that came out best -- the tile levels of the dense top are what the chain is made of (33 us each: a
-	// diagonal tile, its panel, the updates), and how many there are depends on where the dissection cuts (measured,
-	// reduced camera system of the Venice-like leg: 2.34 ms at 25 %, 1.63 ms at 45 %; the model said 2.27 and 1.40)
-	const int n_balanced = std::max(opt.nd_balance_pct, 25);
-	int n_best_balance = opt.nd_balance_pct, n_best_nb = opt.dense_top_nb;
-	int n_best_bank = opt.nd_other_bank;
-	auto Try = [&](int n_nb, int n_balance, double f_margin, int n_bank = -1) {
-		PlanOptions t_opt = opt;
-		t_opt.dense_top_nb = n_nb;
-		t_opt.nd_balance_pct = n_balance;
-		if(n_bank >= 0)
-			t_opt.nd_other_bank = n_bank;
-		Plan t_plan;
-		if(n_nb < 4 || !build_plan_once(n_bcols, cumsum, bcol_ptr, brow, t_opt, t_plan).empty())
-			return;
-		const double f_us = plan_chain_estimate_us(t_plan);
-		if(b_print) {
-			fprintf(stderr, "[plan] dense_top_nb %d, balance %d %%%s: dense dim %d, chain estimate %.0f us\n", n_nb, n_balance,
-				t_opt.nd_other_bank? ", narrower bank" : "", t_plan.dense_dim, f_us);
-		}
-		if(t_plan.dense_dim && f_us < f_best * f_margin) {
-			f_best = std::min(f_best * std::max(f_margin, 1.0), f_us);
-			n_best_balance = n_balance;
-			n_best_nb = n_nb;
-			n_best_bank = t_opt.nd_other_bank;
-			t_plan.order_ms += P.order_ms;
-			t_plan.symbolic_ms += P.symbolic_ms;
-			std::swap(P, t_plan);
-		} else {
-			P.order_ms += t_plan.order_ms; // (the time went into this analysis all the same)
-			P.symbolic_ms += t_plan.symbolic_ms;
-		}
-	};
-	// the balanced base replaces the first plan unless it is clearly worse; everything else must be clearly better (the
-	// model is rough, and rougher for the heavy columns a higher threshold leaves to the block kernels)
-	if(n_balanced != opt.nd_balance_pct)
-		Try(opt.dense_top_nb, n_balanced, 1.10);
-	const int p_nb[3] = {opt.dense_top_nb, opt.dense_top_nb * 2 / 3, opt.dense_top_nb * 3 / 2};
-	const double p_nb_margin[3] = {0.95, 0.95, 0.90};
-	if(n_bcols <= 20000) { // a small graph (the 2-D-like ones of the configs, a reduced camera system): the whole grid, a few ms a plan
-		for(int i = 0; i < 3; ++ i) {
-			if(i > 0 && P.task_cols.empty())
-				break; // everything is in the dense top already: the threshold no longer matters
-			for(int n_balance = 25; n_balance <= 45; n_balance += 10) {
-				if((i > 0 || n_balance > n_balanced) && n_balance >= n_balanced)
-					Try(p_nb[i], n_balance, p_nb_margin[i]);
-			}
-		}
-	} else { // a large one: the balance first, then the threshold at the balance that came out best
-		for(int n_balance = 35; n_balance <= 45; n_balance += 10) {
-			if(n_balance > n_balanced)
-				Try(opt.dense_top_nb, n_balance, 0.95);
-		}
-		const int n_balance_chosen = n_best_balance;
-		Try(p_nb[1], n_balance_chosen, p_nb_margin[1]);
-		Try(p_nb[2], n_balance_chosen, p_nb_margin[2]);
-	}
-	// the other bank of the level cuts (PlanOptions::nd_other_bank): another family of orderings, priced at the threshold that
-	// came out best and every balance (round 4: the Venice-like reduced camera system 1.12 -> 1.00 ms; the model keeps C1 and
-	// C2 where they were, and so does the clock)
-	if(!opt.nd_other_bank) {
-		const int n_nb_chosen = n_best_nb;
-		for(int n_balance = n_balanced; n_balance <= 45; n_balance += 10)
-			Try(n_nb_chosen, n_balance, 0.95, 1);
-	}
-	(void)n_best_bank;
-	return s_err;
-}
+namespace {
 
-static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const int64_t *bcol_ptr,
-	const int32_t *brow, const PlanOptions &r_opt, Plan &P)
+struct TBlockGraph {
+	int32_t n;
+	int64_t n_ablocks;
+	std::vector<int64_t> gptr; // symmetric adjacency, no self loops
+	std::vector<int32_t> gadj;
+	std::vector<int64_t> aoff; // [n_ablocks + 1] offsets of the source blocks in the packed value array
+	int64_t nnz_upper;
+	double graph_ms;
+};
+
+std::string plan_block_graph(int64_t n_bcols, const int64_t *cumsum, const int64_t *bcol_ptr, const int32_t *brow, TBlockGraph &G)
 {
-	PlanOptions opt = r_opt;
-	// development aids (environment, with SLAMPP_HIP_DEV=1: plan.h): override the options of the same names
-	opt.task_height = std::min(std::max(dev_knob("SLAMPP_HIP_DEV_TASK_HEIGHT", opt.task_height), 1), 8);
-	opt.task_max_cols = std::min(std::max(dev_knob("SLAMPP_HIP_DEV_TASK_MAX_COLS", opt.task_max_cols), 1), 64);
-	opt.task_max_blocks = std::min(std::max(dev_knob("SLAMPP_HIP_DEV_TASK_MAX_BLOCKS", opt.task_max_blocks), 1), 1024);
-	opt.nd_balance_pct = std::min(std::max(dev_knob("SLAMPP_HIP_DEV_ND_BALANCE", opt.nd_balance_pct), 1), 49);
-	P = Plan();
 	if(n_bcols <= 0 || n_bcols > INT32_MAX / 2)
 		return "invalid number of block columns";
 	const int32_t n = int32_t(n_bcols);
-	const int64_t n_ablocks = bcol_ptr[n];
-	P.n = n;
-
-	double t0 = now_ms();
-
-	// ---- block graph (symmetric adjacency, no self loops) ----
-	std::vector<int64_t> gptr(n + 1, 0);
+	const double t0 = now_ms();
+	G.n = n;
+	G.n_ablocks = bcol_ptr[n];
+	std::vector<int64_t> &gptr = G.gptr;
+	gptr.assign(n + 1, 0);
 	for(int32_t c = 0; c < n; ++ c) {
 		if(bcol_ptr[c + 1] < bcol_ptr[c])
 			return "block column pointers are not monotonic";
@@ -651,7 +573,8 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 	}
 	for(int32_t c = 0; c < n; ++ c)
 		gptr[c + 1] += gptr[c];
-	std::vector<int32_t> gadj(gptr[n]);
+	std::vector<int32_t> &gadj = G.gadj;
+	gadj.resize(gptr[n]);
 	{
 		std::vector<int64_t> fill(gptr.begin(), gptr.end() - 1);
 		for(int32_t c = 0; c < n; ++ c) {
@@ -664,9 +587,37 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 			}
 		}
 	}
-
+	G.aoff.assign(G.n_ablocks + 1, 0);
+	G.nnz_upper = 0;
+	for(int32_t c = 0; c < n; ++ c) {
+		const int64_t w = cumsum[c + 1] - cumsum[c];
+		if(w <= 0)
+			return "block column of zero or negative width";
+		for(int64_t k = bcol_ptr[c]; k < bcol_ptr[c + 1]; ++ k) {
+			const int64_t h = cumsum[brow[k] + 1] - cumsum[brow[k]];
+			G.aoff[k + 1] = G.aoff[k] + h * w;
+			G.nnz_upper += (brow[k] == c)? w * (w + 1) / 2 : h * w;
+		}
+	}
+	G.graph_ms = now_ms() - t0;
 	if(getenv("SLAMPP_HIP_PLAN_TIMING"))
-		fprintf(stderr, "[plan] graph          %6.2f ms\n", now_ms() - t0);
+		fprintf(stderr, "[plan] graph          %6.2f ms\n", G.graph_ms);
+	return std::string();
+}
+
+// ordering (opt.natural_order, leaf_size, nd_balance_pct, nd_other_bank) and the block symbolic factorization under it
+std::string plan_order_symbolic(const TBlockGraph &G, const int64_t *cumsum, const int64_t *bcol_ptr,
+	const int32_t *brow, const PlanOptions &opt, Plan &P)
+{
+	P = Plan();
+	const int32_t n = G.n;
+	const int64_t n_ablocks = G.n_ablocks;
+	const std::vector<int64_t> &gptr = G.gptr, &aoff = G.aoff;
+	const std::vector<int32_t> &gadj = G.gadj;
+	P.n = n;
+	P.nnz_upper = G.nnz_upper;
+	double t0 = now_ms();
+
 	// ---- ordering ----
 	if(opt.natural_order) {
 		P.perm.resize(n);
@@ -698,7 +649,7 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 		P.uniform_dim = P.uniform_dim && d == (cumsum[1] - cumsum[0]);
 	}
 	double t1 = now_ms();
-	P.order_ms = t1 - t0;
+	P.order_ms = t1 - t0 + G.graph_ms;
 
 	const bool b_timing = getenv("SLAMPP_HIP_PLAN_TIMING") != 0;
 	double t_phase = now_ms();
@@ -708,16 +659,6 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 		fprintf(stderr, "[plan] %-12s %8.2f ms\n", "order", P.order_ms);
 
 	// ---- permuted lower-triangular structure of Lambda ----
-	// offsets of the source blocks in the packed value array
-	std::vector<int64_t> aoff(n_ablocks + 1, 0);
-	for(int32_t c = 0; c < n; ++ c) {
-		const int64_t w = cumsum[c + 1] - cumsum[c];
-		for(int64_t k = bcol_ptr[c]; k < bcol_ptr[c + 1]; ++ k) {
-			const int64_t h = cumsum[brow[k] + 1] - cumsum[brow[k]];
-			aoff[k + 1] = aoff[k] + h * w;
-			P.nnz_upper += (brow[k] == c)? w * (w + 1) / 2 : h * w;
-		}
-	}
 	struct TAEntry { int32_t row; int32_t trans; int64_t src; };
 	std::vector<int64_t> acol_ptr(n + 1, 0);
 	for(int32_t c = 0; c < n; ++ c) {
@@ -817,6 +758,78 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 		}
 	}
 
+	PLAN_PHASE("symbolic");
+#undef PLAN_PHASE
+	P.symbolic_ms = now_ms() - t1;
+	return std::string();
+}
+
+// the update lists of a finished plan: L(i,j) = A(i,j) - sum over pairs L[pa] * L[pb]^T
+std::string plan_pair_lists(Plan &P)
+{
+	const int32_t n = P.n;
+	const int64_t n_lblocks = int64_t(P.lrow.size());
+	std::vector<int32_t> tgt;
+	std::vector<int32_t> ga, gb;
+	{
+		int64_t n_pairs_total = 0;
+		for(int32_t c = 0; c < n; ++ c) {
+			const int64_t m = P.lptr[c + 1] - P.lptr[c] - 1;
+			if(P.dense_pos[c] < 0)
+				n_pairs_total += m * (m + 1) / 2;
+		}
+		tgt.reserve(size_t(n_pairs_total));
+		ga.reserve(size_t(n_pairs_total));
+		gb.reserve(size_t(n_pairs_total));
+	}
+	for(int32_t c = 0; c < n; ++ c) {
+		if(P.dense_pos[c] >= 0)
+			continue; // updates among dense-top columns happen inside the dense factorization
+		const int64_t kb0 = P.lptr[c] + 1, kb1 = P.lptr[c + 1];
+		for(int64_t kb = kb0; kb < kb1; ++ kb) {
+			const int32_t j = P.lrow[kb];
+			int64_t t = P.lptr[j]; // walks down column j; rows of c (>= j) are a subset of rows of j
+			const int64_t t_end = P.lptr[j + 1];
+			for(int64_t ka = kb; ka < kb1; ++ ka) {
+				const int32_t i = P.lrow[ka];
+				while(t < t_end && P.lrow[t] < i)
+					++ t;
+				if(t == t_end || P.lrow[t] != i)
+					return "internal error: symbolic structure is not closed under updates";
+				tgt.push_back(int32_t(t));
+				ga.push_back(int32_t(ka));
+				gb.push_back(int32_t(kb));
+			}
+		}
+	}
+	const size_t n_pairs = tgt.size();
+	P.pptr.assign(n_lblocks + 1, 0);
+	for(size_t p = 0; p < n_pairs; ++ p)
+		++ P.pptr[tgt[p] + 1];
+	for(int64_t k = 0; k < n_lblocks; ++ k)
+		P.pptr[k + 1] += P.pptr[k];
+	P.pa.resize(n_pairs);
+	P.pb.resize(n_pairs);
+	std::vector<int64_t> fill(P.pptr.begin(), P.pptr.end() - 1);
+	for(size_t p = 0; p < n_pairs; ++ p) { // stable: pairs of a block stay ordered by source column
+		const int64_t d = fill[tgt[p]] ++;
+		P.pa[d] = ga[p];
+		P.pb[d] = gb[p];
+	}
+	return std::string();
+}
+
+// dense top (opt.dense_top_*), products per column (the update lists themselves if asked for), row lists, schedule
+// (opt.subtree_size, task_*) of an ordered plan
+std::string plan_finish(const PlanOptions &opt, Plan &P, bool b_pair_lists)
+{
+	const int32_t n = P.n;
+	const double t1 = now_ms();
+	const bool b_timing = getenv("SLAMPP_HIP_PLAN_TIMING") != 0;
+	double t_phase = t1;
+#define PLAN_PHASE(name) do { if(b_timing) { const double t_ = now_ms(); \
+	fprintf(stderr, "[plan] %-12s %8.2f ms\n", name, t_ - t_phase); t_phase = t_; } } while(0)
+
 	// ---- dense top ----
 	std::vector<char> in_dense(n, 0);
 	P.dense_pos.assign(n, -1);
@@ -868,46 +881,26 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 		}
 	}
 
-	PLAN_PHASE("symbolic");
+	PLAN_PHASE("dense top");
 	// ---- update lists ----
-	// column c contributes L(i,c) L(j,c)^T to block (i,j) for every pair of its sub-diagonal rows i >= j
-	{
-		std::vector<int32_t> tgt;
-		std::vector<int32_t> ga, gb;
-		for(int32_t c = 0; c < n; ++ c) {
-			if(in_dense[c])
-				continue; // updates among dense-top columns happen inside the dense factorization
-			const int64_t kb0 = P.lptr[c] + 1, kb1 = P.lptr[c + 1];
-			for(int64_t kb = kb0; kb < kb1; ++ kb) {
-				const int32_t j = P.lrow[kb];
-				int64_t t = P.lptr[j]; // walks down column j; rows of c (>= j) are a subset of rows of j
-				const int64_t t_end = P.lptr[j + 1];
-				for(int64_t ka = kb; ka < kb1; ++ ka) {
-					const int32_t i = P.lrow[ka];
-					while(t < t_end && P.lrow[t] < i)
-						++ t;
-					if(t == t_end || P.lrow[t] != i)
-						return "internal error: symbolic structure is not closed under updates";
-					tgt.push_back(int32_t(t));
-					ga.push_back(int32_t(ka));
-					gb.push_back(int32_t(kb));
-				}
-			}
-		}
-		const size_t n_pairs = tgt.size();
-		P.pptr.assign(n_lblocks + 1, 0);
-		for(size_t p = 0; p < n_pairs; ++ p)
-			++ P.pptr[tgt[p] + 1];
-		for(int64_t k = 0; k < n_lblocks; ++ k)
-			P.pptr[k + 1] += P.pptr[k];
-		P.pa.resize(n_pairs);
-		P.pb.resize(n_pairs);
-		std::vector<int64_t> fill(P.pptr.begin(), P.pptr.end() - 1);
-		for(size_t p = 0; p < n_pairs; ++ p) { // stable: pairs of a block stay ordered by source column
-			const int64_t d = fill[tgt[p]] ++;
-			P.pa[d] = ga[p];
-			P.pb[d] = gb[p];
-		}
+	// column c contributes L(i,c) L(j,c)^T to block (i,j) for every pair of its sub-diagonal rows i >= j.  What the chain
+	// model asks of them is how many products the off-diagonal blocks of a column receive -- counted here without the lists,
+	// which only the plan that is kept needs (plan_pair_lists(); round 6: the lists were half of what a candidate cost)
+	P.col_products.assign(n, 0);
+	for(int32_t c = 0; c < n; ++ c) {
+		if(in_dense[c])
+			continue; // updates among dense-top columns happen inside the dense factorization
+		const int64_t kb0 = P.lptr[c] + 1, kb1 = P.lptr[c + 1];
+		for(int64_t kb = kb0; kb < kb1; ++ kb)
+			P.col_products[P.lrow[kb]] += kb1 - kb - 1;
+	}
+	P.pptr.clear();
+	P.pa.clear();
+	P.pb.clear();
+	if(b_pair_lists) {
+		std::string s_err = plan_pair_lists(P);
+		if(!s_err.empty())
+			return s_err;
 	}
 
 	PLAN_PHASE("pairs");
@@ -1154,8 +1147,322 @@ static std::string build_plan_once(int64_t n_bcols, const int64_t *cumsum, const
 	}
 	PLAN_PHASE("schedule");
 #undef PLAN_PHASE
-	P.symbolic_ms = now_ms() - t1;
+	P.symbolic_ms += now_ms() - t1;
 	return std::string();
 }
+
+} // anonymous namespace
+
+namespace {
+
+// The candidates of one plan search.  A candidate is (dense-top threshold, balance of the dissection, bank of its level
+// cuts); candidates of one (balance, bank) share ordering and symbolic factorization, all share the block graph.  Round 6:
+// the search used to build its up to 13 candidates one after the other, each from the caller's arrays (C1: 42 ms of a
+// 42 ms analysis).  The decisions are the same ones in the same order -- Ensure() only makes sure that what the next
+// decisions will look at has been built, the missing orderings side by side, then the missing candidates side by side.
+class CPlanSearch {
+public:
+	struct TKey {
+		int n_nb, n_balance, n_bank;
+		bool operator <(const TKey &r_o) const
+		{
+			return (n_nb != r_o.n_nb)? n_nb < r_o.n_nb : (n_balance != r_o.n_balance)? n_balance < r_o.n_balance : n_bank < r_o.n_bank;
+		}
+	};
+	struct TCandidate {
+		Plan plan;
+		std::string s_err;
+		double f_us = 0;
+		bool b_built = false;
+	};
+
+private:
+	const TBlockGraph &m_r_graph;
+	const int64_t *m_p_cumsum, *m_p_bcol_ptr;
+	const int32_t *m_p_brow;
+	const PlanOptions m_opt;
+	struct TOrdered {
+		Plan plan; // up to the symbolic factorization
+		std::string s_err;
+		bool b_built = false;
+	};
+	std::map<std::pair<int, int>, TOrdered> m_ordered; // (balance, bank); natural order: one entry
+	std::map<TKey, TCandidate> m_cand;
+	double m_f_order_ms, m_f_symbolic_ms; // wall clock of the search's phases
+
+	std::pair<int, int> t_Ordering_Key(const TKey &r_k) const
+	{
+		return m_opt.natural_order? std::make_pair(0, 0) : std::make_pair(r_k.n_balance, r_k.n_bank);
+	}
+
+	template <class CJob>
+	static void Run_Side_By_Side(size_t n_jobs, CJob job)
+	{
+		if(!n_jobs)
+			return;
+		std::vector<std::thread> threads;
+		std::exception_ptr p_error;
+		std::mutex t_mutex;
+		auto guarded = [&](size_t i) {
+			try {
+				job(i);
+			} catch(...) {
+				std::lock_guard<std::mutex> t_lock(t_mutex);
+				p_error = std::current_exception();
+			}
+		};
+		try {
+			for(size_t i = 1; i < n_jobs; ++ i)
+				threads.emplace_back(guarded, i);
+		} catch(...) { // no more threads: the rest on this one
+			for(size_t i = threads.size() + 1; i < n_jobs; ++ i)
+				guarded(i);
+		}
+		guarded(0);
+		for(size_t t = 0; t < threads.size(); ++ t)
+			threads[t].join();
+		if(p_error)
+			std::rethrow_exception(p_error);
+	}
+
+public:
+	CPlanSearch(const TBlockGraph &r_graph, const int64_t *p_cumsum, const int64_t *p_bcol_ptr, const int32_t *p_brow,
+		const PlanOptions &r_opt)
+		:m_r_graph(r_graph), m_p_cumsum(p_cumsum), m_p_bcol_ptr(p_bcol_ptr), m_p_brow(p_brow), m_opt(r_opt),
+		m_f_order_ms(0), m_f_symbolic_ms(0)
+	{}
+
+	double f_Order_ms() const { return m_f_order_ms; }
+	double f_Symbolic_ms() const { return m_f_symbolic_ms; }
+
+	// orderings (and symbolic factorizations) that are not there yet, side by side
+	void Ensure_Orderings(const std::vector<TKey> &r_keys)
+	{
+		std::vector<std::pair<std::pair<int, int>, TOrdered*> > todo;
+		for(const TKey &r_k : r_keys) {
+			TOrdered &r_o = m_ordered[t_Ordering_Key(r_k)];
+			if(!r_o.b_built) {
+				r_o.b_built = true;
+				todo.push_back(std::make_pair(t_Ordering_Key(r_k), &r_o));
+			}
+		}
+		const double t0 = now_ms();
+		Run_Side_By_Side(todo.size(), [&](size_t i) {
+			PlanOptions t_opt = m_opt;
+			t_opt.nd_balance_pct = todo[i].first.first;
+			t_opt.nd_other_bank = todo[i].first.second;
+			TOrdered &r_o = *todo[i].second;
+			r_o.s_err = plan_order_symbolic(m_r_graph, m_p_cumsum, m_p_bcol_ptr, m_p_brow, t_opt, r_o.plan);
+		});
+		if(!todo.empty()) {
+			m_f_order_ms += now_ms() - t0;
+			if(getenv("SLAMPP_HIP_PLAN_TIMING"))
+				fprintf(stderr, "[plan search] %zu orderings side by side %8.2f ms\n", todo.size(), now_ms() - t0);
+		}
+	}
+
+	// candidates that are not there yet, side by side (their orderings first)
+	void Ensure(const std::vector<TKey> &r_keys)
+	{
+		Ensure_Orderings(r_keys);
+		std::vector<std::pair<TKey, TCandidate*> > todo;
+		for(const TKey &r_k : r_keys) {
+			TCandidate &r_c = m_cand[r_k];
+			if(!r_c.b_built) {
+				r_c.b_built = true;
+				todo.push_back(std::make_pair(r_k, &r_c));
+			}
+		}
+		const double t0 = now_ms();
+		Run_Side_By_Side(todo.size(), [&](size_t i) {
+			const TKey &r_k = todo[i].first;
+			TCandidate &r_c = *todo[i].second;
+			const TOrdered &r_o = m_ordered.find(t_Ordering_Key(r_k))->second; // (there since Ensure_Orderings(); find(): nothing is inserted under the threads' feet)
+			if(r_k.n_nb < 4 && r_k.n_nb != m_opt.dense_top_nb) {
+				r_c.s_err = "threshold too low";
+				return;
+			}
+			if(!(r_c.s_err = r_o.s_err).empty())
+				return;
+			PlanOptions t_opt = m_opt;
+			t_opt.dense_top_nb = r_k.n_nb;
+			t_opt.nd_balance_pct = r_k.n_balance;
+			t_opt.nd_other_bank = r_k.n_bank;
+			r_c.plan = r_o.plan;
+			if((r_c.s_err = plan_finish(t_opt, r_c.plan, false)).empty())
+				r_c.f_us = plan_chain_estimate_us(r_c.plan);
+		});
+		if(!todo.empty()) {
+			m_f_symbolic_ms += now_ms() - t0;
+			if(getenv("SLAMPP_HIP_PLAN_TIMING"))
+				fprintf(stderr, "[plan search] %zu candidates side by side %8.2f ms\n", todo.size(), now_ms() - t0);
+		}
+	}
+
+	TCandidate &r_Get(const TKey &r_k)
+	{
+		Ensure(std::vector<TKey>(1, r_k));
+		return m_cand[r_k];
+	}
+};
+
+} // anonymous namespace
+
+std::string build_plan(int64_t n_bcols, const int64_t *cumsum, const int64_t *bcol_ptr,
+	const int32_t *brow, const PlanOptions &r_opt, Plan &P)
+{
+	PlanOptions opt = r_opt;
+	// development aids (environment, with SLAMPP_HIP_DEV=1: plan.h): override the options of the same names
+	opt.task_height = std::min(std::max(dev_knob("SLAMPP_HIP_DEV_TASK_HEIGHT", opt.task_height), 1), 8);
+	opt.task_max_cols = std::min(std::max(dev_knob("SLAMPP_HIP_DEV_TASK_MAX_COLS", opt.task_max_cols), 1), 64);
+	opt.task_max_blocks = std::min(std::max(dev_knob("SLAMPP_HIP_DEV_TASK_MAX_BLOCKS", opt.task_max_blocks), 1), 1024);
+	const bool b_balance_knob = dev_knob_set("SLAMPP_HIP_DEV_ND_BALANCE");
+	const int n_balance_knob = std::min(std::max(dev_knob("SLAMPP_HIP_DEV_ND_BALANCE", opt.nd_balance_pct), 1), 49);
+	opt.nd_balance_pct = std::min(std::max(opt.nd_balance_pct, 1), 49);
+	P = Plan();
+	TBlockGraph t_graph;
+	{
+		std::string s_err = plan_block_graph(n_bcols, cumsum, bcol_ptr, brow, t_graph);
+		if(!s_err.empty())
+			return s_err;
+	}
+	typedef CPlanSearch::TKey TKey;
+	const bool b_print = getenv("SLAMPP_HIP_PLAN_TIMING") != 0;
+	// (the balance knob overrides the balance of every candidate, as it did when each candidate read it for itself)
+	auto Key = [&](int n_nb, int n_balance, int n_bank) { TKey k = {n_nb, b_balance_knob? n_balance_knob : n_balance, n_bank}; return k; };
+	CPlanSearch search(t_graph, cumsum, bcol_ptr, brow, opt);
+	const TKey t_first = Key(opt.dense_top_nb, opt.nd_balance_pct, opt.nd_other_bank);
+	const bool b_may_search = opt.dense_top_auto && opt.dense_top_nb > 0;
+	// candidates: the balance first (25 / 35 / 45 % at the threshold asked for), then a lower and a higher threshold at the
+	// balance that came out best -- the tile levels of the dense top are what the chain is made of (33 us each: a
+	// diagonal tile, its panel, the updates), and how many there are depends on where the dissection cuts (measured,
+	// reduced camera system of the Venice-like leg: 2.34 ms at 25 %, 1.63 ms at 45 %; the model said 2.27 and 1.40)
+	const int n_balanced = std::max(opt.nd_balance_pct, 25);
+	const bool b_small = n_bcols <= 20000; // a small graph (the 2-D-like ones of the configs, a reduced camera system): the whole grid
+	if(b_may_search && !opt.natural_order && n_bcols <= 8192) {
+		// whether there is a dense top is known once the first plan stands; a graph this small is ordered in a millisecond
+		// or two, so the orderings a search would want are made beside the first one rather than after it
+		std::vector<TKey> spec(1, t_first);
+		for(int n_bank = opt.nd_other_bank; n_bank < 2; ++ n_bank) {
+			for(int n_balance = n_balanced; n_balance <= 45; n_balance += 10)
+				spec.push_back(Key(opt.dense_top_nb, n_balance, n_bank));
+		}
+		search.Ensure_Orderings(spec);
+	}
+	auto Finish = [&]() {
+		const double t0 = now_ms();
+		std::string s_err = plan_pair_lists(P); // (candidates are priced without their update lists)
+		P.order_ms = search.f_Order_ms(); // (wall clock of the whole search: the time went into this analysis)
+		P.symbolic_ms = search.f_Symbolic_ms() + (now_ms() - t0);
+		if(b_print)
+			fprintf(stderr, "[plan] %-12s %8.2f ms\n", "pairs", now_ms() - t0);
+		return s_err;
+	};
+	{
+		CPlanSearch::TCandidate &r_first = search.r_Get(t_first);
+		if(!r_first.s_err.empty())
+			return r_first.s_err;
+		if(!opt.dense_top_auto && b_print) {
+			fprintf(stderr, "[plan] dense_top_nb %d, balance %d %%: dense dim %d, chain estimate %.0f us (as asked for)\n", opt.dense_top_nb,
+				opt.nd_balance_pct, r_first.plan.dense_dim, r_first.f_us);
+		}
+		if(!opt.dense_top_auto || !r_first.plan.dense_dim) { // the only plan (a pose chain at full size comes this way: no copy)
+			std::swap(P, r_first.plan);
+			return Finish();
+		}
+		P = r_first.plan; // (a copy: the search may look at the same candidate again under another name -- the balance knob)
+	}
+	// A dense top: a 2-D-like graph.  Where the line between block-by-block elimination and the dense factorization
+	// is best drawn depends on the graph (Manhattan-like: lower, sphere-like: higher), and its separators are long
+	// enough that balanced halves beat the smallest separator (the opposite of pose chains, whose separators are one
+	// or two vertices and for which the default of 15 % is tuned).  Rebuild with 25 % as the base, then try a lower
+	// and a higher threshold; keep what the chain model clearly prefers.
+	double f_best = plan_chain_estimate_us(P);
+	if(b_print) {
+		fprintf(stderr, "[plan] dense_top_nb %d, balance %d %%: dense dim %d, chain estimate %.0f us\n", opt.dense_top_nb,
+			opt.nd_balance_pct, P.dense_dim, f_best);
+	}
+	int n_best_balance = opt.nd_balance_pct, n_best_nb = opt.dense_top_nb;
+	auto Try = [&](int n_nb, int n_balance, double f_margin, int n_bank = -1) {
+		const TKey t_key = Key(n_nb, n_balance, (n_bank >= 0)? n_bank : opt.nd_other_bank);
+		if(n_nb < 4)
+			return;
+		CPlanSearch::TCandidate &r_c = search.r_Get(t_key);
+		if(!r_c.s_err.empty())
+			return;
+		const double f_us = r_c.f_us;
+		if(b_print) {
+			fprintf(stderr, "[plan] dense_top_nb %d, balance %d %%%s: dense dim %d, chain estimate %.0f us\n", n_nb, n_balance,
+				t_key.n_bank? ", narrower bank" : "", r_c.plan.dense_dim, f_us);
+		}
+		if(r_c.plan.dense_dim && f_us < f_best * f_margin) {
+			f_best = std::min(f_best * std::max(f_margin, 1.0), f_us);
+			n_best_balance = n_balance;
+			n_best_nb = n_nb;
+			P = r_c.plan; // (a copy: the same candidate may be looked at again under another name -- natural order, the balance knob)
+		}
+	};
+	// the balanced base replaces the first plan unless it is clearly worse; everything else must be clearly better (the
+	// model is rough, and rougher for the heavy columns a higher threshold leaves to the block kernels)
+	const int p_nb[3] = {opt.dense_top_nb, opt.dense_top_nb * 2 / 3, opt.dense_top_nb * 3 / 2};
+	const double p_nb_margin[3] = {0.95, 0.95, 0.90};
+	if(b_small) {
+		std::vector<TKey> all;
+		for(int i = 0; i < 3; ++ i) {
+			for(int n_balance = n_balanced; n_balance <= 45; n_balance += 10) {
+				if(p_nb[i] >= 4)
+					all.push_back(Key(p_nb[i], n_balance, opt.nd_other_bank));
+			}
+		}
+		search.Ensure(all);
+	} else {
+		std::vector<TKey> all;
+		for(int n_balance = n_balanced; n_balance <= 45; n_balance += 10)
+			all.push_back(Key(opt.dense_top_nb, n_balance, opt.nd_other_bank));
+		search.Ensure(all);
+	}
+	if(n_balanced != opt.nd_balance_pct)
+		Try(opt.dense_top_nb, n_balanced, 1.10);
+	if(b_small) {
+		for(int i = 0; i < 3; ++ i) {
+			if(i > 0 && P.task_cols.empty())
+				break; // everything is in the dense top already: the threshold no longer matters
+			for(int n_balance = 25; n_balance <= 45; n_balance += 10) {
+				if((i > 0 || n_balance > n_balanced) && n_balance >= n_balanced)
+					Try(p_nb[i], n_balance, p_nb_margin[i]);
+			}
+		}
+	} else { // a large one: the balance first, then the threshold at the balance that came out best
+		for(int n_balance = 35; n_balance <= 45; n_balance += 10) {
+			if(n_balance > n_balanced)
+				Try(opt.dense_top_nb, n_balance, 0.95);
+		}
+		const int n_balance_chosen = n_best_balance;
+		{
+			std::vector<TKey> both;
+			for(int i = 1; i < 3; ++ i) {
+				if(p_nb[i] >= 4)
+					both.push_back(Key(p_nb[i], n_balance_chosen, opt.nd_other_bank));
+			}
+			search.Ensure(both);
+		}
+		Try(p_nb[1], n_balance_chosen, p_nb_margin[1]);
+		Try(p_nb[2], n_balance_chosen, p_nb_margin[2]);
+	}
+	// the other bank of the level cuts (PlanOptions::nd_other_bank): another family of orderings, priced at the threshold that
+	// came out best and every balance (round 4: the Venice-like reduced camera system 1.12 -> 1.00 ms; the model keeps C1 and
+	// C2 where they were, and so does the clock)
+	if(!opt.nd_other_bank) {
+		const int n_nb_chosen = n_best_nb;
+		std::vector<TKey> banks;
+		for(int n_balance = n_balanced; n_balance <= 45; n_balance += 10)
+			banks.push_back(Key(n_nb_chosen, n_balance, 1));
+		search.Ensure(banks);
+		for(int n_balance = n_balanced; n_balance <= 45; n_balance += 10)
+			Try(n_nb_chosen, n_balance, 0.95, 1);
+	}
+	return Finish();
+}
+
 
 } // namespace slampp

@@ -39,6 +39,7 @@ struct Plan {
 	// update lists: L(i,j) = A(i,j) - sum over pairs L[pa] * L[pb]^T
 	std::vector<int64_t> pptr;        // [l_blocks+1]
 	std::vector<int32_t> pa, pb;      // [n_pairs] factor block ids
+	std::vector<int64_t> col_products; // [n] pairs of the off-diagonal blocks of a column (what the chain model prices; there before the lists are)
 	// row lists (forward substitution): blocks L(j,c), c < j, of every block row j
 	std::vector<int64_t> rptr;        // [n+1]
 	std::vector<int32_t> rblk;        // [n_row_entries] factor block ids

@@ -250,6 +250,30 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 				cam_obs[r_fill[obs_cam[o]] ++] = int32_t(o);
 		});
 		SCHUR_SETUP_PHASE("observation lists");
+		// what is ready goes to the device from here on, beside the rest of the analysis (round 6: 130 MB out of pageable
+		// vectors at C5, 7 ms at the end of the analysis; the vectors are not written again, and joined before the final sync)
+		std::exception_ptr p_early_upload_error;
+		struct TJoinEarly { std::thread t; ~TJoinEarly() { if(t.joinable()) t.join(); } } t_early_upload;
+		{
+			const int n_device = s.n_device;
+			hipStream_t st_early = s.stream;
+			auto Early_Uploads = [&, n_device, st_early]() {
+				try {
+					SLAMPP_HIP_CHECK(hipSetDevice(n_device));
+					S.d_ptr.Upload(s.bcol_ptr, st_early);
+					S.d_brow.Upload(s.brow, st_early);
+					S.d_obs_pt.Upload(obs_pt, st_early);
+					S.d_cam_ptr.Upload(cam_ptr, st_early);
+					S.d_cam_obs.Upload(cam_obs, st_early);
+				} catch(...) {
+					p_early_upload_error = std::current_exception();
+				}
+			};
+			if(S.n_obs >= (int64_t(1) << 20))
+				t_early_upload.t = std::thread(Early_Uploads);
+			else
+				Early_Uploads(); // (a small system: a thread's start-up is what it would save)
+		}
 		// contributions to S grouped by block (row = camera of b, col = camera of a, a <= b within a point)
 		const int64_t ubase = S.n_ablocks * DC * DC;
 		std::vector<int64_t> sb_ptr;
@@ -301,33 +325,86 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 				b_tiles_built = true;
 				SCHUR_SETUP_PHASE("runs and tiles");
 				if(!S.tiles.b_enabled) {
-					// the lists of every block after all: the contributions counted (one thread), then placed
-					std::vector<int64_t> cnt(nc * nc + 1, 0);
-					for(int64_t pt = 0; pt < np; ++ pt) {
-						const int64_t o0 = ptr[nc + pt] - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
-						for(int64_t a = o0; a < o1; ++ a)
-							for(int64_t b = a; b < o1; ++ b)
-								++ cnt[int64_t(obs_cam[a]) * nc + obs_cam[b] + 1];
-					}
-					for(int64_t key = 0; key < nc * nc; ++ key) {
-						if(cnt[key + 1])
-							sb_ptr.push_back(cnt[key]);
-						cnt[key + 1] += cnt[key];
+					// the lists of every block after all: a counting sort of the contributions by block.  Round 6: on the threads of
+					// the passes above, a counter array per thread over its range of landmarks (one thread counted and placed the
+					// five million contributions of the uniform-visibility C4 in 37 ms); every contribution lands where the serial
+					// pass put it: inside a block in landmark order
+					const int64_t n_keys = nc * nc;
+					const int n_list_workers = int(std::max<int64_t>(1, std::min<int64_t>(n_setup_workers, (int64_t(1) << 26) / std::max<int64_t>(n_keys, 1)))); // (at most 512 MB of counters)
+					auto For_List_Ranges = [&](int64_t n, const std::function<void(int, int64_t, int64_t)> &r_work) {
+						std::vector<std::thread> threads;
+						for(int t = 0; t < n_list_workers; ++ t) {
+							const int64_t n_first = n * t / n_list_workers, n_last = n * (t + 1) / n_list_workers;
+							if(t + 1 < n_list_workers)
+								threads.emplace_back(r_work, t, n_first, n_last);
+							else
+								r_work(t, n_first, n_last);
+						}
+						for(size_t t = 0; t < threads.size(); ++ t)
+							threads[t].join();
+					};
+					std::vector<std::vector<int64_t> > cnt(n_list_workers);
+					For_List_Ranges(np, [&](int t, int64_t n_first, int64_t n_last) {
+						std::vector<int64_t> &r_cnt = cnt[t];
+						r_cnt.assign(size_t(n_keys), 0);
+						for(int64_t pt = n_first; pt < n_last; ++ pt) {
+							const int64_t o0 = ptr[nc + pt] - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
+							for(int64_t a = o0; a < o1; ++ a)
+								for(int64_t b = a; b < o1; ++ b)
+									++ r_cnt[int64_t(obs_cam[a]) * nc + obs_cam[b]];
+						}
+					});
+					// where every thread's contributions to every block start: block by block, inside a block thread by thread --
+					// the ranges of blocks first by themselves, then shifted by what the ranges before them hold
+					std::vector<int64_t> range_total(n_list_workers, 0);
+					std::vector<std::vector<int64_t> > range_starts(n_list_workers); // start of every nonzero block of the range
+					For_List_Ranges(n_keys, [&](int r, int64_t n_first, int64_t n_last) {
+						int64_t n_sum = 0;
+						for(int64_t key = n_first; key < n_last; ++ key) {
+							const int64_t n_before = n_sum;
+							for(int t = 0; t < n_list_workers; ++ t) {
+								const int64_t n_here = cnt[t][size_t(key)];
+								cnt[t][size_t(key)] = n_sum;
+								n_sum += n_here;
+							}
+							if(n_sum != n_before)
+								range_starts[r].push_back(n_before);
+						}
+						range_total[r] = n_sum;
+					});
+					std::vector<int64_t> range_base(n_list_workers + 1, 0);
+					for(int r = 0; r < n_list_workers; ++ r)
+						range_base[r + 1] = range_base[r] + range_total[r];
+					For_List_Ranges(n_keys, [&](int r, int64_t n_first, int64_t n_last) {
+						if(!range_base[r])
+							return;
+						for(int t = 0; t < n_list_workers; ++ t) {
+							int64_t *p_cnt = cnt[t].data();
+							for(int64_t key = n_first; key < n_last; ++ key)
+								p_cnt[key] += range_base[r];
+						}
+					});
+					for(int r = 0; r < n_list_workers; ++ r) {
+						for(size_t i = 0; i < range_starts[r].size(); ++ i)
+							sb_ptr.push_back(range_starts[r][i] + range_base[r]);
 					}
 					sb_ptr.push_back(n_entries);
-					if(sb_ptr.size() != sb_row.size() + 1)
+					if(sb_ptr.size() != sb_row.size() + 1 || range_base[n_list_workers] != n_entries)
 						throw std::logic_error("reduced camera system: the block list and the contribution counts disagree");
 					ent_a.resize(n_entries);
 					ent_uoff.resize(n_entries);
-					for(int64_t pt = 0; pt < np; ++ pt) {
-						const int64_t o0 = ptr[nc + pt] - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
-						for(int64_t a = o0; a < o1; ++ a)
-							for(int64_t b = a; b < o1; ++ b) {
-								const int64_t d = cnt[int64_t(obs_cam[a]) * nc + obs_cam[b]] ++;
-								ent_a[d] = int32_t(a);
-								ent_uoff[d] = ubase + b * DC * DP + pt * DP * DP;
-							}
-					}
+					For_List_Ranges(np, [&](int t, int64_t n_first, int64_t n_last) {
+						int64_t *p_fill = cnt[t].data();
+						for(int64_t pt = n_first; pt < n_last; ++ pt) {
+							const int64_t o0 = ptr[nc + pt] - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
+							for(int64_t a = o0; a < o1; ++ a)
+								for(int64_t b = a; b < o1; ++ b) {
+									const int64_t d = p_fill[int64_t(obs_cam[a]) * nc + obs_cam[b]] ++;
+									ent_a[d] = int32_t(a);
+									ent_uoff[d] = ubase + b * DC * DP + pt * DP * DP;
+								}
+						}
+					});
 				}
 			} else { // comparison sort on (key, a, b)
 				ent_a.resize(n_entries);
@@ -374,16 +451,15 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 		if(!b_tiles_built)
 			schur_tiles_build(S.tiles, s.n_schur_tiles, int(DC), int(DP), nc, np, ptr, brow, sb_row, sb_col, S.n_ablocks, st);
 		SCHUR_SETUP_PHASE("runs and tiles");
-		S.d_ptr.Upload(s.bcol_ptr, st);
-		S.d_brow.Upload(s.brow, st);
-		S.d_obs_pt.Upload(obs_pt, st);
 		S.d_sb_ptr.Upload(sb_ptr, st);
 		S.d_sb_row.Upload(sb_row, st);
 		S.d_sb_col.Upload(sb_col, st);
 		S.d_ent_a.Upload(ent_a, st);
 		S.d_ent_uoff.Upload(ent_uoff, st);
-		S.d_cam_ptr.Upload(cam_ptr, st);
-		S.d_cam_obs.Upload(cam_obs, st);
+		if(t_early_upload.t.joinable())
+			t_early_upload.t.join();
+		if(p_early_upload_error)
+			std::rethrow_exception(p_early_upload_error);
 		S.d_W.Alloc(size_t(S.n_obs) * (DC * DP));
 		S.d_Cinv.Alloc(size_t(np) * DP * DP);
 		S.d_t.Alloc(size_t(S.n_obs) * DP);

@@ -853,6 +853,57 @@ void build_run(TTileRun &R, const int32_t *p_order, int64_t n_first, int64_t n_l
 	Close();
 }
 
+
+// LSD radix sort of items by bits [n_first_bit, n_last_bit) of their 64-bit keys, 11 bits a pass (2 048 destinations a thread:
+// the writes of a pass stay in the caches; with 16-bit digits every write was a miss), stable, on up to eight threads: a thread
+// counts the digits of its range, the ranges' counts are laid out digit by digit and thread by thread -- where a serial pass
+// would have put the elements --, and every thread moves its own range.  The items carry what later passes need: nothing is
+// read through the permutation.
+template <class TItem, class CKeyOf>
+void radix_sort_items(raw_vector<TItem> &r_items, raw_vector<TItem> &r_tmp, int n_first_bit, int n_last_bit, CKeyOf key_of)
+{
+	enum { DIGIT_BITS = 11, DIGITS = 1 << DIGIT_BITS };
+	const int64_t n = int64_t(r_items.size());
+	r_tmp.resize(size_t(n));
+	const int n_workers = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, std::max(1u, std::thread::hardware_concurrency())), n / 32768)));
+	std::vector<std::vector<int64_t> > cnt(n_workers, std::vector<int64_t>(DIGITS));
+	auto For_Ranges = [&](const std::function<void(int, int64_t, int64_t)> &r_work) {
+		std::vector<std::thread> threads;
+		for(int t = 0; t < n_workers; ++ t) {
+			const int64_t n_first = n * t / n_workers, n_last = n * (t + 1) / n_workers;
+			if(t + 1 < n_workers)
+				threads.emplace_back(r_work, t, n_first, n_last);
+			else
+				r_work(t, n_first, n_last);
+		}
+		for(size_t t = 0; t < threads.size(); ++ t)
+			threads[t].join();
+	};
+	for(int n_shift = n_first_bit; n_shift < n_last_bit; n_shift += DIGIT_BITS) {
+		const uint64_t n_mask = (n_last_bit - n_shift >= DIGIT_BITS)? uint64_t(DIGITS - 1) : (uint64_t(1) << (n_last_bit - n_shift)) - 1;
+		For_Ranges([&](int t, int64_t n_first, int64_t n_last) {
+			std::vector<int64_t> &r_cnt = cnt[t];
+			std::fill(r_cnt.begin(), r_cnt.end(), 0);
+			for(int64_t i = n_first; i < n_last; ++ i)
+				++ r_cnt[(key_of(r_items[i]) >> n_shift) & n_mask];
+		});
+		int64_t n_sum = 0;
+		for(int d = 0; d < DIGITS; ++ d) {
+			for(int t = 0; t < n_workers; ++ t) {
+				const int64_t n_here = cnt[t][d];
+				cnt[t][d] = n_sum;
+				n_sum += n_here;
+			}
+		}
+		For_Ranges([&](int t, int64_t n_first, int64_t n_last) {
+			std::vector<int64_t> &r_cnt = cnt[t];
+			for(int64_t i = n_first; i < n_last; ++ i)
+				r_tmp[r_cnt[(key_of(r_items[i]) >> n_shift) & n_mask] ++] = r_items[i];
+		});
+		r_items.swap(r_tmp);
+	}
+}
+
 } // namespace
 
 void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, int64_t np, const int64_t *ptr, const int32_t *brow,
@@ -917,54 +968,26 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 			}
 		});
 		BUILD_PHASE("hashes");
-		raw_vector<int32_t> order(np), tmp(np);
-		for(int64_t i = 0; i < np; ++ i)
-			order[i] = int32_t(i);
-		{
-			// LSD radix sort, 16 bits a pass: equal hashes stay in landmark order.  Every pass on a few threads (round 5: 21 ms of
-			// C5's analysis on one): a thread counts the digits of its range of the current order, the ranges' counts are laid
-			// out digit by digit and thread by thread -- where a serial pass would have put the elements --, and every thread
-			// moves its own range.
-			const int n_sort_workers = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, std::max(1u, std::thread::hardware_concurrency())), np / 65536)));
-			std::vector<std::vector<int64_t> > cnt(n_sort_workers, std::vector<int64_t>(65536));
-			auto For_Sort_Ranges = [&](const std::function<void(int, int64_t, int64_t)> &r_work) {
-				std::vector<std::thread> threads;
-				for(int t = 0; t < n_sort_workers; ++ t) {
-					const int64_t n_first = np * t / n_sort_workers, n_last = np * (t + 1) / n_sort_workers;
-					if(t + 1 < n_sort_workers)
-						threads.emplace_back(r_work, t, n_first, n_last);
-					else
-						r_work(t, n_first, n_last);
-				}
-				for(size_t t = 0; t < threads.size(); ++ t)
-					threads[t].join();
-			};
-			// (by the upper 48 bits: three passes.  Two lists that differ only in the lowest 16 bits of this hash -- 1e-2 such
-			// pairs among two million -- may come out interleaved; the runs are then cut where "same lists" below says so: a few
-			// more, shorter runs, never a wrong one)
-			for(int n_shift = 16; n_shift < 64; n_shift += 16) {
-				For_Sort_Ranges([&](int t, int64_t n_first, int64_t n_last) {
-					std::vector<int64_t> &r_cnt = cnt[t];
-					std::fill(r_cnt.begin(), r_cnt.end(), 0);
-					for(int64_t i = n_first; i < n_last; ++ i)
-						++ r_cnt[(hash[order[i]] >> n_shift) & 0xFFFF];
-				});
-				int64_t n_sum = 0;
-				for(int d = 0; d < 65536; ++ d) {
-					for(int t = 0; t < n_sort_workers; ++ t) {
-						const int64_t n_here = cnt[t][d];
-						cnt[t][d] = n_sum;
-						n_sum += n_here;
-					}
-				}
-				For_Sort_Ranges([&](int t, int64_t n_first, int64_t n_last) {
-					std::vector<int64_t> &r_cnt = cnt[t];
-					for(int64_t i = n_first; i < n_last; ++ i)
-						tmp[r_cnt[(hash[order[i]] >> n_shift) & 0xFFFF] ++] = order[i];
-				});
-				order.swap(tmp);
+		// Radix sort by the hash (radix_sort_items): equal hashes stay in landmark order.  Round 6: what the passes and the
+		// comparison of neighbours below need of a landmark -- both
+		// hashes, the length of its list -- travels with it (24 bytes an element, read in order, instead of reads of hash[],
+		// hash2[] and k_of[] in the order of the pass before: a cache miss each, 12 + 8 ms at C5's two million landmarks).
+		struct TSortItem { uint64_t n_hash, n_hash2; int32_t n_k, n_landmark; };
+		raw_vector<TSortItem> items(np), items_tmp(np);
+		raw_vector<int32_t> order(np);
+		For_Landmark_Ranges(0, [&](int64_t n_first, int64_t n_last) {
+			for(int64_t pt = n_first; pt < n_last; ++ pt) {
+				TSortItem &r_item = items[pt];
+				r_item.n_hash = hash[pt];
+				r_item.n_hash2 = hash2[pt];
+				r_item.n_k = k_of[pt];
+				r_item.n_landmark = int32_t(pt);
 			}
-		}
+		});
+		// (by the upper 33 bits: three passes.  Lists whose hashes differ only below -- a few hundred pairs among two million --
+		// may come out interleaved; the classes are then cut where "same lists" below says so, and the chains put classes of
+		// one list back together: the same runs)
+		radix_sort_items(items, items_tmp, 31, 64, [](const TSortItem &r_item) { return r_item.n_hash; });
 		BUILD_PHASE("sort");
 		auto Same = [&](int32_t p, int32_t q) -> bool {
 			const int64_t kp0 = ptr[nc + p], kq0 = ptr[nc + q], k = ptr[nc + p + 1] - kp0 - 1;
@@ -1048,10 +1071,14 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 		// systems under 262 144 landmarks (where it costs nothing) still do (SLAMPP_HIP_DEV_RUN_HASH_ONLY, a development knob:
 		// the hashes alone there too, for the tests).
 		const bool b_compare_lists = np < (int64_t(1) << 18) && !dev_knob_set("SLAMPP_HIP_DEV_RUN_HASH_ONLY");
+		if(np)
+			order[0] = items[0].n_landmark;
 		For_Landmark_Ranges(1, [&](int64_t n_first, int64_t n_last) {
 			for(int64_t i = n_first; i < n_last; ++ i) {
-				const int32_t p = order[i - 1], q = order[i];
-				same_as_previous[i] = hash[q] == hash[p] && hash2[q] == hash2[p] && k_of[q] == k_of[p] && (!b_compare_lists || Same(p, q));
+				const TSortItem &r_p = items[i - 1], &r_q = items[i];
+				order[i] = r_q.n_landmark;
+				same_as_previous[i] = r_q.n_hash == r_p.n_hash && r_q.n_hash2 == r_p.n_hash2 && r_q.n_k == r_p.n_k &&
+					(!b_compare_lists || Same(r_p.n_landmark, r_q.n_landmark));
 			}
 		});
 		BUILD_PHASE("  same lists");
@@ -1090,21 +1117,88 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 		BUILD_PHASE("  classes");
 		const bool b_chains = !dev_knob_set("SLAMPP_HIP_DEV_NO_PREFIX_RUNS");
 		if(b_chains) {
-			std::sort(classes.begin(), classes.end(), [&](const TClass &a, const TClass &b) {
-				const int32_t p = order[a.n_first], q = order[b.n_first];
-				return List_Less(p, q) || (!List_Less(q, p) && a.n_first < b.n_first); });
+			// Round 6: by a 64-bit key of the first cameras of the list (a radix sort on a few threads), the lists themselves only
+			// where keys tie -- a comparison sort that reads two lists per comparison was 96 ms at 500 000 landmarks with
+			// 500 000 different lists (uniform visibility).  Camera + 1 in every field, zero behind the end of a short list:
+			// the keys order the first fields' worth of cameras the way List_Less does, a list right before its continuations.
+			const int64_t n_classes = int64_t(classes.size());
+			int n_field_bits = 1;
+			while((int64_t(1) << n_field_bits) <= nc)
+				++ n_field_bits;
+			const int n_fields = std::max(1, 64 / n_field_bits), n_key_bits = n_fields * n_field_bits;
+			struct TClassItem { uint64_t n_key; TClass t_class; };
+			raw_vector<TClassItem> class_items(n_classes), class_items_tmp;
+			const int n_class_workers = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, std::max(1u, std::thread::hardware_concurrency())), n_classes / 16384)));
+			{
+				std::vector<std::thread> threads;
+				auto Keys = [&](int64_t n_first, int64_t n_last) {
+					for(int64_t c = n_first; c < n_last; ++ c) {
+						const int32_t p = order[classes[c].n_first];
+						const int64_t k0 = ptr[nc + p], k = ptr[nc + p + 1] - k0 - 1;
+						uint64_t n_key = 0;
+						for(int f = 0; f < n_fields; ++ f)
+							n_key = (n_key << n_field_bits) | ((f < k)? uint64_t(brow[k0 + f]) + 1 : 0);
+						class_items[c].n_key = n_key;
+						class_items[c].t_class = classes[c];
+					}
+				};
+				for(int t = 0; t + 1 < n_class_workers; ++ t)
+					threads.emplace_back(Keys, n_classes * t / n_class_workers, n_classes * (t + 1) / n_class_workers);
+				Keys(n_classes * (n_class_workers - 1) / n_class_workers, n_classes);
+				for(size_t t = 0; t < threads.size(); ++ t)
+					threads[t].join();
+			}
+			radix_sort_items(class_items, class_items_tmp, 0, n_key_bits, [](const TClassItem &r_item) { return r_item.n_key; }); // (stable: classes of one key stay in the order they were found in)
+			std::vector<TClass> sorted(classes.size());
+			for(int64_t c = 0; c < n_classes; ++ c)
+				sorted[c] = class_items[c].t_class;
+			for(int64_t c0 = 0; c0 < n_classes;) { // keys that tie: lists longer than the key that agree in all of its fields
+				int64_t c1 = c0 + 1;
+				while(c1 < n_classes && class_items[c1].n_key == class_items[c0].n_key)
+					++ c1;
+				if(c1 - c0 > 1) {
+					std::sort(sorted.begin() + c0, sorted.begin() + c1, [&](const TClass &a, const TClass &b) {
+						const int32_t p = order[a.n_first], q = order[b.n_first];
+						return List_Less(p, q) || (!List_Less(q, p) && a.n_first < b.n_first); });
+				}
+				c0 = c1;
+			}
+			classes.swap(sorted);
 		}
 		BUILD_PHASE("  class order");
+		// what the chains ask of every class -- the tiles of its job, the length of its list, whether it continues the class
+		// before it -- read from the lists on a few threads (round 6: 500 000 classes of one landmark each, uniform
+		// visibility, were 15 ms of cache misses in the loop below)
+		const int64_t n_classes_all = int64_t(classes.size());
+		raw_vector<int32_t> class_k(n_classes_all);
+		raw_vector<uint8_t> class_tiles(n_classes_all), class_continues(n_classes_all);
+		{
+			const int n_workers = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, std::max(1u, std::thread::hardware_concurrency())), n_classes_all / 16384)));
+			auto Look = [&](int64_t n_first, int64_t n_last) {
+				for(int64_t c = n_first; c < n_last; ++ c) {
+					const int32_t p = order[classes[c].n_first];
+					class_k[c] = int32_t(ptr[nc + p + 1] - ptr[nc + p] - 1);
+					class_tiles[c] = uint8_t(Tile_Class(p));
+					class_continues[c] = b_chains && c > 0 && Is_Prefix(order[classes[c - 1].n_first], p);
+				}
+			};
+			std::vector<std::thread> threads;
+			for(int t = 0; t + 1 < n_workers; ++ t)
+				threads.emplace_back(Look, n_classes_all * t / n_workers, n_classes_all * (t + 1) / n_workers);
+			Look(n_classes_all * (n_workers - 1) / n_workers, n_classes_all);
+			for(size_t t = 0; t < threads.size(); ++ t)
+				threads[t].join();
+		}
+		BUILD_PHASE("  class lists");
 		std::vector<int32_t> members, members_k;
 		for(size_t c0 = 0; c0 < classes.size();) {
 			size_t c1 = c0 + 1;
 			int64_t n_members = classes[c0].n_count;
-			while(b_chains && c1 < classes.size() && Tile_Class(order[classes[c1].n_first]) == Tile_Class(order[classes[c0].n_first]) &&
-			   Is_Prefix(order[classes[c1 - 1].n_first], order[classes[c1].n_first])) {
+			while(c1 < classes.size() && class_tiles[c1] == class_tiles[c0] && class_continues[c1]) {
 				n_members += classes[c1].n_count;
 				++ c1;
 			}
-			const int64_t k_longest = ptr[nc + order[classes[c1 - 1].n_first] + 1] - ptr[nc + order[classes[c1 - 1].n_first]] - 1;
+			const int64_t k_longest = class_k[c1 - 1];
 			// (a lone long track is no better off here than in the lists; two of them already share their partial blocks)
 			if(n_members >= ((k_longest > OB && n_min_run > 2)? 2 : n_min_run)) {
 				members.clear();
@@ -1112,7 +1206,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 				for(size_t c = c1; c > c0; -- c) { // longest list first
 					const TClass &r_class = classes[c - 1];
 					members.insert(members.end(), order.begin() + r_class.n_first, order.begin() + r_class.n_first + r_class.n_count);
-					members_k.insert(members_k.end(), size_t(r_class.n_count), k_of[order[r_class.n_first]]);
+					members_k.insert(members_k.end(), size_t(r_class.n_count), class_k[c - 1]);
 				}
 				Emit_Run(members.data(), members_k.data(), int64_t(members.size()));
 				if(c1 - c0 > 1)
@@ -1120,6 +1214,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 			}
 			c0 = c1;
 		}
+		BUILD_PHASE("  emit (jobs)");
 		For_Landmark_Ranges(np - int64_t(run_lm.size()), [&](int64_t n_first, int64_t n_last) { // (ranges of the run list: np - its length .. np)
 			for(int64_t i = n_first - (np - int64_t(run_lm.size())); i < n_last - (np - int64_t(run_lm.size())); ++ i)
 				handled[run_lm[i]] = 1;
@@ -1149,14 +1244,17 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 	std::vector<TTileRun> runs;
 	int64_t n_tiles = 0, n_tile_slots = 0, n_tile_points = 0, n_tile_pairs = 0;
 	if(b_use_tiles && n_run_points < np) {
-		std::vector<int32_t> order, tmp;
-		for(int64_t pt = 0; pt < np; ++ pt) {
-			if(!handled[pt])
-				order.push_back(int32_t(pt));
-		}
-		const int64_t n_rest = int64_t(order.size());
-		tmp.resize(n_rest);
-		{
+		// (round 6: the two cameras a landmark is sorted by travel with it -- (first camera, second camera, landmark) in one
+		// 64-bit word, two counting passes over the words: the passes used to read ptr[] and brow[] of every landmark in the
+		// order of the pass before, four cache misses a landmark and 23 ms at 500 000 landmarks)
+		std::vector<int32_t> order;
+		if(nc > 65536) { // (cameras that do not fit the 16-bit fields: the passes read the lists)
+			std::vector<int32_t> tmp;
+			for(int64_t pt = 0; pt < np; ++ pt) {
+				if(!handled[pt])
+					order.push_back(int32_t(pt));
+			}
+			tmp.resize(order.size());
 			std::vector<int64_t> cnt(nc + 1);
 			for(int n_pass = 0; n_pass < 2; ++ n_pass) {
 				std::fill(cnt.begin(), cnt.end(), 0);
@@ -1164,17 +1262,87 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 					const int64_t k0 = ptr[nc + pt], k = ptr[nc + pt + 1] - k0 - 1;
 					return (k == 0)? 0 : brow[k0 + ((n_pass == 0 && k > 1)? 1 : 0)]; // least significant first
 				};
-				for(int64_t i = 0; i < n_rest; ++ i)
+				for(size_t i = 0; i < order.size(); ++ i)
 					++ cnt[Cam(order[i]) + 1];
 				for(int64_t c = 0; c < nc; ++ c)
 					cnt[c + 1] += cnt[c];
-				for(int64_t i = 0; i < n_rest; ++ i)
+				for(size_t i = 0; i < order.size(); ++ i)
 					tmp[cnt[Cam(order[i])] ++] = order[i];
 				order.swap(tmp);
 			}
+		} else {
+			raw_vector<uint64_t> items, items_tmp;
+			items.reserve(size_t(np - n_run_points));
+			for(int64_t pt = 0; pt < np; ++ pt) {
+				if(handled[pt])
+					continue;
+				const int64_t k0 = ptr[nc + pt], k = ptr[nc + pt + 1] - k0 - 1;
+				const uint64_t n_first_cam = (k == 0)? 0 : uint64_t(brow[k0]), n_second_cam = (k > 1)? uint64_t(brow[k0 + 1]) : n_first_cam;
+				items.push_back((n_first_cam << 48) | (n_second_cam << 32) | uint64_t(pt));
+			}
+			const int64_t n_items = int64_t(items.size());
+			items_tmp.resize(size_t(n_items));
+			std::vector<int64_t> cnt(65537);
+			for(int n_shift = 32; n_shift <= 48; n_shift += 16) { // least significant first
+				std::fill(cnt.begin(), cnt.end(), 0);
+				for(int64_t i = 0; i < n_items; ++ i)
+					++ cnt[((items[i] >> n_shift) & 0xFFFF) + 1];
+				for(int64_t c = 0; c < 65536; ++ c)
+					cnt[c + 1] += cnt[c];
+				for(int64_t i = 0; i < n_items; ++ i)
+					items_tmp[cnt[(items[i] >> n_shift) & 0xFFFF] ++] = items[i];
+				items.swap(items_tmp);
+			}
+			order.resize(size_t(n_items));
+			for(int64_t i = 0; i < n_items; ++ i)
+				order[i] = int32_t(uint32_t(items[i]));
 		}
+		const int64_t n_rest = int64_t(order.size());
 		// built piecewise by a few threads (a piece boundary is a tile boundary)
 		const int n_pieces = int(std::max<int64_t>(1, std::min<int64_t>(8, n_rest / 32768)));
+		// Round 6: where the library decides by itself (n_mode < 0) and the runs alone do not carry half of the contributions, the
+		// tiles are tried on a sample first -- the first 4 096 landmarks of every piece -- and left alone if runs and tiles
+		// together would stay well under that half (under 30 %: the decision below asks for 50): landmarks that share no
+		// cameras with their neighbours in this order (uniform visibility) end up on the lists whatever the tiles find, and
+		// forming tiles of all 500 000 of them to learn that was 16 - 23 ms of the analysis.
+		if(n_mode < 0 && n_rest >= 65536 && 2 * n_run_pairs < n_all_pairs) {
+			const int64_t n_sample = 4096;
+			std::vector<TTileRun> sample(n_pieces);
+			std::vector<int64_t> sample_pairs(n_pieces, 0);
+			std::vector<std::thread> threads;
+			for(int t = 0; t < n_pieces; ++ t) {
+				const int64_t n_first = n_rest * t / n_pieces, n_last = std::min(n_first + n_sample, n_rest * (t + 1) / n_pieces);
+				auto Work = [&sample, &sample_pairs, &order, t, n_first, n_last, n_mode, nc, ptr, brow]() {
+					build_run(sample[t], order.data(), n_first, n_last, n_mode, nc, ptr, brow);
+					for(int64_t i = n_first; i < n_last; ++ i) {
+						const int64_t k = ptr[nc + order[i] + 1] - ptr[nc + order[i]] - 1;
+						sample_pairs[t] += k * (k + 1) / 2;
+					}
+				};
+				if(t + 1 < n_pieces)
+					threads.emplace_back(Work);
+				else
+					Work();
+			}
+			for(size_t t = 0; t < threads.size(); ++ t)
+				threads[t].join();
+			int64_t n_sample_all = 0, n_sample_tiled = 0;
+			for(int t = 0; t < n_pieces; ++ t) {
+				n_sample_all += sample_pairs[t];
+				n_sample_tiled += int64_t(sample[t].lm_slot.size());
+			}
+			// pairs outside the runs, and the share of them the sample says tiles would take
+			const int64_t n_rest_pairs = n_all_pairs - n_run_pairs;
+			const double f_tiled = n_sample_all? double(n_sample_tiled) / double(n_sample_all) : 0.0;
+			if(b_build_timing)
+				fprintf(stderr, "[schur tiles] sample: tiles take %.1f %% of the contributions outside the runs\n", 100 * f_tiled);
+			if(double(n_run_pairs) + f_tiled * double(n_rest_pairs) < 0.30 * double(n_all_pairs)) {
+				BUILD_PHASE("tiles (sample)");
+				memset(T.n_run_jobs, 0, sizeof(T.n_run_jobs));
+				memset(T.n_run_job_first, 0, sizeof(T.n_run_job_first));
+				return; // the lists keep everything
+			}
+		}
 		runs.resize(n_pieces);
 		std::vector<std::thread> threads;
 		for(int t = 0; t < n_pieces; ++ t) {

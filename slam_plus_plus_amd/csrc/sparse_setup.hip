@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <unordered_map>
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -83,9 +84,9 @@ void slampp_hip_solver::Refine_Structure()
 
 // index ranges on a few threads (the record loops of the cold path: every entry written once, from the plan alone)
 template <class F>
-static void Parallel_Ranges(int64_t n, int64_t n_min_per_thread, F f)
+static void Parallel_Ranges(int64_t n, int64_t n_min_per_thread, F f, int n_max_threads = 4)
 {
-	const int n_threads = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4, std::max(1u, std::thread::hardware_concurrency())), n / std::max<int64_t>(n_min_per_thread, 1))));
+	const int n_threads = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_max_threads, std::max(1u, std::thread::hardware_concurrency())), n / std::max<int64_t>(n_min_per_thread, 1))));
 	if(n_threads <= 1) {
 		f(int64_t(0), n);
 		return;
@@ -172,217 +173,70 @@ void slampp_hip_solver::Analyze_Sparse()
 	// packed device records (see sparse_kernels.h)
 	const int32_t n_sched = int32_t(P.task_cols.size()); // all columns but those of the dense top
 	raw_vector<TColDesc> cols(n_sched); // in schedule order (raw_vector: not zero-filled -- solver.h; every record is written in full below)
-	for(int32_t i = 0; i < n_sched; ++ i) {
-		const int32_t j = P.task_cols[i];
-		TColDesc &c = cols[i];
-		memset(&c, 0, sizeof(c));
-		c.k0 = P.lptr[j];
-		c.nb = int32_t(P.lptr[j + 1] - P.lptr[j]);
-		c.dj = P.dim[j];
-		c.linv_off = P.linv_off[j];
-		c.cs_new = P.cs_new[j];
-		c.cs_src = P.cs_src[j];
-		c.r0 = P.rptr[j];
-		c.nr = int32_t(P.rptr[j + 1] - P.rptr[j]);
-		c.p0 = P.pptr[P.lptr[j] + 1]; // pairs are stored block by block: those of the sub-diagonal blocks are contiguous
-		const int64_t np = P.pptr[P.lptr[j + 1]] - c.p0;
-		c.np = int32_t(std::min<int64_t>(np, INT32_MAX));
-	}
 	raw_vector<TBlkDesc> blks(n_lblocks);
-	Parallel_Ranges(n_lblocks, 65536, [&](int64_t k_begin, int64_t k_end) {
-	for(int64_t k = k_begin; k < k_end; ++ k) {
-		TBlkDesc &b = blks[k];
-		const int64_t np = P.pptr[k + 1] - P.pptr[k];
-		if(np >= (int64_t(1) << 24))
-			throw std::domain_error("a factor block has 2^24 or more updates: use the dense path");
-		b.loff = P.loff[k];
-		b.asrc = (P.asrc[k] < 0)? -1 : P.asrc[k] * 2 + P.atrans[k];
-		if(k == P.lptr[P.blk_col[k]] && b.asrc >= 0)
-			b.asrc |= 1; // diagonal blocks are read transposed: the lower triangle of the factor block then comes from the upper triangle of Lambda's block, the one the reference's solvers consume
-		b.p0 = P.pptr[k];
-		b.np_di = uint32_t(np) | (uint32_t(P.dim[P.lrow[k]]) << 24);
-		b.xcs = int32_t(P.cs_new[P.lrow[k]]);
-	}
-	});
+	raw_vector<longlong2> pairs(P.pa.size());
+	raw_vector<TRowEnt> rents(P.rblk.size());
 	if(P.loff[n_lblocks] >= (int64_t(1) << 48))
 		throw std::domain_error("the factor has 2^48 or more values");
-	raw_vector<longlong2> pairs(P.pa.size());
-	Parallel_Ranges(n_lblocks, 65536, [&](int64_t k_begin, int64_t k_end) {
-	for(int64_t k = k_begin; k < k_end; ++ k) { // pairs are stored block by block
-		const int64_t n_pos = std::min<int64_t>(k - P.lptr[P.blk_col[k]], 255); // position of the target block in its column
-		for(int64_t e = P.pptr[k]; e < P.pptr[k + 1]; ++ e) {
-			const int64_t dc = P.dim[P.blk_col[P.pa[e]]];
-			pairs[e].x = P.loff[P.pa[e]] | (n_pos << 48) | (dc << 56);
-			pairs[e].y = P.loff[P.pb[e]];
-		}
-	}
-	});
-	raw_vector<TRowEnt> rents(P.rblk.size());
-	for(size_t e = 0; e < P.rblk.size(); ++ e) {
-		const int32_t c = P.blk_col[P.rblk[e]];
-		rents[e].off = P.loff[P.rblk[e]];
-		rents[e].ycs = int32_t(P.cs_new[c]);
-		rents[e].dc = P.dim[c];
-	}
-	// column packages for the upper stages (see sparse_kernels.h); the limits are those of factor_stage_kernel's staged path
-	std::vector<longlong2> pkg;
-	std::vector<int64_t> task_pkg(P.task_ptr.size() - 1, -1);
-	if(P.uniform_dim && (P.max_dim == 3 || P.max_dim == 6 || P.max_dim == 7)) {
-		const int n_stages = int(P.stage_ptr.size()) - 1;
-		// (the wide stages above the leaves and the stages near the root run the same kernel with different capacities)
-		const int n_first_stage = (n_stages > 1)? 1 : n_stages;
-		for(int t = (n_first_stage < n_stages)? P.stage_ptr[n_first_stage] : int(task_pkg.size()); t < int(task_pkg.size()); ++ t) {
-			const bool b_wide = t < P.stage_ptr[std::min(n_bottom_stages, n_stages)];
-			const int PKG_CHUNK = b_wide? int(WIDE_CHUNK) : int(UP_CHUNK), PKG_NR = b_wide? int(WIDE_NR) : int(UP_NR),
-				PKG_NP = b_wide? int(WIDE_NP) : int(UP_NP);
-			task_pkg[t] = int64_t(pkg.size());
-			for(int64_t i = P.task_ptr[t]; i < P.task_ptr[t + 1]; ++ i) {
-				const TColDesc &c = cols[i];
-				const size_t n_at = pkg.size();
-				const bool b_fits = c.nb <= PKG_CHUNK && c.nr <= PKG_NR && c.np <= PKG_NP;
-				const int ne = b_fits? c.nr + c.np : 0;
-				pkg.resize(n_at + (b_fits? package_units(c.nb, ne) : 4), longlong2{0, 0});
-				memcpy(&pkg[n_at], &c, sizeof(TColDesc));
-				if(!b_fits)
-					continue;
-				memcpy(&pkg[n_at + 4], &blks[c.k0], size_t(c.nb) * sizeof(TBlkDesc));
-				longlong2 *p_ent = &pkg[n_at + 4 + 2 * c.nb];
-				int32_t *p_ycs = reinterpret_cast<int32_t*>(p_ent + ne);
-				unsigned char *p_tag = reinterpret_cast<unsigned char*>(p_ent + ne + (ne + 3) / 4);
-				for(int e = 0; e < c.nr; ++ e) { // row entries of the diagonal block: both operands are the block L(j,c)
-					p_ent[e] = longlong2{rents[c.r0 + e].off, rents[c.r0 + e].off};
-					p_ycs[e] = rents[c.r0 + e].ycs;
-					p_tag[e] = 0;
-				}
-				for(int e = 0; e < c.np; ++ e) {
-					const longlong2 pr = pairs[c.p0 + e];
-					p_ent[c.nr + e] = longlong2{pr.x & ((int64_t(1) << 48) - 1), pr.y};
-					p_tag[c.nr + e] = (unsigned char)((pr.x >> 48) & 0xff);
-				}
+	// everything of one column: its blocks, their update pairs (stored block by block), the row entries of its diagonal block
+	auto Fill_Column = [&](int32_t j) {
+		for(int64_t k = P.lptr[j]; k < P.lptr[j + 1]; ++ k) {
+			TBlkDesc &b = blks[k];
+			const int64_t np = P.pptr[k + 1] - P.pptr[k];
+			if(np >= (int64_t(1) << 24))
+				throw std::domain_error("a factor block has 2^24 or more updates: use the dense path");
+			b.loff = P.loff[k];
+			b.asrc = (P.asrc[k] < 0)? -1 : P.asrc[k] * 2 + P.atrans[k];
+			if(k == P.lptr[j] && b.asrc >= 0)
+				b.asrc |= 1; // diagonal blocks are read transposed: the lower triangle of the factor block then comes from the upper triangle of Lambda's block, the one the reference's solvers consume
+			b.p0 = P.pptr[k];
+			b.np_di = uint32_t(np) | (uint32_t(P.dim[P.lrow[k]]) << 24);
+			b.xcs = int32_t(P.cs_new[P.lrow[k]]);
+			const int64_t n_pos = std::min<int64_t>(k - P.lptr[j], 255); // position of the target block in its column
+			for(int64_t e = P.pptr[k]; e < P.pptr[k + 1]; ++ e) {
+				const int64_t dc = P.dim[P.blk_col[P.pa[e]]];
+				pairs[e].x = P.loff[P.pa[e]] | (n_pos << 48) | (dc << 56);
+				pairs[e].y = P.loff[P.pb[e]];
 			}
 		}
-		pkg.resize(pkg.size() + PKG_SPECULATIVE, longlong2{0, 0});
-	}
-	SETUP_PHASE("records");
-	// the records go to the device beside the host work that follows (the packages of the separator tasks: ~10 ms each at C3,
-	// and an upload from a std::vector is a staged copy that keeps its thread): a thread of its own, joined before the rest
-	// of the uploads.  The vectors it reads are not written from here on.
-	std::exception_ptr p_upload_error;
-	struct TJoinUpload { std::thread t; ~TJoinUpload() { if(t.joinable()) t.join(); } } t_upload_thread;
-	auto Upload_Records = [&]() {
-		try {
-			SLAMPP_HIP_CHECK(hipSetDevice(n_device));
-			d_cols.Upload(cols, stream);
-			d_blks.Upload(blks, stream);
-			d_pairs.Upload(pairs, stream);
-			d_rents.Upload(rents, stream);
-			d_task_ptr.Upload(P.task_ptr, stream);
-			if(!pkg.empty()) {
-				d_pkg.Upload(pkg, stream);
-				d_task_pkg.Upload(task_pkg, stream);
-			} else {
-				d_pkg.Free();
-				d_task_pkg.Free();
-			}
-		} catch(...) {
-			p_upload_error = std::current_exception();
+		for(int64_t e = P.rptr[j]; e < P.rptr[j + 1]; ++ e) {
+			const int32_t c = P.blk_col[P.rblk[e]];
+			rents[e].off = P.loff[P.rblk[e]];
+			rents[e].ycs = int32_t(P.cs_new[c]);
+			rents[e].dc = P.dim[c];
 		}
 	};
-	if(b_small)
-		Upload_Records();
-	else
-		t_upload_thread.t = std::thread(Upload_Records);
-	// dense top
-	n_dense_dim = P.dense_dim;
-	n_dense_pad = n_dense_dim? dense_padded_dim(n_dense_dim) : 0;
-	std::vector<TDenseBlk> dense_blks;
-	std::vector<TDenseCol> dense_cols;
-	std::vector<int64_t> dense_blk_loff;
-	if(n_dense_dim) {
-		for(int32_t j = 0; j < P.n; ++ j) {
-			if(P.dense_pos[j] < 0)
-				continue;
-			TDenseCol dc;
-			dc.cs_new = P.cs_new[j]; dc.cs_src = P.cs_src[j]; dc.pos = P.dense_pos[j]; dc.dj = P.dim[j];
-			dense_cols.push_back(dc);
-			for(int64_t k = P.lptr[j]; k < P.lptr[j + 1]; ++ k) {
-				const int32_t i = P.lrow[k];
-				if(P.dense_pos[i] < 0)
-					throw std::logic_error("dense top is not closed upwards");
-				TDenseBlk b;
-				memset(&b, 0, sizeof(b));
-				b.asrc = (P.asrc[k] < 0)? -1 : P.asrc[k] * 2 + P.atrans[k];
-				b.p0 = P.pptr[k];
-				b.np = int32_t(P.pptr[k + 1] - P.pptr[k]);
-				b.dst = int64_t(P.dense_pos[i]) + int64_t(P.dense_pos[j]) * n_dense_pad;
-				b.di = P.dim[i]; b.dj = P.dim[j];
-				if(k == P.lptr[j]) {
-					b.r0 = P.rptr[j];
-					b.nr = int32_t(P.rptr[j + 1] - P.rptr[j]);
-					b.cs_src = P.cs_src[j];
-					b.pos = P.dense_pos[j];
-				} else
-					b.nr = -1;
-				dense_blks.push_back(b);
-				dense_blk_loff.push_back(P.loff[k]);
-			}
+	auto Fill_Scheduled = [&](int64_t i_begin, int64_t i_end) {
+		for(int64_t i = i_begin; i < i_end; ++ i) {
+			const int32_t j = P.task_cols[i];
+			TColDesc &c = cols[i];
+			memset(&c, 0, sizeof(c));
+			c.k0 = P.lptr[j];
+			c.nb = int32_t(P.lptr[j + 1] - P.lptr[j]);
+			c.dj = P.dim[j];
+			c.linv_off = P.linv_off[j];
+			c.cs_new = P.cs_new[j];
+			c.cs_src = P.cs_src[j];
+			c.r0 = P.rptr[j];
+			c.nr = int32_t(P.rptr[j + 1] - P.rptr[j]);
+			c.p0 = P.pptr[P.lptr[j] + 1]; // pairs are stored block by block: those of the sub-diagonal blocks are contiguous
+			const int64_t np = P.pptr[P.lptr[j + 1]] - c.p0;
+			c.np = int32_t(std::min<int64_t>(np, INT32_MAX));
+			Fill_Column(j);
 		}
-		d_dense_blks.Upload(dense_blks, stream);
-		d_dense_blk_loff.Upload(dense_blk_loff, stream);
-		{
-			std::vector<char> covered(n_dense_dim, 0);
-			for(size_t k = 0; k < dense_cols.size(); ++ k)
-				std::fill(covered.begin() + dense_cols[k].pos, covered.begin() + dense_cols[k].pos + dense_cols[k].dj, char(1));
-			std::vector<int32_t> gaps;
-			for(int32_t q = 0; q < n_dense_dim; ++ q) {
-				if(!covered[q])
-					gaps.push_back(q);
-			}
-			n_dense_gaps = int(gaps.size());
-			d_dense_gaps.Upload(gaps, stream);
-			// the same as a byte per position (with the padding behind the last column: tile_zero writes the identity there
-			// while it zeroes the diagonal tiles), and where every entry of the dense system's x goes in the solver's vectors
-			// (the last launch of the substitution stores there: no scatter launch)
-			std::vector<uint8_t> unit(n_dense_pad, uint8_t(1));
-			std::vector<longlong2> dst(n_dense_pad, longlong2{-1, -1});
-			for(size_t k = 0; k < dense_cols.size(); ++ k) {
-				for(int q = 0; q < dense_cols[k].dj; ++ q) {
-					unit[dense_cols[k].pos + q] = 0;
-					dst[dense_cols[k].pos + q] = longlong2{(long long)(dense_cols[k].cs_new + q), (long long)(dense_cols[k].cs_src + q)};
-				}
-			}
-			d_dense_unit.Upload(unit, stream);
-			d_dense_dst.Upload(dst, stream);
-			SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // the vectors live in this scope
+	};
+	// Round 6: the columns of the separator stages first (a tenth of the records at C3) -- the packages of their tasks, the longest
+	// single-threaded piece of the analysis, are built from those on a thread of their own while this one writes the rest
+	const int64_t n_upper_begin = (b_small || P.stage_ptr.size() < 2 || P.stage_ptr[1] - P.stage_ptr[0] <= 512)? 0 : // (few leaf tasks: they may get panel packages too)
+		 P.task_ptr[size_t(P.stage_ptr[size_t(std::min(n_bottom_stages, int(P.stage_ptr.size()) - 1))])];
+	Fill_Scheduled(n_upper_begin, n_sched);
+	auto Fill_Rest = [&]() {
+		Parallel_Ranges(n_upper_begin, 4096, Fill_Scheduled, 8);
+		for(int32_t j = 0; j < P.n; ++ j) { // (the blocks of the dense top's columns are not scheduled; their records are read all the same)
+			if(P.dense_pos[j] >= 0)
+				Fill_Column(j);
 		}
-		d_dense.Alloc(size_t(n_dense_pad) * n_dense_pad);
-		b_dense_clean = false;
-		d_dense_invdiag.Alloc(size_t(n_dense_pad / dense_NB) * dense_NB * dense_NB);
-		d_dense_z.Alloc(n_dense_pad);
-		d_dense_x.Alloc(n_dense_pad);
-		// which 64 x 64 tiles of the dense top are structurally nonzero, and how long the dependent chain is if only
-		// those are touched and independent tile columns are factored side by side
-		b_dense_tiles = false;
-		if(n_dense_top_tiles != 0) {
-			std::vector<char> nonzero;
-			const int T = dense_top_tile_pattern(P, nonzero);
-			if(T != n_dense_pad / dense_NB)
-				throw std::logic_error("dense top: tile count mismatch");
-			if(dense_tiles.Build(T, nonzero, stream)) // two launches (26 us) per tile against three (34 us) per level, and fewer tiles touched
-				b_dense_tiles = n_dense_top_tiles > 0 || 100 * dense_tiles.n_levels <= 85 * T;
-			if(b_timing) {
-				size_t n_nz = 0;
-				for(size_t k = 0; k < nonzero.size(); ++ k)
-					n_nz += nonzero[k];
-				fprintf(stderr, "[setup] dense top: %d tiles per side, %zu of %d lower tiles nonzero before fill, %d levels, "
-					"%d trsm tiles, %d update targets -> %s schedule\n", T, n_nz, T * (T + 1) / 2, dense_tiles.n_levels,
-					dense_tiles.level_trsm_ptr.empty()? 0 : dense_tiles.level_trsm_ptr.back(),
-					dense_tiles.level_tgt_ptr.empty()? 0 : dense_tiles.level_tgt_ptr.back(), b_dense_tiles? "tile" : "dense");
-			}
-		}
-	}
-	n_dense_blks = int(dense_blks.size());
-	n_dense_cols = int(dense_cols.size());
+	};
 	// panel packages for the separator stages (panel_kernel.hip): a task qualifies if its columns' blocks are one range of
 	// the factor and everything fits the kernel's LDS; the updates it receives from earlier stages go to the lists of
 	// panel_update_kernel, block by block
@@ -394,6 +248,7 @@ void slampp_hip_solver::Analyze_Sparse()
 	std::vector<TUpdEnt> upd_ents;
 	// (a second pass, without hand-ups, if a stage's hand-up list would take its workgroups past the LDS of a CU: the list
 	// rides in the dynamic LDS request on top of the task's image, and nothing else bounds its length -- advisor, round 4)
+	auto Build_Panel_Packages = [&]() {
 	for(bool b_hand_up_allowed = n_panel_handup != 0;;) {
 	panel_pkg.clear();
 	panel_off.clear();
@@ -826,6 +681,190 @@ void slampp_hip_solver::Analyze_Sparse()
 		break;
 	b_hand_up_allowed = false;
 	}
+	};
+	std::exception_ptr p_panel_error;
+	struct TJoinPanel { std::thread t; ~TJoinPanel() { if(t.joinable()) t.join(); } } t_panel_thread;
+	if(b_small)
+		Build_Panel_Packages();
+	else {
+		t_panel_thread.t = std::thread([&]() {
+			try {
+				Build_Panel_Packages();
+			} catch(...) {
+				p_panel_error = std::current_exception();
+			}
+		});
+	}
+	Fill_Rest();
+	// column packages for the upper stages (see sparse_kernels.h); the limits are those of factor_stage_kernel's staged path
+	std::vector<longlong2> pkg;
+	std::vector<int64_t> task_pkg(P.task_ptr.size() - 1, -1);
+	if(P.uniform_dim && (P.max_dim == 3 || P.max_dim == 6 || P.max_dim == 7)) {
+		const int n_stages = int(P.stage_ptr.size()) - 1;
+		// (the wide stages above the leaves and the stages near the root run the same kernel with different capacities)
+		const int n_first_stage = (n_stages > 1)? 1 : n_stages;
+		for(int t = (n_first_stage < n_stages)? P.stage_ptr[n_first_stage] : int(task_pkg.size()); t < int(task_pkg.size()); ++ t) {
+			const bool b_wide = t < P.stage_ptr[std::min(n_bottom_stages, n_stages)];
+			const int PKG_CHUNK = b_wide? int(WIDE_CHUNK) : int(UP_CHUNK), PKG_NR = b_wide? int(WIDE_NR) : int(UP_NR),
+				PKG_NP = b_wide? int(WIDE_NP) : int(UP_NP);
+			task_pkg[t] = int64_t(pkg.size());
+			for(int64_t i = P.task_ptr[t]; i < P.task_ptr[t + 1]; ++ i) {
+				const TColDesc &c = cols[i];
+				const size_t n_at = pkg.size();
+				const bool b_fits = c.nb <= PKG_CHUNK && c.nr <= PKG_NR && c.np <= PKG_NP;
+				const int ne = b_fits? c.nr + c.np : 0;
+				pkg.resize(n_at + (b_fits? package_units(c.nb, ne) : 4), longlong2{0, 0});
+				memcpy(&pkg[n_at], &c, sizeof(TColDesc));
+				if(!b_fits)
+					continue;
+				memcpy(&pkg[n_at + 4], &blks[c.k0], size_t(c.nb) * sizeof(TBlkDesc));
+				longlong2 *p_ent = &pkg[n_at + 4 + 2 * c.nb];
+				int32_t *p_ycs = reinterpret_cast<int32_t*>(p_ent + ne);
+				unsigned char *p_tag = reinterpret_cast<unsigned char*>(p_ent + ne + (ne + 3) / 4);
+				for(int e = 0; e < c.nr; ++ e) { // row entries of the diagonal block: both operands are the block L(j,c)
+					p_ent[e] = longlong2{rents[c.r0 + e].off, rents[c.r0 + e].off};
+					p_ycs[e] = rents[c.r0 + e].ycs;
+					p_tag[e] = 0;
+				}
+				for(int e = 0; e < c.np; ++ e) {
+					const longlong2 pr = pairs[c.p0 + e];
+					p_ent[c.nr + e] = longlong2{pr.x & ((int64_t(1) << 48) - 1), pr.y};
+					p_tag[c.nr + e] = (unsigned char)((pr.x >> 48) & 0xff);
+				}
+			}
+		}
+		pkg.resize(pkg.size() + PKG_SPECULATIVE, longlong2{0, 0});
+	}
+	SETUP_PHASE("records");
+	// the records go to the device beside the host work that follows (the packages of the separator tasks: ~10 ms each at C3,
+	// and an upload from a std::vector is a staged copy that keeps its thread): a thread of its own, joined before the rest
+	// of the uploads.  The vectors it reads are not written from here on.
+	std::exception_ptr p_upload_error;
+	struct TJoinUpload { std::thread t; ~TJoinUpload() { if(t.joinable()) t.join(); } } t_upload_thread;
+	auto Upload_Records = [&]() {
+		try {
+			SLAMPP_HIP_CHECK(hipSetDevice(n_device));
+			d_cols.Upload(cols, stream);
+			d_blks.Upload(blks, stream);
+			d_pairs.Upload(pairs, stream);
+			d_rents.Upload(rents, stream);
+			d_task_ptr.Upload(P.task_ptr, stream);
+			if(!pkg.empty()) {
+				d_pkg.Upload(pkg, stream);
+				d_task_pkg.Upload(task_pkg, stream);
+			} else {
+				d_pkg.Free();
+				d_task_pkg.Free();
+			}
+		} catch(...) {
+			p_upload_error = std::current_exception();
+		}
+	};
+	if(b_small)
+		Upload_Records();
+	else
+		t_upload_thread.t = std::thread(Upload_Records);
+	// dense top
+	n_dense_dim = P.dense_dim;
+	n_dense_pad = n_dense_dim? dense_padded_dim(n_dense_dim) : 0;
+	std::vector<TDenseBlk> dense_blks;
+	std::vector<TDenseCol> dense_cols;
+	std::vector<int64_t> dense_blk_loff;
+	if(n_dense_dim) {
+		for(int32_t j = 0; j < P.n; ++ j) {
+			if(P.dense_pos[j] < 0)
+				continue;
+			TDenseCol dc;
+			dc.cs_new = P.cs_new[j]; dc.cs_src = P.cs_src[j]; dc.pos = P.dense_pos[j]; dc.dj = P.dim[j];
+			dense_cols.push_back(dc);
+			for(int64_t k = P.lptr[j]; k < P.lptr[j + 1]; ++ k) {
+				const int32_t i = P.lrow[k];
+				if(P.dense_pos[i] < 0)
+					throw std::logic_error("dense top is not closed upwards");
+				TDenseBlk b;
+				memset(&b, 0, sizeof(b));
+				b.asrc = (P.asrc[k] < 0)? -1 : P.asrc[k] * 2 + P.atrans[k];
+				b.p0 = P.pptr[k];
+				b.np = int32_t(P.pptr[k + 1] - P.pptr[k]);
+				b.dst = int64_t(P.dense_pos[i]) + int64_t(P.dense_pos[j]) * n_dense_pad;
+				b.di = P.dim[i]; b.dj = P.dim[j];
+				if(k == P.lptr[j]) {
+					b.r0 = P.rptr[j];
+					b.nr = int32_t(P.rptr[j + 1] - P.rptr[j]);
+					b.cs_src = P.cs_src[j];
+					b.pos = P.dense_pos[j];
+				} else
+					b.nr = -1;
+				dense_blks.push_back(b);
+				dense_blk_loff.push_back(P.loff[k]);
+			}
+		}
+		SETUP_PHASE("dense records");
+		d_dense_blks.Upload(dense_blks, stream);
+		d_dense_blk_loff.Upload(dense_blk_loff, stream);
+		SETUP_PHASE("dense upload 1");
+		{
+			std::vector<char> covered(n_dense_dim, 0);
+			for(size_t k = 0; k < dense_cols.size(); ++ k)
+				std::fill(covered.begin() + dense_cols[k].pos, covered.begin() + dense_cols[k].pos + dense_cols[k].dj, char(1));
+			std::vector<int32_t> gaps;
+			for(int32_t q = 0; q < n_dense_dim; ++ q) {
+				if(!covered[q])
+					gaps.push_back(q);
+			}
+			n_dense_gaps = int(gaps.size());
+			d_dense_gaps.Upload(gaps, stream);
+			// the same as a byte per position (with the padding behind the last column: tile_zero writes the identity there
+			// while it zeroes the diagonal tiles), and where every entry of the dense system's x goes in the solver's vectors
+			// (the last launch of the substitution stores there: no scatter launch)
+			std::vector<uint8_t> unit(n_dense_pad, uint8_t(1));
+			std::vector<longlong2> dst(n_dense_pad, longlong2{-1, -1});
+			for(size_t k = 0; k < dense_cols.size(); ++ k) {
+				for(int q = 0; q < dense_cols[k].dj; ++ q) {
+					unit[dense_cols[k].pos + q] = 0;
+					dst[dense_cols[k].pos + q] = longlong2{(long long)(dense_cols[k].cs_new + q), (long long)(dense_cols[k].cs_src + q)};
+				}
+			}
+			d_dense_unit.Upload(unit, stream);
+			d_dense_dst.Upload(dst, stream);
+			SETUP_PHASE("dense upload 2");
+			SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // the vectors live in this scope
+		}
+		SETUP_PHASE("dense lists");
+		d_dense.Alloc(size_t(n_dense_pad) * n_dense_pad);
+		b_dense_clean = false;
+		d_dense_invdiag.Alloc(size_t(n_dense_pad / dense_NB) * dense_NB * dense_NB);
+		d_dense_z.Alloc(n_dense_pad);
+		d_dense_x.Alloc(n_dense_pad);
+		SETUP_PHASE("dense allocs");
+		// which 64 x 64 tiles of the dense top are structurally nonzero, and how long the dependent chain is if only
+		// those are touched and independent tile columns are factored side by side
+		b_dense_tiles = false;
+		if(n_dense_top_tiles != 0) {
+			std::vector<char> nonzero;
+			const int T = dense_top_tile_pattern(P, nonzero);
+			if(T != n_dense_pad / dense_NB)
+				throw std::logic_error("dense top: tile count mismatch");
+			if(dense_tiles.Build(T, nonzero, stream)) // two launches (26 us) per tile against three (34 us) per level, and fewer tiles touched
+				b_dense_tiles = n_dense_top_tiles > 0 || 100 * dense_tiles.n_levels <= 85 * T;
+			if(b_timing) {
+				size_t n_nz = 0;
+				for(size_t k = 0; k < nonzero.size(); ++ k)
+					n_nz += nonzero[k];
+				fprintf(stderr, "[setup] dense top: %d tiles per side, %zu of %d lower tiles nonzero before fill, %d levels, "
+					"%d trsm tiles, %d update targets -> %s schedule\n", T, n_nz, T * (T + 1) / 2, dense_tiles.n_levels,
+					dense_tiles.level_trsm_ptr.empty()? 0 : dense_tiles.level_trsm_ptr.back(),
+					dense_tiles.level_tgt_ptr.empty()? 0 : dense_tiles.level_tgt_ptr.back(), b_dense_tiles? "tile" : "dense");
+			}
+		}
+	}
+	n_dense_blks = int(dense_blks.size());
+	n_dense_cols = int(dense_cols.size());
+	SETUP_PHASE("tile schedule");
+	if(t_panel_thread.t.joinable())
+		t_panel_thread.t.join();
+	if(p_panel_error)
+		std::rethrow_exception(p_panel_error);
 	SETUP_PHASE("packages");
 	d_panel_upd_slots.Upload(upd_slots, stream);
 	d_panel_upd_ents.Upload(upd_ents, stream);
@@ -901,82 +940,132 @@ void slampp_hip_solver::Build_Simt()
 	std::vector<TSimtChunk> &chunks = simt_host_chunks;
 	std::vector<int32_t> &prog_all = simt_host_prog, &rest = simt_host_rest;
 	std::vector<int64_t> &tab = simt_host_tab;
-	struct TTask { int32_t n_task; std::vector<int32_t> ops; std::vector<int32_t> ys; };
-	std::vector<int32_t> op_index(P.lrow.size(), -1), y_index(size_t(P.n), -1);
+	// Round 6: the tasks' programs on several threads (a task's program depends on nothing but the plan), the shapes told
+	// apart by a hash of the program with one full comparison per task against its shape's first member instead of a
+	// std::map keyed by the programs (16 000 insertions of 200-word keys at C3), the tables of a shape's chunks on several
+	// threads again.  Shapes, chunks and tables come out in the order the map gave them (programs in lexicographic order,
+	// the tasks of a shape ascending).
+	struct TTask { int32_t n_task; bool b_fits; uint64_t n_hash; std::vector<int32_t> prog, ops, ys; };
 	simt_chunk_ptr.push_back(0);
 	simt_rest_ptr.push_back(0);
 	const size_t W = size_t(n_simt_width);
 	for(int s = 0; s < n_bottom_stages && s < n_stages && s < n_simt_stages; ++ s) {
-		std::map<std::vector<int32_t>, std::vector<TTask> > groups;
-		int32_t n_stage_lds = 0, n_stage_bwd_lds = 0;
-		for(int32_t t = P.stage_ptr[s]; t < P.stage_ptr[s + 1]; ++ t) {
-			std::vector<int32_t> prog(4, 0);
-			TTask tt;
-			tt.n_task = t;
-			int32_t n_blocks = 0;
-			bool b_fits = true;
-			auto op_of = [&](int32_t n_blk) {
-				if(op_index[n_blk] < 0) {
-					op_index[n_blk] = int32_t(tt.ops.size());
-					tt.ops.push_back(n_blk);
-				}
-				return op_index[n_blk];
-			};
-			for(int64_t i = P.task_ptr[t]; i < P.task_ptr[t + 1] && b_fits; ++ i) {
-				const int32_t j = P.task_cols[i];
-				const int32_t nb = int32_t(P.lptr[j + 1] - P.lptr[j]), nr = int32_t(P.rptr[j + 1] - P.rptr[j]);
-				prog.push_back(nb);
-				prog.push_back(nr);
-				const size_t n_touch_at = prog.size();
-				prog.push_back(0); // number of distinct operands of the column, then their indices
-				n_blocks += nb;
-				std::vector<int32_t> touch, body;
-				auto touch_op = [&](int32_t n_op) {
-					if(std::find(touch.begin(), touch.end(), n_op) == touch.end())
-						touch.push_back(n_op);
-					return n_op;
+		const int32_t t0 = P.stage_ptr[s], n_stage_tasks = P.stage_ptr[s + 1] - P.stage_ptr[s];
+		const bool b_simt_timing = getenv("SLAMPP_HIP_PLAN_TIMING") != 0;
+		double t_simt_phase = wall_ms();
+		auto Simt_Phase = [&](const char *p_s_name) { if(b_simt_timing) { const double t_ = wall_ms();
+			fprintf(stderr, "[shapes] stage %d %-12s %8.2f ms\n", s, p_s_name, t_ - t_simt_phase); t_simt_phase = t_; } };
+		std::vector<TTask> tasks_all(size_t(std::max(n_stage_tasks, 0)));
+		Parallel_Ranges(n_stage_tasks, 512, [&](int64_t n_b, int64_t n_e) {
+			std::vector<int32_t> op_index(P.lrow.size(), -1), y_index(size_t(P.n), -1); // (per thread: a few MB, written once)
+			std::vector<int32_t> touch, body;
+			for(int64_t n_i = n_b; n_i < n_e; ++ n_i) {
+				const int32_t t = t0 + int32_t(n_i);
+				TTask &tt = tasks_all[size_t(n_i)];
+				std::vector<int32_t> &prog = tt.prog;
+				prog.assign(4, 0);
+				tt.n_task = t;
+				int32_t n_blocks = 0;
+				bool b_fits = true;
+				auto op_of = [&](int32_t n_blk) {
+					if(op_index[n_blk] < 0) {
+						op_index[n_blk] = int32_t(tt.ops.size());
+						tt.ops.push_back(n_blk);
+					}
+					return op_index[n_blk];
 				};
-				for(int64_t e = P.rptr[j]; e < P.rptr[j + 1]; ++ e) {
-					const int32_t n_blk = P.rblk[e], c = P.blk_col[n_blk];
-					if(y_index[c] < 0) {
-						y_index[c] = int32_t(tt.ys.size());
-						tt.ys.push_back(c);
+				for(int64_t i = P.task_ptr[t]; i < P.task_ptr[t + 1] && b_fits; ++ i) {
+					const int32_t j = P.task_cols[i];
+					const int32_t nb = int32_t(P.lptr[j + 1] - P.lptr[j]), nr = int32_t(P.rptr[j + 1] - P.rptr[j]);
+					prog.push_back(nb);
+					prog.push_back(nr);
+					const size_t n_touch_at = prog.size();
+					prog.push_back(0); // number of distinct operands of the column, then their indices
+					n_blocks += nb;
+					touch.clear();
+					body.clear();
+					auto touch_op = [&](int32_t n_op) {
+						if(std::find(touch.begin(), touch.end(), n_op) == touch.end())
+							touch.push_back(n_op);
+						return n_op;
+					};
+					for(int64_t e = P.rptr[j]; e < P.rptr[j + 1]; ++ e) {
+						const int32_t n_blk = P.rblk[e], c = P.blk_col[n_blk];
+						if(y_index[c] < 0) {
+							y_index[c] = int32_t(tt.ys.size());
+							tt.ys.push_back(c);
+						}
+						body.push_back(touch_op(op_of(n_blk)));
+						body.push_back(y_index[c]);
 					}
-					body.push_back(touch_op(op_of(n_blk)));
-					body.push_back(y_index[c]);
-				}
-				for(int64_t k = P.lptr[j] + 1; k < P.lptr[j + 1]; ++ k) {
-					body.push_back(int32_t(P.pptr[k + 1] - P.pptr[k]));
-					for(int64_t e = P.pptr[k]; e < P.pptr[k + 1]; ++ e) {
-						body.push_back(touch_op(op_of(P.pa[e])));
-						body.push_back(touch_op(op_of(P.pb[e])));
+					for(int64_t k = P.lptr[j] + 1; k < P.lptr[j + 1]; ++ k) {
+						body.push_back(int32_t(P.pptr[k + 1] - P.pptr[k]));
+						for(int64_t e = P.pptr[k]; e < P.pptr[k + 1]; ++ e) {
+							body.push_back(touch_op(op_of(P.pa[e])));
+							body.push_back(touch_op(op_of(P.pb[e])));
+						}
 					}
+					prog[n_touch_at] = int32_t(touch.size());
+					prog.insert(prog.end(), touch.begin(), touch.end());
+					prog.insert(prog.end(), body.begin(), body.end());
+					b_fits = prog.size() <= MAX_PROG;
 				}
-				prog[n_touch_at] = int32_t(touch.size());
-				prog.insert(prog.end(), touch.begin(), touch.end());
-				prog.insert(prog.end(), body.begin(), body.end());
-				b_fits = prog.size() <= MAX_PROG;
+				for(size_t k = 0; k < tt.ops.size(); ++ k)
+					op_index[tt.ops[k]] = -1;
+				for(size_t k = 0; k < tt.ys.size(); ++ k)
+					y_index[tt.ys[k]] = -1;
+				const int32_t n_cols = int32_t(P.task_ptr[t + 1] - P.task_ptr[t]);
+				prog[0] = n_cols;
+				prog[1] = n_blocks;
+				prog[2] = int32_t(tt.ops.size());
+				prog[3] = int32_t(tt.ys.size());
+				tt.b_fits = b_fits && size_t(4 * n_cols + n_blocks) + tt.ops.size() + tt.ys.size() <= MAX_TABLE_BYTES / (8 * W); // (the table is staged in LDS)
+				uint64_t h = 0x9e3779b97f4a7c15ull ^ prog.size();
+				for(size_t k = 0; k < prog.size(); ++ k) {
+					h ^= uint64_t(uint32_t(prog[k])) + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+					h *= 0xff51afd7ed558ccdull;
+				}
+				tt.n_hash = h;
 			}
-			for(size_t k = 0; k < tt.ops.size(); ++ k)
-				op_index[tt.ops[k]] = -1;
-			for(size_t k = 0; k < tt.ys.size(); ++ k)
-				y_index[tt.ys[k]] = -1;
-			const int32_t n_cols = int32_t(P.task_ptr[t + 1] - P.task_ptr[t]);
-			prog[0] = n_cols;
-			prog[1] = n_blocks;
-			prog[2] = int32_t(tt.ops.size());
-			prog[3] = int32_t(tt.ys.size());
-			if(!b_fits || size_t(4 * n_cols + n_blocks) + tt.ops.size() + tt.ys.size() > MAX_TABLE_BYTES / (8 * W)) // (the table is staged in LDS)
-				rest.push_back(t);
-			else
-				groups[prog].push_back(std::move(tt));
-		}
-		for(auto &r_group : groups) {
-			const std::vector<int32_t> &prog = r_group.first;
-			std::vector<TTask> &tasks = r_group.second;
-			if(tasks.size() < MIN_GROUP) {
-				for(const TTask &tt : tasks)
+		}, 8);
+		Simt_Phase("programs");
+		// shapes: tasks of one hash whose programs are the same (compared in full against the shape's first task)
+		std::vector<std::vector<int32_t> > groups; // indices into tasks_all, ascending
+		{
+			std::unordered_map<uint64_t, std::vector<int32_t> > by_hash; // hash -> the shapes that have it
+			for(int32_t n_i = 0; n_i < n_stage_tasks; ++ n_i) {
+				const TTask &tt = tasks_all[size_t(n_i)];
+				if(!tt.b_fits) {
 					rest.push_back(tt.n_task);
+					continue;
+				}
+				std::vector<int32_t> &r_shapes = by_hash[tt.n_hash];
+				int32_t n_group = -1;
+				for(size_t k = 0; k < r_shapes.size() && n_group < 0; ++ k) {
+					if(tasks_all[size_t(groups[size_t(r_shapes[k])][0])].prog == tt.prog)
+						n_group = r_shapes[k];
+				}
+				if(n_group < 0) {
+					n_group = int32_t(groups.size());
+					groups.push_back(std::vector<int32_t>());
+					r_shapes.push_back(n_group);
+				}
+				groups[size_t(n_group)].push_back(n_i);
+			}
+			std::sort(groups.begin(), groups.end(), [&](const std::vector<int32_t> &r_a, const std::vector<int32_t> &r_b) {
+				return tasks_all[size_t(r_a[0])].prog < tasks_all[size_t(r_b[0])].prog; });
+		}
+		Simt_Phase("grouping");
+		// where every shape's program, chunks and tables go
+		struct TChunkJob { int32_t n_group; size_t n_first; int n_fields, n_bwd_fields; int64_t n_tab_off, n_bwd_tab_off; };
+		std::vector<TChunkJob> jobs;
+		int32_t n_stage_lds = 0, n_stage_bwd_lds = 0;
+		for(size_t g = 0; g < groups.size(); ++ g) {
+			const std::vector<int32_t> &r_members = groups[g];
+			const std::vector<int32_t> &prog = tasks_all[size_t(r_members[0])].prog;
+			if(r_members.size() < MIN_GROUP) {
+				for(int32_t n_i : r_members)
+					rest.push_back(tasks_all[size_t(n_i)].n_task);
 				continue;
 			}
 			const int32_t n_prog_off = int32_t(prog_all.size());
@@ -991,21 +1080,38 @@ void slampp_hip_solver::Build_Simt()
 			simt_host_bwd_prog.push_back(n_cols);
 			simt_host_bwd_prog.push_back(n_blocks - n_cols);
 			{
-				const TTask &tt = tasks[0];
+				const TTask &tt = tasks_all[size_t(r_members[0])];
 				for(int64_t i = P.task_ptr[tt.n_task]; i < P.task_ptr[tt.n_task + 1]; ++ i)
 					simt_host_bwd_prog.push_back(int32_t(P.lptr[P.task_cols[i] + 1] - P.lptr[P.task_cols[i]]));
 			}
-			for(size_t n_first = 0; n_first < tasks.size(); n_first += W) {
-				const size_t n_in_chunk = std::min<size_t>(W, tasks.size() - n_first);
+			for(size_t n_first = 0; n_first < r_members.size(); n_first += W) {
+				const size_t n_in_chunk = std::min<size_t>(W, r_members.size() - n_first);
 				TSimtChunk ch;
 				ch.prog_off = n_prog_off;
 				ch.n_tasks = int32_t(n_in_chunk);
 				ch.tab_off = int64_t(tab.size());
 				chunks.push_back(ch);
+				TSimtChunk ch_bwd;
+				ch_bwd.prog_off = n_bwd_prog_off;
+				ch_bwd.n_tasks = int32_t(n_in_chunk);
+				ch_bwd.tab_off = int64_t(simt_host_bwd_tab.size());
+				simt_host_bwd_chunks.push_back(ch_bwd);
+				TChunkJob t_job = {int32_t(g), n_first, n_fields, n_bwd_fields, ch.tab_off, ch_bwd.tab_off};
+				jobs.push_back(t_job);
 				tab.resize(tab.size() + size_t(n_fields) * W);
-				int64_t *p_tab = &tab[size_t(ch.tab_off)];
+				simt_host_bwd_tab.resize(simt_host_bwd_tab.size() + size_t(n_bwd_fields) * W);
+			}
+		}
+		Simt_Phase("layout");
+		Parallel_Ranges(int64_t(jobs.size()), 32, [&](int64_t n_b, int64_t n_e) {
+			for(int64_t n_job = n_b; n_job < n_e; ++ n_job) {
+				const TChunkJob &r_job = jobs[size_t(n_job)];
+				const std::vector<int32_t> &r_members = groups[size_t(r_job.n_group)];
+				const size_t n_first = r_job.n_first, n_in_chunk = std::min<size_t>(W, r_members.size() - n_first);
+				const int n_fields = r_job.n_fields, n_bwd_fields = r_job.n_bwd_fields;
+				int64_t *p_tab = &tab[size_t(r_job.n_tab_off)];
 				for(int n_lane = 0; n_lane < int(W); ++ n_lane) {
-					const TTask &tt = tasks[n_first + std::min<size_t>(n_lane, n_in_chunk - 1)]; // spare lanes repeat the last task
+					const TTask &tt = tasks_all[size_t(r_members[n_first + std::min<size_t>(n_lane, n_in_chunk - 1)])]; // spare lanes repeat the last task
 					int f = 0;
 					for(int64_t i = P.task_ptr[tt.n_task]; i < P.task_ptr[tt.n_task + 1]; ++ i) {
 						const int32_t j = P.task_cols[i];
@@ -1026,15 +1132,9 @@ void slampp_hip_solver::Build_Simt()
 					if(f != n_fields)
 						throw std::logic_error("lane-per-task tables: field count mismatch");
 				}
-				TSimtChunk ch_bwd;
-				ch_bwd.prog_off = n_bwd_prog_off;
-				ch_bwd.n_tasks = int32_t(n_in_chunk);
-				ch_bwd.tab_off = int64_t(simt_host_bwd_tab.size());
-				simt_host_bwd_chunks.push_back(ch_bwd);
-				simt_host_bwd_tab.resize(simt_host_bwd_tab.size() + size_t(n_bwd_fields) * W);
-				int64_t *p_bwd = &simt_host_bwd_tab[size_t(ch_bwd.tab_off)];
+				int64_t *p_bwd = &simt_host_bwd_tab[size_t(r_job.n_bwd_tab_off)];
 				for(int n_lane = 0; n_lane < int(W); ++ n_lane) {
-					const TTask &tt = tasks[n_first + std::min<size_t>(n_lane, n_in_chunk - 1)];
+					const TTask &tt = tasks_all[size_t(r_members[n_first + std::min<size_t>(n_lane, n_in_chunk - 1)])];
 					int f = 0;
 					for(int64_t i = P.task_ptr[tt.n_task]; i < P.task_ptr[tt.n_task + 1]; ++ i) {
 						const int32_t j = P.task_cols[i];
@@ -1054,7 +1154,8 @@ void slampp_hip_solver::Build_Simt()
 						throw std::logic_error("lane-per-task tables: backward field count mismatch");
 				}
 			}
-		}
+		}, 8);
+		Simt_Phase("tables");
 		std::sort(rest.begin() + simt_rest_ptr.back(), rest.end());
 		simt_chunk_ptr.push_back(int32_t(chunks.size()));
 		simt_rest_ptr.push_back(int32_t(rest.size()));
