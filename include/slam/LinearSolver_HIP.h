@@ -41,6 +41,9 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#if defined(__x86_64__) && defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #ifdef _OPENMP
 #include <omp.h>
 #endif // _OPENMP
@@ -83,6 +86,23 @@ protected:
 #else // _OPENMP
 		return 1;
 #endif // _OPENMP
+	}
+
+	/**
+	 *	@brief copies n doubles to the staging without bringing the destination into the caches (x86-64: movnti)
+	 */
+	static inline void Copy_Streaming(double *p_dest, const double *p_src, int n)
+	{
+#if defined(__x86_64__) && defined(__SSE2__)
+		for(int i = 0; i < n; ++ i) {
+			long long n_bits;
+			memcpy(&n_bits, p_src + i, sizeof(n_bits));
+			_mm_stream_si64(reinterpret_cast<long long*>(p_dest + i), n_bits);
+		}
+#else
+		for(int i = 0; i < n; ++ i)
+			p_dest[i] = p_src[i];
+#endif
 	}
 
 	static double f_Wall_Ms()
@@ -336,6 +356,7 @@ protected:
 				n_last = n_lo;
 			}
 			int n_mismatch = 0;
+			const long n_prefetch_distance = 8;
 			#pragma omp parallel for schedule(static) reduction(+:n_mismatch) num_threads(n_thread_num) if(n_block_num >= 16384 && n_last - n_first > 512)
 			for(long k = n_first; k < n_last; ++ k) {
 				const TGatherEntry &t = m_gather[k];
@@ -346,15 +367,26 @@ protected:
 				CUberBlockMatrix::_TyConstMatrixXdRef block = r_lambda.t_Block_AtColumn(t.n_col, t.n_blk);
 				const double *p_src = block.data();
 				double *p_dest = p_values + t.n_dest;
+				// (round 6: the blocks live in pool pages, a few cache lines each at addresses the hardware prefetcher cannot
+				// guess: the block eight entries on is requested while this one is copied; the staging is written with
+				// streaming stores -- it is read next by the DMA engine, not by this core)
+				if(k + n_prefetch_distance < n_last) {
+					const TGatherEntry &t_ahead = m_gather[k + n_prefetch_distance];
+					const char *p_ahead = reinterpret_cast<const char*>(r_lambda.t_Block_AtColumn(t_ahead.n_col, t_ahead.n_blk).data());
+					for(int n_byte = 0, n_bytes = t_ahead.n_rows * t_ahead.n_cols * int(sizeof(double)); n_byte < n_bytes; n_byte += 64)
+						__builtin_prefetch(p_ahead + n_byte, 0, 0);
+				}
 				if(!t.b_transpose) {
-					for(int i = 0, m = t.n_rows * t.n_cols; i < m; ++ i)
-						p_dest[i] = p_src[i];
+					Copy_Streaming(p_dest, p_src, t.n_rows * t.n_cols);
 				} else {
 					for(int c = 0; c < t.n_cols; ++ c)
 						for(int r = 0; r < t.n_rows; ++ r)
 							p_dest[c + r * t.n_cols] = p_src[r + c * t.n_rows]; // dest is n_cols x n_rows
 				}
 			}
+#if defined(__x86_64__) && defined(__SSE2__)
+			_mm_sfence(); // (the streaming stores of this thread; the team's threads passed the loop's barrier)
+#endif
 			if(n_mismatch) {
 				Throw_On_Error(slampp_hip_upload_values_async(m_p_solver, 0, 0)); // (forget the chunks sent so far)
 				return false;
