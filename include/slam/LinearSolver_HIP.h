@@ -639,7 +639,7 @@ public:
 class CLinearSolver_HIP_Factorizer : public CLinearSolver_HIP_Base {
 public:
 	/**
-	 *	@brief where the time of Factorize() goes, summed over the calls of the process (all instances: the nonlinear
+	 *	@brief where the time of Factorize() goes, summed over the calls of the calling thread (all its instances: the nonlinear
 	 *		solvers work on copies of the solver they are given): the analysis of a new structure (ordering is the
 	 *		caller's; symbolic factorization, schedule, uploads of the plan), the gather of lambda's blocks, the library
 	 *		call (values up, numeric factorization, factor down), and the scatter of the factor into r_factor
@@ -648,7 +648,7 @@ public:
 		size_t n_calls, n_analyses;
 		double f_analyze_ms, f_gather_ms, f_factorize_ms, f_scatter_ms;
 	};
-	static TTimes &t_Times() { static TTimes t = {0, 0, 0, 0, 0, 0}; return t; }
+	static TTimes &t_Times() { static thread_local TTimes t = {0, 0, 0, 0, 0, 0}; return t; } /**< @brief per calling thread: solvers used from several threads do not share counters (advisor, round 5) */
 
 protected:
 	std::vector<int32_t> m_l_perm, m_l_dim, m_l_row; /**< @brief structure of the factor (slampp_hip_plan_view) */

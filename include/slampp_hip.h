@@ -304,7 +304,11 @@ int slampp_hip_sync(slampp_hip_solver *p_solver);
  * (NonlinearSolver_Lambda_LM.h:967-1001, 1660-1676); SURVEY section 8(e): pose graphs do not shard, "replicas only
  * (multiple independent problems / damping values per GPU)".  slampp_hip_sync_batch waits and reports per member:
  * p_status[k] = SLAMPP_HIP_OK or SLAMPP_HIP_NOT_POSDEF (a member that is not positive definite does not disturb the
- * others).  The handle's own factor (slampp_hip_solve_again, covariances) is not touched by a batch of more than one. */
+ * others).  The handle's own factor (slampp_hip_solve_again, covariances) is not touched by a batch of more than one that
+ * shares launches.  A batch that is solved member by member (a dense top, regrouped block columns, unaligned bases or odd
+ * strides) goes through the handle's factor arrays: after more than one such member the handle has NO factor of its own
+ * (slampp_hip_solve_again and the covariance calls return SLAMPP_HIP_ERR_INVALID until the next factorization); a batch of
+ * one is an ordinary factorization, and its factor is dropped if slampp_hip_sync_batch reports the member not positive definite. */
 #define SLAMPP_HIP_MAX_BATCH 64
 int slampp_hip_factor_solve_batch_device_async(slampp_hip_solver *p_solver, int n_batch, const double *p_values_dev,
 	int64_t n_values_stride, double *p_rhs_inout_dev, int64_t n_rhs_stride);

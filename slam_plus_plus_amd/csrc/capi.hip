@@ -94,6 +94,7 @@ static void abort_trace_install() // strictly opt-in, once per process
 
 int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id)
 {
+	(void)dev_knobs_refresh(); // (the development switch, plan.h: read on the cold path, remembered for the warm one)
 	if(!pp_solver)
 		return SLAMPP_HIP_ERR_INVALID;
 	*pp_solver = 0;
@@ -118,6 +119,7 @@ int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id)
 
 int slampp_hip_create_multi(slampp_hip_solver **pp_solver, const int *p_device_ids, int n_devices)
 {
+	(void)dev_knobs_refresh(); // (the development switch, plan.h: read on the cold path, remembered for the warm one)
 	if(!pp_solver || !p_device_ids || n_devices < 1)
 		return SLAMPP_HIP_ERR_INVALID;
 	const int n_result = slampp_hip_create(pp_solver, p_device_ids[0]);
@@ -325,6 +327,7 @@ static int set_option_checked(slampp_hip_solver *p_solver, const char *p_s_name,
 
 int slampp_hip_set_option(slampp_hip_solver *p_solver, const char *p_s_name, int64_t n_value)
 {
+	(void)dev_knobs_refresh(); // (the development switch, plan.h: read on the cold path, remembered for the warm one)
 	const int n_result = set_option_checked(p_solver, p_s_name, n_value);
 	// recorded for members that do not exist yet -- only once the handle has accepted it: a refused option that was
 	// recorded anyway would be replayed into the group at the first Schur-mode analysis and fail every analysis after it
@@ -352,6 +355,7 @@ int slampp_hip_group_exchange_count(const slampp_hip_solver *p_solver, int64_t *
 int slampp_hip_set_structure(slampp_hip_solver *p_solver, int64_t n_bcols, const int64_t *p_bcol_cumsum,
 	const int64_t *p_bcol_ptr, const int32_t *p_brow_idx)
 {
+	(void)dev_knobs_refresh();
 	return guarded(p_solver, [&]() -> int {
 		if(n_bcols <= 0 || !p_bcol_cumsum || !p_bcol_ptr || (p_bcol_ptr[n_bcols] > 0 && !p_brow_idx))
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "set_structure: null or empty structure");
@@ -427,6 +431,7 @@ int slampp_hip_apply_damping_device_async(slampp_hip_solver *p_solver, double *p
 
 int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix_cut)
 {
+	(void)dev_knobs_refresh();
 	return guarded(p_solver, [&]() -> int {
 		slampp_hip_solver &s = *p_solver;
 		if(!s.b_has_structure)
@@ -606,7 +611,15 @@ int slampp_hip_factor_solve_batch_device_async(slampp_hip_solver *p_solver, int 
 				s.Enqueue_Sparse(p_values_dev + int64_t(k) * n_values_stride, p_rhs_inout_dev + int64_t(k) * n_rhs_stride, true);
 			}
 			s.p_flag_shared = p_flag_before;
-			s.b_factored = true; // (the last member's factor is the one kept)
+			// The members went through the handle's own factor arrays (and its dense top), one after the other.  A batch of one is
+			// an ordinary factorization that answers through the batch flags: its factor is the handle's, valid unless sync_batch
+			// finds the member not positive definite.  After more than one member the handle holds the last member's factor where
+			// the header promises "not touched": it is declared gone -- slampp_hip_solve_again and the covariance calls refuse
+			// until the next factorization -- rather than passed off as the handle's own (advisor, round 5).
+			s.b_factored = n_batch == 1;
+			s.n_batch_owner_member = (n_batch == 1)? 0 : -1;
+			if(n_batch > 1)
+				schur_invalidate_previous(s.p_schur);
 			return SLAMPP_HIP_OK;
 		}
 		auto Round = [](size_t n) { return (n + 31) / 32 * 32; }; // (256 bytes: every member's base is aligned like the first)
@@ -655,6 +668,11 @@ int slampp_hip_sync_batch(slampp_hip_solver *p_solver, int *p_status, int n_batc
 			p_status[k] = (s.p_host_batch_flag && s.d_batch_flag.p() && s.p_host_batch_flag[k])? SLAMPP_HIP_NOT_POSDEF : SLAMPP_HIP_OK;
 			b_any = b_any || p_status[k] != SLAMPP_HIP_OK;
 		}
+		if(s.n_batch_owner_member >= 0 && s.p_host_batch_flag && s.d_batch_flag.p() && s.p_host_batch_flag[s.n_batch_owner_member]) {
+			s.b_factored = false; // the member whose factor the handle kept failed: there is nothing to solve again from
+			schur_invalidate_previous(s.p_schur);
+		}
+		s.n_batch_owner_member = -1;
 		if(b_any || s.n_batch_pending > n_batch) // (answered for: the next batch starts clean)
 			SLAMPP_HIP_CHECK(hipMemsetAsync(s.d_batch_flag.p(), 0, SLAMPP_HIP_MAX_BATCH * sizeof(int), s.stream));
 		s.n_batch_pending = 0;
@@ -1414,6 +1432,7 @@ struct slampp_hip_plan {
 int slampp_hip_plan_create(slampp_hip_plan **pp_plan, int64_t n_bcols, const int64_t *p_bcol_cumsum,
 	const int64_t *p_bcol_ptr, const int32_t *p_brow_idx, int n_leaf_size, int n_subtree_size, int n_dense_top_nb)
 {
+	(void)dev_knobs_refresh();
 	if(!pp_plan || !p_bcol_cumsum || !p_bcol_ptr || !p_brow_idx)
 		return SLAMPP_HIP_ERR_INVALID;
 	*pp_plan = 0;

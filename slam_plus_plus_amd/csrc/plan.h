@@ -4,6 +4,7 @@
 // (/root/reference/include/slam/LinearSolver_UberBlock.h:285-310) while its CHOLMOD wrapper
 // orders the 6x larger scalar graph (/root/reference/src/slam/LinearSolver_CholMod.cpp:294-300).
 #pragma once
+#include <atomic>
 #include <cstdlib>
 #include <cstdint>
 #include <string>
@@ -13,9 +14,24 @@ namespace slampp {
 
 // Development knobs: integers read from the environment, and only when SLAMPP_HIP_DEV=1 is set there as well -- the
 // environment of the host application must not be able to change the ordering or the plan of every handle by accident
-// (until round 5 some of these were plain names: ND_MIN, ND_SEP).  Read at every use, never cached: the tools that sweep
-// them set them between two analyses of one process.
-inline bool dev_knobs_on() { const char *p = getenv("SLAMPP_HIP_DEV"); return p && atoi(p) != 0; }
+// (until round 5 some of these were plain names: ND_MIN, ND_SEP).  Whether the knobs are on at all is read from the
+// environment where a handle is created, configured or analyzed (dev_knobs_refresh(): the cold path) and remembered: the
+// launch helpers of the warm path ask dev_knob() at every factorization, and without SLAMPP_HIP_DEV=1 -- every production
+// process -- that is a load of a flag, no getenv() beside a host application that may be calling setenv() (advisor, round 5).
+// With the knobs on, a knob's value is read at every use: the tools that sweep them set them between two analyses.
+inline std::atomic<int> &dev_knobs_state() { static std::atomic<int> n_state(-1); return n_state; }
+inline bool dev_knobs_refresh()
+{
+	const char *p = getenv("SLAMPP_HIP_DEV");
+	const int n_on = p && atoi(p) != 0;
+	dev_knobs_state().store(n_on, std::memory_order_relaxed);
+	return n_on != 0;
+}
+inline bool dev_knobs_on()
+{
+	const int n_on = dev_knobs_state().load(std::memory_order_relaxed);
+	return (n_on < 0)? dev_knobs_refresh() : n_on != 0;
+}
 inline bool dev_knob_set(const char *p_s_name) { return dev_knobs_on() && getenv(p_s_name) != 0; }
 inline int dev_knob(const char *p_s_name, int n_default) { return dev_knob_set(p_s_name)? atoi(getenv(p_s_name)) : n_default; }
 

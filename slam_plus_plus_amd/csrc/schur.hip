@@ -908,7 +908,9 @@ schur_obs_t_kernel(int64_t n_obs, int64_t ubase, int64_t nc, const int64_t *ptr,
 	const int64_t n_off_first = (int64_t(__builtin_amdgcn_readlane(int(n_off >> 32), 0)) << 32) | uint32_t(__builtin_amdgcn_readlane(int(n_off), 0));
 	const int64_t n_off_last = (int64_t(__builtin_amdgcn_readlane(int(n_off >> 32), 63)) << 32) | uint32_t(__builtin_amdgcn_readlane(int(n_off), 63));
 	const int64_t n_piece = n_off_last - n_off_first + BLK;
-	const bool b_staged = n_piece <= PIECE; // (wave-uniform; many one- or two-camera landmarks in a row: every lane fetches its own block)
+	const bool b_staged = n_piece <= PIECE && (reinterpret_cast<uintptr_t>(A) & 15) == 0; // (wave-uniform; many one- or two-camera landmarks in a row:
+	// every lane fetches its own block -- and so where the caller's values start at an odd double: the 16-byte requests below
+	// count on an even one; slampp_hip_factor_solve_device_async passes the caller's pointer through unchecked: advisor, round 5)
 	// (round 5) the whole piece is requested at once, in 16-byte pieces -- up to eleven per lane in flight -- and the camera's dx
 	// beside it: the loop of eight 8-byte requests, wait, store took up to three round trips a wave, and the gather of dx a
 	// fourth behind them.  A landmark's blocks start at an odd double where an odd number of 3 x 3 blocks precedes them: the

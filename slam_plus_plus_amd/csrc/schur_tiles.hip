@@ -1081,6 +1081,29 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 					(!b_compare_lists || Same(r_p.n_landmark, r_q.n_landmark));
 			}
 		});
+		if(!b_compare_lists) {
+			// the hashes alone said "same": every class of more than one landmark is held to its lists once, first member
+			// against last (two lists per class instead of two per landmark; advisor, round 5: two unkeyed hashes of the same
+			// 32-bit indices are not 128 independent bits).  A mismatch -- never seen -- sends every neighbour through Same().
+			std::atomic<int> n_collisions(0);
+			For_Landmark_Ranges(1, [&](int64_t n_first, int64_t n_last) {
+				for(int64_t i = n_first; i < n_last; ++ i) {
+					if(same_as_previous[i] && (i + 1 == np || !same_as_previous[i + 1])) { // the last member of a class
+						int64_t f = i;
+						while(f > 0 && same_as_previous[f])
+							-- f; // (may leave this thread's range: read only)
+						if(!Same(items[f].n_landmark, items[i].n_landmark))
+							n_collisions.fetch_add(1, std::memory_order_relaxed);
+					}
+				}
+			});
+			if(n_collisions.load()) {
+				For_Landmark_Ranges(1, [&](int64_t n_first, int64_t n_last) {
+					for(int64_t i = n_first; i < n_last; ++ i)
+						same_as_previous[i] = same_as_previous[i] && Same(items[i - 1].n_landmark, items[i].n_landmark);
+				});
+			}
+		}
 		BUILD_PHASE("  same lists");
 		run_lm.reserve(np);
 		run_k.reserve(np);

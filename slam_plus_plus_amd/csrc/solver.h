@@ -208,6 +208,7 @@ struct slampp_hip_solver {
 	slampp::TBatch t_batch = slampp::t_No_Batch();
 	slampp::CDevArray<double> d_batch_L, d_batch_Linv, d_batch_w, d_batch_handup;
 	slampp::CDevArray<int> d_batch_flag;
+	int n_batch_owner_member = -1; // the batch member whose factor became the handle's own (a batch of one), -1 = none; answered for at sync_batch
 	int *p_host_batch_flag = 0; // pinned, SLAMPP_HIP_MAX_BATCH ints
 	int n_batch_pending = 0;    // members of the batches enqueued since the last slampp_hip_sync_batch (the largest)
 	int n_simt_backward = -1; // option "simt_backward": 1 = the leaf subtrees' backward substitution a lane per task as well and no inv(L_jj) stored for them; 0 = a wave per task; -1 (default) = by the number of leaf subtrees (round 4, after the new ordering: slower below ~12 000 of them, 1.6 % faster at C3, 7 % at a million poses)

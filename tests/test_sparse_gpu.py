@@ -600,6 +600,52 @@ def test_batch_member_that_is_not_positive_definite_fails_alone():
         assert solver.sync_batch(2) == [True, True]
 
 
+def test_batch_solved_member_by_member_leaves_no_stale_factor():
+    """Advisor, round 5: with a dense top the members go through the handle's own factor arrays one after the other.  The
+    handle must not pass the last member's factor -- here a failed one -- off as its own: solve_again refuses until the next
+    factorization; a batch of one IS the handle's factorization, dropped when sync_batch finds it not positive definite."""
+    import torch
+    lam = synth.sphere(24, 24, seed=45)             # a dense top (BATCH_CASES["sphere_dense_top"])
+    bad = _damped(lam, -40.0)
+    assert O.solve_sparse(bad)[0] is False
+    members = [lam, _damped(lam, 0.5), bad]
+    sv, sr = lam.values.shape[0] + lam.values.shape[0] % 2, lam.n_scalars + lam.n_scalars % 2
+    vals = torch.stack([torch.from_numpy(np.pad(m.values, (0, sv - m.values.shape[0]))) for m in members]).cuda().contiguous()
+    rhs = torch.stack([torch.from_numpy(np.pad(m.rhs, (0, sr - m.n_scalars))) for m in members]).cuda().contiguous()
+    solver = CLinearSolver_HIP()
+    assert solver.SymbolicDecomposition_Blocky(lam)
+    assert solver.stats()["schur_dim"] > 0        # (sparse mode: the dimension of the dense top)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef_Blocky(lam, eta)     # the handle has a factor of its own
+    again = lam.rhs.copy()
+    assert solver.Solve_Again(again) and rel_inf(again, eta) < TOL
+    torch.cuda.synchronize()
+    solver.factor_solve_batch_device_async(3, vals.data_ptr(), sv, rhs.data_ptr(), sr)
+    assert solver.sync_batch(3) == [True, True, False]
+    x = rhs.cpu().numpy()
+    for k in (0, 1):
+        assert rel_inf(x[k][:lam.n_scalars], O.solve_sparse(members[k])[1]) < TOL
+    with pytest.raises(Exception):
+        solver.Solve_Again(lam.rhs.copy())          # no factor: neither the failed member's nor a stale one
+    assert solver.Solve_PosDef_Blocky(lam, eta)     # the next factorization brings one back
+    assert solver.Solve_Again(again)
+    # a batch of one that fails: an ordinary factorization that failed
+    r = rhs[2:3].clone()
+    torch.cuda.synchronize()
+    solver.factor_solve_batch_device_async(1, vals[2:3].data_ptr(), sv, r.data_ptr(), sr)
+    assert solver.sync_batch(1) == [False]
+    with pytest.raises(Exception):
+        solver.Solve_Again(lam.rhs.copy())
+    # and one that succeeds: its factor is the handle's
+    r = rhs[1:2].clone()
+    torch.cuda.synchronize()
+    solver.factor_solve_batch_device_async(1, vals[1:2].data_ptr(), sv, r.data_ptr(), sr)
+    assert solver.sync_batch(1) == [True]
+    b = members[1].rhs.copy()
+    assert solver.Solve_Again(b)
+    assert rel_inf(b, O.solve_sparse(members[1])[1]) < TOL
+
+
 def test_batch_is_refused_where_it_does_not_apply():
     from slam_plus_plus_amd.hip_solver import CLinearSolver_Schur_HIP
     ba = synth.ba(20, 600, seed=3)
