@@ -1166,7 +1166,10 @@ def compact_line(out, full_path):
     if out.get("strong_scaling_n1"):
         line["strong_scaling_n1"] = {a: b for a, b in out["strong_scaling_n1"].items() if a not in ("workload", "note", "metric")}
     if out.get("scaling_model"):
-        line["scaling_model"] = {key: {a: b for a, b in m.items() if a in ("serial_ms", "sharded_ms", "device_resident", "host_arrays")}
+        line["scaling_model"] = {key: ({a: b for a, b in m.items() if a in ("serial_ms", "sharded_ms", "device_resident", "host_arrays")}
+                                       if not key.startswith("c4_") else        # (the C4-size legs: the 8-GPU figures only, the rest is in the full record)
+                                       {"serial_ms": m["serial_ms"], "sharded_ms": m["sharded_ms"], "device_resident_at_8": m["device_resident"]["8"],
+                                        "host_arrays_at_8": (m.get("host_arrays") or {}).get("8")})
                                  for key, m in out["scaling_model"].items() if isinstance(m, dict) and "device_resident" in m}
     line["full"] = full_path
     text = json.dumps(_r(line))
@@ -1406,6 +1409,15 @@ def main():
         out["scaling_model"] = {key: scaling_model(out[key], out[key].get("n_values"), out[key].get("n_scalars"),
                                                    out[key].get("n_exchange_doubles"))
                                 for key in ("ba_c5", "ba_1k_1m") if out.get(key)}
+        # ... and what the other two visibility models say: the same model on the C4-size legs of this run
+        # (1k cameras x 500k points, Venice-like and uniform) -- with a reduced camera system that is dense or nearly so the
+        # replicated factorization is most of the step and the landmark shards stop mattering; band visibility is the one
+        # whose reduced system is sparse
+        for key, name in (("ba_schur", "c4_" + legs[0]), ("ba_schur_band", "c4_band"), ("ba_schur_uniform_dense_S", "c4_uniform"),
+                          ("ba_schur_venice", "c4_venice")):
+            if out.get(key) and out[key].get("phases_ms"):
+                out["scaling_model"].setdefault(name, scaling_model(out[key], out[key].get("n_values"), out[key].get("n_scalars"),
+                                                                    out[key].get("n_exchange_doubles")))
     if rank == 0 and world > 1 and out is not None:
         out["rccl_ranks"] = dist.get_world_size()
         out["dist_backend"] = dist.get_backend()      # "nccl" is RCCL on ROCm; "gloo" only under SLAMPP_BENCH_ONE_DEVICE=1 (development)

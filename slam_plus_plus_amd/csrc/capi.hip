@@ -109,6 +109,9 @@ int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id)
 	p->n_device = device_id;
 	if(hipSetDevice(device_id) != hipSuccess ||
 	   hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
+	   hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess || // (round 6: with the handle, not with the first
+	   // staging -- a stream costs milliseconds to make, and those were part of every first solve from host arrays)
+	   hipEventCreateWithFlags(&p->copy_done, hipEventDisableTiming) != hipSuccess ||
 	   hipHostMalloc((void**)&p->p_host_flag, sizeof(int), hipHostMallocDefault) != hipSuccess) {
 		delete p;
 		return SLAMPP_HIP_ERR_DEVICE;
@@ -746,6 +749,13 @@ int slampp_hip_factor_solve(slampp_hip_solver *p_solver, const double *p_values,
 		Parallel_Copy(p_rhs_inout, s.p_pin_rhs, size_t(s.n_scalars));
 	s.times.download_ms = wall_ms() - t2;
 	s.times.total_ms = wall_ms() - t0;
+	if(s.b_pin_values_deferred || s.b_pin_rhs_deferred) {
+		try {
+			s.Register_Staging_Later(); // the first answer is out: the staging it went through is pinned behind it
+		} catch(std::exception&) {
+			// (no thread to be had: the staging stays pageable)
+		}
+	}
 	if(p_times)
 		*p_times = s.times;
 	return n_result;
@@ -781,6 +791,7 @@ int slampp_hip_upload_values_async(slampp_hip_solver *p_solver, int64_t n_first,
 		}
 		if(!s.p_pin_values || !s.d_A.p())
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "upload_values: host_staging was not called");
+		s.Join_Staging_Registration(); // (a first staging being pinned behind the first answer: solver.h)
 		if(n_first == 0)
 			s.n_uploaded = 0; // a new pass over the values (what an abandoned pass has sent is simply sent again)
 		if(n_first != s.n_uploaded || n_count < 0 || n_first + n_count > s.n_values)

@@ -29,6 +29,15 @@ double now_ms()
 // Sub-problems are independent (disjoint vertex sets, disjoint output ranges known up front), so the
 // two halves of a large bisection run on separate threads down to a fixed depth: the ordering is the
 // cold path's largest host cost and the hosts of MI355X boxes have cores to spare.
+//
+// Round 6: no allocation proportional to a subset.  A subset is a range [b, e) of ONE array of vertices (m_verts), which
+// ends up being the ordering: a cut rearranges its range into lower part | upper part | separator, stably, through a
+// scratch array of the same size, and recurses into the first two; the breadth-first queue of a subset is the same range
+// of a third array, the difference array of the cut by number the same range of a fourth.  The recursion used to build
+// four or five std::vectors per subset -- megabytes each at the top levels, so every one of them an mmap and a munmap,
+// which take the address space's lock against the page faults of every other thread of the process (the other halves of
+// the recursion, the rest of the analysis, the caller's own threads): C3's ordering was 12 ms in a quiet process and 22 in
+// one whose heap had been used (the reference's own solver run before ours).  Same cuts, same ordering as before.
 class CNestedDissection {
 	const int32_t m_n;
 	const std::vector<int64_t> &m_ptr;
@@ -39,7 +48,8 @@ class CNestedDissection {
 	const int m_n_cut_min_size, m_n_cut_max_sep; // development knobs of the cut by vertex number, read once (plan.h)
 	std::vector<int32_t> m_set;    // id of the subset a vertex currently belongs to
 	std::vector<int32_t> m_level;  // BFS level (valid for the subset being processed)
-	std::vector<int32_t> &m_out;   // perm[new] = old; every call fills its own range
+	std::vector<int32_t> &m_verts; // the subsets, range by range; in the end perm[new] = old
+	std::vector<int32_t> m_scratch, m_queue, m_diff; // per-range work space (see above)
 	std::atomic<int32_t> m_next_id;
 	// halves of at least this many vertices each run side by side, down to this depth of the recursion (threads start in
 	// ~0.1 ms on the hosts of MI355X boxes: a few thousand vertices are worth one; a small graph -- the 2-D-like ones of the
@@ -54,46 +64,46 @@ public:
 		m_b_other_bank(b_other_bank),
 		m_n_cut_min_size(dev_knob("SLAMPP_HIP_DEV_ND_MIN", 64)), m_n_cut_max_sep(dev_knob("SLAMPP_HIP_DEV_ND_SEP", 4)),
 		m_set(n, -1), m_level(n, -1),
-		m_out(out), m_next_id(0),
+		m_verts(out), m_scratch(n), m_queue(n), m_diff(n, 0), m_next_id(0),
 		parallel_min_size(size_t(std::max(dev_knob("SLAMPP_HIP_DEV_ND_PAR_MIN", (n <= 8192)? 768 : 2048), 16))),
 		parallel_max_depth(dev_knob("SLAMPP_HIP_DEV_ND_PAR_DEPTH", (n <= 8192)? 2 : 6))
 	{
-		m_out.assign(n, -1);
+		m_verts.resize(n);
+		std::iota(m_verts.begin(), m_verts.end(), 0);
 	}
 
 	void Run()
 	{
-		std::vector<int32_t> all(m_n);
-		std::iota(all.begin(), all.end(), 0);
-		Order(all, 0, 0);
+		Order(0, size_t(m_n), 0);
 	}
 
 private:
-	// BFS inside subset `id` from `root`; fills r_queue with the visit order and m_level; returns #levels
-	int32_t BFS(int32_t root, int32_t id, std::vector<int32_t> &r_queue)
+	// BFS inside subset `id` from `root`; fills p_queue with the visit order and m_level; returns #levels (r_n_queue: #visited)
+	int32_t BFS(int32_t root, int32_t id, int32_t *p_queue, size_t &r_n_queue)
 	{
-		r_queue.clear();
-		r_queue.push_back(root);
+		size_t n_tail = 0;
+		p_queue[n_tail ++] = root;
 		m_level[root] = 0;
 		int32_t n_levels = 1;
-		for(size_t h = 0; h < r_queue.size(); ++ h) {
-			const int32_t v = r_queue[h], lv = m_level[v];
+		for(size_t h = 0; h < n_tail; ++ h) {
+			const int32_t v = p_queue[h], lv = m_level[v];
 			for(int64_t e = m_ptr[v]; e < m_ptr[v + 1]; ++ e) {
 				const int32_t w = m_adj[e];
 				if(m_set[w] == id && m_level[w] < 0) {
 					m_level[w] = lv + 1;
 					n_levels = lv + 2;
-					r_queue.push_back(w);
+					p_queue[n_tail ++] = w;
 				}
 			}
 		}
+		r_n_queue = n_tail;
 		return n_levels;
 	}
 
-	void Reset_Levels(const std::vector<int32_t> &verts)
+	void Reset_Levels(size_t b, size_t e)
 	{
-		for(int32_t v : verts)
-			m_level[v] = -1;
+		for(size_t k = b; k < e; ++ k)
+			m_level[m_verts[k]] = -1;
 	}
 
 	int32_t Degree_In(int32_t v, int32_t id) const
@@ -104,61 +114,69 @@ private:
 		return d;
 	}
 
-	// orders a (possibly disconnected) vertex subset into m_out[n_out .. n_out + |S|)
-	void Order(std::vector<int32_t> &S, size_t n_out, int n_depth)
+	// the two parts of a cut, side by side where they are large
+	void Order_Both(size_t b, size_t n_lower, size_t n_upper, int n_depth)
 	{
-		if(S.empty())
+		if(n_depth < parallel_max_depth && std::min(n_lower, n_upper) >= parallel_min_size) {
+			std::thread other([&]() { Order(b + n_lower, b + n_lower + n_upper, n_depth + 1); });
+			Order(b, b + n_lower, n_depth + 1);
+			other.join();
+		} else {
+			Order(b, b + n_lower, n_depth + 1);
+			Order(b + n_lower, b + n_lower + n_upper, n_depth + 1);
+		}
+	}
+
+	// orders the (possibly disconnected) vertex subset m_verts[b, e) in place
+	void Order(size_t b, size_t e, int n_depth)
+	{
+		if(b >= e)
 			return;
 		const int32_t id = m_next_id ++;
-		for(int32_t v : S) {
+		for(size_t k = b; k < e; ++ k) {
+			const int32_t v = m_verts[k];
 			m_set[v] = id;
 			m_level[v] = -1;
 		}
+		const size_t n_size = e - b;
 		TIndexCut t_cut;
 		const TIndexCut *p_cut = 0; // a cut by number that stands unless the level structure finds a narrower one
-		if(Find_Index_Cut(S, id, t_cut)) {
+		if(Find_Index_Cut(b, e, id, t_cut)) {
 			enum { n_small = 256 };
-			if(S.size() >= size_t(n_small) || t_cut.n_sep <= 2) {
-				Apply_Index_Cut(S, id, n_out, n_depth, t_cut);
+			if(n_size >= size_t(n_small) || t_cut.n_sep <= 2) {
+				Apply_Index_Cut(b, e, id, n_depth, t_cut);
 				return;
 			}
 			p_cut = &t_cut;
 		}
 		// split into connected components first (iteratively, flat storage: the landmark part
 		// of a BA system has 500k single-vertex components), then order each one
-		std::vector<int32_t> queue, comp_verts;
+		int32_t *p_queue = &m_queue[b];
+		size_t n_queue = 0, n_comp_verts = 0;
 		std::vector<size_t> comp_ptr(1, 0);
-		queue.reserve(S.size());
-		comp_verts.reserve(S.size());
-		for(size_t s = 0; s < S.size() && comp_verts.size() < S.size(); ++ s) {
-			if(m_level[S[s]] >= 0)
+		for(size_t k = b; k < e && n_comp_verts < n_size; ++ k) {
+			if(m_level[m_verts[k]] >= 0)
 				continue; // already in an earlier component
-			BFS(S[s], id, queue);
-			if(queue.size() == S.size()) {
-				Order_Connected(S, id, n_out, n_depth, queue, p_cut); // the whole subset is one component
+			BFS(m_verts[k], id, p_queue, n_queue);
+			if(n_queue == n_size) {
+				Order_Connected(b, e, id, n_depth, p_cut); // the whole subset is one component (its traversal is in the queue)
 				return;
 			}
-			comp_verts.insert(comp_verts.end(), queue.begin(), queue.end());
-			comp_ptr.push_back(comp_verts.size());
+			std::copy(p_queue, p_queue + n_queue, m_scratch.begin() + b + n_comp_verts); // (the components one behind the other)
+			n_comp_verts += n_queue;
+			comp_ptr.push_back(n_comp_verts);
 		}
-		{
-			std::vector<int32_t> empty;
-			S.swap(empty);
-		}
-		std::vector<int32_t> comp;
+		std::copy(m_scratch.begin() + b, m_scratch.begin() + e, m_verts.begin() + b);
 		for(size_t c = 0; c + 1 < comp_ptr.size(); ++ c) {
-			comp.assign(comp_verts.begin() + comp_ptr[c], comp_verts.begin() + comp_ptr[c + 1]);
-			const size_t n_comp_out = n_out + comp_ptr[c];
-			if(comp.size() == 1) {
-				m_out[n_comp_out] = comp[0];
-				continue;
-			}
+			const size_t cb = b + comp_ptr[c], ce = b + comp_ptr[c + 1];
+			if(ce - cb == 1)
+				continue; // (in place already)
 			const int32_t cid = m_next_id ++; // own id: the recursion must not see the other components
-			for(int32_t v : comp)
-				m_set[v] = cid;
-			Reset_Levels(comp);
-			BFS(comp[0], cid, queue);
-			Order_Connected(comp, cid, n_comp_out, n_depth, queue);
+			for(size_t k = cb; k < ce; ++ k)
+				m_set[m_verts[k]] = cid;
+			Reset_Levels(cb, ce);
+			BFS(m_verts[cb], cid, &m_queue[cb], n_queue);
+			Order_Connected(cb, ce, cid, n_depth, 0);
 		}
 	}
 
@@ -177,34 +195,38 @@ private:
 	// reduced camera system of the band-visibility BA leg: same width either way, but the cut by number left tasks of
 	// seven columns where the level structure leaves four, and its stages took 6 % longer).
 	struct TIndexCut {
-		size_t n_half; // position of the first vertex of the upper part
+		size_t n_half; // position (in the subset) of the first vertex of the upper part
 		int32_t n_sep; // vertices of the lower part with a neighbour in the upper part
 	};
 
-	bool Find_Index_Cut(const std::vector<int32_t> &S, int32_t id, TIndexCut &r_cut)
+	bool Find_Index_Cut(size_t b, size_t e, int32_t id, TIndexCut &r_cut)
 	{
 		const int min_size = m_n_cut_min_size, max_sep = m_n_cut_max_sep;
-		const size_t n_size = S.size();
-		if(n_size < size_t(min_size) || n_size <= size_t(m_leaf) * 4 || !std::is_sorted(S.begin(), S.end()))
+		const size_t n_size = e - b;
+		const int32_t *S = &m_verts[b];
+		if(n_size < size_t(min_size) || n_size <= size_t(m_leaf) * 4 || !std::is_sorted(S, S + n_size))
 			return false;
 		// how many vertices below position p have a neighbour at or above it, for every p of the middle third: a vertex at
-		// position k whose highest neighbour sits at position r counts for p in (k, r] -- a difference array.  m_level is
-		// free here (all -1): it holds the positions for the pass
+		// position k whose highest neighbour sits at position r counts for p in (k, r] -- a difference array (entry p - 1 of
+		// the subset's range of m_diff stands for position p: p runs from 1 to the subset's size).  m_level is free here
+		// (all -1): it holds the positions for the pass
 		for(size_t k = 0; k < n_size; ++ k)
 			m_level[S[k]] = int32_t(k);
 		const size_t n_lo = n_size * 35 / 100, n_hi = n_size - n_lo; // candidates: n_lo < p <= n_hi
-		std::vector<int32_t> diff(n_size + 2, 0);
+		int32_t *diff0 = &m_diff[b]; // diff0[p - 1]: position p = 1 .. n_size
+		std::fill(diff0, diff0 + n_size, 0);
 		for(size_t k = 0; k < n_hi; ++ k) {
 			const int32_t v = S[k];
 			int32_t r = -1;
-			for(int64_t e = m_ptr[v]; e < m_ptr[v + 1]; ++ e) {
-				const int32_t w = m_adj[e];
+			for(int64_t ed = m_ptr[v]; ed < m_ptr[v + 1]; ++ ed) {
+				const int32_t w = m_adj[ed];
 				if(w > v && m_set[w] == id)
 					r = std::max(r, m_level[w]);
 			}
 			if(r > int32_t(k)) {
-				++ diff[k + 1];
-				-- diff[size_t(r) + 1];
+				++ diff0[k]; // position k + 1
+				if(size_t(r) + 1 <= n_size)
+					-- diff0[size_t(r)]; // position r + 1 (beyond the last position there is nothing to end)
 			}
 		}
 		for(size_t k = 0; k < n_size; ++ k)
@@ -212,7 +234,7 @@ private:
 		size_t n_half = 0;
 		int32_t n_best = INT32_MAX, n_run = 0;
 		for(size_t p_ = 1; p_ <= n_hi; ++ p_) {
-			n_run += diff[p_];
+			n_run += diff0[p_ - 1];
 			if(p_ > n_lo) {
 				const size_t n_off = (p_ > n_size / 2)? p_ - n_size / 2 : n_size / 2 - p_;
 				const size_t n_best_off = (n_half > n_size / 2)? n_half - n_size / 2 : n_size / 2 - n_half;
@@ -230,78 +252,69 @@ private:
 		return true;
 	}
 
-	void Apply_Index_Cut(std::vector<int32_t> &S, int32_t id, size_t n_out, int n_depth, const TIndexCut &r_cut)
+	void Apply_Index_Cut(size_t b, size_t e, int32_t id, int n_depth, const TIndexCut &r_cut)
 	{
 		const size_t n_half = r_cut.n_half;
-		const int32_t n_mid = S[n_half]; // lower: numbers below n_mid
-		std::vector<int32_t> sep;
-		for(size_t k = 0; k < n_half; ++ k) {
-			const int32_t v = S[k];
-			for(int64_t e = m_ptr[v]; e < m_ptr[v + 1]; ++ e) {
-				const int32_t w = m_adj[e];
-				if(w >= n_mid && m_set[w] == id) {
-					sep.push_back(v);
-					break;
-				}
+		const int32_t n_mid = m_verts[b + n_half]; // lower: numbers below n_mid
+		// lower | upper | separator through the scratch range (stable: every part stays in ascending order)
+		size_t n_lower = 0, n_sep = 0;
+		int32_t *p_out = &m_scratch[b], *p_sep = &m_queue[b]; // (the queue's range is free here)
+		for(size_t k = b; k < b + n_half; ++ k) {
+			const int32_t v = m_verts[k];
+			bool b_sep = false;
+			for(int64_t ed = m_ptr[v]; ed < m_ptr[v + 1] && !b_sep; ++ ed) {
+				const int32_t w = m_adj[ed];
+				b_sep = w >= n_mid && m_set[w] == id;
 			}
-		}
-		std::vector<int32_t> lower, upper(S.begin() + n_half, S.end());
-		lower.reserve(n_half);
-		for(size_t k = 0, q = 0; k < n_half; ++ k) {
-			if(q < sep.size() && sep[q] == S[k])
-				++ q;
+			if(b_sep)
+				p_sep[n_sep ++] = v;
 			else
-				lower.push_back(S[k]);
+				p_out[n_lower ++] = v;
 		}
-		{
-			std::vector<int32_t> empty;
-			S.swap(empty);
-		}
-		const size_t n_lower = lower.size(), n_upper = upper.size();
-		std::copy(sep.begin(), sep.end(), m_out.begin() + n_out + n_lower + n_upper);
-		if(n_depth < parallel_max_depth && std::min(n_lower, n_upper) >= parallel_min_size) {
-			std::thread other([&]() { Order(upper, n_out + n_lower, n_depth + 1); });
-			Order(lower, n_out, n_depth + 1);
-			other.join();
-		} else {
-			Order(lower, n_out, n_depth + 1);
-			Order(upper, n_out + n_lower, n_depth + 1);
-		}
+		const size_t n_upper = (e - b) - n_half;
+		std::copy(m_verts.begin() + b + n_half, m_verts.begin() + e, p_out + n_lower);
+		std::copy(p_sep, p_sep + n_sep, p_out + n_lower + n_upper);
+		std::copy(p_out, p_out + (e - b), m_verts.begin() + b);
+		Order_Both(b, n_lower, n_upper, n_depth);
 	}
 
 	// Cuthill-McKee-like order of a small connected subset
-	void Order_Leaf(const std::vector<int32_t> &S, int32_t id, size_t n_out, std::vector<int32_t> &r_queue)
+	void Order_Leaf(size_t b, size_t e, int32_t id)
 	{
-		Reset_Levels(S);
-		BFS(S[0], id, r_queue);
-		const int32_t far = r_queue.back();
-		Reset_Levels(S);
-		BFS(far, id, r_queue);
-		std::copy(r_queue.begin(), r_queue.end(), m_out.begin() + n_out);
+		int32_t *p_queue = &m_queue[b];
+		size_t n_queue = 0;
+		Reset_Levels(b, e);
+		BFS(m_verts[b], id, p_queue, n_queue);
+		const int32_t far = p_queue[n_queue - 1];
+		Reset_Levels(b, e);
+		BFS(far, id, p_queue, n_queue);
+		std::copy(p_queue, p_queue + n_queue, m_verts.begin() + b);
 	}
 
-	// r_queue: scratch; on entry it holds a BFS of S (levels set) from an arbitrary root
-	void Order_Connected(std::vector<int32_t> &S, int32_t id, size_t n_out, int n_depth, std::vector<int32_t> &r_queue,
-		const TIndexCut *p_cut = 0)
+	// on entry the subset's range of m_queue holds a BFS of it (levels set) from an arbitrary root
+	void Order_Connected(size_t b, size_t e, int32_t id, int n_depth, const TIndexCut *p_cut)
 	{
-		if(S.size() <= size_t(m_leaf)) {
-			Order_Leaf(S, id, n_out, r_queue);
+		const size_t n_size = e - b;
+		int32_t *p_queue = &m_queue[b];
+		size_t n_queue = n_size;
+		if(n_size <= size_t(m_leaf)) {
+			Order_Leaf(b, e, id);
 			return;
 		}
 		// pseudo-peripheral root: repeat BFS from a minimum-degree vertex of the last level
-		int32_t n_levels = m_level[r_queue.back()] + 1;
+		int32_t n_levels = m_level[p_queue[n_queue - 1]] + 1;
 		for(int n_pass = 0; n_pass < 3; ++ n_pass) {
 			const int32_t last = n_levels - 1;
 			int32_t best = -1, best_deg = INT32_MAX;
-			for(size_t k = r_queue.size(); k > 0 && m_level[r_queue[k - 1]] == last; -- k) {
-				const int32_t v = r_queue[k - 1], d = Degree_In(v, id);
+			for(size_t k = n_queue; k > 0 && m_level[p_queue[k - 1]] == last; -- k) {
+				const int32_t v = p_queue[k - 1], d = Degree_In(v, id);
 				if(d < best_deg) {
 					best_deg = d;
 					best = v;
 				}
 			}
-			Reset_Levels(S);
-			const int32_t n_new = BFS(best, id, r_queue);
+			Reset_Levels(b, e);
+			const int32_t n_new = BFS(best, id, p_queue, n_queue);
 			if(n_new <= n_levels) {
 				n_levels = n_new;
 				break;
@@ -310,19 +323,19 @@ private:
 		}
 		if(n_levels < 3) { // clique-like: no level separates anything
 			if(p_cut) {
-				Reset_Levels(S);
-				Apply_Index_Cut(S, id, n_out, n_depth, *p_cut);
+				Reset_Levels(b, e);
+				Apply_Index_Cut(b, e, id, n_depth, *p_cut);
 				return;
 			}
-			std::copy(r_queue.begin(), r_queue.end(), m_out.begin() + n_out);
+			std::copy(p_queue, p_queue + n_queue, m_verts.begin() + b);
 			return;
 		}
 		// level sizes; pick the smallest level that leaves >= 1/4 of the vertices on either side,
 		// the median level if there is none
 		std::vector<int32_t> count(n_levels, 0);
-		for(int32_t v : S)
-			++ count[m_level[v]];
-		const int64_t n_total = int64_t(S.size());
+		for(size_t k = b; k < e; ++ k)
+			++ count[m_level[m_verts[k]]];
+		const int64_t n_total = int64_t(n_size);
 		int32_t m_best = -1;
 		{
 			int64_t below = 0;
@@ -350,73 +363,87 @@ private:
 				}
 			}
 		}
-		// separator = vertices of level m with a neighbour in level m+1; the rest of level m joins the lower part
-		std::vector<int32_t> sep, lower, upper;
-		lower.reserve(S.size() / 2 + 1);
-		upper.reserve(S.size() / 2 + 1);
-		for(int32_t v : S) {
-			const int32_t lv = m_level[v];
+		// separator = vertices of level m with a neighbour in level m+1; the rest of level m joins the lower part.
+		// The parts are formed in the scratch range (lower from its front, upper and separator marked and placed behind)
+		// and only take the subset's place once the cut stands
+		int32_t *p_lower = &m_scratch[b];
+		size_t n_lower = 0, n_upper = 0, n_sep = 0;
+		// (a first pass decides every vertex's part: 0 lower, 1 upper, 2 separator -- kept in m_diff's range, free here)
+		int32_t *p_part = &m_diff[b];
+		for(size_t k = b; k < e; ++ k) {
+			const int32_t v = m_verts[k], lv = m_level[v];
+			int n_part;
 			if(lv < m_best)
-				lower.push_back(v);
+				n_part = 0;
 			else if(lv > m_best)
-				upper.push_back(v);
+				n_part = 1;
 			else {
 				bool b_sep = false;
-				for(int64_t e = m_ptr[v]; e < m_ptr[v + 1] && !b_sep; ++ e) {
-					const int32_t w = m_adj[e];
+				for(int64_t ed = m_ptr[v]; ed < m_ptr[v + 1] && !b_sep; ++ ed) {
+					const int32_t w = m_adj[ed];
 					b_sep = (m_set[w] == id && m_level[w] == m_best + 1);
 				}
-				(b_sep? sep : lower).push_back(v);
+				n_part = b_sep? 2 : 0;
 			}
+			p_part[k - b] = n_part;
+			n_lower += n_part == 0;
+			n_upper += n_part == 1;
+			n_sep += n_part == 2;
 		}
+		bool b_sort_lower = false;
 		if(m_b_other_bank) {
 			// the other bank of the same cut: the vertices of level m + 1 with a neighbour in level m -- where they are fewer,
 			// they are the separator, and all of level m stays below
-			std::vector<int32_t> sep2;
-			for(int32_t v : upper) {
-				if(m_level[v] != m_best + 1)
+			size_t n_sep2 = 0;
+			for(size_t k = b; k < e; ++ k) {
+				const int32_t v = m_verts[k];
+				if(p_part[k - b] != 1 || m_level[v] != m_best + 1)
 					continue;
 				bool b_sep = false;
-				for(int64_t e = m_ptr[v]; e < m_ptr[v + 1] && !b_sep; ++ e) {
-					const int32_t w = m_adj[e];
+				for(int64_t ed = m_ptr[v]; ed < m_ptr[v + 1] && !b_sep; ++ ed) {
+					const int32_t w = m_adj[ed];
 					b_sep = (m_set[w] == id && m_level[w] == m_best);
 				}
-				if(b_sep)
-					sep2.push_back(v);
-			}
-			if(sep2.size() < sep.size()) {
-				lower.insert(lower.end(), sep.begin(), sep.end());
-				std::sort(lower.begin(), lower.end()); // (subsets stay sorted by vertex number: Find_Index_Cut asks for it)
-				std::vector<int32_t> rest;
-				rest.reserve(upper.size() - sep2.size());
-				std::sort(sep2.begin(), sep2.end());
-				for(int32_t v : upper) {
-					if(!std::binary_search(sep2.begin(), sep2.end(), v))
-						rest.push_back(v);
+				if(b_sep) {
+					p_part[k - b] = 3; // (a candidate of the other bank)
+					++ n_sep2;
 				}
-				upper.swap(rest);
-				sep.swap(sep2);
+			}
+			if(n_sep2 < n_sep) {
+				for(size_t k = b; k < e; ++ k) {
+					int32_t &r_part = p_part[k - b];
+					r_part = (r_part == 2)? 0 : (r_part == 3)? 2 : r_part; // the first bank joins the lower part, the other one is the separator
+				}
+				n_lower += n_sep;
+				n_upper -= n_sep2;
+				n_sep = n_sep2;
+				b_sort_lower = true; // (subsets stay sorted by vertex number: the cut by number asks for it; the separator is sorted as well, as it was)
+			} else {
+				for(size_t k = b; k < e; ++ k) {
+					if(p_part[k - b] == 3)
+						p_part[k - b] = 1;
+				}
 			}
 		}
-		if(p_cut && int32_t(sep.size()) > p_cut->n_sep) { // the cut by number is narrower
-			Reset_Levels(S);
-			Apply_Index_Cut(S, id, n_out, n_depth, *p_cut);
+		if(p_cut && int32_t(n_sep) > p_cut->n_sep) { // the cut by number is narrower
+			Reset_Levels(b, e);
+			Apply_Index_Cut(b, e, id, n_depth, *p_cut);
 			return;
 		}
 		{
-			std::vector<int32_t> empty;
-			S.swap(empty); // release before recursing
+			size_t n_l = 0, n_u = n_lower, n_s = n_lower + n_upper;
+			for(size_t k = b; k < e; ++ k) {
+				const int32_t v = m_verts[k];
+				const int n_part = p_part[k - b];
+				p_lower[(n_part == 0)? n_l ++ : (n_part == 1)? n_u ++ : n_s ++] = v;
+			}
+			if(b_sort_lower) {
+				std::sort(p_lower, p_lower + n_lower);
+				std::sort(p_lower + n_lower + n_upper, p_lower + n_size);
+			}
+			std::copy(p_lower, p_lower + n_size, m_verts.begin() + b);
 		}
-		const size_t n_lower = lower.size(), n_upper = upper.size();
-		std::copy(sep.begin(), sep.end(), m_out.begin() + n_out + n_lower + n_upper);
-		if(n_depth < parallel_max_depth && std::min(n_lower, n_upper) >= parallel_min_size) {
-			std::thread other([&]() { Order(upper, n_out + n_lower, n_depth + 1); });
-			Order(lower, n_out, n_depth + 1);
-			other.join();
-		} else {
-			Order(lower, n_out, n_depth + 1);
-			Order(upper, n_out + n_lower, n_depth + 1);
-		}
+		Order_Both(b, n_lower, n_upper, n_depth);
 	}
 };
 
@@ -693,6 +720,8 @@ std::string plan_order_symbolic(const TBlockGraph &G, const int64_t *cumsum, con
 	std::vector<int64_t> pos(n, -1); // block id of row i in the column being built
 	P.asrc.clear();
 	P.atrans.clear();
+	P.asrc.reserve(size_t(n_ablocks) * 2); // (with lrow: three arrays growing by doubling were a dozen reallocations of megabytes each)
+	P.atrans.reserve(size_t(n_ablocks) * 2);
 	for(int32_t j = 0; j < n; ++ j) {
 		rows.clear();
 		rows.push_back(j);

@@ -86,6 +86,7 @@ void slampp_hip_solver::Refine_Structure()
 template <class F>
 static void Parallel_Ranges(int64_t n, int64_t n_min_per_thread, F f, int n_max_threads = 4)
 {
+	n_max_threads = std::min(n_max_threads, std::max(dev_knob("SLAMPP_HIP_DEV_SETUP_THREADS", n_max_threads), 1)); // (development knob, plan.h)
 	const int n_threads = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_max_threads, std::max(1u, std::thread::hardware_concurrency())), n / std::max<int64_t>(n_min_per_thread, 1))));
 	if(n_threads <= 1) {
 		f(int64_t(0), n);
@@ -248,6 +249,23 @@ void slampp_hip_solver::Analyze_Sparse()
 	std::vector<TUpdEnt> upd_ents;
 	// (a second pass, without hand-ups, if a stage's hand-up list would take its workgroups past the LDS of a CU: the list
 	// rides in the dynamic LDS request on top of the task's image, and nothing else bounds its length -- advisor, round 4)
+	{
+		// room for everything up front (address space only: pages come when they are written): the lists used to grow by
+		// doubling, each step an mmap, a copy and a munmap of megabytes -- and a munmap interrupts every thread of the process
+		// (the TLB shootdown), of which the analysis runs a dozen at this point (round 6)
+		const size_t n_upper_tasks = (P.stage_ptr.size() > 1)? size_t(P.stage_ptr.back() - P.stage_ptr[size_t(std::min(n_bottom_stages, int(P.stage_ptr.size()) - 1))]) : 0;
+		const size_t n_tasks_cap = (n_upper_begin == 0)? P.task_ptr.size() : n_upper_tasks;
+		size_t n_upper_blocks = 0, n_upper_pairs = 0;
+		for(int64_t i = n_upper_begin; i < n_sched; ++ i) {
+			n_upper_blocks += size_t(cols[i].nb);
+			n_upper_pairs += size_t(cols[i].np) + size_t(cols[i].nr);
+		}
+		panel_pkg.reserve(n_tasks_cap * 64 + 3 * n_upper_blocks + n_upper_pairs + 64 * PANEL_W + 4096);
+		upd_slots.reserve(n_upper_blocks + 16);
+		upd_ents.reserve(n_upper_pairs + 16);
+		panel_off.reserve(n_tasks_cap + 16);
+		panel_out_off.reserve(n_tasks_cap + 16);
+	}
 	auto Build_Panel_Packages = [&]() {
 	for(bool b_hand_up_allowed = n_panel_handup != 0;;) {
 	panel_pkg.clear();
@@ -689,7 +707,10 @@ void slampp_hip_solver::Analyze_Sparse()
 	else {
 		t_panel_thread.t = std::thread([&]() {
 			try {
+				const double t_panel = wall_ms();
 				Build_Panel_Packages();
+				if(b_timing)
+					fprintf(stderr, "[setup] %-12s %8.2f ms on their own thread\n", "panel pkgs", wall_ms() - t_panel);
 			} catch(...) {
 				p_panel_error = std::current_exception();
 			}
@@ -956,8 +977,15 @@ void slampp_hip_solver::Build_Simt()
 		auto Simt_Phase = [&](const char *p_s_name) { if(b_simt_timing) { const double t_ = wall_ms();
 			fprintf(stderr, "[shapes] stage %d %-12s %8.2f ms\n", s, p_s_name, t_ - t_simt_phase); t_simt_phase = t_; } };
 		std::vector<TTask> tasks_all(size_t(std::max(n_stage_tasks, 0)));
+		// (the threads' index arrays: made here, before the threads, and given back after them -- an array of megabytes made
+		// and freed by a thread is an mmap and a munmap while a dozen other threads of the analysis run: see the panel packages)
+		enum { SIMT_THREADS = 8 };
+		raw_vector<int32_t> index_pool((P.lrow.size() + size_t(P.n)) * SIMT_THREADS); // (every thread fills its own slice)
+		std::atomic<int> n_next_slice(0);
 		Parallel_Ranges(n_stage_tasks, 512, [&](int64_t n_b, int64_t n_e) {
-			std::vector<int32_t> op_index(P.lrow.size(), -1), y_index(size_t(P.n), -1); // (per thread: a few MB, written once)
+			const size_t n_slice = size_t(n_next_slice.fetch_add(1)) % SIMT_THREADS;
+			int32_t *op_index = &index_pool[(P.lrow.size() + size_t(P.n)) * n_slice], *y_index = op_index + P.lrow.size();
+			std::fill(op_index, op_index + P.lrow.size() + size_t(P.n), -1);
 			std::vector<int32_t> touch, body;
 			for(int64_t n_i = n_b; n_i < n_e; ++ n_i) {
 				const int32_t t = t0 + int32_t(n_i);

@@ -45,10 +45,14 @@ struct CJoiningThreads {
 	}
 };
 
-static void Free_Pinned(double *p, bool b_registered, size_t n_doubles)
+static void Free_Pinned(double *p, bool b_registered, size_t n_doubles, bool b_deferred = false)
 {
 	if(!p)
 		return;
+	if(b_deferred && !b_registered) { // a mapping of ours the driver never saw
+		(void)munmap(p, pinned_bytes(n_doubles));
+		return;
+	}
 	if(b_registered) {
 		// a mapping of its own, never the allocator's memory: pages the driver has pinned do not go back into a heap.  If
 		// the driver will not let go of them, the mapping stays (a leak of address space, not a block that two owners use)
@@ -75,8 +79,11 @@ void slampp_hip_solver::Free_Staging()
 		(void)hipStreamSynchronize(copy_stream);
 	if(stream)
 		(void)hipStreamSynchronize(stream);
-	Free_Pinned(p_pin_values, b_pin_values_registered, n_pin_values);
-	Free_Pinned(p_pin_rhs, b_pin_rhs_registered, n_pin_rhs);
+	Join_Staging_Registration();
+	Free_Pinned(p_pin_values, b_pin_values_registered, n_pin_values, b_pin_values_deferred);
+	Free_Pinned(p_pin_rhs, b_pin_rhs_registered, n_pin_rhs, b_pin_rhs_deferred);
+	b_pin_values_deferred = b_pin_rhs_deferred = false;
+	b_pin_values_registered = b_pin_rhs_registered = false;
 	p_pin_values = p_pin_rhs = 0;
 	n_pin_values = n_pin_rhs = 0;
 	n_uploaded = 0;
@@ -88,12 +95,13 @@ void slampp_hip_solver::Free_Staging()
 // it is the kernel handing out and clearing 4 kB pages one at a time.  The same memory as 2 MB pages (madvise, where
 // transparent huge pages are on or on request), first touched by a few threads and then registered, costs 1 - 5 ms
 // and moves at the same 54 GB/s; without huge pages it is still no slower than hipHostMalloc.
-static double *Alloc_Pinned(size_t n_doubles, bool &r_b_registered) // throw(std::bad_alloc, CDeviceError)
+static double *Alloc_Pinned(size_t n_doubles, bool &r_b_registered, bool b_defer, bool &r_b_deferred) // throw(std::bad_alloc, CDeviceError)
 {
 	const size_t n_huge = size_t(2) << 20;
 	const size_t n_bytes = pinned_bytes(n_doubles);
 	r_b_registered = false;
-	if(n_bytes >= 4 * n_huge) {
+	r_b_deferred = false;
+	if(n_bytes >= 4 * n_huge || b_defer) {
 		// an anonymous mapping aligned to the huge page size (mapped one huge page longer, the ends cut off)
 		char *p = 0;
 		{
@@ -106,6 +114,11 @@ static double *Alloc_Pinned(size_t n_doubles, bool &r_b_registered) // throw(std
 					(void)munmap(p_aligned + n_bytes, size_t((p_begin + n_bytes + n_huge) - (p_aligned + n_bytes)));
 				p = p_aligned;
 			}
+		}
+		if(p && b_defer) { // neither touched nor pinned now: slampp_hip_solver::Register_Staging_Later()
+			(void)madvise(p, n_bytes, MADV_HUGEPAGE);
+			r_b_deferred = true;
+			return (double*)p;
 		}
 		if(p) {
 			(void)madvise(p, n_bytes, MADV_HUGEPAGE);
@@ -146,7 +159,7 @@ static double *Alloc_Pinned(size_t n_doubles, bool &r_b_registered) // throw(std
 	return p;
 }
 
-static void Grow_Pinned(double *&r_p, size_t &r_n, bool &r_b_registered, size_t n_doubles) // throws
+static void Grow_Pinned(double *&r_p, size_t &r_n, bool &r_b_registered, size_t n_doubles, bool b_defer, bool &r_b_deferred) // throws
 {
 	if(r_n >= n_doubles && r_p)
 		return;
@@ -154,10 +167,11 @@ static void Grow_Pinned(double *&r_p, size_t &r_n, bool &r_b_registered, size_t 
 	// LinearSolver_CholMod.cpp:898-901): an incremental solver hands over systems a few blocks larger at every call, and
 	// pinning is milliseconds each time
 	const size_t n_new = (r_p && r_n)? std::max(n_doubles, 2 * r_n) : n_doubles;
-	Free_Pinned(r_p, r_b_registered, r_n);
+	Free_Pinned(r_p, r_b_registered, r_n, r_b_deferred);
 	r_p = 0;
 	r_n = 0;
-	r_p = Alloc_Pinned(n_new, r_b_registered);
+	r_b_registered = r_b_deferred = false;
+	r_p = Alloc_Pinned(n_new, r_b_registered, b_defer, r_b_deferred);
 	r_n = n_new;
 }
 
@@ -166,14 +180,47 @@ static double staging_wall_ms()
 	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// the deferred registration of a first staging (solver.h): pins the mapping where it is, pages and all
+void slampp_hip_solver::Register_Staging_Later()
+{
+	if((!b_pin_values_deferred || b_pin_values_registered) && (!b_pin_rhs_deferred || b_pin_rhs_registered))
+		return;
+	Join_Staging_Registration();
+	t_staging_registration = std::thread([this]() {
+		if(hipSetDevice(n_device) != hipSuccess)
+			return;
+		// (a failure leaves the mapping what it was: transfers keep going through the pageable path)
+		if(b_pin_values_deferred && !b_pin_values_registered && p_pin_values) {
+			if(hipHostRegister(p_pin_values, pinned_bytes(n_pin_values), hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess)
+				b_pin_values_registered = true;
+			else
+				(void)hipGetLastError();
+		}
+		if(b_pin_rhs_deferred && !b_pin_rhs_registered && p_pin_rhs) {
+			if(hipHostRegister(p_pin_rhs, pinned_bytes(n_pin_rhs), hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess)
+				b_pin_rhs_registered = true;
+			else
+				(void)hipGetLastError();
+		}
+	});
+}
+
+void slampp_hip_solver::Join_Staging_Registration()
+{
+	if(t_staging_registration.joinable())
+		t_staging_registration.join();
+}
+
 void slampp_hip_solver::Require_Staging()
 {
+	Join_Staging_Registration();
 	const bool b_timing = getenv("SLAMPP_HIP_PLAN_TIMING") != 0 && (n_pin_values < size_t(n_values) || !p_pin_values);
 	const double t0 = staging_wall_ms();
 	if(!copy_stream)
-		SLAMPP_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+		SLAMPP_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)); // (handles made by slampp_hip_create have one already)
 	if(!copy_done)
 		SLAMPP_HIP_CHECK(hipEventCreateWithFlags(&copy_done, hipEventDisableTiming));
+	const double t_streams = staging_wall_ms();
 	if(n_pin_values < size_t(n_values) || !p_pin_values)
 		n_uploaded = 0;
 	if((n_pin_values < size_t(n_values) && p_pin_values) || (n_pin_rhs < size_t(n_scalars) && p_pin_rhs)) {
@@ -181,17 +228,21 @@ void slampp_hip_solver::Require_Staging()
 		if(stream)
 			(void)hipStreamSynchronize(stream);
 	}
-	Grow_Pinned(p_pin_values, n_pin_values, b_pin_values_registered, size_t(n_values));
+	// (deferral: the first staging of a one-device handle that was told host arrays are coming -- solver.h)
+	const bool b_defer = !b_staging_ever && !p_pin_values && !p_pin_rhs && n_staging_ahead && !b_group_active && group_devices.empty() &&
+		!dev_knob_set("SLAMPP_HIP_DEV_NO_STAGING_DEFERRAL");
+	Grow_Pinned(p_pin_values, n_pin_values, b_pin_values_registered, size_t(n_values), b_defer, b_pin_values_deferred);
 	const double t1 = staging_wall_ms();
-	Grow_Pinned(p_pin_rhs, n_pin_rhs, b_pin_rhs_registered, size_t(n_scalars));
+	Grow_Pinned(p_pin_rhs, n_pin_rhs, b_pin_rhs_registered, size_t(n_scalars), b_defer, b_pin_rhs_deferred);
+	b_staging_ever = true;
 	const double t2 = staging_wall_ms();
 	if(!b_group_active) { // (with landmark shards the values go from the staging straight to the members' devices)
 		d_A.Alloc(size_t(n_values));
 		d_rhs.Alloc(size_t(n_scalars));
 	}
 	if(b_timing) {
-		fprintf(stderr, "[staging] values %.2f ms (%s), rhs %.2f ms, device arrays %.2f ms\n", t1 - t0,
-			b_pin_values_registered? "registered" : "hipHostMalloc", t2 - t1, staging_wall_ms() - t2);
+		fprintf(stderr, "[staging] copy stream %.2f ms, values %.2f ms (%s), rhs %.2f ms, device arrays %.2f ms\n", t_streams - t0, t1 - t_streams,
+			b_pin_values_deferred? "mapped, registration deferred" : b_pin_values_registered? "registered" : "hipHostMalloc", t2 - t1, staging_wall_ms() - t2);
 	}
 }
 
