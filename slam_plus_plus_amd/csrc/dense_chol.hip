@@ -34,12 +34,12 @@ void dense_prepare_padding(double *M, int n_pad, int n, hipStream_t stream)
 }
 
 #ifdef POTRF_VARIANTS // tools/bench_potrf.hip: timing of the two halves
-template <bool b_chol, bool b_inverse>
+template <bool b_chol, bool b_inverse, bool b_pipeline = true>
 __global__ void __launch_bounds__(256)
 potrf_diag_variant(double *M, int ld, int kb, int n, double *invL, int *p_flag)
 {
 	__shared__ double s_buf[POTRF_LDS_DOUBLES];
-	potrf_diag_body<b_chol, b_inverse>(M, ld, kb, n, invL, p_flag, s_buf);
+	potrf_diag_body<b_chol, b_inverse, b_pipeline>(M, ld, kb, n, invL, p_flag, s_buf);
 }
 #endif
 

@@ -268,8 +268,118 @@ __device__ __forceinline__ void potrf_panel_scale(double (&a)[16], double rs)
 		potrf_panel_scale<K + 1>(a, rs);
 }
 
+// ---- round 6: the panel of a diagonal tile as a pipeline of three waves ----
+// The sixteen column steps of a 64 x 16 panel used to be walked by ONE wave that updated, at every step, the trailing columns
+// of its own 64 rows (a[]) and of the copy of the 16 x 16 diagonal block every row of 16 lanes keeps (d[]): 2 (15 - k)
+// v_fmac_f64_dpp at ~11.6 clocks each with one wave on the SIMD (tools/micro/mfma_f64_peak.hip) around a dependent chain of
+// ~110 -- 244 clocks a step by the in-kernel stamps, 3 900 a panel, four panels a tile.  Only the diagonal block is on the
+// chain.  Now wave 0 walks the chain on the diagonal block alone and publishes, step by step, the multipliers of the step
+// (column k of the unit lower factor, negated: m_k(c) = -D(c,k) / d_k) and a step counter in LDS; wave 1 holds the rows below
+// the block (a lane a row) and wave 2 the columns of the block's inverse (a lane a column), and both apply step k as soon as
+// the counter says it is there: a(r,c) += a(r,k) m_k(c), y_j(r) += m_k(r) y_j(k) -- the same multipliers serve both (the
+// inverse of the unit lower factor by forward substitution; the rows are scaled by 1 / sqrt(d) at the end, like the panel).
+// LDS operations of one wave are performed in order, and the accesses are volatile (the compiler keeps their order): the
+// counter is written behind the multipliers and read in front of them, no barrier inside the sixteen steps.  Wave 3 meanwhile
+// applies the previous panel to the tiles further right, as waves 1 - 3 used to.
+// (LDS pointers with their address space spelled out: a volatile access through a generic pointer is a flat instruction with
+// the system-coherence bits set and a wait behind it -- 2 000 clocks a step instead of 130)
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) int lds_i32;
+template <int K, int C>
+__device__ __forceinline__ void potrf_chain_update(double (&d)[16], double ntd)
+{
+	if constexpr(C < 16) {
+		dpp_fmac_row_bcast<C, false>(d[C], d[K], ntd);
+		potrf_chain_update<K, C + 1>(d, ntd);
+	}
+}
+// potrf_panel_pivot for a pivot that sits in lane K of every row of 16 lanes in `v` (other lanes: anything)
+template <int K>
+__device__ __forceinline__ double potrf_chain_pivot(double v, double &r_mine, int g)
+{
+	const double piv_raw = dpp_row_bcast<K>(v);
+	r_mine = (g == K)? piv_raw : r_mine;
+	double piv;
+	asm volatile("v_max_f64 %0, %1, %2" : "=v"(piv) : "v"(piv_raw), "v"(1e-300)); // (one instruction: __builtin_fmax puts a canonicalizing v_max in front)
+	double rw = __builtin_amdgcn_rcp(piv);
+	rw = __builtin_fma(__builtin_fma(-piv, rw, 1.0), rw, rw);
+	rw = __builtin_fma(__builtin_fma(-piv, rw, 1.0), rw, rw);
+	return rw;
+}
+template <int K>
+__device__ __forceinline__ void potrf_chain_steps(double (&d)[16], double rw, double &r_mine, int g, int lane,
+	volatile lds_f64 *s_mult, volatile lds_i32 *s_step)
+{
+	const double ntd = -(d[K] * rw); // lane g: -D(g, k) / d_k
+	if constexpr(K < 15) {
+		s_mult[K * 16 + g] = ntd; // published at once, by every row of 16 lanes (the same value to the same place: no mask to set up on the chain)
+		*s_step = K + 1;
+		// The next pivot is D(K+1,K+1) - D(K+1,K)^2 / d_K: lane K + 1 has all three in its own registers -- a plain FMA there (and
+		// nonsense in the other lanes, not used) and ONE broadcast, instead of the broadcast update of column K + 1 followed by
+		// the broadcast of its diagonal entry: a dependent DPP operation is 16 clocks plus its wait states, and the chain is
+		// made of nothing but latencies (the column's update itself follows below, off the chain)
+		const double t_diag = __builtin_fma(d[K], ntd, d[K + 1]);
+		const double rw_next = potrf_chain_pivot<K + 1>(t_diag, r_mine, g);
+		dpp_fmac_row_bcast<K + 1, true>(d[K + 1], d[K], ntd);
+		potrf_chain_update<K, K + 2>(d, ntd);
+		potrf_chain_steps<K + 1>(d, rw_next, r_mine, g, lane, s_mult, s_step);
+	} else
+		*s_step = 16; // (the last column has nothing below it: the followers only need to know the chain is through)
+}
+template <int K>
+__device__ __forceinline__ void potrf_chain_scale(double (&d)[16], double rs)
+{
+	d[K] *= dpp_row_bcast<K>(rs); // L(c0 + g, c0 + k) = D(g,k) / sqrt(d_k)
+	if constexpr(K < 15)
+		potrf_chain_scale<K + 1>(d, rs);
+}
+__device__ __forceinline__ void potrf_wait_step(volatile lds_i32 *s_step, int n_step)
+{
+	while(*s_step < n_step)
+		__builtin_amdgcn_s_sleep(1);
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // (what is read next is read after the counter)
+}
+// The followers.  A follower is bound by what it issues -- 15 - K FMAs a step at ~10 clocks each with one wave on its SIMD,
+// and the reads of the step's multipliers -- so the trip to LDS must not add to that: the multipliers of step K + 1 (and the
+// counter, read FIRST: LDS serves a wave's requests in order, so a counter that says "there" vouches for what was read behind
+// it) are requested before the arithmetic of step K; only if the counter was not there yet does the follower wait and ask again.
+template <int K>
+__device__ __forceinline__ void potrf_fetch_step(const lds_f64 *s_mult, volatile lds_i32 *s_step, int &r_n_flag, double (&m)[16])
+{
+	r_n_flag = *s_step;
+	asm volatile("" ::: "memory"); // (the compiler keeps the reads below behind the counter's)
+	#pragma unroll
+	for(int c = K + 1; c < 16; ++ c)
+		m[c] = s_mult[K * 16 + c];
+	asm volatile("" ::: "memory");
+}
+// step K and the ones behind it; b_rows: the rows below the block (v = a row's entries of the panel: v[c] += v[K] m_K(c)),
+// else the columns of the inverse (v = a column: v[r] += m_K(r) v[K]) -- the same arithmetic on different data
+template <int K>
+__device__ __forceinline__ void potrf_follow(double (&v)[16], double (&m)[16], int n_flag, const lds_f64 *s_mult, volatile lds_i32 *s_step)
+{
+	if constexpr(K < 15) {
+		if(n_flag < K + 1) { // (wave-uniform) asked too early: wait for the step, then ask again
+			potrf_wait_step(s_step, K + 1);
+			potrf_fetch_step<K>(s_mult, s_step, n_flag, m);
+		}
+		double m_next[16];
+		int n_flag_next = 16;
+		if constexpr(K + 1 < 15)
+			potrf_fetch_step<K + 1>(s_mult, s_step, n_flag_next, m_next);
+		#pragma unroll
+		for(int c = K + 1; c < 16; ++ c)
+			v[c] = __builtin_fma(v[K], m[c], v[c]);
+		// (the step's arithmetic stays here: left to itself the compiler sinks the FMAs of several steps below the last wait,
+		// parks their operands in accumulator registers, and the followers finish 2 000 clocks behind the chain)
+		asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+			"+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+		potrf_follow<K + 1>(v, m_next, n_flag_next, s_mult, s_step);
+	}
+}
+
 #ifdef POTRF_STAMPS
-__device__ long long g_potrf_stamps[32];
+__device__ long long g_potrf_stamps[64];
 #endif
 enum { PL = NB + 1, TL = NB / 2 + 1 };
 
@@ -279,10 +389,20 @@ __device__ __forceinline__ v4f64 mfma_tile16(const double *p_A, int a_m, int a_k
 	int K, int lane, v4f64 acc)
 {
 	const int lo = lane & 15, hi = lane >> 4;
-	for(int ks = 0; ks < K; ks += 4) {
-		const double a = p_A[lo * a_m + (ks + hi) * a_k];
-		const double b = p_B[(ks + hi) * b_k + lo * b_n];
-		acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+	// (round 6: the operands of all K steps are requested before the first product -- K is 16 or 32 at every call site -- instead
+	// of an LDS round trip in front of each of the four or eight dependent matrix instructions: 870 -> ~500 clocks for K = 16)
+	double a[8], b[8];
+	#pragma unroll
+	for(int i = 0; i < 8; ++ i) {
+		if(4 * i < K) {
+			a[i] = p_A[lo * a_m + (4 * i + hi) * a_k];
+			b[i] = p_B[(4 * i + hi) * b_k + lo * b_n];
+		}
+	}
+	#pragma unroll
+	for(int i = 0; i < 8; ++ i) {
+		if(4 * i < K)
+			acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[i], acc, 0, 0, 0);
 	}
 	return acc;
 }
@@ -291,12 +411,17 @@ __device__ __forceinline__ v4f64 mfma_tile16(const double *p_A, int a_m, int a_k
 // computed transposed (m = column of S, n = row) so that the read-modify-write runs along rows
 __device__ __forceinline__ void potrf_update_tile(double *s_L, int c0, int ti, int tj, int lane)
 {
-	const v4f64 zero = {0, 0, 0, 0};
-	const v4f64 acc = mfma_tile16(s_L + c0 * PL + 16 * tj, 1, PL, s_L + c0 * PL + 16 * ti, PL, 1, 16, lane, zero);
 	const int lo = lane & 15, hi = lane >> 4;
+	// (the target's entries are requested with the operands and go in as the accumulator: one trip to LDS in front of the
+	// four products instead of one before and one behind them)
+	v4f64 acc;
 	#pragma unroll
 	for(int reg = 0; reg < 4; ++ reg)
-		s_L[(16 * tj + hi + 4 * reg) * PL + 16 * ti + lo] -= acc[reg];
+		acc[reg] = -s_L[(16 * tj + hi + 4 * reg) * PL + 16 * ti + lo];
+	acc = mfma_tile16(s_L + c0 * PL + 16 * tj, 1, PL, s_L + c0 * PL + 16 * ti, PL, 1, 16, lane, acc);
+	#pragma unroll
+	for(int reg = 0; reg < 4; ++ reg)
+		s_L[(16 * tj + hi + 4 * reg) * PL + 16 * ti + lo] = -acc[reg];
 }
 
 // inverse of the 16 x 16 lower triangular diagonal block at b0: lane c < 16 of the calling wave solves column c.
@@ -330,15 +455,18 @@ __device__ __forceinline__ void potrf_invert_block16(const double *s_L, const do
 		s_X[(b0 + r) * PL + b0 + c] = x[r];
 }
 
-enum { POTRF_LDS_DOUBLES = 2 * NB * PL + (NB / 2) * TL + NB };
+enum { POTRF_LDS_DOUBLES = 2 * NB * PL + (NB / 2) * TL + NB + 16 * 16 + 2 }; // (+ the multipliers of a panel's steps and the step counter: potrf_chain_steps)
 
-template <bool b_chol, bool b_inverse>
+template <bool b_chol, bool b_inverse, bool b_pipeline = true>
 __device__ __forceinline__ void potrf_diag_body(double *M, int ld, int kb, int n, double *invL, int *p_flag, double *s_buf)
 {
 	double *s_L = s_buf;                  // the tile, [col][row]
 	double *s_X = s_L + NB * PL;          // its inverse, [row][col]
 	double *s_T = s_X + NB * PL;          // products L21 X11, [row][col]
 	double *s_rd = s_T + (NB / 2) * TL;   // reciprocals of the diagonal of L
+	lds_f64 *s_mult = (lds_f64*)(s_rd + NB);            // the multipliers of the panel's steps, [step][row of the diagonal block]
+	volatile lds_i32 *s_step = (volatile lds_i32*)(s_rd + NB + 16 * 16); // steps of the panel published so far
+	lds_f64 *s_rd_lds = (lds_f64*)s_rd;
 
 	const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
 	const int o = kb * NB;
@@ -362,11 +490,118 @@ __device__ __forceinline__ void potrf_diag_body(double *M, int ld, int kb, int n
 	bool b_bad = false;
 #ifdef POTRF_STAMPS // tools/bench_potrf.hip: where the time of a tile goes (wave 0, lane 0)
 #define POTRF_STAMP(i) do { if(t == 0) { g_potrf_stamps[2 * (i)] = clock64(); g_potrf_stamps[2 * (i) + 1] = wall_clock64(); } } while(0)
+#define POTRF_STAMP_WAVE(i, w) do { if(t == 64 * (w)) { g_potrf_stamps[2 * (i)] = clock64(); g_potrf_stamps[2 * (i) + 1] = wall_clock64(); } } while(0)
 #else
 #define POTRF_STAMP(i) do {} while(0)
+#define POTRF_STAMP_WAVE(i, w) do {} while(0)
 #endif
 	POTRF_STAMP(0);
-	if(b_chol) {
+	if(b_chol && b_pipeline) {
+		for(int J = 0; J < NB / 16; ++ J) {
+			const int c0 = 16 * J, n_below = NB - c0 - 16; // rows below the diagonal block
+			if(t == 0)
+				*s_step = 0;
+			__syncthreads(); // (the counter is down before anybody looks at it; the tile updates of the step before are in)
+			POTRF_STAMP(1 + 3 * J);
+			if(wave == 0) {
+				// the chain: the diagonal block alone (every row of 16 lanes a copy, as before: the DPP broadcasts stay inside a row)
+				const int g = lane & 15;
+				double d[16];
+				#pragma unroll
+				for(int c = 0; c < 16; ++ c)
+					d[c] = s_L[(c0 + c) * PL + c0 + g];
+				double mine_raw = 1.0;
+				const double rw_first = potrf_panel_pivot<0>(d, mine_raw, g);
+				potrf_chain_steps<0>(d, rw_first, mine_raw, g, lane, (volatile lds_f64*)s_mult, s_step);
+				if(J == 0) POTRF_STAMP_WAVE(16, 0);
+				const double mine = __builtin_fmax(mine_raw, 1e-300);
+				double rs = __builtin_amdgcn_rsq(mine);
+				const double h = 0.5 * mine;
+				rs = rs * (1.5 - h * rs * rs);
+				rs = rs * (1.5 - h * rs * rs);
+				*(volatile lds_f64*)(s_rd_lds + c0 + g) = rs; // (every row of 16 lanes the same values to the same places: no mask)
+				*s_step = 17; // (behind the reciprocal square roots: what the followers scale with)
+				asm volatile("" ::: "memory"); // (published here, not below the scaling: the followers are waiting for it)
+				b_bad = b_bad || (!(mine_raw > 0) && c0 + g < n - o); // (past n rides the right-hand side row)
+				{
+					// the block's own columns scaled: the reciprocal square roots come back from LDS, all sixteen in one trip (by DPP
+					// it was sixteen broadcasts with their wait states: 1 150 clocks for this wave to leave the panel)
+					double rs_c[16];
+					#pragma unroll
+					for(int c = 0; c < 16; ++ c)
+						rs_c[c] = s_rd_lds[c0 + c];
+					if(lane < 16) {
+						#pragma unroll
+						for(int c = 0; c < 16; ++ c)
+							s_L[(c0 + c) * PL + c0 + g] = (g >= c)? d[c] * rs_c[c] : 0.0;
+					}
+				}
+				if(J == 0) POTRF_STAMP_WAVE(17, 0);
+			} else if(wave == 1) {
+				if(lane < n_below) { // the rows below the block, a lane a row
+					const int r = c0 + 16 + lane;
+					double a[16];
+					#pragma unroll
+					for(int c = 0; c < 16; ++ c)
+						a[c] = s_L[(c0 + c) * PL + r];
+					{
+						double m[16];
+						int n_flag;
+						potrf_fetch_step<0>(s_mult, s_step, n_flag, m);
+						potrf_follow<0>(a, m, n_flag, s_mult, s_step);
+					}
+					if(J == 0) POTRF_STAMP_WAVE(18, 1);
+					potrf_wait_step(s_step, 17);
+					double rs_c[16]; // (all sixteen requested before the first store: behind a store the compiler waits for each)
+					#pragma unroll
+					for(int c = 0; c < 16; ++ c)
+						rs_c[c] = s_rd_lds[c0 + c];
+					#pragma unroll
+					for(int c = 0; c < 16; ++ c)
+						s_L[(c0 + c) * PL + r] = a[c] * rs_c[c];
+					if(J == 0) POTRF_STAMP_WAVE(19, 1);
+				}
+			} else if(wave == 2) {
+				if(b_inverse && lane < 16) { // the block's inverse, a lane a column: forward substitution with the same multipliers
+					double y[16];
+					#pragma unroll
+					for(int r = 0; r < 16; ++ r)
+						y[r] = (r == lane)? 1.0 : 0.0;
+					{
+						double m[16];
+						int n_flag;
+						potrf_fetch_step<0>(s_mult, s_step, n_flag, m);
+						potrf_follow<0>(y, m, n_flag, s_mult, s_step);
+					}
+					if(J == 0) POTRF_STAMP_WAVE(20, 2);
+					potrf_wait_step(s_step, 17);
+					double rs_r[16];
+					#pragma unroll
+					for(int r = 0; r < 16; ++ r)
+						rs_r[r] = s_rd_lds[c0 + r];
+					#pragma unroll
+					for(int r = 0; r < 16; ++ r)
+						s_X[(c0 + r) * PL + c0 + lane] = y[r] * rs_r[r];
+					if(J == 0) POTRF_STAMP_WAVE(21, 2);
+				}
+			} else if(J > 0) {
+				// wave 3: the panel before this one applied to the tiles right of this panel's columns
+				const int c_prev = c0 - 16;
+				for(int tj = J + 1; tj < NB / 16; ++ tj) {
+					for(int ti = tj; ti < NB / 16; ++ ti)
+						potrf_update_tile(s_L, c_prev, ti, tj, lane);
+				}
+			}
+			__syncthreads();
+			POTRF_STAMP(2 + 3 * J);
+			// the next panel's columns: tiles (ti, J + 1), ti = J + 1 .. 3, one per wave
+			if(J + 1 + wave < NB / 16)
+				potrf_update_tile(s_L, c0, J + 1 + wave, J + 1, lane);
+			POTRF_STAMP(3 + 3 * J);
+		}
+		__syncthreads();
+		POTRF_STAMP(13);
+	} else if(b_chol) {
 		for(int J = 0; J < NB / 16; ++ J) {
 			const int c0 = 16 * J;
 			if(wave == 0) {

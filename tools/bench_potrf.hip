@@ -14,7 +14,7 @@ int main()
 	double *M, *inv; int *flag;
 	hipMalloc(&M, sizeof(double) * n * n); hipMalloc(&inv, sizeof(double) * n * n); hipMalloc(&flag, 4);
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-	for(int variant = 0; variant < 4; ++ variant) {
+	for(int variant = 0; variant < 6; ++ variant) {
 		float best = 1e9;
 		for(int rep = 0; rep < 20; ++ rep) {
 			hipMemcpy(M, h.data(), sizeof(double) * n * n, hipMemcpyHostToDevice);
@@ -24,20 +24,27 @@ int main()
 			case 1: hipLaunchKernelGGL((potrf_diag_variant<true, false>), dim3(1), dim3(256), 0, 0, M, ld, 0, n, inv, flag); break;
 			case 2: hipLaunchKernelGGL((potrf_diag_variant<false, true>), dim3(1), dim3(256), 0, 0, M, ld, 0, n, inv, flag); break;
 			case 3: hipLaunchKernelGGL((potrf_diag_variant<false, false>), dim3(1), dim3(256), 0, 0, M, ld, 0, n, inv, flag); break;
+			case 4: hipLaunchKernelGGL((potrf_diag_variant<true, true, false>), dim3(1), dim3(256), 0, 0, M, ld, 0, n, inv, flag); break; // round 5's one-wave panels
+			case 5: hipLaunchKernelGGL((potrf_diag_variant<true, false, false>), dim3(1), dim3(256), 0, 0, M, ld, 0, n, inv, flag); break;
 			}
 			hipEventRecord(e1); hipEventSynchronize(e1);
 			float ms; hipEventElapsedTime(&ms, e0, e1); if(ms < best) best = ms;
 		}
-		printf("variant chol=%d inv=%d: %.2f us\n", variant < 2, variant % 2 == 0, best * 1e3);
+		printf("variant chol=%d inv=%d%s: %.2f us\n", variant < 2 || variant >= 4, variant % 2 == 0, (variant >= 4)? " (one-wave panels, round 5)" : "", best * 1e3);
 #ifdef POTRF_STAMPS
-		if(variant < 2) {
-			long long st[32];
+		if(variant < 2 || variant >= 4) {
+			long long st[64];
 			hipMemcpyFromSymbol(st, HIP_SYMBOL(slampp::g_potrf_stamps), sizeof(st));
 			for(int i = 1; i < 15; ++ i)
 				printf("  stamp %2d: +%6lld cycles, +%6lld ns\n", i, st[2 * i] - st[2 * (i - 1)], (st[2 * i + 1] - st[2 * (i - 1) + 1]) * 10);
+			if(variant < 2) { // the three waves of the first panel against its start (stamp 1), by the wall clock (the waves' own clocks are not one clock)
+				const char *p_s_what[6] = {"chain through", "chain wave done", "rows: steps through", "rows done", "inverse: steps through", "inverse done"};
+				for(int i = 16; i < 22; ++ i)
+					printf("  panel 0, %-24s +%6lld ns\n", p_s_what[i - 16], (st[2 * i + 1] - st[2 * 1 + 1]) * 10);
+			}
 		}
 #endif
-		if(variant == 0) { // against a host Cholesky, and inv * L = I
+		if(variant == 0 || variant == 4) { // against a host Cholesky, and inv * L = I
 			std::vector<double> L(n * n), X(n * n), R = h;
 			hipMemcpy(L.data(), M, sizeof(double) * n * n, hipMemcpyDeviceToHost);
 			hipMemcpy(X.data(), inv, sizeof(double) * n * n, hipMemcpyDeviceToHost);

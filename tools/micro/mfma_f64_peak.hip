@@ -237,6 +237,71 @@ static void run(double *out, TWgRecord *d_rec, int n_waves_per_simd, const char 
 		double(n_wgs) * 4 * n_iter * N * f_flops_per_instr / best / 1e9, f_slot_own, f_slot_wall, 100 * (f_slot_wall / f_slot_own - 1), f_mhz);
 }
 
+
+// the shape a product kernel has: RA + RB operands in registers, RA x RB accumulators, every instruction another pair
+template <int RA, int RB>
+__global__ void __launch_bounds__(256) mfma_outer_loop(double *out, TWgRecord *p_rec, int n_iter, double a0, double b0)
+{
+	extern __shared__ double s_pad[];
+	const long long n_w0 = wall_clock64(), n_c0 = clock64();
+	double acc[RA][RB], a[RA], b[RB];
+	#pragma unroll
+	for(int i = 0; i < RA; ++ i)
+		a[i] = a0 + threadIdx.x + i;
+	#pragma unroll
+	for(int j = 0; j < RB; ++ j)
+		b[j] = b0 - j;
+	#pragma unroll
+	for(int i = 0; i < RA; ++ i)
+		#pragma unroll
+		for(int j = 0; j < RB; ++ j)
+			acc[i][j] = 0;
+	for(int it = 0; it < n_iter; ++ it) {
+		#pragma unroll
+		for(int i = 0; i < RA; ++ i)
+			#pragma unroll
+			for(int j = 0; j < RB; ++ j)
+				acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+	}
+	double s = 0;
+	#pragma unroll
+	for(int i = 0; i < RA; ++ i)
+		#pragma unroll
+		for(int j = 0; j < RB; ++ j)
+			s += acc[i][j];
+	const long long n_c1 = clock64(), n_w1 = wall_clock64();
+	if(threadIdx.x == 0) {
+		TWgRecord r;
+		r.n_start = n_w0; r.n_end = n_w1; r.n_clocks = n_c1 - n_c0; r.n_hw_id = 0; r.n_pad = 0;
+		p_rec[blockIdx.x] = r;
+	}
+	if(s == 12345.678)
+		out[threadIdx.x] = s + s_pad[threadIdx.x];
+}
+
+template <int RA, int RB>
+static void run_outer(double *out, TWgRecord *d_rec, int n_waves_per_simd)
+{
+	hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	const int n_wgs = 256 * n_waves_per_simd, n_iter = 16384 * 8 / (RA * RB);
+	const int n_lds = (160 * 1024 / n_waves_per_simd) / 1024 * 1024 - 1024;
+	auto p_kernel = mfma_outer_loop<RA, RB>;
+	(void)hipFuncSetAttribute(reinterpret_cast<const void*>(p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, n_lds);
+	hipFuncAttributes t_attr;
+	(void)hipFuncGetAttributes(&t_attr, reinterpret_cast<const void*>(p_kernel));
+	float best = 1e9f;
+	for(int rep = 0; rep < 5; ++ rep) {
+		(void)hipEventRecord(e0);
+		hipLaunchKernelGGL(p_kernel, dim3(n_wgs), dim3(256), n_lds, 0, out, d_rec, n_iter, 1.0, 2.0);
+		(void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+		float ms; (void)hipEventElapsedTime(&ms, e0, e1); if(ms < best) best = ms;
+	}
+	const double f_instr_per_simd = double(n_wgs) * 4 * double(n_iter) * RA * RB / 1024.0;
+	printf("v_mfma_f64_4x4x4_4b, %d x %d accumulators from %d + %d operands, %d waves/SIMD, %3d VGPRs: %7.1f us, %5.1f TFLOP/s, %5.1f clocks per instruction per SIMD at 2.4 GHz\n",
+		RA, RB, RA, RB, n_waves_per_simd, int(t_attr.numRegs), best * 1e3, double(n_wgs) * 4 * double(n_iter) * RA * RB * 512.0 / best / 1e9,
+		best * 1e-3 * 2.4e9 / f_instr_per_simd);
+}
+
 int main()
 {
 	double *out; (void)hipMalloc(&out, 4096);
@@ -261,6 +326,11 @@ int main()
 	run<8, KIND_4x4x4>(out, d_rec, 4, "v_mfma_f64_4x4x4_4b");
 	run<16, KIND_4x4x4>(out, d_rec, 4, "v_mfma_f64_4x4x4_4b");
 	run<8, KIND_4x4x4>(out, d_rec, 8, "v_mfma_f64_4x4x4_4b");
+	run_outer<2, 4>(out, d_rec, 1);
+	run_outer<4, 4>(out, d_rec, 1);
+	run_outer<4, 4>(out, d_rec, 2);
+	run_outer<8, 8>(out, d_rec, 1);
+	run_outer<8, 8>(out, d_rec, 2);
 	run_fma<8>(out, 256);
 	run_fma<8>(out, 512);
 	run_fma<8>(out, 1024);
