@@ -440,21 +440,37 @@ backward_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__res
 	if(int(threadIdx.x) >= W)
 		return; // (no barrier below)
 	const long long *T = s_tab + threadIdx.x;
+	// x of the task's own columns stays in LDS (round 6): a column's x is what the columns before it in the task multiply their
+	// blocks with, and through memory that was a store and a load of the same thread through L2 per column -- the longest
+	// waits of a kernel that waits 84 % of its time (tools/pmc_waits.sh c3).  Rows outside the task (the separators above,
+	// solved by earlier launches) still come from w.  P[2 + n_cols + b]: which of the task's columns the row of block b is, or -1.
+	double *s_x = reinterpret_cast<double*>(s_tab + (3 * n_cols + n_below) * W) + threadIdx.x;
+	const int32_t *p_local = P + 2 + n_cols;
 	int n_blk_end = n_below;
 	double f_touched = 0;
 	for(int ci = n_cols - 1; ci >= 0; -- ci) {
 		const int nb = P[2 + ci];
 		const long long l_base = T[W * (3 * ci)], cs_new = T[W * (3 * ci + 1)], cs_src = T[W * (3 * ci + 2)];
 		const int n_blk0 = n_blk_end - (nb - 1);
-		if(ci > 0) { // the next column's blocks: a load per cache line, a column of arithmetic ahead of their use
-			const int nb_next = P[2 + ci - 1];
-			const double *p_next = L + T[W * (3 * (ci - 1))];
-			for(int kb = 0; kb < nb_next; ++ kb)
-				f_touched += p_next[kb * DD] + p_next[kb * DD + 16] + p_next[kb * DD + DD - 1];
-		}
 		double acc[D], a[D][D];
 		load_column<D>(w + cs_new, acc); // y_j
 		load_block<D>(L + l_base, a);    // a[q][r] = L_jj(r, q)
+		// The blocks of the column after next: a load per cache line, two columns of arithmetic ahead of their use -- and BEHIND
+		// this column's own first loads (round 6).  Loads come back in the order they were issued (one counter): requested in
+		// front of the column's own loads, as they were, the touches -- misses all the way to HBM -- were what every column's own,
+		// long-arrived data waited behind.  Two columns ahead, because the next column's own loads queue behind these.
+		asm volatile("" ::: "memory");
+		double f_touch_now = 0;
+		if(ci > 1 || (ci == n_cols - 1 && ci > 0)) {
+			const int c_first = (ci > 1)? ci - 2 : ci - 1, c_last = (ci == n_cols - 1)? ci - 1 : c_first; // (the first column handled touches both)
+			for(int c = c_last; c >= c_first; -- c) {
+				const int nb_next = P[2 + c];
+				const double *p_next = L + T[W * (3 * c)];
+				for(int kb = 0; kb < nb_next; ++ kb)
+					f_touch_now += p_next[kb * DD] + p_next[kb * DD + 16] + p_next[kb * DD + DD - 1];
+			}
+		}
+		asm volatile("" ::: "memory");
 		double rd[D];
 		#pragma unroll
 		for(int q = 0; q < D; ++ q) {
@@ -466,9 +482,15 @@ backward_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__res
 		}
 		for(int kb = 1; kb < nb; ++ kb) {
 			const long long xcs = T[W * (3 * n_cols + n_blk0 + kb - 1)];
+			const int n_local = p_local[n_blk0 + kb - 1]; // (wave-uniform)
 			double c[D][D], xi[D];
 			load_block<D>(L + l_base + kb * DD, c); // c[q][r] = L(i,j)(r, q)
-			load_column<D>(w + xcs, xi);
+			if(n_local >= 0) {
+				#pragma unroll
+				for(int r = 0; r < D; ++ r)
+					xi[r] = s_x[(n_local * D + r) * W];
+			} else
+				load_column<D>(w + xcs, xi);
 			#pragma unroll
 			for(int q = 0; q < D; ++ q) {
 				#pragma unroll
@@ -485,6 +507,10 @@ backward_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__res
 				sum -= a[q][r] * x[r];
 			x[q] = sum * rd[q];
 		}
+		#pragma unroll
+		for(int q = 0; q < D; ++ q)
+			s_x[(ci * D + q) * W] = x[q];
+		f_touched += f_touch_now; // (used here: nothing of this column waits for the touches)
 		if(D % 2 == 0) {
 			#pragma unroll
 			for(int q = 0; q < D; q += 2) {

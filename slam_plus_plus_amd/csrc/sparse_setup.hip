@@ -1043,6 +1043,20 @@ void slampp_hip_solver::Build_Simt()
 				for(size_t k = 0; k < tt.ys.size(); ++ k)
 					y_index[tt.ys[k]] = -1;
 				const int32_t n_cols = int32_t(P.task_ptr[t + 1] - P.task_ptr[t]);
+				// (round 6) behind the program proper: for every block below a diagonal, which of the task's columns its row is, or
+				// -1 for a row outside the task -- what the backward kernel keeps x of in LDS.  Implied by the program (a block whose
+				// row is column m of the task is a row entry of m), and part of the shape's key all the same
+				for(int64_t i = P.task_ptr[t]; i < P.task_ptr[t + 1] && b_fits; ++ i) {
+					const int32_t j = P.task_cols[i];
+					for(int64_t k = P.lptr[j] + 1; k < P.lptr[j + 1]; ++ k) {
+						int32_t n_local = -1;
+						for(int64_t i2 = i + 1; i2 < P.task_ptr[t + 1] && n_local < 0; ++ i2) {
+							if(P.task_cols[i2] == P.lrow[k])
+								n_local = int32_t(i2 - P.task_ptr[t]);
+						}
+						prog.push_back(n_local);
+					}
+				}
 				prog[0] = n_cols;
 				prog[1] = n_blocks;
 				prog[2] = int32_t(tt.ops.size());
@@ -1104,13 +1118,15 @@ void slampp_hip_solver::Build_Simt()
 			// the shape's backward program: n_cols, blocks below the diagonals, nb per column
 			const int32_t n_bwd_prog_off = int32_t(simt_host_bwd_prog.size());
 			const int n_bwd_fields = 3 * n_cols + (n_blocks - n_cols);
-			n_stage_bwd_lds = std::max(n_stage_bwd_lds, int32_t(n_bwd_fields * W * 8));
+			n_stage_bwd_lds = std::max(n_stage_bwd_lds, int32_t((n_bwd_fields + n_cols * P.max_dim) * W * 8)); // (the table, and x of the task's own columns)
 			simt_host_bwd_prog.push_back(n_cols);
 			simt_host_bwd_prog.push_back(n_blocks - n_cols);
 			{
 				const TTask &tt = tasks_all[size_t(r_members[0])];
 				for(int64_t i = P.task_ptr[tt.n_task]; i < P.task_ptr[tt.n_task + 1]; ++ i)
 					simt_host_bwd_prog.push_back(int32_t(P.lptr[P.task_cols[i] + 1] - P.lptr[P.task_cols[i]]));
+				// which of the task's columns every below-diagonal block's row is (the tail of the forward program: see there)
+				simt_host_bwd_prog.insert(simt_host_bwd_prog.end(), prog.end() - (n_blocks - n_cols), prog.end());
 			}
 			for(size_t n_first = 0; n_first < r_members.size(); n_first += W) {
 				const size_t n_in_chunk = std::min<size_t>(W, r_members.size() - n_first);
