@@ -340,6 +340,19 @@ typedef struct slampp_hip_phase_time {
 int slampp_hip_get_profile(slampp_hip_solver *p_solver, slampp_hip_phase_time *p_phases, int n_max_phases,
 	int *p_phase_num, int b_reset);
 
+/* The same totals under the names the reference prints with __SCHUR_PROFILING (LinearSolver_Schur.h:1681-1912, in its order):
+ *   "reperm", "slice", "transpose"   always 0: the packed block-CSC with the cameras first is [A U; C] already
+ *   "inverse + multiply + add"       C^-1, U C^-1, (U C^-1) U^T and A - ... are one pass here (schur_init + schur_tiles /
+ *                                    schur_points + schur_gather); the reference's lines "inverse", "diag gemm", "scale",
+ *                                    "gemm" and "add" added up are its counterpart
+ *   "RHS prep"                       schur_rhs (zero where the landmark-major assembly forms the right-hand side on its way)
+ *   "cholsol"                        reduced_sparse, or dense_chol + dense_solve
+ *   "dy solve"                       backsubst
+ * and, in sparse mode, CHOLMOD's two numeric phases (LinearSolver_CholMod.cpp:322-347): "factorize" (with the forward
+ * substitution, which is fused into it) and "solve" (the backward one).  Nothing is reset by this call. */
+int slampp_hip_get_profile_reference_names(slampp_hip_solver *p_solver, slampp_hip_phase_time *p_phases, int n_max_phases,
+	int *p_phase_num);
+
 /* Lambda and eta assembled on the device from per-edge Jacobians (first row after the
  * solve): replaces the host loop that computes every edge's Hessian blocks and the reduction that sums
  * them into Lambda (include/slam/BaseTypes_Binary.h:759-840 Calculate_Hessians_v2,

@@ -1299,6 +1299,58 @@ int slampp_hip_get_profile(slampp_hip_solver *p_solver, slampp_hip_phase_time *p
 	return SLAMPP_HIP_OK;
 }
 
+int slampp_hip_get_profile_reference_names(slampp_hip_solver *p_solver, slampp_hip_phase_time *p_phases, int n_max_phases,
+	int *p_phase_num)
+{
+	if(!p_solver || !p_phase_num)
+		return SLAMPP_HIP_ERR_INVALID;
+	if(p_solver->b_group_active)
+		return slampp_hip_get_profile_reference_names(group_member(*p_solver->p_group, 0), p_phases, n_max_phases, p_phase_num);
+	const slampp_hip_solver &s = *p_solver;
+	auto Sum = [&s](std::initializer_list<const char*> names, int64_t &r_n_count) {
+		double f_ms = 0;
+		r_n_count = 0;
+		for(const char *p_s_name : names) {
+			for(size_t i = 0; i < s.phase_names.size(); ++ i) {
+				if(s.phase_names[i] == p_s_name) {
+					f_ms += s.phase_ms[i];
+					r_n_count = std::max(r_n_count, s.phase_count[i]);
+				}
+			}
+		}
+		return f_ms;
+	};
+	struct TLine { const char *p_s_name; double f_ms; int64_t n_count; };
+	std::vector<TLine> lines;
+	int64_t n = 0;
+	if(s.n_mode == SLAMPP_HIP_MODE_SCHUR && !s.b_schur_fallback) {
+		lines.push_back(TLine{"reperm", 0, 0});
+		lines.push_back(TLine{"slice", 0, 0});
+		lines.push_back(TLine{"transpose", 0, 0});
+		double f = Sum({"schur_init", "schur_tiles", "schur_points", "schur_gather"}, n);
+		lines.push_back(TLine{"inverse + multiply + add", f, n});
+		f = Sum({"schur_rhs"}, n);
+		lines.push_back(TLine{"RHS prep", f, n});
+		f = Sum({"reduced_sparse", "dense_chol", "dense_solve"}, n);
+		lines.push_back(TLine{"cholsol", f, n});
+		f = Sum({"backsubst"}, n);
+		lines.push_back(TLine{"dy solve", f, n});
+	} else {
+		double f = Sum({"factor_leaves", "factor_rest", "factor_wide", "factor_upper", "forward"}, n);
+		lines.push_back(TLine{"factorize", f, n});
+		f = Sum({"backward"}, n);
+		lines.push_back(TLine{"solve", f, n});
+	}
+	*p_phase_num = int(lines.size());
+	for(int i = 0; i < *p_phase_num && i < n_max_phases && p_phases; ++ i) {
+		memset(p_phases[i].name, 0, sizeof(p_phases[i].name));
+		strncpy(p_phases[i].name, lines[size_t(i)].p_s_name, sizeof(p_phases[i].name) - 1);
+		p_phases[i].n_count = lines[size_t(i)].n_count;
+		p_phases[i].f_total_ms = lines[size_t(i)].f_ms;
+	}
+	return SLAMPP_HIP_OK;
+}
+
 int slampp_hip_set_allreduce(slampp_hip_solver *p_solver, slampp_hip_allreduce_fn p_fn, void *p_context)
 {
 	if(!p_solver)

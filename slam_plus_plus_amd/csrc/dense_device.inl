@@ -295,10 +295,10 @@ __device__ __forceinline__ void potrf_chain_update(double (&d)[16], double ntd)
 }
 // potrf_panel_pivot for a pivot that sits in lane K of every row of 16 lanes in `v` (other lanes: anything)
 template <int K>
-__device__ __forceinline__ double potrf_chain_pivot(double v, double &r_mine, int g)
+__device__ __forceinline__ double potrf_chain_pivot(double v, lds_f64 *s_piv)
 {
 	const double piv_raw = dpp_row_bcast<K>(v);
-	r_mine = (g == K)? piv_raw : r_mine;
+	s_piv[K] = piv_raw; // (kept for the scaling behind the chain: lane g reads pivot g back -- a select per step was sixteen masks in scalar registers and two instructions a step on the chain)
 	double piv;
 	asm volatile("v_max_f64 %0, %1, %2" : "=v"(piv) : "v"(piv_raw), "v"(1e-300)); // (one instruction: __builtin_fmax puts a canonicalizing v_max in front)
 	double rw = __builtin_amdgcn_rcp(piv);
@@ -307,7 +307,7 @@ __device__ __forceinline__ double potrf_chain_pivot(double v, double &r_mine, in
 	return rw;
 }
 template <int K>
-__device__ __forceinline__ void potrf_chain_steps(double (&d)[16], double rw, double &r_mine, int g, int lane,
+__device__ __forceinline__ void potrf_chain_steps(double (&d)[16], double rw, lds_f64 *s_piv, int g,
 	volatile lds_f64 *s_mult, volatile lds_i32 *s_step)
 {
 	const double ntd = -(d[K] * rw); // lane g: -D(g, k) / d_k
@@ -319,10 +319,10 @@ __device__ __forceinline__ void potrf_chain_steps(double (&d)[16], double rw, do
 		// the broadcast of its diagonal entry: a dependent DPP operation is 16 clocks plus its wait states, and the chain is
 		// made of nothing but latencies (the column's update itself follows below, off the chain)
 		const double t_diag = __builtin_fma(d[K], ntd, d[K + 1]);
-		const double rw_next = potrf_chain_pivot<K + 1>(t_diag, r_mine, g);
+		const double rw_next = potrf_chain_pivot<K + 1>(t_diag, s_piv);
 		dpp_fmac_row_bcast<K + 1, true>(d[K + 1], d[K], ntd);
 		potrf_chain_update<K, K + 2>(d, ntd);
-		potrf_chain_steps<K + 1>(d, rw_next, r_mine, g, lane, s_mult, s_step);
+		potrf_chain_steps<K + 1>(d, rw_next, s_piv, g, s_mult, s_step);
 	} else
 		*s_step = 16; // (the last column has nothing below it: the followers only need to know the chain is through)
 }
@@ -510,10 +510,10 @@ __device__ __forceinline__ void potrf_diag_body(double *M, int ld, int kb, int n
 				#pragma unroll
 				for(int c = 0; c < 16; ++ c)
 					d[c] = s_L[(c0 + c) * PL + c0 + g];
-				double mine_raw = 1.0;
-				const double rw_first = potrf_panel_pivot<0>(d, mine_raw, g);
-				potrf_chain_steps<0>(d, rw_first, mine_raw, g, lane, (volatile lds_f64*)s_mult, s_step);
+				const double rw_first = potrf_chain_pivot<0>(d[0], s_rd_lds + c0); // (the raw pivots wait in s_rd for the scaling)
+				potrf_chain_steps<0>(d, rw_first, s_rd_lds + c0, g, (volatile lds_f64*)s_mult, s_step);
 				if(J == 0) POTRF_STAMP_WAVE(16, 0);
+				const double mine_raw = s_rd_lds[c0 + g];
 				const double mine = __builtin_fmax(mine_raw, 1e-300);
 				double rs = __builtin_amdgcn_rsq(mine);
 				const double h = 0.5 * mine;

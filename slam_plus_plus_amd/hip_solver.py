@@ -132,6 +132,7 @@ ABI = {
     "slampp_hip_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "slampp_hip_get_reduced_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "slampp_hip_get_profile": (C.c_int, [_P, C.POINTER(PhaseTime), C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "slampp_hip_get_profile_reference_names": (C.c_int, [_P, C.POINTER(PhaseTime), C.c_int, C.POINTER(C.c_int)]),
     "slampp_hip_set_allreduce": (C.c_int, [_P, ALLREDUCE_FN, _P]),
     "slampp_hip_assembly_create": (C.c_int, [_P, C.POINTER(_P), C.c_int64, _P, _P, C.c_int]),
     "slampp_hip_assembly_destroy": (None, [_P]),
@@ -473,6 +474,14 @@ class _SolverBase:
         n = C.c_int(0)
         self._check(self._lib.slampp_hip_get_profile(self._h, buf, 32, C.byref(n), int(reset)))
         return {buf[i].name.decode(): (int(buf[i].n_count), float(buf[i].f_total_ms)) for i in range(min(n.value, 32))}
+
+    def profile_reference_names(self) -> dict:
+        """The same totals under the names the reference prints with __SCHUR_PROFILING (LinearSolver_Schur.h:1895-1912) /
+        CHOLMOD's numeric phases: {name: (count, total_ms)}, in the reference's order (slampp_hip_get_profile_reference_names)."""
+        buf = (PhaseTime * 16)()
+        n = C.c_int(0)
+        self._check(self._lib.slampp_hip_get_profile_reference_names(self._h, buf, 16, C.byref(n)))
+        return {buf[i].name.decode(): (int(buf[i].n_count), float(buf[i].f_total_ms)) for i in range(min(n.value, 16))}
 
     def plan(self) -> dict:
         def getter(v):
