@@ -530,201 +530,12 @@ backward_simt_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__res
 		w[0] = f_touched;
 }
 
-// The same substitution with every load of a column made by the whole wave (round 6, even D).  In backward_simt_kernel a
-// lane fetches its own blocks 16 bytes at a time: every instruction touches as many cache lines as it has lanes, and 18 of them
-// fetch one 288-byte block (2.25 lines) per lane.  Here the wave's lanes share the fetch: 18 lanes a block, three tasks an
-// instruction, straight into LDS (loads that write LDS: no registers, no LDS stores), every line requested once; then each
-// lane reads its own blocks from LDS.  One region, reused column after column: the next column is requested when this one's
-// data is in registers.  Blocks of a column lie next to each other in L, so a task's share of a round is one run of bytes.
-typedef __attribute__((address_space(3))) double lds_f64_t;
-typedef __attribute__((address_space(3))) const long long lds_ci64_t;
-
-// N_P 16-byte pieces a task, from p_base + (offset of the task, in doubles, out of the LDS table row p_off): tasks side by side,
-// 64 / N_P of them an instruction, a piece of padding between the instructions' shares (bank spread of the per-lane reads)
-template <int N_P, int W>
-struct TSimtStage {
-	enum { TPI = 64 / N_P, G = (W + TPI - 1) / TPI, GS = TPI * N_P + 1, n_region_doubles = G * GS * 2 };
-	static __device__ __forceinline__ void Issue(const double *p_base, lds_ci64_t *p_off, lds_f64_t *p_region)
-	{
-		const int j = int(threadIdx.x) / N_P, p = int(threadIdx.x) - j * N_P;
-		(void)p; // (the host pass)
-		#pragma unroll 4
-		for(int g = 0; g < G; ++ g) {
-			const int t = g * TPI + j;
-			if(j < TPI && t < W) {
-#if defined(__HIP_DEVICE_COMPILE__)
-				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p_base + p_off[t] + 2 * p),
-					(__attribute__((address_space(3))) void*)(p_region + g * GS * 2), 16, 0, 0);
-#endif
-			}
-		}
-	}
-	static __device__ __forceinline__ const lds_f64_t *p_Mine(const lds_f64_t *p_region, int t) // where task t's share lies
-	{
-		return p_region + ((t / TPI) * GS + (t % TPI) * N_P) * 2;
-	}
-};
-
-template <int N, class T>
-__device__ __forceinline__ void lds_read_doubles(const lds_f64_t *p_src, T &r_dst) // N doubles (even), 16 bytes a read
-{
-	typedef double v2f64 __attribute__((ext_vector_type(2)));
-	double *p_dst = &r_dst[0];
-	#pragma unroll
-	for(int i = 0; i < N; i += 2) {
-		const v2f64 v = *reinterpret_cast<const __attribute__((address_space(3))) v2f64*>(p_src + i);
-		p_dst[i] = v.x;
-		p_dst[i + 1] = v.y;
-	}
-}
-
-enum { simt_bwd_round_blocks = 3 }; // blocks of a column fetched at a time (sparse_kernels.h: simt_bwd_staged_lds_bytes)
-
-template <int D, int W>
-__global__ void __launch_bounds__(64)
-backward_simt_staged_kernel(const TSimtChunk *__restrict__ chunks, const int32_t *__restrict__ prog, const long long *__restrict__ tab,
-	const double *__restrict__ L, double *w, double *x_out, TBatch t_batch)
-{	{ const int64_t n_member = blockIdx.y; L += n_member * t_batch.l; w += n_member * t_batch.w; x_out += n_member * t_batch.b; } // (TBatch: sparse_kernels.h)
-
-	enum { DD = D * D, VP = D / 2, BP = DD / 2, RB = simt_bwd_round_blocks };
-	typedef TSimtStage<VP, W> CVec;
-	typedef TSimtStage<BP, W> CBlk1;
-	typedef TSimtStage<2 * BP, W> CBlk2;
-	typedef TSimtStage<3 * BP, W> CBlk3;
-	extern __shared__ __attribute__((aligned(16))) long long s_tab[];
-	const TSimtChunk ch = chunks[blockIdx.x];
-	const int32_t *P = prog + ch.prog_off; // wave-uniform: scalar loads
-	const int n_cols = P[0], n_below = P[1];
-	{
-		const int n_entries = (3 * n_cols + n_below) * W;
-		for(int i = threadIdx.x; i < n_entries; i += 64)
-			s_tab[i] = tab[ch.tab_off + i];
-		__syncthreads();
-	}
-	const bool b_task = int(threadIdx.x) < W; // the other lanes only fetch
-	const int n_task = b_task? int(threadIdx.x) : 0;
-	lds_ci64_t *p_tab = (lds_ci64_t*)s_tab;
-	lds_ci64_t *T = p_tab + n_task;
-	lds_f64_t *s_x = (lds_f64_t*)(s_tab + (3 * n_cols + n_below) * W) + n_task;
-	lds_f64_t *s_vec = (lds_f64_t*)(s_tab + (3 * n_cols + n_below) * W) + n_cols * D * W; // y, then x of up to RB rows outside the task
-	lds_f64_t *s_blk = s_vec + (1 + RB) * CVec::n_region_doubles;
-	const int32_t *p_local = P + 2 + n_cols;
-
-	// a round of column c: blocks kb0 .. kb0 + n - 1 of it (block 0 is the diagonal block), y with the first round, and x of
-	// the rows of the round's blocks that lie outside the task
-#define BWD_ISSUE_ROUND(c_, kb0_, n_, n_blk0_) do { \
-		lds_ci64_t *p_lbase = p_tab + W * (3 * (c_)); \
-		const double *p_src = L + (kb0_) * DD; \
-		if((n_) == 1) CBlk1::Issue(p_src, p_lbase, s_blk); else if((n_) == 2) CBlk2::Issue(p_src, p_lbase, s_blk); else CBlk3::Issue(p_src, p_lbase, s_blk); \
-		if((kb0_) == 0) \
-			CVec::Issue(w, p_tab + W * (3 * (c_) + 1), s_vec); \
-		for(int kb = max((kb0_), 1); kb < (kb0_) + (n_); ++ kb) { \
-			if(p_local[(n_blk0_) + kb - 1] < 0) \
-				CVec::Issue(w, p_tab + W * (3 * n_cols + (n_blk0_) + kb - 1), s_vec + (1 + kb - (kb0_)) * CVec::n_region_doubles); \
-		} \
-	} while(0)
-#define BWD_WAIT_LOADS() do { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while(0) // vmcnt(0)
-#define BWD_WAIT_LDS() do { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); } while(0) // lgkmcnt(0)
-
-	int n_blk_end = n_below;
-	{
-		const int nb = P[2 + n_cols - 1];
-		BWD_ISSUE_ROUND(n_cols - 1, 0, min(nb, int(RB)), n_blk_end - (nb - 1));
-	}
-	for(int ci = n_cols - 1; ci >= 0; -- ci) {
-		const int nb = P[2 + ci];
-		const int n_blk0 = n_blk_end - (nb - 1);
-		double acc[D], a[D][D], rd[D];
-		for(int kb0 = 0; kb0 < nb; kb0 += RB) {
-			const int n_round = min(nb - kb0, int(RB));
-			if(kb0 > 0) {
-				BWD_WAIT_LDS(); // (the region's last readers)
-				BWD_ISSUE_ROUND(ci, kb0, n_round, n_blk0);
-			}
-			BWD_WAIT_LOADS();
-			if(b_task) {
-				const lds_f64_t *p_mine = (n_round == 1)? CBlk1::p_Mine(s_blk, n_task) : (n_round == 2)? CBlk2::p_Mine(s_blk, n_task) : CBlk3::p_Mine(s_blk, n_task);
-				if(kb0 == 0) {
-					lds_read_doubles<D>(CVec::p_Mine(s_vec, n_task), acc); // y_j
-					lds_read_doubles<DD>(p_mine, reinterpret_cast<double (&)[DD]>(a)); // a[q][r] = L_jj(r, q)
-					#pragma unroll
-					for(int q = 0; q < D; ++ q) {
-						const double d = a[q][q];
-						double r = __builtin_amdgcn_rcp(d);
-						r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-						r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-						rd[q] = r;
-					}
-				}
-				for(int kb = max(kb0, 1); kb < kb0 + n_round; ++ kb) {
-					const int n_local = p_local[n_blk0 + kb - 1]; // (wave-uniform)
-					double c[D][D], xi[D];
-					lds_read_doubles<DD>(p_mine + (kb - kb0) * DD, reinterpret_cast<double (&)[DD]>(c)); // c[q][r] = L(i,j)(r, q)
-					if(n_local >= 0) {
-						#pragma unroll
-						for(int r = 0; r < D; ++ r)
-							xi[r] = s_x[(n_local * D + r) * W];
-					} else
-						lds_read_doubles<D>(CVec::p_Mine(s_vec + (1 + kb - kb0) * CVec::n_region_doubles, n_task), xi);
-					#pragma unroll
-					for(int q = 0; q < D; ++ q) {
-						#pragma unroll
-						for(int r = 0; r < D; ++ r)
-							acc[q] -= c[q][r] * xi[r];
-					}
-				}
-			}
-		}
-		// the next column's first round: requested before this column's own chain of six
-		BWD_WAIT_LDS();
-		if(ci > 0) {
-			const int nb_next = P[2 + ci - 1];
-			BWD_ISSUE_ROUND(ci - 1, 0, min(nb_next, int(RB)), n_blk0 - (nb_next - 1));
-		}
-		if(b_task) {
-			const long long cs_new = T[W * (3 * ci + 1)], cs_src = T[W * (3 * ci + 2)];
-			double x[D];
-			#pragma unroll
-			for(int q = D - 1; q >= 0; -- q) {
-				double sum = acc[q];
-				#pragma unroll
-				for(int r = q + 1; r < D; ++ r)
-					sum -= a[q][r] * x[r];
-				x[q] = sum * rd[q];
-			}
-			#pragma unroll
-			for(int q = 0; q < D; ++ q)
-				s_x[(ci * D + q) * W] = x[q];
-			#pragma unroll
-			for(int q = 0; q < D; q += 2) {
-				*reinterpret_cast<double2*>(w + cs_new + q) = double2{x[q], x[q + 1]};
-				*reinterpret_cast<double2*>(x_out + cs_src + q) = double2{x[q], x[q + 1]};
-			}
-		}
-		n_blk_end = n_blk0;
-	}
-#undef BWD_ISSUE_ROUND
-#undef BWD_WAIT_LOADS
-#undef BWD_WAIT_LDS
-}
-
-bool simt_bwd_staged(int n_dim)
-{
-	return n_dim == 6 && dev_knob("SLAMPP_HIP_DEV_SIMT_BWD_STAGED", 0) != 0; // development aid (plan.h): 0 = a lane fetches its own blocks
-}
-
 bool launch_backward_simt(const TSimtChunk *chunks, int n_chunks, int n_width, int n_lds_bytes, const int32_t *prog, const int64_t *tab,
-	int n_dim, const double *L, double *w, double *x_out, hipStream_t stream, const TBatch &t_batch, bool b_staged)
+	int n_dim, const double *L, double *w, double *x_out, hipStream_t stream, const TBatch &t_batch)
 {
 	if(n_chunks <= 0)
 		return true;
 	const long long *t = reinterpret_cast<const long long*>(tab);
-	if(n_dim == 6 && b_staged) {
-#define BWD_STAGED(W_) hipLaunchKernelGGL((backward_simt_staged_kernel<6, W_>), dim3(n_chunks, t_batch.n), dim3(64), n_lds_bytes, stream, chunks, prog, t, L, w, x_out, t_batch)
-		if(n_width == 16) BWD_STAGED(16); else if(n_width == 32) BWD_STAGED(32); else BWD_STAGED(64);
-#undef BWD_STAGED
-		return true;
-	}
 #define BWD_LAUNCH(D_, W_) hipLaunchKernelGGL((backward_simt_kernel<D_, W_>), dim3(n_chunks, t_batch.n), dim3(64), n_lds_bytes, stream, chunks, prog, t, L, w, x_out, t_batch)
 #define BWD_WIDTHS(D_) do { if(n_width == 16) BWD_LAUNCH(D_, 16); else if(n_width == 32) BWD_LAUNCH(D_, 32); else BWD_LAUNCH(D_, 64); } while(0)
 	switch(n_dim) {

@@ -197,7 +197,6 @@ struct slampp_hip_solver {
 	slampp::CDevArray<int32_t> d_simt_bwd_prog;
 	slampp::CDevArray<int64_t> d_simt_bwd_tab;
 	std::vector<int32_t> simt_bwd_lds_bytes;
-	std::vector<uint8_t> simt_bwd_stage_staged; // per stage: the whole-wave fetch and its LDS regions (sparse_setup.hip)
 	std::vector<slampp::TSimtChunk> simt_host_bwd_chunks;
 	std::vector<int32_t> simt_host_bwd_prog;
 	std::vector<int64_t> simt_host_bwd_tab;
@@ -220,7 +219,6 @@ struct slampp_hip_solver {
 	int n_simt = -1; // option "simt": 1 / -1 = use it where it applies (default), 0 = never
 	int n_wide_min_tasks = 8192; // option "wide_min_tasks": stages with more tasks than this run one wave per task, one tree level per stage (throughput); below, tasks are slices of the tree in LDS (C3: its 7 513-task stage 0.433 -> 0.404 ms as slices; a million poses: 2.31 ms with the 75 000-task stages wide, 2.36 as slices)
 	int n_simt_width = 32; // option "simt_width": tasks per wave (16, 32, 64)
-	bool b_simt_bwd_staged = false; // the lane-per-task substitution fetches with the whole wave (decided where its LDS is sized)
 	int n_simt_stages = 1; // option "simt_stages": how many of the bottom stages it takes (the stages above the leaves hold
 	                       // single separator columns whose operands other waves wrote: no gain there, measured)
 	void Build_Simt(); // throws; host work only

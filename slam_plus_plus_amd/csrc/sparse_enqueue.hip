@@ -175,7 +175,7 @@ void slampp_hip_solver::Enqueue_Sparse(const double *p_values_dev, double *p_rhs
 			// wave-per-task kernel (their factor kernel stored the inverses)
 			const int n_chunks = simt_chunk_ptr[s] - simt_chunk_ptr[s - 1], n_rest = simt_rest_ptr[s] - simt_rest_ptr[s - 1];
 			launch_backward_simt(d_simt_bwd_chunks.p() + simt_chunk_ptr[s - 1], n_chunks, n_simt_width, simt_bwd_lds_bytes[s - 1],
-				d_simt_bwd_prog.p(), d_simt_bwd_tab.p(), P.max_dim, d_L.p(), d_w.p(), p_rhs_dev, stream, t_batch, simt_bwd_stage_staged[s - 1] != 0);
+				d_simt_bwd_prog.p(), d_simt_bwd_tab.p(), P.max_dim, d_L.p(), d_w.p(), p_rhs_dev, stream, t_batch);
 			if(n_rest > 0) {
 				TDevPlan t_rest = dplan;
 				t_rest.task_map = d_simt_rest.p();

@@ -224,23 +224,7 @@ bool launch_factor_simt(const TSimtChunk *chunks, int n_chunks, int n_width /* t
 // column; tables: per column offset of its first factor block, scalar offsets in the workspace and in the caller's vector,
 // then the workspace offset of every sub-diagonal block's row): x_j from L_jj^T directly, no inverse
 bool launch_backward_simt(const TSimtChunk *chunks, int n_chunks, int n_width, int n_lds_bytes, const int32_t *prog, const int64_t *tab,
-	int n_dim, const double *L, double *w, double *x_out, hipStream_t stream, const TBatch &t_batch = t_No_Batch(),
-	bool b_staged = false /* n_lds_bytes includes simt_bwd_staged_lds_bytes() */);
-// whether the substitution of n_dim-dimensional tasks fetches with the whole wave (backward_simt_staged_kernel; even dimensions
-// that have the kernel), and the LDS it takes on top of the table and the tasks' own x: one region for y and for x of the
-// rows outside the task of a round's blocks, one for the blocks of a round (three blocks a round: simt_kernel.hip)
-bool simt_bwd_staged(int n_dim);
-inline int simt_bwd_staged_lds_bytes(int n_width, int n_dim)
-{
-	const int n_vec_pieces = n_dim / 2, n_blk_pieces = n_dim * n_dim / 2, n_round = 3;
-	const int n_vec_per = 64 / n_vec_pieces, n_vec_groups = (n_width + n_vec_per - 1) / n_vec_per;
-	int n_blk_max = 0;
-	for(int n = 1; n <= n_round; ++ n) {
-		const int n_per = 64 / (n * n_blk_pieces), n_groups = (n_width + n_per - 1) / n_per;
-		n_blk_max = (n_groups * (n_per * n * n_blk_pieces + 1) > n_blk_max)? n_groups * (n_per * n * n_blk_pieces + 1) : n_blk_max;
-	}
-	return 16 * ((1 + n_round) * n_vec_groups * (n_vec_per * n_vec_pieces + 1) + n_blk_max);
-}
+	int n_dim, const double *L, double *w, double *x_out, hipStream_t stream, const TBatch &t_batch = t_No_Batch());
 // inv(L_jj) of the columns cols[col_begin .. col_end) (schedule order) from their factor blocks: for callers that need the
 // inverses the lane-per-task factorization did not store (another right-hand side, covariances)
 bool launch_invert_diagonals(const TDevPlan &p, int64_t col_begin, int64_t col_end, const double *L, double *Linv, hipStream_t stream);

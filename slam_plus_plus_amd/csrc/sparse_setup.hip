@@ -948,7 +948,6 @@ void slampp_hip_solver::Build_Simt()
 	simt_lds_bytes.clear();
 	simt_host_chunks.clear(); simt_host_prog.clear(); simt_host_tab.clear(); simt_host_rest.clear();
 	simt_bwd_lds_bytes.clear();
-	simt_bwd_stage_staged.clear();
 	simt_host_bwd_chunks.clear(); simt_host_bwd_prog.clear(); simt_host_bwd_tab.clear();
 	const Plan &P = plan;
 	if(!n_simt || !P.uniform_dim || (P.max_dim != 3 && P.max_dim != 6 && P.max_dim != 7))
@@ -971,7 +970,6 @@ void slampp_hip_solver::Build_Simt()
 	simt_chunk_ptr.push_back(0);
 	simt_rest_ptr.push_back(0);
 	const size_t W = size_t(n_simt_width);
-	b_simt_bwd_staged = simt_bwd_staged(P.max_dim);
 	for(int s = 0; s < n_bottom_stages && s < n_stages && s < n_simt_stages; ++ s) {
 		const int32_t t0 = P.stage_ptr[s], n_stage_tasks = P.stage_ptr[s + 1] - P.stage_ptr[s];
 		const bool b_simt_timing = getenv("SLAMPP_HIP_PLAN_TIMING") != 0;
@@ -1206,10 +1204,7 @@ void slampp_hip_solver::Build_Simt()
 		simt_chunk_ptr.push_back(int32_t(chunks.size()));
 		simt_rest_ptr.push_back(int32_t(rest.size()));
 		simt_lds_bytes.push_back(n_stage_lds);
-		// the substitution that fetches with the whole wave wants its regions on top, within what a launch gets without asking
-		const bool b_staged = b_simt_bwd_staged && n_stage_bwd_lds + simt_bwd_staged_lds_bytes(int(W), P.max_dim) <= 65536;
-		simt_bwd_lds_bytes.push_back(n_stage_bwd_lds + (b_staged? simt_bwd_staged_lds_bytes(int(W), P.max_dim) : 0));
-		simt_bwd_stage_staged.push_back(b_staged);
+		simt_bwd_lds_bytes.push_back(n_stage_bwd_lds);
 	}
 	if(chunks.empty()) {
 		simt_chunk_ptr.clear();
