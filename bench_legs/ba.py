@@ -291,7 +291,7 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
             tr = sum((kernel_traffic(traffic, k_) or 0.0) * traffic[[n for n in traffic if k_ in n][0]]["launches"]
                      for k_ in present) / \
                 max(traffic[[n for n in traffic if "potrf_diag_kernel" in n][0]]["launches"] / n_panels, 1)
-        out["roofline"] = {"bound": "mfma", "kernel": "dense_cholesky (potrf_diag_kernel with the updates riding + trsm_kernel, one factorization)",
+        out["roofline_dense_cholesky"] = {"bound": "mfma", "kernel": "dense_cholesky (potrf_diag_kernel with the updates riding + trsm_kernel, one factorization)",
                            "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS,
                            "sustained_matrix_rate_measured": F64_MFMA_SUSTAINED_TFLOPS, "traffic": tr, "traffic_source": traffic_file, "flops_per_factorization": st["factor_flops"],
                            "ms_per_factorization": prof["dense_chol"]}
@@ -326,8 +326,6 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
             "bound": "hbm", "kernel": "every kernel of the assembly of S and r (landmark-major runs / tiles / reduction + contribution lists)",
             "achieved": nbytes / (asm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": tr_all, "traffic_source": traffic_file, "algorithmic_bytes_per_step": nbytes, "ms_per_step": asm_ms}
-        if not b_dense:
-            out["roofline"] = out["roofline_schur_assembly_all"]
     if "schur_gather" in prof and prof["schur_gather"] > 0.02 and "schur_tiles" not in prof:
         gb = (288.0 * st["n_update_pairs"] + 2 * 8.0 * 36 * st["l_blocks"]) / (prof["schur_gather"] * 1e-3) / 1e9
         out["roofline_schur_gather"] = {"bound": "hbm", "kernel": "schur_gather_S_kernel", "achieved": gb, "peak": HBM_PEAK_GBS,
@@ -336,8 +334,6 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
                                         "traffic_source": traffic_file,
                                         "traffic_measured_in": "builder's rocprofv3 --pmc run (replayed from the committed file)",
                                         "ms_per_launch": prof["schur_gather"]}
-        if not b_dense:   # then the gather is the dominant kernel of the step
-            out["roofline"] = out["roofline_schur_gather"]
     if "reduced_sparse" in prof and red["l_nnz"] > 0:
         # the reduced camera system through the sparse block path (inner plan: its own nested dissection, a dense top on the
         # matrix cores where it has one).  Priced both ways: SURVEY 8d bytes (8 (nnz + lnz) for the factor, 16 lnz + 32 n for
@@ -355,6 +351,16 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
             "frac": (r_flops / t_s / 1e12 / F64_MFMA_PEAK_TFLOPS) if b_top else (r_bytes / t_s / 1e9 / HBM_PEAK_GBS),
             "traffic": None, "algorithmic_flops": r_flops, "algorithmic_bytes": r_bytes, "ms_per_step": prof["reduced_sparse"],
             "l_nnz": red["l_nnz"], "dense_top_dim": red["schur_dim"]}
+    # the leg's "roofline" is the one of the phase the step spends most of its time in (each stays under its own name as well)
+    phase_ms = {"roofline_dense_cholesky": prof.get("dense_chol", 0.0),
+                "roofline_schur_assembly_all": sum(prof.get(k_, 0.0) for k_ in ("schur_tiles", "schur_gather", "schur_points", "schur_rhs", "schur_init")),
+                "roofline_schur_gather": prof.get("schur_gather", 0.0),
+                "roofline_reduced_sparse": prof.get("reduced_sparse", 0.0)}
+    present = [k_ for k_ in phase_ms if k_ in out]
+    if present:
+        k_dom = max(present, key=lambda k_: phase_ms[k_])
+        out["roofline"] = dict(out[k_dom], name=k_dom, phase_ms=phase_ms[k_dom], share_of_step=phase_ms[k_dom] / ms,
+                               other_phases_ms={k_: phase_ms[k_] for k_ in present if k_ != k_dom})
     if world == 1:
         x = bufs[-1].cpu().numpy()
         out["solve_residual_rel_inf"] = float(np.abs(lam.to_scipy() @ x - lam.rhs).max() / np.abs(lam.rhs).max())

@@ -18,8 +18,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # the repos
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (vendor figure quoted in SURVEY.md section 8d)
-# what a loop of nothing but v_mfma_f64_16x16x4 sustains on this chip (tools/micro/mfma_f64_peak.hip, profiles/r05_mfma_f64_peak.txt:
-# 105 clocks per instruction per SIMD at 2.4 GHz; the vector unit's v_fma_f64 63-70): printed beside `peak`, never instead of it
+# what a loop of nothing but v_mfma_f64_16x16x4 sustains on this chip (tools/micro/mfma_f64_peak.hip, profiles/r06_mfma_f64_peak.txt:
+# 47-49 TFLOP/s with 2-5 waves resident per SIMD = 101-105 clocks per instruction per SIMD, of which the matrix pipe is busy
+# 64 (SQ_VALU_MFMA_BUSY_CYCLES); v_mfma_f64_4x4x4_4b sustains 73 = 93 % of the peak, from operands in registers --
+# profiles/r06_mfma_4x4x4_experiment.txt is what it did inside the update kernel; the vector unit's v_fma_f64 63-70):
+# printed beside `peak`, never instead of it
 F64_MFMA_SUSTAINED_TFLOPS = 47.8
 # Algorithmic work of the default C3 instance (synth.pose_chain(), seed 12345), counted by the
 # reference's own CHOLMOD (AMD ordering) with oracle/_ref/ref_harness cholmod_phases in the build

@@ -44,6 +44,9 @@ def _leg_summary(leg):
         return None
     r = leg.get("roofline") or {}
     s = {"ms_per_step": leg.get("ms_per_step", leg.get("ms_per_solve")), "bound": r.get("bound"), "frac": r.get("frac")}
+    if r.get("name"):   # (BA legs: the roofline of the phase the step spends most of its time in)
+        s["of"] = r["name"].replace("roofline_", "")
+        s["share"] = r.get("share_of_step")
     if leg.get("roofline_reduced_sparse"):
         s["reduced_solve_ms"] = leg["roofline_reduced_sparse"].get("ms_per_step")
     if leg.get("roofline_schur_assembly_all"):

@@ -71,3 +71,25 @@ def test_pose_chains_are_cut_by_vertex_number(n, every):
     ok, x_ref, _ = O.solve_sparse(lam)
     status, x = O.exec_plan(lam, plan)
     assert ok and status == 0 and rel_inf(x, x_ref) < TOL
+
+
+@pytest.mark.parametrize("make", [lambda: synth.pose_chain(n=12000, d=6, seed=5, loop_every=40),
+                                  lambda: synth.pose_chain(n=3000, d=3, seed=6, loop_every=7)])
+def test_plan_does_not_depend_on_how_many_threads_searched_for_it(make, monkeypatch):
+    """Round 6: the ordering recursion hands subgraphs to other threads, and the candidates of the plan search (dense-top
+    threshold x balance) are built side by side; which threads exist is the machine's business, the plan is the structure's.
+    SLAMPP_HIP_DEV_ND_PAR_MIN above the system's size keeps the recursion on one thread (plan.cpp, CNestedDissection);
+    every array of the plan must come out the same."""
+    lam = make()
+    plan_a, st_a = host_plan(lam)
+    monkeypatch.setenv("SLAMPP_HIP_DEV", "1")
+    monkeypatch.setenv("SLAMPP_HIP_DEV_ND_PAR_MIN", "100000000")
+    monkeypatch.setenv("SLAMPP_HIP_DEV_SETUP_THREADS", "1")
+    plan_b, st_b = host_plan(lam)
+    assert set(plan_a) == set(plan_b)
+    for k in plan_a:
+        if isinstance(plan_a[k], np.ndarray):
+            assert np.array_equal(plan_a[k], plan_b[k]), k
+        else:
+            assert plan_a[k] == plan_b[k], k
+    assert st_a["etree_height"] == st_b["etree_height"]

@@ -768,3 +768,24 @@ def test_runs_found_by_the_hashes_alone(mode, monkeypatch):
     assert b.Solve_PosDef_Blocky(lam, eta2) and rel_inf(eta2, x_ref) < TOL
     assert np.array_equal(eta, eta2)                       # the same jobs in the same order: bit for bit
     assert a.stats()["device_bytes"] == b.stats()["device_bytes"]
+
+
+def test_phases_are_also_reported_under_the_reference_names():
+    """slampp_hip_get_profile_reference_names: the same event totals under the names the reference prints with
+    __SCHUR_PROFILING (/root/reference/include/slam/LinearSolver_Schur.h:1895-1912), in its order, each the sum of the
+    phases of slampp_hip_get_profile that do that step's work."""
+    lam = synth.ba(60, 6000, k=4, mode="band")
+    solver = CLinearSolver_Schur_HIP(profile=1)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef(lam, eta)
+    solver.profile(reset=True)
+    eta = lam.rhs.copy()
+    assert solver.Solve_PosDef_Blocky(lam, eta)
+    ours, theirs = solver.profile(), solver.profile_reference_names()
+    assert list(theirs)[:7] == ["reperm", "slice", "transpose", "inverse + multiply + add", "RHS prep", "cholsol", "dy solve"]
+    assert theirs["cholsol"][1] > 0 and theirs["inverse + multiply + add"][1] > 0
+    groups = {"inverse + multiply + add": ("schur_init", "schur_tiles", "schur_points", "schur_gather"), "RHS prep": ("schur_rhs",),
+              "cholsol": ("reduced_sparse", "dense_chol", "dense_solve"), "dy solve": ("backsubst",)}
+    for name, members in groups.items():
+        want = sum(ours[m][1] for m in members if m in ours)
+        assert abs(theirs[name][1] - want) <= 1e-9 + 1e-6 * want, name
