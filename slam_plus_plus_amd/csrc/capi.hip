@@ -22,6 +22,9 @@
 #include <functional>
 #include <sys/mman.h>
 
+#include "preload.h"
+#include <atomic>
+
 using namespace slampp;
 
 // ---------------------------------------------------------------------------------------------
@@ -32,11 +35,13 @@ namespace {
 
 // runs f, maps exceptions to status codes, records the message
 template <class F>
-int guarded(slampp_hip_solver *p, F f)
+int guarded(slampp_hip_solver *p, F f, bool b_join_bringup = true /* false: the entry point waits for the handle's streams itself, or needs none */)
 {
 	if(!p)
 		return SLAMPP_HIP_ERR_INVALID;
 	try {
+		if(b_join_bringup)
+			p->Join_Bringup();
 		if(hipSetDevice(p->n_device) != hipSuccess)
 			throw CDeviceError("hipSetDevice failed");
 		return f();
@@ -92,6 +97,68 @@ static void abort_trace_install() // strictly opt-in, once per process
 	(void)sigaction(SIGABRT, &t_action, &g_abort_previous);
 }
 
+// What slampp_hip_create used to do before it returned (round 6; solver.h: t_bringup), and what the first solve of a process
+// used to find out it had to wait for: the second stream and the first pinned copies on a thread of their own beside the
+// first stream, the first pageable copy and the code objects of the solve paths.
+static void device_bringup(slampp_hip_solver *p)
+{
+	if(hipSetDevice(p->n_device) != hipSuccess) {
+		p->n_bringup_status = SLAMPP_HIP_ERR_DEVICE;
+		return;
+	}
+	static std::atomic<uint64_t> n_devices_warm(0); // a process pays the first uses once per device
+	const uint64_t n_device_bit = uint64_t(1) << (p->n_device & 63);
+	const bool b_first = !(n_devices_warm.fetch_or(n_device_bit) & n_device_bit) && !dev_knob_set("SLAMPP_HIP_DEV_NO_WARMUP"); // (development aid, plan.h)
+	int n_copy_status = SLAMPP_HIP_OK;
+	auto Copy_Side = [p, b_first, &n_copy_status]() {
+		if(hipSetDevice(p->n_device) != hipSuccess ||
+		   hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+		   hipEventCreateWithFlags(&p->copy_done, hipEventDisableTiming) != hipSuccess ||
+		   hipHostMalloc((void**)&p->p_host_flag, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+			n_copy_status = SLAMPP_HIP_ERR_DEVICE;
+			return;
+		}
+		if(b_first) { // the first copies out of and into pinned memory (best effort: a failure here is the first real copy's to report)
+			void *p_dev = 0;
+			if(hipMalloc(&p_dev, 256) == hipSuccess) {
+				*p->p_host_flag = 0;
+				(void)hipMemcpyAsync(p_dev, p->p_host_flag, sizeof(int), hipMemcpyHostToDevice, p->copy_stream);
+				(void)hipMemcpyAsync(p->p_host_flag, p_dev, sizeof(int), hipMemcpyDeviceToHost, p->copy_stream);
+				(void)hipStreamSynchronize(p->copy_stream);
+				(void)hipFree(p_dev);
+			}
+		}
+	};
+	std::thread t_copy_side;
+	try {
+		t_copy_side = std::thread(Copy_Side);
+	} catch(std::exception&) {
+		Copy_Side();
+	}
+	const bool b_timing = getenv("SLAMPP_HIP_PLAN_TIMING") != 0;
+	const double t0 = wall_ms();
+	int n_status = (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) == hipSuccess)? SLAMPP_HIP_OK : SLAMPP_HIP_ERR_DEVICE;
+	const double t1 = wall_ms();
+	if(n_status == SLAMPP_HIP_OK && b_first) {
+		void *p_dev = 0;
+		if(hipMalloc(&p_dev, 65536) == hipSuccess) {
+			std::vector<char> pageable(65536, 0); // the analysis uploads its tables out of pageable vectors
+			(void)hipMemcpyAsync(p_dev, pageable.data(), pageable.size(), hipMemcpyHostToDevice, p->stream);
+			(void)hipStreamSynchronize(p->stream);
+			preload_device_code(p->stream);
+			(void)hipStreamSynchronize(p->stream);
+			(void)hipFree(p_dev);
+		}
+	}
+	const double t2 = wall_ms();
+	if(t_copy_side.joinable())
+		t_copy_side.join();
+	if(b_timing)
+		fprintf(stderr, "[bring-up] stream %.2f ms, first pageable copy + code objects %.2f ms, copy stream and pinned copies waited for %.2f ms%s\n",
+			t1 - t0, t2 - t1, wall_ms() - t2, b_first? "" : " (not the process's first handle on the device)");
+	p->n_bringup_status = (n_status != SLAMPP_HIP_OK)? n_status : n_copy_status;
+}
+
 int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id)
 {
 	(void)dev_knobs_refresh(); // (the development switch, plan.h: read on the cold path, remembered for the warm one)
@@ -107,14 +174,16 @@ int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id)
 	if(!p)
 		return SLAMPP_HIP_ERR_ALLOC;
 	p->n_device = device_id;
-	if(hipSetDevice(device_id) != hipSuccess ||
-	   hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
-	   hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess || // (round 6: with the handle, not with the first
-	   // staging -- a stream costs milliseconds to make, and those were part of every first solve from host arrays)
-	   hipEventCreateWithFlags(&p->copy_done, hipEventDisableTiming) != hipSuccess ||
-	   hipHostMalloc((void**)&p->p_host_flag, sizeof(int), hipHostMallocDefault) != hipSuccess) {
-		delete p;
-		return SLAMPP_HIP_ERR_DEVICE;
+	// the streams, and what a process pays at the first use of each of the runtime's parts, on a thread beside the caller's
+	// next steps (solver.h: t_bringup); a failure is reported by the first entry point that needs the streams
+	if(dev_knob_set("SLAMPP_HIP_DEV_NO_BRINGUP_THREAD")) // (development aid, plan.h: everything before slampp_hip_create returns)
+		device_bringup(p);
+	else {
+		try {
+			p->t_bringup = std::thread(device_bringup, p);
+		} catch(std::exception&) {
+			device_bringup(p);
+		}
 	}
 	*pp_solver = p;
 	return SLAMPP_HIP_OK;
@@ -178,7 +247,8 @@ void slampp_hip_destroy(slampp_hip_solver *p_solver)
 			p_solver->p_group = 0;
 		}
 		(void)hipSetDevice(p_solver->n_device);
-		(void)hipStreamSynchronize(p_solver->stream);
+		if(p_solver->n_Join_Bringup() == SLAMPP_HIP_OK)
+			(void)hipStreamSynchronize(p_solver->stream);
 		for(slampp_hip_assembly *p_assembly : p_solver->assemblies) { // orphaned, not freed: the caller owns the handles
 			assembly_destroy(p_assembly->p_state);
 			p_assembly->p_state = 0;
@@ -396,7 +466,7 @@ int slampp_hip_set_structure(slampp_hip_solver *p_solver, int64_t n_bcols, const
 		s.b_damp_valid = false;
 		s.n_uploaded = 0;
 		return SLAMPP_HIP_OK;
-	});
+	}, false); // (host arrays only)
 }
 
 int slampp_hip_apply_damping_device_async(slampp_hip_solver *p_solver, double *p_values_dev, double f_alpha,
@@ -441,10 +511,13 @@ int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "analyze: set_structure was not called");
 		if(n_mode != SLAMPP_HIP_MODE_SPARSE && n_mode != SLAMPP_HIP_MODE_SCHUR)
 			return fail(p_solver, SLAMPP_HIP_ERR_INVALID, "analyze: unknown mode");
-		SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
-		if(s.copy_stream)
-			SLAMPP_HIP_CHECK(hipStreamSynchronize(s.copy_stream));
-		{
+		if(s.b_analyzed || s.b_factored || s.n_uploaded || s.b_staging_ever) // (not a handle fresh from slampp_hip_create: its streams may still be coming up, and there is nothing on them or on the device)
+			s.Join_Bringup();
+		const bool b_fresh = s.t_bringup.joinable(); // (only this thread and the threads it starts below join)
+		if(!b_fresh) {
+			SLAMPP_HIP_CHECK(hipStreamSynchronize(s.stream));
+			if(s.copy_stream)
+				SLAMPP_HIP_CHECK(hipStreamSynchronize(s.copy_stream));
 			CKeepDeviceMemory t_keep; // (a re-analysis: the arrays cease to exist, their memory waits for the new plan's)
 			s.Free_Device();
 		}
@@ -463,6 +536,7 @@ int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix
 		if(s.n_staging_ahead && s.group_devices.empty() && s.n_values >= (int64_t(1) << 20) && !dev_knob_set("SLAMPP_HIP_DEV_NO_STAGING_AHEAD")) { // (the variable: a development aid, plan.h)
 			t_staging_thread.t = std::thread([&s, &p_staging_error]() {
 				try {
+					s.Join_Bringup();
 					SLAMPP_HIP_CHECK(hipSetDevice(s.n_device));
 					s.Require_Staging();
 				} catch(...) {
@@ -482,6 +556,8 @@ int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix
 			try {
 				if(b_no_landmarks)
 					throw std::domain_error("no landmark part");
+				if(!s.group_devices.empty())
+					s.Join_Bringup(); // (the members exchange with this handle's stream)
 				if(!s.group_devices.empty() && !s.p_group) {
 					s.p_group = group_create(&s.group_devices[0], int(s.group_devices.size()));
 					for(size_t i = 0; i < s.group_options.size(); ++ i) {
@@ -517,9 +593,10 @@ int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix
 			if(p_staging_error)
 				std::rethrow_exception(p_staging_error);
 		}
+		s.Join_Bringup(); // (every path above has: the handle's state after analyze does not depend on which)
 		s.b_analyzed = true;
 		return SLAMPP_HIP_OK;
-	});
+	}, false);
 }
 
 int slampp_hip_factor_solve_device_async(slampp_hip_solver *p_solver, const double *p_values_dev,
@@ -685,7 +762,7 @@ int slampp_hip_sync_batch(slampp_hip_solver *p_solver, int *p_status, int n_batc
 
 void *slampp_hip_stream(slampp_hip_solver *p_solver)
 {
-	return p_solver? (void*)p_solver->stream : 0;
+	return (p_solver && p_solver->n_Join_Bringup() == SLAMPP_HIP_OK)? (void*)p_solver->stream : 0;
 }
 
 int slampp_hip_factor_solve_device(slampp_hip_solver *p_solver, const double *p_values_dev,

@@ -585,3 +585,6 @@ void dense_backsolve(const double *M, int n_pad, int n, const double *p_invdiag,
 }
 
 } // namespace slampp
+
+#include "preload.h"
+SLAMPP_PRELOAD_UNIT(dense_chol) // (the handle's bring-up thread loads this unit's code object: capi.hip)

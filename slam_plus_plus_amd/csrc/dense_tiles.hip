@@ -489,3 +489,6 @@ void tile_backsolve(const CTileSchedule &r_s, const double *M, int n_pad, int n,
 }
 
 } // namespace slampp
+
+#include "preload.h"
+SLAMPP_PRELOAD_UNIT(dense_tiles) // (the handle's bring-up thread loads this unit's code object: capi.hip)

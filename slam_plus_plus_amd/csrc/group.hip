@@ -706,6 +706,10 @@ CDeviceGroup *group_create(const int *p_device_ids, int n_devices) // throw(std:
 			if(n_result != SLAMPP_HIP_OK)
 				throw CDeviceError("device group: cannot create a member");
 		}
+		for(int i = 0; i < n_devices; ++ i) { // (the members' streams came up side by side: solver.h, t_bringup; the group uses them directly)
+			if(g.members[i]->n_Join_Bringup() != SLAMPP_HIP_OK)
+				throw CDeviceError("device group: cannot create a member's streams");
+		}
 		g.p_threads = new CMemberThreads(g.devices);
 	} catch(...) {
 		group_destroy(p_group);

@@ -601,3 +601,6 @@ void launch_panel_update(int n_dim, const TUpdSlot *slots, int n_slots, const TU
 }
 
 } // namespace slampp
+
+#include "preload.h"
+SLAMPP_PRELOAD_UNIT(panel_kernel) // (the handle's bring-up thread loads this unit's code object: capi.hip)

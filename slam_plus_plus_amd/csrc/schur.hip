@@ -254,6 +254,7 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 		// vectors at C5, 7 ms at the end of the analysis; the vectors are not written again, and joined before the final sync)
 		std::exception_ptr p_early_upload_error;
 		struct TJoinEarly { std::thread t; ~TJoinEarly() { if(t.joinable()) t.join(); } } t_early_upload;
+		s.Join_Bringup(); // (a handle fresh from slampp_hip_create: its streams came up beside the checks and the observation lists -- solver.h)
 		{
 			const int n_device = s.n_device;
 			hipStream_t st_early = s.stream;
@@ -1694,3 +1695,6 @@ void schur_enqueue(slampp_hip_solver &s, const double *p_values_dev, double *p_r
 }
 
 } // namespace slampp
+
+#include "preload.h"
+SLAMPP_PRELOAD_UNIT(schur) // (the handle's bring-up thread loads this unit's code object: capi.hip)

@@ -1663,3 +1663,6 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 }
 
 } // namespace slampp
+
+#include "preload.h"
+SLAMPP_PRELOAD_UNIT(schur_tiles) // (the handle's bring-up thread loads this unit's code object: capi.hip)

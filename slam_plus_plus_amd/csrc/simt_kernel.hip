@@ -610,3 +610,6 @@ bool launch_invert_diagonals(const TDevPlan &p, int64_t col_begin, int64_t col_e
 }
 
 } // namespace slampp
+
+#include "preload.h"
+SLAMPP_PRELOAD_UNIT(simt_kernel) // (the handle's bring-up thread loads this unit's code object: capi.hip)

@@ -9,6 +9,7 @@
 #include <vector>
 #include <thread>
 #include <memory>
+#include <mutex>
 
 #include "../../include/slampp_hip.h"
 #include "plan.h"
@@ -268,6 +269,30 @@ struct slampp_hip_solver {
 	std::thread t_staging_registration; // joined wherever the staging is used, replaced or freed
 	void Register_Staging_Later();      // staging.hip
 	void Join_Staging_Registration();
+	// The handle's streams come up on a thread of their own (round 6, capi.hip: device_bringup).  In a process that has used
+	// the device for nothing else, hipStreamCreate takes 8.7 ms for each of the first three streams and 3.3 ms after that, the
+	// first copy out of pinned memory 7.7 ms, the first launch out of a code object 0.4 ms and up (tools/micro/
+	// first_launch_cost.hip) -- 30 ms that a caller's first solve spent waiting, all of it beside nothing: the analysis that
+	// follows a handle's creation is tens of milliseconds of host work.  Whoever touches the streams first joins.
+	std::thread t_bringup;
+	std::mutex m_bringup;
+	int n_bringup_status = SLAMPP_HIP_OK;
+	int n_Join_Bringup() // thread-safe; the status of the bring-up (SLAMPP_HIP_OK or SLAMPP_HIP_ERR_DEVICE)
+	{
+		std::lock_guard<std::mutex> t_lock(m_bringup);
+		if(t_bringup.joinable()) {
+			const double t0 = slampp::wall_ms();
+			t_bringup.join();
+			if(getenv("SLAMPP_HIP_PLAN_TIMING"))
+				fprintf(stderr, "[bring-up] waited for %.2f ms\n", slampp::wall_ms() - t0);
+		}
+		return n_bringup_status;
+	}
+	void Join_Bringup() // for the analysis: throws what guarded() reports as a device error
+	{
+		if(n_Join_Bringup() != SLAMPP_HIP_OK)
+			throw slampp::CDeviceError("the handle's streams could not be created");
+	}
 	hipStream_t copy_stream = 0;
 	hipEvent_t copy_done = 0;
 	int64_t n_uploaded = 0; // values [0, n_uploaded) of the staging are already on their way to d_A

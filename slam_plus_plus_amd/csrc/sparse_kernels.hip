@@ -731,3 +731,6 @@ void launch_gather_values(const int64_t *p_map, int64_t n, const double *p_src, 
 }
 
 } // namespace slampp
+
+#include "preload.h"
+SLAMPP_PRELOAD_UNIT(sparse_kernels) // (the handle's bring-up thread loads this unit's code object: capi.hip)

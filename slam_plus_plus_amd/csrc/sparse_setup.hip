@@ -77,6 +77,7 @@ void slampp_hip_solver::Refine_Structure()
 		}
 	}
 	n_refined_values = int64_t(map.size());
+	Join_Bringup(); // (solver.h: a fresh handle's streams)
 	d_refine_map.Upload(map, stream);
 	d_refined.Alloc(map.size());
 	SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // map lives on this stack frame
@@ -764,6 +765,7 @@ void slampp_hip_solver::Analyze_Sparse()
 	struct TJoinUpload { std::thread t; ~TJoinUpload() { if(t.joinable()) t.join(); } } t_upload_thread;
 	auto Upload_Records = [&]() {
 		try {
+			Join_Bringup(); // (a handle fresh from slampp_hip_create: its streams came up beside the plan and the records -- solver.h)
 			SLAMPP_HIP_CHECK(hipSetDevice(n_device));
 			d_cols.Upload(cols, stream);
 			d_blks.Upload(blks, stream);
@@ -785,6 +787,7 @@ void slampp_hip_solver::Analyze_Sparse()
 		Upload_Records();
 	else
 		t_upload_thread.t = std::thread(Upload_Records);
+	Join_Bringup(); // (this thread's own uploads and allocations begin below)
 	// dense top
 	n_dense_dim = P.dense_dim;
 	n_dense_pad = n_dense_dim? dense_padded_dim(n_dense_dim) : 0;

@@ -187,3 +187,6 @@ bool launch_factor_subtree_image(const TDevPlan &p, const double *A, double *L, 
 }
 
 } // namespace slampp
+
+#include "preload.h"
+SLAMPP_PRELOAD_UNIT(subtree_kernel) // (the handle's bring-up thread loads this unit's code object: capi.hip)
