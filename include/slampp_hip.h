@@ -62,7 +62,11 @@ typedef struct slampp_hip_stats {
 } slampp_hip_stats;
 
 /* lifecycle -- stands in for the solver object's ctor / dtor / Free_Memory()
- * (LinearSolver_CholMod.h:148-167).  device_id: HIP device ordinal. */
+ * (LinearSolver_CholMod.h:148-167).  device_id: HIP device ordinal.
+ * SLAMPP_HIP_ERR_DEVICE without a usable device of that ordinal (there is no CPU fallback).  The handle's HIP streams are
+ * created on a thread of the library's while the caller goes on to set_structure / analyze (milliseconds each in a process
+ * that has made none yet); the first entry point that needs them waits for that thread and is the one to report
+ * SLAMPP_HIP_ERR_DEVICE if they could not be made. */
 int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id);
 
 /* One handle over several devices of this process (SURVEY.md section 8b proposed create(device_ids*, n_dev); section 8e:

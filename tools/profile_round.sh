@@ -4,7 +4,7 @@
 # traffic counters (FETCH_SIZE and WRITE_SIZE do not fit one pass) and the matrix-core counters of the MFMA-bound legs.
 # Usage: tools/profile_round.sh <tag>   (writes under gpurun_out/<tag>/; copy the summaries to profiles/)
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
