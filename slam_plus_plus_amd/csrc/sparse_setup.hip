@@ -783,9 +783,10 @@ void slampp_hip_solver::Analyze_Sparse()
 			p_upload_error = std::current_exception();
 		}
 	};
-	if(b_small)
+	if(b_small) {
 		Upload_Records();
-	else
+		SETUP_PHASE("record uploads");
+	} else
 		t_upload_thread.t = std::thread(Upload_Records);
 	Join_Bringup(); // (this thread's own uploads and allocations begin below)
 	// dense top
