@@ -244,6 +244,7 @@ void slampp_hip_solver::Analyze_Sparse()
 	// panel_update_kernel, block by block
 	std::vector<longlong2> panel_pkg;
 	std::vector<int64_t> panel_off, panel_out_off; // (panel_out_off: per package the offset of its hand-up list, or -1)
+	std::vector<int32_t> panel_units; // per package its size in 16-byte units: what the launch order of a stage goes by
 	int64_t n_handup_doubles = 0;
 	std::vector<int32_t> panel_rest;
 	std::vector<TUpdSlot> upd_slots;
@@ -272,6 +273,7 @@ void slampp_hip_solver::Analyze_Sparse()
 	panel_pkg.clear();
 	panel_off.clear();
 	panel_out_off.clear();
+	panel_units.clear();
 	n_handup_doubles = 0;
 	panel_rest.clear();
 	upd_slots.clear();
@@ -624,6 +626,7 @@ void slampp_hip_solver::Analyze_Sparse()
 				}
 				panel_off.push_back(int64_t(n_at));
 				panel_out_off.push_back(-1);
+				panel_units.push_back(int32_t(n_units));
 				hand_up.push_back(THandUp());
 				Release_Slots();
 			}
@@ -694,11 +697,43 @@ void slampp_hip_solver::Analyze_Sparse()
 			panel_pkg.resize(panel_pkg.size() + 64 * PANEL_W, longlong2{0, 0}); // speculative reads past the last package
 	}
 	bool b_lds_fits = true;
-	for(size_t i = 0; i < panel_cfg.size() && !panel_off.empty(); ++ i)
+	for(size_t i = 0; i < panel_cfg.size() && !panel_off.empty(); ++ i) {
 		b_lds_fits = b_lds_fits && size_t(panel_lds(P.max_dim, true, panel_cfg[i]).TOTAL) * sizeof(double) <= PANEL_LDS_BUDGET;
+		if(b_timing && i + 1 < panel_ptr.size() && panel_ptr[i + 1] > panel_ptr[i]) {
+			const TPanelLds l = panel_lds(P.max_dim, true, panel_cfg[i]);
+			fprintf(stderr, "[setup] stage %d panel launch: %d waves a task, LDS %zu bytes (package %d, blocks %d, inverses + tiles %d, operands %d, fresh %d, hand-up list %d doubles)\n",
+				int(i), panel_cfg[i].n_waves, size_t(l.TOTAL) * sizeof(double), l.IMAGE, l.VEC - l.IMAGE, l.OPS - l.VEC, l.YV - l.OPS, l.OUT - l.YV, l.TOTAL - l.OUT);
+		}
+	}
 	if(b_lds_fits || !b_hand_up_allowed)
 		break;
 	b_hand_up_allowed = false;
+	}
+	// The launch order inside a stage (round 6): workgroups start in the order of their index, and a launch that holds its
+	// tasks more than once over (C3's 2 066-task stage: five workgroups a CU by their LDS, two rounds) ends when the last round's
+	// longest task does.  In the plan's order long and short tasks are mixed, so both rounds last as long as a long task; with the
+	// big packages first the last round is made of short ones.  Nothing on the host refers to a package by its position
+	// any more at this point; the device reads pkg_off[blockIdx.x] and out_off[blockIdx.x] only.
+	if(dev_knob("SLAMPP_HIP_DEV_PANEL_ORDER", 1) != 0) { // (development aid, plan.h: 0 = the plan's order)
+		std::vector<int32_t> order;
+		std::vector<int64_t> off_sorted, out_off_sorted;
+		for(size_t st = 0; st + 1 < panel_ptr.size(); ++ st) {
+			const int32_t n_first = panel_ptr[st], n_num = panel_ptr[st + 1] - n_first;
+			if(n_num < 2)
+				continue;
+			order.resize(size_t(n_num));
+			for(int32_t i = 0; i < n_num; ++ i)
+				order[size_t(i)] = n_first + i;
+			std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return panel_units[size_t(a)] > panel_units[size_t(b)]; });
+			off_sorted.resize(size_t(n_num));
+			out_off_sorted.resize(size_t(n_num));
+			for(int32_t i = 0; i < n_num; ++ i) {
+				off_sorted[size_t(i)] = panel_off[size_t(order[size_t(i)])];
+				out_off_sorted[size_t(i)] = panel_out_off[size_t(order[size_t(i)])];
+			}
+			std::copy(off_sorted.begin(), off_sorted.end(), panel_off.begin() + n_first);
+			std::copy(out_off_sorted.begin(), out_off_sorted.end(), panel_out_off.begin() + n_first);
+		}
 	}
 	};
 	std::exception_ptr p_panel_error;
