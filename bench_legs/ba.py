@@ -170,9 +170,7 @@ def run_ba(args, rank, world, local_rank, dist, schur_sparse=-1, mode="band", ex
     else:
         lam, own = lam_full, slice(int(lam_full.cumsum[lam_full.n_matrix_cut]), lam_full.n_scalars)
     solver = CLinearSolver_Schur_HIP(device=local_rank, schur_sparse=schur_sparse)
-    t0 = time.perf_counter()
-    solver.SymbolicDecomposition_Blocky(lam)
-    analyze_ms = (time.perf_counter() - t0) * 1e3
+    analyze_ms = timed_cold_analysis(solver, lam)
     if dist is not None:
         solver.set_option("shard_rank", rank)
         solver.set_option("shard_world", world)

@@ -264,9 +264,7 @@ def run_c3(args, rank, world, local_rank, dist):
     dev = torch.device(f"cuda:{local_rank}")
     lam = synth.pose_chain(n=args.poses)
     solver = CLinearSolver_HIP(device=local_rank)
-    t0 = time.perf_counter()
-    solver.SymbolicDecomposition_Blocky(lam)
-    analyze_ms = (time.perf_counter() - t0) * 1e3
+    analyze_ms = timed_cold_analysis(solver, lam)
     stats = solver.stats()
     counts = algorithmic_counts_c3(lam, stats)
     vals = torch.from_numpy(lam.values).to(dev)

@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-__all__ = ['ROOT', 'HBM_PEAK_GBS', 'F64_MFMA_PEAK_TFLOPS', 'F64_MFMA_SUSTAINED_TFLOPS', 'C3_REF', '_KEEP', 'host_cores', 'log', 'load_traffic', 'kernel_traffic', 'kernel_traffic_mean', 'kernel_traffic_sum', 'host_path_leg', 'dropin_leg', '_DevPtr', 'make_allreduce', 'dataclasses_replace_points', 'shared_system']
+__all__ = ['ROOT', 'HBM_PEAK_GBS', 'F64_MFMA_PEAK_TFLOPS', 'F64_MFMA_SUSTAINED_TFLOPS', 'C3_REF', '_KEEP', 'host_cores', 'log', 'timed_cold_analysis', 'load_traffic', 'kernel_traffic', 'kernel_traffic_mean', 'kernel_traffic_sum', 'host_path_leg', 'dropin_leg', '_DevPtr', 'make_allreduce', 'dataclasses_replace_points', 'shared_system']
 
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # the repository
@@ -35,6 +35,26 @@ def host_cores():
     return O.host_cores()
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+def timed_cold_analysis(solver, lam):
+    """analyze_ms_cold: set_structure + analyze of a fresh handle, on an idle device, in a process whose runtime is up.
+    (i) The first handle of a process pays the runtime's first uses -- streams, first copies, code objects: 25 ms and more
+    (profiles/r06_first_launch_cost.txt) -- which are no part of any analysis: a throwaway handle takes them, once.
+    (ii) A handle destroyed a moment ago leaves the driver releasing its memory, and the first copy on the next handle's
+    stream then completes 4-12 ms late (seen as C1 / C2 at 18-27 instead of 9-10 ms): the device is
+    given 30 ms to settle before the clock starts."""
+    import torch
+    if not _KEEP.get("runtime_warm"):
+        from slam_plus_plus_amd import synth
+        from slam_plus_plus_amd.hip_solver import CLinearSolver_HIP
+        warm = CLinearSolver_HIP(device=torch.cuda.current_device())
+        warm.SymbolicDecomposition_Blocky(synth.pose_chain(n=64))
+        del warm
+        _KEEP["runtime_warm"] = True
+    torch.cuda.synchronize()
+    time.sleep(0.03)
+    t0 = time.perf_counter()
+    solver.SymbolicDecomposition_Blocky(lam)
+    return (time.perf_counter() - t0) * 1e3
 def load_traffic(workload):
     """HBM traffic per launch from the committed PMC summary of this round (tools/profile_round.sh ->
     profiles/*_traffic.json): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB units,

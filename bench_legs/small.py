@@ -34,9 +34,7 @@ def run_small_configs(args, local_rank):
             continue
         lam = make()
         solver = CLinearSolver_HIP(device=local_rank)
-        t0 = time.perf_counter()
-        solver.SymbolicDecomposition_Blocky(lam)
-        analyze_ms = (time.perf_counter() - t0) * 1e3
+        analyze_ms = timed_cold_analysis(solver, lam)
         vals = torch.from_numpy(lam.values).to(dev)
         reps = 20
         bufs = [torch.from_numpy(lam.rhs).to(dev) for _ in range(reps + 1)]

@@ -27,6 +27,8 @@ for name in (sys.argv[1:] or ["c1", "c2", "c3", "venice", "c5", "uniform"]):
     for rep in range(reps):
         s = cls()
         print(f"--- {name} rep {rep}", file=sys.stderr, flush=True)
+        if os.environ.get("SETTLE_MS"):      # let the driver finish releasing the previous handle's memory first
+            time.sleep(float(os.environ["SETTLE_MS"]) * 1e-3)
         t0 = time.perf_counter()
         s.SymbolicDecomposition_Blocky(lam)
         times.append((time.perf_counter() - t0) * 1e3)
