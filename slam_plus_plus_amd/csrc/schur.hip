@@ -469,6 +469,22 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 		schur_tiles_join(S.tiles); // (the run tables, uploaded beside everything since the runs were found)
 		SLAMPP_HIP_CHECK(hipStreamSynchronize(st));
 		SCHUR_SETUP_PHASE("uploads");
+		if(S.n_obs >= (int64_t(1) << 20) || !S.tiles.trash.empty()) {
+			// the observation lists are on the device: their memory (C5: 100 MB) goes back to the system on a thread behind the
+			// analysis' return, not at the end of this scope (solver.h: TTrash, t_discard)
+			s.Join_Discard();
+			for(size_t i = 0; i < S.tiles.trash.size(); ++ i)
+				s.analysis_trash.emplace_back(std::move(S.tiles.trash[i])); // (the tile analysis' hashes, sort items and orders)
+			S.tiles.trash.clear();
+			Discard_Later(s.analysis_trash, obs_pt); Discard_Later(s.analysis_trash, obs_cam); Discard_Later(s.analysis_trash, cam_obs);
+			Discard_Later(s.analysis_trash, ent_a); Discard_Later(s.analysis_trash, ent_uoff);
+			slampp_hip_solver *p_solver = &s;
+			try {
+				s.t_discard = std::thread([p_solver]() { p_solver->analysis_trash.clear(); });
+			} catch(std::system_error&) {
+				s.analysis_trash.clear();
+			}
+		}
 #undef SCHUR_SETUP_PHASE
 	} catch(...) {
 		delete p;

@@ -29,6 +29,7 @@ struct TRunUpload {
 };
 
 struct CSchurTiles {
+	CTrashList trash;        // work arrays of schur_tiles_build that nobody reads any more: the caller frees them when it suits (solver.h: TTrash)
 	bool b_enabled = false;  // some landmarks go through the tiles
 	bool b_hybrid = false;   // ... and some through the contribution lists (the x-lists below)
 	int64_t n_tiles = 0, n_slots = 0, n_tile_points = 0, n_list_points = 0, n_tile_pairs = 0, n_all_pairs = 0, n_rb = 0, n_max_slots = 0, n_max_k = 0;

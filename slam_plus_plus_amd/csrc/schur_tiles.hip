@@ -928,6 +928,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 	fprintf(stderr, "[schur tiles] %-20s %8.2f ms\n", name, t_ - t_build_phase); t_build_phase = t_; } } while(0)
 	std::vector<uint8_t> handled(np, 0); // landmarks that do not go through the contribution lists
 	std::vector<int64_t> slot_key;       // the block of S of every partial block: runs first, then tiles
+	CTrashList trash; // (schur_tiles.h: the big work arrays of the passes below, freed beside the uploads)
 
 	// ---- runs: landmarks with identical camera lists, found by sorting hashes of the lists ----
 	std::vector<TRunJob> jobs;
@@ -1259,6 +1260,9 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 				}
 			}
 		}
+		Discard_Later(trash, hash); Discard_Later(trash, hash2); Discard_Later(trash, k_of); Discard_Later(trash, items);
+		Discard_Later(trash, items_tmp); Discard_Later(trash, order); Discard_Later(trash, same_as_previous);
+		Discard_Later(trash, members); Discard_Later(trash, members_k);
 	}
 	BUILD_PHASE("runs -> jobs");
 	const int64_t n_run_slots = int64_t(slot_key.size()), n_run_points = int64_t(run_lm.size());
@@ -1441,6 +1445,9 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 		else
 			Upload_Runs(); // (a small system: a thread's start-up is what it would save)
 	}
+	for(size_t i = 0; i < trash.size(); ++ i)
+		T.trash.emplace_back(std::move(trash[i])); // (the caller frees them behind the analysis: schur.hip)
+	trash.clear();
 	const size_t n_run_jobs_all = T.p_run_upload->jobs.size();
 	T.n_tiles = n_tiles;
 	T.n_slots = n_slots;

@@ -100,6 +100,14 @@ struct CNoInitAlloc : std::allocator<T> {
 };
 template <class T> using raw_vector = std::vector<T, CNoInitAlloc<T> >;
 
+// work arrays of the analysis that nobody reads any more, kept until a thread that has nothing urgent left frees them:
+// giving 150 MB back to the system (C5: hashes, sort items, orders of two million landmarks) is 9 - 15 ms of page-table
+// work, and it used to happen on the analysis' own thread at the end of a scope
+struct TTrash { virtual ~TTrash() {} };
+template <class T> struct TTrashOf : TTrash { T t; explicit TTrashOf(T &r) { t.swap(r); } };
+typedef std::vector<std::unique_ptr<TTrash> > CTrashList;
+template <class T> inline void Discard_Later(CTrashList &r_trash, T &r_v) { r_trash.emplace_back(new TTrashOf<T>(r_v)); }
+
 // while one of these lives on a thread, the device arrays freed on that thread keep their memory (a re-analysis)
 struct CKeepDeviceMemory {
 	bool b_before;
@@ -274,6 +282,11 @@ struct slampp_hip_solver {
 	// first copy out of pinned memory 7.7 ms, the first launch out of a code object 0.4 ms and up (tools/micro/
 	// first_launch_cost.hip) -- 30 ms that a caller's first solve spent waiting, all of it beside nothing: the analysis that
 	// follows a handle's creation is tens of milliseconds of host work.  Whoever touches the streams first joins.
+	// (round 6) the sparse analysis' record vectors -- 70 MB at C3 -- are freed on a thread behind the analysis (slampp::TTrash),
+	// joined by the next analysis and by the destructor
+	slampp::CTrashList analysis_trash;
+	std::thread t_discard;
+	void Join_Discard() { if(t_discard.joinable()) t_discard.join(); }
 	std::thread t_bringup;
 	std::mutex m_bringup;
 	int n_bringup_status = SLAMPP_HIP_OK;

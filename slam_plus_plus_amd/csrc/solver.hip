@@ -44,6 +44,7 @@ slampp_hip_solver::slampp_hip_solver()
 slampp_hip_solver::~slampp_hip_solver()
 {
 	(void)n_Join_Bringup();
+	Join_Discard();
 	Free_Device();
 	for(size_t i = 0; i < phase_pending.size(); ++ i) {
 		(void)hipEventDestroy(phase_pending[i].start);

@@ -119,6 +119,7 @@ static void Parallel_Ranges(int64_t n, int64_t n_min_per_thread, F f, int n_max_
 
 void slampp_hip_solver::Analyze_Sparse()
 {
+	Join_Discard(); // (the previous analysis' arrays)
 	if(p_sinv) { // lists of the previous plan
 		sparse_inverse_destroy(p_sinv);
 		p_sinv = 0;
@@ -972,6 +973,19 @@ void slampp_hip_solver::Analyze_Sparse()
 		d_timing.Alloc(1 + 32 * 4096);
 		SLAMPP_HIP_CHECK(hipMemsetAsync(d_timing.p(), 0, (1 + 32 * 4096) * sizeof(long long), stream));
 		dplan.p_timing = d_timing.p();
+	}
+	if(!b_small) {
+		// the record vectors are on the device: giving their memory back to the system (70 MB at C3: 3 - 4 ms of page-table
+		// work) is nobody's critical path -- a thread does it behind the analysis' return (solver.h: TTrash, t_discard)
+		Join_Discard();
+		Discard_Later(analysis_trash, cols); Discard_Later(analysis_trash, blks); Discard_Later(analysis_trash, pairs);
+		Discard_Later(analysis_trash, rents); Discard_Later(analysis_trash, pkg); Discard_Later(analysis_trash, task_pkg);
+		Discard_Later(analysis_trash, panel_pkg); Discard_Later(analysis_trash, upd_slots); Discard_Later(analysis_trash, upd_ents);
+		try {
+			t_discard = std::thread([this]() { analysis_trash.clear(); });
+		} catch(std::system_error&) {
+			analysis_trash.clear();
+		}
 	}
 }
 
