@@ -1010,11 +1010,11 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 		// at 1 / 2 / 4 times the base length: the longest jobs set the length of a launch; C5 1.197 / 1.223 / 1.183): the
 		// kernel can, the analysis does not ask for it (development knob, tests/test_schur_gpu.py)
 		const int64_t n_piece_mult = dev_knob_set("SLAMPP_HIP_DEV_RUN_PIECE_MULT")? std::max(1, std::min(4, dev_knob("SLAMPP_HIP_DEV_RUN_PIECE_MULT", 1))) : 1;
-		auto Emit_Run = [&](const int32_t *p_members, const int32_t *p_members_k, int64_t n_members) {
+		auto Emit_Run = [&](const int32_t *p_members, const int32_t *p_members_k /* null: every member has k_all observations */, int64_t n_members, int64_t k_all) {
 			// (pieces of 32 where a job keeps ten or sixteen accumulator tiles -- nine cameras and up at 6 x 6 --: those jobs are
 			// the long ones, and more of them spread better: 164 + 123 -> 130 + 103 us for the two widest kernels of the
 			// Venice-like C4, for 18 us more in the reduction of the partial blocks)
-			const int64_t k_run = p_members_k[0];
+			const int64_t k_run = p_members_k? p_members_k[0] : k_all;
 			const int64_t n_piece_len = ((std::min<int64_t>(k_run, OB) * DC > 48 && !dev_knob_set("SLAMPP_HIP_DEV_RUN_PIECE"))? 32 : n_piece_max) * n_piece_mult;
 			for(int64_t f = 0; f < n_members; f += n_piece_len) {
 				const int64_t n_piece = std::min<int64_t>(n_piece_len, n_members - f);
@@ -1026,12 +1026,17 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 				// a read of k_of[] and a write of handled[] per landmark, both in hash order, were most of the 20 ms this loop took
 				// at C5's two million landmarks)
 				run_lm.insert(run_lm.end(), p_members + f, p_members + f + n_piece);
-				run_k.insert(run_k.end(), p_members_k + f, p_members_k + f + n_piece);
-				for(int64_t e = f; e < f + n_piece; ++ e)
-					n_run_pairs += int64_t(p_members_k[e]) * (p_members_k[e] + 1) / 2;
+				if(p_members_k) {
+					run_k.insert(run_k.end(), p_members_k + f, p_members_k + f + n_piece);
+					for(int64_t e = f; e < f + n_piece; ++ e)
+						n_run_pairs += int64_t(p_members_k[e]) * (p_members_k[e] + 1) / 2;
+				} else { // (one class: the same list for all of them -- round 6: no copy of the members, no array of equal lengths)
+					run_k.insert(run_k.end(), size_t(n_piece), int32_t(k_all));
+					n_run_pairs += n_piece * (k_all * (k_all + 1) / 2);
+				}
 				for(int64_t rb = 0; rb < n_blocks; ++ rb) {
 					const int64_t n_kb_r = std::min<int64_t>(OB, k - rb * OB);
-					int64_t n_reach = 0; // landmarks of the piece with observations in row block rb
+					int64_t n_reach = p_members_k? 0 : n_piece; // landmarks of the piece with observations in row block rb (one class: all of them)
 					while(n_reach < n_piece && run_k[size_t(n_lm_first + n_reach)] > rb * OB)
 						++ n_reach;
 					for(int64_t cb = 0; cb <= rb; ++ cb) {
@@ -1224,7 +1229,9 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 			}
 			const int64_t k_longest = class_k[c1 - 1];
 			// (a lone long track is no better off here than in the lists; two of them already share their partial blocks)
-			if(n_members >= ((k_longest > OB && n_min_run > 2)? 2 : n_min_run)) {
+			if(n_members >= ((k_longest > OB && n_min_run > 2)? 2 : n_min_run) && c1 - c0 == 1)
+				Emit_Run(order.data() + classes[c0].n_first, 0, n_members, k_longest); // (the members as they lie in the sorted order)
+			else if(n_members >= ((k_longest > OB && n_min_run > 2)? 2 : n_min_run)) {
 				members.clear();
 				members_k.clear();
 				for(size_t c = c1; c > c0; -- c) { // longest list first
@@ -1232,7 +1239,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 					members.insert(members.end(), order.begin() + r_class.n_first, order.begin() + r_class.n_first + r_class.n_count);
 					members_k.insert(members_k.end(), size_t(r_class.n_count), class_k[c - 1]);
 				}
-				Emit_Run(members.data(), members_k.data(), int64_t(members.size()));
+				Emit_Run(members.data(), members_k.data(), int64_t(members.size()), 0);
 				if(c1 - c0 > 1)
 					T.n_prefix_points += n_members;
 			}
