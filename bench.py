@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--full-json", default=None, help="where the full record goes (default gpurun_out/bench_full_n<N>.json); the stdout line is the compact one")
     ap.add_argument("--group-reps", type=int, default=3, help="warm solves of the in-library device group leg (--gpus N, N > 1)")
     ap.add_argument("--no-group-leg", action="store_true", help="leave out the one-process device group leg at N > 1")
+    ap.add_argument("--no-cold-process", action="store_true", help="leave out the cold analyses in a process of their own (bench_legs/cold.py): analyze_ms_cold is then the in-process number")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -209,6 +210,29 @@ def main():
             if out.get(key) and out[key].get("phases_ms"):
                 out["scaling_model"].setdefault(name, scaling_model(out[key], out[key].get("n_values"), out[key].get("n_scalars"),
                                                                     out[key].get("n_exchange_doubles")))
+    if rank == 0 and world == 1 and out is not None and args.workload == "all" and not args.ba_solve_only and not args.c3_solve_only and not args.no_cold_process:
+        # analyze_ms_cold of every leg from a process that holds nothing but that leg's system (bench_legs/cold.py says why);
+        # this process's own measurement stays beside it
+        from bench_legs import cold
+        specs = {"own_ordering": f"chain:{args.poses}", "C1": "manhattan:3500", "C2": "sphere:50:50",
+                 "ba_schur": f"ba:{args.ba_cams}:{args.ba_points}:{legs[0]}", "ba_schur_band": f"ba:{args.ba_cams}:{args.ba_points}:band",
+                 "ba_schur_uniform_dense_S": f"ba:{args.ba_cams}:{args.ba_points}:uniform", "ba_schur_venice": f"ba:{args.ba_cams}:{args.ba_points}:venice",
+                 "ba_c5": f"ba:{args.c5_cams}:{args.c5_points}:{args.c5_mode}", "ba_1k_1m": f"ba:{args.target_cams}:{args.target_points}:{args.c5_mode}"}
+        where = {k_: (out.get("other_configs", {}).get(k_) if k_ in ("C1", "C2") else out.get(k_)) for k_ in specs}
+        where = {k_: v for k_, v in where.items() if isinstance(v, dict) and v.get("analyze_ms_cold") is not None}
+        try:
+            res = cold.run_in_subprocess(sorted(set(specs[k_] for k_ in where)))
+        except Exception as e:
+            res = {"error": str(e)[:200]}
+        if "error" in res:
+            out["analyze_ms_cold_process"] = res
+        else:
+            for k_, leg in where.items():
+                t = res.get(specs[k_])
+                if t:
+                    leg["analyze_ms_cold_in_bench_process"] = leg["analyze_ms_cold"]
+                    leg["analyze_ms_cold"] = float(sorted(t)[len(t) // 2])
+                    leg["analyze_ms_cold_all"] = t
     if rank == 0 and world > 1 and out is not None:
         out["rccl_ranks"] = dist.get_world_size()
         out["dist_backend"] = dist.get_backend()      # "nccl" is RCCL on ROCm; "gloo" only under SLAMPP_BENCH_ONE_DEVICE=1 (development)

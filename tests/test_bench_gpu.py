@@ -102,6 +102,10 @@ def test_bench_default_run_carries_the_n1_points_of_the_scaling_curves():
     assert d["n_gpus"] == 1 and "C3" in d["config"]["workload"]
     for key in ("ba_schur", "ba_c5", "ba_1k_1m"):
         assert d[key]["n_gpus"] == 1 and d[key]["solve_residual_rel_inf"] < 1e-9, key
+        # (round 6) analyze_ms_cold comes from a process of its own (bench_legs/cold.py), this process's measurement beside it
+        assert len(d[key]["analyze_ms_cold_all"]) == 3 and d[key]["analyze_ms_cold"] in d[key]["analyze_ms_cold_all"], key
+        assert d[key]["analyze_ms_cold_in_bench_process"] > 0, key
+    assert d["own_ordering"]["analyze_ms_cold_in_bench_process"] > 0 and "analyze_ms_cold_process" not in d
 
 
 def test_bench_c3_with_the_reference_prints_conditioning_beside_the_error():

@@ -1,4 +1,4 @@
-"""Dev helper: what the analysis (set_structure + analyze, what the first Solve_PosDef_Blocky pays before any arithmetic) costs
+"""Dev helper (bench_legs/cold.py is the form the bench itself uses): what the analysis (set_structure + analyze, what the first Solve_PosDef_Blocky pays before any arithmetic) costs
 on the bench's workloads, a fresh handle every time; with SLAMPP_HIP_PLAN_TIMING=1 the phases on stderr.
 usage: cold_path.py [c1 c2 c3 venice band c5 uniform 1kx1m]"""
 import sys, os, time
