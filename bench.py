@@ -110,6 +110,22 @@ def main():
     if one_device:
         local_rank = 0
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    legs = [m for m in args.ba_legs.split(",") if m]
+    cold_res, cold_specs = None, {}
+    if world == 1 and args.workload == "all" and not args.ba_solve_only and not args.c3_solve_only and not args.no_cold_process:
+        # the cold analyses first, in a process of their own, while this one holds nothing yet (bench_legs/cold.py: beside a parent
+        # that held the bench's systems and tensors the child measured C5 at 73-83 ms, on its own at 52-58)
+        from bench_legs import cold
+        cold_specs = {"own_ordering": f"chain:{args.poses}", "C1": "manhattan:3500", "C2": "sphere:50:50",
+                      "ba_schur": f"ba:{args.ba_cams}:{args.ba_points}:{legs[0]}", "ba_schur_band": f"ba:{args.ba_cams}:{args.ba_points}:band",
+                      "ba_schur_uniform_dense_S": f"ba:{args.ba_cams}:{args.ba_points}:uniform", "ba_schur_venice": f"ba:{args.ba_cams}:{args.ba_points}:venice",
+                      "ba_c5": f"ba:{args.c5_cams}:{args.c5_points}:{args.c5_mode}", "ba_1k_1m": f"ba:{args.target_cams}:{args.target_points}:{args.c5_mode}"}
+        wanted = {"own_ordering", "C1", "C2", "ba_schur", "ba_c5", "ba_1k_1m"} | {k_ for k_, m in (("ba_schur_band", "band"), ("ba_schur_uniform_dense_S", "uniform"), ("ba_schur_venice", "venice")) if m in legs[1:]}
+        wanted -= {k_ for k_ in ("C1", "C2") if k_ not in args.small_configs.split(",")}
+        try:
+            cold_res = cold.run_in_subprocess(sorted(set(cold_specs[k_] for k_ in wanted)))
+        except Exception as e:
+            cold_res = {"error": str(e)[:200]}
     import torch
     if not one_device and torch.cuda.device_count() < world:
         raise SystemExit(f"bench.py --gpus {world}: {torch.cuda.device_count()} HIP device(s) visible")
@@ -131,7 +147,6 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     out = None
-    legs = [m for m in args.ba_legs.split(",") if m]
 
     def promote(ba, scaling):
         return {"metric": "BA Schur solve GFLOP/s (algorithmic flops / wall-clock)", "value": ba["GFLOP/s"],
@@ -210,25 +225,16 @@ def main():
             if out.get(key) and out[key].get("phases_ms"):
                 out["scaling_model"].setdefault(name, scaling_model(out[key], out[key].get("n_values"), out[key].get("n_scalars"),
                                                                     out[key].get("n_exchange_doubles")))
-    if rank == 0 and world == 1 and out is not None and args.workload == "all" and not args.ba_solve_only and not args.c3_solve_only and not args.no_cold_process:
-        # analyze_ms_cold of every leg from a process that holds nothing but that leg's system (bench_legs/cold.py says why);
-        # this process's own measurement stays beside it
-        from bench_legs import cold
-        specs = {"own_ordering": f"chain:{args.poses}", "C1": "manhattan:3500", "C2": "sphere:50:50",
-                 "ba_schur": f"ba:{args.ba_cams}:{args.ba_points}:{legs[0]}", "ba_schur_band": f"ba:{args.ba_cams}:{args.ba_points}:band",
-                 "ba_schur_uniform_dense_S": f"ba:{args.ba_cams}:{args.ba_points}:uniform", "ba_schur_venice": f"ba:{args.ba_cams}:{args.ba_points}:venice",
-                 "ba_c5": f"ba:{args.c5_cams}:{args.c5_points}:{args.c5_mode}", "ba_1k_1m": f"ba:{args.target_cams}:{args.target_points}:{args.c5_mode}"}
-        where = {k_: (out.get("other_configs", {}).get(k_) if k_ in ("C1", "C2") else out.get(k_)) for k_ in specs}
+    if cold_res is not None and out is not None:
+        # analyze_ms_cold of every leg from a process that holds nothing but that leg's system (bench_legs/cold.py says why; it ran
+        # before this process touched the device); this process's own measurement stays beside it
+        where = {k_: (out.get("other_configs", {}).get(k_) if k_ in ("C1", "C2") else out.get(k_)) for k_ in cold_specs}
         where = {k_: v for k_, v in where.items() if isinstance(v, dict) and v.get("analyze_ms_cold") is not None}
-        try:
-            res = cold.run_in_subprocess(sorted(set(specs[k_] for k_ in where)))
-        except Exception as e:
-            res = {"error": str(e)[:200]}
-        if "error" in res:
-            out["analyze_ms_cold_process"] = res
+        if "error" in cold_res:
+            out["analyze_ms_cold_process"] = cold_res
         else:
             for k_, leg in where.items():
-                t = res.get(specs[k_])
+                t = cold_res.get(cold_specs[k_])
                 if t:
                     leg["analyze_ms_cold_in_bench_process"] = leg["analyze_ms_cold"]
                     leg["analyze_ms_cold"] = float(sorted(t)[len(t) // 2])

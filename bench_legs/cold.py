@@ -54,7 +54,8 @@ def main(specs, reps=3, settle_ms=30.0):
 
 
 def run_in_subprocess(specs, timeout=900):
-    """{spec: [ms, ...]} from a child process (bench.py: after its own legs are done and their memory is gone)."""
+    """{spec: [ms, ...]} from a child process (bench.py: before its own legs, while the parent holds nothing: a child measured
+    beside a parent that held the bench's systems and tensors saw C5 at 73-83 ms, on its own 52-58)."""
     import subprocess
     r = subprocess.run([sys.executable, "-m", "bench_legs.cold"] + list(specs), cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
