@@ -72,3 +72,24 @@ def test_nan_in_lambda_is_reported_as_failure():
     vals[len(vals) // 2] = np.nan
     bad = dataclasses.replace(lam, values=vals)
     assert CLinearSolver_HIP().Solve_PosDef(bad, bad.rhs.copy()) is False
+
+
+def test_a_handle_can_be_dropped_or_used_at_once_while_its_streams_are_still_coming_up():
+    """Round 6: slampp_hip_create returns before the handle's streams exist (capi.hip: device_bringup, on a thread).  Destroying
+    the handle straight away, asking for its stream straight away and analyzing straight away all have to meet that thread
+    properly; options and the structure do not need it."""
+    for _ in range(8):
+        s = CLinearSolver_HIP()
+        del s                                   # destroyed while the thread may still be creating the streams
+    s = CLinearSolver_HIP()
+    assert s.stream() != 0                      # waits for the thread
+    del s
+    lam = synth.pose_chain(n=300, seed=4)
+    for _ in range(4):
+        s = CLinearSolver_HIP()
+        s.set_option("leaf_size", 4)            # host state only
+        eta = lam.rhs.copy()
+        assert s.Solve_PosDef(lam, eta)         # set_structure + analyze + solve on a handle fresh from create
+        ok, x_ref, _ = O.solve_sparse(lam)
+        assert ok and np.abs(eta - x_ref).max() / np.abs(x_ref).max() < 1e-10
+        del s
