@@ -594,6 +594,8 @@ int slampp_hip_analyze(slampp_hip_solver *p_solver, int n_mode, int64_t n_matrix
 				std::rethrow_exception(p_staging_error);
 		}
 		s.Join_Bringup(); // (every path above has: the handle's state after analyze does not depend on which)
+		if(!s.t_discard.joinable())
+			host_pool_release(); // (no thread is freeing this analysis' arrays: what its work arrays left mapped goes back now -- solver.h)
 		s.b_analyzed = true;
 		return SLAMPP_HIP_OK;
 	}, false);

@@ -480,9 +480,10 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 			Discard_Later(s.analysis_trash, ent_a); Discard_Later(s.analysis_trash, ent_uoff);
 			slampp_hip_solver *p_solver = &s;
 			try {
-				s.t_discard = std::thread([p_solver]() { p_solver->analysis_trash.clear(); });
+				s.t_discard = std::thread([p_solver]() { p_solver->analysis_trash.clear(); host_pool_release(); });
 			} catch(std::system_error&) {
 				s.analysis_trash.clear();
+				host_pool_release();
 			}
 		}
 #undef SCHUR_SETUP_PHASE

@@ -22,8 +22,8 @@ struct TRunJob { // one wave of the run kernel
 // waits for it): the thread owns what it reads
 struct TRunUpload {
 	std::thread t;
-	std::vector<TRunJob> jobs;
-	std::vector<int32_t> run_lm, run_k;
+	raw_vector<TRunJob> jobs;
+	raw_vector<int32_t> run_lm, run_k;
 	std::exception_ptr p_error;
 	~TRunUpload() { if(t.joinable()) t.join(); }
 };

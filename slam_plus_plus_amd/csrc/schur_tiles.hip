@@ -926,13 +926,13 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 	double t_build_phase = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 #define BUILD_PHASE(name) do { if(b_build_timing) { const double t_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); \
 	fprintf(stderr, "[schur tiles] %-20s %8.2f ms\n", name, t_ - t_build_phase); t_build_phase = t_; } } while(0)
-	std::vector<uint8_t> handled(np, 0); // landmarks that do not go through the contribution lists
-	std::vector<int64_t> slot_key;       // the block of S of every partial block: runs first, then tiles
+	raw_vector<uint8_t> handled(np, 0); // landmarks that do not go through the contribution lists
+	raw_vector<int64_t> slot_key;       // the block of S of every partial block: runs first, then tiles
 	CTrashList trash; // (schur_tiles.h: the big work arrays of the passes below, freed beside the uploads)
 
 	// ---- runs: landmarks with identical camera lists, found by sorting hashes of the lists ----
-	std::vector<TRunJob> jobs;
-	std::vector<int32_t> run_lm, run_k;
+	raw_vector<TRunJob> jobs;
+	raw_vector<int32_t> run_lm, run_k;
 	int64_t n_run_pairs = 0;
 	if(b_use_runs) {
 		// (the passes over the landmarks that do not depend on each other run on a few threads: at C5's two million landmarks
@@ -1560,7 +1560,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 	T.d_rb_sb.Upload(rb_sb, stream);
 	T.d_P.Alloc(size_t(n_slots) * DC * DC);
 	T.d_R.Alloc(size_t(n_slots) * DC);
-	const std::vector<uint8_t> &in_tile = handled;
+	const raw_vector<uint8_t> &in_tile = handled;
 	BUILD_PHASE("uploads (runs)");
 
 	// the landmarks that stay with the contribution lists: lists of their own, for the blocks of S they touch

@@ -90,11 +90,37 @@ public:
 // allocator for the big work arrays of the analysis that are written in full before they are read: std::vector<T>(n)
 // zero-fills -- 32 MB on one thread, a page fault every 4 KB: 5 ms, and C5's analysis made six of them --; with this
 // allocator the elements are left as they are and the pages are first touched by the (threaded) loops that fill them
+// ... and from one megabyte on their memory is mapped by the library itself, aligned to 2 MB and offered to the kernel as
+// transparent huge pages (round 6, solver.hip: host_pool_*).  First touches are what an analysis of a large system waits for
+// (tools/micro/page_touch.cpp on the box: 256 MB of fresh 4 KB pages take 38 ms to touch on one thread and 15 - 17 ms on
+// eight -- the threads queue for the process's memory map --, and 30 - 39 ms to unmap; as huge pages 9.7 / 1.7 - 2.2 ms and
+// 12 - 19 ms).  The C library's allocator hands out addresses 16 bytes behind a page boundary, which madvise() refuses: the
+// one attempt at huge pages of the round's first hours did nothing for that reason.  A dropped array's mapping is kept for the
+// next array of about its size and everything goes back to the system when the analysis is over (host_pool_release, called by
+// the thread that frees the analysis' arrays).
+void *host_pool_alloc(size_t n_bytes); // throws std::bad_alloc
+void host_pool_free(void *p) noexcept;
+void host_pool_release() noexcept;     // unmaps the blocks nobody holds
+enum { host_pool_min_bytes = 1 << 20 };
+
 template <class T>
 struct CNoInitAlloc : std::allocator<T> {
 	template <class U> struct rebind { typedef CNoInitAlloc<U> other; };
 	CNoInitAlloc() {}
 	template <class U> CNoInitAlloc(const CNoInitAlloc<U>&) {}
+	T *allocate(size_t n)
+	{
+		if(n > size_t(-1) / sizeof(T))
+			throw std::bad_alloc();
+		return (n * sizeof(T) >= size_t(host_pool_min_bytes))? static_cast<T*>(host_pool_alloc(n * sizeof(T))) : static_cast<T*>(::operator new(n * sizeof(T)));
+	}
+	void deallocate(T *p, size_t n) noexcept
+	{
+		if(n * sizeof(T) >= size_t(host_pool_min_bytes))
+			host_pool_free(p);
+		else
+			::operator delete(p);
+	}
 	template <class U> void construct(U *p) { ::new((void*)p) U; } // default-initialization: nothing for arithmetic types
 	template <class U, class... CArgs> void construct(U *p, CArgs&&... args) { ::new((void*)p) U(std::forward<CArgs>(args)...); }
 };

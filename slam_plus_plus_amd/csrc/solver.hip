@@ -8,6 +8,8 @@
 #include <unistd.h>
 #include <pthread.h>
 #include "solver.h"
+#include <unordered_map>
+#include <sys/mman.h>
 #include "sparse_inverse.h"
 
 #include <algorithm>
@@ -41,10 +43,103 @@ slampp_hip_solver::slampp_hip_solver()
 	memset(&times, 0, sizeof(times));
 }
 
+// ---- the mappings behind raw_vector (solver.h) ----
+namespace slampp {
+
+namespace {
+
+struct THostBlock { void *p_map; size_t n_map_bytes, n_bytes; }; // the mapping as mmap() gave it, and the aligned part handed out
+
+struct THostPool {
+	std::mutex t_mutex;
+	std::vector<std::pair<void*, THostBlock> > free_blocks; // (aligned address, block) of the mappings nobody holds
+	std::unordered_map<void*, THostBlock> held;            // aligned address -> block
+};
+
+THostPool &r_Host_Pool()
+{
+	static THostPool *p_pool = new THostPool(); // (never destroyed: containers of other static objects may be freed after it would be)
+	return *p_pool;
+}
+
+} // anonymous namespace
+
+void *host_pool_alloc(size_t n_bytes)
+{
+	const size_t n_huge = size_t(2) << 20;
+	const size_t n_need = (n_bytes + n_huge - 1) / n_huge * n_huge;
+	THostPool &r_pool = r_Host_Pool();
+	{
+		std::lock_guard<std::mutex> t_lock(r_pool.t_mutex);
+		size_t n_best = size_t(-1);
+		for(size_t i = 0; i < r_pool.free_blocks.size(); ++ i) { // the smallest block that holds it and is not more than twice as large
+			const size_t n_size = r_pool.free_blocks[i].second.n_bytes;
+			if(n_size >= n_need && n_size <= 2 * n_need && (n_best == size_t(-1) || n_size < r_pool.free_blocks[n_best].second.n_bytes))
+				n_best = i;
+		}
+		if(n_best != size_t(-1)) {
+			const std::pair<void*, THostBlock> t_block = r_pool.free_blocks[n_best];
+			r_pool.free_blocks[n_best] = r_pool.free_blocks.back();
+			r_pool.free_blocks.pop_back();
+			r_pool.held[t_block.first] = t_block.second;
+			return t_block.first;
+		}
+	}
+	THostBlock t_block;
+	t_block.n_map_bytes = n_need + n_huge;
+	t_block.n_bytes = n_need;
+	t_block.p_map = mmap(0, t_block.n_map_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+	if(t_block.p_map == MAP_FAILED)
+		throw std::bad_alloc();
+	void *p = (void*)((uintptr_t(t_block.p_map) + n_huge - 1) / n_huge * n_huge);
+	if(!dev_knob_set("SLAMPP_HIP_DEV_NO_HUGE_PAGES")) // (development aid, plan.h)
+		(void)madvise(p, n_need, MADV_HUGEPAGE); // (refused or ignored where the system has them off: 4 KB pages then, as before)
+	try {
+		std::lock_guard<std::mutex> t_lock(r_pool.t_mutex);
+		r_pool.held[p] = t_block;
+	} catch(std::bad_alloc&) {
+		(void)munmap(t_block.p_map, t_block.n_map_bytes);
+		throw;
+	}
+	return p;
+}
+
+void host_pool_free(void *p) noexcept
+{
+	if(!p)
+		return;
+	THostPool &r_pool = r_Host_Pool();
+	std::lock_guard<std::mutex> t_lock(r_pool.t_mutex);
+	std::unordered_map<void*, THostBlock>::iterator p_it = r_pool.held.find(p);
+	if(p_it == r_pool.held.end())
+		return; // (not ours: cannot happen -- CNoInitAlloc decides by the same size on both ways)
+	try {
+		r_pool.free_blocks.push_back(std::make_pair(p, p_it->second));
+	} catch(std::bad_alloc&) {
+		(void)munmap(p_it->second.p_map, p_it->second.n_map_bytes);
+	}
+	r_pool.held.erase(p_it);
+}
+
+void host_pool_release() noexcept
+{
+	std::vector<std::pair<void*, THostBlock> > blocks;
+	{
+		THostPool &r_pool = r_Host_Pool();
+		std::lock_guard<std::mutex> t_lock(r_pool.t_mutex);
+		blocks.swap(r_pool.free_blocks);
+	}
+	for(size_t i = 0; i < blocks.size(); ++ i)
+		(void)munmap(blocks[i].second.p_map, blocks[i].second.n_map_bytes);
+}
+
+} // ~slampp
+
 slampp_hip_solver::~slampp_hip_solver()
 {
 	(void)n_Join_Bringup();
 	Join_Discard();
+	host_pool_release();
 	Free_Device();
 	for(size_t i = 0; i < phase_pending.size(); ++ i) {
 		(void)hipEventDestroy(phase_pending[i].start);

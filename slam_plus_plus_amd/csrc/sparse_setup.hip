@@ -243,13 +243,13 @@ void slampp_hip_solver::Analyze_Sparse()
 	// panel packages for the separator stages (panel_kernel.hip): a task qualifies if its columns' blocks are one range of
 	// the factor and everything fits the kernel's LDS; the updates it receives from earlier stages go to the lists of
 	// panel_update_kernel, block by block
-	std::vector<longlong2> panel_pkg;
+	raw_vector<longlong2> panel_pkg; // (raw_vector: the big arrays of the analysis live in mappings of the library's own, on huge pages -- solver.h)
 	std::vector<int64_t> panel_off, panel_out_off; // (panel_out_off: per package the offset of its hand-up list, or -1)
 	std::vector<int32_t> panel_units; // per package its size in 16-byte units: what the launch order of a stage goes by
 	int64_t n_handup_doubles = 0;
 	std::vector<int32_t> panel_rest;
-	std::vector<TUpdSlot> upd_slots;
-	std::vector<TUpdEnt> upd_ents;
+	raw_vector<TUpdSlot> upd_slots;
+	raw_vector<TUpdEnt> upd_ents;
 	// (a second pass, without hand-ups, if a stage's hand-up list would take its workgroups past the LDS of a CU: the list
 	// rides in the dynamic LDS request on top of the task's image, and nothing else bounds its length -- advisor, round 4)
 	{
@@ -755,7 +755,7 @@ void slampp_hip_solver::Analyze_Sparse()
 	}
 	Fill_Rest();
 	// column packages for the upper stages (see sparse_kernels.h); the limits are those of factor_stage_kernel's staged path
-	std::vector<longlong2> pkg;
+	raw_vector<longlong2> pkg;
 	std::vector<int64_t> task_pkg(P.task_ptr.size() - 1, -1);
 	if(P.uniform_dim && (P.max_dim == 3 || P.max_dim == 6 || P.max_dim == 7)) {
 		const int n_stages = int(P.stage_ptr.size()) - 1;
@@ -982,9 +982,10 @@ void slampp_hip_solver::Analyze_Sparse()
 		Discard_Later(analysis_trash, rents); Discard_Later(analysis_trash, pkg); Discard_Later(analysis_trash, task_pkg);
 		Discard_Later(analysis_trash, panel_pkg); Discard_Later(analysis_trash, upd_slots); Discard_Later(analysis_trash, upd_ents);
 		try {
-			t_discard = std::thread([this]() { analysis_trash.clear(); });
+			t_discard = std::thread([this]() { analysis_trash.clear(); host_pool_release(); });
 		} catch(std::system_error&) {
 			analysis_trash.clear();
+			host_pool_release();
 		}
 	}
 }
