@@ -278,8 +278,9 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 		// contributions to S grouped by block (row = camera of b, col = camera of a, a <= b within a point)
 		const int64_t ubase = S.n_ablocks * DC * DC;
 		std::vector<int64_t> sb_ptr;
-		std::vector<int32_t> sb_row, sb_col, ent_a;
-		std::vector<int64_t> ent_uoff;
+		std::vector<int32_t> sb_row, sb_col;
+		raw_vector<int32_t> ent_a;    // (the contribution lists -- 5 M entries at the uniform-visibility C4 -- and the counters they are
+		raw_vector<int64_t> ent_uoff; // placed with: mappings of the library's own on huge pages, solver.h)
 		bool b_tiles_built = false;
 		{
 			int64_t n_entries = 0;
@@ -344,9 +345,9 @@ CSchurState *schur_analyze(slampp_hip_solver &s)
 						for(size_t t = 0; t < threads.size(); ++ t)
 							threads[t].join();
 					};
-					std::vector<std::vector<int64_t> > cnt(n_list_workers);
+					std::vector<raw_vector<int64_t> > cnt(n_list_workers);
 					For_List_Ranges(np, [&](int t, int64_t n_first, int64_t n_last) {
-						std::vector<int64_t> &r_cnt = cnt[t];
+						raw_vector<int64_t> &r_cnt = cnt[t];
 						r_cnt.assign(size_t(n_keys), 0);
 						for(int64_t pt = n_first; pt < n_last; ++ pt) {
 							const int64_t o0 = ptr[nc + pt] - ptr[nc] - pt, o1 = ptr[nc + pt + 1] - ptr[nc] - (pt + 1);
