@@ -442,24 +442,35 @@ static int Main_Time(int n_arg_num, const char **p_arg_list)
 		}
 		t_times = hip_solver.t_Last_Times();
 	} else {
-		CLinearSolver_CholMod ref_solver;
-		for(int i = 0; i < n_ref_reps; ++ i) {
-			x_ref = rhs;
-			const double t0 = f_NowMs();
-			b_ok = ref_solver.Solve_PosDef(lambda, x_ref) && b_ok; // (its tag is basic: the analysis re-runs on every call)
-			ref_ms.push_back(f_NowMs() - t0);
+		// DROPIN_HIP_FIRST=1 (development aid): the HIP solver's calls before the reference's instead of after them -- what the
+		// first call costs in a process whose heap the reference has not been through
+		const bool b_hip_first = getenv("DROPIN_HIP_FIRST") != 0;
+		auto Run_Reference = [&]() {
+			CLinearSolver_CholMod ref_solver;
+			for(int i = 0; i < n_ref_reps; ++ i) {
+				x_ref = rhs;
+				const double t0 = f_NowMs();
+				b_ok = ref_solver.Solve_PosDef(lambda, x_ref) && b_ok; // (its tag is basic: the analysis re-runs on every call)
+				ref_ms.push_back(f_NowMs() - t0);
+			}
+		};
+		if(!b_hip_first)
+			Run_Reference();
+		{
+			CLinearSolver_HIP hip_solver;
+			double t0 = f_NowMs();
+			b_ok = hip_solver.Solve_PosDef(lambda, x_hip) && b_ok;
+			f_hip_cold_ms = f_NowMs() - t0;
+			for(int i = 0; i < n_reps; ++ i) {
+				x_hip = rhs;
+				t0 = f_NowMs();
+				b_ok = hip_solver.Solve_PosDef_Blocky(lambda, x_hip) && b_ok;
+				hip_warm_ms.push_back(f_NowMs() - t0);
+			}
+			t_times = hip_solver.t_Last_Times();
 		}
-		CLinearSolver_HIP hip_solver;
-		double t0 = f_NowMs();
-		b_ok = hip_solver.Solve_PosDef(lambda, x_hip) && b_ok;
-		f_hip_cold_ms = f_NowMs() - t0;
-		for(int i = 0; i < n_reps; ++ i) {
-			x_hip = rhs;
-			t0 = f_NowMs();
-			b_ok = hip_solver.Solve_PosDef_Blocky(lambda, x_hip) && b_ok;
-			hip_warm_ms.push_back(f_NowMs() - t0);
-		}
-		t_times = hip_solver.t_Last_Times();
+		if(b_hip_first)
+			Run_Reference();
 	}
 	f_err = (x_hip - x_ref).lpNorm<Eigen::Infinity>() / x_ref.lpNorm<Eigen::Infinity>();
 	std::sort(hip_warm_ms.begin(), hip_warm_ms.end());
