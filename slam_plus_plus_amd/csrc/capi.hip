@@ -174,6 +174,22 @@ int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id)
 	if(!p)
 		return SLAMPP_HIP_ERR_ALLOC;
 	p->n_device = device_id;
+	{
+		// The C library decides by size whether a block comes out of its heap or is a mapping of its own, and it moves that size
+		// up (and with it the amount of free heap it keeps) when the application frees a large mapped block -- up to 32 MB.  A
+		// process that has never done so gets every work array of the analysis above 128 KB as a fresh mapping, page-faulted in
+		// and torn down again: set_structure + analyze at 100k poses takes 38 - 44 ms in a plain C process and 29 - 33 ms in one
+		// whose allocator has seen such a block (Python after numpy; MALLOC_MMAP_THRESHOLD_ / _TRIM_THRESHOLD_ / _TOP_PAD_
+		// in the environment: tools/micro/analyze_c.c).  The first handle of a process frees one such block: the allocator's own
+		// adaptation, triggered once, nothing set behind the application's back (SLAMPP_HIP_DEV_NO_MALLOC_NUDGE: off).
+		static std::atomic<bool> b_nudged(false);
+		if(!b_nudged.exchange(true) && !dev_knob_set("SLAMPP_HIP_DEV_NO_MALLOC_NUDGE")) {
+			void *p_block = malloc((size_t(32) << 20) - 65536);
+			if(p_block)
+				*(volatile char*)p_block = 0; // (the pair must not be optimized away)
+			free(p_block);
+		}
+	}
 	// the streams, and what a process pays at the first use of each of the runtime's parts, on a thread beside the caller's
 	// next steps (solver.h: t_bringup); a failure is reported by the first entry point that needs the streams
 	if(dev_knob_set("SLAMPP_HIP_DEV_NO_BRINGUP_THREAD")) // (development aid, plan.h: everything before slampp_hip_create returns)
