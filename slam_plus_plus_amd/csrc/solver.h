@@ -293,11 +293,11 @@ struct slampp_hip_solver {
 	double *p_pin_values = 0, *p_pin_rhs = 0;
 	size_t n_pin_values = 0, n_pin_rhs = 0;
 	bool b_pin_values_registered = false, b_pin_rhs_registered = false; // malloc + hipHostRegister rather than hipHostMalloc
-	// Round 6: the FIRST staging of a handle whose caller hands over host arrays (option "staging_ahead") is a plain mapping --
-	// not touched, not pinned: the first call's gather first-touches it and its transfers go through the runtime's pageable path
-	// (43 GB/s on this pool against 54 pinned) -- and is registered in place on a thread of its own once the first answer is out
-	// (Register_Staging_Later / Join_Staging_Registration).  Pinning 58 MB beside the analysis cost the first call at C3 20 ms of
-	// registration and 20 more of the analysis' page faults waiting for the address space's lock.
+	// Round 6, a development knob now (SLAMPP_HIP_DEV_STAGING_DEFERRAL; staging.hip says what turned it around): the FIRST staging
+	// of a handle whose caller hands over host arrays (option "staging_ahead") as a plain mapping -- not touched, not pinned: the
+	// first call's gather first-touches it and its transfers go through the runtime's pageable path -- registered in place on a
+	// thread of its own once the first answer is out (Register_Staging_Later / Join_Staging_Registration).  By default the
+	// staging is pinned beside the analysis (slampp_hip_analyze's staging thread), as in round 5.
 	bool b_pin_values_deferred = false, b_pin_rhs_deferred = false; // mapped, not registered (yet)
 	bool b_staging_ever = false;       // this handle has had a staging before: no deferral again
 	std::thread t_staging_registration; // joined wherever the staging is used, replaced or freed

@@ -228,9 +228,13 @@ void slampp_hip_solver::Require_Staging()
 		if(stream)
 			(void)hipStreamSynchronize(stream);
 	}
-	// (deferral: the first staging of a one-device handle that was told host arrays are coming -- solver.h)
+	// (deferral: the first staging of a one-device handle that was told host arrays are coming -- solver.h.  Built early in round 6,
+	// when pinning 58 MB beside the analysis slowed the analysis by more than the first upload out of unregistered memory cost;
+	// with the analysis' work arrays on huge pages and in the heap that turned around -- first call through the header at C3
+	// 66-71 ms deferred, 54-55 registered beside the analysis; Venice-like 73-78 against 61-62 -- and it is a development
+	// knob now, SLAMPP_HIP_DEV_STAGING_DEFERRAL)
 	const bool b_defer = !b_staging_ever && !p_pin_values && !p_pin_rhs && n_staging_ahead && !b_group_active && group_devices.empty() &&
-		!dev_knob_set("SLAMPP_HIP_DEV_NO_STAGING_DEFERRAL");
+		dev_knob_set("SLAMPP_HIP_DEV_STAGING_DEFERRAL");
 	Grow_Pinned(p_pin_values, n_pin_values, b_pin_values_registered, size_t(n_values), b_defer, b_pin_values_deferred);
 	const double t1 = staging_wall_ms();
 	Grow_Pinned(p_pin_rhs, n_pin_rhs, b_pin_rhs_registered, size_t(n_scalars), b_defer, b_pin_rhs_deferred);
