@@ -188,6 +188,27 @@ int slampp_hip_create(slampp_hip_solver **pp_solver, int device_id)
 			if(p_block)
 				*(volatile char*)p_block = 0; // (the pair must not be optimized away)
 			free(p_block);
+			// ... and the heap the analysis' remaining vectors (the planner's, the header's) will come out of now grows by 4 KB
+			// page faults: with glibc >= 2.35 GLIBC_TUNABLES=glibc.malloc.hugetlb=1 makes it ask for huge pages and takes the first
+			// call through the header at 100k poses from 50.7 to 42.6 - 44.6 ms, but that is read at process start.  The same for the
+			// part of the heap this process is about to use: two blocks just under the (now 32 MB) mapping threshold come out of the
+			// heap, their range is offered to the kernel as huge pages, and they are freed again -- 60 MB of untouched heap that
+			// stays (the allocator gives free heap back from 64 MB on), on huge pages once something is written there.
+			if(!dev_knob_set("SLAMPP_HIP_DEV_NO_HEAP_HUGE_PAGES")) {
+				const size_t n_block = (size_t(30) << 20);
+				void *p_a = malloc(n_block), *p_b = malloc(n_block);
+				void *p_blocks[2] = {p_a, p_b};
+				for(int i = 0; i < 2; ++ i) {
+					if(!p_blocks[i])
+						continue;
+					const uintptr_t n_huge = uintptr_t(2) << 20;
+					const uintptr_t n_begin = (uintptr_t(p_blocks[i]) + n_huge - 1) / n_huge * n_huge, n_end = (uintptr_t(p_blocks[i]) + n_block) / n_huge * n_huge;
+					if(n_end > n_begin)
+						(void)madvise((void*)n_begin, size_t(n_end - n_begin), MADV_HUGEPAGE); // (a hint on memory that is ours right now; refused or ignored where huge pages are off)
+				}
+				free(p_b);
+				free(p_a);
+			}
 		}
 	}
 	// the streams, and what a process pays at the first use of each of the runtime's parts, on a thread beside the caller's
