@@ -1002,6 +1002,15 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 		};
 		const int64_t n_piece_max = std::max(1, std::min(64, dev_knob("SLAMPP_HIP_DEV_RUN_PIECE", 64)));
 		std::vector<TRunJob> jobs_nt[5][2][2];
+		// what a pass over runs leaves behind (round 6: the runs are emitted by a few threads, each into one of these, and the
+		// results put behind each other in the runs' order -- the tables come out as one thread wrote them)
+		struct TEmitOut {
+			raw_vector<int32_t> run_lm, run_k;
+			raw_vector<int64_t> slot_key;
+			std::vector<TRunJob> jobs_nt[5][2][2];
+			int64_t n_run_pairs = 0, n_prefix_points = 0;
+			std::vector<int32_t> members, members_k; // (scratch)
+		};
 		// the jobs of one run: `members` (positions in `order`), longest camera list first -- every other member's list is that
 		// list or a prefix of it; pieces of at most 64 landmarks, a job per pair of observation blocks, over the piece's
 		// landmarks that reach into the row block (they are the first ones: sorted by length)
@@ -1010,7 +1019,11 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 		// at 1 / 2 / 4 times the base length: the longest jobs set the length of a launch; C5 1.197 / 1.223 / 1.183): the
 		// kernel can, the analysis does not ask for it (development knob, tests/test_schur_gpu.py)
 		const int64_t n_piece_mult = dev_knob_set("SLAMPP_HIP_DEV_RUN_PIECE_MULT")? std::max(1, std::min(4, dev_knob("SLAMPP_HIP_DEV_RUN_PIECE_MULT", 1))) : 1;
-		auto Emit_Run = [&](const int32_t *p_members, const int32_t *p_members_k /* null: every member has k_all observations */, int64_t n_members, int64_t k_all) {
+		auto Emit_Run = [&](TEmitOut &r_out, const int32_t *p_members, const int32_t *p_members_k /* null: every member has k_all observations */, int64_t n_members, int64_t k_all) {
+			raw_vector<int32_t> &run_lm = r_out.run_lm, &run_k = r_out.run_k; // (this thread's: positions and offsets in the jobs are relative to them until the merge)
+			raw_vector<int64_t> &slot_key = r_out.slot_key;
+			std::vector<TRunJob> (&jobs_nt)[5][2][2] = r_out.jobs_nt;
+			int64_t &n_run_pairs = r_out.n_run_pairs;
 			// (pieces of 32 where a job keeps ten or sixteen accumulator tiles -- nine cameras and up at 6 x 6 --: those jobs are
 			// the long ones, and more of them spread better: 164 + 123 -> 130 + 103 us for the two widest kernels of the
 			// Venice-like C4, for 18 us more in the reduction of the partial blocks)
@@ -1219,7 +1232,10 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 				threads[t].join();
 		}
 		BUILD_PHASE("  class lists");
-		std::vector<int32_t> members, members_k;
+		std::vector<int32_t> members, members_k; // (kept for the discard list below)
+		struct TGroup { size_t c0, c1; int64_t n_members; };
+		std::vector<TGroup> groups;
+		int64_t n_emit_members = 0;
 		for(size_t c0 = 0; c0 < classes.size();) {
 			size_t c1 = c0 + 1;
 			int64_t n_members = classes[c0].n_count;
@@ -1229,21 +1245,101 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 			}
 			const int64_t k_longest = class_k[c1 - 1];
 			// (a lone long track is no better off here than in the lists; two of them already share their partial blocks)
-			if(n_members >= ((k_longest > OB && n_min_run > 2)? 2 : n_min_run) && c1 - c0 == 1)
-				Emit_Run(order.data() + classes[c0].n_first, 0, n_members, k_longest); // (the members as they lie in the sorted order)
-			else if(n_members >= ((k_longest > OB && n_min_run > 2)? 2 : n_min_run)) {
-				members.clear();
-				members_k.clear();
-				for(size_t c = c1; c > c0; -- c) { // longest list first
-					const TClass &r_class = classes[c - 1];
-					members.insert(members.end(), order.begin() + r_class.n_first, order.begin() + r_class.n_first + r_class.n_count);
-					members_k.insert(members_k.end(), size_t(r_class.n_count), class_k[c - 1]);
-				}
-				Emit_Run(members.data(), members_k.data(), int64_t(members.size()), 0);
-				if(c1 - c0 > 1)
-					T.n_prefix_points += n_members;
+			if(n_members >= ((k_longest > OB && n_min_run > 2)? 2 : n_min_run)) {
+				groups.push_back(TGroup{c0, c1, n_members});
+				n_emit_members += n_members;
 			}
 			c0 = c1;
+		}
+		auto Emit_Groups = [&](TEmitOut &r_out, size_t g0, size_t g1) {
+			for(size_t g = g0; g < g1; ++ g) {
+				const size_t c0 = groups[g].c0, c1 = groups[g].c1;
+				const int64_t n_members = groups[g].n_members, k_longest = class_k[c1 - 1];
+				if(c1 - c0 == 1)
+					Emit_Run(r_out, order.data() + classes[c0].n_first, 0, n_members, k_longest); // (the members as they lie in the sorted order)
+				else {
+					r_out.members.clear();
+					r_out.members_k.clear();
+					for(size_t c = c1; c > c0; -- c) { // longest list first
+						const TClass &r_class = classes[c - 1];
+						r_out.members.insert(r_out.members.end(), order.begin() + r_class.n_first, order.begin() + r_class.n_first + r_class.n_count);
+						r_out.members_k.insert(r_out.members_k.end(), size_t(r_class.n_count), class_k[c - 1]);
+					}
+					Emit_Run(r_out, r_out.members.data(), r_out.members_k.data(), int64_t(r_out.members.size()), 0);
+					r_out.n_prefix_points += n_members;
+				}
+			}
+		};
+		{
+			const int n_emit_workers = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(dev_knob("SLAMPP_HIP_DEV_EMIT_THREADS", 8), std::max(1u, std::thread::hardware_concurrency())), n_emit_members / 65536))); // (development aid, plan.h: 1 = one thread, for comparing the tables)
+			std::vector<TEmitOut> outs;
+			outs.resize(size_t(n_emit_workers));
+			std::vector<size_t> g_begin(size_t(n_emit_workers) + 1, groups.size());
+			{ // ranges of groups with about the same number of landmarks
+				g_begin[0] = 0;
+				int64_t n_seen = 0;
+				int t = 1;
+				for(size_t g = 0; g < groups.size() && t < n_emit_workers; ++ g) {
+					n_seen += groups[g].n_members;
+					while(t < n_emit_workers && n_seen >= n_emit_members * t / n_emit_workers)
+						g_begin[size_t(t ++)] = g + 1;
+				}
+			}
+			std::exception_ptr p_emit_error;
+			std::mutex t_error_mutex;
+			{
+				std::vector<std::thread> threads;
+				auto Work = [&](int t) {
+					try {
+						outs[size_t(t)].run_lm.reserve(size_t(n_emit_members / n_emit_workers + 65536));
+						outs[size_t(t)].run_k.reserve(size_t(n_emit_members / n_emit_workers + 65536));
+						Emit_Groups(outs[size_t(t)], g_begin[size_t(t)], g_begin[size_t(t) + 1]);
+					} catch(...) {
+						std::lock_guard<std::mutex> t_lock(t_error_mutex);
+						p_emit_error = std::current_exception();
+					}
+				};
+				for(int t = 1; t < n_emit_workers; ++ t)
+					threads.emplace_back(Work, t);
+				Work(0);
+				for(size_t t = 0; t < threads.size(); ++ t)
+					threads[t].join();
+			}
+			if(p_emit_error)
+				std::rethrow_exception(p_emit_error);
+			// behind each other, in the order of the runs: positions in the run list and offsets of the partial blocks become global
+			if(n_emit_workers == 1) {
+				run_lm.swap(outs[0].run_lm);
+				run_k.swap(outs[0].run_k);
+				slot_key.swap(outs[0].slot_key);
+				for(int nt = 0; nt < 5; ++ nt)
+					for(int d = 0; d < 2; ++ d)
+						for(int x = 0; x < 2; ++ x)
+							jobs_nt[nt][d][x].swap(outs[0].jobs_nt[nt][d][x]);
+			} else {
+				for(int t = 0; t < n_emit_workers; ++ t) {
+					TEmitOut &r_out = outs[size_t(t)];
+					const int64_t n_lm_base = int64_t(run_lm.size()), n_slot_base = int64_t(slot_key.size());
+					for(int nt = 0; nt < 5; ++ nt) {
+						for(int d = 0; d < 2; ++ d) {
+							for(int x = 0; x < 2; ++ x) {
+								for(TRunJob &r_job : r_out.jobs_nt[nt][d][x]) {
+									r_job.n_first = int32_t(r_job.n_first + n_lm_base);
+									r_job.n_pbase += n_slot_base;
+								}
+								jobs_nt[nt][d][x].insert(jobs_nt[nt][d][x].end(), r_out.jobs_nt[nt][d][x].begin(), r_out.jobs_nt[nt][d][x].end());
+							}
+						}
+					}
+					run_lm.insert(run_lm.end(), r_out.run_lm.begin(), r_out.run_lm.end());
+					run_k.insert(run_k.end(), r_out.run_k.begin(), r_out.run_k.end());
+					slot_key.insert(slot_key.end(), r_out.slot_key.begin(), r_out.slot_key.end());
+				}
+			}
+			for(int t = 0; t < n_emit_workers; ++ t) {
+				n_run_pairs += outs[size_t(t)].n_run_pairs;
+				T.n_prefix_points += outs[size_t(t)].n_prefix_points;
+			}
 		}
 		BUILD_PHASE("  emit (jobs)");
 		For_Landmark_Ranges(np - int64_t(run_lm.size()), [&](int64_t n_first, int64_t n_last) { // (ranges of the run list: np - its length .. np)
@@ -1272,6 +1368,22 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 		Discard_Later(trash, members); Discard_Later(trash, members_k);
 	}
 	BUILD_PHASE("runs -> jobs");
+	if(b_build_timing) { // (what the tables hash to: one thread and several must agree -- SLAMPP_HIP_DEV_EMIT_THREADS)
+		uint64_t n_hash = 1469598103934665603ull;
+		auto Mix = [&n_hash](const void *p, size_t n_bytes) {
+			const unsigned char *p_bytes = (const unsigned char*)p;
+			for(size_t i = 0; i < n_bytes; ++ i)
+				n_hash = (n_hash ^ p_bytes[i]) * 1099511628211ull;
+		};
+		Mix(run_lm.data(), run_lm.size() * sizeof(int32_t));
+		Mix(run_k.data(), run_k.size() * sizeof(int32_t));
+		Mix(slot_key.data(), slot_key.size() * sizeof(int64_t));
+		for(const TRunJob &r_job : jobs) {
+			const int64_t fields[7] = {r_job.n_first, r_job.n_points, r_job.n_k, r_job.n_rb, r_job.n_cb, r_job.n_pad, r_job.n_pbase};
+			Mix(fields, sizeof(fields));
+		}
+		fprintf(stderr, "[schur tiles] run tables: %zu landmarks, %zu jobs, %zu partial blocks, hash %016llx\n", run_lm.size(), jobs.size(), slot_key.size(), (unsigned long long)n_hash);
+	}
 	const int64_t n_run_slots = int64_t(slot_key.size()), n_run_points = int64_t(run_lm.size());
 
 	// ---- tiles: the other landmarks by (first camera, second camera) -- two counting sorts --, cut where a tile is full ----
