@@ -1341,6 +1341,8 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 						outs[size_t(t)].run_lm.reserve(size_t(n_emit_members / n_emit_workers + 65536));
 						outs[size_t(t)].run_k.reserve(size_t(n_emit_members / n_emit_workers + 65536));
 						Emit_Groups(outs[size_t(t)], g_begin[size_t(t)], g_begin[size_t(t) + 1]);
+						for(int32_t n_landmark : outs[size_t(t)].run_lm)
+							handled[size_t(n_landmark)] = 1; // (a landmark is in one run: no two threads write the same byte)
 					} catch(...) {
 						std::lock_guard<std::mutex> t_lock(t_error_mutex);
 						p_emit_error = std::current_exception();
@@ -1388,12 +1390,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 				T.n_prefix_points += outs[size_t(t)].n_prefix_points;
 			}
 		}
-		BUILD_PHASE("  emit (jobs)");
-		For_Landmark_Ranges(np - int64_t(run_lm.size()), [&](int64_t n_first, int64_t n_last) { // (ranges of the run list: np - its length .. np)
-			for(int64_t i = n_first - (np - int64_t(run_lm.size())); i < n_last - (np - int64_t(run_lm.size())); ++ i)
-				handled[run_lm[i]] = 1;
-		});
-		BUILD_PHASE("  emit");
+		BUILD_PHASE("  emit (jobs)"); // (with the marks of the landmarks that are in runs: each emitting thread sets its own)
 		for(int nt = 1; nt <= 4; ++ nt) {
 			for(int d = 0; d < 2; ++ d) {
 				// one launch per (tiles a side, diagonal): where some jobs of a class have landmarks that end early, all its jobs
@@ -1584,7 +1581,7 @@ void schur_tiles_build(CSchurTiles &T, int n_mode, int DC, int DP, int64_t nc, i
 				raw_vector<int64_t> run_rec(p_up->run_lm.size());
 				{ // offset of every landmark's first U block in the values (a read of ptr[] per landmark, in hash order: a few threads)
 					const int64_t n = int64_t(run_rec.size());
-					const int n_workers = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4, std::max(1u, std::thread::hardware_concurrency())), n / 65536)));
+					const int n_workers = int(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, std::max(1u, std::thread::hardware_concurrency())), n / 65536))); // (round 6: eight -- the analysis waits for this thread at its end)
 					int64_t *p_rec = run_rec.data();
 					const int32_t *p_lm = p_up->run_lm.data();
 					auto Fill = [=](int64_t n_first, int64_t n_last) {
