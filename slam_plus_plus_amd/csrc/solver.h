@@ -234,7 +234,7 @@ struct slampp_hip_solver {
 	std::vector<int32_t> simt_bwd_lds_bytes;
 	std::vector<slampp::TSimtChunk> simt_host_bwd_chunks;
 	std::vector<int32_t> simt_host_bwd_prog;
-	std::vector<int64_t> simt_host_bwd_tab;
+	slampp::raw_vector<int64_t> simt_host_bwd_tab; // (raw_vector: written in full by the table pass, never zero-filled; its own mapping on huge pages)
 	// inv(L_jj) of the columns the lane-per-task kernel factors is not on the solve's path any more (its backward kernel solves with
 	// L_jj^T): stored only once something has asked for it (another right-hand side, covariances) -- from then on always
 	bool b_leaf_linv_wanted = false, b_leaf_linv_valid = true;
@@ -260,7 +260,7 @@ struct slampp_hip_solver {
 	void Upload_Simt(); // throws
 	std::vector<slampp::TSimtChunk> simt_host_chunks; // what Build_Simt() made, until Upload_Simt() has sent it
 	std::vector<int32_t> simt_host_prog, simt_host_rest;
-	std::vector<int64_t> simt_host_tab;
+	slampp::raw_vector<int64_t> simt_host_tab;
 	// dense top of the sparse path (plan.h): assembled Schur complement + dense factor workspaces
 	slampp::CDevArray<slampp::TDenseBlk> d_dense_blks;
 	slampp::CDevArray<int64_t> d_dense_blk_loff; // where each of those blocks lives in the factor's block layout (slampp_hip_factorize)

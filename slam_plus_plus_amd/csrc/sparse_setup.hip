@@ -1014,7 +1014,9 @@ void slampp_hip_solver::Build_Simt()
 	const int n_stages = int(P.stage_ptr.size()) - 1;
 	std::vector<TSimtChunk> &chunks = simt_host_chunks;
 	std::vector<int32_t> &prog_all = simt_host_prog, &rest = simt_host_rest;
-	std::vector<int64_t> &tab = simt_host_tab;
+	raw_vector<int64_t> &tab = simt_host_tab;
+	size_t n_tab_size = 0, n_bwd_tab_size = 0; // (the tables are laid out first and made in one piece after the layout of a stage: round 6 --
+	// grown chunk by chunk, zero-filled and moved as they grew, they were most of the 5 ms the layout took at C3)
 	// Round 6: the tasks' programs on several threads (a task's program depends on nothing but the plan), the shapes told
 	// apart by a hash of the program with one full comparison per task against its shape's first member instead of a
 	// std::map keyed by the programs (16 000 insertions of 200-word keys at C3), the tables of a shape's chunks on several
@@ -1187,19 +1189,21 @@ void slampp_hip_solver::Build_Simt()
 				TSimtChunk ch;
 				ch.prog_off = n_prog_off;
 				ch.n_tasks = int32_t(n_in_chunk);
-				ch.tab_off = int64_t(tab.size());
+				ch.tab_off = int64_t(n_tab_size);
 				chunks.push_back(ch);
 				TSimtChunk ch_bwd;
 				ch_bwd.prog_off = n_bwd_prog_off;
 				ch_bwd.n_tasks = int32_t(n_in_chunk);
-				ch_bwd.tab_off = int64_t(simt_host_bwd_tab.size());
+				ch_bwd.tab_off = int64_t(n_bwd_tab_size);
 				simt_host_bwd_chunks.push_back(ch_bwd);
 				TChunkJob t_job = {int32_t(g), n_first, n_fields, n_bwd_fields, ch.tab_off, ch_bwd.tab_off};
 				jobs.push_back(t_job);
-				tab.resize(tab.size() + size_t(n_fields) * W);
-				simt_host_bwd_tab.resize(simt_host_bwd_tab.size() + size_t(n_bwd_fields) * W);
+				n_tab_size += size_t(n_fields) * W;
+				n_bwd_tab_size += size_t(n_bwd_fields) * W;
 			}
 		}
+		tab.resize(n_tab_size); // (raw_vector: what was there stays, the new part is written in full below)
+		simt_host_bwd_tab.resize(n_bwd_tab_size);
 		Simt_Phase("layout");
 		Parallel_Ranges(int64_t(jobs.size()), 32, [&](int64_t n_b, int64_t n_e) {
 			for(int64_t n_job = n_b; n_job < n_e; ++ n_job) {
@@ -1296,10 +1300,10 @@ void slampp_hip_solver::Upload_Simt()
 	SLAMPP_HIP_CHECK(hipStreamSynchronize(stream)); // (the host copies are no longer needed)
 	{ std::vector<TSimtChunk> e; simt_host_bwd_chunks.swap(e); }
 	{ std::vector<int32_t> e; simt_host_bwd_prog.swap(e); }
-	{ std::vector<int64_t> e; simt_host_bwd_tab.swap(e); }
+	{ raw_vector<int64_t> e; simt_host_bwd_tab.swap(e); }
 	{ std::vector<TSimtChunk> e; simt_host_chunks.swap(e); }
 	{ std::vector<int32_t> e0, e1; simt_host_prog.swap(e0); simt_host_rest.swap(e1); }
-	{ std::vector<int64_t> e; simt_host_tab.swap(e); }
+	{ raw_vector<int64_t> e; simt_host_tab.swap(e); }
 	if(getenv("SLAMPP_HIP_PLAN_TIMING")) {
 		for(size_t s = 0; s + 1 < simt_chunk_ptr.size(); ++ s) {
 			fprintf(stderr, "[setup] stage %zu: %d tasks -> %d chunks of 64 lanes, %d tasks left to the wave-per-task kernel\n", s,
